@@ -1,0 +1,59 @@
+"""The REAL reference, where it can be run -- TEST INFRASTRUCTURE ONLY.
+
+* ``compiled()``: torch.ops.d2ref.* = the reference's own C++ CPU ops, built by
+  oracle/build_ref.py into oracle/_ref/libd2ref.so (travels to the GPU box prebuilt).
+* ``py_mask_ops()`` / ``py_boxes()``: the reference's own Python modules loaded by file path
+  from /root/reference (only exists in the build container; used to generate tests/golden/).
+"""
+import importlib.util
+import os
+import sys
+import types
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_REF_LIB = os.path.join(_HERE, "_ref", "libd2ref.so")
+REF_ROOT = os.environ.get("D2_REFERENCE_ROOT", "/root/reference")
+_loaded = False
+
+
+def have_compiled():
+    return os.path.exists(_REF_LIB)
+
+
+def have_tree():
+    return os.path.isdir(os.path.join(REF_ROOT, "detectron2", "layers"))
+
+
+def compiled():
+    """Returns torch.ops.d2ref (nms_rotated, box_iou_rotated, roi_align_rotated_forward/backward)."""
+    global _loaded
+    import torch
+
+    if not _loaded:
+        if not have_compiled():
+            from . import build_ref
+
+            if not build_ref.build(verbose=False):
+                raise RuntimeError("compiled reference unavailable (no oracle/_ref, no reference tree)")
+        torch.ops.load_library(_REF_LIB)
+        _loaded = True
+    return torch.ops.d2ref
+
+
+def _load_by_path(name, relpath):
+    path = os.path.join(REF_ROOT, relpath)
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def py_mask_ops():
+    """detectron2/layers/mask_ops.py (deps: torch, numpy, PIL only)."""
+    return _load_by_path("_d2ref_mask_ops", "detectron2/layers/mask_ops.py")
+
+
+def py_boxes():
+    """detectron2/structures/boxes.py (deps: torch, numpy only)."""
+    return _load_by_path("_d2ref_boxes", "detectron2/structures/boxes.py")

@@ -1,0 +1,98 @@
+"""Generates tests/golden/*.npz by RUNNING THE REFERENCE in the build container.
+
+Sources of truth (all under /root/reference, never copied):
+  * compiled C++ CPU ops (oracle/_ref, built by oracle/build_ref.py from
+    detectron2/layers/csrc/{ROIAlignRotated,box_iou_rotated,nms_rotated}/*_cpu.cpp)
+  * python modules loaded by file path: detectron2/layers/mask_ops.py, detectron2/structures/boxes.py
+Run:  PYTHONPATH=/root/repo python tests/golden/make_golden.py
+The .npz files are committed; /root/reference is not needed (and absent) on the GPU box.
+"""
+import os
+
+import numpy as np
+import torch
+
+from oracle import ref
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def rot_boxes(rng, n, scale=100.0, maxwh=60.0):
+    b = np.zeros((n, 5), np.float32)
+    b[:, 0] = rng.uniform(0, scale, n)
+    b[:, 1] = rng.uniform(0, scale, n)
+    b[:, 2] = rng.uniform(1, maxwh, n)
+    b[:, 3] = rng.uniform(1, maxwh, n)
+    b[:, 4] = rng.uniform(-180, 180, n)
+    return b
+
+
+def main():
+    ops = ref.compiled()
+    mo, bx = ref.py_mask_ops(), ref.py_boxes()
+    rng = np.random.default_rng(1234)
+
+    # --- ROIAlignRotated forward / backward (compiled reference) ---
+    N, C, H, W, K = 2, 3, 20, 24, 64
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    r = np.zeros((K, 6), np.float32)
+    r[:, 0] = rng.integers(0, N, K)
+    r[:, 1] = rng.uniform(-4, W * 2 + 4, K)
+    r[:, 2] = rng.uniform(-4, H * 2 + 4, K)
+    r[:, 3] = rng.uniform(0, 40, K)
+    r[:, 4] = rng.uniform(0, 40, K)
+    r[:, 5] = rng.uniform(-180, 180, K)
+    r[:8, 5] = [0, 90, 180, 270, -90, 45, 0, 0]
+    r[6, 3:5] = 0  # empty box
+    g = rng.standard_normal((K, C, 7, 7)).astype(np.float32)
+    d = dict(x=x, rois=r, grad=g)
+    for sr in (0, 2):
+        d[f"out_sr{sr}"] = ops.roi_align_rotated_forward(
+            torch.from_numpy(x), torch.from_numpy(r), 0.5, 7, 7, sr).numpy()
+        d[f"gin_sr{sr}"] = ops.roi_align_rotated_backward(
+            torch.from_numpy(g), torch.from_numpy(r), 0.5, 7, 7, N, C, H, W, sr).numpy()
+    np.savez_compressed(os.path.join(OUT, "roi_align_rotated.npz"), **d)
+
+    # --- box_iou_rotated + nms_rotated (compiled reference) ---
+    b1, b2 = rot_boxes(rng, 96), rot_boxes(rng, 80)
+    b1[:10, 4] = rng.choice([0, 90, -90, 180, 45], 10)
+    b1[:10, :4] = np.round(b1[:10, :4])
+    b2[:10] = b1[:10]  # identical pairs -> IoU 1 paths
+    b2[10, 2] = 0  # zero-area
+    iou = ops.box_iou_rotated(torch.from_numpy(b1), torch.from_numpy(b2)).numpy()
+    nb = rot_boxes(rng, 300, scale=120.0)
+    sc = rng.permutation(300).astype(np.float32) / 300.0  # distinct scores
+    d = dict(b1=b1, b2=b2, iou=iou, nms_boxes=nb, nms_scores=sc)
+    for thr in (0.2, 0.5, 0.7):
+        d[f"keep_{int(thr * 10)}"] = ops.nms_rotated(torch.from_numpy(nb), torch.from_numpy(sc), thr).numpy()
+    np.savez_compressed(os.path.join(OUT, "rotated_iou_nms.npz"), **d)
+
+    # --- pairwise_iou / ioa / intersection (reference python) ---
+    p1 = rng.uniform(0, 100, (40, 4)).astype(np.float32)
+    p1[:, 2:] += p1[:, :2]
+    p2 = rng.uniform(0, 100, (500, 4)).astype(np.float32)
+    p2[:, 2:] += p2[:, :2]
+    p2[0] = p1[0]
+    p2[1] = [10, 10, 10, 20]  # empty
+    B1, B2 = bx.Boxes(torch.from_numpy(p1)), bx.Boxes(torch.from_numpy(p2))
+    np.savez_compressed(
+        os.path.join(OUT, "pairwise_iou.npz"), b1=p1, b2=p2,
+        iou=bx.pairwise_iou(B1, B2).numpy(), ioa=bx.pairwise_ioa(B1, B2).numpy(),
+        intersection=bx.pairwise_intersection(B1, B2).numpy())
+
+    # --- paste_masks_in_image (reference python, CPU path) ---
+    torch.manual_seed(1234)
+    n, h, w = 12, 120, 160
+    masks = torch.rand(n, 28, 28)
+    xy = torch.rand(n, 2) * torch.tensor([w * 0.8, h * 0.8])
+    wh = torch.rand(n, 2) * torch.tensor([w * 0.5, h * 0.5]) + 2
+    boxes = torch.cat([xy - 5, xy + wh], 1)
+    out = mo.paste_masks_in_image(masks, boxes, (h, w), 0.5).numpy()
+    out_u8 = mo.paste_masks_in_image(masks, boxes, (h, w), -1).numpy()
+    np.savez_compressed(os.path.join(OUT, "paste_masks.npz"), masks=masks.numpy(), boxes=boxes.numpy(),
+                        shape=np.array([h, w]), out_bits=np.packbits(out), out_u8=out_u8)
+    print("golden vectors written to", OUT)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,300 @@
+"""Pins the CPU oracle (oracle/d2_oracle.c) against (a) every known answer the reference's own
+tests hold for the hot path, (b) fixtures produced by running the reference (tests/golden/,
+made by tests/golden/make_golden.py), and (c) the compiled reference (oracle/_ref) live when it
+is present.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import ref
+
+from _torch_ref import dcn_torch
+
+
+# ---------------------------------------------------------------- ROIAlign known answers
+def test_roi_align_known_answers():
+    # /root/reference/tests/layers/test_roi_align.py:14-47
+    x = np.arange(25, dtype=np.float32).reshape(1, 1, 5, 5)
+    rois = np.array([[0, 1, 1, 3, 3]], np.float32)
+    old = oracle.roi_align_forward(x, rois, (4, 4), 1.0, 0, False)[0, 0]
+    new = oracle.roi_align_forward(x, rois, (4, 4), 1.0, 0, True)[0, 0]
+    old_exp = [[7.5, 8, 8.5, 9], [10, 10.5, 11, 11.5], [12.5, 13, 13.5, 14], [15, 15.5, 16, 16.5]]
+    new_exp = [[4.5, 5.0, 5.5, 6.0], [7.0, 7.5, 8.0, 8.5], [9.5, 10.0, 10.5, 11.0],
+               [12.0, 12.5, 13.0, 13.5]]
+    assert np.allclose(old, old_exp)
+    assert np.allclose(new, new_exp)
+
+
+def test_roi_align_empty_box_and_grad():
+    # test_roi_align.py:111-121
+    rng = np.random.default_rng(0)
+    x = rng.random((1, 1, 5, 5), dtype=np.float32)
+    rois = np.array([[0, 3, 4, 5, 4]], np.float32)
+    o = oracle.roi_align_forward(x, rois, (7, 7), 1.0, 0, True)
+    assert o.shape == (1, 1, 7, 7) and (o == 0).all()
+    g = oracle.roi_align_backward(np.ones_like(o), rois, x.shape, 1.0, 0, True)
+    assert (g == 0).all()
+
+
+def test_roi_align_equals_rotated_at_zero_angle():
+    # /root/reference/tests/modeling/test_roi_pooler.py:14-59: ROIAlignV2 == ROIAlignRotated(0 deg)
+    rng = np.random.default_rng(1)
+    x = rng.random((2, 4, 10, 8), dtype=np.float32)
+    b = rng.random((10, 4), dtype=np.float32) * 64
+    b[:, 2:] = b[:, :2] + np.maximum(b[:, 2:], 1.0)
+    bi = rng.integers(0, 2, 10).astype(np.float32)
+    rois = np.concatenate([bi[:, None], b], 1)
+    rrois = np.stack([bi, (b[:, 0] + b[:, 2]) / 2, (b[:, 1] + b[:, 3]) / 2, b[:, 2] - b[:, 0],
+                      b[:, 3] - b[:, 1], np.zeros(10, np.float32)], 1)
+    for sr in (0, 2):
+        a = oracle.roi_align_forward(x, rois, (14, 14), 1 / 16, sr, True)
+        r = oracle.roi_align_rotated_forward(x, rrois, (14, 14), 1 / 16, sr)
+        assert np.allclose(a, r, atol=1e-4)
+
+
+def test_roi_align_grid_sample_equivalence_and_autograd():
+    # test_roi_align.py:64-77 (grid_sample + avg_pool formulation) and backward vs autograd of it
+    rng = np.random.default_rng(2)
+    H = W = 30
+    x = (rng.random((1, 2, H, W)) * 100).astype(np.float32)
+    box = np.array([[0, 10, 10, 20, 20], [0, 3.3, 5.1, 17.2, 26.9]], np.float32)
+    for ratio in (1, 2, 3):
+        out = oracle.roi_align_forward(x, box, (5, 5), 1.0, ratio, True)
+        xt = torch.from_numpy(x).double().requires_grad_(True)
+        outs = []
+        for b in box:
+            n = 5 * ratio
+            t = (torch.arange(n, dtype=torch.float64) + 0.5) / n
+            px = b[1] + t * (b[3] - b[1])
+            py = b[2] + t * (b[4] - b[2])
+            gx = px / W * 2 - 1
+            gy = py / H * 2 - 1
+            grid = torch.stack(torch.meshgrid(gy, gx, indexing="ij")[::-1], -1)[None]
+            s = torch.nn.functional.grid_sample(xt, grid, align_corners=False, padding_mode="border")
+            outs.append(torch.nn.functional.avg_pool2d(s, ratio))
+        ref_out = torch.cat(outs)
+        assert np.allclose(out, ref_out.detach().numpy(), rtol=1e-5, atol=1e-4)
+        g = rng.standard_normal(out.shape).astype(np.float32)
+        ref_out.backward(torch.from_numpy(g).double())
+        gin = oracle.roi_align_backward(g, box, x.shape, 1.0, ratio, True)
+        assert np.allclose(gin, xt.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
+# ---------------------------------------------------------------- ROIAlignRotated
+def test_roi_align_rotated_known_answers():
+    # /root/reference/tests/layers/test_roi_align_rotated.py:30-71
+    x = np.arange(25, dtype=np.float32).reshape(1, 1, 5, 5)
+    exp = np.array([[4.5, 5.0, 5.5, 6.0], [7.0, 7.5, 8.0, 8.5], [9.5, 10.0, 10.5, 11.0],
+                    [12.0, 12.5, 13.0, 13.5]], np.float32)
+    for k, ang in enumerate((0, 90, 180, 270)):
+        rois = np.array([[0, 2, 2, 2, 2, ang]], np.float32)
+        o = oracle.roi_align_rotated_forward(x, rois, (4, 4), 1.0, 0)[0, 0]
+        assert np.allclose(o, np.rot90(exp, -k), atol=1e-4), ang  # :67-69 rotated CW
+
+
+def test_roi_align_rotated_golden(golden_dir):
+    d = np.load(os.path.join(golden_dir, "roi_align_rotated.npz"))
+    N, C, H, W = d["x"].shape
+    for sr in (0, 2):
+        o = oracle.roi_align_rotated_forward(d["x"], d["rois"], (7, 7), 0.5, sr)
+        assert np.array_equal(o, d[f"out_sr{sr}"])  # bit-exact vs compiled reference
+        g = oracle.roi_align_rotated_backward(d["grad"], d["rois"], (N, C, H, W), 0.5, sr)
+        assert np.array_equal(g, d[f"gin_sr{sr}"])
+
+
+def test_roi_align_rotated_negative_size_raises():
+    x = np.zeros((1, 1, 5, 5), np.float32)
+    with pytest.raises(RuntimeError):
+        oracle.roi_align_rotated_forward(x, np.array([[0, 2, 2, -1, 2, 0]], np.float32), (2, 2), 1.0, 0)
+
+
+# ---------------------------------------------------------------- IoU
+def test_pairwise_iou_known_answers():
+    # /root/reference/tests/structures/test_boxes.py:152-186
+    b1 = np.array([[0, 0, 1, 1], [0, 0, 1, 1]], np.float32)
+    b2 = np.array([[0, 0, 1, 1], [0, 0.5, 1, 1], [0, 0, 0.5, 1], [0, 0, 0.5, 0.5],
+                   [0.5, 0.5, 1, 1], [0.5, 0.5, 1.5, 1.5]], np.float32)
+    iou = oracle.pairwise_iou(b1, b2)
+    exp = np.array([[1, .5, .5, .25, .25, .25 / 1.75]] * 2, np.float32)
+    assert np.allclose(iou, exp)
+    ioa = oracle.pairwise_iou(b1, b2, "ioa")
+    assert np.allclose(ioa, np.array([[1, 1, 1, 1, 1, .25]] * 2, np.float32))
+
+
+def test_pairwise_iou_golden(golden_dir):
+    d = np.load(os.path.join(golden_dir, "pairwise_iou.npz"))
+    for mode in ("iou", "ioa", "intersection"):
+        assert np.array_equal(oracle.pairwise_iou(d["b1"], d["b2"], mode), d[mode])
+
+
+def test_box_iou_rotated_known_answers():
+    # /root/reference/tests/structures/test_rotated_boxes.py
+    f = lambda a, b: oracle.box_iou_rotated(np.array(a, np.float32), np.array(b, np.float32))
+    assert np.allclose(f([[0.5, 0.5, 1, 1, 0]], [[0.25, 0.5, 0.5, 1, 0]]), 0.5)  # :46-51
+    assert np.allclose(f([[565, 565, 10, 10.0, 0]], [[565, 565, 10, 8.3, 0]]), 0.83, atol=1e-5)  # :61-68
+    # :277-290 45 degrees
+    e = f([[1, 1, np.sqrt(2), np.sqrt(2), 0], [1, 1, 2, 2, 0]] * 1, [[1, 1, 2, 2, 45]])
+    assert np.allclose(e[0, 0], 0.5, atol=1e-5)
+    # :292-299 orthogonal
+    assert np.allclose(f([[5, 5, 10, 6, 55]], [[5, 5, 10, 6, -35]]), 6.0 * 6 / (4 * 6 + 10 * 6), atol=1e-5)
+    # :348-369 issue 1207 -> 0
+    assert f([[160.0, 153.0, 230.0, 23.0, -37.0]], [[-0.122, 197.5, 0.122, 155.5, 90.0]])[0, 0] < 1e-4
+    # :97-147 issues 2154 / 2167 -> 1
+    a = [[296.6620178222656, 458.73883056640625, 23.515729904174805, 47.677001953125, 0.08795166015625]]
+    b = [[296.66201781, 458.73882916, 23.51573, 47.67702, 0.087951]]
+    assert np.allclose(f(a, b), 1.0, atol=1e-3)
+    a = [[2563.74462890625000000000, 1436.79016113281250000000, 2174.70336914062500000000,
+          214.09500122070312500000, 115.11834716796875000000]]
+    assert np.allclose(f(a, a), 1.0, atol=1e-3)
+    # :78-95 extreme coords >= 0
+    assert f([[1e4, 1e4, 1e-3, 1e-3, 0]], [[1e4, 1e4, 1e3, 1e3, 30]])[0, 0] >= 0
+
+
+def test_rotated_iou_nms_golden(golden_dir):
+    d = np.load(os.path.join(golden_dir, "rotated_iou_nms.npz"))
+    assert np.array_equal(oracle.box_iou_rotated(d["b1"], d["b2"]), d["iou"])
+    for thr in (0.2, 0.5, 0.7):
+        k = oracle.nms_rotated(d["nms_boxes"], d["nms_scores"], thr)
+        assert np.array_equal(k, d[f"keep_{int(thr * 10)}"])
+
+
+# ---------------------------------------------------------------- NMS
+def _greedy_nms_python(boxes, scores, thr):
+    """Restates the reference's own test oracle tests/layers/test_nms_rotated.py:44-66."""
+    order = np.argsort(-scores, kind="stable")
+    keep = []
+    x1, y1, x2, y2 = boxes.T
+    areas = (x2 - x1) * (y2 - y1)
+    while order.size > 0:
+        i = order[0]
+        keep.append(i)
+        xx1 = np.maximum(x1[i], x1[order[1:]])
+        yy1 = np.maximum(y1[i], y1[order[1:]])
+        xx2 = np.minimum(x2[i], x2[order[1:]])
+        yy2 = np.minimum(y2[i], y2[order[1:]])
+        w = np.maximum(np.float32(0), xx2 - xx1)
+        h = np.maximum(np.float32(0), yy2 - yy1)
+        inter = w * h
+        ovr = inter / (areas[i] + areas[order[1:]] - inter)
+        order = order[1:][ovr <= thr]
+    return np.array(keep, np.int64)
+
+
+def _random_boxes(rng, n, size=100.0):
+    b = rng.random((n, 4), dtype=np.float32) * np.float32(size * 0.5)
+    b = np.maximum(b, 1.0)
+    b[:, 2:] += b[:, :2]
+    return b.astype(np.float32)
+
+
+def test_nms_matches_reference_greedy_oracle():
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 63, 64, 65, 500, 2000):
+        b = _random_boxes(rng, n)
+        s = (rng.permutation(n) / max(n, 1)).astype(np.float32)
+        for thr in (0.2, 0.5, 0.8):
+            assert np.array_equal(oracle.nms(b, s, thr), _greedy_nms_python(b, s, np.float32(thr) if False else thr))
+
+
+def test_nms_rotated_zero_angle_equals_nms():
+    # test_nms_rotated.py:100-112 (rotated at 0 deg vs horizontal NMS; reference allows edit
+    # distance <= 1 because of >= vs >; with generic boxes they agree exactly)
+    rng = np.random.default_rng(4)
+    b = _random_boxes(rng, 300)
+    s = (rng.permutation(300) / 300).astype(np.float32)
+    rb = np.stack([(b[:, 0] + b[:, 2]) / 2, (b[:, 1] + b[:, 3]) / 2, b[:, 2] - b[:, 0], b[:, 3] - b[:, 1],
+                   np.zeros(300, np.float32)], 1)
+    for thr in (0.2, 0.5, 0.8):
+        k1, k2 = oracle.nms(b, s, thr), oracle.nms_rotated(rb, s, thr)
+        assert abs(len(k1) - len(k2)) <= 1 and len(set(k1) ^ set(k2)) <= 2
+
+
+def test_batched_nms_is_per_class_nms():
+    rng = np.random.default_rng(5)
+    n = 1500
+    b, s = _random_boxes(rng, n), (rng.permutation(n) / n).astype(np.float32)
+    idx = rng.integers(0, 7, n)
+    k = oracle.batched_nms(b, s, idx, 0.5)
+    exp = np.concatenate([np.nonzero(idx == c)[0][oracle.nms(b[idx == c], s[idx == c], 0.5)] for c in range(7)])
+    exp = exp[np.argsort(-s[exp], kind="stable")]
+    assert np.array_equal(k, exp)
+    assert len(oracle.batched_nms(np.zeros((0, 4)), np.zeros(0), np.zeros(0), 0.5)) == 0
+
+
+# ---------------------------------------------------------------- paste_masks
+def test_paste_masks_golden(golden_dir):
+    d = np.load(os.path.join(golden_dir, "paste_masks.npz"))
+    h, w = d["shape"]
+    n = d["masks"].shape[0]
+    exp = np.unpackbits(d["out_bits"])[: n * h * w].reshape(n, h, w).astype(bool)
+    out = oracle.paste_masks_in_image(d["masks"], d["boxes"], (int(h), int(w)), 0.5)
+    assert np.array_equal(out, exp)
+    out8 = oracle.paste_masks_in_image(d["masks"], d["boxes"], (int(h), int(w)), -1)
+    assert np.array_equal(out8, d["out_u8"])
+
+
+# ---------------------------------------------------------------- deformable conv
+DCN_GOLDEN = np.array([[30, 41.25, 48.75, 45, 28.75], [62.25, 81, 90, 80.25, 50.25],
+                       [99.75, 126, 135, 117.75, 72.75], [105, 131.25, 138.75, 120, 73.75],
+                       [71.75, 89.25, 93.75, 80.75, 49.5]], np.float32)
+
+
+def test_deform_conv_golden():
+    # /root/reference/tests/layers/test_deformable.py:16-58
+    x = np.arange(25, dtype=np.float32).reshape(1, 1, 5, 5)
+    off = np.full((1, 18, 5, 5), 0.5, np.float32)
+    w = np.ones((1, 1, 3, 3), np.float32)
+    o = oracle.deform_conv_forward(x, off, w, padding=1)
+    assert np.allclose(o[0, 0], DCN_GOLDEN)
+    m = np.full((1, 9, 5, 5), 0.5, np.float32)
+    o2 = oracle.deform_conv_forward(x, off, w, mask=m, padding=1)
+    assert np.allclose(o2[0, 0], DCN_GOLDEN * 0.5)
+
+
+@pytest.mark.parametrize("modulated", [False, True])
+@pytest.mark.parametrize("groups,dg", [(1, 1), (2, 2), (2, 1)])
+def test_deform_conv_fwd_bwd_vs_torch_autograd(modulated, groups, dg):
+    torch.manual_seed(7)
+    B, C, H, W, Co = 2, 4, 7, 9, 6
+    stride, pad, dil = (1, 1), (1, 1), (1, 1)
+    x = torch.randn(B, C, H, W, dtype=torch.float64, requires_grad=True)
+    off = (torch.randn(B, dg * 18, H, W, dtype=torch.float64) * 1.5).requires_grad_(True)
+    msk = torch.sigmoid(torch.randn(B, dg * 9, H, W, dtype=torch.float64)).requires_grad_(True) if modulated else None
+    wt = (torch.randn(Co, C // groups, 3, 3, dtype=torch.float64) * 0.2).requires_grad_(True)
+    bias = torch.randn(Co, dtype=torch.float64, requires_grad=True) if modulated else None
+    out = dcn_torch(x, off, wt, msk, bias, stride, pad, dil, groups, dg)
+    go = torch.randn_like(out)
+    out.backward(go)
+    f = lambda t: t.detach().float().numpy() if t is not None else None
+    o = oracle.deform_conv_forward(f(x), f(off), f(wt), mask=f(msk), bias=f(bias), stride=stride,
+                                   padding=pad, dilation=dil, groups=groups, deformable_groups=dg)
+    assert np.allclose(o, f(out), rtol=1e-4, atol=1e-4)
+    g = oracle.deform_conv_backward(f(x), f(off), f(wt), f(go), mask=f(msk), with_bias=modulated,
+                                    stride=stride, padding=pad, dilation=dil, groups=groups,
+                                    deformable_groups=dg)
+    assert np.allclose(g["grad_input"], f(x.grad), rtol=1e-4, atol=1e-4)
+    assert np.allclose(g["grad_weight"], f(wt.grad), rtol=1e-4, atol=1e-4)
+    # d/d(offset) of a bilinear sample is discontinuous on integer coordinates; random offsets
+    # are generic so the analytic formulas must agree
+    assert np.allclose(g["grad_offset"], f(off.grad), rtol=1e-3, atol=1e-3)
+    if modulated:
+        assert np.allclose(g["grad_mask"], f(msk.grad), rtol=1e-4, atol=1e-4)
+        assert np.allclose(g["grad_bias"], f(bias.grad), rtol=1e-4, atol=1e-4)
+
+
+# ---------------------------------------------------------------- live compiled reference
+@pytest.mark.skipif(not (ref.have_compiled() or ref.have_tree()), reason="compiled reference unavailable")
+def test_live_against_compiled_reference():
+    ops = ref.compiled()
+    rng = np.random.default_rng(11)
+    n = 200
+    b = np.stack([rng.uniform(0, 80, n), rng.uniform(0, 80, n), rng.uniform(1, 50, n),
+                  rng.uniform(1, 50, n), rng.uniform(-180, 180, n)], 1).astype(np.float32)
+    iou = ops.box_iou_rotated(torch.from_numpy(b), torch.from_numpy(b[:50])).numpy()
+    assert np.array_equal(oracle.box_iou_rotated(b, b[:50]), iou)
+    s = (rng.permutation(n) / n).astype(np.float32)
+    k = ops.nms_rotated(torch.from_numpy(b), torch.from_numpy(s), 0.3).numpy()
+    assert np.array_equal(oracle.nms_rotated(b, s, 0.3), k)
