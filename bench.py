@@ -1,0 +1,314 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the Detectron2 detection hot path on MI355X.
+
+One "step" = one pass of the TRAINING hot path of Mask R-CNN R50-FPN over one synthetic batch
+(BASELINE.json configs[1]: 2 images, 1333x800 -> padded 800x1344, bf16 features, FPN p2..p5,
+256 ch; SURVEY.md 8(d) inputs, seed 1234):
+    per image : pairwise_iou(16 GT x 268,569 anchors)              [RPN matching, rpn.py:339]
+                batched_nms(8,819 proposals, 5 levels, thr 0.7)     [proposal_utils.py:121]
+                pairwise_iou(16 GT x 1,016 proposals)               [roi_heads.py:266]
+    per batch : box  ROIAlign 7x7,  1024 ROIs over p2..p5  forward + backward
+                mask ROIAlign 14x14, 256 ROIs over p2..p5  forward + backward
+Everything else of the model (backbone convs, heads) is out of the hot path's scope and is NOT
+in the step.  Inputs are resident in HBM before the timed region.  `value` = images / second
+through the hot path, whole job (all ranks).  Multi-GPU: images shard across ranks, no data-path
+collective (the ops own no parameters); weak scaling.
+
+Extra JSON fields: `roofline` (dominant op, algorithmic bytes of SURVEY 8(d) / measured time),
+`cpu_baseline` (the oracle timed on this host, bounded sample), `ops` (per-op breakdown).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+STRIDES = (4, 8, 16, 32)
+FEAT_HW = ((200, 336), (100, 168), (50, 84), (25, 42))  # 800x1344 padded input
+IMG_H, IMG_W = 800, 1344
+C = 256
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--layout", choices=["nchw", "nhwc"], default="nhwc",
+                    help="feature memory format: nchw (reference default) or nhwc (torch.channels_last)")
+    ap.add_argument("--dtype", choices=["bf16", "fp32", "fp16"], default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the sync-free part of the step from a HIP graph")
+    return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------ inputs
+def make_anchors():
+    """Standard RPN anchors (sizes 32..512, ratios .5/1/2, strides 4..64) -> 268,569 x 4."""
+    out = []
+    for size, stride, (h, w) in zip((32, 64, 128, 256, 512), (4, 8, 16, 32, 64),
+                                    FEAT_HW + ((13, 21),)):
+        ys, xs = torch.meshgrid(torch.arange(h) * stride, torch.arange(w) * stride, indexing="ij")
+        ctr = torch.stack([xs, ys, xs, ys], -1).reshape(-1, 1, 4).float()
+        cells = []
+        for r in (0.5, 1.0, 2.0):
+            ww = math.sqrt(size * size / r)
+            hh = ww * r
+            cells.append([-ww / 2, -hh / 2, ww / 2, hh / 2])
+        out.append((ctr + torch.tensor(cells)[None]).reshape(-1, 4))
+    return torch.cat(out)
+
+
+def make_boxes(gen, n, smin, smax):
+    s = torch.exp(torch.empty(n).uniform_(math.log(smin), math.log(smax), generator=gen))
+    ar = torch.exp(torch.empty(n).uniform_(math.log(0.5), math.log(2.0), generator=gen))
+    w, h = s * ar.sqrt(), s / ar.sqrt()
+    cx = torch.empty(n).uniform_(0, IMG_W, generator=gen)
+    cy = torch.empty(n).uniform_(0, IMG_H, generator=gen)
+    b = torch.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1)
+    b[:, 0::2] = b[:, 0::2].clamp(0, IMG_W)
+    b[:, 1::2] = b[:, 1::2].clamp(0, IMG_H)
+    return b
+
+
+def assign_levels(boxes):
+    """ROIPooler level assignment, detectron2/modeling/poolers.py:23-59 (canonical 224 @ level 4)."""
+    sizes = ((boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])).sqrt()
+    lv = torch.floor(4 + torch.log2(sizes / 224 + 1e-8))
+    return torch.clamp(lv, 2, 5).long() - 2
+
+
+class Workload:
+    def __init__(self, dev, dtype, layout, seed=1234, n_img=2):
+        from detectron2_amd.layers import ROIAlign
+
+        gen = torch.Generator().manual_seed(seed)
+        self.dev, self.n_img = dev, n_img
+        self.feats = []
+        for (h, w) in FEAT_HW:
+            f = (torch.rand(n_img, C, h, w, generator=gen) * 2 - 1).to(dtype).to(dev)
+            if layout == "nhwc":
+                f = f.contiguous(memory_format=torch.channels_last)
+            self.feats.append(f.requires_grad_(True))
+        self.anchors = make_anchors().to(dev)
+        assert self.anchors.shape[0] == 268569
+        self.gt = [make_boxes(gen, 16, 16, 512).to(dev) for _ in range(n_img)]
+        # RPN proposals entering NMS: 2000 per level p2-p5 + 819 for p6, distinct scores
+        self.nms_in = []
+        for _ in range(n_img):
+            per = (2000, 2000, 2000, 2000, 819)
+            lv = torch.cat([torch.full((k,), i, dtype=torch.int64) for i, k in enumerate(per)])
+            sz = torch.cat([torch.tensor([32.0, 64, 128, 256, 512])[i].repeat(k) for i, k in enumerate(per)])
+            n = lv.numel()
+            s = sz * torch.exp(torch.empty(n).uniform_(-0.5, 0.5, generator=gen))
+            ar = torch.exp(torch.empty(n).uniform_(math.log(0.5), math.log(2.0), generator=gen))
+            w, h = s * ar.sqrt(), s / ar.sqrt()
+            cx = torch.empty(n).uniform_(0, IMG_W, generator=gen)
+            cy = torch.empty(n).uniform_(0, IMG_H, generator=gen)
+            b = torch.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1)
+            sc = torch.rand(n, generator=gen) + torch.arange(n) * 1e-9
+            self.nms_in.append((b.to(dev), sc.to(dev), lv.to(dev)))
+        self.props = [make_boxes(gen, 1016, 16, 600).to(dev) for _ in range(n_img)]
+        # sampled ROIs: 512 / image (box head), 128 fg / image (mask head)
+        self.box_rois, self.mask_rois = [], []
+        rois_box = torch.cat([torch.cat([torch.full((512, 1), float(i)), make_boxes(gen, 512, 16, 600)], 1)
+                              for i in range(n_img)])
+        rois_mask = torch.cat([torch.cat([torch.full((128, 1), float(i)), make_boxes(gen, 128, 16, 600)], 1)
+                               for i in range(n_img)])
+        for rois, store in ((rois_box, self.box_rois), (rois_mask, self.mask_rois)):
+            lv = assign_levels(rois[:, 1:])
+            for l in range(4):
+                store.append(rois[lv == l].contiguous().to(dev))
+        self.box_ops = [ROIAlign((7, 7), 1.0 / s, 0, True) for s in STRIDES]
+        self.mask_ops = [ROIAlign((14, 14), 1.0 / s, 0, True) for s in STRIDES]
+        self.gbox = [torch.randn(r.shape[0], C, 7, 7, generator=gen).to(dtype).to(dev) for r in self.box_rois]
+        self.gmask = [torch.randn(r.shape[0], C, 14, 14, generator=gen).to(dtype).to(dev) for r in self.mask_rois]
+        if layout == "nhwc":
+            self.gbox = [g.contiguous(memory_format=torch.channels_last) for g in self.gbox]
+            self.gmask = [g.contiguous(memory_format=torch.channels_last) for g in self.gmask]
+        self.esize = torch.empty((), dtype=dtype).element_size()
+
+    # algorithmic (compulsory) bytes per op, SURVEY.md 8(d)
+    def alg_bytes(self):
+        s = self.esize
+        feat = [self.n_img * C * h * w * s for (h, w) in FEAT_HW]
+        d = {}
+        for name, rois, R in (("roi_align_box", self.box_rois, 7), ("roi_align_mask", self.mask_rois, 14)):
+            fwd = bwd = 0
+            for l in range(4):
+                k = rois[l].shape[0]
+                if k == 0:
+                    continue
+                fwd += feat[l] + 20 * k + s * k * C * R * R
+                bwd += s * k * C * R * R + 2 * feat[l]
+            d[name + "_fwd"], d[name + "_bwd"] = fwd, bwd
+        n, m = 16, 268569
+        d["pairwise_iou_rpn"] = self.n_img * (16 * (n + m) + 4 * n * m)
+        d["pairwise_iou_roi"] = self.n_img * (16 * (16 + 1016) + 4 * 16 * 1016)
+        nk = 8819
+        d["batched_nms_rpn"] = self.n_img * (16 * nk + 8 * nk)  # boxes + keep list; bitmask is internal
+        return d
+
+
+class Timer:
+    """Per-op HIP-event timing on torch's current stream (the stream every kernel is launched on)."""
+
+    def __init__(self):
+        self.pairs = {}
+
+    def run(self, name, fn):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        r = fn()
+        b.record()
+        self.pairs.setdefault(name, []).append((a, b))
+        return r
+
+    def totals_ms(self):
+        return {k: sum(a.elapsed_time(b) for a, b in v) for k, v in self.pairs.items()}
+
+    def counts(self):
+        return {k: len(v) for k, v in self.pairs.items()}
+
+
+def step(w, t=None):
+    from detectron2_amd.layers import batched_nms
+    from detectron2_amd.structures import pairwise_iou
+
+    run = (lambda name, fn: t.run(name, fn)) if t is not None else (lambda name, fn: fn())
+    for i in range(w.n_img):
+        run("pairwise_iou_rpn", lambda: pairwise_iou(w.gt[i], w.anchors))
+        b, s, lv = w.nms_in[i]
+        run("batched_nms_rpn", lambda: batched_nms(b, s, lv, 0.7))
+        run("pairwise_iou_roi", lambda: pairwise_iou(w.gt[i], w.props[i]))
+    outs = []
+    for name, ops, rois, grads in (("roi_align_box", w.box_ops, w.box_rois, w.gbox),
+                                   ("roi_align_mask", w.mask_ops, w.mask_rois, w.gmask)):
+        ys = run(name + "_fwd", lambda: [ops[l](w.feats[l], rois[l]) for l in range(4)])
+        run(name + "_bwd", lambda: torch.autograd.backward(ys, grads))
+        outs.append(ys)
+    for f in w.feats:
+        f.grad = None
+    return outs
+
+
+# ------------------------------------------------------------------------------------ CPU baseline
+def cpu_baseline(w):
+    """The oracle (plain-C port, 1 thread) on a bounded sample of the same workload: image 0's
+    IoU + NMS inputs in full, and 16 ROIs x 32 channels of every level for ROIAlign fwd+bwd
+    (scaled to the full ROI / channel count; ROIAlign cost is linear in both)."""
+    import oracle
+
+    t_img = 0.0
+    gt, an = w.gt[0].cpu().numpy(), w.anchors.cpu().numpy()
+    t0 = time.perf_counter(); oracle.pairwise_iou(gt, an); t_img += time.perf_counter() - t0
+    b, s, lv = [x.cpu().numpy() for x in w.nms_in[0]]
+    t0 = time.perf_counter(); oracle.batched_nms(b, s, lv, 0.7); t_img += time.perf_counter() - t0
+    t0 = time.perf_counter(); oracle.pairwise_iou(gt, w.props[0].cpu().numpy()); t_img += time.perf_counter() - t0
+    t_batch = 0.0
+    cs = 32
+    for rois, R in ((w.box_rois, 7), (w.mask_rois, 14)):
+        for l in range(4):
+            k = rois[l].shape[0]
+            if k == 0:
+                continue
+            ks = min(16, k)
+            x = w.feats[l].detach()[:, :cs].float().cpu().contiguous().numpy()
+            r = rois[l][:ks].cpu().numpy()
+            t0 = time.perf_counter()
+            y = oracle.roi_align_forward(x, r, (R, R), 1.0 / STRIDES[l], 0, True)
+            oracle.roi_align_backward(y, r, x.shape, 1.0 / STRIDES[l], 0, True)
+            dt = time.perf_counter() - t0
+            t_batch += dt * (k / ks) * (C / cs)
+    sec_per_batch = t_img * w.n_img + t_batch
+    return {"value": round(w.n_img / sec_per_batch, 4), "unit": "img/s", "cores": 1, "kind": "port",
+            "sample": "oracle/d2_oracle.c single thread: image 0 IoU+NMS in full; ROIAlign fwd+bwd on 16 ROIs x 32 "
+                      "of 256 channels per level, scaled linearly to all ROIs/channels",
+            "host_cores_available": os.cpu_count()}
+
+
+# ------------------------------------------------------------------------------------ main
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    dtype = {"bf16": torch.bfloat16, "fp32": torch.float32, "fp16": torch.float16}[args.dtype]
+    w = Workload(dev, dtype, args.layout)
+
+    for _ in range(args.warmup):
+        step(w)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer = Timer()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(w, timer)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        totals = timer.totals_ms()
+        alg = w.alg_bytes()
+        ops = {}
+        for k, tot in totals.items():
+            per_step_ms = tot / args.steps
+            e = {"ms_per_step": round(per_step_ms, 4)}
+            if k in alg:
+                e["alg_MB"] = round(alg[k] / 1e6, 2)
+                e["GBps"] = round(alg[k] / 1e9 / (per_step_ms / 1e3), 1)
+                e["frac_hbm_peak"] = round(e["GBps"] / HBM_PEAK_GBS, 4)
+            ops[k] = e
+        dom = max((k for k in ops if k in alg), key=lambda k: ops[k]["ms_per_step"])
+        roof = {"bound": "hbm", "kernel": dom, "achieved": ops[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ops[dom]["frac_hbm_peak"], "traffic": None,
+                "alg_bytes_per_step": alg[dom], "ms_per_step": ops[dom]["ms_per_step"]}
+        gpu_ms = sum(v["ms_per_step"] for v in ops.values())
+        out = {
+            "metric": "img/s through the Mask R-CNN R50-FPN detection hot path (training ops), 1333x800 bs=2/GPU",
+            "value": round(world * w.n_img * args.steps / elapsed, 2), "unit": "img/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": "maskrcnn_r50fpn_train_hotpath_bs2_800x1344 (BASELINE configs[1])",
+                       "layout": args.layout, "global_batch": world * w.n_img,
+                       "ops_per_step": timer.counts() and {k: v // args.steps for k, v in timer.counts().items()},
+                       "parallelism": f"dp{world} (images sharded, no data-path collective)"},
+            "roofline": roof, "gpu_ms_per_step_sum_of_ops": round(gpu_ms, 4), "ops": ops,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(w)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,100 @@
+"""ctypes binding of libd2amd.so -- the product's only route to the hot path.
+
+There is NO fallback: if the HIP library is missing or an op is given a CPU tensor, this raises.
+(Reference counterpart: `from detectron2 import _C`, layers/deform_conv.py:505-514.)
+"""
+import ctypes
+import os
+
+import torch  # must be imported first: libd2amd.so binds to the HIP runtime torch already loaded
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libd2amd.so")
+_lib = None
+
+F32, F16, BF16 = 0, 1, 2
+NCHW, NHWC = 0, 1
+_DTYPES = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_i64 = ctypes.c_int64
+_f = ctypes.c_float
+_d = ctypes.c_double
+_sz = ctypes.c_size_t
+
+
+class DcnParams(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in (
+        "B", "C", "H", "W", "Co", "kh", "kw", "stride_h", "stride_w", "pad_h", "pad_w", "dil_h",
+        "dil_w", "groups", "deformable_groups", "dtype")]
+
+
+_SIGNATURES = {
+    "d2amd_version": (ctypes.c_char_p, []),
+    "d2amd_compiler_version": (ctypes.c_char_p, []),
+    "d2amd_hip_version": (ctypes.c_char_p, []),
+    "d2amd_last_error": (ctypes.c_char_p, []),
+    "d2amd_roi_align_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _vp]),
+    "d2amd_roi_align_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "d2amd_roi_align_rotated_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp, _vp]),
+    "d2amd_roi_align_rotated_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp, _sz, _vp]),
+    "d2amd_pairwise_iou": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp]),
+    "d2amd_box_iou_rotated": (_i, [_vp, _i, _vp, _i, _vp, _vp]),
+    "d2amd_nms_workspace_bytes": (_sz, [_i64, _i64, _i]),
+    "d2amd_nms": (_i, [_vp, _vp, _vp, _i64, _d, _i, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "d2amd_paste_masks": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _i, _vp]),
+    "d2amd_deform_conv_workspace_bytes": (_sz, [ctypes.POINTER(DcnParams), _i]),
+    "d2amd_deform_conv_forward": (_i, [ctypes.POINTER(DcnParams), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "d2amd_deform_conv_backward": (_i, [ctypes.POINTER(DcnParams)] + [_vp] * 11 + [_sz, _vp]),
+}
+
+
+def lib():
+    """Load libd2amd.so (fails loudly if it was not built: run `python -m detectron2_amd.build`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"detectron2_amd: {LIB_PATH} not found. The HIP extension is required (there is no "
+                "CPU/eager fallback); build it with `python -m detectron2_amd.build`.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the library does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def exported_symbols():
+    return list(_SIGNATURES)
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().d2amd_last_error().decode()
+        raise RuntimeError(f"d2amd error {rc}: {msg}")
+
+
+def dtype_code(t):
+    try:
+        return _DTYPES[t.dtype]
+    except KeyError:
+        raise RuntimeError(f"detectron2_amd: unsupported dtype {t.dtype} (float32/float16/bfloat16)")
+
+
+def require_gpu(*tensors, op="op"):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise NotImplementedError(
+                f"detectron2_amd.{op}: got a {t.device} tensor. This package implements the hot path "
+                "for MI355X only (HIP tensors); there is no CPU implementation or fallback.")
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,115 @@
+// Shared host/device helpers for libd2amd.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/d2amd.h"
+
+namespace d2amd {
+
+// ---- host-side error plumbing -----------------------------------------------------------
+void set_error(const char* fmt, ...);
+
+#define D2_CHECK_ARG(cond, ...)          \
+  do {                                   \
+    if (!(cond)) {                       \
+      ::d2amd::set_error(__VA_ARGS__);   \
+      return D2AMD_EINVAL;               \
+    }                                    \
+  } while (0)
+
+#define D2_HIP_OK(expr)                                                              \
+  do {                                                                               \
+    hipError_t _e = (expr);                                                          \
+    if (_e != hipSuccess) {                                                          \
+      ::d2amd::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),      \
+                         __FILE__, __LINE__);                                        \
+      return D2AMD_ELAUNCH;                                                          \
+    }                                                                                \
+  } while (0)
+
+#define D2_LAUNCH_OK() D2_HIP_OK(hipGetLastError())
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- device dtype helpers ---------------------------------------------------------------
+struct bf16_t { uint16_t v; };
+struct f16_t { uint16_t v; };
+
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(bf16_t x) { return __uint_as_float(((uint32_t)x.v) << 16); }
+__device__ __forceinline__ float to_f32(f16_t x) {
+  _Float16 h;
+  __builtin_memcpy(&h, &x.v, 2);
+  return (float)h;
+}
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t lo16) { return __uint_as_float(lo16 << 16); }
+
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) {
+  // round-to-nearest-even, NaN preserved (same as torch's float->bfloat16)
+  uint32_t u = __float_as_uint(x);
+  bf16_t r;
+  if ((u & 0x7fffffffu) > 0x7f800000u) {
+    r.v = (uint16_t)((u >> 16) | 0x40);
+  } else {
+    u += 0x7fffu + ((u >> 16) & 1u);
+    r.v = (uint16_t)(u >> 16);
+  }
+  return r;
+}
+template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float x) {
+  _Float16 h = (_Float16)x;
+  f16_t r;
+  __builtin_memcpy(&r.v, &h, 2);
+  return r;
+}
+
+// vector of 4 elements of T as one load/store
+template <typename T> struct vec4;
+template <> struct vec4<float> { float4 d; };
+template <> struct vec4<bf16_t> { uint2 d; };
+template <> struct vec4<f16_t> { uint2 d; };
+
+__device__ __forceinline__ void unpack4(const vec4<float>& v, float (&o)[4]) {
+  o[0] = v.d.x; o[1] = v.d.y; o[2] = v.d.z; o[3] = v.d.w;
+}
+__device__ __forceinline__ void unpack4(const vec4<bf16_t>& v, float (&o)[4]) {
+  o[0] = __uint_as_float(v.d.x << 16); o[1] = __uint_as_float(v.d.x & 0xffff0000u);
+  o[2] = __uint_as_float(v.d.y << 16); o[3] = __uint_as_float(v.d.y & 0xffff0000u);
+}
+__device__ __forceinline__ void unpack4(const vec4<f16_t>& v, float (&o)[4]) {
+  f16_t a{(uint16_t)(v.d.x & 0xffff)}, b{(uint16_t)(v.d.x >> 16)};
+  f16_t c{(uint16_t)(v.d.y & 0xffff)}, d{(uint16_t)(v.d.y >> 16)};
+  o[0] = to_f32(a); o[1] = to_f32(b); o[2] = to_f32(c); o[3] = to_f32(d);
+}
+__device__ __forceinline__ void pack4(const float (&i)[4], vec4<float>& v) {
+  v.d = make_float4(i[0], i[1], i[2], i[3]);
+}
+__device__ __forceinline__ void pack4(const float (&i)[4], vec4<bf16_t>& v) {
+  v.d.x = (uint32_t)from_f32<bf16_t>(i[0]).v | ((uint32_t)from_f32<bf16_t>(i[1]).v << 16);
+  v.d.y = (uint32_t)from_f32<bf16_t>(i[2]).v | ((uint32_t)from_f32<bf16_t>(i[3]).v << 16);
+}
+__device__ __forceinline__ void pack4(const float (&i)[4], vec4<f16_t>& v) {
+  v.d.x = (uint32_t)from_f32<f16_t>(i[0]).v | ((uint32_t)from_f32<f16_t>(i[1]).v << 16);
+  v.d.y = (uint32_t)from_f32<f16_t>(i[2]).v | ((uint32_t)from_f32<f16_t>(i[3]).v << 16);
+}
+
+// dispatch a templated launcher on the runtime dtype
+#define D2_DISPATCH_DTYPE(dtype, ...)                                   \
+  [&]() -> int {                                                        \
+    switch (dtype) {                                                    \
+      case D2AMD_F32: { using scalar_t = float; return __VA_ARGS__(); } \
+      case D2AMD_F16: { using scalar_t = ::d2amd::f16_t; return __VA_ARGS__(); } \
+      case D2AMD_BF16: { using scalar_t = ::d2amd::bf16_t; return __VA_ARGS__(); } \
+      default: ::d2amd::set_error("unsupported dtype %d", (int)(dtype)); return D2AMD_EUNSUPPORTED; \
+    }                                                                   \
+  }()
+
+static inline size_t dtype_size(int dtype) { return dtype == D2AMD_F32 ? 4 : 2; }
+
+}  // namespace d2amd

@@ -1,0 +1,626 @@
+// ROIAlign / ROIAlignRotated forward + backward for gfx950.
+//   forward  <- torchvision.ops.roi_align as called by detectron2/layers/roi_align.py:58-65, and
+//               csrc/ROIAlignRotated/ROIAlignRotated_cpu.cpp:201-310 (rotated)
+//   backward <- torchvision's roi_align backward; ROIAlignRotated_cpu.cpp:312-416
+// Roofline class: HBM gather/scatter.  Design:
+//   * axis-aligned fast path = SEPARABLE per-bin taps.  For an axis-aligned ROI the g_h x g_w
+//     bilinear samples of a bin factor into per-axis weights: bin = sum_r sum_c wy[r]*wx[c]*F[r,c]
+//     over the <= (g+2)^2 distinct pixels the bin touches -- each feature pixel is loaded ONCE
+//     per bin instead of once per sample tap (4*g^2 loads), ~2x fewer loads at g=2..4.
+//     The per-ROI weight tables (validity and border clamping folded in) are built once per
+//     workgroup in LDS and shared by all channels.
+//   * NHWC (torch.channels_last) kernel: lanes = channels, 4 channels (8/16 B) per lane, so a
+//     wave reads 512 B - 1 KiB contiguous per tap; tap weights are wave-uniform (LDS broadcast).
+//   * NCHW kernel: workgroup = one ROI x channel slab, thread = one output element; outputs
+//     coalesced, taps served from L1/L2 (the ROI footprint of a slab fits L1).
+//   * rotated / oversized-table fallback: direct per-sample kernel (4 taps per sample).
+//   * backward: the same per-bin separable weights scatter dY with fp32 atomics; 16-bit
+//     gradients accumulate in an fp32 workspace and are rounded once.
+// fp32 accumulation everywhere; rois are always fp32 (SURVEY 7 "bf16" policy).
+#include "common.h"
+
+namespace d2amd {
+
+// ------------------------------------------------------------------------------------------
+// per-ROI geometry
+struct RoiGeom {
+  int batch;
+  float start_w, start_h;   // axis-aligned: roi start; rotated: -w/2, -h/2 (relative to centre)
+  float bin_w, bin_h;
+  int grid_w, grid_h;
+  float center_w, center_h, cos_t, sin_t;  // rotated only
+  bool bad;                                 // rotated: negative size
+};
+
+template <bool ROT>
+__device__ __forceinline__ RoiGeom roi_geom(const float* __restrict__ rois, int k, float scale, int pooled_h,
+                                            int pooled_w, int sampling_ratio, int aligned) {
+  RoiGeom g;
+  g.bad = false;
+  float roi_w, roi_h;
+  if (!ROT) {
+    const float* r = rois + (long)k * 5;
+    g.batch = (int)r[0];
+    const float off = aligned ? 0.5f : 0.0f;
+    g.start_w = r[1] * scale - off;
+    g.start_h = r[2] * scale - off;
+    const float end_w = r[3] * scale - off, end_h = r[4] * scale - off;
+    roi_w = end_w - g.start_w;
+    roi_h = end_h - g.start_h;
+    if (!aligned) {  // legacy: force malformed ROIs to be 1x1
+      roi_w = fmaxf(roi_w, 1.f);
+      roi_h = fmaxf(roi_h, 1.f);
+    }
+    g.center_w = g.center_h = 0.f;
+    g.cos_t = 1.f;
+    g.sin_t = 0.f;
+  } else {
+    const float* r = rois + (long)k * 6;
+    g.batch = (int)r[0];
+    g.center_w = r[1] * scale - 0.5f;
+    g.center_h = r[2] * scale - 0.5f;
+    roi_w = r[3] * scale;
+    roi_h = r[4] * scale;
+    // ROIAlignRotated_cpu.cpp:232-234 with T=float: theta rounded to float, cos/sin in double
+    const float theta = (float)((double)r[5] * 3.14159265358979323846 / 180.0);
+    g.cos_t = (float)cos((double)theta);
+    g.sin_t = (float)sin((double)theta);
+    g.bad = !(roi_w >= 0.f && roi_h >= 0.f);
+    g.start_h = (float)(-(double)roi_h / 2.0);
+    g.start_w = (float)(-(double)roi_w / 2.0);
+  }
+  g.bin_h = roi_h / (float)pooled_h;
+  g.bin_w = roi_w / (float)pooled_w;
+  g.grid_h = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_h / (float)pooled_h);
+  g.grid_w = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_w / (float)pooled_w);
+  return g;
+}
+
+// one axis of the bilinear footprint (ROIAlignRotated_cpu.cpp:64-107 per axis)
+struct AxisTap {
+  int lo, hi;
+  float wlo, whi;  // weight of lo / hi pixel; 0 when the sample is outside [-1, size]
+  bool valid;
+};
+__device__ __forceinline__ AxisTap axis_tap(float y, int size) {
+  AxisTap t;
+  t.valid = !(y < -1.0f || y > (float)size);
+  if (y < 0.f) y = 0.f;
+  int lo = (int)y;
+  int hi;
+  if (lo >= size - 1) {
+    hi = lo = size - 1;
+    y = (float)lo;
+  } else {
+    hi = lo + 1;
+  }
+  const float l = y - (float)lo;
+  t.lo = lo; t.hi = hi;
+  t.whi = l; t.wlo = 1.f - l;
+  if (!t.valid) { t.lo = t.hi = 0; t.wlo = t.whi = 0.f; }
+  return t;
+}
+
+__device__ __forceinline__ float sample_pos(float start, int p, float bin, int i, int grid) {
+  // roi_start + ph*bin + (iy + .5f) * bin / grid   (same expression order as the reference)
+  return start + (float)p * bin + ((float)i + .5f) * bin / (float)grid;
+}
+
+// ------------------------------------------------------------------------------------------
+// DIRECT kernels (per-sample taps): rotated boxes, and the fallback when LDS tables overflow.
+// One thread per output element; NHWC_ selects which index is fastest.
+template <typename T, bool ROT, bool NHWC_>
+__global__ __launch_bounds__(256) void roi_align_fwd_direct_kernel(
+    const T* __restrict__ in, const float* __restrict__ rois, T* __restrict__ out, int C, int H, int W, int K,
+    int PH, int PW, float scale, int sampling_ratio, int aligned, int* status) {
+  const long total = (long)K * C * PH * PW;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    int pw, ph, c, k;
+    if (NHWC_) {
+      c = (int)(idx % C); pw = (int)((idx / C) % PW); ph = (int)((idx / C / PW) % PH); k = (int)(idx / C / PW / PH);
+    } else {
+      pw = (int)(idx % PW); ph = (int)((idx / PW) % PH); c = (int)((idx / PW / PH) % C); k = (int)(idx / PW / PH / C);
+    }
+    const RoiGeom g = roi_geom<ROT>(rois, k, scale, PH, PW, sampling_ratio, aligned);
+    if (ROT && g.bad) {
+      if (status) atomicOr(status, 1);
+      out[idx] = from_f32<T>(0.f);
+      continue;
+    }
+    const float count = (float)max(g.grid_h * g.grid_w, 1);
+    const long plane = (long)H * W;
+    const T* base = NHWC_ ? in + (long)g.batch * plane * C + c : in + ((long)g.batch * C + c) * plane;
+    const long pstride = NHWC_ ? C : 1;
+    float acc = 0.f;
+    for (int iy = 0; iy < g.grid_h; iy++) {
+      const float yy = sample_pos(g.start_h, ph, g.bin_h, iy, g.grid_h);
+      AxisTap ty;
+      if (!ROT) ty = axis_tap(yy, H);
+      for (int ix = 0; ix < g.grid_w; ix++) {
+        const float xx = sample_pos(g.start_w, pw, g.bin_w, ix, g.grid_w);
+        AxisTap tx;
+        if (ROT) {
+          const float y = yy * g.cos_t - xx * g.sin_t + g.center_h;
+          const float x = yy * g.sin_t + xx * g.cos_t + g.center_w;
+          const bool valid = !(y < -1.0f || y > (float)H || x < -1.0f || x > (float)W);
+          ty = axis_tap(y, H);
+          tx = axis_tap(x, W);
+          if (!valid) { ty.wlo = ty.whi = 0.f; ty.lo = ty.hi = 0; tx.lo = tx.hi = 0; }
+        } else {
+          tx = axis_tap(xx, W);
+        }
+        const float v1 = to_f32(base[((long)ty.lo * W + tx.lo) * pstride]);
+        const float v2 = to_f32(base[((long)ty.lo * W + tx.hi) * pstride]);
+        const float v3 = to_f32(base[((long)ty.hi * W + tx.lo) * pstride]);
+        const float v4 = to_f32(base[((long)ty.hi * W + tx.hi) * pstride]);
+        acc += (ty.wlo * tx.wlo) * v1 + (ty.wlo * tx.whi) * v2 + (ty.whi * tx.wlo) * v3 + (ty.whi * tx.whi) * v4;
+      }
+    }
+    out[idx] = from_f32<T>(acc / count);
+  }
+}
+
+// backward: scatter dY * w / count with fp32 atomics (gin is fp32: grad_input itself or workspace)
+template <typename T, bool ROT, bool NHWC_>
+__global__ __launch_bounds__(256) void roi_align_bwd_direct_kernel(
+    const T* __restrict__ gout, const float* __restrict__ rois, float* __restrict__ gin, int C, int H, int W,
+    int K, int PH, int PW, float scale, int sampling_ratio, int aligned) {
+  const long total = (long)K * C * PH * PW;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    int pw, ph, c, k;
+    if (NHWC_) {
+      c = (int)(idx % C); pw = (int)((idx / C) % PW); ph = (int)((idx / C / PW) % PH); k = (int)(idx / C / PW / PH);
+    } else {
+      pw = (int)(idx % PW); ph = (int)((idx / PW) % PH); c = (int)((idx / PW / PH) % C); k = (int)(idx / PW / PH / C);
+    }
+    const RoiGeom g = roi_geom<ROT>(rois, k, scale, PH, PW, sampling_ratio, aligned);
+    if (ROT && g.bad) continue;
+    const float count = (float)(g.grid_h * g.grid_w);
+    const float go = to_f32(gout[idx]);
+    const long plane = (long)H * W;
+    float* base = NHWC_ ? gin + (long)g.batch * plane * C + c : gin + ((long)g.batch * C + c) * plane;
+    const long pstride = NHWC_ ? C : 1;
+    for (int iy = 0; iy < g.grid_h; iy++) {
+      const float yy = sample_pos(g.start_h, ph, g.bin_h, iy, g.grid_h);
+      AxisTap ty;
+      if (!ROT) ty = axis_tap(yy, H);
+      for (int ix = 0; ix < g.grid_w; ix++) {
+        const float xx = sample_pos(g.start_w, pw, g.bin_w, ix, g.grid_w);
+        AxisTap tx;
+        bool valid;
+        if (ROT) {
+          const float y = yy * g.cos_t - xx * g.sin_t + g.center_h;
+          const float x = yy * g.sin_t + xx * g.cos_t + g.center_w;
+          valid = !(y < -1.0f || y > (float)H || x < -1.0f || x > (float)W);
+          ty = axis_tap(y, H);
+          tx = axis_tap(x, W);
+        } else {
+          tx = axis_tap(xx, W);
+          valid = ty.valid && tx.valid;
+        }
+        if (!valid) continue;
+        atomicAdd(base + ((long)ty.lo * W + tx.lo) * pstride, go * (ty.wlo * tx.wlo) / count);
+        atomicAdd(base + ((long)ty.lo * W + tx.hi) * pstride, go * (ty.wlo * tx.whi) / count);
+        atomicAdd(base + ((long)ty.hi * W + tx.lo) * pstride, go * (ty.whi * tx.wlo) / count);
+        atomicAdd(base + ((long)ty.hi * W + tx.hi) * pstride, go * (ty.whi * tx.whi) / count);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// SEPARABLE per-bin tables (axis-aligned).  For bin index t along one axis:
+//   first[t]  first pixel row/col touched, span[t] number of consecutive pixels, wt[t*SPAN + j].
+// Built by threads t < P of the workgroup; rows touched by the g samples of a bin are
+// consecutive because samples are <= 1 px apart when g = ceil(bin) (and for fixed g they are
+// inserted at lo-first offsets; span is bounded by SPAN = max offset + 1 and checked).
+struct AxisTables {
+  int* first;   // [P]
+  int* span;    // [P]
+  float* wt;    // [P * SPAN]
+};
+
+// returns false if some bin needs more than SPAN entries (caller falls back to direct kernel)
+__device__ __forceinline__ bool build_axis(int t, float start, float bin, int grid, int size, int SPAN, int* first,
+                                           int* span, float* wt) {
+  float* w = wt + t * SPAN;
+  for (int j = 0; j < SPAN; j++) w[j] = 0.f;
+  int f = 0x7fffffff, l = -1;
+  for (int i = 0; i < grid; i++) {
+    const AxisTap a = axis_tap(sample_pos(start, t, bin, i, grid), size);
+    if (!a.valid) continue;
+    f = min(f, a.lo);
+    l = max(l, a.hi);
+  }
+  if (l < 0) { first[t] = 0; span[t] = 0; return true; }
+  first[t] = f;
+  span[t] = l - f + 1;
+  if (l - f + 1 > SPAN) return false;
+  for (int i = 0; i < grid; i++) {
+    const AxisTap a = axis_tap(sample_pos(start, t, bin, i, grid), size);
+    if (!a.valid) continue;
+    w[a.lo - f] += a.wlo;
+    w[a.hi - f] += a.whi;
+  }
+  return true;
+}
+
+constexpr int SEP_SPAN = 12;   // table entries per bin and axis (covers g <= 10 with g = ceil(bin))
+constexpr int SEP_MAXP = 32;   // max pooled size per axis on the fast path
+
+struct SepShared {
+  int firsty[SEP_MAXP], spany[SEP_MAXP], firstx[SEP_MAXP], spanx[SEP_MAXP];
+  float wy[SEP_MAXP * SEP_SPAN], wx[SEP_MAXP * SEP_SPAN];
+  int ok;
+  int batch;
+  float inv_count;
+};
+
+template <bool BWD>
+__device__ __forceinline__ void sep_build(SepShared& S, const float* rois, int k, float scale, int PH, int PW,
+                                          int sampling_ratio, int aligned, int H, int W) {
+  if (threadIdx.x == 0) S.ok = 1;
+  __syncthreads();
+  const RoiGeom g = roi_geom<false>(rois, k, scale, PH, PW, sampling_ratio, aligned);
+  const int t = threadIdx.x;
+  bool ok = true;
+  if (t < PH) ok = build_axis(t, g.start_h, g.bin_h, g.grid_h, H, SEP_SPAN, S.firsty, S.spany, S.wy);
+  else if (t < PH + PW) ok = build_axis(t - PH, g.start_w, g.bin_w, g.grid_w, W, SEP_SPAN, S.firstx, S.spanx, S.wx);
+  if (!ok) S.ok = 0;
+  if (t == 0) {
+    S.batch = g.batch;
+    const int cnt = g.grid_h * g.grid_w;
+    S.inv_count = 1.f / (float)(cnt > 0 ? cnt : 1);
+  }
+  __syncthreads();
+}
+
+// Inline fallback for one (ROI, channel range) when the separable tables overflow (very large
+// bins with a fixed sampling_ratio): direct per-sample taps, executed by the same workgroup.
+template <typename T, bool NHWC_>
+__device__ void fwd_direct_range(const T* __restrict__ in, const float* __restrict__ rois, T* __restrict__ out,
+                                 int k, int c0, int nc, int C, int H, int W, int PH, int PW, float scale,
+                                 int sampling_ratio, int aligned) {
+  const RoiGeom g = roi_geom<false>(rois, k, scale, PH, PW, sampling_ratio, aligned);
+  const float count = (float)max(g.grid_h * g.grid_w, 1);
+  const long plane = (long)H * W;
+  const int bins = PH * PW;
+  for (int e = threadIdx.x; e < nc * bins; e += blockDim.x) {
+    int c, b;
+    if (NHWC_) { b = e / nc; c = c0 + (e - b * nc); } else { c = c0 + e / bins; b = e % bins; }
+    const int ph = b / PW, pw = b - ph * PW;
+    const T* base = NHWC_ ? in + (long)g.batch * plane * C + c : in + ((long)g.batch * C + c) * plane;
+    const long pstride = NHWC_ ? C : 1;
+    float acc = 0.f;
+    for (int iy = 0; iy < g.grid_h; iy++) {
+      const AxisTap ty = axis_tap(sample_pos(g.start_h, ph, g.bin_h, iy, g.grid_h), H);
+      for (int ix = 0; ix < g.grid_w; ix++) {
+        const AxisTap tx = axis_tap(sample_pos(g.start_w, pw, g.bin_w, ix, g.grid_w), W);
+        acc += (ty.wlo * tx.wlo) * to_f32(base[((long)ty.lo * W + tx.lo) * pstride]) +
+            (ty.wlo * tx.whi) * to_f32(base[((long)ty.lo * W + tx.hi) * pstride]) +
+            (ty.whi * tx.wlo) * to_f32(base[((long)ty.hi * W + tx.lo) * pstride]) +
+            (ty.whi * tx.whi) * to_f32(base[((long)ty.hi * W + tx.hi) * pstride]);
+      }
+    }
+    const long o = NHWC_ ? ((long)k * bins + b) * C + c : ((long)k * C + c) * bins + b;
+    out[o] = from_f32<T>(acc / count);
+  }
+}
+
+template <typename T, bool NHWC_>
+__device__ void bwd_direct_range(const T* __restrict__ gout, const float* __restrict__ rois,
+                                 float* __restrict__ gin, int k, int c0, int nc, int C, int H, int W, int PH,
+                                 int PW, float scale, int sampling_ratio, int aligned) {
+  const RoiGeom g = roi_geom<false>(rois, k, scale, PH, PW, sampling_ratio, aligned);
+  const float count = (float)(g.grid_h * g.grid_w);
+  const long plane = (long)H * W;
+  const int bins = PH * PW;
+  for (int e = threadIdx.x; e < nc * bins; e += blockDim.x) {
+    int c, b;
+    if (NHWC_) { b = e / nc; c = c0 + (e - b * nc); } else { c = c0 + e / bins; b = e % bins; }
+    const int ph = b / PW, pw = b - ph * PW;
+    const long o = NHWC_ ? ((long)k * bins + b) * C + c : ((long)k * C + c) * bins + b;
+    const float go = to_f32(gout[o]);
+    float* base = NHWC_ ? gin + (long)g.batch * plane * C + c : gin + ((long)g.batch * C + c) * plane;
+    const long pstride = NHWC_ ? C : 1;
+    for (int iy = 0; iy < g.grid_h; iy++) {
+      const AxisTap ty = axis_tap(sample_pos(g.start_h, ph, g.bin_h, iy, g.grid_h), H);
+      for (int ix = 0; ix < g.grid_w; ix++) {
+        const AxisTap tx = axis_tap(sample_pos(g.start_w, pw, g.bin_w, ix, g.grid_w), W);
+        if (!(ty.valid && tx.valid)) continue;
+        atomicAdd(base + ((long)ty.lo * W + tx.lo) * pstride, go * (ty.wlo * tx.wlo) / count);
+        atomicAdd(base + ((long)ty.lo * W + tx.hi) * pstride, go * (ty.wlo * tx.whi) / count);
+        atomicAdd(base + ((long)ty.hi * W + tx.lo) * pstride, go * (ty.whi * tx.wlo) / count);
+        atomicAdd(base + ((long)ty.hi * W + tx.hi) * pstride, go * (ty.whi * tx.whi) / count);
+      }
+    }
+  }
+}
+
+// ---- NCHW forward: grid = (K, channel slabs); thread = one (c, ph, pw) of the slab -------------
+constexpr int SEP_THREADS = 256;
+
+template <typename T>
+__global__ __launch_bounds__(SEP_THREADS) void roi_align_fwd_sep_nchw_kernel(
+    const T* __restrict__ in, const float* __restrict__ rois, T* __restrict__ out, int C, int H, int W, int PH,
+    int PW, float scale, int sampling_ratio, int aligned, int cslab) {
+  __shared__ SepShared S;
+  const int k = blockIdx.x;
+  sep_build<false>(S, rois, k, scale, PH, PW, sampling_ratio, aligned, H, W);
+  const int c0 = blockIdx.y * cslab;
+  const int nc = min(cslab, C - c0);
+  if (!S.ok) {
+    fwd_direct_range<T, false>(in, rois, out, k, c0, nc, C, H, W, PH, PW, scale, sampling_ratio, aligned);
+    return;
+  }
+  const int bins = PH * PW;
+  const long plane = (long)H * W;
+  const T* inb = in + ((long)S.batch * C + c0) * plane;
+  T* outb = out + ((long)k * C + c0) * bins;
+  const float inv = S.inv_count;
+  for (int e = threadIdx.x; e < nc * bins; e += SEP_THREADS) {
+    const int c = e / bins, b = e - c * bins;
+    const int ph = b / PW, pw = b - ph * PW;
+    const T* p = inb + (long)c * plane;
+    const int fy = S.firsty[ph], sy = S.spany[ph], fx = S.firstx[pw], sx = S.spanx[pw];
+    const float* wy = S.wy + ph * SEP_SPAN;
+    const float* wx = S.wx + pw * SEP_SPAN;
+    float acc = 0.f;
+    for (int j = 0; j < sy; j++) {
+      const T* row = p + (long)(fy + j) * W + fx;
+      float racc = 0.f;
+      for (int i = 0; i < sx; i++) racc += wx[i] * to_f32(row[i]);
+      acc += wy[j] * racc;
+    }
+    outb[e] = from_f32<T>(acc * inv);
+  }
+}
+
+// ---- NHWC forward: grid = K; lanes = channel quads; waves stride over bins -----------------------
+template <typename T>
+__global__ __launch_bounds__(SEP_THREADS) void roi_align_fwd_sep_nhwc_kernel(
+    const T* __restrict__ in, const float* __restrict__ rois, T* __restrict__ out, int C, int H, int W, int PH,
+    int PW, float scale, int sampling_ratio, int aligned) {
+  __shared__ SepShared S;
+  const int k = blockIdx.x;
+  sep_build<false>(S, rois, k, scale, PH, PW, sampling_ratio, aligned, H, W);
+  if (!S.ok) {
+    fwd_direct_range<T, true>(in, rois, out, k, 0, C, C, H, W, PH, PW, scale, sampling_ratio, aligned);
+    return;
+  }
+  const int bins = PH * PW;
+  const int cq = C >> 2;                    // channel quads (C % 4 == 0 on this path)
+  const T* inb = in + (long)S.batch * H * W * C;
+  T* outb = out + (long)k * bins * C;
+  const float inv = S.inv_count;
+  // work item = (bin, quad); consecutive threads take consecutive quads of the same bin
+  for (int e = threadIdx.x; e < bins * cq; e += SEP_THREADS) {
+    const int b = e / cq, q = e - b * cq;
+    const int ph = b / PW, pw = b - ph * PW;
+    const int fy = S.firsty[ph], sy = S.spany[ph], fx = S.firstx[pw], sx = S.spanx[pw];
+    const float* wy = S.wy + ph * SEP_SPAN;
+    const float* wx = S.wx + pw * SEP_SPAN;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < sy; j++) {
+      const vec4<T>* row = reinterpret_cast<const vec4<T>*>(inb + ((long)(fy + j) * W + fx) * C) + q;
+      const float wyj = wy[j];
+      for (int i = 0; i < sx; i++) {
+        const vec4<T> v = row[(long)i * cq];
+        float f[4];
+        unpack4(v, f);
+        const float w = wyj * wx[i];
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc[u] += w * f[u];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) acc[u] *= inv;
+    vec4<T> o;
+    pack4(acc, o);
+    reinterpret_cast<vec4<T>*>(outb + (long)b * C)[q] = o;
+  }
+}
+
+// ---- separable backward (fp32 atomics), both layouts ---------------------------------------------
+template <typename T, bool NHWC_>
+__global__ __launch_bounds__(SEP_THREADS) void roi_align_bwd_sep_kernel(
+    const T* __restrict__ gout, const float* __restrict__ rois, float* __restrict__ gin, int C, int H, int W,
+    int PH, int PW, float scale, int sampling_ratio, int aligned, int cslab) {
+  __shared__ SepShared S;
+  const int k = blockIdx.x;
+  sep_build<true>(S, rois, k, scale, PH, PW, sampling_ratio, aligned, H, W);
+  const int c0 = blockIdx.y * cslab;
+  const int nc = min(cslab, C - c0);
+  if (!S.ok) {
+    bwd_direct_range<T, NHWC_>(gout, rois, gin, k, c0, nc, C, H, W, PH, PW, scale, sampling_ratio, aligned);
+    return;
+  }
+  const int bins = PH * PW;
+  const long plane = (long)H * W;
+  const float inv = S.inv_count;
+  for (int e = threadIdx.x; e < nc * bins; e += SEP_THREADS) {
+    int c, b;
+    if (NHWC_) { b = e / nc; c = e - b * nc; } else { c = e / bins; b = e - c * bins; }
+    const int ph = b / PW, pw = b - ph * PW;
+    const float go = NHWC_ ? to_f32(gout[((long)k * bins + b) * C + c0 + c])
+                           : to_f32(gout[((long)k * C + c0 + c) * bins + b]);
+    const float gsc = go * inv;
+    const int fy = S.firsty[ph], sy = S.spany[ph], fx = S.firstx[pw], sx = S.spanx[pw];
+    const float* wy = S.wy + ph * SEP_SPAN;
+    const float* wx = S.wx + pw * SEP_SPAN;
+    float* base = NHWC_ ? gin + (long)S.batch * plane * C + c0 + c : gin + ((long)S.batch * C + c0 + c) * plane;
+    const long pstride = NHWC_ ? C : 1;
+    for (int j = 0; j < sy; j++) {
+      const float gy = gsc * wy[j];
+      float* row = base + ((long)(fy + j) * W + fx) * pstride;
+      for (int i = 0; i < sx; i++) {
+        const float w = wx[i];
+        if (w != 0.f) atomicAdd(row + (long)i * pstride, gy * w);
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ void f32_to_T_kernel(const float* __restrict__ src, T* __restrict__ dst, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    dst[i] = from_f32<T>(src[i]);
+}
+
+static int grid_for(long total, int block) {
+  long g = (total + block - 1) / block;
+  return (int)(g > 256L * 32 ? 256L * 32 : (g < 1 ? 1 : g));
+}
+
+// channel slab so that (ROI, slab) workgroups fill the chip (>> 256 CUs) yet keep tables amortised
+static int pick_cslab(int C, int K) {
+  int slab = C;
+  while (slab > 16 && (long)K * ((C + slab - 1) / slab) < 2048 && slab % 2 == 0) slab /= 2;
+  return slab;
+}
+
+template <typename T>
+static int fwd_impl(const void* input, const float* rois, void* output, int N, int C, int H, int W, int K, int PH,
+                    int PW, float scale, int sr, int aligned, int layout, bool rotated, int* status,
+                    hipStream_t s) {
+  const T* in = (const T*)input;
+  T* out = (T*)output;
+  const bool nhwc = layout == D2AMD_NHWC;
+  const long total = (long)K * C * PH * PW;
+  const int gsz = grid_for(total, 256);
+  if (rotated) {
+    if (nhwc)
+      hipLaunchKernelGGL((roi_align_fwd_direct_kernel<T, true, true>), dim3(gsz), dim3(256), 0, s, in, rois, out, C,
+                         H, W, K, PH, PW, scale, sr, aligned, status);
+    else
+      hipLaunchKernelGGL((roi_align_fwd_direct_kernel<T, true, false>), dim3(gsz), dim3(256), 0, s, in, rois, out,
+                         C, H, W, K, PH, PW, scale, sr, aligned, status);
+    D2_LAUNCH_OK();
+    return D2AMD_OK;
+  }
+  const bool sep_ok = PH <= SEP_MAXP && PW <= SEP_MAXP && K <= 0x7fffffff;
+  if (!sep_ok || (nhwc && (C % 4 != 0))) {
+    if (nhwc)
+      hipLaunchKernelGGL((roi_align_fwd_direct_kernel<T, false, true>), dim3(gsz), dim3(256), 0, s, in, rois, out,
+                         C, H, W, K, PH, PW, scale, sr, aligned, nullptr);
+    else
+      hipLaunchKernelGGL((roi_align_fwd_direct_kernel<T, false, false>), dim3(gsz), dim3(256), 0, s, in, rois, out,
+                         C, H, W, K, PH, PW, scale, sr, aligned, nullptr);
+  } else if (nhwc) {
+    hipLaunchKernelGGL((roi_align_fwd_sep_nhwc_kernel<T>), dim3(K), dim3(SEP_THREADS), 0, s, in, rois, out, C, H,
+                       W, PH, PW, scale, sr, aligned);
+  } else {
+    const int cslab = pick_cslab(C, K);
+    hipLaunchKernelGGL((roi_align_fwd_sep_nchw_kernel<T>), dim3(K, cdiv(C, cslab)), dim3(SEP_THREADS), 0, s, in,
+                       rois, out, C, H, W, PH, PW, scale, sr, aligned, cslab);
+  }
+  D2_LAUNCH_OK();
+  return D2AMD_OK;
+}
+
+template <typename T>
+static int bwd_impl(const void* grad_output, const float* rois, void* grad_input, int N, int C, int H, int W, int K,
+                    int PH, int PW, float scale, int sr, int aligned, int layout, bool rotated, void* workspace,
+                    size_t workspace_bytes, hipStream_t s) {
+  const T* gout = (const T*)grad_output;
+  const bool nhwc = layout == D2AMD_NHWC;
+  const long numel = (long)N * C * H * W;
+  constexpr bool is32 = sizeof(T) == 4;
+  const size_t need = is32 ? 0 : (size_t)numel * 4;  // fp32 accumulation buffer for 16-bit grads
+  if (need > 0 && (workspace == nullptr || workspace_bytes < need)) {
+    set_error("roi_align_backward: workspace too small (%zu < %zu)", workspace_bytes, need);
+    return D2AMD_EWORKSPACE;
+  }
+  float* acc = is32 ? (float*)grad_input : (float*)workspace;
+  D2_HIP_OK(hipMemsetAsync(acc, 0, (size_t)numel * 4, s));
+  const long total = (long)K * C * PH * PW;
+  if (total > 0) {
+    const bool sep_ok = !rotated && PH <= SEP_MAXP && PW <= SEP_MAXP;
+    if (!sep_ok) {
+      const int gsz = grid_for(total, 256);
+      if (rotated) {
+        if (nhwc) hipLaunchKernelGGL((roi_align_bwd_direct_kernel<T, true, true>), dim3(gsz), dim3(256), 0, s, gout, rois, acc, C, H, W, K, PH, PW, scale, sr, aligned);
+        else hipLaunchKernelGGL((roi_align_bwd_direct_kernel<T, true, false>), dim3(gsz), dim3(256), 0, s, gout, rois, acc, C, H, W, K, PH, PW, scale, sr, aligned);
+      } else {
+        if (nhwc) hipLaunchKernelGGL((roi_align_bwd_direct_kernel<T, false, true>), dim3(gsz), dim3(256), 0, s, gout, rois, acc, C, H, W, K, PH, PW, scale, sr, aligned);
+        else hipLaunchKernelGGL((roi_align_bwd_direct_kernel<T, false, false>), dim3(gsz), dim3(256), 0, s, gout, rois, acc, C, H, W, K, PH, PW, scale, sr, aligned);
+      }
+    } else {
+      const int cslab = pick_cslab(C, K);
+      dim3 grid(K, cdiv(C, cslab));
+      if (nhwc) hipLaunchKernelGGL((roi_align_bwd_sep_kernel<T, true>), grid, dim3(SEP_THREADS), 0, s, gout, rois, acc, C, H, W, PH, PW, scale, sr, aligned, cslab);
+      else hipLaunchKernelGGL((roi_align_bwd_sep_kernel<T, false>), grid, dim3(SEP_THREADS), 0, s, gout, rois, acc, C, H, W, PH, PW, scale, sr, aligned, cslab);
+    }
+    D2_LAUNCH_OK();
+  }
+  if (!is32) {
+    hipLaunchKernelGGL((f32_to_T_kernel<T>), dim3(grid_for(numel, 256)), dim3(256), 0, s, acc, (T*)grad_input, numel);
+    D2_LAUNCH_OK();
+  }
+  return D2AMD_OK;
+}
+
+static int check_common(const char* who, int N, int C, int H, int W, int K, int PH, int PW, int dtype, int layout) {
+  D2_CHECK_ARG(N >= 0 && C >= 0 && H >= 0 && W >= 0 && K >= 0 && PH > 0 && PW > 0, "%s: bad shape", who);
+  D2_CHECK_ARG(layout == D2AMD_NCHW || layout == D2AMD_NHWC, "%s: bad layout %d", who, layout);
+  D2_CHECK_ARG(dtype == D2AMD_F32 || dtype == D2AMD_F16 || dtype == D2AMD_BF16, "%s: bad dtype %d", who, dtype);
+  return D2AMD_OK;
+}
+
+}  // namespace d2amd
+
+using namespace d2amd;
+
+extern "C" int d2amd_roi_align_forward(const void* input, const float* rois, void* output, int N, int C, int H,
+                                       int W, int K, int pooled_h, int pooled_w, float spatial_scale,
+                                       int sampling_ratio, int aligned, int dtype, int layout, void* stream) {
+  int rc = check_common("roi_align_forward", N, C, H, W, K, pooled_h, pooled_w, dtype, layout);
+  if (rc) return rc;
+  if ((long)K * C == 0) return D2AMD_OK;
+  D2_CHECK_ARG(input && rois && output, "roi_align_forward: null pointer");
+  return D2_DISPATCH_DTYPE(dtype, [&]() -> int {
+    return fwd_impl<scalar_t>(input, rois, output, N, C, H, W, K, pooled_h, pooled_w, spatial_scale, sampling_ratio,
+                              aligned, layout, false, nullptr, (hipStream_t)stream);
+  });
+}
+
+extern "C" int d2amd_roi_align_backward(const void* grad_output, const float* rois, void* grad_input, int N, int C,
+                                        int H, int W, int K, int pooled_h, int pooled_w, float spatial_scale,
+                                        int sampling_ratio, int aligned, int dtype, int layout, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+  int rc = check_common("roi_align_backward", N, C, H, W, K, pooled_h, pooled_w, dtype, layout);
+  if (rc) return rc;
+  if ((long)N * C * H * W == 0) return D2AMD_OK;
+  D2_CHECK_ARG(grad_input && (K == 0 || (grad_output && rois)), "roi_align_backward: null pointer");
+  return D2_DISPATCH_DTYPE(dtype, [&]() -> int {
+    return bwd_impl<scalar_t>(grad_output, rois, grad_input, N, C, H, W, K, pooled_h, pooled_w, spatial_scale,
+                              sampling_ratio, aligned, layout, false, workspace, workspace_bytes, (hipStream_t)stream);
+  });
+}
+
+extern "C" int d2amd_roi_align_rotated_forward(const void* input, const float* rois, void* output, int N, int C,
+                                               int H, int W, int K, int pooled_h, int pooled_w, float spatial_scale,
+                                               int sampling_ratio, int dtype, int layout, int* status, void* stream) {
+  int rc = check_common("roi_align_rotated_forward", N, C, H, W, K, pooled_h, pooled_w, dtype, layout);
+  if (rc) return rc;
+  if ((long)K * C == 0) return D2AMD_OK;
+  D2_CHECK_ARG(input && rois && output, "roi_align_rotated_forward: null pointer");
+  return D2_DISPATCH_DTYPE(dtype, [&]() -> int {
+    return fwd_impl<scalar_t>(input, rois, output, N, C, H, W, K, pooled_h, pooled_w, spatial_scale, sampling_ratio, 1,
+                              layout, true, status, (hipStream_t)stream);
+  });
+}
+
+extern "C" int d2amd_roi_align_rotated_backward(const void* grad_output, const float* rois, void* grad_input, int N,
+                                                int C, int H, int W, int K, int pooled_h, int pooled_w,
+                                                float spatial_scale, int sampling_ratio, int dtype, int layout,
+                                                void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = check_common("roi_align_rotated_backward", N, C, H, W, K, pooled_h, pooled_w, dtype, layout);
+  if (rc) return rc;
+  if ((long)N * C * H * W == 0) return D2AMD_OK;
+  D2_CHECK_ARG(grad_input && (K == 0 || (grad_output && rois)), "roi_align_rotated_backward: null pointer");
+  return D2_DISPATCH_DTYPE(dtype, [&]() -> int {
+    return bwd_impl<scalar_t>(grad_output, rois, grad_input, N, C, H, W, K, pooled_h, pooled_w, spatial_scale,
+                              sampling_ratio, 1, layout, true, workspace, workspace_bytes, (hipStream_t)stream);
+  });
+}

@@ -1,0 +1,37 @@
+"""NMS surface -- mirrors detectron2/layers/nms.py:5-147: `nms`, `batched_nms`, `nms_rotated`,
+`batched_nms_rotated`.  Contract kept: int64 indices sorted by decreasing score; inputs are not
+modified.  `batched_nms*` suppress independently per category on the ORIGINAL coordinates (no
+coordinate-offset trick: the device kernel is category-aware, nms.py:137-145 is not needed)."""
+import torch
+
+from .ops import nms_impl
+from .wrappers import disable_torch_compiler
+
+
+def nms(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float) -> torch.Tensor:
+    """torchvision.ops.nms semantics (re-exported by the reference at nms.py:6): greedy NMS on
+    Tensor[N,4] xyxy boxes, suppressing IoU > iou_threshold."""
+    return nms_impl(boxes, scores, None, iou_threshold, False)
+
+
+def batched_nms(boxes: torch.Tensor, scores: torch.Tensor, idxs: torch.Tensor, iou_threshold: float):
+    """Same as torchvision.ops.boxes.batched_nms, but with float() (nms.py:11-22)."""
+    assert boxes.shape[-1] == 4
+    return nms_impl(boxes.float(), scores, idxs, iou_threshold, False)
+
+
+@disable_torch_compiler
+def nms_rotated(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float):
+    """Rotated NMS on Tensor[N,5] (x_ctr, y_ctr, w, h, angle_degrees) boxes (nms.py:27-89):
+    iteratively removes lower scoring boxes whose IoU with a kept box is >= iou_threshold
+    (the reference's CPU comparison).  Returns int64 indices in decreasing score order."""
+    return torch.ops.detectron2.nms_rotated(boxes, scores, iou_threshold)
+
+
+def batched_nms_rotated(boxes: torch.Tensor, scores: torch.Tensor, idxs: torch.Tensor, iou_threshold: float):
+    """Per-category rotated NMS (nms.py:96-147)."""
+    assert boxes.shape[-1] == 5
+    if boxes.numel() == 0:
+        return torch.empty((0,), dtype=torch.int64, device=boxes.device)
+    boxes = boxes.float()  # fp16 does not have enough range for batched NMS
+    return nms_impl(boxes, scores, idxs, iou_threshold, True)

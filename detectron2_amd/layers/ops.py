@@ -1,0 +1,144 @@
+"""Registers the reference's native-op surface -- torch.ops.detectron2.{nms_rotated,
+box_iou_rotated, roi_align_rotated_forward, roi_align_rotated_backward} with the schemas of
+detectron2/layers/csrc/vision.cpp:115-120 -- on top of the C ABI (libd2amd.so), plus
+torch.ops.d2amd.* for the ops the reference gets from torchvision / plain torch.  Registered
+through torch.library so they are TorchScript-callable and opaque to torch.compile, like the
+reference's ops (SURVEY 8b "Threading / streams")."""
+import torch
+
+from .. import _C
+from .roi_align import _empty_like_layout, _prep_input
+
+_DEFS = {
+    "nms_rotated": "(Tensor dets, Tensor scores, float iou_threshold) -> Tensor",
+    "box_iou_rotated": "(Tensor boxes1, Tensor boxes2) -> Tensor",
+    "roi_align_rotated_forward": "(Tensor input, Tensor rois, float spatial_scale, int pooled_height, "
+                                 "int pooled_width, int sampling_ratio) -> Tensor",
+    "roi_align_rotated_backward": "(Tensor grad, Tensor rois, float spatial_scale, int pooled_height, "
+                                  "int pooled_width, int batch_size, int channels, int height, int width, "
+                                  "int sampling_ratio) -> Tensor",
+}
+
+
+def nms_impl(boxes, scores, idxs, iou_threshold, rotated):
+    """Shared driver of nms / batched_nms / nms_rotated / batched_nms_rotated (d2amd_nms)."""
+    bw = 5 if rotated else 4
+    assert boxes.dim() == 2 and boxes.shape[1] == bw, boxes.shape
+    n = boxes.shape[0]
+    if n == 0:  # nothing to compute on any device (nms.py:125-126)
+        return torch.empty((0,), dtype=torch.int64, device=boxes.device)
+    _C.require_gpu(boxes, scores, idxs, op="nms")
+    boxes = boxes.detach().float().contiguous()
+    scores = scores.detach().float().contiguous()
+    assert scores.shape[0] == n
+    max_per_class = 0
+    if idxs is not None:
+        idxs = idxs.detach().to(torch.int64).contiguous()
+        assert idxs.shape[0] == n
+        if n > 16384:
+            # the suppression bitmask is n x (largest category / 64) words: size it from the data
+            # (one extra host sync, only for very large inputs)
+            max_per_class = int(torch.unique(idxs, return_counts=True)[1].max().item())
+    L = _C.lib()
+    with torch.cuda.device(boxes.device):
+        ws_bytes = L.d2amd_nms_workspace_bytes(n, max_per_class, int(rotated))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=boxes.device)
+        keep = torch.empty(n, dtype=torch.int64, device=boxes.device)
+        result = torch.empty(2, dtype=torch.int64, device=boxes.device)
+        _C.check(L.d2amd_nms(_C.ptr(boxes), _C.ptr(scores), _C.ptr(idxs), n, float(iou_threshold), int(rotated),
+                             max_per_class, _C.ptr(keep), _C.ptr(result), _C.ptr(ws), ws_bytes, _C.stream()))
+    num, flags = result.tolist()  # the only host sync of the NMS pipeline
+    if flags & 2:
+        raise RuntimeError("batched_nms: category ids must be in [0, 65535]")
+    if flags & 1:
+        raise RuntimeError("batched_nms: internal error: category larger than max_per_class")
+    return keep[:num]
+
+
+def _nms_rotated(dets, scores, iou_threshold):
+    return nms_impl(dets, scores, None, iou_threshold, True)
+
+
+def _box_iou_rotated(boxes1, boxes2):
+    _C.require_gpu(boxes1, boxes2, op="box_iou_rotated")
+    b1 = boxes1.detach().float().contiguous()
+    b2 = boxes2.detach().float().contiguous()
+    assert b1.dim() == 2 and b1.shape[1] == 5 and b2.dim() == 2 and b2.shape[1] == 5
+    n, m = b1.shape[0], b2.shape[0]
+    out = torch.empty((n, m), dtype=torch.float32, device=b1.device)  # always fp32 (box_iou_rotated_cpu.cpp:29)
+    if n and m:
+        with torch.cuda.device(b1.device):
+            _C.check(_C.lib().d2amd_box_iou_rotated(_C.ptr(b1), n, _C.ptr(b2), m, _C.ptr(out), _C.stream()))
+    return out
+
+
+def _roi_align_rotated_forward(input, rois, spatial_scale, pooled_height, pooled_width, sampling_ratio):
+    _C.require_gpu(input, rois, op="roi_align_rotated_forward")
+    assert rois.dim() == 2 and rois.shape[1] == 6
+    x, layout = _prep_input(input.detach())
+    r = rois.detach().float().contiguous()
+    n, c, h, w = x.shape
+    k = r.shape[0]
+    out = _empty_like_layout(x, (k, c, pooled_height, pooled_width), layout)
+    if out.numel() == 0:
+        return out
+    status = torch.zeros(1, dtype=torch.int32, device=x.device)
+    with torch.cuda.device(x.device):
+        _C.check(_C.lib().d2amd_roi_align_rotated_forward(
+            _C.ptr(x), _C.ptr(r), _C.ptr(out), n, c, h, w, k, pooled_height, pooled_width, float(spatial_scale),
+            int(sampling_ratio), _C.dtype_code(x), layout, _C.ptr(status), _C.stream()))
+    return out
+
+
+def _roi_align_rotated_backward(grad, rois, spatial_scale, pooled_height, pooled_width, batch_size, channels,
+                                height, width, sampling_ratio):
+    _C.require_gpu(grad, rois, op="roi_align_rotated_backward")
+    layout = _C.NHWC if (grad.dim() == 4 and not grad.is_contiguous()
+                         and grad.is_contiguous(memory_format=torch.channels_last)) else _C.NCHW
+    g = grad.detach() if layout == _C.NHWC else grad.detach().contiguous()
+    r = rois.detach().float().contiguous()
+    shape = (batch_size, channels, height, width)
+    gin = _empty_like_layout(g, shape, layout)
+    if gin.numel() == 0:
+        return gin
+    ws, ws_bytes = None, 0
+    if g.dtype != torch.float32:
+        ws = torch.empty(gin.numel(), dtype=torch.float32, device=g.device)
+        ws_bytes = ws.numel() * 4
+    with torch.cuda.device(g.device):
+        _C.check(_C.lib().d2amd_roi_align_rotated_backward(
+            _C.ptr(g), _C.ptr(r), _C.ptr(gin), batch_size, channels, height, width, r.shape[0], pooled_height,
+            pooled_width, float(spatial_scale), int(sampling_ratio), _C.dtype_code(g), layout, _C.ptr(ws),
+            ws_bytes, _C.stream()))
+    return gin
+
+
+_IMPLS = {
+    "nms_rotated": _nms_rotated,
+    "box_iou_rotated": _box_iou_rotated,
+    "roi_align_rotated_forward": _roi_align_rotated_forward,
+    "roi_align_rotated_backward": _roi_align_rotated_backward,
+}
+
+_lib_handle = torch.library.Library("detectron2", "FRAGMENT")
+for _name, _schema in _DEFS.items():
+    try:
+        _lib_handle.define(_name + _schema)
+    except RuntimeError:
+        pass  # a real detectron2 build already defined the schema; we only add the device kernel
+    # "CUDA" is the dispatch key of HIP devices in PyTorch-ROCm
+    _lib_handle.impl(_name, _IMPLS[_name], "CUDA")
+
+
+def _cpu_stub(name):
+    def f(*a, **k):
+        raise NotImplementedError(
+            f"torch.ops.detectron2.{name}: detectron2_amd implements this op for MI355X (HIP tensors) only")
+    return f
+
+
+for _name in _DEFS:
+    try:
+        _lib_handle.impl(_name, _cpu_stub(_name), "CPU")
+    except RuntimeError:
+        pass

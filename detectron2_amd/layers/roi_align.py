@@ -1,0 +1,112 @@
+"""ROIAlign -- mirrors detectron2/layers/roi_align.py:7-74 (torchvision.ops.roi_align semantics).
+
+Differences from the reference, by design (SURVEY 7 "bf16"): ROI coordinates are always kept in
+fp32 (the reference casts them to the input dtype, which under AMP torchvision undoes again);
+16-bit features are sampled with fp32 weights and fp32 accumulation.  channels_last inputs are
+consumed and produced natively (NHWC kernels)."""
+import torch
+from torch import nn
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+from torch.nn.modules.utils import _pair
+
+from .. import _C
+from .wrappers import disable_torch_compiler
+
+
+def _layout_of(x):
+    """NHWC when the tensor is channels_last-dense (and not also NCHW-dense)."""
+    if x.dim() == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last):
+        return _C.NHWC
+    return _C.NCHW
+
+
+def _prep_input(x):
+    layout = _layout_of(x)
+    if layout == _C.NCHW:
+        x = x.contiguous()
+    return x, layout
+
+
+def _empty_like_layout(x, shape, layout):
+    if layout == _C.NHWC:
+        return torch.empty(shape, dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    return torch.empty(shape, dtype=x.dtype, device=x.device)
+
+
+class _ROIAlign(Function):
+    @staticmethod
+    @disable_torch_compiler
+    def forward(ctx, input, rois, output_size, spatial_scale, sampling_ratio, aligned):
+        _C.require_gpu(input, rois, op="roi_align")
+        ph, pw = _pair(output_size)
+        x, layout = _prep_input(input)
+        rois = rois.detach().float().contiguous()
+        n, c, h, w = x.shape
+        k = rois.shape[0]
+        out = _empty_like_layout(x, (k, c, ph, pw), layout)
+        with torch.cuda.device(x.device):
+            _C.check(_C.lib().d2amd_roi_align_forward(
+                _C.ptr(x), _C.ptr(rois), _C.ptr(out), n, c, h, w, k, ph, pw, float(spatial_scale),
+                int(sampling_ratio), int(bool(aligned)), _C.dtype_code(x), layout, _C.stream()))
+        ctx.save_for_backward(rois)
+        ctx.cfg = (ph, pw, float(spatial_scale), int(sampling_ratio), bool(aligned), tuple(x.shape), layout)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        (rois,) = ctx.saved_tensors
+        ph, pw, scale, sr, aligned, shape, layout = ctx.cfg
+        n, c, h, w = shape
+        k = rois.shape[0]
+        if layout == _C.NHWC:
+            g = grad_output.contiguous(memory_format=torch.channels_last)
+        else:
+            g = grad_output.contiguous()
+        gin = _empty_like_layout(g, shape, layout)
+        ws, ws_bytes = None, 0
+        if g.dtype != torch.float32:
+            ws = torch.empty(n * c * h * w, dtype=torch.float32, device=g.device)
+            ws_bytes = ws.numel() * 4
+        with torch.cuda.device(g.device):
+            _C.check(_C.lib().d2amd_roi_align_backward(
+                _C.ptr(g), _C.ptr(rois), _C.ptr(gin), n, c, h, w, k, ph, pw, scale, sr, int(aligned),
+                _C.dtype_code(g), layout, _C.ptr(ws), ws_bytes, _C.stream()))
+        return gin, None, None, None, None, None
+
+
+def roi_align(input, boxes, output_size, spatial_scale=1.0, sampling_ratio=-1, aligned=False):
+    """Functional form with torchvision.ops.roi_align's signature (re-exported by
+    detectron2/layers/__init__.py:6).  `boxes`: Tensor[K,5] or a list of Tensor[L,4] per image."""
+    if not isinstance(boxes, torch.Tensor):
+        ids = torch.cat([torch.full_like(b[:, :1], i) for i, b in enumerate(boxes)], 0)
+        boxes = torch.cat([ids, torch.cat(list(boxes), 0)], 1)
+    return _ROIAlign.apply(input, boxes, output_size, spatial_scale, sampling_ratio, aligned)
+
+
+class ROIAlign(nn.Module):
+    def __init__(self, output_size, spatial_scale, sampling_ratio, aligned=True):
+        """Same arguments as the reference (roi_align.py:8-37): `aligned=True` shifts the ROI by
+        -0.5 px after scaling (the correct pixel model); `sampling_ratio=0` samples densely."""
+        super().__init__()
+        self.output_size = output_size
+        self.spatial_scale = spatial_scale
+        self.sampling_ratio = sampling_ratio
+        self.aligned = aligned
+
+    def forward(self, input, rois):
+        """input: NCHW images; rois: Bx5 boxes (batch index, x1, y1, x2, y2)."""
+        assert rois.dim() == 2 and rois.size(1) == 5
+        if input.is_quantized:
+            input = input.dequantize()
+        return roi_align(input, rois, self.output_size, self.spatial_scale, self.sampling_ratio, self.aligned)
+
+    def __repr__(self):
+        tmpstr = self.__class__.__name__ + "("
+        tmpstr += "output_size=" + str(self.output_size)
+        tmpstr += ", spatial_scale=" + str(self.spatial_scale)
+        tmpstr += ", sampling_ratio=" + str(self.sampling_ratio)
+        tmpstr += ", aligned=" + str(self.aligned)
+        tmpstr += ")"
+        return tmpstr

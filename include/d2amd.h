@@ -1,0 +1,136 @@
+/*
+ * d2amd.h -- C ABI of libd2amd.so: the MI355X (gfx950) implementation of Detectron2's
+ * per-image detection hot path.  This is the drop-in boundary: every entry point below is
+ * what a binding of the reference's native-op surface would call.  The reference has no C
+ * ABI of its own -- its boundary is a pybind11 module + TORCH_LIBRARY ops
+ * (detectron2/layers/csrc/vision.cpp:81-120); each function cites the reference entry it
+ * replaces.  INTEGRATION.md shows the Python (ctypes / torch.library) stub that binds them.
+ *
+ * Conventions
+ *   - plain C, no torch/ATen types: device pointers + sizes + a HIP stream (hipStream_t
+ *     passed as void*; NULL = the legacy default stream).
+ *   - every pointer is a DEVICE pointer on the current HIP device unless it says (host).
+ *   - calls are asynchronous on `stream`; nothing synchronises the device.
+ *   - return 0 on success, a negative D2AMD_E* code otherwise; d2amd_last_error() (host,
+ *     thread-local) describes the failure.  The reference raises RuntimeError through
+ *     TORCH_CHECK/AT_ERROR (SURVEY 8b "Errors"); the Python layer turns codes into that.
+ *   - tensors are dense; `layout` says whether a 4-D feature tensor is NCHW-contiguous
+ *     (the reference's layout) or NHWC-contiguous (torch.channels_last).
+ *   - floating-point I/O dtype is selected by `dtype`; all accumulation is fp32.
+ */
+#ifndef D2AMD_H_
+#define D2AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define D2AMD_OK 0
+#define D2AMD_EINVAL (-1)    /* bad argument / shape (reference: TORCH_CHECK failures) */
+#define D2AMD_ELAUNCH (-2)   /* HIP launch / runtime error */
+#define D2AMD_EWORKSPACE (-3)/* workspace too small */
+#define D2AMD_EUNSUPPORTED (-4)
+
+enum d2amd_dtype { D2AMD_F32 = 0, D2AMD_F16 = 1, D2AMD_BF16 = 2 };
+enum d2amd_layout { D2AMD_NCHW = 0, D2AMD_NHWC = 1 };
+enum d2amd_iou_mode { D2AMD_IOU = 0, D2AMD_IOA = 1, D2AMD_INTERSECTION = 2 };
+
+/* ---- introspection: vision.cpp:16-79 get_cuda_version / has_cuda / get_compiler_version */
+const char* d2amd_version(void);          /* library version string (host) */
+const char* d2amd_compiler_version(void); /* "clang x.y.z" like get_compiler_version() */
+const char* d2amd_hip_version(void);      /* "HIP x.y" like get_cuda_version() under WITH_HIP */
+const char* d2amd_last_error(void);       /* last error message of this thread (host) */
+
+/* ---- ROIAlign (axis-aligned).  Replaces torchvision.ops.roi_align as called from
+ * detectron2/layers/roi_align.py:58-65 (forward) and its autograd backward.
+ * input  [N,C,H,W] `dtype`, `layout`; rois [K,5] fp32 (b, x1, y1, x2, y2);
+ * output [K,C,PH,PW] `dtype`, same `layout` convention as input (NCHW or NHWC dense). */
+int d2amd_roi_align_forward(const void* input, const float* rois, void* output, int N, int C,
+                            int H, int W, int K, int pooled_h, int pooled_w,
+                            float spatial_scale, int sampling_ratio, int aligned, int dtype,
+                            int layout, void* stream);
+/* grad_input [N,C,H,W] is fully overwritten (zero-filled then accumulated).  For 16-bit
+ * dtypes `workspace` must hold N*C*H*W floats (fp32 accumulation, converted once); for fp32
+ * it may be NULL. */
+int d2amd_roi_align_backward(const void* grad_output, const float* rois, void* grad_input,
+                             int N, int C, int H, int W, int K, int pooled_h, int pooled_w,
+                             float spatial_scale, int sampling_ratio, int aligned, int dtype,
+                             int layout, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- ROIAlignRotated.  Replaces torch.ops.detectron2.roi_align_rotated_forward/backward
+ * (vision.cpp:118-119; csrc/ROIAlignRotated/ROIAlignRotated.h:50-113).
+ * rois [K,6] fp32 (b, cx, cy, w, h, angle_degrees).  Negative w/h is reported through
+ * `status` (device int32, set non-zero; mirrors the CPU AT_ASSERTM at
+ * ROIAlignRotated_cpu.cpp:236-238); may be NULL. */
+int d2amd_roi_align_rotated_forward(const void* input, const float* rois, void* output, int N,
+                                    int C, int H, int W, int K, int pooled_h, int pooled_w,
+                                    float spatial_scale, int sampling_ratio, int dtype,
+                                    int layout, int* status, void* stream);
+int d2amd_roi_align_rotated_backward(const void* grad_output, const float* rois,
+                                     void* grad_input, int N, int C, int H, int W, int K,
+                                     int pooled_h, int pooled_w, float spatial_scale,
+                                     int sampling_ratio, int dtype, int layout, void* workspace,
+                                     size_t workspace_bytes, void* stream);
+
+/* ---- pairwise box IoU.  detectron2/structures/boxes.py:312-377 (pairwise_iou / _ioa /
+ * _intersection): boxes1 [n,4], boxes2 [m,4] fp32 xyxy -> out [n,m] fp32. */
+int d2amd_pairwise_iou(const float* boxes1, int n, const float* boxes2, int m, int mode,
+                       float* out, void* stream);
+/* torch.ops.detectron2.box_iou_rotated (vision.cpp:117; box_iou_rotated.h:20-33):
+ * boxes [.,5] fp32 (cx, cy, w, h, angle_degrees) -> out [n,m] fp32. */
+int d2amd_box_iou_rotated(const float* boxes1, int n, const float* boxes2, int m, float* out,
+                          void* stream);
+
+/* ---- NMS.  One entry serves torchvision.ops.nms / batched_nms (detectron2/layers/nms.py:6,
+ * 11-22) and torch.ops.detectron2.nms_rotated / batched_nms_rotated (vision.cpp:116,
+ * nms_rotated.h:22-37, nms.py:96-147).
+ *   boxes   [n,4] xyxy (rotated=0) or [n,5] cxcywha (rotated=1), fp32
+ *   scores  [n] fp32;  idxs [n] int64 category per box, or NULL (single category)
+ *   suppression: IoU >  iou_threshold (rotated=0, torchvision CPU semantics)
+ *                IoU >= iou_threshold (rotated=1, nms_rotated_cpu.cpp:54); compare in double.
+ *   keep_out [n] int64: kept ORIGINAL indices in decreasing score order (ties: lower index
+ *            first);  result [2] int64 (device): {number kept, error flags}.  error flag bit 0:
+ *            a category has more than `max_per_class` boxes, bit 1: category id out of range.
+ *   max_per_class: upper bound on boxes in one category (sizes the suppression bitmask);
+ *            <= 0 means "unknown" = n.   Category ids must lie in [0, 65535].
+ * The whole pipeline (sort, bitmask, greedy reduction, compaction) runs on the device; the
+ * caller's only host sync is reading `result`. */
+size_t d2amd_nms_workspace_bytes(int64_t n, int64_t max_per_class, int rotated);
+int d2amd_nms(const float* boxes, const float* scores, const int64_t* idxs, int64_t n,
+              double iou_threshold, int rotated, int64_t max_per_class, int64_t* keep_out,
+              int64_t* result, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- paste_masks_in_image.  detectron2/layers/mask_ops.py:74-147.
+ * masks [n,mh,mw] `mask_dtype`; boxes [n,4] fp32; out [n,img_h,img_w] uint8:
+ * threshold >= 0 -> 0/1 (torch.bool storage), threshold < 0 -> trunc(value*255). */
+int d2amd_paste_masks(const void* masks, const float* boxes, int n, int mh, int mw, int img_h,
+                      int img_w, float threshold, uint8_t* out, int mask_dtype, void* stream);
+
+/* ---- deformable convolution v1 / v2.  Replaces detectron2._C.deform_conv_forward,
+ * deform_conv_backward_input, deform_conv_backward_filter, modulated_deform_conv_forward,
+ * modulated_deform_conv_backward (vision.cpp:85-102; csrc/deformable/deform_conv.h:116-375).
+ * x [B,C,H,W], offset [B,dg*2*kh*kw,Ho,Wo], mask [B,dg*kh*kw,Ho,Wo] or NULL (v1),
+ * weight [Co,C/groups,kh,kw], bias [Co] or NULL, out [B,Co,Ho,Wo]; all `dtype`, NCHW.
+ * Unlike the reference there is no column buffer in HBM and no per-image loop. */
+typedef struct d2amd_dcn_params {
+  int B, C, H, W, Co, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, groups,
+      deformable_groups, dtype;
+} d2amd_dcn_params;
+size_t d2amd_deform_conv_workspace_bytes(const d2amd_dcn_params* p, int backward);
+int d2amd_deform_conv_forward(const d2amd_dcn_params* p, const void* x, const void* offset,
+                              const void* mask, const void* weight, const void* bias, void* out,
+                              void* workspace, size_t workspace_bytes, void* stream);
+/* Any of the grad_* outputs may be NULL to skip it.  Non-NULL outputs are overwritten. */
+int d2amd_deform_conv_backward(const d2amd_dcn_params* p, const void* x, const void* offset,
+                               const void* mask, const void* weight, const void* grad_out,
+                               void* grad_input, void* grad_offset, void* grad_mask,
+                               void* grad_weight, void* grad_bias, void* workspace,
+                               size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* D2AMD_H_ */

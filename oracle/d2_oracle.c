@@ -609,12 +609,13 @@ int64_t orc_nms(const float* dets, const float* scores, int64_t n, double iou_th
     for (int64_t _j = _i + 1; _j < n; _j++) {
       int64_t j = order[_j];
       if (suppressed[j]) continue;
-      float xx1 = ix1 > dets[4 * j] ? ix1 : dets[4 * j];         /* std::max(ix1, x1[j]) */
-      float yy1 = iy1 > dets[4 * j + 1] ? iy1 : dets[4 * j + 1];
-      float xx2 = ix2 < dets[4 * j + 2] ? ix2 : dets[4 * j + 2]; /* std::min(ix2, x2[j]) */
-      float yy2 = iy2 < dets[4 * j + 3] ? iy2 : dets[4 * j + 3];
-      float w = (xx2 - xx1) > 0.f ? (xx2 - xx1) : 0.f; /* std::max(0, xx2 - xx1) */
-      float h = (yy2 - yy1) > 0.f ? (yy2 - yy1) : 0.f;
+      /* std::max(a,b) = (a<b)?b:a ; std::min(a,b) = (b<a)?b:a  (NaN behaviour kept) */
+      float xx1 = (ix1 < dets[4 * j]) ? dets[4 * j] : ix1;             /* std::max(ix1, x1[j]) */
+      float yy1 = (iy1 < dets[4 * j + 1]) ? dets[4 * j + 1] : iy1;
+      float xx2 = (dets[4 * j + 2] < ix2) ? dets[4 * j + 2] : ix2;     /* std::min(ix2, x2[j]) */
+      float yy2 = (dets[4 * j + 3] < iy2) ? dets[4 * j + 3] : iy2;
+      float w = (0.f < (xx2 - xx1)) ? (xx2 - xx1) : 0.f; /* std::max(0, xx2 - xx1) */
+      float h = (0.f < (yy2 - yy1)) ? (yy2 - yy1) : 0.f;
       float inter = w * h;
       float ovr = inter / (iarea + areas[j] - inter);
       if (ovr > iou_threshold) suppressed[j] = 1;

