@@ -7,8 +7,9 @@ One "step" = one pass of the TRAINING hot path of Mask R-CNN R50-FPN over one sy
     per image : pairwise_iou(16 GT x 268,569 anchors)              [RPN matching, rpn.py:339]
                 batched_nms(8,819 proposals, 5 levels, thr 0.7)     [proposal_utils.py:121]
                 pairwise_iou(16 GT x 1,016 proposals)               [roi_heads.py:266]
-    per batch : box  ROIAlign 7x7,  1024 ROIs over p2..p5  forward + backward
-                mask ROIAlign 14x14, 256 ROIs over p2..p5  forward + backward
+    per batch : box  ROIPooler 7x7,   1024 ROIs over p2..p5  forward + backward   [roi_heads.py:_forward_box]
+                mask ROIPooler 14x14, 256 ROIs over p2..p5  forward + backward   [roi_heads.py:_forward_mask]
+                (ROIPooler = level assignment + ROIAlignV2 on the assigned level, poolers.py:206-263)
 Everything else of the model (backbone convs, heads) is out of the hot path's scope and is NOT
 in the step.  Inputs are resident in HBM before the timed region.  `value` = images / second
 through the hot path, whole job (all ranks).  Multi-GPU: images shard across ranks, no data-path
@@ -35,6 +36,7 @@ STRIDES = (4, 8, 16, 32)
 FEAT_HW = ((200, 336), (100, 168), (50, 84), (25, 42))  # 800x1344 padded input
 IMG_H, IMG_W = 800, 1344
 C = 256
+IMAGES_PER_GPU = 2
 
 
 def parse():
@@ -86,24 +88,29 @@ def assign_levels(boxes):
     return torch.clamp(lv, 2, 5).long() - 2
 
 
-class Workload:
-    def __init__(self, dev, dtype, layout, seed=1234, n_img=2):
-        from detectron2_amd.layers import ROIAlign
+def image_generator(seed, image_id):
+    """One RNG stream per GLOBAL image id: the synthetic batch does not depend on how it is sharded."""
+    return torch.Generator().manual_seed(seed * 100003 + image_id)
 
-        gen = torch.Generator().manual_seed(seed)
-        self.dev, self.n_img = dev, n_img
+
+class Workload:
+    def __init__(self, dev, dtype, layout, seed=1234, image_ids=(0, 1)):
+        n_img = len(image_ids)
+        gens = [image_generator(seed, i) for i in image_ids]
+        gen = gens[0]
+        self.dev, self.n_img, self.image_ids = dev, n_img, list(image_ids)
         self.feats = []
         for (h, w) in FEAT_HW:
-            f = (torch.rand(n_img, C, h, w, generator=gen) * 2 - 1).to(dtype).to(dev)
+            f = torch.stack([torch.rand(C, h, w, generator=g) * 2 - 1 for g in gens]).to(dtype).to(dev)
             if layout == "nhwc":
                 f = f.contiguous(memory_format=torch.channels_last)
             self.feats.append(f.requires_grad_(True))
         self.anchors = make_anchors().to(dev)
         assert self.anchors.shape[0] == 268569
-        self.gt = [make_boxes(gen, 16, 16, 512).to(dev) for _ in range(n_img)]
+        self.gt = [make_boxes(g, 16, 16, 512).to(dev) for g in gens]
         # RPN proposals entering NMS: 2000 per level p2-p5 + 819 for p6, distinct scores
         self.nms_in = []
-        for _ in range(n_img):
+        for gen in gens:
             per = (2000, 2000, 2000, 2000, 819)
             lv = torch.cat([torch.full((k,), i, dtype=torch.int64) for i, k in enumerate(per)])
             sz = torch.cat([torch.tensor([32.0, 64, 128, 256, 512])[i].repeat(k) for i, k in enumerate(per)])
@@ -116,24 +123,25 @@ class Workload:
             b = torch.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1)
             sc = torch.rand(n, generator=gen) + torch.arange(n) * 1e-9
             self.nms_in.append((b.to(dev), sc.to(dev), lv.to(dev)))
-        self.props = [make_boxes(gen, 1016, 16, 600).to(dev) for _ in range(n_img)]
-        # sampled ROIs: 512 / image (box head), 128 fg / image (mask head)
-        self.box_rois, self.mask_rois = [], []
-        rois_box = torch.cat([torch.cat([torch.full((512, 1), float(i)), make_boxes(gen, 512, 16, 600)], 1)
-                              for i in range(n_img)])
-        rois_mask = torch.cat([torch.cat([torch.full((128, 1), float(i)), make_boxes(gen, 128, 16, 600)], 1)
-                               for i in range(n_img)])
-        for rois, store in ((rois_box, self.box_rois), (rois_mask, self.mask_rois)):
-            lv = assign_levels(rois[:, 1:])
-            for l in range(4):
-                store.append(rois[lv == l].contiguous().to(dev))
-        self.box_ops = [ROIAlign((7, 7), 1.0 / s, 0, True) for s in STRIDES]
-        self.mask_ops = [ROIAlign((14, 14), 1.0 / s, 0, True) for s in STRIDES]
-        self.gbox = [torch.randn(r.shape[0], C, 7, 7, generator=gen).to(dtype).to(dev) for r in self.box_rois]
-        self.gmask = [torch.randn(r.shape[0], C, 14, 14, generator=gen).to(dtype).to(dev) for r in self.mask_rois]
-        if layout == "nhwc":
-            self.gbox = [g.contiguous(memory_format=torch.channels_last) for g in self.gbox]
-            self.gmask = [g.contiguous(memory_format=torch.channels_last) for g in self.gmask]
+        self.props = [make_boxes(g, 1016, 16, 600).to(dev) for g in gens]
+        # sampled ROIs: 512 / image (box head), 128 fg / image (mask head), as list[Boxes] per image
+        from detectron2_amd.modeling import ROIPooler
+        from detectron2_amd.structures import Boxes
+
+        box_b = [make_boxes(g, 512, 16, 600) for g in gens]
+        mask_b = [make_boxes(g, 128, 16, 600) for g in gens]
+        self.box_lists = [Boxes(b.to(dev)) for b in box_b]
+        self.mask_lists = [Boxes(b.to(dev)) for b in mask_b]
+        self.box_level_counts = [torch.bincount(assign_levels(torch.cat(bb)), minlength=4).tolist()
+                                 for bb in (box_b, mask_b)]
+        scales = [1.0 / s for s in STRIDES]
+        self.box_pooler = ROIPooler(7, scales, 0, "ROIAlignV2")
+        self.mask_pooler = ROIPooler(14, scales, 0, "ROIAlignV2")
+        mf = torch.channels_last if layout == "nhwc" else torch.contiguous_format
+        self.gbox = torch.cat([torch.randn(512, C, 7, 7, generator=g) for g in gens]).to(dtype).to(dev) \
+            .contiguous(memory_format=mf)
+        self.gmask = torch.cat([torch.randn(128, C, 14, 14, generator=g) for g in gens]).to(dtype).to(dev) \
+            .contiguous(memory_format=mf)
         self.esize = torch.empty((), dtype=dtype).element_size()
 
     # algorithmic (compulsory) bytes per op, SURVEY.md 8(d)
@@ -141,10 +149,11 @@ class Workload:
         s = self.esize
         feat = [self.n_img * C * h * w * s for (h, w) in FEAT_HW]
         d = {}
-        for name, rois, R in (("roi_align_box", self.box_rois, 7), ("roi_align_mask", self.mask_rois, 14)):
+        for name, counts, R in (("roi_align_box", self.box_level_counts[0], 7),
+                                ("roi_align_mask", self.box_level_counts[1], 14)):
             fwd = bwd = 0
             for l in range(4):
-                k = rois[l].shape[0]
+                k = counts[l]
                 if k == 0:
                     continue
                 fwd += feat[l] + 20 * k + s * k * C * R * R
@@ -190,11 +199,11 @@ def step(w, t=None):
         run("batched_nms_rpn", lambda: batched_nms(b, s, lv, 0.7))
         run("pairwise_iou_roi", lambda: pairwise_iou(w.gt[i], w.props[i]))
     outs = []
-    for name, ops, rois, grads in (("roi_align_box", w.box_ops, w.box_rois, w.gbox),
-                                   ("roi_align_mask", w.mask_ops, w.mask_rois, w.gmask)):
-        ys = run(name + "_fwd", lambda: [ops[l](w.feats[l], rois[l]) for l in range(4)])
-        run(name + "_bwd", lambda: torch.autograd.backward(ys, grads))
-        outs.append(ys)
+    for name, pooler, lists, grad in (("roi_align_box", w.box_pooler, w.box_lists, w.gbox),
+                                      ("roi_align_mask", w.mask_pooler, w.mask_lists, w.gmask)):
+        y = run(name + "_fwd", lambda: pooler(w.feats, lists))
+        run(name + "_bwd", lambda: torch.autograd.backward([y], [grad]))
+        outs.append(y)
     for f in w.feats:
         f.grad = None
     return outs
@@ -215,14 +224,19 @@ def cpu_baseline(w):
     t0 = time.perf_counter(); oracle.pairwise_iou(gt, w.props[0].cpu().numpy()); t_img += time.perf_counter() - t0
     t_batch = 0.0
     cs = 32
-    for rois, R in ((w.box_rois, 7), (w.mask_rois, 14)):
+    for lists, R in ((w.box_lists, 7), (w.mask_lists, 14)):
+        allb = torch.cat([b.tensor.cpu() for b in lists])
+        bidx = torch.cat([torch.full((len(b),), float(i)) for i, b in enumerate(lists)])
+        rois_all = torch.cat([bidx[:, None], allb], 1)
+        lv = assign_levels(allb)
         for l in range(4):
-            k = rois[l].shape[0]
+            rl = rois_all[lv == l]
+            k = rl.shape[0]
             if k == 0:
                 continue
             ks = min(16, k)
             x = w.feats[l].detach()[:, :cs].float().cpu().contiguous().numpy()
-            r = rois[l][:ks].cpu().numpy()
+            r = rl[:ks].contiguous().numpy()
             t0 = time.perf_counter()
             y = oracle.roi_align_forward(x, r, (R, R), 1.0 / STRIDES[l], 0, True)
             oracle.roi_align_backward(y, r, x.shape, 1.0 / STRIDES[l], 0, True)
@@ -251,27 +265,19 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     dtype = {"bf16": torch.bfloat16, "fp32": torch.float32, "fp16": torch.float16}[args.dtype]
-    w = Workload(dev, dtype, args.layout)
+    from detectron2_amd.sharding import Stopwatch, global_image_ids
+
+    # weak scaling: 2 images per GPU; rank r owns images [2r, 2r+1] of the global synthetic batch
+    w = Workload(dev, dtype, args.layout, image_ids=global_image_ids(IMAGES_PER_GPU, rank, world))
 
     for _ in range(args.warmup):
         step(w)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
+    sw = Stopwatch(dist, dev)
     timer = Timer()
-    t0 = time.perf_counter()
+    sw.start()
     for _ in range(args.steps):
         step(w, timer)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = sw.stop()
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3

@@ -30,6 +30,14 @@ class DcnParams(ctypes.Structure):
         "dil_w", "groups", "deformable_groups", "dtype")]
 
 
+class PoolerParams(ctypes.Structure):
+    _fields_ = ([(n, ctypes.c_int) for n in ("num_levels", "N", "C")] +
+                [("H", ctypes.c_int * 8), ("W", ctypes.c_int * 8), ("spatial_scale", ctypes.c_float * 8)] +
+                [(n, ctypes.c_int) for n in ("pooled_h", "pooled_w", "sampling_ratio", "aligned", "dtype", "layout",
+                                             "min_level", "max_level", "canonical_level")] +
+                [("canonical_box_size", ctypes.c_float)])
+
+
 _SIGNATURES = {
     "d2amd_version": (ctypes.c_char_p, []),
     "d2amd_compiler_version": (ctypes.c_char_p, []),
@@ -37,6 +45,9 @@ _SIGNATURES = {
     "d2amd_last_error": (ctypes.c_char_p, []),
     "d2amd_roi_align_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _vp]),
     "d2amd_roi_align_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "d2amd_roi_pooler_supported": (_i, [ctypes.POINTER(PoolerParams), _i]),
+    "d2amd_roi_pooler_forward": (_i, [ctypes.POINTER(PoolerParams), ctypes.POINTER(_vp), _vp, _vp, _i, _vp]),
+    "d2amd_roi_pooler_backward": (_i, [ctypes.POINTER(PoolerParams), _vp, _vp, ctypes.POINTER(_vp), _i, _vp]),
     "d2amd_roi_align_rotated_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp, _vp]),
     "d2amd_roi_align_rotated_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp, _sz, _vp]),
     "d2amd_pairwise_iou": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp]),

@@ -25,6 +25,7 @@ SOURCES = {
     "nms.hip": ["-ffp-contract=off"],
     "paste_masks.hip": ["-ffp-contract=off"],
     "roi_align.hip": [],
+    "roi_pool.hip": [],
     "deform_conv.hip": [],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall",

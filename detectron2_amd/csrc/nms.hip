@@ -201,12 +201,23 @@ __device__ __forceinline__ u64 bcast64(u64 v, int lane) {
   return ((u64)hi << 32) | lo;
 }
 
-__global__ __launch_bounds__(64) void nms_reduce_kernel(const u64* __restrict__ mask,
-                                                        const uint32_t* __restrict__ cls_s, int n, int wcap,
-                                                        int max_per_class, const int* __restrict__ seg_start,
-                                                        int* counters, u64* keepbits) {
+// One 512-thread workgroup (8 waves) per category segment.  The serial part -- resolving the
+// 64x64 diagonal block with a scalar chain -- runs on wave 0 only; the other waves exist to
+// keep the suppression rows of the NEXT blocks in flight: wave v owns rows 8v..8v+7 of every
+// 64-row block, lane = bitmask word, and a 4-deep register ring prefetches those rows three
+// blocks ahead so that the HBM/fabric latency (~1-2 us) never sits on the chain.  After the
+// chain, every wave ORs the rows that were kept into the LDS `removed` bitset (ds_or_b64).
+constexpr int RED_THREADS = 512;
+constexpr int RED_ROWS = 64 / (RED_THREADS / 64);  // suppression rows per thread and block
+constexpr int RED_DEPTH = 4;  // ring depth (blocks in flight, including the current one)
+
+__global__ __launch_bounds__(RED_THREADS) void nms_reduce_kernel(const u64* __restrict__ mask,
+                                                                 const uint32_t* __restrict__ cls_s, int n, int wcap,
+                                                                 int max_per_class, const int* __restrict__ seg_start,
+                                                                 int* counters, u64* keepbits) {
   extern __shared__ __attribute__((aligned(16))) u64 removed[];  // [wcap]
-  const int lane = threadIdx.x;
+  __shared__ u64 kept_s;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int nseg = cls_s ? counters[0] : 1;
   for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
     int s = cls_s ? seg_start[seg] : 0;
@@ -218,39 +229,77 @@ __global__ __launch_bounds__(64) void nms_reduce_kernel(const u64* __restrict__ 
       while (lo < hi) { int mid = (lo + hi) >> 1; if (cls_s[mid] <= c) lo = mid + 1; else hi = mid; }
       e = lo;
     }
-    if (e - s > max_per_class) { if (lane == 0) atomicOr(&counters[1], 1); continue; }
+    if (e - s > max_per_class) { if (tid == 0) atomicOr(&counters[1], 1); continue; }
     const int b0 = s >> 6, b1 = (e - 1) >> 6;
     const int nb = b1 - b0 + 1;  // <= wcap by construction
     __syncthreads();
-    for (int w = lane; w < nb; w += 64) removed[w] = 0;
+    for (int w = tid; w < nb; w += RED_THREADS) removed[w] = 0;
     __syncthreads();
-    for (int b = b0; b <= b1; b++) {
-      const int row = b * 64 + lane;
-      const bool valid = row >= s && row < e;
-      const u64 D = valid ? mask[(long)row * wcap] : 0ull;
-      const u64 validmask = __ballot(valid);
-      u64 rem = removed[b - b0] | ~validmask;
-      rem = ((u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(rem >> 32)) << 32) |
-          (u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rem);  // provably uniform -> SALU chain
+
+    // rows of block b owned by this thread: b*64 + RED_ROWS*wid + r, word 1 + lane (first 64 later words)
+    auto fetch_rows = [&](int b, u64 (&v)[RED_ROWS]) {
+      const bool in = b <= b1 && (1 + lane) <= (b1 - b);
 #pragma unroll
-      for (int i = 0; i < 64; i++) {
-        const u64 Di = bcast64(D, i);
-        rem |= ((rem >> i) & 1ull) ? 0ull : Di;
+      for (int r = 0; r < RED_ROWS; r++) {
+        const int row = b * 64 + RED_ROWS * wid + r;
+        v[r] = (in && row >= s && row < e) ? mask[(long)row * wcap + 1 + lane] : 0ull;
       }
-      const u64 kept = ~rem;
-      if (lane == 0 && kept) atomicOr(&keepbits[b], kept);
-      const int nlater = b1 - b;
-      for (int w = 1 + lane; w <= nlater; w += 64) {
-        u64 acc = 0;
-        u64 kk = kept;
-        while (kk) {
-          int i = __builtin_ctzll(kk);
-          kk &= kk - 1;
-          acc |= mask[((long)b * 64 + i) * wcap + w];
+    };
+    auto fetch_diag = [&](int b) -> u64 {
+      const int row = b * 64 + lane;
+      return (wid == 0 && b <= b1 && row >= s && row < e) ? mask[(long)row * wcap] : 0ull;
+    };
+
+    u64 ring[RED_DEPTH][RED_ROWS];
+    u64 dring[RED_DEPTH];
+#pragma unroll
+    for (int d = 0; d < RED_DEPTH - 1; d++) { fetch_rows(b0 + d, ring[d]); dring[d] = fetch_diag(b0 + d); }
+
+    for (int bq = b0; bq <= b1; bq += RED_DEPTH) {
+#pragma unroll
+      for (int u = 0; u < RED_DEPTH; u++) {
+        const int b = bq + u;
+        if (b > b1) break;  // uniform
+        fetch_rows(b + RED_DEPTH - 1, ring[(u + RED_DEPTH - 1) % RED_DEPTH]);
+        dring[(u + RED_DEPTH - 1) % RED_DEPTH] = fetch_diag(b + RED_DEPTH - 1);
+        if (wid == 0) {
+          const int row = b * 64 + lane;
+          const bool valid = row >= s && row < e;
+          const u64 D = dring[u];
+          const u64 validmask = __ballot(valid);
+          u64 rem = removed[b - b0] | ~validmask;
+          rem = ((u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(rem >> 32)) << 32) |
+              (u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rem);  // provably uniform -> SALU chain
+#pragma unroll
+          for (int i = 0; i < 64; i++) {
+            const u64 Di = bcast64(D, i);
+            rem |= ((rem >> i) & 1ull) ? 0ull : Di;
+          }
+          const u64 kept = ~rem;
+          if (lane == 0) {
+            kept_s = kept;
+            if (kept) atomicOr(&keepbits[b], kept);
+          }
         }
-        removed[b - b0 + w] |= acc;
+        __syncthreads();
+        const u64 kept = kept_s;
+        const int nlater = b1 - b;
+        {
+          u64 acc = 0;
+#pragma unroll
+          for (int r = 0; r < RED_ROWS; r++) acc |= ((kept >> (RED_ROWS * wid + r)) & 1ull) ? ring[u][r] : 0ull;
+          if (acc) atomicOr(&removed[b - b0 + 1 + lane], acc);  // acc != 0 implies 1 + lane <= nlater
+        }
+        // categories with more than 4096 boxes: remaining words, fetched after the chain
+        for (int w = 65 + lane; w <= nlater; w += 64) {
+          u64 acc = 0;
+#pragma unroll
+          for (int r = 0; r < RED_ROWS; r++)
+            if ((kept >> (RED_ROWS * wid + r)) & 1ull) acc |= mask[((long)b * 64 + RED_ROWS * wid + r) * wcap + w];
+          if (acc) atomicOr(&removed[b - b0 + w], acc);
+        }
+        __syncthreads();
       }
-      __syncthreads();
     }
   }
 }
@@ -363,8 +412,8 @@ extern "C" int d2amd_nms(const float* boxes, const float* scores, const int64_t*
     hipLaunchKernelGGL((nms_mask_kernel<false>), mgrid, dim3(64), 0, s, w.boxes_s, cls_s, N, wcap, iou_threshold,
                        w.mask);
   D2_LAUNCH_OK();
-  const int rgrid = idxs ? 1024 : 1;
-  hipLaunchKernelGGL(nms_reduce_kernel, dim3(rgrid), dim3(64), (size_t)wcap * 8, s, w.mask, cls_s, N, wcap, mpc,
+  const int rgrid = idxs ? 512 : 1;
+  hipLaunchKernelGGL(nms_reduce_kernel, dim3(rgrid), dim3(RED_THREADS), (size_t)wcap * 8, s, w.mask, cls_s, N, wcap, mpc,
                      w.seg_start, w.counters, w.keepbits);
   D2_LAUNCH_OK();
   hipLaunchKernelGGL(nms_scatter_flags_kernel, dim3(cdiv(N, T)), dim3(T), 0, s, w.keepbits, rankpos, N, w.flag_r);

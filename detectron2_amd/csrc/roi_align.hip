@@ -17,94 +17,9 @@
 //   * backward: the same per-bin separable weights scatter dY with fp32 atomics; 16-bit
 //     gradients accumulate in an fp32 workspace and are rounded once.
 // fp32 accumulation everywhere; rois are always fp32 (SURVEY 7 "bf16" policy).
-#include "common.h"
+#include "roi_common.h"
 
 namespace d2amd {
-
-// ------------------------------------------------------------------------------------------
-// per-ROI geometry
-struct RoiGeom {
-  int batch;
-  float start_w, start_h;   // axis-aligned: roi start; rotated: -w/2, -h/2 (relative to centre)
-  float bin_w, bin_h;
-  int grid_w, grid_h;
-  float center_w, center_h, cos_t, sin_t;  // rotated only
-  bool bad;                                 // rotated: negative size
-};
-
-template <bool ROT>
-__device__ __forceinline__ RoiGeom roi_geom(const float* __restrict__ rois, int k, float scale, int pooled_h,
-                                            int pooled_w, int sampling_ratio, int aligned) {
-  RoiGeom g;
-  g.bad = false;
-  float roi_w, roi_h;
-  if (!ROT) {
-    const float* r = rois + (long)k * 5;
-    g.batch = (int)r[0];
-    const float off = aligned ? 0.5f : 0.0f;
-    g.start_w = r[1] * scale - off;
-    g.start_h = r[2] * scale - off;
-    const float end_w = r[3] * scale - off, end_h = r[4] * scale - off;
-    roi_w = end_w - g.start_w;
-    roi_h = end_h - g.start_h;
-    if (!aligned) {  // legacy: force malformed ROIs to be 1x1
-      roi_w = fmaxf(roi_w, 1.f);
-      roi_h = fmaxf(roi_h, 1.f);
-    }
-    g.center_w = g.center_h = 0.f;
-    g.cos_t = 1.f;
-    g.sin_t = 0.f;
-  } else {
-    const float* r = rois + (long)k * 6;
-    g.batch = (int)r[0];
-    g.center_w = r[1] * scale - 0.5f;
-    g.center_h = r[2] * scale - 0.5f;
-    roi_w = r[3] * scale;
-    roi_h = r[4] * scale;
-    // ROIAlignRotated_cpu.cpp:232-234 with T=float: theta rounded to float, cos/sin in double
-    const float theta = (float)((double)r[5] * 3.14159265358979323846 / 180.0);
-    g.cos_t = (float)cos((double)theta);
-    g.sin_t = (float)sin((double)theta);
-    g.bad = !(roi_w >= 0.f && roi_h >= 0.f);
-    g.start_h = (float)(-(double)roi_h / 2.0);
-    g.start_w = (float)(-(double)roi_w / 2.0);
-  }
-  g.bin_h = roi_h / (float)pooled_h;
-  g.bin_w = roi_w / (float)pooled_w;
-  g.grid_h = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_h / (float)pooled_h);
-  g.grid_w = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_w / (float)pooled_w);
-  return g;
-}
-
-// one axis of the bilinear footprint (ROIAlignRotated_cpu.cpp:64-107 per axis)
-struct AxisTap {
-  int lo, hi;
-  float wlo, whi;  // weight of lo / hi pixel; 0 when the sample is outside [-1, size]
-  bool valid;
-};
-__device__ __forceinline__ AxisTap axis_tap(float y, int size) {
-  AxisTap t;
-  t.valid = !(y < -1.0f || y > (float)size);
-  if (y < 0.f) y = 0.f;
-  int lo = (int)y;
-  int hi;
-  if (lo >= size - 1) {
-    hi = lo = size - 1;
-    y = (float)lo;
-  } else {
-    hi = lo + 1;
-  }
-  const float l = y - (float)lo;
-  t.lo = lo; t.hi = hi;
-  t.whi = l; t.wlo = 1.f - l;
-  if (!t.valid) { t.lo = t.hi = 0; t.wlo = t.whi = 0.f; }
-  return t;
-}
-
-__device__ __forceinline__ float sample_pos(float start, int p, float bin, int i, int grid) {
-  // roi_start + ph*bin + (iy + .5f) * bin / grid   (same expression order as the reference)
-  return start + (float)p * bin + ((float)i + .5f) * bin / (float)grid;
-}
 
 // ------------------------------------------------------------------------------------------
 // DIRECT kernels (per-sample taps): rotated boxes, and the fallback when LDS tables overflow.
@@ -208,218 +123,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_direct_kernel(
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// SEPARABLE per-bin tables (axis-aligned).  For bin index t along one axis:
-//   first[t]  first pixel row/col touched, span[t] number of consecutive pixels, wt[t*SPAN + j].
-// Built by threads t < P of the workgroup; rows touched by the g samples of a bin are
-// consecutive because samples are <= 1 px apart when g = ceil(bin) (and for fixed g they are
-// inserted at lo-first offsets; span is bounded by SPAN = max offset + 1 and checked).
-struct AxisTables {
-  int* first;   // [P]
-  int* span;    // [P]
-  float* wt;    // [P * SPAN]
-};
-
-// returns false if some bin needs more than SPAN entries (caller falls back to direct kernel)
-__device__ __forceinline__ bool build_axis(int t, float start, float bin, int grid, int size, int SPAN, int* first,
-                                           int* span, float* wt) {
-  float* w = wt + t * SPAN;
-  for (int j = 0; j < SPAN; j++) w[j] = 0.f;
-  int f = 0x7fffffff, l = -1;
-  for (int i = 0; i < grid; i++) {
-    const AxisTap a = axis_tap(sample_pos(start, t, bin, i, grid), size);
-    if (!a.valid) continue;
-    f = min(f, a.lo);
-    l = max(l, a.hi);
-  }
-  if (l < 0) { first[t] = 0; span[t] = 0; return true; }
-  first[t] = f;
-  span[t] = l - f + 1;
-  if (l - f + 1 > SPAN) return false;
-  for (int i = 0; i < grid; i++) {
-    const AxisTap a = axis_tap(sample_pos(start, t, bin, i, grid), size);
-    if (!a.valid) continue;
-    w[a.lo - f] += a.wlo;
-    w[a.hi - f] += a.whi;
-  }
-  return true;
-}
-
-constexpr int SEP_SPAN = 12;   // table entries per bin and axis (covers g <= 10 with g = ceil(bin))
-constexpr int SEP_MAXP = 32;   // max pooled size per axis on the fast path
-
-struct SepShared {
-  int firsty[SEP_MAXP], spany[SEP_MAXP], firstx[SEP_MAXP], spanx[SEP_MAXP];
-  float wy[SEP_MAXP * SEP_SPAN], wx[SEP_MAXP * SEP_SPAN];
-  int ok;
-  int batch;
-  float inv_count;
-};
-
-template <bool BWD>
-__device__ __forceinline__ void sep_build(SepShared& S, const float* rois, int k, float scale, int PH, int PW,
-                                          int sampling_ratio, int aligned, int H, int W) {
-  if (threadIdx.x == 0) S.ok = 1;
-  __syncthreads();
-  const RoiGeom g = roi_geom<false>(rois, k, scale, PH, PW, sampling_ratio, aligned);
-  const int t = threadIdx.x;
-  bool ok = true;
-  if (t < PH) ok = build_axis(t, g.start_h, g.bin_h, g.grid_h, H, SEP_SPAN, S.firsty, S.spany, S.wy);
-  else if (t < PH + PW) ok = build_axis(t - PH, g.start_w, g.bin_w, g.grid_w, W, SEP_SPAN, S.firstx, S.spanx, S.wx);
-  if (!ok) S.ok = 0;
-  if (t == 0) {
-    S.batch = g.batch;
-    const int cnt = g.grid_h * g.grid_w;
-    S.inv_count = 1.f / (float)(cnt > 0 ? cnt : 1);
-  }
-  __syncthreads();
-}
-
-// Inline fallback for one (ROI, channel range) when the separable tables overflow (very large
-// bins with a fixed sampling_ratio): direct per-sample taps, executed by the same workgroup.
-template <typename T, bool NHWC_>
-__device__ void fwd_direct_range(const T* __restrict__ in, const float* __restrict__ rois, T* __restrict__ out,
-                                 int k, int c0, int nc, int C, int H, int W, int PH, int PW, float scale,
-                                 int sampling_ratio, int aligned) {
-  const RoiGeom g = roi_geom<false>(rois, k, scale, PH, PW, sampling_ratio, aligned);
-  const float count = (float)max(g.grid_h * g.grid_w, 1);
-  const long plane = (long)H * W;
-  const int bins = PH * PW;
-  for (int e = threadIdx.x; e < nc * bins; e += blockDim.x) {
-    int c, b;
-    if (NHWC_) { b = e / nc; c = c0 + (e - b * nc); } else { c = c0 + e / bins; b = e % bins; }
-    const int ph = b / PW, pw = b - ph * PW;
-    const T* base = NHWC_ ? in + (long)g.batch * plane * C + c : in + ((long)g.batch * C + c) * plane;
-    const long pstride = NHWC_ ? C : 1;
-    float acc = 0.f;
-    for (int iy = 0; iy < g.grid_h; iy++) {
-      const AxisTap ty = axis_tap(sample_pos(g.start_h, ph, g.bin_h, iy, g.grid_h), H);
-      for (int ix = 0; ix < g.grid_w; ix++) {
-        const AxisTap tx = axis_tap(sample_pos(g.start_w, pw, g.bin_w, ix, g.grid_w), W);
-        acc += (ty.wlo * tx.wlo) * to_f32(base[((long)ty.lo * W + tx.lo) * pstride]) +
-            (ty.wlo * tx.whi) * to_f32(base[((long)ty.lo * W + tx.hi) * pstride]) +
-            (ty.whi * tx.wlo) * to_f32(base[((long)ty.hi * W + tx.lo) * pstride]) +
-            (ty.whi * tx.whi) * to_f32(base[((long)ty.hi * W + tx.hi) * pstride]);
-      }
-    }
-    const long o = NHWC_ ? ((long)k * bins + b) * C + c : ((long)k * C + c) * bins + b;
-    out[o] = from_f32<T>(acc / count);
-  }
-}
-
-template <typename T, bool NHWC_>
-__device__ void bwd_direct_range(const T* __restrict__ gout, const float* __restrict__ rois,
-                                 float* __restrict__ gin, int k, int c0, int nc, int C, int H, int W, int PH,
-                                 int PW, float scale, int sampling_ratio, int aligned) {
-  const RoiGeom g = roi_geom<false>(rois, k, scale, PH, PW, sampling_ratio, aligned);
-  const float count = (float)(g.grid_h * g.grid_w);
-  const long plane = (long)H * W;
-  const int bins = PH * PW;
-  for (int e = threadIdx.x; e < nc * bins; e += blockDim.x) {
-    int c, b;
-    if (NHWC_) { b = e / nc; c = c0 + (e - b * nc); } else { c = c0 + e / bins; b = e % bins; }
-    const int ph = b / PW, pw = b - ph * PW;
-    const long o = NHWC_ ? ((long)k * bins + b) * C + c : ((long)k * C + c) * bins + b;
-    const float go = to_f32(gout[o]);
-    float* base = NHWC_ ? gin + (long)g.batch * plane * C + c : gin + ((long)g.batch * C + c) * plane;
-    const long pstride = NHWC_ ? C : 1;
-    for (int iy = 0; iy < g.grid_h; iy++) {
-      const AxisTap ty = axis_tap(sample_pos(g.start_h, ph, g.bin_h, iy, g.grid_h), H);
-      for (int ix = 0; ix < g.grid_w; ix++) {
-        const AxisTap tx = axis_tap(sample_pos(g.start_w, pw, g.bin_w, ix, g.grid_w), W);
-        if (!(ty.valid && tx.valid)) continue;
-        atomicAdd(base + ((long)ty.lo * W + tx.lo) * pstride, go * (ty.wlo * tx.wlo) / count);
-        atomicAdd(base + ((long)ty.lo * W + tx.hi) * pstride, go * (ty.wlo * tx.whi) / count);
-        atomicAdd(base + ((long)ty.hi * W + tx.lo) * pstride, go * (ty.whi * tx.wlo) / count);
-        atomicAdd(base + ((long)ty.hi * W + tx.hi) * pstride, go * (ty.whi * tx.whi) / count);
-      }
-    }
-  }
-}
-
-// ---- NCHW forward: grid = (K, channel slabs); thread = one (c, ph, pw) of the slab -------------
 constexpr int SEP_THREADS = 256;
-
-template <typename T>
-__global__ __launch_bounds__(SEP_THREADS) void roi_align_fwd_sep_nchw_kernel(
-    const T* __restrict__ in, const float* __restrict__ rois, T* __restrict__ out, int C, int H, int W, int PH,
-    int PW, float scale, int sampling_ratio, int aligned, int cslab) {
-  __shared__ SepShared S;
-  const int k = blockIdx.x;
-  sep_build<false>(S, rois, k, scale, PH, PW, sampling_ratio, aligned, H, W);
-  const int c0 = blockIdx.y * cslab;
-  const int nc = min(cslab, C - c0);
-  if (!S.ok) {
-    fwd_direct_range<T, false>(in, rois, out, k, c0, nc, C, H, W, PH, PW, scale, sampling_ratio, aligned);
-    return;
-  }
-  const int bins = PH * PW;
-  const long plane = (long)H * W;
-  const T* inb = in + ((long)S.batch * C + c0) * plane;
-  T* outb = out + ((long)k * C + c0) * bins;
-  const float inv = S.inv_count;
-  for (int e = threadIdx.x; e < nc * bins; e += SEP_THREADS) {
-    const int c = e / bins, b = e - c * bins;
-    const int ph = b / PW, pw = b - ph * PW;
-    const T* p = inb + (long)c * plane;
-    const int fy = S.firsty[ph], sy = S.spany[ph], fx = S.firstx[pw], sx = S.spanx[pw];
-    const float* wy = S.wy + ph * SEP_SPAN;
-    const float* wx = S.wx + pw * SEP_SPAN;
-    float acc = 0.f;
-    for (int j = 0; j < sy; j++) {
-      const T* row = p + (long)(fy + j) * W + fx;
-      float racc = 0.f;
-      for (int i = 0; i < sx; i++) racc += wx[i] * to_f32(row[i]);
-      acc += wy[j] * racc;
-    }
-    outb[e] = from_f32<T>(acc * inv);
-  }
-}
-
-// ---- NHWC forward: grid = K; lanes = channel quads; waves stride over bins -----------------------
-template <typename T>
-__global__ __launch_bounds__(SEP_THREADS) void roi_align_fwd_sep_nhwc_kernel(
-    const T* __restrict__ in, const float* __restrict__ rois, T* __restrict__ out, int C, int H, int W, int PH,
-    int PW, float scale, int sampling_ratio, int aligned) {
-  __shared__ SepShared S;
-  const int k = blockIdx.x;
-  sep_build<false>(S, rois, k, scale, PH, PW, sampling_ratio, aligned, H, W);
-  if (!S.ok) {
-    fwd_direct_range<T, true>(in, rois, out, k, 0, C, C, H, W, PH, PW, scale, sampling_ratio, aligned);
-    return;
-  }
-  const int bins = PH * PW;
-  const int cq = C >> 2;                    // channel quads (C % 4 == 0 on this path)
-  const T* inb = in + (long)S.batch * H * W * C;
-  T* outb = out + (long)k * bins * C;
-  const float inv = S.inv_count;
-  // work item = (bin, quad); consecutive threads take consecutive quads of the same bin
-  for (int e = threadIdx.x; e < bins * cq; e += SEP_THREADS) {
-    const int b = e / cq, q = e - b * cq;
-    const int ph = b / PW, pw = b - ph * PW;
-    const int fy = S.firsty[ph], sy = S.spany[ph], fx = S.firstx[pw], sx = S.spanx[pw];
-    const float* wy = S.wy + ph * SEP_SPAN;
-    const float* wx = S.wx + pw * SEP_SPAN;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int j = 0; j < sy; j++) {
-      const vec4<T>* row = reinterpret_cast<const vec4<T>*>(inb + ((long)(fy + j) * W + fx) * C) + q;
-      const float wyj = wy[j];
-      for (int i = 0; i < sx; i++) {
-        const vec4<T> v = row[(long)i * cq];
-        float f[4];
-        unpack4(v, f);
-        const float w = wyj * wx[i];
-#pragma unroll
-        for (int u = 0; u < 4; u++) acc[u] += w * f[u];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++) acc[u] *= inv;
-    vec4<T> o;
-    pack4(acc, o);
-    reinterpret_cast<vec4<T>*>(outb + (long)b * C)[q] = o;
-  }
-}
 
 // ---- separable backward (fp32 atomics), both layouts ---------------------------------------------
 template <typename T, bool NHWC_>
@@ -498,22 +202,13 @@ static int fwd_impl(const void* input, const float* rois, void* output, int N, i
     D2_LAUNCH_OK();
     return D2AMD_OK;
   }
-  const bool sep_ok = PH <= SEP_MAXP && PW <= SEP_MAXP && K <= 0x7fffffff;
-  if (!sep_ok || (nhwc && (C % 4 != 0))) {
-    if (nhwc)
-      hipLaunchKernelGGL((roi_align_fwd_direct_kernel<T, false, true>), dim3(gsz), dim3(256), 0, s, in, rois, out,
-                         C, H, W, K, PH, PW, scale, sr, aligned, nullptr);
-    else
-      hipLaunchKernelGGL((roi_align_fwd_direct_kernel<T, false, false>), dim3(gsz), dim3(256), 0, s, in, rois, out,
-                         C, H, W, K, PH, PW, scale, sr, aligned, nullptr);
-  } else if (nhwc) {
-    hipLaunchKernelGGL((roi_align_fwd_sep_nhwc_kernel<T>), dim3(K), dim3(SEP_THREADS), 0, s, in, rois, out, C, H,
-                       W, PH, PW, scale, sr, aligned);
-  } else {
-    const int cslab = pick_cslab(C, K);
-    hipLaunchKernelGGL((roi_align_fwd_sep_nchw_kernel<T>), dim3(K, cdiv(C, cslab)), dim3(SEP_THREADS), 0, s, in,
-                       rois, out, C, H, W, PH, PW, scale, sr, aligned, cslab);
-  }
+  // axis-aligned with pooled size > SEP_MAXP (the fused kernels of roi_pool.hip serve the rest)
+  if (nhwc)
+    hipLaunchKernelGGL((roi_align_fwd_direct_kernel<T, false, true>), dim3(gsz), dim3(256), 0, s, in, rois, out, C, H,
+                       W, K, PH, PW, scale, sr, aligned, nullptr);
+  else
+    hipLaunchKernelGGL((roi_align_fwd_direct_kernel<T, false, false>), dim3(gsz), dim3(256), 0, s, in, rois, out, C,
+                       H, W, K, PH, PW, scale, sr, aligned, nullptr);
   D2_LAUNCH_OK();
   return D2AMD_OK;
 }
@@ -567,6 +262,15 @@ static int check_common(const char* who, int N, int C, int H, int W, int K, int 
   return D2AMD_OK;
 }
 
+static d2amd_pooler_params single_level(int N, int C, int H, int W, int ph, int pw, float scale, int sr, int aligned,
+                                        int dtype, int layout) {
+  d2amd_pooler_params p{};
+  p.num_levels = 1; p.N = N; p.C = C; p.H[0] = H; p.W[0] = W; p.spatial_scale[0] = scale;
+  p.pooled_h = ph; p.pooled_w = pw; p.sampling_ratio = sr; p.aligned = aligned; p.dtype = dtype; p.layout = layout;
+  p.min_level = p.max_level = p.canonical_level = 0; p.canonical_box_size = 1.f;
+  return p;
+}
+
 }  // namespace d2amd
 
 using namespace d2amd;
@@ -578,6 +282,12 @@ extern "C" int d2amd_roi_align_forward(const void* input, const float* rois, voi
   if (rc) return rc;
   if ((long)K * C == 0) return D2AMD_OK;
   D2_CHECK_ARG(input && rois && output, "roi_align_forward: null pointer");
+  if (pooled_h <= SEP_MAXP && pooled_w <= SEP_MAXP) {  // single-level case of the fused pooler
+    const d2amd_pooler_params p = single_level(N, C, H, W, pooled_h, pooled_w, spatial_scale, sampling_ratio, aligned,
+                                               dtype, layout);
+    const void* lv[1] = {input};
+    return d2amd_roi_pooler_forward(&p, lv, rois, output, K, stream);
+  }
   return D2_DISPATCH_DTYPE(dtype, [&]() -> int {
     return fwd_impl<scalar_t>(input, rois, output, N, C, H, W, K, pooled_h, pooled_w, spatial_scale, sampling_ratio,
                               aligned, layout, false, nullptr, (hipStream_t)stream);
@@ -592,6 +302,12 @@ extern "C" int d2amd_roi_align_backward(const void* grad_output, const float* ro
   if (rc) return rc;
   if ((long)N * C * H * W == 0) return D2AMD_OK;
   D2_CHECK_ARG(grad_input && (K == 0 || (grad_output && rois)), "roi_align_backward: null pointer");
+  if (layout == D2AMD_NHWC && pooled_h <= SEP_MAXP && pooled_w <= SEP_MAXP) {  // atomic-free tile gather
+    const d2amd_pooler_params p = single_level(N, C, H, W, pooled_h, pooled_w, spatial_scale, sampling_ratio, aligned,
+                                               dtype, layout);
+    void* lv[1] = {grad_input};
+    return d2amd_roi_pooler_backward(&p, grad_output, rois, lv, K, stream);
+  }
   return D2_DISPATCH_DTYPE(dtype, [&]() -> int {
     return bwd_impl<scalar_t>(grad_output, rois, grad_input, N, C, H, W, K, pooled_h, pooled_w, spatial_scale,
                               sampling_ratio, aligned, layout, false, workspace, workspace_bytes, (hipStream_t)stream);

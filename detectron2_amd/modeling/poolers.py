@@ -1,0 +1,212 @@
+"""ROIPooler -- mirrors detectron2/modeling/poolers.py:23-263 (same constructor, same
+`forward(x: list[Tensor], box_lists: list[Boxes])`, same level-assignment rule), but the multi-level
+case is ONE fused HIP launch per direction (d2amd_roi_pooler_forward / _backward) instead of the
+reference's per-level `nonzero` (host sync) -> ROIAlign -> `index_put_` loop:
+
+  * level assignment runs inside the kernel, in fp32, operation for operation as
+    `assign_boxes_to_levels` (poolers.py:51-59);
+  * channels_last (NHWC) features: forward = flattened-tap gather, backward = atomic-free,
+    deterministic tile gather that writes every grad element once in the I/O dtype;
+  * NCHW features: fused forward; backward falls back to the reference's per-level structure on
+    the v0 atomic kernels (roi_align.hip).
+`pooler_type` "ROIAlignRotated" keeps the per-level loop; "ROIPool" is not part of the hot path.
+"""
+import ctypes
+import math
+from typing import List
+
+import torch
+from torch import nn
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from .. import _C
+from ..layers.roi_align import ROIAlign, _layout_of
+from ..layers.roi_align_rotated import ROIAlignRotated
+from ..layers.wrappers import disable_torch_compiler
+
+__all__ = ["ROIPooler", "assign_boxes_to_levels", "convert_boxes_to_pooler_format"]
+
+
+def _areas(box_lists):
+    return torch.cat([b.area() if hasattr(b, "area") else (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+                      for b in box_lists])
+
+
+def assign_boxes_to_levels(box_lists, min_level: int, max_level: int, canonical_box_size: int,
+                           canonical_level: int):
+    """Same contract as poolers.py:23-59: int64 level offsets (from `min_level`) of all boxes."""
+    box_sizes = torch.sqrt(_areas(box_lists))
+    level_assignments = torch.floor(canonical_level + torch.log2(box_sizes / canonical_box_size + 1e-8))
+    level_assignments = torch.clamp(level_assignments, min=min_level, max=max_level)
+    return level_assignments.to(torch.int64) - min_level
+
+
+def convert_boxes_to_pooler_format(box_lists):
+    """(M, 5) [batch index, x0, y0, x1, y1] (or (M, 6) for rotated boxes), poolers.py:74-104."""
+    tensors = [b.tensor if hasattr(b, "tensor") else b for b in box_lists]
+    boxes = torch.cat(tensors, dim=0)
+    sizes = torch.tensor([len(t) for t in tensors], device=boxes.device)
+    indices = torch.repeat_interleave(torch.arange(len(sizes), dtype=boxes.dtype, device=boxes.device), sizes)
+    return torch.cat([indices[:, None], boxes], dim=1)
+
+
+def _params(cfg, feats_shape, hw, dtype_code, layout):
+    out_hw, scales, sr, aligned, min_level, max_level, canon_size, canon_level = cfg
+    p = _C.PoolerParams()
+    p.num_levels = len(scales)
+    p.N, p.C = feats_shape
+    for l, ((h, w), s) in enumerate(zip(hw, scales)):
+        p.H[l], p.W[l], p.spatial_scale[l] = h, w, s
+    p.pooled_h, p.pooled_w = out_hw
+    p.sampling_ratio, p.aligned = sr, int(aligned)
+    p.dtype, p.layout = dtype_code, layout
+    p.min_level, p.max_level, p.canonical_level = min_level, max_level, canon_level
+    p.canonical_box_size = float(canon_size)
+    return p
+
+
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+class _FusedROIPool(Function):
+    @staticmethod
+    @disable_torch_compiler
+    def forward(ctx, rois, cfg, *feats):
+        _C.require_gpu(rois, *feats, op="ROIPooler")
+        layout = _layout_of(feats[0])
+        xs = [f if layout == _C.NHWC else f.contiguous() for f in feats]
+        n, c = xs[0].shape[:2]
+        hw = [tuple(x.shape[2:]) for x in xs]
+        k = rois.shape[0]
+        p = _params(cfg, (n, c), hw, _C.dtype_code(xs[0]), layout)
+        ph, pw = cfg[0]
+        mf = torch.channels_last if layout == _C.NHWC else torch.contiguous_format
+        out = torch.empty((k, c, ph, pw), dtype=xs[0].dtype, device=xs[0].device, memory_format=mf)
+        with torch.cuda.device(xs[0].device):
+            _C.check(_C.lib().d2amd_roi_pooler_forward(ctypes.byref(p), _ptr_array(xs), _C.ptr(rois), _C.ptr(out), k,
+                                                       _C.stream()))
+        ctx.save_for_backward(rois)
+        ctx.cfg, ctx.hw, ctx.nc, ctx.layout = cfg, hw, (n, c), layout
+        ctx.needs = [f.requires_grad for f in feats]
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        (rois,) = ctx.saved_tensors
+        cfg, hw, (n, c), layout = ctx.cfg, ctx.hw, ctx.nc, ctx.layout
+        k = rois.shape[0]
+        if layout == _C.NHWC:
+            g = grad_output.contiguous(memory_format=torch.channels_last)
+            grads = [torch.empty((n, c, h, w), dtype=g.dtype, device=g.device, memory_format=torch.channels_last)
+                     for (h, w) in hw]
+            p = _params(cfg, (n, c), hw, _C.dtype_code(g), layout)
+            with torch.cuda.device(g.device):
+                _C.check(_C.lib().d2amd_roi_pooler_backward(ctypes.byref(p), _C.ptr(g), _C.ptr(rois),
+                                                            _ptr_array(grads), k, _C.stream()))
+        else:
+            # NCHW: the reference's per-level structure on the atomic kernels
+            out_hw, scales, sr, aligned, min_level, max_level, canon_size, canon_level = cfg
+            g = grad_output.contiguous()
+            if len(scales) > 1:
+                levels = assign_boxes_to_levels([rois[:, 1:]], min_level, max_level, canon_size, canon_level)
+            else:
+                levels = torch.zeros(k, dtype=torch.int64, device=g.device)
+            grads = []
+            for l, ((h, w), s) in enumerate(zip(hw, scales)):
+                inds = torch.nonzero(levels == l, as_tuple=True)[0]
+                gl, rl = g.index_select(0, inds), rois.index_select(0, inds)
+                gin = torch.empty((n, c, h, w), dtype=g.dtype, device=g.device)
+                ws, ws_bytes = None, 0
+                if g.dtype != torch.float32:
+                    ws = torch.empty(gin.numel(), dtype=torch.float32, device=g.device)
+                    ws_bytes = ws.numel() * 4
+                with torch.cuda.device(g.device):
+                    _C.check(_C.lib().d2amd_roi_align_backward(
+                        _C.ptr(gl), _C.ptr(rl), _C.ptr(gin), n, c, h, w, rl.shape[0], out_hw[0], out_hw[1], float(s),
+                        int(sr), int(aligned), _C.dtype_code(g), _C.NCHW, _C.ptr(ws), ws_bytes, _C.stream()))
+                grads.append(gin)
+        return (None, None) + tuple(gr if need else None for gr, need in zip(grads, ctx.needs))
+
+
+class ROIPooler(nn.Module):
+    """Region of interest feature map pooler over one or more feature maps (poolers.py:114-263)."""
+
+    def __init__(self, output_size, scales, sampling_ratio, pooler_type, canonical_box_size=224,
+                 canonical_level=4):
+        super().__init__()
+        if isinstance(output_size, int):
+            output_size = (output_size, output_size)
+        assert len(output_size) == 2
+        assert isinstance(output_size[0], int) and isinstance(output_size[1], int)
+        self.output_size = output_size
+        self.pooler_type = pooler_type
+        self.sampling_ratio = sampling_ratio
+        self.scales = [float(s) for s in scales]
+        if pooler_type in ("ROIAlign", "ROIAlignV2"):
+            aligned = pooler_type == "ROIAlignV2"
+            self.level_poolers = nn.ModuleList(
+                ROIAlign(output_size, spatial_scale=s, sampling_ratio=sampling_ratio, aligned=aligned)
+                for s in scales)
+        elif pooler_type == "ROIAlignRotated":
+            self.level_poolers = nn.ModuleList(
+                ROIAlignRotated(output_size, spatial_scale=s, sampling_ratio=sampling_ratio) for s in scales)
+        elif pooler_type == "ROIPool":
+            raise ValueError("ROIPool (torchvision.ops.RoIPool) is outside the MI355X hot path; use ROIAlignV2")
+        else:
+            raise ValueError("Unknown pooler type: {}".format(pooler_type))
+        # strides must be powers of two forming a pyramid (poolers.py:187-201)
+        min_level = -(math.log2(scales[0]))
+        max_level = -(math.log2(scales[-1]))
+        assert math.isclose(min_level, int(min_level)) and math.isclose(max_level, int(max_level)), \
+            "Featuremap stride is not power of 2!"
+        self.min_level = int(min_level)
+        self.max_level = int(max_level)
+        assert len(scales) == self.max_level - self.min_level + 1, \
+            "[ROIPooler] Sizes of input featuremaps do not form a pyramid!"
+        assert 0 <= self.min_level and self.min_level <= self.max_level
+        self.canonical_level = canonical_level
+        assert canonical_box_size > 0
+        self.canonical_box_size = canonical_box_size
+
+    def _fusable(self, x):
+        if self.pooler_type not in ("ROIAlign", "ROIAlignV2") or len(x) > 8:
+            return False
+        if max(self.output_size) > 32 or not all(t.is_cuda for t in x):
+            return False
+        lay, dt = _layout_of(x[0]), x[0].dtype
+        return all(_layout_of(t) == lay and t.dtype == dt and t.shape[:2] == x[0].shape[:2] for t in x)
+
+    def forward(self, x: List[torch.Tensor], box_lists):
+        """x: list of NCHW feature maps (scales as constructed); box_lists: N Boxes / RotatedBoxes (image
+        coordinates).  Returns (M, C, output_size, output_size), M = total number of boxes."""
+        num_level_assignments = len(self.level_poolers)
+        assert isinstance(x, list) and isinstance(box_lists, list), "Arguments to pooler must be lists"
+        assert len(x) == num_level_assignments, \
+            "unequal value, num_level_assignments={}, but x is list of {} Tensors".format(num_level_assignments, len(x))
+        assert len(box_lists) == x[0].size(0), \
+            "unequal value, x[0] batch dim 0 is {}, but box_list has length {}".format(x[0].size(0), len(box_lists))
+        if len(box_lists) == 0:
+            return torch.zeros((0, x[0].shape[1]) + tuple(self.output_size), dtype=x[0].dtype, device=x[0].device)
+        pooler_fmt_boxes = convert_boxes_to_pooler_format(box_lists)
+        if self._fusable(x):
+            cfg = (tuple(self.output_size), tuple(self.scales), int(self.sampling_ratio),
+                   self.pooler_type == "ROIAlignV2", self.min_level, self.max_level, self.canonical_box_size,
+                   self.canonical_level)
+            return _FusedROIPool.apply(pooler_fmt_boxes.detach().float().contiguous(), cfg, *x)
+        if num_level_assignments == 1:
+            return self.level_poolers[0](x[0], pooler_fmt_boxes)
+        # reference structure (poolers.py:247-263)
+        level_assignments = assign_boxes_to_levels(box_lists, self.min_level, self.max_level,
+                                                   self.canonical_box_size, self.canonical_level)
+        output = torch.zeros((pooler_fmt_boxes.shape[0], x[0].shape[1], self.output_size[0], self.output_size[0]),
+                             dtype=x[0].dtype, device=x[0].device)
+        for level, pooler in enumerate(self.level_poolers):
+            inds = torch.nonzero(level_assignments == level, as_tuple=True)[0]
+            output.index_put_((inds,), pooler(x[level], pooler_fmt_boxes[inds]))
+        return output

@@ -60,6 +60,33 @@ int d2amd_roi_align_backward(const void* grad_output, const float* rois, void* g
                              float spatial_scale, int sampling_ratio, int aligned, int dtype,
                              int layout, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- fused multi-level ROI pooler.  Replaces ROIPooler.forward
+ * (detectron2/modeling/poolers.py:206-263: assign_boxes_to_levels -> per-level nonzero /
+ * ROIAlign / index_put_) and its autograd backward with ONE launch per direction.
+ * Level of a box = clamp(floor(canonical_level + log2(sqrt(area)/canonical_box_size + 1e-8)),
+ * min_level, max_level) - min_level, evaluated in fp32 exactly like poolers.py:51-59 (ignored
+ * when num_levels == 1).  rois [K,5] fp32 (batch index, x1, y1, x2, y2) in image coordinates;
+ * inputs[l] is [N,C,H[l],W[l]] in `dtype`/`layout`; output [K,C,pooled_h,pooled_w], same layout
+ * convention.  `inputs` / `grad_inputs` are HOST arrays of num_levels device pointers.
+ * Backward (NHWC only) overwrites every element of every grad_inputs[l]; it uses no atomics and
+ * no workspace and is deterministic.  d2amd_roi_pooler_supported tells whether the fused
+ * kernels serve a configuration (pooled size <= 32; backward: NHWC); otherwise loop over the
+ * levels with d2amd_roi_align_forward/backward as the reference does. */
+#define D2AMD_POOLER_MAX_LEVELS 8
+typedef struct d2amd_pooler_params {
+  int num_levels, N, C;
+  int H[D2AMD_POOLER_MAX_LEVELS], W[D2AMD_POOLER_MAX_LEVELS];
+  float spatial_scale[D2AMD_POOLER_MAX_LEVELS];
+  int pooled_h, pooled_w, sampling_ratio, aligned, dtype, layout;
+  int min_level, max_level, canonical_level;
+  float canonical_box_size;
+} d2amd_pooler_params;
+int d2amd_roi_pooler_supported(const d2amd_pooler_params* p, int backward);
+int d2amd_roi_pooler_forward(const d2amd_pooler_params* p, const void* const* inputs, const float* rois,
+                             void* output, int K, void* stream);
+int d2amd_roi_pooler_backward(const d2amd_pooler_params* p, const void* grad_output, const float* rois,
+                              void* const* grad_inputs, int K, void* stream);
+
 /* ---- ROIAlignRotated.  Replaces torch.ops.detectron2.roi_align_rotated_forward/backward
  * (vision.cpp:118-119; csrc/ROIAlignRotated/ROIAlignRotated.h:50-113).
  * rois [K,6] fp32 (b, cx, cy, w, h, angle_degrees).  Negative w/h is reported through

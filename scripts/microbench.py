@@ -1,17 +1,26 @@
 """Per-op GPU time in isolation: each op is launched REP times back-to-back between two HIP events
-(no host sync in between), so launch gaps overlap and the figure is device time per call."""
+(no host sync in between), so launch gaps overlap and the figure is device time per call.
+Covers every op of SURVEY.md 8(a) at the 8(d) micro-benchmark shapes.
+
+    python scripts/microbench.py [nhwc|nchw] [--quick]
+"""
 import json
-import sys
+import math
 import os
+import sys
+
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
+from detectron2_amd.layers import (ModulatedDeformConv, DeformConv, batched_nms, nms, paste_masks_in_image,
+                                   pairwise_iou_rotated, nms_rotated)
 from detectron2_amd.structures import pairwise_iou
-from detectron2_amd.layers import paste_masks_in_image
+
+HBM, MFMA_BF16 = 8000.0, 2500.0  # GB/s, TFLOP/s (MI355X_MICROARCH.md)
 
 
-def timeit(fn, rep=30, warm=3):
+def timeit(fn, rep=20, warm=3):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -24,29 +33,78 @@ def timeit(fn, rep=30, warm=3):
     return a.elapsed_time(b) / rep
 
 
+def nms_inputs(gen, n, ncls, dev):
+    s = torch.exp(torch.empty(n).uniform_(math.log(8), math.log(400), generator=gen))
+    ar = torch.exp(torch.empty(n).uniform_(math.log(0.5), math.log(2.0), generator=gen))
+    w, h = s * ar.sqrt(), s / ar.sqrt()
+    cx = torch.empty(n).uniform_(0, 1344, generator=gen)
+    cy = torch.empty(n).uniform_(0, 800, generator=gen)
+    b = torch.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1)
+    sc = torch.rand(n, generator=gen) + torch.arange(n) * 1e-9
+    idx = torch.randint(0, ncls, (n,), generator=gen)
+    return b.to(dev), sc.to(dev), idx.to(dev)
+
+
 def main():
-    layout = sys.argv[1] if len(sys.argv) > 1 else "nhwc"
+    layout = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "nhwc"
+    quick = "--quick" in sys.argv
     dev = torch.device("cuda", 0)
     w = bench.Workload(dev, torch.bfloat16, layout)
     alg = w.alg_bytes()
-    res = {}
-    res["pairwise_iou_rpn(1 img)"] = timeit(lambda: pairwise_iou(w.gt[0], w.anchors))
-    for name, ops, rois, grads in (("box", w.box_ops, w.box_rois, w.gbox), ("mask", w.mask_ops, w.mask_rois, w.gmask)):
-        for l in range(4):
-            k = rois[l].shape[0]
-            x = w.feats[l].detach()
-            res[f"roi_fwd_{name}_p{l+2}(K={k})"] = timeit(lambda: ops[l](x, rois[l]))
-            xg = w.feats[l]
-            y = ops[l](xg, rois[l])
-            res[f"roi_bwd_{name}_p{l+2}(K={k})"] = timeit(
-                lambda: torch.autograd.grad(y, xg, grads[l], retain_graph=True))
+    res, extra = {}, {}
+
+    def rec(name, ms, bytes_=None, flops=None):
+        res[name] = round(ms, 4)
+        if bytes_:
+            extra[name] = {"alg_MB": round(bytes_ / 1e6, 2), "GBps": round(bytes_ / 1e6 / ms, 1),
+                           "frac_hbm": round(bytes_ / 1e6 / ms / HBM, 4)}
+        if flops:
+            extra[name] = {"GFLOP": round(flops / 1e9, 2), "TFLOPs": round(flops / 1e9 / ms, 1),
+                           "frac_mfma_bf16": round(flops / 1e9 / ms / MFMA_BF16, 4)}
+
+    rec("pairwise_iou_rpn(16x268569)", timeit(lambda: pairwise_iou(w.gt[0], w.anchors)), alg["pairwise_iou_rpn"] / 2)
+    rec("pairwise_iou_roi(16x1016)", timeit(lambda: pairwise_iou(w.gt[0], w.props[0])))
+    for name, pooler, lists, grad in (("box7", w.box_pooler, w.box_lists, w.gbox),
+                                      ("mask14", w.mask_pooler, w.mask_lists, w.gmask)):
+        key = "roi_align_box" if name == "box7" else "roi_align_mask"
+        rec(f"pooler_fwd_{name}", timeit(lambda: pooler([f.detach() for f in w.feats], lists)), alg[key + "_fwd"])
+        y = pooler(w.feats, lists)
+        rec(f"pooler_bwd_{name}", timeit(lambda: torch.autograd.grad([y], w.feats, [grad], retain_graph=True)),
+            alg[key + "_bwd"])
+        del y
+    gen = torch.Generator().manual_seed(7)
+    b, s, lv = w.nms_in[0]
+    rec("batched_nms_rpn(8819,5cls,.7)", timeit(lambda: batched_nms(b, s, lv, 0.7)))
+    b2, s2, i2 = nms_inputs(gen, 20000, 80, dev)
+    rec("batched_nms_boxhead(20000,80cls,.5)", timeit(lambda: batched_nms(b2, s2, i2, 0.5), rep=10))
+    b3, s3, i3 = nms_inputs(gen, 100000, 80, dev)
+    rec("batched_nms_retinanet(100000,80cls,.5)", timeit(lambda: batched_nms(b3, s3, i3, 0.5), rep=5))
+    rec("nms(4096,.5)", timeit(lambda: nms(b2[:4096], s2[:4096], 0.5)))
     m = torch.rand(100, 28, 28, device=dev)
     xy = torch.rand(100, 2, device=dev) * torch.tensor([1333 * 0.8, 800 * 0.8], device=dev)
     wh = torch.rand(100, 2, device=dev) * torch.tensor([1333 * 0.4, 800 * 0.4], device=dev) + 4
     bx = torch.cat([xy, xy + wh], 1)
-    res["paste_masks(100x800x1333)"] = timeit(lambda: paste_masks_in_image(m, bx, (800, 1333), 0.5))
-    print(json.dumps({"layout": layout, "ms": {k: round(v, 4) for k, v in res.items()},
-                      "alg_MB": {k: round(v / 1e6, 1) for k, v in alg.items()}}))
+    rec("paste_masks(100x800x1333)", timeit(lambda: paste_masks_in_image(m, bx, (800, 1333), 0.5)),
+        100 * 800 * 1333 + 4 * 100 * 28 * 28 + 1600)
+    if not quick:
+        rb = torch.cat([(b2[:2000, :2] + b2[:2000, 2:]) / 2, b2[:2000, 2:] - b2[:2000, :2],
+                        torch.rand(2000, 1, device=dev) * 360 - 180], 1)
+        rec("pairwise_iou_rotated(64x2000)", timeit(lambda: pairwise_iou_rotated(rb[:64], rb), rep=5))
+        rec("nms_rotated(2000,.5)", timeit(lambda: nms_rotated(rb, s2[:2000], 0.5), rep=5))
+        # DCNv2, the three R50 stages of SURVEY 8(a) a5/a6, bf16
+        for tag, (C, H, W) in (("res3", (128, 100, 168)), ("res4", (256, 50, 84)), ("res5", (512, 25, 42))):
+            mod = ModulatedDeformConv(C, C, 3, padding=1, bias=False).to(dev).to(torch.bfloat16)
+            x = torch.randn(2, C, H, W, device=dev, dtype=torch.bfloat16, requires_grad=True)
+            off = (torch.randn(2, 18, H, W, device=dev) * 2).to(torch.bfloat16).requires_grad_(True)
+            msk = torch.sigmoid(torch.randn(2, 9, H, W, device=dev)).to(torch.bfloat16).requires_grad_(True)
+            flops = 2.0 * C * C * 9 * 2 * H * W
+            rec(f"dcnv2_fwd_{tag}", timeit(lambda: mod(x.detach(), off.detach(), msk.detach()), rep=10), flops=flops)
+            y = mod(x, off, msk)
+            g = torch.randn_like(y)
+            rec(f"dcnv2_bwd_{tag}", timeit(lambda: torch.autograd.grad(
+                [y], [x, off, msk, mod.weight], [g], retain_graph=True), rep=10), flops=2 * flops)
+            del y
+    print(json.dumps({"layout": layout, "ms": res, "derived": extra}))
 
 
 if __name__ == "__main__":

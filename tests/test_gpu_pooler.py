@@ -1,0 +1,198 @@
+"""GPU parity tests of the fused multi-level ROIPooler (csrc/roi_pool.hip) -- SURVEY 8(a) row a4.
+
+Oracle: the level-assignment restatement (tests/test_tile_gather_math.py pins it against torch on
+the CPU) + the oracle's per-level ROIAlign forward / backward, i.e. exactly the reference's
+ROIPooler.forward structure (detectron2/modeling/poolers.py:247-263) evaluated on the CPU."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from detectron2_amd.modeling import ROIPooler, assign_boxes_to_levels, convert_boxes_to_pooler_format
+from detectron2_amd.structures import Boxes
+
+from test_tile_gather_math import assign_levels_restated
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+SCALES = [1 / 4, 1 / 8, 1 / 16, 1 / 32]
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-12))
+
+
+def make_inputs(rng, n_img, C, img_h, img_w, per_img):
+    feats = [rng.standard_normal((n_img, C, -(-img_h // s), -(-img_w // s))).astype(np.float32)
+             for s in (4, 8, 16, 32)]
+    boxes = []
+    for _ in range(n_img):
+        s = np.exp(rng.uniform(np.log(4), np.log(0.9 * min(img_h, img_w)), per_img))
+        ar = np.exp(rng.uniform(np.log(0.4), np.log(2.5), per_img))
+        w, h = s * np.sqrt(ar), s / np.sqrt(ar)
+        cx, cy = rng.uniform(0, img_w, per_img), rng.uniform(0, img_h, per_img)
+        b = np.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1)
+        b[:, 0::2] = b[:, 0::2].clip(0, img_w)
+        b[:, 1::2] = b[:, 1::2].clip(0, img_h)
+        boxes.append(b.astype(np.float32))
+    return feats, boxes
+
+
+def oracle_pooler(feats, boxes, out, sr, aligned, grad=None):
+    """reference structure on the CPU: levels -> per-level oracle ROIAlign -> scatter rows"""
+    allb = np.concatenate(boxes)
+    bidx = np.concatenate([np.full(len(b), i, np.float32) for i, b in enumerate(boxes)])
+    rois = np.concatenate([bidx[:, None], allb], 1).astype(np.float32)
+    lv = assign_levels_restated(allb, 2, 5, 224, 4)
+    C = feats[0].shape[1]
+    y = np.zeros((len(rois), C, out, out), np.float32)
+    gins = []
+    for l, f in enumerate(feats):
+        sel = np.nonzero(lv == l)[0]
+        y[sel] = oracle.roi_align_forward(f, rois[sel], (out, out), SCALES[l], sr, aligned)
+        if grad is not None:
+            gins.append(oracle.roi_align_backward(np.ascontiguousarray(grad[sel]), rois[sel], f.shape, SCALES[l],
+                                                  sr, aligned))
+    return y, gins, lv
+
+
+@pytest.mark.parametrize("layout", ["nhwc", "nchw"])
+@pytest.mark.parametrize("out,sr,ptype", [(7, 0, "ROIAlignV2"), (14, 2, "ROIAlignV2"), (7, 0, "ROIAlign")])
+def test_fused_pooler_fp32_vs_oracle(layout, out, sr, ptype):
+    rng = np.random.default_rng(out * 31 + sr)
+    feats, boxes = make_inputs(rng, 2, 8, 160, 224, 40)
+    boxes[0][0] = [0, 0, 224, 160]      # whole image -> top level, large sampling grid
+    boxes[0][1] = [10, 10, 10, 10]      # empty box
+    boxes[1][0] = [100, 50, 101.5, 52]  # tiny box: many bins per pixel
+    aligned = ptype == "ROIAlignV2"
+    pooler = ROIPooler(out, SCALES, sr, ptype)
+    xs = [torch.from_numpy(f).to(DEV).requires_grad_(True) for f in feats]
+    xin = [x.contiguous(memory_format=torch.channels_last) if layout == "nhwc" else x for x in xs]
+    y = pooler(xin, [Boxes(torch.from_numpy(b).to(DEV)) for b in boxes])
+    g = rng.standard_normal(y.shape).astype(np.float32)
+    exp, gexp, lv = oracle_pooler(feats, boxes, out, sr, aligned, g)
+    assert len(set(lv.tolist())) == 4, "test inputs must hit every level"
+    assert y.shape == exp.shape
+    assert rel_err(y.detach().cpu().numpy(), exp) < 1e-4
+    y.backward(torch.from_numpy(g).to(DEV))
+    for x, ge in zip(xs, gexp):
+        assert rel_err(x.grad.cpu().numpy(), ge) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_fused_pooler_16bit_nhwc(dtype):
+    rng = np.random.default_rng(5)
+    feats, boxes = make_inputs(rng, 2, 64, 128, 192, 48)
+    fq = [torch.from_numpy(f).to(dtype) for f in feats]
+    feats_r = [f.float().numpy() for f in fq]
+    pooler = ROIPooler(7, SCALES, 0, "ROIAlignV2")
+    xs = [f.to(DEV).requires_grad_(True) for f in fq]
+    y = pooler([x.contiguous(memory_format=torch.channels_last) for x in xs],
+               [Boxes(torch.from_numpy(b).to(DEV)) for b in boxes])
+    assert y.dtype == dtype and y.is_contiguous(memory_format=torch.channels_last)
+    gq = torch.from_numpy(rng.standard_normal(y.shape).astype(np.float32)).to(dtype)
+    exp, gexp, _ = oracle_pooler(feats_r, boxes, 7, 0, True, gq.float().numpy())
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    assert rel_err(y.float().detach().cpu().numpy(), exp) < 2 * ulp
+    y.backward(gq.to(DEV))
+    for x, ge in zip(xs, gexp):
+        assert rel_err(x.grad.float().cpu().numpy(), ge) < 2 * ulp
+
+
+def test_fused_pooler_level_assignment_and_structure():
+    """device level assignment == torch's on the same boxes; fused == per-level ROIAlign loop"""
+    rng = np.random.default_rng(9)
+    feats, boxes = make_inputs(rng, 2, 16, 256, 320, 300)
+    # exact level boundaries (sqrt(area) = 112, 224, 448)
+    boxes[0][:3] = [[0, 0, 112, 112], [0, 0, 224, 224], [10, 10, 234, 234]]
+    bl = [Boxes(torch.from_numpy(b).to(DEV)) for b in boxes]
+    xs = [torch.from_numpy(f).to(DEV).contiguous(memory_format=torch.channels_last) for f in feats]
+    pooler = ROIPooler(7, SCALES, 0, "ROIAlignV2")
+    y = pooler(xs, bl)
+    lv = assign_boxes_to_levels(bl, 2, 5, 224, 4)
+    fmt = convert_boxes_to_pooler_format(bl)
+    ref = torch.zeros_like(y)
+    for l, lp in enumerate(pooler.level_poolers):
+        inds = torch.nonzero(lv == l, as_tuple=True)[0]
+        ref.index_put_((inds,), lp(xs[l], fmt[inds]))
+    assert torch.equal(y, ref)  # same kernels, same arithmetic -> bit-identical rows
+    # CPU restatement of the levels agrees with the device's torch ops
+    assert np.array_equal(lv.cpu().numpy(), assign_levels_restated(np.concatenate(boxes), 2, 5, 224, 4))
+
+
+def test_fused_pooler_backward_is_deterministic_and_complete():
+    """tile gather: bit-identical across runs, and every grad element is written (no stale memory)"""
+    rng = np.random.default_rng(2)
+    feats, boxes = make_inputs(rng, 2, 32, 200, 264, 256)
+    bl = [Boxes(torch.from_numpy(b).to(DEV)) for b in boxes]
+    pooler = ROIPooler(14, SCALES, 0, "ROIAlignV2")
+    grads = []
+    for rep in range(2):
+        xs = [torch.from_numpy(f).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+              for f in feats]
+        # poison the allocator's free blocks so unwritten grad elements would show up as NaN
+        junk = [torch.full_like(x, float("nan")) for x in xs]
+        del junk
+        y = pooler(xs, bl)
+        torch.manual_seed(0)
+        y.backward(torch.randn_like(y))
+        grads.append([x.grad.clone() for x in xs])
+    for a, b in zip(*grads):
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, b)
+
+
+def test_fused_pooler_edge_cases():
+    pooler = ROIPooler(7, SCALES, 0, "ROIAlignV2")
+    xs = [torch.randn(2, 8, 64 // s, 96 // s, device=DEV).contiguous(memory_format=torch.channels_last)
+          .requires_grad_(True) for s in (1, 2, 4, 8)]
+    # no boxes at all: (0, C, 7, 7), backward gives zero grads
+    y = pooler(xs, [Boxes(torch.zeros(0, 4, device=DEV)), Boxes(torch.zeros(0, 4, device=DEV))])
+    assert y.shape == (0, 8, 7, 7)
+    y.sum().backward()
+    assert all((x.grad == 0).all() for x in xs)
+    # empty box list == zero images
+    z = pooler([x[:0] for x in xs], [])
+    assert z.shape == (0, 8, 7, 7)
+    # boxes entirely outside the image / inverted boxes give zero rows and zero gradient
+    for x in xs:
+        x.grad = None
+    b = torch.tensor([[1000., 1000, 1100, 1100], [50, 50, 40, 40]], device=DEV)
+    y = pooler(xs, [Boxes(b), Boxes(torch.zeros(0, 4, device=DEV))])
+    assert (y == 0).all()
+    y.sum().backward()
+    assert all((x.grad == 0).all() for x in xs)
+    # single level pooler == ROIAlign module
+    from detectron2_amd.layers import ROIAlign
+    p1 = ROIPooler((7, 7), [1 / 4], 2, "ROIAlign")
+    bb = torch.tensor([[4., 4, 60, 50], [10, 20, 90, 80]], device=DEV)
+    a = p1([xs[0]], [Boxes(bb[:1]), Boxes(bb[1:])])
+    r = ROIAlign((7, 7), 1 / 4, 2, False)(xs[0], torch.cat([torch.tensor([[0.], [1.]], device=DEV), bb], 1))
+    assert torch.equal(a, r)
+
+
+def test_fused_pooler_full_size_adjoint():
+    """BASELINE config 2 shapes (2 x 800x1344, 256 ch bf16 NHWC, 1024 ROIs, 7x7): forward/backward are
+    adjoint -- <pool(x), g> == sum_l <x_l, grad_l> -- and match an fp32 run to bf16 precision."""
+    torch.manual_seed(1)
+    rng = np.random.default_rng(1)
+    hw = [(200, 336), (100, 168), (50, 84), (25, 42)]
+    _, boxes = make_inputs(rng, 2, 1, 800, 1344, 512)
+    bl = [Boxes(torch.from_numpy(b).to(DEV)) for b in boxes]
+    pooler = ROIPooler(7, SCALES, 0, "ROIAlignV2")
+    xf = [torch.randn(2, 256, h, w, device=DEV).contiguous(memory_format=torch.channels_last) for h, w in hw]
+    xs = [x.clone().requires_grad_(True) for x in xf]
+    y = pooler(xs, bl)
+    g = torch.randn_like(y)
+    y.backward(g)
+    lhs = (y.detach().double() * g.double()).sum()
+    rhs = sum((x.detach().double() * x.grad.double()).sum() for x in xs)
+    assert abs(lhs - rhs) / abs(lhs) < 1e-5
+    xb = [x.to(torch.bfloat16).requires_grad_(True) for x in xf]
+    yb = pooler(xb, bl)
+    yb.backward(g.to(torch.bfloat16))
+    yr = pooler([x.detach().float() for x in xb], bl)
+    assert rel_err(yb.float().detach().cpu().numpy(), yr.cpu().numpy()) < 2.0 ** -7
+    for a, b in zip(xb, xs):
+        assert rel_err(a.grad.float().cpu().numpy(), b.grad.cpu().numpy()) < 2.0 ** -6
