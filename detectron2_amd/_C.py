@@ -3,6 +3,7 @@
 There is NO fallback: if the HIP library is missing or an op is given a CPU tensor, this raises.
 (Reference counterpart: `from detectron2 import _C`, layers/deform_conv.py:505-514.)
 """
+import contextlib
 import ctypes
 import os
 
@@ -45,9 +46,12 @@ _SIGNATURES = {
     "d2amd_last_error": (ctypes.c_char_p, []),
     "d2amd_roi_align_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _vp]),
     "d2amd_roi_align_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "d2amd_boxes_to_rois": (_i, [_vp, ctypes.POINTER(_i), _i, _i, _vp, _vp]),
     "d2amd_roi_pooler_supported": (_i, [ctypes.POINTER(PoolerParams), _i]),
     "d2amd_roi_pooler_forward": (_i, [ctypes.POINTER(PoolerParams), ctypes.POINTER(_vp), _vp, _vp, _i, _vp]),
-    "d2amd_roi_pooler_backward": (_i, [ctypes.POINTER(PoolerParams), _vp, _vp, ctypes.POINTER(_vp), _i, _vp]),
+    "d2amd_roi_pooler_workspace_bytes": (_sz, [_i]),
+    "d2amd_roi_pooler_backward": (_i, [ctypes.POINTER(PoolerParams), _vp, _vp, ctypes.POINTER(_vp), _i, _vp, _sz,
+                                       _vp]),
     "d2amd_roi_align_rotated_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp, _vp]),
     "d2amd_roi_align_rotated_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp, _sz, _vp]),
     "d2amd_pairwise_iou": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp]),
@@ -105,6 +109,17 @@ def require_gpu(*tensors, op="op"):
 
 def ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+_NULL_CTX = contextlib.nullcontext()
+
+
+def on_device(device):
+    """Context that makes `device` current for a C-ABI call (kernels launch on the current device).
+    One process per GPU is the deployment model, so this is normally a no-op object."""
+    if device.index is None or device.index == torch.cuda.current_device():
+        return _NULL_CTX
+    return torch.cuda.device(device)
 
 
 def stream():

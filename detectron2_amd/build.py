@@ -57,7 +57,7 @@ def build(force=False, verbose=False):
         if (not force and os.path.exists(obj)
                 and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_m)):
             return obj, False
-        cmd = [hipcc, "-c", src, "-o", obj] + COMMON + SOURCES[name]
+        cmd = [hipcc, "-c", src, "-o", obj] + COMMON + SOURCES[name] + os.environ.get("D2AMD_EXTRA_FLAGS", "").split()
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

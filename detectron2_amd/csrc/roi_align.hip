@@ -306,7 +306,7 @@ extern "C" int d2amd_roi_align_backward(const void* grad_output, const float* ro
     const d2amd_pooler_params p = single_level(N, C, H, W, pooled_h, pooled_w, spatial_scale, sampling_ratio, aligned,
                                                dtype, layout);
     void* lv[1] = {grad_input};
-    return d2amd_roi_pooler_backward(&p, grad_output, rois, lv, K, stream);
+    return d2amd_roi_pooler_backward(&p, grad_output, rois, lv, K, workspace, workspace_bytes, stream);
   }
   return D2_DISPATCH_DTYPE(dtype, [&]() -> int {
     return bwd_impl<scalar_t>(grad_output, rois, grad_input, N, C, H, W, K, pooled_h, pooled_w, spatial_scale,

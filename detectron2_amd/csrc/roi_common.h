@@ -19,29 +19,46 @@ struct RoiGeom {
   bool bad;                                 // rotated: negative size
 };
 
+// axis-aligned geometry from the 5 ROI values (shared by every axis-aligned kernel so that the list
+// scan, the forward and the backward see bit-identical starts / bins / grids)
+__device__ __forceinline__ RoiGeom roi_geom_box(float b, float x1, float y1, float x2, float y2, float scale,
+                                                int pooled_h, int pooled_w, int sampling_ratio, int aligned) {
+  RoiGeom g;
+  g.bad = false;
+  g.batch = (int)b;
+  const float off = aligned ? 0.5f : 0.0f;
+  g.start_w = x1 * scale - off;
+  g.start_h = y1 * scale - off;
+  const float end_w = x2 * scale - off, end_h = y2 * scale - off;
+  float roi_w = end_w - g.start_w;
+  float roi_h = end_h - g.start_h;
+  if (!aligned) {  // legacy: force malformed ROIs to be 1x1
+    roi_w = fmaxf(roi_w, 1.f);
+    roi_h = fmaxf(roi_h, 1.f);
+  }
+  g.center_w = g.center_h = 0.f;
+  g.cos_t = 1.f;
+  g.sin_t = 0.f;
+  g.roi_w = roi_w;
+  g.roi_h = roi_h;
+  g.bin_h = roi_h / (float)pooled_h;
+  g.bin_w = roi_w / (float)pooled_w;
+  g.grid_h = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_h / (float)pooled_h);
+  g.grid_w = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_w / (float)pooled_w);
+  return g;
+}
+
 template <bool ROT>
 __device__ __forceinline__ RoiGeom roi_geom(const float* __restrict__ rois, int k, float scale, int pooled_h,
                                             int pooled_w, int sampling_ratio, int aligned) {
+  if (!ROT) {
+    const float* r = rois + (long)k * 5;
+    return roi_geom_box(r[0], r[1], r[2], r[3], r[4], scale, pooled_h, pooled_w, sampling_ratio, aligned);
+  }
   RoiGeom g;
   g.bad = false;
   float roi_w, roi_h;
-  if (!ROT) {
-    const float* r = rois + (long)k * 5;
-    g.batch = (int)r[0];
-    const float off = aligned ? 0.5f : 0.0f;
-    g.start_w = r[1] * scale - off;
-    g.start_h = r[2] * scale - off;
-    const float end_w = r[3] * scale - off, end_h = r[4] * scale - off;
-    roi_w = end_w - g.start_w;
-    roi_h = end_h - g.start_h;
-    if (!aligned) {  // legacy: force malformed ROIs to be 1x1
-      roi_w = fmaxf(roi_w, 1.f);
-      roi_h = fmaxf(roi_h, 1.f);
-    }
-    g.center_w = g.center_h = 0.f;
-    g.cos_t = 1.f;
-    g.sin_t = 0.f;
-  } else {
+  {
     const float* r = rois + (long)k * 6;
     g.batch = (int)r[0];
     g.center_w = r[1] * scale - 0.5f;

@@ -20,6 +20,8 @@
 //   G[y,x,:] += sum_ph sum_pw Wy[y][ph] Wx[x][pw] dY[k,ph,pw,:] in registers, then writes every
 //   pixel of grad_input exactly once in the I/O dtype.  tests/test_tile_gather_math.py checks this
 //   formulation against the oracle's sample-by-sample scatter on the CPU.
+#include <stdlib.h>
+
 #include "roi_common.h"
 
 namespace d2amd {
@@ -35,6 +37,9 @@ struct PoolLevels {
   int num_levels, N, C, PH, PW, sr, aligned, K;
   int min_level, max_level, canonical_level;
   float canonical_size;
+  unsigned long long* dbg;  // profiling only (D2AMD_PROFILE builds): cycle stamps of one workgroup
+  int dbg_block;
+  int ablate;  // profiling only (D2AMD_ABLATE): bit0 skip gather, bit1 skip weights, bit2 skip list scan
 };
 
 // detectron2/modeling/poolers.py:51-59 in fp32, operation for operation:
@@ -54,17 +59,20 @@ __device__ __forceinline__ int assign_level(const float* __restrict__ box, const
 
 // ---- 16-byte channel vectors ------------------------------------------------------------------
 template <typename T> struct V16 { static constexpr int N = 16 / (int)sizeof(T); };
+// native 4 x u32 vector: a first-class SSA value (arrays of HIP's raw16 struct that live across loop
+// iterations were left in scratch memory by hipcc, which serialised the prefetch)
+typedef unsigned int raw16 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void unpack16(const uint4& r, float (&f)[4], float) {
+__device__ __forceinline__ void unpack16(const raw16& r, float (&f)[4], float) {
   f[0] = __uint_as_float(r.x); f[1] = __uint_as_float(r.y); f[2] = __uint_as_float(r.z); f[3] = __uint_as_float(r.w);
 }
-__device__ __forceinline__ void unpack16(const uint4& r, float (&f)[8], bf16_t) {
+__device__ __forceinline__ void unpack16(const raw16& r, float (&f)[8], bf16_t) {
   f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
   f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
   f[4] = __uint_as_float(r.z << 16); f[5] = __uint_as_float(r.z & 0xffff0000u);
   f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
 }
-__device__ __forceinline__ void unpack16(const uint4& r, float (&f)[8], f16_t) {
+__device__ __forceinline__ void unpack16(const raw16& r, float (&f)[8], f16_t) {
   const uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
   for (int i = 0; i < 4; i++) {
@@ -72,15 +80,15 @@ __device__ __forceinline__ void unpack16(const uint4& r, float (&f)[8], f16_t) {
     f[2 * i + 1] = to_f32(f16_t{(uint16_t)(w[i] >> 16)});
   }
 }
-__device__ __forceinline__ uint4 pack16(const float (&f)[4], float) {
-  return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+__device__ __forceinline__ raw16 pack16(const float (&f)[4], float) {
+  return raw16{__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3])};
 }
 template <typename T>
-__device__ __forceinline__ uint4 pack16(const float (&f)[8], T) {
+__device__ __forceinline__ raw16 pack16(const float (&f)[8], T) {
   uint32_t w[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) w[i] = (uint32_t)from_f32<T>(f[2 * i]).v | ((uint32_t)from_f32<T>(f[2 * i + 1]).v << 16);
-  return make_uint4(w[0], w[1], w[2], w[3]);
+  return raw16{w[0], w[1], w[2], w[3]};
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -131,13 +139,13 @@ __global__ __launch_bounds__(POOL_THREADS) void pool_fwd_nhwc_kernel(PoolLevels 
     for (int t0 = 0; t0 < nt; t0 += U) {
       float w[U];
       if constexpr (VEC > 1) {
-        uint4 raw[U];
+        raw16 raw[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
           const int t = t0 + u, tt = min(t, nt - 1);
           const int j = (int)(((uint32_t)tt * rcp) >> 16), i = tt - j * sx;
           w[u] = t < nt ? wy[j] * wx[i] : 0.f;
-          raw[u] = *reinterpret_cast<const uint4*>(base + ((long)j * W + i) * C);
+          raw[u] = *reinterpret_cast<const raw16*>(base + ((long)j * W + i) * C);
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -163,7 +171,7 @@ __global__ __launch_bounds__(POOL_THREADS) void pool_fwd_nhwc_kernel(PoolLevels 
     for (int c = 0; c < VEC; c++) acc[c] *= inv;
     T* o = outk + (long)b * C + (long)q * VEC;
     if constexpr (VEC > 1) {
-      *reinterpret_cast<uint4*>(o) = pack16(acc, T{});
+      *reinterpret_cast<raw16*>(o) = pack16(acc, T{});
     } else {
       o[0] = from_f32<T>(acc[0]);
     }
@@ -230,30 +238,80 @@ __global__ __launch_bounds__(POOL_THREADS) void pool_fwd_nchw_kernel(PoolLevels 
 
 // ------------------------------------------------------------------------------------------------
 // BACKWARD, NHWC: tile gather.
+//
+// What the measurements of the first two versions (profiles/r01, DESIGN.md log) say about this kernel:
+// it is bound by the LATENCY of the longest per-tile ROI list, not by bandwidth.  Coarse FPN levels
+// have few tiles and every large ROI covers many of them (p4 of the bench batch: 154 tiles, lists of
+// up to 33 ROIs; p2: 2,100 tiles, lists <= 9), and a workgroup walks its list serially.  Hence:
+//   * the list scan stores the geometry of every hit in LDS (no global load, no division in the
+//     per-ROI loop) and loads candidate ROIs unconditionally (a conditional load compiles to
+//     load + s_waitcnt vmcnt(0));
+//   * per ROI, all dY loads of a lane are issued first (NB in flight), the axis weights of the NEXT
+//     ROI are computed while they fly (weights are double-buffered), then the FMAs run: one
+//     barrier and about one exposed L2 latency per ROI;
+//   * a group is 512 threads: 2 row halves x 8 pixel columns x 32 channel lanes, 4 rows per thread
+//     (32 accumulators: ~100 VGPRs, 4 waves / SIMD);
+//   * GROUPS > 1 (coarse levels): the workgroup has GROUPS x 512 threads, group g walks list entries
+//     g, g + GROUPS, ... with private accumulators, and the partial tiles are summed through LDS in a
+//     fixed order (still deterministic) -- the critical path shrinks GROUPS-fold.
 constexpr int TILE = 8;          // TILE x TILE pixels per workgroup
 constexpr int LPP = 32;          // lanes (16-B channel groups) per pixel; 256 threads = 8 pixel columns
-constexpr int LIST_CHUNK = 1024;  // ROIs scanned per list-building pass
+constexpr int LCH = 512;         // ROIs scanned per list-building pass
 constexpr int MAXP = SEP_MAXP;   // 32: one lane per bin along an axis
+constexpr int CT = 256;          // threads per row-split of a group: 8 pixel columns x 32 channel lanes
 
+// Per-ROI record written once per backward call by roi_records_kernel: what a tile workgroup needs
+// to decide "does this ROI touch my tile" with a few integer compares (the first versions evaluated
+// the whole geometry -- two IEEE divisions, sqrt, log2 -- per candidate and per tile: ~6k cycles of
+// every workgroup), plus the geometry the weights need.
+struct HitGeo { float start_h, start_w, bin_h, bin_w, inv; int grid; };  // grid = grid_h | grid_w << 16
+struct RoiRec {
+  int level, batch;        // level = -1: contributes nothing (no level, empty sampling grid, outside)
+  int fy0, fy1, fx0, fx1;  // conservative pixel rectangle [fy0, fy1] x [fx0, fx1] that can receive gradient
+  HitGeo g;
+};  // 48 bytes
+
+template <int GROUPS>
 struct TileShared {
-  int list[LIST_CHUNK];
-  float Wy[TILE][MAXP], Wx[TILE][MAXP];  // Wx carries 1/count
-  uint32_t ymask[TILE], xmask[TILE];
-  int wave_cnt[POOL_THREADS / 64];
-  int list_len;
+  int list[LCH];
+  HitGeo geo[LCH];
+  float WyT[GROUPS][2][MAXP][TILE];          // [group][buffer][bin][tile row]
+  float Wx[GROUPS][2][TILE][MAXP];           // [group][buffer][tile col][bin], carries 1/count
+  uint32_t ymask[GROUPS][2][TILE], xmask[GROUPS][2][TILE];
+  int wave_cnt[LCH / 64];
 };
 
-// conservative footprint test: can ROI `g` put gradient on rows [y0, y0+TILE) x cols [x0, x0+TILE)?
-__device__ __forceinline__ bool footprint_hits(const RoiGeom& g, int H, int W, int y0, int x0) {
+// conservative footprint rectangle of an ROI on its level; false if it cannot contribute
+__device__ __forceinline__ bool footprint_rect(const RoiGeom& g, int H, int W, int& fy0, int& fy1, int& fx0,
+                                               int& fx1) {
   if (g.grid_h <= 0 || g.grid_w <= 0) return false;
   // samples lie strictly inside (start, start + roi); valid ones in [-1, size]; pixels touched are
   // floor(max(s, 0)) and +1, clamped to size - 1
   const float ylo = fmaxf(g.start_h, 0.f), yhi = g.start_h + g.roi_h;
   const float xlo = fmaxf(g.start_w, 0.f), xhi = g.start_w + g.roi_w;
   if (!(yhi >= -1.f && g.start_h <= (float)H && xhi >= -1.f && g.start_w <= (float)W)) return false;  // also NaN
-  const int fy0 = (int)fminf(ylo, 1e9f), fy1 = min((int)fminf(fmaxf(yhi, 0.f), 1e9f) + 1, H - 1);
-  const int fx0 = (int)fminf(xlo, 1e9f), fx1 = min((int)fminf(fmaxf(xhi, 0.f), 1e9f) + 1, W - 1);
-  return fy1 >= y0 && fy0 < y0 + TILE && fx1 >= x0 && fx0 < x0 + TILE;
+  fy0 = (int)fminf(ylo, 1e9f); fy1 = min((int)fminf(fmaxf(yhi, 0.f), 1e9f) + 1, H - 1);
+  fx0 = (int)fminf(xlo, 1e9f); fx1 = min((int)fminf(fmaxf(xhi, 0.f), 1e9f) + 1, W - 1);
+  return true;
+}
+
+__global__ void roi_records_kernel(PoolLevels L, const float* __restrict__ rois, RoiRec* __restrict__ rec) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= L.K) return;
+  const float* r = rois + (long)k * 5;
+  RoiRec o{};
+  o.level = -1;
+  o.batch = (int)r[0];
+  const int lvl = assign_level(r + 1, L);
+  if (lvl >= 0) {
+    const RoiGeom g = roi_geom_box(r[0], r[1], r[2], r[3], r[4], L.scale[lvl], L.PH, L.PW, L.sr, L.aligned);
+    if (footprint_rect(g, L.H[lvl], L.W[lvl], o.fy0, o.fy1, o.fx0, o.fx1)) {
+      o.level = lvl;
+      o.g = HitGeo{g.start_h, g.start_w, g.bin_h, g.bin_w, 1.f / (float)(g.grid_h * g.grid_w),
+                   (g.grid_h & 0xffff) | (g.grid_w << 16)};
+    }
+  }
+  rec[k] = o;
 }
 
 // total weight the `grid` samples of bin p put on pixel `pix` along one axis
@@ -268,12 +326,18 @@ __device__ __forceinline__ float axis_weight(float start, float bin, int grid, i
   return w;
 }
 
-template <typename T, int VEC>
-__global__ __launch_bounds__(POOL_THREADS) void pool_bwd_nhwc_kernel(PoolLevels L, const float* __restrict__ rois,
-                                                                    const T* __restrict__ gout, int nslab,
-                                                                    int total_blocks) {
-  __shared__ TileShared S;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+// RS = row splits of the tile inside a group (1: a thread owns all 8 rows of its pixel column,
+// 2: 4 rows); a group has RS * 256 threads.  GROUPS = list splits.  NB = loads in flight per lane.
+template <typename T, int VEC, int GROUPS, int RS, int NB>
+// 4 waves / SIMD (<= 128 VGPRs): two 512-thread workgroups per CU; measured faster than the 146-178 VGPR builds
+__global__ __launch_bounds__(CT * RS * GROUPS, 4) void pool_bwd_nhwc_kernel(PoolLevels L,
+                                                                         const RoiRec* __restrict__ rec,
+                                                                         const T* __restrict__ gout, int nslab,
+                                                                         int total_blocks) {
+  constexpr int GT = CT * RS, NT = GT * GROUPS, TR = TILE / RS;
+  __shared__ TileShared<GROUPS> S;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int grp = tid / GT, t = tid % GT;  // group, thread in group
   // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, so give each XCD one
   // contiguous run of tiles (neighbouring tiles share the dY rows of their ROIs in that XCD's L2)
   const int per_xcd = (total_blocks + 7) >> 3;
@@ -286,7 +350,6 @@ __global__ __launch_bounds__(POOL_THREADS) void pool_bwd_nhwc_kernel(PoolLevels 
   for (int l = 1; l < POOL_MAX_LEVELS; l++)
     if (l < L.num_levels && tile >= L.tile_base[l]) lvl = l;
   const int H = L.H[lvl], W = L.W[lvl];
-  const float scale = L.scale[lvl];
   const int tiles_x = (W + TILE - 1) / TILE, tiles_y = (H + TILE - 1) / TILE;
   int tl = tile - L.tile_base[lvl];
   const int n = tl / (tiles_y * tiles_x);
@@ -294,127 +357,240 @@ __global__ __launch_bounds__(POOL_THREADS) void pool_bwd_nhwc_kernel(PoolLevels 
   const int y0 = (tl / tiles_x) * TILE, x0 = (tl % tiles_x) * TILE;
   const int C = L.C, PH = L.PH, PW = L.PW, K = L.K;
   const int CG = C / VEC;
-  const int col = tid >> 5;                 // pixel column of this thread inside the tile (0..7)
-  const int cg = slab * LPP + (tid & 31);   // channel group
+  const int rh = t / CT, col = (t >> 5) & 7, lp = t & 31;  // row split / pixel column / channel lane
+  const int cg = slab * LPP + lp;
   const bool cg_ok = cg < CG;
-  const long cofs = (long)cg * VEC;
+  const long cofs = (long)min(cg, CG - 1) * VEC;
 
-  float acc[TILE][VEC];
+  float acc[TR][VEC];  // rows rh*TR .. rh*TR + TR - 1 of column col
 #pragma unroll
-  for (int i = 0; i < TILE; i++)
+  for (int i = 0; i < TR; i++)
 #pragma unroll
     for (int c = 0; c < VEC; c++) acc[i][c] = 0.f;
 
-  for (int kbase = 0; kbase < K; kbase += LIST_CHUNK) {
-    // ---- (1) ordered list of the ROIs of this chunk that touch the tile ----------------------
-    __syncthreads();
-    if (tid == 0) S.list_len = 0;
-    __syncthreads();
-    const int kend = min(K, kbase + LIST_CHUNK);
-    for (int r0 = kbase; r0 < kend; r0 += POOL_THREADS) {
-      const int r = r0 + tid;
-      bool hit = false;
-      if (r < kend) {
-        const float* rr = rois + (long)r * 5;
-        if ((int)rr[0] == n && assign_level(rr + 1, L) == lvl) {
-          const RoiGeom g = roi_geom<false>(rois, r, scale, PH, PW, L.sr, L.aligned);
-          hit = footprint_hits(g, H, W, y0, x0);
-        }
-      }
-      const unsigned long long bal = __ballot(hit);
-      if (lane == 0) S.wave_cnt[wid] = __builtin_popcountll(bal);
-      __syncthreads();
-      int off = S.list_len;
-      for (int w = 0; w < wid; w++) off += S.wave_cnt[w];
-      if (hit) S.list[off + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = r;
-      __syncthreads();
-      if (tid == 0) S.list_len += S.wave_cnt[0] + S.wave_cnt[1] + S.wave_cnt[2] + S.wave_cnt[3];
-      __syncthreads();
+  // axis weights of list entry `li` -> buffer wb of this group.  RS == 1: every thread evaluates one
+  // (tile row, bin) and one (tile col, bin) pair; RS == 2: threads 0-255 the rows, 256-511 the columns.
+  auto compute_weights = [&](int li, int wb) __attribute__((always_inline)) {
+    const HitGeo g = S.geo[li];
+    const int grid_h = g.grid & 0xffff, grid_w = g.grid >> 16;
+    const int r = (t >> 5) & 7, p = t & 31, w4 = (t >> 6) & 3;
+    if (RS == 1 || t < CT) {
+      float wv = 0.f;
+      if (p < PH && y0 + r < H) wv = axis_weight(g.start_h, g.bin_h, grid_h, p, y0 + r, H);
+      S.WyT[grp][wb][p][r] = wv;
+      const unsigned long long bm = __ballot(wv != 0.f);
+      if (lane == 0) { S.ymask[grp][wb][2 * w4] = (uint32_t)bm; S.ymask[grp][wb][2 * w4 + 1] = (uint32_t)(bm >> 32); }
     }
-    const int nlist = S.list_len;
-    // ---- (2)+(3) per ROI: axis weights for this tile, then the gather -------------------------
-    for (int li = 0; li < nlist; li++) {
-      const int k = S.list[li];
-      const RoiGeom g = roi_geom<false>(rois, k, scale, PH, PW, L.sr, L.aligned);
-      __syncthreads();  // previous ROI's weights are no longer read
-      {
-        const int r = tid >> 5, p = tid & 31;  // (tile row / column, bin)
-        float wyv = 0.f, wxv = 0.f;
-        if (p < PH && y0 + r < H) wyv = axis_weight(g.start_h, g.bin_h, g.grid_h, p, y0 + r, H);
-        if (p < PW && x0 + r < W) wxv = axis_weight(g.start_w, g.bin_w, g.grid_w, p, x0 + r, W);
-        const float inv = 1.f / (float)(g.grid_h * g.grid_w);
-        S.Wy[r][p] = wyv;
-        S.Wx[r][p] = wxv * inv;
-        const unsigned long long by = __ballot(wyv != 0.f), bx = __ballot(wxv != 0.f);
-        if (lane == 0) {
-          S.ymask[2 * wid] = (uint32_t)by; S.ymask[2 * wid + 1] = (uint32_t)(by >> 32);
-          S.xmask[2 * wid] = (uint32_t)bx; S.xmask[2 * wid + 1] = (uint32_t)(bx >> 32);
-        }
+    if (RS == 1 || t >= CT) {
+      float wv = 0.f;
+      if (p < PW && x0 + r < W) wv = axis_weight(g.start_w, g.bin_w, grid_w, p, x0 + r, W);
+      S.Wx[grp][wb][r][p] = wv * g.inv;
+      const unsigned long long bm = __ballot(wv != 0.f);
+      if (lane == 0) { S.xmask[grp][wb][2 * w4] = (uint32_t)bm; S.xmask[grp][wb][2 * w4 + 1] = (uint32_t)(bm >> 32); }
+    }
+  };
+
+#ifdef D2AMD_PROFILE
+  const bool dbg_on = L.dbg && logical == L.dbg_block && tid == 0;
+  int dbg_n = 0;
+#define STAMP() do { if (dbg_on && dbg_n < 120) L.dbg[dbg_n++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP() do {} while (0)
+#endif
+  STAMP();
+#ifdef D2AMD_PROFILE
+  const unsigned long long rt0 = wall_clock64();
+#endif
+  for (int kbase = 0; kbase < K; kbase += LCH) {
+    // ---- (1) ordered list (+ geometry) of the ROIs of this chunk that touch the tile ----------
+    const int kend = min(K, kbase + LCH);
+    constexpr int ROUNDS = (LCH + NT - 1) / NT;
+    int4 ra[ROUNDS];
+    int2 rb[ROUNDS];
+#pragma unroll
+    for (int q = 0; q < ROUNDS; q++) {  // raw clamped loads of the record heads, all in flight together
+      const long r = min(kbase + q * NT + tid, K - 1);
+      ra[q] = *reinterpret_cast<const int4*>(&rec[r].level);  // level, batch, fy0, fy1
+      rb[q] = *reinterpret_cast<const int2*>(&rec[r].fx0);    // fx0, fx1
+    }
+    bool hit[ROUNDS];
+    unsigned long long bal[ROUNDS];
+#pragma unroll
+    for (int q = 0; q < ROUNDS; q++) {
+      const int r = kbase + q * NT + tid;
+      hit[q] = r < kend && q * NT + tid < LCH && ra[q].x == lvl && ra[q].y == n && ra[q].w >= y0 &&
+          ra[q].z < y0 + TILE && rb[q].y >= x0 && rb[q].x < x0 + TILE;
+      bal[q] = __ballot(hit[q]);
+    }
+    __syncthreads();  // previous chunk's readers of list / geo / wave_cnt are done
+    if (lane == 0) {
+#pragma unroll
+      for (int q = 0; q < ROUNDS; q++) {
+        const int slot = q * (NT / 64) + (tid >> 6);
+        if (slot < LCH / 64) S.wave_cnt[slot] = __builtin_popcountll(bal[q]);
       }
-      __syncthreads();
-      uint32_t yu = 0;
+    }
+    __syncthreads();
+    int nlist = 0;
+    {
+      int run = 0;
+      constexpr int NSLOT = LCH / 64;  // waves of candidates, in ROI order
 #pragma unroll
-      for (int i = 0; i < TILE; i++) yu |= S.ymask[i];
-      uint32_t xm = S.xmask[col];
-      if (!cg_ok || yu == 0) xm = 0;
-      const T* gk = gout + (long)k * PH * PW * C + cofs;
-      while (xm) {
-        const int pw = __builtin_ctz(xm);
-        xm &= xm - 1;
-        const float wxv = S.Wx[col][pw];
-        uint32_t yb = yu;
-        while (yb) {
-          // up to 4 bins of this column per batch: 4 independent 16-B loads in flight
-          int phs[4];
-          bool ok[4];
+      for (int sl = 0; sl < NSLOT; sl++) {
+        const int q = sl / (NT / 64), w = sl % (NT / 64);
+        if (q < ROUNDS && w == (tid >> 6) && hit[q < ROUNDS ? q : 0])
+          S.list[run + __builtin_popcountll(bal[q < ROUNDS ? q : 0] & ((1ull << lane) - 1ull))] =
+              kbase + q * NT + tid;
+        run += S.wave_cnt[sl];
+      }
+      nlist = run;
+    }
+    if (L.ablate & 4) nlist = 0;
+    STAMP();
+    if (nlist == 0) continue;  // uniform
+    __syncthreads();           // list complete
+    for (int i = tid; i < nlist; i += NT) S.geo[i] = rec[S.list[i]].g;  // geometry of the hits -> LDS
+    __syncthreads();
+
+    // ---- (2)+(3) per group: software pipeline over its list entries grp, grp + GROUPS, ... ------
+    const int iters = (nlist + GROUPS - 1) / GROUPS;
+    if (grp < nlist) compute_weights(grp, 0);
+    __syncthreads();
+    STAMP();
+    for (int it = 0; it < iters; it++) {
+      const int li = grp + it * GROUPS, wb = it & 1;
+      const bool active = li < nlist;
+      const bool next_active = li + GROUPS < nlist;
+      uint32_t yu = 0;  // bins that touch this thread's TR rows
 #pragma unroll
-          for (int u = 0; u < 4; u++) {
-            ok[u] = yb != 0;
-            phs[u] = ok[u] ? __builtin_ctz(yb) : phs[0];
-            if (ok[u]) yb &= yb - 1;
-          }
-          float f[4][VEC];
+      for (int i = 0; i < TR; i++) yu |= S.ymask[grp][wb][rh * TR + i];
+      uint32_t xb = (active && cg_ok && !(L.ablate & 1)) ? S.xmask[grp][wb][col] : 0u;
+      if (!active) yu = 0;
+      const T* gk = gout + (long)S.list[active ? li : 0] * PH * PW * C + cofs;
+      bool weights_done = false;
+      // batches of NB = (NB/2 bins of this thread's rows) x (2 bins of its column)
+      uint32_t yb = yu;
+      do {  // at least once, so that the next ROI's weights are always computed
+        int phs[NB / 2], npy = 0;
+#pragma unroll
+        for (int u = 0; u < NB / 2; u++) {
+          phs[u] = yb ? __builtin_ctz(yb) : 0;
+          if (yb) { npy++; yb &= yb - 1; }
+        }
+        uint32_t xq = xb;
+        do {
+          int pws[2];
+          pws[0] = xq ? __builtin_ctz(xq) : 0;
+          const bool okA = xq != 0;
+          if (xq) xq &= xq - 1;
+          pws[1] = xq ? __builtin_ctz(xq) : pws[0];
+          const bool okB = xq != 0;
+          if (xq) xq &= xq - 1;
+          raw16 raw[NB];
           if constexpr (VEC > 1) {
-            uint4 raw[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) raw[u] = *reinterpret_cast<const uint4*>(gk + ((long)phs[u] * PW + pw) * C);
-#pragma unroll
-            for (int u = 0; u < 4; u++) unpack16(raw[u], f[u], T{});
+            for (int u = 0; u < NB / 2; u++) {  // unconditional (clamped) loads: all NB in flight
+              raw[u] = *reinterpret_cast<const raw16*>(gk + ((long)phs[u] * PW + pws[0]) * C);
+              raw[NB / 2 + u] = *reinterpret_cast<const raw16*>(gk + ((long)phs[u] * PW + pws[1]) * C);
+            }
           } else {
 #pragma unroll
-            for (int u = 0; u < 4; u++) f[u][0] = to_f32(gk[((long)phs[u] * PW + pw) * C]);
+            for (int u = 0; u < NB / 2; u++) {
+              raw[u] = raw16{__float_as_uint(to_f32(gk[((long)phs[u] * PW + pws[0]) * C])), 0u, 0u, 0u};
+              raw[NB / 2 + u] = raw16{__float_as_uint(to_f32(gk[((long)phs[u] * PW + pws[1]) * C])), 0u, 0u, 0u};
+            }
           }
+          if (!weights_done) {  // uniform; overlaps the loads above
+            STAMP();
+            if (next_active) compute_weights(li + GROUPS, wb ^ 1);
+            weights_done = true;
+            STAMP();
+          }
+          const float wxA = okA ? S.Wx[grp][wb][col][pws[0]] : 0.f;
+          const float wxB = okB ? S.Wx[grp][wb][col][pws[1]] : 0.f;
 #pragma unroll
-          for (int u = 0; u < 4; u++) {
-            if (!ok[u]) continue;
+          for (int u = 0; u < NB / 2; u++) {
+            if (u >= npy) break;  // uniform
+            float wy[TR];
 #pragma unroll
-            for (int i = 0; i < TILE; i++) {
-              const float wyi = S.Wy[i][phs[u]];
-              if (wyi != 0.f) {  // rows are shared by the whole wave: uniform branch
-                const float w = wyi * wxv;
+            for (int i = 0; i < TR; i += 4) {
+              const float4 w4v = *reinterpret_cast<const float4*>(&S.WyT[grp][wb][phs[u]][rh * TR + i]);
+              wy[i] = w4v.x; wy[i + 1] = w4v.y; wy[i + 2] = w4v.z; wy[i + 3] = w4v.w;
+            }
+            float fA[VEC], fB[VEC];
+            if constexpr (VEC > 1) {
+              unpack16(raw[u], fA, T{});
+              unpack16(raw[NB / 2 + u], fB, T{});
+            } else {
+              fA[0] = __uint_as_float(raw[u].x);
+              fB[0] = __uint_as_float(raw[NB / 2 + u].x);
+            }
 #pragma unroll
-                for (int c = 0; c < VEC; c++) acc[i][c] += w * f[u][c];
+            for (int i = 0; i < TR; i++) {
+              if (wy[i] != 0.f) {  // rows are shared by the whole wave: uniform branch
+                const float a = wy[i] * wxA, b2 = wy[i] * wxB;
+#pragma unroll
+                for (int c = 0; c < VEC; c++) acc[i][c] += a * fA[c] + b2 * fB[c];
               }
             }
           }
-        }
+        } while (xq);
+      } while (yb);
+      __syncthreads();  // weights[wb ^ 1] complete; everyone is done with weights[wb]
+      STAMP();
+    }
+  }
+  STAMP();
+#ifdef D2AMD_PROFILE
+  if (dbg_on) { L.dbg[127] = dbg_n; L.dbg[126] = wall_clock64() - rt0; L.dbg[125] = __builtin_readcyclecounter() - L.dbg[0]; }
+#endif
+  // ---- partial tiles of groups 1.. are added to group 0 in a fixed order (deterministic) -------
+  if constexpr (GROUPS > 1) {
+    __shared__ float part[GT][TR * VEC + 1];
+    for (int g = 1; g < GROUPS; g++) {
+      __syncthreads();
+      if (grp == g) {
+#pragma unroll
+        for (int i = 0; i < TR; i++)
+#pragma unroll
+          for (int c = 0; c < VEC; c++) part[t][i * VEC + c] = acc[i][c];
+      }
+      __syncthreads();
+      if (grp == 0) {
+#pragma unroll
+        for (int i = 0; i < TR; i++)
+#pragma unroll
+          for (int c = 0; c < VEC; c++) acc[i][c] += part[t][i * VEC + c];
       }
     }
   }
   // ---- write the tile: every pixel of grad_input exactly once ---------------------------------
-  if (cg_ok && x0 + col < W) {
-    T* gi = (T*)L.data[lvl] + (((long)n * H + y0) * W + x0 + col) * C + cofs;
+  if (grp == 0 && cg_ok && x0 + col < W) {
+    T* gi = (T*)L.data[lvl] + (((long)n * H + y0 + rh * TR) * W + x0 + col) * C + cofs;
 #pragma unroll
-    for (int i = 0; i < TILE; i++) {
-      if (y0 + i >= H) break;
+    for (int i = 0; i < TR; i++) {
+      if (y0 + rh * TR + i >= H) break;
       T* o = gi + (long)i * W * C;
       if constexpr (VEC > 1) {
-        *reinterpret_cast<uint4*>(o) = pack16(acc[i], T{});
+        *reinterpret_cast<raw16*>(o) = pack16(acc[i], T{});
       } else {
         o[0] = from_f32<T>(acc[i][0]);
       }
     }
   }
+}
+
+// ---- convert_boxes_to_pooler_format (poolers.py:62-104) in one launch, no host sync -----------------
+struct ImgEnds { int n; int end[D2AMD_POOLER_MAX_IMAGES]; };  // exclusive prefix ends of the per-image box counts
+__global__ void boxes_to_rois_kernel(const float* __restrict__ boxes, int K, int width, ImgEnds e,
+                                     float* __restrict__ rois) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  int b = 0;
+  for (int i = 0; i < e.n; i++) b += (k >= e.end[i]) ? 1 : 0;
+  float* o = rois + (long)k * (width + 1);
+  o[0] = (float)b;
+  for (int c = 0; c < width; c++) o[1 + c] = boxes[(long)k * width + c];
 }
 
 // ---- host side ------------------------------------------------------------------------------------
@@ -441,6 +617,8 @@ static PoolLevels make_levels(const d2amd_pooler_params* p, const void* const* d
   L.sr = p->sampling_ratio; L.aligned = p->aligned; L.K = K;
   L.min_level = p->min_level; L.max_level = p->max_level; L.canonical_level = p->canonical_level;
   L.canonical_size = p->canonical_box_size;
+  { const char* e = getenv("D2AMD_ABLATE"); L.ablate = e ? atoi(e) : 0; }
+  L.dbg = nullptr; L.dbg_block = -1;
   int base = 0;
   for (int l = 0; l < p->num_levels; l++) {
     L.data[l] = data[l]; L.H[l] = p->H[l]; L.W[l] = p->W[l]; L.scale[l] = p->spatial_scale[l];
@@ -491,31 +669,144 @@ static int pool_fwd_impl(const d2amd_pooler_params* p, const void* const* inputs
   return D2AMD_OK;
 }
 
+// one side stream + fork/join events per device, created on first use (never destroyed: process lifetime)
+struct SideStream { hipStream_t stream; hipEvent_t fork, join; };
+static SideStream* side_stream() {
+  static SideStream table[64];
+  static bool made[64] = {};
+  static const bool off = getenv("D2AMD_NO_SIDE_STREAM") != nullptr;
+  int dev = 0;
+  if (off || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!made[dev]) {
+    SideStream t{};
+    if (hipStreamCreateWithFlags(&t.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&t.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+    table[dev] = t;
+    made[dev] = true;
+  }
+  return &table[dev];
+}
+
+// levels with at most this many tiles take the GROUPS > 1 kernel (few tiles <=> long ROI lists)
+constexpr int COARSE_TILES = 512;
+
+template <typename T, int VEC, int GROUPS, int RS>
+static void launch_bwd(const PoolLevels& L, const RoiRec* rec, const void* gout, int nslab, long total,
+                       hipStream_t s) {
+  const int grid = (int)((total + 7) / 8) * 8;
+  hipLaunchKernelGGL((pool_bwd_nhwc_kernel<T, VEC, GROUPS, RS, 8>), dim3(grid), dim3(CT * RS * GROUPS), 0, s, L, rec,
+                     (const T*)gout, nslab, (int)total);
+}
+
 template <typename T>
 static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_output, const float* rois,
-                              void* const* grad_inputs, int K, hipStream_t s) {
-  const PoolLevels L = make_levels(p, (const void* const*)grad_inputs, K);
+                              void* const* grad_inputs, int K, void* workspace, size_t workspace_bytes,
+                              hipStream_t s) {
   constexpr int VEC = V16<T>::N;
   const bool vec = (p->C % VEC == 0) && all_aligned16((const void* const*)grad_inputs, p->num_levels, grad_output);
   const int cg = vec ? p->C / VEC : p->C;
   const int nslab = cdiv(cg, LPP);
-  const long total = (long)L.tile_base[POOL_MAX_LEVELS] * nslab;
-  if (total == 0) return D2AMD_OK;
-  D2_CHECK_ARG(total < (1l << 30), "roi_pooler_backward: too many tiles");
-  const int grid = (int)((total + 7) / 8) * 8;
-  if (vec)
-    hipLaunchKernelGGL((pool_bwd_nhwc_kernel<T, VEC>), dim3(grid), dim3(POOL_THREADS), 0, s, L, rois,
-                       (const T*)grad_output, nslab, (int)total);
-  else
-    hipLaunchKernelGGL((pool_bwd_nhwc_kernel<T, 1>), dim3(grid), dim3(POOL_THREADS), 0, s, L, rois,
-                       (const T*)grad_output, nslab, (int)total);
-  D2_LAUNCH_OK();
+  const size_t need = (size_t)(K > 0 ? K : 1) * sizeof(RoiRec);
+  if (workspace == nullptr || workspace_bytes < need) {
+    set_error("roi_pooler_backward: workspace too small (%zu < %zu)", workspace_bytes, need);
+    return D2AMD_EWORKSPACE;
+  }
+  RoiRec* rec = (RoiRec*)workspace;
+  if (K > 0) {
+    const PoolLevels L0 = make_levels(p, (const void* const*)grad_inputs, K);
+    hipLaunchKernelGGL(roi_records_kernel, dim3(cdiv(K, 256)), dim3(256), 0, s, L0, rois, rec);
+    D2_LAUNCH_OK();
+  }
+  // profiling switches: D2AMD_BWD_CFG = "<fine GROUPS><fine RS><coarse GROUPS><coarse RS>", e.g. 1122
+  static const int cfg = getenv("D2AMD_BWD_CFG") ? atoi(getenv("D2AMD_BWD_CFG")) : 1222;
+  const int fg = cfg / 1000 % 10, fr = cfg / 100 % 10, cgp = cfg / 10 % 10, cr = cfg % 10;
+  // The coarse-level launch has few, long-running workgroups (latency bound) and the fine-level one
+  // fills the chip at 16 waves / CU: they overlap on a library-owned side stream (fork / join with
+  // events; both only read `rec` and dY and write disjoint grad tensors).
+  SideStream* side = side_stream();
+  bool forked = false;
+  for (int pass = 1; pass >= 0; pass--) {  // pass 1: coarse levels (side stream), pass 0: fine levels
+    PoolLevels L = make_levels(p, (const void* const*)grad_inputs, K);
+    int base = 0;
+    for (int l = 0; l < p->num_levels; l++) {
+      const int tiles = cdiv(p->H[l], TILE) * cdiv(p->W[l], TILE) * p->N;
+      const bool coarse = tiles <= COARSE_TILES;
+      L.tile_base[l] = base;
+      if (coarse == (pass == 1)) base += tiles;
+    }
+    for (int l = p->num_levels; l <= POOL_MAX_LEVELS; l++) L.tile_base[l] = base;
+    const long total = (long)base * nslab;
+    if (total == 0) continue;
+    D2_CHECK_ARG(total < (1l << 30), "roi_pooler_backward: too many tiles");
+    hipStream_t ls = s;
+    if (pass == 1 && side) {
+      D2_HIP_OK(hipEventRecord(side->fork, s));
+      D2_HIP_OK(hipStreamWaitEvent(side->stream, side->fork, 0));
+      ls = side->stream;
+      forked = true;
+    }
+#ifdef D2AMD_PROFILE
+    static unsigned long long* dbg_dev = nullptr;
+    if (getenv("D2AMD_DBG_BLOCK")) {
+      if (!dbg_dev) (void)hipMalloc(&dbg_dev, 128 * 8);
+      (void)hipMemsetAsync(dbg_dev, 0, 128 * 8, ls);
+      L.dbg = dbg_dev;
+      L.dbg_block = (pass == atoi(getenv("D2AMD_DBG_PASS") ? getenv("D2AMD_DBG_PASS") : "0")) ? atoi(getenv("D2AMD_DBG_BLOCK")) : -1;
+    }
+#endif
+    const int g = pass == 0 ? fg : cgp, r = pass == 0 ? fr : cr;
+    if (!vec) {
+      if (g == 1) launch_bwd<T, 1, 1, 1>(L, rec, grad_output, nslab, total, ls);
+      else launch_bwd<T, 1, 2, 1>(L, rec, grad_output, nslab, total, ls);
+    } else if (g == 1 && r == 1) launch_bwd<T, VEC, 1, 1>(L, rec, grad_output, nslab, total, ls);
+    else if (g == 1 && r == 2) launch_bwd<T, VEC, 1, 2>(L, rec, grad_output, nslab, total, ls);
+    else if (g == 2 && r == 1) launch_bwd<T, VEC, 2, 1>(L, rec, grad_output, nslab, total, ls);
+    else if (g == 2 && r == 2) launch_bwd<T, VEC, 2, 2>(L, rec, grad_output, nslab, total, ls);
+    else if (g == 4 && r == 1) launch_bwd<T, VEC, 4, 1>(L, rec, grad_output, nslab, total, ls);
+    else { set_error("roi_pooler_backward: bad D2AMD_BWD_CFG %d", cfg); return D2AMD_EINVAL; }
+    D2_LAUNCH_OK();
+    if (pass == 1 && forked) D2_HIP_OK(hipEventRecord(side->join, side->stream));
+#ifdef D2AMD_PROFILE
+    if (L.dbg && L.dbg_block >= 0) {
+      unsigned long long h[128];
+      (void)hipStreamSynchronize(ls);
+      (void)hipMemcpy(h, L.dbg, sizeof(h), hipMemcpyDeviceToHost);
+      fprintf(stderr, "[d2amd dbg] pass %d block %d realtime(100MHz) %llu cycles %llu -> %.0f MHz; stamps %llu:", pass,
+              L.dbg_block, h[126], h[125], h[126] ? 100.0 * (double)h[125] / (double)h[126] : 0.0, h[127]);
+      for (unsigned i = 1; i < h[127] && i < 120; i++) fprintf(stderr, " %llu", h[i] - h[i - 1]);
+      fprintf(stderr, "\n");
+    }
+#endif
+  }
+  if (forked) D2_HIP_OK(hipStreamWaitEvent(s, side->join, 0));
   return D2AMD_OK;
 }
 
 }  // namespace d2amd
 
 using namespace d2amd;
+
+extern "C" int d2amd_boxes_to_rois(const float* boxes, const int* counts, int num_images, int width, float* rois,
+                                   void* stream) {
+  D2_CHECK_ARG(num_images >= 0 && num_images <= D2AMD_POOLER_MAX_IMAGES, "boxes_to_rois: %d images (max %d)",
+               num_images, D2AMD_POOLER_MAX_IMAGES);
+  D2_CHECK_ARG(width == 4 || width == 5, "boxes_to_rois: box width %d", width);
+  ImgEnds e{};
+  e.n = num_images;
+  long K = 0;
+  for (int i = 0; i < num_images; i++) {
+    D2_CHECK_ARG(counts && counts[i] >= 0, "boxes_to_rois: bad count");
+    K += counts[i];
+    e.end[i] = (int)K;
+  }
+  if (K == 0) return D2AMD_OK;
+  D2_CHECK_ARG(boxes && rois && K < (1l << 31), "boxes_to_rois: null pointer / too many boxes");
+  hipLaunchKernelGGL(boxes_to_rois_kernel, dim3(cdiv(K, 256)), dim3(256), 0, (hipStream_t)stream, boxes, (int)K, width,
+                     e, rois);
+  D2_LAUNCH_OK();
+  return D2AMD_OK;
+}
 
 extern "C" int d2amd_roi_pooler_supported(const d2amd_pooler_params* p, int backward) {
   if (check_pooler(p, "roi_pooler_supported")) return 0;
@@ -543,8 +834,11 @@ extern "C" int d2amd_roi_pooler_forward(const d2amd_pooler_params* p, const void
   });
 }
 
+extern "C" size_t d2amd_roi_pooler_workspace_bytes(int K) { return (size_t)(K > 0 ? K : 1) * sizeof(RoiRec); }
+
 extern "C" int d2amd_roi_pooler_backward(const d2amd_pooler_params* p, const void* grad_output, const float* rois,
-                                         void* const* grad_inputs, int K, void* stream) {
+                                         void* const* grad_inputs, int K, void* workspace, size_t workspace_bytes,
+                                         void* stream) {
   int rc = check_pooler(p, "roi_pooler_backward");
   if (rc) return rc;
   D2_CHECK_ARG(K >= 0, "roi_pooler_backward: bad K");
@@ -556,6 +850,7 @@ extern "C" int d2amd_roi_pooler_backward(const d2amd_pooler_params* p, const voi
   }
   if ((long)p->N * p->C == 0) return D2AMD_OK;
   return D2_DISPATCH_DTYPE(p->dtype, [&]() -> int {
-    return pool_bwd_nhwc_impl<scalar_t>(p, grad_output, rois, grad_inputs, K, (hipStream_t)stream);
+    return pool_bwd_nhwc_impl<scalar_t>(p, grad_output, rois, grad_inputs, K, workspace, workspace_bytes,
+                                        (hipStream_t)stream);
   });
 }

@@ -79,7 +79,7 @@ def _dcn_forward(x, offset, mask, weight, bias, stride, padding, dilation, group
     out = x_.new_empty(out_size)
     p = _params(x_, weight_, stride, padding, dilation, groups, deformable_groups)
     L = _C.lib()
-    with torch.cuda.device(x_.device):
+    with _C.on_device(x_.device):
         ws_bytes = L.d2amd_deform_conv_workspace_bytes(ctypes.byref(p), 0)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x_.device)
         _C.check(L.d2amd_deform_conv_forward(ctypes.byref(p), _C.ptr(x_), _C.ptr(offset_), _C.ptr(mask_),
@@ -100,7 +100,7 @@ def _dcn_backward(x, offset, mask, weight, grad_output, stride, padding, dilatio
     gb = x_.new_empty(weight_.shape[0]) if with_bias else None
     p = _params(x_, weight_, stride, padding, dilation, groups, deformable_groups)
     L = _C.lib()
-    with torch.cuda.device(x_.device):
+    with _C.on_device(x_.device):
         ws_bytes = L.d2amd_deform_conv_workspace_bytes(ctypes.byref(p), 1)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x_.device)
         _C.check(L.d2amd_deform_conv_backward(

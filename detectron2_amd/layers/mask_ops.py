@@ -36,7 +36,7 @@ def paste_masks_in_image(masks: torch.Tensor, boxes, image_shape: Tuple[int, int
     m = m.contiguous()
     b = boxes.detach().float().contiguous()
     out = torch.empty((N, img_h, img_w), dtype=torch.uint8, device=m.device)
-    with torch.cuda.device(m.device):
+    with _C.on_device(m.device):
         _C.check(_C.lib().d2amd_paste_masks(_C.ptr(m), _C.ptr(b), N, m.shape[1], m.shape[2], img_h, img_w,
                                             float(threshold), _C.ptr(out), _C.dtype_code(m), _C.stream()))
     return out.view(torch.bool) if threshold >= 0 else out

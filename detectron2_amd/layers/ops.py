@@ -40,7 +40,7 @@ def nms_impl(boxes, scores, idxs, iou_threshold, rotated):
             # (one extra host sync, only for very large inputs)
             max_per_class = int(torch.unique(idxs, return_counts=True)[1].max().item())
     L = _C.lib()
-    with torch.cuda.device(boxes.device):
+    with _C.on_device(boxes.device):
         ws_bytes = L.d2amd_nms_workspace_bytes(n, max_per_class, int(rotated))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=boxes.device)
         keep = torch.empty(n, dtype=torch.int64, device=boxes.device)
@@ -67,7 +67,7 @@ def _box_iou_rotated(boxes1, boxes2):
     n, m = b1.shape[0], b2.shape[0]
     out = torch.empty((n, m), dtype=torch.float32, device=b1.device)  # always fp32 (box_iou_rotated_cpu.cpp:29)
     if n and m:
-        with torch.cuda.device(b1.device):
+        with _C.on_device(b1.device):
             _C.check(_C.lib().d2amd_box_iou_rotated(_C.ptr(b1), n, _C.ptr(b2), m, _C.ptr(out), _C.stream()))
     return out
 
@@ -83,7 +83,7 @@ def _roi_align_rotated_forward(input, rois, spatial_scale, pooled_height, pooled
     if out.numel() == 0:
         return out
     status = torch.zeros(1, dtype=torch.int32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _C.on_device(x.device):
         _C.check(_C.lib().d2amd_roi_align_rotated_forward(
             _C.ptr(x), _C.ptr(r), _C.ptr(out), n, c, h, w, k, pooled_height, pooled_width, float(spatial_scale),
             int(sampling_ratio), _C.dtype_code(x), layout, _C.ptr(status), _C.stream()))
@@ -105,7 +105,7 @@ def _roi_align_rotated_backward(grad, rois, spatial_scale, pooled_height, pooled
     if g.dtype != torch.float32:
         ws = torch.empty(gin.numel(), dtype=torch.float32, device=g.device)
         ws_bytes = ws.numel() * 4
-    with torch.cuda.device(g.device):
+    with _C.on_device(g.device):
         _C.check(_C.lib().d2amd_roi_align_rotated_backward(
             _C.ptr(g), _C.ptr(r), _C.ptr(gin), batch_size, channels, height, width, r.shape[0], pooled_height,
             pooled_width, float(spatial_scale), int(sampling_ratio), _C.dtype_code(g), layout, _C.ptr(ws),

@@ -45,7 +45,7 @@ class _ROIAlign(Function):
         n, c, h, w = x.shape
         k = rois.shape[0]
         out = _empty_like_layout(x, (k, c, ph, pw), layout)
-        with torch.cuda.device(x.device):
+        with _C.on_device(x.device):
             _C.check(_C.lib().d2amd_roi_align_forward(
                 _C.ptr(x), _C.ptr(rois), _C.ptr(out), n, c, h, w, k, ph, pw, float(spatial_scale),
                 int(sampling_ratio), int(bool(aligned)), _C.dtype_code(x), layout, _C.stream()))
@@ -66,10 +66,14 @@ class _ROIAlign(Function):
             g = grad_output.contiguous()
         gin = _empty_like_layout(g, shape, layout)
         ws, ws_bytes = None, 0
-        if g.dtype != torch.float32:
+        fused = layout == _C.NHWC and max(ph, pw) <= 32  # tile-gather backward: no fp32 staging buffer
+        if fused:
+            ws_bytes = 48 * max(k, 1)  # per-ROI records
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=g.device)
+        elif g.dtype != torch.float32:
             ws = torch.empty(n * c * h * w, dtype=torch.float32, device=g.device)
             ws_bytes = ws.numel() * 4
-        with torch.cuda.device(g.device):
+        with _C.on_device(g.device):
             _C.check(_C.lib().d2amd_roi_align_backward(
                 _C.ptr(g), _C.ptr(rois), _C.ptr(gin), n, c, h, w, k, ph, pw, scale, sr, int(aligned),
                 _C.dtype_code(g), layout, _C.ptr(ws), ws_bytes, _C.stream()))

@@ -43,15 +43,39 @@ def assign_boxes_to_levels(box_lists, min_level: int, max_level: int, canonical_
 
 
 def convert_boxes_to_pooler_format(box_lists):
-    """(M, 5) [batch index, x0, y0, x1, y1] (or (M, 6) for rotated boxes), poolers.py:74-104."""
+    """(M, 5) [batch index, x0, y0, x1, y1] (or (M, 6) for rotated boxes), poolers.py:74-104.
+    On HIP tensors this is one torch.cat plus one kernel launch and -- unlike the reference's
+    torch.repeat_interleave -- never synchronises with the host."""
     tensors = [b.tensor if hasattr(b, "tensor") else b for b in box_lists]
-    boxes = torch.cat(tensors, dim=0)
+    boxes = torch.cat(tensors, dim=0) if len(tensors) != 1 else tensors[0]
+    n_img, width = len(tensors), boxes.shape[1]
+    if boxes.is_cuda and boxes.dtype == torch.float32 and n_img <= 64 and width in (4, 5):
+        boxes = boxes.detach().contiguous()
+        rois = torch.empty((boxes.shape[0], width + 1), dtype=torch.float32, device=boxes.device)
+        counts = (ctypes.c_int * n_img)(*[int(t.shape[0]) for t in tensors])
+        with _C.on_device(boxes.device):
+            _C.check(_C.lib().d2amd_boxes_to_rois(_C.ptr(boxes), counts, n_img, width, _C.ptr(rois), _C.stream()))
+        return rois
     sizes = torch.tensor([len(t) for t in tensors], device=boxes.device)
     indices = torch.repeat_interleave(torch.arange(len(sizes), dtype=boxes.dtype, device=boxes.device), sizes)
     return torch.cat([indices[:, None], boxes], dim=1)
 
 
+_PARAMS_CACHE = {}
+
+
 def _params(cfg, feats_shape, hw, dtype_code, layout):
+    key = (cfg, feats_shape, tuple(hw), dtype_code, layout)
+    p = _PARAMS_CACHE.get(key)
+    if p is not None:
+        return p
+    p = _PARAMS_CACHE[key] = _build_params(cfg, feats_shape, hw, dtype_code, layout)
+    if len(_PARAMS_CACHE) > 256:
+        _PARAMS_CACHE.clear()
+    return p
+
+
+def _build_params(cfg, feats_shape, hw, dtype_code, layout):
     out_hw, scales, sr, aligned, min_level, max_level, canon_size, canon_level = cfg
     p = _C.PoolerParams()
     p.num_levels = len(scales)
@@ -87,7 +111,7 @@ class _FusedROIPool(Function):
         ph, pw = cfg[0]
         mf = torch.channels_last if layout == _C.NHWC else torch.contiguous_format
         out = torch.empty((k, c, ph, pw), dtype=xs[0].dtype, device=xs[0].device, memory_format=mf)
-        with torch.cuda.device(xs[0].device):
+        with _C.on_device(xs[0].device):
             _C.check(_C.lib().d2amd_roi_pooler_forward(ctypes.byref(p), _ptr_array(xs), _C.ptr(rois), _C.ptr(out), k,
                                                        _C.stream()))
         ctx.save_for_backward(rois)
@@ -106,9 +130,11 @@ class _FusedROIPool(Function):
             grads = [torch.empty((n, c, h, w), dtype=g.dtype, device=g.device, memory_format=torch.channels_last)
                      for (h, w) in hw]
             p = _params(cfg, (n, c), hw, _C.dtype_code(g), layout)
-            with torch.cuda.device(g.device):
+            ws_bytes = 48 * max(k, 1)  # d2amd_roi_pooler_workspace_bytes(k): per-ROI records
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=g.device)
+            with _C.on_device(g.device):
                 _C.check(_C.lib().d2amd_roi_pooler_backward(ctypes.byref(p), _C.ptr(g), _C.ptr(rois),
-                                                            _ptr_array(grads), k, _C.stream()))
+                                                            _ptr_array(grads), k, _C.ptr(ws), ws_bytes, _C.stream()))
         else:
             # NCHW: the reference's per-level structure on the atomic kernels
             out_hw, scales, sr, aligned, min_level, max_level, canon_size, canon_level = cfg
@@ -126,7 +152,7 @@ class _FusedROIPool(Function):
                 if g.dtype != torch.float32:
                     ws = torch.empty(gin.numel(), dtype=torch.float32, device=g.device)
                     ws_bytes = ws.numel() * 4
-                with torch.cuda.device(g.device):
+                with _C.on_device(g.device):
                     _C.check(_C.lib().d2amd_roi_align_backward(
                         _C.ptr(gl), _C.ptr(rl), _C.ptr(gin), n, c, h, w, rl.shape[0], out_hw[0], out_hw[1], float(s),
                         int(sr), int(aligned), _C.dtype_code(g), _C.NCHW, _C.ptr(ws), ws_bytes, _C.stream()))
@@ -198,7 +224,9 @@ class ROIPooler(nn.Module):
             cfg = (tuple(self.output_size), tuple(self.scales), int(self.sampling_ratio),
                    self.pooler_type == "ROIAlignV2", self.min_level, self.max_level, self.canonical_box_size,
                    self.canonical_level)
-            return _FusedROIPool.apply(pooler_fmt_boxes.detach().float().contiguous(), cfg, *x)
+            if pooler_fmt_boxes.dtype != torch.float32:
+                pooler_fmt_boxes = pooler_fmt_boxes.float()
+            return _FusedROIPool.apply(pooler_fmt_boxes.detach(), cfg, *x)
         if num_level_assignments == 1:
             return self.level_poolers[0](x[0], pooler_fmt_boxes)
         # reference structure (poolers.py:247-263)

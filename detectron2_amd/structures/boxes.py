@@ -41,7 +41,7 @@ def _pairwise(boxes1, boxes2, mode):
     n, m = b1.shape[0], b2.shape[0]
     out = torch.empty((n, m), dtype=torch.float32, device=b1.device)
     if n and m:
-        with torch.cuda.device(b1.device):
+        with _C.on_device(b1.device):
             _C.check(_C.lib().d2amd_pairwise_iou(_C.ptr(b1), n, _C.ptr(b2), m, mode, _C.ptr(out), _C.stream()))
     return out
 

@@ -53,8 +53,8 @@ int d2amd_roi_align_forward(const void* input, const float* rois, void* output, 
                             float spatial_scale, int sampling_ratio, int aligned, int dtype,
                             int layout, void* stream);
 /* grad_input [N,C,H,W] is fully overwritten (zero-filled then accumulated).  For 16-bit
- * dtypes `workspace` must hold N*C*H*W floats (fp32 accumulation, converted once); for fp32
- * it may be NULL. */
+ * dtypes on the NCHW path `workspace` must hold N*C*H*W floats (fp32 accumulation, converted
+ * once); the NHWC path (pooled size <= 32) needs d2amd_roi_pooler_workspace_bytes(K) instead. */
 int d2amd_roi_align_backward(const void* grad_output, const float* rois, void* grad_input,
                              int N, int C, int H, int W, int K, int pooled_h, int pooled_w,
                              float spatial_scale, int sampling_ratio, int aligned, int dtype,
@@ -68,11 +68,19 @@ int d2amd_roi_align_backward(const void* grad_output, const float* rois, void* g
  * when num_levels == 1).  rois [K,5] fp32 (batch index, x1, y1, x2, y2) in image coordinates;
  * inputs[l] is [N,C,H[l],W[l]] in `dtype`/`layout`; output [K,C,pooled_h,pooled_w], same layout
  * convention.  `inputs` / `grad_inputs` are HOST arrays of num_levels device pointers.
- * Backward (NHWC only) overwrites every element of every grad_inputs[l]; it uses no atomics and
- * no workspace and is deterministic.  d2amd_roi_pooler_supported tells whether the fused
+ * Backward (NHWC only) overwrites every element of every grad_inputs[l]; it uses no atomics, no
+ * fp32 staging buffer (only d2amd_roi_pooler_workspace_bytes(K) of per-ROI records) and is
+ * deterministic.  d2amd_roi_pooler_supported tells whether the fused
  * kernels serve a configuration (pooled size <= 32; backward: NHWC); otherwise loop over the
  * levels with d2amd_roi_align_forward/backward as the reference does. */
 #define D2AMD_POOLER_MAX_LEVELS 8
+#define D2AMD_POOLER_MAX_IMAGES 64
+/* convert_boxes_to_pooler_format (poolers.py:62-104) in one launch and without the host sync of
+ * torch.repeat_interleave: boxes [K,width] (width 4: xyxy, 5: rotated), the K boxes of image 0 first,
+ * then image 1, ...; counts (host) [num_images] boxes per image -> rois [K,width+1] with the batch
+ * index in column 0. */
+int d2amd_boxes_to_rois(const float* boxes, const int* counts, int num_images, int width, float* rois,
+                        void* stream);
 typedef struct d2amd_pooler_params {
   int num_levels, N, C;
   int H[D2AMD_POOLER_MAX_LEVELS], W[D2AMD_POOLER_MAX_LEVELS];
@@ -84,8 +92,10 @@ typedef struct d2amd_pooler_params {
 int d2amd_roi_pooler_supported(const d2amd_pooler_params* p, int backward);
 int d2amd_roi_pooler_forward(const d2amd_pooler_params* p, const void* const* inputs, const float* rois,
                              void* output, int K, void* stream);
+size_t d2amd_roi_pooler_workspace_bytes(int K); /* backward: per-ROI records (48 B each) */
 int d2amd_roi_pooler_backward(const d2amd_pooler_params* p, const void* grad_output, const float* rois,
-                              void* const* grad_inputs, int K, void* stream);
+                              void* const* grad_inputs, int K, void* workspace, size_t workspace_bytes,
+                              void* stream);
 
 /* ---- ROIAlignRotated.  Replaces torch.ops.detectron2.roi_align_rotated_forward/backward
  * (vision.cpp:118-119; csrc/ROIAlignRotated/ROIAlignRotated.h:50-113).

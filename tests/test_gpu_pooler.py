@@ -61,10 +61,12 @@ def oracle_pooler(feats, boxes, out, sr, aligned, grad=None):
 @pytest.mark.parametrize("out,sr,ptype", [(7, 0, "ROIAlignV2"), (14, 2, "ROIAlignV2"), (7, 0, "ROIAlign")])
 def test_fused_pooler_fp32_vs_oracle(layout, out, sr, ptype):
     rng = np.random.default_rng(out * 31 + sr)
-    feats, boxes = make_inputs(rng, 2, 8, 160, 224, 40)
-    boxes[0][0] = [0, 0, 224, 160]      # whole image -> top level, large sampling grid
+    feats, boxes = make_inputs(rng, 2, 8, 512, 640, 40)
+    boxes[0][0] = [0, 0, 640, 512]      # whole image -> top level, large sampling grid
     boxes[0][1] = [10, 10, 10, 10]      # empty box
     boxes[1][0] = [100, 50, 101.5, 52]  # tiny box: many bins per pixel
+    boxes[1][1] = [30, 40, 300, 290]    # level 4
+    boxes[1][2] = [5, 5, 150, 140]      # level 3
     aligned = ptype == "ROIAlignV2"
     pooler = ROIPooler(out, SCALES, sr, ptype)
     xs = [torch.from_numpy(f).to(DEV).requires_grad_(True) for f in feats]
