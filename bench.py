@@ -249,6 +249,23 @@ def cpu_baseline(w):
             "host_cores_available": os.cpu_count()}
 
 
+def pmc_traffic(op, layout):
+    """HBM bytes per launch of the op's kernels from the committed rocprofv3 PMC passes
+    (profiles/<round>/pmc_traffic_<layout>.json, written by scripts/pmc_summary.py from separate
+    FETCH_SIZE / WRITE_SIZE runs, gfx950 FETCH_SIZE x2 correction applied there); None if absent."""
+    import glob
+
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_traffic_{layout}.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if op in d.get("ops", {}):
+            best = d["ops"][op].get("hbm_bytes_per_launch")
+    return best
+
+
 # ------------------------------------------------------------------------------------ main
 def main():
     args = parse()
@@ -292,10 +309,19 @@ def main():
                 e["GBps"] = round(alg[k] / 1e9 / (per_step_ms / 1e3), 1)
                 e["frac_hbm_peak"] = round(e["GBps"] / HBM_PEAK_GBS, 4)
             ops[k] = e
-        dom = max((k for k in ops if k in alg), key=lambda k: ops[k]["ms_per_step"])
-        roof = {"bound": "hbm", "kernel": dom, "achieved": ops[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ops[dom]["frac_hbm_peak"], "traffic": None,
-                "alg_bytes_per_step": alg[dom], "ms_per_step": ops[dom]["ms_per_step"]}
+        counts = {k: v // args.steps for k, v in timer.counts().items()}
+        for k in ops:
+            ops[k]["launches_per_step"] = counts[k]
+            ops[k]["ms_per_launch"] = round(ops[k]["ms_per_step"] / counts[k], 4)
+        # dominant op = longest single launch among the HBM-bound ops (SURVEY 8d roofline classes)
+        dom = max((k for k in ops if k in alg and alg[k] > 4e6), key=lambda k: ops[k]["ms_per_launch"])
+        per_launch_bytes = alg[dom] / counts[dom]
+        achieved = per_launch_bytes / 1e9 / (ops[dom]["ms_per_launch"] / 1e3)
+        roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, args.layout),
+                "alg_bytes_per_launch": int(per_launch_bytes), "ms_per_launch": ops[dom]["ms_per_launch"],
+                "timing": "HIP events on the launch stream around the op (kernel + its fork/join), mean over the "
+                          "timed steps"}
         gpu_ms = sum(v["ms_per_step"] for v in ops.values())
         out = {
             "metric": "img/s through the Mask R-CNN R50-FPN detection hot path (training ops), 1333x800 bs=2/GPU",
@@ -305,7 +331,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "maskrcnn_r50fpn_train_hotpath_bs2_800x1344 (BASELINE configs[1])",
                        "layout": args.layout, "global_batch": world * w.n_img,
-                       "ops_per_step": timer.counts() and {k: v // args.steps for k, v in timer.counts().items()},
+                       "ops_per_step": counts,
                        "parallelism": f"dp{world} (images sharded, no data-path collective)"},
             "roofline": roof, "gpu_ms_per_step_sum_of_ops": round(gpu_ms, 4), "ops": ops,
         }

@@ -60,13 +60,15 @@ class _ROIAlign(Function):
         ph, pw, scale, sr, aligned, shape, layout = ctx.cfg
         n, c, h, w = shape
         k = rois.shape[0]
+        fused = max(ph, pw) <= 32  # tile-gather backward (NHWC kernel; NCHW inputs get channels_last grads)
+        if fused:
+            layout = _C.NHWC
         if layout == _C.NHWC:
             g = grad_output.contiguous(memory_format=torch.channels_last)
         else:
             g = grad_output.contiguous()
         gin = _empty_like_layout(g, shape, layout)
         ws, ws_bytes = None, 0
-        fused = layout == _C.NHWC and max(ph, pw) <= 32  # tile-gather backward: no fp32 staging buffer
         if fused:
             ws_bytes = 48 * max(k, 1)  # per-ROI records
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=g.device)
