@@ -1,0 +1,115 @@
+// Shared pieces of the deformable-convolution kernels (deform_conv.hip: generic / fp32 path,
+// deform_conv_tc.hip: 16-bit fragment-ordered MFMA path).
+#pragma once
+#include "common.h"
+
+namespace d2amd {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+struct DcnShape {
+  int B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, G, DG, Ho, Wo;
+  int K2, L, P, Cg, Cog, cpg;
+};
+
+static DcnShape make_shape(const d2amd_dcn_params* p) {
+  DcnShape s;
+  s.B = p->B; s.C = p->C; s.H = p->H; s.W = p->W; s.Co = p->Co; s.kh = p->kh; s.kw = p->kw;
+  s.sh = p->stride_h; s.sw = p->stride_w; s.ph = p->pad_h; s.pw = p->pad_w; s.dh = p->dil_h; s.dw = p->dil_w;
+  s.G = p->groups; s.DG = p->deformable_groups;
+  s.Ho = (s.H + 2 * s.ph - (s.dh * (s.kh - 1) + 1)) / s.sh + 1;
+  s.Wo = (s.W + 2 * s.pw - (s.dw * (s.kw - 1) + 1)) / s.sw + 1;
+  s.K2 = s.kh * s.kw; s.L = s.Ho * s.Wo; s.P = s.B * s.L;
+  s.Cg = s.C / s.G; s.Cog = s.Co / s.G; s.cpg = s.C / s.DG;
+  return s;
+}
+
+// ---- MFMA wrappers per element type ----------------------------------------------------------
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  static constexpr int KSTEP = 16, BK = 64, PAD = 8;
+  typedef bf16x8_t frag;
+  __device__ static __forceinline__ frag load(const bf16_t* row, int s, int lane) {
+    return *reinterpret_cast<const frag*>(row + s * 16 + 8 * (lane >> 5));
+  }
+  __device__ static __forceinline__ f32x16_t mma(frag a, frag b, f32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mma<f16_t> {
+  static constexpr int KSTEP = 16, BK = 64, PAD = 8;
+  typedef f16x8_t frag;
+  __device__ static __forceinline__ frag load(const f16_t* row, int s, int lane) {
+    return *reinterpret_cast<const frag*>(row + s * 16 + 8 * (lane >> 5));
+  }
+  __device__ static __forceinline__ f32x16_t mma(frag a, frag b, f32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  static constexpr int KSTEP = 2, BK = 32, PAD = 4;  // rows stay 16-B aligned for vector stores
+  typedef float frag;
+  __device__ static __forceinline__ frag load(const float* row, int s, int lane) { return row[s * 2 + (lane >> 5)]; }
+  __device__ static __forceinline__ f32x16_t mma(frag a, frag b, f32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+  }
+};
+
+// C/D fragment of a 32x32 MFMA: element r of lane l is (row, col) =
+// ((r & 3) + 8 * (r >> 2) + 4 * (l >> 5), l & 31)
+__device__ __forceinline__ int frag_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// ---- layout kernels ---------------------------------------------------------------------------
+// [B][R][S] -> [B][S][R] (32x32 LDS tiles): NCHW <-> NHWC with R = C, S = H*W.
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void transpose_kernel(const TI* __restrict__ in, TO* __restrict__ out, int R, int S) {
+  __shared__ float tile[32][33];
+  const long b = blockIdx.z;
+  const int s0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int j = ty; j < 32; j += 8) {
+    int r = r0 + j, s = s0 + tx;
+    if (r < R && s < S) tile[j][tx] = to_f32(in[(b * R + r) * S + s]);
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    int s = s0 + j, r = r0 + tx;
+    if (r < R && s < S) out[(b * S + s) * R + r] = from_f32<TO>(tile[tx][j]);
+  }
+}
+
+template <typename TI, typename TO>
+static int launch_transpose(const TI* in, TO* out, int B, int R, int S, hipStream_t st) {
+  if ((long)B * R * S == 0) return D2AMD_OK;
+  dim3 grid(cdiv(S, 32), cdiv(R, 32), B);
+  D2_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "deform_conv: tensor too large for transpose grid");
+  hipLaunchKernelGGL((transpose_kernel<TI, TO>), grid, dim3(256), 0, st, in, out, R, S);
+  D2_LAUNCH_OK();
+  return D2AMD_OK;
+}
+
+// ---- 16-bit fragment-ordered MFMA path (deform_conv_tc.hip) ------------------------------------
+struct TcPlan {
+  bool ok;
+  int MT, NWM, NWN, ksplit, BM, BN, n_cot, n_pt, NC64, S, ndg;
+  size_t wp_bytes, partial_bytes, lds;
+};
+TcPlan dcn_tc_plan_fwd(const DcnShape& s, int dtype);
+template <typename T>
+int dcn_tc_forward(const DcnShape& s, const TcPlan& pl, const void* x_nhwc, const void* offset, const void* mask,
+                   const void* weight, const void* bias, void* out, void* wp, float* partial, hipStream_t st);
+
+struct TcBwPlan {
+  bool ok;
+  int tiles_y, tiles_x, R, PHt, PWt;
+  size_t lds, wp_bytes;
+};
+TcBwPlan dcn_tc_plan_bwd(const DcnShape& s, int dtype);
+template <typename T>
+int dcn_tc_backward_data(const DcnShape& s, const TcBwPlan& pl, const void* x_nhwc, const void* offset,
+                         const void* mask, const void* weight, const void* gout_nhwc, float* gx, float* goff,
+                         float* gmask, void* wp, hipStream_t st);
+
+}  // namespace d2amd

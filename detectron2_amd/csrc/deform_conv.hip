@@ -17,94 +17,9 @@
 //     position chunks (fp32 atomics); (3) d(bias) = row sums of dY.
 // Accumulation is fp32 everywhere; column values are rounded to the I/O dtype before the MFMA
 // exactly like the reference's column buffer.
-#include "common.h"
+#include "dcn_common.h"
 
 namespace d2amd {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
-typedef __attribute__((ext_vector_type(16))) float f32x16_t;
-
-struct DcnShape {
-  int B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, G, DG, Ho, Wo;
-  int K2, L, P, Cg, Cog, cpg;
-};
-
-static DcnShape make_shape(const d2amd_dcn_params* p) {
-  DcnShape s;
-  s.B = p->B; s.C = p->C; s.H = p->H; s.W = p->W; s.Co = p->Co; s.kh = p->kh; s.kw = p->kw;
-  s.sh = p->stride_h; s.sw = p->stride_w; s.ph = p->pad_h; s.pw = p->pad_w; s.dh = p->dil_h; s.dw = p->dil_w;
-  s.G = p->groups; s.DG = p->deformable_groups;
-  s.Ho = (s.H + 2 * s.ph - (s.dh * (s.kh - 1) + 1)) / s.sh + 1;
-  s.Wo = (s.W + 2 * s.pw - (s.dw * (s.kw - 1) + 1)) / s.sw + 1;
-  s.K2 = s.kh * s.kw; s.L = s.Ho * s.Wo; s.P = s.B * s.L;
-  s.Cg = s.C / s.G; s.Cog = s.Co / s.G; s.cpg = s.C / s.DG;
-  return s;
-}
-
-// ---- MFMA wrappers per element type ----------------------------------------------------------
-template <typename T> struct Mma;
-template <> struct Mma<bf16_t> {
-  static constexpr int KSTEP = 16, BK = 64, PAD = 8;
-  typedef bf16x8_t frag;
-  __device__ static __forceinline__ frag load(const bf16_t* row, int s, int lane) {
-    return *reinterpret_cast<const frag*>(row + s * 16 + 8 * (lane >> 5));
-  }
-  __device__ static __forceinline__ f32x16_t mma(frag a, frag b, f32x16_t c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-  }
-};
-template <> struct Mma<f16_t> {
-  static constexpr int KSTEP = 16, BK = 64, PAD = 8;
-  typedef f16x8_t frag;
-  __device__ static __forceinline__ frag load(const f16_t* row, int s, int lane) {
-    return *reinterpret_cast<const frag*>(row + s * 16 + 8 * (lane >> 5));
-  }
-  __device__ static __forceinline__ f32x16_t mma(frag a, frag b, f32x16_t c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-  }
-};
-template <> struct Mma<float> {
-  static constexpr int KSTEP = 2, BK = 32, PAD = 4;  // rows stay 16-B aligned for vector stores
-  typedef float frag;
-  __device__ static __forceinline__ frag load(const float* row, int s, int lane) { return row[s * 2 + (lane >> 5)]; }
-  __device__ static __forceinline__ f32x16_t mma(frag a, frag b, f32x16_t c) {
-    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-  }
-};
-
-// C/D fragment of a 32x32 MFMA: element r of lane l is (row, col) =
-// ((r & 3) + 8 * (r >> 2) + 4 * (l >> 5), l & 31)
-__device__ __forceinline__ int frag_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
-
-// ---- layout kernels ---------------------------------------------------------------------------
-// [B][R][S] -> [B][S][R] (32x32 LDS tiles): NCHW <-> NHWC with R = C, S = H*W.
-template <typename TI, typename TO>
-__global__ __launch_bounds__(256) void transpose_kernel(const TI* __restrict__ in, TO* __restrict__ out, int R, int S) {
-  __shared__ float tile[32][33];
-  const long b = blockIdx.z;
-  const int s0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-  for (int j = ty; j < 32; j += 8) {
-    int r = r0 + j, s = s0 + tx;
-    if (r < R && s < S) tile[j][tx] = to_f32(in[(b * R + r) * S + s]);
-  }
-  __syncthreads();
-  for (int j = ty; j < 32; j += 8) {
-    int s = s0 + j, r = r0 + tx;
-    if (r < R && s < S) out[(b * S + s) * R + r] = from_f32<TO>(tile[tx][j]);
-  }
-}
-
-template <typename TI, typename TO>
-static int launch_transpose(const TI* in, TO* out, int B, int R, int S, hipStream_t st) {
-  if ((long)B * R * S == 0) return D2AMD_OK;
-  dim3 grid(cdiv(S, 32), cdiv(R, 32), B);
-  D2_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "deform_conv: tensor too large for transpose grid");
-  hipLaunchKernelGGL((transpose_kernel<TI, TO>), grid, dim3(256), 0, st, in, out, R, S);
-  D2_LAUNCH_OK();
-  return D2AMD_OK;
-}
 
 // weight (Co, Cg, K2) -> wr [g][tap][co][ci]  and  wt [g][tap][ci][co]
 template <typename T>
@@ -585,18 +500,29 @@ static size_t al(size_t x) { return (x + 255) / 256 * 256; }
 struct DcnWs {
   void *x_nhwc, *wr, *wt, *gout_nhwc;
   float *gx, *goff, *gmask, *gwr;
+  int dtype;
+  void* tc_wp;        // fragment-ordered weights of the 16-bit MFMA path
+  float* tc_partial;  // fp32 partial outputs when its reduction is split
+  TcPlan tc;
   size_t total;
 };
 
 static DcnWs carve_ws(const DcnShape& s, int dtype, bool backward, void* base) {
   DcnWs w{};
+  w.dtype = dtype;
   const size_t es = dtype_size(dtype);
   size_t off = 0;
   auto take = [&](size_t bytes) { void* r = base ? (char*)base + off : nullptr; off += al(bytes); return r; };
   w.x_nhwc = take((size_t)s.B * s.H * s.W * s.C * es);
   const size_t wbytes = (size_t)s.Co * s.Cg * s.K2 * es;
   if (!backward) {
-    w.wr = take(wbytes);
+    w.tc = dcn_tc_plan_fwd(s, dtype);
+    if (w.tc.ok) {
+      w.tc_wp = take(w.tc.wp_bytes);
+      w.tc_partial = (float*)take(w.tc.partial_bytes);
+    } else {
+      w.wr = take(wbytes);
+    }
   } else {
     w.wt = take(wbytes);
     w.gout_nhwc = take((size_t)s.P * s.Co * es);
@@ -640,6 +566,10 @@ static int fwd_host(const DcnShape& s, const void* x, const void* offset, const 
   if (s.B == 0) return D2AMD_OK;
   int rc = launch_transpose<T, T>((const T*)x, (T*)w.x_nhwc, s.B, s.C, s.H * s.W, st);
   if (rc) return rc;
+  if constexpr (sizeof(T) == 2) {
+    if (w.tc.ok)
+      return dcn_tc_forward<T>(s, w.tc, w.x_nhwc, offset, mask, weight, bias, out, w.tc_wp, w.tc_partial, st);
+  }
   const long nw = (long)s.Co * s.Cg * s.K2;
   hipLaunchKernelGGL((repack_weight_kernel<T>), dim3(cdiv(nw, 256) > 4096 ? 4096 : cdiv(nw, 256)), dim3(256), 0, st,
                      (const T*)weight, (T*)w.wr, (T*)nullptr, s.G, s.Cog, s.Cg, s.K2);
@@ -671,18 +601,30 @@ static int bwd_host(const DcnShape& s, const void* x, const void* offset, const 
   if (rc) return rc;
   const bool need_data = gin || goffset || (gmask && mask);
   if (need_data) {
-    const long nw = (long)s.Co * s.Cg * s.K2;
-    hipLaunchKernelGGL((repack_weight_kernel<T>), dim3(cdiv(nw, 256) > 4096 ? 4096 : cdiv(nw, 256)), dim3(256), 0, st,
-                       (const T*)weight, (T*)nullptr, (T*)w.wt, s.G, s.Cog, s.Cg, s.K2);
-    D2_LAUNCH_OK();
     rc = launch_transpose<T, T>((const T*)gout, (T*)w.gout_nhwc, s.B, s.Co, s.L, st);
     if (rc) return rc;
     D2_HIP_OK(hipMemsetAsync(w.gx, 0, (size_t)s.B * s.H * s.W * s.C * 4, st));
     float* goff_f = goffset ? (is32 ? (float*)goffset : w.goff) : nullptr;
     float* gmask_f = (gmask && mask) ? (is32 ? (float*)gmask : w.gmask) : nullptr;
+    bool tc_done = false;
+    if constexpr (!is32) {
+      const TcBwPlan bp = dcn_tc_plan_bwd(s, sizeof(T) == 2 ? (int)w.dtype : D2AMD_F32);
+      if (bp.ok) {  // 16-bit MFMA path with the LDS patch (deform_conv_tc.hip); w.wt holds its packed weights
+        rc = dcn_tc_backward_data<T>(s, bp, w.x_nhwc, offset, mask, weight, w.gout_nhwc, w.gx, goff_f, gmask_f, w.wt, st);
+        if (rc) return rc;
+        tc_done = true;
+      }
+    }
+    const long nw = (long)s.Co * s.Cg * s.K2;
+    if (!tc_done) {
+      hipLaunchKernelGGL((repack_weight_kernel<T>), dim3(cdiv(nw, 256) > 4096 ? 4096 : cdiv(nw, 256)), dim3(256), 0,
+                         st, (const T*)weight, (T*)nullptr, (T*)w.wt, s.G, s.Cog, s.Cg, s.K2);
+      D2_LAUNCH_OK();
+    }
     dim3 grid(cdiv(s.P, BW_BN), s.K2, s.DG);
     D2_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "deform_conv: kernel / deformable groups too large");
-    if (vec)
+    if (tc_done) {
+    } else if (vec)
       hipLaunchKernelGGL((dcn_bwd_data_kernel<T, true>), grid, dim3(BW_THREADS), 0, st, s, (const T*)w.x_nhwc,
                          (const T*)offset, (const T*)mask, (const T*)w.wt, (const T*)w.gout_nhwc, w.gx, goff_f, gmask_f);
     else

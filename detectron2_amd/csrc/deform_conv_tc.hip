@@ -1,0 +1,800 @@
+// Deformable convolution v1 / v2, 16-bit (bf16 / f16) MFMA path for gfx950 -- forward.
+// Replaces detectron2/layers/csrc/deformable/deform_conv_cuda.cu:272-440,826-1004 (im2col to an HBM
+// column buffer + at::addmm_ per image) for the shapes of BASELINE config 5 (R50 res3-res5 3x3 DCN).
+//
+// Why this shape of kernel (numbers for res3: C = Co = 128, P = 2*100*168 positions, bf16):
+//   * the dense contraction is 9.9 GFLOP = 4 us of MFMA; the deformable gather is 4 corners x 9 taps x
+//     C channels per position = 310 MB of L2 reads and ~70 VALU per (position, 8 channels): the
+//     kernel is bound by the gather's VALU + L1 rate, not by the matrix pipe.  So the gather is done
+//     exactly ONCE per (position, tap, channel) per output-channel tile, with 128-B coalesced
+//     segments, and everything else is arranged so that it costs (almost) no issue slots.
+//   * both MFMA operands live in LDS in FRAGMENT ORDER ([tile][kstep][lane][16 B]): the weight tile
+//     is a straight 16-B copy of a pre-packed global buffer, the gathered column tile is written by
+//     the gathering lane into the slot the consuming lane reads; every ds_read_b128 / ds_write_b128
+//     is bank-conflict free (33-slot pitch between the k-halves, see slot()).
+//   * per-(position, tap) bilinear tables (4 byte offsets + 4 weights with the modulation mask
+//     folded in) are built once per workgroup in LDS and shared by all channel chunks.
+//   * a stage = (tap, 64 input channels).  Global loads of stage s+1 (16-B gathers + weight copy)
+//     are issued before the MFMAs of stage s and land in the other LDS buffer afterwards: one
+//     barrier per stage.
+//   * blockIdx -> tile map is XCD-aware: each XCD gets one contiguous range of position tiles, so
+//     the x pixels its workgroups gather stay in that XCD's 4 MiB L2.
+//   * small feature maps (res5: 2,100 positions) do not fill 256 CUs with output tiles alone:
+//     the (tap, channel) reduction is split over `ksplit` workgroups writing fp32 partials that a
+//     tiny deterministic kernel sums (+ bias, -> 16 bit).
+#include "dcn_common.h"
+
+#include <stdlib.h>
+
+namespace d2amd {
+
+typedef unsigned int raw16 __attribute__((ext_vector_type(4)));
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+
+struct TcEntry {
+  uint32_t off[4];  // byte offset of the corner pixel's channel 0 in x (NHWC); 0 when unused
+  float w[4];       // bilinear weight x modulation mask; 0 for corners / samples outside the image
+};
+static_assert(sizeof(TcEntry) == 32, "TcEntry layout");
+
+struct TcArgs {
+  const void *x, *offset, *mask, *wp, *bias;
+  void* out;
+  float* partial;
+  int n_pt, n_cot, ksplit, NC64, S, total;
+};
+
+constexpr int TC_BPITCH = 4 * 66;  // 16-B slots per 32-position tile of the column buffer
+
+// slot of (n-tile, kstep, k-half, position in tile) in the column buffer
+__device__ __forceinline__ int tc_slot(int ntile, int ks, int half, int n32) {
+  return ntile * TC_BPITCH + ks * 66 + half * 33 + n32;
+}
+
+__device__ __forceinline__ void tc_unpack(const raw16& r, float (&f)[8], bf16_t) {
+  f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
+  f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
+  f[4] = __uint_as_float(r.z << 16); f[5] = __uint_as_float(r.z & 0xffff0000u);
+  f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
+}
+__device__ __forceinline__ void tc_unpack(const raw16& r, float (&f)[8], f16_t) {
+  const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    f[2 * i] = to_f32(f16_t{(uint16_t)(w[i] & 0xffffu)});
+    f[2 * i + 1] = to_f32(f16_t{(uint16_t)(w[i] >> 16)});
+  }
+}
+__device__ __forceinline__ raw16 tc_pack(const float (&f)[8], bf16_t) {
+  raw16 r;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN preserved
+    const f32x2_t v = {f[2 * i], f[2 * i + 1]};
+    r[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+  }
+  return r;
+}
+__device__ __forceinline__ raw16 tc_pack(const float (&f)[8], f16_t) {
+  raw16 r;
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+    r[i] = (uint32_t)from_f32<f16_t>(f[2 * i]).v | ((uint32_t)from_f32<f16_t>(f[2 * i + 1]).v << 16);
+  return r;
+}
+
+// bilinear table entry of (position p, tap, deformable group), as deform_conv_cuda_kernel.cu:96-130,
+// 216-270 (v1) / 665-700, 785-860 (v2): sample inside (-1, H) x (-1, W), corners outside contribute 0
+template <typename T>
+__device__ __forceinline__ TcEntry tc_make_entry(const DcnShape& s, const T* __restrict__ offset,
+                                                 const T* __restrict__ mask, int p, int tap, int dgi) {
+  TcEntry e;
+#pragma unroll
+  for (int t = 0; t < 4; t++) { e.off[t] = 0u; e.w[t] = 0.f; }
+  if (p >= s.P) return e;
+  const int b = p / s.L, l = p - b * s.L;
+  const int ho = l / s.Wo, wo = l - ho * s.Wo;
+  const int i = tap / s.kw, j = tap - i * s.kw;
+  const long obase = ((long)b * s.DG + dgi) * 2 * s.K2;
+  const float off_h = to_f32(offset[(obase + 2 * tap) * s.L + l]);
+  const float off_w = to_f32(offset[(obase + 2 * tap + 1) * s.L + l]);
+  const float m = mask ? to_f32(mask[(((long)b * s.DG + dgi) * s.K2 + tap) * s.L + l]) : 1.f;
+  const float h_im = (float)(ho * s.sh - s.ph + i * s.dh) + off_h;
+  const float w_im = (float)(wo * s.sw - s.pw + j * s.dw) + off_w;
+  if (!(h_im > -1.f && w_im > -1.f && h_im < (float)s.H && w_im < (float)s.W)) return e;
+  const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+  const int h_high = h_low + 1, w_high = w_low + 1;
+  const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+  const float hh = 1.f - lh, hw = 1.f - lw;
+  const uint32_t pix = (uint32_t)s.C * (uint32_t)sizeof(T);
+  const long rowbase = (long)b * s.H;
+  if (h_low >= 0 && w_low >= 0) { e.off[0] = (uint32_t)((rowbase + h_low) * s.W + w_low) * pix; e.w[0] = hh * hw * m; }
+  if (h_low >= 0 && w_high <= s.W - 1) { e.off[1] = (uint32_t)((rowbase + h_low) * s.W + w_high) * pix; e.w[1] = hh * lw * m; }
+  if (h_high <= s.H - 1 && w_low >= 0) { e.off[2] = (uint32_t)((rowbase + h_high) * s.W + w_low) * pix; e.w[2] = lh * hw * m; }
+  if (h_high <= s.H - 1 && w_high <= s.W - 1) { e.off[3] = (uint32_t)((rowbase + h_high) * s.W + w_high) * pix; e.w[3] = lh * lw * m; }
+  return e;
+}
+
+// ---- weight packing: (Co, Cg, K2) -> [g][co tile][stage = (tap, c64)][m-tile][kstep][lane][8] -------
+// element j of lane l = W[co = cot*BM + mt*32 + (l & 31)][ci = c64*64 + ks*16 + (l >> 5)*8 + j][tap]
+// (the A operand of v_mfma_f32_32x32x16: lane l holds row l & 31, k = 8*(l >> 5) .. +8); rows >= Cog are 0.
+template <typename T>
+__global__ __launch_bounds__(256) void tc_pack_weight_kernel(const T* __restrict__ w, T* __restrict__ wp, int G,
+                                                            int Cog, int Cg, int K2, int BM, int n_cot, int NC64) {
+  const int S = K2 * NC64, MTA = BM / 32;
+  const long total = (long)G * n_cot * S * MTA * 4 * 64;
+  for (long gi = (long)blockIdx.x * blockDim.x + threadIdx.x; gi < total; gi += (long)gridDim.x * blockDim.x) {
+    long r = gi;
+    const int lane = (int)(r % 64); r /= 64;
+    const int ks = (int)(r % 4); r /= 4;
+    const int mt = (int)(r % MTA); r /= MTA;
+    const int st = (int)(r % S); r /= S;
+    const int cot = (int)(r % n_cot); r /= n_cot;
+    const int g = (int)r;
+    const int tap = st / NC64, c64 = st - tap * NC64;
+    const int co = cot * BM + mt * 32 + (lane & 31);
+    const int ci0 = c64 * 64 + ks * 16 + (lane >> 5) * 8;
+    T v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      v[j] = co < Cog ? w[(((long)g * Cog + co) * Cg + ci0 + j) * K2 + tap] : from_f32<T>(0.f);
+#pragma unroll
+    for (int j = 0; j < 8; j++) wp[gi * 8 + j] = v[j];
+  }
+}
+
+// ---- forward kernel ---------------------------------------------------------------------------------
+// Wave-specialised workgroup: NWM x NWN MATRIX waves (wave (wm, wn) owns output rows
+// (wm*MT .. +MT) * 32 of the BM = 32*MT*NWM row tile and positions wn*32 .. +32 of the BN = 32*NWN
+// position tile; they also copy the weight tile) and NG GATHER waves (bilinear gather of the column
+// tile, (BN*8) / (64*NG) items of (position, 8 channels) per lane and stage).  An in-order wave only
+// overlaps the matrix pipe with VALU when the two alternate in its own instruction stream, which hipcc
+// does not produce for this loop; a matrix wave and a gather wave resident on the same SIMD overlap
+// by construction.  One s_barrier per stage orders column/weight buffer hand-off (double buffered).
+template <typename T, int MT, int NWM, int NWN, int NG>
+__global__ __launch_bounds__(64 * (NWM * NWN + NG)) void dcn_fwd_tc_kernel(DcnShape s, TcArgs a) {
+  typedef Mma<T> M;
+  constexpr int NMW = NWM * NWN, NT = 64 * (NMW + NG), BM = 32 * MT * NWM, BN = 32 * NWN;
+  constexpr int ITEMS = (BN * 8) / (64 * NG);   // gather items per lane and stage
+  constexpr int ACOPY = (BM * 8) / (64 * NMW);  // 16-B weight slots per matrix-wave lane and stage
+  constexpr int ASLOTS = BM * 8, BSLOTS = NWN * TC_BPITCH;
+  static_assert((BN * 8) % (64 * NG) == 0 && (BM * 8) % (64 * NMW) == 0, "tile / thread mismatch");
+  extern __shared__ __attribute__((aligned(16))) unsigned char tc_smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  // XCD-aware decode: XCD x (= blockIdx % 8) works on one contiguous range of logical tiles
+  const int per_xcd = (a.total + 7) >> 3;
+  const int logical = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if (logical >= a.total) return;
+  const int inner = a.n_cot * s.G * a.ksplit;
+  const int pt = logical / inner;
+  int rr = logical - pt * inner;
+  const int cot = rr % a.n_cot; rr /= a.n_cot;
+  const int g = rr % s.G;
+  const int kz = rr / s.G;
+  const int p0 = pt * BN;
+  const int dg_first = (g * s.Cg) / s.cpg, dg_last = ((g + 1) * s.Cg - 1) / s.cpg;
+  const int ndg = dg_last - dg_first + 1;
+  const int nrows = s.K2 * ndg;
+
+  TcEntry* ent = reinterpret_cast<TcEntry*>(tc_smem);
+  raw16* As = reinterpret_cast<raw16*>(tc_smem + (size_t)nrows * BN * sizeof(TcEntry));
+  raw16* Bs = As + 2 * ASLOTS;
+
+  {
+    const T* offset = (const T*)a.offset;
+    const T* mask = (const T*)a.mask;
+    for (int e = tid; e < nrows * BN; e += NT) {
+      const int row = e / BN, n = e - row * BN;
+      const int tap = row / ndg, dgi = dg_first + (row - tap * ndg);
+      ent[e] = tc_make_entry<T>(s, offset, mask, p0 + n, tap, dgi);
+    }
+  }
+  __syncthreads();  // barrier #0: tables ready
+
+  const int s_lo = (int)((long)kz * a.S / a.ksplit), s_hi = (int)((long)(kz + 1) * a.S / a.ksplit);
+  const int nst = s_hi - s_lo;  // >= 1 (ksplit <= S)
+
+  if (wid >= NMW) {
+    // ================================ GATHER waves ================================================
+    const int gt = tid - 64 * NMW;  // thread index among the gather waves
+    const char* xb = (const char*)a.x;
+    raw16 graw[2][ITEMS][4];
+    float gw[2][ITEMS][4];
+    auto issue = [&](int st, raw16 (&raw)[ITEMS][4], float (&w)[ITEMS][4]) __attribute__((always_inline)) {
+      const int tap = st / a.NC64, c64 = st - tap * a.NC64;
+      const int cabs = g * s.Cg + c64 * 64;
+      const TcEntry* er = ent + (tap * ndg + (cabs / s.cpg - dg_first)) * BN;
+#pragma unroll
+      for (int it = 0; it < ITEMS; it++) {
+        const int i = it * (64 * NG) + gt;
+        const int n = i >> 3, sub = i & 7;
+        const raw16 eo = *reinterpret_cast<const raw16*>(&er[n].off[0]);
+        const raw16 ew = *reinterpret_cast<const raw16*>(&er[n].w[0]);
+        const uint32_t cofs = (uint32_t)(cabs + sub * 8) * (uint32_t)sizeof(T);
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          raw[it][c] = *reinterpret_cast<const raw16*>(xb + (eo[c] + cofs));
+          w[it][c] = __uint_as_float(ew[c]);
+        }
+      }
+    };
+    auto combine = [&](int buf, const raw16 (&raw)[ITEMS][4], const float (&w)[ITEMS][4]) __attribute__((always_inline)) {
+      raw16* Bb = Bs + buf * BSLOTS;
+#pragma unroll
+      for (int it = 0; it < ITEMS; it++) {
+        const int i = it * (64 * NG) + gt;
+        const int n = i >> 3, sub = i & 7;
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          float f[8];
+          tc_unpack(raw[it][c], f, T{});
+          const float wc = w[it][c];
+#pragma unroll
+          for (int u = 0; u < 8; u++) v[u] = c == 0 ? wc * f[u] : v[u] + wc * f[u];
+        }
+        Bb[tc_slot(n >> 5, sub >> 1, sub & 1, n & 31)] = tc_pack(v, T{});
+      }
+    };
+    // the gathers run TWO stages ahead of the matrix waves (register double buffer), so the L2
+    // latency of stage j+2 hides behind the combine of stage j+1
+    issue(s_lo, graw[0], gw[0]);
+    if (nst > 1) issue(s_lo + 1, graw[1], gw[1]);
+    combine(0, graw[0], gw[0]);
+    if (nst > 2) issue(s_lo + 2, graw[0], gw[0]);
+    __syncthreads();  // barrier #1: stage 0 staged
+    // iteration j (matrix waves compute stage j): stage j+1 -> buffer (j+1)&1; registers (j+1)&1
+    for (int j = 0; j < nst; j += 2) {
+      if (j + 1 < nst) {
+        combine(1, graw[1], gw[1]);
+        if (j + 3 < nst) issue(s_lo + j + 3, graw[1], gw[1]);
+      }
+      __syncthreads();
+      if (j + 1 < nst) {
+        if (j + 2 < nst) {
+          combine(0, graw[0], gw[0]);
+          if (j + 4 < nst) issue(s_lo + j + 4, graw[0], gw[0]);
+        }
+        __syncthreads();
+      }
+    }
+    return;
+  }
+
+  // ================================== MATRIX waves ==================================================
+  const int wm = wid % NWM, wn = wid / NWM;
+  const raw16* wsrc = (const raw16*)a.wp + ((size_t)(g * a.n_cot + cot) * a.S) * ASLOTS;
+  f32x16_t acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; m++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[m][r] = 0.f;
+  raw16 araw[ACOPY];
+  auto a_issue = [&](int st) __attribute__((always_inline)) {
+    const raw16* src = wsrc + (size_t)st * ASLOTS;
+#pragma unroll
+    for (int q = 0; q < ACOPY; q++) araw[q] = src[q * (64 * NMW) + tid];
+  };
+  auto a_store = [&](int buf) __attribute__((always_inline)) {
+    raw16* Ab = As + buf * ASLOTS;
+#pragma unroll
+    for (int q = 0; q < ACOPY; q++) Ab[q * (64 * NMW) + tid] = araw[q];
+  };
+  auto mfma_stage = [&](int buf) __attribute__((always_inline)) {
+    const raw16* Ab = As + buf * ASLOTS;
+    const raw16* Bb = Bs + buf * BSLOTS;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      const typename M::frag b = __builtin_bit_cast(typename M::frag, Bb[tc_slot(wn, ks, lane >> 5, lane & 31)]);
+#pragma unroll
+      for (int m = 0; m < MT; m++) {
+        const typename M::frag av =
+            __builtin_bit_cast(typename M::frag, Ab[((wm * MT + m) * 4 + ks) * 64 + lane]);
+        acc[m] = M::mma(av, b, acc[m]);
+      }
+    }
+  };
+  a_issue(s_lo);
+  a_store(0);
+  __syncthreads();  // barrier #1
+  for (int j = 0; j < nst; j++) {
+    const int cur = j & 1;
+    const bool more = j + 1 < nst;  // uniform
+    if (more) a_issue(s_lo + j + 1);
+    mfma_stage(cur);
+    if (more) a_store(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: out[b][g*Cog + co][l] (+ bias), or fp32 partials when the reduction is split
+  const int p = p0 + wn * 32 + (lane & 31);
+  const T* bias = (const T*)a.bias;
+  const bool add_bias = bias != nullptr && a.ksplit == 1;  // uniform
+  if (add_bias) {  // all bias loads in flight together (clamped rows), then one pass of stores
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+      float bv[16];
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int co = min(cot * BM + (wm * MT + m) * 32 + frag_row(r, lane), s.Cog - 1);
+        bv[r] = to_f32(bias[g * s.Cog + co]);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[m][r] += bv[r];
+    }
+  }
+  if (p < s.P) {
+    const int b = p / s.L, l = p - b * s.L;
+    const long obase = ((long)b * s.Co + (long)g * s.Cog) * s.L + l;
+    T* outp = (T*)a.out;
+    float* part = a.partial + (a.ksplit > 1 ? (long)kz * s.B * s.Co * s.L : 0l);
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int co = cot * BM + (wm * MT + m) * 32 + frag_row(r, lane);
+        if (co < s.Cog) {
+          const long o = obase + (long)co * s.L;
+          if (a.ksplit == 1) outp[o] = from_f32<T>(acc[m][r]);
+          else part[o] = acc[m][r];
+        }
+      }
+    }
+  }
+}
+
+// out[i] = sum_kz partial[kz][i] (+ bias[co]) in a fixed order
+template <typename T>
+__global__ __launch_bounds__(256) void tc_reduce_partial_kernel(const float* __restrict__ partial, const T* __restrict__ bias,
+                                                               T* __restrict__ out, long n, int ksplit, int Co, int L) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float v = 0.f;
+    for (int k = 0; k < ksplit; k++) v += partial[(long)k * n + i];
+    if (bias) v += to_f32(bias[(i / L) % Co]);
+    out[i] = from_f32<T>(v);
+  }
+}
+
+// ---- host side --------------------------------------------------------------------------------------
+static int tc_env_cfg(int (&v)[4]) {
+  const char* e = getenv("D2AMD_DCN_CFG");  // "MT,NWM,NWN,KSPLIT" (profiling switch)
+  if (!e) return 0;
+  return sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4;
+}
+
+TcPlan dcn_tc_plan_fwd(const DcnShape& s, int dtype) {
+  TcPlan pl{};
+  pl.ok = false;
+  if (getenv("D2AMD_DCN_V1")) return pl;
+  if (dtype != D2AMD_BF16 && dtype != D2AMD_F16) return pl;
+  if (s.Cg % 64 != 0 || s.cpg % 64 != 0 || s.P <= 0) return pl;
+  if ((long)s.B * s.H * s.W * s.C * 2 >= (1l << 32)) return pl;   // 32-bit byte offsets into x
+  int ndg_max = 1;
+  for (int g = 0; g < s.G; g++) {
+    const int n = ((g + 1) * s.Cg - 1) / s.cpg - (g * s.Cg) / s.cpg + 1;
+    ndg_max = n > ndg_max ? n : ndg_max;
+  }
+  if (s.K2 * ndg_max > 32) return pl;
+  pl.ndg = ndg_max;
+  pl.NC64 = s.Cg / 64;
+  pl.S = s.K2 * pl.NC64;
+  // tile shape: a 256-row tile amortises one gather over twice the MFMA work; position tiles shrink
+  // until the launch has about one workgroup per CU, then the (tap, channel) reduction is split
+  int MT = s.Cog <= 64 ? 2 : 4, NWM = s.Cog >= 256 ? 2 : 1, NWN = NWM == 1 ? 4 : 2, ks = 1;
+  auto wgs = [&](int nwn, int k) { return (long)cdiv(s.P, 32 * nwn) * cdiv(s.Cog, 32 * MT * NWM) * s.G * k; };
+  while (NWN > 1 && wgs(NWN, 1) < 240) NWN >>= 1;
+  while (ks < 4 && wgs(NWN, ks) < 240 && pl.S / (ks + 1) >= 6) ks++;
+  int ev[4];
+  if (tc_env_cfg(ev)) { MT = ev[0]; NWM = ev[1]; NWN = ev[2]; ks = ev[3]; }
+  if (ks < 1 || ks > pl.S) ks = 1;
+  pl.MT = MT; pl.NWM = NWM; pl.NWN = NWN; pl.ksplit = ks;
+  pl.BM = 32 * MT * NWM; pl.BN = 32 * NWN;
+  pl.n_cot = cdiv(s.Cog, pl.BM);
+  pl.n_pt = cdiv(s.P, pl.BN);
+  pl.wp_bytes = (size_t)s.G * pl.n_cot * pl.S * pl.BM * 64 * 2;
+  pl.partial_bytes = ks > 1 ? (size_t)ks * s.B * s.Co * s.L * 4 : 0;
+  pl.lds = (size_t)s.K2 * pl.ndg * pl.BN * sizeof(TcEntry) + 2 * (size_t)pl.BM * 8 * 16 +
+      2 * (size_t)pl.NWN * TC_BPITCH * 16;
+  pl.ok = pl.lds <= 160 * 1024;
+  return pl;
+}
+
+template <typename T, int MT, int NWM, int NWN>
+static int tc_launch_fwd(const DcnShape& s, const TcPlan& pl, const TcArgs& a, hipStream_t st) {
+  auto kern = dcn_fwd_tc_kernel<T, MT, NWM, NWN, NWN>;  // one gather wave per 32 positions
+  if (pl.lds > 64 * 1024)
+    D2_HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
+  const int grid = (a.total + 7) / 8 * 8;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (NWM * NWN + NWN)), pl.lds, st, s, a);
+  D2_LAUNCH_OK();
+  return D2AMD_OK;
+}
+
+template <typename T>
+int dcn_tc_forward(const DcnShape& s, const TcPlan& pl, const void* x_nhwc, const void* offset, const void* mask,
+                   const void* weight, const void* bias, void* out, void* wp, float* partial, hipStream_t st) {
+  {
+    const long groups16 = (long)s.G * pl.n_cot * pl.S * (pl.BM / 32) * 4 * 64;
+    const int blocks = cdiv(groups16, 256) > 8192 ? 8192 : cdiv(groups16, 256);
+    hipLaunchKernelGGL((tc_pack_weight_kernel<T>), dim3(blocks), dim3(256), 0, st, (const T*)weight, (T*)wp, s.G,
+                       s.Cog, s.Cg, s.K2, pl.BM, pl.n_cot, pl.NC64);
+    D2_LAUNCH_OK();
+  }
+  TcArgs a{};
+  a.x = x_nhwc; a.offset = offset; a.mask = mask; a.wp = wp; a.bias = bias; a.out = out; a.partial = partial;
+  a.n_pt = pl.n_pt; a.n_cot = pl.n_cot; a.ksplit = pl.ksplit; a.NC64 = pl.NC64; a.S = pl.S;
+  const long total = (long)pl.n_pt * pl.n_cot * s.G * pl.ksplit;
+  D2_CHECK_ARG(total < (1l << 30), "deform_conv: too many tiles");
+  a.total = (int)total;
+  int rc = D2AMD_EUNSUPPORTED;
+  const int key = pl.MT * 100 + pl.NWM * 10 + pl.NWN;
+  switch (key) {
+    case 414: rc = tc_launch_fwd<T, 4, 1, 4>(s, pl, a, st); break;
+    case 412: rc = tc_launch_fwd<T, 4, 1, 2>(s, pl, a, st); break;
+    case 411: rc = tc_launch_fwd<T, 4, 1, 1>(s, pl, a, st); break;
+    case 422: rc = tc_launch_fwd<T, 4, 2, 2>(s, pl, a, st); break;
+    case 421: rc = tc_launch_fwd<T, 4, 2, 1>(s, pl, a, st); break;
+    case 222: rc = tc_launch_fwd<T, 2, 2, 2>(s, pl, a, st); break;
+    case 214: rc = tc_launch_fwd<T, 2, 1, 4>(s, pl, a, st); break;
+    case 212: rc = tc_launch_fwd<T, 2, 1, 2>(s, pl, a, st); break;
+    case 211: rc = tc_launch_fwd<T, 2, 1, 1>(s, pl, a, st); break;
+    default: set_error("deform_conv: no kernel for tile config MT=%d NWM=%d NWN=%d", pl.MT, pl.NWM, pl.NWN);
+  }
+  if (rc) return rc;
+  if (pl.ksplit > 1) {
+    const long n = (long)s.B * s.Co * s.L;
+    const int blocks = cdiv(n, 256) > 4096 ? 4096 : cdiv(n, 256);
+    hipLaunchKernelGGL((tc_reduce_partial_kernel<T>), dim3(blocks), dim3(256), 0, st, (const float*)partial,
+                       (const T*)bias, (T*)out, n, pl.ksplit, s.Co, s.L);
+    D2_LAUNCH_OK();
+  }
+  return D2AMD_OK;
+}
+
+template int dcn_tc_forward<bf16_t>(const DcnShape&, const TcPlan&, const void*, const void*, const void*, const void*,
+                                    const void*, void*, void*, float*, hipStream_t);
+template int dcn_tc_forward<f16_t>(const DcnShape&, const TcPlan&, const void*, const void*, const void*, const void*,
+                                   const void*, void*, void*, float*, hipStream_t);
+
+// =====================================================================================================
+// Backward w.r.t. input / offset / mask, 16-bit path.
+// Replaces deform_conv_cuda.cu:442-640,1006-1221 with deform_conv_cuda_kernel.cu:272-452,862-1066
+// (dcol = W^T dY into an HBM column buffer, then col2im with one global atomic per (sample corner,
+// channel) and a col2im_coord kernel that re-reads the column buffer).
+//
+// Workgroup = one 8x8 tile of output positions x one deformable group; stage = (32-channel chunk, tap).
+// Per stage: dcol[32 ch][64 pos] = W^T[tap, chunk] dY by MFMA (K = Cog split over two wave halves),
+// exchanged through LDS, then
+//   phase A  lane = (position, 8 channels): re-gather the 4 corners of x, form the bilinear value and
+//            its coordinate derivatives, reduce d(offset) / d(mask) over channels (wave shuffles,
+//            one owner thread per (tap, position) accumulates in LDS -> plain stores at the end);
+//   phase B  lane = channel, half-wave = (position, corner): dX contribution w_corner * mask * dcol
+//            added into an LDS-resident fp32 PATCH of the input (the 8x8 tile's taps +- R pixels),
+//            with ds_add_f32; only samples displaced by more than R pixels go to global atomics.
+// After the 9 taps of a chunk the patch is flushed with one 128-B-coalesced global atomic per touched
+// (pixel, 32 channels): ~10x fewer device-scope atomics than one per sample corner, which is what
+// bounded the first version (profiles/r01: 2.3 ms for res3, atomics execute beyond the XCD L2).
+struct BwEntry {
+  uint32_t pix[4];  // pixel index (b*H + y)*W + x of the corner; 0 when unused
+  float w[4];       // bilinear corner weights (mask NOT folded in); 0 for corners outside
+  float lh, lw, m;
+  uint32_t flags;   // bit c: corner c inside the image; bit 4: sample inside (-1,H)x(-1,W) and position valid
+  int py, px;       // patch coordinates of corner 0 (h_low, w_low); may lie outside the patch
+  int pad[2];
+};
+static_assert(sizeof(BwEntry) == 64, "BwEntry layout");
+
+struct BwArgs {
+  const void *x, *offset, *mask, *wp, *gout;  // x NHWC, gout NHWC [P][Co], wp = tc_pack_weight_t layout
+  float *gx, *goff, *gmask;                   // gx fp32 NHWC (zero-filled), goff / gmask fp32 NCHW-like
+  int tiles_y, tiles_x, total, R, PHt, PWt;
+};
+
+// weight (Co, Cg, K2) -> [g][tap][c32][ks][lane][8]: element j of lane l =
+// W[co = ks*16 + (l >> 5)*8 + j][ci = c32*32 + (l & 31)][tap]  (A operand rows = input channels, k = co)
+template <typename T>
+__global__ __launch_bounds__(256) void tc_pack_weight_t_kernel(const T* __restrict__ w, T* __restrict__ wp, int G,
+                                                              int Cog, int Cg, int K2) {
+  const int NC32 = Cg / 32, KS = Cog / 16;
+  const long total = (long)G * K2 * NC32 * KS * 64;
+  for (long gi = (long)blockIdx.x * blockDim.x + threadIdx.x; gi < total; gi += (long)gridDim.x * blockDim.x) {
+    long r = gi;
+    const int lane = (int)(r % 64); r /= 64;
+    const int ks = (int)(r % KS); r /= KS;
+    const int c32 = (int)(r % NC32); r /= NC32;
+    const int tap = (int)(r % K2); r /= K2;
+    const int g = (int)r;
+    const int ci = c32 * 32 + (lane & 31);
+    const int co0 = ks * 16 + (lane >> 5) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; j++) wp[gi * 8 + j] = w[(((long)g * Cog + co0 + j) * Cg + ci) * K2 + tap];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void dcn_bwd_data_tc_kernel(DcnShape s, BwArgs a) {
+  typedef Mma<T> M;
+  extern __shared__ __attribute__((aligned(16))) unsigned char bw_smem[];
+  __shared__ __attribute__((aligned(16))) BwEntry ent[64];
+  __shared__ __attribute__((aligned(16))) float Cs[64][36];
+  float* red = reinterpret_cast<float*>(bw_smem);              // [K2][64][3]
+  float* patch = red + s.K2 * 64 * 3;                           // [PHt*PWt][32]
+  const int npatch = a.PHt * a.PWt * 32;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int per_xcd = (a.total + 7) >> 3;
+  const int logical = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if (logical >= a.total) return;
+  const int dgi = logical % s.DG;
+  int tile = logical / s.DG;
+  const int tx = tile % a.tiles_x; tile /= a.tiles_x;
+  const int ty = tile % a.tiles_y;
+  const int b = tile / a.tiles_y;
+  const int oy = ty * 8 * s.sh - s.ph - a.R, ox = tx * 8 * s.sw - s.pw - a.R;
+
+  for (int i = tid; i < s.K2 * 64 * 3 + npatch; i += 256) red[i] = 0.f;  // red and patch are contiguous
+
+  const T* offset = (const T*)a.offset;
+  const T* mask = (const T*)a.mask;
+  const char* xb = (const char*)a.x;
+  const T* gout = (const T*)a.gout;
+  const raw16* wp = (const raw16*)a.wp;
+  const int KS = s.Cog / 16, KH = KS / 2;  // ksteps in total / per wave half
+  const int nt = wid & 1, khalf = wid >> 1;
+  // this lane's position as B-operand column (n = nt*32 + (lane & 31))
+  const int nB = nt * 32 + (lane & 31);
+  const int hoB = ty * 8 + (nB >> 3), woB = tx * 8 + (nB & 7);
+  const bool validB = hoB < s.Ho && woB < s.Wo;
+  const long pB = ((long)b * s.Ho + hoB) * s.Wo + woB;
+  const uint32_t pixbytes = (uint32_t)s.C * (uint32_t)sizeof(T);
+
+  const int c_lo = dgi * s.cpg, c_hi = c_lo + s.cpg;
+  for (int cabs = c_lo; cabs < c_hi; cabs += 32) {
+    const int g = cabs / s.Cg, c32 = (cabs - g * s.Cg) >> 5;
+    for (int tap = 0; tap < s.K2; tap++) {
+      // ---- (1) table of this tap (threads 0..63), while everyone starts on the operand loads
+      if (tid < 64) {
+        BwEntry e;
+#pragma unroll
+        for (int t = 0; t < 4; t++) { e.pix[t] = 0u; e.w[t] = 0.f; }
+        e.lh = e.lw = 0.f; e.m = 0.f; e.flags = 0u; e.py = e.px = -(1 << 20); e.pad[0] = e.pad[1] = 0;
+        const int ho = ty * 8 + (tid >> 3), wo = tx * 8 + (tid & 7);
+        if (ho < s.Ho && wo < s.Wo) {
+          const int l = ho * s.Wo + wo;
+          const int i = tap / s.kw, j = tap - i * s.kw;
+          const long obase = ((long)b * s.DG + dgi) * 2 * s.K2;
+          const float off_h = to_f32(offset[(obase + 2 * tap) * s.L + l]);
+          const float off_w = to_f32(offset[(obase + 2 * tap + 1) * s.L + l]);
+          e.m = mask ? to_f32(mask[(((long)b * s.DG + dgi) * s.K2 + tap) * s.L + l]) : 1.f;
+          const float h_im = (float)(ho * s.sh - s.ph + i * s.dh) + off_h;
+          const float w_im = (float)(wo * s.sw - s.pw + j * s.dw) + off_w;
+          if (h_im > -1.f && w_im > -1.f && h_im < (float)s.H && w_im < (float)s.W) {
+            const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+            const int h_high = h_low + 1, w_high = w_low + 1;
+            const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+            const float hh = 1.f - lh, hw = 1.f - lw;
+            e.lh = lh; e.lw = lw; e.flags = 16u;
+            e.py = h_low - oy; e.px = w_low - ox;
+            const long rowbase = (long)b * s.H;
+            if (h_low >= 0 && w_low >= 0) { e.pix[0] = (uint32_t)((rowbase + h_low) * s.W + w_low); e.w[0] = hh * hw; e.flags |= 1u; }
+            if (h_low >= 0 && w_high <= s.W - 1) { e.pix[1] = (uint32_t)((rowbase + h_low) * s.W + w_high); e.w[1] = hh * lw; e.flags |= 2u; }
+            if (h_high <= s.H - 1 && w_low >= 0) { e.pix[2] = (uint32_t)((rowbase + h_high) * s.W + w_low); e.w[2] = lh * hw; e.flags |= 4u; }
+            if (h_high <= s.H - 1 && w_high <= s.W - 1) { e.pix[3] = (uint32_t)((rowbase + h_high) * s.W + w_high); e.w[3] = lh * lw; e.flags |= 8u; }
+          }
+        }
+        ent[tid] = e;
+      }
+      // ---- (2) dcol tile by MFMA: rows = the 32 channels of the chunk, cols = this wave's 32 positions,
+      //          K = this wave half's share of the group's output channels; operand fragments straight
+      //          from L2 (weights pre-packed in fragment order, dY as [position][Co])
+      f32x16_t acc;
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[r] = 0.f;
+      {
+        const raw16* wsrc = wp + ((((size_t)g * s.K2 + tap) * (s.Cg >> 5) + c32) * KS) * 64 + lane;
+        const T* gsrc = gout + pB * s.Co + (long)g * s.Cog + (lane >> 5) * 8;
+        const raw16 zero = {0u, 0u, 0u, 0u};
+        constexpr int KB = 4;
+        raw16 af[2][KB], bf[2][KB];
+        auto ld = [&](int k0, raw16 (&A)[KB], raw16 (&Bq)[KB]) __attribute__((always_inline)) {
+#pragma unroll
+          for (int u = 0; u < KB; u++) {
+            const int ks = min(k0 + u, KS - 1);
+            A[u] = wsrc[(size_t)ks * 64];
+            Bq[u] = validB ? *reinterpret_cast<const raw16*>(gsrc + ks * 16) : zero;
+          }
+        };
+        const int k_lo = khalf * KH, k_hi = k_lo + KH;
+        ld(k_lo, af[0], bf[0]);
+        for (int k0 = k_lo; k0 < k_hi; k0 += 2 * KB) {
+          if (k0 + KB < k_hi) ld(k0 + KB, af[1], bf[1]);
+#pragma unroll
+          for (int u = 0; u < KB; u++)
+            if (k0 + u < k_hi)
+              acc = M::mma(__builtin_bit_cast(typename M::frag, af[0][u]), __builtin_bit_cast(typename M::frag, bf[0][u]), acc);
+          if (k0 + KB < k_hi) {
+            if (k0 + 2 * KB < k_hi) ld(k0 + 2 * KB, af[0], bf[0]);
+#pragma unroll
+            for (int u = 0; u < KB; u++)
+              if (k0 + KB + u < k_hi)
+                acc = M::mma(__builtin_bit_cast(typename M::frag, af[1][u]), __builtin_bit_cast(typename M::frag, bf[1][u]), acc);
+          }
+        }
+      }
+      // ---- (3) the two K halves meet in LDS: Cs[position][channel]
+      if (khalf == 0) {
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++)
+          *reinterpret_cast<float4*>(&Cs[nB][8 * rg + 4 * (lane >> 5)]) =
+              make_float4(acc[4 * rg], acc[4 * rg + 1], acc[4 * rg + 2], acc[4 * rg + 3]);
+      }
+      __syncthreads();
+      if (khalf == 1) {
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+          float4* q = reinterpret_cast<float4*>(&Cs[nB][8 * rg + 4 * (lane >> 5)]);
+          float4 v = *q;
+          v.x += acc[4 * rg]; v.y += acc[4 * rg + 1]; v.z += acc[4 * rg + 2]; v.w += acc[4 * rg + 3];
+          *q = v;
+        }
+      }
+      __syncthreads();
+      // ---- (4) phase A: d(offset), d(mask).  thread = (position n, 8 channels q*8..)
+      if (a.goff || a.gmask) {
+        const int n = tid >> 2, q = tid & 3;
+        const BwEntry& e = ent[n];
+        const uint32_t flags = e.flags;
+        float s_h = 0.f, s_w = 0.f, s_m = 0.f;
+        if (flags & 16u) {
+          const uint32_t cofs = (uint32_t)(cabs + q * 8) * (uint32_t)sizeof(T);
+          raw16 raw[4];
+#pragma unroll
+          for (int c = 0; c < 4; c++) raw[c] = *reinterpret_cast<const raw16*>(xb + ((size_t)e.pix[c] * pixbytes + cofs));
+          float v[4][8];
+#pragma unroll
+          for (int c = 0; c < 4; c++) {
+            tc_unpack(raw[c], v[c], T{});
+            if (!(flags & (1u << c))) {
+#pragma unroll
+              for (int u = 0; u < 8; u++) v[c][u] = 0.f;
+            }
+          }
+          const float4 d0 = *reinterpret_cast<const float4*>(&Cs[n][q * 8]);
+          const float4 d1 = *reinterpret_cast<const float4*>(&Cs[n][q * 8 + 4]);
+          const float d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+          const float lh = e.lh, lw = e.lw, hh = 1.f - lh, hw = 1.f - lw, m = e.m;
+          const float w0 = e.w[0], w1 = e.w[1], w2 = e.w[2], w3 = e.w[3];
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const float val = w0 * v[0][u] + w1 * v[1][u] + w2 * v[2][u] + w3 * v[3][u];
+            const float dvh = -hw * v[0][u] - lw * v[1][u] + hw * v[2][u] + lw * v[3][u];
+            const float dvw = -hh * v[0][u] + hh * v[1][u] - lh * v[2][u] + lh * v[3][u];
+            s_h += dvh * d[u] * m;
+            s_w += dvw * d[u] * m;
+            s_m += d[u] * val;
+          }
+        }
+        s_h += __shfl_xor(s_h, 1); s_w += __shfl_xor(s_w, 1); s_m += __shfl_xor(s_m, 1);
+        s_h += __shfl_xor(s_h, 2); s_w += __shfl_xor(s_w, 2); s_m += __shfl_xor(s_m, 2);
+        if (q == 0) {  // the only thread that touches red[tap][n]
+          float* rp = red + (tap * 64 + n) * 3;
+          rp[0] += s_h; rp[1] += s_w; rp[2] += s_m;
+        }
+      }
+      // ---- (5) phase B: dX.  half-wave = (position, corner), lane = channel of the chunk
+      if (a.gx) {
+        const int ch = lane & 31, sub = lane >> 5;
+#pragma unroll 4
+        for (int it = 0; it < 32; it++) {
+          const int pid = (it * 4 + wid) * 2 + sub;
+          const int n = pid >> 2, c = pid & 3;
+          const BwEntry& e = ent[n];
+          const float wgt = e.w[c] * e.m;
+          if (wgt != 0.f && (e.flags & 16u)) {
+            const float val = wgt * Cs[n][ch];
+            const int yy = e.py + (c >> 1), xx = e.px + (c & 1);
+            if ((unsigned)yy < (unsigned)a.PHt && (unsigned)xx < (unsigned)a.PWt)
+              atomicAdd(&patch[(yy * a.PWt + xx) * 32 + ch], val);
+            else
+              atomicAdd(a.gx + (size_t)e.pix[c] * s.C + cabs + ch, val);
+          }
+        }
+      }
+      __syncthreads();  // ent / Cs are rewritten by the next stage
+    }
+    // ---- flush the patch of this channel chunk: one coalesced atomic per touched (pixel, channel)
+    if (a.gx) {
+      for (int i = tid; i < npatch; i += 256) {
+        const float v = patch[i];
+        if (v != 0.f) {
+          patch[i] = 0.f;
+          const int pixel = i >> 5, ch = i & 31;
+          const int yy = pixel / a.PWt, xx = pixel - yy * a.PWt;
+          const int hy = oy + yy, wx = ox + xx;
+          if (hy >= 0 && hy < s.H && wx >= 0 && wx < s.W)
+            atomicAdd(a.gx + (((size_t)b * s.H + hy) * s.W + wx) * s.C + cabs + ch, v);
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // ---- d(offset) / d(mask): every (tap, position) of this deformable group has exactly one owner
+  for (int i = tid; i < s.K2 * 64; i += 256) {
+    const int tap = i >> 6, n = i & 63;
+    const int ho = ty * 8 + (n >> 3), wo = tx * 8 + (n & 7);
+    if (ho >= s.Ho || wo >= s.Wo) continue;
+    const int l = ho * s.Wo + wo;
+    const float* rp = red + i * 3;
+    const long ob = ((long)b * s.DG + dgi) * 2 * s.K2;
+    if (a.goff) {
+      a.goff[(ob + 2 * tap) * s.L + l] = rp[0];
+      a.goff[(ob + 2 * tap + 1) * s.L + l] = rp[1];
+    }
+    if (a.gmask) a.gmask[(((long)b * s.DG + dgi) * s.K2 + tap) * s.L + l] = rp[2];
+  }
+}
+
+TcBwPlan dcn_tc_plan_bwd(const DcnShape& s, int dtype) {
+  TcBwPlan pl{};
+  pl.ok = false;
+  if (getenv("D2AMD_DCN_V1") || getenv("D2AMD_DCN_BWD_V1")) return pl;
+  if (dtype != D2AMD_BF16 && dtype != D2AMD_F16) return pl;
+  if (s.Cg % 32 != 0 || s.cpg % 32 != 0 || s.Cog % 32 != 0 || s.K2 > 32 || s.P <= 0) return pl;
+  if ((long)s.B * s.H * s.W * s.C * 4 >= (1l << 40) || (long)s.B * s.H * s.W >= (1l << 31)) return pl;
+  pl.tiles_y = cdiv(s.Ho, 8); pl.tiles_x = cdiv(s.Wo, 8);
+  const size_t red_bytes = (size_t)s.K2 * 64 * 3 * 4;
+  // largest displacement margin R whose patch fits ~48 KB (two workgroups per CU)
+  const char* er = getenv("D2AMD_DCN_PATCH_R");  // profiling switch; -1 disables the patch
+  int R = -1;
+  for (int r = 0; r <= 8; r++) {
+    const long ph = 7l * s.sh + (long)(s.kh - 1) * s.dh + 2 + 2 * r, pw = 7l * s.sw + (long)(s.kw - 1) * s.dw + 2 + 2 * r;
+    if (ph * pw * 32 * 4 + (long)red_bytes <= 56 * 1024) R = r;
+  }
+  if (er) R = atoi(er) < R ? atoi(er) : R;
+  pl.R = R;
+  if (R >= 0) {
+    pl.PHt = 7 * s.sh + (s.kh - 1) * s.dh + 2 + 2 * R;
+    pl.PWt = 7 * s.sw + (s.kw - 1) * s.dw + 2 + 2 * R;
+  } else {
+    pl.PHt = pl.PWt = 0;
+  }
+  pl.lds = red_bytes + (size_t)pl.PHt * pl.PWt * 32 * 4;
+  pl.wp_bytes = (size_t)s.Co * s.Cg * s.K2 * 2;
+  pl.ok = true;
+  return pl;
+}
+
+template <typename T>
+int dcn_tc_backward_data(const DcnShape& s, const TcBwPlan& pl, const void* x_nhwc, const void* offset,
+                         const void* mask, const void* weight, const void* gout_nhwc, float* gx, float* goff,
+                         float* gmask, void* wp, hipStream_t st) {
+  {
+    const long groups16 = (long)s.G * s.K2 * (s.Cg / 32) * (s.Cog / 16) * 64;
+    const int blocks = cdiv(groups16, 256) > 8192 ? 8192 : cdiv(groups16, 256);
+    hipLaunchKernelGGL((tc_pack_weight_t_kernel<T>), dim3(blocks), dim3(256), 0, st, (const T*)weight, (T*)wp, s.G,
+                       s.Cog, s.Cg, s.K2);
+    D2_LAUNCH_OK();
+  }
+  BwArgs a{};
+  a.x = x_nhwc; a.offset = offset; a.mask = mask; a.wp = wp; a.gout = gout_nhwc;
+  a.gx = gx; a.goff = goff; a.gmask = gmask;
+  a.tiles_y = pl.tiles_y; a.tiles_x = pl.tiles_x; a.R = pl.R < 0 ? 0 : pl.R; a.PHt = pl.PHt; a.PWt = pl.PWt;
+  const long total = (long)s.B * pl.tiles_y * pl.tiles_x * s.DG;
+  D2_CHECK_ARG(total < (1l << 30), "deform_conv: too many tiles");
+  a.total = (int)total;
+  auto kern = dcn_bwd_data_tc_kernel<T>;
+  if (pl.lds > 48 * 1024)
+    D2_HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
+  const int grid = (a.total + 7) / 8 * 8;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), pl.lds, st, s, a);
+  D2_LAUNCH_OK();
+  return D2AMD_OK;
+}
+
+template int dcn_tc_backward_data<bf16_t>(const DcnShape&, const TcBwPlan&, const void*, const void*, const void*,
+                                          const void*, const void*, float*, float*, float*, void*, hipStream_t);
+template int dcn_tc_backward_data<f16_t>(const DcnShape&, const TcBwPlan&, const void*, const void*, const void*,
+                                         const void*, const void*, float*, float*, float*, void*, hipStream_t);
+
+}  // namespace d2amd

@@ -1,0 +1,188 @@
+"""GPU parity of the 16-bit deformable-convolution MFMA path (detectron2_amd/csrc/deform_conv_tc.hip)
+against the CPU oracle evaluated on the same 16-bit-rounded inputs.
+
+The tile configuration, reduction split and the backward's LDS patch margin are selected by
+heuristics from the shape; the profiling switches D2AMD_DCN_CFG / D2AMD_DCN_PATCH_R (read on every
+call) force each code path here: every tile shape, split reductions, ragged channel / position
+tails, conv groups, deformable groups, stride / dilation, image borders, samples that leave the
+patch (global-atomic fallback) and the patch disabled altogether.  Reference behaviour:
+detectron2/layers/csrc/deformable/deform_conv_cuda_kernel.cu:216-452,785-1066.
+Tolerance: f16 4e-3, bf16 3e-2 of the output's max magnitude (16-bit I/O rounding; the same
+bars as tests/test_gpu_parity.py::test_deform_conv_16bit)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from detectron2_amd import layers
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL = {torch.float16: 4e-3, torch.bfloat16: 3e-2}
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-12))
+
+
+class env:
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kw}
+        for k, v in self.kw.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = str(v)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def make_case(seed, B, C, Co, H, W, groups=1, dg=1, stride=1, pad=1, dil=1, modulated=True, off_scale=1.5,
+              dtype=torch.float16, k=3):
+    g = torch.Generator().manual_seed(seed)
+    Ho = (H + 2 * pad - (dil * (k - 1) + 1)) // stride + 1
+    Wo = (W + 2 * pad - (dil * (k - 1) + 1)) // stride + 1
+    q = lambda t: t.to(dtype)
+    x = q(torch.randn(B, C, H, W, generator=g))
+    off = q(torch.randn(B, dg * 2 * k * k, Ho, Wo, generator=g) * off_scale)
+    msk = q(torch.sigmoid(torch.randn(B, dg * k * k, Ho, Wo, generator=g))) if modulated else None
+    w = q(torch.randn(Co, C // groups, k, k, generator=g) * 0.05)
+    bias = q(torch.randn(Co, generator=g)) if modulated else None
+    go = q(torch.randn(B, Co, Ho, Wo, generator=g))
+    kw = dict(stride=stride, padding=pad, dilation=dil, groups=groups, deformable_groups=dg)
+    return x, off, msk, w, bias, go, kw
+
+
+def run_gpu(x, off, msk, w, bias, go, kw, backward=True):
+    xt, ot, wt = [t.to(DEV).requires_grad_(backward) for t in (x, off, w)]
+    mt = msk.to(DEV).requires_grad_(backward) if msk is not None else None
+    bt = bias.to(DEV).requires_grad_(backward) if bias is not None else None
+    a = (kw["stride"], kw["padding"], kw["dilation"], kw["groups"], kw["deformable_groups"])
+    if msk is not None:
+        y = layers.modulated_deform_conv(xt, ot, mt, wt, bt, *a)
+    else:
+        y = layers.deform_conv(xt, ot, wt, *a)
+    res = {"out": y.detach().float().cpu().numpy()}
+    if backward:
+        y.backward(go.to(DEV))
+        res.update(grad_input=xt.grad.float().cpu().numpy(), grad_offset=ot.grad.float().cpu().numpy(),
+                   grad_weight=wt.grad.float().cpu().numpy())
+        if msk is not None:
+            res.update(grad_mask=mt.grad.float().cpu().numpy(), grad_bias=bt.grad.float().cpu().numpy())
+    return res
+
+
+def run_oracle(x, off, msk, w, bias, go, kw, backward=True):
+    f = lambda t: None if t is None else t.float().numpy()
+    res = {"out": oracle.deform_conv_forward(f(x), f(off), f(w), mask=f(msk), bias=f(bias), **kw)}
+    if backward:
+        g = oracle.deform_conv_backward(f(x), f(off), f(w), f(go), mask=f(msk), with_bias=msk is not None, **kw)
+        res.update({k: v for k, v in g.items() if v is not None})
+    return res
+
+
+def check(case, tol, backward=True, keys=None):
+    got = run_gpu(*case, backward=backward)
+    exp = run_oracle(*case, backward=backward)
+    for k in (keys or exp.keys()):
+        assert got[k].shape == exp[k].shape, k
+        assert rel_err(got[k], exp[k]) < tol, (k, rel_err(got[k], exp[k]))
+
+
+# ---------------------------------------------------------------------------------------- forward
+@pytest.mark.parametrize("cfg", ["4,1,4,1", "4,1,2,1", "4,1,1,1", "4,2,2,1", "4,2,1,1", "2,2,2,1", "2,1,4,1",
+                                 "2,1,2,1", "2,1,1,1", "4,1,2,2", "4,2,1,3", "2,1,1,4"])
+def test_fwd_every_tile_config(cfg):
+    """Co = 160 is not a multiple of any row tile (zero-padded weight rows, guarded stores); P = 2*13*19
+    = 494 leaves ragged position tiles; the last digit splits the (tap, channel) reduction."""
+    case = make_case(11, 2, 128, 160, 13, 19)
+    with env(D2AMD_DCN_CFG=cfg):
+        check(case, TOL[torch.float16], backward=False)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("modulated", [True, False])
+def test_fwd_bwd_default_heuristics(dtype, modulated):
+    case = make_case(12, 2, 128, 128, 18, 21, modulated=modulated, dtype=dtype)
+    check(case, TOL[dtype])
+
+
+@pytest.mark.parametrize("B,C,Co,H,W,groups,dg,stride,pad,dil", [
+    (2, 128, 64, 15, 17, 2, 1, 1, 1, 1),    # conv groups (Cg = 64)
+    (1, 256, 96, 12, 14, 1, 2, 1, 1, 1),    # deformable groups
+    (1, 256, 128, 11, 13, 2, 4, 1, 1, 1),   # both (cpg = 64 < Cg = 128)
+    (2, 64, 64, 17, 19, 1, 1, 2, 1, 1),     # stride 2
+    (1, 64, 32, 16, 15, 1, 1, 1, 2, 2),     # dilation 2
+    (3, 64, 64, 9, 9, 1, 1, 1, 0, 1),       # no padding
+    (1, 64, 64, 4, 5, 1, 1, 1, 1, 1),       # map smaller than one tile
+])
+def test_fwd_bwd_shapes(B, C, Co, H, W, groups, dg, stride, pad, dil):
+    case = make_case(100 + C + Co + H, B, C, Co, H, W, groups, dg, stride, pad, dil)
+    check(case, TOL[torch.float16])
+
+
+def test_bwd_channel_multiples_of_32():
+    """The backward path accepts 32-channel granularity (forward falls back to the generic kernel)."""
+    case = make_case(13, 2, 96, 96, 10, 12)
+    check(case, TOL[torch.float16])
+
+
+@pytest.mark.parametrize("patch_r", [-1, 0, 1, 4])
+def test_bwd_patch_margins_and_large_offsets(patch_r):
+    """Offsets of ~6 px throw most samples out of small patches (global-atomic fallback) and out of the
+    image; patch_r = -1 disables the LDS patch."""
+    case = make_case(14, 2, 64, 64, 19, 23, off_scale=6.0)
+    with env(D2AMD_DCN_PATCH_R=patch_r):
+        check(case, TOL[torch.float16])
+
+
+def test_bwd_large_co_k_pipeline():
+    """Co = 512: the dcol MFMA loop runs 16 k-steps per wave half through its two-deep register pipeline."""
+    case = make_case(15, 1, 64, 512, 9, 10)
+    check(case, TOL[torch.float16])
+
+
+def test_5x5_kernel():
+    case = make_case(16, 1, 64, 64, 12, 13, pad=2, k=5)
+    check(case, TOL[torch.float16])
+
+
+def test_v1_switch_matches():
+    """D2AMD_DCN_V1 selects the generic kernels: both implementations agree on the same input."""
+    case = make_case(17, 2, 128, 128, 14, 15)
+    a = run_gpu(*case)
+    with env(D2AMD_DCN_V1=1):
+        b = run_gpu(*case)
+    for k in a:
+        assert rel_err(a[k], b[k]) < 2 * TOL[torch.float16], k
+
+
+def test_res4_shape_zero_offset_is_conv2d():
+    """BASELINE config 5 res4 shape: zero offsets + unit mask reduce DCN to conv2d (size-independent
+    property, checked against torch) in both directions."""
+    torch.manual_seed(5)
+    B, C, H, W = 2, 256, 50, 84
+    x = torch.randn(B, C, H, W, device=DEV).bfloat16().requires_grad_(True)
+    w = (torch.randn(C, C, 3, 3, device=DEV) * 0.02).bfloat16().requires_grad_(True)
+    off = torch.zeros(B, 18, H, W, device=DEV).bfloat16()
+    one = torch.ones(B, 9, H, W, device=DEV).bfloat16()
+    y = layers.modulated_deform_conv(x, off, one, w, None, 1, 1, 1, 1, 1)
+    xr, wr = x.detach().float().requires_grad_(True), w.detach().float().requires_grad_(True)
+    ref = torch.nn.functional.conv2d(xr, wr, padding=1)
+    assert rel_err(y.float().detach().cpu().numpy(), ref.detach().cpu().numpy()) < 2e-2
+    go = torch.randn_like(ref)
+    y.backward(go.bfloat16())
+    ref.backward(go.bfloat16().float())
+    assert rel_err(x.grad.float().cpu().numpy(), xr.grad.cpu().numpy()) < 2e-2
+    assert rel_err(w.grad.float().cpu().numpy(), wr.grad.cpu().numpy()) < 2e-2
