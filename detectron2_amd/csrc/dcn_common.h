@@ -103,7 +103,7 @@ int dcn_tc_forward(const DcnShape& s, const TcPlan& pl, const void* x_nhwc, cons
 
 struct TcBwPlan {
   bool ok;
-  int tiles_y, tiles_x, R, PHt, PWt;
+  int tiles_y, tiles_x, csplit;
   size_t lds, wp_bytes;
 };
 TcBwPlan dcn_tc_plan_bwd(const DcnShape& s, int dtype);

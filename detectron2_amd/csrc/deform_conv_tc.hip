@@ -43,6 +43,7 @@ struct TcArgs {
   void* out;
   float* partial;
   int n_pt, n_cot, ksplit, NC64, S, total;
+  int ablate;  // profiling only (D2AMD_DCN_ABLATE): 1 no gather loads, 2 no combine, 4 no MFMA, 8 no weight copy
 };
 
 constexpr int TC_BPITCH = 4 * 66;  // 16-B slots per 32-position tile of the column buffer
@@ -214,13 +215,22 @@ __global__ __launch_bounds__(64 * (NWM * NWN + NG)) void dcn_fwd_tc_kernel(DcnSh
         const uint32_t cofs = (uint32_t)(cabs + sub * 8) * (uint32_t)sizeof(T);
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-          raw[it][c] = *reinterpret_cast<const raw16*>(xb + (eo[c] + cofs));
+          if (!(a.ablate & 1)) raw[it][c] = *reinterpret_cast<const raw16*>(xb + (eo[c] + cofs));
+          else raw[it][c] = eo;
           w[it][c] = __uint_as_float(ew[c]);
         }
       }
     };
     auto combine = [&](int buf, const raw16 (&raw)[ITEMS][4], const float (&w)[ITEMS][4]) __attribute__((always_inline)) {
       raw16* Bb = Bs + buf * BSLOTS;
+      if (a.ablate & 2) {
+#pragma unroll
+        for (int it = 0; it < ITEMS; it++) {
+          const int i = it * (64 * NG) + gt;
+          Bb[tc_slot(i >> 8, (i >> 4) & 3, (i >> 3) & 1, (i >> 3) & 31)] = raw[it][0] ^ raw[it][1] ^ raw[it][2] ^ raw[it][3];
+        }
+        return;
+      }
 #pragma unroll
       for (int it = 0; it < ITEMS; it++) {
         const int i = it * (64 * NG) + gt;
@@ -272,6 +282,7 @@ __global__ __launch_bounds__(64 * (NWM * NWN + NG)) void dcn_fwd_tc_kernel(DcnSh
     for (int r = 0; r < 16; r++) acc[m][r] = 0.f;
   raw16 araw[ACOPY];
   auto a_issue = [&](int st) __attribute__((always_inline)) {
+    if (a.ablate & 8) return;
     const raw16* src = wsrc + (size_t)st * ASLOTS;
 #pragma unroll
     for (int q = 0; q < ACOPY; q++) araw[q] = src[q * (64 * NMW) + tid];
@@ -282,6 +293,7 @@ __global__ __launch_bounds__(64 * (NWM * NWN + NG)) void dcn_fwd_tc_kernel(DcnSh
     for (int q = 0; q < ACOPY; q++) Ab[q * (64 * NMW) + tid] = araw[q];
   };
   auto mfma_stage = [&](int buf) __attribute__((always_inline)) {
+    if (a.ablate & 4) return;
     const raw16* Ab = As + buf * ASLOTS;
     const raw16* Bb = Bs + buf * BSLOTS;
 #pragma unroll
@@ -424,6 +436,7 @@ int dcn_tc_forward(const DcnShape& s, const TcPlan& pl, const void* x_nhwc, cons
   TcArgs a{};
   a.x = x_nhwc; a.offset = offset; a.mask = mask; a.wp = wp; a.bias = bias; a.out = out; a.partial = partial;
   a.n_pt = pl.n_pt; a.n_cot = pl.n_cot; a.ksplit = pl.ksplit; a.NC64 = pl.NC64; a.S = pl.S;
+  { const char* e = getenv("D2AMD_DCN_ABLATE"); a.ablate = e ? atoi(e) : 0; }
   const long total = (long)pl.n_pt * pl.n_cot * s.G * pl.ksplit;
   D2_CHECK_ARG(total < (1l << 30), "deform_conv: too many tiles");
   a.total = (int)total;
@@ -463,77 +476,80 @@ template int dcn_tc_forward<f16_t>(const DcnShape&, const TcPlan&, const void*, 
 // (dcol = W^T dY into an HBM column buffer, then col2im with one global atomic per (sample corner,
 // channel) and a col2im_coord kernel that re-reads the column buffer).
 //
-// Workgroup = one 8x8 tile of output positions x one deformable group; stage = (32-channel chunk, tap).
-// Per stage: dcol[32 ch][64 pos] = W^T[tap, chunk] dY by MFMA (K = Cog split over two wave halves),
-// exchanged through LDS, then
-//   phase A  lane = (position, 8 channels): re-gather the 4 corners of x, form the bilinear value and
-//            its coordinate derivatives, reduce d(offset) / d(mask) over channels (wave shuffles,
-//            one owner thread per (tap, position) accumulates in LDS -> plain stores at the end);
-//   phase B  lane = channel, half-wave = (position, corner): dX contribution w_corner * mask * dcol
-//            added into an LDS-resident fp32 PATCH of the input (the 8x8 tile's taps +- R pixels),
-//            with ds_add_f32; only samples displaced by more than R pixels go to global atomics.
-// After the 9 taps of a chunk the patch is flushed with one 128-B-coalesced global atomic per touched
-// (pixel, 32 channels): ~10x fewer device-scope atomics than one per sample corner, which is what
-// bounded the first version (profiles/r01: 2.3 ms for res3, atomics execute beyond the XCD L2).
+// Workgroup = one 8x8 tile of output positions x one deformable group; stage = (64-channel chunk, tap).
+// Per stage: dcol[64 ch][64 pos] = W^T[tap, chunk] dY by MFMA (operand fragments straight from L2:
+// weights pre-packed in fragment order, dY as [position][Co]; K = Cog split over two wave halves that
+// meet in LDS), then
+//   phase A  lane = (position, 8 channels): re-gather the 4 corners of x, form the bilinear value and its
+//            coordinate derivatives, reduce d(offset) / d(mask) over channels (wave shuffles; one owner
+//            thread per (tap, position) accumulates in LDS -> plain stores at the end, no atomics);
+//   phase B  dX: one wave instruction = one (position, corner) pair x 64 channels = ONE 256-B contiguous
+//            global fp32 atomic; the pair's weight / target are wave-uniform (SGPRs), pairs with zero
+//            weight are skipped by a scalar branch.
+// Measured on MI355X (profiles/r01/dcn_*): device-scope fp32 atomics retire ~0.75 lane-ops/clk/CU when
+// every instruction covers whole 128-B lines (4x the first version's strided pattern).  Accumulating in
+// an LDS-resident patch first was tried and is SLOWER: ds_add_f32 retires ~0.2 lane-ops/clk/CU.
 struct BwEntry {
   uint32_t pix[4];  // pixel index (b*H + y)*W + x of the corner; 0 when unused
   float w[4];       // bilinear corner weights (mask NOT folded in); 0 for corners outside
   float lh, lw, m;
   uint32_t flags;   // bit c: corner c inside the image; bit 4: sample inside (-1,H)x(-1,W) and position valid
-  int py, px;       // patch coordinates of corner 0 (h_low, w_low); may lie outside the patch
-  int pad[2];
 };
-static_assert(sizeof(BwEntry) == 64, "BwEntry layout");
+static_assert(sizeof(BwEntry) == 48, "BwEntry layout");
+struct BwPair { float wgt; uint32_t eofs; };  // weight * mask of a (position, corner); element offset pix * C
 
 struct BwArgs {
   const void *x, *offset, *mask, *wp, *gout;  // x NHWC, gout NHWC [P][Co], wp = tc_pack_weight_t layout
   float *gx, *goff, *gmask;                   // gx fp32 NHWC (zero-filled), goff / gmask fp32 NCHW-like
-  int tiles_y, tiles_x, total, R, PHt, PWt;
+  int tiles_y, tiles_x, total, csplit;  // csplit: workgroups per (tile, deformable group), each a share of the channel chunks
+  int ablate;  // profiling only: 1 no MFMA, 2 no phase A, 4 no phase B, 16 phase B without the atomics
 };
 
-// weight (Co, Cg, K2) -> [g][tap][c32][ks][lane][8]: element j of lane l =
-// W[co = ks*16 + (l >> 5)*8 + j][ci = c32*32 + (l & 31)][tap]  (A operand rows = input channels, k = co)
+// weight (Co, Cg, K2) -> [g][tap][c64][mt(2)][ks][lane][8]: element j of lane l =
+// W[co = ks*16 + (l >> 5)*8 + j][ci = c64*64 + mt*32 + (l & 31)][tap]  (A operand rows = input channels, k = co)
 template <typename T>
 __global__ __launch_bounds__(256) void tc_pack_weight_t_kernel(const T* __restrict__ w, T* __restrict__ wp, int G,
                                                               int Cog, int Cg, int K2) {
-  const int NC32 = Cg / 32, KS = Cog / 16;
-  const long total = (long)G * K2 * NC32 * KS * 64;
+  const int NC64 = Cg / 64, KS = Cog / 16;
+  const long total = (long)G * K2 * NC64 * 2 * KS * 64;
   for (long gi = (long)blockIdx.x * blockDim.x + threadIdx.x; gi < total; gi += (long)gridDim.x * blockDim.x) {
     long r = gi;
     const int lane = (int)(r % 64); r /= 64;
     const int ks = (int)(r % KS); r /= KS;
-    const int c32 = (int)(r % NC32); r /= NC32;
+    const int mt = (int)(r % 2); r /= 2;
+    const int c64 = (int)(r % NC64); r /= NC64;
     const int tap = (int)(r % K2); r /= K2;
     const int g = (int)r;
-    const int ci = c32 * 32 + (lane & 31);
+    const int ci = c64 * 64 + mt * 32 + (lane & 31);
     const int co0 = ks * 16 + (lane >> 5) * 8;
 #pragma unroll
     for (int j = 0; j < 8; j++) wp[gi * 8 + j] = w[(((long)g * Cog + co0 + j) * Cg + ci) * K2 + tap];
   }
 }
 
+constexpr int BW_CPITCH = 68;  // floats per position row of the dcol tile (16-B aligned rows, spread banks)
+
 template <typename T>
 __global__ __launch_bounds__(256, 2) void dcn_bwd_data_tc_kernel(DcnShape s, BwArgs a) {
   typedef Mma<T> M;
   extern __shared__ __attribute__((aligned(16))) unsigned char bw_smem[];
   __shared__ __attribute__((aligned(16))) BwEntry ent[64];
-  __shared__ __attribute__((aligned(16))) float Cs[64][36];
-  float* red = reinterpret_cast<float*>(bw_smem);              // [K2][64][3]
-  float* patch = red + s.K2 * 64 * 3;                           // [PHt*PWt][32]
-  const int npatch = a.PHt * a.PWt * 32;
+  __shared__ __attribute__((aligned(8))) BwPair pairs[256];
+  __shared__ __attribute__((aligned(16))) float Cs[64 * BW_CPITCH];
+  float* red = reinterpret_cast<float*>(bw_smem);  // [K2][64][3]
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int per_xcd = (a.total + 7) >> 3;
   const int logical = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
   if (logical >= a.total) return;
-  const int dgi = logical % s.DG;
-  int tile = logical / s.DG;
+  const int cz = logical % a.csplit;
+  int tile = logical / a.csplit;
+  const int dgi = tile % s.DG; tile /= s.DG;
   const int tx = tile % a.tiles_x; tile /= a.tiles_x;
   const int ty = tile % a.tiles_y;
   const int b = tile / a.tiles_y;
-  const int oy = ty * 8 * s.sh - s.ph - a.R, ox = tx * 8 * s.sw - s.pw - a.R;
 
-  for (int i = tid; i < s.K2 * 64 * 3 + npatch; i += 256) red[i] = 0.f;  // red and patch are contiguous
+  for (int i = tid; i < s.K2 * 64 * 3; i += 256) red[i] = 0.f;
 
   const T* offset = (const T*)a.offset;
   const T* mask = (const T*)a.mask;
@@ -548,34 +564,39 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_tc_kernel(DcnShape s, BwA
   const bool validB = hoB < s.Ho && woB < s.Wo;
   const long pB = ((long)b * s.Ho + hoB) * s.Wo + woB;
   const uint32_t pixbytes = (uint32_t)s.C * (uint32_t)sizeof(T);
+  // this thread's (position, corner) for the tables
+  const int nE = tid >> 2, cE = tid & 3;
+  const int hoE = ty * 8 + (nE >> 3), woE = tx * 8 + (nE & 7);
+  const bool validE = hoE < s.Ho && woE < s.Wo;
+  const int lE = hoE * s.Wo + woE;
 
-  const int c_lo = dgi * s.cpg, c_hi = c_lo + s.cpg;
-  for (int cabs = c_lo; cabs < c_hi; cabs += 32) {
-    const int g = cabs / s.Cg, c32 = (cabs - g * s.Cg) >> 5;
+  const int nchunk = s.cpg >> 6;
+  const int c_lo = dgi * s.cpg + 64 * (int)((long)cz * nchunk / a.csplit);
+  const int c_hi = dgi * s.cpg + 64 * (int)((long)(cz + 1) * nchunk / a.csplit);
+  for (int cabs = c_lo; cabs < c_hi; cabs += 64) {
+    const int g = cabs / s.Cg, c64 = (cabs - g * s.Cg) >> 6;
     for (int tap = 0; tap < s.K2; tap++) {
-      // ---- (1) table of this tap (threads 0..63), while everyone starts on the operand loads
-      if (tid < 64) {
+      // ---- (1) tables of this tap: every thread evaluates the sample of its position (4 threads per
+      //          position, one per corner), writes its pair record; corner 0 also writes the entry
+      {
         BwEntry e;
 #pragma unroll
         for (int t = 0; t < 4; t++) { e.pix[t] = 0u; e.w[t] = 0.f; }
-        e.lh = e.lw = 0.f; e.m = 0.f; e.flags = 0u; e.py = e.px = -(1 << 20); e.pad[0] = e.pad[1] = 0;
-        const int ho = ty * 8 + (tid >> 3), wo = tx * 8 + (tid & 7);
-        if (ho < s.Ho && wo < s.Wo) {
-          const int l = ho * s.Wo + wo;
+        e.lh = e.lw = 0.f; e.m = 0.f; e.flags = 0u;
+        if (validE) {
           const int i = tap / s.kw, j = tap - i * s.kw;
           const long obase = ((long)b * s.DG + dgi) * 2 * s.K2;
-          const float off_h = to_f32(offset[(obase + 2 * tap) * s.L + l]);
-          const float off_w = to_f32(offset[(obase + 2 * tap + 1) * s.L + l]);
-          e.m = mask ? to_f32(mask[(((long)b * s.DG + dgi) * s.K2 + tap) * s.L + l]) : 1.f;
-          const float h_im = (float)(ho * s.sh - s.ph + i * s.dh) + off_h;
-          const float w_im = (float)(wo * s.sw - s.pw + j * s.dw) + off_w;
+          const float off_h = to_f32(offset[(obase + 2 * tap) * s.L + lE]);
+          const float off_w = to_f32(offset[(obase + 2 * tap + 1) * s.L + lE]);
+          e.m = mask ? to_f32(mask[(((long)b * s.DG + dgi) * s.K2 + tap) * s.L + lE]) : 1.f;
+          const float h_im = (float)(hoE * s.sh - s.ph + i * s.dh) + off_h;
+          const float w_im = (float)(woE * s.sw - s.pw + j * s.dw) + off_w;
           if (h_im > -1.f && w_im > -1.f && h_im < (float)s.H && w_im < (float)s.W) {
             const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
             const int h_high = h_low + 1, w_high = w_low + 1;
             const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
             const float hh = 1.f - lh, hw = 1.f - lw;
             e.lh = lh; e.lw = lw; e.flags = 16u;
-            e.py = h_low - oy; e.px = w_low - ox;
             const long rowbase = (long)b * s.H;
             if (h_low >= 0 && w_low >= 0) { e.pix[0] = (uint32_t)((rowbase + h_low) * s.W + w_low); e.w[0] = hh * hw; e.flags |= 1u; }
             if (h_low >= 0 && w_high <= s.W - 1) { e.pix[1] = (uint32_t)((rowbase + h_low) * s.W + w_high); e.w[1] = hh * lw; e.flags |= 2u; }
@@ -583,96 +604,116 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_tc_kernel(DcnShape s, BwA
             if (h_high <= s.H - 1 && w_high <= s.W - 1) { e.pix[3] = (uint32_t)((rowbase + h_high) * s.W + w_high); e.w[3] = lh * lw; e.flags |= 8u; }
           }
         }
-        ent[tid] = e;
+        if (cE == 0) ent[nE] = e;
+        const float wsel = cE == 0 ? e.w[0] : cE == 1 ? e.w[1] : cE == 2 ? e.w[2] : e.w[3];
+        const uint32_t psel = cE == 0 ? e.pix[0] : cE == 1 ? e.pix[1] : cE == 2 ? e.pix[2] : e.pix[3];
+        pairs[tid] = BwPair{wsel * e.m, psel * (uint32_t)s.C};
       }
-      // ---- (2) dcol tile by MFMA: rows = the 32 channels of the chunk, cols = this wave's 32 positions,
-      //          K = this wave half's share of the group's output channels; operand fragments straight
-      //          from L2 (weights pre-packed in fragment order, dY as [position][Co])
-      f32x16_t acc;
+      // ---- (2) dcol tile by MFMA: rows = the 64 channels of the chunk (2 M-tiles), cols = this wave's 32
+      //          positions, K = this wave half's share of the group's output channels
+      f32x16_t acc[2];
 #pragma unroll
-      for (int r = 0; r < 16; r++) acc[r] = 0.f;
-      {
-        const raw16* wsrc = wp + ((((size_t)g * s.K2 + tap) * (s.Cg >> 5) + c32) * KS) * 64 + lane;
+      for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[m][r] = 0.f;
+      if (!(a.ablate & 1)) {
+        const raw16* wsrc = wp + ((((size_t)g * s.K2 + tap) * (s.Cg >> 6) + c64) * 2 * KS) * 64 + lane;
         const T* gsrc = gout + pB * s.Co + (long)g * s.Cog + (lane >> 5) * 8;
         const raw16 zero = {0u, 0u, 0u, 0u};
-        constexpr int KB = 4;
-        raw16 af[2][KB], bf[2][KB];
-        auto ld = [&](int k0, raw16 (&A)[KB], raw16 (&Bq)[KB]) __attribute__((always_inline)) {
+        constexpr int KB = 2;
+        raw16 af[2][2][KB], bf[2][KB];
+        auto ld = [&](int k0, raw16 (&A)[2][KB], raw16 (&Bq)[KB]) __attribute__((always_inline)) {
 #pragma unroll
           for (int u = 0; u < KB; u++) {
             const int ks = min(k0 + u, KS - 1);
-            A[u] = wsrc[(size_t)ks * 64];
+            A[0][u] = wsrc[(size_t)ks * 64];
+            A[1][u] = wsrc[(size_t)(KS + ks) * 64];
             Bq[u] = validB ? *reinterpret_cast<const raw16*>(gsrc + ks * 16) : zero;
           }
+        };
+        auto mm = [&](int k0, int k_hi, const raw16 (&A)[2][KB], const raw16 (&Bq)[KB]) __attribute__((always_inline)) {
+#pragma unroll
+          for (int u = 0; u < KB; u++)
+            if (k0 + u < k_hi) {  // uniform
+              const typename M::frag bq = __builtin_bit_cast(typename M::frag, Bq[u]);
+              acc[0] = M::mma(__builtin_bit_cast(typename M::frag, A[0][u]), bq, acc[0]);
+              acc[1] = M::mma(__builtin_bit_cast(typename M::frag, A[1][u]), bq, acc[1]);
+            }
         };
         const int k_lo = khalf * KH, k_hi = k_lo + KH;
         ld(k_lo, af[0], bf[0]);
         for (int k0 = k_lo; k0 < k_hi; k0 += 2 * KB) {
           if (k0 + KB < k_hi) ld(k0 + KB, af[1], bf[1]);
-#pragma unroll
-          for (int u = 0; u < KB; u++)
-            if (k0 + u < k_hi)
-              acc = M::mma(__builtin_bit_cast(typename M::frag, af[0][u]), __builtin_bit_cast(typename M::frag, bf[0][u]), acc);
+          mm(k0, k_hi, af[0], bf[0]);
           if (k0 + KB < k_hi) {
             if (k0 + 2 * KB < k_hi) ld(k0 + 2 * KB, af[0], bf[0]);
-#pragma unroll
-            for (int u = 0; u < KB; u++)
-              if (k0 + KB + u < k_hi)
-                acc = M::mma(__builtin_bit_cast(typename M::frag, af[1][u]), __builtin_bit_cast(typename M::frag, bf[1][u]), acc);
+            mm(k0 + KB, k_hi, af[1], bf[1]);
           }
         }
       }
       // ---- (3) the two K halves meet in LDS: Cs[position][channel]
       if (khalf == 0) {
 #pragma unroll
-        for (int rg = 0; rg < 4; rg++)
-          *reinterpret_cast<float4*>(&Cs[nB][8 * rg + 4 * (lane >> 5)]) =
-              make_float4(acc[4 * rg], acc[4 * rg + 1], acc[4 * rg + 2], acc[4 * rg + 3]);
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+          for (int rg = 0; rg < 4; rg++)
+            *reinterpret_cast<float4*>(&Cs[nB * BW_CPITCH + 32 * m + 8 * rg + 4 * (lane >> 5)]) =
+                make_float4(acc[m][4 * rg], acc[m][4 * rg + 1], acc[m][4 * rg + 2], acc[m][4 * rg + 3]);
       }
       __syncthreads();
       if (khalf == 1) {
 #pragma unroll
-        for (int rg = 0; rg < 4; rg++) {
-          float4* q = reinterpret_cast<float4*>(&Cs[nB][8 * rg + 4 * (lane >> 5)]);
-          float4 v = *q;
-          v.x += acc[4 * rg]; v.y += acc[4 * rg + 1]; v.z += acc[4 * rg + 2]; v.w += acc[4 * rg + 3];
-          *q = v;
-        }
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+          for (int rg = 0; rg < 4; rg++) {
+            float4* q = reinterpret_cast<float4*>(&Cs[nB * BW_CPITCH + 32 * m + 8 * rg + 4 * (lane >> 5)]);
+            float4 v = *q;
+            v.x += acc[m][4 * rg]; v.y += acc[m][4 * rg + 1]; v.z += acc[m][4 * rg + 2]; v.w += acc[m][4 * rg + 3];
+            *q = v;
+          }
       }
       __syncthreads();
-      // ---- (4) phase A: d(offset), d(mask).  thread = (position n, 8 channels q*8..)
-      if (a.goff || a.gmask) {
+      // ---- (4) phase A: d(offset), d(mask).  thread = (position n, channels q*8.. and (q+4)*8..)
+      if ((a.goff || a.gmask) && !(a.ablate & 2)) {
         const int n = tid >> 2, q = tid & 3;
         const BwEntry& e = ent[n];
         const uint32_t flags = e.flags;
         float s_h = 0.f, s_w = 0.f, s_m = 0.f;
         if (flags & 16u) {
-          const uint32_t cofs = (uint32_t)(cabs + q * 8) * (uint32_t)sizeof(T);
-          raw16 raw[4];
+          raw16 raw[2][4];
 #pragma unroll
-          for (int c = 0; c < 4; c++) raw[c] = *reinterpret_cast<const raw16*>(xb + ((size_t)e.pix[c] * pixbytes + cofs));
-          float v[4][8];
+          for (int h = 0; h < 2; h++) {
+            const uint32_t cofs = (uint32_t)(cabs + (q + 4 * h) * 8) * (uint32_t)sizeof(T);
 #pragma unroll
-          for (int c = 0; c < 4; c++) {
-            tc_unpack(raw[c], v[c], T{});
-            if (!(flags & (1u << c))) {
-#pragma unroll
-              for (int u = 0; u < 8; u++) v[c][u] = 0.f;
-            }
+            for (int c = 0; c < 4; c++)
+              raw[h][c] = *reinterpret_cast<const raw16*>(xb + ((size_t)e.pix[c] * pixbytes + cofs));
           }
-          const float4 d0 = *reinterpret_cast<const float4*>(&Cs[n][q * 8]);
-          const float4 d1 = *reinterpret_cast<const float4*>(&Cs[n][q * 8 + 4]);
-          const float d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
           const float lh = e.lh, lw = e.lw, hh = 1.f - lh, hw = 1.f - lw, m = e.m;
           const float w0 = e.w[0], w1 = e.w[1], w2 = e.w[2], w3 = e.w[3];
 #pragma unroll
-          for (int u = 0; u < 8; u++) {
-            const float val = w0 * v[0][u] + w1 * v[1][u] + w2 * v[2][u] + w3 * v[3][u];
-            const float dvh = -hw * v[0][u] - lw * v[1][u] + hw * v[2][u] + lw * v[3][u];
-            const float dvw = -hh * v[0][u] + hh * v[1][u] - lh * v[2][u] + lh * v[3][u];
-            s_h += dvh * d[u] * m;
-            s_w += dvw * d[u] * m;
-            s_m += d[u] * val;
+          for (int h = 0; h < 2; h++) {
+            float v[4][8];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+              tc_unpack(raw[h][c], v[c], T{});
+              if (!(flags & (1u << c))) {
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[c][u] = 0.f;
+              }
+            }
+            const float* cp = &Cs[n * BW_CPITCH + (q + 4 * h) * 8];
+            const float4 d0 = *reinterpret_cast<const float4*>(cp);
+            const float4 d1 = *reinterpret_cast<const float4*>(cp + 4);
+            const float d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+              const float val = w0 * v[0][u] + w1 * v[1][u] + w2 * v[2][u] + w3 * v[3][u];
+              const float dvh = -hw * v[0][u] - lw * v[1][u] + hw * v[2][u] + lw * v[3][u];
+              const float dvw = -hh * v[0][u] + hh * v[1][u] - lh * v[2][u] + lh * v[3][u];
+              s_h += dvh * d[u] * m;
+              s_w += dvw * d[u] * m;
+              s_m += d[u] * val;
+            }
           }
         }
         s_h += __shfl_xor(s_h, 1); s_w += __shfl_xor(s_w, 1); s_m += __shfl_xor(s_m, 1);
@@ -682,44 +723,38 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_tc_kernel(DcnShape s, BwA
           rp[0] += s_h; rp[1] += s_w; rp[2] += s_m;
         }
       }
-      // ---- (5) phase B: dX.  half-wave = (position, corner), lane = channel of the chunk
-      if (a.gx) {
-        const int ch = lane & 31, sub = lane >> 5;
-#pragma unroll 4
-        for (int it = 0; it < 32; it++) {
-          const int pid = (it * 4 + wid) * 2 + sub;
-          const int n = pid >> 2, c = pid & 3;
-          const BwEntry& e = ent[n];
-          const float wgt = e.w[c] * e.m;
-          if (wgt != 0.f && (e.flags & 16u)) {
-            const float val = wgt * Cs[n][ch];
-            const int yy = e.py + (c >> 1), xx = e.px + (c & 1);
-            if ((unsigned)yy < (unsigned)a.PHt && (unsigned)xx < (unsigned)a.PWt)
-              atomicAdd(&patch[(yy * a.PWt + xx) * 32 + ch], val);
-            else
-              atomicAdd(a.gx + (size_t)e.pix[c] * s.C + cabs + ch, val);
+      // ---- (5) phase B: dX.  wave instruction = one (position, corner) pair x 64 channels
+      if (a.gx && !(a.ablate & 4)) {
+        float* gxc = a.gx + cabs + lane;
+        constexpr int UB = 8;
+        for (int it0 = 0; it0 < 64; it0 += UB) {
+          float wg[UB], dv[UB];
+          uint32_t eo[UB];
+#pragma unroll
+          for (int u = 0; u < UB; u++) {
+            const int pid = (it0 + u) * 4 + wid;
+            const BwPair pr = pairs[pid];
+            wg[u] = pr.wgt; eo[u] = pr.eofs;
+            dv[u] = Cs[(pid >> 2) * BW_CPITCH + lane];
+          }
+#pragma unroll
+          for (int u = 0; u < UB; u++) {
+            const float wgu = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wg[u])));
+            const uint32_t eou = (uint32_t)__builtin_amdgcn_readfirstlane((int)eo[u]);
+            if (wgu != 0.f) {  // scalar branch
+              const float val = wgu * dv[u];
+              if (a.ablate & 16) { if (val == 123.456f) Cs[0] = val; }
+              else atomicAdd(gxc + eou, val);
+            }
           }
         }
       }
-      __syncthreads();  // ent / Cs are rewritten by the next stage
-    }
-    // ---- flush the patch of this channel chunk: one coalesced atomic per touched (pixel, channel)
-    if (a.gx) {
-      for (int i = tid; i < npatch; i += 256) {
-        const float v = patch[i];
-        if (v != 0.f) {
-          patch[i] = 0.f;
-          const int pixel = i >> 5, ch = i & 31;
-          const int yy = pixel / a.PWt, xx = pixel - yy * a.PWt;
-          const int hy = oy + yy, wx = ox + xx;
-          if (hy >= 0 && hy < s.H && wx >= 0 && wx < s.W)
-            atomicAdd(a.gx + (((size_t)b * s.H + hy) * s.W + wx) * s.C + cabs + ch, v);
-        }
-      }
-      __syncthreads();
+      __syncthreads();  // ent / pairs / Cs are rewritten by the next stage
     }
   }
-  // ---- d(offset) / d(mask): every (tap, position) of this deformable group has exactly one owner
+  // ---- d(offset) / d(mask): with csplit == 1 every (tap, position) of this deformable group has exactly
+  //      one owner (plain stores); otherwise the csplit channel shares add into the zero-filled output
+  __syncthreads();
   for (int i = tid; i < s.K2 * 64; i += 256) {
     const int tap = i >> 6, n = i & 63;
     const int ho = ty * 8 + (n >> 3), wo = tx * 8 + (n & 7);
@@ -727,11 +762,15 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_tc_kernel(DcnShape s, BwA
     const int l = ho * s.Wo + wo;
     const float* rp = red + i * 3;
     const long ob = ((long)b * s.DG + dgi) * 2 * s.K2;
-    if (a.goff) {
-      a.goff[(ob + 2 * tap) * s.L + l] = rp[0];
-      a.goff[(ob + 2 * tap + 1) * s.L + l] = rp[1];
+    float* ph = a.goff ? a.goff + (ob + 2 * tap) * s.L + l : nullptr;
+    float* pm = a.gmask ? a.gmask + (((long)b * s.DG + dgi) * s.K2 + tap) * s.L + l : nullptr;
+    if (a.csplit == 1) {
+      if (ph) { ph[0] = rp[0]; ph[s.L] = rp[1]; }
+      if (pm) pm[0] = rp[2];
+    } else {
+      if (ph) { atomicAdd(ph, rp[0]); atomicAdd(ph + s.L, rp[1]); }
+      if (pm) atomicAdd(pm, rp[2]);
     }
-    if (a.gmask) a.gmask[(((long)b * s.DG + dgi) * s.K2 + tap) * s.L + l] = rp[2];
   }
 }
 
@@ -740,26 +779,19 @@ TcBwPlan dcn_tc_plan_bwd(const DcnShape& s, int dtype) {
   pl.ok = false;
   if (getenv("D2AMD_DCN_V1") || getenv("D2AMD_DCN_BWD_V1")) return pl;
   if (dtype != D2AMD_BF16 && dtype != D2AMD_F16) return pl;
-  if (s.Cg % 32 != 0 || s.cpg % 32 != 0 || s.Cog % 32 != 0 || s.K2 > 32 || s.P <= 0) return pl;
-  if ((long)s.B * s.H * s.W * s.C * 4 >= (1l << 40) || (long)s.B * s.H * s.W >= (1l << 31)) return pl;
+  if (s.Cg % 64 != 0 || s.cpg % 64 != 0 || s.Cog % 32 != 0 || s.K2 > 64 || s.P <= 0) return pl;
+  if ((long)s.B * s.H * s.W * s.C >= (1l << 31)) return pl;  // 32-bit element offsets into gx / x
   pl.tiles_y = cdiv(s.Ho, 8); pl.tiles_x = cdiv(s.Wo, 8);
-  const size_t red_bytes = (size_t)s.K2 * 64 * 3 * 4;
-  // largest displacement margin R whose patch fits ~48 KB (two workgroups per CU)
-  const char* er = getenv("D2AMD_DCN_PATCH_R");  // profiling switch; -1 disables the patch
-  int R = -1;
-  for (int r = 0; r <= 8; r++) {
-    const long ph = 7l * s.sh + (long)(s.kh - 1) * s.dh + 2 + 2 * r, pw = 7l * s.sw + (long)(s.kw - 1) * s.dw + 2 + 2 * r;
-    if (ph * pw * 32 * 4 + (long)red_bytes <= 56 * 1024) R = r;
+  {  // small maps: split the channel chunks of a tile over several workgroups until ~4 per CU
+    const long tiles = (long)s.B * pl.tiles_y * pl.tiles_x * s.DG;
+    const int nchunk = s.cpg / 64;
+    int cs = 1;
+    while (cs < nchunk && tiles * cs < 1024) cs++;
+    const char* e = getenv("D2AMD_DCN_CSPLIT");  // profiling switch
+    if (e && atoi(e) >= 1) cs = atoi(e) < nchunk ? atoi(e) : nchunk;
+    pl.csplit = cs;
   }
-  if (er) R = atoi(er) < R ? atoi(er) : R;
-  pl.R = R;
-  if (R >= 0) {
-    pl.PHt = 7 * s.sh + (s.kh - 1) * s.dh + 2 + 2 * R;
-    pl.PWt = 7 * s.sw + (s.kw - 1) * s.dw + 2 + 2 * R;
-  } else {
-    pl.PHt = pl.PWt = 0;
-  }
-  pl.lds = red_bytes + (size_t)pl.PHt * pl.PWt * 32 * 4;
+  pl.lds = (size_t)s.K2 * 64 * 3 * 4;
   pl.wp_bytes = (size_t)s.Co * s.Cg * s.K2 * 2;
   pl.ok = true;
   return pl;
@@ -770,7 +802,7 @@ int dcn_tc_backward_data(const DcnShape& s, const TcBwPlan& pl, const void* x_nh
                          const void* mask, const void* weight, const void* gout_nhwc, float* gx, float* goff,
                          float* gmask, void* wp, hipStream_t st) {
   {
-    const long groups16 = (long)s.G * s.K2 * (s.Cg / 32) * (s.Cog / 16) * 64;
+    const long groups16 = (long)s.G * s.K2 * (s.Cg / 64) * 2 * (s.Cog / 16) * 64;
     const int blocks = cdiv(groups16, 256) > 8192 ? 8192 : cdiv(groups16, 256);
     hipLaunchKernelGGL((tc_pack_weight_t_kernel<T>), dim3(blocks), dim3(256), 0, st, (const T*)weight, (T*)wp, s.G,
                        s.Cog, s.Cg, s.K2);
@@ -779,15 +811,17 @@ int dcn_tc_backward_data(const DcnShape& s, const TcBwPlan& pl, const void* x_nh
   BwArgs a{};
   a.x = x_nhwc; a.offset = offset; a.mask = mask; a.wp = wp; a.gout = gout_nhwc;
   a.gx = gx; a.goff = goff; a.gmask = gmask;
-  a.tiles_y = pl.tiles_y; a.tiles_x = pl.tiles_x; a.R = pl.R < 0 ? 0 : pl.R; a.PHt = pl.PHt; a.PWt = pl.PWt;
-  const long total = (long)s.B * pl.tiles_y * pl.tiles_x * s.DG;
+  a.tiles_y = pl.tiles_y; a.tiles_x = pl.tiles_x; a.csplit = pl.csplit;
+  { const char* e = getenv("D2AMD_DCN_ABLATE_BWD"); a.ablate = e ? atoi(e) : 0; }
+  if (pl.csplit > 1) {  // channel shares accumulate d(offset) / d(mask) with atomics
+    if (goff) D2_HIP_OK(hipMemsetAsync(goff, 0, (size_t)s.B * s.DG * 2 * s.K2 * s.L * 4, st));
+    if (gmask) D2_HIP_OK(hipMemsetAsync(gmask, 0, (size_t)s.B * s.DG * s.K2 * s.L * 4, st));
+  }
+  const long total = (long)s.B * pl.tiles_y * pl.tiles_x * s.DG * pl.csplit;
   D2_CHECK_ARG(total < (1l << 30), "deform_conv: too many tiles");
   a.total = (int)total;
-  auto kern = dcn_bwd_data_tc_kernel<T>;
-  if (pl.lds > 48 * 1024)
-    D2_HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
   const int grid = (a.total + 7) / 8 * 8;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), pl.lds, st, s, a);
+  hipLaunchKernelGGL((dcn_bwd_data_tc_kernel<T>), dim3(grid), dim3(256), pl.lds, st, s, a);
   D2_LAUNCH_OK();
   return D2AMD_OK;
 }

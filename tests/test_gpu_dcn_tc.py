@@ -1,11 +1,10 @@
 """GPU parity of the 16-bit deformable-convolution MFMA path (detectron2_amd/csrc/deform_conv_tc.hip)
 against the CPU oracle evaluated on the same 16-bit-rounded inputs.
 
-The tile configuration, reduction split and the backward's LDS patch margin are selected by
-heuristics from the shape; the profiling switches D2AMD_DCN_CFG / D2AMD_DCN_PATCH_R (read on every
-call) force each code path here: every tile shape, split reductions, ragged channel / position
-tails, conv groups, deformable groups, stride / dilation, image borders, samples that leave the
-patch (global-atomic fallback) and the patch disabled altogether.  Reference behaviour:
+The forward's tile configuration and reduction split are selected by heuristics from the shape; the
+profiling switch D2AMD_DCN_CFG (read on every call) forces each code path here: every tile shape,
+split reductions, ragged channel / position tails, conv groups, deformable groups, stride /
+dilation, image borders, large offsets.  Reference behaviour:
 detectron2/layers/csrc/deformable/deform_conv_cuda_kernel.cu:216-452,785-1066.
 Tolerance: f16 4e-3, bf16 3e-2 of the output's max magnitude (16-bit I/O rounding; the same
 bars as tests/test_gpu_parity.py::test_deform_conv_16bit)."""
@@ -132,18 +131,24 @@ def test_fwd_bwd_shapes(B, C, Co, H, W, groups, dg, stride, pad, dil):
     check(case, TOL[torch.float16])
 
 
-def test_bwd_channel_multiples_of_32():
-    """The backward path accepts 32-channel granularity (forward falls back to the generic kernel)."""
+def test_channels_not_multiple_of_64_use_generic_kernels():
+    """C = 96: neither MFMA path applies (64-channel stages); the generic kernels serve the call."""
     case = make_case(13, 2, 96, 96, 10, 12)
     check(case, TOL[torch.float16])
 
 
-@pytest.mark.parametrize("patch_r", [-1, 0, 1, 4])
-def test_bwd_patch_margins_and_large_offsets(patch_r):
-    """Offsets of ~6 px throw most samples out of small patches (global-atomic fallback) and out of the
-    image; patch_r = -1 disables the LDS patch."""
+def test_bwd_large_offsets():
+    """Offsets of ~6 px throw many samples out of the image and far from their output position."""
     case = make_case(14, 2, 64, 64, 19, 23, off_scale=6.0)
-    with env(D2AMD_DCN_PATCH_R=patch_r):
+    check(case, TOL[torch.float16])
+
+
+@pytest.mark.parametrize("csplit", [1, 2, 4])
+def test_bwd_channel_split(csplit):
+    """The channel chunks of a tile can be shared by several workgroups (small feature maps); the shares add
+    d(offset) / d(mask) with atomics."""
+    case = make_case(18, 1, 256, 64, 10, 11, dg=1)
+    with env(D2AMD_DCN_CSPLIT=csplit):
         check(case, TOL[torch.float16])
 
 
