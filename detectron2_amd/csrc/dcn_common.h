@@ -93,7 +93,7 @@ static int launch_transpose(const TI* in, TO* out, int B, int R, int S, hipStrea
 // ---- 16-bit fragment-ordered MFMA path (deform_conv_tc.hip) ------------------------------------
 struct TcPlan {
   bool ok;
-  int MT, NWM, NWN, ksplit, BM, BN, n_cot, n_pt, NC64, S, ndg;
+  int MT, NWM, NWN, NKS, wave, ksplit, BM, BN, n_cot, n_pt, NCH, S, ndg;
   size_t wp_bytes, partial_bytes, lds;
 };
 TcPlan dcn_tc_plan_fwd(const DcnShape& s, int dtype);

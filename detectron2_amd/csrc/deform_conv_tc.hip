@@ -42,16 +42,20 @@ struct TcArgs {
   const void *x, *offset, *mask, *wp, *bias;
   void* out;
   float* partial;
-  int n_pt, n_cot, ksplit, NC64, S, total;
+  int n_pt, n_cot, ksplit, NCH, S, total;  // NCH: channel chunks (16*NKS channels) per conv group
   int ablate;  // profiling only (D2AMD_DCN_ABLATE): 1 no gather loads, 2 no combine, 4 no MFMA, 8 no weight copy
+  unsigned long long* stamps;  // profiling only (D2AMD_DCN_STAMPS): per workgroup {start, after tables, after loop, end} (100 MHz)
 };
 
-constexpr int TC_BPITCH = 4 * 66;  // 16-B slots per 32-position tile of the column buffer
-
-// slot of (n-tile, kstep, k-half, position in tile) in the column buffer
-__device__ __forceinline__ int tc_slot(int ntile, int ks, int half, int n32) {
-  return ntile * TC_BPITCH + ks * 66 + half * 33 + n32;
-}
+// Column buffer: per 32-position tile, 2*NKS "subs" (kstep, k-half) of 32 consecutive 16-B slots each, at a
+// pitch that spreads the 8 lanes of one ds_write_b128 group over the banks: NKS = 4: a group is one position
+// x 8 subs -> odd pitch; NKS = 2: two positions x 4 subs -> pitch = 2 (mod 8).  Reads (32 consecutive slots
+// per half-wave) are conflict free for any pitch.
+template <int NKS> struct TcB {
+  static constexpr int PS = NKS == 4 ? 33 : 34;
+  static constexpr int TILE = 2 * NKS * PS;  // 16-B slots per 32-position tile
+  __device__ static __forceinline__ int slot(int ntile, int sub, int n32) { return ntile * TILE + sub * PS + n32; }
+};
 
 __device__ __forceinline__ void tc_unpack(const raw16& r, float (&f)[8], bf16_t) {
   f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
@@ -116,25 +120,26 @@ __device__ __forceinline__ TcEntry tc_make_entry(const DcnShape& s, const T* __r
   return e;
 }
 
-// ---- weight packing: (Co, Cg, K2) -> [g][co tile][stage = (tap, c64)][m-tile][kstep][lane][8] -------
-// element j of lane l = W[co = cot*BM + mt*32 + (l & 31)][ci = c64*64 + ks*16 + (l >> 5)*8 + j][tap]
+// ---- weight packing: (Co, Cg, K2) -> [g][co tile][stage = (tap, chunk)][m-tile][kstep < NKS][lane][8] ----
+// element j of lane l = W[co = cot*BM + mt*32 + (l & 31)][ci = chunk*16*NKS + ks*16 + (l >> 5)*8 + j][tap]
 // (the A operand of v_mfma_f32_32x32x16: lane l holds row l & 31, k = 8*(l >> 5) .. +8); rows >= Cog are 0.
 template <typename T>
 __global__ __launch_bounds__(256) void tc_pack_weight_kernel(const T* __restrict__ w, T* __restrict__ wp, int G,
-                                                            int Cog, int Cg, int K2, int BM, int n_cot, int NC64) {
-  const int S = K2 * NC64, MTA = BM / 32;
-  const long total = (long)G * n_cot * S * MTA * 4 * 64;
+                                                            int Cog, int Cg, int K2, int BM, int n_cot, int NCH,
+                                                            int NKS) {
+  const int S = K2 * NCH, MTA = BM / 32;
+  const long total = (long)G * n_cot * S * MTA * NKS * 64;
   for (long gi = (long)blockIdx.x * blockDim.x + threadIdx.x; gi < total; gi += (long)gridDim.x * blockDim.x) {
     long r = gi;
     const int lane = (int)(r % 64); r /= 64;
-    const int ks = (int)(r % 4); r /= 4;
+    const int ks = (int)(r % NKS); r /= NKS;
     const int mt = (int)(r % MTA); r /= MTA;
     const int st = (int)(r % S); r /= S;
     const int cot = (int)(r % n_cot); r /= n_cot;
     const int g = (int)r;
-    const int tap = st / NC64, c64 = st - tap * NC64;
+    const int tap = st / NCH, cc = st - tap * NCH;
     const int co = cot * BM + mt * 32 + (lane & 31);
-    const int ci0 = c64 * 64 + ks * 16 + (lane >> 5) * 8;
+    const int ci0 = cc * 16 * NKS + ks * 16 + (lane >> 5) * 8;
     T v[8];
 #pragma unroll
     for (int j = 0; j < 8; j++)
@@ -152,14 +157,17 @@ __global__ __launch_bounds__(256) void tc_pack_weight_kernel(const T* __restrict
 // overlaps the matrix pipe with VALU when the two alternate in its own instruction stream, which hipcc
 // does not produce for this loop; a matrix wave and a gather wave resident on the same SIMD overlap
 // by construction.  One s_barrier per stage orders column/weight buffer hand-off (double buffered).
-template <typename T, int MT, int NWM, int NWN, int NG>
+template <typename T, int MT, int NWM, int NWN, int NG, int NKS>
 __global__ __launch_bounds__(64 * (NWM * NWN + NG)) void dcn_fwd_tc_kernel(DcnShape s, TcArgs a) {
   typedef Mma<T> M;
+  typedef TcB<NKS> BL;
   constexpr int NMW = NWM * NWN, NT = 64 * (NMW + NG), BM = 32 * MT * NWM, BN = 32 * NWN;
-  constexpr int ITEMS = (BN * 8) / (64 * NG);   // gather items per lane and stage
-  constexpr int ACOPY = (BM * 8) / (64 * NMW);  // 16-B weight slots per matrix-wave lane and stage
-  constexpr int ASLOTS = BM * 8, BSLOTS = NWN * TC_BPITCH;
-  static_assert((BN * 8) % (64 * NG) == 0 && (BM * 8) % (64 * NMW) == 0, "tile / thread mismatch");
+  constexpr int NSUB = 2 * NKS, CHUNK = 16 * NKS;       // (kstep, k-half) subs per stage; channels per stage
+  constexpr int ITEMS = (BN * NSUB) / (64 * NG);        // gather items per lane and stage
+  constexpr int ACOPY = (BM * NSUB) / (64 * NMW);       // 16-B weight slots per matrix-wave lane and stage
+  constexpr int ASLOTS = BM * NSUB, BSLOTS = NWN * BL::TILE;
+  static_assert((BN * NSUB) % (64 * NG) == 0 && (BM * NSUB) % (64 * NMW) == 0, "tile / thread mismatch");
+  static_assert(NKS == 2 || NKS == 4, "NKS");
   extern __shared__ __attribute__((aligned(16))) unsigned char tc_smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -181,6 +189,8 @@ __global__ __launch_bounds__(64 * (NWM * NWN + NG)) void dcn_fwd_tc_kernel(DcnSh
   TcEntry* ent = reinterpret_cast<TcEntry*>(tc_smem);
   raw16* As = reinterpret_cast<raw16*>(tc_smem + (size_t)nrows * BN * sizeof(TcEntry));
   raw16* Bs = As + 2 * ASLOTS;
+  unsigned long long* stamp = (a.stamps && tid == 0) ? a.stamps + 4 * (size_t)blockIdx.x : nullptr;
+  if (stamp) stamp[0] = wall_clock64();
 
   {
     const T* offset = (const T*)a.offset;
@@ -188,10 +198,12 @@ __global__ __launch_bounds__(64 * (NWM * NWN + NG)) void dcn_fwd_tc_kernel(DcnSh
     for (int e = tid; e < nrows * BN; e += NT) {
       const int row = e / BN, n = e - row * BN;
       const int tap = row / ndg, dgi = dg_first + (row - tap * ndg);
+      if (a.ablate & 32) { TcEntry z{}; ent[e] = z; continue; }
       ent[e] = tc_make_entry<T>(s, offset, mask, p0 + n, tap, dgi);
     }
   }
   __syncthreads();  // barrier #0: tables ready
+  if (stamp) stamp[1] = wall_clock64();
 
   const int s_lo = (int)((long)kz * a.S / a.ksplit), s_hi = (int)((long)(kz + 1) * a.S / a.ksplit);
   const int nst = s_hi - s_lo;  // >= 1 (ksplit <= S)
@@ -203,13 +215,13 @@ __global__ __launch_bounds__(64 * (NWM * NWN + NG)) void dcn_fwd_tc_kernel(DcnSh
     raw16 graw[2][ITEMS][4];
     float gw[2][ITEMS][4];
     auto issue = [&](int st, raw16 (&raw)[ITEMS][4], float (&w)[ITEMS][4]) __attribute__((always_inline)) {
-      const int tap = st / a.NC64, c64 = st - tap * a.NC64;
-      const int cabs = g * s.Cg + c64 * 64;
+      const int tap = st / a.NCH, cc = st - tap * a.NCH;
+      const int cabs = g * s.Cg + cc * CHUNK;
       const TcEntry* er = ent + (tap * ndg + (cabs / s.cpg - dg_first)) * BN;
 #pragma unroll
       for (int it = 0; it < ITEMS; it++) {
         const int i = it * (64 * NG) + gt;
-        const int n = i >> 3, sub = i & 7;
+        const int n = i / NSUB, sub = i % NSUB;
         const raw16 eo = *reinterpret_cast<const raw16*>(&er[n].off[0]);
         const raw16 ew = *reinterpret_cast<const raw16*>(&er[n].w[0]);
         const uint32_t cofs = (uint32_t)(cabs + sub * 8) * (uint32_t)sizeof(T);
@@ -227,14 +239,14 @@ __global__ __launch_bounds__(64 * (NWM * NWN + NG)) void dcn_fwd_tc_kernel(DcnSh
 #pragma unroll
         for (int it = 0; it < ITEMS; it++) {
           const int i = it * (64 * NG) + gt;
-          Bb[tc_slot(i >> 8, (i >> 4) & 3, (i >> 3) & 1, (i >> 3) & 31)] = raw[it][0] ^ raw[it][1] ^ raw[it][2] ^ raw[it][3];
+          Bb[BL::slot(i / (32 * NSUB), i % NSUB, (i / NSUB) & 31)] = raw[it][0] ^ raw[it][1] ^ raw[it][2] ^ raw[it][3];
         }
         return;
       }
 #pragma unroll
       for (int it = 0; it < ITEMS; it++) {
         const int i = it * (64 * NG) + gt;
-        const int n = i >> 3, sub = i & 7;
+        const int n = i / NSUB, sub = i % NSUB;
         float v[8];
 #pragma unroll
         for (int c = 0; c < 4; c++) {
@@ -244,7 +256,7 @@ __global__ __launch_bounds__(64 * (NWM * NWN + NG)) void dcn_fwd_tc_kernel(DcnSh
 #pragma unroll
           for (int u = 0; u < 8; u++) v[u] = c == 0 ? wc * f[u] : v[u] + wc * f[u];
         }
-        Bb[tc_slot(n >> 5, sub >> 1, sub & 1, n & 31)] = tc_pack(v, T{});
+        Bb[BL::slot(n >> 5, sub, n & 31)] = tc_pack(v, T{});
       }
     };
     // the gathers run TWO stages ahead of the matrix waves (register double buffer), so the L2
@@ -297,12 +309,12 @@ __global__ __launch_bounds__(64 * (NWM * NWN + NG)) void dcn_fwd_tc_kernel(DcnSh
     const raw16* Ab = As + buf * ASLOTS;
     const raw16* Bb = Bs + buf * BSLOTS;
 #pragma unroll
-    for (int ks = 0; ks < 4; ks++) {
-      const typename M::frag b = __builtin_bit_cast(typename M::frag, Bb[tc_slot(wn, ks, lane >> 5, lane & 31)]);
+    for (int ks = 0; ks < NKS; ks++) {
+      const typename M::frag b = __builtin_bit_cast(typename M::frag, Bb[BL::slot(wn, 2 * ks + (lane >> 5), lane & 31)]);
 #pragma unroll
       for (int m = 0; m < MT; m++) {
         const typename M::frag av =
-            __builtin_bit_cast(typename M::frag, Ab[((wm * MT + m) * 4 + ks) * 64 + lane]);
+            __builtin_bit_cast(typename M::frag, Ab[((wm * MT + m) * NKS + ks) * 64 + lane]);
         acc[m] = M::mma(av, b, acc[m]);
       }
     }
@@ -320,6 +332,7 @@ __global__ __launch_bounds__(64 * (NWM * NWN + NG)) void dcn_fwd_tc_kernel(DcnSh
   }
 
   // ---- epilogue: out[b][g*Cog + co][l] (+ bias), or fp32 partials when the reduction is split
+  if (stamp) stamp[2] = wall_clock64();
   const int p = p0 + wn * 32 + (lane & 31);
   const T* bias = (const T*)a.bias;
   const bool add_bias = bias != nullptr && a.ksplit == 1;  // uniform
@@ -336,7 +349,7 @@ __global__ __launch_bounds__(64 * (NWM * NWN + NG)) void dcn_fwd_tc_kernel(DcnSh
       for (int r = 0; r < 16; r++) acc[m][r] += bv[r];
     }
   }
-  if (p < s.P) {
+  if (p < s.P && !(a.ablate & 16)) {
     const int b = p / s.L, l = p - b * s.L;
     const long obase = ((long)b * s.Co + (long)g * s.Cog) * s.L + l;
     T* outp = (T*)a.out;
@@ -346,6 +359,225 @@ __global__ __launch_bounds__(64 * (NWM * NWN + NG)) void dcn_fwd_tc_kernel(DcnSh
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int co = cot * BM + (wm * MT + m) * 32 + frag_row(r, lane);
+        if (co < s.Cog) {
+          const long o = obase + (long)co * s.L;
+          if (a.ksplit == 1) outp[o] = from_f32<T>(acc[m][r]);
+          else part[o] = acc[m][r];
+        }
+      }
+    }
+  }
+  if (stamp) stamp[3] = wall_clock64();
+}
+
+// ---- forward kernel, autonomous-wave form -------------------------------------------------------------
+// One WAVE = one (32*MT output channels) x (32 positions) tile x one share of the (tap, channel) reduction,
+// with NO workgroup barrier and NO LDS: lane (n, half) gathers the 8 channels k = 8*half.. of its own
+// position n straight into the B-operand registers of v_mfma_f32_32x32x16 (the fragment layout of that
+// instruction IS "one position, 8 consecutive k per lane"), and reads the A operand (weights, pre-packed in
+// fragment order, 1 KiB coalesced per wave instruction) from L1/L2.  Measured motivation (profiles/r01,
+// dcn_fwd timeline): the LDS-staged workgroup kernel above spends 2/3 of its time in per-stage barrier /
+// LDS hand-off latency chains and in the tail of unevenly filled CUs, not on the matrix pipe, the VALU or
+// L1 bandwidth.  Autonomous waves balance at wave granularity (1,050 waves on 1,024 SIMDs for res3) and
+// keep two stages of operands in flight in registers.
+template <typename T, int MT, int NKS>
+__global__ __launch_bounds__(64, 2) void dcn_fwd_wave_kernel(DcnShape s, TcArgs a) {
+#ifdef D2AMD_WAVE_ABLATE
+  constexpr int WAB = D2AMD_WAVE_ABLATE;
+#else
+  constexpr int WAB = 0;
+#endif
+  typedef Mma<T> M;
+  constexpr int CHUNK = 16 * NKS, ASLOTS = 32 * MT * 2 * NKS;  // channels per stage; 16-B weight slots per stage
+  const int lane = threadIdx.x, n32 = lane & 31, half = lane >> 5;
+  const int per_xcd = (a.total + 7) >> 3;
+  const int logical = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if (logical >= a.total) return;
+  const int inner = a.n_cot * s.G * a.ksplit;
+  const int pt = logical / inner;
+  int rr = logical - pt * inner;
+  const int cot = rr % a.n_cot; rr /= a.n_cot;
+  const int g = rr % s.G;
+  const int kz = rr / s.G;
+  const int p = pt * 32 + n32;
+  const bool pvalid = p < s.P;
+  const int pc = pvalid ? p : s.P - 1;
+  const int b = pc / s.L, l = pc - b * s.L;
+  const int ho = l / s.Wo, wo = l - ho * s.Wo;
+  const T* offset = (const T*)a.offset;
+  const T* mask = (const T*)a.mask;
+  const char* xb = (const char*)a.x;
+  const raw16* wsrc = (const raw16*)a.wp + ((size_t)(g * a.n_cot + cot) * a.S) * ASLOTS + lane;
+  const int s_lo = (int)((long)kz * a.S / a.ksplit), s_hi = (int)((long)(kz + 1) * a.S / a.ksplit);
+  const uint32_t pix = (uint32_t)s.C * (uint32_t)sizeof(T);
+
+  // raw (offset_h, offset_w, mask) of (tap, deformable group) for this lane's position
+  auto tap_raw = [&](int tap, int dgi, float (&r)[3]) __attribute__((always_inline)) {
+    const long obase = ((long)b * s.DG + dgi) * 2 * s.K2;
+    r[0] = to_f32(offset[(obase + 2 * tap) * s.L + l]);
+    r[1] = to_f32(offset[(obase + 2 * tap + 1) * s.L + l]);
+    r[2] = mask ? to_f32(mask[(((long)b * s.DG + dgi) * s.K2 + tap) * s.L + l]) : 1.f;
+  };
+  // bilinear table of the current tap: byte offsets of the 4 corners + weights (x mask); see tc_make_entry
+  uint32_t eoff[4];
+  float ew[4];
+  auto make_entry = [&](int tap, const float (&r)[3]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < 4; t++) { eoff[t] = 0u; ew[t] = 0.f; }
+    const int i = tap / s.kw, j = tap - i * s.kw;
+    const float h_im = (float)(ho * s.sh - s.ph + i * s.dh) + r[0];
+    const float w_im = (float)(wo * s.sw - s.pw + j * s.dw) + r[1];
+    if (pvalid && h_im > -1.f && w_im > -1.f && h_im < (float)s.H && w_im < (float)s.W) {
+      const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+      const int h_high = h_low + 1, w_high = w_low + 1;
+      const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+      const float hh = 1.f - lh, hw = 1.f - lw, m = r[2];
+      const long rowbase = (long)b * s.H;
+      if (h_low >= 0 && w_low >= 0) { eoff[0] = (uint32_t)((rowbase + h_low) * s.W + w_low) * pix; ew[0] = hh * hw * m; }
+      if (h_low >= 0 && w_high <= s.W - 1) { eoff[1] = (uint32_t)((rowbase + h_low) * s.W + w_high) * pix; ew[1] = hh * lw * m; }
+      if (h_high <= s.H - 1 && w_low >= 0) { eoff[2] = (uint32_t)((rowbase + h_high) * s.W + w_low) * pix; ew[2] = lh * hw * m; }
+      if (h_high <= s.H - 1 && w_high <= s.W - 1) { eoff[3] = (uint32_t)((rowbase + h_high) * s.W + w_high) * pix; ew[3] = lh * lw * m; }
+    }
+  };
+
+  f32x16_t acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; m++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[m][r] = 0.f;
+
+  // The stages of one bilinear TABLE (tap, deformable group) are consecutive: SPT = min(cpg, Cg) / CHUNK
+  // of them (even, because both are multiples of 64).  The reduction share of this wave is a range of
+  // whole tables.  All loads sit in straight-line code (clamped indices instead of branches) so that the
+  // compiler's s_waitcnt counting stays exact and the stage-ahead prefetch really is asynchronous: with
+  // loads inside data-dependent branches hipcc falls back to vmcnt(0) before every stage.
+  const int dg_first = (g * s.Cg) / s.cpg, dg_last = ((g + 1) * s.Cg - 1) / s.cpg;
+  const int ndg = dg_last - dg_first + 1;
+  const int SPT = a.NCH / ndg;              // stages per table
+  const int ntab = s.K2 * ndg;
+  const int tb_lo = (int)((long)kz * ntab / a.ksplit), tb_hi = (int)((long)(kz + 1) * ntab / a.ksplit);
+
+  struct Tab { uint32_t off[4]; float w[4]; };
+  auto load_raw = [&](int tb, float (&r)[3]) __attribute__((always_inline)) {
+    tb = min(tb, ntab - 1);
+    const int tap = tb / ndg, dgi = dg_first + (tb - tap * ndg);
+    tap_raw(tap, dgi, r);
+  };
+  auto build = [&](int tb, const float (&r)[3], Tab& t) __attribute__((always_inline)) {
+    tb = min(tb, ntab - 1);
+    make_entry(tb / ndg, r);
+#pragma unroll
+    for (int c = 0; c < 4; c++) { t.off[c] = eoff[c]; t.w[c] = ew[c]; }
+  };
+  raw16 graw[2][NKS][4], araw[2][MT][NKS];
+  float gw[2][4];
+  // loads of stage (table tb, chunk q) with table registers `t`
+  auto issue = [&](int tb, int q, const Tab& t, raw16 (&gr)[NKS][4], raw16 (&ar)[MT][NKS], float (&w)[4]) __attribute__((always_inline)) {
+    const int tap = tb / ndg, dl = tb - tap * ndg;
+    const int cc = dl * SPT + q;                      // chunk index inside the conv group
+    const int st = tap * a.NCH + cc;
+    const uint32_t cofs = (uint32_t)(g * s.Cg + cc * CHUNK + half * 8) * (uint32_t)sizeof(T);
+    if (!(WAB & 1)) {
+#pragma unroll
+      for (int ks = 0; ks < NKS; ks++)
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+          gr[ks][c] = *reinterpret_cast<const raw16*>(xb + (t.off[c] + cofs + (uint32_t)(ks * 16 * sizeof(T))));
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) w[c] = t.w[c];
+    const raw16* src = wsrc + (size_t)st * ASLOTS;
+    if (!(WAB & 8)) {
+#pragma unroll
+      for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ks++) ar[m][ks] = src[(m * NKS + ks) * 64];
+    }
+  };
+  auto compute = [&](const raw16 (&gr)[NKS][4], const raw16 (&ar)[MT][NKS], const float (&w)[4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ks = 0; ks < NKS; ks++) {
+      raw16 bp;
+      if (WAB & 2) {
+        bp = gr[ks][0] ^ gr[ks][1] ^ gr[ks][2] ^ gr[ks][3];
+      } else {
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          float f[8];
+          tc_unpack(gr[ks][c], f, T{});
+#pragma unroll
+          for (int u = 0; u < 8; u++) v[u] = c == 0 ? w[c] * f[u] : v[u] + w[c] * f[u];
+        }
+        bp = tc_pack(v, T{});
+      }
+      const typename M::frag bq = __builtin_bit_cast(typename M::frag, bp);
+      if (WAB & 4) {
+#pragma unroll
+        for (int m = 0; m < MT; m++) acc[m][0] += __uint_as_float(bp.x ^ ar[m][ks].x);
+      } else {
+#pragma unroll
+        for (int m = 0; m < MT; m++) acc[m] = M::mma(__builtin_bit_cast(typename M::frag, ar[m][ks]), bq, acc[m]);
+      }
+    }
+  };
+  auto select = [&](bool first, const Tab& x, const Tab& y, Tab& o) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) { o.off[c] = first ? x.off[c] : y.off[c]; o.w[c] = first ? x.w[c] : y.w[c]; }
+  };
+
+  if (tb_lo < tb_hi) {
+    Tab cur, nxt;
+    float r0[3], r1[3], rn[3];
+    load_raw(tb_lo, r0);
+    load_raw(tb_lo + 1, r1);
+    load_raw(tb_lo + 2, rn);
+    build(tb_lo, r0, cur);
+    build(tb_lo + 1, r1, nxt);
+    issue(tb_lo, 0, cur, graw[0], araw[0], gw[0]);
+    for (int tb = tb_lo; tb < tb_hi; tb++) {
+      const int tbn = min(tb + 1, tb_hi - 1);  // table of the stage after this table's last one (clamped)
+      for (int q = 0; q < SPT; q += 2) {
+        // stage q + 1 is always in this table (SPT is even)
+        issue(tb, q + 1, cur, graw[1], araw[1], gw[1]);
+        compute(graw[0], araw[0], gw[0]);
+        // stage q + 2: this table, or chunk 0 of the next one (the very last iteration re-issues a valid
+        // stage of the last table; its operands are never consumed)
+        const bool same = q + 2 < SPT;  // uniform
+        Tab t;
+        select(same, cur, nxt, t);
+        issue(same ? tb : tbn, same ? q + 2 : 0, t, graw[0], araw[0], gw[0]);
+        compute(graw[1], araw[1], gw[1]);
+      }
+      cur = nxt;
+      build(tb + 2, rn, nxt);     // table tb + 2 (clamped), from the values loaded two tables ago
+      load_raw(tb + 3, rn);
+    }
+  }
+
+  // ---- epilogue: out[b][g*Cog + co][l] (+ bias), or fp32 partials when the reduction is split
+  const T* bias = (const T*)a.bias;
+  const bool add_bias = bias != nullptr && a.ksplit == 1;  // uniform
+  constexpr int BM = 32 * MT;
+  if (add_bias) {
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+      float bv[16];
+#pragma unroll
+      for (int r = 0; r < 16; r++) bv[r] = to_f32(bias[g * s.Cog + min(cot * BM + m * 32 + frag_row(r, lane), s.Cog - 1)]);
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[m][r] += bv[r];
+    }
+  }
+  if (pvalid && !(WAB & 16)) {
+    const long obase = ((long)b * s.Co + (long)g * s.Cog) * s.L + l;
+    T* outp = (T*)a.out;
+    float* part = a.partial + (a.ksplit > 1 ? (long)kz * s.B * s.Co * s.L : 0l);
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int co = cot * BM + m * 32 + frag_row(r, lane);
         if (co < s.Cog) {
           const long o = obase + (long)co * s.L;
           if (a.ksplit == 1) outp[o] = from_f32<T>(acc[m][r]);
@@ -369,10 +601,11 @@ __global__ __launch_bounds__(256) void tc_reduce_partial_kernel(const float* __r
 }
 
 // ---- host side --------------------------------------------------------------------------------------
-static int tc_env_cfg(int (&v)[4]) {
-  const char* e = getenv("D2AMD_DCN_CFG");  // "MT,NWM,NWN,KSPLIT" (profiling switch)
+static int tc_env_cfg(int (&v)[6]) {
+  const char* e = getenv("D2AMD_DCN_CFG");  // "MT,NWM,NWN,KSPLIT[,NKS[,WAVE]]" (profiling switch)
   if (!e) return 0;
-  return sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4;
+  v[4] = 0; v[5] = -1;
+  return sscanf(e, "%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5]) >= 4;
 }
 
 TcPlan dcn_tc_plan_fwd(const DcnShape& s, int dtype) {
@@ -389,60 +622,102 @@ TcPlan dcn_tc_plan_fwd(const DcnShape& s, int dtype) {
   }
   if (s.K2 * ndg_max > 32) return pl;
   pl.ndg = ndg_max;
-  pl.NC64 = s.Cg / 64;
-  pl.S = s.K2 * pl.NC64;
-  // tile shape: a 256-row tile amortises one gather over twice the MFMA work; position tiles shrink
-  // until the launch has about one workgroup per CU, then the (tap, channel) reduction is split
-  int MT = s.Cog <= 64 ? 2 : 4, NWM = s.Cog >= 256 ? 2 : 1, NWN = NWM == 1 ? 4 : 2, ks = 1;
+  // Tile shape (measured, profiles/r01/dcn_fwd_sweep.txt): 128 output channels x 64 positions per workgroup
+  // (2 matrix + 2 gather waves), 32-channel stages: 43 KB of LDS and <= 168 VGPRs keep three workgroups
+  // per CU resident, which hides the per-stage barrier / LDS hand-off latency and lets every workgroup
+  // of the launch start at once (a second round of workgroups costs a full workgroup lifetime).  Small
+  // maps split the (tap, channel) reduction until there are ~2 workgroups per CU.
+  int MT = s.Cog <= 64 ? 2 : 4, NWM = 1, NWN = 2, ks = 1, NKS = 2, wave = 0;
   auto wgs = [&](int nwn, int k) { return (long)cdiv(s.P, 32 * nwn) * cdiv(s.Cog, 32 * MT * NWM) * s.G * k; };
-  while (NWN > 1 && wgs(NWN, 1) < 240) NWN >>= 1;
-  while (ks < 4 && wgs(NWN, ks) < 240 && pl.S / (ks + 1) >= 6) ks++;
-  int ev[4];
-  if (tc_env_cfg(ev)) { MT = ev[0]; NWM = ev[1]; NWN = ev[2]; ks = ev[3]; }
+  {
+    const int stages = s.K2 * (s.Cg / 32);
+    while (ks < 8 && wgs(NWN, ks) < 480 && stages / (ks + 1) >= 8) ks++;
+  }
+  int ev[6];
+  if (tc_env_cfg(ev)) {
+    MT = ev[0]; NWM = ev[1]; NWN = ev[2]; ks = ev[3];
+    NKS = (ev[4] == 2 || ev[4] == 4) ? ev[4] : 4;
+    wave = ev[5] == 1;
+  }
+  if (wave) {
+    if (NWM != 1 || NWN != 1 || NKS != 2 || (MT != 4 && MT != 2)) return pl;  // no such instantiation
+  }
+  pl.wave = wave;
+  pl.NKS = NKS;
+  pl.NCH = s.Cg / (16 * NKS);
+  pl.S = s.K2 * pl.NCH;
   if (ks < 1 || ks > pl.S) ks = 1;
   pl.MT = MT; pl.NWM = NWM; pl.NWN = NWN; pl.ksplit = ks;
   pl.BM = 32 * MT * NWM; pl.BN = 32 * NWN;
   pl.n_cot = cdiv(s.Cog, pl.BM);
   pl.n_pt = cdiv(s.P, pl.BN);
-  pl.wp_bytes = (size_t)s.G * pl.n_cot * pl.S * pl.BM * 64 * 2;
+  pl.wp_bytes = (size_t)s.G * pl.n_cot * pl.S * pl.BM * 16 * NKS * 2;
   pl.partial_bytes = ks > 1 ? (size_t)ks * s.B * s.Co * s.L * 4 : 0;
-  pl.lds = (size_t)s.K2 * pl.ndg * pl.BN * sizeof(TcEntry) + 2 * (size_t)pl.BM * 8 * 16 +
-      2 * (size_t)pl.NWN * TC_BPITCH * 16;
+  const size_t btile = NKS == 4 ? TcB<4>::TILE : TcB<2>::TILE;
+  pl.lds = (size_t)s.K2 * pl.ndg * pl.BN * sizeof(TcEntry) + 2 * (size_t)pl.BM * 2 * NKS * 16 +
+      2 * (size_t)pl.NWN * btile * 16;
+  if (wave) pl.lds = 0;
   pl.ok = pl.lds <= 160 * 1024;
   return pl;
 }
 
-template <typename T, int MT, int NWM, int NWN>
-static int tc_launch_fwd(const DcnShape& s, const TcPlan& pl, const TcArgs& a, hipStream_t st) {
-  auto kern = dcn_fwd_tc_kernel<T, MT, NWM, NWN, NWN>;  // one gather wave per 32 positions
+template <typename T, int MT, int NWM, int NWN, int NKS>
+static int tc_launch_fwd2(const DcnShape& s, const TcPlan& pl, const TcArgs& a, hipStream_t st) {
+  auto kern = dcn_fwd_tc_kernel<T, MT, NWM, NWN, NWN, NKS>;  // one gather wave per 32 positions
   if (pl.lds > 64 * 1024)
     D2_HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
   const int grid = (a.total + 7) / 8 * 8;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (NWM * NWN + NWN)), pl.lds, st, s, a);
+  const char* sp = getenv("D2AMD_DCN_STAMPS");  // profiling only: dump per-workgroup timestamps to this file
+  TcArgs a2 = a;
+  if (sp) {
+    D2_HIP_OK(hipMalloc(&a2.stamps, (size_t)grid * 4 * 8));
+    D2_HIP_OK(hipMemsetAsync(a2.stamps, 0, (size_t)grid * 4 * 8, st));
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (NWM * NWN + NWN)), pl.lds, st, s, a2);
   D2_LAUNCH_OK();
+  if (sp) {
+    D2_HIP_OK(hipStreamSynchronize(st));
+    unsigned long long* h = (unsigned long long*)malloc((size_t)grid * 4 * 8);
+    D2_HIP_OK(hipMemcpy(h, a2.stamps, (size_t)grid * 4 * 8, hipMemcpyDeviceToHost));
+    FILE* f = fopen(sp, "w");
+    if (f) {
+      for (int i = 0; i < grid; i++) fprintf(f, "%d %llu %llu %llu %llu\n", i, h[4 * i], h[4 * i + 1], h[4 * i + 2], h[4 * i + 3]);
+      fclose(f);
+    }
+    free(h);
+    (void)hipFree(a2.stamps);
+  }
   return D2AMD_OK;
+}
+
+template <typename T, int MT, int NWM, int NWN>
+static int tc_launch_fwd(const DcnShape& s, const TcPlan& pl, const TcArgs& a, hipStream_t st) {
+  return pl.NKS == 2 ? tc_launch_fwd2<T, MT, NWM, NWN, 2>(s, pl, a, st) : tc_launch_fwd2<T, MT, NWM, NWN, 4>(s, pl, a, st);
 }
 
 template <typename T>
 int dcn_tc_forward(const DcnShape& s, const TcPlan& pl, const void* x_nhwc, const void* offset, const void* mask,
                    const void* weight, const void* bias, void* out, void* wp, float* partial, hipStream_t st) {
   {
-    const long groups16 = (long)s.G * pl.n_cot * pl.S * (pl.BM / 32) * 4 * 64;
+    const long groups16 = (long)s.G * pl.n_cot * pl.S * (pl.BM / 32) * pl.NKS * 64;
     const int blocks = cdiv(groups16, 256) > 8192 ? 8192 : cdiv(groups16, 256);
     hipLaunchKernelGGL((tc_pack_weight_kernel<T>), dim3(blocks), dim3(256), 0, st, (const T*)weight, (T*)wp, s.G,
-                       s.Cog, s.Cg, s.K2, pl.BM, pl.n_cot, pl.NC64);
+                       s.Cog, s.Cg, s.K2, pl.BM, pl.n_cot, pl.NCH, pl.NKS);
     D2_LAUNCH_OK();
   }
   TcArgs a{};
   a.x = x_nhwc; a.offset = offset; a.mask = mask; a.wp = wp; a.bias = bias; a.out = out; a.partial = partial;
-  a.n_pt = pl.n_pt; a.n_cot = pl.n_cot; a.ksplit = pl.ksplit; a.NC64 = pl.NC64; a.S = pl.S;
+  a.n_pt = pl.n_pt; a.n_cot = pl.n_cot; a.ksplit = pl.ksplit; a.NCH = pl.NCH; a.S = pl.S;
   { const char* e = getenv("D2AMD_DCN_ABLATE"); a.ablate = e ? atoi(e) : 0; }
   const long total = (long)pl.n_pt * pl.n_cot * s.G * pl.ksplit;
   D2_CHECK_ARG(total < (1l << 30), "deform_conv: too many tiles");
   a.total = (int)total;
   int rc = D2AMD_EUNSUPPORTED;
-  const int key = pl.MT * 100 + pl.NWM * 10 + pl.NWN;
+  const int key = pl.wave ? -(pl.MT * 10 + pl.NKS) : pl.MT * 100 + pl.NWM * 10 + pl.NWN;
+  const int grid = (a.total + 7) / 8 * 8;
   switch (key) {
+    case -42: hipLaunchKernelGGL((dcn_fwd_wave_kernel<T, 4, 2>), dim3(grid), dim3(64), 0, st, s, a); rc = 0; break;
+    case -22: hipLaunchKernelGGL((dcn_fwd_wave_kernel<T, 2, 2>), dim3(grid), dim3(64), 0, st, s, a); rc = 0; break;
     case 414: rc = tc_launch_fwd<T, 4, 1, 4>(s, pl, a, st); break;
     case 412: rc = tc_launch_fwd<T, 4, 1, 2>(s, pl, a, st); break;
     case 411: rc = tc_launch_fwd<T, 4, 1, 1>(s, pl, a, st); break;
@@ -455,6 +730,7 @@ int dcn_tc_forward(const DcnShape& s, const TcPlan& pl, const void* x_nhwc, cons
     default: set_error("deform_conv: no kernel for tile config MT=%d NWM=%d NWN=%d", pl.MT, pl.NWM, pl.NWN);
   }
   if (rc) return rc;
+  D2_LAUNCH_OK();
   if (pl.ksplit > 1) {
     const long n = (long)s.B * s.Co * s.L;
     const int blocks = cdiv(n, 256) > 4096 ? 4096 : cdiv(n, 256);

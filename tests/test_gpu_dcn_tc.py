@@ -101,10 +101,14 @@ def check(case, tol, backward=True, keys=None):
 
 # ---------------------------------------------------------------------------------------- forward
 @pytest.mark.parametrize("cfg", ["4,1,4,1", "4,1,2,1", "4,1,1,1", "4,2,2,1", "4,2,1,1", "2,2,2,1", "2,1,4,1",
-                                 "2,1,2,1", "2,1,1,1", "4,1,2,2", "4,2,1,3", "2,1,1,4"])
+                                 "2,1,2,1", "2,1,1,1", "4,1,2,2", "4,2,1,3", "2,1,1,4",
+                                 "4,1,4,1,2", "4,1,2,1,2", "4,1,1,1,2", "4,2,2,1,2", "4,2,1,2,2", "2,1,2,3,2",
+                                 "2,2,2,1,2", "2,1,4,1,2", "2,1,1,1,2",
+                                 "4,1,1,1,2,1", "4,1,1,3,2,1", "2,1,1,1,2,1", "2,1,1,4,2,1"])
 def test_fwd_every_tile_config(cfg):
     """Co = 160 is not a multiple of any row tile (zero-padded weight rows, guarded stores); P = 2*13*19
-    = 494 leaves ragged position tiles; the last digit splits the (tap, channel) reduction."""
+    = 494 leaves ragged position tiles; the 4th field splits the (tap, channel) reduction, the 5th selects
+    32- instead of 64-channel stages, the 6th the autonomous-wave kernel (the default)."""
     case = make_case(11, 2, 128, 160, 13, 19)
     with env(D2AMD_DCN_CFG=cfg):
         check(case, TOL[torch.float16], backward=False)
