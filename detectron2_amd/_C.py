@@ -56,6 +56,11 @@ _SIGNATURES = {
     "d2amd_roi_align_rotated_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp, _sz, _vp]),
     "d2amd_pairwise_iou": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp]),
     "d2amd_box_iou_rotated": (_i, [_vp, _i, _vp, _i, _vp, _vp]),
+    "d2amd_matcher_workspace_bytes": (_sz, [_i]),
+    "d2amd_match_boxes": (_i, [_vp, _i, _vp, _i, ctypes.POINTER(_f), ctypes.POINTER(ctypes.c_int8), _i, _i, _vp, _vp,
+                               _vp, _sz, _vp]),
+    "d2amd_match_quality_matrix": (_i, [_vp, _i, _i, ctypes.POINTER(_f), ctypes.POINTER(ctypes.c_int8), _i, _i, _vp,
+                                        _vp, _vp, _sz, _vp]),
     "d2amd_nms_workspace_bytes": (_sz, [_i64, _i64, _i]),
     "d2amd_nms": (_i, [_vp, _vp, _vp, _i64, _d, _i, _i64, _vp, _vp, _vp, _sz, _vp]),
     "d2amd_paste_masks": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _i, _vp]),

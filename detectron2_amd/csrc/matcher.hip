@@ -1,0 +1,235 @@
+// Fused anchor / proposal matching: pairwise_iou + Matcher without the M x N matrix.
+//   replaces  detectron2/structures/boxes.py:312-358 (pairwise_iou) followed by
+//             detectron2/modeling/matcher.py:62-127 (Matcher.__call__, set_low_quality_matches_)
+//   as called from proposal_generator/rpn.py:307-364 (G x 268,569 anchors per image) and
+//   roi_heads/roi_heads.py:257-295 (G x ~1,000 proposals).
+// The reference materialises the matrix (17 MB per image for the RPN), then makes ~8 elementwise /
+// reduction passes over it (max over dim 0, one mask per label interval, max over dim 1, equality,
+// nonzero, index_put).  Here: pass 1 keeps the running column maximum in registers and the row maxima
+// in LDS (wave max -> one LDS atomic per wave and ground-truth box -> one global atomic per block);
+// pass 2 (allow_low_quality_matches only) re-evaluates the same fp32 IoU expression and compares with
+// the row maximum.  Roofline: HBM, 16 N bytes read per pass + 9 N bytes written.
+// Bit-exact: same IoU arithmetic as iou.hip (this unit is compiled with -ffp-contract=off), torch.max
+// tie rule (first maximal index), NaN propagation of torch.max.
+// The same kernels also serve Matcher.__call__(matrix) for callers that already hold a matrix.
+#pragma clang fp contract(off)
+#include "common.h"
+
+namespace d2amd {
+
+__device__ __forceinline__ float mt_tmin(float a, float b) { return (a != a || b != b) ? __builtin_nanf("") : (a < b ? a : b); }
+__device__ __forceinline__ float mt_tmax(float a, float b) { return (a != a || b != b) ? __builtin_nanf("") : (a > b ? a : b); }
+
+// structures/boxes.py:312-358, operation for operation (see iou.hip iou_one<D2AMD_IOU>)
+__device__ __forceinline__ float mt_iou(float4 a, float area1, float4 b) {
+  float w = mt_tmin(a.z, b.z) - mt_tmax(a.x, b.x);
+  float h = mt_tmin(a.w, b.w) - mt_tmax(a.y, b.y);
+  if (w < 0) w = 0;
+  if (h < 0) h = 0;
+  const float inter = w * h;
+  const float area2 = (b.z - b.x) * (b.w - b.y);
+  if (inter > 0) return inter / (area1 + area2 - inter);
+  return 0.f;
+}
+
+struct MatchCfg {
+  float thr[D2AMD_MATCHER_MAX_THRESHOLDS];
+  int8_t lab[D2AMD_MATCHER_MAX_THRESHOLDS + 1];
+  int T;
+};
+
+// matcher.py:96-101: labels start at 1; each interval [low, high) with low = -inf / thr[k-1],
+// high = thr[k] / +inf overwrites (NaN matches no interval and keeps 1)
+__device__ __forceinline__ int8_t mt_label(float v, const MatchCfg& c) {
+  int8_t l = 1;
+  for (int k = 0; k <= c.T; k++) {
+    const bool ge_low = k == 0 ? (v >= -__builtin_inff()) : (v >= c.thr[k - 1]);
+    const bool lt_high = k == c.T ? (v < __builtin_inff()) : (v < c.thr[k]);
+    if (ge_low && lt_high) l = c.lab[k];
+  }
+  return l;
+}
+
+// order-preserving float -> uint key for non-negative values; NaN maps above every number so that a
+// row containing NaN reports NaN as its maximum, like torch.max
+__device__ __forceinline__ uint32_t mt_key(float v) { return v != v ? 0xffffffffu : (v <= 0.f ? 0u : __float_as_uint(v)); }
+
+constexpr int MT_BLOCK = 256;
+constexpr int MT_CHUNK = 512;  // ground-truth boxes staged per LDS pass
+
+// FUSED: IoU from boxes; else values from the row-major M x N matrix `q`
+template <bool FUSED>
+__global__ __launch_bounds__(MT_BLOCK) void match_pass1_kernel(const float4* __restrict__ gt, int M,
+                                                              const float4* __restrict__ boxes, int N,
+                                                              const float* __restrict__ q, MatchCfg cfg,
+                                                              int64_t* __restrict__ matches, int8_t* __restrict__ labels,
+                                                              uint32_t* __restrict__ rowmax) {
+  __shared__ float4 g4[MT_CHUNK];
+  __shared__ float garea[MT_CHUNK];
+  __shared__ uint32_t rmax[MT_CHUNK];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const long n = (long)blockIdx.x * MT_BLOCK + tid;
+  const bool valid = n < N;
+  float4 b = make_float4(0, 0, 0, 0);
+  if (FUSED && valid) b = boxes[n];
+  float best = 0.f;
+  int besti = 0;
+  bool have = false;
+  for (int m0 = 0; m0 < M; m0 += MT_CHUNK) {
+    const int mc = min(MT_CHUNK, M - m0);
+    __syncthreads();
+    for (int i = tid; i < mc; i += MT_BLOCK) {
+      if (FUSED) {
+        const float4 a = gt[m0 + i];
+        g4[i] = a;
+        garea[i] = (a.z - a.x) * (a.w - a.y);
+      }
+      rmax[i] = 0u;
+    }
+    __syncthreads();
+    for (int i = 0; i < mc; i++) {
+      float v = 0.f;
+      if (valid) v = FUSED ? mt_iou(g4[i], garea[i], b) : q[(long)(m0 + i) * N + n];
+      if (valid) {
+        // torch.max(dim=0): first maximal value; NaN is maximal
+        const bool better = !have || (v > best) || (v != v && best == best);
+        if (better) { best = v; besti = m0 + i; have = true; }
+      }
+      if (rowmax) {  // uniform.  row maximum: wave max, then one LDS atomic per wave
+        uint32_t k = valid ? mt_key(v) : 0u;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) k = max(k, (uint32_t)__shfl_xor((int)k, o));
+        if (lane == 0 && k != 0u) atomicMax(&rmax[i], k);
+      }
+    }
+    __syncthreads();
+    if (rowmax)
+      for (int i = tid; i < mc; i += MT_BLOCK)
+        if (rmax[i] != 0u) atomicMax(&rowmax[m0 + i], rmax[i]);
+  }
+  if (valid) {
+    matches[n] = besti;
+    labels[n] = mt_label(best, cfg);
+  }
+}
+
+// set_low_quality_matches_ (matcher.py:103-127): label 1 for every prediction whose quality with some
+// ground truth equals that ground truth's row maximum (ties included; a row maximum of 0 matches every
+// prediction with quality 0, exactly like the reference's `==` + nonzero)
+template <bool FUSED>
+__global__ __launch_bounds__(MT_BLOCK) void match_pass2_kernel(const float4* __restrict__ gt, int M,
+                                                              const float4* __restrict__ boxes, int N,
+                                                              const float* __restrict__ q,
+                                                              const uint32_t* __restrict__ rowmax,
+                                                              int8_t* __restrict__ labels) {
+  __shared__ float4 g4[MT_CHUNK];
+  __shared__ float garea[MT_CHUNK];
+  __shared__ uint32_t rmax[MT_CHUNK];
+  const int tid = threadIdx.x;
+  const long n = (long)blockIdx.x * MT_BLOCK + tid;
+  const bool valid = n < N;
+  float4 b = make_float4(0, 0, 0, 0);
+  if (FUSED && valid) b = boxes[n];
+  bool hit = false;
+  for (int m0 = 0; m0 < M; m0 += MT_CHUNK) {
+    const int mc = min(MT_CHUNK, M - m0);
+    __syncthreads();
+    for (int i = tid; i < mc; i += MT_BLOCK) {
+      if (FUSED) {
+        const float4 a = gt[m0 + i];
+        g4[i] = a;
+        garea[i] = (a.z - a.x) * (a.w - a.y);
+      }
+      rmax[i] = rowmax[m0 + i];
+    }
+    __syncthreads();
+    if (valid) {
+      for (int i = 0; i < mc; i++) {
+        const float v = FUSED ? mt_iou(g4[i], garea[i], b) : q[(long)(m0 + i) * N + n];
+        // float equality like the reference (NaN never equal); the key of a non-negative value is its bits
+        if (v == v && mt_key(v) == rmax[i] && rmax[i] != 0xffffffffu) hit = true;
+      }
+    }
+  }
+  if (valid && hit) labels[n] = 1;
+}
+
+__global__ void match_fill_kernel(int64_t* matches, int8_t* labels, int N, int8_t lab0) {
+  const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n < N) { matches[n] = 0; labels[n] = lab0; }
+}
+
+static int match_impl(const float* gt, int M, const float* boxes, const float* q, int N, const float* thresholds,
+                      const int8_t* labels, int T, int allow_low, int64_t* matches, int8_t* match_labels,
+                      void* workspace, size_t workspace_bytes, hipStream_t s) {
+  D2_CHECK_ARG(M >= 0 && N >= 0, "match: negative size");
+  D2_CHECK_ARG(T >= 0 && T <= D2AMD_MATCHER_MAX_THRESHOLDS && labels != nullptr && (T == 0 || thresholds != nullptr),
+               "match: %d thresholds (max %d)", T, D2AMD_MATCHER_MAX_THRESHOLDS);
+  MatchCfg cfg{};
+  cfg.T = T;
+  for (int k = 0; k < T; k++) {
+    D2_CHECK_ARG(thresholds[k] > 0.f && (k == 0 || thresholds[k - 1] <= thresholds[k]),
+                 "match: thresholds must be positive and ascending");
+    cfg.thr[k] = thresholds[k];
+  }
+  for (int k = 0; k <= T; k++) {
+    D2_CHECK_ARG(labels[k] >= -1 && labels[k] <= 1, "match: labels must be in {-1, 0, 1}");
+    cfg.lab[k] = labels[k];
+  }
+  if (N == 0) return D2AMD_OK;
+  D2_CHECK_ARG(matches && match_labels, "match: null output");
+  const int grid = cdiv(N, MT_BLOCK);
+  if (M == 0) {  // matcher.py:80-90: no ground truth -> index 0, labels[0]
+    hipLaunchKernelGGL(match_fill_kernel, dim3(grid), dim3(MT_BLOCK), 0, s, matches, match_labels, N, cfg.lab[0]);
+    D2_LAUNCH_OK();
+    return D2AMD_OK;
+  }
+  D2_CHECK_ARG(q != nullptr || (gt != nullptr && boxes != nullptr), "match: null input");
+  uint32_t* rowmax = nullptr;
+  if (allow_low) {
+    if (workspace == nullptr || workspace_bytes < (size_t)M * 4) {
+      set_error("match: workspace too small (%zu < %zu)", workspace_bytes, (size_t)M * 4);
+      return D2AMD_EWORKSPACE;
+    }
+    rowmax = (uint32_t*)workspace;
+    D2_HIP_OK(hipMemsetAsync(rowmax, 0, (size_t)M * 4, s));
+  }
+  if (q)
+    hipLaunchKernelGGL((match_pass1_kernel<false>), dim3(grid), dim3(MT_BLOCK), 0, s, nullptr, M, nullptr, N, q, cfg,
+                       matches, match_labels, rowmax);
+  else
+    hipLaunchKernelGGL((match_pass1_kernel<true>), dim3(grid), dim3(MT_BLOCK), 0, s, (const float4*)gt, M,
+                       (const float4*)boxes, N, nullptr, cfg, matches, match_labels, rowmax);
+  D2_LAUNCH_OK();
+  if (allow_low) {
+    if (q)
+      hipLaunchKernelGGL((match_pass2_kernel<false>), dim3(grid), dim3(MT_BLOCK), 0, s, nullptr, M, nullptr, N, q,
+                         rowmax, match_labels);
+    else
+      hipLaunchKernelGGL((match_pass2_kernel<true>), dim3(grid), dim3(MT_BLOCK), 0, s, (const float4*)gt, M,
+                         (const float4*)boxes, N, nullptr, rowmax, match_labels);
+    D2_LAUNCH_OK();
+  }
+  return D2AMD_OK;
+}
+
+}  // namespace d2amd
+
+using namespace d2amd;
+
+extern "C" size_t d2amd_matcher_workspace_bytes(int M) { return (size_t)(M > 0 ? M : 1) * 4; }
+
+extern "C" int d2amd_match_boxes(const float* gt_boxes, int M, const float* boxes, int N, const float* thresholds,
+                                 const int8_t* labels, int T, int allow_low_quality, int64_t* matches,
+                                 int8_t* match_labels, void* workspace, size_t workspace_bytes, void* stream) {
+  return match_impl(gt_boxes, M, boxes, nullptr, N, thresholds, labels, T, allow_low_quality, matches, match_labels,
+                    workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int d2amd_match_quality_matrix(const float* quality, int M, int N, const float* thresholds,
+                                          const int8_t* labels, int T, int allow_low_quality, int64_t* matches,
+                                          int8_t* match_labels, void* workspace, size_t workspace_bytes, void* stream) {
+  D2_CHECK_ARG(quality != nullptr || (long)M * N == 0, "match_quality_matrix: null matrix");
+  return match_impl(nullptr, M, nullptr, quality, N, thresholds, labels, T, allow_low_quality, matches, match_labels,
+                    workspace, workspace_bytes, (hipStream_t)stream);
+}

@@ -114,7 +114,7 @@ template <int BW>
 __global__ __launch_bounds__(RK_THREADS) void nms_rank_kernel(
     const float* __restrict__ boxes, const float* __restrict__ scores, const int64_t* __restrict__ idxs, int n,
     int* __restrict__ order, int* __restrict__ rankpos, uint32_t* __restrict__ cls_s, float* __restrict__ boxes_s,
-    int* __restrict__ counters) {
+    int* __restrict__ counters, int rounds) {
   __shared__ u64 Ks[RANK_MAX_N];  // 96 KiB
   const int tid = threadIdx.x, jp = tid & 31, il = tid >> 5;
   constexpr int PER = RANK_MAX_N / RK_THREADS;  // 12
@@ -139,28 +139,32 @@ __global__ __launch_bounds__(RK_THREADS) void nms_rank_kernel(
     if (bad && blockIdx.x == 0) atomicOr(&counters[1], 2);
   }
   __syncthreads();
-  const int i = blockIdx.x * RK_IB + il;
-  if (i >= n) return;
-  const u64 Ki = Ks[i];
-  const u64 M48 = 0x0000ffffffffffffull;
-  const u64 Si = Ki & M48;
-  int r_s = 0, r_cm = 0;
-  for (int j = jp; j < n; j += 32) {
-    const u64 K = Ks[j];
-    r_cm += (K < Ki) ? 1 : 0;          // class-major position
-    r_s += ((K & M48) < Si) ? 1 : 0;   // global score rank (ties: lower index first)
-  }
-#pragma unroll
-  for (int o = 16; o >= 1; o >>= 1) {  // the 32 lanes of a half-wave share box i
-    r_s += __shfl_xor(r_s, o);
-    r_cm += __shfl_xor(r_cm, o);
-  }
+  // `rounds` boxes per half-wave: the launch has at most ~one workgroup per CU (the 96 KiB key table
+  // allows only one resident workgroup per CU, so a 257th workgroup would cost a whole second round)
   constexpr int STRIDE = BW == 4 ? 4 : 8;
-  if (jp < BW) boxes_s[(long)r_cm * STRIDE + jp] = boxes[(long)i * BW + jp];
-  if (jp == 0) {
-    order[r_s] = i;
-    rankpos[r_cm] = r_s;
-    cls_s[r_cm] = (uint32_t)(Ki >> 48);
+  const u64 M48 = 0x0000ffffffffffffull;
+  for (int t = 0; t < rounds; t++) {
+    const int i = (blockIdx.x * rounds + t) * RK_IB + il;
+    if (i >= n) break;  // uniform per half-wave
+    const u64 Ki = Ks[i];
+    const u64 Si = Ki & M48;
+    int r_s = 0, r_cm = 0;
+    for (int j = jp; j < n; j += 32) {
+      const u64 K = Ks[j];
+      r_cm += (K < Ki) ? 1 : 0;          // class-major position
+      r_s += ((K & M48) < Si) ? 1 : 0;   // global score rank (ties: lower index first)
+    }
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) {  // the 32 lanes of a half-wave share box i
+      r_s += __shfl_xor(r_s, o);
+      r_cm += __shfl_xor(r_cm, o);
+    }
+    if (jp < BW) boxes_s[(long)r_cm * STRIDE + jp] = boxes[(long)i * BW + jp];
+    if (jp == 0) {
+      order[r_s] = i;
+      rankpos[r_cm] = r_s;
+      cls_s[r_cm] = (uint32_t)(Ki >> 48);
+    }
   }
 }
 
@@ -540,12 +544,14 @@ extern "C" int d2amd_nms(const float* boxes, const float* scores, const int64_t*
   const int* rankpos = nullptr;
   const uint32_t* cls_s = nullptr;
   if (small) {
+    const int rk_rounds = cdiv(cdiv(N, RK_IB), 240);  // <= 240 workgroups: one round on 256 CUs
+    const int rk_grid = cdiv(N, RK_IB * rk_rounds);
     if (rotated)
-      hipLaunchKernelGGL((nms_rank_kernel<5>), dim3(cdiv(N, RK_IB)), dim3(RK_THREADS), 0, s, boxes, scores, idxs, N,
-                         w.order, w.rankpos, w.cls_s, w.boxes_s, w.counters);
+      hipLaunchKernelGGL((nms_rank_kernel<5>), dim3(rk_grid), dim3(RK_THREADS), 0, s, boxes, scores, idxs, N,
+                         w.order, w.rankpos, w.cls_s, w.boxes_s, w.counters, rk_rounds);
     else
-      hipLaunchKernelGGL((nms_rank_kernel<4>), dim3(cdiv(N, RK_IB)), dim3(RK_THREADS), 0, s, boxes, scores, idxs, N,
-                         w.order, w.rankpos, w.cls_s, w.boxes_s, w.counters);
+      hipLaunchKernelGGL((nms_rank_kernel<4>), dim3(rk_grid), dim3(RK_THREADS), 0, s, boxes, scores, idxs, N,
+                         w.order, w.rankpos, w.cls_s, w.boxes_s, w.counters, rk_rounds);
     D2_LAUNCH_OK();
     if (idxs) {
       rankpos = w.rankpos;

@@ -4,7 +4,7 @@ modified.  `batched_nms*` suppress independently per category on the ORIGINAL co
 coordinate-offset trick: the device kernel is category-aware, nms.py:137-145 is not needed)."""
 import torch
 
-from .ops import nms_impl
+from .ops import nms_images, nms_impl
 from .wrappers import disable_torch_compiler
 
 
@@ -35,3 +35,14 @@ def batched_nms_rotated(boxes: torch.Tensor, scores: torch.Tensor, idxs: torch.T
         return torch.empty((0,), dtype=torch.int64, device=boxes.device)
     boxes = boxes.float()  # fp16 does not have enough range for batched NMS
     return nms_impl(boxes, scores, idxs, iou_threshold, True)
+
+
+def batched_nms_images(inputs, iou_threshold: float):
+    """`batched_nms` of every image of a batch: inputs = [(boxes [n,4], scores [n], idxs [n]), ...] ->
+    list of kept-index tensors (each as `batched_nms` would return).  Replaces the per-image loop +
+    per-image host sync of find_top_rpn_proposals (proposal_generator/proposal_utils.py:118-135) and
+    DenseDetector._decode_multi_level_predictions / inference (meta_arch/dense_detector.py:186-260):
+    the images' device pipelines overlap on separate HIP streams and there is one sync per batch."""
+    for b, _s, _i in inputs:
+        assert b.shape[-1] == 4
+    return nms_images([(b.float(), s, i) for b, s, i in inputs], iou_threshold, False)

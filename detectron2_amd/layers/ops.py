@@ -20,13 +20,12 @@ _DEFS = {
 }
 
 
-def nms_impl(boxes, scores, idxs, iou_threshold, rotated):
-    """Shared driver of nms / batched_nms / nms_rotated / batched_nms_rotated (d2amd_nms)."""
+def _nms_launch(boxes, scores, idxs, iou_threshold, rotated, stream_ptr=None):
+    """Allocate the outputs / workspace of one NMS on torch's current stream and enqueue the device
+    pipeline (d2amd_nms) on `stream_ptr` (default: the current stream).  No host sync."""
     bw = 5 if rotated else 4
     assert boxes.dim() == 2 and boxes.shape[1] == bw, boxes.shape
     n = boxes.shape[0]
-    if n == 0:  # nothing to compute on any device (nms.py:125-126)
-        return torch.empty((0,), dtype=torch.int64, device=boxes.device)
     _C.require_gpu(boxes, scores, idxs, op="nms")
     boxes = boxes.detach().float().contiguous()
     scores = scores.detach().float().contiguous()
@@ -46,13 +45,74 @@ def nms_impl(boxes, scores, idxs, iou_threshold, rotated):
         keep = torch.empty(n, dtype=torch.int64, device=boxes.device)
         result = torch.empty(2, dtype=torch.int64, device=boxes.device)
         _C.check(L.d2amd_nms(_C.ptr(boxes), _C.ptr(scores), _C.ptr(idxs), n, float(iou_threshold), int(rotated),
-                             max_per_class, _C.ptr(keep), _C.ptr(result), _C.ptr(ws), ws_bytes, _C.stream()))
-    num, flags = result.tolist()  # the only host sync of the NMS pipeline
+                             max_per_class, _C.ptr(keep), _C.ptr(result), _C.ptr(ws), ws_bytes,
+                             stream_ptr if stream_ptr is not None else _C.stream()))
+    return keep, result, (boxes, scores, idxs, ws)  # the inputs / workspace must outlive the launch
+
+
+def _nms_finish(keep, num, flags):
     if flags & 2:
         raise RuntimeError("batched_nms: category ids must be in [0, 65535]")
     if flags & 1:
         raise RuntimeError("batched_nms: internal error: category larger than max_per_class")
     return keep[:num]
+
+
+def nms_impl(boxes, scores, idxs, iou_threshold, rotated):
+    """Shared driver of nms / batched_nms / nms_rotated / batched_nms_rotated (d2amd_nms)."""
+    if boxes.shape[0] == 0:  # nothing to compute on any device (nms.py:125-126)
+        assert boxes.dim() == 2 and boxes.shape[1] == (5 if rotated else 4), boxes.shape
+        return torch.empty((0,), dtype=torch.int64, device=boxes.device)
+    keep, result, _hold = _nms_launch(boxes, scores, idxs, iou_threshold, rotated)
+    num, flags = result.tolist()  # the only host sync of the NMS pipeline
+    return _nms_finish(keep, num, flags)
+
+
+_SIDE_STREAMS = {}
+
+
+def nms_images(inputs, iou_threshold, rotated=False):
+    """NMS of every image of a batch in one call: `inputs` = [(boxes, scores, idxs | None), ...].
+    The reference runs the RPN / RetinaNet NMS in a per-image Python loop, each iteration ending in a
+    device->host sync (proposal_generator/proposal_utils.py:118-135, meta_arch/dense_detector.py:186-260).
+    Images are independent, so their (latency-bound) device pipelines are enqueued on separate HIP
+    streams that fork from / join into the current stream, and the kept counts are read with ONE sync."""
+    if not inputs:
+        return []
+    dev = inputs[0][0].device
+    cur = torch.cuda.current_stream(dev)
+    pool = _SIDE_STREAMS.setdefault(dev.index, [])
+    fork = torch.cuda.Event()
+    fork.record(cur)  # fork point: taken BEFORE anything of this call is enqueued on `cur`
+    launched = []
+    k = 0
+    for boxes, scores, idxs in inputs:
+        if boxes.shape[0] == 0:
+            launched.append(None)
+            continue
+        if k == 0:
+            st = cur  # the first image stays on the current stream
+        else:
+            while len(pool) < min(k, 3):
+                pool.append(torch.cuda.Stream(device=dev))
+            st = pool[(k - 1) % len(pool)]
+            st.wait_event(fork)  # inputs are ready; does not wait for the images launched above
+        launched.append((_nms_launch(boxes, scores, idxs, iou_threshold, rotated,
+                                     stream_ptr=_C.ctypes.c_void_p(st.cuda_stream)), st))
+        k += 1
+    for item in launched:
+        if item is not None and item[1] is not cur:
+            cur.wait_stream(item[1])  # join: everything enqueued later on `cur` sees the results
+    live = [it for it in launched if it is not None]
+    counts = torch.stack([it[0][1] for it in live]).tolist() if live else []  # ONE host sync
+    out, j = [], 0
+    for (boxes, _s, _i), it in zip(inputs, launched):
+        if it is None:
+            out.append(torch.empty((0,), dtype=torch.int64, device=boxes.device))
+        else:
+            out.append(_nms_finish(it[0][0], *counts[j]))
+            j += 1
+    return out
 
 
 def _nms_rotated(dets, scores, iou_threshold):

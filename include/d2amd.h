@@ -121,6 +121,24 @@ int d2amd_pairwise_iou(const float* boxes1, int n, const float* boxes2, int m, i
 int d2amd_box_iou_rotated(const float* boxes1, int n, const float* boxes2, int m, float* out,
                           void* stream);
 
+/* ---- anchor / proposal matching.  Matcher.__call__ + set_low_quality_matches_
+ * (detectron2/modeling/matcher.py:62-127) fused with pairwise_iou (structures/boxes.py:312-358), as called
+ * from proposal_generator/rpn.py:307-364 and roi_heads/roi_heads.py:257-295: the M x N matrix is never
+ * written.  gt_boxes [M,4], boxes [N,4] fp32 xyxy; thresholds (host) [T] positive ascending, labels (host)
+ * [T+1] in {-1,0,1} (Matcher's constructor arguments); matches [N] int64 = index of the first maximal-IoU
+ * ground truth (0 when M == 0), match_labels [N] int8.  workspace: d2amd_matcher_workspace_bytes(M)
+ * (row maxima, only used with allow_low_quality).  The reference's `assert torch.all(matrix >= 0)` is not
+ * evaluated (it would cost a host sync); NaN qualities propagate like torch.max.
+ * d2amd_match_quality_matrix is Matcher.__call__ for a caller that already holds the row-major M x N matrix. */
+#define D2AMD_MATCHER_MAX_THRESHOLDS 8
+size_t d2amd_matcher_workspace_bytes(int M);
+int d2amd_match_boxes(const float* gt_boxes, int M, const float* boxes, int N, const float* thresholds,
+                      const int8_t* labels, int T, int allow_low_quality, int64_t* matches,
+                      int8_t* match_labels, void* workspace, size_t workspace_bytes, void* stream);
+int d2amd_match_quality_matrix(const float* quality, int M, int N, const float* thresholds,
+                               const int8_t* labels, int T, int allow_low_quality, int64_t* matches,
+                               int8_t* match_labels, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- NMS.  One entry serves torchvision.ops.nms / batched_nms (detectron2/layers/nms.py:6,
  * 11-22) and torch.ops.detectron2.nms_rotated / batched_nms_rotated (vision.cpp:116,
  * nms_rotated.h:22-37, nms.py:96-147).

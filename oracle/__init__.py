@@ -113,6 +113,21 @@ def pairwise_iou(b1, b2, mode="iou"):
     return out
 
 
+def matcher(quality, thresholds, labels, allow_low_quality_matches=False):
+    """Matcher(thresholds, labels, allow_low_quality_matches)(quality) -> (matches int64, labels int8)."""
+    q = _f32(quality)
+    m, n = q.shape
+    thr = _f32(thresholds)
+    lab = np.ascontiguousarray(np.asarray(labels, dtype=np.int8))
+    assert lab.shape[0] == thr.shape[0] + 1
+    matches = np.zeros(n, np.int64)
+    out = np.zeros(n, np.int8)
+    lib().orc_matcher(_p(q), m, n, _p(thr), lab.ctypes.data_as(ctypes.POINTER(ctypes.c_int8)), thr.shape[0],
+                      int(bool(allow_low_quality_matches)), _p(matches, _i64p),
+                      out.ctypes.data_as(ctypes.POINTER(ctypes.c_int8)))
+    return matches, out
+
+
 def box_iou_rotated(b1, b2):
     b1, b2 = _f32(b1).reshape(-1, 5), _f32(b2).reshape(-1, 5)
     out = np.zeros((b1.shape[0], b2.shape[0]), np.float32)

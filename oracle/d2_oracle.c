@@ -980,3 +980,49 @@ int orc_deform_conv_backward(const float* x, const float* offset, const float* m
 #ifdef __cplusplus
 }
 #endif
+
+/* ---------------------------------------------------------------------------------------------
+ * Matcher.__call__ + set_low_quality_matches_   (detectron2/modeling/matcher.py:62-127)
+ * q [M,N] row-major match-quality matrix; thr [T] (the constructor's thresholds, without the
+ * -inf / +inf sentinels); lab [T+1]; matches [N] int64; out [N] int8.
+ *   matcher.py:80-90   M == 0 (numel == 0): matches = 0, labels = lab[0]
+ *   matcher.py:94      matched_vals, matches = q.max(dim=0)  -- first maximal index, NaN is maximal
+ *   matcher.py:96-101  labels start at 1; every interval low <= v < high overwrites with its label
+ *   matcher.py:103-127 low-quality: every (g, n) with q[g][n] == max_n q[g][:] -> label 1
+ * Parity: pinned against the reference class itself (tests/golden/matcher.npz, generated by
+ * tests/golden/make_golden.py from /root/reference/detectron2/modeling/matcher.py). */
+static int orc_isnan(float v) { return v != v; }
+void orc_matcher(const float* q, int M, int N, const float* thr, const signed char* lab, int T, int allow_low,
+                 long long* matches, signed char* out) {
+  if (M == 0 || N == 0) {
+    for (int n = 0; n < N; n++) { matches[n] = 0; out[n] = lab[0]; }
+    return;
+  }
+  for (int n = 0; n < N; n++) {
+    float best = q[n];
+    int bi = 0;
+    for (int g = 1; g < M; g++) {
+      const float v = q[(long)g * N + n];
+      if ((v > best) || (orc_isnan(v) && !orc_isnan(best))) { best = v; bi = g; }
+    }
+    signed char l = 1;
+    for (int k = 0; k <= T; k++) {
+      const int ge_low = (k == 0) ? (best >= -INFINITY) : (best >= thr[k - 1]);
+      const int lt_high = (k == T) ? (best < INFINITY) : (best < thr[k]);
+      if (ge_low && lt_high) l = lab[k];
+    }
+    matches[n] = bi;
+    out[n] = l;
+  }
+  if (allow_low) {
+    for (int g = 0; g < M; g++) {
+      float hi = q[(long)g * N];
+      for (int n = 1; n < N; n++) {
+        const float v = q[(long)g * N + n];
+        if ((v > hi) || (orc_isnan(v) && !orc_isnan(hi))) hi = v;
+      }
+      for (int n = 0; n < N; n++)
+        if (q[(long)g * N + n] == hi) out[n] = 1;
+    }
+  }
+}

@@ -57,3 +57,29 @@ def py_mask_ops():
 def py_boxes():
     """detectron2/structures/boxes.py (deps: torch, numpy only)."""
     return _load_by_path("_d2ref_boxes", "detectron2/structures/boxes.py")
+
+
+def py_matcher():
+    """detectron2/modeling/matcher.py.  Its only non-torch import is `nonzero_tuple` from
+    detectron2.layers (layers/wrappers.py:150-162: `x.nonzero().unbind(1)` outside scripting); the
+    package itself is not importable here, so a stub module providing exactly that helper is
+    registered for the duration of the load."""
+    saved = {k: sys.modules.get(k) for k in ("detectron2", "detectron2.layers")}
+    pkg, layers = types.ModuleType("detectron2"), types.ModuleType("detectron2.layers")
+
+    def nonzero_tuple(x):
+        if x.dim() == 0:
+            return x.unsqueeze(0).nonzero().unbind(1)
+        return x.nonzero().unbind(1)
+
+    layers.nonzero_tuple = nonzero_tuple
+    pkg.layers = layers
+    sys.modules["detectron2"], sys.modules["detectron2.layers"] = pkg, layers
+    try:
+        return _load_by_path("_d2ref_matcher", "detectron2/modeling/matcher.py")
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v

@@ -3,7 +3,8 @@
 Sources of truth (all under /root/reference, never copied):
   * compiled C++ CPU ops (oracle/_ref, built by oracle/build_ref.py from
     detectron2/layers/csrc/{ROIAlignRotated,box_iou_rotated,nms_rotated}/*_cpu.cpp)
-  * python modules loaded by file path: detectron2/layers/mask_ops.py, detectron2/structures/boxes.py
+  * python modules loaded by file path: detectron2/layers/mask_ops.py, detectron2/structures/boxes.py,
+    detectron2/modeling/matcher.py (with a stub for its one `detectron2.layers.nonzero_tuple` import)
 Run:  PYTHONPATH=/root/repo python tests/golden/make_golden.py
 The .npz files are committed; /root/reference is not needed (and absent) on the GPU box.
 """
@@ -91,6 +92,27 @@ def main():
     out_u8 = mo.paste_masks_in_image(masks, boxes, (h, w), -1).numpy()
     np.savez_compressed(os.path.join(OUT, "paste_masks.npz"), masks=masks.numpy(), boxes=boxes.numpy(),
                         shape=np.array([h, w]), out_bits=np.packbits(out), out_u8=out_u8)
+    # --- Matcher on pairwise_iou (reference python: modeling/matcher.py + structures/boxes.py) ---
+    mt = ref.py_matcher()
+    g = rng.uniform(0, 200, (12, 4)).astype(np.float32)
+    g[:, 2:] = g[:, :2] + rng.uniform(10, 120, (12, 2)).astype(np.float32)
+    a = rng.uniform(0, 260, (3000, 4)).astype(np.float32)
+    a[:, 2:] = a[:, :2] + rng.uniform(4, 150, (3000, 2)).astype(np.float32)
+    a[:12] = g                      # exact matches (IoU 1)
+    a[12:24] = g                    # ties of the row maximum
+    g[11] = [900, 900, 950, 950]    # a ground truth no anchor overlaps: row maximum 0
+    a[100] = a[101]                 # duplicate predictions
+    q = bx.pairwise_iou(bx.Boxes(torch.from_numpy(g)), bx.Boxes(torch.from_numpy(a)))
+    d = dict(gt=g, boxes=a, quality=q.numpy())
+    cases = {"rpn": ([0.3, 0.7], [0, -1, 1], True), "roi": ([0.5], [0, 1], False),
+             "retina": ([0.4, 0.5], [0, -1, 1], True), "three": ([0.2, 0.4, 0.6], [-1, 0, -1, 1], False)}
+    for name, (thr, lab, low) in cases.items():
+        m, l = mt.Matcher(thr, lab, allow_low_quality_matches=low)(q)
+        d[f"{name}_matches"], d[f"{name}_labels"] = m.numpy(), l.numpy()
+        d[f"{name}_cfg"] = np.array([len(thr)] + thr + lab + [int(low)], np.float64)
+    m0, l0 = mt.Matcher([0.3, 0.7], [0, -1, 1], True)(torch.zeros(0, 7))
+    d["empty_matches"], d["empty_labels"] = m0.numpy(), l0.numpy()
+    np.savez_compressed(os.path.join(OUT, "matcher.npz"), **d)
     print("golden vectors written to", OUT)
 
 

@@ -290,6 +290,28 @@ def test_batched_nms_config4_100k():
     assert np.array_equal(again, np.arange(len(got)))
 
 
+def test_batched_nms_images_equals_per_image_loop():
+    """nms_images (one call for the batch, side streams, one host sync) == the per-image loop, bit for bit,
+    including an empty image and images of different sizes."""
+    from detectron2_amd.layers import batched_nms_images
+    rng = np.random.default_rng(77)
+    inputs = []
+    for n in (3000, 0, 8819, 1):
+        b = rng.uniform(0, 800, (n, 4)).astype(np.float32)
+        b[:, 2:] = b[:, :2] + rng.uniform(4, 200, (n, 2)).astype(np.float32)
+        s = ((rng.permutation(n) + 1) / (n + 1)).astype(np.float32)
+        idx = rng.integers(0, 5, n)
+        inputs.append((cu(b), cu(s), torch.as_tensor(idx).to(DEV)))
+    for rep in range(3):  # repeated calls reuse the side streams
+        got = batched_nms_images(inputs, 0.7)
+        for (b, s, i), g in zip(inputs, got):
+            exp = batched_nms(b, s, i, 0.7)
+            assert g.dtype == torch.int64 and torch.equal(g, exp)
+    b, s, i = inputs[2]
+    assert np.array_equal(got[2].cpu().numpy(),
+                          oracle.batched_nms(b.cpu().numpy(), s.cpu().numpy(), i.cpu().numpy(), 0.7))
+
+
 def test_nms_rotated_bit_exact(golden_dir):
     d = np.load(os.path.join(golden_dir, "rotated_iou_nms.npz"))
     for thr in (0.2, 0.5, 0.7):

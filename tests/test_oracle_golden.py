@@ -298,3 +298,28 @@ def test_live_against_compiled_reference():
     s = (rng.permutation(n) / n).astype(np.float32)
     k = ops.nms_rotated(torch.from_numpy(b), torch.from_numpy(s), 0.3).numpy()
     assert np.array_equal(oracle.nms_rotated(b, s, 0.3), k)
+
+
+# ---------------------------------------------------------------------------------------- Matcher
+def _matcher_cases(g):
+    for name in ("rpn", "roi", "retina", "three"):
+        cfg = g[f"{name}_cfg"]
+        t = int(cfg[0])
+        thr, lab, low = list(cfg[1:1 + t]), [int(v) for v in cfg[1 + t:2 + 2 * t]], bool(cfg[-1])
+        yield name, thr, lab, low
+
+
+def test_matcher_restatement_matches_reference_class(golden_dir):
+    """oracle.matcher == the reference's Matcher (detectron2/modeling/matcher.py) on the reference's own
+    pairwise_iou matrix: first-maximum ties, threshold intervals, low-quality matches incl. a ground
+    truth whose row maximum is 0, and the empty-ground-truth path."""
+    g = np.load(os.path.join(golden_dir, "matcher.npz"))
+    for name, thr, lab, low in _matcher_cases(g):
+        m, l = oracle.matcher(g["quality"], thr, lab, low)
+        assert np.array_equal(m, g[f"{name}_matches"]), name
+        assert np.array_equal(l, g[f"{name}_labels"]), name
+        assert l.dtype == np.int8 and m.dtype == np.int64
+    m, l = oracle.matcher(np.zeros((0, 7), np.float32), [0.3, 0.7], [0, -1, 1], True)
+    assert np.array_equal(m, g["empty_matches"]) and np.array_equal(l, g["empty_labels"])
+    # and the restated IoU feeds it bit-identically
+    assert np.array_equal(oracle.pairwise_iou(g["gt"], g["boxes"]), g["quality"])
