@@ -36,10 +36,6 @@ for L in nhwc; do
   find $OUT/prof_$L -type f -name "*kernel_trace.csv" -size +8M -delete
 done
 if [ "${3:-}" = "pmc" ]; then
-  echo "== rocprof PMC (HBM traffic), separate passes"
-  for CNT in FETCH_SIZE WRITE_SIZE; do
-    timeout 600 rocprofv3 --pmc $CNT --output-format csv -d $OUT/pmc_$CNT -o bench -- python $REPO/bench.py --steps 5 --warmup 2 --layout nhwc --no-cpu-baseline > $OUT/pmc_$CNT.log 2>&1; echo "pmc $CNT rc=$?"
-    python $REPO/scripts/pmc_summary.py $OUT/pmc_$CNT $CNT > $OUT/pmc_$CNT.summary.json 2>> $OUT/pmc_$CNT.log; cat $OUT/pmc_$CNT.summary.json | cut -c1-1500
-    find $OUT/pmc_$CNT -type f -size +4M -delete
-  done
+  echo "== rocprof PMC (HBM traffic), separate passes per counter and op"
+  bash $REPO/scripts/gpu_pmc.sh $TAG/pmc nhwc roi_align_box_fwd roi_align_box_bwd roi_align_mask_fwd roi_align_mask_bwd pairwise_iou_rpn
 fi

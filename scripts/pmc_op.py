@@ -28,4 +28,24 @@ elif op == "batched_nms_rpn":
     b, s, lv = w.nms_in[0]
     for _ in range(N):
         batched_nms(b, s, lv, 0.7)
+elif op.startswith("dcn_"):  # dcn_fwd_res3 / dcn_bwd_res4 ...: DCNv2 at the R50 stage shapes, bf16, batch 2
+    from detectron2_amd.layers import ModulatedDeformConv
+    C, H, W = {"res3": (128, 100, 168), "res4": (256, 50, 84), "res5": (512, 25, 42)}[op.split("_")[2]]
+    mod = ModulatedDeformConv(C, C, 3, padding=1, bias=False).to(dev).to(torch.bfloat16)
+    x = torch.randn(2, C, H, W, device=dev, dtype=torch.bfloat16, requires_grad=True)
+    off = (torch.randn(2, 18, H, W, device=dev) * 2).to(torch.bfloat16).requires_grad_(True)
+    msk = torch.sigmoid(torch.randn(2, 9, H, W, device=dev)).to(torch.bfloat16).requires_grad_(True)
+    if "_fwd_" in op:
+        for _ in range(N):
+            mod(x.detach(), off.detach(), msk.detach())
+    else:
+        y = mod(x, off, msk)
+        g = torch.randn_like(y)
+        for _ in range(N):
+            torch.autograd.grad([y], [x, off, msk, mod.weight], [g], retain_graph=True)
+elif op == "match_rpn":
+    from detectron2_amd.modeling import Matcher
+    mt = Matcher([0.3, 0.7], [0, -1, 1], allow_low_quality_matches=True)
+    for _ in range(N):
+        mt.match_boxes(w.gt[0], w.anchors)
 torch.cuda.synchronize()
