@@ -112,4 +112,13 @@ int dcn_tc_backward_data(const DcnShape& s, const TcBwPlan& pl, const void* x_nh
                          const void* mask, const void* weight, const void* gout_nhwc, float* gx, float* goff,
                          float* gmask, void* wp, hipStream_t st);
 
+struct TcBwwPlan {
+  bool ok;
+  int n_cot, n_cit, pch, ksteps_per_image;
+};
+TcBwwPlan dcn_tc_plan_bww(const DcnShape& s, int dtype);
+template <typename T>
+int dcn_tc_backward_weight(const DcnShape& s, const TcBwwPlan& pl, const void* x_nhwc, const void* offset,
+                           const void* mask, const void* gout_nchw, float* gwr, hipStream_t st);
+
 }  // namespace d2amd

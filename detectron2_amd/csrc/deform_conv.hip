@@ -663,7 +663,17 @@ static int bwd_host(const DcnShape& s, const void* x, const void* offset, const 
     nchunks = cdiv(s.P, pchunk);
     dim3 grid(nchunks, nblk * co_tiles, s.K2);
     D2_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "deform_conv: too many channel blocks");
-    if (vec)
+    bool tc_w = false;
+    if constexpr (!is32) {
+      const TcBwwPlan wp = dcn_tc_plan_bww(s, (int)w.dtype);
+      if (wp.ok) {  // 16-bit MFMA path (deform_conv_tc.hip)
+        rc = dcn_tc_backward_weight<T>(s, wp, w.x_nhwc, offset, mask, gout, w.gwr, st);
+        if (rc) return rc;
+        tc_w = true;
+      }
+    }
+    if (tc_w) {
+    } else if (vec)
       hipLaunchKernelGGL((dcn_bwd_weight_kernel<T, true>), grid, dim3(WG_THREADS), 0, st, s, (const T*)w.x_nhwc,
                          (const T*)offset, (const T*)mask, (const T*)gout, w.gwr, pchunk, nblk);
     else

@@ -1108,3 +1108,277 @@ template int dcn_tc_backward_data<f16_t>(const DcnShape&, const TcBwPlan&, const
                                          const void*, const void*, float*, float*, float*, void*, hipStream_t);
 
 }  // namespace d2amd
+
+namespace d2amd {
+
+// =====================================================================================================
+// Backward w.r.t. the weight, 16-bit path:  dW[co][ci][tap] = sum_p dY[co][p] * col[(tap, ci)][p].
+// Replaces deform_conv_cuda.cu:642-824 / 1160-1221 (im2col into the HBM column buffer again, then one
+// GEMM per image accumulating into grad_weight).
+// The contraction runs over POSITIONS, so both MFMA operands need 8 consecutive positions per lane:
+//   A  = dY, [co][position] in the reference's NCHW layout already: 16-B loads straight from global;
+//   B  = the deformable column: a lane gathers (position, 8 channels) -- the transpose of what the
+//        instruction wants -- so each wave turns its 16-position x 64-channel column tile through a
+//        2.5 KB wave-private LDS buffer (8 x ds_write_b16 per item, 2 x ds_read_b64 per fragment; the
+//        wave's own LDS operations are ordered, no barrier).
+// One WAVE = 64 output channels x 64 input channels of one tap x a range of 16-position k-steps; waves
+// are fully independent (no workgroup barrier).  All global loads of a k-step sit in straight-line code
+// and run one k-step ahead in registers (clamped indices instead of branches: with loads inside
+// data-dependent branches hipcc serialises the pipeline with s_waitcnt vmcnt(0)).  The bilinear table of a
+// k-step is computed once per lane (its own position) and shared by the 64 channels.
+// Result: fp32 atomics into the [g][tap][co][ci] staging buffer (4,096 per wave), unpacked by
+// unpack_gw_kernel like the generic path.
+struct BwwArgs {
+  const void *x, *offset, *mask, *gout;  // x NHWC; gout NCHW [B][Co][L]
+  float* gwr;                            // [g][tap][co][ci] fp32, zero-filled
+  int n_cot, n_cit, pch, total, ksteps_per_image;
+};
+
+// AB: compile-time ablation for profiling (D2AMD_DCN_ABLATE_BWW selects the instantiation): 1 no gather loads,
+// 2 no combine / LDS transpose, 4 no MFMA, 8 no dY loads, 16 no atomics, 32 no table loads
+template <typename T, int AB>
+__global__ __launch_bounds__(256, 2) void dcn_bwd_weight_tc_kernel(DcnShape s, BwwArgs a) {
+  typedef Mma<T> M;
+  constexpr int TPITCH = 10;  // dwords per channel row of the transposition buffer: 16 positions x 2 B + 8 B pad
+  __shared__ uint32_t tbuf_all[4][64 * TPITCH];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  uint32_t* tbuf = tbuf_all[wid];
+  const int per_xcd = (a.total + 7) >> 3;
+  const int logical = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if (logical >= a.total) return;
+  // decode: position chunk fastest over the 4 waves of a workgroup, then (ci tile, co tile, tap, group)
+  int r = logical * 4 + wid;
+  const int pc = r % a.pch; r /= a.pch;
+  const int cit = r % a.n_cit; r /= a.n_cit;
+  const int cot = r % a.n_cot; r /= a.n_cot;
+  const int tap = r % s.K2;
+  const int g = r / s.K2;
+  if (g >= s.G) return;
+  const int cabs = g * s.Cg + cit * 64;     // first absolute input channel of this wave
+  const int dgi = cabs / s.cpg;
+  const int co0 = cot * 64;                 // first output channel inside the group
+  const long nk = (long)s.B * a.ksteps_per_image;
+  const int k_lo = (int)((long)pc * nk / a.pch), k_hi = (int)((long)(pc + 1) * nk / a.pch);
+
+  const T* offset = (const T*)a.offset;
+  const T* mask = (const T*)a.mask;
+  const char* xb = (const char*)a.x;
+  const T* gout = (const T*)a.gout;
+  const uint32_t pix = (uint32_t)s.C * (uint32_t)sizeof(T);
+  const int pos = lane & 15, cq = lane >> 4;        // gather role: position in the k-step, channel quarter
+  const int n32 = lane & 31, khalf = lane >> 5;     // MFMA role
+  const int ti = tap / s.kw, tj = tap - ti * s.kw;
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; m++)
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+#pragma unroll
+      for (int q = 0; q < 16; q++) acc[m][n][q] = 0.f;
+
+  struct Raw { float oh, ow, mk; };
+  auto load_raw = [&](int k, Raw& rw) __attribute__((always_inline)) {
+    k = min(k, (int)nk - 1);
+    const int b = k / a.ksteps_per_image, l = min((k - b * a.ksteps_per_image) * 16 + pos, s.L - 1);
+    const long obase = ((long)b * s.DG + dgi) * 2 * s.K2;
+    if (AB & 32) { rw.oh = 0.3f; rw.ow = 0.4f; rw.mk = 0.5f; return; }
+    rw.oh = to_f32(offset[(obase + 2 * tap) * s.L + l]);
+    rw.ow = to_f32(offset[(obase + 2 * tap + 1) * s.L + l]);
+    rw.mk = mask ? to_f32(mask[(((long)b * s.DG + dgi) * s.K2 + tap) * s.L + l]) : 1.f;
+  };
+  struct Ent { uint32_t off[4]; float w[4]; };
+  auto build = [&](int k, const Raw& rw, Ent& e) __attribute__((always_inline)) {
+    k = min(k, (int)nk - 1);
+    const int b = k / a.ksteps_per_image, l = (k - b * a.ksteps_per_image) * 16 + pos;
+#pragma unroll
+    for (int t = 0; t < 4; t++) { e.off[t] = 0u; e.w[t] = 0.f; }
+    const int lc = min(l, s.L - 1);
+    const int ho = lc / s.Wo, wo = lc - ho * s.Wo;
+    const float h_im = (float)(ho * s.sh - s.ph + ti * s.dh) + rw.oh;
+    const float w_im = (float)(wo * s.sw - s.pw + tj * s.dw) + rw.ow;
+    if (l < s.L && h_im > -1.f && w_im > -1.f && h_im < (float)s.H && w_im < (float)s.W) {
+      const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+      const int h_high = h_low + 1, w_high = w_low + 1;
+      const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+      const float hh = 1.f - lh, hw = 1.f - lw, m = rw.mk;
+      const long rowbase = (long)b * s.H;
+      if (h_low >= 0 && w_low >= 0) { e.off[0] = (uint32_t)((rowbase + h_low) * s.W + w_low) * pix; e.w[0] = hh * hw * m; }
+      if (h_low >= 0 && w_high <= s.W - 1) { e.off[1] = (uint32_t)((rowbase + h_low) * s.W + w_high) * pix; e.w[1] = hh * lw * m; }
+      if (h_high <= s.H - 1 && w_low >= 0) { e.off[2] = (uint32_t)((rowbase + h_high) * s.W + w_low) * pix; e.w[2] = lh * hw * m; }
+      if (h_high <= s.H - 1 && w_high <= s.W - 1) { e.off[3] = (uint32_t)((rowbase + h_high) * s.W + w_high) * pix; e.w[3] = lh * lw * m; }
+    }
+  };
+  // operands of k-step k: 2 gather items (this lane's position x channels (it*4 + cq)*8..) and 2 dY fragments
+  auto issue = [&](int k, const Ent& e, raw16 (&gr)[2][4], raw16 (&ar)[2]) __attribute__((always_inline)) {
+    k = min(k, (int)nk - 1);
+    const int b = k / a.ksteps_per_image, l0 = (k - b * a.ksteps_per_image) * 16;
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+      const uint32_t cofs = (uint32_t)(cabs + (it * 4 + cq) * 8) * (uint32_t)sizeof(T);
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        if (AB & 1) gr[it][c] = raw16{e.off[c], cofs, 0u, 0u};
+        else gr[it][c] = *reinterpret_cast<const raw16*>(xb + (e.off[c] + cofs));
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+      // 8 positions l0 + khalf*8 .. of output channel co0 + m*32 + n32.  The window is clamped to the row
+      // ([L - 8, L) at the image tail) so that the load never leaves the row; compute() shifts it back
+      const int co = min(co0 + m * 32 + n32, s.Cog - 1);
+      const int lw = min(l0 + khalf * 8, s.L - 8);
+      if (AB & 8) ar[m] = raw16{(uint32_t)lw, (uint32_t)co, 0u, 0u};
+      else ar[m] = *reinterpret_cast<const raw16*>(gout + ((long)b * s.Co + (long)g * s.Cog + co) * s.L + lw);
+    }
+  };
+  auto compute = [&](int k, const Ent& e, const raw16 (&gr)[2][4], const raw16 (&ar)[2]) __attribute__((always_inline)) {
+    // combine -> transposed into the wave's LDS buffer: tbuf[channel][position].  The buffer is wave-private
+    // and a wave's DS operations execute in order; the asm statements only stop the COMPILER from moving
+    // the 16-bit stores across the 64-bit loads of the other type.
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+      if (AB & 2) { tbuf[lane] = gr[it][0].x ^ gr[it][1].x ^ gr[it][2].x ^ gr[it][3].x; continue; }
+      float v[8];
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        float f[8];
+        tc_unpack(gr[it][c], f, T{});
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = c == 0 ? e.w[c] * f[u] : v[u] + e.w[c] * f[u];
+      }
+      const raw16 pk = tc_pack(v, T{});
+      uint16_t* row = reinterpret_cast<uint16_t*>(tbuf) + ((it * 4 + cq) * 8) * (TPITCH * 2) + pos;
+#pragma unroll
+      for (int u = 0; u < 8; u++) row[u * (TPITCH * 2)] = (uint16_t)(u & 1 ? pk[u >> 1] >> 16 : pk[u >> 1] & 0xffffu);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // dY fragment: at the image tail the window was loaded from [L - 8, L); shift it down by `sh` elements
+    // so that element j is position l + j again, zero-filling the positions past the row end
+    const int kk = min(k, (int)nk - 1);
+    const int lq = (kk - (kk / a.ksteps_per_image) * a.ksteps_per_image) * 16 + khalf * 8;
+    const int sh = lq - min(lq, s.L - 8);  // 0 inside the row; >= 8: nothing valid
+    raw16 af[2];
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+      unsigned long long lo = (unsigned long long)ar[m].x | ((unsigned long long)ar[m].y << 32);
+      unsigned long long hi = (unsigned long long)ar[m].z | ((unsigned long long)ar[m].w << 32);
+      if (sh >= 8) { lo = 0ull; hi = 0ull; }
+      else if (sh >= 4) { lo = sh == 4 ? hi : hi >> (16 * (sh - 4)); hi = 0ull; }
+      else if (sh > 0) { lo = (lo >> (16 * sh)) | (hi << (64 - 16 * sh)); hi = hi >> (16 * sh); }
+      af[m] = raw16{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+    }
+#pragma unroll
+    for (int n = 0; n < 2; n++) {
+      const uint32_t* rp = tbuf + (n * 32 + n32) * TPITCH + khalf * 4;
+      const uint2 lo = *reinterpret_cast<const uint2*>(rp);
+      const uint2 hi = *reinterpret_cast<const uint2*>(rp + 2);
+      const raw16 bq = {lo.x, lo.y, hi.x, hi.y};
+      const typename M::frag bfr = __builtin_bit_cast(typename M::frag, bq);
+      if (AB & 4) {
+#pragma unroll
+        for (int m = 0; m < 2; m++) acc[m][n][0] += __uint_as_float(af[m].x ^ bq.x);
+      } else {
+#pragma unroll
+        for (int m = 0; m < 2; m++) acc[m][n] = M::mma(__builtin_bit_cast(typename M::frag, af[m]), bfr, acc[m][n]);
+      }
+    }
+    asm volatile("" ::: "memory");
+  };
+
+  if (k_lo < k_hi) {
+    Raw r1, r2;
+    Ent e0, e1;
+    raw16 g0[2][4], g1[2][4], a0[2], a1[2];
+    load_raw(k_lo, r1);
+    build(k_lo, r1, e0);
+    load_raw(k_lo + 1, r1);
+    load_raw(k_lo + 2, r2);
+    issue(k_lo, e0, g0, a0);
+    for (int k = k_lo; k < k_hi; k += 2) {
+      // k + 1 (clamped past the end: harmless re-computation of the last k-step, never accumulated)
+      build(k + 1, r1, e1);
+      load_raw(k + 3, r1);
+      issue(k + 1, e1, g1, a1);
+      compute(k, e0, g0, a0);
+      build(k + 2, r2, e0);
+      load_raw(k + 4, r2);
+      issue(k + 2, e0, g0, a0);
+      if (k + 1 < k_hi) compute(k + 1, e1, g1, a1);
+    }
+  }
+  // ---- fp32 atomics into gwr[g][tap][co][ci]
+  float* dst = a.gwr + (((long)g * s.K2 + tap) * s.Cog) * s.Cg + (cabs - g * s.Cg);
+#pragma unroll
+  for (int m = 0; m < 2; m++)
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        const int co = co0 + m * 32 + frag_row(q, lane);
+        if (co < s.Cog) {
+          if (AB & 16) { if (acc[m][n][q] == 123.456f) dst[0] = 1.f; }
+          else atomicAdd(dst + (long)co * s.Cg + n * 32 + n32, acc[m][n][q]);
+        }
+      }
+}
+
+TcBwwPlan dcn_tc_plan_bww(const DcnShape& s, int dtype) {
+  TcBwwPlan pl{};
+  pl.ok = false;
+  if (getenv("D2AMD_DCN_V1") || getenv("D2AMD_DCN_BWW_V1")) return pl;
+  if (dtype != D2AMD_BF16 && dtype != D2AMD_F16) return pl;
+  if (s.Cg % 64 != 0 || s.cpg % 64 != 0 || s.P <= 0 || s.L < 8) return pl;
+  if ((long)s.B * s.H * s.W * s.C * 2 >= (1l << 32)) return pl;
+  pl.n_cot = cdiv(s.Cog, 64);
+  pl.n_cit = s.Cg / 64;
+  pl.ksteps_per_image = cdiv(s.L, 16);
+  const long tiles = (long)s.G * s.K2 * pl.n_cot * pl.n_cit;
+  const long nk = (long)s.B * pl.ksteps_per_image;
+  long pch = (2304 + tiles - 1) / tiles;      // ~2 waves per SIMD in total (measured: profiles/r01/v5_dcn_bww_sweep.txt)
+  if (pch < 8) pch = 8;
+  if (pch > nk / 4) pch = nk / 4 > 0 ? nk / 4 : 1;  // at least 4 k-steps per wave
+  pch = (pch + 3) / 4 * 4;                     // the 4 waves of a workgroup take consecutive chunks
+  const char* e = getenv("D2AMD_DCN_BWW_PCH");  // profiling switch
+  if (e && atoi(e) > 0) pch = (atoi(e) + 3) / 4 * 4;
+  pl.pch = (int)pch;
+  pl.ok = true;
+  return pl;
+}
+
+template <typename T>
+int dcn_tc_backward_weight(const DcnShape& s, const TcBwwPlan& pl, const void* x_nhwc, const void* offset,
+                           const void* mask, const void* gout_nchw, float* gwr, hipStream_t st) {
+  BwwArgs a{};
+  a.x = x_nhwc; a.offset = offset; a.mask = mask; a.gout = gout_nchw; a.gwr = gwr;
+  a.n_cot = pl.n_cot; a.n_cit = pl.n_cit; a.pch = pl.pch; a.ksteps_per_image = pl.ksteps_per_image;
+  const long waves = (long)s.G * s.K2 * pl.n_cot * pl.n_cit * pl.pch;
+  D2_CHECK_ARG(waves / 4 < (1l << 30), "deform_conv: too many tiles");
+  a.total = (int)(waves / 4);
+  const int grid = (a.total + 7) / 8 * 8;
+  const char* ab = getenv("D2AMD_DCN_ABLATE_BWW");  // profiling only
+  switch (ab ? atoi(ab) : 0) {
+#ifdef D2AMD_DCN_ABLATION_BUILD
+    case 1: hipLaunchKernelGGL((dcn_bwd_weight_tc_kernel<T, 1>), dim3(grid), dim3(256), 0, st, s, a); break;
+    case 2: hipLaunchKernelGGL((dcn_bwd_weight_tc_kernel<T, 2>), dim3(grid), dim3(256), 0, st, s, a); break;
+    case 4: hipLaunchKernelGGL((dcn_bwd_weight_tc_kernel<T, 4>), dim3(grid), dim3(256), 0, st, s, a); break;
+    case 8: hipLaunchKernelGGL((dcn_bwd_weight_tc_kernel<T, 8>), dim3(grid), dim3(256), 0, st, s, a); break;
+    case 16: hipLaunchKernelGGL((dcn_bwd_weight_tc_kernel<T, 16>), dim3(grid), dim3(256), 0, st, s, a); break;
+    case 32: hipLaunchKernelGGL((dcn_bwd_weight_tc_kernel<T, 32>), dim3(grid), dim3(256), 0, st, s, a); break;
+    case 41: hipLaunchKernelGGL((dcn_bwd_weight_tc_kernel<T, 41>), dim3(grid), dim3(256), 0, st, s, a); break;
+    case 47: hipLaunchKernelGGL((dcn_bwd_weight_tc_kernel<T, 47>), dim3(grid), dim3(256), 0, st, s, a); break;
+    case 63: hipLaunchKernelGGL((dcn_bwd_weight_tc_kernel<T, 63>), dim3(grid), dim3(256), 0, st, s, a); break;
+#endif
+    default: hipLaunchKernelGGL((dcn_bwd_weight_tc_kernel<T, 0>), dim3(grid), dim3(256), 0, st, s, a);
+  }
+  D2_LAUNCH_OK();
+  return D2AMD_OK;
+}
+
+template int dcn_tc_backward_weight<bf16_t>(const DcnShape&, const TcBwwPlan&, const void*, const void*, const void*,
+                                            const void*, float*, hipStream_t);
+template int dcn_tc_backward_weight<f16_t>(const DcnShape&, const TcBwwPlan&, const void*, const void*, const void*,
+                                           const void*, float*, hipStream_t);
+
+}  // namespace d2amd

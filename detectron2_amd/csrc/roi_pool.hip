@@ -40,6 +40,9 @@ struct PoolLevels {
   unsigned long long* dbg;  // profiling only (D2AMD_PROFILE builds): cycle stamps of one workgroup
   int dbg_block;
   int ablate;  // profiling only (D2AMD_ABLATE): bit0 skip gather, bit1 skip weights, bit2 skip list scan
+  const int* tile_cnt;    // backward: per tile, number of ROIs that touch it (nullptr: tiles scan the records)
+  const void* tile_list;  // backward: [tile][TILE_CAP] TileEntry in ROI order (valid when tile_cnt[tile] <= TILE_CAP)
+  unsigned long long* wgstamps;  // profiling only (D2AMD_POOL_STAMPS): per workgroup {start, lists done, loop done, end, #ROIs}
 };
 
 // detectron2/modeling/poolers.py:51-59 in fp32, operation for operation:
@@ -265,6 +268,8 @@ constexpr int CT = 256;          // threads per row-split of a group: 8 pixel co
 // the whole geometry -- two IEEE divisions, sqrt, log2 -- per candidate and per tile: ~6k cycles of
 // every workgroup), plus the geometry the weights need.
 struct HitGeo { float start_h, start_w, bin_h, bin_w, inv; int grid; };  // grid = grid_h | grid_w << 16
+// global tile id (numbering of tile_lists_kernel) of the first tile of each level in this launch
+struct PoolTileIds { int first[POOL_MAX_LEVELS]; };
 struct RoiRec {
   int level, batch;        // level = -1: contributes nothing (no level, empty sampling grid, outside)
   int fy0, fy1, fx0, fx1;  // conservative pixel rectangle [fy0, fy1] x [fx0, fx1] that can receive gradient
@@ -314,6 +319,61 @@ __global__ void roi_records_kernel(PoolLevels L, const float* __restrict__ rois,
   rec[k] = o;
 }
 
+// Per-tile ROI lists, built once per backward call by one WAVE per tile: the 64 lanes test 64 records at
+// a time against the tile (a few integer compares on the record heads), ballot + prefix keep ROI order.
+// Without them every tile workgroup scanned all K records itself: 2.2 us per 512 records and tile
+// (profiles/r01/v4_pool_bwd_timeline.txt), 4.4 of the 5.5 us an EMPTY box-head tile took.  Tiles with
+// more than TILE_CAP ROIs (clustered proposals) keep the in-kernel scan.
+constexpr int TILE_CAP = 64;
+// list entry = ROI index + the geometry the weights need (one dependent load less in the tile workgroup)
+struct __attribute__((aligned(16))) TileEntry { HitGeo g; int roi; int pad; };  // 32 bytes
+static_assert(sizeof(TileEntry) == 32, "TileEntry layout");
+struct TileGeom { int lvl, n, y0, x0; };
+__device__ __forceinline__ TileGeom tile_geom(const PoolLevels& L, int tile) {
+  TileGeom g;
+  g.lvl = 0;
+#pragma unroll
+  for (int l = 1; l < POOL_MAX_LEVELS; l++)
+    if (l < L.num_levels && tile >= L.tile_base[l]) g.lvl = l;
+  const int H = L.H[g.lvl], W = L.W[g.lvl];
+  const int tiles_x = (W + 7) / 8, tiles_y = (H + 7) / 8;
+  int tl = tile - L.tile_base[g.lvl];
+  g.n = tl / (tiles_y * tiles_x);
+  tl -= g.n * tiles_y * tiles_x;
+  g.y0 = (tl / tiles_x) * 8;
+  g.x0 = (tl % tiles_x) * 8;
+  return g;
+}
+
+// L.tile_base here numbers ALL tiles of all levels (make_levels); the two backward launches map their
+// own tile numbering onto it through `first` (tile id of their first tile per level).
+__global__ __launch_bounds__(256) void tile_lists_kernel(PoolLevels L, const RoiRec* __restrict__ rec, int ntiles,
+                                                        int* __restrict__ tile_cnt, TileEntry* __restrict__ tile_list) {
+  const int lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile >= ntiles) return;
+  const TileGeom g = tile_geom(L, tile);
+  int cnt = 0;
+  for (int k0 = 0; k0 < L.K; k0 += 64) {
+    const int k = min(k0 + lane, L.K - 1);
+    const int4 ra = *reinterpret_cast<const int4*>(&rec[k].level);  // level, batch, fy0, fy1
+    const int2 rb = *reinterpret_cast<const int2*>(&rec[k].fx0);    // fx0, fx1
+    const bool hit = k0 + lane < L.K && ra.x == g.lvl && ra.y == g.n && ra.w >= g.y0 && ra.z < g.y0 + 8 &&
+        rb.y >= g.x0 && rb.x < g.x0 + 8;
+    const unsigned long long bal = __ballot(hit);
+    const int pos = cnt + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+    if (hit && pos < TILE_CAP) {
+      TileEntry e;
+      e.g = rec[k].g;
+      e.roi = k0 + lane;
+      e.pad = 0;
+      tile_list[(long)tile * TILE_CAP + pos] = e;
+    }
+    cnt += __builtin_popcountll(bal);
+  }
+  if (lane == 0) tile_cnt[tile] = cnt;
+}
+
 // total weight the `grid` samples of bin p put on pixel `pix` along one axis
 __device__ __forceinline__ float axis_weight(float start, float bin, int grid, int p, int pix, int size) {
   float w = 0.f;
@@ -333,7 +393,7 @@ template <typename T, int VEC, int GROUPS, int RS, int NB>
 __global__ __launch_bounds__(CT * RS * GROUPS, 4) void pool_bwd_nhwc_kernel(PoolLevels L,
                                                                          const RoiRec* __restrict__ rec,
                                                                          const T* __restrict__ gout, int nslab,
-                                                                         int total_blocks) {
+                                                                         int total_blocks, PoolTileIds ids) {
   constexpr int GT = CT * RS, NT = GT * GROUPS, TR = TILE / RS;
   __shared__ TileShared<GROUPS> S;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -343,6 +403,10 @@ __global__ __launch_bounds__(CT * RS * GROUPS, 4) void pool_bwd_nhwc_kernel(Pool
   const int per_xcd = (total_blocks + 7) >> 3;
   const int logical = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
   if (logical >= total_blocks) return;
+  unsigned long long* wst = (L.wgstamps && tid == 0) ? L.wgstamps + 5 * (size_t)logical : nullptr;
+  if (wst) wst[0] = wall_clock64();
+  unsigned long long wst_list = 0;
+  int wst_n = 0;
   const int slab = logical % nslab;
   const int tile = logical / nslab;
   int lvl = 0;
@@ -401,7 +465,29 @@ __global__ __launch_bounds__(CT * RS * GROUPS, 4) void pool_bwd_nhwc_kernel(Pool
 #ifdef D2AMD_PROFILE
   const unsigned long long rt0 = wall_clock64();
 #endif
-  for (int kbase = 0; kbase < K; kbase += LCH) {
+  // prepared list of this tile (tile_lists_kernel), if it fits.  The entries carry the geometry, so the
+  // workgroup pays two dependent memory round trips (count, entries) before the weights instead of three
+  // (count, indices, records).  Entries are only read when they were written: fetching all TILE_CAP slots
+  // unconditionally (to overlap with the count) reads cold, never-written memory and was measured 2x slower.
+  int tl_cnt = -1;
+  if (L.tile_cnt) {
+    const int gtile = ids.first[lvl] + (tile - L.tile_base[lvl]);
+    const int c = L.tile_cnt[gtile];
+    if (c <= TILE_CAP) {
+      tl_cnt = c;
+      if (tid < c) {
+        const TileEntry e = ((const TileEntry*)L.tile_list)[(long)gtile * TILE_CAP + tid];
+        S.list[tid] = e.roi;
+        S.geo[tid] = e.g;
+      }
+    }
+  }
+  const bool prelist = tl_cnt >= 0;  // uniform
+  for (int kbase = 0; kbase < (prelist ? 1 : K); kbase += LCH) {
+    int nlist = 0;
+    if (prelist) {
+      nlist = tl_cnt;
+    } else {
     // ---- (1) ordered list (+ geometry) of the ROIs of this chunk that touch the tile ----------
     const int kend = min(K, kbase + LCH);
     constexpr int ROUNDS = (LCH + NT - 1) / NT;
@@ -431,7 +517,6 @@ __global__ __launch_bounds__(CT * RS * GROUPS, 4) void pool_bwd_nhwc_kernel(Pool
       }
     }
     __syncthreads();
-    int nlist = 0;
     {
       int run = 0;
       constexpr int NSLOT = LCH / 64;  // waves of candidates, in ROI order
@@ -445,12 +530,16 @@ __global__ __launch_bounds__(CT * RS * GROUPS, 4) void pool_bwd_nhwc_kernel(Pool
       }
       nlist = run;
     }
+    }  // !prelist
     if (L.ablate & 4) nlist = 0;
+    if (wst) { wst_list = wall_clock64(); wst_n += nlist; }
     STAMP();
     if (nlist == 0) continue;  // uniform
     __syncthreads();           // list complete
-    for (int i = tid; i < nlist; i += NT) S.geo[i] = rec[S.list[i]].g;  // geometry of the hits -> LDS
-    __syncthreads();
+    if (!prelist) {
+      for (int i = tid; i < nlist; i += NT) S.geo[i] = rec[S.list[i]].g;  // geometry of the hits -> LDS
+      __syncthreads();
+    }
 
     // ---- (2)+(3) per group: software pipeline over its list entries grp, grp + GROUPS, ... ------
     const int iters = (nlist + GROUPS - 1) / GROUPS;
@@ -544,6 +633,7 @@ __global__ __launch_bounds__(CT * RS * GROUPS, 4) void pool_bwd_nhwc_kernel(Pool
 #ifdef D2AMD_PROFILE
   if (dbg_on) { L.dbg[127] = dbg_n; L.dbg[126] = wall_clock64() - rt0; L.dbg[125] = __builtin_readcyclecounter() - L.dbg[0]; }
 #endif
+  if (wst) { wst[1] = wst_list; wst[2] = wall_clock64(); wst[4] = (unsigned long long)wst_n; }
   // ---- partial tiles of groups 1.. are added to group 0 in a fixed order (deterministic) -------
   if constexpr (GROUPS > 1) {
     __shared__ float part[GT][TR * VEC + 1];
@@ -578,6 +668,7 @@ __global__ __launch_bounds__(CT * RS * GROUPS, 4) void pool_bwd_nhwc_kernel(Pool
       }
     }
   }
+  if (wst) wst[3] = wall_clock64();
 }
 
 // ---- convert_boxes_to_pooler_format (poolers.py:62-104) in one launch, no host sync -----------------
@@ -618,7 +709,7 @@ static PoolLevels make_levels(const d2amd_pooler_params* p, const void* const* d
   L.min_level = p->min_level; L.max_level = p->max_level; L.canonical_level = p->canonical_level;
   L.canonical_size = p->canonical_box_size;
   { const char* e = getenv("D2AMD_ABLATE"); L.ablate = e ? atoi(e) : 0; }
-  L.dbg = nullptr; L.dbg_block = -1;
+  L.dbg = nullptr; L.dbg_block = -1; L.wgstamps = nullptr; L.tile_cnt = nullptr; L.tile_list = nullptr;
   int base = 0;
   for (int l = 0; l < p->num_levels; l++) {
     L.data[l] = data[l]; L.H[l] = p->H[l]; L.W[l] = p->W[l]; L.scale[l] = p->spatial_scale[l];
@@ -693,10 +784,17 @@ constexpr int COARSE_TILES = 512;
 
 template <typename T, int VEC, int GROUPS, int RS>
 static void launch_bwd(const PoolLevels& L, const RoiRec* rec, const void* gout, int nslab, long total,
-                       hipStream_t s) {
+                       hipStream_t s, const PoolTileIds& ids) {
   const int grid = (int)((total + 7) / 8) * 8;
   hipLaunchKernelGGL((pool_bwd_nhwc_kernel<T, VEC, GROUPS, RS, 8>), dim3(grid), dim3(CT * RS * GROUPS), 0, s, L, rec,
-                     (const T*)gout, nslab, (int)total);
+                     (const T*)gout, nslab, (int)total, ids);
+}
+
+static size_t pool_al(size_t x) { return (x + 255) / 256 * 256; }
+static long pool_ntiles(const d2amd_pooler_params* p) {
+  long n = 0;
+  for (int l = 0; l < p->num_levels; l++) n += (long)cdiv(p->H[l], TILE) * cdiv(p->W[l], TILE) * p->N;
+  return n;
 }
 
 template <typename T>
@@ -713,10 +811,23 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
     return D2AMD_EWORKSPACE;
   }
   RoiRec* rec = (RoiRec*)workspace;
+  // per-tile ROI lists live behind the records when the caller sized the workspace with
+  // d2amd_roi_pooler_backward_workspace_bytes (the older K-only size still works: tiles then scan)
+  const long ntiles = pool_ntiles(p);
+  const size_t off_cnt = pool_al(need), off_list = off_cnt + pool_al((size_t)ntiles * 4);
+  const bool lists = K > 0 && ntiles > 0 && workspace_bytes >= off_list + (size_t)ntiles * TILE_CAP * sizeof(TileEntry) &&
+      getenv("D2AMD_POOL_NOLISTS") == nullptr;
+  int* tile_cnt = lists ? (int*)((char*)workspace + off_cnt) : nullptr;
+  TileEntry* tile_list = lists ? (TileEntry*)((char*)workspace + off_list) : nullptr;
+  const PoolLevels L0 = make_levels(p, (const void* const*)grad_inputs, K);
   if (K > 0) {
-    const PoolLevels L0 = make_levels(p, (const void* const*)grad_inputs, K);
     hipLaunchKernelGGL(roi_records_kernel, dim3(cdiv(K, 256)), dim3(256), 0, s, L0, rois, rec);
     D2_LAUNCH_OK();
+    if (lists) {
+      hipLaunchKernelGGL(tile_lists_kernel, dim3(cdiv(ntiles, 4)), dim3(256), 0, s, L0, rec, (int)ntiles, tile_cnt,
+                         tile_list);
+      D2_LAUNCH_OK();
+    }
   }
   // profiling switches: D2AMD_BWD_CFG = "<fine GROUPS><fine RS><coarse GROUPS><coarse RS>", e.g. 1122
   static const int cfg = getenv("D2AMD_BWD_CFG") ? atoi(getenv("D2AMD_BWD_CFG")) : 1222;
@@ -728,11 +839,15 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
   bool forked = false;
   for (int pass = 1; pass >= 0; pass--) {  // pass 1: coarse levels (side stream), pass 0: fine levels
     PoolLevels L = make_levels(p, (const void* const*)grad_inputs, K);
+    PoolTileIds ids{};
+    L.tile_cnt = tile_cnt;
+    L.tile_list = tile_list;
     int base = 0;
     for (int l = 0; l < p->num_levels; l++) {
       const int tiles = cdiv(p->H[l], TILE) * cdiv(p->W[l], TILE) * p->N;
       const bool coarse = tiles <= COARSE_TILES;
       L.tile_base[l] = base;
+      ids.first[l] = L0.tile_base[l];
       if (coarse == (pass == 1)) base += tiles;
     }
     for (int l = p->num_levels; l <= POOL_MAX_LEVELS; l++) L.tile_base[l] = base;
@@ -755,17 +870,37 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
       L.dbg_block = (pass == atoi(getenv("D2AMD_DBG_PASS") ? getenv("D2AMD_DBG_PASS") : "0")) ? atoi(getenv("D2AMD_DBG_BLOCK")) : -1;
     }
 #endif
+    const char* stamp_path = getenv("D2AMD_POOL_STAMPS");  // profiling only: per-workgroup timeline dump
+    if (stamp_path) {
+      D2_HIP_OK(hipMalloc(&L.wgstamps, (size_t)total * 5 * 8));
+      D2_HIP_OK(hipMemsetAsync(L.wgstamps, 0, (size_t)total * 5 * 8, ls));
+    }
     const int g = pass == 0 ? fg : cgp, r = pass == 0 ? fr : cr;
     if (!vec) {
-      if (g == 1) launch_bwd<T, 1, 1, 1>(L, rec, grad_output, nslab, total, ls);
-      else launch_bwd<T, 1, 2, 1>(L, rec, grad_output, nslab, total, ls);
-    } else if (g == 1 && r == 1) launch_bwd<T, VEC, 1, 1>(L, rec, grad_output, nslab, total, ls);
-    else if (g == 1 && r == 2) launch_bwd<T, VEC, 1, 2>(L, rec, grad_output, nslab, total, ls);
-    else if (g == 2 && r == 1) launch_bwd<T, VEC, 2, 1>(L, rec, grad_output, nslab, total, ls);
-    else if (g == 2 && r == 2) launch_bwd<T, VEC, 2, 2>(L, rec, grad_output, nslab, total, ls);
-    else if (g == 4 && r == 1) launch_bwd<T, VEC, 4, 1>(L, rec, grad_output, nslab, total, ls);
+      if (g == 1) launch_bwd<T, 1, 1, 1>(L, rec, grad_output, nslab, total, ls, ids);
+      else launch_bwd<T, 1, 2, 1>(L, rec, grad_output, nslab, total, ls, ids);
+    } else if (g == 1 && r == 1) launch_bwd<T, VEC, 1, 1>(L, rec, grad_output, nslab, total, ls, ids);
+    else if (g == 1 && r == 2) launch_bwd<T, VEC, 1, 2>(L, rec, grad_output, nslab, total, ls, ids);
+    else if (g == 2 && r == 1) launch_bwd<T, VEC, 2, 1>(L, rec, grad_output, nslab, total, ls, ids);
+    else if (g == 2 && r == 2) launch_bwd<T, VEC, 2, 2>(L, rec, grad_output, nslab, total, ls, ids);
+    else if (g == 4 && r == 1) launch_bwd<T, VEC, 4, 1>(L, rec, grad_output, nslab, total, ls, ids);
     else { set_error("roi_pooler_backward: bad D2AMD_BWD_CFG %d", cfg); return D2AMD_EINVAL; }
     D2_LAUNCH_OK();
+    if (stamp_path) {
+      D2_HIP_OK(hipStreamSynchronize(ls));
+      unsigned long long* h = (unsigned long long*)malloc((size_t)total * 5 * 8);
+      D2_HIP_OK(hipMemcpy(h, L.wgstamps, (size_t)total * 5 * 8, hipMemcpyDeviceToHost));
+      char fn[512];
+      snprintf(fn, sizeof(fn), "%s.pass%d", stamp_path, pass);
+      FILE* f = fopen(fn, "w");
+      if (f) {
+        for (long i = 0; i < total; i++)
+          fprintf(f, "%ld %llu %llu %llu %llu %llu\n", i, h[5 * i], h[5 * i + 1], h[5 * i + 2], h[5 * i + 3], h[5 * i + 4]);
+        fclose(f);
+      }
+      free(h);
+      (void)hipFree(L.wgstamps);
+    }
     if (pass == 1 && forked) D2_HIP_OK(hipEventRecord(side->join, side->stream));
 #ifdef D2AMD_PROFILE
     if (L.dbg && L.dbg_block >= 0) {
@@ -835,6 +970,13 @@ extern "C" int d2amd_roi_pooler_forward(const d2amd_pooler_params* p, const void
 }
 
 extern "C" size_t d2amd_roi_pooler_workspace_bytes(int K) { return (size_t)(K > 0 ? K : 1) * sizeof(RoiRec); }
+
+extern "C" size_t d2amd_roi_pooler_backward_workspace_bytes(const d2amd_pooler_params* p, int K) {
+  const size_t need = (size_t)(K > 0 ? K : 1) * sizeof(RoiRec);
+  if (check_pooler(p, "roi_pooler_backward_workspace_bytes")) return need;
+  const long ntiles = pool_ntiles(p);
+  return pool_al(need) + pool_al((size_t)ntiles * 4) + (size_t)ntiles * TILE_CAP * sizeof(TileEntry) + 256;
+}
 
 extern "C" int d2amd_roi_pooler_backward(const d2amd_pooler_params* p, const void* grad_output, const float* rois,
                                          void* const* grad_inputs, int K, void* workspace, size_t workspace_bytes,

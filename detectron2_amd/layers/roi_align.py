@@ -70,7 +70,10 @@ class _ROIAlign(Function):
         gin = _empty_like_layout(g, shape, layout)
         ws, ws_bytes = None, 0
         if fused:
-            ws_bytes = 48 * max(k, 1)  # per-ROI records
+            # per-ROI records + per-tile ROI lists (d2amd_roi_pooler_backward_workspace_bytes for one level)
+            nt = ((h + 7) // 8) * ((w + 7) // 8) * n
+            al = lambda x: (x + 255) // 256 * 256
+            ws_bytes = al(48 * max(k, 1)) + al(4 * nt) + 64 * 32 * nt + 256
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=g.device)
         elif g.dtype != torch.float32:
             ws = torch.empty(n * c * h * w, dtype=torch.float32, device=g.device)

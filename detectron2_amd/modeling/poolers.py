@@ -133,7 +133,8 @@ class _FusedROIPool(Function):
         grads = [torch.empty((n, c, h, w), dtype=g.dtype, device=g.device, memory_format=torch.channels_last)
                  for (h, w) in hw]
         p = _params(cfg, (n, c), hw, _C.dtype_code(g), _C.NHWC)
-        ws_bytes = 48 * max(k, 1)  # d2amd_roi_pooler_workspace_bytes(k): per-ROI records
+        # per-ROI records + per-tile ROI lists (one wave per 8x8 tile bins the ROIs once per call)
+        ws_bytes = _C.lib().d2amd_roi_pooler_backward_workspace_bytes(ctypes.byref(p), k)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=g.device)
         with _C.on_device(g.device):
             _C.check(_C.lib().d2amd_roi_pooler_backward(ctypes.byref(p), _C.ptr(g), _C.ptr(rois),

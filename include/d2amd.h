@@ -92,7 +92,10 @@ typedef struct d2amd_pooler_params {
 int d2amd_roi_pooler_supported(const d2amd_pooler_params* p, int backward);
 int d2amd_roi_pooler_forward(const d2amd_pooler_params* p, const void* const* inputs, const float* rois,
                              void* output, int K, void* stream);
-size_t d2amd_roi_pooler_workspace_bytes(int K); /* backward: per-ROI records (48 B each) */
+size_t d2amd_roi_pooler_workspace_bytes(int K); /* backward, minimum: per-ROI records (48 B each) */
+/* backward, recommended: records + per-tile ROI lists (one wave per 8x8 tile bins the ROIs once per call;
+ * with the minimum size every tile workgroup scans all K records itself, ~2 us per 512 records and tile) */
+size_t d2amd_roi_pooler_backward_workspace_bytes(const d2amd_pooler_params* p, int K);
 int d2amd_roi_pooler_backward(const d2amd_pooler_params* p, const void* grad_output, const float* rois,
                               void* const* grad_inputs, int K, void* workspace, size_t workspace_bytes,
                               void* stream);

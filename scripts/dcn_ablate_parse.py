@@ -14,3 +14,7 @@ for lab in plan["fwd"]:
 i = 0
 for lab in plan["bwd"]:
     print(lab, [round(v, 1) for v in b[i:i + rep]]); i += rep
+i = 0
+w = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if "dcn_bwd_weight" in r["Kernel_Name"]]
+for lab in plan.get("bww", []):
+    print(lab, [round(v, 1) for v in w[i:i + rep]]); i += rep

@@ -1,0 +1,33 @@
+"""Per-workgroup timeline of the tile-gather backward (D2AMD_POOL_STAMPS).  python scripts/pool_stamps.py [box|mask]"""
+import os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+which = sys.argv[1] if len(sys.argv) > 1 else "box"
+w = bench.Workload(torch.device("cuda", 0), torch.bfloat16, "nhwc")
+pooler, lists, grad = (w.box_pooler, w.box_lists, w.gbox) if which == "box" else (w.mask_pooler, w.mask_lists, w.gmask)
+y = pooler(w.feats, lists)
+for _ in range(3):
+    torch.autograd.grad([y], w.feats, [grad], retain_graph=True)
+torch.cuda.synchronize()
+os.environ["D2AMD_POOL_STAMPS"] = "/tmp/pool_stamps"
+torch.autograd.grad([y], w.feats, [grad], retain_graph=True)
+torch.cuda.synchronize()
+os.environ.pop("D2AMD_POOL_STAMPS")
+for ps, name in ((0, "fine levels"), (1, "coarse levels")):
+    d = np.loadtxt(f"/tmp/pool_stamps.pass{ps}", dtype=np.int64)
+    d = d[d[:, 1] > 0]
+    t0 = d[:, 1].min()
+    st, ls, lp, en = [(d[:, i] - t0) / 100.0 for i in (1, 2, 3, 4)]
+    ls = np.where(d[:, 2] > 0, ls, st)
+    n = d[:, 5]
+    print(f"{which} {name}: {len(d)} workgroups, span {en.max():.1f} us; ROIs/tile mean {n.mean():.2f} max {n.max()} zero {np.mean(n == 0):.2f}")
+    print(f"  start p50 {np.median(st):.1f} p90 {np.percentile(st, 90):.1f} max {st.max():.1f}")
+    for nm, a, b in (("scan", st, ls), ("rois", ls, lp), ("write", lp, en), ("total", st, en)):
+        v = b - a
+        print(f"  {nm:6s}: mean {v.mean():.2f} p50 {np.median(v):.2f} p90 {np.percentile(v, 90):.2f} max {v.max():.2f} us")
+    for k in (0, 1, 2, 4, 8):
+        m = n == k
+        if m.any():
+            print(f"  tiles with {k} ROIs: {m.sum()}, total mean {(en - st)[m].mean():.2f} us, rois-phase mean {(lp - ls)[m].mean():.2f}")

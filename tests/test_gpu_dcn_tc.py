@@ -156,6 +156,15 @@ def test_bwd_channel_split(csplit):
         check(case, TOL[torch.float16])
 
 
+@pytest.mark.parametrize("pch", [4, 8, 24])
+def test_bwd_weight_position_chunks(pch):
+    """The weight gradient splits the positions over `pch` waves per (tap, channel tile); L = 13*17 = 221 is not
+    a multiple of the 16-position k-step (masked tail per image), Co = 96 leaves a ragged output-channel tile."""
+    case = make_case(19, 3, 128, 96, 13, 17)
+    with env(D2AMD_DCN_BWW_PCH=pch):
+        check(case, TOL[torch.float16], keys=["grad_weight", "grad_bias"])
+
+
 def test_bwd_large_co_k_pipeline():
     """Co = 512: the dcol MFMA loop runs 16 k-steps per wave half through its two-deep register pipeline."""
     case = make_case(15, 1, 64, 512, 9, 10)
