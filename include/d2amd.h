@@ -142,6 +142,29 @@ int d2amd_match_quality_matrix(const float* quality, int M, int N, const float* 
                                const int8_t* labels, int T, int allow_low_quality, int64_t* matches,
                                int8_t* match_labels, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- RPN / RetinaNet proposal selection in front of NMS, all images and feature levels in one call.
+ * Replaces proposal_generator/rpn.py:468-533 (_decode_proposals), modeling/box_regression.py:71-116
+ * (Box2BoxTransform.apply_deltas) and proposal_generator/proposal_utils.py:62-120 (per-level topk + gather,
+ * isfinite filter, Boxes.clip, Boxes.nonempty).
+ *   logits  [N, Atot] fp32 objectness of every anchor, levels concatenated (level l = columns
+ *           [sum(level_sizes[:l]), +level_sizes[l]));  deltas [N, Atot, 4];  anchors [Atot, 4] xyxy
+ *   level_sizes (host) [L];  image_hw (host) [N][2] = (height, width);  weights (host) [4] = Box2BoxTransform
+ *   weights (wx, wy, ww, wh);  scale_clamp = its clamp on dw / dh.
+ * Per (image, level) the min(level_sizes[l], pre_nms_topk) highest logits are selected (ties: lower anchor
+ * index first), decoded, clipped to the image; Ktot = sum of those counts.  Outputs, [N, Ktot] row-major
+ * with levels concatenated in order and scores descending inside a level:
+ *   boxes [N,Ktot,4], scores [N,Ktot], valid [N,Ktot] uint8 (finite and both sides > min_box_size after the
+ *   clip; invalid rows hold a zero box and score -inf), level [Ktot] int64, flags [1] int32 (bit 0: a
+ *   non-finite box or score was seen -- the reference raises FloatingPointError in training).
+ * Nothing synchronises with the host. */
+#define D2AMD_RPN_MAX_LEVELS 8
+size_t d2amd_rpn_select_workspace_bytes(int N, int Atot);
+int d2amd_rpn_select_proposals(const float* logits, const float* deltas, const float* anchors, int N, int Atot,
+                               const int* level_sizes, int L, const int* image_hw, int pre_nms_topk,
+                               float min_box_size, const float* weights, float scale_clamp, float* boxes_out,
+                               float* scores_out, uint8_t* valid_out, int64_t* level_out, int* flags_out,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- NMS.  One entry serves torchvision.ops.nms / batched_nms (detectron2/layers/nms.py:6,
  * 11-22) and torch.ops.detectron2.nms_rotated / batched_nms_rotated (vision.cpp:116,
  * nms_rotated.h:22-37, nms.py:96-147).

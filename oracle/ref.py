@@ -83,3 +83,52 @@ def py_matcher():
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+
+
+def _with_stubs(stubs, fn):
+    saved = {k: sys.modules.get(k) for k in stubs}
+    sys.modules.update(stubs)
+    try:
+        return fn()
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+def py_box_regression():
+    """detectron2/modeling/box_regression.py (Box2BoxTransform).  Its module-level imports of the loss helpers
+    (fvcore.nn, detectron2.layers.{ciou,diou}_loss), unused by apply_deltas / get_deltas, are stubbed."""
+    import torch
+
+    fv, fvnn = types.ModuleType("fvcore"), types.ModuleType("fvcore.nn")
+    fvnn.giou_loss = fvnn.smooth_l1_loss = lambda *a, **k: (_ for _ in ()).throw(NotImplementedError())
+    fv.nn = fvnn
+    pkg, layers, structs = (types.ModuleType(n) for n in ("detectron2", "detectron2.layers", "detectron2.structures"))
+    layers.cat = lambda ts, dim=0: torch.cat(ts, dim)
+    layers.ciou_loss = layers.diou_loss = fvnn.giou_loss
+    structs.Boxes = py_boxes().Boxes
+    pkg.layers, pkg.structures = layers, structs
+    stubs = {"fvcore": fv, "fvcore.nn": fvnn, "detectron2": pkg, "detectron2.layers": layers,
+             "detectron2.structures": structs}
+    return _with_stubs(stubs, lambda: _load_by_path("_d2ref_box_regression", "detectron2/modeling/box_regression.py"))
+
+
+def py_proposal_utils(batched_nms):
+    """detectron2/modeling/proposal_generator/proposal_utils.py (find_top_rpn_proposals) with
+    detectron2.layers.batched_nms = the given function (torchvision is not installed: the oracle's restatement
+    is passed in), cat / move_device_like as in layers/wrappers.py, Boxes / Instances from the reference files."""
+    import torch
+
+    pkg, layers, structs = (types.ModuleType(n) for n in ("detectron2", "detectron2.layers", "detectron2.structures"))
+    layers.batched_nms = batched_nms
+    layers.cat = lambda ts, dim=0: torch.cat(ts, dim)
+    layers.move_device_like = lambda src, dst: src.to(dst.device)
+    structs.Boxes = py_boxes().Boxes
+    structs.Instances = _load_by_path("_d2ref_instances", "detectron2/structures/instances.py").Instances
+    pkg.layers, pkg.structures = layers, structs
+    stubs = {"detectron2": pkg, "detectron2.layers": layers, "detectron2.structures": structs}
+    return _with_stubs(stubs, lambda: _load_by_path("_d2ref_proposal_utils",
+                                                    "detectron2/modeling/proposal_generator/proposal_utils.py"))

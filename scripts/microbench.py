@@ -64,6 +64,20 @@ def main():
 
     rec("pairwise_iou_rpn(16x268569)", timeit(lambda: pairwise_iou(w.gt[0], w.anchors)), alg["pairwise_iou_rpn"] / 2)
     rec("pairwise_iou_roi(16x1016)", timeit(lambda: pairwise_iou(w.gt[0], w.props[0])))
+    # fused IoU + Matcher (f3), batch NMS in one call and the fused RPN proposal path (f2)
+    from detectron2_amd.layers import batched_nms_images
+    from detectron2_amd.modeling import Matcher, find_top_rpn_proposals_fused
+    mt = Matcher([0.3, 0.7], [0, -1, 1], allow_low_quality_matches=True)
+    rec("match_boxes_rpn(16x268569,fused iou+matcher)", timeit(lambda: mt.match_boxes(w.gt[0], w.anchors)),
+        2 * 16 * 268569 + 9 * 268569)
+    rec("batched_nms_images(2x8819)", timeit(lambda: batched_nms_images(w.nms_in, 0.7)))
+    gen0 = torch.Generator().manual_seed(11)
+    sizes = [201600, 50400, 12600, 3150, 819]
+    A = [bench.make_boxes(gen0, a, 16, 512).to(dev) for a in sizes]
+    Lg = [(torch.randn(2, a, generator=gen0) + torch.arange(a) * 1e-7).to(dev) for a in sizes]
+    Dl = [(torch.randn(2, a, 4, generator=gen0) * 0.2).to(dev) for a in sizes]
+    rec("find_top_rpn_proposals_fused(2 img,268569 anchors,2000/1000)",
+        timeit(lambda: find_top_rpn_proposals_fused(A, Lg, Dl, [(800, 1344)] * 2, 0.7, 2000, 1000, 0.0, True), rep=10))
     for name, pooler, lists, grad in (("box7", w.box_pooler, w.box_lists, w.gbox),
                                       ("mask14", w.mask_pooler, w.mask_lists, w.gmask)):
         key = "roi_align_box" if name == "box7" else "roi_align_mask"

@@ -113,6 +113,40 @@ def main():
     m0, l0 = mt.Matcher([0.3, 0.7], [0, -1, 1], True)(torch.zeros(0, 7))
     d["empty_matches"], d["empty_labels"] = m0.numpy(), l0.numpy()
     np.savez_compressed(os.path.join(OUT, "matcher.npz"), **d)
+    # --- RPN proposals: Box2BoxTransform.apply_deltas + find_top_rpn_proposals (reference python) ---
+    import oracle
+    br = ref.py_box_regression()
+
+    def nms_stub(boxes, scores, idxs, thr):  # torchvision is not installed: the restatement stands in
+        return torch.from_numpy(oracle.batched_nms(boxes.numpy(), scores.numpy(), idxs.numpy(), thr))
+
+    pu = ref.py_proposal_utils(nms_stub)
+    N, sizes, topk = 2, (1200, 300, 75), 200
+    H, W = 160, 208
+    anchors, logits, deltas = [], [], []
+    for li, a_l in enumerate(sizes):
+        s0 = 16.0 * 2 ** li
+        c = rng.uniform(0, [W, H], (a_l, 2))
+        wh_ = s0 * np.exp(rng.uniform(-0.4, 0.4, (a_l, 2)))
+        anchors.append(np.concatenate([c - wh_ / 2, c + wh_ / 2], 1).astype(np.float32))
+        logits.append(rng.standard_normal((N, a_l)).astype(np.float32))
+        d = (rng.standard_normal((N, a_l, 4)) * [0.3, 0.3, 0.5, 0.5]).astype(np.float32)
+        d[0, :3, 2] = 9.0          # exercises the scale clamp
+        d[1, 5:9] = [[-30, 0, 0, 0], [0, 0, -8, -8], [40, 40, 0, 0], [0, 0, 0, 0]]  # clipped away / tiny boxes
+        deltas.append(d)
+    tr = br.Box2BoxTransform(weights=(1.0, 1.0, 1.0, 1.0))
+    props = [torch.stack([tr.apply_deltas(torch.from_numpy(d[i]), torch.from_numpy(a)) for i in range(N)])
+             for a, d in zip(anchors, deltas)]
+    res = pu.find_top_rpn_proposals(props, [torch.from_numpy(l) for l in logits], [(H, W)] * N, 0.7, topk, 300, 2.0, False)
+    d = dict(image_hw=np.array([H, W]), pre_nms_topk=np.array(topk), post_nms_topk=np.array(300),
+             nms_thresh=np.array(0.7), min_box_size=np.array(2.0))
+    for li in range(len(sizes)):
+        d[f"anchors{li}"], d[f"logits{li}"], d[f"deltas{li}"] = anchors[li], logits[li], deltas[li]
+        d[f"decoded{li}"] = props[li].numpy()
+    for i, r in enumerate(res):
+        d[f"boxes_img{i}"] = r.proposal_boxes.tensor.numpy()
+        d[f"scores_img{i}"] = r.objectness_logits.numpy()
+    np.savez_compressed(os.path.join(OUT, "rpn_proposals.npz"), **d)
     print("golden vectors written to", OUT)
 
 

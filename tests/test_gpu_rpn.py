@@ -1,0 +1,102 @@
+"""GPU parity of the fused RPN proposal selection (detectron2_amd/csrc/rpn.hip + modeling/proposal_utils.py,
+SURVEY 8(f) row 2) against the reference's functions (tests/golden/rpn_proposals.npz) and the oracle:
+selection indices and validity exact (distinct logits), decoded boxes to the rounding of exp()
+(rtol 2e-6 / atol 2e-4 px), the NMS + top-k part exact on the device's own decoded boxes."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import rpn as orpn
+from detectron2_amd.modeling import find_top_rpn_proposals_fused, rpn_select_proposals
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "rpn_proposals.npz"))
+    anchors = [g[f"anchors{l}"] for l in range(3)]
+    logits = [g[f"logits{l}"] for l in range(3)]
+    deltas = [g[f"deltas{l}"] for l in range(3)]
+    n = logits[0].shape[0]
+    hw = [tuple(int(v) for v in g["image_hw"])] * n
+    return g, anchors, logits, deltas, hw
+
+
+def _dev(xs):
+    return [torch.from_numpy(x).to(DEV) for x in xs]
+
+
+def test_rpn_select_matches_oracle_and_reference_decode(golden_dir):
+    g, anchors, logits, deltas, hw = _golden(golden_dir)
+    topk, minsz = int(g["pre_nms_topk"]), float(g["min_box_size"])
+    boxes, scores, valid, lv, flags = rpn_select_proposals(_dev(anchors), _dev(logits), _dev(deltas), hw, topk, minsz)
+    exp = orpn.select(anchors, logits, deltas, hw, topk, minsz)
+    assert int(flags.item()) == 0
+    for i, (eb, es, ev, el, eidx) in enumerate(exp):
+        assert np.array_equal(lv.cpu().numpy(), el)
+        assert np.array_equal(valid[i].cpu().numpy(), ev)
+        gs = scores[i].cpu().numpy()
+        assert np.array_equal(gs[ev], es[ev]) and np.all(np.isneginf(gs[~ev]))
+        gb = boxes[i].cpu().numpy()
+        assert np.allclose(gb[ev], eb[ev], rtol=2e-6, atol=2e-4)
+        assert np.all(gb[~ev] == 0)
+        # the reference's own decode of the selected anchors, clipped
+        off = 0
+        for l in range(3):
+            k = min(anchors[l].shape[0], topk)
+            ref = g[f"decoded{l}"][i][eidx[off:off + k]].copy()
+            ref[:, 0::2] = np.clip(ref[:, 0::2], 0, hw[i][1]); ref[:, 1::2] = np.clip(ref[:, 1::2], 0, hw[i][0])
+            m = ev[off:off + k]
+            assert np.allclose(gb[off:off + k][m], ref[m], rtol=2e-6, atol=2e-4)
+            off += k
+
+
+def test_find_top_rpn_proposals_fused_matches_reference(golden_dir):
+    g, anchors, logits, deltas, hw = _golden(golden_dir)
+    res = find_top_rpn_proposals_fused(_dev(anchors), _dev(logits), _dev(deltas), hw, float(g["nms_thresh"]),
+                                       int(g["pre_nms_topk"]), int(g["post_nms_topk"]), float(g["min_box_size"]), False)
+    for i, r in enumerate(res):
+        assert np.array_equal(r.objectness_logits.cpu().numpy(), g[f"scores_img{i}"])   # same proposals, same order
+        assert np.allclose(r.proposal_boxes.tensor.cpu().numpy(), g[f"boxes_img{i}"], rtol=2e-6, atol=2e-4)
+
+
+def test_rpn_full_size_pipeline_and_nonfinite():
+    """BASELINE configs[1] shapes: 5 FPN levels, 268,569 anchors x 2 images, pre/post top-k 2000/1000.  The NMS
+    part is exact given the device's decoded boxes; NaN deltas raise in training and are dropped otherwise."""
+    torch.manual_seed(3)
+    sizes = [201600, 50400, 12600, 3150, 819]
+    H, W = 800, 1344
+    anchors, logits, deltas = [], [], []
+    for l, a in enumerate(sizes):
+        s = 32.0 * 2 ** l
+        c = torch.rand(a, 2) * torch.tensor([W, H])
+        wh = s * torch.exp(torch.rand(a, 2) - 0.5)
+        anchors.append(torch.cat([c - wh / 2, c + wh / 2], 1))
+        logits.append(torch.randn(2, a) + torch.arange(a) * 1e-7)
+        deltas.append(torch.randn(2, a, 4) * torch.tensor([0.2, 0.2, 0.3, 0.3]))
+    hw = [(H, W)] * 2
+    A, Lg, D = [t.to(DEV) for t in anchors], [t.to(DEV) for t in logits], [t.to(DEV) for t in deltas]
+    boxes, scores, valid, lv, flags = rpn_select_proposals(A, Lg, D, hw, 2000, 0.0)
+    assert boxes.shape == (2, 8819, 4) and int(flags.item()) == 0
+    exp = orpn.select([a.numpy() for a in anchors], [t.numpy() for t in logits], [t.numpy() for t in deltas], hw, 2000, 0.0)
+    for i in range(2):
+        assert np.array_equal(valid[i].cpu().numpy(), exp[i][2])
+        assert np.array_equal(scores[i].cpu().numpy()[exp[i][2]], exp[i][1][exp[i][2]])
+        assert np.allclose(boxes[i].cpu().numpy()[exp[i][2]], exp[i][0][exp[i][2]], rtol=2e-6, atol=5e-4)
+    res = find_top_rpn_proposals_fused(A, Lg, D, hw, 0.7, 2000, 1000, 0.0, True)
+    sel = [(boxes[i].cpu().numpy(), scores[i].cpu().numpy(), valid[i].cpu().numpy(), lv.cpu().numpy(), None)
+           for i in range(2)]
+    ref = orpn.find_top_rpn_proposals(None, None, None, hw, 0.7, 2000, 1000, 0.0, selected=sel)
+    for r, (eb, es) in zip(res, ref):
+        assert len(r) == len(es) <= 1000
+        assert np.array_equal(r.objectness_logits.cpu().numpy(), es)
+        assert np.array_equal(r.proposal_boxes.tensor.cpu().numpy(), eb)
+    # non-finite predictions
+    D[0][1, :4000, 2] = float("nan")
+    with pytest.raises(FloatingPointError):
+        find_top_rpn_proposals_fused(A, Lg, D, hw, 0.7, 2000, 1000, 0.0, True)
+    res = find_top_rpn_proposals_fused(A, Lg, D, hw, 0.7, 2000, 1000, 0.0, False)
+    assert torch.isfinite(res[1].proposal_boxes.tensor).all() and len(res[1]) > 0

@@ -323,3 +323,31 @@ def test_matcher_restatement_matches_reference_class(golden_dir):
     assert np.array_equal(m, g["empty_matches"]) and np.array_equal(l, g["empty_labels"])
     # and the restated IoU feeds it bit-identically
     assert np.array_equal(oracle.pairwise_iou(g["gt"], g["boxes"]), g["quality"])
+
+
+# ---------------------------------------------------------------------------------------- RPN proposals
+def _rpn_case(g):
+    L = 3
+    anchors = [g[f"anchors{l}"] for l in range(L)]
+    logits = [g[f"logits{l}"] for l in range(L)]
+    deltas = [g[f"deltas{l}"] for l in range(L)]
+    n = logits[0].shape[0]
+    hw = [tuple(int(v) for v in g["image_hw"])] * n
+    return anchors, logits, deltas, hw
+
+
+def test_rpn_restatement_matches_reference_functions(golden_dir):
+    """oracle/rpn.py vs the reference's Box2BoxTransform.apply_deltas and find_top_rpn_proposals
+    (tests/golden/rpn_proposals.npz): decode to ~1 ulp of exp(), selection / NMS result identical."""
+    from oracle import rpn
+    g = np.load(os.path.join(golden_dir, "rpn_proposals.npz"))
+    anchors, logits, deltas, hw = _rpn_case(g)
+    for l in range(3):
+        for i in range(logits[0].shape[0]):
+            got = rpn.apply_deltas(deltas[l][i], anchors[l])
+            assert np.allclose(got, g[f"decoded{l}"][i], rtol=2e-6, atol=2e-4)
+    res = rpn.find_top_rpn_proposals(anchors, logits, deltas, hw, float(g["nms_thresh"]), int(g["pre_nms_topk"]),
+                                     int(g["post_nms_topk"]), float(g["min_box_size"]))
+    for i, (b, s) in enumerate(res):
+        assert np.array_equal(s, g[f"scores_img{i}"])          # same proposals, same order
+        assert np.allclose(b, g[f"boxes_img{i}"], rtol=2e-6, atol=2e-4)
