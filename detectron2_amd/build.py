@@ -30,6 +30,7 @@ SOURCES = {
     "deform_conv_tc.hip": [],
     "matcher.hip": ["-ffp-contract=off"],
     "rpn.hip": ["-ffp-contract=off"],
+    "mask_targets.hip": ["-ffp-contract=off"],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall",
           "-Wno-unused-function", "-Wno-unused-variable", "-fhip-fp32-correctly-rounded-divide-sqrt"]

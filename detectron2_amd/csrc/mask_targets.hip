@@ -1,0 +1,73 @@
+// Mask-head training targets: BitMasks.crop_and_resize in one kernel.
+//   replaces  detectron2/structures/masks.py:193-224: bit_masks.to(float32) [an fp32 copy of every full
+//             resolution mask: 4 B per pixel], ROIAlign((M, M), 1.0, 0, aligned=True) on it, `>= 0.5`.
+// One thread per output bin reads the bool / uint8 mask directly (1 B per tap) and evaluates the bin's
+// adaptive sampling grid SEQUENTIALLY in torchvision's CPU order (sum over iy, ix of the 4-tap bilinear
+// value, then / count): the thresholded result is bit-identical to the reference pipeline, including bins
+// whose mean is exactly 0.5.  Roofline: HBM-light (the G boxes' footprints of the masks are read once from
+// L2); the point of the kernel is the 4 B/px fp32 copy it does not make.
+// Compiled with -ffp-contract=off.
+#pragma clang fp contract(off)
+#include "common.h"
+
+namespace d2amd {
+
+// ROIAlignRotated_cpu.cpp:64-125 / torchvision roi_align pre_calc: value of the bilinear sample at (y, x)
+__device__ __forceinline__ float crop_sample(const uint8_t* __restrict__ m, int H, int W, float y, float x) {
+  if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) return 0.f;  // w = 0: contributes exactly 0
+  if (y < 0.f) y = 0.f;
+  if (x < 0.f) x = 0.f;
+  int y_low = (int)y, x_low = (int)x, y_high, x_high;
+  if (y_low >= H - 1) { y_high = y_low = H - 1; y = (float)y_low; } else { y_high = y_low + 1; }
+  if (x_low >= W - 1) { x_high = x_low = W - 1; x = (float)x_low; } else { x_high = x_low + 1; }
+  const float ly = y - (float)y_low, lx = x - (float)x_low;
+  const float hy = (float)(1. - (double)ly), hx = (float)(1. - (double)lx);
+  const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+  const float v1 = m[(long)y_low * W + x_low] ? 1.f : 0.f, v2 = m[(long)y_low * W + x_high] ? 1.f : 0.f;
+  const float v3 = m[(long)y_high * W + x_low] ? 1.f : 0.f, v4 = m[(long)y_high * W + x_high] ? 1.f : 0.f;
+  return w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+}
+
+__global__ __launch_bounds__(64) void bitmask_crop_kernel(const uint8_t* __restrict__ masks,
+                                                         const float* __restrict__ boxes, int G, int H, int W, int M,
+                                                         uint8_t* __restrict__ out) {
+  const int g = blockIdx.y;
+  const int bin = blockIdx.x * 64 + threadIdx.x;
+  if (bin >= M * M) return;
+  const int ph = bin / M, pw = bin - ph * M;
+  const float* b = boxes + (long)g * 4;
+  // roi_align.py:21-35 with aligned = True, spatial_scale = 1, sampling_ratio = 0
+  const float roi_start_w = b[0] * 1.0f - 0.5f, roi_start_h = b[1] * 1.0f - 0.5f;
+  const float roi_end_w = b[2] * 1.0f - 0.5f, roi_end_h = b[3] * 1.0f - 0.5f;
+  const float roi_width = roi_end_w - roi_start_w, roi_height = roi_end_h - roi_start_h;
+  const float bin_size_h = roi_height / (float)M, bin_size_w = roi_width / (float)M;
+  const int grid_h = (int)ceilf(roi_height / (float)M), grid_w = (int)ceilf(roi_width / (float)M);
+  const float count = (float)max(grid_h * grid_w, 1);
+  const uint8_t* m = masks + (long)g * H * W;
+  float v = 0.f;
+  for (int iy = 0; iy < grid_h; iy++) {
+    const float yy = roi_start_h + (float)ph * bin_size_h + ((float)iy + .5f) * bin_size_h / (float)grid_h;
+    for (int ix = 0; ix < grid_w; ix++) {
+      const float xx = roi_start_w + (float)pw * bin_size_w + ((float)ix + .5f) * bin_size_w / (float)grid_w;
+      v += crop_sample(m, H, W, yy, xx);
+    }
+  }
+  v /= count;
+  out[(long)g * M * M + bin] = v >= 0.5f ? 1 : 0;
+}
+
+}  // namespace d2amd
+
+using namespace d2amd;
+
+extern "C" int d2amd_bitmask_crop_and_resize(const uint8_t* masks, const float* boxes, int G, int H, int W,
+                                             int mask_size, uint8_t* out, void* stream) {
+  D2_CHECK_ARG(G >= 0 && H >= 0 && W >= 0 && mask_size > 0, "bitmask_crop_and_resize: bad shape");
+  if (G == 0) return D2AMD_OK;
+  D2_CHECK_ARG(H > 0 && W > 0 && masks && boxes && out, "bitmask_crop_and_resize: null pointer / empty mask");
+  D2_CHECK_ARG(G <= 65535, "bitmask_crop_and_resize: too many masks (%d)", G);
+  dim3 grid(cdiv((long)mask_size * mask_size, 64), G);
+  hipLaunchKernelGGL(bitmask_crop_kernel, grid, dim3(64), 0, (hipStream_t)stream, masks, boxes, G, H, W, mask_size, out);
+  D2_LAUNCH_OK();
+  return D2AMD_OK;
+}

@@ -1,0 +1,48 @@
+"""BitMasks -- the part of detectron2/structures/masks.py:88-224 on the hot path: the (G, H, W) bool holder
+and `crop_and_resize`, the Mask R-CNN training-target rasteriser.  One fused HIP kernel
+(d2amd_bitmask_crop_and_resize) instead of `to(float32)` + ROIAlign + `>= 0.5`."""
+import torch
+
+from .. import _C
+
+
+class BitMasks:
+    def __init__(self, tensor):
+        if isinstance(tensor, torch.Tensor):
+            tensor = tensor.to(torch.bool)
+        else:
+            tensor = torch.as_tensor(tensor, dtype=torch.bool, device=torch.device("cpu"))
+        assert tensor.dim() == 3, tensor.size()
+        self.image_size = tensor.shape[1:]
+        self.tensor = tensor
+
+    def to(self, *args, **kwargs):
+        return BitMasks(self.tensor.to(*args, **kwargs))
+
+    @property
+    def device(self):
+        return self.tensor.device
+
+    def __len__(self):
+        return self.tensor.shape[0]
+
+    def __getitem__(self, item):
+        if isinstance(item, int):
+            return BitMasks(self.tensor[item].unsqueeze(0))
+        m = self.tensor[item]
+        assert m.dim() == 3, "Indexing on BitMasks with {} returns a tensor with shape {}!".format(item, m.shape)
+        return BitMasks(m)
+
+    def crop_and_resize(self, boxes: torch.Tensor, mask_size: int) -> torch.Tensor:
+        """Crop each bitmask by its box and resize to (mask_size, mask_size) -> bool (N, mask_size, mask_size)."""
+        assert len(boxes) == len(self), "{} != {}".format(len(boxes), len(self))
+        _C.require_gpu(self.tensor, op="BitMasks.crop_and_resize")
+        m = self.tensor.contiguous().view(torch.uint8)
+        b = boxes.detach().to(device=m.device, dtype=torch.float32).contiguous()
+        g, h, w = m.shape
+        out = torch.empty((g, mask_size, mask_size), dtype=torch.uint8, device=m.device)
+        if g:
+            with _C.on_device(m.device):
+                _C.check(_C.lib().d2amd_bitmask_crop_and_resize(_C.ptr(m), _C.ptr(b), g, h, w, int(mask_size),
+                                                                _C.ptr(out), _C.stream()))
+        return out.view(torch.bool)

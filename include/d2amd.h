@@ -190,6 +190,14 @@ int d2amd_nms(const float* boxes, const float* scores, const int64_t* idxs, int6
 int d2amd_paste_masks(const void* masks, const float* boxes, int n, int mh, int mw, int img_h,
                       int img_w, float threshold, uint8_t* out, int mask_dtype, void* stream);
 
+/* ---- BitMasks.crop_and_resize (detectron2/structures/masks.py:193-224): the Mask R-CNN training targets.
+ * masks [G,H,W] uint8 / bool storage (non-zero = inside), boxes [G,4] fp32 xyxy (box g crops mask g) ->
+ * out [G,mask_size,mask_size] uint8 0/1 = (ROIAlign((M,M), 1.0, 0, aligned=True)(mask as fp32) >= 0.5),
+ * without the fp32 copy of the full-resolution masks; sampling and summation order are torchvision's CPU
+ * roi_align, so the thresholded result is bit-identical to the reference pipeline. */
+int d2amd_bitmask_crop_and_resize(const uint8_t* masks, const float* boxes, int G, int H, int W,
+                                  int mask_size, uint8_t* out, void* stream);
+
 /* ---- deformable convolution v1 / v2.  Replaces detectron2._C.deform_conv_forward,
  * deform_conv_backward_input, deform_conv_backward_filter, modulated_deform_conv_forward,
  * modulated_deform_conv_backward (vision.cpp:85-102; csrc/deformable/deform_conv.h:116-375).
