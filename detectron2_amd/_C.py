@@ -124,13 +124,22 @@ def ptr(t):
 _NULL_CTX = contextlib.nullcontext()
 
 
+_get_device = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def on_device(device):
     """Context that makes `device` current for a C-ABI call (kernels launch on the current device).
     One process per GPU is the deployment model, so this is normally a no-op object."""
-    if device.index is None or device.index == torch.cuda.current_device():
+    if device.index is None or device.index == _get_device():
         return _NULL_CTX
     return torch.cuda.device(device)
 
 
 def stream():
+    """hipStream_t of torch's current stream on the current device, as a void*.  Uses the raw C accessor:
+    torch.cuda.current_stream() builds a Stream object and costs ~15 us per call, more than some of the
+    kernels launched on it."""
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(_get_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -4,9 +4,25 @@ import torch
 
 
 def disable_torch_compiler(func):
-    if hasattr(torch, "compiler") and hasattr(torch.compiler, "disable"):
-        return torch.compiler.disable(func)
-    return func
+    """Keep `func` opaque to torch.compile (reference: layers/wrappers.py:51-62).  torch.compiler.disable wraps
+    every call in a dynamo frame guard (~20 us, more than some of the kernels behind these ops), so the wrapper
+    is only entered while a compile is actually tracing; eager calls go straight to `func`."""
+    if not (hasattr(torch, "compiler") and hasattr(torch.compiler, "disable")):
+        return func
+    disabled = torch.compiler.disable(func)
+    is_compiling = getattr(torch.compiler, "is_compiling", None)
+    if is_compiling is None:
+        return disabled
+
+    import functools
+
+    @functools.wraps(func)
+    def wrapper(*args, **kwargs):
+        if is_compiling():
+            return disabled(*args, **kwargs)
+        return func(*args, **kwargs)
+
+    return wrapper
 
 
 class _NewEmptyTensorOp(torch.autograd.Function):
