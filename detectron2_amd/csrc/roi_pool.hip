@@ -28,6 +28,10 @@ namespace d2amd {
 
 constexpr int POOL_MAX_LEVELS = 8;
 constexpr int POOL_THREADS = 256;
+#ifndef D2AMD_FWD_U
+#define D2AMD_FWD_U 8
+#endif
+constexpr int FWD_U = D2AMD_FWD_U;
 
 struct PoolLevels {
   const void* data[POOL_MAX_LEVELS];  // forward: feature maps; backward: grad_input (written)
@@ -96,15 +100,16 @@ __device__ __forceinline__ raw16 pack16(const float (&f)[8], T) {
 
 // ------------------------------------------------------------------------------------------------
 // FORWARD, NHWC.  grid = (K, nsplit); VEC = 16 B of channels per lane (or 1 for odd C / alignment)
-template <typename T, int VEC>
-__global__ __launch_bounds__(POOL_THREADS) void pool_fwd_nhwc_kernel(PoolLevels L, const float* __restrict__ rois,
-                                                                    T* __restrict__ out, int nsplit) {
+template <typename T, int VEC, int NTHR>
+__global__ __launch_bounds__(NTHR) void pool_fwd_nhwc_kernel(PoolLevels L, const float* __restrict__ rois,
+                                                            T* __restrict__ out, int nsplit) {
   __shared__ SepShared S;
   __shared__ int s_level;
   const int k = blockIdx.x, tid = threadIdx.x;
-  if (tid == 0) s_level = assign_level(rois + (long)k * 5 + 1, L);
-  __syncthreads();
-  const int lvl = __builtin_amdgcn_readfirstlane(s_level);
+  unsigned long long* wst = (L.wgstamps && tid == 0) ? L.wgstamps + 5 * ((size_t)blockIdx.y * gridDim.x + k) : nullptr;
+  if (wst) wst[0] = wall_clock64();
+  // every thread evaluates the (wave-uniform) level itself: one broadcast load, no LDS round trip / barrier
+  const int lvl = __builtin_amdgcn_readfirstlane(assign_level(rois + (long)k * 5 + 1, L));
   const int C = L.C, PH = L.PH, PW = L.PW, bins = PH * PW;
   const int per = (bins + nsplit - 1) / nsplit;
   const int b_lo = blockIdx.y * per, b_hi = min(bins, b_lo + per);
@@ -112,7 +117,7 @@ __global__ __launch_bounds__(POOL_THREADS) void pool_fwd_nhwc_kernel(PoolLevels 
   const int CG = C / VEC;
   T* outk = out + (long)k * bins * C;
   if (lvl < 0) {  // reference: row of the zero-initialised output that no level fills
-    for (int e = tid; e < (b_hi - b_lo) * C; e += POOL_THREADS) outk[(long)b_lo * C + e] = from_f32<T>(0.f);
+    for (int e = tid; e < (b_hi - b_lo) * C; e += NTHR) outk[(long)b_lo * C + e] = from_f32<T>(0.f);
     return;
   }
   const int H = L.H[lvl], W = L.W[lvl];
@@ -125,8 +130,9 @@ __global__ __launch_bounds__(POOL_THREADS) void pool_fwd_nhwc_kernel(PoolLevels 
   }
   const T* inb = in + (long)S.batch * H * W * C;
   const float inv = S.inv_count;
-  constexpr int U = 8;  // independent loads in flight per lane
-  for (int e = tid; e < (b_hi - b_lo) * CG; e += POOL_THREADS) {
+  constexpr int U = FWD_U;  // independent loads in flight per lane
+  if (wst) { wst[1] = wall_clock64(); wst[4] = (unsigned long long)lvl; }
+  for (int e = tid; e < (b_hi - b_lo) * CG; e += NTHR) {
     const int bl = e / CG, q = e - bl * CG;
     const int b = b_lo + bl;
     const int ph = b / PW, pw = b - ph * PW;
@@ -179,6 +185,7 @@ __global__ __launch_bounds__(POOL_THREADS) void pool_fwd_nhwc_kernel(PoolLevels 
       o[0] = from_f32<T>(acc[0]);
     }
   }
+  if (wst) { wst[2] = wall_clock64(); wst[3] = wst[2]; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -739,16 +746,50 @@ static int pool_fwd_impl(const d2amd_pooler_params* p, const void* const* inputs
   if (p->layout == D2AMD_NHWC) {
     const bool vec = (p->C % VEC == 0) && all_aligned16(inputs, p->num_levels, output);
     const int cg = vec ? p->C / VEC : p->C;
-    const int passes = cdiv((long)bins * cg, POOL_THREADS);
-    int nsplit = K > 0 ? 4096 / K : 1;
+    // workgroup shape (profiles/r01/v5_pool_fwd_sweep.txt): the kernel is insensitive to it within +-10 % --
+    // the per-workgroup prologue (ROI load, level, table build: ~4 us) and the tap loads trade off -- because
+    // the bound is the ~5.5 TB/s of tap bytes requested through L1 (each pixel of a bin's footprint is
+    // re-requested by the neighbouring bins); 512 threads and ~1,000 workgroups measured best
+    int nthr = vec ? 512 : 256;
+    { const char* e = getenv("D2AMD_FWD_THREADS"); if (e && (atoi(e) == 256 || atoi(e) == 512 || atoi(e) == 1024)) nthr = atoi(e); }
+    if (!vec) nthr = 256;
+    const int passes = cdiv((long)bins * cg, nthr);
+    int nsplit = K > 0 ? 1024 / K : 1;
+    { const char* e = getenv("D2AMD_FWD_NSPLIT"); if (e && atoi(e) > 0) nsplit = atoi(e); }  // profiling switch
     nsplit = nsplit < 1 ? 1 : (nsplit > passes ? passes : nsplit);
     if (nsplit > bins) nsplit = bins;
     D2_CHECK_ARG(nsplit <= 65535, "roi_pooler_forward: internal split too large");
     dim3 grid(K, nsplit);
-    if (vec)
-      hipLaunchKernelGGL((pool_fwd_nhwc_kernel<T, VEC>), grid, dim3(POOL_THREADS), 0, s, L, rois, (T*)output, nsplit);
+    PoolLevels Lf = L;
+    const char* stamp_path = getenv("D2AMD_POOL_STAMPS");  // profiling only: per-workgroup timeline dump
+    const long nwg = (long)K * nsplit;
+    if (stamp_path) {
+      D2_HIP_OK(hipMalloc(&Lf.wgstamps, (size_t)nwg * 5 * 8));
+      D2_HIP_OK(hipMemsetAsync(Lf.wgstamps, 0, (size_t)nwg * 5 * 8, s));
+    }
+    if (vec && nthr == 1024)
+      hipLaunchKernelGGL((pool_fwd_nhwc_kernel<T, VEC, 1024>), grid, dim3(1024), 0, s, Lf, rois, (T*)output, nsplit);
+    else if (vec && nthr == 512)
+      hipLaunchKernelGGL((pool_fwd_nhwc_kernel<T, VEC, 512>), grid, dim3(512), 0, s, Lf, rois, (T*)output, nsplit);
+    else if (vec)
+      hipLaunchKernelGGL((pool_fwd_nhwc_kernel<T, VEC, 256>), grid, dim3(256), 0, s, Lf, rois, (T*)output, nsplit);
     else
-      hipLaunchKernelGGL((pool_fwd_nhwc_kernel<T, 1>), grid, dim3(POOL_THREADS), 0, s, L, rois, (T*)output, nsplit);
+      hipLaunchKernelGGL((pool_fwd_nhwc_kernel<T, 1, 256>), grid, dim3(256), 0, s, Lf, rois, (T*)output, nsplit);
+    if (stamp_path) {
+      D2_HIP_OK(hipStreamSynchronize(s));
+      unsigned long long* h = (unsigned long long*)malloc((size_t)nwg * 5 * 8);
+      D2_HIP_OK(hipMemcpy(h, Lf.wgstamps, (size_t)nwg * 5 * 8, hipMemcpyDeviceToHost));
+      char fn[512];
+      snprintf(fn, sizeof(fn), "%s.fwd", stamp_path);
+      FILE* f = fopen(fn, "w");
+      if (f) {
+        for (long i = 0; i < nwg; i++)
+          fprintf(f, "%ld %llu %llu %llu %llu %llu\n", i, h[5 * i], h[5 * i + 1], h[5 * i + 2], h[5 * i + 3], h[5 * i + 4]);
+        fclose(f);
+      }
+      free(h);
+      (void)hipFree(Lf.wgstamps);
+    }
   } else {
     int cslab = p->C;
     while (cslab > 16 && (long)K * cdiv(p->C, cslab) < 2048 && cslab % 2 == 0) cslab /= 2;

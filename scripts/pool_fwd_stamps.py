@@ -1,0 +1,28 @@
+import os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+which = sys.argv[1] if len(sys.argv) > 1 else "box"
+w = bench.Workload(torch.device("cuda", 0), torch.bfloat16, "nhwc")
+pooler, lists = (w.box_pooler, w.box_lists) if which == "box" else (w.mask_pooler, w.mask_lists)
+for _ in range(3):
+    pooler([f.detach() for f in w.feats], lists)
+torch.cuda.synchronize()
+os.environ["D2AMD_POOL_STAMPS"] = "/tmp/pool_stamps"
+pooler([f.detach() for f in w.feats], lists)
+torch.cuda.synchronize()
+os.environ.pop("D2AMD_POOL_STAMPS")
+d = np.loadtxt("/tmp/pool_stamps.fwd", dtype=np.int64)
+d = d[d[:, 1] > 0]
+t0 = d[:, 1].min()
+st, tb, en = [(d[:, i] - t0) / 100.0 for i in (1, 2, 3)]
+ok = d[:, 2] > 0
+print(f"{which} fwd: {len(d)} workgroups, span {en[ok].max():.1f} us; start p50 {np.median(st):.1f} p90 {np.percentile(st,90):.1f} max {st.max():.1f}")
+for nm, a, b in (("tables", st, tb), ("bins", tb, en), ("total", st, en)):
+    v = (b - a)[ok]
+    print(f"  {nm:7s}: mean {v.mean():.2f} p50 {np.median(v):.2f} p90 {np.percentile(v, 90):.2f} max {v.max():.2f} us")
+for l in range(4):
+    m = ok & (d[:, 5] == l)
+    if m.any():
+        print(f"  level {l}: {m.sum()} wgs, bins mean {(en - tb)[m].mean():.2f} us")
