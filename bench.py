@@ -144,6 +144,19 @@ class Workload:
             .contiguous(memory_format=mf)
         self.esize = torch.empty((), dtype=dtype).element_size()
 
+    # algorithmic bytes of ONE tile-gather launch (fine = FPN levels with > 512 tiles: p2, p3 here): the levels'
+    # share of SURVEY 8(d)'s backward formula  s*K_l*C*R^2 (dY rows of the ROIs on those levels) + 2*s*N*C*H_l*W_l
+    def alg_bytes_bwd_kernel(self, which, fine):
+        s = self.esize
+        counts, R = (self.box_level_counts[0], 7) if which == "box" else (self.box_level_counts[1], 14)
+        tot = 0
+        for l, (h, w) in enumerate(FEAT_HW):
+            tiles = ((h + 7) // 8) * ((w + 7) // 8) * self.n_img
+            if (tiles > 512) != fine:
+                continue
+            tot += s * counts[l] * C * R * R + 2 * s * self.n_img * C * h * w
+        return tot
+
     # algorithmic (compulsory) bytes per op, SURVEY.md 8(d)
     def alg_bytes(self):
         s = self.esize
@@ -301,10 +314,25 @@ def main():
         step(w)
     sw = Stopwatch(dist, dev)
     dom_timer = Timer(only=ROOFLINE_OP)  # HIP events around the roofline op only, inside the timed region
+    # ... and HIP events on the launch stream right around its dominant KERNEL (the fine-level tile gather),
+    # recorded by the library itself (d2amd_timing_*): this is the duration rocprofv3 reports for the kernel
+    import ctypes
+    from detectron2_amd import _C as _dc
+    _dc.lib().d2amd_timing_enable(1)  # only the roofline kernel (fine levels, 7x7) inside the timed region
     sw.start()
     for _ in range(args.steps):
         step(w, dom_timer)
     elapsed = sw.stop()
+    ktimes = {}
+    def read_ktimes():
+        for kn in ("pool_bwd_fine_r7", "pool_bwd_coarse_r7", "pool_bwd_fine_r14", "pool_bwd_coarse_r14"):
+            tot, cnt = ctypes.c_double(0.0), ctypes.c_int(0)
+            _dc.check(_dc.lib().d2amd_timing_read(kn.encode(), ctypes.byref(tot), ctypes.byref(cnt)))
+            if cnt.value and kn not in ktimes:
+                ktimes[kn] = (tot.value / cnt.value, cnt.value)
+
+    read_ktimes()
+    _dc.lib().d2amd_timing_enable(15)  # the untimed breakdown pass times all four tile-gather launches
     # per-op breakdown: a separate, UNTIMED pass with events around every op (their host cost would otherwise
     # sit in the timed region: ~0.15 ms of a 0.9 ms step)
     timer = Timer()
@@ -312,6 +340,8 @@ def main():
     for _ in range(bsteps):
         step(w, timer)
     torch.cuda.synchronize()
+    read_ktimes()
+    _dc.lib().d2amd_timing_enable(0)
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
@@ -331,17 +361,33 @@ def main():
         for k in ops:
             ops[k]["launches_per_step"] = counts[k]
             ops[k]["ms_per_launch"] = round(ops[k]["ms_per_step"] / counts[k], 4)
-        # roofline op = the longest single launch among the HBM-bound ops (SURVEY 8d roofline classes); its time
-        # is the mean of the HIP-event pairs recorded around it INSIDE the timed region
+        # roofline: the dominant kernel = the fine-level tile-gather launch of the box-head backward
+        # (pool_bwd_nhwc_kernel<.., 1, 2, 8> in the rocprofv3 stats), timed by HIP events on its launch stream
+        # inside the timed region.  Its algorithmic bytes: SURVEY 8(d)'s backward formula restricted to the levels
+        # this launch writes (dY read once + 2 x grad_input of those levels).
         dom = ROOFLINE_OP
-        per_launch_bytes = alg[dom] / counts[dom]
         ops[dom]["ms_per_launch_timed_region"] = round(dom_ms_timed / counts[dom], 4)
-        achieved = per_launch_bytes / 1e9 / (dom_ms_timed / counts[dom] / 1e3)
-        roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, args.layout),
-                "alg_bytes_per_launch": int(per_launch_bytes), "ms_per_launch": round(dom_ms_timed / counts[dom], 4),
-                "timing": "HIP events on the launch stream around the op (kernel + its fork/join), mean over the "
-                          "timed steps"}
+        if args.layout == "nhwc" and "pool_bwd_fine_r7" in ktimes:
+            k_ms, k_n = ktimes["pool_bwd_fine_r7"]
+            kb = w.alg_bytes_bwd_kernel("box", fine=True)
+            roof = {"bound": "hbm", "kernel": "pool_bwd_nhwc_kernel (fine FPN levels) of roi_align_box_bwd",
+                    "achieved": round(kb / 1e9 / (k_ms / 1e3), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(kb / 1e9 / (k_ms / 1e3) / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, args.layout),
+                    "traffic_note": "PMC bytes are for the whole op (both tile-gather launches + records)",
+                    "alg_bytes_per_launch": int(kb), "ms_per_launch": round(k_ms, 4), "launches_timed": k_n,
+                    "timing": "HIP events recorded by the library on the kernel's launch stream right around the launch, "
+                              "mean over the timed steps",
+                    "op": {"name": dom, "alg_bytes": int(alg[dom] / counts[dom]),
+                           "ms_per_launch_events_around_op": round(dom_ms_timed / counts[dom], 4),
+                           "frac": round(alg[dom] / counts[dom] / 1e9 / (dom_ms_timed / counts[dom] / 1e3) / HBM_PEAK_GBS, 4)},
+                    "kernels_ms": {k: round(v[0], 4) for k, v in ktimes.items()}}
+        else:
+            per_launch_bytes = alg[dom] / counts[dom]
+            achieved = per_launch_bytes / 1e9 / (dom_ms_timed / counts[dom] / 1e3)
+            roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, args.layout),
+                    "alg_bytes_per_launch": int(per_launch_bytes), "ms_per_launch": round(dom_ms_timed / counts[dom], 4),
+                    "timing": "HIP events on the launch stream around the op (kernels + fork/join), mean over the timed steps"}
         gpu_ms = sum(v["ms_per_step"] for v in ops.values())
         out = {
             "metric": "img/s through the Mask R-CNN R50-FPN detection hot path (training ops), 1333x800 bs=2/GPU",

@@ -44,6 +44,8 @@ _SIGNATURES = {
     "d2amd_compiler_version": (ctypes.c_char_p, []),
     "d2amd_hip_version": (ctypes.c_char_p, []),
     "d2amd_last_error": (ctypes.c_char_p, []),
+    "d2amd_timing_enable": (None, [_i]),
+    "d2amd_timing_read": (_i, [ctypes.c_char_p, ctypes.POINTER(_d), ctypes.POINTER(_i)]),
     "d2amd_roi_align_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _vp]),
     "d2amd_roi_align_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _vp, _sz, _vp]),
     "d2amd_boxes_to_rois": (_i, [_vp, ctypes.POINTER(_i), _i, _i, _vp, _vp]),

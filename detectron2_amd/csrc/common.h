@@ -12,6 +12,9 @@ namespace d2amd {
 
 // ---- host-side error plumbing -----------------------------------------------------------
 void set_error(const char* fmt, ...);
+// kernel timing aid (api.hip): events on the launch stream around selected kernels when enabled
+bool timing_begin(const char* name, hipStream_t s);
+void timing_end(const char* name, hipStream_t s);
 
 #define D2_CHECK_ARG(cond, ...)          \
   do {                                   \

@@ -917,6 +917,9 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
       D2_HIP_OK(hipMemsetAsync(L.wgstamps, 0, (size_t)total * 5 * 8, ls));
     }
     const int g = pass == 0 ? fg : cgp, r = pass == 0 ? fr : cr;
+    const char* tname = pass == 0 ? (p->pooled_h <= 7 ? "pool_bwd_fine_r7" : "pool_bwd_fine_r14")
+                                  : (p->pooled_h <= 7 ? "pool_bwd_coarse_r7" : "pool_bwd_coarse_r14");
+    const bool timed = timing_begin(tname, ls);
     if (!vec) {
       if (g == 1) launch_bwd<T, 1, 1, 1>(L, rec, grad_output, nslab, total, ls, ids);
       else launch_bwd<T, 1, 2, 1>(L, rec, grad_output, nslab, total, ls, ids);
@@ -927,6 +930,7 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
     else if (g == 4 && r == 1) launch_bwd<T, VEC, 4, 1>(L, rec, grad_output, nslab, total, ls, ids);
     else { set_error("roi_pooler_backward: bad D2AMD_BWD_CFG %d", cfg); return D2AMD_EINVAL; }
     D2_LAUNCH_OK();
+    if (timed) timing_end(tname, ls);
     if (stamp_path) {
       D2_HIP_OK(hipStreamSynchronize(ls));
       unsigned long long* h = (unsigned long long*)malloc((size_t)total * 5 * 8);

@@ -44,6 +44,14 @@ const char* d2amd_compiler_version(void); /* "clang x.y.z" like get_compiler_ver
 const char* d2amd_hip_version(void);      /* "HIP x.y" like get_cuda_version() under WITH_HIP */
 const char* d2amd_last_error(void);       /* last error message of this thread (host) */
 
+/* ---- kernel timing aid (measurement only).  When enabled, HIP events are recorded on the LAUNCH stream right
+ * before / after the tile-gather backward kernels ("pool_bwd_fine_r7", "pool_bwd_coarse_r7", "..._r14": fine /
+ * coarse FPN levels, pooled size <= 7 / larger); the coarse launch runs on a library-owned side stream that
+ * events recorded by the caller cannot see.  d2amd_timing_read waits for the events and returns the summed
+ * duration and the number of launches since the last d2amd_timing_enable. */
+void d2amd_timing_enable(int mask); /* bit 0: pool_bwd_fine_r7, 1: pool_bwd_coarse_r7, 2: ..fine_r14, 3: ..coarse_r14; 0 = off */
+int d2amd_timing_read(const char* kernel, double* total_ms, int* launches);
+
 /* ---- ROIAlign (axis-aligned).  Replaces torchvision.ops.roi_align as called from
  * detectron2/layers/roi_align.py:58-65 (forward) and its autograd backward.
  * input  [N,C,H,W] `dtype`, `layout`; rois [K,5] fp32 (b, x1, y1, x2, y2);
