@@ -104,7 +104,8 @@ int dcn_tc_forward(const DcnShape& s, const TcPlan& pl, const void* x_nhwc, cons
 struct TcBwPlan {
   bool ok;
   int tiles_y, tiles_x, csplit;
-  size_t lds, wp_bytes;
+  int R, PHt, PWt, csplit_patch;  // LDS-patch variant: displacement margin (-1: all-atomics kernel), patch size
+  size_t lds, lds_patch, wp_bytes;
 };
 TcBwPlan dcn_tc_plan_bwd(const DcnShape& s, int dtype);
 template <typename T>

@@ -1050,6 +1050,264 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_tc_kernel(DcnShape s, BwA
   }
 }
 
+// ---- backward data with an LDS-resident dX patch and conflict-free ownership --------------------------------
+// EXPERIMENT, not the default (see dcn_tc_plan_bwd): measured slower than the all-atomics kernel above.
+// Same stage structure as dcn_bwd_data_tc_kernel, 32-channel chunks.  dX contributions are not sent to global
+// atomics one by one (the 0.75 lane-op/clk/CU floor that bounds that kernel) and not to LDS fp32 atomics either
+// (ds_add_f32 is slower still, 0.2 lane-op/clk/CU): they are accumulated in an fp32 PATCH of the input in LDS --
+// the pixels the 8x8 tile's taps can reach when displaced by up to R pixels -- with PLAIN read-modify-writes made
+// race free by ownership: wave w owns channels 8w..8w+7 of the chunk, and one of its instructions covers the four
+// corners of ONE sample x its 8 channels (four distinct pixels by construction); a wave's DS operations execute in
+// order, different waves touch different channels.  The order of the additions is fixed (position, tap ascending):
+// the patch part of dX is deterministic.  Samples displaced by more than R pixels fall back to global atomics.
+// After the 9 taps of a chunk the patch is flushed with one 128-B coalesced global atomic per touched pixel.
+struct BwEntryP {
+  uint32_t pix[4];
+  float w[4];
+  float lh, lw, m;
+  uint32_t flags;
+  int py, px;   // patch coordinates of corner 0
+  int pad[2];
+};
+static_assert(sizeof(BwEntryP) == 64, "BwEntryP layout");
+
+struct BwpArgs {
+  const void *x, *offset, *mask, *wp, *gout;
+  float *gx, *goff, *gmask;
+  int tiles_y, tiles_x, total, csplit, R, PHt, PWt;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void dcn_bwd_data_patch_kernel(DcnShape s, BwpArgs a) {
+  typedef Mma<T> M;
+  constexpr int CP = 36;  // floats per position row of the dcol tile
+  extern __shared__ __attribute__((aligned(16))) unsigned char bwp_smem[];
+  __shared__ __attribute__((aligned(16))) BwEntryP ent[64];
+  __shared__ __attribute__((aligned(16))) float Cs[64 * CP];
+  float* red = reinterpret_cast<float*>(bwp_smem);  // [K2][64][3]
+  float* patch = red + s.K2 * 64 * 3;               // [PHt * PWt][32]
+  const int npatch = a.PHt * a.PWt * 32;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int per_xcd = (a.total + 7) >> 3;
+  const int logical = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if (logical >= a.total) return;
+  const int cz = logical % a.csplit;
+  int tile = logical / a.csplit;
+  const int dgi = tile % s.DG; tile /= s.DG;
+  const int tx = tile % a.tiles_x; tile /= a.tiles_x;
+  const int ty = tile % a.tiles_y;
+  const int b = tile / a.tiles_y;
+  const int oy = ty * 8 * s.sh - s.ph - a.R, ox = tx * 8 * s.sw - s.pw - a.R;
+
+  for (int i = tid; i < s.K2 * 64 * 3 + npatch; i += 256) red[i] = 0.f;  // red and patch are contiguous
+
+  const T* offset = (const T*)a.offset;
+  const T* mask = (const T*)a.mask;
+  const char* xb = (const char*)a.x;
+  const T* gout = (const T*)a.gout;
+  const raw16* wp = (const raw16*)a.wp;
+  const int KS = s.Cog / 16, KH = KS / 2;
+  const int nt = wid & 1, khalf = wid >> 1;
+  const int nB = nt * 32 + (lane & 31);
+  const int hoB = ty * 8 + (nB >> 3), woB = tx * 8 + (nB & 7);
+  const bool validB = hoB < s.Ho && woB < s.Wo;
+  const long pB = ((long)b * s.Ho + hoB) * s.Wo + woB;
+  const uint32_t pixbytes = (uint32_t)s.C * (uint32_t)sizeof(T);
+  const int nE = tid >> 2;
+  const int hoE = ty * 8 + (nE >> 3), woE = tx * 8 + (nE & 7);
+  const bool validE = hoE < s.Ho && woE < s.Wo;
+  const int lE = hoE * s.Wo + woE;
+
+  const int nchunk = s.cpg >> 5;
+  const int c_lo = dgi * s.cpg + 32 * (int)((long)cz * nchunk / a.csplit);
+  const int c_hi = dgi * s.cpg + 32 * (int)((long)(cz + 1) * nchunk / a.csplit);
+  for (int cabs = c_lo; cabs < c_hi; cabs += 32) {
+    const int g = cabs / s.Cg, crel = cabs - g * s.Cg, c64 = crel >> 6, mt = (crel >> 5) & 1;
+    for (int tap = 0; tap < s.K2; tap++) {
+      // ---- (1) table of this tap (4 threads per position evaluate it, one writes)
+      {
+        BwEntryP e;
+#pragma unroll
+        for (int t = 0; t < 4; t++) { e.pix[t] = 0u; e.w[t] = 0.f; }
+        e.lh = e.lw = 0.f; e.m = 0.f; e.flags = 0u; e.py = e.px = -(1 << 20); e.pad[0] = e.pad[1] = 0;
+        if (validE) {
+          const int i = tap / s.kw, j = tap - i * s.kw;
+          const long obase = ((long)b * s.DG + dgi) * 2 * s.K2;
+          const float off_h = to_f32(offset[(obase + 2 * tap) * s.L + lE]);
+          const float off_w = to_f32(offset[(obase + 2 * tap + 1) * s.L + lE]);
+          e.m = mask ? to_f32(mask[(((long)b * s.DG + dgi) * s.K2 + tap) * s.L + lE]) : 1.f;
+          const float h_im = (float)(hoE * s.sh - s.ph + i * s.dh) + off_h;
+          const float w_im = (float)(woE * s.sw - s.pw + j * s.dw) + off_w;
+          if (h_im > -1.f && w_im > -1.f && h_im < (float)s.H && w_im < (float)s.W) {
+            const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+            const int h_high = h_low + 1, w_high = w_low + 1;
+            const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+            const float hh = 1.f - lh, hw = 1.f - lw;
+            e.lh = lh; e.lw = lw; e.flags = 16u;
+            e.py = h_low - oy; e.px = w_low - ox;
+            const long rowbase = (long)b * s.H;
+            if (h_low >= 0 && w_low >= 0) { e.pix[0] = (uint32_t)((rowbase + h_low) * s.W + w_low); e.w[0] = hh * hw; e.flags |= 1u; }
+            if (h_low >= 0 && w_high <= s.W - 1) { e.pix[1] = (uint32_t)((rowbase + h_low) * s.W + w_high); e.w[1] = hh * lw; e.flags |= 2u; }
+            if (h_high <= s.H - 1 && w_low >= 0) { e.pix[2] = (uint32_t)((rowbase + h_high) * s.W + w_low); e.w[2] = lh * hw; e.flags |= 4u; }
+            if (h_high <= s.H - 1 && w_high <= s.W - 1) { e.pix[3] = (uint32_t)((rowbase + h_high) * s.W + w_high); e.w[3] = lh * lw; e.flags |= 8u; }
+          }
+        }
+        if ((tid & 3) == 0) ent[nE] = e;
+      }
+      // ---- (2) dcol tile by MFMA: 32 channels x this wave's 32 positions, K = this wave half's share of Co
+      f32x16_t acc;
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[r] = 0.f;
+      {
+        const raw16* wsrc = wp + (((((size_t)g * s.K2 + tap) * (s.Cg >> 6) + c64) * 2 + mt) * KS) * 64 + lane;
+        const T* gsrc = gout + pB * s.Co + (long)g * s.Cog + (lane >> 5) * 8;
+        const raw16 zero = {0u, 0u, 0u, 0u};
+        constexpr int KB = 4;
+        raw16 af[2][KB], bf[2][KB];
+        auto ld = [&](int k0, raw16 (&A)[KB], raw16 (&Bq)[KB]) __attribute__((always_inline)) {
+#pragma unroll
+          for (int u = 0; u < KB; u++) {
+            const int ks = min(k0 + u, KS - 1);
+            A[u] = wsrc[(size_t)ks * 64];
+            Bq[u] = validB ? *reinterpret_cast<const raw16*>(gsrc + ks * 16) : zero;
+          }
+        };
+        auto mm = [&](int k0, int k_hi, const raw16 (&A)[KB], const raw16 (&Bq)[KB]) __attribute__((always_inline)) {
+#pragma unroll
+          for (int u = 0; u < KB; u++)
+            if (k0 + u < k_hi)
+              acc = M::mma(__builtin_bit_cast(typename M::frag, A[u]), __builtin_bit_cast(typename M::frag, Bq[u]), acc);
+        };
+        const int k_lo = khalf * KH, k_hi = k_lo + KH;
+        ld(k_lo, af[0], bf[0]);
+        for (int k0 = k_lo; k0 < k_hi; k0 += 2 * KB) {
+          if (k0 + KB < k_hi) ld(k0 + KB, af[1], bf[1]);
+          mm(k0, k_hi, af[0], bf[0]);
+          if (k0 + KB < k_hi) {
+            if (k0 + 2 * KB < k_hi) ld(k0 + 2 * KB, af[0], bf[0]);
+            mm(k0 + KB, k_hi, af[1], bf[1]);
+          }
+        }
+      }
+      // ---- (3) the two K halves meet in LDS: Cs[position][channel]
+      if (khalf == 0) {
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++)
+          *reinterpret_cast<float4*>(&Cs[nB * CP + 8 * rg + 4 * (lane >> 5)]) =
+              make_float4(acc[4 * rg], acc[4 * rg + 1], acc[4 * rg + 2], acc[4 * rg + 3]);
+      }
+      __syncthreads();
+      if (khalf == 1) {
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+          float4* q = reinterpret_cast<float4*>(&Cs[nB * CP + 8 * rg + 4 * (lane >> 5)]);
+          float4 v = *q;
+          v.x += acc[4 * rg]; v.y += acc[4 * rg + 1]; v.z += acc[4 * rg + 2]; v.w += acc[4 * rg + 3];
+          *q = v;
+        }
+      }
+      __syncthreads();
+      // ---- (4) phase A: d(offset), d(mask).  thread = (position n, 8 channels q*8..)
+      if (a.goff || a.gmask) {
+        const int n = tid >> 2, q = tid & 3;
+        const BwEntryP& e = ent[n];
+        const uint32_t flags = e.flags;
+        float s_h = 0.f, s_w = 0.f, s_m = 0.f;
+        if (flags & 16u) {
+          const uint32_t cofs = (uint32_t)(cabs + q * 8) * (uint32_t)sizeof(T);
+          raw16 raw[4];
+#pragma unroll
+          for (int c = 0; c < 4; c++) raw[c] = *reinterpret_cast<const raw16*>(xb + ((size_t)e.pix[c] * pixbytes + cofs));
+          float v[4][8];
+#pragma unroll
+          for (int c = 0; c < 4; c++) {
+            tc_unpack(raw[c], v[c], T{});
+            if (!(flags & (1u << c))) {
+#pragma unroll
+              for (int u = 0; u < 8; u++) v[c][u] = 0.f;
+            }
+          }
+          const float4 d0 = *reinterpret_cast<const float4*>(&Cs[n * CP + q * 8]);
+          const float4 d1 = *reinterpret_cast<const float4*>(&Cs[n * CP + q * 8 + 4]);
+          const float d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+          const float lh = e.lh, lw = e.lw, hh = 1.f - lh, hw = 1.f - lw, m = e.m;
+          const float w0 = e.w[0], w1 = e.w[1], w2 = e.w[2], w3 = e.w[3];
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const float val = w0 * v[0][u] + w1 * v[1][u] + w2 * v[2][u] + w3 * v[3][u];
+            const float dvh = -hw * v[0][u] - lw * v[1][u] + hw * v[2][u] + lw * v[3][u];
+            const float dvw = -hh * v[0][u] + hh * v[1][u] - lh * v[2][u] + lh * v[3][u];
+            s_h += dvh * d[u] * m;
+            s_w += dvw * d[u] * m;
+            s_m += d[u] * val;
+          }
+        }
+        s_h += __shfl_xor(s_h, 1); s_w += __shfl_xor(s_w, 1); s_m += __shfl_xor(s_m, 1);
+        s_h += __shfl_xor(s_h, 2); s_w += __shfl_xor(s_w, 2); s_m += __shfl_xor(s_m, 2);
+        if (q == 0) {
+          float* rp = red + (tap * 64 + n) * 3;
+          rp[0] += s_h; rp[1] += s_w; rp[2] += s_m;
+        }
+      }
+      // ---- (5) phase B: dX into the patch.  wave w owns channels 8w..8w+7; lanes 0..31 = (corner, channel) of
+      //          ONE sample per instruction (4 distinct pixels), positions in ascending order
+      if (a.gx && lane < 32) {
+        const int c = lane >> 3, ch = wid * 8 + (lane & 7);
+#pragma unroll 4
+        for (int n = 0; n < 64; n++) {
+          const BwEntryP& e = ent[n];
+          const float wgt = e.w[c] * e.m;
+          if (wgt != 0.f && (e.flags & 16u)) {
+            const float val = wgt * Cs[n * CP + ch];
+            const int yy = e.py + (c >> 1), xx = e.px + (c & 1);
+            if ((unsigned)yy < (unsigned)a.PHt && (unsigned)xx < (unsigned)a.PWt) {
+              float* pp = &patch[(yy * a.PWt + xx) * 32 + ch];
+              *pp = *pp + val;
+            } else {
+              atomicAdd(a.gx + (size_t)e.pix[c] * s.C + cabs + ch, val);
+            }
+          }
+        }
+      }
+      __syncthreads();  // ent / Cs are rewritten by the next stage; patch rows are complete for the flush
+    }
+    // ---- flush the patch of this channel chunk: one coalesced atomic per touched (pixel, 32 channels)
+    if (a.gx) {
+      for (int i = tid; i < npatch; i += 256) {
+        const float v = patch[i];
+        if (v != 0.f) {
+          patch[i] = 0.f;
+          const int pixel = i >> 5, ch = i & 31;
+          const int yy = pixel / a.PWt, xx = pixel - yy * a.PWt;
+          const int hy = oy + yy, wx = ox + xx;
+          if (hy >= 0 && hy < s.H && wx >= 0 && wx < s.W)
+            atomicAdd(a.gx + (((size_t)b * s.H + hy) * s.W + wx) * s.C + cabs + ch, v);
+        }
+      }
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < s.K2 * 64; i += 256) {
+    const int tap = i >> 6, n = i & 63;
+    const int ho = ty * 8 + (n >> 3), wo = tx * 8 + (n & 7);
+    if (ho >= s.Ho || wo >= s.Wo) continue;
+    const int l = ho * s.Wo + wo;
+    const float* rp = red + i * 3;
+    const long ob = ((long)b * s.DG + dgi) * 2 * s.K2;
+    float* ph = a.goff ? a.goff + (ob + 2 * tap) * s.L + l : nullptr;
+    float* pm = a.gmask ? a.gmask + (((long)b * s.DG + dgi) * s.K2 + tap) * s.L + l : nullptr;
+    if (a.csplit == 1) {
+      if (ph) { ph[0] = rp[0]; ph[s.L] = rp[1]; }
+      if (pm) pm[0] = rp[2];
+    } else {
+      if (ph) { atomicAdd(ph, rp[0]); atomicAdd(ph + s.L, rp[1]); }
+      if (pm) atomicAdd(pm, rp[2]);
+    }
+  }
+}
+
 TcBwPlan dcn_tc_plan_bwd(const DcnShape& s, int dtype) {
   TcBwPlan pl{};
   pl.ok = false;
@@ -1069,6 +1327,33 @@ TcBwPlan dcn_tc_plan_bwd(const DcnShape& s, int dtype) {
   }
   pl.lds = (size_t)s.K2 * 64 * 3 * 4;
   pl.wp_bytes = (size_t)s.Co * s.Cg * s.K2 * 2;
+  // LDS patch variant (dcn_bwd_data_patch_kernel): the largest displacement margin R whose patch fits ~48 KB
+  pl.R = -1; pl.PHt = pl.PWt = 0;
+  {
+    const size_t red_bytes = (size_t)s.K2 * 64 * 3 * 4;
+    for (int r = 0; r <= 8; r++) {
+      const long ph = 7l * s.sh + (long)(s.kh - 1) * s.dh + 2 + 2 * r, pw = 7l * s.sw + (long)(s.kw - 1) * s.dw + 2 + 2 * r;
+      if (ph * pw * 32 * 4 + (long)red_bytes <= 54 * 1024) pl.R = r;
+    }
+    // MEASURED SLOWER than the all-atomics kernel (profiles/r01/v6_dcn_bwd_patch_sweep.txt: 890 vs 544 us for
+    // res3, independent of R): a wave's 64 samples per stage form a serial chain of LDS read-modify-writes
+    // (possible aliasing forbids batching them), ~150 cycles each.  Kept selectable for the record
+    // (D2AMD_DCN_PATCH_R >= 0), off by default.
+    const char* er = getenv("D2AMD_DCN_PATCH_R");
+    pl.R = er ? (atoi(er) < pl.R ? atoi(er) : pl.R) : -1;
+    if (pl.R >= 0) {
+      pl.PHt = 7 * s.sh + (s.kh - 1) * s.dh + 2 + 2 * pl.R;
+      pl.PWt = 7 * s.sw + (s.kw - 1) * s.dw + 2 + 2 * pl.R;
+      pl.lds_patch = red_bytes + (size_t)pl.PHt * pl.PWt * 32 * 4;
+      const long tiles = (long)s.B * pl.tiles_y * pl.tiles_x * s.DG;
+      const int nchunk = s.cpg / 32;
+      int cs = 1;
+      while (cs < nchunk && tiles * cs < 1024) cs++;
+      const char* e = getenv("D2AMD_DCN_CSPLIT");
+      if (e && atoi(e) >= 1) cs = atoi(e) < nchunk ? atoi(e) : nchunk;
+      pl.csplit_patch = cs;
+    }
+  }
   pl.ok = true;
   return pl;
 }
@@ -1083,6 +1368,26 @@ int dcn_tc_backward_data(const DcnShape& s, const TcBwPlan& pl, const void* x_nh
     hipLaunchKernelGGL((tc_pack_weight_t_kernel<T>), dim3(blocks), dim3(256), 0, st, (const T*)weight, (T*)wp, s.G,
                        s.Cog, s.Cg, s.K2);
     D2_LAUNCH_OK();
+  }
+  if (pl.R >= 0) {  // LDS patch + ownership variant
+    BwpArgs a{};
+    a.x = x_nhwc; a.offset = offset; a.mask = mask; a.wp = wp; a.gout = gout_nhwc;
+    a.gx = gx; a.goff = goff; a.gmask = gmask;
+    a.tiles_y = pl.tiles_y; a.tiles_x = pl.tiles_x; a.csplit = pl.csplit_patch;
+    a.R = pl.R; a.PHt = pl.PHt; a.PWt = pl.PWt;
+    if (a.csplit > 1) {
+      if (goff) D2_HIP_OK(hipMemsetAsync(goff, 0, (size_t)s.B * s.DG * 2 * s.K2 * s.L * 4, st));
+      if (gmask) D2_HIP_OK(hipMemsetAsync(gmask, 0, (size_t)s.B * s.DG * s.K2 * s.L * 4, st));
+    }
+    const long total = (long)s.B * pl.tiles_y * pl.tiles_x * s.DG * a.csplit;
+    D2_CHECK_ARG(total < (1l << 30), "deform_conv: too many tiles");
+    a.total = (int)total;
+    auto kern = dcn_bwd_data_patch_kernel<T>;
+    if (pl.lds_patch > 40 * 1024)
+      D2_HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_patch));
+    hipLaunchKernelGGL(kern, dim3((a.total + 7) / 8 * 8), dim3(256), pl.lds_patch, st, s, a);
+    D2_LAUNCH_OK();
+    return D2AMD_OK;
   }
   BwArgs a{};
   a.x = x_nhwc; a.offset = offset; a.mask = mask; a.wp = wp; a.gout = gout_nhwc;

@@ -5,7 +5,7 @@ rows.sort(key=lambda r: int(r['Start_Timestamp']))
 def durs(nm):
     return [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in rows if nm in r['Kernel_Name']]
 f = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if "dcn_fwd_tc_kernel" in r["Kernel_Name"] or "dcn_fwd_wave_kernel" in r["Kernel_Name"]]
-b = durs("dcn_bwd_data_tc_kernel")
+b = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if "dcn_bwd_data_tc_kernel" in r["Kernel_Name"] or "dcn_bwd_data_patch_kernel" in r["Kernel_Name"]]
 rep = plan["rep"]
 i = 0
 for lab in plan["fwd"]:

@@ -141,10 +141,21 @@ def test_channels_not_multiple_of_64_use_generic_kernels():
     check(case, TOL[torch.float16])
 
 
-def test_bwd_large_offsets():
-    """Offsets of ~6 px throw many samples out of the image and far from their output position."""
+@pytest.mark.parametrize("patch_r", [None, -1, 0, 1, 3])
+def test_bwd_large_offsets_and_patch_margins(patch_r):
+    """Offsets of ~6 px throw many samples out of the image and out of small LDS patches (global-atomic
+    fallback of the experimental dcn_bwd_data_patch_kernel, patch_r >= 0); None / -1: the default all-atomics
+    kernel."""
     case = make_case(14, 2, 64, 64, 19, 23, off_scale=6.0)
-    check(case, TOL[torch.float16])
+    with env(D2AMD_DCN_PATCH_R=patch_r):
+        check(case, TOL[torch.float16])
+
+
+@pytest.mark.parametrize("patch_r", [None, 4])
+def test_bwd_both_data_kernels_groups_and_deformable_groups(patch_r):
+    case = make_case(21, 1, 256, 128, 11, 13, groups=2, dg=4)
+    with env(D2AMD_DCN_PATCH_R=patch_r):
+        check(case, TOL[torch.float16])
 
 
 @pytest.mark.parametrize("csplit", [1, 2, 4])
