@@ -211,6 +211,10 @@ def step(w, t=None):
     from detectron2_amd.structures import pairwise_iou
 
     run = (lambda name, fn: t.run(name, fn)) if t is not None else (lambda name, fn: fn())
+    # a training iteration produces NEW feature maps: drop the NHWC staging copies an NCHW run cached for the
+    # previous step's tensors (the two poolers of one step still share one copy)
+    from detectron2_amd.modeling import poolers as _poolers
+    _poolers._NHWC_CACHE.clear()
     for i in range(w.n_img):
         run("pairwise_iou_rpn", lambda: pairwise_iou(w.gt[i], w.anchors))
     # RPN NMS of all images of the batch: one call, the images' device pipelines overlap on HIP streams and
