@@ -29,6 +29,8 @@ namespace d2amd {
 
 typedef unsigned long long u64;
 
+constexpr int RK_GROUP = 8;  // keys per scalar-load group of the ranking kernel (2 x s_load_dwordx16)
+constexpr int RK_JC = 512;   // keys per chunk: one (64-box block, chunk) task is ~2.5k VALU instructions per wave
 constexpr int RANK_MAX_N = 12288;  // brute-force ranking up to here (index must fit 16 bits)
 
 struct NmsWorkspace {
@@ -41,8 +43,12 @@ struct NmsWorkspace {
   float* boxes_s;     // [n64 * 8] boxes in segment order (aligned: float4; rotated: 5 of 8 floats)
   u64* mask;          // [n64 * wcap]
   u64* diagT;         // [n64] transposed diagonal word per row
+  u64* w1T;           // [n64] transposed word 1: bit i = row i of the previous block suppresses this box
+  u64* w2T;           // [n64] transposed word 2: same for the block before the previous one
   u64* keepbits;      // [nblocks]   } zeroed together
   int* counters;      // [4]: nseg, error flags }
+  int* rk_cnt;        // [chunks][2][n64] partial rank counts (brute-force ranking path)
+  void* rk_keys;      // [n padded to RK_GROUP] 16-B key records (brute-force ranking path)
   uint8_t* flag_r;    // [n] kept flag in rank order              (radix path)
   int* seg_start;     // [65536]
   void* sort_temp;
@@ -84,10 +90,14 @@ static void carve(NmsWorkspace& w, void* base, int64_t n, int wcap) {
   w.boxes_s = (float*)take(n64 * 8 * 4);
   w.mask = (u64*)take((size_t)n64 * wcap * 8);
   w.diagT = (u64*)take((size_t)n64 * 8);
+  w.w1T = (u64*)take((size_t)n64 * 8);
+  w.w2T = (u64*)take((size_t)n64 * 8);
   const size_t z0 = off;
   w.keepbits = (u64*)take((n64 / 64) * 8);
   w.counters = (int*)take(4 * 4);
   w.zero_bytes = off - z0;
+  w.rk_keys = take(n <= RANK_MAX_N ? (size_t)(n + RK_GROUP) * 16 : 0);
+  w.rk_cnt = (int*)take(n <= RANK_MAX_N ? (size_t)((n + RK_JC - 1) / RK_JC) * 2 * n64 * 4 : 0);
   w.flag_r = (uint8_t*)take(n);
   w.seg_start = (int*)take(65536 * 4);
   w.sort_temp_bytes = sort_temp_bytes(n);
@@ -105,67 +115,126 @@ __device__ __forceinline__ u64 score_key(float s, int i) {
   return ((u64)(~u) << 16) | (u64)(uint32_t)i;
 }
 
-constexpr int RK_THREADS = 1024;
-constexpr int RK_IB = RK_THREADS / 32;  // boxes ranked per workgroup (one per half-wave)
+constexpr int RK_THREADS = 256;
 
-// All n keys are converted and staged in LDS by ONE bulk pass (every load in flight at once: one
-// memory latency per workgroup), then each half-wave ranks one box against all of them from LDS.
+// Box record in segment order (8 floats): axis-aligned { x1, y1, x2, y2, area, category bits, flags, 0 },
+// rotated { cx, cy, w, h, angle, category bits, 0, 0 }.  flags bit 0 = a coordinate is NaN / inf.
+constexpr int BOX_REC = 8;
+
+template <int BW>
+__device__ __forceinline__ void store_box_record(float* __restrict__ boxes_s, int p, const float* __restrict__ src,
+                                                 uint32_t cls) {
+  float* d = boxes_s + (long)p * BOX_REC;
+  if constexpr (BW == 4) {
+    const float4 b = *reinterpret_cast<const float4*>(src);
+    const float area = (b.z - b.x) * (b.w - b.y);  // torchvision nms_kernel_impl: areas = (x2 - x1) * (y2 - y1)
+    const bool fin = (fabsf(b.x) < INFINITY) && (fabsf(b.y) < INFINITY) && (fabsf(b.z) < INFINITY) &&
+                     (fabsf(b.w) < INFINITY);
+    reinterpret_cast<float4*>(d)[0] = b;
+    reinterpret_cast<float4*>(d)[1] = make_float4(area, __uint_as_float(cls), __uint_as_float(fin ? 0u : 1u), 0.f);
+  } else {
+    float v[BOX_REC];
+#pragma unroll
+    for (int k = 0; k < BW; k++) v[k] = src[k];
+    v[5] = __uint_as_float(cls); v[6] = 0.f; v[7] = 0.f;
+    reinterpret_cast<float4*>(d)[0] = make_float4(v[0], v[1], v[2], v[3]);
+    reinterpret_cast<float4*>(d)[1] = make_float4(v[4], v[5], v[6], v[7]);
+  }
+}
+
+// Key record of one box (16 B): { K, S }, read by the ranking kernel through the scalar cache (wave-uniform
+// addresses).  The array is padded to a multiple of RK_GROUP records with all-ones sentinels that never count.
+// (Comparing S as a double + the category as u32 -- 5 full-rate VALU per pair -- measured 29 us against 18 us
+// for the two v_cmp_lt_u64 per pair used here.)
+struct RankGroup { uint4 k[RK_GROUP]; };
+
+__device__ __forceinline__ uint4 rank_key(float score, int64_t c, int t) {
+  const u64 S = score_key(score, t);
+  const u64 K = ((u64)c << 48) | S;
+  return make_uint4((uint32_t)K, (uint32_t)(K >> 32), (uint32_t)S, (uint32_t)(S >> 32));
+}
+
+// Zeroes the reduction's accumulators (replaces a memset launch) and builds the key records.
+__global__ void nms_prep_kernel(const float* __restrict__ scores, const int64_t* __restrict__ idxs, int n,
+                                uint4* __restrict__ keys, uint32_t* __restrict__ zero, int zero_words) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int q = t; q < zero_words; q += gridDim.x * blockDim.x) zero[q] = 0u;
+  const int npad = (n + RK_GROUP - 1) / RK_GROUP * RK_GROUP;
+  if (t >= npad) return;
+  if (t >= n) {
+    keys[t] = make_uint4(~0u, ~0u, ~0u, ~0u);
+    return;
+  }
+  int64_t c = idxs ? idxs[t] : 0;
+  if (c < 0 || c > 65535) c = 0;  // (flagged by the ranking kernel: the counters are being zeroed here)
+  keys[t] = rank_key(scores[t], c, t);
+}
+
+// Every box needs two counts over all n keys: r_s = #{S_j < S_i} (global score rank) and r_cm = #{K_j < K_i}
+// (class-major position).  Work item = (block of 64 boxes, one box per lane) x (chunk of RK_JC keys): the keys
+// come in through the scalar cache (wave-uniform addresses -> s_load, operands in SGPRs), so a pair costs only
+// its compares and carry adds -- no per-lane memory traffic, no LDS (the first version walked a 96 KiB LDS key
+// table with one read per lane per pair: 44 us at n = 8.8k).  Partial counts are added to global counters; the
+// wave that completes a block's last chunk scatters that block.
 template <int BW>
 __global__ __launch_bounds__(RK_THREADS) void nms_rank_kernel(
-    const float* __restrict__ boxes, const float* __restrict__ scores, const int64_t* __restrict__ idxs, int n,
+    const float* __restrict__ boxes, const int64_t* __restrict__ idxs, const uint4* __restrict__ keys, int n,
     int* __restrict__ order, int* __restrict__ rankpos, uint32_t* __restrict__ cls_s, float* __restrict__ boxes_s,
-    int* __restrict__ counters, int rounds) {
-  __shared__ u64 Ks[RANK_MAX_N];  // 96 KiB
-  const int tid = threadIdx.x, jp = tid & 31, il = tid >> 5;
-  constexpr int PER = RANK_MAX_N / RK_THREADS;  // 12
-  {
-    float sc[PER];
-    int64_t cc[PER];
-#pragma unroll
-    for (int q = 0; q < PER; q++) {  // raw clamped loads first, conversion after: keeps them all in flight
-      const int j = min(tid + q * RK_THREADS, n - 1);
-      sc[q] = scores[j];
-      cc[q] = idxs ? idxs[j] : 0;
-    }
-    bool bad = false;
-#pragma unroll
-    for (int q = 0; q < PER; q++) {
-      const int j = tid + q * RK_THREADS;
-      int64_t c = cc[q];
-      if (j < n && (c < 0 || c > 65535)) bad = true;
-      if (c < 0 || c > 65535) c = 0;
-      if (j < n) Ks[j] = ((u64)c << 48) | score_key(sc[q], j);
-    }
-    if (bad && blockIdx.x == 0) atomicOr(&counters[1], 2);
+    int* __restrict__ counters, int* __restrict__ rk_cnt, int nchunks) {
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int n64 = (n + 63) & ~63;
+  const int j0 = blockIdx.x * RK_JC;  // RK_JC is a multiple of RK_GROUP
+  const int jn = min(RK_JC, n - j0);
+  const int ib = blockIdx.y * (RK_THREADS / 64) + wid;  // block of 64 boxes
+  const int i = ib * 64 + lane;
+  if (ib * 64 >= n) return;  // uniform per wave
+  if (blockIdx.x == 0 && idxs && i < n) {
+    const int64_t c = idxs[i];
+    if (c < 0 || c > 65535) atomicOr(&counters[1], 2);
   }
-  __syncthreads();
-  // `rounds` boxes per half-wave: the launch has at most ~one workgroup per CU (the 96 KiB key table
-  // allows only one resident workgroup per CU, so a 257th workgroup would cost a whole second round)
-  constexpr int STRIDE = BW == 4 ? 4 : 8;
-  const u64 M48 = 0x0000ffffffffffffull;
-  for (int t = 0; t < rounds; t++) {
-    const int i = (blockIdx.x * rounds + t) * RK_IB + il;
-    if (i >= n) break;  // uniform per half-wave
-    const u64 Ki = Ks[i];
-    const u64 Si = Ki & M48;
-    int r_s = 0, r_cm = 0;
-    for (int j = jp; j < n; j += 32) {
-      const u64 K = Ks[j];
-      r_cm += (K < Ki) ? 1 : 0;          // class-major position
-      r_s += ((K & M48) < Si) ? 1 : 0;   // global score rank (ties: lower index first)
-    }
+  const uint4 mine = keys[min(i, n - 1)];
+  const u64 m0 = ((u64)mine.y << 32) | mine.x, m1 = ((u64)mine.w << 32) | mine.z;
+  int r_s = 0, r_cm = 0;
+  const RankGroup* gp = reinterpret_cast<const RankGroup*>(keys + j0);
+  const int ngroups = (jn + RK_GROUP - 1) / RK_GROUP;
+  RankGroup cur = gp[0];
+  for (int g = 0; g < ngroups; g++) {
+    const RankGroup nxt = gp[min(g + 1, ngroups - 1)];  // in flight while this group is compared
 #pragma unroll
-    for (int o = 16; o >= 1; o >>= 1) {  // the 32 lanes of a half-wave share box i
-      r_s += __shfl_xor(r_s, o);
-      r_cm += __shfl_xor(r_cm, o);
+    for (int q = 0; q < RK_GROUP; q++) {
+      const uint4 k = cur.k[q];
+      const u64 k0 = ((u64)k.y << 32) | k.x, k1 = ((u64)k.w << 32) | k.z;
+      r_cm += (k0 < m0) ? 1 : 0;
+      r_s += (k1 < m1) ? 1 : 0;
     }
-    if (jp < BW) boxes_s[(long)r_cm * STRIDE + jp] = boxes[(long)i * BW + jp];
-    if (jp == 0) {
-      order[r_s] = i;
-      rankpos[r_cm] = r_s;
-      cls_s[r_cm] = (uint32_t)(Ki >> 48);
-    }
+    cur = nxt;
   }
+  // partial counts of this chunk (plain stores; summed by nms_rank_scatter_kernel -- a last-arriver scheme with
+  // device-scope fences per wave cost 40+ us here)
+  int* part = rk_cnt + (long)blockIdx.x * 2 * n64;
+  part[i] = r_s;
+  part[n64 + i] = r_cm;
+}
+
+template <int BW>
+__global__ void nms_rank_scatter_kernel(const float* __restrict__ boxes, const uint4* __restrict__ keys, int n,
+                                        const int* __restrict__ rk_cnt, int nchunks, int* __restrict__ order,
+                                        int* __restrict__ rankpos, uint32_t* __restrict__ cls_s,
+                                        float* __restrict__ boxes_s) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int n64 = (n + 63) & ~63;
+  int r_s = 0, r_cm = 0;
+  for (int c = 0; c < nchunks; c++) {
+    r_s += rk_cnt[(long)c * 2 * n64 + i];
+    r_cm += rk_cnt[(long)c * 2 * n64 + n64 + i];
+  }
+  const uint4 mine = keys[i];
+  const uint32_t cls = mine.y >> 16;
+  order[r_s] = i;
+  rankpos[r_cm] = r_s;
+  cls_s[r_cm] = cls;
+  store_box_record<BW>(boxes_s, r_cm, boxes + (long)i * BW, cls);
 }
 
 // segment starts of the class-major sequence (small path; the radix path finds them while gathering)
@@ -203,9 +272,7 @@ __global__ void nms_gather_boxes_kernel(const float* __restrict__ boxes, const i
   if (p >= n) return;
   int r = rankpos ? rankpos[p] : p;
   int src = order[r];
-  constexpr int STRIDE = BW == 4 ? 4 : 8;
-#pragma unroll
-  for (int k = 0; k < BW; k++) boxes_s[(long)p * STRIDE + k] = boxes[(long)src * BW + k];
+  store_box_record<BW>(boxes_s, p, boxes + (long)src * BW, cls_s ? cls_s[p] : 0u);
   bool start = cls_s ? (p == 0 || cls_s[p] != cls_s[p - 1]) : (p == 0);
   if (start) {
     int pos = atomicAdd(&counters[0], 1);
@@ -214,17 +281,64 @@ __global__ void nms_gather_boxes_kernel(const float* __restrict__ boxes, const i
 }
 
 // ---- step 2: wavefront bitmask ------------------------------------------------------------
-__device__ __forceinline__ float bcast(float v, int lane) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+// 64 x 64 bit transpose inside a wave: lane j receives bit j of every lane's word (bit i = lane i).
+// The transposed diagonal / first / second off-diagonal words (row suppresses column -> column is
+// suppressed by row) are exactly these transposes: the IoU test of a (row, column) pair is evaluated
+// once, in the reference's argument order, and read from either side.
+__device__ __forceinline__ u64 wave_transpose64(u64 word, int lane) {
+  const uint32_t lo = (uint32_t)word, hi = (uint32_t)(word >> 32);
+  u64 out = 0;
+#pragma unroll
+  for (int j = 0; j < 64; j++) {
+    const u64 b = __ballot(((j < 32 ? lo : hi) >> (j & 31)) & 1u);
+    out = (lane == j) ? b : out;
+  }
+  return out;
 }
 
-// The j loop is deliberately NOT fully unrolled: every wave runs the body exactly once per j, so a
-// 64x unrolled body (20 KB of straight-line code) made the kernel instruction-fetch bound (31 us
-// for 2,640 live tiles; the arithmetic is ~3 us).
-template <bool ROT>
-__global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes_s,
-                                                      const uint32_t* __restrict__ cls_s, int n, int wcap,
-                                                      double thr, u64* __restrict__ mask, u64* __restrict__ diagT) {
+__device__ __forceinline__ void store_mask_words(u64 word, int row, int col0, int lane, int w, int n, int wcap,
+                                                 u64* __restrict__ mask, u64* __restrict__ diagT,
+                                                 u64* __restrict__ w1T, u64* __restrict__ w2T) {
+  if (row < n) mask[(long)row * wcap + w] = word;
+  if (w <= 2) {  // uniform
+    const u64 t = wave_transpose64(word, lane);
+    if (col0 + lane < n) (w == 0 ? diagT : w == 1 ? w1T : w2T)[col0 + lane] = t;
+  }
+}
+
+// v_max_f32 / v_min_f32 without the compiler's canonicalisation; the second operand is wave-uniform (SGPR)
+__device__ __forceinline__ float vmaxf_s(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %2, %1" : "=v"(r) : "v"(a), "s"(b));
+  return r;
+}
+__device__ __forceinline__ float vminf_s(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %2, %1" : "=v"(r) : "v"(a), "s"(b));
+  return r;
+}
+__device__ __forceinline__ float vmax0f(float a) {
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(a));
+  return r;
+}
+
+struct ColGroup { float v[4][BOX_REC]; };  // 4 column records = 2 x s_load_dwordx16 through the scalar cache
+
+// Axis-aligned tile (rb, w): lane = row rb * 64 + lane against the 64 columns of block rb + w.
+// torchvision's test is   ovr = inter / (iarea + jarea - inter);  ovr > thr   with float ovr, double thr.
+// FAST path (finite boxes, 0 < denom < inf): with f = largest float <= thr, g = next float up and
+// mid = (f + g) / 2, the correctly rounded quotient satisfies  ovr > thr  <=>  ovr >= g  <=>  x > mid, or
+// x == mid when the tie rounds up to g (g even), for the real x = inter / denom; and  x > mid  <=>  inter > mid * denom
+// evaluated EXACTLY in double (25-bit mid x 24-bit denom = 49 bits).  This replaces the ~12-instruction IEEE
+// division by cvt/cvt/mul/cmp.  max/min: with finite operands (a < b) ? b : a equals v_max_f32 except for the
+// sign of a zero, which cannot change a `> thr` outcome.  Anything else (a non-finite coordinate in the tile,
+// denom outside (0, inf), an out-of-range threshold) takes the literal formula.
+template <bool FAST, bool TIE_UP>
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes_s, int use_cls, int n, int wcap,
+                                                      double thr, double mid, u64* __restrict__ mask,
+                                                      u64* __restrict__ diagT, u64* __restrict__ w1T,
+                                                      u64* __restrict__ w2T) {
   const int rb = blockIdx.x, w = blockIdx.y;
   const int lane = threadIdx.x;
   const int cb = rb + w;
@@ -232,111 +346,163 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
   const int col0 = cb * 64;
   const int nblocks = (n + 63) >> 6;
   if (cb >= nblocks) return;  // never read by the reduction
-  u64 word = 0, wordT = 0;
+  u64 word = 0;
   bool live = true;
-  if (cls_s) {
+  if (use_cls) {
     // categories ascend along the sorted sequence: tile is empty unless ranges touch
-    uint32_t row_last = cls_s[min(rb * 64 + 63, n - 1)];
-    uint32_t col_first = cls_s[col0];
+    const uint32_t row_last = __float_as_uint(boxes_s[(long)min(rb * 64 + 63, n - 1) * BOX_REC + 5]);
+    const uint32_t col_first = __float_as_uint(boxes_s[(long)col0 * BOX_REC + 5]);
     live = col_first <= row_last;
   }
   if (live) {
     const int rrow = min(row, n - 1), rcol = min(col0 + lane, n - 1);
-    uint32_t my_cls = cls_s ? cls_s[rrow] : 0u;
-    uint32_t col_cls = cls_s ? cls_s[rcol] : 0u;
-    if constexpr (!ROT) {
-      const float4 rbx = reinterpret_cast<const float4*>(boxes_s)[rrow];
-      const float4 cbx = reinterpret_cast<const float4*>(boxes_s)[rcol];
-      const float iarea = (rbx.z - rbx.x) * (rbx.w - rbx.y);
-      const float carea = (cbx.z - cbx.x) * (cbx.w - cbx.y);
-#pragma unroll 4
-      for (int j = 0; j < 64; j++) {
-        const float jx1 = bcast(cbx.x, j), jy1 = bcast(cbx.y, j), jx2 = bcast(cbx.z, j), jy2 = bcast(cbx.w, j);
-        const float jarea = bcast(carea, j);
-        const uint32_t jcls = (uint32_t)__builtin_amdgcn_readlane((int)col_cls, j);
-        // torchvision nms_kernel_impl: std::max(a,b) = (a<b)?b:a, std::min(a,b) = (b<a)?b:a
-        float xx1 = (rbx.x < jx1) ? jx1 : rbx.x;
-        float yy1 = (rbx.y < jy1) ? jy1 : rbx.y;
-        float xx2 = (jx2 < rbx.z) ? jx2 : rbx.z;
-        float yy2 = (jy2 < rbx.w) ? jy2 : rbx.w;
-        float ww = xx2 - xx1, hh = yy2 - yy1;
-        ww = (0.f < ww) ? ww : 0.f;
-        hh = (0.f < hh) ? hh : 0.f;
-        float inter = ww * hh;
-        // max/min, the product and a + b are symmetric in (row, col), so one value serves both
-        // the word (row suppresses later col) and, on diagonal tiles, the transposed word
-        float ovr = inter / (iarea + jarea - inter);
-        const bool hit = ((double)ovr > thr) && (jcls == my_cls) && (col0 + j < n) && (row < n);
-        word |= (hit && (col0 + j > row)) ? (1ull << j) : 0ull;
-        wordT |= (hit && (col0 + j < row)) ? (1ull << j) : 0ull;
-      }
-    } else {
-      __shared__ RotIouScratch<64> S;
-      float rbx[5], cbx[5];
+    const float4 rbx = reinterpret_cast<const float4*>(boxes_s)[rrow * 2];
+    const float4 rex = reinterpret_cast<const float4*>(boxes_s)[rrow * 2 + 1];
+    const float iarea = rex.x;
+    const uint32_t my_cls = __float_as_uint(rex.y);
+    const uint32_t cflags = __float_as_uint(boxes_s[(long)rcol * BOX_REC + 6]);
+    const bool weird = __ballot((__float_as_uint(rex.z) | cflags) & 1u) != 0ull;  // uniform
+    const ColGroup* cg = reinterpret_cast<const ColGroup*>(boxes_s + (long)col0 * BOX_REC);
+    // (records of the last block beyond n are allocated but unwritten: whatever they hold is masked below)
+    bool exact = !FAST || weird;  // uniform
+    if (!exact) {
+      bool bad = false;
+      // not unrolled: every wave runs the body once per group, a 64x unrolled body is instruction-fetch bound
+#pragma unroll 1
+      for (int g = 0; g < 16; g++) {
+        const ColGroup c = cg[g];
+        uint32_t nib = 0;
 #pragma unroll
-      for (int k = 0; k < 5; k++) { rbx[k] = boxes_s[(long)rrow * 8 + k]; cbx[k] = boxes_s[(long)rcol * 8 + k]; }
-      for (int j = 0; j < 64; j++) {
-        if (col0 + j >= n) break;  // uniform
-        float jb[5];
-#pragma unroll
-        for (int k = 0; k < 5; k++) jb[k] = __shfl(cbx[k], j);
-        const uint32_t jcls = (uint32_t)__shfl((int)col_cls, j);
-        // every lane evaluates (uniform control flow); cheap rejection by category / triangle first.
-        // The reference evaluates iou(kept box, later box) (nms_rotated_cpu.cpp:45-54) and the
-        // polygon clip is not symmetric in floating point: keep that argument order in both words.
-        const bool same = (jcls == my_cls) && (row < n);
-        const bool cand = same && (col0 + j > row);
-        float ovr = 0.f;
-        if (cand) ovr = single_box_iou_rotated<64>(rbx, jb, S, lane);
-        word |= (cand && ((double)ovr >= thr)) ? (1ull << j) : 0ull;  // nms_rotated_cpu.cpp:54
-        if (w == 0) {  // uniform
-          const bool candT = same && (col0 + j < row);
-          float ovrT = 0.f;
-          if (candT) ovrT = single_box_iou_rotated<64>(jb, rbx, S, lane);
-          wordT |= (candT && ((double)ovrT >= thr)) ? (1ull << j) : 0ull;
+        for (int q = 0; q < 4; q++) {
+          const float jx1 = c.v[q][0], jy1 = c.v[q][1], jx2 = c.v[q][2], jy2 = c.v[q][3], jarea = c.v[q][4];
+          const uint32_t jcls = __float_as_uint(c.v[q][5]);
+          const float xx1 = vmaxf_s(rbx.x, jx1), yy1 = vmaxf_s(rbx.y, jy1);
+          const float xx2 = vminf_s(rbx.z, jx2), yy2 = vminf_s(rbx.w, jy2);
+          const float ww = vmax0f(xx2 - xx1), hh = vmax0f(yy2 - yy1);
+          const float inter = ww * hh;
+          const float denom = iarea + jarea - inter;
+          const double p = mid * (double)denom;
+          const bool hit = TIE_UP ? ((double)inter >= p) : ((double)inter > p);
+          bad |= !__builtin_amdgcn_classf(denom, 0x180);  // not (+normal | +denormal): redo the tile literally
+          nib |= (hit && jcls == my_cls) ? (1u << q) : 0u;
         }
+        word |= (u64)nib << (4 * g);
+      }
+      exact = __ballot(bad) != 0ull;  // (columns beyond n may raise it too: harmless)
+    }
+    if (exact) {
+      word = 0;
+#pragma unroll 1
+      for (int g = 0; g < 16; g++) {
+        const ColGroup c = cg[g];
+        uint32_t nib = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const float jx1 = c.v[q][0], jy1 = c.v[q][1], jx2 = c.v[q][2], jy2 = c.v[q][3], jarea = c.v[q][4];
+          const uint32_t jcls = __float_as_uint(c.v[q][5]);
+          // torchvision nms_kernel_impl: std::max(a,b) = (a<b)?b:a, std::min(a,b) = (b<a)?b:a
+          float xx1 = (rbx.x < jx1) ? jx1 : rbx.x;
+          float yy1 = (rbx.y < jy1) ? jy1 : rbx.y;
+          float xx2 = (jx2 < rbx.z) ? jx2 : rbx.z;
+          float yy2 = (jy2 < rbx.w) ? jy2 : rbx.w;
+          float ww = xx2 - xx1, hh = yy2 - yy1;
+          ww = (0.f < ww) ? ww : 0.f;
+          hh = (0.f < hh) ? hh : 0.f;
+          const float inter = ww * hh;
+          const float ovr = inter / (iarea + jarea - inter);
+          nib |= (((double)ovr > thr) && jcls == my_cls) ? (1u << q) : 0u;
+        }
+        word |= (u64)nib << (4 * g);
       }
     }
+    // validity of the columns / rows and the strict upper triangle of the diagonal tile, applied once
+    const int jmax = n - col0;  // > 0
+    if (jmax < 64) word &= (1ull << jmax) - 1ull;
+    if (w == 0) word &= (lane < 63) ? ~((2ull << lane) - 1ull) : 0ull;
+    if (row >= n) word = 0;
   }
-  if (row < n) {
-    mask[(long)row * wcap + w] = word;
-    if (w == 0) diagT[row] = wordT;
+  store_mask_words(word, row, col0, lane, w, n, wcap, mask, diagT, w1T, w2T);
+}
+
+// Rotated tile: the polygon clip is not symmetric in floating point and the reference evaluates
+// iou(kept box, later box) (nms_rotated_cpu.cpp:45-54): rows are the earlier boxes, so that is the order
+// used here, once per pair (the transposed words come from the bit transpose of the same results).
+__global__ __launch_bounds__(64) void nms_mask_rot_kernel(const float* __restrict__ boxes_s, int n, int wcap,
+                                                          double thr, u64* __restrict__ mask,
+                                                          u64* __restrict__ diagT, u64* __restrict__ w1T,
+                                                          u64* __restrict__ w2T) {
+  const int rb = blockIdx.x, w = blockIdx.y;
+  const int lane = threadIdx.x;
+  const int cb = rb + w;
+  const int row = rb * 64 + lane;
+  const int col0 = cb * 64;
+  const int nblocks = (n + 63) >> 6;
+  if (cb >= nblocks) return;
+  u64 word = 0;
+  const uint32_t row_last = __float_as_uint(boxes_s[(long)min(rb * 64 + 63, n - 1) * BOX_REC + 5]);
+  const uint32_t col_first = __float_as_uint(boxes_s[(long)col0 * BOX_REC + 5]);
+  if (col_first <= row_last) {
+    __shared__ RotIouScratch<64> S;
+    const int rrow = min(row, n - 1), rcol = min(col0 + lane, n - 1);
+    float rbx[5], cbx[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) { rbx[k] = boxes_s[(long)rrow * BOX_REC + k]; cbx[k] = boxes_s[(long)rcol * BOX_REC + k]; }
+    const uint32_t my_cls = __float_as_uint(boxes_s[(long)rrow * BOX_REC + 5]);
+    const uint32_t col_cls = __float_as_uint(boxes_s[(long)rcol * BOX_REC + 5]);
+    for (int j = 0; j < 64; j++) {
+      if (col0 + j >= n) break;  // uniform
+      float jb[5];
+#pragma unroll
+      for (int k = 0; k < 5; k++) jb[k] = __shfl(cbx[k], j);
+      const uint32_t jcls = (uint32_t)__shfl((int)col_cls, j);
+      // every lane evaluates (uniform control flow); cheap rejection by category / triangle first
+      const bool cand = (jcls == my_cls) && (row < n) && (col0 + j > row);
+      float ovr = 0.f;
+      if (cand) ovr = single_box_iou_rotated<64>(rbx, jb, S, lane);
+      word |= (cand && ((double)ovr >= thr)) ? (1ull << j) : 0ull;  // nms_rotated_cpu.cpp:54
+    }
   }
+  store_mask_words(word, row, col0, lane, w, n, wcap, mask, diagT, w1T, w2T);
 }
 
 // ---- step 3: greedy reduction ----------------------------------------------------------------
-// One 320-thread workgroup (5 waves) per category segment, walking its 64-row blocks in order.
+// One workgroup (wave 0 + RED_GROUPS pusher waves) per category segment, walking its 64-row blocks in order.
 //   wave 0     resolves the diagonal block: kept_j = cand_j && !(DT_j & kept), iterated as a
 //              lane-parallel fixed point (DT_j = transposed diagonal word; position t is final
-//              after t iterations and the typical depth is a handful -- v0/v1 ran a 64-step
-//              scalar chain), publishes `kept`, and ORs word 1 of the kept rows into
-//              removed[b+1] itself: the only data the NEXT diagonal block needs from this one.
-//              Its inputs (DT, word 1) are staged in LDS a window of RED_WIN blocks at a time, so
-//              the serial chain never touches global memory.
-//   waves 1-4  "pushers": wave g owns the blocks b = g (mod 4), all 64 rows of it (128 VGPRs),
-//              lane = word 2 + lane.  A pusher loads its whole block, then sits
-//              out three barriers before `kept` of that block exists -- prefetch depth comes from
-//              the other pushers' loads being in flight meanwhile.  (A register ring in one wave
-//              does not work: hipcc emits s_waitcnt vmcnt(0) at every ring read inside divergent
-//              / looped code, which drains the loads just issued -- measured 3 us per block.)
-// One barrier per block; the pushers' LDS ORs land one barrier before wave 0 needs them.
-constexpr int RED_THREADS = 320;
-constexpr int RED_GROUPS = 4;
-constexpr int RED_PUSH_ROWS = 64;   // rows per pusher wave (one wave per group)
+//              after t iterations and the typical depth is 1-2), and publishes `kept`.  Suppression
+//              by the previous two blocks comes from the TRANSPOSED words 1 and 2 (w1T, w2T: bit i =
+//              row i of that block suppresses me) tested against the previous two `kept` values held
+//              in registers: nothing on the block-to-block chain goes through an LDS atomic.  DT, w1T,
+//              w2T are staged in LDS a window of RED_WIN blocks at a time.
+//   pushers    wave 1 + g owns the half-block units u = g (mod RED_GROUPS): 32 rows in 64 VGPRs,
+//              lane = word RED_NEAR + lane, loaded one round ahead; once `kept` of the unit's block is
+//              published it ORs the kept rows into removed[] (LDS atomics).  Block rel only needs the
+//              pushes of blocks <= rel - RED_NEAR, so a push has two blocks of slack.
+// Synchronisation is by LDS flags (kept_ready / pushed[g]), not barriers: with one barrier per block
+// every block waited for a pusher to issue its row loads (1.5 us per block; 0.3-0.4 us now).
+constexpr int RED_NEAR = 3;          // wave 0 handles words 0 .. RED_NEAR - 1 itself (transposed words against the previous `kept`s)
+constexpr int RED_GROUPS = 15;       // pusher waves; each owns every 8th half block, so its row loads have ~4 blocks of lead time
+constexpr int RED_THREADS = 64 * (1 + RED_GROUPS);
+constexpr int RED_SPLIT = 2;         // a block's 64 rows are pushed as 2 units of 32 rows: 64 VGPRs of rows per pusher
+constexpr int RED_PUSH_ROWS = 64 / RED_SPLIT;  // (64-row units needed 128 VGPRs and spilled, which serialised the row loads)
 constexpr int RED_WIN = 64;         // blocks of (DT, word 1) staged in LDS at a time (2 x 32 KiB)
 
 __global__ __launch_bounds__(RED_THREADS) void nms_reduce_kernel(const u64* __restrict__ mask,
                                                                  const u64* __restrict__ diagT,
+                                                                 const u64* __restrict__ w1T,
+                                                                 const u64* __restrict__ w2T,
                                                                  const uint32_t* __restrict__ cls_s, int n, int wcap,
                                                                  int max_per_class, const int* __restrict__ seg_start,
-                                                                 int* counters, u64* keepbits) {
+                                                                 int* counters, u64* keepbits, u64* dbg) {
   extern __shared__ __attribute__((aligned(16))) u64 removed[];  // [wcap]
-  __shared__ u64 dt_s[RED_WIN * 64], w1_s[RED_WIN * 64];
-  __shared__ u64 kept_s[2];
+  __shared__ u64 dt_s[RED_WIN * 64], wt_s[RED_WIN * 64], wu_s[RED_WIN * 64];
+  __shared__ u64 kept_s[RED_WIN];
+  __shared__ int flag_s[1 + RED_GROUPS];  // [0] blocks resolved by wave 0; [1 + g] blocks pushed by pusher g
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int grp = wid - 1;  // pushers only
   const int nseg = cls_s ? counters[0] : 1;
   for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+    if (dbg && seg == 0 && tid == 0) dbg[120] = wall_clock64();
     int s = cls_s ? seg_start[seg] : 0;
     int e = n;
     if (cls_s) {
@@ -349,74 +515,118 @@ __global__ __launch_bounds__(RED_THREADS) void nms_reduce_kernel(const u64* __re
     if (e - s > max_per_class) { if (tid == 0) atomicOr(&counters[1], 1); continue; }
     const int b0 = s >> 6, b1 = (e - 1) >> 6;
     const int nb = b1 - b0 + 1;  // <= wcap by construction
+    if (dbg && seg == 0 && tid == 0) dbg[121] = wall_clock64();
     __syncthreads();
+    if (dbg && seg == 0 && tid == 0) dbg[126] = wall_clock64();
     for (int w = tid; w < nb; w += RED_THREADS) removed[w] = 0;
 
-    u64 rows[RED_PUSH_ROWS];  // pusher: word 2 + lane of the 64 rows of the block it currently owns
-    const int wi = min(2 + lane, wcap - 1);
-    auto load_block = [&](int b) {  // unconditional clamped loads, raw (validity applied at use)
-#pragma unroll
-      for (int r = 0; r < RED_PUSH_ROWS; r++) {
-        // rows up to n64 - 1 are allocated (never kept if >= n): no clamp, so the row base is a
-        // wave-uniform SGPR address and the lane offset is the only VGPR
-        const u64* rowp = mask + (long)(b * 64 + r) * wcap;
-        rows[r] = rowp[wi];
-      }
-    };
-    if (wid != 0 && b0 + grp <= b1) load_block(b0 + grp);
+    const int wi = min(RED_NEAR + lane, wcap - 1);
+    const int nunits = nb * RED_SPLIT;
 
-    for (int b = b0; b <= b1; b++) {
-      const int rel = b - b0;
-      if ((rel % RED_WIN) == 0) {  // stage the next window of wave 0's inputs (uniform)
-        __syncthreads();           // wave 0 is done with the previous window
-        const int rows_w = min(RED_WIN, b1 - b + 1) * 64;
-        for (int q = tid; q < rows_w; q += RED_THREADS) {
-          const int row = b * 64 + q;
-          const long rc = min(row, n - 1);
-          const u64 d = diagT[rc], w1 = mask[rc * wcap + min(1, wcap - 1)];
-          const bool valid = row >= s && row < e;
-          dt_s[q] = valid ? d : 0ull;
-          w1_s[q] = (valid && (row >> 6) < b1) ? w1 : 0ull;
-        }
-        __syncthreads();
-      }
-      if (wid == 0) {
-        const int row = b * 64 + lane;
-        const bool valid = row >= s && row < e;
-        const u64 cand = ~removed[rel] & __ballot(valid);
-        const u64 dt = dt_s[(rel % RED_WIN) * 64 + lane];
-        const bool cj = (cand >> lane) & 1ull;
-        u64 kept = cand;
-        for (;;) {
-          const u64 nk = __ballot(cj && (dt & kept) == 0ull);
-          if (nk == kept) break;
-          kept = nk;
-        }
-        if (lane == 0) {
-          kept_s[b & 1] = kept;
-          if (kept) atomicOr(&keepbits[b], kept);
-        }
-        const u64 w1 = w1_s[(rel % RED_WIN) * 64 + lane];
-        if (((kept >> lane) & 1ull) && w1) atomicOr(&removed[rel + 1], w1);
-      }
+    // Flag-synchronised pipeline instead of one workgroup barrier per block (measured: 1.5 us per block with
+    // the barrier -- every block waited for a pusher to issue its 64 row loads -- against ~0.3 us of actual
+    // dependency chain).  wave 0 publishes `kept` of block rel and bumps kept_ready; pusher g bumps
+    // pushed[g] after OR-ing a block's rows into removed[]; wave 0 starts block rel once every block <= rel - 2
+    // has been pushed (block rel - 1 reaches it through the transposed word 1 w1T and the previous `kept`).  All flags live in
+    // LDS; the waves of a workgroup are co-resident, so the spin loops always make progress.
+    if (tid <= RED_GROUPS) flag_s[tid] = 0;
+    u64 prev_kept = 0, prev2_kept = 0;  // wave 0: `kept` of the previous two blocks of this segment
+    for (int bw = b0; bw <= b1; bw += RED_WIN) {  // windows of wave 0's staged inputs (one for <= 4096 boxes)
       __syncthreads();
-      if (wid != 0 && (rel % RED_GROUPS) == grp) {  // this group's block: `kept` is known now
-        const u64 kept = kept_s[b & 1];
-        const int nlater = b1 - b;
-        u64 acc = 0;
-#pragma unroll
-        for (int r = 0; r < RED_PUSH_ROWS; r++)  // kept rows lie in [s, e) by construction
-          acc |= ((kept >> r) & 1ull) ? rows[r] : 0ull;
-        if ((2 + lane) <= nlater && acc) atomicOr(&removed[rel + 2 + lane], acc);
-        // categories with more than ~4200 boxes: remaining words, fetched now that `kept` is known
-        for (int w = 66 + lane; w <= nlater; w += 64) {
-          u64 a2 = 0;
-          for (int r = 0; r < RED_PUSH_ROWS; r++) {
-            if ((kept >> r) & 1ull) a2 |= mask[((long)b * 64 + r) * wcap + w];
+      if (dbg && seg == 0 && tid == 0) dbg[127] = wall_clock64();
+      const int wend = min(b1, bw + RED_WIN - 1);
+      const int rows_w = (wend - bw + 1) * 64;
+      for (int q = tid; q < rows_w; q += RED_THREADS) {
+        const int row = bw * 64 + q;
+        const long rc = min(row, n - 1);
+        const u64 d = diagT[rc], wt = w1T[rc], wu = w2T[rc];  // (w1T / w2T of the first blocks: never written nor used)
+        const bool valid = row >= s && row < e;
+        dt_s[q] = valid ? d : 0ull;
+        wt_s[q] = (valid && (row >> 6) > b0) ? wt : 0ull;
+        wu_s[q] = (valid && (row >> 6) > b0 + 1) ? wu : 0ull;
+      }
+      if (dbg && seg == 0 && lane == 0 && wid < 2) dbg[124 + wid] = wall_clock64();
+      __syncthreads();
+      if (dbg && seg == 0 && tid == 0) dbg[122] = wall_clock64();
+      if (wid == 0) {
+        for (int b = bw; b <= wend; b++) {
+          const int rel = b - b0;
+          if (dbg && seg == 0 && lane == 0 && rel < 120) dbg[rel] = wall_clock64();  // profiling only
+          const u64 dt = dt_s[(b - bw) * 64 + lane], wt = wt_s[(b - bw) * 64 + lane], wu = wu_s[(b - bw) * 64 + lane];
+          // wait for the pushers: group g must have finished its blocks <= rel - 2
+          if (rel >= RED_NEAR) {
+            const int g = lane < RED_GROUPS ? lane : 0;
+            const int ulast = (rel - RED_NEAR + 1) * RED_SPLIT - 1;  // last unit of block rel - RED_NEAR
+            const int need = ulast >= g ? (ulast - g) / RED_GROUPS + 1 : 0;
+            while (__ballot(__hip_atomic_load(&flag_s[1 + g], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need))
+              __builtin_amdgcn_s_sleep(1);
           }
-          if (a2) atomicOr(&removed[rel + w], a2);
+          const int row = b * 64 + lane;
+          const bool valid = row >= s && row < e;
+          const u64 rem = __hip_atomic_load(&removed[rel], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          // suppressed by a kept row two or more blocks back (pushers), or of the previous block (transposed
+          // word 1 against the previous `kept`: no LDS atomic + re-read on the chain)
+          const bool cj = valid && !((rem >> lane) & 1ull) && ((wt & prev_kept) | (wu & prev2_kept)) == 0ull;
+          u64 kept = __ballot(cj);
+          int iters = 0;
+          for (;;) {
+            const u64 nk = __ballot(cj && (dt & kept) == 0ull);
+            iters++;
+            if (nk == kept) break;
+            kept = nk;
+          }
+          prev2_kept = prev_kept;
+          prev_kept = kept;
+          if (dbg && seg == 0 && lane == 0 && rel < 120) dbg[128 + rel] = (u64)iters;
+          if (lane == 0) {
+            kept_s[(b - bw)] = kept;
+            if (kept) atomicOr(&keepbits[b], kept);
+            __hip_atomic_store(&flag_s[0], rel + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
         }
-        if (b + RED_GROUPS <= b1) load_block(b + RED_GROUPS);  // in flight for the next 3 barriers
+        if (dbg && seg == 0 && lane == 0) dbg[123] = wall_clock64();
+      } else {
+        // pusher: `rows` = word 2 + lane of the 32 rows of the unit it owns next; the array lives only inside this
+        // branch and is redefined by an unconditional (clamped) prefetch on every iteration -- carried across the
+        // outer loops or loaded conditionally, the compiler kept two copies, spilled and drained vmcnt per unit
+        const int u0 = (bw - b0) * RED_SPLIT, u1 = (wend - b0 + 1) * RED_SPLIT - 1;
+        u64 rows[RED_PUSH_ROWS];
+        auto load_unit = [&](int u) {
+          // rows up to n64 - 1 are allocated (never kept if >= n): the row base is a wave-uniform SGPR address
+          // lanes beyond the segment's last block re-read the last needed word (same cache line, masked at use):
+          // 64 distinct words per row pulled 5 lines per row through this CU where ~2 are needed
+          const int wl = min(wi, max(b1 - (b0 + u / RED_SPLIT), 0));
+          const u64* base = mask + ((long)(b0 + u / RED_SPLIT) * 64 + (u % RED_SPLIT) * RED_PUSH_ROWS) * wcap + wl;
+#pragma unroll
+          for (int r = 0; r < RED_PUSH_ROWS; r++) rows[r] = base[(long)r * wcap];
+        };
+        const int ufirst = u0 + ((grp - u0) % RED_GROUPS + RED_GROUPS) % RED_GROUPS;
+        load_unit(min(ufirst, u1));
+        for (int u = ufirst; u <= u1; u += RED_GROUPS) {
+          const int rel = u / RED_SPLIT, b = b0 + rel;  // u % RED_GROUPS == grp
+          while (__hip_atomic_load(&flag_s[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= rel)
+            __builtin_amdgcn_s_sleep(1);
+          const int r0 = (u % RED_SPLIT) * RED_PUSH_ROWS;
+          const uint32_t kept = (uint32_t)(kept_s[(b - bw)] >> r0);
+          const int nlater = b1 - b;
+          u64 acc = 0;
+#pragma unroll
+          for (int r = 0; r < RED_PUSH_ROWS; r++)  // kept rows lie in [s, e) by construction
+            acc |= ((kept >> r) & 1u) ? rows[r] : 0ull;
+          if ((RED_NEAR + lane) <= nlater && acc) atomicOr(&removed[rel + RED_NEAR + lane], acc);
+          // categories with more than ~4200 boxes: remaining words, fetched now that `kept` is known
+          for (int w = 64 + RED_NEAR + lane; w <= nlater; w += 64) {
+            u64 a2 = 0;
+            for (int r = 0; r < RED_PUSH_ROWS; r++) {
+              if ((kept >> r) & 1u) a2 |= mask[((long)b * 64 + r0 + r) * wcap + w];
+            }
+            if (a2) atomicOr(&removed[rel + w], a2);
+          }
+          load_unit(min(u + RED_GROUPS, u1));
+          // release: the LDS ORs above are complete before the count becomes visible
+          if (lane == 0)
+            __hip_atomic_store(&flag_s[1 + grp], u / RED_GROUPS + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
       }
     }
   }
@@ -540,18 +750,30 @@ extern "C" int d2amd_nms(const float* boxes, const float* scores, const int64_t*
   const int N = (int)n, nblocks = (N + 63) / 64;
   const int T = 256;
   const bool small = N <= RANK_MAX_N;
-  D2_HIP_OK(hipMemsetAsync(w.keepbits, 0, w.zero_bytes, s));
   const int* rankpos = nullptr;
   const uint32_t* cls_s = nullptr;
   if (small) {
-    const int rk_rounds = cdiv(cdiv(N, RK_IB), 240);  // <= 240 workgroups: one round on 256 CUs
-    const int rk_grid = cdiv(N, RK_IB * rk_rounds);
+    const int zero_words = (int)(w.zero_bytes / 4);
+    const int npad = cdiv(N, RK_GROUP) * RK_GROUP;
+    hipLaunchKernelGGL(nms_prep_kernel, dim3(cdiv(npad, T)), dim3(T), 0, s, scores, idxs, N, (uint4*)w.rk_keys,
+                       (uint32_t*)w.keepbits, zero_words);
+    D2_LAUNCH_OK();
+    const int rk_chunks = cdiv(N, RK_JC);
+    const dim3 rk_grid(rk_chunks, cdiv(cdiv(N, 64), RK_THREADS / 64));
     if (rotated)
-      hipLaunchKernelGGL((nms_rank_kernel<5>), dim3(rk_grid), dim3(RK_THREADS), 0, s, boxes, scores, idxs, N,
-                         w.order, w.rankpos, w.cls_s, w.boxes_s, w.counters, rk_rounds);
+      hipLaunchKernelGGL((nms_rank_kernel<5>), rk_grid, dim3(RK_THREADS), 0, s, boxes, idxs, (const uint4*)w.rk_keys, N,
+                         w.order, w.rankpos, w.cls_s, w.boxes_s, w.counters, w.rk_cnt, rk_chunks);
     else
-      hipLaunchKernelGGL((nms_rank_kernel<4>), dim3(rk_grid), dim3(RK_THREADS), 0, s, boxes, scores, idxs, N,
-                         w.order, w.rankpos, w.cls_s, w.boxes_s, w.counters, rk_rounds);
+      hipLaunchKernelGGL((nms_rank_kernel<4>), rk_grid, dim3(RK_THREADS), 0, s, boxes, idxs, (const uint4*)w.rk_keys, N,
+                         w.order, w.rankpos, w.cls_s, w.boxes_s, w.counters, w.rk_cnt, rk_chunks);
+    D2_LAUNCH_OK();
+    if (rotated)
+      hipLaunchKernelGGL((nms_rank_scatter_kernel<5>), dim3(cdiv(N, T)), dim3(T), 0, s, boxes, (const uint4*)w.rk_keys,
+                         N, w.rk_cnt, rk_chunks, w.order, w.rankpos, w.cls_s, w.boxes_s);
+    else
+      hipLaunchKernelGGL((nms_rank_scatter_kernel<4>), dim3(cdiv(N, T)), dim3(T), 0, s, boxes, (const uint4*)w.rk_keys,
+                         N, w.rk_cnt, rk_chunks, w.order, w.rankpos, w.cls_s, w.boxes_s);
+#undef D2_RANK
     D2_LAUNCH_OK();
     if (idxs) {
       rankpos = w.rankpos;
@@ -560,6 +782,7 @@ extern "C" int d2amd_nms(const float* boxes, const float* scores, const int64_t*
       D2_LAUNCH_OK();
     }
   } else {
+    D2_HIP_OK(hipMemsetAsync(w.keepbits, 0, w.zero_bytes, s));
     hipLaunchKernelGGL(nms_init_kernel, dim3(cdiv(N, T)), dim3(T), 0, s, w.iota, N);
     D2_LAUNCH_OK();
     size_t tb = w.sort_temp_bytes;
@@ -584,17 +807,50 @@ extern "C" int d2amd_nms(const float* boxes, const float* scores, const int64_t*
     D2_LAUNCH_OK();
   }
   dim3 mgrid(nblocks, wcap);
-  if (rotated)
-    hipLaunchKernelGGL((nms_mask_kernel<true>), mgrid, dim3(64), 0, s, w.boxes_s, cls_s, N, wcap, iou_threshold,
-                       w.mask, w.diagT);
-  else
-    hipLaunchKernelGGL((nms_mask_kernel<false>), mgrid, dim3(64), 0, s, w.boxes_s, cls_s, N, wcap, iou_threshold,
-                       w.mask, w.diagT);
+  if (rotated) {
+    hipLaunchKernelGGL(nms_mask_rot_kernel, mgrid, dim3(64), 0, s, w.boxes_s, N, wcap, iou_threshold, w.mask, w.diagT,
+                       w.w1T, w.w2T);
+  } else {
+    // division-free threshold test (see nms_mask_kernel): f = largest float <= thr, g = next float up
+    float f = (float)iou_threshold;
+    if ((double)f > iou_threshold) f = nextafterf(f, -INFINITY);
+    const float g = nextafterf(f, INFINITY);
+    const bool fast = iou_threshold >= 1e-30 && iou_threshold <= 1e30;  // f, g normal
+    const double mid = ((double)f + (double)g) * 0.5;
+    uint32_t gbits;
+    memcpy(&gbits, &g, 4);
+    const bool tie_up = (gbits & 1u) == 0u;
+    const int use_cls = idxs ? 1 : 0;
+#define D2_MASK(F_, T_)                                                                                          \
+  hipLaunchKernelGGL((nms_mask_kernel<F_, T_>), mgrid, dim3(64), 0, s, w.boxes_s, use_cls, N, wcap, iou_threshold, \
+                     mid, w.mask, w.diagT, w.w1T, w.w2T)
+    static const bool mask_exact = getenv("D2AMD_NMS_MASK_EXACT") != nullptr;  // test switch: literal formula
+    if (!fast || mask_exact) D2_MASK(false, false);
+    else if (tie_up) D2_MASK(true, true);
+    else D2_MASK(true, false);
+#undef D2_MASK
+  }
   D2_LAUNCH_OK();
   const int rgrid = idxs ? 512 : 1;
-  hipLaunchKernelGGL(nms_reduce_kernel, dim3(rgrid), dim3(RED_THREADS), (size_t)wcap * 8, s, w.mask, w.diagT, cls_s,
-                     N, wcap, mpc, w.seg_start, w.counters, w.keepbits);
+  u64* red_dbg = nullptr;
+  const char* red_stamps = getenv("D2AMD_NMS_STAMPS");  // profiling only: per-block stamps of segment 0
+  if (red_stamps) {
+    D2_HIP_OK(hipMalloc(&red_dbg, 256 * 8));
+    D2_HIP_OK(hipMemsetAsync(red_dbg, 0, 256 * 8, s));
+  }
+  hipLaunchKernelGGL(nms_reduce_kernel, dim3(rgrid), dim3(RED_THREADS), (size_t)wcap * 8, s, w.mask, w.diagT, w.w1T, w.w2T, cls_s,
+                     N, wcap, mpc, w.seg_start, w.counters, w.keepbits, red_dbg);
   D2_LAUNCH_OK();
+  if (red_stamps) {
+    u64 h[256];
+    D2_HIP_OK(hipStreamSynchronize(s));
+    D2_HIP_OK(hipMemcpy(h, red_dbg, sizeof(h), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[d2amd nms] per-block 10ns ticks (fixed-point iterations):");
+    for (int i = 1; i < 120 && h[i]; i++) fprintf(stderr, " %llu(%llu)", h[i] - h[i - 1], h[128 + i - 1]);
+    fprintf(stderr, "\n[d2amd nms] phases (10ns ticks): segment search %llu, staging %llu, block loop %llu; staging loads done wave0 +%llu, pusher +%llu; sync1 +%llu sync2 +%llu\n",
+            h[121] - h[120], h[122] - h[121], h[123] - h[122], h[124] - h[121], h[125] - h[121], h[126] - h[121], h[127] - h[121]);
+    (void)hipFree(red_dbg);
+  }
   if (small) {
     hipLaunchKernelGGL(nms_finalize_small_kernel, dim3(1), dim3(FIN_THREADS), 0, s, w.keepbits, rankpos, w.order, N,
                        keep_out, w.counters, result);
