@@ -155,7 +155,7 @@ __device__ __forceinline__ uint4 rank_key(float score, int64_t c, int t) {
 }
 
 // Zeroes the reduction's accumulators (replaces a memset launch) and builds the key records.
-__global__ void nms_prep_kernel(const float* __restrict__ scores, const int64_t* __restrict__ idxs, int n,
+__device__ __forceinline__ void nms_prep_body(const float* __restrict__ scores, const int64_t* __restrict__ idxs, int n,
                                 uint4* __restrict__ keys, uint32_t* __restrict__ zero, int zero_words) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   for (int q = t; q < zero_words; q += gridDim.x * blockDim.x) zero[q] = 0u;
@@ -177,13 +177,14 @@ __global__ void nms_prep_kernel(const float* __restrict__ scores, const int64_t*
 // table with one read per lane per pair: 44 us at n = 8.8k).  Partial counts are added to global counters; the
 // wave that completes a block's last chunk scatters that block.
 template <int BW>
-__global__ __launch_bounds__(RK_THREADS) void nms_rank_kernel(
+__device__ __forceinline__ void nms_rank_body(
     const float* __restrict__ boxes, const int64_t* __restrict__ idxs, const uint4* __restrict__ keys, int n,
     int* __restrict__ order, int* __restrict__ rankpos, uint32_t* __restrict__ cls_s, float* __restrict__ boxes_s,
     int* __restrict__ counters, int* __restrict__ rk_cnt, int nchunks) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int n64 = (n + 63) & ~63;
   const int j0 = blockIdx.x * RK_JC;  // RK_JC is a multiple of RK_GROUP
+  if (j0 >= n) return;                // (batched launch: the grid is sized for the largest image)
   const int jn = min(RK_JC, n - j0);
   const int ib = blockIdx.y * (RK_THREADS / 64) + wid;  // block of 64 boxes
   const int i = ib * 64 + lane;
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(RK_THREADS) void nms_rank_kernel(
 }
 
 template <int BW>
-__global__ void nms_rank_scatter_kernel(const float* __restrict__ boxes, const uint4* __restrict__ keys, int n,
+__device__ __forceinline__ void nms_rank_scatter_body(const float* __restrict__ boxes, const uint4* __restrict__ keys, int n,
                                         const int* __restrict__ rk_cnt, int nchunks, int* __restrict__ order,
                                         int* __restrict__ rankpos, uint32_t* __restrict__ cls_s,
                                         float* __restrict__ boxes_s) {
@@ -238,7 +239,7 @@ __global__ void nms_rank_scatter_kernel(const float* __restrict__ boxes, const u
 }
 
 // segment starts of the class-major sequence (small path; the radix path finds them while gathering)
-__global__ void nms_segments_kernel(const uint32_t* __restrict__ cls_s, int n, int* seg_start, int* counters) {
+__device__ __forceinline__ void nms_segments_body(const uint32_t* __restrict__ cls_s, int n, int* seg_start, int* counters) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   const uint32_t c = cls_s[p], cprev = cls_s[max(p - 1, 0)];
@@ -335,7 +336,7 @@ struct ColGroup { float v[4][BOX_REC]; };  // 4 column records = 2 x s_load_dwor
 // sign of a zero, which cannot change a `> thr` outcome.  Anything else (a non-finite coordinate in the tile,
 // denom outside (0, inf), an out-of-range threshold) takes the literal formula.
 template <bool FAST, bool TIE_UP>
-__global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes_s, int use_cls, int n, int wcap,
+__device__ __forceinline__ void nms_mask_body(const float* __restrict__ boxes_s, int use_cls, int n, int wcap,
                                                       double thr, double mid, u64* __restrict__ mask,
                                                       u64* __restrict__ diagT, u64* __restrict__ w1T,
                                                       u64* __restrict__ w2T) {
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
   const int row = rb * 64 + lane;
   const int col0 = cb * 64;
   const int nblocks = (n + 63) >> 6;
-  if (cb >= nblocks) return;  // never read by the reduction
+  if (cb >= nblocks || w >= wcap) return;  // never read by the reduction (or: batched grid larger than this image)
   u64 word = 0;
   bool live = true;
   if (use_cls) {
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
 // Rotated tile: the polygon clip is not symmetric in floating point and the reference evaluates
 // iou(kept box, later box) (nms_rotated_cpu.cpp:45-54): rows are the earlier boxes, so that is the order
 // used here, once per pair (the transposed words come from the bit transpose of the same results).
-__global__ __launch_bounds__(64) void nms_mask_rot_kernel(const float* __restrict__ boxes_s, int n, int wcap,
+__device__ __forceinline__ void nms_mask_rot_body(const float* __restrict__ boxes_s, int n, int wcap,
                                                           double thr, u64* __restrict__ mask,
                                                           u64* __restrict__ diagT, u64* __restrict__ w1T,
                                                           u64* __restrict__ w2T) {
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(64) void nms_mask_rot_kernel(const float* __restric
   const int row = rb * 64 + lane;
   const int col0 = cb * 64;
   const int nblocks = (n + 63) >> 6;
-  if (cb >= nblocks) return;
+  if (cb >= nblocks || w >= wcap) return;
   u64 word = 0;
   const uint32_t row_last = __float_as_uint(boxes_s[(long)min(rb * 64 + 63, n - 1) * BOX_REC + 5]);
   const uint32_t col_first = __float_as_uint(boxes_s[(long)col0 * BOX_REC + 5]);
@@ -487,7 +488,7 @@ constexpr int RED_SPLIT = 2;         // a block's 64 rows are pushed as 2 units 
 constexpr int RED_PUSH_ROWS = 64 / RED_SPLIT;  // (64-row units needed 128 VGPRs and spilled, which serialised the row loads)
 constexpr int RED_WIN = 64;         // blocks of (DT, word 1) staged in LDS at a time (2 x 32 KiB)
 
-__global__ __launch_bounds__(RED_THREADS) void nms_reduce_kernel(const u64* __restrict__ mask,
+__device__ __forceinline__ void nms_reduce_body(const u64* __restrict__ mask,
                                                                  const u64* __restrict__ diagT,
                                                                  const u64* __restrict__ w1T,
                                                                  const u64* __restrict__ w2T,
@@ -635,7 +636,7 @@ __global__ __launch_bounds__(RED_THREADS) void nms_reduce_kernel(const u64* __re
 // ---- step 4: compaction ------------------------------------------------------------------------
 // small n: one workgroup does scatter-to-rank-order and ordered compaction out of LDS
 constexpr int FIN_THREADS = 1024;
-__global__ __launch_bounds__(FIN_THREADS) void nms_finalize_small_kernel(
+__device__ __forceinline__ void nms_finalize_small_body(
     const u64* __restrict__ keepbits, const int* __restrict__ rankpos, const int* __restrict__ order, int n,
     int64_t* __restrict__ keep_out, const int* __restrict__ counters, int64_t* __restrict__ result) {
   __shared__ uint8_t flags[RANK_MAX_N];
@@ -716,6 +717,69 @@ __global__ __launch_bounds__(COMPACT_BLOCK) void nms_compact_kernel(const uint8_
   if (tid == 0) { result[0] = base_s; result[1] = counters[1]; }
 }
 
+// ---- batched launch: blockIdx.z = image --------------------------------------------------------
+// The per-image pipelines of a batch (RPN / RetinaNet NMS of every image) run as ONE launch per stage: half the
+// launches and no stream fork/join on the host, and the latency-bound stages (reduction, compaction) of all
+// images overlap on the device.  The grid of a stage is sized for the largest image; the bodies exit early.
+constexpr int NMS_MAX_BATCH = 8;
+struct NmsImg {
+  const float* boxes;
+  const float* scores;
+  const int64_t* idxs;
+  int n, wcap, mpc, rk_chunks;
+  NmsWorkspace w;
+  int64_t* keep_out;
+  int64_t* result;
+  const int* rankpos;      // null without categories: segment order == rank order
+  const uint32_t* cls_s;
+};
+struct NmsBatch {
+  double thr, mid;
+  u64* dbg;
+  int count;
+  NmsImg img[NMS_MAX_BATCH];
+};
+
+__global__ void nms_prep_kernel(const NmsBatch B) {
+  const NmsImg& I = B.img[blockIdx.z];
+  nms_prep_body(I.scores, I.idxs, I.n, (uint4*)I.w.rk_keys, (uint32_t*)I.w.keepbits, (int)(I.w.zero_bytes / 4));
+}
+template <int BW>
+__global__ __launch_bounds__(RK_THREADS) void nms_rank_kernel(const NmsBatch B) {
+  const NmsImg& I = B.img[blockIdx.z];
+  nms_rank_body<BW>(I.boxes, I.idxs, (const uint4*)I.w.rk_keys, I.n, I.w.order, I.w.rankpos, I.w.cls_s, I.w.boxes_s,
+                    I.w.counters, I.w.rk_cnt, I.rk_chunks);
+}
+template <int BW>
+__global__ void nms_rank_scatter_kernel(const NmsBatch B) {
+  const NmsImg& I = B.img[blockIdx.z];
+  nms_rank_scatter_body<BW>(I.boxes, (const uint4*)I.w.rk_keys, I.n, I.w.rk_cnt, I.rk_chunks, I.w.order, I.w.rankpos,
+                            I.w.cls_s, I.w.boxes_s);
+}
+__global__ void nms_segments_kernel(const NmsBatch B) {
+  const NmsImg& I = B.img[blockIdx.z];
+  if (I.cls_s) nms_segments_body(I.w.cls_s, I.n, I.w.seg_start, I.w.counters);
+}
+template <bool FAST, bool TIE_UP>
+__global__ __launch_bounds__(64) void nms_mask_kernel(const NmsBatch B) {
+  const NmsImg& I = B.img[blockIdx.z];
+  nms_mask_body<FAST, TIE_UP>(I.w.boxes_s, I.cls_s ? 1 : 0, I.n, I.wcap, B.thr, B.mid, I.w.mask, I.w.diagT, I.w.w1T,
+                              I.w.w2T);
+}
+__global__ __launch_bounds__(64) void nms_mask_rot_kernel(const NmsBatch B) {
+  const NmsImg& I = B.img[blockIdx.z];
+  nms_mask_rot_body(I.w.boxes_s, I.n, I.wcap, B.thr, I.w.mask, I.w.diagT, I.w.w1T, I.w.w2T);
+}
+__global__ __launch_bounds__(RED_THREADS) void nms_reduce_kernel(const NmsBatch B) {
+  const NmsImg& I = B.img[blockIdx.z];
+  nms_reduce_body(I.w.mask, I.w.diagT, I.w.w1T, I.w.w2T, I.cls_s, I.n, I.wcap, I.mpc, I.w.seg_start, I.w.counters,
+                  I.w.keepbits, blockIdx.z == 0 ? B.dbg : nullptr);
+}
+__global__ __launch_bounds__(FIN_THREADS) void nms_finalize_small_kernel(const NmsBatch B) {
+  const NmsImg& I = B.img[blockIdx.z];
+  nms_finalize_small_body(I.w.keepbits, I.rankpos, I.w.order, I.n, I.keep_out, I.w.counters, I.result);
+}
+
 }  // namespace d2amd
 
 using namespace d2amd;
@@ -728,6 +792,154 @@ extern "C" size_t d2amd_nms_workspace_bytes(int64_t n, int64_t max_per_class, in
   return w.total;
 }
 
+// threshold constants of the division-free mask test (see nms_mask_body): f = largest float <= thr, g = next up
+struct MaskThr { double mid; bool fast, tie_up; };
+static MaskThr mask_thr(double thr) {
+  float f = (float)thr;
+  if ((double)f > thr) f = nextafterf(f, -INFINITY);
+  const float g = nextafterf(f, INFINITY);
+  uint32_t gbits;
+  memcpy(&gbits, &g, 4);
+  MaskThr m;
+  m.fast = thr >= 1e-30 && thr <= 1e30;  // f, g normal
+  m.mid = ((double)f + (double)g) * 0.5;
+  m.tie_up = (gbits & 1u) == 0u;
+  return m;
+}
+
+// mask + reduction of the images in B (every image already has its segment-ordered box records)
+static int nms_mask_reduce(NmsBatch& B, int rotated, bool any_cls, hipStream_t s) {
+  int nb_max = 0, wcap_max = 0;
+  for (int k = 0; k < B.count; k++) {
+    nb_max = std::max(nb_max, (B.img[k].n + 63) / 64);
+    wcap_max = std::max(wcap_max, B.img[k].wcap);
+  }
+  const dim3 mgrid(nb_max, wcap_max, B.count);
+  if (rotated) {
+    hipLaunchKernelGGL(nms_mask_rot_kernel, mgrid, dim3(64), 0, s, B);
+  } else {
+    const MaskThr m = mask_thr(B.thr);
+    B.mid = m.mid;
+    static const bool mask_exact = getenv("D2AMD_NMS_MASK_EXACT") != nullptr;  // test switch: literal formula
+    if (!m.fast || mask_exact) hipLaunchKernelGGL((nms_mask_kernel<false, false>), mgrid, dim3(64), 0, s, B);
+    else if (m.tie_up) hipLaunchKernelGGL((nms_mask_kernel<true, true>), mgrid, dim3(64), 0, s, B);
+    else hipLaunchKernelGGL((nms_mask_kernel<true, false>), mgrid, dim3(64), 0, s, B);
+  }
+  D2_LAUNCH_OK();
+  const int rgrid = any_cls ? 512 : 1;
+  const char* red_stamps = getenv("D2AMD_NMS_STAMPS");  // profiling only: per-block stamps of segment 0 of image 0
+  B.dbg = nullptr;
+  if (red_stamps) {
+    D2_HIP_OK(hipMalloc(&B.dbg, 256 * 8));
+    D2_HIP_OK(hipMemsetAsync(B.dbg, 0, 256 * 8, s));
+  }
+  hipLaunchKernelGGL(nms_reduce_kernel, dim3(rgrid, 1, B.count), dim3(RED_THREADS), (size_t)wcap_max * 8, s, B);
+  D2_LAUNCH_OK();
+  if (red_stamps) {
+    u64 h[256];
+    D2_HIP_OK(hipStreamSynchronize(s));
+    D2_HIP_OK(hipMemcpy(h, B.dbg, sizeof(h), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[d2amd nms] per-block 10ns ticks (fixed-point iterations):");
+    for (int i = 1; i < 120 && h[i]; i++) fprintf(stderr, " %llu(%llu)", h[i] - h[i - 1], h[128 + i - 1]);
+    fprintf(stderr, "\n[d2amd nms] phases (10ns ticks): segment search %llu, staging %llu, block loop %llu; staging loads done wave0 +%llu, pusher +%llu; sync1 +%llu sync2 +%llu\n",
+            h[121] - h[120], h[122] - h[121], h[123] - h[122], h[124] - h[121], h[125] - h[121], h[126] - h[121], h[127] - h[121]);
+    (void)hipFree(B.dbg);
+    B.dbg = nullptr;
+  }
+  return D2AMD_OK;
+}
+
+// whole pipeline of a batch of images that all take the brute-force ranking path (n <= RANK_MAX_N)
+static int nms_run_small(NmsBatch& B, int rotated, hipStream_t s) {
+  const int T = 256;
+  int n_max = 0, chunks_max = 0;
+  bool any_cls = false;
+  for (int k = 0; k < B.count; k++) {
+    n_max = std::max(n_max, B.img[k].n);
+    chunks_max = std::max(chunks_max, B.img[k].rk_chunks);
+    any_cls |= B.img[k].idxs != nullptr;
+  }
+  const int npad = cdiv(n_max, RK_GROUP) * RK_GROUP;
+  hipLaunchKernelGGL(nms_prep_kernel, dim3(cdiv(npad, T), 1, B.count), dim3(T), 0, s, B);
+  D2_LAUNCH_OK();
+  const dim3 rk_grid(chunks_max, cdiv(cdiv(n_max, 64), RK_THREADS / 64), B.count);
+  if (rotated) hipLaunchKernelGGL((nms_rank_kernel<5>), rk_grid, dim3(RK_THREADS), 0, s, B);
+  else hipLaunchKernelGGL((nms_rank_kernel<4>), rk_grid, dim3(RK_THREADS), 0, s, B);
+  D2_LAUNCH_OK();
+  const dim3 ngrid(cdiv(n_max, T), 1, B.count);
+  if (rotated) hipLaunchKernelGGL((nms_rank_scatter_kernel<5>), ngrid, dim3(T), 0, s, B);
+  else hipLaunchKernelGGL((nms_rank_scatter_kernel<4>), ngrid, dim3(T), 0, s, B);
+  D2_LAUNCH_OK();
+  if (any_cls) {
+    hipLaunchKernelGGL(nms_segments_kernel, ngrid, dim3(T), 0, s, B);
+    D2_LAUNCH_OK();
+  }
+  const int rc = nms_mask_reduce(B, rotated, any_cls, s);
+  if (rc != D2AMD_OK) return rc;
+  hipLaunchKernelGGL(nms_finalize_small_kernel, dim3(1, 1, B.count), dim3(FIN_THREADS), 0, s, B);
+  D2_LAUNCH_OK();
+  return D2AMD_OK;
+}
+
+static int nms_fill_img(NmsImg& I, const float* boxes, const float* scores, const int64_t* idxs, int64_t n,
+                        int64_t max_per_class, int64_t* keep_out, int64_t* result, void* workspace,
+                        size_t workspace_bytes) {
+  D2_CHECK_ARG(n > 0 && n < (1ll << 31) - 64, "nms: bad n %lld", (long long)n);
+  D2_CHECK_ARG(boxes && scores && keep_out && workspace && result, "nms: null pointer");
+  I.boxes = boxes;
+  I.scores = scores;
+  I.idxs = idxs;
+  I.n = (int)n;
+  I.wcap = wcap_for(n, max_per_class);
+  I.mpc = (max_per_class <= 0 || max_per_class > n) ? (int)n : (int)max_per_class;
+  I.rk_chunks = cdiv((int)n, RK_JC);
+  carve(I.w, workspace, n, I.wcap);
+  if (workspace_bytes < I.w.total) {
+    set_error("nms: workspace too small (%zu < %zu)", workspace_bytes, I.w.total);
+    return D2AMD_EWORKSPACE;
+  }
+  I.keep_out = keep_out;
+  I.result = result;
+  I.rankpos = idxs ? I.w.rankpos : nullptr;
+  I.cls_s = idxs ? I.w.cls_s : nullptr;
+  return D2AMD_OK;
+}
+
+extern "C" int d2amd_nms_batched(int count, const float* const* boxes, const float* const* scores,
+                                 const int64_t* const* idxs, const int64_t* n, double iou_threshold, int rotated,
+                                 const int64_t* max_per_class, int64_t* const* keep_out, int64_t* const* result,
+                                 void* const* workspace, const size_t* workspace_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  D2_CHECK_ARG(count >= 0 && boxes && scores && n && keep_out && result && workspace && workspace_bytes,
+               "nms_batched: null pointer");
+  for (int k0 = 0; k0 < count; k0 += NMS_MAX_BATCH) {
+    NmsBatch B;
+    memset(&B, 0, sizeof(B));
+    B.thr = iou_threshold;
+    for (int k = k0; k < count && k < k0 + NMS_MAX_BATCH; k++) {
+      D2_CHECK_ARG(n[k] >= 0 && result[k], "nms_batched: bad image %d", k);
+      if (n[k] == 0) {
+        D2_HIP_OK(hipMemsetAsync(result[k], 0, 16, s));
+        continue;
+      }
+      D2_CHECK_ARG(n[k] <= RANK_MAX_N, "nms_batched: image %d has %lld boxes (> %d): use d2amd_nms", k,
+                   (long long)n[k], RANK_MAX_N);
+      const int rc = nms_fill_img(B.img[B.count], boxes[k], scores[k], idxs ? idxs[k] : nullptr, n[k],
+                                  max_per_class ? max_per_class[k] : 0, keep_out[k], result[k], workspace[k],
+                                  workspace_bytes[k]);
+      if (rc != D2AMD_OK) return rc;
+      B.count++;
+    }
+    if (B.count) {
+      const int rc = nms_run_small(B, rotated, s);
+      if (rc != D2AMD_OK) return rc;
+    }
+  }
+  return D2AMD_OK;
+}
+
+extern "C" int d2amd_nms_batched_max_boxes(void) { return RANK_MAX_N; }
+
 extern "C" int d2amd_nms(const float* boxes, const float* scores, const int64_t* idxs, int64_t n,
                          double iou_threshold, int rotated, int64_t max_per_class, int64_t* keep_out,
                          int64_t* result, void* workspace, size_t workspace_bytes, void* stream) {
@@ -738,128 +950,44 @@ extern "C" int d2amd_nms(const float* boxes, const float* scores, const int64_t*
     D2_HIP_OK(hipMemsetAsync(result, 0, 16, s));
     return D2AMD_OK;
   }
-  D2_CHECK_ARG(boxes && scores && keep_out && workspace, "nms: null pointer");
-  const int wcap = wcap_for(n, max_per_class);
-  const int mpc = (max_per_class <= 0 || max_per_class > n) ? (int)n : (int)max_per_class;
-  NmsWorkspace w;
-  carve(w, workspace, n, wcap);
-  if (workspace_bytes < w.total) {
-    set_error("nms: workspace too small (%zu < %zu)", workspace_bytes, w.total);
-    return D2AMD_EWORKSPACE;
-  }
-  const int N = (int)n, nblocks = (N + 63) / 64;
+  NmsBatch B;
+  memset(&B, 0, sizeof(B));
+  B.thr = iou_threshold;
+  B.count = 1;
+  NmsImg& I = B.img[0];
+  int rc = nms_fill_img(I, boxes, scores, idxs, n, max_per_class, keep_out, result, workspace, workspace_bytes);
+  if (rc != D2AMD_OK) return rc;
+  if (n <= RANK_MAX_N) return nms_run_small(B, rotated, s);
+  // ---- large inputs: radix sorts instead of the brute-force ranking ----
+  NmsWorkspace& w = I.w;
+  const int N = (int)n;
   const int T = 256;
-  const bool small = N <= RANK_MAX_N;
-  const int* rankpos = nullptr;
-  const uint32_t* cls_s = nullptr;
-  if (small) {
-    const int zero_words = (int)(w.zero_bytes / 4);
-    const int npad = cdiv(N, RK_GROUP) * RK_GROUP;
-    hipLaunchKernelGGL(nms_prep_kernel, dim3(cdiv(npad, T)), dim3(T), 0, s, scores, idxs, N, (uint4*)w.rk_keys,
-                       (uint32_t*)w.keepbits, zero_words);
-    D2_LAUNCH_OK();
-    const int rk_chunks = cdiv(N, RK_JC);
-    const dim3 rk_grid(rk_chunks, cdiv(cdiv(N, 64), RK_THREADS / 64));
-    if (rotated)
-      hipLaunchKernelGGL((nms_rank_kernel<5>), rk_grid, dim3(RK_THREADS), 0, s, boxes, idxs, (const uint4*)w.rk_keys, N,
-                         w.order, w.rankpos, w.cls_s, w.boxes_s, w.counters, w.rk_cnt, rk_chunks);
-    else
-      hipLaunchKernelGGL((nms_rank_kernel<4>), rk_grid, dim3(RK_THREADS), 0, s, boxes, idxs, (const uint4*)w.rk_keys, N,
-                         w.order, w.rankpos, w.cls_s, w.boxes_s, w.counters, w.rk_cnt, rk_chunks);
-    D2_LAUNCH_OK();
-    if (rotated)
-      hipLaunchKernelGGL((nms_rank_scatter_kernel<5>), dim3(cdiv(N, T)), dim3(T), 0, s, boxes, (const uint4*)w.rk_keys,
-                         N, w.rk_cnt, rk_chunks, w.order, w.rankpos, w.cls_s, w.boxes_s);
-    else
-      hipLaunchKernelGGL((nms_rank_scatter_kernel<4>), dim3(cdiv(N, T)), dim3(T), 0, s, boxes, (const uint4*)w.rk_keys,
-                         N, w.rk_cnt, rk_chunks, w.order, w.rankpos, w.cls_s, w.boxes_s);
-#undef D2_RANK
-    D2_LAUNCH_OK();
-    if (idxs) {
-      rankpos = w.rankpos;
-      cls_s = w.cls_s;
-      hipLaunchKernelGGL(nms_segments_kernel, dim3(cdiv(N, T)), dim3(T), 0, s, w.cls_s, N, w.seg_start, w.counters);
-      D2_LAUNCH_OK();
-    }
-  } else {
-    D2_HIP_OK(hipMemsetAsync(w.keepbits, 0, w.zero_bytes, s));
-    hipLaunchKernelGGL(nms_init_kernel, dim3(cdiv(N, T)), dim3(T), 0, s, w.iota, N);
-    D2_LAUNCH_OK();
-    size_t tb = w.sort_temp_bytes;
-    D2_HIP_OK(rocprim::radix_sort_pairs_desc(w.sort_temp, tb, scores, w.keys_out, w.iota, w.order, (unsigned)N, 0,
-                                             32, s, false));
-    if (idxs) {
-      hipLaunchKernelGGL(nms_gather_cls_kernel, dim3(cdiv(N, T)), dim3(T), 0, s, idxs, w.order, N, w.cls_r,
-                         w.counters);
-      D2_LAUNCH_OK();
-      tb = w.sort_temp_bytes;
-      D2_HIP_OK(rocprim::radix_sort_pairs(w.sort_temp, tb, w.cls_r, w.cls_s, w.iota, w.rankpos, (unsigned)N, 0, 16,
-                                          s, false));
-      rankpos = w.rankpos;
-      cls_s = w.cls_s;
-    }
-    if (rotated)
-      hipLaunchKernelGGL((nms_gather_boxes_kernel<5>), dim3(cdiv(N, T)), dim3(T), 0, s, boxes, w.order, rankpos,
-                         cls_s, N, w.boxes_s, w.seg_start, w.counters);
-    else
-      hipLaunchKernelGGL((nms_gather_boxes_kernel<4>), dim3(cdiv(N, T)), dim3(T), 0, s, boxes, w.order, rankpos,
-                         cls_s, N, w.boxes_s, w.seg_start, w.counters);
-    D2_LAUNCH_OK();
-  }
-  dim3 mgrid(nblocks, wcap);
-  if (rotated) {
-    hipLaunchKernelGGL(nms_mask_rot_kernel, mgrid, dim3(64), 0, s, w.boxes_s, N, wcap, iou_threshold, w.mask, w.diagT,
-                       w.w1T, w.w2T);
-  } else {
-    // division-free threshold test (see nms_mask_kernel): f = largest float <= thr, g = next float up
-    float f = (float)iou_threshold;
-    if ((double)f > iou_threshold) f = nextafterf(f, -INFINITY);
-    const float g = nextafterf(f, INFINITY);
-    const bool fast = iou_threshold >= 1e-30 && iou_threshold <= 1e30;  // f, g normal
-    const double mid = ((double)f + (double)g) * 0.5;
-    uint32_t gbits;
-    memcpy(&gbits, &g, 4);
-    const bool tie_up = (gbits & 1u) == 0u;
-    const int use_cls = idxs ? 1 : 0;
-#define D2_MASK(F_, T_)                                                                                          \
-  hipLaunchKernelGGL((nms_mask_kernel<F_, T_>), mgrid, dim3(64), 0, s, w.boxes_s, use_cls, N, wcap, iou_threshold, \
-                     mid, w.mask, w.diagT, w.w1T, w.w2T)
-    static const bool mask_exact = getenv("D2AMD_NMS_MASK_EXACT") != nullptr;  // test switch: literal formula
-    if (!fast || mask_exact) D2_MASK(false, false);
-    else if (tie_up) D2_MASK(true, true);
-    else D2_MASK(true, false);
-#undef D2_MASK
-  }
+  D2_HIP_OK(hipMemsetAsync(w.keepbits, 0, w.zero_bytes, s));
+  hipLaunchKernelGGL(nms_init_kernel, dim3(cdiv(N, T)), dim3(T), 0, s, w.iota, N);
   D2_LAUNCH_OK();
-  const int rgrid = idxs ? 512 : 1;
-  u64* red_dbg = nullptr;
-  const char* red_stamps = getenv("D2AMD_NMS_STAMPS");  // profiling only: per-block stamps of segment 0
-  if (red_stamps) {
-    D2_HIP_OK(hipMalloc(&red_dbg, 256 * 8));
-    D2_HIP_OK(hipMemsetAsync(red_dbg, 0, 256 * 8, s));
-  }
-  hipLaunchKernelGGL(nms_reduce_kernel, dim3(rgrid), dim3(RED_THREADS), (size_t)wcap * 8, s, w.mask, w.diagT, w.w1T, w.w2T, cls_s,
-                     N, wcap, mpc, w.seg_start, w.counters, w.keepbits, red_dbg);
-  D2_LAUNCH_OK();
-  if (red_stamps) {
-    u64 h[256];
-    D2_HIP_OK(hipStreamSynchronize(s));
-    D2_HIP_OK(hipMemcpy(h, red_dbg, sizeof(h), hipMemcpyDeviceToHost));
-    fprintf(stderr, "[d2amd nms] per-block 10ns ticks (fixed-point iterations):");
-    for (int i = 1; i < 120 && h[i]; i++) fprintf(stderr, " %llu(%llu)", h[i] - h[i - 1], h[128 + i - 1]);
-    fprintf(stderr, "\n[d2amd nms] phases (10ns ticks): segment search %llu, staging %llu, block loop %llu; staging loads done wave0 +%llu, pusher +%llu; sync1 +%llu sync2 +%llu\n",
-            h[121] - h[120], h[122] - h[121], h[123] - h[122], h[124] - h[121], h[125] - h[121], h[126] - h[121], h[127] - h[121]);
-    (void)hipFree(red_dbg);
-  }
-  if (small) {
-    hipLaunchKernelGGL(nms_finalize_small_kernel, dim3(1), dim3(FIN_THREADS), 0, s, w.keepbits, rankpos, w.order, N,
-                       keep_out, w.counters, result);
-  } else {
-    hipLaunchKernelGGL(nms_scatter_flags_kernel, dim3(cdiv(N, T)), dim3(T), 0, s, w.keepbits, rankpos, N, w.flag_r);
+  size_t tb = w.sort_temp_bytes;
+  D2_HIP_OK(rocprim::radix_sort_pairs_desc(w.sort_temp, tb, scores, w.keys_out, w.iota, w.order, (unsigned)N, 0, 32,
+                                           s, false));
+  if (idxs) {
+    hipLaunchKernelGGL(nms_gather_cls_kernel, dim3(cdiv(N, T)), dim3(T), 0, s, idxs, w.order, N, w.cls_r, w.counters);
     D2_LAUNCH_OK();
-    hipLaunchKernelGGL(nms_compact_kernel, dim3(1), dim3(COMPACT_BLOCK), 0, s, w.flag_r, w.order, N, keep_out,
-                       w.counters, result);
+    tb = w.sort_temp_bytes;
+    D2_HIP_OK(rocprim::radix_sort_pairs(w.sort_temp, tb, w.cls_r, w.cls_s, w.iota, w.rankpos, (unsigned)N, 0, 16, s,
+                                        false));
   }
+  if (rotated)
+    hipLaunchKernelGGL((nms_gather_boxes_kernel<5>), dim3(cdiv(N, T)), dim3(T), 0, s, boxes, w.order, I.rankpos,
+                       I.cls_s, N, w.boxes_s, w.seg_start, w.counters);
+  else
+    hipLaunchKernelGGL((nms_gather_boxes_kernel<4>), dim3(cdiv(N, T)), dim3(T), 0, s, boxes, w.order, I.rankpos,
+                       I.cls_s, N, w.boxes_s, w.seg_start, w.counters);
+  D2_LAUNCH_OK();
+  rc = nms_mask_reduce(B, rotated, idxs != nullptr, s);
+  if (rc != D2AMD_OK) return rc;
+  hipLaunchKernelGGL(nms_scatter_flags_kernel, dim3(cdiv(N, T)), dim3(T), 0, s, w.keepbits, I.rankpos, N, w.flag_r);
+  D2_LAUNCH_OK();
+  hipLaunchKernelGGL(nms_compact_kernel, dim3(1), dim3(COMPACT_BLOCK), 0, s, w.flag_r, w.order, N, keep_out,
+                     w.counters, result);
   D2_LAUNCH_OK();
   return D2AMD_OK;
 }

@@ -69,17 +69,65 @@ def nms_impl(boxes, scores, idxs, iou_threshold, rotated):
 
 
 _SIDE_STREAMS = {}
+_BATCH_MAX = None
+
+
+def _nms_images_batched(inputs, iou_threshold, rotated):
+    """All images through d2amd_nms_batched: one launch per pipeline stage for the whole batch, one
+    [count, 2] result tensor, one host sync."""
+    ct = _C.ctypes
+    L = _C.lib()
+    dev = inputs[0][0].device
+    bw = 5 if rotated else 4
+    cnt = len(inputs)
+    hold = []
+    arr = lambda vals: (ct.c_void_p * cnt)(*vals)
+    with _C.on_device(dev):
+        result = torch.empty((cnt, 2), dtype=torch.int64, device=dev)
+        pb, ps, pi, pk, pr, pw = [], [], [], [], [], []
+        ns, wb, keeps = [], [], []
+        for k, (boxes, scores, idxs) in enumerate(inputs):
+            assert boxes.dim() == 2 and boxes.shape[1] == bw, boxes.shape
+            n = boxes.shape[0]
+            _C.require_gpu(boxes, scores, idxs, op="nms")
+            boxes = boxes.detach().float().contiguous()
+            scores = scores.detach().float().contiguous()
+            assert scores.shape[0] == n
+            if idxs is not None:
+                idxs = idxs.detach().to(torch.int64).contiguous()
+                assert idxs.shape[0] == n
+            nbytes = L.d2amd_nms_workspace_bytes(n, 0, int(rotated))
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            keep = torch.empty(n, dtype=torch.int64, device=dev)
+            hold.append((boxes, scores, idxs, ws))
+            keeps.append(keep)
+            pb.append(boxes.data_ptr()); ps.append(scores.data_ptr())
+            pi.append(idxs.data_ptr() if idxs is not None else None)
+            pk.append(keep.data_ptr()); pr.append(result.data_ptr() + 16 * k); pw.append(ws.data_ptr())
+            ns.append(n); wb.append(nbytes)
+        _C.check(L.d2amd_nms_batched(cnt, arr(pb), arr(ps), arr(pi), (ct.c_int64 * cnt)(*ns), float(iou_threshold),
+                                     int(rotated), None, arr(pk), arr(pr), arr(pw), (ct.c_size_t * cnt)(*wb),
+                                     _C.stream()))
+    counts = result.tolist()  # the only host sync; `hold` keeps inputs / workspaces alive until here
+    del hold
+    return [_nms_finish(keep, num, flags) for keep, (num, flags) in zip(keeps, counts)]
 
 
 def nms_images(inputs, iou_threshold, rotated=False):
     """NMS of every image of a batch in one call: `inputs` = [(boxes, scores, idxs | None), ...].
     The reference runs the RPN / RetinaNet NMS in a per-image Python loop, each iteration ending in a
     device->host sync (proposal_generator/proposal_utils.py:118-135, meta_arch/dense_detector.py:186-260).
-    Images are independent, so their (latency-bound) device pipelines are enqueued on separate HIP
-    streams that fork from / join into the current stream, and the kept counts are read with ONE sync."""
+    Images are independent: up to d2amd_nms_batched_max_boxes() boxes per image the whole batch runs as one
+    device pipeline (d2amd_nms_batched); larger inputs are enqueued on separate HIP streams that fork from /
+    join into the current stream.  Either way the kept counts are read with ONE sync."""
+    global _BATCH_MAX
     if not inputs:
         return []
+    if _BATCH_MAX is None:
+        _BATCH_MAX = int(_C.lib().d2amd_nms_batched_max_boxes())
     dev = inputs[0][0].device
+    if all(b.shape[0] <= _BATCH_MAX and b.device == dev for b, _s, _i in inputs):
+        return _nms_images_batched(inputs, iou_threshold, rotated)
     cur = torch.cuda.current_stream(dev)
     pool = _SIDE_STREAMS.setdefault(dev.index, [])
     fork = torch.cuda.Event()

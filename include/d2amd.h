@@ -191,6 +191,17 @@ size_t d2amd_nms_workspace_bytes(int64_t n, int64_t max_per_class, int rotated);
 int d2amd_nms(const float* boxes, const float* scores, const int64_t* idxs, int64_t n,
               double iou_threshold, int rotated, int64_t max_per_class, int64_t* keep_out,
               int64_t* result, void* workspace, size_t workspace_bytes, void* stream);
+/* The NMS of every image of a batch as ONE device pipeline (one launch per stage for all images): replaces the
+ * per-image Python loops of find_top_rpn_proposals (proposal_generator/proposal_utils.py:118-135) and of
+ * DenseDetector inference (meta_arch/dense_detector.py:186-260).  Arrays of `count` per-image arguments, each with
+ * the meaning it has in d2amd_nms (idxs / max_per_class may be NULL; idxs[k] may be NULL); workspace[k] sized by
+ * d2amd_nms_workspace_bytes(n[k], ...).  Every n[k] must be <= d2amd_nms_batched_max_boxes() (larger inputs go
+ * through d2amd_nms, which sorts by radix).  Results are identical to `count` calls of d2amd_nms. */
+int d2amd_nms_batched(int count, const float* const* boxes, const float* const* scores,
+                      const int64_t* const* idxs, const int64_t* n, double iou_threshold, int rotated,
+                      const int64_t* max_per_class, int64_t* const* keep_out, int64_t* const* result,
+                      void* const* workspace, const size_t* workspace_bytes, void* stream);
+int d2amd_nms_batched_max_boxes(void);
 
 /* ---- paste_masks_in_image.  detectron2/layers/mask_ops.py:74-147.
  * masks [n,mh,mw] `mask_dtype`; boxes [n,4] fp32; out [n,img_h,img_w] uint8:

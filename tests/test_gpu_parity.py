@@ -291,8 +291,9 @@ def test_batched_nms_config4_100k():
 
 
 def test_batched_nms_images_equals_per_image_loop():
-    """nms_images (one call for the batch, side streams, one host sync) == the per-image loop, bit for bit,
-    including an empty image and images of different sizes."""
+    """nms_images (one call for the batch, one host sync) == the per-image loop, bit for bit, including an empty
+    image and images of different sizes; with an image beyond the batched pipeline's limit the batch takes the
+    side-stream route."""
     from detectron2_amd.layers import batched_nms_images
     rng = np.random.default_rng(77)
     inputs = []
@@ -302,14 +303,67 @@ def test_batched_nms_images_equals_per_image_loop():
         s = ((rng.permutation(n) + 1) / (n + 1)).astype(np.float32)
         idx = rng.integers(0, 5, n)
         inputs.append((cu(b), cu(s), torch.as_tensor(idx).to(DEV)))
+    big = rng.uniform(0, 800, (13000, 4)).astype(np.float32)
+    big[:, 2:] = big[:, :2] + rng.uniform(4, 200, (13000, 2)).astype(np.float32)
+    big_in = (cu(big), cu(((rng.permutation(13000) + 1) / 13001).astype(np.float32)),
+              torch.as_tensor(rng.integers(0, 5, 13000)).to(DEV))
     for rep in range(3):  # repeated calls reuse the side streams
-        got = batched_nms_images(inputs, 0.7)
-        for (b, s, i), g in zip(inputs, got):
-            exp = batched_nms(b, s, i, 0.7)
-            assert g.dtype == torch.int64 and torch.equal(g, exp)
+        for batch in (inputs, inputs + [big_in]):
+            got = batched_nms_images(batch, 0.7)
+            for (b, s, i), g in zip(batch, got):
+                exp = batched_nms(b, s, i, 0.7)
+                assert g.dtype == torch.int64 and torch.equal(g, exp)
     b, s, i = inputs[2]
     assert np.array_equal(got[2].cpu().numpy(),
                           oracle.batched_nms(b.cpu().numpy(), s.cpu().numpy(), i.cpu().numpy(), 0.7))
+
+
+def test_nms_batched_pipeline_mixed_batch():
+    """d2amd_nms_batched: more images than one launch group (8), sizes from 1 to 12288 boxes, an image without
+    categories, ties in the scores, degenerate (zero-area / non-finite) boxes -- each image equals the single-image
+    call and the oracle."""
+    from detectron2_amd.layers.ops import nms_images
+    rng = np.random.default_rng(78)
+    inputs = []
+    for k, n in enumerate((64, 65, 1, 2000, 0, 12288, 513, 129, 8819, 700, 4097)):
+        b = rng.uniform(0, 600, (n, 4)).astype(np.float32)
+        b[:, 2:] = b[:, :2] + rng.uniform(0, 150, (n, 2)).astype(np.float32)
+        s = rng.integers(0, 50, n).astype(np.float32) / 50  # many exact ties
+        if n > 100:
+            b[5] = b[6]                      # duplicates
+            b[7, 2:] = b[7, :2]              # zero area
+            b[9, 0] = np.inf                 # non-finite coordinate: literal formula for its tiles
+            b[11, 1] = np.nan
+        idx = None if k == 2 or k == 7 else torch.as_tensor(rng.integers(0, 3 + k, n)).to(DEV)
+        inputs.append((cu(b), cu(s), idx))
+    got = nms_images(inputs, 0.5)
+    for (b, s, i), g in zip(inputs, got):
+        exp = nms(b, s, 0.5) if i is None else batched_nms(b, s, i, 0.5)
+        assert g.dtype == torch.int64 and torch.equal(g, exp)
+    for k in (3, 6, 7, 9):
+        b, s, i = inputs[k]
+        ref = (oracle.nms(b.cpu().numpy(), s.cpu().numpy(), 0.5) if i is None else
+               oracle.batched_nms(b.cpu().numpy(), s.cpu().numpy(), i.cpu().numpy(), 0.5))
+        assert np.array_equal(got[k].cpu().numpy(), ref), k
+
+
+def test_nms_threshold_boundaries_division_free():
+    """The mask kernel replaces ovr > thr by an exact double-precision product test: probe thresholds that are
+    floats, midpoints between floats and values just around them, on boxes built to have IoU exactly at simple
+    fractions, against the oracle's literal formula; and the literal-formula switch gives the same answers."""
+    rng = np.random.default_rng(79)
+    n = 1500
+    # integer-coordinate boxes on a small lattice: many pairs share an IoU that is an exact small fraction
+    x1 = rng.integers(0, 24, n); y1 = rng.integers(0, 24, n)
+    b = np.stack([x1, y1, x1 + rng.integers(1, 9, n), y1 + rng.integers(1, 9, n)], 1).astype(np.float32)
+    s = _distinct_scores(rng, n)
+    f = np.float32(1 / 3)
+    g = np.nextafter(f, np.float32(1))
+    thrs = [0.5, 0.25, float(f), float(g), (float(f) + float(g)) / 2, float(np.nextafter(f, np.float32(0))),
+            1 / 3, 0.2, 1.0 / 7, 0.6000000238418579, 0.6, 2.0 / 3, 0.75, 1.0, 1e-3]
+    for thr in thrs:
+        got = nms(cu(b), cu(s), thr).cpu().numpy()
+        assert np.array_equal(got, oracle.nms(b, s, thr)), thr
 
 
 def test_nms_rotated_bit_exact(golden_dir):
