@@ -73,6 +73,10 @@ _SIGNATURES = {
     "d2amd_nms_batched_max_boxes": (_i, []),
     "d2amd_paste_masks": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _i, _vp]),
     "d2amd_bitmask_crop_and_resize": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "d2amd_mask_rcnn_inference": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "d2amd_mask_rcnn_loss_workspace_bytes": (_sz, [_i]),
+    "d2amd_mask_rcnn_loss_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "d2amd_mask_rcnn_loss_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "d2amd_deform_conv_workspace_bytes": (_sz, [ctypes.POINTER(DcnParams), _i]),
     "d2amd_deform_conv_forward": (_i, [ctypes.POINTER(DcnParams), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "d2amd_deform_conv_backward": (_i, [ctypes.POINTER(DcnParams)] + [_vp] * 11 + [_sz, _vp]),

@@ -31,6 +31,7 @@ SOURCES = {
     "matcher.hip": ["-ffp-contract=off"],
     "rpn.hip": ["-ffp-contract=off"],
     "mask_targets.hip": ["-ffp-contract=off"],
+    "mask_head.hip": [],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall",
           "-Wno-unused-function", "-Wno-unused-variable", "-fhip-fp32-correctly-rounded-divide-sqrt"]

@@ -47,6 +47,8 @@ struct PoolLevels {
   const int* tile_cnt;    // backward: per tile, number of ROIs that touch it (nullptr: tiles scan the records)
   const void* tile_list;  // backward: [tile][TILE_CAP] TileEntry in ROI order (valid when tile_cnt[tile] <= TILE_CAP)
   unsigned long long* wgstamps;  // profiling only (D2AMD_POOL_STAMPS): per workgroup {start, lists done, loop done, end, #ROIs}
+  const int* queue;  // backward: per-XCD work queues of this launch (tile_lists_kernel), [8][qcap]; nullptr: static order
+  int qcap;
 };
 
 // detectron2/modeling/poolers.py:51-59 in fp32, operation for operation:
@@ -269,6 +271,7 @@ constexpr int LPP = 32;          // lanes (16-B channel groups) per pixel; 256 t
 constexpr int LCH = 512;         // ROIs scanned per list-building pass
 constexpr int MAXP = SEP_MAXP;   // 32: one lane per bin along an axis
 constexpr int CT = 256;          // threads per row-split of a group: 8 pixel columns x 32 channel lanes
+constexpr int QCTR = 32;         // work-queue counters: [pass][xcd] heads, then [pass][xcd] tails
 
 // Per-ROI record written once per backward call by roi_records_kernel: what a tile workgroup needs
 // to decide "does this ROI touch my tile" with a few integer compares (the first versions evaluated
@@ -307,8 +310,11 @@ __device__ __forceinline__ bool footprint_rect(const RoiGeom& g, int H, int W, i
   return true;
 }
 
-__global__ void roi_records_kernel(PoolLevels L, const float* __restrict__ rois, RoiRec* __restrict__ rec) {
+// Also resets the work queues of the backward launches (counters = 0, slots = -1 "no tile").
+__global__ void roi_records_kernel(PoolLevels L, const float* __restrict__ rois, RoiRec* __restrict__ rec,
+                                   int* __restrict__ qmem, int qints) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int i = k; i < qints; i += gridDim.x * blockDim.x) qmem[i] = i < QCTR ? 0 : -1;
   if (k >= L.K) return;
   const float* r = rois + (long)k * 5;
   RoiRec o{};
@@ -352,10 +358,35 @@ __device__ __forceinline__ TileGeom tile_geom(const PoolLevels& L, int tile) {
   return g;
 }
 
+// Work queues (v8).  The static blockIdx -> tile order of the first versions gave each XCD one contiguous run of
+// tiles; the levels are numbered one after the other, so the XCDs that got the coarser level (longer ROI lists)
+// finished last while the others idled (profiles/r01/v5_pool_bwd_timeline.txt: 90 % of the workgroups had started
+// after 46 us of a 98 us kernel), and ~12 % (box) / 55 % (mask) of the workgroups only wrote zeros.  Now the wave
+// that bins the ROIs of a tile also schedules it:
+//   * a tile with no ROI is zero-filled right here (16-B stores) and never reaches a tile workgroup;
+//   * the others are pushed on the queue of their XCD: 4x4-tile blocks are dealt to the 8 XCDs (neighbouring
+//     tiles share the dY rows of their ROIs in that XCD's L2), heavy tiles (>= thr ROIs) from the front, light
+//     ones from the back, so the long lists start first (longest-processing-time-first) and the empty slots in
+//     between cost one L2 round trip each.
+// Workgroup b of a backward launch serves slot b >> 3 of the queue of XCD b & 7 (workgroups are dealt
+// round-robin to the XCDs).  The order in which tiles are processed depends on atomics; the value written to
+// every pixel does not (one workgroup per tile, fixed ROI order): the backward stays deterministic.
+struct TileQueues {
+  int* mem;                        // QCTR counters, then pass 0 queues [8][cap[0]], then pass 1 queues [8][cap[1]]
+  int cap[2], thr[2];
+  int pass_base[POOL_MAX_LEVELS];  // pass-local tile id of the first tile of each level
+  unsigned coarse_mask;            // bit l: level l belongs to pass 1
+  int esize, zero_fill;            // element size; 1: empty tiles are zero-filled here (16-B aligned rows)
+};
+__host__ __device__ __forceinline__ int tile_xcd(int lvl, int n, int ty, int tx, int tiles_x) {
+  return ((ty >> 2) * ((tiles_x + 3) >> 2) + (tx >> 2) + 3 * n + 5 * lvl) & 7;
+}
+
 // L.tile_base here numbers ALL tiles of all levels (make_levels); the two backward launches map their
 // own tile numbering onto it through `first` (tile id of their first tile per level).
 __global__ __launch_bounds__(256) void tile_lists_kernel(PoolLevels L, const RoiRec* __restrict__ rec, int ntiles,
-                                                        int* __restrict__ tile_cnt, TileEntry* __restrict__ tile_list) {
+                                                        int* __restrict__ tile_cnt, TileEntry* __restrict__ tile_list,
+                                                        TileQueues Q) {
   const int lane = threadIdx.x & 63;
   const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (tile >= ntiles) return;
@@ -379,6 +410,26 @@ __global__ __launch_bounds__(256) void tile_lists_kernel(PoolLevels L, const Roi
     cnt += __builtin_popcountll(bal);
   }
   if (lane == 0) tile_cnt[tile] = cnt;
+  if (Q.mem == nullptr) return;
+  const int H = L.H[g.lvl], W = L.W[g.lvl];
+  if (cnt == 0 && Q.zero_fill) {  // nothing to gather: write the zeros here
+    const int rows = min(8, H - g.y0), cols = min(8, W - g.x0);
+    const long px = (long)L.C * Q.esize, rowbytes = cols * px;
+    char* base = (char*)L.data[g.lvl] + (((long)g.n * H + g.y0) * W + g.x0) * px;
+    for (int r = 0; r < rows; r++)
+      for (long o = lane * 16; o < rowbytes; o += 64 * 16)
+        *reinterpret_cast<uint4*>(base + (long)r * W * px + o) = uint4{0u, 0u, 0u, 0u};
+    return;
+  }
+  if (lane == 0) {
+    const int pass = (Q.coarse_mask >> g.lvl) & 1;
+    const int u = Q.pass_base[g.lvl] + (tile - L.tile_base[g.lvl]);  // tile id inside its launch
+    const int x = tile_xcd(g.lvl, g.n, g.y0 >> 3, g.x0 >> 3, (W + 7) >> 3);
+    int* q = Q.mem + QCTR + (pass ? 8 * Q.cap[0] : 0) + x * Q.cap[pass];
+    const bool heavy = cnt >= Q.thr[pass];
+    const int at = atomicAdd(Q.mem + (heavy ? 0 : 16) + pass * 8 + x, 1);
+    q[heavy ? at : Q.cap[pass] - 1 - at] = (min(cnt, 255) << 24) | u;
+  }
 }
 
 // total weight the `grid` samples of bin p put on pixel `pix` along one axis
@@ -407,15 +458,26 @@ __global__ __launch_bounds__(CT * RS * GROUPS, 4) void pool_bwd_nhwc_kernel(Pool
   const int grp = tid / GT, t = tid % GT;  // group, thread in group
   // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, so give each XCD one
   // contiguous run of tiles (neighbouring tiles share the dY rows of their ROIs in that XCD's L2)
-  const int per_xcd = (total_blocks + 7) >> 3;
-  const int logical = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-  if (logical >= total_blocks) return;
+  int logical, slab, tile, qcnt = -1;
+  if (L.queue) {  // work queue of this XCD (tile_lists_kernel): heavy tiles first, empty tiles never arrive
+    const int j = (int)(blockIdx.x >> 3);
+    const int e = L.queue[(long)(blockIdx.x & 7) * L.qcap + j / nslab];
+    if (e < 0) return;
+    logical = (int)blockIdx.x;
+    slab = j % nslab;
+    tile = e & 0xffffff;
+    qcnt = (int)((unsigned)e >> 24);
+  } else {
+    const int per_xcd = (total_blocks + 7) >> 3;
+    logical = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (logical >= total_blocks) return;
+    slab = logical % nslab;
+    tile = logical / nslab;
+  }
   unsigned long long* wst = (L.wgstamps && tid == 0) ? L.wgstamps + 5 * (size_t)logical : nullptr;
   if (wst) wst[0] = wall_clock64();
   unsigned long long wst_list = 0;
   int wst_n = 0;
-  const int slab = logical % nslab;
-  const int tile = logical / nslab;
   int lvl = 0;
 #pragma unroll
   for (int l = 1; l < POOL_MAX_LEVELS; l++)
@@ -479,7 +541,7 @@ __global__ __launch_bounds__(CT * RS * GROUPS, 4) void pool_bwd_nhwc_kernel(Pool
   int tl_cnt = -1;
   if (L.tile_cnt) {
     const int gtile = ids.first[lvl] + (tile - L.tile_base[lvl]);
-    const int c = L.tile_cnt[gtile];
+    const int c = qcnt >= 0 ? qcnt : L.tile_cnt[gtile];
     if (c <= TILE_CAP) {
       tl_cnt = c;
       if (tid < c) {
@@ -716,7 +778,7 @@ static PoolLevels make_levels(const d2amd_pooler_params* p, const void* const* d
   L.min_level = p->min_level; L.max_level = p->max_level; L.canonical_level = p->canonical_level;
   L.canonical_size = p->canonical_box_size;
   { const char* e = getenv("D2AMD_ABLATE"); L.ablate = e ? atoi(e) : 0; }
-  L.dbg = nullptr; L.dbg_block = -1; L.wgstamps = nullptr; L.tile_cnt = nullptr; L.tile_list = nullptr;
+  L.dbg = nullptr; L.dbg_block = -1; L.wgstamps = nullptr; L.tile_cnt = nullptr; L.tile_list = nullptr; L.queue = nullptr; L.qcap = 0;
   int base = 0;
   for (int l = 0; l < p->num_levels; l++) {
     L.data[l] = data[l]; L.H[l] = p->H[l]; L.W[l] = p->W[l]; L.scale[l] = p->spatial_scale[l];
@@ -826,7 +888,7 @@ constexpr int COARSE_TILES = 512;
 template <typename T, int VEC, int GROUPS, int RS>
 static void launch_bwd(const PoolLevels& L, const RoiRec* rec, const void* gout, int nslab, long total,
                        hipStream_t s, const PoolTileIds& ids) {
-  const int grid = (int)((total + 7) / 8) * 8;
+  const int grid = L.queue ? 8 * L.qcap * nslab : (int)((total + 7) / 8) * 8;
   hipLaunchKernelGGL((pool_bwd_nhwc_kernel<T, VEC, GROUPS, RS, 8>), dim3(grid), dim3(CT * RS * GROUPS), 0, s, L, rec,
                      (const T*)gout, nslab, (int)total, ids);
 }
@@ -861,12 +923,42 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
   int* tile_cnt = lists ? (int*)((char*)workspace + off_cnt) : nullptr;
   TileEntry* tile_list = lists ? (TileEntry*)((char*)workspace + off_list) : nullptr;
   const PoolLevels L0 = make_levels(p, (const void* const*)grad_inputs, K);
+  // work queues (see tile_lists_kernel): capacity per XCD = the tiles the 4x4-block deal gives it
+  TileQueues Q{};
+  const size_t off_q = off_list + pool_al((size_t)ntiles * TILE_CAP * sizeof(TileEntry));
+  long nblocks4 = 0;
+  for (int l = 0; l < p->num_levels; l++) nblocks4 += (long)cdiv(cdiv(p->H[l], TILE), 4) * cdiv(cdiv(p->W[l], TILE), 4) * p->N;
+  const bool queues = lists && nblocks4 <= 8192 && ntiles < (1l << 24) &&
+      workspace_bytes >= off_q + (size_t)(QCTR + 8 * ntiles) * sizeof(int) && getenv("D2AMD_POOL_NOQUEUE") == nullptr;
+  if (queues) {
+    int per[2][8] = {};
+    int base[2] = {0, 0};
+    for (int l = 0; l < p->num_levels; l++) {
+      const int ty = cdiv(p->H[l], TILE), tx = cdiv(p->W[l], TILE);
+      const int pass = ty * tx * p->N <= COARSE_TILES ? 1 : 0;
+      if (pass) Q.coarse_mask |= 1u << l;
+      Q.pass_base[l] = base[pass];
+      base[pass] += ty * tx * p->N;
+      for (int n = 0; n < p->N; n++)
+        for (int by = 0; by < ty; by += 4)
+          for (int bx = 0; bx < tx; bx += 4)
+            per[pass][tile_xcd(l, n, by, bx, tx)] += min(4, ty - by) * min(4, tx - bx);
+    }
+    for (int x = 0; x < 8; x++) { Q.cap[0] = max(Q.cap[0], per[0][x]); Q.cap[1] = max(Q.cap[1], per[1][x]); }
+    static const int thr_f = getenv("D2AMD_POOL_QTHR_FINE") ? atoi(getenv("D2AMD_POOL_QTHR_FINE")) : 4;
+    static const int thr_c = getenv("D2AMD_POOL_QTHR_COARSE") ? atoi(getenv("D2AMD_POOL_QTHR_COARSE")) : 16;
+    Q.thr[0] = thr_f; Q.thr[1] = thr_c;
+    Q.mem = (int*)((char*)workspace + off_q);
+    Q.esize = (int)sizeof(T);
+    Q.zero_fill = vec ? 1 : 0;
+  }
+  const int qints = queues ? QCTR + 8 * (Q.cap[0] + Q.cap[1]) : 0;
   if (K > 0) {
-    hipLaunchKernelGGL(roi_records_kernel, dim3(cdiv(K, 256)), dim3(256), 0, s, L0, rois, rec);
+    hipLaunchKernelGGL(roi_records_kernel, dim3(cdiv(K, 256)), dim3(256), 0, s, L0, rois, rec, Q.mem, qints);
     D2_LAUNCH_OK();
     if (lists) {
       hipLaunchKernelGGL(tile_lists_kernel, dim3(cdiv(ntiles, 4)), dim3(256), 0, s, L0, rec, (int)ntiles, tile_cnt,
-                         tile_list);
+                         tile_list, Q);
       D2_LAUNCH_OK();
     }
   }
@@ -892,8 +984,13 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
       if (coarse == (pass == 1)) base += tiles;
     }
     for (int l = p->num_levels; l <= POOL_MAX_LEVELS; l++) L.tile_base[l] = base;
-    const long total = (long)base * nslab;
+    long total = (long)base * nslab;
     if (total == 0) continue;
+    if (queues) {
+      L.queue = Q.mem + QCTR + (pass ? 8 * Q.cap[0] : 0);
+      L.qcap = Q.cap[pass];
+      total = 8l * L.qcap * nslab;  // workgroups of this launch (stamps are indexed by workgroup)
+    }
     D2_CHECK_ARG(total < (1l << 30), "roi_pooler_backward: too many tiles");
     hipStream_t ls = s;
     if (pass == 1 && side) {
@@ -1020,7 +1117,8 @@ extern "C" size_t d2amd_roi_pooler_backward_workspace_bytes(const d2amd_pooler_p
   const size_t need = (size_t)(K > 0 ? K : 1) * sizeof(RoiRec);
   if (check_pooler(p, "roi_pooler_backward_workspace_bytes")) return need;
   const long ntiles = pool_ntiles(p);
-  return pool_al(need) + pool_al((size_t)ntiles * 4) + (size_t)ntiles * TILE_CAP * sizeof(TileEntry) + 256;
+  return pool_al(need) + pool_al((size_t)ntiles * 4) + pool_al((size_t)ntiles * TILE_CAP * sizeof(TileEntry)) +
+      pool_al((size_t)(QCTR + 8 * ntiles) * sizeof(int)) + 256;
 }
 
 extern "C" int d2amd_roi_pooler_backward(const d2amd_pooler_params* p, const void* grad_output, const float* rois,

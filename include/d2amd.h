@@ -217,6 +217,29 @@ int d2amd_paste_masks(const void* masks, const float* boxes, int n, int mh, int 
 int d2amd_bitmask_crop_and_resize(const uint8_t* masks, const float* boxes, int G, int H, int W,
                                   int mask_size, uint8_t* out, void* stream);
 
+/* ---- Mask-head glue.  detectron2/modeling/roi_heads/mask_head.py:31-158.
+ * logits [B,C,HW] `dtype` (HW = Hmask*Wmask, contiguous NCHW), classes [B] int64 or NULL (class-agnostic,
+ * C == 1), gt_masks [B,HW] uint8 / bool storage (the output of d2amd_bitmask_crop_and_resize).
+ * mask_rcnn_inference (mask_head.py:116-158): out [B,1,HW] = sigmoid(logits[b, classes[b]]), same dtype;
+ *   a class outside [0, C) yields NaN rows (the reference's gather raises an index error).
+ * mask_rcnn_loss forward (mask_head.py:31-113): loss_out[0] = mean over B*HW of
+ *   binary_cross_entropy_with_logits(logits[b, gt_classes[b]], gt_masks) in fp32;
+ *   stats_out[5] int64 = {#incorrect ((x > 0) != gt), #positive gt, #false positive, #false negative,
+ *   #rows whose class is outside [0, C)} -- the counts behind mask_rcnn/accuracy, false_positive,
+ *   false_negative (mask_head.py:88-95), left on the device (the reference reads each with .item()).
+ *   Deterministic (fixed-order reduction).  B == 0 is the caller's case (`pred_mask_logits.sum() * 0`).
+ * mask_rcnn_loss backward: grad_logits [B,C,HW] `dtype`, written completely: grad_loss[0] *
+ *   (sigmoid(x) - gt) / (B*HW) in the class plane, 0 elsewhere.  grad_loss is a DEVICE scalar (fp32). */
+int d2amd_mask_rcnn_inference(const void* logits, const int64_t* classes, int B, int C, int HW, int dtype,
+                              void* out, void* stream);
+size_t d2amd_mask_rcnn_loss_workspace_bytes(int B);
+int d2amd_mask_rcnn_loss_forward(const void* logits, const int64_t* gt_classes, const uint8_t* gt_masks, int B,
+                                 int C, int HW, int dtype, float* loss_out, int64_t* stats_out, void* workspace,
+                                 size_t workspace_bytes, void* stream);
+int d2amd_mask_rcnn_loss_backward(const void* logits, const int64_t* gt_classes, const uint8_t* gt_masks,
+                                  const float* grad_loss, int B, int C, int HW, int dtype, void* grad_logits,
+                                  void* stream);
+
 /* ---- deformable convolution v1 / v2.  Replaces detectron2._C.deform_conv_forward,
  * deform_conv_backward_input, deform_conv_backward_filter, modulated_deform_conv_forward,
  * modulated_deform_conv_backward (vision.cpp:85-102; csrc/deformable/deform_conv.h:116-375).

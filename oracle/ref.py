@@ -132,3 +132,57 @@ def py_proposal_utils(batched_nms):
     stubs = {"detectron2": pkg, "detectron2.layers": layers, "detectron2.structures": structs}
     return _with_stubs(stubs, lambda: _load_by_path("_d2ref_proposal_utils",
                                                     "detectron2/modeling/proposal_generator/proposal_utils.py"))
+
+
+class _EventRecorder:
+    """Stand-in for detectron2.utils.events.EventStorage: keeps what mask_rcnn_loss logs."""
+
+    def __init__(self):
+        self.scalars = {}
+        self.iter = 0
+
+    def put_scalar(self, name, value, **kw):
+        self.scalars[name] = float(value)
+
+    def put_image(self, *a, **k):
+        pass
+
+
+def py_mask_head():
+    """detectron2/modeling/roi_heads/mask_head.py (mask_rcnn_loss, mask_rcnn_inference).  Module-level imports that
+    the two functions do not use (fvcore weight_init, configurable, the conv layer classes, the registry) are
+    stubbed; `cat` / `move_device_like` as in layers/wrappers.py; Instances from the reference file;
+    get_event_storage returns an _EventRecorder exposed as `module._d2_events`."""
+    import torch
+
+    fv, fvnn, fvwi = (types.ModuleType(n) for n in ("fvcore", "fvcore.nn", "fvcore.nn.weight_init"))
+    fv.nn, fvnn.weight_init = fvnn, fvwi
+    names = ("detectron2", "detectron2.config", "detectron2.layers", "detectron2.layers.wrappers",
+             "detectron2.structures", "detectron2.utils", "detectron2.utils.events", "detectron2.utils.registry")
+    pkg, cfg, layers, wrappers, structs, utils, events, registry = (types.ModuleType(n) for n in names)
+    cfg.configurable = lambda f=None, **k: f
+    layers.Conv2d, layers.ConvTranspose2d = torch.nn.Conv2d, torch.nn.ConvTranspose2d
+    layers.ShapeSpec = object
+    layers.get_norm = lambda *a, **k: None
+    layers.cat = lambda ts, dim=0: torch.cat(ts, dim)
+    wrappers.move_device_like = lambda src, dst: src.to(dst.device)
+    structs.Instances = _load_by_path("_d2ref_instances", "detectron2/structures/instances.py").Instances
+    rec = _EventRecorder()
+    events.get_event_storage = lambda: rec
+
+    class Registry:
+        def __init__(self, name):
+            self.name = name
+
+        def register(self, obj=None):
+            return obj if obj is not None else (lambda o: o)
+
+    registry.Registry = Registry
+    pkg.config, pkg.layers, pkg.structures, pkg.utils = cfg, layers, structs, utils
+    layers.wrappers, utils.events, utils.registry = wrappers, events, registry
+    stubs = dict(zip(names, (pkg, cfg, layers, wrappers, structs, utils, events, registry)))
+    stubs.update({"fvcore": fv, "fvcore.nn": fvnn, "fvcore.nn.weight_init": fvwi})
+    mod = _with_stubs(stubs, lambda: _load_by_path("_d2ref_mask_head", "detectron2/modeling/roi_heads/mask_head.py"))
+    mod._d2_events = rec
+    mod._d2_Instances = structs.Instances
+    return mod

@@ -150,5 +150,71 @@ def main():
     print("golden vectors written to", OUT)
 
 
+class _FakeBoxes:
+    def __init__(self, n):
+        self.tensor = torch.zeros(n, 4)
+
+    def __len__(self):
+        return len(self.tensor)
+
+
+class _FakeMasks:
+    """gt_masks whose crop_and_resize returns prepared (n, M, M) bool targets (the rasteriser itself is pinned
+    separately: BitMasks.crop_and_resize goes through torchvision's roi_align, not installed here)."""
+
+    def __init__(self, targets):
+        self.targets = targets
+
+    def __len__(self):
+        return len(self.targets)
+
+    def crop_and_resize(self, boxes, side):
+        assert side == self.targets.shape[-1]
+        return self.targets
+
+
+def mask_head_golden():
+    """mask_rcnn_loss / mask_rcnn_inference of detectron2/modeling/roi_heads/mask_head.py run on CPU (fp32)."""
+    mh = ref.py_mask_head()
+    rng = np.random.default_rng(77)
+    d = {}
+    for name, per_img, C, M in (("a", [20, 0, 17], 5, 14), ("b", [6], 20, 28), ("agn", [9, 4], 1, 7)):
+        B = sum(per_img)
+        logits = (rng.standard_normal((B, C, M, M)) * 3).astype(np.float32)
+        logits.reshape(-1)[:6] = [0.0, -0.0, 40.0, -40.0, 90.0, -90.0]  # threshold / saturation cases
+        cls = rng.integers(0, C, B).astype(np.int64)
+        gt = rng.random((B, M, M)) < 0.4
+        inst, pred_inst, o = [], [], 0
+        for n in per_img:
+            i = mh._d2_Instances((M, M))
+            i.gt_classes = torch.from_numpy(cls[o:o + n])
+            i.proposal_boxes = _FakeBoxes(n)
+            i.gt_masks = _FakeMasks(torch.from_numpy(gt[o:o + n]))
+            inst.append(i)
+            q = mh._d2_Instances((M, M))
+            q.pred_classes = torch.from_numpy(cls[o:o + n])
+            pred_inst.append(q)
+            o += n
+        x = torch.from_numpy(logits).requires_grad_(True)
+        loss = mh.mask_rcnn_loss(x, inst)
+        (loss * 1.75).backward()
+        ev = mh._d2_events.scalars
+        mh.mask_rcnn_inference(torch.from_numpy(logits), pred_inst)
+        probs = torch.cat([q.pred_masks for q in pred_inst]).numpy()
+        d.update({f"{name}_logits": logits, f"{name}_classes": cls, f"{name}_gt": gt, f"{name}_per_img": np.array(per_img),
+                  f"{name}_loss": loss.detach().numpy(), f"{name}_grad_x1p75": x.grad.numpy(), f"{name}_probs": probs,
+                  f"{name}_accuracy": np.array(ev["mask_rcnn/accuracy"]),
+                  f"{name}_false_positive": np.array(ev["mask_rcnn/false_positive"]),
+                  f"{name}_false_negative": np.array(ev["mask_rcnn/false_negative"])})
+    np.savez_compressed(os.path.join(OUT, "mask_head.npz"), **d)
+    print("mask_head.npz written")
+
+
 if __name__ == "__main__":
-    main()
+    import sys
+
+    if len(sys.argv) > 1 and sys.argv[1] == "mask_head":
+        mask_head_golden()
+    else:
+        main()
+        mask_head_golden()

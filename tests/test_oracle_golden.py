@@ -351,3 +351,24 @@ def test_rpn_restatement_matches_reference_functions(golden_dir):
     for i, (b, s) in enumerate(res):
         assert np.array_equal(s, g[f"scores_img{i}"])          # same proposals, same order
         assert np.allclose(b, g[f"boxes_img{i}"], rtol=2e-6, atol=2e-4)
+
+
+def test_mask_head_restatement_matches_reference_functions(golden_dir):
+    """oracle/mask_head.py vs the reference's own mask_rcnn_loss / mask_rcnn_inference run on CPU
+    (tests/golden/mask_head.npz, generated through oracle/ref.py::py_mask_head): loss, the logged accuracy /
+    false positive / false negative, autograd gradient (x 1.75 upstream) and inference probabilities."""
+    from oracle import mask_head as omh
+
+    g = np.load(os.path.join(golden_dir, "mask_head.npz"))
+    for name in ("a", "b", "agn"):
+        x, cls, gt = g[f"{name}_logits"], g[f"{name}_classes"], g[f"{name}_gt"]
+        loss, st = omh.mask_rcnn_loss(x, cls, gt)
+        assert abs(loss - float(g[f"{name}_loss"])) <= 1e-5 * abs(float(g[f"{name}_loss"]))
+        for k in ("accuracy", "false_positive", "false_negative"):
+            assert abs(st[k] - float(g[f"{name}_{k}"])) < 1e-12, k
+        grad = omh.mask_rcnn_loss_grad(x, cls, gt, 1.75)
+        assert np.abs(grad - g[f"{name}_grad_x1p75"]).max() <= 1e-6 * np.abs(grad).max() + 1e-12
+        assert np.abs(grad[g[f"{name}_grad_x1p75"] == 0]).max(initial=0.0) < 1e-30  # other planes: zero (fp32 saturates at -90)
+        probs = omh.mask_rcnn_inference(x, cls)
+        assert probs.shape == g[f"{name}_probs"].shape
+        assert np.abs(probs - g[f"{name}_probs"]).max() <= 1e-6
