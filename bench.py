@@ -42,13 +42,12 @@ IMAGES_PER_GPU = 2
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--layout", choices=["nchw", "nhwc"], default="nhwc",
                     help="feature memory format: nchw (reference default) or nhwc (torch.channels_last)")
     ap.add_argument("--dtype", choices=["bf16", "fp32", "fp16"], default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", action="store_true", help="replay the sync-free part of the step from a HIP graph")
     return ap.parse_args()
 
 
@@ -329,7 +328,8 @@ def main():
     elapsed = sw.stop()
     ktimes = {}
     def read_ktimes():
-        for kn in ("pool_bwd_fine_r7", "pool_bwd_coarse_r7", "pool_bwd_fine_r14", "pool_bwd_coarse_r14"):
+        for kn in ("pool_bwd_staged_r7", "pool_bwd_staged_r14", "pool_bwd_fine_r7", "pool_bwd_coarse_r7",
+                   "pool_bwd_fine_r14", "pool_bwd_coarse_r14"):
             tot, cnt = ctypes.c_double(0.0), ctypes.c_int(0)
             _dc.check(_dc.lib().d2amd_timing_read(kn.encode(), ctypes.byref(tot), ctypes.byref(cnt)))
             if cnt.value and kn not in ktimes:
@@ -365,13 +365,28 @@ def main():
         for k in ops:
             ops[k]["launches_per_step"] = counts[k]
             ops[k]["ms_per_launch"] = round(ops[k]["ms_per_step"] / counts[k], 4)
-        # roofline: the dominant kernel = the fine-level tile-gather launch of the box-head backward
-        # (pool_bwd_nhwc_kernel<.., 1, 2, 8> in the rocprofv3 stats), timed by HIP events on its launch stream
-        # inside the timed region.  Its algorithmic bytes: SURVEY 8(d)'s backward formula restricted to the levels
-        # this launch writes (dY read once + 2 x grad_input of those levels).
+        # roofline: the dominant kernel = the tile-gather launch of the box-head backward (pool_bwd_staged_kernel in
+        # the rocprofv3 stats; with D2AMD_POOL_NOSTAGED the fine-level launch of the two-launch register-gather
+        # kernels), timed by HIP events on its launch stream inside the timed region.  Its algorithmic bytes:
+        # SURVEY 8(d)'s backward formula for the levels the launch writes (dY read once + 2 x grad_input).
         dom = ROOFLINE_OP
         ops[dom]["ms_per_launch_timed_region"] = round(dom_ms_timed / counts[dom], 4)
-        if args.layout == "nhwc" and "pool_bwd_fine_r7" in ktimes:
+        if args.layout == "nhwc" and "pool_bwd_staged_r7" in ktimes:
+            # one launch for all FPN levels (LDS-staged tile gather): SURVEY 8(d)'s backward bytes of the whole op
+            k_ms, k_n = ktimes["pool_bwd_staged_r7"]
+            kb = alg[dom] / counts[dom]
+            roof = {"bound": "hbm", "kernel": "pool_bwd_staged_kernel (all FPN levels) of roi_align_box_bwd",
+                    "achieved": round(kb / 1e9 / (k_ms / 1e3), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(kb / 1e9 / (k_ms / 1e3) / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, args.layout),
+                    "traffic_note": "PMC bytes are for the whole op (records + tile lists/zero fill + tile gather)",
+                    "alg_bytes_per_launch": int(kb), "ms_per_launch": round(k_ms, 4), "launches_timed": k_n,
+                    "timing": "HIP events recorded by the library on the kernel's launch stream right around the launch, "
+                              "mean over the timed steps",
+                    "op": {"name": dom, "alg_bytes": int(alg[dom] / counts[dom]),
+                           "ms_per_launch_events_around_op": round(dom_ms_timed / counts[dom], 4),
+                           "frac": round(alg[dom] / counts[dom] / 1e9 / (dom_ms_timed / counts[dom] / 1e3) / HBM_PEAK_GBS, 4)},
+                    "kernels_ms": {k: round(v[0], 4) for k, v in ktimes.items()}}
+        elif args.layout == "nhwc" and "pool_bwd_fine_r7" in ktimes:
             k_ms, k_n = ktimes["pool_bwd_fine_r7"]
             kb = w.alg_bytes_bwd_kernel("box", fine=True)
             roof = {"bound": "hbm", "kernel": "pool_bwd_nhwc_kernel (fine FPN levels) of roi_align_box_bwd",

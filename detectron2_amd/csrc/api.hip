@@ -27,7 +27,8 @@ static TimingSlot g_slots[8];
 static int g_nslots = 0;
 static int g_timing_mask = 0;  // bit i: time the i-th registered kernel name (registration order below)
 static const char* const g_timing_names[] = {"pool_bwd_fine_r7", "pool_bwd_coarse_r7", "pool_bwd_fine_r14",
-                                              "pool_bwd_coarse_r14"};
+                                              "pool_bwd_coarse_r14", "pool_bwd_staged_r7", "pool_bwd_staged_r14"};
+static const int g_timing_bits[] = {0, 1, 2, 3, 0, 2};  // the single staged launch answers to the "fine" bits
 static TimingSlot* timing_slot(const char* name) {
   for (int i = 0; i < g_nslots; i++)
     if (!strcmp(g_slots[i].name, name)) return &g_slots[i];
@@ -38,8 +39,8 @@ static TimingSlot* timing_slot(const char* name) {
 bool timing_begin(const char* name, hipStream_t s) {
   if (!g_timing_mask) return false;
   int bit = -1;
-  for (int i = 0; i < 4; i++)
-    if (!strcmp(g_timing_names[i], name)) bit = i;
+  for (int i = 0; i < 6; i++)
+    if (!strcmp(g_timing_names[i], name)) bit = g_timing_bits[i];
   if (bit < 0 || !(g_timing_mask & (1 << bit))) return false;
   TimingSlot* t = timing_slot(name);
   if (!t || t->ev.size() >= 65536) return false;

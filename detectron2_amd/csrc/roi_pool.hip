@@ -740,6 +740,318 @@ __global__ __launch_bounds__(CT * RS * GROUPS, 4) void pool_bwd_nhwc_kernel(Pool
   if (wst) wst[3] = wall_clock64();
 }
 
+// ------------------------------------------------------------------------------------------------
+// BACKWARD, NHWC: tile gather with the dY WINDOW STAGED IN LDS (v8).
+//
+// What the per-phase stamps of the kernel above say (profiles/r01/v8_pool_bwd_phase_stamps.txt): of the ~7,000
+// cycles a tile workgroup spends per ROI, ~4,500 pass between the barrier and the moment its gather loads are
+// issued.  Every lane asks for the dY vectors of "its" (ph, pw) pairs itself: the 16 threads that own the other
+// pixel columns / row halves of the tile request the same vectors again, and the batches are padded to NB
+// clamped loads, so a 512-thread group pushes 64 wave-loads of 1 KB through the CU's one texture-address path
+// (64 B / clk: >= 1,000 cycles of pure issue) for ~8 KB of distinct data, and waits an L2 round trip for them.
+// Here the group loads the WINDOW of bins that touch the tile (contiguous [ph_lo, ph_hi] x [pw_lo, pw_hi]:
+// typically 3 x 3 ... 4 x 4 of the 7 x 7 / 14 x 14) ONCE, one 16-B load per thread and 16 bins, into LDS, one
+// item ahead of the FMAs, and the lanes read their vectors from LDS (128 B / clk, ~100 cycles).
+//   * item = (list entry, chunk of window rows holding <= WINCAP bins); almost always one item per ROI;
+//   * one barrier per item: loads of item i + 1 are issued right after it, the axis weights of entry e + 2 are
+//     computed while they fly (weights are TRIPLE buffered, the window of e + 1 must be known to issue its loads),
+//     then the FMAs of item i run from LDS buffer i & 1, then the loaded vectors go to buffer (i + 1) & 1;
+//   * one workgroup shape (512 threads) for all levels: a single launch, no side stream, tiles dealt by the
+//     work queues (heavy first); long lists no longer need the list split (GROUPS) because an item costs less.
+constexpr int WINCAP = 32;  // bins staged per item: 2 loads per thread
+template <typename T>
+struct StagedShared {
+  int list[LCH];
+  HitGeo geo[LCH];
+  // axis weights of NSLOT = 3 * EPR list entries (EPR = 32 / PB entries are evaluated per round, PB = bins per
+  // axis rounded up to 8 / 16 / 32):  WyT[(slot * PB + bin) * 8 + tile row],  Wx[(slot * 8 + tile col) * PB + bin]
+  // (carries 1 / count)
+  float WyT[3 * MAXP * TILE];
+  float Wx[3 * MAXP * TILE];
+  uint32_t ymask[12][TILE], xmask[12][TILE];
+  uint32_t yall[12][4], xall[12][4];  // per weights wave: union of its rows' / columns' masks
+  raw16 D[2][WINCAP][LPP];   // staged dY vectors: [buffer][bin of the item][channel lane]
+  int wave_cnt[LCH / 64];
+};
+struct Window { int ph_lo, nph, pw_lo, npw, rpc, nitems; float rnpw; };
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(2 * CT, 4) void pool_bwd_staged_kernel(PoolLevels L, const RoiRec* __restrict__ rec,
+                                                                   const T* __restrict__ gout, int nslab,
+                                                                   int total_blocks, PoolTileIds ids) {
+  constexpr int NT = 2 * CT, TR = TILE / 2;
+  __shared__ StagedShared<T> S;
+  const int tid = threadIdx.x, lane = tid & 63;
+  int logical, slab, tile, qcnt = -1;
+  if (L.queue) {
+    const int j = (int)(blockIdx.x >> 3);
+    const int e = L.queue[(long)(blockIdx.x & 7) * L.qcap + j / nslab];
+    if (e < 0) return;
+    logical = (int)blockIdx.x;
+    slab = j % nslab;
+    tile = e & 0xffffff;
+    qcnt = (int)((unsigned)e >> 24);
+  } else {
+    const int per_xcd = (total_blocks + 7) >> 3;
+    logical = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (logical >= total_blocks) return;
+    slab = logical % nslab;
+    tile = logical / nslab;
+  }
+  unsigned long long* wst = (L.wgstamps && tid == 0) ? L.wgstamps + 5 * (size_t)logical : nullptr;
+  if (wst) wst[0] = wall_clock64();
+  unsigned long long wst_list = 0;
+  int wst_n = 0;
+  int lvl = 0;
+#pragma unroll
+  for (int l = 1; l < POOL_MAX_LEVELS; l++)
+    if (l < L.num_levels && tile >= L.tile_base[l]) lvl = l;
+  const int H = L.H[lvl], W = L.W[lvl];
+  const int tiles_x = (W + TILE - 1) / TILE, tiles_y = (H + TILE - 1) / TILE;
+  int tl = tile - L.tile_base[lvl];
+  const int n = tl / (tiles_y * tiles_x);
+  tl -= n * tiles_y * tiles_x;
+  const int y0 = (tl / tiles_x) * TILE, x0 = (tl % tiles_x) * TILE;
+  const int C = L.C, PH = L.PH, PW = L.PW, K = L.K;
+  const int CG = C / VEC;
+  const int rh = tid / CT, col = (tid >> 5) & 7, lp = tid & 31;  // row half / pixel column / channel lane
+  const int cg = slab * LPP + lp;
+  const bool cg_ok = cg < CG;
+  const long cofs = (long)min(cg, CG - 1) * VEC;
+  const int sb = tid >> 5;  // staging: this thread moves bins sb and sb + 16 of an item (channel lane lp)
+#undef STAMP
+#ifdef D2AMD_PROFILE
+  const bool dbg_on = L.dbg && logical == L.dbg_block && tid == 0;
+  int dbg_n = 0;
+#define STAMP() do { if (dbg_on && dbg_n < 120) L.dbg[dbg_n++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP() do {} while (0)
+#endif
+  STAMP();
+
+  float acc[TR][VEC];
+#pragma unroll
+  for (int i = 0; i < TR; i++)
+#pragma unroll
+    for (int c = 0; c < VEC; c++) acc[i][c] = 0.f;
+
+  // Axis weights.  PB = bins per axis rounded up to 8 / 16 / 32; one entry needs 8 x PB (row, bin) and 8 x PB
+  // (column, bin) pairs = 2 * PB / 8 waves, so the 8 waves of the group evaluate EPR = 32 / PB list entries per
+  // ROUND, all at the same time (box head: 4 entries, one wave per entry and axis).  Weights live in NSLOT = 3 EPR
+  // slots: round r + 2 is evaluated during the first item of round r and overwrites round r - 1.
+  const int PB = (PH <= 8 && PW <= 8) ? 8 : (PH <= 16 && PW <= 16) ? 16 : 32;  // uniform
+  const int lg = PB == 8 ? 3 : PB == 16 ? 4 : 5;
+  const int EPR = 32 >> lg, NSLOT = 3 * EPR;
+  const int wave = tid >> 6;
+  int nlist = 0;
+  auto compute_round = [&](int first) __attribute__((always_inline)) {
+    const int rows_per_wave = 64 >> lg, waves_per_axis = TILE >> (6 - lg);  // 8,1 / 4,2 / 2,4
+    const int wpe = 2 * waves_per_axis;                                      // waves per entry: 2 / 4 / 8
+    const int li = first + wave / wpe;
+    if (li >= nlist) return;  // uniform per wave
+    const int slot = li % NSLOT;
+    const int w2 = wave % wpe;
+    const HitGeo g = S.geo[li];
+    const bool is_x = w2 >= waves_per_axis;
+    const int wa = is_x ? w2 - waves_per_axis : w2;  // wave within its axis
+    const int p = lane & (PB - 1), r = wa * rows_per_wave + (lane >> lg);
+    const int grid = is_x ? (g.grid >> 16) : (g.grid & 0xffff);
+    const int P = is_x ? PW : PH, size = is_x ? W : H, pix = (is_x ? x0 : y0) + r;
+    float wv = 0.f;
+    if (p < P && pix < size) wv = axis_weight(is_x ? g.start_w : g.start_h, is_x ? g.bin_w : g.bin_h, grid, p, pix, size);
+    if (is_x) S.Wx[((slot << 3) + r) * PB + p] = wv * g.inv;
+    else S.WyT[((slot << lg) + p) * TILE + r] = wv;
+    const unsigned long long bm = __ballot(wv != 0.f);
+    if (lane < rows_per_wave) {
+      const uint32_t m = (uint32_t)(bm >> (lane << lg)) & (PB == 32 ? 0xffffffffu : ((1u << PB) - 1u));
+      if (is_x) S.xmask[slot][wa * rows_per_wave + lane] = m;
+      else S.ymask[slot][wa * rows_per_wave + lane] = m;
+    }
+    if (lane == 0) {
+      uint32_t u = 0;
+      for (int q = 0; q < rows_per_wave; q++) u |= (uint32_t)(bm >> (q << lg)) & (PB == 32 ? 0xffffffffu : ((1u << PB) - 1u));
+      if (is_x) S.xall[slot][wa] = u;
+      else S.yall[slot][wa] = u;
+    }
+  };
+  // window of bins of entry buffer wb that touch the tile (uniform; valid after the barrier that follows its weights)
+  auto window_of = [&](int wb) __attribute__((always_inline)) {
+    const int waves_per_axis = PB / 8;
+    uint32_t ya = S.yall[wb][0], xa = S.xall[wb][0];
+    if (waves_per_axis > 1) { ya |= S.yall[wb][1]; xa |= S.xall[wb][1]; }
+    if (waves_per_axis > 2) { ya |= S.yall[wb][2] | S.yall[wb][3]; xa |= S.xall[wb][2] | S.xall[wb][3]; }
+    Window w;
+    if (ya == 0 || xa == 0) { w.ph_lo = 0; w.nph = 0; w.pw_lo = 0; w.npw = 1; w.rpc = WINCAP; w.nitems = 1; w.rnpw = 1.f; return w; }
+    w.ph_lo = __builtin_ctz(ya); w.nph = 32 - __builtin_clz(ya) - w.ph_lo;
+    w.pw_lo = __builtin_ctz(xa); w.npw = 32 - __builtin_clz(xa) - w.pw_lo;
+    w.rnpw = __builtin_amdgcn_rcpf((float)w.npw);
+    w.rpc = (int)((WINCAP + 0.5f) * w.rnpw);  // WINCAP / npw;  npw <= MAXP = 32 = WINCAP: at least one row of bins
+    w.nitems = (int)((w.nph + w.rpc - 0.5f) * __builtin_amdgcn_rcpf((float)w.rpc));  // ceil(nph / rpc)
+    return w;
+  };
+  // issue the loads of item (entry li with window w, chunk c): bins sb and sb + 16 of the chunk, channel lane lp
+  auto issue_loads = [&](int li, const Window& w, int c, raw16& r0, raw16& r1) __attribute__((always_inline)) {
+    const int pa = w.ph_lo + c * w.rpc;
+    const int nb = min(w.rpc, w.ph_lo + w.nph - pa) * w.npw;  // bins of this item (<= WINCAP); 0 for an empty window
+    const T* gk = gout + (long)S.list[li] * PH * PW * C + cofs;
+    if (nb > 0) {  // uniform
+      const int j0 = min(sb, nb - 1);
+      const int q0 = (int)((j0 + 0.5f) * w.rnpw);  // j0 / npw
+      r0 = *reinterpret_cast<const raw16*>(gk + ((long)(pa + q0) * PW + w.pw_lo + (j0 - q0 * w.npw)) * C);
+      if (nb > 16) {  // uniform
+        const int j1 = min(sb + 16, nb - 1);
+        const int q1 = (int)((j1 + 0.5f) * w.rnpw);
+        r1 = *reinterpret_cast<const raw16*>(gk + ((long)(pa + q1) * PW + w.pw_lo + (j1 - q1 * w.npw)) * C);
+      }
+    }
+    return nb;
+  };
+
+  int tl_cnt = -1;
+  if (L.tile_cnt) {
+    const int gtile = ids.first[lvl] + (tile - L.tile_base[lvl]);
+    const int c = qcnt >= 0 ? qcnt : L.tile_cnt[gtile];
+    if (c <= TILE_CAP) {
+      tl_cnt = c;
+      if (tid < c) {
+        const TileEntry e = ((const TileEntry*)L.tile_list)[(long)gtile * TILE_CAP + tid];
+        S.list[tid] = e.roi;
+        S.geo[tid] = e.g;
+      }
+    }
+  }
+  const bool prelist = tl_cnt >= 0;  // uniform
+  for (int kbase = 0; kbase < (prelist ? 1 : K); kbase += LCH) {
+    nlist = 0;
+    if (prelist) {
+      nlist = tl_cnt;
+    } else {
+      // ordered list (+ geometry) of the ROIs of this chunk of records that touch the tile (tiles with more
+      // than TILE_CAP ROIs, or no prepared lists)
+      const int kend = min(K, kbase + LCH);
+      const long r = min(kbase + tid, K - 1);
+      const int4 ra = *reinterpret_cast<const int4*>(&rec[r].level);  // level, batch, fy0, fy1
+      const int2 rb = *reinterpret_cast<const int2*>(&rec[r].fx0);    // fx0, fx1
+      const bool hit = kbase + tid < kend && ra.x == lvl && ra.y == n && ra.w >= y0 && ra.z < y0 + TILE &&
+          rb.y >= x0 && rb.x < x0 + TILE;
+      const unsigned long long bal = __ballot(hit);
+      __syncthreads();  // previous chunk's readers of list / geo / wave_cnt / weights / D are done
+      if (lane == 0) S.wave_cnt[tid >> 6] = __builtin_popcountll(bal);
+      __syncthreads();
+      int run = 0;
+#pragma unroll
+      for (int sl = 0; sl < NT / 64; sl++) {
+        if (sl == (tid >> 6) && hit) S.list[run + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = kbase + tid;
+        run += S.wave_cnt[sl];
+      }
+      nlist = run;
+    }
+    if (wst) { wst_list = wall_clock64(); wst_n += nlist; }
+    if (nlist == 0) continue;  // uniform
+    __syncthreads();           // list complete
+    if (!prelist) {
+      for (int i = tid; i < nlist; i += NT) S.geo[i] = rec[S.list[i]].g;
+      __syncthreads();
+    }
+
+    // ---- pipeline over the items of the list --------------------------------------------------------
+    compute_round(0);
+    compute_round(EPR);
+    __syncthreads();
+    raw16 r0 = raw16{0u, 0u, 0u, 0u}, r1 = raw16{0u, 0u, 0u, 0u};
+    Window wc = window_of(0);
+    {
+      const int nb = issue_loads(0, wc, 0, r0, r1);
+      if (sb < nb) S.D[0][sb][lp] = r0;
+      if (sb + 16 < nb) S.D[0][sb + 16][lp] = r1;
+    }
+    int e = 0, c = 0, db = 0;
+    while (true) {
+      STAMP();
+      __syncthreads();  // D[db] and the weights of e (and e + 1) are complete; everyone is done with D[db ^ 1]
+      STAMP();
+      // next item: the next chunk of this entry's window, or the first chunk of the next entry
+      int e2 = e, c2 = c + 1;
+      Window wn = wc;
+      if (c2 >= wc.nitems) { e2 = e + 1; c2 = 0; }
+      const bool have_next = e2 < nlist;
+      int nb2 = 0;
+      if (have_next) {
+        if (e2 != e) wn = window_of(e2 % NSLOT);
+        nb2 = issue_loads(e2, wn, c2, r0, r1);
+      }
+      STAMP();
+      if (c == 0 && (e & (EPR - 1)) == 0) compute_round(e + 2 * EPR);  // overlaps the loads
+      STAMP();
+      // FMAs of item (e, c) from D[db]
+      {
+        const int wb = e % NSLOT;
+        const int pa = wc.ph_lo + c * wc.rpc;
+        const int nrow = min(wc.rpc, wc.ph_lo + wc.nph - pa);
+        uint32_t yu = 0;
+#pragma unroll
+        for (int i = 0; i < TR; i++) yu |= S.ymask[wb][rh * TR + i];
+        yu &= nrow > 0 ? (((nrow >= 32 ? 0u : (1u << nrow)) - 1u) << pa) : 0u;
+        const uint32_t xb = (cg_ok && !(L.ablate & 1)) ? S.xmask[wb][col] : 0u;
+        while (yu) {  // uniform per wave (a wave holds one row half)
+          const int ph = __builtin_ctz(yu);
+          yu &= yu - 1;
+          const float4 w4v = *reinterpret_cast<const float4*>(&S.WyT[((wb << lg) + ph) * TILE + rh * TR]);
+          const float wy[TR] = {w4v.x, w4v.y, w4v.z, w4v.w};
+          const int dbase = (ph - pa) * wc.npw - wc.pw_lo;
+          // separable: first the column taps of this bin row, t = sum_pw Wx[col][pw] dY[ph][pw], then the rows
+          float t[VEC];
+#pragma unroll
+          for (int q = 0; q < VEC; q++) t[q] = 0.f;
+          uint32_t xq = xb;
+          while (xq) {
+            const int pwA = __builtin_ctz(xq);
+            xq &= xq - 1;
+            const bool okB = xq != 0;
+            const int pwB = okB ? __builtin_ctz(xq) : pwA;
+            xq &= xq - 1;
+            const raw16 va = S.D[db][dbase + pwA][lp], vb = S.D[db][dbase + pwB][lp];
+            const float* wxr = &S.Wx[((wb << 3) + col) * PB];
+            const float wxA = wxr[pwA];
+            const float wxB = okB ? wxr[pwB] : 0.f;
+            float fA[VEC], fB[VEC];
+            unpack16(va, fA, T{});
+            unpack16(vb, fB, T{});
+#pragma unroll
+            for (int q = 0; q < VEC; q++) t[q] += wxA * fA[q] + wxB * fB[q];
+          }
+#pragma unroll
+          for (int i = 0; i < TR; i++) {
+            if (wy[i] != 0.f) {  // rows are shared by the whole wave: uniform branch
+#pragma unroll
+              for (int q = 0; q < VEC; q++) acc[i][q] += wy[i] * t[q];
+            }
+          }
+        }
+      }
+      STAMP();
+      if (!have_next) break;
+      if (sb < nb2) S.D[db ^ 1][sb][lp] = r0;
+      if (sb + 16 < nb2) S.D[db ^ 1][sb + 16][lp] = r1;
+      e = e2; c = c2; wc = wn; db ^= 1;
+    }
+  }
+#ifdef D2AMD_PROFILE
+  if (dbg_on) { L.dbg[127] = dbg_n; L.dbg[126] = 0; L.dbg[125] = __builtin_readcyclecounter() - L.dbg[0]; }
+#endif
+  if (wst) { wst[1] = wst_list; wst[2] = wall_clock64(); wst[4] = (unsigned long long)wst_n; }
+  // ---- write the tile: every pixel of grad_input exactly once ---------------------------------
+  if (cg_ok && x0 + col < W) {
+    T* gi = (T*)L.data[lvl] + (((long)n * H + y0 + rh * TR) * W + x0 + col) * C + cofs;
+#pragma unroll
+    for (int i = 0; i < TR; i++) {
+      if (y0 + rh * TR + i >= H) break;
+      *reinterpret_cast<raw16*>(gi + (long)i * W * C) = pack16(acc[i], T{});
+    }
+  }
+  if (wst) wst[3] = wall_clock64();
+}
+
 // ---- convert_boxes_to_pooler_format (poolers.py:62-104) in one launch, no host sync -----------------
 struct ImgEnds { int n; int end[D2AMD_POOLER_MAX_IMAGES]; };  // exclusive prefix ends of the per-image box counts
 __global__ void boxes_to_rois_kernel(const float* __restrict__ boxes, int K, int width, ImgEnds e,
@@ -930,12 +1242,15 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
   for (int l = 0; l < p->num_levels; l++) nblocks4 += (long)cdiv(cdiv(p->H[l], TILE), 4) * cdiv(cdiv(p->W[l], TILE), 4) * p->N;
   const bool queues = lists && nblocks4 <= 8192 && ntiles < (1l << 24) &&
       workspace_bytes >= off_q + (size_t)(QCTR + 8 * ntiles) * sizeof(int) && getenv("D2AMD_POOL_NOQUEUE") == nullptr;
+  // one launch of the LDS-staged kernel for all levels (16-B channel vectors + work queues), else the two-launch
+  // register-gather kernels
+  const bool staged = queues && vec && getenv("D2AMD_POOL_NOSTAGED") == nullptr;
   if (queues) {
     int per[2][8] = {};
     int base[2] = {0, 0};
     for (int l = 0; l < p->num_levels; l++) {
       const int ty = cdiv(p->H[l], TILE), tx = cdiv(p->W[l], TILE);
-      const int pass = ty * tx * p->N <= COARSE_TILES ? 1 : 0;
+      const int pass = (!staged && ty * tx * p->N <= COARSE_TILES) ? 1 : 0;
       if (pass) Q.coarse_mask |= 1u << l;
       Q.pass_base[l] = base[pass];
       base[pass] += ty * tx * p->N;
@@ -945,7 +1260,9 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
             per[pass][tile_xcd(l, n, by, bx, tx)] += min(4, ty - by) * min(4, tx - bx);
     }
     for (int x = 0; x < 8; x++) { Q.cap[0] = max(Q.cap[0], per[0][x]); Q.cap[1] = max(Q.cap[1], per[1][x]); }
-    static const int thr_f = getenv("D2AMD_POOL_QTHR_FINE") ? atoi(getenv("D2AMD_POOL_QTHR_FINE")) : 4;
+    static const int thr_s = getenv("D2AMD_POOL_QTHR") ? atoi(getenv("D2AMD_POOL_QTHR")) : 6;
+    static const int thr_f0 = getenv("D2AMD_POOL_QTHR_FINE") ? atoi(getenv("D2AMD_POOL_QTHR_FINE")) : 4;
+    const int thr_f = staged ? thr_s : thr_f0;
     static const int thr_c = getenv("D2AMD_POOL_QTHR_COARSE") ? atoi(getenv("D2AMD_POOL_QTHR_COARSE")) : 16;
     Q.thr[0] = thr_f; Q.thr[1] = thr_c;
     Q.mem = (int*)((char*)workspace + off_q);
@@ -968,6 +1285,67 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
   // The coarse-level launch has few, long-running workgroups (latency bound) and the fine-level one
   // fills the chip at 16 waves / CU: they overlap on a library-owned side stream (fork / join with
   // events; both only read `rec` and dY and write disjoint grad tensors).
+  if (staged) {
+    PoolLevels L = L0;
+    PoolTileIds ids{};
+    for (int l = 0; l < p->num_levels; l++) ids.first[l] = L0.tile_base[l];
+    L.tile_cnt = tile_cnt;
+    L.tile_list = tile_list;
+    L.queue = Q.mem + QCTR;
+    L.qcap = Q.cap[0];
+    const long total = 8l * L.qcap * nslab;
+    if (total == 0) return D2AMD_OK;
+    D2_CHECK_ARG(total < (1l << 30), "roi_pooler_backward: too many tiles");
+    const char* stamp_path = getenv("D2AMD_POOL_STAMPS");  // profiling only: per-workgroup timeline dump
+    if (stamp_path) {
+      D2_HIP_OK(hipMalloc(&L.wgstamps, (size_t)total * 5 * 8));
+      D2_HIP_OK(hipMemsetAsync(L.wgstamps, 0, (size_t)total * 5 * 8, s));
+    }
+#ifdef D2AMD_PROFILE
+    static unsigned long long* dbg_dev = nullptr;
+    if (getenv("D2AMD_DBG_BLOCK")) {
+      if (!dbg_dev) (void)hipMalloc(&dbg_dev, 128 * 8);
+      (void)hipMemsetAsync(dbg_dev, 0, 128 * 8, s);
+      L.dbg = dbg_dev;
+      L.dbg_block = atoi(getenv("D2AMD_DBG_BLOCK"));
+    }
+#endif
+    const char* tname = p->pooled_h <= 7 ? "pool_bwd_staged_r7" : "pool_bwd_staged_r14";
+    const bool timed = timing_begin(tname, s);
+    hipLaunchKernelGGL((pool_bwd_staged_kernel<T, VEC>), dim3((unsigned)total), dim3(2 * CT), 0, s, L, rec,
+                       (const T*)grad_output, nslab, (int)total, ids);
+    D2_LAUNCH_OK();
+    if (timed) timing_end(tname, s);
+#ifdef D2AMD_PROFILE
+    if (L.dbg && L.dbg_block >= 0) {
+      unsigned long long h[128];
+      (void)hipStreamSynchronize(s);
+      (void)hipMemcpy(h, L.dbg, sizeof(h), hipMemcpyDeviceToHost);
+      fprintf(stderr, "[d2amd dbg] staged block %d cycles %llu; stamps %llu:", L.dbg_block, h[125], h[127]);
+      for (unsigned i = 1; i < h[127] && i < 120; i++) fprintf(stderr, " %llu", h[i] - h[i - 1]);
+      fprintf(stderr, "\n");
+    }
+#endif
+    if (stamp_path) {
+      D2_HIP_OK(hipStreamSynchronize(s));
+      unsigned long long* h = (unsigned long long*)malloc((size_t)total * 5 * 8);
+      D2_HIP_OK(hipMemcpy(h, L.wgstamps, (size_t)total * 5 * 8, hipMemcpyDeviceToHost));
+      char fn[512];
+      snprintf(fn, sizeof(fn), "%s.pass0", stamp_path);
+      FILE* f = fopen(fn, "w");
+      if (f) {
+        for (long i = 0; i < total; i++)
+          fprintf(f, "%ld %llu %llu %llu %llu %llu\n", i, h[5 * i], h[5 * i + 1], h[5 * i + 2], h[5 * i + 3], h[5 * i + 4]);
+        fclose(f);
+      }
+      free(h);
+      (void)hipFree(L.wgstamps);
+      snprintf(fn, sizeof(fn), "%s.pass1", stamp_path);
+      f = fopen(fn, "w");  // no second launch
+      if (f) fclose(f);
+    }
+    return D2AMD_OK;
+  }
   SideStream* side = side_stream();
   bool forked = false;
   for (int pass = 1; pass >= 0; pass--) {  // pass 1: coarse levels (side stream), pass 0: fine levels

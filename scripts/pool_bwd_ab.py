@@ -29,7 +29,8 @@ for name, pooler, lists, grad in (("box", w.box_pooler, w.box_lists, w.gbox), ("
     torch.cuda.synchronize()
     ks = {}
     import ctypes
-    for k in (f"pool_bwd_fine_r{7 if name == 'box' else 14}", f"pool_bwd_coarse_r{7 if name == 'box' else 14}"):
+    r = 7 if name == "box" else 14
+    for k in (f"pool_bwd_staged_r{r}", f"pool_bwd_fine_r{r}", f"pool_bwd_coarse_r{r}"):
         tot, n = ctypes.c_double(0), ctypes.c_int(0)
         if _C.lib().d2amd_timing_read(k.encode(), ctypes.byref(tot), ctypes.byref(n)) == 0 and n.value:
             ks[k] = round(tot.value / n.value, 4)

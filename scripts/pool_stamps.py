@@ -16,6 +16,8 @@ torch.autograd.grad([y], w.feats, [grad], retain_graph=True)
 torch.cuda.synchronize()
 os.environ.pop("D2AMD_POOL_STAMPS")
 for ps, name in ((0, "fine levels"), (1, "coarse levels")):
+    if os.path.getsize(f"/tmp/pool_stamps.pass{ps}") == 0:
+        continue  # single-launch (LDS-staged) backward: everything is in pass 0
     d = np.loadtxt(f"/tmp/pool_stamps.pass{ps}", dtype=np.int64)
     d = d[d[:, 1] > 0]
     t0 = d[:, 1].min()
@@ -27,7 +29,7 @@ for ps, name in ((0, "fine levels"), (1, "coarse levels")):
     for nm, a, b in (("scan", st, ls), ("rois", ls, lp), ("write", lp, en), ("total", st, en)):
         v = b - a
         print(f"  {nm:6s}: mean {v.mean():.2f} p50 {np.median(v):.2f} p90 {np.percentile(v, 90):.2f} max {v.max():.2f} us")
-    for k in (0, 1, 2, 4, 8):
+    for k in (0, 1, 2, 4, 8, 16, 32):
         m = n == k
         if m.any():
             print(f"  tiles with {k} ROIs: {m.sum()}, total mean {(en - st)[m].mean():.2f} us, rois-phase mean {(lp - ls)[m].mean():.2f}")

@@ -107,8 +107,14 @@ def test_mask_head_vs_oracle(dtype, tol, B, C, M):
     gw = omh.mask_rcnn_loss_grad(xn, cls, gt, 0.5)
     gg = xt.grad.float().cpu().numpy()
     assert xt.grad.dtype == dtype
-    assert np.abs(gg - gw).max() <= tol * np.abs(gw).max()
-    assert np.array_equal(gg == 0, gw == 0) or dtype != torch.float32  # planes of other classes are exact zeros
+    sub = {torch.float16: 2.0 ** -25, torch.bfloat16: 0.0, torch.float32: 0.0}[dtype]  # f16 gradients this small are subnormal
+    assert np.abs(gg - gw).max() <= tol * np.abs(gw).max() + sub
+    other = np.ones(gg.shape, bool)
+    if C > 1:
+        other[np.arange(B), cls] = False
+    else:
+        other[:] = False
+    assert not gg[other].any()  # planes of the other classes are exact zeros
     pred = [Inst(pred_classes=torch.from_numpy(cls).to(DEV))]
     mask_rcnn_inference(x.to(DEV), pred)
     assert pred[0].pred_masks.dtype == dtype
