@@ -1,7 +1,7 @@
 // paste_masks_in_image: rasterise N soft masks (e.g. 28x28) into N full-image binary masks.
 // Replaces detectron2/layers/mask_ops.py:17-147 (grid build + F.grid_sample + threshold +
-// index_put) with ONE kernel: no fp32 grid tensor (8 B/px), no fp32 sampled image (4 B/px) --
-// only the compulsory 1 B/px output is written, 16 B per lane (coalesced "scatter").
+// index_put) with a zero fill + ONE kernel over the box regions: no fp32 grid tensor (8 B/px), no fp32
+// sampled image (4 B/px) -- only the compulsory 1 B/px output is written.
 // Bit-exact vs the reference's CPU path: same region rule (skip_empty=True, one mask per chunk,
 // mask_ops.py:38-43,116-119) and the same fp32 evaluation order as ATen's CPU grid_sampler
 // (see oracle/d2_oracle.c, orc_paste_sample).  Compiled with FP contraction off; the FMAs
@@ -12,17 +12,22 @@
 namespace d2amd {
 
 constexpr int PASTE_BLOCK = 256;
+constexpr int PASTE_ROWS = 8;  // image rows per workgroup: 8 rows x 32 column lanes
 
-template <typename T, int VEC>
-__global__ __launch_bounds__(PASTE_BLOCK) void paste_masks_kernel(
+// The output is 1 B / px and almost all of it is zeros (the boxes of the BASELINE shape cover ~5 % of the
+// N x H x W pixels).  The first version gave every thread 16 consecutive pixels of the flattened image: a wave
+// whose 1,024 pixels touched a box row evaluated the sampling path for all 16 of its iterations while the lanes
+// outside the box columns idled -- 36 of its 55 us (zero fill alone: 18 us, profiles/r01/v8_paste_bench.txt).
+// Now: (1) the whole output is zero-filled (hipMemsetAsync: 15 us for 107 MB, the writes land in the 256 MB
+// Infinity Cache), (2) this kernel visits only the box REGIONS, densely: workgroup = 8 image rows of one mask,
+// lane = (row, column mod 32), the row terms (gy, iy, row weights) once per thread, then a walk over the
+// region's columns.  Same fp32 evaluation order as before (bit-exact vs ATen's CPU grid_sampler).
+template <typename T>
+__global__ __launch_bounds__(PASTE_BLOCK) void paste_region_kernel(
     const T* __restrict__ masks, const float* __restrict__ boxes, int mh, int mw, int img_h, int img_w,
     float threshold, uint8_t* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) float smask[];  // [mh*mw]
   const int n = blockIdx.y;
-  const long plane = (long)img_h * img_w;
-  const long p0 = ((long)blockIdx.x * PASTE_BLOCK) * VEC;  // first pixel of this block
-  if (p0 >= plane) return;
-  const long p1 = min(plane, p0 + (long)PASTE_BLOCK * VEC);
   const float x0 = boxes[n * 4 + 0], y0 = boxes[n * 4 + 1], x1 = boxes[n * 4 + 2], y1 = boxes[n * 4 + 3];
   // region touched by the reference's CPU path (mask_ops.py:38-43), ints after clamp
   float fx0 = floorf(x0) - 1.f, fy0 = floorf(y0) - 1.f, fx1 = ceilf(x1) + 1.f, fy1 = ceilf(y1) + 1.f;
@@ -31,86 +36,53 @@ __global__ __launch_bounds__(PASTE_BLOCK) void paste_masks_kernel(
   fx1 = fx1 > (float)img_w ? (float)img_w : fx1;
   fy1 = fy1 > (float)img_h ? (float)img_h : fy1;
   const int rx0 = (int)fx0, ry0 = (int)fy0, rx1 = (int)fx1, ry1 = (int)fy1;
-  const int row_first = (int)(p0 / img_w), row_last = (int)((p1 - 1) / img_w);
-  const bool block_live = (row_last >= ry0) && (row_first < ry1) && (rx1 > rx0);  // uniform
-  if (block_live) {
-    for (int i = threadIdx.x; i < mh * mw; i += PASTE_BLOCK) smask[i] = to_f32(masks[(long)n * mh * mw + i]);
-    __syncthreads();
-  }
-  const long p = p0 + (long)threadIdx.x * VEC;
-  if (p >= plane) return;
-  uint8_t res[VEC];
-#pragma unroll
-  for (int v = 0; v < VEC; v++) res[v] = 0;
-  if (block_live) {
-    const float sx = (float)mw / 2.f, sy = (float)mh / 2.f;
-    const float dxw = x1 - x0, dyh = y1 - y0;
-#pragma unroll
-    for (int v = 0; v < VEC; v++) {
-      const long q = p + v;
-      if (q >= plane) break;
-      const int py = (int)(q / img_w), px = (int)(q - (long)py * img_w);
-      if (py < ry0 || py >= ry1 || px < rx0 || px >= rx1) continue;
-      const float gy = ((float)py + 0.5f - y0) / dyh * 2.f - 1.f;
-      const float gx = ((float)px + 0.5f - x0) / dxw * 2.f - 1.f;
-      const float ix = __builtin_fmaf(gx + 1.f, sx, -0.5f);
-      const float iy = __builtin_fmaf(gy + 1.f, sy, -0.5f);
-      const float flx = floorf(ix), fly = floorf(iy);
-      float val = 0.f;
-      if (flx > -4.0e8f && flx < 4.0e8f && fly > -4.0e8f && fly < 4.0e8f) {
-        const int xw = (int)flx, yn = (int)fly;
-        const float w = ix - flx, e = 1.f - w;
-        const float nn = iy - fly, s = 1.f - nn;
-        const float nw = s * e, ne = s * w, sw = nn * e, se = nn * w;
-        const bool x0ok = xw >= 0 && xw < mw, x1ok = xw + 1 >= 0 && xw + 1 < mw;
-        const bool y0ok = yn >= 0 && yn < mh, y1ok = yn + 1 >= 0 && yn + 1 < mh;
-        const float v00 = (y0ok && x0ok) ? smask[yn * mw + xw] : 0.f;
-        const float v01 = (y0ok && x1ok) ? smask[yn * mw + xw + 1] : 0.f;
-        const float v10 = (y1ok && x0ok) ? smask[(yn + 1) * mw + xw] : 0.f;
-        const float v11 = (y1ok && x1ok) ? smask[(yn + 1) * mw + xw + 1] : 0.f;
-        val = v00 * nw;
-        val = __builtin_fmaf(v01, ne, val);
-        val = __builtin_fmaf(v10, sw, val);
-        val = __builtin_fmaf(v11, se, val);
-      }
-      res[v] = threshold >= 0.f ? (uint8_t)(val >= threshold) : (uint8_t)(int)(val * 255.f);
+  const int row0 = blockIdx.x * PASTE_ROWS;
+  if (row0 >= ry1 || row0 + PASTE_ROWS <= ry0 || rx1 <= rx0) return;  // uniform: no region pixel in these rows
+  for (int i = threadIdx.x; i < mh * mw; i += PASTE_BLOCK) smask[i] = to_f32(masks[(long)n * mh * mw + i]);
+  __syncthreads();
+  const int py = row0 + (threadIdx.x >> 5);
+  if (py < ry0 || py >= ry1) return;
+  const float sx = (float)mw / 2.f, sy = (float)mh / 2.f;
+  const float dxw = x1 - x0, dyh = y1 - y0;
+  const float gy = ((float)py + 0.5f - y0) / dyh * 2.f - 1.f;
+  const float iy = __builtin_fmaf(gy + 1.f, sy, -0.5f);
+  const float fly = floorf(iy);
+  const bool yfin = fly > -4.0e8f && fly < 4.0e8f;
+  const int yn = yfin ? (int)fly : 0;
+  const float nn = iy - fly, s_ = 1.f - nn;
+  const bool y0ok = yn >= 0 && yn < mh, y1ok = yn + 1 >= 0 && yn + 1 < mh;
+  uint8_t* orow = out + ((long)n * img_h + py) * img_w;
+  for (int px = rx0 + (threadIdx.x & 31); px < rx1; px += 32) {
+    const float gx = ((float)px + 0.5f - x0) / dxw * 2.f - 1.f;
+    const float ix = __builtin_fmaf(gx + 1.f, sx, -0.5f);
+    const float flx = floorf(ix);
+    float val = 0.f;
+    if (flx > -4.0e8f && flx < 4.0e8f && yfin) {
+      const int xw = (int)flx;
+      const float w = ix - flx, e = 1.f - w;
+      const float nw = s_ * e, ne = s_ * w, sw = nn * e, se = nn * w;
+      const bool x0ok = xw >= 0 && xw < mw, x1ok = xw + 1 >= 0 && xw + 1 < mw;
+      const float v00 = (y0ok && x0ok) ? smask[yn * mw + xw] : 0.f;
+      const float v01 = (y0ok && x1ok) ? smask[yn * mw + xw + 1] : 0.f;
+      const float v10 = (y1ok && x0ok) ? smask[(yn + 1) * mw + xw] : 0.f;
+      const float v11 = (y1ok && x1ok) ? smask[(yn + 1) * mw + xw + 1] : 0.f;
+      val = v00 * nw;
+      val = __builtin_fmaf(v01, ne, val);
+      val = __builtin_fmaf(v10, sw, val);
+      val = __builtin_fmaf(v11, se, val);
     }
-  }
-  uint8_t* o = out + (long)n * plane + p;
-  if (VEC == 16) {
-    uint4 pk;
-    __builtin_memcpy(&pk, res, 16);
-    *reinterpret_cast<uint4*>(o) = pk;
-  } else if (VEC == 4) {
-    uint32_t pk;
-    __builtin_memcpy(&pk, res, 4);
-    *reinterpret_cast<uint32_t*>(o) = pk;
-  } else {
-    o[0] = res[0];
+    orow[px] = threshold >= 0.f ? (uint8_t)(val >= threshold) : (uint8_t)(int)(val * 255.f);
   }
 }
 
 template <typename T>
 static int launch_paste(const void* masks, const float* boxes, int n, int mh, int mw, int img_h, int img_w,
                         float threshold, uint8_t* out, hipStream_t s) {
-  const long plane = (long)img_h * img_w;
   const size_t lds = (size_t)mh * mw * sizeof(float);
-  const bool a16 = (plane % 16 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
-  const bool a4 = (plane % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 3) == 0);
-  dim3 block(PASTE_BLOCK);
-  if (a16) {
-    dim3 grid(cdiv(plane, (long)PASTE_BLOCK * 16), n);
-    hipLaunchKernelGGL((paste_masks_kernel<T, 16>), grid, block, lds, s, (const T*)masks, boxes, mh, mw, img_h,
-                       img_w, threshold, out);
-  } else if (a4) {
-    dim3 grid(cdiv(plane, (long)PASTE_BLOCK * 4), n);
-    hipLaunchKernelGGL((paste_masks_kernel<T, 4>), grid, block, lds, s, (const T*)masks, boxes, mh, mw, img_h,
-                       img_w, threshold, out);
-  } else {
-    dim3 grid(cdiv(plane, (long)PASTE_BLOCK), n);
-    hipLaunchKernelGGL((paste_masks_kernel<T, 1>), grid, block, lds, s, (const T*)masks, boxes, mh, mw, img_h,
-                       img_w, threshold, out);
-  }
+  D2_HIP_OK(hipMemsetAsync(out, 0, (size_t)n * img_h * img_w, s));
+  dim3 grid(cdiv(img_h, PASTE_ROWS), n);
+  hipLaunchKernelGGL((paste_region_kernel<T>), grid, dim3(PASTE_BLOCK), lds, s, (const T*)masks, boxes, mh, mw, img_h,
+                     img_w, threshold, out);
   D2_LAUNCH_OK();
   return D2AMD_OK;
 }
