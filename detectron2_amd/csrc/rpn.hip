@@ -15,6 +15,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "common.h"
+#include "topk.h"
 
 namespace d2amd {
 
@@ -50,7 +51,8 @@ __device__ __forceinline__ bool rpn_finite(float v) { return fabsf(v) <= 3.40282
 
 __global__ __launch_bounds__(256) void rpn_decode_kernel(
     const float* __restrict__ logits, const float4* __restrict__ deltas, const float4* __restrict__ anchors,
-    const uint32_t* __restrict__ sorted_vals, int N, int Atot, RpnLevels lv, RpnImages im, float wx, float wy, float ww,
+    const uint32_t* __restrict__ sorted_vals, const uint32_t* __restrict__ sel, int N, int Atot, RpnLevels lv,
+    RpnImages im, float wx, float wy, float ww,
     float wh, float scale_clamp, float min_size, float4* __restrict__ boxes, float* __restrict__ scores,
     uint8_t* __restrict__ valid, int64_t* __restrict__ level_ids, int* __restrict__ flags) {
   const int Ktot = lv.koff[lv.L];
@@ -63,7 +65,8 @@ __global__ __launch_bounds__(256) void rpn_decode_kernel(
     if (q < lv.L && j >= lv.koff[q]) l = q;
   const int r = j - lv.koff[l];
   // the sort is keyed by (image, level): segment (img, l) starts at img * Atot + aoff[l]
-  const int a = (int)sorted_vals[(long)img * Atot + lv.aoff[l] + r];
+  // radix-select path: sel holds the rank-ordered anchor index inside the level; sort path: the sorted values
+  const int a = sel ? lv.aoff[l] + (int)sel[(long)img * Ktot + j] : (int)sorted_vals[(long)img * Atot + lv.aoff[l] + r];
   const float score = logits[(long)img * Atot + a];
   const float4 b = anchors[a];
   const float4 d = deltas[(long)img * Atot + a];
@@ -90,6 +93,57 @@ __global__ __launch_bounds__(256) void rpn_decode_kernel(
   if (img == 0) level_ids[j] = l;
 }
 
+// ---- dense detectors (RetinaNet / FCOS-style heads): meta_arch/dense_detector.py:186-245 ---------------------
+struct DensePtrs {
+  const float* logits[D2AMD_RPN_MAX_LEVELS];   // [N, A_l, K]
+  const float4* deltas[D2AMD_RPN_MAX_LEVELS];  // [N, A_l]
+  const float4* anchors[D2AMD_RPN_MAX_LEVELS]; // [A_l]
+  int A[D2AMD_RPN_MAX_LEVELS];
+};
+
+// one thread per output row: decode the selected (anchor, class) pairs; rows past a segment's count are parked
+// as zero boxes with score -inf (they neither suppress nor get suppressed in the NMS that follows)
+__global__ __launch_bounds__(256) void dense_decode_kernel(DensePtrs D, const uint32_t* __restrict__ sel,
+                                                          const int* __restrict__ cnt, int N, int K, RpnLevels lv,
+                                                          float wx, float wy, float ww, float wh, float scale_clamp,
+                                                          float4* __restrict__ boxes, float* __restrict__ scores,
+                                                          int64_t* __restrict__ classes, uint8_t* __restrict__ valid) {
+  const int Ktot = lv.koff[lv.L];
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)N * Ktot) return;
+  const int img = (int)(t / Ktot), j = (int)(t - (long)img * Ktot);
+  int l = 0;
+#pragma unroll
+  for (int q = 1; q < D2AMD_RPN_MAX_LEVELS; q++)
+    if (q < lv.L && j >= lv.koff[q]) l = q;
+  const int r = j - lv.koff[l];
+  if (r >= cnt[img * lv.L + l]) {
+    boxes[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    scores[t] = -__builtin_inff();
+    classes[t] = 0;
+    valid[t] = 0;
+    return;
+  }
+  const uint32_t e = sel[t];
+  const int a = (int)(e / (uint32_t)K), c = (int)(e - (uint32_t)a * (uint32_t)K);
+  const float x = D.logits[l][((long)img * D.A[l] + a) * K + c];
+  const float4 b = D.anchors[l][a];
+  const float4 d = D.deltas[l][(long)img * D.A[l] + a];
+  // box_regression.py:88-116, fp32 (dense_detector.py:220-222: no clip, no size filter here)
+  const float widths = b.z - b.x, heights = b.w - b.y;
+  const float ctr_x = b.x + 0.5f * widths, ctr_y = b.y + 0.5f * heights;
+  const float dx = d.x / wx, dy = d.y / wy;
+  float dw = d.z / ww, dh = d.w / wh;
+  dw = dw != dw ? dw : fminf(dw, scale_clamp);
+  dh = dh != dh ? dh : fminf(dh, scale_clamp);
+  const float pcx = dx * widths + ctr_x, pcy = dy * heights + ctr_y;
+  const float pw = expf(dw) * widths, ph = expf(dh) * heights;
+  boxes[t] = make_float4(pcx - 0.5f * pw, pcy - 0.5f * ph, pcx + 0.5f * pw, pcy + 0.5f * ph);
+  scores[t] = 1.f / (1.f + expf(-x));  // the value the selection ranked
+  classes[t] = c;
+  valid[t] = 1;
+}
+
 struct RpnWs { u64 *k0, *k1; uint32_t *v0, *v1; int* flags; void* temp; size_t temp_bytes, total; };
 static size_t ral(size_t x) { return (x + 255) / 256 * 256; }
 static RpnWs rpn_carve(long n, void* base) {
@@ -112,9 +166,20 @@ static RpnWs rpn_carve(long n, void* base) {
 
 using namespace d2amd;
 
+// radix-select path: [sel N x Ktot u32][cnt N x L int][topk workspace]; sized for the worst case Ktot = Atot, one level
+static size_t rpn_select_ws(int N, int Atot) {
+  TopkInput in{};
+  in.N = N; in.L = 1;
+  in.size[0] = Atot; in.k[0] = Atot < TOPK_MAX_K ? Atot : TOPK_MAX_K; in.koff[0] = 0; in.koff[1] = in.k[0];
+  // a split into L levels needs at most L x the per-segment state of one level and never more candidates
+  return ral((size_t)N * Atot * 4) + ral((size_t)N * D2AMD_RPN_MAX_LEVELS * 4) +
+      topk_workspace_bytes(in) * D2AMD_RPN_MAX_LEVELS;
+}
+
 extern "C" size_t d2amd_rpn_select_workspace_bytes(int N, int Atot) {
   if (N <= 0 || Atot <= 0) return 256;
-  return rpn_carve((long)N * Atot, nullptr).total + 256;
+  const size_t a = rpn_carve((long)N * Atot, nullptr).total + 256, b = rpn_select_ws(N, Atot) + 256;
+  return a > b ? a : b;
 }
 
 extern "C" int d2amd_rpn_select_proposals(const float* logits, const float* deltas, const float* anchors, int N,
@@ -148,6 +213,38 @@ extern "C" int d2amd_rpn_select_proposals(const float* logits, const float* delt
   for (int i = 0; i < N; i++) { im.h[i] = image_hw[2 * i]; im.w[i] = image_hw[2 * i + 1]; }
   hipStream_t s = (hipStream_t)stream;
   const long n = (long)N * Atot;
+  static const bool use_sort = getenv("D2AMD_RPN_SORT") != nullptr;  // A/B switch: the first (full radix sort) path
+  if (pre_nms_topk <= TOPK_MAX_K && !use_sort) {
+    // radix-select top-k per (image, level), then decode of the selected anchors
+    TopkInput in{};
+    in.N = N; in.L = L;
+    for (int l = 0; l < L; l++) {
+      in.ptr[l] = logits + lv.aoff[l];
+      in.stride[l] = Atot;
+      in.size[l] = level_sizes[l];
+      in.k[l] = lv.koff[l + 1] - lv.koff[l];
+      in.koff[l] = lv.koff[l];
+    }
+    in.koff[L] = (int)k;
+    const size_t off_cnt = ral((size_t)N * k * 4), off_tk = off_cnt + ral((size_t)N * L * 4);
+    const size_t need = off_tk + topk_workspace_bytes(in);
+    if (workspace == nullptr || workspace_bytes < need) {
+      set_error("rpn_select_proposals: workspace too small (%zu < %zu)", workspace_bytes, need);
+      return D2AMD_EWORKSPACE;
+    }
+    uint32_t* sel = (uint32_t*)workspace;
+    int* cnt = (int*)((char*)workspace + off_cnt);
+    D2_HIP_OK(hipMemsetAsync(flags_out, 0, sizeof(int), s));
+    int rc = topk_select(in, false, false, 0.f, sel, cnt, (char*)workspace + off_tk, workspace_bytes - off_tk, s);
+    if (rc) return rc;
+    const long nt = (long)N * k;
+    hipLaunchKernelGGL(rpn_decode_kernel, dim3(cdiv(nt, 256)), dim3(256), 0, s, logits, (const float4*)deltas,
+                       (const float4*)anchors, (const uint32_t*)nullptr, (const uint32_t*)sel, N, Atot, lv, im,
+                       weights[0], weights[1], weights[2], weights[3], scale_clamp, min_box_size, (float4*)boxes_out,
+                       scores_out, valid_out, level_out, flags_out);
+    D2_LAUNCH_OK();
+    return D2AMD_OK;
+  }
   RpnWs w = rpn_carve(n, workspace);
   if (workspace == nullptr || workspace_bytes < w.total) {
     set_error("rpn_select_proposals: workspace too small (%zu < %zu)", workspace_bytes, w.total);
@@ -162,8 +259,76 @@ extern "C" int d2amd_rpn_select_proposals(const float* logits, const float* delt
                                       (unsigned)(32 + seg_bits), s, false));
   const long nt = (long)N * k;
   hipLaunchKernelGGL(rpn_decode_kernel, dim3(cdiv(nt, 256)), dim3(256), 0, s, logits, (const float4*)deltas,
-                     (const float4*)anchors, w.v1, N, Atot, lv, im, weights[0], weights[1], weights[2], weights[3],
+                     (const float4*)anchors, w.v1, (const uint32_t*)nullptr, N, Atot, lv, im, weights[0], weights[1],
+                     weights[2], weights[3],
                      scale_clamp, min_box_size, (float4*)boxes_out, scores_out, valid_out, level_out, flags_out);
+  D2_LAUNCH_OK();
+  return D2AMD_OK;
+}
+
+static int dense_layout(int N, const int* level_anchors, int L, int num_classes, int topk, TopkInput& in, RpnLevels& lv) {
+  D2_CHECK_ARG(N >= 0 && N <= D2AMD_POOLER_MAX_IMAGES && L >= 1 && L <= D2AMD_RPN_MAX_LEVELS && level_anchors,
+               "dense_select: bad image / level count");
+  D2_CHECK_ARG(num_classes >= 1 && topk >= 1 && topk <= TOPK_MAX_K, "dense_select: classes %d, topk %d (max %d)",
+               num_classes, topk, TOPK_MAX_K);
+  in = TopkInput{};
+  lv = RpnLevels{};
+  in.N = N > 0 ? N : 1; in.L = L; lv.L = L;
+  long k = 0;
+  for (int l = 0; l < L; l++) {
+    const long e = (long)level_anchors[l] * num_classes;
+    D2_CHECK_ARG(level_anchors[l] >= 0 && e < (1l << 31), "dense_select: level %d too large", l);
+    in.size[l] = (int)e; in.stride[l] = e;
+    in.k[l] = (int)(e < topk ? e : topk);
+    in.koff[l] = (int)k; lv.koff[l] = (int)k;
+    k += in.k[l];
+  }
+  in.koff[L] = (int)k;
+  for (int l = L; l <= D2AMD_RPN_MAX_LEVELS; l++) lv.koff[l] = (int)k;
+  return D2AMD_OK;
+}
+
+extern "C" size_t d2amd_dense_select_workspace_bytes(int N, const int* level_anchors, int L, int num_classes,
+                                                     int topk_candidates) {
+  TopkInput in; RpnLevels lv;
+  if (dense_layout(N, level_anchors, L, num_classes, topk_candidates, in, lv)) return 256;
+  return ral((size_t)in.N * in.koff[L] * 4) + topk_workspace_bytes(in) + 256;
+}
+
+extern "C" int d2amd_dense_select_predictions(const float* const* logits, const float* const* deltas,
+                                              const float* const* anchors, int N, const int* level_anchors, int L,
+                                              int num_classes, float score_thresh, int topk_candidates,
+                                              const float* weights, float scale_clamp, float* boxes_out,
+                                              float* scores_out, int64_t* classes_out, uint8_t* valid_out,
+                                              int* counts_out, void* workspace, size_t workspace_bytes, void* stream) {
+  TopkInput in; RpnLevels lv;
+  int rc = dense_layout(N, level_anchors, L, num_classes, topk_candidates, in, lv);
+  if (rc) return rc;
+  const long k = in.koff[L];
+  if (N == 0 || k == 0) return D2AMD_OK;
+  D2_CHECK_ARG(logits && deltas && anchors && weights && boxes_out && scores_out && classes_out && valid_out &&
+               counts_out, "dense_select: null pointer");
+  DensePtrs D{};
+  for (int l = 0; l < L; l++) {
+    D2_CHECK_ARG(level_anchors[l] == 0 || (logits[l] && deltas[l] && anchors[l]), "dense_select: null level %d", l);
+    D.logits[l] = logits[l]; D.deltas[l] = (const float4*)deltas[l]; D.anchors[l] = (const float4*)anchors[l];
+    D.A[l] = level_anchors[l];
+    in.ptr[l] = logits[l];
+  }
+  const size_t off_tk = ral((size_t)N * k * 4);
+  const size_t need = off_tk + topk_workspace_bytes(in);
+  if (workspace == nullptr || workspace_bytes < need) {
+    set_error("dense_select: workspace too small (%zu < %zu)", workspace_bytes, need);
+    return D2AMD_EWORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  uint32_t* sel = (uint32_t*)workspace;
+  rc = topk_select(in, true, true, score_thresh, sel, counts_out, (char*)workspace + off_tk, workspace_bytes - off_tk, s);
+  if (rc) return rc;
+  const long nt = (long)N * k;
+  hipLaunchKernelGGL(dense_decode_kernel, dim3(cdiv(nt, 256)), dim3(256), 0, s, D, sel, counts_out, N, num_classes, lv,
+                     weights[0], weights[1], weights[2], weights[3], scale_clamp, (float4*)boxes_out, scores_out,
+                     classes_out, valid_out);
   D2_LAUNCH_OK();
   return D2AMD_OK;
 }

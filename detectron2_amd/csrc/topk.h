@@ -1,0 +1,36 @@
+// Segmented top-k selection by radix select (internal; used by rpn.hip).  See topk.hip.
+#pragma once
+#include "common.h"
+
+namespace d2amd {
+
+constexpr int TOPK_MAX_LEVELS = 8;
+constexpr int TOPK_MAX_K = 16384;  // per segment: the final ordering is an LDS bitonic sort of 64-bit keys (128 KB)
+
+// Scores of N images x L levels.  Element i of (image, level l) lives at ptr[l][image * stride[l] + i].
+struct TopkInput {
+  const float* ptr[TOPK_MAX_LEVELS];
+  long stride[TOPK_MAX_LEVELS];
+  int size[TOPK_MAX_LEVELS];      // elements per image on level l
+  int k[TOPK_MAX_LEVELS];         // selection size of a (image, level) segment: min(size, topk)
+  int koff[TOPK_MAX_LEVELS + 1];  // prefix of k
+  int L, N;
+};
+
+size_t topk_workspace_bytes(const TopkInput& in);
+
+// For every segment (image, level): the k[l] best candidates, best first, ties towards the lower element index.
+//   sigmoid:  the score of an element is 1 / (1 + exp(-x)) of the stored value (fp32), else the value itself
+//   use_thr:  only elements whose score is > thr are candidates (a segment may then select fewer than k[l])
+// Outputs: sel [N][Ktot] element index inside its level (rows [koff[l], koff[l] + cnt) of a segment are valid),
+//          cnt [N][L] selected count per segment.  Nothing synchronises with the host.
+int topk_select(const TopkInput& in, bool sigmoid, bool use_thr, float thr, uint32_t* sel, int* cnt, void* ws,
+                size_t ws_bytes, hipStream_t s);
+
+__device__ __forceinline__ uint32_t topk_desc_key(float s) {  // ascending key order = descending score; NaN first
+  uint32_t u = __float_as_uint(s);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return ~u;
+}
+
+}  // namespace d2amd

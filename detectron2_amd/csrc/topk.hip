@@ -1,0 +1,453 @@
+// Segmented top-k by RADIX SELECT: the k best of every (image, feature level) segment without sorting the
+// segment.  Serves the pre-NMS selection of the RPN (proposal_generator/proposal_utils.py:62-80: `logits_i.topk`)
+// and of RetinaNet / dense detectors (meta_arch/dense_detector.py:207-223: score threshold, `nonzero`, `topk`).
+// The first RPN path radix-SORTED all N x 268,569 (key, value) pairs (rocprim, 35-bit keys): 0.25 of its 0.44 ms;
+// for RetinaNet's N x 16 M class scores a sort is out of the question.  Here:
+//   1-3. three histogram passes over the scores (11 + 11 + 10 key bits; LDS-privatised histograms flushed with
+//        atomics; the last workgroup of a segment to finish scans the bins and narrows the key prefix) find the
+//        exact 32-bit key T of the k-th best candidate, the number c_lt of strictly better ones and how many
+//        ties at T are needed;
+//   4.   (only if more ties than needed) ties are counted per workgroup and prefix-summed, so that the ones with
+//        the lowest element index are taken: the selection is deterministic;
+//   5.   one compaction pass writes the <= k selected (key, index) pairs;
+//   6.   one workgroup per segment orders them in LDS (bitonic, 64-bit keys = score key : index).
+// Every pass reads 4 B per element (HBM bound); nothing synchronises with the host.
+#include "topk.h"
+
+namespace d2amd {
+
+constexpr int TK_THREADS = 256;
+constexpr int TK_ITEMS = 16;
+constexpr int TK_CHUNK = TK_THREADS * TK_ITEMS;  // elements per workgroup
+constexpr int TK_BINS = 2048;
+
+struct SegState {
+  uint32_t prefix;  // key bits resolved so far
+  int k_rem;        // still to take from the current bucket
+  int c_lt;         // candidates strictly better than the current bucket
+  int total;        // candidates of the segment
+  int take_all;     // fewer candidates than k: all of them are selected
+  int ties_total, need;
+  int done[4];      // workgroups finished per pass (0-2: histogram passes, 3: tie count)
+  int cnt_lt, cnt_tie;
+  int cnt;          // selected = min(k, total)
+  int pad[2];
+};
+static_assert(sizeof(SegState) == 64, "SegState layout");
+
+struct TkParams {
+  TopkInput in;
+  int sigmoid, use_thr;
+  float thr, xlo;  // xlo: stored values below it cannot pass the threshold (saves the exp)
+  int maxblk;      // workgroups per segment in the grid
+  int tickets;     // 1: the last workgroup of a segment (atomic ticket) scans; 0: separate scan launches
+  int reps;        // consecutive TK_CHUNK chunks per workgroup (keeps the workgroups of a segment <= ~256: every
+                   // workgroup takes a ticket on ONE address per pass, and 3,000 returning atomics there cost 0.3 ms)
+};
+
+__device__ __forceinline__ bool tk_key(const TkParams& P, float x, uint32_t& key) {
+  float s = x;
+  if (P.sigmoid) {
+    if (P.use_thr && x < P.xlo) return false;
+    s = 1.f / (1.f + expf(-x));
+  }
+  if (P.use_thr && !(s > P.thr)) return false;
+  key = topk_desc_key(s);
+  return true;
+}
+
+// exclusive prefix of one int per thread over the 256-thread workgroup (wave shuffles + 4 wave totals through LDS);
+// a serial scan by one thread costs ~130 cycles of dependent LDS latency per element: 14 us for 256
+__device__ __forceinline__ int tk_block_excl_scan(int v, int* lds4, int& total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int y = __shfl_up(x, d, 64);
+    if (lane >= d) x += y;
+  }
+  __syncthreads();  // lds4 may still be read from a previous call
+  if (lane == 63) lds4[w] = x;
+  __syncthreads();
+  int base = 0;
+  total = 0;
+#pragma unroll
+  for (int i = 0; i < TK_THREADS / 64; i++) {
+    const int t = lds4[i];
+    if (i < w) base += t;
+    total += t;
+  }
+  return base + x - v;
+}
+
+// the TK_ITEMS values of this thread, all loads in flight together (out of range: a value no test accepts)
+__device__ __forceinline__ void tk_load(const float* __restrict__ x, long base, int size, float (&v)[TK_ITEMS], bool (&ok)[TK_ITEMS]) {
+#pragma unroll
+  for (int j = 0; j < TK_ITEMS; j++) {
+    const long i = base + (long)j * TK_THREADS + threadIdx.x;
+    ok[j] = i < size;
+    v[j] = x[ok[j] ? i : (long)size - 1];
+  }
+}
+
+template <typename TT>
+__device__ __forceinline__ TT ld_agent(const TT* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// scan of a segment's bins (ascending key = best first) by one 256-thread workgroup: narrows the key prefix
+template <int PASS>
+__device__ __forceinline__ void tk_scan_bins(const TkParams& P, SegState* S, const int* gh, int l) {
+  const int tid = threadIdx.x;
+  const uint32_t prefix = PASS > 0 ? S->prefix : 0u;
+  constexpr int BINS = PASS == 2 ? 1024 : 2048, PER = BINS / TK_THREADS;
+  __shared__ int lds4[TK_THREADS / 64];
+  __shared__ int s_bin, s_before;
+  int loc[PER], sum = 0;
+#pragma unroll
+  for (int j = 0; j < PER; j++) { loc[j] = ld_agent(&gh[tid * PER + j]); sum += loc[j]; }
+  if (tid == 0) { s_bin = -1; s_before = 0; }
+  int s_total;
+  int run = tk_block_excl_scan(sum, lds4, s_total);
+  int k_rem = PASS == 0 ? P.in.k[l] : S->k_rem;
+  if (PASS == 0 && s_total < k_rem) {  // not enough candidates: everything is selected (uniform)
+    if (tid == 0) { S->total = s_total; S->take_all = 1; S->cnt = s_total; }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < PER; j++) {
+    if (run < k_rem && run + loc[j] >= k_rem) { s_bin = tid * PER + j; s_before = run; }
+    run += loc[j];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const int b = s_bin;  // exists: k_rem >= 1 and the bins hold >= k_rem candidates
+    if (PASS == 0) { S->total = s_total; S->cnt = k_rem; S->prefix = (uint32_t)b; }
+    else if (PASS == 1) S->prefix = (prefix << 11) | (uint32_t)b;
+    else S->prefix = (prefix << 10) | (uint32_t)b;
+    S->c_lt = (PASS == 0 ? 0 : S->c_lt) + s_before;
+    S->k_rem = k_rem - s_before;
+    if (PASS == 2) { S->ties_total = ld_agent(&gh[b]); S->need = k_rem - s_before; }
+  }
+}
+
+// PASS 0: bins = key >> 21 of all candidates; 1: (key >> 10) & 2047 where key >> 21 == prefix; 2: key & 1023 where
+// key >> 10 == prefix.
+template <int PASS>
+__global__ __launch_bounds__(TK_THREADS) void tk_hist_kernel(TkParams P, SegState* __restrict__ st, int* __restrict__ hist) {
+  const int seg = blockIdx.y, l = seg % P.in.L, img = seg / P.in.L;
+  const int size = P.in.size[l];
+  const long span = (long)TK_CHUNK * P.reps;
+  const long base0 = (long)blockIdx.x * span;
+  if (base0 >= size) return;
+  const int nblk = (int)((size + span - 1) / span);
+  SegState* S = st + seg;
+  const int tid = threadIdx.x;
+  if (PASS > 0 && S->take_all) return;  // written by the previous launch
+  __shared__ int h[TK_BINS];
+  __shared__ int s_last;
+  for (int i = tid; i < TK_BINS; i += TK_THREADS) h[i] = 0;
+  __syncthreads();
+  const uint32_t prefix = PASS > 0 ? S->prefix : 0u;
+  const float* x = P.in.ptr[l] + (long)img * P.in.stride[l];
+  for (int rep = 0; rep < P.reps; rep++) {
+    const long base = base0 + (long)rep * TK_CHUNK;
+    if (base >= size) break;
+    float v[TK_ITEMS];
+    bool ok[TK_ITEMS];
+    tk_load(x, base, size, v, ok);
+#pragma unroll
+    for (int j = 0; j < TK_ITEMS; j++) {
+      uint32_t key;
+      if (!ok[j] || !tk_key(P, v[j], key)) continue;
+      if (PASS == 0) atomicAdd(&h[key >> 21], 1);
+      else if (PASS == 1) { if ((key >> 21) == prefix) atomicAdd(&h[(key >> 10) & 2047u], 1); }
+      else { if ((key >> 10) == prefix) atomicAdd(&h[key & 1023u], 1); }
+    }
+  }
+  __syncthreads();
+  int* gh = hist + ((long)seg * 3 + PASS) * TK_BINS;
+  for (int i = tid; i < TK_BINS; i += TK_THREADS)
+    if (h[i]) atomicAdd(&gh[i], h[i]);
+  if (!P.tickets) return;  // tk_scan_kernel follows
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) s_last = atomicAdd(&S->done[PASS], 1) == nblk - 1;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  tk_scan_bins<PASS>(P, S, gh, l);
+}
+
+// separate launch of the bin scan (large segments: thousands of tickets on one address would serialise in L2)
+template <int PASS>
+__global__ __launch_bounds__(TK_THREADS) void tk_scan_kernel(TkParams P, SegState* __restrict__ st, int* __restrict__ hist) {
+  const int seg = blockIdx.x, l = seg % P.in.L;
+  SegState* S = st + seg;
+  if (P.in.size[l] == 0 || (PASS > 0 && S->take_all)) return;
+  tk_scan_bins<PASS>(P, S, hist + ((long)seg * 3 + PASS) * TK_BINS, l);
+}
+
+// exclusive prefix of the per-workgroup tie counts of one segment (one 256-thread workgroup; thread t owns a run)
+__device__ __forceinline__ void tk_ties_scan(int* bt, int nblk) {
+  const int tid = threadIdx.x;
+  const int per = (nblk + TK_THREADS - 1) / TK_THREADS;
+  const int lo = min(tid * per, nblk), hi = min(lo + per, nblk);
+  int sum = 0;
+  for (int i = lo; i < hi; i++) sum += ld_agent(&bt[i]);
+  __shared__ int lds4[TK_THREADS / 64];
+  int tot;
+  int run = tk_block_excl_scan(sum, lds4, tot);
+  for (int i = lo; i < hi; i++) { const int v = ld_agent(&bt[i]); bt[i] = run; run += v; }
+}
+
+// per workgroup: number of ties (key == T); last workgroup: exclusive prefix over the workgroups of the segment
+__global__ __launch_bounds__(TK_THREADS) void tk_ties_kernel(TkParams P, SegState* __restrict__ st, int* __restrict__ blk_ties) {
+  const int seg = blockIdx.y, l = seg % P.in.L, img = seg / P.in.L;
+  const int size = P.in.size[l];
+  const long span = (long)TK_CHUNK * P.reps;
+  const long base0 = (long)blockIdx.x * span;
+  if (base0 >= size) return;
+  const int nblk = (int)((size + span - 1) / span);
+  SegState* S = st + seg;
+  if (S->take_all || S->ties_total <= S->need) return;  // all ties are taken: no order needed
+  const int tid = threadIdx.x;
+  const uint32_t T = S->prefix;
+  const float* x = P.in.ptr[l] + (long)img * P.in.stride[l];
+  int c = 0;
+  for (int rep = 0; rep < P.reps; rep++) {
+    const long base = base0 + (long)rep * TK_CHUNK;
+    if (base >= size) break;
+    float v[TK_ITEMS];
+    bool ok[TK_ITEMS];
+    tk_load(x, base, size, v, ok);
+#pragma unroll
+    for (int j = 0; j < TK_ITEMS; j++) {
+      uint32_t key;
+      if (ok[j] && tk_key(P, v[j], key) && key == T) c++;
+    }
+  }
+  __shared__ int red[TK_THREADS];
+  __shared__ int s_last;
+  red[tid] = c;
+  __syncthreads();
+  for (int s2 = TK_THREADS / 2; s2 > 0; s2 >>= 1) {
+    if (tid < s2) red[tid] += red[tid + s2];
+    __syncthreads();
+  }
+  int* bt = blk_ties + (long)seg * P.maxblk;
+  if (tid == 0) {
+    __hip_atomic_store(&bt[blockIdx.x], red[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (P.tickets) {
+      __threadfence();
+      s_last = atomicAdd(&S->done[3], 1) == nblk - 1;
+    } else {
+      s_last = 0;  // tk_ties_scan_kernel follows
+    }
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  tk_ties_scan(bt, nblk);
+}
+
+__global__ __launch_bounds__(TK_THREADS) void tk_ties_scan_kernel(TkParams P, SegState* __restrict__ st, int* __restrict__ blk_ties) {
+  const int seg = blockIdx.x, l = seg % P.in.L;
+  const SegState* S = st + seg;
+  const int size = P.in.size[l];
+  if (size == 0 || S->take_all || S->ties_total <= S->need) return;
+  const long span = (long)TK_CHUNK * P.reps;
+  tk_ties_scan(blk_ties + (long)seg * P.maxblk, (int)((size + span - 1) / span));
+}
+
+__global__ __launch_bounds__(TK_THREADS) void tk_compact_kernel(TkParams P, SegState* __restrict__ st,
+                                                               const int* __restrict__ blk_ties,
+                                                               unsigned long long* __restrict__ cand, int kmax) {
+  const int seg = blockIdx.y, l = seg % P.in.L, img = seg / P.in.L;
+  const int size = P.in.size[l];
+  const long span = (long)TK_CHUNK * P.reps;
+  const long base0 = (long)blockIdx.x * span;
+  if (base0 >= size) return;
+  SegState* S = st + seg;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool take_all = S->take_all != 0;
+  const uint32_t T = S->prefix;
+  const int c_lt = S->c_lt, need = S->need;
+  const bool ordered = !take_all && S->ties_total > need;  // uniform
+  const float* x = P.in.ptr[l] + (long)img * P.in.stride[l];
+  unsigned long long* out = cand + (long)seg * kmax;
+  __shared__ int wcnt[TK_ITEMS][TK_THREADS / 64];
+  __shared__ int lds4[TK_THREADS / 64];
+  __shared__ int s_base_lt, s_base_tie;
+  int before = ordered ? blk_ties[(long)seg * P.maxblk + blockIdx.x] : 0;  // ties in the workgroups before this one
+  for (int rep = 0; rep < P.reps; rep++) {
+  const long base = base0 + (long)rep * TK_CHUNK;
+  if (base >= size) break;  // uniform
+  __syncthreads();          // the previous chunk's readers of wcnt / s_base_* are done
+  uint32_t keys[TK_ITEMS];
+  unsigned lt_bits = 0, tie_bits = 0;  // bit j: element j of this thread is strictly better / a tie
+  unsigned long long bal[TK_ITEMS];
+  float v[TK_ITEMS];
+  bool ok[TK_ITEMS];
+  tk_load(x, base, size, v, ok);
+#pragma unroll
+  for (int j = 0; j < TK_ITEMS; j++) {
+    uint32_t key = 0;
+    const bool c = ok[j] && tk_key(P, v[j], key);
+    keys[j] = key;
+    if (c && (take_all || key < T)) lt_bits |= 1u << j;
+    const bool tie = c && !take_all && key == T;
+    if (tie) tie_bits |= 1u << j;
+    if (ordered) {  // uniform
+      bal[j] = __ballot(tie);
+      if (lane == 0) wcnt[j][wave] = __builtin_popcountll(bal[j]);
+    }
+  }
+  if (!__syncthreads_or((lt_bits | tie_bits) != 0u)) continue;  // uniform: nothing selected in this chunk (the usual case)
+  // one atomic per workgroup and counter (2,000 returning atomics on ONE address serialise in L2: 20 us)
+  int tot_lt, tot_tie = 0;
+  const int my_lt = tk_block_excl_scan(__builtin_popcount(lt_bits), lds4, tot_lt);
+  int my_tie = 0;
+  if (!ordered) my_tie = tk_block_excl_scan(__builtin_popcount(tie_bits), lds4, tot_tie);
+  if (tid == 0) {
+    s_base_lt = tot_lt ? atomicAdd(&S->cnt_lt, tot_lt) : 0;
+    s_base_tie = tot_tie ? atomicAdd(&S->cnt_tie, tot_tie) : 0;
+  }
+  __syncthreads();
+  {
+    int p_lt = s_base_lt + my_lt, p_tie = c_lt + s_base_tie + my_tie;
+#pragma unroll
+    for (int j = 0; j < TK_ITEMS; j++) {
+      const long i = base + (long)j * TK_THREADS + tid;
+      const unsigned long long e = ((unsigned long long)keys[j] << 32) | (uint32_t)i;
+      if (lt_bits & (1u << j)) out[p_lt++] = e;
+      else if (!ordered && (tie_bits & (1u << j))) out[p_tie++] = e;
+    }
+  }
+  if (!ordered) continue;
+  // rank of a tie in element-index order: rows j ascending, inside a row waves then lanes ascending
+  // (wcnt is complete: the scans above contain workgroup barriers)
+#pragma unroll
+  for (int j = 0; j < TK_ITEMS; j++) {
+    int row_before = 0, row_total = 0;
+#pragma unroll
+    for (int w = 0; w < TK_THREADS / 64; w++) {
+      const int v = wcnt[j][w];
+      if (w < wave) row_before += v;
+      row_total += v;
+    }
+    if (tie_bits & (1u << j)) {
+      const int rank = before + row_before + __builtin_popcountll(bal[j] & ((1ull << lane) - 1ull));
+      if (rank < need) {
+        const long i = base + (long)j * TK_THREADS + tid;
+        out[c_lt + rank] = ((unsigned long long)keys[j] << 32) | (uint32_t)i;
+      }
+    }
+    before += row_total;
+  }
+  }
+}
+
+// one workgroup per segment: bitonic sort of the selected (key : index) pairs in LDS, write the indices
+__global__ __launch_bounds__(1024) void tk_sort_kernel(TkParams P, const SegState* __restrict__ st,
+                                                      const unsigned long long* __restrict__ cand, int kmax, int pow2,
+                                                      uint32_t* __restrict__ sel, int* __restrict__ cnt_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long sk[];
+  const int seg = blockIdx.x, l = seg % P.in.L, img = seg / P.in.L;
+  const int tid = threadIdx.x;
+  const int n = st[seg].cnt;
+  if (tid == 0) cnt_out[seg] = n;
+  int p2 = 1;
+  while (p2 < n) p2 <<= 1;  // uniform; <= pow2
+  const unsigned long long* in = cand + (long)seg * kmax;
+  for (int i = tid; i < p2; i += 1024) sk[i] = i < n ? in[i] : ~0ull;
+  __syncthreads();
+  // element i is handled by thread i % 1024: for j < 64 the partner i ^ j belongs to the same wave, whose LDS
+  // accesses are ordered -- only the steps with j >= 64 need the workgroup barrier (15 of the 66 steps of 2,048)
+  for (int k2 = 2; k2 <= p2; k2 <<= 1) {
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < p2; i += 1024) {
+        const int ix = i ^ j;
+        if (ix > i) {
+          const unsigned long long a = sk[i], b = sk[ix];
+          const bool up = (i & k2) == 0;
+          if ((a > b) == up) { sk[i] = b; sk[ix] = a; }
+        }
+      }
+      if (j >= 64 || (j == 1 && (k2 << 1) > 64)) __syncthreads();  // uniform
+      else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+  }
+  uint32_t* o = sel + (long)img * P.in.koff[P.in.L] + P.in.koff[l];
+  for (int i = tid; i < n; i += 1024) o[i] = (uint32_t)sk[i];
+}
+
+struct TkWs { SegState* st; int* hist; int* blk_ties; unsigned long long* cand; size_t zero_bytes, total; int maxblk, kmax, reps, tickets; };
+static size_t tk_al(size_t x) { return (x + 255) / 256 * 256; }
+static TkWs tk_carve(const TopkInput& in, void* base) {
+  TkWs w{};
+  const long ns = (long)in.N * in.L;
+  int maxsize = 0, kmax = 1;
+  for (int l = 0; l < in.L; l++) { maxsize = in.size[l] > maxsize ? in.size[l] : maxsize; kmax = in.k[l] > kmax ? in.k[l] : kmax; }
+  const int chunks = maxsize > 0 ? (maxsize + TK_CHUNK - 1) / TK_CHUNK : 1;
+  // small segments (RPN): few workgroups, the last one of a segment scans (tickets) -- saves 4 launches; large ones
+  // (RetinaNet: 3,000 chunks per segment): one chunk per workgroup for occupancy, separate scan launches
+  w.tickets = chunks <= 256;
+  w.reps = w.tickets ? 1 : (chunks + 1023) / 1024;  // ~1,000 workgroups per large segment: amortises the LDS histogram
+  w.maxblk = (chunks + w.reps - 1) / w.reps;
+  w.kmax = kmax;
+  size_t off = 0;
+  auto take = [&](size_t b) { void* r = base ? (char*)base + off : nullptr; off += tk_al(b); return r; };
+  w.st = (SegState*)take(ns * sizeof(SegState));
+  w.hist = (int*)take(ns * 3 * TK_BINS * sizeof(int));
+  w.zero_bytes = off;  // states + histograms are zeroed per call
+  w.blk_ties = (int*)take(ns * w.maxblk * sizeof(int));
+  w.cand = (unsigned long long*)take(ns * kmax * sizeof(unsigned long long));
+  w.total = off;
+  return w;
+}
+
+size_t topk_workspace_bytes(const TopkInput& in) { return tk_carve(in, nullptr).total + 256; }
+
+int topk_select(const TopkInput& in, bool sigmoid, bool use_thr, float thr, uint32_t* sel, int* cnt, void* ws,
+                size_t ws_bytes, hipStream_t s) {
+  D2_CHECK_ARG(in.L >= 1 && in.L <= TOPK_MAX_LEVELS && in.N >= 1, "topk_select: bad segment layout");
+  const TkWs w = tk_carve(in, ws);
+  if (ws == nullptr || ws_bytes < w.total) {
+    set_error("topk_select: workspace too small (%zu < %zu)", ws_bytes, w.total);
+    return D2AMD_EWORKSPACE;
+  }
+  D2_CHECK_ARG(w.kmax <= TOPK_MAX_K, "topk_select: k = %d per segment exceeds %d", w.kmax, TOPK_MAX_K);
+  D2_CHECK_ARG((long)in.N * in.L <= 65535, "topk_select: too many segments");
+  TkParams P{};
+  P.in = in;
+  P.sigmoid = sigmoid; P.use_thr = use_thr; P.thr = thr;
+  P.xlo = -__builtin_inff();
+  if (sigmoid && use_thr) {
+    if (thr >= 1.f) P.xlo = __builtin_inff();
+    else if (thr > 0.f) P.xlo = logf(thr / (1.f - thr)) - 1e-2f;
+  }
+  P.maxblk = w.maxblk;
+  P.reps = w.reps;
+  P.tickets = w.tickets;
+  D2_HIP_OK(hipMemsetAsync(ws, 0, w.zero_bytes, s));
+  dim3 grid(w.maxblk, in.N * in.L), block(TK_THREADS);
+  const dim3 segs(in.N * in.L);
+  hipLaunchKernelGGL(tk_hist_kernel<0>, grid, block, 0, s, P, w.st, w.hist);
+  if (!w.tickets) hipLaunchKernelGGL(tk_scan_kernel<0>, segs, block, 0, s, P, w.st, w.hist);
+  hipLaunchKernelGGL(tk_hist_kernel<1>, grid, block, 0, s, P, w.st, w.hist);
+  if (!w.tickets) hipLaunchKernelGGL(tk_scan_kernel<1>, segs, block, 0, s, P, w.st, w.hist);
+  hipLaunchKernelGGL(tk_hist_kernel<2>, grid, block, 0, s, P, w.st, w.hist);
+  if (!w.tickets) hipLaunchKernelGGL(tk_scan_kernel<2>, segs, block, 0, s, P, w.st, w.hist);
+  hipLaunchKernelGGL(tk_ties_kernel, grid, block, 0, s, P, w.st, w.blk_ties);
+  if (!w.tickets) hipLaunchKernelGGL(tk_ties_scan_kernel, segs, block, 0, s, P, w.st, w.blk_ties);
+  hipLaunchKernelGGL(tk_compact_kernel, grid, block, 0, s, P, w.st, w.blk_ties, w.cand, w.kmax);
+  int pow2 = 1;
+  while (pow2 < w.kmax) pow2 <<= 1;
+  if ((size_t)pow2 * 8 > 64 * 1024)  // dynamic LDS beyond the default limit
+    D2_HIP_OK(hipFuncSetAttribute((const void*)tk_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pow2 * 8));
+  hipLaunchKernelGGL(tk_sort_kernel, dim3(in.N * in.L), dim3(1024), (size_t)pow2 * 8, s, P, w.st, w.cand, w.kmax, pow2, sel,
+                     cnt);
+  D2_LAUNCH_OK();
+  return D2AMD_OK;
+}
+
+}  // namespace d2amd

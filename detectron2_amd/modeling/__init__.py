@@ -1,7 +1,8 @@
 """Hot-path callers mirrored from `detectron2.modeling` (only what SURVEY.md section 8 lists)."""
+from .dense_detector import Detections, dense_detector_inference_fused, dense_select_predictions
 from .mask_head import mask_rcnn_inference, mask_rcnn_loss, mask_rcnn_loss_from_targets
 from .matcher import Matcher
 from .proposal_utils import Proposals, find_top_rpn_proposals_fused, rpn_select_proposals
 from .poolers import ROIPooler, assign_boxes_to_levels, convert_boxes_to_pooler_format
 
-__all__ = ["mask_rcnn_loss", "mask_rcnn_inference", "mask_rcnn_loss_from_targets", "Matcher", "Proposals", "find_top_rpn_proposals_fused", "rpn_select_proposals", "ROIPooler", "assign_boxes_to_levels", "convert_boxes_to_pooler_format"]
+__all__ = ["Detections", "dense_detector_inference_fused", "dense_select_predictions", "mask_rcnn_loss", "mask_rcnn_inference", "mask_rcnn_loss_from_targets", "Matcher", "Proposals", "find_top_rpn_proposals_fused", "rpn_select_proposals", "ROIPooler", "assign_boxes_to_levels", "convert_boxes_to_pooler_format"]

@@ -164,6 +164,7 @@ int d2amd_match_quality_matrix(const float* quality, int M, int N, const float* 
  *   boxes [N,Ktot,4], scores [N,Ktot], valid [N,Ktot] uint8 (finite and both sides > min_box_size after the
  *   clip; invalid rows hold a zero box and score -inf), level [Ktot] int64, flags [1] int32 (bit 0: a
  *   non-finite box or score was seen -- the reference raises FloatingPointError in training).
+ * The selection is a segmented radix select (csrc/topk.hip) for pre_nms_topk <= 16384, a full radix sort above.
  * Nothing synchronises with the host. */
 #define D2AMD_RPN_MAX_LEVELS 8
 size_t d2amd_rpn_select_workspace_bytes(int N, int Atot);
@@ -172,6 +173,27 @@ int d2amd_rpn_select_proposals(const float* logits, const float* deltas, const f
                                float min_box_size, const float* weights, float scale_clamp, float* boxes_out,
                                float* scores_out, uint8_t* valid_out, int64_t* level_out, int* flags_out,
                                void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- Dense-detector (RetinaNet) prediction selection in front of NMS, all images and levels in one call.
+ * Replaces meta_arch/dense_detector.py:186-245 (_decode_per_level_predictions per level and image: `scores >
+ * score_thresh`, `nonzero` [host sync], `topk`, gather, Box2BoxTransform.apply_deltas) and the `sigmoid_()` over
+ * all class logits in front of it (meta_arch/retinanet.py:267).
+ *   logits[l]  [N, A_l, K] fp32 class LOGITS of level l (device pointers in a host array), deltas[l] [N, A_l, 4],
+ *   anchors[l] [A_l, 4] xyxy;  level_anchors (host) [L] = A_l;  K = num_classes.
+ * Per (image, level): the candidates are the (anchor, class) pairs with sigmoid(logit) > score_thresh; the
+ * min(topk_candidates, #candidates) best are selected by a segmented radix select (no sort of the A_l*K scores, no
+ * host sync; ties: lower flattened index a*K + c first; topk_candidates <= 16384), decoded WITHOUT clipping.
+ * Outputs, [N, Ktot] row-major, Ktot = sum_l min(A_l*K, topk_candidates), levels in order, scores descending inside
+ * a level: boxes [N,Ktot,4], scores [N,Ktot] (= sigmoid(logit)), classes [N,Ktot] int64, valid [N,Ktot] uint8 (rows
+ * past a segment's count: zero box, score -inf, class 0, valid 0), counts [N,L] int32. */
+size_t d2amd_dense_select_workspace_bytes(int N, const int* level_anchors, int L, int num_classes,
+                                          int topk_candidates);
+int d2amd_dense_select_predictions(const float* const* logits, const float* const* deltas,
+                                   const float* const* anchors, int N, const int* level_anchors, int L,
+                                   int num_classes, float score_thresh, int topk_candidates, const float* weights,
+                                   float scale_clamp, float* boxes_out, float* scores_out, int64_t* classes_out,
+                                   uint8_t* valid_out, int* counts_out, void* workspace, size_t workspace_bytes,
+                                   void* stream);
 
 /* ---- NMS.  One entry serves torchvision.ops.nms / batched_nms (detectron2/layers/nms.py:6,
  * 11-22) and torch.ops.detectron2.nms_rotated / batched_nms_rotated (vision.cpp:116,

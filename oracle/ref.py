@@ -186,3 +186,33 @@ def py_mask_head():
     mod._d2_events = rec
     mod._d2_Instances = structs.Instances
     return mod
+
+
+def py_dense_detector():
+    """detectron2/modeling/meta_arch/dense_detector.py (DenseDetector._decode_per_level_predictions /
+    _decode_multi_level_predictions).  Loaded under its real dotted name so that its relative import of
+    `..postprocessing` resolves to a stub; the visualisation / backbone imports it does not use for decoding are
+    stubbed too.  Returns (module, Box2BoxTransform class, Boxes class, Instances class)."""
+    import torch
+
+    names = ("detectron2", "detectron2.data", "detectron2.data.detection_utils", "detectron2.layers",
+             "detectron2.modeling", "detectron2.modeling.meta_arch", "detectron2.modeling.postprocessing",
+             "detectron2.structures", "detectron2.utils", "detectron2.utils.events")
+    pkg, data, du, layers, modeling, meta, post, structs, utils, events = (types.ModuleType(n) for n in names)
+    for m in (pkg, data, modeling, meta, utils):
+        m.__path__ = []  # mark as packages
+    du.convert_image_to_rgb = lambda *a, **k: None
+    layers.move_device_like = lambda src, dst: src.to(dst.device)
+    layers.cat = lambda ts, dim=0: torch.cat(ts, dim)
+    modeling.Backbone = torch.nn.Module
+    post.detector_postprocess = lambda *a, **k: None
+    structs.Boxes = py_boxes().Boxes
+    structs.Instances = _load_by_path("_d2ref_instances", "detectron2/structures/instances.py").Instances
+    structs.ImageList = object
+    events.get_event_storage = lambda: _EventRecorder()
+    br = py_box_regression()
+    stubs = dict(zip(names, (pkg, data, du, layers, modeling, meta, post, structs, utils, events)))
+    mod = _with_stubs(stubs, lambda: _load_by_path("detectron2.modeling.meta_arch.dense_detector",
+                                                    "detectron2/modeling/meta_arch/dense_detector.py"))
+    sys.modules.pop("detectron2.modeling.meta_arch.dense_detector", None)
+    return mod, br.Box2BoxTransform, structs.Boxes, structs.Instances

@@ -210,11 +210,52 @@ def mask_head_golden():
     print("mask_head.npz written")
 
 
+def dense_detector_golden():
+    """DenseDetector._decode_multi_level_predictions of detectron2/modeling/meta_arch/dense_detector.py on CPU, with
+    scores = sigmoid(logits) as meta_arch/retinanet.py:267 prepares them."""
+    import types
+
+    mod, B2B, Boxes, _ = ref.py_dense_detector()
+    rng = np.random.default_rng(2024)
+    N, K, sizes = 2, 5, [300, 80, 12]
+    thr, topk = 0.3, 50
+    dd = mod.DenseDetector.__new__(mod.DenseDetector)
+    dd.__dict__["box2box_transform"] = B2B(weights=(1.0, 1.0, 2.0, 2.0))
+    anchors, logits, deltas = [], [], []
+    for li, a_l in enumerate(sizes):
+        s0 = 32.0 * 2 ** li
+        c = rng.uniform(0, [320, 256], (a_l, 2))
+        wh_ = s0 * np.exp(rng.uniform(-0.4, 0.4, (a_l, 2)))
+        anchors.append(np.concatenate([c - wh_ / 2, c + wh_ / 2], 1).astype(np.float32))
+        logits.append((rng.standard_normal((N, a_l, K)) * 1.5 - 1.5).astype(np.float32))
+        d = (rng.standard_normal((N, a_l, 4)) * [0.3, 0.3, 0.5, 0.5]).astype(np.float32)
+        d[0, :2, 2] = 30.0  # exercises the scale clamp
+        deltas.append(d)
+    d = dict(score_thresh=np.array(thr), topk=np.array(topk), weights=np.array([1.0, 1.0, 2.0, 2.0]))
+    for li in range(len(sizes)):
+        d[f"anchors{li}"], d[f"logits{li}"], d[f"deltas{li}"] = anchors[li], logits[li], deltas[li]
+    for i in range(N):
+        scores = [torch.from_numpy(l[i]).clone().sigmoid_() for l in logits]
+        for sc in scores:  # the fixture must not depend on topk's order of equal scores
+            v = sc[sc > thr]
+            assert len(torch.unique(v)) == len(v)
+        inst = dd._decode_multi_level_predictions([Boxes(torch.from_numpy(a)) for a in anchors], scores,
+                                                  [torch.from_numpy(x[i]) for x in deltas], thr, topk, (256, 320))
+        d[f"boxes_img{i}"] = inst.pred_boxes.tensor.numpy()
+        d[f"scores_img{i}"] = inst.scores.numpy()
+        d[f"classes_img{i}"] = inst.pred_classes.numpy()
+    np.savez_compressed(os.path.join(OUT, "dense_detector.npz"), **d)
+    print("dense_detector.npz written", [len(d[f"scores_img{i}"]) for i in range(N)])
+
+
 if __name__ == "__main__":
     import sys
 
     if len(sys.argv) > 1 and sys.argv[1] == "mask_head":
         mask_head_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "dense_detector":
+        dense_detector_golden()
     else:
         main()
         mask_head_golden()
+        dense_detector_golden()

@@ -372,3 +372,20 @@ def test_mask_head_restatement_matches_reference_functions(golden_dir):
         probs = omh.mask_rcnn_inference(x, cls)
         assert probs.shape == g[f"{name}_probs"].shape
         assert np.abs(probs - g[f"{name}_probs"]).max() <= 1e-6
+
+
+def test_dense_detector_restatement_matches_reference_functions(golden_dir):
+    """oracle/dense_detector.py vs the reference's own DenseDetector._decode_multi_level_predictions run on CPU
+    (tests/golden/dense_detector.npz, oracle/ref.py::py_dense_detector): same (anchor, class) selection in the same
+    order, scores and decoded boxes to the rounding of exp()."""
+    from oracle import dense_detector as odd
+
+    g = np.load(os.path.join(golden_dir, "dense_detector.npz"))
+    anchors = [g[f"anchors{l}"] for l in range(3)]
+    for i in range(2):
+        b, s, c = odd.decode_multi_level(anchors, [g[f"logits{l}"][i] for l in range(3)],
+                                         [g[f"deltas{l}"][i] for l in range(3)], float(g["score_thresh"]),
+                                         int(g["topk"]), tuple(g["weights"]))
+        assert np.array_equal(c, g[f"classes_img{i}"])
+        np.testing.assert_allclose(s, g[f"scores_img{i}"], rtol=2e-6, atol=0)
+        np.testing.assert_allclose(b, g[f"boxes_img{i}"], rtol=2e-6, atol=1e-4)
