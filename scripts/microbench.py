@@ -78,6 +78,32 @@ def main():
     Dl = [(torch.randn(2, a, 4, generator=gen0) * 0.2).to(dev) for a in sizes]
     rec("find_top_rpn_proposals_fused(2 img,268569 anchors,2000/1000)",
         timeit(lambda: find_top_rpn_proposals_fused(A, Lg, Dl, [(800, 1344)] * 2, 0.7, 2000, 1000, 0.0, True), rep=10))
+    if not quick:  # BASELINE configs[3]: RetinaNet R50-FPN inference selection, 2 x 16.1 M class scores
+        from detectron2_amd.modeling import dense_detector_inference_fused, dense_select_predictions
+        rs = [9 * 16800, 9 * 4200, 9 * 1050, 9 * 273, 9 * 77]
+        RA = [bench.make_boxes(gen0, a, 16, 512).to(dev) for a in rs]
+        RL = [(torch.randn(2, a, 80, generator=gen0) * 1.2 - 4.6).to(dev) for a in rs]
+        RD = [(torch.randn(2, a, 4, generator=gen0) * 0.2).to(dev) for a in rs]
+        nbytes = sum(x.numel() for x in RL) * 4
+        rec("dense_select_predictions(retinanet 2 img,16.1M scores/img,thr .05,top 1000)",
+            timeit(lambda: dense_select_predictions(RA, RL, RD, 0.05, 1000), rep=10), 4 * nbytes)
+        rec("dense_detector_inference_fused(retinanet 2 img,+nms .5,top 100)",
+            timeit(lambda: dense_detector_inference_fused(RA, RL, RD, [(800, 1344)] * 2, 0.05, 1000, 0.5, 100), rep=10))
+        del RL, RD
+    # mask-head glue: loss forward + backward and inference select at the Mask R-CNN shapes
+    from detectron2_amd.modeling import mask_rcnn_inference, mask_rcnn_loss_from_targets
+    ml = (torch.randn(256, 80, 28, 28, generator=gen0)).to(dev).bfloat16().requires_grad_(True)
+    mc = torch.randint(0, 80, (256,), generator=gen0).to(dev)
+    mg = (torch.rand(256, 28, 28, generator=gen0) < 0.4).to(dev)
+    def _mask_loss():
+        loss, _ = mask_rcnn_loss_from_targets(ml, mc, mg)
+        loss.backward()
+        ml.grad = None
+    rec("mask_rcnn_loss fwd+bwd(256x80x28x28 bf16)", timeit(_mask_loss), 2 * ml.numel() + 3 * 256 * 784)
+    class _I:
+        pred_classes = mc
+        def __len__(self): return 256
+    rec("mask_rcnn_inference(256x80x28x28 bf16)", timeit(lambda: mask_rcnn_inference(ml.detach(), [_I()])))
     for name, pooler, lists, grad in (("box7", w.box_pooler, w.box_lists, w.gbox),
                                       ("mask14", w.mask_pooler, w.mask_lists, w.gmask)):
         key = "roi_align_box" if name == "box7" else "roi_align_mask"
