@@ -20,7 +20,7 @@ if [ "${2:-tests}" = "tests" ]; then
 fi
 echo "== bench"
 for L in nhwc nchw; do
-  timeout 600 python bench.py --steps 30 --warmup 5 --layout $L > $OUT/bench_$L.json 2> $OUT/bench_$L.err; echo "bench $L rc=$?"
+  timeout 600 python bench.py --steps 200 --warmup 20 --layout $L > $OUT/bench_$L.json 2> $OUT/bench_$L.err; echo "bench $L rc=$?"
   cat $OUT/bench_$L.json; tail -3 $OUT/bench_$L.err
 done
 echo "== microbench"

@@ -22,3 +22,6 @@ pr.disable()
 s = io.StringIO()
 pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(28)
 print("\n".join(l[:150] for l in s.getvalue().splitlines()[:60]))
+s = io.StringIO()
+pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(30)
+print("\n".join(l[:150] for l in s.getvalue().splitlines()[:50]))

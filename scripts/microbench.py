@@ -95,11 +95,14 @@ def main():
     ml = (torch.randn(256, 80, 28, 28, generator=gen0)).to(dev).bfloat16().requires_grad_(True)
     mc = torch.randint(0, 80, (256,), generator=gen0).to(dev)
     mg = (torch.rand(256, 28, 28, generator=gen0) < 0.4).to(dev)
-    def _mask_loss():
-        loss, _ = mask_rcnn_loss_from_targets(ml, mc, mg)
-        loss.backward()
-        ml.grad = None
-    rec("mask_rcnn_loss fwd+bwd(256x80x28x28 bf16)", timeit(_mask_loss), 2 * ml.numel() + 3 * 256 * 784)
+    rec("mask_rcnn_loss forward(256x80x28x28 bf16)", timeit(lambda: mask_rcnn_loss_from_targets(ml, mc, mg)),
+        256 * 784 * 3)
+    from detectron2_amd import _C as _dc
+    _g, _one, _t8, _x = torch.empty_like(ml), torch.ones((), device=dev), mg.view(torch.uint8), ml.detach()
+    rec("mask_rcnn_loss backward kernel(256x80x28x28 bf16)",
+        timeit(lambda: _dc.lib().d2amd_mask_rcnn_loss_backward(_dc.ptr(_x), _dc.ptr(mc), _dc.ptr(_t8), _dc.ptr(_one), 256, 80,
+                                                               784, _dc.dtype_code(_x), _dc.ptr(_g), _dc.stream())),
+        2 * ml.numel() + 3 * 256 * 784)
     class _I:
         pred_classes = mc
         def __len__(self): return 256
