@@ -469,7 +469,7 @@ __global__ __launch_bounds__(64 * LISTS_WAVES) void tile_lists_kernel(PoolLevels
     const int u = Q.pass_base[g.lvl] + (tile - L.tile_base[g.lvl]);  // tile id inside its launch
     int* q = Q.mem + QCTR + (pass ? 8 * Q.cap[0] : 0) + x * Q.cap[pass];
     const int at = s_slot[wave];
-    q[heavy ? at : Q.cap[pass] - 1 - at] = (min(cnt, 255) << 24) | u;
+    q[heavy ? at : Q.cap[pass] - 1 - at] = (min(cnt, 127) << 24) | u;  // positive: -1 marks an unused slot (127 > TILE_CAP)
   }
 }
 

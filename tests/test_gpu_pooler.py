@@ -198,3 +198,46 @@ def test_fused_pooler_full_size_adjoint():
     assert rel_err(yb.float().detach().cpu().numpy(), yr.cpu().numpy()) < 2.0 ** -7
     for a, b in zip(xb, xs):
         assert rel_err(a.grad.float().cpu().numpy(), b.grad.cpu().numpy()) < 2.0 ** -6
+
+
+@pytest.mark.parametrize("case", ["clustered_overflow", "pooled28_pb32", "tiny_rois_multichunk", "two_slabs_f16"])
+def test_fused_pooler_staged_backward_paths(case):
+    """Paths of the LDS-staged tile gather that the BASELINE shapes do not reach: tiles with more than 64 ROIs
+    (in-kernel scan of > 512 records in two passes), a second, partial channel slab, 32 bins per axis (one list entry
+    per weight round), windows of more than 32 bins (several items per ROI)."""
+    rng = np.random.default_rng(abs(hash(case)) % 1000)
+    dtype, tol = torch.float32, 1e-4
+    if case == "clustered_overflow":
+        n_img, C, out, sr, per = 1, 136, 7, 0, 700   # fp32: 128 channels per slab -> 2 slabs, the second partial
+        feats, boxes = make_inputs(rng, n_img, C, 160, 224, per)
+        c = rng.uniform([60, 40], [90, 60], (per, 2))          # all boxes around one spot: > 64 ROIs on its tiles
+        s = np.exp(rng.uniform(np.log(6), np.log(120), (per, 1))) * rng.uniform(0.7, 1.4, (per, 2))
+        boxes = [np.concatenate([c - s / 2, c + s / 2], 1).clip(0, [224, 160, 224, 160]).astype(np.float32)]
+    elif case == "pooled28_pb32":
+        n_img, C, out, sr, per = 2, 8, 28, 2, 24
+        feats, boxes = make_inputs(rng, n_img, C, 128, 160, per)
+    elif case == "tiny_rois_multichunk":
+        n_img, C, out, sr, per = 2, 16, 14, 0, 96
+        feats, boxes = make_inputs(rng, n_img, C, 96, 128, per)
+        for b in boxes:                                        # boxes of 3-10 px: 14 bins inside one or two pixels
+            c = rng.uniform([10, 10], [118, 86], (per, 2))
+            s = rng.uniform(3, 10, (per, 2))
+            b[:] = np.concatenate([c - s / 2, c + s / 2], 1)
+    else:
+        n_img, C, out, sr, per = 2, 320, 7, 0, 64              # f16: 256 channels per slab -> 2 slabs, the second partial
+        feats, boxes = make_inputs(rng, n_img, C, 96, 128, per)
+        dtype, tol = torch.float16, 2.0 ** -8
+        feats = [np.float16(f).astype(np.float32) for f in feats]
+    grad = rng.standard_normal((sum(len(b) for b in boxes), C, out, out)).astype(np.float32)
+    if dtype != torch.float32:
+        grad = np.float16(grad).astype(np.float32)
+    want, gins, _ = oracle_pooler(feats, boxes, out, sr, True, grad)
+    xs = [torch.from_numpy(f).to(DEV).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+          for f in feats]
+    pooler = ROIPooler(out, SCALES, sr, "ROIAlignV2")
+    y = pooler(xs, [Boxes(torch.from_numpy(b).to(DEV)) for b in boxes])
+    assert rel_err(y.detach().float().cpu().numpy(), want) <= tol
+    y.backward(torch.from_numpy(grad).to(DEV).to(dtype))
+    for x, g in zip(xs, gins):
+        assert torch.isfinite(x.grad).all()
+        assert rel_err(x.grad.float().cpu().numpy(), g) <= tol
