@@ -50,7 +50,7 @@ def test_dense_select_golden(golden_dir):
         np.testing.assert_allclose(b, g[f"boxes_img{i}"], rtol=2e-6, atol=1e-4)
 
 
-@pytest.mark.parametrize("case", ["retinanet_800x1344", "small_ragged", "all_pass", "none_pass"])
+@pytest.mark.parametrize("case", ["retinanet_800x1344", "small_ragged", "all_pass", "none_pass", "big_k"])
 def test_dense_select_vs_oracle(case):
     rng = np.random.default_rng(hash(case) % 1000)
     if case == "retinanet_800x1344":  # BASELINE configs[3] shapes: 9 anchors / location, 80 classes, 2 images
@@ -58,6 +58,8 @@ def test_dense_select_vs_oracle(case):
         mean = -4.0
     elif case == "small_ragged":
         N, K, sizes, thr, topk, mean = 3, 7, [1000, 1, 0, 37], 0.2, 64, -1.0
+    elif case == "big_k":  # 10,000 selected per segment: 16,384-entry LDS sort (128 KB of dynamic LDS)
+        N, K, sizes, thr, topk, mean = 2, 4, [3000, 2600], 0.0, 10000, 0.0
     elif case == "all_pass":
         N, K, sizes, thr, topk, mean = 1, 3, [5000, 10], 0.0, 100, 2.0
     else:
