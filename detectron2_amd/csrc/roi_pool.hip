@@ -816,7 +816,9 @@ struct StagedShared {
 };
 struct Window { int ph_lo, nph, pw_lo, npw, rpc, nitems; float rnpw; };
 
-template <typename T, int VEC>
+// PB = bins per axis rounded up to 8 / 16 / 32 (compile time: the slot / wave arithmetic folds to shifts, and the
+// 7x7 and 14x14 poolers show up as separate kernels in rocprofv3)
+template <typename T, int VEC, int PB>
 __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_staged_kernel(PoolLevels L, const RoiRec* __restrict__ rec,
                                                                    const T* __restrict__ gout, int nslab,
                                                                    int total_blocks, PoolTileIds ids) {
@@ -880,14 +882,13 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_staged_kernel(PoolLevels L
   // (column, bin) pairs = 2 * PB / 8 waves, so the 8 waves of the group evaluate EPR = 32 / PB list entries per
   // ROUND, all at the same time (box head: 4 entries, one wave per entry and axis).  Weights live in NSLOT = 3 EPR
   // slots: round r + 2 is evaluated during the first item of round r and overwrites round r - 1.
-  const int PB = (PH <= 8 && PW <= 8) ? 8 : (PH <= 16 && PW <= 16) ? 16 : 32;  // uniform
-  const int lg = PB == 8 ? 3 : PB == 16 ? 4 : 5;
-  const int EPR = 32 >> lg, NSLOT = 3 * EPR;
+  constexpr int lg = PB == 8 ? 3 : PB == 16 ? 4 : 5;
+  constexpr int EPR = 32 >> lg, NSLOT = 3 * EPR;
   const int wave = tid >> 6;
   int nlist = 0;
   auto compute_round = [&](int first) __attribute__((always_inline)) {
-    const int rows_per_wave = 64 >> lg, waves_per_axis = TILE >> (6 - lg);  // 8,1 / 4,2 / 2,4
-    const int wpe = 2 * waves_per_axis;                                      // waves per entry: 2 / 4 / 8
+    constexpr int rows_per_wave = 64 >> lg, waves_per_axis = TILE >> (6 - lg);  // 8,1 / 4,2 / 2,4
+    constexpr int wpe = 2 * waves_per_axis;                                      // waves per entry: 2 / 4 / 8
     const int li = first + wave / wpe;
     if (li >= nlist) return;  // uniform per wave
     const int slot = li % NSLOT;
@@ -917,7 +918,7 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_staged_kernel(PoolLevels L
   };
   // window of bins of entry buffer wb that touch the tile (uniform; valid after the barrier that follows its weights)
   auto window_of = [&](int wb) __attribute__((always_inline)) {
-    const int waves_per_axis = PB / 8;
+    constexpr int waves_per_axis = PB / 8;
     uint32_t ya = S.yall[wb][0], xa = S.xall[wb][0];
     if (waves_per_axis > 1) { ya |= S.yall[wb][1]; xa |= S.xall[wb][1]; }
     if (waves_per_axis > 2) { ya |= S.yall[wb][2] | S.yall[wb][3]; xa |= S.xall[wb][2] | S.xall[wb][3]; }
@@ -1353,8 +1354,16 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
 #endif
     const char* tname = p->pooled_h <= 7 ? "pool_bwd_staged_r7" : "pool_bwd_staged_r14";
     const bool timed = timing_begin(tname, s);
-    hipLaunchKernelGGL((pool_bwd_staged_kernel<T, VEC>), dim3((unsigned)total), dim3(2 * CT), 0, s, L, rec,
-                       (const T*)grad_output, nslab, (int)total, ids);
+    const int pmax = p->pooled_h > p->pooled_w ? p->pooled_h : p->pooled_w;
+    if (pmax <= 8)
+      hipLaunchKernelGGL((pool_bwd_staged_kernel<T, VEC, 8>), dim3((unsigned)total), dim3(2 * CT), 0, s, L, rec,
+                         (const T*)grad_output, nslab, (int)total, ids);
+    else if (pmax <= 16)
+      hipLaunchKernelGGL((pool_bwd_staged_kernel<T, VEC, 16>), dim3((unsigned)total), dim3(2 * CT), 0, s, L, rec,
+                         (const T*)grad_output, nslab, (int)total, ids);
+    else
+      hipLaunchKernelGGL((pool_bwd_staged_kernel<T, VEC, 32>), dim3((unsigned)total), dim3(2 * CT), 0, s, L, rec,
+                         (const T*)grad_output, nslab, (int)total, ids);
     D2_LAUNCH_OK();
     if (timed) timing_end(tname, s);
 #ifdef D2AMD_PROFILE
