@@ -134,10 +134,14 @@ __global__ __launch_bounds__(NTHR) void pool_fwd_nhwc_kernel(PoolLevels L, const
   const float inv = S.inv_count;
   constexpr int U = FWD_U;  // independent loads in flight per lane
   if (wst) { wst[1] = wall_clock64(); wst[4] = (unsigned long long)lvl; }
+  // index arithmetic without integer divisions: CG is a power of two for the usual channel counts, and
+  // b / PW == (b * rcp_pw) >> 16 for b < 1024 (PH, PW <= 32)
+  const int cg_shift = (CG & (CG - 1)) == 0 ? __builtin_ctz(CG) : -1;  // uniform
+  const uint32_t rcp_pw = (65536u + (uint32_t)PW - 1u) / (uint32_t)PW;
   for (int e = tid; e < (b_hi - b_lo) * CG; e += NTHR) {
-    const int bl = e / CG, q = e - bl * CG;
+    const int bl = cg_shift >= 0 ? (e >> cg_shift) : e / CG, q = e - bl * CG;
     const int b = b_lo + bl;
-    const int ph = b / PW, pw = b - ph * PW;
+    const int ph = (int)(((uint32_t)b * rcp_pw) >> 16), pw = b - ph * PW;
     const int fy = S.firsty[ph], sy = S.spany[ph], fx = S.firstx[pw], sx = S.spanx[pw];
     const float* wy = S.wy + ph * SEP_SPAN;
     const float* wx = S.wx + pw * SEP_SPAN;
