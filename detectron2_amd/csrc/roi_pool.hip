@@ -1111,6 +1111,19 @@ __global__ void boxes_to_rois_kernel(const float* __restrict__ boxes, int K, int
   for (int c = 0; c < width; c++) o[1 + c] = boxes[(long)k * width + c];
 }
 
+// the same for per-image box tensors that were never concatenated (ROIPooler.forward's box_lists): saves the
+// torch.cat and a separate call on the host
+struct ImgBoxes { int n; int end[D2AMD_POOLER_MAX_IMAGES]; const float* ptr[D2AMD_POOLER_MAX_IMAGES]; };
+__global__ void box_lists_to_rois_kernel(ImgBoxes e, int K, float* __restrict__ rois) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  int b = 0;
+  for (int i = 0; i < e.n; i++) b += (k >= e.end[i]) ? 1 : 0;
+  const float4 v = reinterpret_cast<const float4*>(e.ptr[b])[k - (b ? e.end[b - 1] : 0)];
+  float* o = rois + (long)k * 5;
+  o[0] = (float)b; o[1] = v.x; o[2] = v.y; o[3] = v.z; o[4] = v.w;
+}
+
 // ---- host side ------------------------------------------------------------------------------------
 static int check_pooler(const d2amd_pooler_params* p, const char* who) {
   D2_CHECK_ARG(p != nullptr, "%s: null params", who);
@@ -1541,6 +1554,29 @@ extern "C" int d2amd_roi_pooler_forward(const d2amd_pooler_params* p, const void
   return D2_DISPATCH_DTYPE(p->dtype, [&]() -> int {
     return pool_fwd_impl<scalar_t>(p, inputs, rois, output, K, (hipStream_t)stream);
   });
+}
+
+extern "C" int d2amd_roi_pooler_forward_box_lists(const d2amd_pooler_params* p, const void* const* inputs,
+                                                  const float* const* boxes, const int* counts, int num_images,
+                                                  float* rois_out, void* output, void* stream) {
+  D2_CHECK_ARG(num_images >= 0 && num_images <= D2AMD_POOLER_MAX_IMAGES && (num_images == 0 || (boxes && counts)),
+               "roi_pooler_forward_box_lists: %d images (max %d)", num_images, D2AMD_POOLER_MAX_IMAGES);
+  ImgBoxes e{};
+  e.n = num_images;
+  long K = 0;
+  for (int i = 0; i < num_images; i++) {
+    D2_CHECK_ARG(counts[i] >= 0 && (counts[i] == 0 || (boxes[i] && ((uintptr_t)boxes[i] & 15) == 0)),
+                 "roi_pooler_forward_box_lists: image %d: bad count / null or unaligned boxes", i);
+    K += counts[i];
+    e.end[i] = (int)K;
+    e.ptr[i] = boxes[i];
+  }
+  D2_CHECK_ARG(K < (1l << 31), "roi_pooler_forward_box_lists: too many boxes");
+  if (K == 0) return D2AMD_OK;
+  D2_CHECK_ARG(rois_out != nullptr, "roi_pooler_forward_box_lists: null rois_out");
+  hipLaunchKernelGGL(box_lists_to_rois_kernel, dim3(cdiv(K, 256)), dim3(256), 0, (hipStream_t)stream, e, (int)K, rois_out);
+  D2_LAUNCH_OK();
+  return d2amd_roi_pooler_forward(p, inputs, rois_out, output, (int)K, stream);
 }
 
 extern "C" size_t d2amd_roi_pooler_workspace_bytes(int K) { return (size_t)(K > 0 ? K : 1) * sizeof(RoiRec); }

@@ -118,6 +118,13 @@ class _FusedROIPool(Function):
     @staticmethod
     @disable_torch_compiler
     def forward(ctx, rois, cfg, *feats):
+        # rois: the (M, 5) pooler-format tensor, or a tuple of per-image (n_i, 4) fp32 HIP box tensors -- then the
+        # conversion happens inside the same C call (d2amd_roi_pooler_forward_box_lists: no torch.cat, one call less)
+        box_lists = None
+        if isinstance(rois, tuple):
+            box_lists = rois
+            rois = torch.empty((sum(int(b.shape[0]) for b in box_lists), 5), dtype=torch.float32,
+                               device=feats[0].device)
         _C.require_gpu(rois, *feats, op="ROIPooler")
         layout = _layout_of(feats[0])
         nchw_in = layout == _C.NCHW and feats[0].dtype != torch.float32
@@ -138,8 +145,15 @@ class _FusedROIPool(Function):
         mf = torch.channels_last if layout == _C.NHWC else torch.contiguous_format
         out = torch.empty((k, c, ph, pw), dtype=xs[0].dtype, device=xs[0].device, memory_format=mf)
         with _C.on_device(xs[0].device):
-            _C.check(_C.lib().d2amd_roi_pooler_forward(ctypes.byref(p), _ptr_array(xs), _C.ptr(rois), _C.ptr(out), k,
-                                                       _C.stream()))
+            if box_lists is None:
+                _C.check(_C.lib().d2amd_roi_pooler_forward(ctypes.byref(p), _ptr_array(xs), _C.ptr(rois), _C.ptr(out), k,
+                                                           _C.stream()))
+            else:
+                n_img = len(box_lists)
+                counts = (ctypes.c_int * n_img)(*[int(b.shape[0]) for b in box_lists])
+                _C.check(_C.lib().d2amd_roi_pooler_forward_box_lists(ctypes.byref(p), _ptr_array(xs),
+                                                                     _ptr_array(box_lists), counts, n_img,
+                                                                     _C.ptr(rois), _C.ptr(out), _C.stream()))
         ctx.save_for_backward(rois)
         ctx.cfg, ctx.hw, ctx.nc, ctx.layout = cfg, hw, (n, c), layout
         ctx.needs = [f.requires_grad for f in feats]
@@ -229,11 +243,19 @@ class ROIPooler(nn.Module):
             "unequal value, x[0] batch dim 0 is {}, but box_list has length {}".format(x[0].size(0), len(box_lists))
         if len(box_lists) == 0:
             return torch.zeros((0, x[0].shape[1]) + tuple(self.output_size), dtype=x[0].dtype, device=x[0].device)
-        pooler_fmt_boxes = convert_boxes_to_pooler_format(box_lists)
-        if self._fusable(x):
+        fusable = self._fusable(x)
+        if fusable:
             cfg = (tuple(self.output_size), tuple(self.scales), int(self.sampling_ratio),
                    self.pooler_type == "ROIAlignV2", self.min_level, self.max_level, self.canonical_box_size,
                    self.canonical_level)
+            # fast path: per-image fp32 HIP box tensors go to the C ABI as they are
+            bt = tuple(b.tensor if hasattr(b, "tensor") else b for b in box_lists)
+            dev = x[0].device
+            if len(bt) <= 64 and all(t.dtype == torch.float32 and t.device == dev and t.dim() == 2 and t.shape[1] == 4
+                                     and t.is_contiguous() and not t.requires_grad and t.data_ptr() % 16 == 0 for t in bt):
+                return _FusedROIPool.apply(bt, cfg, *x)
+        pooler_fmt_boxes = convert_boxes_to_pooler_format(box_lists)
+        if fusable:
             if pooler_fmt_boxes.dtype != torch.float32:
                 pooler_fmt_boxes = pooler_fmt_boxes.float()
             return _FusedROIPool.apply(pooler_fmt_boxes.detach(), cfg, *x)

@@ -100,6 +100,13 @@ typedef struct d2amd_pooler_params {
 int d2amd_roi_pooler_supported(const d2amd_pooler_params* p, int backward);
 int d2amd_roi_pooler_forward(const d2amd_pooler_params* p, const void* const* inputs, const float* rois,
                              void* output, int K, void* stream);
+/* The same for box lists that were never concatenated (ROIPooler.forward's `box_lists`, poolers.py:206-263):
+ * boxes (host array of num_images device pointers, each [counts[i], 4] fp32 xyxy, 16-byte aligned), counts (host).
+ * Writes rois_out [K,5] (convert_boxes_to_pooler_format, needed again by the backward) and pools from it: one call
+ * instead of torch.cat + d2amd_boxes_to_rois + d2amd_roi_pooler_forward. */
+int d2amd_roi_pooler_forward_box_lists(const d2amd_pooler_params* p, const void* const* inputs,
+                                       const float* const* boxes, const int* counts, int num_images,
+                                       float* rois_out, void* output, void* stream);
 size_t d2amd_roi_pooler_workspace_bytes(int K); /* backward, minimum: per-ROI records (48 B each) */
 /* backward, recommended: records + per-tile ROI lists (one wave per 8x8 tile bins the ROIs once per call;
  * with the minimum size every tile workgroup scans all K records itself, ~2 us per 512 records and tile) */
