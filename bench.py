@@ -375,7 +375,7 @@ def main():
             # one launch for all FPN levels (LDS-staged tile gather): SURVEY 8(d)'s backward bytes of the whole op
             k_ms, k_n = ktimes["pool_bwd_staged_r7"]
             kb = alg[dom] / counts[dom]
-            roof = {"bound": "hbm", "kernel": "pool_bwd_staged_kernel (all FPN levels) of roi_align_box_bwd",
+            roof = {"bound": "hbm", "kernel": "pool_bwd_staged_kernel<T, 8, 8> (7x7 pooler, all FPN levels) of roi_align_box_bwd",
                     "achieved": round(kb / 1e9 / (k_ms / 1e3), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(kb / 1e9 / (k_ms / 1e3) / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, args.layout),
                     "traffic_note": "PMC bytes are for the whole op (records + tile lists/zero fill + tile gather)",
