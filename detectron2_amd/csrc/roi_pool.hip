@@ -1098,6 +1098,356 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_staged_kernel(PoolLevels L
   if (wst) wst[3] = wall_clock64();
 }
 
+// ------------------------------------------------------------------------------------------------
+// BACKWARD, NHWC, 16-bit I/O: the staged tile gather with the contraction on MFMA (v9).
+//
+// Per item the gather is a small GEMM: G[64 pixels x 256 channels] += Wt[64 x nb] . dY[nb x 256] over the nb <= 32
+// staged bins.  The VALU version spends most of an item in that contraction (per thread ~6 LDS round trips and ~250
+// dependent VALU instructions, profiles/r01/v8_pool_bwd_phase_stamps.txt); here
+//   * the group builds the item's weight matrix Wt[pixel][bin] = Wy[row][ph] Wx[col][pw] / count once in LDS, as a
+//     HIGH and a LOW 16-bit part (w = hi + lo: the product keeps ~16 significant bits, accumulation is fp32 in the
+//     MFMA, so the result matches the fp32-weight VALU kernel to the rounding of the output);
+//   * wave w owns the 32 channels [32 w, 32 w + 32) of the slab for all 64 pixels: 2 accumulator tiles of
+//     v_mfma_f32_32x32x16 (32 VGPRs, like the VALU kernel);
+//   * A = Wt: one ds_read_b128 per (pixel tile, k step); B = dY straight from the [bin][channel] image the staging
+//     writes, through ds_read_b64_tr_b16 (the hardware 4 x 4 transpose: lane i of a 16-lane group addresses row
+//     i >> 2, columns 4 (i & 3) .. + 3 of a [4 bins][16 channels] block and receives column i -- checked on the
+//     device by scripts/probes/probe_tr16.hip); rows past nb are zero-filled by the staging (0 x stale NaN);
+//   * the epilogue transposes the accumulators through LDS so that every pixel is stored as 16-B channel vectors.
+// Everything around the contraction (queues, lists, weight rounds, windows, items, one barrier per item) is the
+// staged kernel's.  fp32 I/O keeps the VALU kernel (fp32 MFMA runs at the vector rate).
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 pbf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 pf16x8_t;
+__device__ __forceinline__ f32x16_t pool_mma(s16x8_t a, s16x8_t b, f32x16_t c, bf16_t) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pbf16x8_t, a), __builtin_bit_cast(pbf16x8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16_t pool_mma(s16x8_t a, s16x8_t b, f32x16_t c, f16_t) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(pf16x8_t, a), __builtin_bit_cast(pf16x8_t, b), c, 0, 0, 0);
+}
+constexpr int WPITCH = WINCAP + 8;  // 16-bit elements per pixel row of the weight image (80 B: conflict-free b128 reads)
+struct __attribute__((aligned(16))) MfmaShared {
+  uint16_t Whi[2][TILE * TILE][WPITCH];  // [buffer][pixel = row * 8 + col][bin of the item]
+  uint16_t Wlo[2][TILE * TILE][WPITCH];
+};
+
+template <typename T, int PB>
+__global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, const RoiRec* __restrict__ rec,
+                                                                   const T* __restrict__ gout, int nslab,
+                                                                   int total_blocks, PoolTileIds ids) {
+  constexpr int NT = 2 * CT, TR = TILE / 2, VEC = 8;
+  __shared__ StagedShared<T> S;
+  __shared__ MfmaShared M;
+  const int tid = threadIdx.x, lane = tid & 63;
+  int logical, slab, tile, qcnt = -1;
+  if (L.queue) {
+    const int j = (int)(blockIdx.x >> 3);
+    const int e = L.queue[(long)(blockIdx.x & 7) * L.qcap + j / nslab];
+    if (e < 0) return;
+    logical = (int)blockIdx.x;
+    slab = j % nslab;
+    tile = e & 0xffffff;
+    qcnt = (int)((unsigned)e >> 24);
+  } else {
+    const int per_xcd = (total_blocks + 7) >> 3;
+    logical = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (logical >= total_blocks) return;
+    slab = logical % nslab;
+    tile = logical / nslab;
+  }
+  unsigned long long* wst = (L.wgstamps && tid == 0) ? L.wgstamps + 5 * (size_t)logical : nullptr;
+  if (wst) wst[0] = wall_clock64();
+  unsigned long long wst_list = 0;
+  int wst_n = 0;
+  int lvl = 0;
+#pragma unroll
+  for (int l = 1; l < POOL_MAX_LEVELS; l++)
+    if (l < L.num_levels && tile >= L.tile_base[l]) lvl = l;
+  const int H = L.H[lvl], W = L.W[lvl];
+  const int tiles_x = (W + TILE - 1) / TILE, tiles_y = (H + TILE - 1) / TILE;
+  int tl = tile - L.tile_base[lvl];
+  const int n = tl / (tiles_y * tiles_x);
+  tl -= n * tiles_y * tiles_x;
+  const int y0 = (tl / tiles_x) * TILE, x0 = (tl % tiles_x) * TILE;
+  const int C = L.C, PH = L.PH, PW = L.PW, K = L.K;
+  const int CG = C / VEC;
+  const int rh = tid / CT, col = (tid >> 5) & 7, lp = tid & 31;  // row half / pixel column / channel lane
+  const int cg = slab * LPP + lp;
+  const bool cg_ok = cg < CG;
+  const long cofs = (long)min(cg, CG - 1) * VEC;
+  const int sb = tid >> 5;  // staging: this thread moves bins sb and sb + 16 of an item (channel lane lp)
+#undef STAMP
+#ifdef D2AMD_PROFILE
+  const bool dbg_on = L.dbg && logical == L.dbg_block && tid == 0;
+  int dbg_n = 0;
+#define STAMP() do { if (dbg_on && dbg_n < 120) L.dbg[dbg_n++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP() do {} while (0)
+#endif
+  STAMP();
+
+  // wave w accumulates channels [32 w, 32 w + 32) of the slab: acc[mt] = pixels of tile rows 4 mt .. 4 mt + 3
+  f32x16_t acc[2];
+#pragma unroll
+  for (int i = 0; i < 16; i++) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
+
+  // Axis weights.  PB = bins per axis rounded up to 8 / 16 / 32; one entry needs 8 x PB (row, bin) and 8 x PB
+  // (column, bin) pairs = 2 * PB / 8 waves, so the 8 waves of the group evaluate EPR = 32 / PB list entries per
+  // ROUND, all at the same time (box head: 4 entries, one wave per entry and axis).  Weights live in NSLOT = 3 EPR
+  // slots: round r + 2 is evaluated during the first item of round r and overwrites round r - 1.
+  constexpr int lg = PB == 8 ? 3 : PB == 16 ? 4 : 5;
+  constexpr int EPR = 32 >> lg, NSLOT = 3 * EPR;
+  const int wave = tid >> 6;
+  const bool wave_ok = slab * (LPP * VEC) + 32 * wave < C && !(L.ablate & 1);  // this wave's 32 channels exist (C % 32 == 0)
+  int nlist = 0;
+  auto compute_round = [&](int first) __attribute__((always_inline)) {
+    constexpr int rows_per_wave = 64 >> lg, waves_per_axis = TILE >> (6 - lg);  // 8,1 / 4,2 / 2,4
+    constexpr int wpe = 2 * waves_per_axis;                                      // waves per entry: 2 / 4 / 8
+    const int li = first + wave / wpe;
+    if (li >= nlist) return;  // uniform per wave
+    const int slot = li % NSLOT;
+    const int w2 = wave % wpe;
+    const HitGeo g = S.geo[li];
+    const bool is_x = w2 >= waves_per_axis;
+    const int wa = is_x ? w2 - waves_per_axis : w2;  // wave within its axis
+    const int p = lane & (PB - 1), r = wa * rows_per_wave + (lane >> lg);
+    const int grid = is_x ? (g.grid >> 16) : (g.grid & 0xffff);
+    const int P = is_x ? PW : PH, size = is_x ? W : H, pix = (is_x ? x0 : y0) + r;
+    float wv = 0.f;
+    if (p < P && pix < size) wv = axis_weight(is_x ? g.start_w : g.start_h, is_x ? g.bin_w : g.bin_h, grid, p, pix, size);
+    if (is_x) S.Wx[((slot << 3) + r) * PB + p] = wv * g.inv;
+    else S.WyT[((slot << lg) + p) * TILE + r] = wv;
+    const unsigned long long bm = __ballot(wv != 0.f);
+    if (lane < rows_per_wave) {
+      const uint32_t m = (uint32_t)(bm >> (lane << lg)) & (PB == 32 ? 0xffffffffu : ((1u << PB) - 1u));
+      if (is_x) S.xmask[slot][wa * rows_per_wave + lane] = m;
+      else S.ymask[slot][wa * rows_per_wave + lane] = m;
+    }
+    if (lane == 0) {
+      uint32_t u = 0;
+      for (int q = 0; q < rows_per_wave; q++) u |= (uint32_t)(bm >> (q << lg)) & (PB == 32 ? 0xffffffffu : ((1u << PB) - 1u));
+      if (is_x) S.xall[slot][wa] = u;
+      else S.yall[slot][wa] = u;
+    }
+  };
+  // window of bins of entry buffer wb that touch the tile (uniform; valid after the barrier that follows its weights)
+  auto window_of = [&](int wb) __attribute__((always_inline)) {
+    constexpr int waves_per_axis = PB / 8;
+    uint32_t ya = S.yall[wb][0], xa = S.xall[wb][0];
+    if (waves_per_axis > 1) { ya |= S.yall[wb][1]; xa |= S.xall[wb][1]; }
+    if (waves_per_axis > 2) { ya |= S.yall[wb][2] | S.yall[wb][3]; xa |= S.xall[wb][2] | S.xall[wb][3]; }
+    Window w;
+    if (ya == 0 || xa == 0) { w.ph_lo = 0; w.nph = 0; w.pw_lo = 0; w.npw = 1; w.rpc = WINCAP; w.nitems = 1; w.rnpw = 1.f; return w; }
+    w.ph_lo = __builtin_ctz(ya); w.nph = 32 - __builtin_clz(ya) - w.ph_lo;
+    w.pw_lo = __builtin_ctz(xa); w.npw = 32 - __builtin_clz(xa) - w.pw_lo;
+    w.rnpw = __builtin_amdgcn_rcpf((float)w.npw);
+    w.rpc = (int)((WINCAP + 0.5f) * w.rnpw);  // WINCAP / npw;  npw <= MAXP = 32 = WINCAP: at least one row of bins
+    w.nitems = (int)((w.nph + w.rpc - 0.5f) * __builtin_amdgcn_rcpf((float)w.rpc));  // ceil(nph / rpc)
+    return w;
+  };
+  // issue the loads of item (entry li with window w, chunk c): bins sb and sb + 16 of the chunk, channel lane lp
+  auto issue_loads = [&](int li, const Window& w, int c, raw16& r0, raw16& r1) __attribute__((always_inline)) {
+    const int pa = w.ph_lo + c * w.rpc;
+    const int nb = min(w.rpc, w.ph_lo + w.nph - pa) * w.npw;  // bins of this item (<= WINCAP); 0 for an empty window
+    const T* gk = gout + (long)S.list[li] * PH * PW * C + cofs;
+    if (nb > 0) {  // uniform
+      const int j0 = min(sb, nb - 1);
+      const int q0 = (int)((j0 + 0.5f) * w.rnpw);  // j0 / npw
+      r0 = *reinterpret_cast<const raw16*>(gk + ((long)(pa + q0) * PW + w.pw_lo + (j0 - q0 * w.npw)) * C);
+      if (nb > 16) {  // uniform
+        const int j1 = min(sb + 16, nb - 1);
+        const int q1 = (int)((j1 + 0.5f) * w.rnpw);
+        r1 = *reinterpret_cast<const raw16*>(gk + ((long)(pa + q1) * PW + w.pw_lo + (j1 - q1 * w.npw)) * C);
+      }
+    }
+    return nb;
+  };
+
+  // weight image of item (entry slot, window w, chunk c) -> buffer buf: thread = (pixel, 4 consecutive bins).
+  // hi = w rounded to the I/O dtype, lo = (w - hi) rounded (hardware conversions: v_cvt_pk_bf16_f32 / v_cvt_f16_f32)
+  auto build_wimg = [&](int buf, int slot, const Window& w, int c) __attribute__((always_inline)) {
+    const int px = tid >> 3, kq = (tid & 7) * 4, r = px >> 3, cx = px & 7;
+    const int pa = w.ph_lo + c * w.rpc;
+    const int nb = min(w.rpc, w.ph_lo + w.nph - pa) * w.npw;
+    int q = (int)((kq + 0.5f) * w.rnpw);  // kq / npw; the following bins advance (q, pi) incrementally
+    int pi = kq - q * w.npw;
+    const float* wyp = &S.WyT[((slot << lg) + pa) * TILE + r];
+    const float* wxp = &S.Wx[((slot << 3) + cx) * PB + w.pw_lo];
+    float wv[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      wv[j] = kq + j < nb ? wyp[q * TILE] * wxp[pi] : 0.f;
+      if (++pi == w.npw) { pi = 0; q++; }
+    }
+    uint16_t hi[4], lo[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if constexpr (sizeof(T) == 2 && __is_same(T, bf16_t)) {
+        const __bf16 h = (__bf16)wv[j];
+        const __bf16 l = (__bf16)(wv[j] - (float)h);
+        hi[j] = __builtin_bit_cast(uint16_t, h);
+        lo[j] = __builtin_bit_cast(uint16_t, l);
+      } else {
+        const _Float16 h = (_Float16)wv[j];
+        const _Float16 l = (_Float16)(wv[j] - (float)h);
+        hi[j] = __builtin_bit_cast(uint16_t, h);
+        lo[j] = __builtin_bit_cast(uint16_t, l);
+      }
+    }
+    *reinterpret_cast<uint2*>(&M.Whi[buf][px][kq]) = uint2{(uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16)};
+    *reinterpret_cast<uint2*>(&M.Wlo[buf][px][kq]) = uint2{(uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16)};
+  };
+  // contraction of one item: acc += (Whi + Wlo)[buf] . D[buf]
+  auto contract = [&](int buf, int nb) __attribute__((always_inline)) {
+    if (!wave_ok || nb <= 0) return;  // uniform per wave
+    const char* dimg = reinterpret_cast<const char*>(&S.D[buf][0][0]);
+    const int kh = lane >> 5;
+    // tr16 address of this lane inside a [4 bins][16 channels] block of the wave's 32 channels
+    const int tr_off = ((lane & 15) >> 2) * (LPP * 16) + (32 * wave + 16 * ((lane >> 4) & 1) + (lane & 3) * 4) * 2;
+#pragma unroll
+    for (int ks = 0; ks < WINCAP / 16; ks++) {
+      if (ks * 16 >= nb) break;  // uniform
+      const char* bp = dimg + (16 * ks + 8 * kh) * (LPP * 16) + tr_off;
+      const s16x4_t t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)bp);
+      const s16x4_t t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(bp + 4 * (LPP * 16)));
+      const s16x8_t b = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+      for (int mt = 0; mt < 2; mt++) {
+        const int px = 32 * mt + (lane & 31);
+        const s16x8_t ah = *reinterpret_cast<const s16x8_t*>(&M.Whi[buf][px][16 * ks + 8 * kh]);
+        const s16x8_t al = *reinterpret_cast<const s16x8_t*>(&M.Wlo[buf][px][16 * ks + 8 * kh]);
+        acc[mt] = pool_mma(ah, b, acc[mt], T{});
+        acc[mt] = pool_mma(al, b, acc[mt], T{});
+      }
+    }
+  };
+
+  int tl_cnt = -1;
+  if (L.tile_cnt) {
+    const int gtile = ids.first[lvl] + (tile - L.tile_base[lvl]);
+    const int c = qcnt >= 0 ? qcnt : L.tile_cnt[gtile];
+    if (c <= TILE_CAP) {
+      tl_cnt = c;
+      if (tid < c) {
+        const TileEntry e = ((const TileEntry*)L.tile_list)[(long)gtile * TILE_CAP + tid];
+        S.list[tid] = e.roi;
+        S.geo[tid] = e.g;
+      }
+    }
+  }
+  const bool prelist = tl_cnt >= 0;  // uniform
+  for (int kbase = 0; kbase < (prelist ? 1 : K); kbase += LCH) {
+    nlist = 0;
+    if (prelist) {
+      nlist = tl_cnt;
+    } else {
+      // ordered list (+ geometry) of the ROIs of this chunk of records that touch the tile (tiles with more
+      // than TILE_CAP ROIs, or no prepared lists)
+      const int kend = min(K, kbase + LCH);
+      const long r = min(kbase + tid, K - 1);
+      const int4 ra = *reinterpret_cast<const int4*>(&rec[r].level);  // level, batch, fy0, fy1
+      const int2 rb = *reinterpret_cast<const int2*>(&rec[r].fx0);    // fx0, fx1
+      const bool hit = kbase + tid < kend && ra.x == lvl && ra.y == n && ra.w >= y0 && ra.z < y0 + TILE &&
+          rb.y >= x0 && rb.x < x0 + TILE;
+      const unsigned long long bal = __ballot(hit);
+      __syncthreads();  // previous chunk's readers of list / geo / wave_cnt / weights / D are done
+      if (lane == 0) S.wave_cnt[tid >> 6] = __builtin_popcountll(bal);
+      __syncthreads();
+      int run = 0;
+#pragma unroll
+      for (int sl = 0; sl < NT / 64; sl++) {
+        if (sl == (tid >> 6) && hit) S.list[run + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = kbase + tid;
+        run += S.wave_cnt[sl];
+      }
+      nlist = run;
+    }
+    if (wst) { wst_list = wall_clock64(); wst_n += nlist; }
+    if (nlist == 0) continue;  // uniform
+    __syncthreads();           // list complete
+    if (!prelist) {
+      for (int i = tid; i < nlist; i += NT) S.geo[i] = rec[S.list[i]].g;
+      __syncthreads();
+    }
+
+    // ---- pipeline over the items of the list --------------------------------------------------------
+    compute_round(0);
+    compute_round(EPR);
+    __syncthreads();
+    raw16 r0 = raw16{0u, 0u, 0u, 0u}, r1 = raw16{0u, 0u, 0u, 0u};
+    Window wc = window_of(0);
+    int nb_cur;
+    {
+      const int nb = issue_loads(0, wc, 0, r0, r1);
+      build_wimg(0, 0, wc, 0);
+      const raw16 z = raw16{0u, 0u, 0u, 0u};
+      S.D[0][sb][lp] = sb < nb ? r0 : z;            // rows past nb: zeros (their weights are 0, stale bits might be NaN)
+      S.D[0][sb + 16][lp] = sb + 16 < nb ? r1 : z;
+      nb_cur = nb;
+    }
+    int e = 0, c = 0, db = 0;
+    while (true) {
+      STAMP();
+      __syncthreads();  // D[db] and the weights of e (and e + 1) are complete; everyone is done with D[db ^ 1]
+      STAMP();
+      // next item: the next chunk of this entry's window, or the first chunk of the next entry
+      int e2 = e, c2 = c + 1;
+      Window wn = wc;
+      if (c2 >= wc.nitems) { e2 = e + 1; c2 = 0; }
+      const bool have_next = e2 < nlist;
+      int nb2 = 0;
+      if (have_next) {
+        if (e2 != e) wn = window_of(e2 % NSLOT);
+        nb2 = issue_loads(e2, wn, c2, r0, r1);
+      }
+      STAMP();
+      if (c == 0 && (e & (EPR - 1)) == 0) compute_round(e + 2 * EPR);  // overlaps the loads
+      STAMP();
+      // contraction of item (e, c) on the matrix cores, then the weight image of the next item
+      contract(db, nb_cur);
+      STAMP();
+      if (have_next) build_wimg(db ^ 1, e2 % NSLOT, wn, c2);
+      STAMP();
+      if (!have_next) break;
+      {
+        const raw16 z = raw16{0u, 0u, 0u, 0u};
+        S.D[db ^ 1][sb][lp] = sb < nb2 ? r0 : z;
+        S.D[db ^ 1][sb + 16][lp] = sb + 16 < nb2 ? r1 : z;
+      }
+      e = e2; c = c2; wc = wn; db ^= 1; nb_cur = nb2;
+    }
+  }
+#ifdef D2AMD_PROFILE
+  if (dbg_on) { L.dbg[127] = dbg_n; L.dbg[126] = 0; L.dbg[125] = __builtin_readcyclecounter() - L.dbg[0]; }
+#endif
+  if (wst) { wst[1] = wst_list; wst[2] = wall_clock64(); wst[4] = (unsigned long long)wst_n; }
+  // ---- epilogue: accumulators (lane = channel, registers = pixels) -> LDS [pixel][channel] in the I/O dtype ->
+  // 16-B channel vectors per pixel (every pixel of grad_input is written exactly once)
+  __syncthreads();  // everyone is done with D
+  T* obuf = reinterpret_cast<T*>(&S.D[0][0][0]);  // 64 pixels x 256 channels x 2 B = the two D buffers
+  if (slab * (LPP * VEC) + 32 * wave < C) {
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int px = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        obuf[px * (LPP * VEC) + 32 * wave + (lane & 31)] = from_f32<T>(acc[mt][r]);
+      }
+  }
+  __syncthreads();
+  if (cg_ok && x0 + col < W) {
+    T* gi = (T*)L.data[lvl] + (((long)n * H + y0 + rh * TR) * W + x0 + col) * C + cofs;
+#pragma unroll
+    for (int i = 0; i < TR; i++) {
+      if (y0 + rh * TR + i >= H) break;
+      const int px = (rh * TR + i) * TILE + col;
+      *reinterpret_cast<raw16*>(gi + (long)i * W * C) = *reinterpret_cast<const raw16*>(obuf + px * (LPP * VEC) + lp * VEC);
+    }
+  }
+  if (wst) wst[3] = wall_clock64();
+}
+
 // ---- convert_boxes_to_pooler_format (poolers.py:62-104) in one launch, no host sync -----------------
 struct ImgEnds { int n; int end[D2AMD_POOLER_MAX_IMAGES]; };  // exclusive prefix ends of the per-image box counts
 __global__ void boxes_to_rois_kernel(const float* __restrict__ boxes, int K, int width, ImgEnds e,
@@ -1372,7 +1722,24 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
     const char* tname = p->pooled_h <= 7 ? "pool_bwd_staged_r7" : "pool_bwd_staged_r14";
     const bool timed = timing_begin(tname, s);
     const int pmax = p->pooled_h > p->pooled_w ? p->pooled_h : p->pooled_w;
-    if (pmax <= 8)
+    bool mfma = false;
+    if constexpr (sizeof(T) == 2) {  // 16-bit I/O: contraction on the matrix cores
+      static const bool no_mfma = getenv("D2AMD_POOL_NOMFMA") != nullptr;
+      mfma = !no_mfma && p->C % 32 == 0;
+      if (mfma) {
+        if (pmax <= 8)
+          hipLaunchKernelGGL((pool_bwd_mfma_kernel<T, 8>), dim3((unsigned)total), dim3(2 * CT), 0, s, L, rec,
+                             (const T*)grad_output, nslab, (int)total, ids);
+        else if (pmax <= 16)
+          hipLaunchKernelGGL((pool_bwd_mfma_kernel<T, 16>), dim3((unsigned)total), dim3(2 * CT), 0, s, L, rec,
+                             (const T*)grad_output, nslab, (int)total, ids);
+        else
+          hipLaunchKernelGGL((pool_bwd_mfma_kernel<T, 32>), dim3((unsigned)total), dim3(2 * CT), 0, s, L, rec,
+                             (const T*)grad_output, nslab, (int)total, ids);
+      }
+    }
+    if (mfma) {
+    } else if (pmax <= 8)
       hipLaunchKernelGGL((pool_bwd_staged_kernel<T, VEC, 8>), dim3((unsigned)total), dim3(2 * CT), 0, s, L, rec,
                          (const T*)grad_output, nslab, (int)total, ids);
     else if (pmax <= 16)
