@@ -365,8 +365,8 @@ def main():
         for k in ops:
             ops[k]["launches_per_step"] = counts[k]
             ops[k]["ms_per_launch"] = round(ops[k]["ms_per_step"] / counts[k], 4)
-        # roofline: the dominant kernel = the tile-gather launch of the box-head backward (pool_bwd_staged_kernel in
-        # the rocprofv3 stats; with D2AMD_POOL_NOSTAGED the fine-level launch of the two-launch register-gather
+        # roofline: the dominant kernel = the tile-gather launch of the box-head backward (pool_bwd_mfma_kernel /
+        # pool_bwd_staged_kernel in the rocprofv3 stats; with D2AMD_POOL_NOSTAGED the fine-level launch of the two-launch register-gather
         # kernels), timed by HIP events on its launch stream inside the timed region.  Its algorithmic bytes:
         # SURVEY 8(d)'s backward formula for the levels the launch writes (dY read once + 2 x grad_input).
         dom = ROOFLINE_OP
@@ -375,7 +375,7 @@ def main():
             # one launch for all FPN levels (LDS-staged tile gather): SURVEY 8(d)'s backward bytes of the whole op
             k_ms, k_n = ktimes["pool_bwd_staged_r7"]
             kb = alg[dom] / counts[dom]
-            roof = {"bound": "hbm", "kernel": "pool_bwd_staged_kernel<T, 8, 8> (7x7 pooler, all FPN levels) of roi_align_box_bwd",
+            roof = {"bound": "hbm", "kernel": "pool_bwd_mfma_kernel<T, 8> (16-bit I/O; fp32: pool_bwd_staged_kernel<float, 4, 8>), the 7x7 pooler's tile gather over all FPN levels, of roi_align_box_bwd",
                     "achieved": round(kb / 1e9 / (k_ms / 1e3), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(kb / 1e9 / (k_ms / 1e3) / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, args.layout),
                     "traffic_note": "PMC bytes are for the whole op (records + tile lists/zero fill + tile gather)",
