@@ -120,3 +120,49 @@ def test_no_product_code_touches_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "libd2oracle" not in src, f
+
+
+def test_round1_late_entries_host_checks(lib):
+    """Host-side argument checks / workspace sizes of the entries added for SURVEY 8(f) rows 2 and 4 (no GPU needed)."""
+    # mask-head glue
+    assert lib.d2amd_mask_rcnn_loss_workspace_bytes(256) >= 256 * 24
+    rc = lib.d2amd_mask_rcnn_inference(None, None, 4, 80, 784, 2, None, None)  # class-specific logits need classes
+    assert rc == -1 and b"classes" in lib.d2amd_last_error()
+    rc = lib.d2amd_mask_rcnn_loss_forward(None, None, None, 0, 80, 784, 2, None, None, None, 0, None)
+    assert rc == -1 and b"empty case" in lib.d2amd_last_error()
+    # dense-detector selection: workspace grows with the score count; top-k beyond the LDS ordering limit is refused
+    lv = (ctypes.c_int * 2)(9 * 16800, 9 * 4200)
+    small = lib.d2amd_dense_select_workspace_bytes(1, lv, 2, 80, 1000)
+    assert small > 2 * 1000 * 8 and lib.d2amd_dense_select_workspace_bytes(2, lv, 2, 80, 1000) > small
+    rc = lib.d2amd_dense_select_predictions(None, None, None, 1, lv, 2, 80, 0.05, 20000, None, 0.0, None, None, None, None,
+                                            None, None, 0, None)
+    assert rc == -1 and b"topk" in lib.d2amd_last_error()
+    # pooler forward from un-concatenated box lists: too many images
+    p = _C.PoolerParams()
+    rc = lib.d2amd_roi_pooler_forward_box_lists(ctypes.byref(p), None, None, None, 65, None, None, None)
+    assert rc == -1 and b"images" in lib.d2amd_last_error()
+    # pooler backward workspace covers records + per-tile lists + work queues
+    p.num_levels, p.N, p.C = 1, 2, 256
+    p.H[0], p.W[0], p.spatial_scale[0] = 200, 336, 0.25
+    p.pooled_h = p.pooled_w = 7
+    p.aligned, p.dtype, p.layout = 1, 2, 1
+    tiles = 25 * 42 * 2
+    assert lib.d2amd_roi_pooler_backward_workspace_bytes(ctypes.byref(p), 1024) >= 1024 * 48 + tiles * (4 + 64 * 32 + 32)
+
+
+def test_late_python_surface_rejects_cpu_tensors():
+    from detectron2_amd.modeling import dense_select_predictions, mask_rcnn_inference, mask_rcnn_loss_from_targets
+
+    with pytest.raises(NotImplementedError):
+        mask_rcnn_loss_from_targets(torch.zeros(2, 3, 7, 7), torch.zeros(2, dtype=torch.int64), torch.zeros(2, 7, 7, dtype=torch.bool))
+
+    class I:
+        pred_classes = torch.zeros(2, dtype=torch.int64)
+
+        def __len__(self):
+            return 2
+
+    with pytest.raises(NotImplementedError):
+        mask_rcnn_inference(torch.zeros(2, 3, 7, 7), [I()])
+    with pytest.raises(NotImplementedError):
+        dense_select_predictions([torch.zeros(4, 4)], [torch.zeros(1, 4, 2)], [torch.zeros(1, 4, 4)], 0.05, 10)
