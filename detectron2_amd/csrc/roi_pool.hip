@@ -1259,13 +1259,16 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
     const int nb = min(w.rpc, w.ph_lo + w.nph - pa) * w.npw;  // bins of this item (<= WINCAP); 0 for an empty window
     const T* gk = gout + (long)S.list[li] * PH * PW * C + cofs;
     if (nb > 0) {  // uniform
+      // 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate): bin index < 1024, C <= 8192 (checked by the host)
       const int j0 = min(sb, nb - 1);
       const int q0 = (int)((j0 + 0.5f) * w.rnpw);  // j0 / npw
-      r0 = *reinterpret_cast<const raw16*>(gk + ((long)(pa + q0) * PW + w.pw_lo + (j0 - q0 * w.npw)) * C);
+      const unsigned b0 = __umul24(pa + q0, PW) + w.pw_lo + j0 - __umul24(q0, w.npw);
+      r0 = *reinterpret_cast<const raw16*>(gk + __umul24(b0, C));
       if (nb > 16) {  // uniform
         const int j1 = min(sb + 16, nb - 1);
         const int q1 = (int)((j1 + 0.5f) * w.rnpw);
-        r1 = *reinterpret_cast<const raw16*>(gk + ((long)(pa + q1) * PW + w.pw_lo + (j1 - q1 * w.npw)) * C);
+        const unsigned b1 = __umul24(pa + q1, PW) + w.pw_lo + j1 - __umul24(q1, w.npw);
+        r1 = *reinterpret_cast<const raw16*>(gk + __umul24(b1, C));
       }
     }
     return nb;
@@ -1278,7 +1281,7 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
     const int pa = w.ph_lo + c * w.rpc;
     const int nb = min(w.rpc, w.ph_lo + w.nph - pa) * w.npw;
     int q = (int)((kq + 0.5f) * w.rnpw);  // kq / npw; the following bins advance (q, pi) incrementally
-    int pi = kq - q * w.npw;
+    int pi = kq - (int)__umul24(q, w.npw);
     const float* wyp = &S.WyT[((slot << lg) + pa) * TILE + r];
     const float* wxp = &S.Wx[((slot << 3) + cx) * PB + w.pw_lo];
     float wv[4];
@@ -1731,7 +1734,7 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
     bool mfma = false;
     if constexpr (sizeof(T) == 2) {  // 16-bit I/O: contraction on the matrix cores
       static const bool no_mfma = getenv("D2AMD_POOL_NOMFMA") != nullptr;
-      mfma = !no_mfma && p->C % 32 == 0;
+      mfma = !no_mfma && p->C % 32 == 0 && p->C <= 8192;
       if (mfma) {
         if (pmax <= 8)
           hipLaunchKernelGGL((pool_bwd_mfma_kernel<T, 8>), dim3((unsigned)total), dim3(2 * CT), 0, s, L, rec,
