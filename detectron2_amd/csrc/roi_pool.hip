@@ -155,12 +155,17 @@ __global__ __launch_bounds__(NTHR) void pool_fwd_nhwc_kernel(PoolLevels L, const
       float w[U];
       if constexpr (VEC > 1) {
         raw16 raw[U];
+        // The kernel is VALU-issue bound (the v8 ISA had five quarter-rate / 64-bit integer multiplies per tap and a
+        // branch + LDS wait around every weight read): 24-bit multiplies (full rate; t < 4096, rcp < 2^17, pixel offset
+        // < 2^15, C <= 8192 checked by the host), one 32-bit element offset per tap, weights read unconditionally
+        // (clamped tap) and selected.
 #pragma unroll
         for (int u = 0; u < U; u++) {
           const int t = t0 + u, tt = min(t, nt - 1);
-          const int j = (int)(((uint32_t)tt * rcp) >> 16), i = tt - j * sx;
-          w[u] = t < nt ? wy[j] * wx[i] : 0.f;
-          raw[u] = *reinterpret_cast<const raw16*>(base + ((long)j * W + i) * C);
+          const uint32_t j = __umul24((uint32_t)tt, rcp) >> 16, i = (uint32_t)tt - __umul24(j, (uint32_t)sx);
+          const float wv = wy[j] * wx[i];
+          w[u] = t < nt ? wv : 0.f;
+          raw[u] = *reinterpret_cast<const raw16*>(base + __umul24(__umul24(j, (uint32_t)W) + i, (uint32_t)C));
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -1536,7 +1541,10 @@ static int pool_fwd_impl(const d2amd_pooler_params* p, const void* const* inputs
   const int bins = p->pooled_h * p->pooled_w;
   constexpr int VEC = V16<T>::N;
   if (p->layout == D2AMD_NHWC) {
-    const bool vec = (p->C % VEC == 0) && all_aligned16(inputs, p->num_levels, output);
+    int wmax = 0;
+    for (int l = 0; l < p->num_levels; l++) wmax = p->W[l] > wmax ? p->W[l] : wmax;
+    // the vector kernel's 32-bit tap offsets: (12 rows x W) x C elements must stay below 2^32
+    const bool vec = (p->C % VEC == 0) && all_aligned16(inputs, p->num_levels, output) && p->C <= 8192 && wmax <= 16384;
     const int cg = vec ? p->C / VEC : p->C;
     // workgroup shape (profiles/r01/v5_pool_fwd_sweep.txt): the kernel is insensitive to it within +-10 % --
     // the per-workgroup prologue (ROI load, level, table build: ~4 us) and the tap loads trade off -- because
