@@ -135,3 +135,64 @@ def test_level_assignment_restatement_matches_torch():
     ref = torch.clamp(torch.floor(4 + torch.log2(sizes / 224 + 1e-8)), min=2, max=5).to(torch.int64) - 2
     got = assign_levels_restated(boxes, 2, 5, 224, 4)
     assert np.array_equal(got, ref.numpy())
+
+
+def axis_weights_closed_form(start, bin_sz, grid, P, size):
+    """the v9 device formulation (csrc/roi_pool.hip axis_weight): a valid sample at y puts
+    max(0, 1 - |clamp(y, 0, size - 1) - pix|) on pixel pix; sample spacing bin / grid divided once"""
+    Wm = np.zeros((size, P), f32)
+    step = f32(f32(bin_sz) / f32(grid))
+    pix = np.arange(size, dtype=f32)
+    for p in range(P):
+        y0 = f32(f32(start) + f32(p) * f32(bin_sz) + f32(0.5) * step)
+        for i in range(grid):
+            y = f32(y0 + f32(i) * step)
+            if y < f32(-1.0) or y > f32(size):
+                continue
+            yc = min(max(y, f32(0)), f32(size - 1))
+            Wm[:, p] += np.maximum(f32(1) - np.abs(yc - pix), f32(0)).astype(f32)
+    return Wm
+
+
+def test_closed_form_axis_weights_equal_the_tap_classification():
+    """Both formulations of the per-axis weights agree to fp32 rounding (the backward's bar is 1e-4), including samples
+    below 0, beyond the last pixel, outside [-1, size] and degenerate (zero-size) bins."""
+    rng = np.random.default_rng(3)
+    worst = 0.0
+    for _ in range(300):
+        size = int(rng.integers(1, 40))
+        P = int(rng.integers(1, 15))
+        start = f32(rng.uniform(-6, size + 3))
+        bin_sz = f32(0.0 if rng.random() < 0.05 else np.exp(rng.uniform(np.log(0.05), np.log(9.0))))
+        grid = int(rng.integers(1, 9))
+        a = axis_weights(start, bin_sz, grid, P, size)
+        b = axis_weights_closed_form(start, bin_sz, grid, P, size)
+        worst = max(worst, float(np.abs(a - b).max()))
+    assert worst < 2e-5, worst
+
+
+def _split_16(w, kind):
+    """hi + lo split of fp32 weights into two 16-bit values (the MFMA kernel's weight image)"""
+    import torch
+
+    dt = torch.bfloat16 if kind == "bf16" else torch.float16
+    t = torch.from_numpy(w)
+    hi = t.to(dt)
+    lo = (t - hi.float()).to(dt)
+    return hi.float().numpy(), lo.float().numpy()
+
+
+@pytest.mark.parametrize("kind,bits", [("bf16", 15), ("f16", 14)])  # f16: the low part of a tiny weight is subnormal
+def test_hi_lo_weight_split_keeps_fp32_accuracy(kind, bits):
+    """pool_bwd_mfma_kernel contracts (hi + lo) . dY on the matrix cores with fp32 accumulation: the split weights
+    reproduce the fp32 weights to >= `bits` significant bits, so a 32-bin contraction matches the fp32-weight result
+    far inside the 16-bit output rounding."""
+    rng = np.random.default_rng(11)
+    w = (rng.random(4096) * np.exp(rng.uniform(-6, 0, 4096))).astype(f32)  # weights in (0, 1], several decades
+    hi, lo = _split_16(w, kind)
+    rel = np.abs((hi + lo).astype(np.float64) - w) / w
+    assert rel.max() < 2.0 ** -bits, rel.max()
+    dy = np.float32(rng.standard_normal((4096 // 32, 32)))
+    ref = (w.reshape(-1, 32).astype(np.float64) * dy).sum(1)
+    got = ((hi + lo).reshape(-1, 32).astype(np.float64) * dy).sum(1)
+    assert np.abs(got - ref).max() < 2.0 ** -(bits - 3) * np.abs(ref).max()
