@@ -182,7 +182,7 @@ def _split_16(w, kind):
     return hi.float().numpy(), lo.float().numpy()
 
 
-@pytest.mark.parametrize("kind,bits", [("bf16", 15), ("f16", 14)])  # f16: the low part of a tiny weight is subnormal
+@pytest.mark.parametrize("kind,bits", [("bf16", 15), ("f16", 20)])
 def test_hi_lo_weight_split_keeps_fp32_accuracy(kind, bits):
     """pool_bwd_mfma_kernel contracts (hi + lo) . dY on the matrix cores with fp32 accumulation: the split weights
     reproduce the fp32 weights to >= `bits` significant bits, so a 32-bin contraction matches the fp32-weight result
@@ -190,9 +190,10 @@ def test_hi_lo_weight_split_keeps_fp32_accuracy(kind, bits):
     rng = np.random.default_rng(11)
     w = (rng.random(4096) * np.exp(rng.uniform(-6, 0, 4096))).astype(f32)  # weights in (0, 1], several decades
     hi, lo = _split_16(w, kind)
-    rel = np.abs((hi + lo).astype(np.float64) - w) / w
-    assert rel.max() < 2.0 ** -bits, rel.max()
+    err = np.abs((hi + lo).astype(np.float64) - w)
+    floor = 2.0 ** -24 if kind == "f16" else 0.0  # f16: the low part of a small weight is subnormal (spacing 2^-24)
+    assert (err <= np.maximum(2.0 ** -bits * w, floor)).all(), (err / w).max()
     dy = np.float32(rng.standard_normal((4096 // 32, 32)))
     ref = (w.reshape(-1, 32).astype(np.float64) * dy).sum(1)
     got = ((hi + lo).reshape(-1, 32).astype(np.float64) * dy).sum(1)
-    assert np.abs(got - ref).max() < 2.0 ** -(bits - 3) * np.abs(ref).max()
+    assert np.abs(got - ref).max() < 2.0 ** -12 * np.abs(ref).max()  # 16-bit outputs round at 2^-9 / 2^-11
