@@ -1282,9 +1282,12 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
   // weight image of item (entry slot, window w, chunk c) -> buffer buf: thread = (pixel, 4 consecutive bins).
   // hi = w rounded to the I/O dtype, lo = (w - hi) rounded (hardware conversions: v_cvt_pk_bf16_f32 / v_cvt_f16_f32)
   auto build_wimg = [&](int buf, int slot, const Window& w, int c) __attribute__((always_inline)) {
-    const int px = tid >> 3, kq = (tid & 7) * 4, r = px >> 3, cx = px & 7;
+    // wave = 4 consecutive bins, lane = pixel: the waves whose bins lie in a k step the contraction never reads
+    // (bins >= nb rounded up to 16: half of the waves for the typical 9-16 bin window) skip the build altogether
+    const int px = lane, kq = (tid >> 6) * 4, r = px >> 3, cx = px & 7;
     const int pa = w.ph_lo + c * w.rpc;
     const int nb = min(w.rpc, w.ph_lo + w.nph - pa) * w.npw;
+    if (kq >= ((nb + 15) & ~15)) return;  // uniform per wave
     int q = (int)((kq + 0.5f) * w.rnpw);  // kq / npw; the following bins advance (q, pi) incrementally
     int pi = kq - (int)__umul24(q, w.npw);
     const float* wyp = &S.WyT[((slot << lg) + pa) * TILE + r];
@@ -1397,7 +1400,7 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
       build_wimg(0, 0, wc, 0);
       const raw16 z = raw16{0u, 0u, 0u, 0u};
       S.D[0][sb][lp] = sb < nb ? r0 : z;            // rows past nb: zeros (their weights are 0, stale bits might be NaN)
-      S.D[0][sb + 16][lp] = sb + 16 < nb ? r1 : z;
+      if (nb > 16) S.D[0][sb + 16][lp] = sb + 16 < nb ? r1 : z;  // uniform; the second k step is not read otherwise
       nb_cur = nb;
     }
     int e = 0, c = 0, db = 0;
@@ -1427,7 +1430,7 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
       {
         const raw16 z = raw16{0u, 0u, 0u, 0u};
         S.D[db ^ 1][sb][lp] = sb < nb2 ? r0 : z;
-        S.D[db ^ 1][sb + 16][lp] = sb + 16 < nb2 ? r1 : z;
+        if (nb2 > 16) S.D[db ^ 1][sb + 16][lp] = sb + 16 < nb2 ? r1 : z;
       }
       e = e2; c = c2; wc = wn; db ^= 1; nb_cur = nb2;
     }
