@@ -47,6 +47,7 @@ struct PoolLevels {
   const int* tile_cnt;    // backward: per tile, number of ROIs that touch it (nullptr: tiles scan the records)
   const void* tile_list;  // backward: [tile][TILE_CAP] TileEntry in ROI order (valid when tile_cnt[tile] <= TILE_CAP)
   unsigned long long* wgstamps;  // profiling only (D2AMD_POOL_STAMPS): per workgroup {start, lists done, loop done, end, #ROIs}
+  int tab_off;       // forward: 1 = no 32-bit tap table (a level holds >= 2^32 elements per image)
   const int* queue;  // backward: per-XCD work queues of this launch (tile_lists_kernel), [8][qcap]; nullptr: static order
   int qcap;
 };
@@ -138,6 +139,74 @@ __global__ __launch_bounds__(NTHR) void pool_fwd_nhwc_kernel(PoolLevels L, const
   // b / PW == (b * rcp_pw) >> 16 for b < 1024 (PH, PW <= 32)
   const int cg_shift = (CG & (CG - 1)) == 0 ? __builtin_ctz(CG) : -1;  // uniform
   const uint32_t rcp_pw = (65536u + (uint32_t)PW - 1u) / (uint32_t)PW;
+  // TAP TABLE (v9).  The gather loop is VALU-issue bound and, per tap, spent as many instructions on rebuilding the
+  // tap (row / column from the flattened index, two weight reads and their product, the element offset) as on using
+  // it (8 unpack + 4 packed FMA) -- identically in each of the 32 channel lanes of a bin and again in every pass.
+  // The workgroup now builds each bin's taps ONCE: {32-bit element offset from the image base, weight x 1 / count},
+  // ntcap slots per bin in LDS; the loop reads a tap with one ds_read_b64.  ROIs with a bin of more than ntcap taps
+  // (bins wider than ~4 px) keep the arithmetic path below.
+  if constexpr (VEC > 1) {
+    constexpr int TAPTAB = 3200;  // 196 bins x 16 taps
+    __shared__ uint2 taptab[TAPTAB];
+    const int nbins = b_hi - b_lo;
+    const int lgcap = nbins * 32 <= TAPTAB ? 5 : nbins * 16 <= TAPTAB ? 4 : nbins * 8 <= TAPTAB ? 3 : -1;  // uniform
+    bool over = lgcap < 0 || L.tab_off;  // tab_off: the image is too large for 32-bit offsets (host)
+    if (!over) {
+      for (int bl = tid; bl < nbins; bl += NTHR) {
+        const int b = b_lo + bl;
+        const int ph = (int)(((uint32_t)b * rcp_pw) >> 16), pw = b - ph * PW;
+        over |= S.spany[ph] * S.spanx[pw] > (1 << lgcap);
+      }
+    }
+    if (!__syncthreads_or(over)) {
+      const int cap = 1 << lgcap;
+      for (int idx = tid; idx < nbins << lgcap; idx += NTHR) {
+        const int bl = idx >> lgcap, t = idx & (cap - 1);
+        const int b = b_lo + bl;
+        const int ph = (int)(((uint32_t)b * rcp_pw) >> 16), pw = b - ph * PW;
+        const int sx = S.spanx[pw], nt = S.spany[ph] * sx;
+        if (t < nt) {
+          const uint32_t rcp = (65536u + (uint32_t)sx - 1u) / (uint32_t)sx;
+          const uint32_t j = __umul24((uint32_t)t, rcp) >> 16, i = (uint32_t)t - __umul24(j, (uint32_t)sx);
+          const uint32_t pix = __umul24((uint32_t)S.firsty[ph] + j, (uint32_t)W) + (uint32_t)S.firstx[pw] + i;
+          taptab[idx] = uint2{pix * (uint32_t)C, __float_as_uint(S.wy[ph * SEP_SPAN + j] * S.wx[pw * SEP_SPAN + i] * inv)};
+        }
+      }
+      __syncthreads();
+      for (int e = tid; e < nbins * CG; e += NTHR) {
+        const int bl = cg_shift >= 0 ? (e >> cg_shift) : e / CG, q = e - bl * CG;
+        const int b = b_lo + bl;
+        const int ph = (int)(((uint32_t)b * rcp_pw) >> 16), pw = b - ph * PW;
+        const int nt = S.spany[ph] * S.spanx[pw];
+        const uint2* tab = taptab + (bl << lgcap);
+        const T* base = inb + q * VEC;
+        float acc[VEC];
+#pragma unroll
+        for (int c = 0; c < VEC; c++) acc[c] = 0.f;
+        for (int t0 = 0; t0 < nt; t0 += U) {
+          raw16 raw[U];
+          float w[U];
+#pragma unroll
+          for (int u = 0; u < U; u++) {
+            const int t = t0 + u;
+            const uint2 tp = tab[min(t, nt - 1)];
+            w[u] = t < nt ? __uint_as_float(tp.y) : 0.f;
+            raw[u] = *reinterpret_cast<const raw16*>(base + tp.x);
+          }
+#pragma unroll
+          for (int u = 0; u < U; u++) {
+            float f[VEC];
+            unpack16(raw[u], f, T{});
+#pragma unroll
+            for (int c = 0; c < VEC; c++) acc[c] += w[u] * f[c];
+          }
+        }
+        *reinterpret_cast<raw16*>(outk + (long)b * C + (long)q * VEC) = pack16(acc, T{});
+      }
+      if (wst) { wst[2] = wall_clock64(); wst[3] = wst[2]; }
+      return;
+    }
+  }
   for (int e = tid; e < (b_hi - b_lo) * CG; e += NTHR) {
     const int bl = cg_shift >= 0 ? (e >> cg_shift) : e / CG, q = e - bl * CG;
     const int b = b_lo + bl;
@@ -1516,7 +1585,7 @@ static PoolLevels make_levels(const d2amd_pooler_params* p, const void* const* d
   L.min_level = p->min_level; L.max_level = p->max_level; L.canonical_level = p->canonical_level;
   L.canonical_size = p->canonical_box_size;
   { const char* e = getenv("D2AMD_ABLATE"); L.ablate = e ? atoi(e) : 0; }
-  L.dbg = nullptr; L.dbg_block = -1; L.wgstamps = nullptr; L.tile_cnt = nullptr; L.tile_list = nullptr; L.queue = nullptr; L.qcap = 0;
+  L.dbg = nullptr; L.dbg_block = -1; L.wgstamps = nullptr; L.tile_cnt = nullptr; L.tile_list = nullptr; L.queue = nullptr; L.qcap = 0; L.tab_off = 0;
   int base = 0;
   for (int l = 0; l < p->num_levels; l++) {
     L.data[l] = data[l]; L.H[l] = p->H[l]; L.W[l] = p->W[l]; L.scale[l] = p->spatial_scale[l];
@@ -1564,6 +1633,8 @@ static int pool_fwd_impl(const d2amd_pooler_params* p, const void* const* inputs
     D2_CHECK_ARG(nsplit <= 65535, "roi_pooler_forward: internal split too large");
     dim3 grid(K, nsplit);
     PoolLevels Lf = L;
+    for (int l = 0; l < p->num_levels; l++)
+      if ((long)p->H[l] * p->W[l] * p->C >= (1l << 32)) Lf.tab_off = 1;
     const char* stamp_path = getenv("D2AMD_POOL_STAMPS");  // profiling only: per-workgroup timeline dump
     const long nwg = (long)K * nsplit;
     if (stamp_path) {
