@@ -214,11 +214,14 @@ def step(w, t=None):
     # previous step's tensors (the two poolers of one step still share one copy)
     from detectron2_amd.modeling import poolers as _poolers
     _poolers._NHWC_CACHE.clear()
+    # RPN NMS of all images of the batch: one call, one launch per pipeline stage for the whole batch; the kept
+    # counts come back with ONE host sync (the reference loops over images, one sync each).  The sync is deferred
+    # past the anchor-labelling IoU, which does not depend on the proposals (RPN.forward computes the two in either
+    # order: rpn.py label_and_sample_anchors / predict_proposals): the host enqueues it while the NMS pipeline runs.
+    nms_done = run("batched_nms_rpn", lambda: batched_nms_images(w.nms_in, 0.7, defer=True))
     for i in range(w.n_img):
         run("pairwise_iou_rpn", lambda: pairwise_iou(w.gt[i], w.anchors))
-    # RPN NMS of all images of the batch: one call, the images' device pipelines overlap on HIP streams and
-    # the kept counts come back with one host sync (the reference loops over images, one sync each)
-    run("batched_nms_rpn", lambda: batched_nms_images(w.nms_in, 0.7))
+    run("batched_nms_rpn_sync", nms_done)
     for i in range(w.n_img):
         run("pairwise_iou_roi", lambda: pairwise_iou(w.gt[i], w.props[i]))
     outs = []

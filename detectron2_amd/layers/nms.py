@@ -37,12 +37,14 @@ def batched_nms_rotated(boxes: torch.Tensor, scores: torch.Tensor, idxs: torch.T
     return nms_impl(boxes, scores, idxs, iou_threshold, True)
 
 
-def batched_nms_images(inputs, iou_threshold: float):
+def batched_nms_images(inputs, iou_threshold: float, defer: bool = False):
     """`batched_nms` of every image of a batch: inputs = [(boxes [n,4], scores [n], idxs [n]), ...] ->
     list of kept-index tensors (each as `batched_nms` would return).  Replaces the per-image loop +
     per-image host sync of find_top_rpn_proposals (proposal_generator/proposal_utils.py:118-135) and
     DenseDetector._decode_multi_level_predictions / inference (meta_arch/dense_detector.py:186-260):
-    the images' device pipelines overlap on separate HIP streams and there is one sync per batch."""
+    the images' device pipelines overlap on separate HIP streams and there is one sync per batch.
+    defer=True enqueues everything and returns a callable that performs that sync and returns the list: work that does
+    not depend on the NMS (e.g. the anchor-labelling IoU of the same RPN iteration) can be enqueued in between."""
     for b, _s, _i in inputs:
         assert b.shape[-1] == 4
-    return nms_images([(b.float(), s, i) for b, s, i in inputs], iou_threshold, False)
+    return nms_images([(b.float(), s, i) for b, s, i in inputs], iou_threshold, False, defer)

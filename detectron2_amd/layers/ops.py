@@ -72,7 +72,7 @@ _SIDE_STREAMS = {}
 _BATCH_MAX = None
 
 
-def _nms_images_batched(inputs, iou_threshold, rotated):
+def _nms_images_batched(inputs, iou_threshold, rotated, defer=False):
     """All images through d2amd_nms_batched: one launch per pipeline stage for the whole batch, one
     [count, 2] result tensor, one host sync."""
     ct = _C.ctypes
@@ -108,13 +108,18 @@ def _nms_images_batched(inputs, iou_threshold, rotated):
         _C.check(L.d2amd_nms_batched(cnt, arr(pb), arr(ps), arr(pi), (ct.c_int64 * cnt)(*ns), float(iou_threshold),
                                      int(rotated), None, arr(pk), arr(pr), arr(pw), (ct.c_size_t * cnt)(*wb),
                                      _C.stream()))
-    counts = result.tolist()  # the only host sync; `hold` keeps inputs / workspaces alive until here
-    del hold
-    return [_nms_finish(keep, num, flags) for keep, (num, flags) in zip(keeps, counts)]
+    def finish():
+        counts = result.tolist()  # the only host sync; `hold` keeps inputs / workspaces alive until here
+        hold.clear()
+        return [_nms_finish(keep, num, flags) for keep, (num, flags) in zip(keeps, counts)]
+
+    return finish if defer else finish()
 
 
-def nms_images(inputs, iou_threshold, rotated=False):
+def nms_images(inputs, iou_threshold, rotated=False, defer=False):
     """NMS of every image of a batch in one call: `inputs` = [(boxes, scores, idxs | None), ...].
+    defer=True: everything is enqueued and a callable is returned; calling it performs the one host sync and returns
+    the kept indices -- the caller can enqueue independent work (e.g. the anchor labelling IoU) in between.
     The reference runs the RPN / RetinaNet NMS in a per-image Python loop, each iteration ending in a
     device->host sync (proposal_generator/proposal_utils.py:118-135, meta_arch/dense_detector.py:186-260).
     Images are independent: up to d2amd_nms_batched_max_boxes() boxes per image the whole batch runs as one
@@ -122,12 +127,12 @@ def nms_images(inputs, iou_threshold, rotated=False):
     join into the current stream.  Either way the kept counts are read with ONE sync."""
     global _BATCH_MAX
     if not inputs:
-        return []
+        return (lambda: []) if defer else []
     if _BATCH_MAX is None:
         _BATCH_MAX = int(_C.lib().d2amd_nms_batched_max_boxes())
     dev = inputs[0][0].device
     if all(b.shape[0] <= _BATCH_MAX and b.device == dev for b, _s, _i in inputs):
-        return _nms_images_batched(inputs, iou_threshold, rotated)
+        return _nms_images_batched(inputs, iou_threshold, rotated, defer)
     cur = torch.cuda.current_stream(dev)
     pool = _SIDE_STREAMS.setdefault(dev.index, [])
     fork = torch.cuda.Event()
@@ -152,15 +157,20 @@ def nms_images(inputs, iou_threshold, rotated=False):
         if item is not None and item[1] is not cur:
             cur.wait_stream(item[1])  # join: everything enqueued later on `cur` sees the results
     live = [it for it in launched if it is not None]
-    counts = torch.stack([it[0][1] for it in live]).tolist() if live else []  # ONE host sync
-    out, j = [], 0
-    for (boxes, _s, _i), it in zip(inputs, launched):
-        if it is None:
-            out.append(torch.empty((0,), dtype=torch.int64, device=boxes.device))
-        else:
-            out.append(_nms_finish(it[0][0], *counts[j]))
-            j += 1
-    return out
+    stacked = torch.stack([it[0][1] for it in live]) if live else None
+
+    def finish():
+        counts = stacked.tolist() if live else []  # ONE host sync
+        out, j = [], 0
+        for (boxes, _s, _i), it in zip(inputs, launched):
+            if it is None:
+                out.append(torch.empty((0,), dtype=torch.int64, device=boxes.device))
+            else:
+                out.append(_nms_finish(it[0][0], *counts[j]))
+                j += 1
+        return out
+
+    return finish if defer else finish()
 
 
 def _nms_rotated(dets, scores, iou_threshold):
