@@ -72,7 +72,7 @@ _SIGNATURES = {
     "d2amd_dense_select_workspace_bytes": (_sz, [_i, ctypes.POINTER(_i), _i, _i, _i]),
     "d2amd_dense_select_predictions": (_i, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i,
                                             ctypes.POINTER(_i), _i, _i, _f, _i, ctypes.POINTER(_f), _f, _vp, _vp, _vp,
-                                            _vp, _vp, _vp, _sz, _vp]),
+                                            _vp, _vp, _vp, _vp, _sz, _vp]),
     "d2amd_nms_workspace_bytes": (_sz, [_i64, _i64, _i]),
     "d2amd_nms": (_i, [_vp, _vp, _vp, _i64, _d, _i, _i64, _vp, _vp, _vp, _sz, _vp]),
     "d2amd_nms_batched": (_i, [_i, _vp, _vp, _vp, _vp, _d, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

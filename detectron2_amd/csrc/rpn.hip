@@ -107,7 +107,8 @@ __global__ __launch_bounds__(256) void dense_decode_kernel(DensePtrs D, const ui
                                                           const int* __restrict__ cnt, int N, int K, RpnLevels lv,
                                                           float wx, float wy, float ww, float wh, float scale_clamp,
                                                           float4* __restrict__ boxes, float* __restrict__ scores,
-                                                          int64_t* __restrict__ classes, uint8_t* __restrict__ valid) {
+                                                          int64_t* __restrict__ classes, uint8_t* __restrict__ valid,
+                                                          float* __restrict__ logits_out) {
   const int Ktot = lv.koff[lv.L];
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (long)N * Ktot) return;
@@ -122,6 +123,7 @@ __global__ __launch_bounds__(256) void dense_decode_kernel(DensePtrs D, const ui
     scores[t] = -__builtin_inff();
     classes[t] = 0;
     valid[t] = 0;
+    if (logits_out) logits_out[t] = -__builtin_inff();
     return;
   }
   const uint32_t e = sel[t];
@@ -139,7 +141,8 @@ __global__ __launch_bounds__(256) void dense_decode_kernel(DensePtrs D, const ui
   const float pcx = dx * widths + ctr_x, pcy = dy * heights + ctr_y;
   const float pw = expf(dw) * widths, ph = expf(dh) * heights;
   boxes[t] = make_float4(pcx - 0.5f * pw, pcy - 0.5f * ph, pcx + 0.5f * pw, pcy + 0.5f * ph);
-  scores[t] = 1.f / (1.f + expf(-x));  // the value the selection ranked
+  scores[t] = 1.f / (1.f + expf(-x));  // retinanet.py:267 `sigmoid_()`, applied to the selected rows only
+  if (logits_out) logits_out[t] = x;     // the value the selection ranked: an exp-independent NMS order
   classes[t] = c;
   valid[t] = 1;
 }
@@ -235,7 +238,7 @@ extern "C" int d2amd_rpn_select_proposals(const float* logits, const float* delt
     uint32_t* sel = (uint32_t*)workspace;
     int* cnt = (int*)((char*)workspace + off_cnt);
     D2_HIP_OK(hipMemsetAsync(flags_out, 0, sizeof(int), s));
-    int rc = topk_select(in, false, false, 0.f, sel, cnt, (char*)workspace + off_tk, workspace_bytes - off_tk, s);
+    int rc = topk_select(in, false, 0.f, sel, cnt, (char*)workspace + off_tk, workspace_bytes - off_tk, s);
     if (rc) return rc;
     const long nt = (long)N * k;
     hipLaunchKernelGGL(rpn_decode_kernel, dim3(cdiv(nt, 256)), dim3(256), 0, s, logits, (const float4*)deltas,
@@ -300,7 +303,8 @@ extern "C" int d2amd_dense_select_predictions(const float* const* logits, const 
                                               int num_classes, float score_thresh, int topk_candidates,
                                               const float* weights, float scale_clamp, float* boxes_out,
                                               float* scores_out, int64_t* classes_out, uint8_t* valid_out,
-                                              int* counts_out, void* workspace, size_t workspace_bytes, void* stream) {
+                                              int* counts_out, float* logits_out, void* workspace,
+                                              size_t workspace_bytes, void* stream) {
   TopkInput in; RpnLevels lv;
   int rc = dense_layout(N, level_anchors, L, num_classes, topk_candidates, in, lv);
   if (rc) return rc;
@@ -323,12 +327,12 @@ extern "C" int d2amd_dense_select_predictions(const float* const* logits, const 
   }
   hipStream_t s = (hipStream_t)stream;
   uint32_t* sel = (uint32_t*)workspace;
-  rc = topk_select(in, true, true, score_thresh, sel, counts_out, (char*)workspace + off_tk, workspace_bytes - off_tk, s);
+  rc = topk_select(in, true, logit_lower_bound(score_thresh), sel, counts_out, (char*)workspace + off_tk, workspace_bytes - off_tk, s);
   if (rc) return rc;
   const long nt = (long)N * k;
   hipLaunchKernelGGL(dense_decode_kernel, dim3(cdiv(nt, 256)), dim3(256), 0, s, D, sel, counts_out, N, num_classes, lv,
                      weights[0], weights[1], weights[2], weights[3], scale_clamp, (float4*)boxes_out, scores_out,
-                     classes_out, valid_out);
+                     classes_out, valid_out, logits_out);
   D2_LAUNCH_OK();
   return D2AMD_OK;
 }

@@ -19,13 +19,20 @@ struct TopkInput {
 
 size_t topk_workspace_bytes(const TopkInput& in);
 
-// For every segment (image, level): the k[l] best candidates, best first, ties towards the lower element index.
-//   sigmoid:  the score of an element is 1 / (1 + exp(-x)) of the stored value (fp32), else the value itself
-//   use_thr:  only elements whose score is > thr are candidates (a segment may then select fewer than k[l])
+// For every segment (image, level): the k[l] best candidates by stored value, best first, ties towards the lower
+// element index.
+//   use_thr:  only elements with value >= xmin are candidates (a segment may then select fewer than k[l]); a NaN
+//             xmin admits none.  Callers that threshold a monotone function of the value (sigmoid) pass the
+//             equivalent bound on the value itself: logit_lower_bound().
 // Outputs: sel [N][Ktot] element index inside its level (rows [koff[l], koff[l] + cnt) of a segment are valid),
 //          cnt [N][L] selected count per segment.  Nothing synchronises with the host.
-int topk_select(const TopkInput& in, bool sigmoid, bool use_thr, float thr, uint32_t* sel, int* cnt, void* ws,
-                size_t ws_bytes, hipStream_t s);
+int topk_select(const TopkInput& in, bool use_thr, float xmin, uint32_t* sel, int* cnt, void* ws, size_t ws_bytes,
+                hipStream_t s);
+
+// Smallest fp32 logit x whose sigmoid exceeds the fp32 threshold `thr` in exact arithmetic:
+// sigmoid(x) > thr  <=>  x > log(thr / (1 - thr)), evaluated once on the host in double.  thr >= 1: none (NaN);
+// thr < 0: all (-inf); thr == 0: every x whose fp32 sigmoid is not flushed to zero (exp(-x) finite in fp32).
+float logit_lower_bound(float thr);
 
 __device__ __forceinline__ uint32_t topk_desc_key(float s) {  // ascending key order = descending score; NaN first
   uint32_t u = __float_as_uint(s);

@@ -12,6 +12,8 @@
 //   5.   one compaction pass writes the <= k selected (key, index) pairs;
 //   6.   one workgroup per segment orders them in LDS (bitonic, 64-bit keys = score key : index).
 // Every pass reads 4 B per element (HBM bound); nothing synchronises with the host.
+#include <cmath>
+
 #include "topk.h"
 
 namespace d2amd {
@@ -37,22 +39,21 @@ static_assert(sizeof(SegState) == 64, "SegState layout");
 
 struct TkParams {
   TopkInput in;
-  int sigmoid, use_thr;
-  float thr, xlo;  // xlo: stored values below it cannot pass the threshold (saves the exp)
+  int use_thr;
+  float xmin;      // use_thr: an element is a candidate iff x >= xmin (NaN xmin: none is)
   int maxblk;      // workgroups per segment in the grid
   int tickets;     // 1: the last workgroup of a segment (atomic ticket) scans; 0: separate scan launches
   int reps;        // consecutive TK_CHUNK chunks per workgroup (keeps the workgroups of a segment <= ~256: every
                    // workgroup takes a ticket on ONE address per pass, and 3,000 returning atomics there cost 0.3 ms)
 };
 
+// The key is the order-preserving image of the STORED value.  Dense detectors store class logits and the reference
+// ranks sigmoid(logit): sigmoid is monotone, so ranking the logit gives the same order wherever the fp32 scores differ
+// and a defined one (higher logit, then lower index) inside a group of equal fp32 scores -- independent of any exp()
+// implementation.  The score threshold arrives as the equivalent bound on the stored value (logit_lower_bound()).
 __device__ __forceinline__ bool tk_key(const TkParams& P, float x, uint32_t& key) {
-  float s = x;
-  if (P.sigmoid) {
-    if (P.use_thr && x < P.xlo) return false;
-    s = 1.f / (1.f + expf(-x));
-  }
-  if (P.use_thr && !(s > P.thr)) return false;
-  key = topk_desc_key(s);
+  if (P.use_thr && !(x >= P.xmin)) return false;
+  key = topk_desc_key(x);
   return true;
 }
 
@@ -405,10 +406,20 @@ static TkWs tk_carve(const TopkInput& in, void* base) {
   return w;
 }
 
+float logit_lower_bound(float thr) {
+  if (thr != thr || thr >= 1.f) return __builtin_nanf("");
+  if (thr < 0.f) return -__builtin_inff();
+  if (thr == 0.f) return -88.72283f;  // largest -x with expf(-x) finite: below it the fp32 score is 1 / inf = 0
+  const double t = (double)thr, T = log(t / (1.0 - t));
+  float f = (float)T;  // nearest fp32 to T: the bound is f if f > T, else its successor
+  if (!((double)f > T)) f = nextafterf(f, __builtin_inff());
+  return f;
+}
+
 size_t topk_workspace_bytes(const TopkInput& in) { return tk_carve(in, nullptr).total + 256; }
 
-int topk_select(const TopkInput& in, bool sigmoid, bool use_thr, float thr, uint32_t* sel, int* cnt, void* ws,
-                size_t ws_bytes, hipStream_t s) {
+int topk_select(const TopkInput& in, bool use_thr, float xmin, uint32_t* sel, int* cnt, void* ws, size_t ws_bytes,
+                hipStream_t s) {
   D2_CHECK_ARG(in.L >= 1 && in.L <= TOPK_MAX_LEVELS && in.N >= 1, "topk_select: bad segment layout");
   const TkWs w = tk_carve(in, ws);
   if (ws == nullptr || ws_bytes < w.total) {
@@ -419,12 +430,7 @@ int topk_select(const TopkInput& in, bool sigmoid, bool use_thr, float thr, uint
   D2_CHECK_ARG((long)in.N * in.L <= 65535, "topk_select: too many segments");
   TkParams P{};
   P.in = in;
-  P.sigmoid = sigmoid; P.use_thr = use_thr; P.thr = thr;
-  P.xlo = -__builtin_inff();
-  if (sigmoid && use_thr) {
-    if (thr >= 1.f) P.xlo = __builtin_inff();
-    else if (thr > 0.f) P.xlo = logf(thr / (1.f - thr)) - 1e-2f;
-  }
+  P.use_thr = use_thr; P.xmin = xmin;
   P.maxblk = w.maxblk;
   P.reps = w.reps;
   P.tickets = w.tickets;

@@ -7,8 +7,11 @@ counterpart of `DenseDetector._decode_multi_level_predictions` (meta_arch/dense_
   (d2amd_dense_select_predictions: one call, no host sync -- the reference runs `sigmoid_` over all N x 16 M class
   logits, then per level and image `nonzero` [a sync] + `topk` + gathers) -> per-image, per-class NMS of all images in
   one call (batched_nms_images) -> the max_detections best per image.
-Scores equal the reference's up to the rounding of exp(); ties between equal scores resolve towards the lower
-flattened (anchor, class) index (torch.topk leaves that order unspecified)."""
+Ranking is by LOGIT (sigmoid is monotone): the reference's `topk` order wherever its fp32 scores differ, and a defined
+order -- higher logit, then lower flattened (anchor, class) index -- inside a group of equal fp32 scores, where
+torch.topk's is unspecified.  It does not depend on any exp() implementation; the reported scores are sigmoid(logit)
+of the selected rows and equal the reference's up to the rounding of exp().  The threshold `score > t`
+(dense_detector.py:207) is applied in its exact form `logit > log(t / (1 - t))` (double, fp32 t)."""
 import ctypes
 import math
 from typing import List
@@ -46,10 +49,12 @@ def _ptrs(tensors):
 
 def dense_select_predictions(anchors: List[torch.Tensor], pred_logits: List[torch.Tensor],
                              pred_anchor_deltas: List[torch.Tensor], score_thresh: float, topk_candidates: int,
-                             weights=(1.0, 1.0, 1.0, 1.0), scale_clamp: float = _DEFAULT_SCALE_CLAMP):
+                             weights=(1.0, 1.0, 1.0, 1.0), scale_clamp: float = _DEFAULT_SCALE_CLAMP,
+                             return_logits: bool = False):
     """anchors[l] [A_l,4]; pred_logits[l] [N,A_l,K] class LOGITS (not probabilities); pred_anchor_deltas[l] [N,A_l,4].
     Returns boxes [N,Ktot,4], scores [N,Ktot], classes [N,Ktot] int64, valid [N,Ktot] bool, counts [N,L] int32, all on
-    the device; rows of a level are score-descending, rows past its count are zero boxes with score -inf."""
+    the device; rows of a level are best first, rows past its count are zero boxes with score -inf.  With
+    return_logits, a sixth tensor [N,Ktot]: the selected logits (the ranking key; -inf past the count)."""
     _C.require_gpu(*anchors, *pred_logits, *pred_anchor_deltas, op="dense_select_predictions")
     nl = len(anchors)
     assert nl == len(pred_logits) == len(pred_anchor_deltas) and nl >= 1
@@ -67,8 +72,10 @@ def dense_select_predictions(anchors: List[torch.Tensor], pred_logits: List[torc
     classes = torch.empty((n, ktot), dtype=torch.int64, device=dev)
     valid = torch.empty((n, ktot), dtype=torch.uint8, device=dev)
     counts = torch.zeros((n, nl), dtype=torch.int32, device=dev)
+    sel_logits = torch.empty((n, ktot), dtype=torch.float32, device=dev) if return_logits else None
     if n == 0 or ktot == 0:
-        return boxes, scores, classes, valid.bool(), counts
+        out = (boxes, scores, classes, valid.bool(), counts)
+        return out + (sel_logits,) if return_logits else out
     L = _C.lib()
     lv = (ctypes.c_int * nl)(*sizes)
     wts = (ctypes.c_float * 4)(*[float(v) for v in weights])
@@ -78,8 +85,10 @@ def dense_select_predictions(anchors: List[torch.Tensor], pred_logits: List[torc
         _C.check(L.d2amd_dense_select_predictions(_ptrs(lg), _ptrs(dl), _ptrs(an), n, lv, nl, k_cls, float(score_thresh),
                                                   int(topk_candidates), wts, float(scale_clamp), _C.ptr(boxes),
                                                   _C.ptr(scores), _C.ptr(classes), _C.ptr(valid), _C.ptr(counts),
-                                                  _C.ptr(ws), ws_bytes, _C.stream()))
-    return boxes, scores, classes, valid.bool(), counts
+                                                  _C.ptr(sel_logits) if return_logits else None, _C.ptr(ws),
+                                                  ws_bytes, _C.stream()))
+    out = (boxes, scores, classes, valid.bool(), counts)
+    return out + (sel_logits,) if return_logits else out
 
 
 def dense_detector_inference_fused(anchors, pred_logits, pred_anchor_deltas, image_sizes, score_thresh: float,
@@ -87,11 +96,12 @@ def dense_detector_inference_fused(anchors, pred_logits, pred_anchor_deltas, ima
                                    weights=(1.0, 1.0, 1.0, 1.0), scale_clamp: float = _DEFAULT_SCALE_CLAMP):
     """-> list of N `Detections` (pred_boxes: Boxes, scores, pred_classes), score-descending, at most
     max_detections each (retinanet.py:297-309).  Two host syncs per batch (NMS counts, valid counts)."""
-    boxes, scores, classes, valid, _ = dense_select_predictions(anchors, pred_logits, pred_anchor_deltas, score_thresh,
-                                                                topk_candidates, weights, scale_clamp)
+    boxes, scores, classes, valid, _, rank = dense_select_predictions(
+        anchors, pred_logits, pred_anchor_deltas, score_thresh, topk_candidates, weights, scale_clamp, return_logits=True)
     n = boxes.shape[0]
-    # rows past a level's count are zero-area boxes with score -inf: they neither suppress nor get suppressed, sort last
-    keeps = batched_nms_images([(boxes[i], scores[i], classes[i]) for i in range(n)], nms_thresh)  # sync 1
+    # rows past a level's count are zero-area boxes with score -inf: they neither suppress nor get suppressed, sort last.
+    # The NMS ranks by the selected LOGITS (same order as the scores, but independent of the exp() rounding)
+    keeps = batched_nms_images([(boxes[i], rank[i], classes[i]) for i in range(n)], nms_thresh)  # sync 1
     keeps = [k[:max_detections] for k in keeps]
     counts = torch.stack([valid[i][k].sum() for i, k in enumerate(keeps)]).tolist() if n else []  # sync 2
     out = []

@@ -190,17 +190,22 @@ int d2amd_rpn_select_proposals(const float* logits, const float* deltas, const f
  * Per (image, level): the candidates are the (anchor, class) pairs with sigmoid(logit) > score_thresh; the
  * min(topk_candidates, #candidates) best are selected by a segmented radix select (no sort of the A_l*K scores, no
  * host sync; ties: lower flattened index a*K + c first; topk_candidates <= 16384), decoded WITHOUT clipping.
- * Outputs, [N, Ktot] row-major, Ktot = sum_l min(A_l*K, topk_candidates), levels in order, scores descending inside
- * a level: boxes [N,Ktot,4], scores [N,Ktot] (= sigmoid(logit)), classes [N,Ktot] int64, valid [N,Ktot] uint8 (rows
- * past a segment's count: zero box, score -inf, class 0, valid 0), counts [N,L] int32. */
+ * Outputs, [N, Ktot] row-major, Ktot = sum_l min(A_l*K, topk_candidates), levels in order, best first inside a
+ * level: boxes [N,Ktot,4], scores [N,Ktot] (= sigmoid(logit)), classes [N,Ktot] int64, valid [N,Ktot] uint8 (rows
+ * past a segment's count: zero box, score -inf, class 0, valid 0), counts [N,L] int32, logits_out [N,Ktot] or NULL
+ * (the selected logits: an exp()-independent ranking key for the NMS that follows; -inf past the count).
+ * Ranking: by LOGIT descending, equal logits towards the lower flattened (anchor, class) index.  sigmoid is
+ * monotone, so this is the reference's `topk` order wherever its fp32 scores differ, and a defined order inside a
+ * group of equal fp32 scores (torch.topk leaves that unspecified).  Candidates: logit > log(t / (1 - t)) for the fp32
+ * threshold t, evaluated in double (the exact-arithmetic form of `sigmoid(logit) > t`, dense_detector.py:207). */
 size_t d2amd_dense_select_workspace_bytes(int N, const int* level_anchors, int L, int num_classes,
                                           int topk_candidates);
 int d2amd_dense_select_predictions(const float* const* logits, const float* const* deltas,
                                    const float* const* anchors, int N, const int* level_anchors, int L,
                                    int num_classes, float score_thresh, int topk_candidates, const float* weights,
                                    float scale_clamp, float* boxes_out, float* scores_out, int64_t* classes_out,
-                                   uint8_t* valid_out, int* counts_out, void* workspace, size_t workspace_bytes,
-                                   void* stream);
+                                   uint8_t* valid_out, int* counts_out, float* logits_out, void* workspace,
+                                   size_t workspace_bytes, void* stream);
 
 /* ---- NMS.  One entry serves torchvision.ops.nms / batched_nms (detectron2/layers/nms.py:6,
  * 11-22) and torch.ops.detectron2.nms_rotated / batched_nms_rotated (vision.cpp:116,

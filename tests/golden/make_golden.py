@@ -244,8 +244,35 @@ def dense_detector_golden():
         d[f"boxes_img{i}"] = inst.pred_boxes.tensor.numpy()
         d[f"scores_img{i}"] = inst.scores.numpy()
         d[f"classes_img{i}"] = inst.pred_classes.numpy()
+    # second case ("t_" keys): HEAVY TIES.  Quantised logits (many equal values), a block of large logits whose fp32
+    # sigmoid saturates to the same score although the logits differ, +0 / -0, and a level where the k-th score is
+    # tied.  torch.topk's order inside a group of equal scores is unspecified: the consumer
+    # (tests/test_oracle_golden.py) requires the same selection outside the tied k-th group and an order that differs
+    # only inside groups of equal fp32 score.
+    rng = np.random.default_rng(77)
+    sizes_t, K_t, thr_t, topk_t = [400, 60, 9], 4, 0.2, 120
+    d["t_score_thresh"], d["t_topk"] = np.array(thr_t), np.array(topk_t)
+    for li, a_l in enumerate(sizes_t):
+        c = rng.uniform(0, [320, 256], (a_l, 2))
+        wh_ = 32.0 * 2 ** li * np.exp(rng.uniform(-0.4, 0.4, (a_l, 2)))
+        d[f"t_anchors{li}"] = np.concatenate([c - wh_ / 2, c + wh_ / 2], 1).astype(np.float32)
+        lg = (np.round(rng.standard_normal((N, a_l, K_t)) * 4) / 2).astype(np.float32)  # steps of 0.5
+        lg[:, : a_l // 8, 0] = (17.5 + rng.uniform(0, 8, (N, a_l // 8))).astype(np.float32)  # sigmoid -> 1.0 or 1 - 2^-24
+        lg[:, a_l // 8, 1], lg[:, a_l // 8 + 1, 1] = 0.0, -0.0
+        d[f"t_logits{li}"] = lg
+        d[f"t_deltas{li}"] = (rng.standard_normal((N, a_l, 4)) * [0.3, 0.3, 0.5, 0.5]).astype(np.float32)
+    for i in range(N):
+        scores = [torch.from_numpy(d[f"t_logits{l}"][i]).clone().sigmoid_() for l in range(3)]
+        inst = dd._decode_multi_level_predictions(
+            [Boxes(torch.from_numpy(d[f"t_anchors{l}"])) for l in range(3)], scores,
+            [torch.from_numpy(d[f"t_deltas{l}"][i]) for l in range(3)], thr_t, topk_t, (256, 320))
+        d[f"t_boxes_img{i}"] = inst.pred_boxes.tensor.numpy()
+        d[f"t_scores_img{i}"] = inst.scores.numpy()
+        d[f"t_classes_img{i}"] = inst.pred_classes.numpy()
+        d[f"t_counts_img{i}"] = np.array([min(topk_t, int((sc > thr_t).sum())) for sc in scores])
     np.savez_compressed(os.path.join(OUT, "dense_detector.npz"), **d)
-    print("dense_detector.npz written", [len(d[f"scores_img{i}"]) for i in range(N)])
+    print("dense_detector.npz written", [len(d[f"scores_img{i}"]) for i in range(N)],
+          [len(d[f"t_scores_img{i}"]) for i in range(N)])
 
 
 if __name__ == "__main__":

@@ -3,6 +3,8 @@
 Oracle: the level-assignment restatement (tests/test_tile_gather_math.py pins it against torch on
 the CPU) + the oracle's per-level ROIAlign forward / backward, i.e. exactly the reference's
 ROIPooler.forward structure (detectron2/modeling/poolers.py:247-263) evaluated on the CPU."""
+import zlib
+
 import numpy as np
 import pytest
 import torch
@@ -205,7 +207,7 @@ def test_fused_pooler_staged_backward_paths(case):
     """Paths of the LDS-staged tile gather that the BASELINE shapes do not reach: tiles with more than 64 ROIs
     (in-kernel scan of > 512 records in two passes), a second, partial channel slab, 32 bins per axis (one list entry
     per weight round), windows of more than 32 bins (several items per ROI)."""
-    rng = np.random.default_rng(abs(hash(case)) % 1000)
+    rng = np.random.default_rng(zlib.crc32(case.encode()) % 1000)  # fixed per case (hash() changes per process)
     dtype, tol = torch.float32, 1e-4
     if case == "clustered_overflow":
         n_img, C, out, sr, per = 1, 136, 7, 0, 700   # fp32: 128 channels per slab -> 2 slabs, the second partial

@@ -376,8 +376,8 @@ def test_mask_head_restatement_matches_reference_functions(golden_dir):
 
 def test_dense_detector_restatement_matches_reference_functions(golden_dir):
     """oracle/dense_detector.py vs the reference's own DenseDetector._decode_multi_level_predictions run on CPU
-    (tests/golden/dense_detector.npz, oracle/ref.py::py_dense_detector): same (anchor, class) selection in the same
-    order, scores and decoded boxes to the rounding of exp()."""
+    (tests/golden/dense_detector.npz, oracle/ref.py::py_dense_detector).  Case 1 (no equal scores among the
+    candidates): same (anchor, class) selection in the same order, scores and decoded boxes to the rounding of exp()."""
     from oracle import dense_detector as odd
 
     g = np.load(os.path.join(golden_dir, "dense_detector.npz"))
@@ -389,3 +389,41 @@ def test_dense_detector_restatement_matches_reference_functions(golden_dir):
         assert np.array_equal(c, g[f"classes_img{i}"])
         np.testing.assert_allclose(s, g[f"scores_img{i}"], rtol=2e-6, atol=0)
         np.testing.assert_allclose(b, g[f"boxes_img{i}"], rtol=2e-6, atol=1e-4)
+
+
+def test_dense_detector_logit_ranking_refines_reference_topk(golden_dir):
+    """Case 2 ("t_" keys): heavy ties -- quantised logits, saturated sigmoids (different logits, one fp32 score),
+    +0 / -0, tied k-th scores.  The logit ranking must select what the reference's `topk` selected and order it like
+    the reference, except INSIDE groups of equal fp32 score (unspecified for torch.topk)."""
+    from _dense_compare import assert_same_selection_up_to_ties
+    from oracle import dense_detector as odd
+
+    g = np.load(os.path.join(golden_dir, "dense_detector.npz"))
+    anchors = [g[f"t_anchors{l}"] for l in range(3)]
+    thr, topk = float(g["t_score_thresh"]), int(g["t_topk"])
+    tot_id = tot_tail = tot_moved = 0
+    for i in range(2):
+        got = odd.decode_multi_level(anchors, [g[f"t_logits{l}"][i] for l in range(3)],
+                                     [g[f"t_deltas{l}"][i] for l in range(3)], thr, topk, tuple(g["weights"]))
+        ref = (g[f"t_boxes_img{i}"], g[f"t_scores_img{i}"], g[f"t_classes_img{i}"])
+        n_id, n_tail, n_moved = assert_same_selection_up_to_ties(got, ref, g[f"t_counts_img{i}"], topk)
+        tot_id, tot_tail, tot_moved = tot_id + n_id, tot_tail + n_tail, tot_moved + n_moved
+    # the fixture really exercises ties (rows sit at other positions than in the reference) and most rows are pinned
+    assert tot_moved > 20 and tot_id > 4 * tot_tail, (tot_id, tot_tail, tot_moved)
+
+
+def test_logit_lower_bound_is_the_exact_threshold():
+    """`sigmoid(x) > t` in exact arithmetic <=> x > log(t / (1 - t)) <=> x >= logit_lower_bound(t): the fp32 bound and
+    its predecessor straddle the logit of t evaluated in extended precision; plus the special thresholds."""
+    from oracle import dense_detector as odd
+
+    for t in [0.05, 0.3, 0.5, 0.2, 1e-6, 0.999999, 0.9]:
+        t32 = np.float32(t)
+        b = odd.logit_lower_bound(t)
+        below = np.nextafter(b, np.float32(-np.inf), dtype=np.float32)
+        t_ld = np.longdouble(t32)
+        logit_t = np.log(t_ld / (np.longdouble(1) - t_ld))
+        assert np.longdouble(b) > logit_t and not np.longdouble(below) > logit_t, t
+    assert np.isnan(odd.logit_lower_bound(1.0)) and np.isnan(odd.logit_lower_bound(1.5))
+    assert odd.logit_lower_bound(-0.1) == -np.inf
+    assert odd.sigmoid32(odd.logit_lower_bound(0.0)) > 0
