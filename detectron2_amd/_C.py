@@ -45,6 +45,7 @@ _SIGNATURES = {
     "d2amd_hip_version": (ctypes.c_char_p, []),
     "d2amd_last_error": (ctypes.c_char_p, []),
     "d2amd_timing_enable": (None, [_i]),
+    "d2amd_timing_select": (None, [ctypes.c_char_p]),
     "d2amd_timing_read": (_i, [ctypes.c_char_p, ctypes.POINTER(_d), ctypes.POINTER(_i)]),
     "d2amd_roi_align_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _vp]),
     "d2amd_roi_align_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _vp, _sz, _vp]),
@@ -79,6 +80,7 @@ _SIGNATURES = {
     "d2amd_nms_batched_max_boxes": (_i, []),
     "d2amd_paste_masks": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _i, _vp]),
     "d2amd_bitmask_crop_and_resize": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "d2amd_bitmask_crop_and_resize_indexed": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "d2amd_mask_rcnn_inference": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "d2amd_mask_rcnn_loss_workspace_bytes": (_sz, [_i]),
     "d2amd_mask_rcnn_loss_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),

@@ -22,27 +22,29 @@ void set_error(const char* fmt, ...) {
 // HIP events recorded on the LAUNCH stream right before / after selected kernels (the side stream of the
 // tile-gather backward is not visible to events a caller records on its own stream).  Off by default.
 namespace d2amd {
-struct TimingSlot { const char* name; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; };
-static TimingSlot g_slots[8];
-static int g_nslots = 0;
-static int g_timing_mask = 0;  // bit i: time the i-th registered kernel name (registration order below)
+struct TimingSlot { std::string name; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; };
+static std::vector<TimingSlot> g_slots;
+static std::vector<std::string> g_selected;  // d2amd_timing_select: kernel names to time
+static int g_timing_mask = 0;  // d2amd_timing_enable: bit i times the pooler tile-gather launches below
 static const char* const g_timing_names[] = {"pool_bwd_fine_r7", "pool_bwd_coarse_r7", "pool_bwd_fine_r14",
                                               "pool_bwd_coarse_r14", "pool_bwd_staged_r7", "pool_bwd_staged_r14"};
 static const int g_timing_bits[] = {0, 1, 2, 3, 0, 2};  // the single staged launch answers to the "fine" bits
-static TimingSlot* timing_slot(const char* name) {
-  for (int i = 0; i < g_nslots; i++)
-    if (!strcmp(g_slots[i].name, name)) return &g_slots[i];
-  if (g_nslots >= 8) return nullptr;
-  g_slots[g_nslots].name = name;
-  return &g_slots[g_nslots++];
+static TimingSlot* timing_slot(const char* name, bool create) {
+  for (auto& t : g_slots)
+    if (t.name == name) return &t;
+  if (!create || g_slots.size() >= 64) return nullptr;
+  g_slots.reserve(64);  // pointers into the vector stay valid
+  g_slots.push_back(TimingSlot{name, {}});
+  return &g_slots.back();
 }
 bool timing_begin(const char* name, hipStream_t s) {
-  if (!g_timing_mask) return false;
-  int bit = -1;
-  for (int i = 0; i < 6; i++)
-    if (!strcmp(g_timing_names[i], name)) bit = g_timing_bits[i];
-  if (bit < 0 || !(g_timing_mask & (1 << bit))) return false;
-  TimingSlot* t = timing_slot(name);
+  if (!g_timing_mask && g_selected.empty()) return false;
+  bool on = false;
+  for (const auto& n : g_selected) on = on || n == name;
+  for (int i = 0; i < 6 && !on; i++)
+    if (!strcmp(g_timing_names[i], name)) on = (g_timing_mask & (1 << g_timing_bits[i])) != 0;
+  if (!on) return false;
+  TimingSlot* t = timing_slot(name, true);
   if (!t || t->ev.size() >= 65536) return false;
   hipEvent_t a, b;
   if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return false;
@@ -51,20 +53,39 @@ bool timing_begin(const char* name, hipStream_t s) {
   return true;
 }
 void timing_end(const char* name, hipStream_t s) {
-  TimingSlot* t = timing_slot(name);
+  TimingSlot* t = timing_slot(name, false);
   if (t && !t->ev.empty()) (void)hipEventRecord(t->ev.back().second, s);
+}
+static void timing_clear() {
+  for (auto& t : g_slots) {
+    for (auto& p : t.ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    t.ev.clear();
+  }
 }
 }  // namespace d2amd
 
 extern "C" {
 
 void d2amd_timing_enable(int on) {
+  d2amd::timing_clear();
+  d2amd::g_timing_mask = on;
+}
+
+void d2amd_timing_select(const char* names_csv) {
   using namespace d2amd;
-  for (int i = 0; i < g_nslots; i++) {
-    for (auto& p : g_slots[i].ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-    g_slots[i].ev.clear();
+  timing_clear();
+  g_selected.clear();
+  if (!names_csv) return;
+  std::string cur;
+  for (const char* p = names_csv;; p++) {
+    if (*p == ',' || *p == 0) {
+      if (!cur.empty()) g_selected.push_back(cur);
+      cur.clear();
+      if (*p == 0) break;
+    } else if (*p != ' ') {
+      cur.push_back(*p);
+    }
   }
-  g_timing_mask = on;
 }
 
 int d2amd_timing_read(const char* kernel, double* total_ms, int* launches) {
@@ -72,9 +93,9 @@ int d2amd_timing_read(const char* kernel, double* total_ms, int* launches) {
   D2_CHECK_ARG(kernel && total_ms && launches, "timing_read: null pointer");
   *total_ms = 0.0;
   *launches = 0;
-  for (int i = 0; i < g_nslots; i++) {
-    if (strcmp(g_slots[i].name, kernel)) continue;
-    for (auto& p : g_slots[i].ev) {
+  for (auto& t : g_slots) {
+    if (t.name != kernel) continue;
+    for (auto& p : t.ev) {
       float ms = 0.f;
       D2_HIP_OK(hipEventSynchronize(p.second));
       D2_HIP_OK(hipEventElapsedTime(&ms, p.first, p.second));

@@ -715,6 +715,7 @@ int dcn_tc_forward(const DcnShape& s, const TcPlan& pl, const void* x_nhwc, cons
   int rc = D2AMD_EUNSUPPORTED;
   const int key = pl.wave ? -(pl.MT * 10 + pl.NKS) : pl.MT * 100 + pl.NWM * 10 + pl.NWN;
   const int grid = (a.total + 7) / 8 * 8;
+  const bool timed = timing_begin("dcn_fwd", st);
   switch (key) {
     case -42: hipLaunchKernelGGL((dcn_fwd_wave_kernel<T, 4, 2>), dim3(grid), dim3(64), 0, st, s, a); rc = 0; break;
     case -22: hipLaunchKernelGGL((dcn_fwd_wave_kernel<T, 2, 2>), dim3(grid), dim3(64), 0, st, s, a); rc = 0; break;
@@ -729,6 +730,7 @@ int dcn_tc_forward(const DcnShape& s, const TcPlan& pl, const void* x_nhwc, cons
     case 211: rc = tc_launch_fwd<T, 2, 1, 1>(s, pl, a, st); break;
     default: set_error("deform_conv: no kernel for tile config MT=%d NWM=%d NWN=%d", pl.MT, pl.NWM, pl.NWN);
   }
+  if (timed) timing_end("dcn_fwd", st);
   if (rc) return rc;
   D2_LAUNCH_OK();
   if (pl.ksplit > 1) {
@@ -1385,7 +1387,9 @@ int dcn_tc_backward_data(const DcnShape& s, const TcBwPlan& pl, const void* x_nh
     auto kern = dcn_bwd_data_patch_kernel<T>;
     if (pl.lds_patch > 40 * 1024)
       D2_HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_patch));
+    const bool timed = timing_begin("dcn_bwd_data", st);
     hipLaunchKernelGGL(kern, dim3((a.total + 7) / 8 * 8), dim3(256), pl.lds_patch, st, s, a);
+    if (timed) timing_end("dcn_bwd_data", st);
     D2_LAUNCH_OK();
     return D2AMD_OK;
   }
@@ -1402,7 +1406,9 @@ int dcn_tc_backward_data(const DcnShape& s, const TcBwPlan& pl, const void* x_nh
   D2_CHECK_ARG(total < (1l << 30), "deform_conv: too many tiles");
   a.total = (int)total;
   const int grid = (a.total + 7) / 8 * 8;
+  const bool timed = timing_begin("dcn_bwd_data", st);
   hipLaunchKernelGGL((dcn_bwd_data_tc_kernel<T>), dim3(grid), dim3(256), pl.lds, st, s, a);
+  if (timed) timing_end("dcn_bwd_data", st);
   D2_LAUNCH_OK();
   return D2AMD_OK;
 }
@@ -1663,6 +1669,7 @@ int dcn_tc_backward_weight(const DcnShape& s, const TcBwwPlan& pl, const void* x
   a.total = (int)(waves / 4);
   const int grid = (a.total + 7) / 8 * 8;
   const char* ab = getenv("D2AMD_DCN_ABLATE_BWW");  // profiling only
+  const bool timed = timing_begin("dcn_bwd_weight", st);
   switch (ab ? atoi(ab) : 0) {
 #ifdef D2AMD_DCN_ABLATION_BUILD
     case 1: hipLaunchKernelGGL((dcn_bwd_weight_tc_kernel<T, 1>), dim3(grid), dim3(256), 0, st, s, a); break;
@@ -1677,6 +1684,7 @@ int dcn_tc_backward_weight(const DcnShape& s, const TcBwwPlan& pl, const void* x
 #endif
     default: hipLaunchKernelGGL((dcn_bwd_weight_tc_kernel<T, 0>), dim3(grid), dim3(256), 0, st, s, a);
   }
+  if (timed) timing_end("dcn_bwd_weight", st);
   D2_LAUNCH_OK();
   return D2AMD_OK;
 }

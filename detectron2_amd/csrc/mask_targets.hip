@@ -29,8 +29,10 @@ __device__ __forceinline__ float crop_sample(const uint8_t* __restrict__ m, int 
 }
 
 __global__ __launch_bounds__(64) void bitmask_crop_kernel(const uint8_t* __restrict__ masks,
-                                                         const float* __restrict__ boxes, int G, int H, int W, int M,
-                                                         uint8_t* __restrict__ out) {
+                                                         const float* __restrict__ boxes,
+                                                         const int64_t* __restrict__ mask_index, int n_masks, int G,
+                                                         int H, int W, int M, uint8_t* __restrict__ out,
+                                                         int* __restrict__ status) {
   const int g = blockIdx.y;
   const int bin = blockIdx.x * 64 + threadIdx.x;
   if (bin >= M * M) return;
@@ -43,7 +45,18 @@ __global__ __launch_bounds__(64) void bitmask_crop_kernel(const uint8_t* __restr
   const float bin_size_h = roi_height / (float)M, bin_size_w = roi_width / (float)M;
   const int grid_h = (int)ceilf(roi_height / (float)M), grid_w = (int)ceilf(roi_width / (float)M);
   const float count = (float)max(grid_h * grid_w, 1);
-  const uint8_t* m = masks + (long)g * H * W;
+  // box g crops mask mask_index[g] (the matched ground truth of a sampled proposal: roi_heads.py:280-291 indexes
+  // gt_masks[sampled_targets], a full-resolution copy per proposal for BitMasks) or mask g
+  long mi = g;
+  if (mask_index) {
+    mi = mask_index[g];
+    if (mi < 0 || mi >= n_masks) {  // torch indexing raises IndexError: flag it, write zeros
+      if (bin == 0 && status) atomicOr(status, 1);
+      out[(long)g * M * M + bin] = 0;
+      return;
+    }
+  }
+  const uint8_t* m = masks + mi * H * W;
   float v = 0.f;
   for (int iy = 0; iy < grid_h; iy++) {
     const float yy = roi_start_h + (float)ph * bin_size_h + ((float)iy + .5f) * bin_size_h / (float)grid_h;
@@ -60,14 +73,27 @@ __global__ __launch_bounds__(64) void bitmask_crop_kernel(const uint8_t* __restr
 
 using namespace d2amd;
 
-extern "C" int d2amd_bitmask_crop_and_resize(const uint8_t* masks, const float* boxes, int G, int H, int W,
-                                             int mask_size, uint8_t* out, void* stream) {
-  D2_CHECK_ARG(G >= 0 && H >= 0 && W >= 0 && mask_size > 0, "bitmask_crop_and_resize: bad shape");
+static int crop_launch(const uint8_t* masks, const float* boxes, const int64_t* mask_index, int n_masks, int G, int H,
+                       int W, int mask_size, uint8_t* out, int* status, void* stream) {
+  D2_CHECK_ARG(G >= 0 && H >= 0 && W >= 0 && mask_size > 0 && n_masks >= 0, "bitmask_crop_and_resize: bad shape");
   if (G == 0) return D2AMD_OK;
   D2_CHECK_ARG(H > 0 && W > 0 && masks && boxes && out, "bitmask_crop_and_resize: null pointer / empty mask");
-  D2_CHECK_ARG(G <= 65535, "bitmask_crop_and_resize: too many masks (%d)", G);
+  D2_CHECK_ARG(G <= 65535, "bitmask_crop_and_resize: too many boxes (%d)", G);
   dim3 grid(cdiv((long)mask_size * mask_size, 64), G);
-  hipLaunchKernelGGL(bitmask_crop_kernel, grid, dim3(64), 0, (hipStream_t)stream, masks, boxes, G, H, W, mask_size, out);
+  hipLaunchKernelGGL(bitmask_crop_kernel, grid, dim3(64), 0, (hipStream_t)stream, masks, boxes, mask_index, n_masks, G, H,
+                     W, mask_size, out, status);
   D2_LAUNCH_OK();
   return D2AMD_OK;
+}
+
+extern "C" int d2amd_bitmask_crop_and_resize(const uint8_t* masks, const float* boxes, int G, int H, int W,
+                                             int mask_size, uint8_t* out, void* stream) {
+  return crop_launch(masks, boxes, nullptr, G, G, H, W, mask_size, out, nullptr, stream);
+}
+
+extern "C" int d2amd_bitmask_crop_and_resize_indexed(const uint8_t* masks, int n_masks, const float* boxes,
+                                                     const int64_t* mask_index, int n_boxes, int H, int W,
+                                                     int mask_size, uint8_t* out, int* status, void* stream) {
+  D2_CHECK_ARG(n_boxes == 0 || mask_index, "bitmask_crop_and_resize_indexed: null index");
+  return crop_launch(masks, boxes, mask_index, n_masks, n_boxes, H, W, mask_size, out, status, stream);
 }

@@ -815,6 +815,7 @@ static int nms_mask_reduce(NmsBatch& B, int rotated, bool any_cls, hipStream_t s
     wcap_max = std::max(wcap_max, B.img[k].wcap);
   }
   const dim3 mgrid(nb_max, wcap_max, B.count);
+  const bool timed_mask = timing_begin("nms_mask", s);
   if (rotated) {
     hipLaunchKernelGGL(nms_mask_rot_kernel, mgrid, dim3(64), 0, s, B);
   } else {
@@ -825,6 +826,7 @@ static int nms_mask_reduce(NmsBatch& B, int rotated, bool any_cls, hipStream_t s
     else if (m.tie_up) hipLaunchKernelGGL((nms_mask_kernel<true, true>), mgrid, dim3(64), 0, s, B);
     else hipLaunchKernelGGL((nms_mask_kernel<true, false>), mgrid, dim3(64), 0, s, B);
   }
+  if (timed_mask) timing_end("nms_mask", s);
   D2_LAUNCH_OK();
   const int rgrid = any_cls ? 512 : 1;
   const char* red_stamps = getenv("D2AMD_NMS_STAMPS");  // profiling only: per-block stamps of segment 0 of image 0
@@ -833,7 +835,9 @@ static int nms_mask_reduce(NmsBatch& B, int rotated, bool any_cls, hipStream_t s
     D2_HIP_OK(hipMalloc(&B.dbg, 256 * 8));
     D2_HIP_OK(hipMemsetAsync(B.dbg, 0, 256 * 8, s));
   }
+  const bool timed_red = timing_begin("nms_reduce", s);
   hipLaunchKernelGGL(nms_reduce_kernel, dim3(rgrid, 1, B.count), dim3(RED_THREADS), (size_t)wcap_max * 8, s, B);
+  if (timed_red) timing_end("nms_reduce", s);
   D2_LAUNCH_OK();
   if (red_stamps) {
     u64 h[256];

@@ -1641,6 +1641,8 @@ static int pool_fwd_impl(const d2amd_pooler_params* p, const void* const* inputs
       D2_HIP_OK(hipMalloc(&Lf.wgstamps, (size_t)nwg * 5 * 8));
       D2_HIP_OK(hipMemsetAsync(Lf.wgstamps, 0, (size_t)nwg * 5 * 8, s));
     }
+    const char* tname = p->pooled_h <= 7 ? "pool_fwd_r7" : "pool_fwd_r14";
+    const bool timed = timing_begin(tname, s);
     if (vec && nthr == 1024)
       hipLaunchKernelGGL((pool_fwd_nhwc_kernel<T, VEC, 1024>), grid, dim3(1024), 0, s, Lf, rois, (T*)output, nsplit);
     else if (vec && nthr == 512)
@@ -1649,6 +1651,7 @@ static int pool_fwd_impl(const d2amd_pooler_params* p, const void* const* inputs
       hipLaunchKernelGGL((pool_fwd_nhwc_kernel<T, VEC, 256>), grid, dim3(256), 0, s, Lf, rois, (T*)output, nsplit);
     else
       hipLaunchKernelGGL((pool_fwd_nhwc_kernel<T, 1, 256>), grid, dim3(256), 0, s, Lf, rois, (T*)output, nsplit);
+    if (timed) timing_end(tname, s);
     if (stamp_path) {
       D2_HIP_OK(hipStreamSynchronize(s));
       unsigned long long* h = (unsigned long long*)malloc((size_t)nwg * 5 * 8);

@@ -46,3 +46,25 @@ class BitMasks:
                 _C.check(_C.lib().d2amd_bitmask_crop_and_resize(_C.ptr(m), _C.ptr(b), g, h, w, int(mask_size),
                                                                 _C.ptr(out), _C.stream()))
         return out.view(torch.bool)
+
+    def crop_and_resize_indexed(self, boxes: torch.Tensor, mask_index: torch.Tensor, mask_size: int,
+                                status: torch.Tensor = None) -> torch.Tensor:
+        """`self[mask_index].crop_and_resize(boxes, mask_size)` without the (len(boxes), H, W) indexed copy: box i
+        crops mask mask_index[i].  This is what Mask R-CNN training does per image with the matched ground truth
+        of every sampled proposal (roi_heads.py:280-291 then mask_head.py:65-67).  An index outside
+        [0, len(self)) sets bit 0 of `status` (int32[1] on the device, optional; read it where a sync is due)."""
+        assert len(boxes) == len(mask_index), "{} != {}".format(len(boxes), len(mask_index))
+        _C.require_gpu(self.tensor, op="BitMasks.crop_and_resize_indexed")
+        m = self.tensor.contiguous().view(torch.uint8)
+        b = boxes.detach().to(device=m.device, dtype=torch.float32).contiguous()
+        idx = mask_index.detach().to(device=m.device, dtype=torch.int64).contiguous()
+        g, h, w = m.shape
+        n = b.shape[0]
+        out = torch.empty((n, mask_size, mask_size), dtype=torch.uint8, device=m.device)
+        if n:
+            assert g > 0, "indexing an empty BitMasks"
+            with _C.on_device(m.device):
+                _C.check(_C.lib().d2amd_bitmask_crop_and_resize_indexed(_C.ptr(m), g, _C.ptr(b), _C.ptr(idx), n, h, w,
+                                                                        int(mask_size), _C.ptr(out), _C.ptr(status),
+                                                                        _C.stream()))
+        return out.view(torch.bool)

@@ -44,12 +44,15 @@ const char* d2amd_compiler_version(void); /* "clang x.y.z" like get_compiler_ver
 const char* d2amd_hip_version(void);      /* "HIP x.y" like get_cuda_version() under WITH_HIP */
 const char* d2amd_last_error(void);       /* last error message of this thread (host) */
 
-/* ---- kernel timing aid (measurement only).  When enabled, HIP events are recorded on the LAUNCH stream right
- * before / after the tile-gather backward kernels ("pool_bwd_fine_r7", "pool_bwd_coarse_r7", "..._r14": fine /
- * coarse FPN levels, pooled size <= 7 / larger); the coarse launch runs on a library-owned side stream that
- * events recorded by the caller cannot see.  d2amd_timing_read waits for the events and returns the summed
- * duration and the number of launches since the last d2amd_timing_enable. */
-void d2amd_timing_enable(int mask); /* bit 0: pool_bwd_fine_r7, 1: pool_bwd_coarse_r7, 2: ..fine_r14, 3: ..coarse_r14; 0 = off */
+/* ---- kernel timing aid (measurement only: bench.py's `roofline` needs the duration of ONE kernel inside a multi-
+ * kernel op, on the stream it is launched on -- some launches run on library-owned side streams that events
+ * recorded by the caller cannot see).  For every selected kernel name, HIP events are recorded on the LAUNCH stream
+ * right before / after each launch; d2amd_timing_read waits for them and returns the summed duration and the number
+ * of launches since the last select / enable.  Names: "pool_bwd_staged_r7" / "_r14" (tile-gather backward of the
+ * fused pooler, pooled size <= 7 / larger), "pool_fwd_r7" / "_r14", "dcn_fwd", "dcn_bwd_data", "dcn_bwd_weight",
+ * "nms_mask", "nms_reduce".  Off by default (no events, no cost). */
+void d2amd_timing_select(const char* names_csv); /* comma-separated kernel names; NULL or "" = none */
+void d2amd_timing_enable(int mask); /* legacy: bit 0 pool_bwd_*_r7 fine, 1 coarse, 2 / 3 the same for _r14; 0 = off */
 int d2amd_timing_read(const char* kernel, double* total_ms, int* launches);
 
 /* ---- ROIAlign (axis-aligned).  Replaces torchvision.ops.roi_align as called from
@@ -250,6 +253,14 @@ int d2amd_paste_masks(const void* masks, const float* boxes, int n, int mh, int 
  * roi_align, so the thresholded result is bit-identical to the reference pipeline. */
 int d2amd_bitmask_crop_and_resize(const uint8_t* masks, const float* boxes, int G, int H, int W,
                                   int mask_size, uint8_t* out, void* stream);
+/* Same, for the sampled proposals of an image: box i crops mask mask_index[i] of the image's n_masks ground-truth
+ * masks -- `gt_masks[sampled_targets].crop_and_resize(proposal_boxes, M)` (roi_heads/roi_heads.py:280-291 +
+ * mask_head.py:65-67) without the (n_boxes, H, W) indexed copy `BitMasks.__getitem__` (masks.py:122-142) makes.
+ * status [1] int32 (device, zeroed by the caller, may be NULL): bit 0 = an index outside [0, n_masks) (torch
+ * indexing raises IndexError; such rows are written as zeros). */
+int d2amd_bitmask_crop_and_resize_indexed(const uint8_t* masks, int n_masks, const float* boxes,
+                                          const int64_t* mask_index, int n_boxes, int H, int W, int mask_size,
+                                          uint8_t* out, int* status, void* stream);
 
 /* ---- Mask-head glue.  detectron2/modeling/roi_heads/mask_head.py:31-158.
  * logits [B,C,HW] `dtype` (HW = Hmask*Wmask, contiguous NCHW), classes [B] int64 or NULL (class-agnostic,

@@ -67,3 +67,27 @@ def test_crop_and_resize_full_size_equals_roialign_path():
 def test_crop_and_resize_empty():
     out = BitMasks(torch.zeros(0, 20, 30, dtype=torch.bool, device=DEV)).crop_and_resize(torch.zeros(0, 4, device=DEV), 28)
     assert tuple(out.shape) == (0, 28, 28) and out.dtype == torch.bool
+
+
+def test_crop_and_resize_indexed_equals_indexing_then_crop():
+    """`gt_masks[sampled_targets].crop_and_resize(proposal_boxes, M)` (roi_heads.py:280-291 + mask_head.py:65-67)
+    without the indexed copy: bit-identical to indexing first, both on the device and against the oracle pipeline;
+    an index outside the masks is flagged and yields zeros."""
+    rng = np.random.default_rng(21)
+    g, h, w, M, n = 5, 120, 161, 28, 37
+    masks = blob_masks(rng, g, h, w)
+    idx = rng.integers(0, g, n)
+    xy = rng.uniform(-5, [w * 0.6, h * 0.6], (n, 2))
+    wh = rng.uniform(3, [w * 0.7, h * 0.7], (n, 2))
+    boxes = np.concatenate([xy, xy + wh], 1).astype(np.float32)
+    bm = BitMasks(torch.from_numpy(masks).to(DEV))
+    bt, it = torch.from_numpy(boxes).to(DEV), torch.from_numpy(idx).to(DEV)
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    got = bm.crop_and_resize_indexed(bt, it, M, status)
+    assert got.dtype == torch.bool and tuple(got.shape) == (n, M, M) and int(status.item()) == 0
+    assert torch.equal(got, bm[it].crop_and_resize(bt, M))
+    assert np.array_equal(got.cpu().numpy(), reference_pipeline(masks[idx], boxes, M))
+    it[3] = g  # out of range
+    bad = bm.crop_and_resize_indexed(bt, it, M, status)
+    assert int(status.item()) == 1 and not bool(bad[3].any()) and torch.equal(bad[4:], got[4:])
+    assert tuple(bm.crop_and_resize_indexed(bt[:0], it[:0], M).shape) == (0, M, M)
