@@ -1,27 +1,50 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the Detectron2 detection hot path on MI355X.
 
-One "step" = one pass of the TRAINING hot path of Mask R-CNN R50-FPN over one synthetic batch
-(BASELINE.json configs[1]: 2 images, 1333x800 -> padded 800x1344, bf16 features, FPN p2..p5,
-256 ch; SURVEY.md 8(d) inputs, seed 1234):
-    per image : pairwise_iou(16 GT x 268,569 anchors)              [RPN matching, rpn.py:339]
-                batched_nms(8,819 proposals, 5 levels, thr 0.7)     [proposal_utils.py:121]
-                pairwise_iou(16 GT x 1,016 proposals)               [roi_heads.py:266]
-    per batch : box  ROIPooler 7x7,   1024 ROIs over p2..p5  forward + backward   [roi_heads.py:_forward_box]
-                mask ROIPooler 14x14, 256 ROIs over p2..p5  forward + backward   [roi_heads.py:_forward_mask]
-                (ROIPooler = level assignment + ROIAlignV2 on the assigned level, poolers.py:206-263)
-Everything else of the model (backbone convs, heads) is out of the hot path's scope and is NOT
-in the step.  Inputs are resident in HBM before the timed region.  `value` = images / second
-through the hot path, whole job (all ranks).  Multi-GPU: images shard across ranks, no data-path
-collective (the ops own no parameters); weak scaling.
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload maskrcnn_train|retinanet_100k|dcn_r50]
 
-Extra JSON fields: `roofline` (dominant op, algorithmic bytes of SURVEY 8(d) / measured time),
-`cpu_baseline` (the oracle timed on this host, bounded sample), `ops` (per-op breakdown).
+`--gpus N` with N > 1 and no torchrun environment: bench.py launches itself as N ranks (one per GPU, RCCL) through
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`; under torchrun it reads
+RANK / LOCAL_RANK / WORLD_SIZE.  Rank 0 prints ONE JSON line.
+
+Workloads (all inputs synthetic, resident in HBM before the timed region; SURVEY.md 8(d) shapes):
+
+maskrcnn_train (default; BASELINE.json configs[1] / [2], the configuration the metric is quoted on)
+    One step = one pass of the TRAINING hot path of Mask R-CNN R50-FPN over 2 images per GPU (1333x800 -> padded
+    800x1344, bf16 FPN features p2..p5, 256 channels), in the order GeneralizedRCNN.forward issues it:
+      RPN       Matcher.match_boxes(16 GT x 268,569 anchors) per image           [rpn.py:307-364: pairwise_iou + Matcher]
+                find_top_rpn_proposals_fused: per-level top-2000 of the objectness logits, decode, clip, per-level
+                NMS 0.7 of 2 x 8,819 boxes, top 1000                              [rpn.py:468-533, proposal_utils.py:22-135]
+      ROI heads Matcher.match_boxes(16 GT x 1,016 proposals + GT) per image       [roi_heads.py:257-295]
+                box  ROIPooler 7x7,  512 ROIs / image over p2..p5, forward        [roi_heads.py:_forward_box]
+                mask ROIPooler 14x14, 128 fg ROIs / image, forward                [roi_heads.py:_forward_mask]
+                mask targets: gt_masks[matched].crop_and_resize(fg boxes, 28) on (16, 800, 1344) bitmasks / image
+                mask_rcnn_loss forward on (256, 80, 28, 28) logits                [mask_head.py:33-112]
+      backward  ONE autograd pass: mask_rcnn_loss backward + both poolers' backward into the FPN features
+      N > 1     gradient all-reduce of the model's 44.1 M trainable parameters (RCCL over xGMI; the ROI heads'
+                bucket is issued before the pooler backward and overlaps it; see detectron2_amd/sharding.py)
+    Not in the step because out of the hot path's scope: backbone / head convolutions and FCs (their
+    outputs -- logits, deltas, mask logits, dY of the pooled features -- are inputs here), `subsample_labels` (the
+    sampled ROI lists are fixed inputs), the optimizer.  `value` = images / second through the hot path, whole job.
+
+retinanet_100k (configs[3]): RetinaNet R50-FPN inference with TOPK_CANDIDATES_TEST 20000 x 5 levels = 100k candidates
+    per image, SCORE_THRESH_TEST 0, 80 classes: dense_detector_inference_fused (threshold + top-k over 2 x 16.1 M
+    class logits, decode, per-class NMS 0.5 of 2 x 100,000 boxes, top 100).  value = images / second.
+
+dcn_r50 (configs[4]): the 13 ModulatedDeformConv (DCNv2) blocks of R50 res3-res5 (4 x 128ch @100x168, 6 x 256ch
+    @50x84, 3 x 512ch @25x42), forward + backward (dX, d offset, d mask, dW), bf16, 2 images.  value = images / second;
+    roofline bound = MFMA.
+
+Extra JSON fields: `roofline` (dominant kernel, algorithmic bytes / flops of SURVEY 8(d) over its HIP-event time),
+`cpu_baseline` (the oracle timed on this host), `ops` (per-op breakdown from a separate untimed pass).
 """
 import argparse
+import ctypes
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,32 +54,67 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_BF16_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
 STRIDES = (4, 8, 16, 32)
 FEAT_HW = ((200, 336), (100, 168), (50, 84), (25, 42))  # 800x1344 padded input
+ANCHOR_HW = FEAT_HW + ((13, 21),)
 IMG_H, IMG_W = 800, 1344
 C = 256
 IMAGES_PER_GPU = 2
+N_GT = 16
+WORKLOADS = ("maskrcnn_train", "retinanet_100k", "dcn_r50")
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", choices=WORKLOADS, default="maskrcnn_train")
     ap.add_argument("--layout", choices=["nchw", "nhwc"], default="nhwc",
                     help="feature memory format: nchw (reference default) or nhwc (torch.channels_last)")
     ap.add_argument("--dtype", choices=["bf16", "fp32", "fp16"], default="bf16")
+    ap.add_argument("--grad-allreduce", choices=["bf16", "fp32", "off"], default="bf16",
+                    help="N > 1, maskrcnn_train: wire dtype of the gradient all-reduce (bf16 = the reference's "
+                         "fp16_compress_hook idea, fp32 = plain DDP) or off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    return ap.parse_args()
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="test hook: launcher + process group + gradient all-reduce + timing reduction only, no "
+                         "hot-path op (runs without a GPU with --backend gloo); the JSON line says so")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
+    a = ap.parse_args(argv)
+    dflt = {"maskrcnn_train": (200, 20), "retinanet_100k": (30, 5), "dcn_r50": (20, 3)}[a.workload]
+    a.steps = dflt[0] if a.steps is None else a.steps
+    a.warmup = dflt[1] if a.warmup is None else a.warmup
+    return a
+
+
+# ------------------------------------------------------------------------------------ launcher
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def relaunch_under_torchrun(args):
+    """`bench.py --gpus N` started as a plain process: become N ranks (engine/launch.py:27-84 does this with
+    mp.start_processes; torchrun gives the same one-process-per-GPU layout and is what the driver uses)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: required by RCCL on this host driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
 
 
 # ------------------------------------------------------------------------------------ inputs
-def make_anchors():
-    """Standard RPN anchors (sizes 32..512, ratios .5/1/2, strides 4..64) -> 268,569 x 4."""
+def level_anchors():
+    """Standard RPN anchors (sizes 32..512, ratios .5/1/2, strides 4..64), per level -> 268,569 x 4 in total."""
     out = []
-    for size, stride, (h, w) in zip((32, 64, 128, 256, 512), (4, 8, 16, 32, 64),
-                                    FEAT_HW + ((13, 21),)):
+    for size, stride, (h, w) in zip((32, 64, 128, 256, 512), (4, 8, 16, 32, 64), ANCHOR_HW):
         ys, xs = torch.meshgrid(torch.arange(h) * stride, torch.arange(w) * stride, indexing="ij")
         ctr = torch.stack([xs, ys, xs, ys], -1).reshape(-1, 1, 4).float()
         cells = []
@@ -65,7 +123,11 @@ def make_anchors():
             hh = ww * r
             cells.append([-ww / 2, -hh / 2, ww / 2, hh / 2])
         out.append((ctr + torch.tensor(cells)[None]).reshape(-1, 4))
-    return torch.cat(out)
+    return out
+
+
+def make_anchors():
+    return torch.cat(level_anchors())
 
 
 def make_boxes(gen, n, smin, smax):
@@ -92,22 +154,38 @@ def image_generator(seed, image_id):
     return torch.Generator().manual_seed(seed * 100003 + image_id)
 
 
+def blob_bitmasks(gen, boxes):
+    """(G, H, W) bool: an ellipse inside every GT box ('Bernoulli-blob bitmasks')."""
+    g = boxes.shape[0]
+    yy = torch.arange(IMG_H).view(1, -1, 1).float() + 0.5
+    xx = torch.arange(IMG_W).view(1, 1, -1).float() + 0.5
+    cx, cy = ((boxes[:, 0] + boxes[:, 2]) / 2).view(g, 1, 1), ((boxes[:, 1] + boxes[:, 3]) / 2).view(g, 1, 1)
+    rx = ((boxes[:, 2] - boxes[:, 0]) / 2).clamp(min=1).view(g, 1, 1)
+    ry = ((boxes[:, 3] - boxes[:, 1]) / 2).clamp(min=1).view(g, 1, 1)
+    return ((xx - cx) / rx) ** 2 + ((yy - cy) / ry) ** 2 <= 1.0
+
+
 class Workload:
-    def __init__(self, dev, dtype, layout, seed=1234, image_ids=(0, 1)):
+    """maskrcnn_train inputs of one rank (also used by scripts/microbench.py)."""
+
+    def __init__(self, dev, dtype, layout, seed=1234, image_ids=(0, 1), full=True):
+        from detectron2_amd.modeling import Matcher, ROIPooler
+        from detectron2_amd.structures import BitMasks, Boxes
+
         n_img = len(image_ids)
         gens = [image_generator(seed, i) for i in image_ids]
-        gen = gens[0]
-        self.dev, self.n_img, self.image_ids = dev, n_img, list(image_ids)
+        self.dev, self.n_img, self.image_ids, self.dtype, self.layout = dev, n_img, list(image_ids), dtype, layout
         self.feats = []
         for (h, w) in FEAT_HW:
             f = torch.stack([torch.rand(C, h, w, generator=g) * 2 - 1 for g in gens]).to(dtype).to(dev)
             if layout == "nhwc":
                 f = f.contiguous(memory_format=torch.channels_last)
             self.feats.append(f.requires_grad_(True))
-        self.anchors = make_anchors().to(dev)
+        self.anchor_levels = [a.to(dev) for a in level_anchors()]
+        self.anchors = torch.cat(self.anchor_levels)
         assert self.anchors.shape[0] == 268569
-        self.gt = [make_boxes(g, 16, 16, 512).to(dev) for g in gens]
-        # RPN proposals entering NMS: 2000 per level p2-p5 + 819 for p6, distinct scores
+        self.gt = [make_boxes(g, N_GT, 16, 512).to(dev) for g in gens]
+        # RPN proposals entering NMS (stand-alone NMS input of SURVEY 8(d) micro (i); scripts/microbench.py)
         self.nms_in = []
         for gen in gens:
             per = (2000, 2000, 2000, 2000, 819)
@@ -124,9 +202,6 @@ class Workload:
             self.nms_in.append((b.to(dev), sc.to(dev), lv.to(dev)))
         self.props = [make_boxes(g, 1016, 16, 600).to(dev) for g in gens]
         # sampled ROIs: 512 / image (box head), 128 fg / image (mask head), as list[Boxes] per image
-        from detectron2_amd.modeling import ROIPooler
-        from detectron2_amd.structures import Boxes
-
         box_b = [make_boxes(g, 512, 16, 600) for g in gens]
         mask_b = [make_boxes(g, 128, 16, 600) for g in gens]
         self.box_lists = [Boxes(b.to(dev)) for b in box_b]
@@ -142,19 +217,24 @@ class Workload:
         self.gmask = torch.cat([torch.randn(128, C, 14, 14, generator=g) for g in gens]).to(dtype).to(dev) \
             .contiguous(memory_format=mf)
         self.esize = torch.empty((), dtype=dtype).element_size()
-
-    # algorithmic bytes of ONE tile-gather launch (fine = FPN levels with > 512 tiles: p2, p3 here): the levels'
-    # share of SURVEY 8(d)'s backward formula  s*K_l*C*R^2 (dY rows of the ROIs on those levels) + 2*s*N*C*H_l*W_l
-    def alg_bytes_bwd_kernel(self, which, fine):
-        s = self.esize
-        counts, R = (self.box_level_counts[0], 7) if which == "box" else (self.box_level_counts[1], 14)
-        tot = 0
-        for l, (h, w) in enumerate(FEAT_HW):
-            tiles = ((h + 7) // 8) * ((w + 7) // 8) * self.n_img
-            if (tiles > 512) != fine:
-                continue
-            tot += s * counts[l] * C * R * R + 2 * s * self.n_img * C * h * w
-        return tot
+        if not full:
+            return
+        # RPN head outputs (inputs of the proposal path): objectness logits / anchor deltas per level
+        self.rpn_logits = [torch.stack([torch.randn(a.shape[0], generator=g) for g in gens]).to(dev)
+                           for a in self.anchor_levels]
+        self.rpn_deltas = [torch.stack([torch.randn(a.shape[0], 4, generator=g) * 0.2 for g in gens]).to(dev)
+                           for a in self.anchor_levels]
+        self.image_sizes = [(IMG_H, IMG_W)] * n_img
+        self.anchor_matcher = Matcher([0.3, 0.7], [0, -1, 1], allow_low_quality_matches=True)   # rpn.py / defaults
+        self.proposal_matcher = Matcher([0.5], [0, 1], allow_low_quality_matches=False)          # roi_heads.py
+        self.props_with_gt = [torch.cat([p, g]) for p, g in zip(self.props, self.gt)]           # add_ground_truth_to_proposals
+        # mask head: GT bitmasks, the matched GT of every fg ROI, GT classes, the mask head's logits
+        self.gt_masks = [BitMasks(blob_bitmasks(g, b.cpu()).to(dev)) for g, b in zip(gens, self.gt)]
+        self.fg_gt_index = [torch.randint(0, N_GT, (128,), generator=g).to(dev) for g in gens]
+        self.fg_classes = torch.cat([torch.randint(0, 80, (128,), generator=g) for g in gens]).to(dev)
+        self.mask_logits = torch.cat([torch.randn(128, 80, 28, 28, generator=g) for g in gens]).to(dtype).to(dev) \
+            .requires_grad_(True)
+        self.crop_status = torch.zeros(1, dtype=torch.int32, device=dev)
 
     # algorithmic (compulsory) bytes per op, SURVEY.md 8(d)
     def alg_bytes(self):
@@ -171,26 +251,26 @@ class Workload:
                 fwd += feat[l] + 20 * k + s * k * C * R * R
                 bwd += s * k * C * R * R + 2 * feat[l]
             d[name + "_fwd"], d[name + "_bwd"] = fwd, bwd
-        d["roi_align_bwd"] = d["roi_align_box_bwd"] + d["roi_align_mask_bwd"]  # the step runs them in one backward pass
-        n, m = 16, 268569
-        d["pairwise_iou_rpn"] = self.n_img * (16 * (n + m) + 4 * n * m)
-        d["pairwise_iou_roi"] = self.n_img * (16 * (16 + 1016) + 4 * 16 * 1016)
-        nk = 8819
-        d["batched_nms_rpn"] = self.n_img * (16 * nk + 8 * nk)  # boxes + keep list; bitmask is internal
+        d["backward"] = d["roi_align_box_bwd"] + d["roi_align_mask_bwd"]  # + the mask loss backward (2 x logits)
+        d["backward"] += 2 * 256 * 80 * 784 * s
+        n, m = N_GT, 268569
+        d["match_anchors"] = self.n_img * (16 * (n + m) + 9 * m)       # boxes in, (int64 match, int8 label) out
+        d["match_proposals"] = self.n_img * (16 * (n + 1032) + 9 * 1032)
+        d["rpn_proposals"] = self.n_img * m * (4 + 4)                    # logits read by the select passes (>= 2x)
+        d["mask_loss_fwd"] = 256 * 784 * (s + 1)
         return d
 
 
 class Timer:
     """Per-op HIP-event timing on torch's current stream (the stream every kernel is launched on).
-    `only`: time just this op and call the others bare (two events cost ~10 us of host time; in the timed
-    region only the roofline op carries them, the full breakdown comes from a separate, untimed pass)."""
+    `only`: time just these ops and call the others bare (two events cost ~10 us of host time)."""
 
     def __init__(self, only=None):
         self.pairs = {}
         self.only = only
 
     def run(self, name, fn):
-        if self.only is not None and name != self.only:
+        if self.only is not None and name not in self.only:
             return fn()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
@@ -206,73 +286,146 @@ class Timer:
         return {k: len(v) for k, v in self.pairs.items()}
 
 
-def step(w, t=None):
-    from detectron2_amd.layers import batched_nms_images
-    from detectron2_amd.structures import pairwise_iou
+def read_kernel_times(names):
+    """{kernel: (mean ms, launches)} from the library's launch-stream events (d2amd_timing_*)."""
+    from detectron2_amd import _C as _dc
+
+    out = {}
+    for kn in names:
+        tot, cnt = ctypes.c_double(0.0), ctypes.c_int(0)
+        _dc.check(_dc.lib().d2amd_timing_read(kn.encode(), ctypes.byref(tot), ctypes.byref(cnt)))
+        if cnt.value:
+            out[kn] = (tot.value / cnt.value, cnt.value)
+    return out
+
+
+# ------------------------------------------------------------------------------------ maskrcnn_train
+def step(w, t=None, grads=None):
+    from detectron2_amd.modeling import find_top_rpn_proposals_fused, mask_rcnn_loss_from_targets
+    from detectron2_amd.modeling import poolers as _poolers
 
     run = (lambda name, fn: t.run(name, fn)) if t is not None else (lambda name, fn: fn())
     # a training iteration produces NEW feature maps: drop the NHWC staging copies an NCHW run cached for the
     # previous step's tensors (the two poolers of one step still share one copy)
-    from detectron2_amd.modeling import poolers as _poolers
     _poolers._NHWC_CACHE.clear()
-    # RPN NMS of all images of the batch: one call, one launch per pipeline stage for the whole batch; the kept
-    # counts come back with ONE host sync (the reference loops over images, one sync each).  The sync is deferred
-    # past the anchor-labelling IoU, which does not depend on the proposals (RPN.forward computes the two in either
-    # order: rpn.py label_and_sample_anchors / predict_proposals): the host enqueues it while the NMS pipeline runs.
-    nms_done = run("batched_nms_rpn", lambda: batched_nms_images(w.nms_in, 0.7, defer=True))
+    # RPN: anchor labelling (does not depend on the proposals) and the proposal path
     for i in range(w.n_img):
-        run("pairwise_iou_rpn", lambda: pairwise_iou(w.gt[i], w.anchors))
-    run("batched_nms_rpn_sync", nms_done)
+        run("match_anchors", lambda: w.anchor_matcher.match_boxes(w.gt[i], w.anchors))
+    props = run("rpn_proposals", lambda: find_top_rpn_proposals_fused(
+        w.anchor_levels, w.rpn_logits, w.rpn_deltas, w.image_sizes, 0.7, 2000, 1000, 0.0, True))
+    # ROI heads: proposal labelling (the sampled lists themselves are fixed inputs: subsample_labels is out of scope)
     for i in range(w.n_img):
-        run("pairwise_iou_roi", lambda: pairwise_iou(w.gt[i], w.props[i]))
-    # both poolers forward, then ONE backward pass through both (a training iteration sums the box- and mask-head
-    # losses and calls backward once: the autograd engine is entered once, both tile gathers run inside it)
+        run("match_proposals", lambda: w.proposal_matcher.match_boxes(w.gt[i], w.props_with_gt[i]))
     yb = run("roi_align_box_fwd", lambda: w.box_pooler(w.feats, w.box_lists))
     ym = run("roi_align_mask_fwd", lambda: w.mask_pooler(w.feats, w.mask_lists))
-    run("roi_align_bwd", lambda: torch.autograd.backward([yb, ym], [w.gbox, w.gmask]))
-    outs = [yb, ym]
+    tg = run("mask_targets", lambda: torch.cat([
+        w.gt_masks[i].crop_and_resize_indexed(w.mask_lists[i].tensor, w.fg_gt_index[i], 28, w.crop_status)
+        for i in range(w.n_img)]))
+    loss, _stats = run("mask_loss_fwd", lambda: mask_rcnn_loss_from_targets(w.mask_logits, w.fg_classes, tg))
+    # N > 1: the ROI heads' weight gradients exist before the poolers' backward runs -> their bucket's all-reduce
+    # overlaps it; the remaining buckets (RPN head, FPN, backbone) follow the feature gradients
+    n_early = grads.ready_after("roi_heads.box_head") if grads is not None else 0
+    if grads is not None:
+        run("allreduce_issue", lambda: [grads.reduce(i) for i in range(n_early)])
+    # ONE backward pass (a training iteration sums the losses and calls backward once)
+    run("backward", lambda: torch.autograd.backward([yb, ym, loss], [w.gbox, w.gmask, None]))
+    if grads is not None:
+        run("allreduce_issue", lambda: [grads.reduce(i) for i in range(n_early, grads.num_buckets)])
+        run("allreduce_wait", grads.finish)
     for f in w.feats:
         f.grad = None
-    return outs
+    w.mask_logits.grad = None
+    return props
 
 
-# ------------------------------------------------------------------------------------ CPU baseline
-def cpu_baseline(w):
-    """The oracle (plain-C port, 1 thread) on a bounded sample of the same workload: image 0's
-    IoU + NMS inputs in full, and 16 ROIs x 32 channels of every level for ROIAlign fwd+bwd
-    (scaled to the full ROI / channel count; ROIAlign cost is linear in both)."""
+def _threads():
+    return max(1, min(32, os.cpu_count() or 1))
+
+
+def _median_time(fn, runs=5):
+    fn()  # warm-up
+    ts = []
+    for _ in range(runs):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts))
+
+
+def cpu_baseline_maskrcnn(w):
+    """The oracle (oracle/d2_oracle.c + numpy restatements, kind "port") on the SAME step, unsampled: image 0's
+    per-image ops in full (x n_img), both poolers forward + backward over all ROIs and all 256 channels (channel
+    slabs on a thread pool: ctypes releases the GIL; torchvision's CPU roi_align is parallel over ROIs, the
+    reference's own CPU kernels are single-threaded), mask targets and mask loss of the batch.  Median of 5 runs
+    after one warm-up."""
+    from concurrent.futures import ThreadPoolExecutor
+
     import oracle
+    from oracle import mask_head as omh
+    from oracle import rpn as orpn
 
-    t_img = 0.0
+    T = _threads()
     gt, an = w.gt[0].cpu().numpy(), w.anchors.cpu().numpy()
-    t0 = time.perf_counter(); oracle.pairwise_iou(gt, an); t_img += time.perf_counter() - t0
-    b, s, lv = [x.cpu().numpy() for x in w.nms_in[0]]
-    t0 = time.perf_counter(); oracle.batched_nms(b, s, lv, 0.7); t_img += time.perf_counter() - t0
-    t0 = time.perf_counter(); oracle.pairwise_iou(gt, w.props[0].cpu().numpy()); t_img += time.perf_counter() - t0
-    t_batch = 0.0
-    cs = 32
-    for lists, R in ((w.box_lists, 7), (w.mask_lists, 14)):
+    anchors_l = [a.cpu().numpy() for a in w.anchor_levels]
+    lg = [x[:1].cpu().numpy() for x in w.rpn_logits]
+    dl = [x[:1].cpu().numpy() for x in w.rpn_deltas]
+    pg = w.props_with_gt[0].cpu().numpy()
+
+    def per_image():
+        q = oracle.pairwise_iou(gt, an)
+        oracle.matcher(q, [0.3, 0.7], [0, -1, 1], True)
+        orpn.find_top_rpn_proposals(anchors_l, lg, dl, [(IMG_H, IMG_W)], 0.7, 2000, 1000, 0.0)
+        oracle.matcher(oracle.pairwise_iou(gt, pg), [0.5], [0, 1], False)
+
+    t_img = _median_time(per_image)
+    jobs = []
+    for lists, R, gout in ((w.box_lists, 7, w.gbox), (w.mask_lists, 14, w.gmask)):
         allb = torch.cat([b.tensor.cpu() for b in lists])
         bidx = torch.cat([torch.full((len(b),), float(i)) for i, b in enumerate(lists)])
         rois_all = torch.cat([bidx[:, None], allb], 1)
         lv = assign_levels(allb)
+        g_all = gout.detach().float().cpu()
         for l in range(4):
-            rl = rois_all[lv == l]
-            k = rl.shape[0]
-            if k == 0:
+            sel = lv == l
+            if int(sel.sum()) == 0:
                 continue
-            ks = min(16, k)
-            x = w.feats[l].detach()[:, :cs].float().cpu().contiguous().numpy()
-            r = rl[:ks].contiguous().numpy()
-            t0 = time.perf_counter()
-            y = oracle.roi_align_forward(x, r, (R, R), 1.0 / STRIDES[l], 0, True)
-            oracle.roi_align_backward(y, r, x.shape, 1.0 / STRIDES[l], 0, True)
-            dt = time.perf_counter() - t0
-            t_batch += dt * (k / ks) * (C / cs)
-    sec_per_batch = t_img * w.n_img + t_batch
-    return {"value": round(w.n_img / sec_per_batch, 4), "unit": "img/s", "cores": 1, "kind": "port",
-            "sample": "oracle/d2_oracle.c single thread: image 0 IoU+NMS in full; ROIAlign fwd+bwd on 16 ROIs x 32 "
-                      "of 256 channels per level, scaled linearly to all ROIs/channels",
+            r = rois_all[sel].contiguous().numpy()
+            x = w.feats[l].detach().float().cpu().contiguous()
+            g = g_all[sel].contiguous()
+            cs = C // T if C % T == 0 else C
+            for c0 in range(0, C, cs):
+                jobs.append((x[:, c0:c0 + cs].contiguous().numpy(), r, g[:, c0:c0 + cs].contiguous().numpy(), R,
+                             1.0 / STRIDES[l]))
+
+    def one(job):
+        x, r, g, R, sc = job
+        oracle.roi_align_forward(x, r, (R, R), sc, 0, True)
+        oracle.roi_align_backward(g, r, x.shape, sc, 0, True)
+
+    with ThreadPoolExecutor(T) as ex:
+        t_pool = _median_time(lambda: list(ex.map(one, jobs)))
+    masks = [m.tensor.cpu().numpy().astype(np.float32)[:, None] for m in w.gt_masks]
+    idx = [i.cpu().numpy() for i in w.fg_gt_index]
+    mb = [b.tensor.cpu().numpy() for b in w.mask_lists]
+    logits = w.mask_logits.detach().float().cpu().numpy()
+    cls = w.fg_classes.cpu().numpy()
+
+    def mask_part():
+        tg = []
+        for m, i, b in zip(masks, idx, mb):
+            rois = np.concatenate([i.astype(np.float32)[:, None], b], 1)
+            tg.append(oracle.roi_align_forward(m, rois, (28, 28), 1.0, 0, True)[:, 0] >= 0.5)
+        tg = np.concatenate(tg)
+        omh.mask_rcnn_loss(logits, cls, tg)
+        omh.mask_rcnn_loss_grad(logits, cls, tg)
+
+    t_mask = _median_time(mask_part, runs=3)
+    sec = t_img * w.n_img + t_pool + t_mask
+    return {"value": round(w.n_img / sec, 4), "unit": "img/s", "cores": T, "kind": "port",
+            "sample": f"the full step, unsampled, median of 5 runs: per-image ops (IoU+Matcher x2, RPN top-k/decode/NMS) "
+                      f"of image 0 on 1 thread x {w.n_img} images = {t_img * w.n_img:.3f} s; both poolers fwd+bwd, all "
+                      f"ROIs x 256 channels in channel slabs on {T} threads = {t_pool:.3f} s; mask targets + loss "
+                      f"fwd/bwd (1 thread, 3 runs) = {t_mask:.3f} s",
             "host_cores_available": os.cpu_count()}
 
 
@@ -293,144 +446,403 @@ def pmc_traffic(op, layout):
     return best
 
 
-ROOFLINE_OP = "roi_align_bwd"      # the op holding the dominant kernel (the box head's tile gather)
-ROOFLINE_KERNEL_OP = "roi_align_box_bwd"  # algorithmic bytes / PMC traffic of that kernel's pooler
+def bench_maskrcnn(args, ctx):
+    from detectron2_amd import _C as _dc
+    from detectron2_amd.sharding import (MASK_RCNN_R50_FPN_GRADIENTS, GradientBuckets, Stopwatch, global_image_ids)
+
+    dev, rank, world, dist = ctx["dev"], ctx["rank"], ctx["world"], ctx["dist"]
+    dtype = {"bf16": torch.bfloat16, "fp32": torch.float32, "fp16": torch.float16}[args.dtype]
+    # weak scaling: 2 images per GPU; rank r owns images [2r, 2r+1] of the global synthetic batch
+    w = Workload(dev, dtype, args.layout, image_ids=global_image_ids(IMAGES_PER_GPU, rank, world))
+    grads = make_gradient_buckets(args, dev, dist, world)
+    for _ in range(args.warmup):
+        step(w, None, grads)
+    sw = Stopwatch(dist, dev)
+    KERN = "pool_bwd_staged_r7"
+    _dc.lib().d2amd_timing_select(KERN.encode())  # HIP events around the roofline kernel only, in the timed region
+    dom_timer = Timer(only=("backward",))
+    sw.start()
+    for _ in range(args.steps):
+        step(w, dom_timer, grads)
+    elapsed = sw.stop()
+    ktimes = read_kernel_times([KERN])
+    knames = ["pool_bwd_staged_r7", "pool_bwd_staged_r14", "pool_fwd_r7", "pool_fwd_r14", "nms_mask", "nms_reduce"]
+    _dc.lib().d2amd_timing_select(",".join(knames).encode())
+    timer = Timer()  # per-op breakdown: a separate, UNTIMED pass with events around every op
+    bsteps = min(args.steps, 20)
+    for _ in range(bsteps):
+        step(w, timer, grads)
+    torch.cuda.synchronize()
+    for k, v in read_kernel_times(knames).items():
+        ktimes.setdefault(k, v)
+    _dc.lib().d2amd_timing_select(None)
+    if rank != 0:
+        return None
+    ms_step = elapsed / args.steps * 1e3
+    alg = w.alg_bytes()
+    counts = {k: v // bsteps for k, v in timer.counts().items()}
+    ops = {}
+    for k, tot in timer.totals_ms().items():
+        e = {"ms_per_step": round(tot / bsteps, 4), "launches_per_step": counts[k]}
+        if k in alg:
+            e["alg_MB"] = round(alg[k] / 1e6, 2)
+            e["GBps"] = round(alg[k] / 1e6 / max(e["ms_per_step"], 1e-9), 1)
+            e["frac_hbm_peak"] = round(e["GBps"] / HBM_PEAK_GBS, 4)
+        ops[k] = e
+    dom_ms_timed = dom_timer.totals_ms()["backward"] / args.steps
+    ops["backward"]["ms_per_step_timed_region"] = round(dom_ms_timed, 4)
+    if args.layout == "nhwc" and KERN in ktimes:
+        k_ms, k_n = ktimes[KERN]
+        kb = alg["roi_align_box_bwd"]
+        roof = {"bound": "hbm",
+                "kernel": "pool_bwd_mfma_kernel<T, 8> (16-bit I/O; fp32: pool_bwd_staged_kernel<float, 4, 8>): the 7x7 "
+                          "(box head) pooler's tile gather over all FPN levels, inside `backward`",
+                "achieved": round(kb / 1e6 / k_ms, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(kb / 1e6 / k_ms / HBM_PEAK_GBS, 4),
+                "traffic": pmc_traffic("roi_align_box_bwd", args.layout),
+                "traffic_note": "PMC bytes of the box-head pooler backward (records + tile lists + tile gather)",
+                "alg_bytes_per_launch": int(kb), "ms_per_launch": round(k_ms, 4), "launches_timed": k_n,
+                "alg_bytes_note": "SURVEY 8(d) ROIAlign bwd: s*K*C*R^2 (dY) + 2*s*sum_l N*C*H_l*W_l (zero fill + write of dX)",
+                "timing": "HIP events recorded by the library on the kernel's launch stream right around the launch, "
+                          "mean over the timed steps",
+                "kernels_ms": {k: round(v[0], 4) for k, v in ktimes.items()}}
+    else:
+        per = alg["backward"]
+        roof = {"bound": "hbm", "kernel": "backward (both poolers' tile gather + mask loss backward)",
+                "achieved": round(per / 1e6 / dom_ms_timed, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(per / 1e6 / dom_ms_timed / HBM_PEAK_GBS, 4), "traffic": None,
+                "alg_bytes_per_launch": int(per), "ms_per_launch": round(dom_ms_timed, 4),
+                "timing": "HIP events on the launch stream around the op, mean over the timed steps",
+                "kernels_ms": {k: round(v[0], 4) for k, v in ktimes.items()}}
+    out = {
+        "metric": "img/s through the Mask R-CNN R50-FPN detection hot path (training ops), 1333x800 bs=2/GPU",
+        "value": round(world * w.n_img * args.steps / elapsed, 2), "unit": "img/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "maskrcnn_r50fpn_train_hotpath_bs2_800x1344 (BASELINE configs[1]; configs[2] at n_gpus 8)",
+                   "layout": args.layout, "global_batch": world * w.n_img, "ops_per_step": counts,
+                   "parallelism": f"dp{world}: images sharded, no data-path collective; "
+                                  + (grads_description(grads) if grads is not None else
+                                     "no gradient all-reduce (world size 1, like DDP)")},
+        "roofline": roof, "gpu_ms_per_step_sum_of_ops": round(sum(v["ms_per_step"] for v in ops.values()), 4),
+        "ops": ops,
+        "ops_note": f"per-op times: separate untimed pass of {bsteps} steps with HIP events around every op",
+    }
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline_maskrcnn(w)
+    return out
+
+
+def make_gradient_buckets(args, dev, dist, world):
+    from detectron2_amd.sharding import MASK_RCNN_R50_FPN_GRADIENTS, GradientBuckets
+
+    if dist is None or world == 1 or args.grad_allreduce == "off":
+        return None
+    g = dict(MASK_RCNN_R50_FPN_GRADIENTS)
+    names = [n for n, _ in MASK_RCNN_R50_FPN_GRADIENTS]
+    # three buckets in gradient-ready order: ROI heads | RPN head + FPN + res5 | res4 + res3 (34 / 38 / 17 MB in bf16)
+    layout = [[(n, g[n]) for n in names[0:3]], [(n, g[n]) for n in names[3:6]], [(n, g[n]) for n in names[6:8]]]
+    wire = torch.bfloat16 if args.grad_allreduce == "bf16" else None
+    return GradientBuckets(layout, dev, dist, torch.float32, wire)
+
+
+def grads_description(grads):
+    return (f"gradient all-reduce of {grads.numel():,} parameters ({grads.wire_bytes() / 1e6:.1f} MB on the wire, "
+            f"{str(grads.wire_dtype).replace('torch.', '')}, {grads.num_buckets} buckets, RCCL, async; the ROI heads' "
+            f"bucket overlaps the pooler backward) inside the timed step")
+
+
+# ------------------------------------------------------------------------------------ retinanet_100k
+RETINA_A = [9 * 16800, 9 * 4200, 9 * 1050, 9 * 273, 9 * 77]  # anchors per level at 800x1344 (p3..p7, 9 / location)
+RETINA_K, RETINA_TOPK, RETINA_NMS, RETINA_MAXDET = 80, 20000, 0.5, 100
+
+
+def retina_inputs(dev, image_ids, seed=1234):
+    gens = [image_generator(seed + 7, i) for i in image_ids]
+    g0 = torch.Generator().manual_seed(seed + 99)
+    anchors = []
+    for li, a in enumerate(RETINA_A):
+        s = 32.0 * 2 ** li
+        anchors.append(make_boxes(g0, a, s * 0.7, s * 1.5).to(dev))
+    logits = [torch.stack([torch.randn(a, RETINA_K, generator=g) * 1.2 - 4.6 for g in gens]).to(dev) for a in RETINA_A]
+    deltas = [torch.stack([torch.randn(a, 4, generator=g) * 0.2 for g in gens]).to(dev) for a in RETINA_A]
+    return anchors, logits, deltas
+
+
+def bench_retinanet(args, ctx):
+    from detectron2_amd import _C as _dc
+    from detectron2_amd.modeling import dense_detector_inference_fused
+    from detectron2_amd.sharding import Stopwatch, global_image_ids
+
+    dev, rank, world, dist = ctx["dev"], ctx["rank"], ctx["world"], ctx["dist"]
+    ids = global_image_ids(IMAGES_PER_GPU, rank, world)
+    anchors, logits, deltas = retina_inputs(dev, ids)
+    sizes = [(IMG_H, IMG_W)] * len(ids)
+
+    def one():
+        return dense_detector_inference_fused(anchors, logits, deltas, sizes, 0.0, RETINA_TOPK, RETINA_NMS,
+                                              RETINA_MAXDET)
+
+    for _ in range(args.warmup):
+        one()
+    knames = ["nms_mask", "nms_reduce"]
+    _dc.lib().d2amd_timing_select(",".join(knames).encode())
+    sw = Stopwatch(dist, dev)
+    sw.start()
+    for _ in range(args.steps):
+        res = one()
+    elapsed = sw.stop()
+    ktimes = read_kernel_times(knames)
+    _dc.lib().d2amd_timing_select(None)
+    if rank != 0:
+        return None
+    n_img = len(ids)
+    n_box = sum(min(a * RETINA_K, RETINA_TOPK) for a in RETINA_A)
+    # SURVEY 8(d) NMS: pairs = upper triangle within class; bytes = 16N + 2 x 8 * sum_c n_c * ceil(n_c / 64)
+    # (bitmask write + read) + 8 N_keep, per image; classes ~ uniform over 80
+    per_cls = n_box / RETINA_K
+    pairs = RETINA_K * per_cls * (per_cls - 1) / 2
+    mask_bytes = 8 * RETINA_K * per_cls * math.ceil(per_cls / 64)
+    alg_img = 16 * n_box + 2 * mask_bytes + 8 * RETINA_MAXDET
+    dom = max(ktimes, key=lambda k: ktimes[k][0]) if ktimes else None
+    roof = {"bound": "hbm", "kernel": None, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+            "traffic": None}
+    if dom:
+        k_ms, k_n = ktimes[dom]
+        kb = n_img * alg_img  # one launch serves the images of the batch
+        roof = {"bound": "hbm",
+                "kernel": {"nms_mask": "nms_mask_kernel (wavefront suppression bitmask, per class)",
+                           "nms_reduce": "nms_reduce_kernel (greedy reduction over the bitmask)"}[dom],
+                "achieved": round(kb / 1e6 / k_ms, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(kb / 1e6 / k_ms / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("retinanet_" + dom, "nhwc"),
+                "alg_bytes_per_launch": int(kb), "ms_per_launch": round(k_ms, 4), "launches_timed": k_n,
+                "alg_bytes_note": "SURVEY 8(d) NMS: 16N boxes + bitmask write+read 2*8*sum_c n_c*ceil(n_c/64) + 8*N_keep; "
+                                  "the kernel is VALU/LDS bound (IoU tests), so this fraction is small by construction: "
+                                  "see pairs_per_s",
+                "pairs_per_s": round(n_img * pairs / (k_ms / 1e3), 1),
+                "timing": "HIP events recorded by the library on the kernel's launch stream, mean over the timed steps",
+                "kernels_ms": {k: round(v[0], 4) for k, v in ktimes.items()}}
+    out = {
+        "metric": "img/s through the RetinaNet R50-FPN inference hot path (select + decode + batched NMS), 100k candidates/img",
+        "value": round(world * n_img * args.steps / elapsed, 2), "unit": "img/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
+        "config": {"workload": "retinanet_r50fpn_inference_100k_candidates_800x1344 (BASELINE configs[3])",
+                   "candidates_per_image": n_box, "class_logits_per_image": sum(RETINA_A) * RETINA_K,
+                   "num_classes": RETINA_K, "topk_candidates": RETINA_TOPK, "score_thresh": 0.0, "nms_thresh": RETINA_NMS,
+                   "detections_kept": [len(r) for r in res], "global_batch": world * n_img,
+                   "parallelism": f"dp{world}: images sharded, replicas only (inference, no collective)"},
+        "roofline": roof,
+    }
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline_retinanet(anchors, logits, deltas)
+    return out
+
+
+def cpu_baseline_retinanet(anchors, logits, deltas):
+    """oracle/dense_detector.py (numpy restatement + the C NMS port) on image 0, in full; median of 3 runs."""
+    from oracle import dense_detector as odd
+
+    an = [a.cpu().numpy() for a in anchors]
+    lg = [x[0].cpu().numpy() for x in logits]
+    dl = [x[0].cpu().numpy() for x in deltas]
+    t = _median_time(lambda: odd.inference_single_image(an, lg, dl, 0.0, RETINA_TOPK, RETINA_NMS, RETINA_MAXDET), runs=3)
+    return {"value": round(1.0 / t, 4), "unit": "img/s", "cores": 1, "kind": "port",
+            "sample": f"image 0 in full (16.1 M class logits -> 100k candidates -> per-class NMS -> top 100), numpy "
+                      f"selection + oracle/d2_oracle.c NMS, 1 thread, median of 3 runs after a warm-up = {t:.3f} s",
+            "host_cores_available": os.cpu_count()}
+
+
+# ------------------------------------------------------------------------------------ dcn_r50
+DCN_STAGES = (("res3", 4, 128, 100, 168), ("res4", 6, 256, 50, 84), ("res5", 3, 512, 25, 42))
+
+
+def bench_dcn(args, ctx):
+    from detectron2_amd import _C as _dc
+    from detectron2_amd.layers import ModulatedDeformConv
+    from detectron2_amd.sharding import Stopwatch, global_image_ids
+
+    dev, rank, world, dist = ctx["dev"], ctx["rank"], ctx["world"], ctx["dist"]
+    dtype = {"bf16": torch.bfloat16, "fp32": torch.float32, "fp16": torch.float16}[args.dtype]
+    ids = global_image_ids(IMAGES_PER_GPU, rank, world)
+    n_img = len(ids)
+    gen = image_generator(4321, ids[0])
+    blocks, flops_fwd = [], 0.0
+    for tag, nblk, ch, h, wd in DCN_STAGES:
+        for b in range(nblk):
+            mod = ModulatedDeformConv(ch, ch, 3, padding=1, bias=False).to(dev).to(dtype)
+            x = torch.randn(n_img, ch, h, wd, generator=gen).to(dev).to(dtype)
+            if args.layout == "nhwc":
+                x = x.contiguous(memory_format=torch.channels_last)
+            off = (torch.randn(n_img, 18, h, wd, generator=gen) * 2).to(dev).to(dtype)
+            msk = torch.sigmoid(torch.randn(n_img, 9, h, wd, generator=gen)).to(dev).to(dtype)
+            gy = torch.randn(n_img, ch, h, wd, generator=gen).to(dev).to(dtype)
+            if args.layout == "nhwc":
+                gy = gy.contiguous(memory_format=torch.channels_last)
+            blocks.append((tag, mod, x.requires_grad_(True), off.requires_grad_(True), msk.requires_grad_(True), gy))
+            flops_fwd += 2.0 * ch * ch * 9 * n_img * h * wd
+
+    def one(t=None):
+        run = (lambda name, fn: t.run(name, fn)) if t is not None else (lambda name, fn: fn())
+        for tag, mod, x, off, msk, gy in blocks:
+            y = run("fwd_" + tag, lambda: mod(x, off, msk))
+            run("bwd_" + tag, lambda: torch.autograd.backward([y], [gy]))
+            x.grad = off.grad = msk.grad = mod.weight.grad = None
+
+    for _ in range(args.warmup):
+        one()
+    knames = ["dcn_fwd", "dcn_bwd_data", "dcn_bwd_weight"]
+    _dc.lib().d2amd_timing_select(",".join(knames).encode())
+    sw = Stopwatch(dist, dev)
+    sw.start()
+    for _ in range(args.steps):
+        one()
+    elapsed = sw.stop()
+    ktimes = read_kernel_times(knames)
+    _dc.lib().d2amd_timing_select(None)
+    timer = Timer()
+    bsteps = min(args.steps, 5)
+    for _ in range(bsteps):
+        one(timer)
+    torch.cuda.synchronize()
+    if rank != 0:
+        return None
+    # every kernel is launched once per block; its algorithmic flops per launch = the GEMM it carries, averaged over
+    # the 13 blocks (all three stages have the same 2*C*9C*H*W): fwd C x 9C x P, bwd-data 9C x C x P, bwd-weight C x 9C x P
+    per_launch = flops_fwd / len(blocks)
+    roof = {"bound": "mfma", "kernel": None, "achieved": None, "peak": MFMA_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": None, "traffic": None}
+    if ktimes and args.dtype != "fp32":
+        dom = max(ktimes, key=lambda k: ktimes[k][0] * ktimes[k][1])
+        k_ms, k_n = ktimes[dom]
+        roof = {"bound": "mfma",
+                "kernel": {"dcn_fwd": "dcn_fwd_wave_kernel / dcn_fwd_tc_kernel (gather + MFMA, no column buffer)",
+                           "dcn_bwd_data": "dcn_bwd_data_tc_kernel (dcol = W^T dY on MFMA + dX / d offset / d mask)",
+                           "dcn_bwd_weight": "dcn_bwd_weight_tc_kernel (dW = dY col^T on MFMA)"}[dom],
+                "achieved": round(per_launch / 1e9 / k_ms, 1), "peak": MFMA_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(per_launch / 1e9 / k_ms / MFMA_BF16_TFLOPS, 4), "traffic": pmc_traffic(dom, args.layout),
+                "alg_flops_per_launch": per_launch, "ms_per_launch": round(k_ms, 4), "launches_timed": k_n,
+                "alg_flops_note": "SURVEY 8(d) DCN: 2*Co*Ci*kh*kw*N*Ho*Wo per block and GEMM (9.9 GFLOP for 2 images, "
+                                  "identical for res3/res4/res5); mean over the 13 blocks' launches",
+                "timing": "HIP events recorded by the library on the kernel's launch stream, mean over the timed steps",
+                "kernels_ms": {k: round(v[0], 4) for k, v in ktimes.items()},
+                "kernels_frac_mfma": {k: round(per_launch / 1e9 / v[0] / MFMA_BF16_TFLOPS, 4) for k, v in ktimes.items()}}
+    ops = {k: {"ms_per_step": round(v / bsteps, 4), "launches_per_step": timer.counts()[k] // bsteps}
+           for k, v in timer.totals_ms().items()}
+    out = {
+        "metric": "img/s through the 13 DCNv2 blocks of R50 res3-res5 (ModulatedDeformConv forward + backward), 1333x800 bs=2/GPU",
+        "value": round(world * n_img * args.steps / elapsed, 2), "unit": "img/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "dcnv2_r50_res3-5_13_blocks_fwd+bwd_bs2_800x1344 (BASELINE configs[4])",
+                   "layout": args.layout, "global_batch": world * n_img,
+                   "gflop_per_step": round(3 * flops_fwd / 1e9, 1),
+                   "parallelism": f"dp{world}: images sharded; DCN weight gradients reduce with the model's (not in this step)"},
+        "roofline": roof, "ops": ops,
+        "step_tflops": round(3 * flops_fwd / 1e12 / (elapsed / args.steps), 1),
+    }
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline_dcn(blocks)
+    return out
+
+
+def cpu_baseline_dcn(blocks):
+    """oracle/d2_oracle.c DCNv2 forward + backward on ONE block (the first res5 block: smallest maps, same flops),
+    its images on separate threads; scaled by the 13 blocks of the step (every block has the same flops)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    import oracle
+
+    tag, mod, x, off, msk, gy = [b for b in blocks if b[0] == "res5"][0]
+    n = x.shape[0]
+    xs = x.detach().float().cpu().contiguous().numpy()
+    of = off.detach().float().cpu().numpy()
+    mk = msk.detach().float().cpu().numpy()
+    g = gy.detach().float().cpu().contiguous().numpy()
+    wt = mod.weight.detach().float().cpu().numpy()
+
+    def one(i):
+        oracle.deform_conv_forward(xs[i:i + 1], of[i:i + 1], wt, mask=mk[i:i + 1], padding=1)
+        oracle.deform_conv_backward(xs[i:i + 1], of[i:i + 1], wt, g[i:i + 1], mask=mk[i:i + 1], padding=1)
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(n) as ex:
+        list(ex.map(one, range(n)))
+    t = time.perf_counter() - t0
+    return {"value": round(n / (t * len(blocks)), 4), "unit": "img/s", "cores": n, "kind": "port",
+            "sample": f"1 of the 13 blocks (res5, {n} images on {n} threads, forward + backward, one run = {t:.2f} s), "
+                      f"scaled x13 (equal flops per block)",
+            "host_cores_available": os.cpu_count()}
+
+
+# ------------------------------------------------------------------------------------ plumbing-only (tests)
+def bench_plumbing(args, ctx):
+    """Launcher + process group + GradientBuckets + Stopwatch with NO hot-path op: what tests/test_sharding_gloo.py
+    drives on CPU with --backend gloo.  Not a measurement."""
+    from detectron2_amd.sharding import Stopwatch, global_image_ids
+
+    dev, rank, world, dist = ctx["dev"], ctx["rank"], ctx["world"], ctx["dist"]
+    grads = make_gradient_buckets(args, dev, dist, world)
+    sw = Stopwatch(dist, dev)
+    sw.start()
+    check = None
+    for _ in range(args.steps):
+        if grads is not None:
+            for i, g in enumerate(grads.grads):
+                g.fill_(float(rank + 1))
+            for i in range(grads.num_buckets):
+                grads.reduce(i)
+            grads.finish()
+            check = [float(g[0]) for g in grads.grads]
+    elapsed = sw.stop()
+    if rank != 0:
+        return None
+    return {"metric": "plumbing only (no hot-path op): not a measurement", "value": None, "unit": "img/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "plumbing_only": True,
+            "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4), "backend": args.backend,
+            "image_ids_rank0": global_image_ids(IMAGES_PER_GPU, rank, world),
+            "allreduce_mean": check, "expected_mean": (world + 1) / 2.0,
+            "buckets": grads.num_buckets if grads is not None else 0,
+            "parallelism": grads_description(grads) if grads is not None else "no all-reduce"}
 
 
 # ------------------------------------------------------------------------------------ main
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch_under_torchrun(args))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks")
+    gpu = args.backend == "nccl"
+    if gpu:
+        assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+        assert torch.cuda.device_count() > local, f"rank {rank}: no GPU {local} ({torch.cuda.device_count()} visible)"
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+    else:
+        assert args.plumbing_only, "--backend gloo only serves --plumbing-only"
+        dev = torch.device("cpu")
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    dtype = {"bf16": torch.bfloat16, "fp32": torch.float32, "fp16": torch.float16}[args.dtype]
-    from detectron2_amd.sharding import Stopwatch, global_image_ids
-
-    # weak scaling: 2 images per GPU; rank r owns images [2r, 2r+1] of the global synthetic batch
-    w = Workload(dev, dtype, args.layout, image_ids=global_image_ids(IMAGES_PER_GPU, rank, world))
-
-    for _ in range(args.warmup):
-        step(w)
-    sw = Stopwatch(dist, dev)
-    dom_timer = Timer(only=ROOFLINE_OP)  # HIP events around the roofline op only, inside the timed region
-    # ... and HIP events on the launch stream right around its dominant KERNEL (the fine-level tile gather),
-    # recorded by the library itself (d2amd_timing_*): this is the duration rocprofv3 reports for the kernel
-    import ctypes
-    from detectron2_amd import _C as _dc
-    _dc.lib().d2amd_timing_enable(1)  # only the roofline kernel (fine levels, 7x7) inside the timed region
-    sw.start()
-    for _ in range(args.steps):
-        step(w, dom_timer)
-    elapsed = sw.stop()
-    ktimes = {}
-    def read_ktimes():
-        for kn in ("pool_bwd_staged_r7", "pool_bwd_staged_r14", "pool_bwd_fine_r7", "pool_bwd_coarse_r7",
-                   "pool_bwd_fine_r14", "pool_bwd_coarse_r14"):
-            tot, cnt = ctypes.c_double(0.0), ctypes.c_int(0)
-            _dc.check(_dc.lib().d2amd_timing_read(kn.encode(), ctypes.byref(tot), ctypes.byref(cnt)))
-            if cnt.value and kn not in ktimes:
-                ktimes[kn] = (tot.value / cnt.value, cnt.value)
-
-    read_ktimes()
-    _dc.lib().d2amd_timing_enable(15)  # the untimed breakdown pass times all four tile-gather launches
-    # per-op breakdown: a separate, UNTIMED pass with events around every op (their host cost would otherwise
-    # sit in the timed region: ~0.15 ms of a 0.9 ms step)
-    timer = Timer()
-    bsteps = min(args.steps, 20)
-    for _ in range(bsteps):
-        step(w, timer)
-    torch.cuda.synchronize()
-    read_ktimes()
-    _dc.lib().d2amd_timing_enable(0)
-
-    if rank == 0:
-        ms_step = elapsed / args.steps * 1e3
-        totals = {k: v * args.steps / bsteps for k, v in timer.totals_ms().items()}
-        dom_ms_timed = dom_timer.totals_ms()[ROOFLINE_OP] / args.steps
-        alg = w.alg_bytes()
-        ops = {}
-        for k, tot in totals.items():
-            per_step_ms = tot / args.steps
-            e = {"ms_per_step": round(per_step_ms, 4)}
-            if k in alg:
-                e["alg_MB"] = round(alg[k] / 1e6, 2)
-                e["GBps"] = round(alg[k] / 1e9 / (per_step_ms / 1e3), 1)
-                e["frac_hbm_peak"] = round(e["GBps"] / HBM_PEAK_GBS, 4)
-            ops[k] = e
-        counts = {k: v // bsteps for k, v in timer.counts().items()}
-        for k in ops:
-            ops[k]["launches_per_step"] = counts[k]
-            ops[k]["ms_per_launch"] = round(ops[k]["ms_per_step"] / counts[k], 4)
-        # roofline: the dominant kernel = the tile-gather launch of the box-head backward (pool_bwd_mfma_kernel /
-        # pool_bwd_staged_kernel in the rocprofv3 stats; with D2AMD_POOL_NOSTAGED the fine-level launch of the two-launch register-gather
-        # kernels), timed by HIP events on its launch stream inside the timed region.  Its algorithmic bytes:
-        # SURVEY 8(d)'s backward formula for the levels the launch writes (dY read once + 2 x grad_input).
-        dom = ROOFLINE_OP
-        ops[dom]["ms_per_launch_timed_region"] = round(dom_ms_timed / counts[dom], 4)
-        if args.layout == "nhwc" and "pool_bwd_staged_r7" in ktimes:
-            # one launch for all FPN levels (LDS-staged tile gather): SURVEY 8(d)'s backward bytes of the whole op
-            k_ms, k_n = ktimes["pool_bwd_staged_r7"]
-            kb = alg[ROOFLINE_KERNEL_OP]
-            roof = {"bound": "hbm", "kernel": "pool_bwd_mfma_kernel<T, 8> (16-bit I/O; fp32: pool_bwd_staged_kernel<float, 4, 8>), the 7x7 (box head) pooler's tile gather over all FPN levels, inside roi_align_bwd",
-                    "achieved": round(kb / 1e9 / (k_ms / 1e3), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(kb / 1e9 / (k_ms / 1e3) / HBM_PEAK_GBS, 4),
-                    "traffic": pmc_traffic(ROOFLINE_KERNEL_OP, args.layout),
-                    "traffic_note": "PMC bytes of the box-head pooler backward (records + tile lists/zero fill + tile gather)",
-                    "alg_bytes_per_launch": int(kb), "ms_per_launch": round(k_ms, 4), "launches_timed": k_n,
-                    "timing": "HIP events recorded by the library on the kernel's launch stream right around the launch, "
-                              "mean over the timed steps",
-                    "op": {"name": dom, "alg_bytes": int(alg[dom] / counts[dom]),
-                           "ms_per_launch_events_around_op": round(dom_ms_timed / counts[dom], 4),
-                           "frac": round(alg[dom] / counts[dom] / 1e9 / (dom_ms_timed / counts[dom] / 1e3) / HBM_PEAK_GBS, 4)},
-                    "kernels_ms": {k: round(v[0], 4) for k, v in ktimes.items()}}
-        elif args.layout == "nhwc" and "pool_bwd_fine_r7" in ktimes:
-            k_ms, k_n = ktimes["pool_bwd_fine_r7"]
-            kb = w.alg_bytes_bwd_kernel("box", fine=True)
-            roof = {"bound": "hbm", "kernel": "pool_bwd_nhwc_kernel (fine FPN levels) of roi_align_box_bwd",
-                    "achieved": round(kb / 1e9 / (k_ms / 1e3), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(kb / 1e9 / (k_ms / 1e3) / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, args.layout),
-                    "traffic_note": "PMC bytes are for the whole op (both tile-gather launches + records)",
-                    "alg_bytes_per_launch": int(kb), "ms_per_launch": round(k_ms, 4), "launches_timed": k_n,
-                    "timing": "HIP events recorded by the library on the kernel's launch stream right around the launch, "
-                              "mean over the timed steps",
-                    "op": {"name": dom, "alg_bytes": int(alg[dom] / counts[dom]),
-                           "ms_per_launch_events_around_op": round(dom_ms_timed / counts[dom], 4),
-                           "frac": round(alg[dom] / counts[dom] / 1e9 / (dom_ms_timed / counts[dom] / 1e3) / HBM_PEAK_GBS, 4)},
-                    "kernels_ms": {k: round(v[0], 4) for k, v in ktimes.items()}}
+        if gpu:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
-            per_launch_bytes = alg[dom] / counts[dom]
-            achieved = per_launch_bytes / 1e9 / (dom_ms_timed / counts[dom] / 1e3)
-            roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, args.layout),
-                    "alg_bytes_per_launch": int(per_launch_bytes), "ms_per_launch": round(dom_ms_timed / counts[dom], 4),
-                    "timing": "HIP events on the launch stream around the op (kernels + fork/join), mean over the timed steps"}
-        gpu_ms = sum(v["ms_per_step"] for v in ops.values())
-        out = {
-            "metric": "img/s through the Mask R-CNN R50-FPN detection hot path (training ops), 1333x800 bs=2/GPU",
-            "value": round(world * w.n_img * args.steps / elapsed, 2), "unit": "img/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
-            "data": "synthetic",
-            "config": {"workload": "maskrcnn_r50fpn_train_hotpath_bs2_800x1344 (BASELINE configs[1])",
-                       "layout": args.layout, "global_batch": world * w.n_img,
-                       "ops_per_step": counts,
-                       "parallelism": f"dp{world} (images sharded, no data-path collective)"},
-            "roofline": roof, "gpu_ms_per_step_sum_of_ops": round(gpu_ms, 4), "ops": ops,
-            "ops_note": f"per-op times: separate untimed pass of {bsteps} steps with HIP events around every op",
-        }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(w)
-        print(json.dumps(out))
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctx = {"dev": dev, "rank": rank, "world": world, "dist": dist}
+    if args.plumbing_only:
+        out = bench_plumbing(args, ctx)
+    else:
+        out = {"maskrcnn_train": bench_maskrcnn, "retinanet_100k": bench_retinanet, "dcn_r50": bench_dcn}[args.workload](args, ctx)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

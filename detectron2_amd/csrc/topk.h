@@ -5,7 +5,7 @@
 namespace d2amd {
 
 constexpr int TOPK_MAX_LEVELS = 8;
-constexpr int TOPK_MAX_K = 16384;  // per segment: the final ordering is an LDS bitonic sort of 64-bit keys (128 KB)
+constexpr int TOPK_MAX_K = 65536;  // per segment: ordered in LDS runs of 16,384 (128 KB) merged by rank (topk.hip)
 
 // Scores of N images x L levels.  Element i of (image, level l) lives at ptr[l][image * stride[l] + i].
 struct TopkInput {

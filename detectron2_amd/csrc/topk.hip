@@ -347,18 +347,27 @@ __global__ __launch_bounds__(TK_THREADS) void tk_compact_kernel(TkParams P, SegS
   }
 }
 
-// one workgroup per segment: bitonic sort of the selected (key : index) pairs in LDS, write the indices
+// Final ordering of the <= k selected (key : index) pairs of a segment.  One workgroup bitonic-sorts a RUN of up to
+// TK_RUN pairs in LDS (128 KB); a segment with more (RetinaNet with TOPK_CANDIDATES_TEST 20000: BASELINE configs[3])
+// is cut into runs, every run is sorted by its own workgroup and written back, and tk_merge_kernel places every
+// element at  rank = position in its run + sum over the other runs of #elements below it  (binary searches; the
+// 64-bit keys are unique, so the ranks are a permutation).
+constexpr int TK_RUN = 16384;
+
 __global__ __launch_bounds__(1024) void tk_sort_kernel(TkParams P, const SegState* __restrict__ st,
-                                                      const unsigned long long* __restrict__ cand, int kmax, int pow2,
+                                                      unsigned long long* __restrict__ cand, int kmax,
                                                       uint32_t* __restrict__ sel, int* __restrict__ cnt_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long sk[];
   const int seg = blockIdx.x, l = seg % P.in.L, img = seg / P.in.L;
   const int tid = threadIdx.x;
-  const int n = st[seg].cnt;
-  if (tid == 0) cnt_out[seg] = n;
+  const int total = st[seg].cnt;
+  if (tid == 0 && blockIdx.y == 0) cnt_out[seg] = total;
+  const int lo = blockIdx.y * TK_RUN;
+  if (lo >= total && blockIdx.y > 0) return;
+  const int n = min(total - lo, TK_RUN);
   int p2 = 1;
-  while (p2 < n) p2 <<= 1;  // uniform; <= pow2
-  const unsigned long long* in = cand + (long)seg * kmax;
+  while (p2 < n) p2 <<= 1;  // uniform
+  unsigned long long* in = cand + (long)seg * kmax + lo;
   for (int i = tid; i < p2; i += 1024) sk[i] = i < n ? in[i] : ~0ull;
   __syncthreads();
   // element i is handled by thread i % 1024: for j < 64 the partner i ^ j belongs to the same wave, whose LDS
@@ -377,8 +386,39 @@ __global__ __launch_bounds__(1024) void tk_sort_kernel(TkParams P, const SegStat
       else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
   }
+  if (total <= TK_RUN) {  // single run: done
+    uint32_t* o = sel + (long)img * P.in.koff[P.in.L] + P.in.koff[l];
+    for (int i = tid; i < n; i += 1024) o[i] = (uint32_t)sk[i];
+  } else {
+    for (int i = tid; i < n; i += 1024) in[i] = sk[i];  // the sorted run, in place (this workgroup owns the range)
+  }
+}
+
+__global__ __launch_bounds__(256) void tk_merge_kernel(TkParams P, const SegState* __restrict__ st,
+                                                      const unsigned long long* __restrict__ cand, int kmax,
+                                                      uint32_t* __restrict__ sel) {
+  const int seg = blockIdx.x, l = seg % P.in.L, img = seg / P.in.L;
+  const int total = st[seg].cnt;
+  if (total <= TK_RUN) return;  // tk_sort_kernel wrote the result
+  const int runs = (total + TK_RUN - 1) / TK_RUN;
+  const unsigned long long* base = cand + (long)seg * kmax;
   uint32_t* o = sel + (long)img * P.in.koff[P.in.L] + P.in.koff[l];
-  for (int i = tid; i < n; i += 1024) o[i] = (uint32_t)sk[i];
+  for (int i = blockIdx.y * 256 + threadIdx.x; i < total; i += gridDim.y * 256) {
+    const unsigned long long key = base[i];
+    const int own = i / TK_RUN;
+    int rank = i - own * TK_RUN;
+    for (int r = 0; r < runs; r++) {
+      if (r == own) continue;
+      const unsigned long long* run = base + (long)r * TK_RUN;
+      int lo = 0, hi = min(total - r * TK_RUN, TK_RUN);  // first position whose key is >= key (keys are unique)
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (run[mid] < key) lo = mid + 1; else hi = mid;
+      }
+      rank += lo;
+    }
+    o[rank] = (uint32_t)key;
+  }
 }
 
 struct TkWs { SegState* st; int* hist; int* blk_ties; unsigned long long* cand; size_t zero_bytes, total; int maxblk, kmax, reps, tickets; };
@@ -447,12 +487,18 @@ int topk_select(const TopkInput& in, bool use_thr, float xmin, uint32_t* sel, in
   if (!w.tickets) hipLaunchKernelGGL(tk_ties_scan_kernel, segs, block, 0, s, P, w.st, w.blk_ties);
   hipLaunchKernelGGL(tk_compact_kernel, grid, block, 0, s, P, w.st, w.blk_ties, w.cand, w.kmax);
   int pow2 = 1;
-  while (pow2 < w.kmax) pow2 <<= 1;
+  while (pow2 < w.kmax && pow2 < TK_RUN) pow2 <<= 1;
   if ((size_t)pow2 * 8 > 64 * 1024)  // dynamic LDS beyond the default limit
     D2_HIP_OK(hipFuncSetAttribute((const void*)tk_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pow2 * 8));
-  hipLaunchKernelGGL(tk_sort_kernel, dim3(in.N * in.L), dim3(1024), (size_t)pow2 * 8, s, P, w.st, w.cand, w.kmax, pow2, sel,
-                     cnt);
+  const int runs = (w.kmax + TK_RUN - 1) / TK_RUN;
+  hipLaunchKernelGGL(tk_sort_kernel, dim3(in.N * in.L, runs), dim3(1024), (size_t)pow2 * 8, s, P, w.st, w.cand, w.kmax,
+                     sel, cnt);
   D2_LAUNCH_OK();
+  if (runs > 1) {
+    hipLaunchKernelGGL(tk_merge_kernel, dim3(in.N * in.L, cdiv(w.kmax, 1024)), dim3(256), 0, s, P, w.st, w.cand, w.kmax,
+                       sel);
+    D2_LAUNCH_OK();
+  }
   return D2AMD_OK;
 }
 

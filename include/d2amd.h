@@ -174,7 +174,7 @@ int d2amd_match_quality_matrix(const float* quality, int M, int N, const float* 
  *   boxes [N,Ktot,4], scores [N,Ktot], valid [N,Ktot] uint8 (finite and both sides > min_box_size after the
  *   clip; invalid rows hold a zero box and score -inf), level [Ktot] int64, flags [1] int32 (bit 0: a
  *   non-finite box or score was seen -- the reference raises FloatingPointError in training).
- * The selection is a segmented radix select (csrc/topk.hip) for pre_nms_topk <= 16384, a full radix sort above.
+ * The selection is a segmented radix select (csrc/topk.hip) for pre_nms_topk <= 65536, a full radix sort above.
  * Nothing synchronises with the host. */
 #define D2AMD_RPN_MAX_LEVELS 8
 size_t d2amd_rpn_select_workspace_bytes(int N, int Atot);
@@ -192,7 +192,7 @@ int d2amd_rpn_select_proposals(const float* logits, const float* deltas, const f
  *   anchors[l] [A_l, 4] xyxy;  level_anchors (host) [L] = A_l;  K = num_classes.
  * Per (image, level): the candidates are the (anchor, class) pairs with sigmoid(logit) > score_thresh; the
  * min(topk_candidates, #candidates) best are selected by a segmented radix select (no sort of the A_l*K scores, no
- * host sync; ties: lower flattened index a*K + c first; topk_candidates <= 16384), decoded WITHOUT clipping.
+ * host sync; ties: lower flattened index a*K + c first; topk_candidates <= 65536), decoded WITHOUT clipping.
  * Outputs, [N, Ktot] row-major, Ktot = sum_l min(A_l*K, topk_candidates), levels in order, best first inside a
  * level: boxes [N,Ktot,4], scores [N,Ktot] (= sigmoid(logit)), classes [N,Ktot] int64, valid [N,Ktot] uint8 (rows
  * past a segment's count: zero box, score -inf, class 0, valid 0), counts [N,L] int32, logits_out [N,Ktot] or NULL

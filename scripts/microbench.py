@@ -62,7 +62,7 @@ def main():
             extra[name] = {"GFLOP": round(flops / 1e9, 2), "TFLOPs": round(flops / 1e9 / ms, 1),
                            "frac_mfma_bf16": round(flops / 1e9 / ms / MFMA_BF16, 4)}
 
-    rec("pairwise_iou_rpn(16x268569)", timeit(lambda: pairwise_iou(w.gt[0], w.anchors)), alg["pairwise_iou_rpn"] / 2)
+    rec("pairwise_iou_rpn(16x268569)", timeit(lambda: pairwise_iou(w.gt[0], w.anchors)), 16 * (16 + 268569) + 4 * 16 * 268569)
     rec("pairwise_iou_roi(16x1016)", timeit(lambda: pairwise_iou(w.gt[0], w.props[0])))
     # fused IoU + Matcher (f3), batch NMS in one call and the fused RPN proposal path (f2)
     from detectron2_amd.layers import batched_nms_images

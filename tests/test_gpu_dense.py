@@ -80,7 +80,8 @@ def test_dense_select_golden_heavy_ties(golden_dir):
         np.testing.assert_allclose(got[0], wb, rtol=2e-6, atol=1e-3)
 
 
-@pytest.mark.parametrize("case", ["retinanet_800x1344", "small_ragged", "all_pass", "none_pass", "big_k"])
+@pytest.mark.parametrize("case", ["retinanet_800x1344", "small_ragged", "all_pass", "none_pass", "big_k", "k20000_two_runs",
+                                  "k50000_four_runs"])
 def test_dense_select_vs_oracle(case):
     rng = np.random.default_rng(zlib.crc32(case.encode()) % 1000)  # a fixed seed per case
     if case == "retinanet_800x1344":  # BASELINE configs[3] shapes: 9 anchors / location, 80 classes, 2 images
@@ -90,6 +91,10 @@ def test_dense_select_vs_oracle(case):
         N, K, sizes, thr, topk, mean = 3, 7, [1000, 1, 0, 37], 0.2, 64, -1.0
     elif case == "big_k":  # 10,000 selected per segment: 16,384-entry LDS sort (128 KB of dynamic LDS)
         N, K, sizes, thr, topk, mean = 2, 4, [3000, 2600], 0.0, 10000, 0.0
+    elif case == "k20000_two_runs":  # BASELINE configs[3]: TOPK_CANDIDATES_TEST 20000 -> two LDS runs + rank merge
+        N, K, sizes, thr, topk, mean = 2, 8, [6000, 2400, 1000], 0.0, 20000, 0.0
+    elif case == "k50000_four_runs":  # four runs, the last one partial; second level below one run
+        N, K, sizes, thr, topk, mean = 1, 8, [7000, 1500], 0.0, 50000, 0.0
     elif case == "all_pass":
         N, K, sizes, thr, topk, mean = 1, 3, [5000, 10], 0.0, 100, 2.0
     else:
@@ -199,7 +204,7 @@ def test_dense_detector_inference_fused_matches_oracle():
 def test_dense_select_errors():
     a = [torch.zeros(4, 4, device=DEV)]
     with pytest.raises(RuntimeError):  # topk beyond the LDS ordering limit
-        dense_select_predictions(a, [torch.zeros(1, 4, 2, device=DEV)], [torch.zeros(1, 4, 4, device=DEV)], 0.05, 20000)
+        dense_select_predictions(a, [torch.zeros(1, 4, 2, device=DEV)], [torch.zeros(1, 4, 4, device=DEV)], 0.05, 70000)
     with pytest.raises(NotImplementedError):  # CPU tensors: no fallback
         dense_select_predictions([torch.zeros(4, 4)], [torch.zeros(1, 4, 2)], [torch.zeros(1, 4, 4)], 0.05, 10)
     b, s, c, v, n = dense_select_predictions(a, [torch.zeros(0, 4, 2, device=DEV)], [torch.zeros(0, 4, 4, device=DEV)], 0.05, 10)

@@ -134,7 +134,7 @@ def test_round1_late_entries_host_checks(lib):
     lv = (ctypes.c_int * 2)(9 * 16800, 9 * 4200)
     small = lib.d2amd_dense_select_workspace_bytes(1, lv, 2, 80, 1000)
     assert small > 2 * 1000 * 8 and lib.d2amd_dense_select_workspace_bytes(2, lv, 2, 80, 1000) > small
-    rc = lib.d2amd_dense_select_predictions(None, None, None, 1, lv, 2, 80, 0.05, 20000, None, 0.0, None, None, None, None,
+    rc = lib.d2amd_dense_select_predictions(None, None, None, 1, lv, 2, 80, 0.05, 70000, None, 0.0, None, None, None, None,
                                             None, None, None, 0, None)
     assert rc == -1 and b"topk" in lib.d2amd_last_error()
     # pooler forward from un-concatenated box lists: too many images
