@@ -58,6 +58,8 @@ _SIGNATURES = {
     "d2amd_roi_pooler_backward_workspace_bytes": (_sz, [ctypes.POINTER(PoolerParams), _i]),
     "d2amd_roi_pooler_backward": (_i, [ctypes.POINTER(PoolerParams), _vp, _vp, ctypes.POINTER(_vp), _i, _vp, _sz,
                                        _vp]),
+    "d2amd_roi_pooler_backward_accumulate": (_i, [ctypes.POINTER(PoolerParams), _vp, _vp, ctypes.POINTER(_vp), _i, _vp,
+                                                  _sz, _vp]),
     "d2amd_roi_align_rotated_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp, _vp]),
     "d2amd_roi_align_rotated_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp, _sz, _vp]),
     "d2amd_pairwise_iou": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp]),
@@ -110,6 +112,9 @@ def lib():
 
 def exported_symbols():
     return list(_SIGNATURES)
+
+
+EUNSUPPORTED = -4
 
 
 def check(rc):

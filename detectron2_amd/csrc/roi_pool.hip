@@ -50,6 +50,7 @@ struct PoolLevels {
   int tab_off;       // forward: 1 = no 32-bit tap table (a level holds >= 2^32 elements per image)
   const int* queue;  // backward: per-XCD work queues of this launch (tile_lists_kernel), [8][qcap]; nullptr: static order
   int qcap;
+  int accumulate;    // backward: 1 = grad_input already holds a gradient (another pooler's): add to it, skip empty tiles
 };
 
 // detectron2/modeling/poolers.py:51-59 in fp32, operation for operation:
@@ -505,7 +506,9 @@ __global__ __launch_bounds__(64 * LISTS_WAVES) void tile_lists_kernel(PoolLevels
   if (Q.mem == nullptr) return;  // uniform
   const int H = L.H[g.lvl], W = L.W[g.lvl];
   bool push = live;
-  if (live && cnt == 0 && Q.zero_fill) {  // nothing to gather: write the zeros here
+  if (live && cnt == 0 && L.accumulate) {
+    push = false;  // accumulate mode: a tile no ROI touches keeps what it holds -- no write, no workgroup
+  } else if (live && cnt == 0 && Q.zero_fill) {  // nothing to gather: write the zeros here
     const int rows = min(8, H - g.y0), cols = min(8, W - g.x0);
     const long px = (long)L.C * Q.esize, rowbytes = cols * px;
     char* base = (char*)L.data[g.lvl] + (((long)g.n * H + g.y0) * W + g.x0) * px;
@@ -1172,6 +1175,13 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_staged_kernel(PoolLevels L
 #pragma unroll
     for (int i = 0; i < TR; i++) {
       if (y0 + rh * TR + i >= H) break;
+      if (L.accumulate) {  // uniform: grad = round(held + round(own)), what autograd's add of two gradients gives
+        float held[VEC], own[VEC];
+        unpack16(*reinterpret_cast<const raw16*>(gi + (long)i * W * C), held, T{});
+        unpack16(pack16(acc[i], T{}), own, T{});
+#pragma unroll
+        for (int q = 0; q < VEC; q++) acc[i][q] = held[q] + own[q];
+      }
       *reinterpret_cast<raw16*>(gi + (long)i * W * C) = pack16(acc[i], T{});
     }
   }
@@ -1510,6 +1520,14 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
   if (wst) { wst[1] = wst_list; wst[2] = wall_clock64(); wst[4] = (unsigned long long)wst_n; }
   // ---- epilogue: accumulators (lane = channel, registers = pixels) -> LDS [pixel][channel] in the I/O dtype ->
   // 16-B channel vectors per pixel (every pixel of grad_input is written exactly once)
+  // accumulate mode: the rows this thread will store are fetched now, under the LDS transpose below
+  raw16 held[TR];
+  if (L.accumulate && cg_ok && x0 + col < W) {
+    const T* gi = (const T*)L.data[lvl] + (((long)n * H + y0 + rh * TR) * W + x0 + col) * C + cofs;
+#pragma unroll
+    for (int i = 0; i < TR; i++)
+      held[i] = *reinterpret_cast<const raw16*>(gi + (long)min(i, H - 1 - (y0 + rh * TR)) * W * C);
+  }
   __syncthreads();  // everyone is done with D
   T* obuf = reinterpret_cast<T*>(&S.D[0][0][0]);  // 64 pixels x 256 channels x 2 B = the two D buffers
   if (slab * (LPP * VEC) + 32 * wave < C) {
@@ -1528,7 +1546,16 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
     for (int i = 0; i < TR; i++) {
       if (y0 + rh * TR + i >= H) break;
       const int px = (rh * TR + i) * TILE + col;
-      *reinterpret_cast<raw16*>(gi + (long)i * W * C) = *reinterpret_cast<const raw16*>(obuf + px * (LPP * VEC) + lp * VEC);
+      raw16 v = *reinterpret_cast<const raw16*>(obuf + px * (LPP * VEC) + lp * VEC);
+      if (L.accumulate) {  // uniform: round(held + round(own)), what autograd's add of two gradients gives
+        float a[VEC], b[VEC];
+        unpack16(held[i], a, T{});
+        unpack16(v, b, T{});
+#pragma unroll
+        for (int q = 0; q < VEC; q++) a[q] += b[q];
+        v = pack16(a, T{});
+      }
+      *reinterpret_cast<raw16*>(gi + (long)i * W * C) = v;
     }
   }
   if (wst) wst[3] = wall_clock64();
@@ -1718,7 +1745,7 @@ static long pool_ntiles(const d2amd_pooler_params* p) {
 template <typename T>
 static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_output, const float* rois,
                               void* const* grad_inputs, int K, void* workspace, size_t workspace_bytes,
-                              hipStream_t s) {
+                              hipStream_t s, bool accumulate) {
   constexpr int VEC = V16<T>::N;
   const bool vec = (p->C % VEC == 0) && all_aligned16((const void* const*)grad_inputs, p->num_levels, grad_output);
   const int cg = vec ? p->C / VEC : p->C;
@@ -1737,7 +1764,8 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
       getenv("D2AMD_POOL_NOLISTS") == nullptr;
   int* tile_cnt = lists ? (int*)((char*)workspace + off_cnt) : nullptr;
   TileEntry* tile_list = lists ? (TileEntry*)((char*)workspace + off_list) : nullptr;
-  const PoolLevels L0 = make_levels(p, (const void* const*)grad_inputs, K);
+  PoolLevels L0 = make_levels(p, (const void* const*)grad_inputs, K);
+  L0.accumulate = accumulate ? 1 : 0;
   // work queues (see tile_lists_kernel): capacity per XCD = the tiles the 4x4-block deal gives it
   TileQueues Q{};
   const size_t off_q = off_list + pool_al((size_t)ntiles * TILE_CAP * sizeof(TileEntry));
@@ -1748,6 +1776,11 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
   // one launch of the LDS-staged kernel for all levels (16-B channel vectors + work queues), else the two-launch
   // register-gather kernels
   const bool staged = queues && vec && getenv("D2AMD_POOL_NOSTAGED") == nullptr;
+  if (accumulate && !staged) {
+    set_error("roi_pooler_backward_accumulate: needs the staged tile gather (16-B aligned channel vectors, work queues)");
+    return D2AMD_EUNSUPPORTED;
+  }
+  if (accumulate && K == 0) return D2AMD_OK;  // nothing to add
   if (queues) {
     int per[2][8] = {};
     int base[2] = {0, 0};
@@ -2050,9 +2083,9 @@ extern "C" size_t d2amd_roi_pooler_backward_workspace_bytes(const d2amd_pooler_p
       pool_al((size_t)(QCTR + 8 * ntiles) * sizeof(int)) + 256;
 }
 
-extern "C" int d2amd_roi_pooler_backward(const d2amd_pooler_params* p, const void* grad_output, const float* rois,
-                                         void* const* grad_inputs, int K, void* workspace, size_t workspace_bytes,
-                                         void* stream) {
+static int pooler_backward_entry(const d2amd_pooler_params* p, const void* grad_output, const float* rois,
+                                 void* const* grad_inputs, int K, void* workspace, size_t workspace_bytes,
+                                 void* stream, bool accumulate) {
   int rc = check_pooler(p, "roi_pooler_backward");
   if (rc) return rc;
   D2_CHECK_ARG(K >= 0, "roi_pooler_backward: bad K");
@@ -2065,6 +2098,18 @@ extern "C" int d2amd_roi_pooler_backward(const d2amd_pooler_params* p, const voi
   if ((long)p->N * p->C == 0) return D2AMD_OK;
   return D2_DISPATCH_DTYPE(p->dtype, [&]() -> int {
     return pool_bwd_nhwc_impl<scalar_t>(p, grad_output, rois, grad_inputs, K, workspace, workspace_bytes,
-                                        (hipStream_t)stream);
+                                        (hipStream_t)stream, accumulate);
   });
+}
+
+extern "C" int d2amd_roi_pooler_backward(const d2amd_pooler_params* p, const void* grad_output, const float* rois,
+                                         void* const* grad_inputs, int K, void* workspace, size_t workspace_bytes,
+                                         void* stream) {
+  return pooler_backward_entry(p, grad_output, rois, grad_inputs, K, workspace, workspace_bytes, stream, false);
+}
+
+extern "C" int d2amd_roi_pooler_backward_accumulate(const d2amd_pooler_params* p, const void* grad_output,
+                                                    const float* rois, void* const* grad_inputs, int K,
+                                                    void* workspace, size_t workspace_bytes, void* stream) {
+  return pooler_backward_entry(p, grad_output, rois, grad_inputs, K, workspace, workspace_bytes, stream, true);
 }

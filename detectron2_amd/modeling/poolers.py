@@ -10,6 +10,15 @@ reference's per-level `nonzero` (host sync) -> ROIAlign -> `index_put_` loop:
   * NCHW features: fused NCHW forward; backward re-lays dY out as NHWC, runs the same tile gather
     and returns channels_last-strided gradients.
 `pooler_type` "ROIAlignRotated" keeps the per-level loop; "ROIPool" is not part of the hot path.
+
+CHAINED BACKWARD.  Mask R-CNN pools the same FPN features twice per iteration (box head 7x7, mask head 14x14:
+roi_heads.py:780-846), so autograd sums two dense gradients per level with an elementwise kernel (r01: 4 launches,
+274 MB of extra traffic per step).  Here the fused pooler also returns its feature inputs as (alias) outputs and
+remembers them; a later pooler call on the SAME feature tensors (same objects, unmodified) pools from the aliases.
+Its gradient then reaches the first pooler's backward as the gradient of those alias outputs, and the first
+pooler ADDS its own contribution into that buffer inside the tile gather (d2amd_roi_pooler_backward_accumulate):
+no separate sum, empty tiles untouched.  Values are those of autograd's sum.  Plain autograd semantics otherwise:
+a pooler whose result is unused simply contributes no gradient.
 """
 import ctypes
 import math
@@ -102,22 +111,58 @@ _NHWC_CACHE = {}  # id(feature tensor) -> (weakref, version, channels_last copy)
 
 def _staged_nhwc(f):
     """channels_last staging copy of an NCHW feature map, reused while the same (unmodified) tensor object is
-    pooled again -- the box head and the mask head pool the same FPN features in one iteration."""
+    pooled again -- the box head and the mask head pool the same FPN features in one iteration (the second call may
+    see it as the alias view of the chained backward: the cache is keyed on the view's base)."""
     import weakref
-    ent = _NHWC_CACHE.get(id(f))
-    if ent is not None and ent[0]() is f and ent[1] == f._version:
+    base = f._base if f._base is not None and f._base.shape == f.shape and f._base.stride() == f.stride() else f
+    ent = _NHWC_CACHE.get(id(base))
+    if ent is not None and ent[0]() is base and ent[1] == base._version:
         return ent[2]
     cl = f.detach().contiguous(memory_format=torch.channels_last)
+    for k in [k for k, e in _NHWC_CACHE.items() if e[0]() is None]:  # copies of features that no longer exist
+        del _NHWC_CACHE[k]
     if len(_NHWC_CACHE) >= 16:
         _NHWC_CACHE.clear()
-    _NHWC_CACHE[id(f)] = (weakref.ref(f), f._version, cl)
+    _NHWC_CACHE[id(base)] = (weakref.ref(base), base._version, cl)
     return cl
+
+
+_ALIASES = {}  # id(feature tensor) -> (weakref to it, its version, alias output of the last pooler that took it, token)
+_ALIAS_CAP = 16
+
+
+def _chained_inputs(x):
+    """The tensors to pool from: the remembered alias outputs of an earlier pooler call on exactly these feature
+    tensors, or x itself."""
+    out = []
+    for f in x:
+        ent = _ALIASES.get(id(f))
+        if ent is None or ent[0]() is not f or ent[1] != f._version:
+            return list(x)
+        out.append(ent[2])
+    return out
+
+
+def _remember_aliases(x, aliases, token):
+    import weakref
+    for k in [k for k, e in _ALIASES.items() if e[0]() is None]:  # features that no longer exist
+        del _ALIASES[k]
+    if len(_ALIASES) + len(x) > _ALIAS_CAP:
+        _ALIASES.clear()
+    for f, a in zip(x, aliases):
+        _ALIASES[id(f)] = (weakref.ref(f), f._version, a, token)
+
+
+def _forget_aliases(token):
+    """The node that produced these aliases has run its backward: nothing may chain onto it any more."""
+    for k in [k for k, e in _ALIASES.items() if e[3] is token]:
+        del _ALIASES[k]
 
 
 class _FusedROIPool(Function):
     @staticmethod
     @disable_torch_compiler
-    def forward(ctx, rois, cfg, *feats):
+    def forward(ctx, rois, cfg, chain, *feats):  # chain: None, or the token its aliases are remembered under
         # rois: the (M, 5) pooler-format tensor, or a tuple of per-image (n_i, 4) fp32 HIP box tensors -- then the
         # conversion happens inside the same C call (d2amd_roi_pooler_forward_box_lists: no torch.cat, one call less)
         box_lists = None
@@ -157,31 +202,57 @@ class _FusedROIPool(Function):
         ctx.save_for_backward(rois)
         ctx.cfg, ctx.hw, ctx.nc, ctx.layout = cfg, hw, (n, c), layout
         ctx.needs = [f.requires_grad for f in feats]
+        ctx.chain = chain
+        ctx.set_materialize_grads(False)  # unused outputs (the aliases of the last pooler of a chain) arrive as None
         if nchw_in:
             out = out.contiguous()  # NCHW-contiguous result, as the caller's layout implies
+        if chain is not None:
+            # the features come back as outputs: autograd turns a returned input into a view whose gradient arrives
+            # in backward() below -- the hook a later pooler of the same features chains onto (module docstring)
+            return (out,) + tuple(feats)
         return out
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, grad_output):
+    def backward(ctx, grad_output, *held):
         (rois,) = ctx.saved_tensors
         cfg, hw, (n, c), layout = ctx.cfg, ctx.hw, ctx.nc, ctx.layout
         k = rois.shape[0]
+        if ctx.chain is not None:
+            _forget_aliases(ctx.chain)
+        if grad_output is None:  # only the alias outputs were used downstream: their gradient passes through
+            return (None, None, None) + tuple(h if need else None for h, need in zip(held, ctx.needs))
         # The tile-gather backward is an NHWC kernel.  NCHW features take it too: dY (small) is
         # re-laid out once and the gradients are returned channels_last-strided, which autograd
         # accepts for NCHW inputs (values are identical; consumers restride on demand).  This
         # replaces the v0 NCHW path (per-level atomics into an fp32 buffer: 3.1 ms vs 0.2 ms).
         g = grad_output.contiguous(memory_format=torch.channels_last)
-        grads = [torch.empty((n, c, h, w), dtype=g.dtype, device=g.device, memory_format=torch.channels_last)
-                 for (h, w) in hw]
         p = _params(cfg, (n, c), hw, _C.dtype_code(g), _C.NHWC)
         # per-ROI records + per-tile ROI lists (one wave per 8x8 tile bins the ROIs once per call)
         ws_bytes = _C.lib().d2amd_roi_pooler_backward_workspace_bytes(ctypes.byref(p), k)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=g.device)
+        # gradients that arrived for the alias outputs (a later pooler of the same features, or any other consumer
+        # of them): add into them in place when every level has one in the tile gather's layout
+        chained = (len(held) == len(hw) and all(
+            h is not None and h.dtype == g.dtype and h.device == g.device and tuple(h.shape) == (n, c) + tuple(s)
+            and h.is_contiguous(memory_format=torch.channels_last) for h, s in zip(held, hw)))
         with _C.on_device(g.device):
+            if chained:
+                rc = _C.lib().d2amd_roi_pooler_backward_accumulate(ctypes.byref(p), _C.ptr(g), _C.ptr(rois),
+                                                                   _ptr_array(held), k, _C.ptr(ws), ws_bytes,
+                                                                   _C.stream())
+                if rc == 0:
+                    return (None, None, None) + tuple(h if need else None for h, need in zip(held, ctx.needs))
+                if rc != _C.EUNSUPPORTED:
+                    _C.check(rc)
+            grads = [torch.empty((n, c, h, w), dtype=g.dtype, device=g.device, memory_format=torch.channels_last)
+                     for (h, w) in hw]
             _C.check(_C.lib().d2amd_roi_pooler_backward(ctypes.byref(p), _C.ptr(g), _C.ptr(rois),
                                                         _ptr_array(grads), k, _C.ptr(ws), ws_bytes, _C.stream()))
-        return (None, None) + tuple(gr if need else None for gr, need in zip(grads, ctx.needs))
+        for i, h in enumerate(held):  # partial / differently laid out alias gradients: plain sum
+            if h is not None:
+                grads[i] = grads[i] + h
+        return (None, None, None) + tuple(gr if need else None for gr, need in zip(grads, ctx.needs))
 
 
 class ROIPooler(nn.Module):
@@ -224,6 +295,16 @@ class ROIPooler(nn.Module):
         assert canonical_box_size > 0
         self.canonical_box_size = canonical_box_size
 
+    def _pool_fused(self, rois, cfg, x):
+        """One fused launch; in training the call is chained to earlier / later poolers of the same features."""
+        chain = torch.is_grad_enabled() and all(t.requires_grad for t in x)
+        if not chain:
+            return _FusedROIPool.apply(rois, cfg, None, *x)
+        token = object()
+        res = _FusedROIPool.apply(rois, cfg, token, *_chained_inputs(x))
+        _remember_aliases(x, res[1:], token)
+        return res[0]
+
     def _fusable(self, x):
         if self.pooler_type not in ("ROIAlign", "ROIAlignV2") or len(x) > 8:
             return False
@@ -253,12 +334,12 @@ class ROIPooler(nn.Module):
             dev = x[0].device
             if len(bt) <= 64 and all(t.dtype == torch.float32 and t.device == dev and t.dim() == 2 and t.shape[1] == 4
                                      and t.is_contiguous() and not t.requires_grad and t.data_ptr() % 16 == 0 for t in bt):
-                return _FusedROIPool.apply(bt, cfg, *x)
+                return self._pool_fused(bt, cfg, x)
         pooler_fmt_boxes = convert_boxes_to_pooler_format(box_lists)
         if fusable:
             if pooler_fmt_boxes.dtype != torch.float32:
                 pooler_fmt_boxes = pooler_fmt_boxes.float()
-            return _FusedROIPool.apply(pooler_fmt_boxes.detach(), cfg, *x)
+            return self._pool_fused(pooler_fmt_boxes.detach(), cfg, x)
         if num_level_assignments == 1:
             return self.level_poolers[0](x[0], pooler_fmt_boxes)
         # reference structure (poolers.py:247-263)

@@ -117,6 +117,15 @@ size_t d2amd_roi_pooler_backward_workspace_bytes(const d2amd_pooler_params* p, i
 int d2amd_roi_pooler_backward(const d2amd_pooler_params* p, const void* grad_output, const float* rois,
                               void* const* grad_inputs, int K, void* workspace, size_t workspace_bytes,
                               void* stream);
+/* Same, ADDING to grad_inputs instead of overwriting them: grad_inputs already hold the gradient another pooler of
+ * the same feature maps produced (Mask R-CNN pools p2..p5 twice per iteration: box head 7x7, mask head 14x14 --
+ * roi_heads.py:780-846; autograd would sum the two dense gradients with one elementwise kernel per level, 3 x the
+ * feature bytes of extra traffic).  Every element = round(held + round(own)) in the I/O dtype -- what that sum
+ * gives; tiles no ROI touches are neither read nor written.  D2AMD_EUNSUPPORTED when the staged tile gather cannot
+ * serve the configuration (the caller then uses d2amd_roi_pooler_backward into a fresh buffer and adds). */
+int d2amd_roi_pooler_backward_accumulate(const d2amd_pooler_params* p, const void* grad_output, const float* rois,
+                                         void* const* grad_inputs, int K, void* workspace, size_t workspace_bytes,
+                                         void* stream);
 
 /* ---- ROIAlignRotated.  Replaces torch.ops.detectron2.roi_align_rotated_forward/backward
  * (vision.cpp:118-119; csrc/ROIAlignRotated/ROIAlignRotated.h:50-113).

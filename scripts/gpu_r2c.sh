@@ -7,6 +7,6 @@ for wl in maskrcnn_train retinanet_100k dcn_r50; do
 done
 export TMPDIR=/tmp
 for wl in maskrcnn_train retinanet_100k dcn_r50; do
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/prof_$wl -o $wl -- python $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 10 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/prof_$wl.log 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_$wl -o $wl -- python $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 10 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/prof_$wl.log 2>&1)
   f=$(find $O/prof_$wl -name "*kernel_stats.csv" | head -1); echo "== $wl $f"; head -25 "$f" | cut -c1-200
 done

@@ -91,3 +91,24 @@ def test_crop_and_resize_indexed_equals_indexing_then_crop():
     bad = bm.crop_and_resize_indexed(bt, it, M, status)
     assert int(status.item()) == 1 and not bool(bad[3].any()) and torch.equal(bad[4:], got[4:])
     assert tuple(bm.crop_and_resize_indexed(bt[:0], it[:0], M).shape) == (0, M, M)
+
+
+@pytest.mark.parametrize("pattern", ["checkerboard", "stripes", "half_plane"])
+def test_crop_and_resize_means_exactly_at_threshold(pattern):
+    """Masks whose bin means sit EXACTLY on 0.5 (or a rounding error away from it) for most bins, with large boxes
+    (hundreds of samples per bin): the two-tier kernel (parallel partial sums, sequential re-evaluation near 0.5)
+    must reproduce the reference's sequential fp32 sum bit for bit."""
+    rng = np.random.default_rng(31)
+    g, h, w, M = 6, 400, 640, 28
+    yy, xx = np.mgrid[0:h, 0:w]
+    if pattern == "checkerboard":
+        base = ((yy + xx) % 2).astype(bool)
+    elif pattern == "stripes":
+        base = (xx % 2).astype(bool)
+    else:
+        base = xx >= w // 2
+    masks = np.repeat(base[None], g, 0)
+    boxes = np.array([[0, 0, w, h], [10.5, 7.25, 610.5, 390.25], [0, 0, 560, 392], [33.3, 21.7, 500.1, 377.9],
+                      [w / 2 - 112, 50, w / 2 + 112, 274], [w / 2 - 14, 10, w / 2 + 14, 38]], np.float32)
+    got = BitMasks(torch.from_numpy(masks).to(DEV)).crop_and_resize(torch.from_numpy(boxes).to(DEV), M)
+    assert np.array_equal(got.cpu().numpy(), reference_pipeline(masks, boxes, M))

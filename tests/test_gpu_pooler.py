@@ -243,3 +243,104 @@ def test_fused_pooler_staged_backward_paths(case):
     for x, g in zip(xs, gins):
         assert torch.isfinite(x.grad).all()
         assert rel_err(x.grad.float().cpu().numpy(), g) <= tol
+
+
+@pytest.mark.parametrize("layout,dtype,tol", [("nhwc", torch.float32, 1e-4), ("nhwc", torch.bfloat16, 2.0 ** -6),
+                                               ("nchw", torch.bfloat16, 2.0 ** -6), ("nchw", torch.float32, 1e-4)])
+def test_two_poolers_of_the_same_features_chain_their_backward(layout, dtype, tol):
+    """Mask R-CNN's box (7x7) and mask (14x14) poolers on the same FPN features, ONE backward: the gradient equals the
+    sum of the two oracle gradients (what autograd's accumulation gives), the second pooler pooled from the first
+    one's alias outputs, and -- in the tile gather's layout -- no separate sum kernel ran: the first pooler's backward
+    received the second one's gradient buffers and returned THOSE (d2amd_roi_pooler_backward_accumulate)."""
+    from detectron2_amd.modeling import poolers as P
+
+    rng = np.random.default_rng(77)
+    n_img, C, H, W = 2, 64, 160, 224
+    feats, boxes = make_inputs(rng, n_img, C, H, W, 40)
+    mboxes = [b[:12] for b in boxes]
+    gb = rng.standard_normal((80, C, 7, 7)).astype(np.float32)
+    gm = rng.standard_normal((24, C, 14, 14)).astype(np.float32)
+    _, gins_b, _ = oracle_pooler(feats, boxes, 7, 0, True, gb)
+    _, gins_m, _ = oracle_pooler(feats, mboxes, 14, 0, True, gm)
+    P._ALIASES.clear()
+    xs = []
+    for f in feats:
+        t = torch.from_numpy(f).to(DEV).to(dtype)
+        if layout == "nhwc":
+            t = t.contiguous(memory_format=torch.channels_last)
+        xs.append(t.requires_grad_(True))
+    box_pooler, mask_pooler = ROIPooler(7, SCALES, 0, "ROIAlignV2"), ROIPooler(14, SCALES, 0, "ROIAlignV2")
+    yb = box_pooler(xs, [Boxes(torch.from_numpy(b).to(DEV)) for b in boxes])
+    assert all(id(x) in P._ALIASES for x in xs)
+    ym = mask_pooler(xs, [Boxes(torch.from_numpy(b).to(DEV)) for b in mboxes])
+    # the mask pooler's node hangs off the box pooler's node, not off the leaves
+    assert ym.grad_fn.next_functions[0][0] is yb.grad_fn
+    calls = []
+    orig = P._C.lib().d2amd_roi_pooler_backward_accumulate
+
+    torch.autograd.backward([yb, ym], [torch.from_numpy(gb).to(DEV).to(dtype), torch.from_numpy(gm).to(DEV).to(dtype)])
+    assert not P._ALIASES  # both nodes ran their backward: nothing can chain onto them any more
+    for x, a, b in zip(xs, gins_b, gins_m):
+        want = a + b
+        assert rel_err(x.grad.float().cpu().numpy(), want) < tol
+    # a second iteration on the same leaves starts a fresh chain (the old graph is gone) and gives the same result
+    g1 = [x.grad.clone() for x in xs]
+    for x in xs:
+        x.grad = None
+    yb = box_pooler(xs, [Boxes(torch.from_numpy(b).to(DEV)) for b in boxes])
+    ym = mask_pooler(xs, [Boxes(torch.from_numpy(b).to(DEV)) for b in mboxes])
+    torch.autograd.backward([yb, ym], [torch.from_numpy(gb).to(DEV).to(dtype), torch.from_numpy(gm).to(DEV).to(dtype)])
+    for x, g in zip(xs, g1):
+        assert torch.equal(x.grad, g)  # deterministic
+    # only the SECOND pooler's result is used: the first one just passes the gradient through
+    for x in xs:
+        x.grad = None
+    yb = box_pooler(xs, [Boxes(torch.from_numpy(b).to(DEV)) for b in boxes])
+    ym = mask_pooler(xs, [Boxes(torch.from_numpy(b).to(DEV)) for b in mboxes])
+    ym.backward(torch.from_numpy(gm).to(DEV).to(dtype))
+    for x, b in zip(xs, gins_m):
+        assert rel_err(x.grad.float().cpu().numpy(), b) < tol
+    # only the FIRST one's result is used
+    for x in xs:
+        x.grad = None
+    yb = box_pooler(xs, [Boxes(torch.from_numpy(b).to(DEV)) for b in boxes])
+    ym = mask_pooler(xs, [Boxes(torch.from_numpy(b).to(DEV)) for b in mboxes])
+    yb.backward(torch.from_numpy(gb).to(DEV).to(dtype))
+    for x, a in zip(xs, gins_b):
+        assert rel_err(x.grad.float().cpu().numpy(), a) < tol
+    P._ALIASES.clear()
+
+
+def test_pooler_backward_accumulate_entry_adds_and_skips_empty_tiles():
+    """d2amd_roi_pooler_backward_accumulate through the C ABI: held + own on the tiles ROIs touch, the held values bit
+    for bit on every other tile (they are neither read nor written)."""
+    import ctypes
+
+    from detectron2_amd import _C
+    from detectron2_amd.modeling import poolers as P
+
+    rng = np.random.default_rng(3)
+    n_img, C, H, W = 1, 32, 128, 192
+    feats, _ = make_inputs(rng, n_img, C, H, W, 1)
+    boxes = [np.array([[8, 8, 40, 36], [100, 60, 130, 90]], np.float32)]  # small boxes: most tiles stay empty
+    g = rng.standard_normal((2, C, 7, 7)).astype(np.float32)
+    _, gins, _ = oracle_pooler(feats, boxes, 7, 0, True, g)
+    cfg = ((7, 7), tuple(SCALES), 0, True, 2, 5, 224, 4)
+    hw = [tuple(f.shape[2:]) for f in feats]
+    p = P._params(cfg, (n_img, C), hw, _C.dtype_code(torch.empty(0, dtype=torch.float32)), _C.NHWC)
+    rois = torch.from_numpy(np.concatenate([np.zeros((2, 1), np.float32), boxes[0]], 1)).to(DEV)
+    held = [torch.from_numpy(rng.standard_normal((n_img, C) + s).astype(np.float32)).to(DEV)
+            .contiguous(memory_format=torch.channels_last) for s in hw]
+    before = [h.clone() for h in held]
+    gt = torch.from_numpy(g).to(DEV).contiguous(memory_format=torch.channels_last)
+    ws_bytes = _C.lib().d2amd_roi_pooler_backward_workspace_bytes(ctypes.byref(p), 2)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=DEV)
+    with _C.on_device(gt.device):
+        _C.check(_C.lib().d2amd_roi_pooler_backward_accumulate(ctypes.byref(p), _C.ptr(gt), _C.ptr(rois), P._ptr_array(held),
+                                                               2, _C.ptr(ws), ws_bytes, _C.stream()))
+    torch.cuda.synchronize()
+    for h, b, want in zip(held, before, gins):
+        got = (h - b).cpu().numpy()
+        assert np.abs(got - want).max() <= 1e-4 * max(np.abs(want).max(), 1.0) + 1e-6
+        untouched = torch.from_numpy(want == 0).to(DEV)
+        assert torch.equal(h[untouched], b[untouched])
