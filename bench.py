@@ -303,6 +303,7 @@ def read_kernel_times(names):
 def step(w, t=None, grads=None):
     from detectron2_amd.modeling import find_top_rpn_proposals_fused, mask_rcnn_loss_from_targets
     from detectron2_amd.modeling import poolers as _poolers
+    from detectron2_amd.structures import crop_and_resize_batch
 
     run = (lambda name, fn: t.run(name, fn)) if t is not None else (lambda name, fn: fn())
     # a training iteration produces NEW feature maps: drop the NHWC staging copies an NCHW run cached for the
@@ -318,9 +319,8 @@ def step(w, t=None, grads=None):
         run("match_proposals", lambda: w.proposal_matcher.match_boxes(w.gt[i], w.props_with_gt[i]))
     yb = run("roi_align_box_fwd", lambda: w.box_pooler(w.feats, w.box_lists))
     ym = run("roi_align_mask_fwd", lambda: w.mask_pooler(w.feats, w.mask_lists))
-    tg = run("mask_targets", lambda: torch.cat([
-        w.gt_masks[i].crop_and_resize_indexed(w.mask_lists[i].tensor, w.fg_gt_index[i], 28, w.crop_status)
-        for i in range(w.n_img)]))
+    tg = run("mask_targets", lambda: crop_and_resize_batch(
+        w.gt_masks, [b.tensor for b in w.mask_lists], 28, w.fg_gt_index, w.crop_status))
     loss, _stats = run("mask_loss_fwd", lambda: mask_rcnn_loss_from_targets(w.mask_logits, w.fg_classes, tg))
     # N > 1: the ROI heads' weight gradients exist before the poolers' backward runs -> their bucket's all-reduce
     # overlaps it; the remaining buckets (RPN head, FPN, backbone) follow the feature gradients

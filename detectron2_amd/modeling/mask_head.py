@@ -89,17 +89,24 @@ def mask_rcnn_loss(pred_mask_logits: torch.Tensor, instances: List, vis_period: 
     cls_agnostic_mask = pred_mask_logits.size(1) == 1
     mask_side_len = pred_mask_logits.size(2)
     assert pred_mask_logits.size(2) == pred_mask_logits.size(3), "Mask prediction must be square!"
-    gt_classes, gt_masks = [], []
+    from ..structures.masks import BitMasks, crop_and_resize_batch
+
+    gt_classes, per_img = [], []
     for per_image in instances:
         if len(per_image) == 0:
             continue
         if not cls_agnostic_mask:
             gt_classes.append(per_image.gt_classes.to(dtype=torch.int64))
-        gt_masks.append(per_image.gt_masks.crop_and_resize(per_image.proposal_boxes.tensor, mask_side_len)
-                        .to(device=pred_mask_logits.device))
-    if len(gt_masks) == 0:
+        per_img.append((per_image.gt_masks, per_image.proposal_boxes.tensor))
+    if len(per_img) == 0:
         return pred_mask_logits.sum() * 0
-    gt_masks = torch.cat(gt_masks, dim=0)
+    dev = pred_mask_logits.device
+    if (len(per_img) <= 64 and all(isinstance(m, BitMasks) and m.tensor.device == dev for m, _ in per_img)
+            and len({tuple(m.image_size) for m, _ in per_img}) == 1):
+        # bitmask targets of the whole batch in one launch (the reference loops over the images and concatenates)
+        gt_masks = crop_and_resize_batch([m for m, _ in per_img], [b for _, b in per_img], mask_side_len)
+    else:
+        gt_masks = torch.cat([m.crop_and_resize(b, mask_side_len).to(device=dev) for m, b in per_img], dim=0)
     cls = None if cls_agnostic_mask else torch.cat(gt_classes, dim=0)
     loss, stats = mask_rcnn_loss_from_targets(pred_mask_logits, cls, gt_masks)
     storage = storage if storage is not None else _event_storage()

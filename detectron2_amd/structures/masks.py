@@ -1,6 +1,9 @@
 """BitMasks -- the part of detectron2/structures/masks.py:88-224 on the hot path: the (G, H, W) bool holder
 and `crop_and_resize`, the Mask R-CNN training-target rasteriser.  One fused HIP kernel
 (d2amd_bitmask_crop_and_resize) instead of `to(float32)` + ROIAlign + `>= 0.5`."""
+import ctypes
+from typing import List, Optional
+
 import torch
 
 from .. import _C
@@ -68,3 +71,34 @@ class BitMasks:
                                                                         int(mask_size), _C.ptr(out), _C.ptr(status),
                                                                         _C.stream()))
         return out.view(torch.bool)
+
+
+def crop_and_resize_batch(gt_masks: List["BitMasks"], boxes: List[torch.Tensor], mask_size: int,
+                          mask_index: Optional[List[torch.Tensor]] = None, status: torch.Tensor = None) -> torch.Tensor:
+    """`torch.cat([m[idx].crop_and_resize(b, M) for m, b, idx in ...])` -- the loop `mask_rcnn_loss` runs over the
+    images of a batch (mask_head.py:57-77) -- in ONE launch: gt_masks[i] are image i's BitMasks (all of one H x W),
+    boxes[i] its (n_i, 4) boxes, mask_index[i] the mask every box crops (None: box g crops mask g)."""
+    n_img = len(gt_masks)
+    assert n_img == len(boxes) and (mask_index is None or len(mask_index) == n_img)
+    assert 0 < n_img <= 64, n_img
+    ms = [m.tensor.contiguous().view(torch.uint8) for m in gt_masks]
+    _C.require_gpu(*ms, op="crop_and_resize_batch")
+    dev = ms[0].device
+    h, w = ms[0].shape[1:]
+    assert all(tuple(m.shape[1:]) == (h, w) for m in ms), "all images of the batch share one (padded) size"
+    bs = [b.detach().to(device=dev, dtype=torch.float32).contiguous() for b in boxes]
+    ix = None if mask_index is None else [i.detach().to(device=dev, dtype=torch.int64).contiguous() for i in mask_index]
+    nb = [int(b.shape[0]) for b in bs]
+    if ix is None:
+        assert all(n == int(m.shape[0]) for n, m in zip(nb, ms)), "without an index every mask needs exactly one box"
+    else:
+        assert all(int(i.shape[0]) == n for i, n in zip(ix, nb))
+    out = torch.empty((sum(nb), mask_size, mask_size), dtype=torch.uint8, device=dev)
+    if sum(nb):
+        vp = lambda ts: (ctypes.c_void_p * n_img)(*[t.data_ptr() for t in ts])
+        ci = lambda vs: (ctypes.c_int * n_img)(*vs)
+        with _C.on_device(dev):
+            _C.check(_C.lib().d2amd_bitmask_crop_and_resize_batch(
+                n_img, vp(ms), ci([int(m.shape[0]) for m in ms]), vp(bs), vp(ix) if ix is not None else None, ci(nb),
+                int(h), int(w), int(mask_size), _C.ptr(out), _C.ptr(status), _C.stream()))
+    return out.view(torch.bool)

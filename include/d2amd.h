@@ -270,6 +270,14 @@ int d2amd_bitmask_crop_and_resize(const uint8_t* masks, const float* boxes, int 
 int d2amd_bitmask_crop_and_resize_indexed(const uint8_t* masks, int n_masks, const float* boxes,
                                           const int64_t* mask_index, int n_boxes, int H, int W, int mask_size,
                                           uint8_t* out, int* status, void* stream);
+/* All images of a batch in ONE launch (mask_rcnn_loss loops over the images and concatenates, mask_head.py:57-77):
+ * host arrays of num_images (<= 64) device pointers / counts; every image's masks are [n_masks[i], H, W]; mask_index
+ * may be NULL (then n_boxes[i] == n_masks[i], box g of an image crops its mask g); out [sum n_boxes, M, M] in image
+ * order. */
+int d2amd_bitmask_crop_and_resize_batch(int num_images, const uint8_t* const* masks, const int* n_masks,
+                                        const float* const* boxes, const int64_t* const* mask_index,
+                                        const int* n_boxes, int H, int W, int mask_size, uint8_t* out, int* status,
+                                        void* stream);
 
 /* ---- Mask-head glue.  detectron2/modeling/roi_heads/mask_head.py:31-158.
  * logits [B,C,HW] `dtype` (HW = Hmask*Wmask, contiguous NCHW), classes [B] int64 or NULL (class-agnostic,

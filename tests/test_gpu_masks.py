@@ -112,3 +112,34 @@ def test_crop_and_resize_means_exactly_at_threshold(pattern):
                       [w / 2 - 112, 50, w / 2 + 112, 274], [w / 2 - 14, 10, w / 2 + 14, 38]], np.float32)
     got = BitMasks(torch.from_numpy(masks).to(DEV)).crop_and_resize(torch.from_numpy(boxes).to(DEV), M)
     assert np.array_equal(got.cpu().numpy(), reference_pipeline(masks, boxes, M))
+
+
+def test_crop_and_resize_batch_equals_per_image_loop():
+    """The whole batch in one launch (images with different numbers of masks and boxes, with and without an index)
+    == the reference's per-image loop + cat, and == the oracle pipeline."""
+    from detectron2_amd.structures import crop_and_resize_batch
+
+    rng = np.random.default_rng(8)
+    h, w, M = 150, 210, 28
+    counts_m, counts_b = [4, 1, 7], [9, 0, 30]
+    masks = [blob_masks(rng, g, h, w) for g in counts_m]
+    boxes, idx = [], []
+    for g, n in zip(counts_m, counts_b):
+        s = np.exp(rng.uniform(np.log(3), np.log(180), (n, 1))) * rng.uniform(0.6, 1.6, (n, 2))
+        c = rng.uniform([0, 0], [w, h], (n, 2))
+        boxes.append(np.concatenate([c - s / 2, c + s / 2], 1).astype(np.float32))
+        idx.append(rng.integers(0, g, n))
+    bms = [BitMasks(torch.from_numpy(m).to(DEV)) for m in masks]
+    bt = [torch.from_numpy(b).to(DEV) for b in boxes]
+    it = [torch.from_numpy(i).to(DEV) for i in idx]
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    got = crop_and_resize_batch(bms, bt, M, it, status)
+    want = torch.cat([m.crop_and_resize_indexed(b, i, M) for m, b, i in zip(bms, bt, it)])
+    assert int(status.item()) == 0 and torch.equal(got, want)
+    ref = np.concatenate([reference_pipeline(m[i], b, M) for m, b, i in zip(masks, boxes, idx) if len(b)])
+    assert np.array_equal(got.cpu().numpy(), ref)
+    # no index: box g of an image crops its mask g
+    bt2 = [torch.from_numpy(b[:g] if len(b) >= g else np.tile(np.array([[1, 2, 30, 40]], np.float32), (g, 1))).to(DEV)
+           for b, g in zip(boxes, counts_m)]
+    got2 = crop_and_resize_batch(bms, bt2, M)
+    assert torch.equal(got2, torch.cat([m.crop_and_resize(b, M) for m, b in zip(bms, bt2)]))
