@@ -29,8 +29,16 @@ __global__ __launch_bounds__(PASTE_BLOCK) void paste_region_kernel(
   extern __shared__ __attribute__((aligned(16))) float smask[];  // [mh*mw]
   const int n = blockIdx.y;
   const float x0 = boxes[n * 4 + 0], y0 = boxes[n * 4 + 1], x1 = boxes[n * 4 + 2], y1 = boxes[n * 4 + 3];
-  // region touched by the reference's CPU path (mask_ops.py:38-43), ints after clamp
-  float fx0 = floorf(x0) - 1.f, fy0 = floorf(y0) - 1.f, fx1 = ceilf(x1) + 1.f, fy1 = ceilf(y1) + 1.f;
+  // Region that can hold a non-zero sample.  The reference's CPU path crops to [floor(x0) - 1, ceil(x1) + 1)
+  // (mask_ops.py:38-43, skip_empty=True), its device path samples the whole image (skip_empty=False, :116-119):
+  // with zero padding, bilinear values are non-zero up to half a mask pixel = extent / (2 M) image pixels outside
+  // the box (14 px for an 800 px box, M = 28).  Invisible at threshold 0.5 for masks in [0, 1], visible for lower
+  // thresholds and the uint8 soft output -- so the region is grown by that margin: everything outside it is exactly
+  // 0 in the full-image evaluation too (the memset's value).
+  const float mx = ceilf(fabsf(x1 - x0) / (2.f * (float)mw)) + 1.f, my = ceilf(fabsf(y1 - y0) / (2.f * (float)mh)) + 1.f;
+  float fx0 = floorf(fminf(x0, x1)) - 1.f - mx, fy0 = floorf(fminf(y0, y1)) - 1.f - my;
+  float fx1 = ceilf(fmaxf(x0, x1)) + 1.f + mx, fy1 = ceilf(fmaxf(y0, y1)) + 1.f + my;
+  if (!(fx0 == fx0 && fx1 == fx1 && fy0 == fy0 && fy1 == fy1)) { fx0 = fy0 = 0.f; fx1 = (float)img_w; fy1 = (float)img_h; }  // NaN box
   fx0 = fx0 < 0.f ? 0.f : fx0;
   fy0 = fy0 < 0.f ? 0.f : fy0;
   fx1 = fx1 > (float)img_w ? (float)img_w : fx1;

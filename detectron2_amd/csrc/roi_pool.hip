@@ -379,11 +379,13 @@ struct TileShared {
 __device__ __forceinline__ bool footprint_rect(const RoiGeom& g, int H, int W, int& fy0, int& fy1, int& fx0,
                                                int& fx1) {
   if (g.grid_h <= 0 || g.grid_w <= 0) return false;
-  // samples lie strictly inside (start, start + roi); valid ones in [-1, size]; pixels touched are
-  // floor(max(s, 0)) and +1, clamped to size - 1
-  const float ylo = fmaxf(g.start_h, 0.f), yhi = g.start_h + g.roi_h;
-  const float xlo = fmaxf(g.start_w, 0.f), xhi = g.start_w + g.roi_w;
-  if (!(yhi >= -1.f && g.start_h <= (float)H && xhi >= -1.f && g.start_w <= (float)W)) return false;  // also NaN
+  // samples lie strictly inside (start, start + roi) -- or (start + roi, start) for an inverted ROI (x2 < x1 with
+  // aligned = True and sampling_ratio > 0: negative bin size, the forward still samples there); valid ones in
+  // [-1, size]; pixels touched are floor(max(s, 0)) and +1, clamped to size - 1
+  const float y_a = fminf(g.start_h, g.start_h + g.roi_h), yhi = fmaxf(g.start_h, g.start_h + g.roi_h);
+  const float x_a = fminf(g.start_w, g.start_w + g.roi_w), xhi = fmaxf(g.start_w, g.start_w + g.roi_w);
+  const float ylo = fmaxf(y_a, 0.f), xlo = fmaxf(x_a, 0.f);
+  if (!(yhi >= -1.f && y_a <= (float)H && xhi >= -1.f && x_a <= (float)W)) return false;  // also NaN
   fy0 = (int)fminf(ylo, 1e9f); fy1 = min((int)fminf(fmaxf(yhi, 0.f), 1e9f) + 1, H - 1);
   fx0 = (int)fminf(xlo, 1e9f); fx1 = min((int)fminf(fmaxf(xhi, 0.f), 1e9f) + 1, W - 1);
   return true;

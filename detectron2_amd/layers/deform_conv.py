@@ -24,19 +24,19 @@ def _params(x, weight, stride, padding, dilation, groups, deformable_groups):
         dtype=_C.dtype_code(x))
 
 
+def _conv_out_extent(size, pad, dil, kernel, stride):
+    """Output extent of one spatial axis of a (deformable) convolution."""
+    return (size + 2 * pad - (dil * (kernel - 1) + 1)) // stride + 1
+
+
 def _output_size(input, weight, padding, dilation, stride):
-    channels = weight.size(0)
-    output_size = (input.size(0), channels)
-    for d in range(input.dim() - 2):
-        in_size = input.size(d + 2)
-        pad = padding[d]
-        kernel = dilation[d] * (weight.size(d + 2) - 1) + 1
-        stride_ = stride[d]
-        output_size += ((in_size + (2 * pad) - kernel) // stride_ + 1,)
-    if not all(map(lambda s: s > 0, output_size)):
-        raise ValueError(
-            "convolution input is too small (output would be {})".format("x".join(map(str, output_size))))
-    return output_size
+    """(N, Co, Ho, Wo) of the convolution; ValueError with the reference's message when an extent is not positive."""
+    spatial = tuple(_conv_out_extent(input.size(ax + 2), padding[ax], dilation[ax], weight.size(ax + 2), stride[ax])
+                    for ax in range(input.dim() - 2))
+    size = (input.size(0), weight.size(0)) + spatial
+    if min(size) <= 0:
+        raise ValueError("convolution input is too small (output would be {})".format("x".join(str(v) for v in size)))
+    return size
 
 
 def _check_shapes(x, offset, mask, weight, out_size, groups, deformable_groups):
@@ -110,55 +110,50 @@ def _dcn_backward(x, offset, mask, weight, grad_output, stride, padding, dilatio
 
 
 class _DeformConv(Function):
+    """autograd entry of DCNv1; positional arguments as the reference's `deform_conv` (deform_conv.py:16-141)."""
+
     @staticmethod
     def forward(ctx, input, offset, weight, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1,
                 im2col_step=64):
         if input is not None and input.dim() != 4:
             raise ValueError("Expected 4D tensor as input, got {}D tensor instead.".format(input.dim()))
-        ctx.stride = _pair(stride)
-        ctx.padding = _pair(padding)
-        ctx.dilation = _pair(dilation)
-        ctx.groups = groups
-        ctx.deformable_groups = deformable_groups
-        ctx.im2col_step = im2col_step  # accepted for API compatibility; all images are batched
-        ctx.save_for_backward(input, offset, weight)
         if not input.is_cuda:
             raise NotImplementedError("Deformable Conv is not supported on CPUs!")
-        return _dcn_forward(input, offset, None, weight, None, ctx.stride, ctx.padding, ctx.dilation, groups,
-                            deformable_groups)
+        # im2col_step is accepted for API compatibility only: there is no column buffer, all images are batched
+        ctx.geom = (_pair(stride), _pair(padding), _pair(dilation), groups, deformable_groups)
+        ctx.stride, ctx.padding, ctx.dilation = ctx.geom[:3]
+        ctx.groups, ctx.deformable_groups, ctx.im2col_step = groups, deformable_groups, im2col_step
+        ctx.save_for_backward(input, offset, weight)
+        return _dcn_forward(input, offset, None, weight, None, *ctx.geom)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_output):
-        input, offset, weight = ctx.saved_tensors
         if not grad_output.is_cuda:
             raise NotImplementedError("Deformable Conv is not supported on CPUs!")
-        need_input = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
-        need_weight = ctx.needs_input_grad[2]
-        gi, goff, _, gw, _ = _dcn_backward(input, offset, None, weight, grad_output, ctx.stride, ctx.padding,
-                                           ctx.dilation, ctx.groups, ctx.deformable_groups, need_input, need_weight,
-                                           False)
-        return gi, goff, gw, None, None, None, None, None, None
+        input, offset, weight = ctx.saved_tensors
+        wants = ctx.needs_input_grad
+        gi, goff, _, gw, _ = _dcn_backward(input, offset, None, weight, grad_output, *ctx.geom,
+                                           wants[0] or wants[1], wants[2], False)
+        return (gi, goff, gw) + (None,) * 6
 
     _output_size = staticmethod(_output_size)
 
 
 class _ModulatedDeformConv(Function):
+    """autograd entry of DCNv2; positional arguments as the reference's `modulated_deform_conv` (:187-309)."""
+
     @staticmethod
     def forward(ctx, input, offset, mask, weight, bias=None, stride=1, padding=0, dilation=1, groups=1,
                 deformable_groups=1):
-        ctx.stride = stride
-        ctx.padding = padding
-        ctx.dilation = dilation
-        ctx.groups = groups
-        ctx.deformable_groups = deformable_groups
-        ctx.with_bias = bias is not None
         if not input.is_cuda:
             raise NotImplementedError("Deformable Conv is not supported on CPUs!")
-        if weight.requires_grad or mask.requires_grad or offset.requires_grad or input.requires_grad:
+        ctx.stride, ctx.padding, ctx.dilation = stride, padding, dilation  # scalars, as the reference keeps them
+        ctx.groups, ctx.deformable_groups, ctx.with_bias = groups, deformable_groups, bias is not None
+        ctx.geom = (_pair(stride), _pair(padding), _pair(dilation), groups, deformable_groups)
+        if any(t.requires_grad for t in (input, offset, mask, weight)):
             ctx.save_for_backward(input, offset, mask, weight)
-        return _dcn_forward(input, offset, mask, weight, bias, _pair(stride), _pair(padding), _pair(dilation),
-                            groups, deformable_groups)
+        return _dcn_forward(input, offset, mask, weight, bias, *ctx.geom)
 
     @staticmethod
     @once_differentiable
@@ -166,131 +161,83 @@ class _ModulatedDeformConv(Function):
         if not grad_output.is_cuda:
             raise NotImplementedError("Deformable Conv is not supported on CPUs!")
         input, offset, mask, weight = ctx.saved_tensors
-        gi, goff, gm, gw, gb = _dcn_backward(input, offset, mask, weight, grad_output, _pair(ctx.stride),
-                                             _pair(ctx.padding), _pair(ctx.dilation), ctx.groups,
-                                             ctx.deformable_groups, True, True, ctx.with_bias)
-        return gi, goff, gm, gw, gb, None, None, None, None, None
-
-    @staticmethod
-    def _infer_shape(ctx, input, weight):
-        n = input.size(0)
-        channels_out = weight.size(0)
-        height, width = input.shape[2:4]
-        kernel_h, kernel_w = weight.shape[2:4]
-        height_out = (height + 2 * ctx.padding - (ctx.dilation * (kernel_h - 1) + 1)) // ctx.stride + 1
-        width_out = (width + 2 * ctx.padding - (ctx.dilation * (kernel_w - 1) + 1)) // ctx.stride + 1
-        return n, channels_out, height_out, width_out
+        grads = _dcn_backward(input, offset, mask, weight, grad_output, *ctx.geom, True, True, ctx.with_bias)
+        return tuple(grads) + (None,) * 5
 
 
 deform_conv = _DeformConv.apply
 modulated_deform_conv = _ModulatedDeformConv.apply
 
 
-class DeformConv(nn.Module):
+class _DeformConvModule(nn.Module):
+    """What DeformConv and ModulatedDeformConv share: the nn.Conv2d-style weight (same name and shape as the
+    reference's, so checkpoints load unchanged), the empty-batch shortcut, the optional norm / activation tail and
+    the repr.  `_REPR` lists the attributes `extra_repr` prints, in the reference's order (the exact strings are
+    pinned by tests/layers/test_deformable.py:157-171)."""
+
+    _REPR = ("in_channels", "out_channels", "kernel_size", "stride", "padding", "dilation", "groups",
+             "deformable_groups")
+
+    def _setup(self, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, deformable_groups,
+               norm, activation):
+        for what, c in (("in_channels", in_channels), ("out_channels", out_channels)):
+            assert c % groups == 0, "{} {} cannot be divisible by groups {}".format(what, c, groups)
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size = _pair(kernel_size)
+        self.stride, self.padding, self.dilation = stride, padding, dilation
+        self.groups, self.deformable_groups = groups, deformable_groups
+        self.norm, self.activation = norm, activation
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels // groups, *self.kernel_size))
+        nn.init.kaiming_uniform_(self.weight, nonlinearity="relu")
+
+    def _empty_result(self, x):
+        """Zero images in: the (0, Co, Ho, Wo) result without touching the device kernels."""
+        hw = [_conv_out_extent(x.shape[2 + ax], _pair(self.padding)[ax], _pair(self.dilation)[ax],
+                               self.kernel_size[ax], _pair(self.stride)[ax]) for ax in (0, 1)]
+        return _NewEmptyTensorOp.apply(x, [x.shape[0], self.weight.shape[0]] + hw)
+
+    def _tail(self, y):
+        for f in (self.norm, self.activation):
+            if f is not None:
+                y = f(y)
+        return y
+
+    def extra_repr(self):
+        fields = ["{}={}".format(k, getattr(self, k)) for k in self._REPR]
+        return ", ".join(fields + ["bias=" + str(self.bias is not None)])
+
+
+class DeformConv(_DeformConvModule):
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
                  deformable_groups=1, bias=False, norm=None, activation=None):
         """Deformable convolution (DCNv1).  Arguments as nn.Conv2d plus `deformable_groups`,
         `norm` (nn.Module) and `activation` (callable) -- reference deform_conv.py:317-365."""
-        super(DeformConv, self).__init__()
+        super().__init__()
         assert not bias
-        assert in_channels % groups == 0, "in_channels {} cannot be divisible by groups {}".format(
-            in_channels, groups)
-        assert out_channels % groups == 0, "out_channels {} cannot be divisible by groups {}".format(
-            out_channels, groups)
-        self.in_channels = in_channels
-        self.out_channels = out_channels
-        self.kernel_size = _pair(kernel_size)
-        self.stride = _pair(stride)
-        self.padding = _pair(padding)
-        self.dilation = _pair(dilation)
-        self.groups = groups
-        self.deformable_groups = deformable_groups
-        self.norm = norm
-        self.activation = activation
-        self.weight = nn.Parameter(torch.Tensor(out_channels, in_channels // self.groups, *self.kernel_size))
+        self._setup(in_channels, out_channels, kernel_size, _pair(stride), _pair(padding), _pair(dilation), groups,
+                    deformable_groups, norm, activation)
         self.bias = None
-        nn.init.kaiming_uniform_(self.weight, nonlinearity="relu")
 
     def forward(self, x, offset):
         if x.numel() == 0:
-            output_shape = [
-                (i + 2 * p - (di * (k - 1) + 1)) // s + 1
-                for i, p, di, k, s in zip(x.shape[-2:], self.padding, self.dilation, self.kernel_size, self.stride)
-            ]
-            output_shape = [x.shape[0], self.weight.shape[0]] + output_shape
-            return _NewEmptyTensorOp.apply(x, output_shape)
-        x = deform_conv(x, offset, self.weight, self.stride, self.padding, self.dilation, self.groups,
-                        self.deformable_groups)
-        if self.norm is not None:
-            x = self.norm(x)
-        if self.activation is not None:
-            x = self.activation(x)
-        return x
-
-    def extra_repr(self):
-        tmpstr = "in_channels=" + str(self.in_channels)
-        tmpstr += ", out_channels=" + str(self.out_channels)
-        tmpstr += ", kernel_size=" + str(self.kernel_size)
-        tmpstr += ", stride=" + str(self.stride)
-        tmpstr += ", padding=" + str(self.padding)
-        tmpstr += ", dilation=" + str(self.dilation)
-        tmpstr += ", groups=" + str(self.groups)
-        tmpstr += ", deformable_groups=" + str(self.deformable_groups)
-        tmpstr += ", bias=False"
-        return tmpstr
+            return self._empty_result(x)
+        return self._tail(deform_conv(x, offset, self.weight, self.stride, self.padding, self.dilation, self.groups,
+                                      self.deformable_groups))
 
 
-class ModulatedDeformConv(nn.Module):
+class ModulatedDeformConv(_DeformConvModule):
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
                  deformable_groups=1, bias=True, norm=None, activation=None):
         """Modulated deformable convolution (DCNv2) -- reference deform_conv.py:415-460.
         stride / padding / dilation are scalars here, as in the reference."""
-        super(ModulatedDeformConv, self).__init__()
-        self.in_channels = in_channels
-        self.out_channels = out_channels
-        self.kernel_size = _pair(kernel_size)
-        self.stride = stride
-        self.padding = padding
-        self.dilation = dilation
-        self.groups = groups
-        self.deformable_groups = deformable_groups
+        super().__init__()
+        self._setup(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, deformable_groups, norm,
+                    activation)
         self.with_bias = bias
-        self.norm = norm
-        self.activation = activation
-        self.weight = nn.Parameter(torch.Tensor(out_channels, in_channels // groups, *self.kernel_size))
-        if bias:
-            self.bias = nn.Parameter(torch.Tensor(out_channels))
-        else:
-            self.bias = None
-        nn.init.kaiming_uniform_(self.weight, nonlinearity="relu")
-        if self.bias is not None:
-            nn.init.constant_(self.bias, 0)
+        self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
 
     def forward(self, x, offset, mask):
         if x.numel() == 0:
-            output_shape = [
-                (i + 2 * p - (di * (k - 1) + 1)) // s + 1
-                for i, p, di, k, s in zip(x.shape[-2:], _pair(self.padding), _pair(self.dilation), self.kernel_size,
-                                          _pair(self.stride))
-            ]
-            output_shape = [x.shape[0], self.weight.shape[0]] + output_shape
-            return _NewEmptyTensorOp.apply(x, output_shape)
-        x = modulated_deform_conv(x, offset, mask, self.weight, self.bias, self.stride, self.padding, self.dilation,
-                                  self.groups, self.deformable_groups)
-        if self.norm is not None:
-            x = self.norm(x)
-        if self.activation is not None:
-            x = self.activation(x)
-        return x
-
-    def extra_repr(self):
-        tmpstr = "in_channels=" + str(self.in_channels)
-        tmpstr += ", out_channels=" + str(self.out_channels)
-        tmpstr += ", kernel_size=" + str(self.kernel_size)
-        tmpstr += ", stride=" + str(self.stride)
-        tmpstr += ", padding=" + str(self.padding)
-        tmpstr += ", dilation=" + str(self.dilation)
-        tmpstr += ", groups=" + str(self.groups)
-        tmpstr += ", deformable_groups=" + str(self.deformable_groups)
-        tmpstr += ", bias=" + str(self.with_bias)
-        return tmpstr
+            return self._empty_result(x)
+        return self._tail(modulated_deform_conv(x, offset, mask, self.weight, self.bias, self.stride, self.padding,
+                                                self.dilation, self.groups, self.deformable_groups))

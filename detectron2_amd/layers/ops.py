@@ -135,8 +135,17 @@ def nms_images(inputs, iou_threshold, rotated=False, defer=False):
         return _nms_images_batched(inputs, iou_threshold, rotated, defer)
     cur = torch.cuda.current_stream(dev)
     pool = _SIDE_STREAMS.setdefault(dev.index, [])
+    # every dtype / layout conversion of every image runs on `cur` BEFORE the fork event: the side streams wait for
+    # that event only, so nothing they read may be produced after it (conversions inside _nms_launch are then no-ops)
+    bw = 5 if rotated else 4
+    prepared = []
+    for boxes, scores, idxs in inputs:
+        assert boxes.dim() == 2 and boxes.shape[1] == bw, boxes.shape
+        prepared.append((boxes.detach().float().contiguous(), scores.detach().float().contiguous(),
+                         None if idxs is None else idxs.detach().to(torch.int64).contiguous()))
+    inputs = prepared
     fork = torch.cuda.Event()
-    fork.record(cur)  # fork point: taken BEFORE anything of this call is enqueued on `cur`
+    fork.record(cur)  # fork point: after the conversions, before any NMS kernel of this call
     launched = []
     k = 0
     for boxes, scores, idxs in inputs:
@@ -150,8 +159,11 @@ def nms_images(inputs, iou_threshold, rotated=False, defer=False):
                 pool.append(torch.cuda.Stream(device=dev))
             st = pool[(k - 1) % len(pool)]
             st.wait_event(fork)  # inputs are ready; does not wait for the images launched above
-        launched.append((_nms_launch(boxes, scores, idxs, iou_threshold, rotated,
-                                     stream_ptr=_C.ctypes.c_void_p(st.cuda_stream)), st))
+        res = _nms_launch(boxes, scores, idxs, iou_threshold, rotated, stream_ptr=_C.ctypes.c_void_p(st.cuda_stream))
+        if st is not cur:  # allocated on `cur`'s pool, used on `st`: tell the caching allocator
+            for t in (res[0], res[1]) + tuple(x for x in res[2] if x is not None):
+                t.record_stream(st)
+        launched.append((res, st))
         k += 1
     for item in launched:
         if item is not None and item[1] is not cur:
@@ -205,6 +217,11 @@ def _roi_align_rotated_forward(input, rois, spatial_scale, pooled_height, pooled
         _C.check(_C.lib().d2amd_roi_align_rotated_forward(
             _C.ptr(x), _C.ptr(r), _C.ptr(out), n, c, h, w, k, pooled_height, pooled_width, float(spatial_scale),
             int(sampling_ratio), _C.dtype_code(x), layout, _C.ptr(status), _C.stream()))
+    # ROIAlignRotated_cpu.cpp:236-238: AT_ASSERTM(roi_width >= 0 && roi_height >= 0, ...) -> RuntimeError.  Reading the
+    # status word is one host sync; the reference's device forward ends in cudaDeviceSynchronize()
+    # (ROIAlignRotated_cuda.cu:379), so the call was never asynchronous for its callers.
+    if int(status.item()) != 0:
+        raise RuntimeError("ROIs in ROIAlignRotated do not have non-negative size!")
     return out
 
 

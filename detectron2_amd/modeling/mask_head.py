@@ -110,6 +110,10 @@ def mask_rcnn_loss(pred_mask_logits: torch.Tensor, instances: List, vis_period: 
     cls = None if cls_agnostic_mask else torch.cat(gt_classes, dim=0)
     loss, stats = mask_rcnn_loss_from_targets(pred_mask_logits, cls, gt_masks)
     storage = storage if storage is not None else _event_storage()
+    if storage is None:
+        # nobody reads the statistics (no host sync here): a gt class outside [0, C) -- an IndexError in the
+        # reference's gather (mask_head.py:78-79) -- must still not pass silently: it turns the loss into NaN
+        loss = torch.where(stats[4] > 0, torch.full_like(loss, float("nan")), loss)
     if storage is not None:
         incorrect, positive, false_pos, false_neg, bad = stats.tolist()  # the one host sync
         if bad:

@@ -161,15 +161,17 @@ def batched_nms(boxes, scores, idxs, iou_threshold, rotated=False):
     return keep[:k].copy()
 
 
-def paste_masks_in_image(masks, boxes, image_shape, threshold=0.5, return_soft=False):
+def paste_masks_in_image(masks, boxes, image_shape, threshold=0.5, return_soft=False, skip_empty=True):
+    """skip_empty=True: the reference's CPU path (bbox region only); False: its device path (whole image sampled,
+    mask_ops.py:116-119) -- they differ outside the box for thresholds below 0.5 and the soft uint8 output."""
     masks, boxes = _f32(masks), _f32(boxes).reshape(-1, 4)
     n = masks.shape[0]
     h, w = image_shape
     out = np.zeros((n, h, w), np.uint8)
     soft = np.zeros((n, h, w), np.float32) if return_soft else None
     if n:
-        lib().orc_paste_masks(_p(masks), _p(boxes), n, masks.shape[1], masks.shape[2], h, w,
-                              ctypes.c_float(threshold), _p(out, _u8p), _p(soft))
+        lib().orc_paste_masks_ex(_p(masks), _p(boxes), n, masks.shape[1], masks.shape[2], h, w,
+                                 ctypes.c_float(threshold), _p(out, _u8p), _p(soft), int(bool(skip_empty)))
     res = out.astype(bool) if threshold >= 0 else out
     return (res, soft) if return_soft else res
 

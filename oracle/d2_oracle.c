@@ -707,8 +707,18 @@ static int orc_clampi(float v, int lo, int hi, int use_lo) {
   return (int)v;
 }
 
+int orc_paste_masks_ex(const float* masks, const float* boxes, int n, int mh, int mw, int img_h,
+                       int img_w, float threshold, uint8_t* out, float* soft_out /* may be NULL */,
+                       int skip_empty);
 int orc_paste_masks(const float* masks, const float* boxes, int n, int mh, int mw, int img_h,
                     int img_w, float threshold, uint8_t* out, float* soft_out /* may be NULL */) {
+  return orc_paste_masks_ex(masks, boxes, n, mh, mw, img_h, img_w, threshold, out, soft_out, 1);
+}
+/* skip_empty = 1: the CPU path (one mask per chunk, bbox region only, mask_ops.py:116-119,134);
+ * skip_empty = 0: the device path of the reference -- the whole image is sampled. */
+int orc_paste_masks_ex(const float* masks, const float* boxes, int n, int mh, int mw, int img_h,
+                       int img_w, float threshold, uint8_t* out, float* soft_out /* may be NULL */,
+                       int skip_empty) {
   memset(out, 0, (size_t)n * img_h * img_w);
   if (soft_out) memset(soft_out, 0, sizeof(float) * (size_t)n * img_h * img_w);
   for (int k = 0; k < n; k++) {
@@ -719,6 +729,7 @@ int orc_paste_masks(const float* masks, const float* boxes, int n, int mh, int m
     int y0i = orc_clampi(floorf(b[1]) - 1.f, 0, 0, 1);
     int x1i = orc_clampi(ceilf(b[2]) + 1.f, 0, img_w, 0);
     int y1i = orc_clampi(ceilf(b[3]) + 1.f, 0, img_h, 0);
+    if (!skip_empty) { x0i = 0; y0i = 0; x1i = img_w; y1i = img_h; }
     for (int py = y0i; py < y1i; py++)
       for (int px = x0i; px < x1i; px++) {
         float v = orc_paste_sample(m, mh, mw, b[0], b[1], b[2], b[3], px, py);

@@ -275,11 +275,30 @@ def dense_detector_golden():
           [len(d[f"t_scores_img{i}"]) for i in range(N)])
 
 
+def paste_device_path_golden():
+    """paste_masks_in_image as the reference evaluates it for DEVICE tensors: `_do_paste_mask(..., skip_empty=False)`
+    (mask_ops.py:116-119,134) samples the whole image, so values up to half a mask pixel outside the box are non-zero
+    -- visible below threshold 0.5 and in the uint8 soft output.  Run on CPU tensors (same ATen grid_sampler)."""
+    mo = ref.py_mask_ops()
+    torch.manual_seed(77)
+    n, h, w = 6, 150, 200
+    masks = torch.rand(n, 28, 28)
+    boxes = torch.tensor([[20.3, 10.7, 180.2, 140.9], [-30.0, -20.0, 120.0, 90.0], [60.0, 50.0, 64.5, 53.2],
+                          [5.0, 100.0, 195.0, 149.0], [100.0, 0.0, 260.0, 150.0], [150.5, 20.5, 190.5, 140.5]])
+    soft, _ = mo._do_paste_mask(masks[:, None], boxes, h, w, skip_empty=False)
+    np.savez_compressed(os.path.join(OUT, "paste_masks_full.npz"), masks=masks.numpy(), boxes=boxes.numpy(),
+                        shape=np.array([h, w]), out_u8=(soft * 255).to(torch.uint8).numpy(),
+                        out_thr01=np.packbits((soft >= 0.1).numpy()), out_thr05=np.packbits((soft >= 0.5).numpy()))
+    print("paste_masks_full.npz written", int((soft > 0).sum()))
+
+
 if __name__ == "__main__":
     import sys
 
     if len(sys.argv) > 1 and sys.argv[1] == "mask_head":
         mask_head_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "paste_full":
+        paste_device_path_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "dense_detector":
         dense_detector_golden()
     else:

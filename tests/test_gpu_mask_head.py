@@ -143,6 +143,12 @@ def test_mask_head_edge_cases():
     gt = torch.zeros(4, 14, 14, dtype=torch.bool, device=DEV)
     with pytest.raises(IndexError):
         mask_rcnn_loss(x, [Inst(gt_classes=bad, gt_masks=Targets(gt), proposal_boxes=Boxes(4))], storage=Recorder())
+    # ... and without an event storage (nothing reads the counter, no host sync): the loss is poisoned, not silent
+    silent = mask_rcnn_loss(x, [Inst(gt_classes=bad, gt_masks=Targets(gt), proposal_boxes=Boxes(4))])
+    assert torch.isnan(silent).item()
+    ok = mask_rcnn_loss(x, [Inst(gt_classes=torch.tensor([0, 1, 2, 2], device=DEV), gt_masks=Targets(gt),
+                                  proposal_boxes=Boxes(4))])
+    assert torch.isfinite(ok).item()
     # inference: out-of-range class -> NaN row, others untouched; empty input
     pred = [Inst(pred_classes=bad)]
     mask_rcnn_inference(x.detach(), pred)

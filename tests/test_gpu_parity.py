@@ -404,12 +404,29 @@ def test_paste_masks_bit_exact(golden_dir):
     exp = np.unpackbits(d["out_bits"])[: n * h * w].reshape(n, h, w).astype(bool)
     got = paste_masks_in_image(cu(d["masks"]), cu(d["boxes"]), (h, w), 0.5)
     assert got.dtype == torch.bool and np.array_equal(got.cpu().numpy(), exp)
+    # threshold < 0 (soft uint8): device tensors follow the reference's DEVICE path, which samples the whole image
+    # (mask_ops.py:116-119): compare with the oracle's skip_empty=False mode (pinned by paste_masks_full.npz)
     got8 = paste_masks_in_image(cu(d["masks"]), Boxes(cu(d["boxes"])), (h, w), -1)
-    assert got8.dtype == torch.uint8 and np.array_equal(got8.cpu().numpy(), d["out_u8"])
+    assert got8.dtype == torch.uint8
+    assert np.array_equal(got8.cpu().numpy(), oracle.paste_masks_in_image(d["masks"], d["boxes"], (h, w), -1,
+                                                                          skip_empty=False))
     # odd plane sizes exercise the 4-byte and 1-byte store paths
     for hh, ww in [(37, 41), (30, 50), (64, 64)]:
         g = paste_masks_in_image(cu(d["masks"]), cu(d["boxes"] * 0.3), (hh, ww), 0.5).cpu().numpy()
         assert np.array_equal(g, oracle.paste_masks_in_image(d["masks"], d["boxes"] * 0.3, (hh, ww), 0.5))
+
+
+def test_paste_masks_device_path_golden(golden_dir):
+    """Large boxes, threshold 0.1 and the soft uint8 output: bit-exact against the reference's own
+    `_do_paste_mask(..., skip_empty=False)` -- the region kernel covers the half-mask-pixel margin outside the box."""
+    d = np.load(os.path.join(golden_dir, "paste_masks_full.npz"))
+    h, w = int(d["shape"][0]), int(d["shape"][1])
+    n = d["masks"].shape[0]
+    got8 = paste_masks_in_image(cu(d["masks"]), cu(d["boxes"]), (h, w), -1)
+    assert np.array_equal(got8.cpu().numpy(), d["out_u8"])
+    for thr, key in ((0.1, "out_thr01"), (0.5, "out_thr05")):
+        exp = np.unpackbits(d[key])[: n * h * w].reshape(n, h, w).astype(bool)
+        assert np.array_equal(paste_masks_in_image(cu(d["masks"]), cu(d["boxes"]), (h, w), thr).cpu().numpy(), exp)
 
 
 def test_paste_masks_full_size():
@@ -568,3 +585,15 @@ def test_registered_ops_scriptable():
     assert np.array_equal(f(cu(b), cu(s)).cpu().numpy(), oracle.nms_rotated(b, s, 0.5))
     iou = torch.ops.detectron2.box_iou_rotated(cu(b), cu(b[:7]))
     assert np.array_equal(iou.cpu().numpy(), oracle.box_iou_rotated(b, b[:7]))
+
+
+def test_roi_align_rotated_negative_size_raises():
+    """ROIAlignRotated_cpu.cpp:236-238: AT_ASSERTM(roi_width >= 0 && roi_height >= 0) -> RuntimeError."""
+    from detectron2_amd.layers import ROIAlignRotated
+
+    x = torch.randn(1, 4, 16, 16, device=DEV)
+    good = torch.tensor([[0, 8.0, 8.0, 6.0, 4.0, 30.0]], device=DEV)
+    assert ROIAlignRotated((3, 3), 1.0, 2)(x, good).shape == (1, 4, 3, 3)
+    bad = torch.tensor([[0, 8.0, 8.0, -6.0, 4.0, 30.0]], device=DEV)
+    with pytest.raises(RuntimeError, match="non-negative size"):
+        ROIAlignRotated((3, 3), 1.0, 2)(x, bad)

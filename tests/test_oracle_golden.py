@@ -236,6 +236,22 @@ def test_paste_masks_golden(golden_dir):
     assert np.array_equal(out8, d["out_u8"])
 
 
+def test_paste_masks_device_path_golden(golden_dir):
+    """The oracle's skip_empty=False mode == the reference's `_do_paste_mask(..., skip_empty=False)` (what it runs
+    for device tensors): the whole image is sampled, pixels up to half a mask pixel outside the box are non-zero."""
+    d = np.load(os.path.join(golden_dir, "paste_masks_full.npz"))
+    h, w = int(d["shape"][0]), int(d["shape"][1])
+    n = d["masks"].shape[0]
+    out8 = oracle.paste_masks_in_image(d["masks"], d["boxes"], (h, w), -1, skip_empty=False)
+    assert np.array_equal(out8, d["out_u8"])
+    for thr, key in ((0.1, "out_thr01"), (0.5, "out_thr05")):
+        exp = np.unpackbits(d[key])[: n * h * w].reshape(n, h, w).astype(bool)
+        assert np.array_equal(oracle.paste_masks_in_image(d["masks"], d["boxes"], (h, w), thr, skip_empty=False), exp)
+    # ... and the CPU path (bbox region only) really differs from it below threshold 0.5
+    cpu8 = oracle.paste_masks_in_image(d["masks"], d["boxes"], (h, w), -1, skip_empty=True)
+    assert (cpu8 != out8).sum() > 50
+
+
 # ---------------------------------------------------------------- deformable conv
 DCN_GOLDEN = np.array([[30, 41.25, 48.75, 45, 28.75], [62.25, 81, 90, 80.25, 50.25],
                        [99.75, 126, 135, 117.75, 72.75], [105, 131.25, 138.75, 120, 73.75],
