@@ -4,20 +4,21 @@ modified.  `batched_nms*` suppress independently per category on the ORIGINAL co
 coordinate-offset trick: the device kernel is category-aware, nms.py:137-145 is not needed)."""
 import torch
 
-from .ops import nms_images, nms_impl
+from .ops import nms_images, nms_impl  # noqa: F401  (importing .ops registers torch.ops.d2amd.* / detectron2.*)
 from .wrappers import disable_torch_compiler
 
 
 def nms(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float) -> torch.Tensor:
     """torchvision.ops.nms semantics (re-exported by the reference at nms.py:6): greedy NMS on
-    Tensor[N,4] xyxy boxes, suppressing IoU > iou_threshold."""
-    return nms_impl(boxes, scores, None, iou_threshold, False)
+    Tensor[N,4] xyxy boxes, suppressing IoU > iou_threshold.  `torch.jit.script`-able (a registered op)."""
+    return torch.ops.d2amd.nms(boxes, scores, iou_threshold)
 
 
 def batched_nms(boxes: torch.Tensor, scores: torch.Tensor, idxs: torch.Tensor, iou_threshold: float):
-    """Same as torchvision.ops.boxes.batched_nms, but with float() (nms.py:11-22)."""
+    """Same as torchvision.ops.boxes.batched_nms, but with float() (nms.py:11-22).  `torch.jit.script`-able with
+    identical results (tests/layers/test_nms.py:16-29)."""
     assert boxes.shape[-1] == 4
-    return nms_impl(boxes.float(), scores, idxs, iou_threshold, False)
+    return torch.ops.d2amd.batched_nms(boxes.float(), scores, idxs, iou_threshold)
 
 
 @disable_torch_compiler
@@ -28,13 +29,15 @@ def nms_rotated(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float)
     return torch.ops.detectron2.nms_rotated(boxes, scores, iou_threshold)
 
 
+@torch.jit.script_if_tracing
 def batched_nms_rotated(boxes: torch.Tensor, scores: torch.Tensor, idxs: torch.Tensor, iou_threshold: float):
-    """Per-category rotated NMS (nms.py:96-147)."""
+    """Per-category rotated NMS (nms.py:96-147; `script_if_tracing` like the reference, :96).  The device kernel is
+    category-aware, so the reference's coordinate-offset trick (:137-145) is not needed."""
     assert boxes.shape[-1] == 5
     if boxes.numel() == 0:
         return torch.empty((0,), dtype=torch.int64, device=boxes.device)
     boxes = boxes.float()  # fp16 does not have enough range for batched NMS
-    return nms_impl(boxes, scores, idxs, iou_threshold, True)
+    return torch.ops.d2amd.batched_nms_rotated(boxes, scores, idxs, iou_threshold)
 
 
 def batched_nms_images(inputs, iou_threshold: float, defer: bool = False):

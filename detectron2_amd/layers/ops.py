@@ -268,7 +268,8 @@ for _name, _schema in _DEFS.items():
 def _cpu_stub(name):
     def f(*a, **k):
         raise NotImplementedError(
-            f"torch.ops.detectron2.{name}: detectron2_amd implements this op for MI355X (HIP tensors) only")
+            f"torch.ops.{name if '.' in name else 'detectron2.' + name}: detectron2_amd implements this op for MI355X "
+            f"(HIP tensors) only")
     return f
 
 
@@ -277,3 +278,53 @@ for _name in _DEFS:
         _lib_handle.impl(_name, _cpu_stub(_name), "CPU")
     except RuntimeError:
         pass
+
+
+# ---- torch.ops.d2amd.*: the ops the reference gets from torchvision / plain torch, as registered ops, so that the
+# Python surface around them (layers.nms.batched_nms, layers.mask_ops.paste_masks_in_image) is `torch.jit.script`-able
+# like the reference's (tests/layers/test_nms.py:16-29, tests/layers/test_mask_ops.py:156-165)
+_D2AMD_DEFS = {
+    "nms": "(Tensor boxes, Tensor scores, float iou_threshold) -> Tensor",
+    "batched_nms": "(Tensor boxes, Tensor scores, Tensor idxs, float iou_threshold) -> Tensor",
+    "batched_nms_rotated": "(Tensor boxes, Tensor scores, Tensor idxs, float iou_threshold) -> Tensor",
+    "paste_masks": "(Tensor masks, Tensor boxes, int img_h, int img_w, float threshold) -> Tensor",
+}
+
+
+def _paste_masks(masks, boxes, img_h, img_w, threshold):
+    _C.require_gpu(masks, boxes, op="paste_masks_in_image")
+    n = masks.shape[0]
+    m = masks.detach()
+    if m.dtype not in (torch.float32, torch.float16, torch.bfloat16):
+        m = m.float()
+    m = m.contiguous()
+    b = boxes.detach().float().contiguous()
+    out = torch.empty((n, img_h, img_w), dtype=torch.uint8, device=m.device)
+    with _C.on_device(m.device):
+        _C.check(_C.lib().d2amd_paste_masks(_C.ptr(m), _C.ptr(b), n, m.shape[1], m.shape[2], img_h, img_w,
+                                            float(threshold), _C.ptr(out), _C.dtype_code(m), _C.stream()))
+    return out.view(torch.bool) if threshold >= 0 else out
+
+
+_D2AMD_IMPLS = {
+    "nms": lambda boxes, scores, thr: nms_impl(boxes, scores, None, thr, False),
+    "batched_nms": lambda boxes, scores, idxs, thr: nms_impl(boxes, scores, idxs, thr, False),
+    "batched_nms_rotated": lambda boxes, scores, idxs, thr: nms_impl(boxes, scores, idxs, thr, True),
+    "paste_masks": _paste_masks,
+}
+
+def _cpu_nms_stub(name):
+    stub = _cpu_stub("d2amd." + name)
+
+    def f(boxes, *rest):
+        if boxes.shape[0] == 0:  # nothing to compute on any device (nms.py:125-126)
+            return torch.empty((0,), dtype=torch.int64, device=boxes.device)
+        return stub()
+    return f
+
+
+_d2amd_lib = torch.library.Library("d2amd", "DEF")
+for _name, _schema in _D2AMD_DEFS.items():
+    _d2amd_lib.define(_name + _schema)
+    _d2amd_lib.impl(_name, _D2AMD_IMPLS[_name], "CUDA")
+    _d2amd_lib.impl(_name, _cpu_stub("d2amd." + _name) if _name == "paste_masks" else _cpu_nms_stub(_name), "CPU")

@@ -597,3 +597,40 @@ def test_roi_align_rotated_negative_size_raises():
     bad = torch.tensor([[0, 8.0, 8.0, -6.0, 4.0, 30.0]], device=DEV)
     with pytest.raises(RuntimeError, match="non-negative size"):
         ROIAlignRotated((3, 3), 1.0, 2)(x, bad)
+
+
+def test_batched_nms_and_paste_masks_are_scriptable_with_identical_results():
+    """The reference's own contracts: `torch.jit.script(batched_nms)` == eager for N = 2000, 50 classes, thresholds
+    .2 / .5 / .8, inputs not mutated (tests/layers/test_nms.py:16-29); `torch.jit.script(paste_masks_in_image)`
+    bit-identical to eager, 10 masks 28x28 -> 150x150 (tests/layers/test_mask_ops.py:156-165)."""
+    from detectron2_amd.layers.mask_ops import _paste_masks_tensor_shape, pad_masks, scale_boxes
+
+    torch.manual_seed(0)
+    n = 2000
+    boxes = torch.rand(n, 4, device=DEV) * 100
+    boxes[:, 2:] += boxes[:, :2]
+    scores = torch.rand(n, device=DEV)
+    idxs = torch.randint(0, 50, (n,), device=DEV)
+    scripted = torch.jit.script(batched_nms)
+    for thr in (0.2, 0.5, 0.8):
+        backup = boxes.clone()
+        a, b = batched_nms(boxes, scores, idxs, thr), scripted(boxes, scores, idxs, thr)
+        assert torch.equal(boxes, backup) and torch.equal(a, b) and a.dtype == torch.int64
+        assert np.array_equal(a.cpu().numpy(), oracle.batched_nms(boxes.cpu().numpy(), scores.cpu().numpy(),
+                                                                 idxs.cpu().numpy(), thr))
+    masks = torch.rand(10, 28, 28, device=DEV)
+    pb = torch.rand(10, 4, device=DEV) * 60
+    pb[:, 2:] = pb[:, :2] + 20 + pb[:, 2:]
+    sp = torch.jit.script(paste_masks_in_image)
+    for thr in (0.5, -1.0):
+        e, s2 = paste_masks_in_image(masks, pb, (150, 150), thr), sp(masks, pb, (150, 150), thr)
+        assert tuple(e.shape) == (10, 150, 150) and e.dtype == s2.dtype and torch.equal(e, s2)
+    assert sp(masks[:0], pb[:0], (150, 150), 0.5).shape == (0, 150, 150)
+    t = _paste_masks_tensor_shape(masks, pb, (torch.tensor(150), torch.tensor(150)), 0.5)
+    assert torch.equal(t, paste_masks_in_image(masks, pb, (150, 150), 0.5))
+    # helpers of the module (mask_ops.py:219-262)
+    pm, scale = pad_masks(masks, 1)
+    assert pm.shape == (10, 30, 30) and scale == 30 / 28 and torch.equal(pm[:, 1:-1, 1:-1], masks) and pm[:, 0].sum() == 0
+    sb = scale_boxes(pb, scale)
+    assert torch.allclose((sb[:, 2:] - sb[:, :2]), (pb[:, 2:] - pb[:, :2]) * scale, rtol=1e-5)
+    assert torch.allclose((sb[:, 2:] + sb[:, :2]), (pb[:, 2:] + pb[:, :2]), rtol=1e-5)

@@ -166,3 +166,24 @@ def test_late_python_surface_rejects_cpu_tensors():
         mask_rcnn_inference(torch.zeros(2, 3, 7, 7), [I()])
     with pytest.raises(NotImplementedError):
         dense_select_predictions([torch.zeros(4, 4)], [torch.zeros(1, 4, 2)], [torch.zeros(1, 4, 4)], 0.05, 10)
+
+
+def test_C_shim_has_the_reference_extension_surface():
+    """detectron2_amd._C_shim mirrors the pybind11 module of csrc/vision.cpp:81-113: names, arity and the
+    introspection results `utils/collect_env.py` prints (has_cuda() is False on ROCm builds, vision.cpp:41-47)."""
+    import inspect
+    import sys
+
+    import detectron2_amd._C_shim as shim
+
+    arity = {"deform_conv_forward": 17, "deform_conv_backward_input": 18, "deform_conv_backward_filter": 18,
+             "modulated_deform_conv_forward": 19, "modulated_deform_conv_backward": 24}  # deform_conv.h:116-375
+    for name, n in arity.items():
+        assert len(inspect.signature(getattr(shim, name)).parameters) == n, name
+    assert shim.has_cuda() is False and shim.get_cuda_version().startswith("HIP ")
+    assert shim.get_compiler_version().startswith("clang ")
+    assert shim.install("d2amd_test_pkg._C") is shim and sys.modules["d2amd_test_pkg._C"] is shim
+    del sys.modules["d2amd_test_pkg._C"]
+    with pytest.raises(RuntimeError):  # CPU tensors: AT_ERROR("Not compiled with GPU support") / TORCH_CHECK
+        shim.deform_conv_forward(torch.zeros(1, 1, 3, 3), torch.zeros(1, 1, 3, 3), torch.zeros(1, 18, 3, 3),
+                                 torch.zeros(1), torch.zeros(1), torch.zeros(1), 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 64)
