@@ -79,6 +79,9 @@ def parse(argv=None):
                     help="N > 1, maskrcnn_train: wire dtype of the gradient all-reduce (bf16 = the reference's "
                          "fp16_compress_hook idea, fp32 = plain DDP) or off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="maskrcnn_train: launch every op eagerly in the timed region (default: the two sync-free halves "
+                         "of the step are captured once in HIP graphs and replayed)")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="test hook: launcher + process group + gradient all-reduce + timing reduction only, no "
                          "hot-path op (runs without a GPU with --backend gloo); the JSON line says so")
@@ -309,11 +312,14 @@ def step(w, t=None, grads=None):
     # a training iteration produces NEW feature maps: drop the NHWC staging copies an NCHW run cached for the
     # previous step's tensors (the two poolers of one step still share one copy)
     _poolers._NHWC_CACHE.clear()
-    # RPN: anchor labelling (does not depend on the proposals) and the proposal path
+    # RPN: the proposal path is enqueued first (selection + decode + NMS of both images), its one host sync is
+    # deferred past the anchor labelling, which does not depend on the proposals (RPN.forward computes the two in either
+    # order: rpn.py label_and_sample_anchors / predict_proposals): the device works through both while the host waits
+    rpn_done = run("rpn_proposals", lambda: find_top_rpn_proposals_fused(
+        w.anchor_levels, w.rpn_logits, w.rpn_deltas, w.image_sizes, 0.7, 2000, 1000, 0.0, True, defer=True))
     for i in range(w.n_img):
         run("match_anchors", lambda: w.anchor_matcher.match_boxes(w.gt[i], w.anchors))
-    props = run("rpn_proposals", lambda: find_top_rpn_proposals_fused(
-        w.anchor_levels, w.rpn_logits, w.rpn_deltas, w.image_sizes, 0.7, 2000, 1000, 0.0, True))
+    props = run("rpn_proposals_sync", rpn_done)
     # ROI heads: proposal labelling (the sampled lists themselves are fixed inputs: subsample_labels is out of scope)
     for i in range(w.n_img):
         run("match_proposals", lambda: w.proposal_matcher.match_boxes(w.gt[i], w.props_with_gt[i]))
@@ -336,6 +342,77 @@ def step(w, t=None, grads=None):
         f.grad = None
     w.mask_logits.grad = None
     return props
+
+
+class GraphedStep:
+    """The same step with its two sync-free halves captured in HIP graphs (torch.cuda.CUDAGraph drives
+    hipStreamBeginCapture / hipGraphLaunch; every kernel of libd2amd.so is launched on torch's current stream, so the
+    capture sees them all):
+      graph A  RPN selection + decode + NMS of the batch, then the anchor labelling        -> ONE host sync (counts)
+      graph B  proposal labelling, both poolers forward, mask targets, mask loss, ONE backward pass
+    The step is launch-bound when issued eagerly (~40 kernels of 5-80 us through Python): replaying removes the host
+    from the critical path.  Inputs live at fixed addresses (a training loop would copy its batch into them); the
+    proposal lists are rebuilt from graph A's buffers after the sync, like the eager path does."""
+
+    def __init__(self, w, grads):
+        from detectron2_amd.modeling import find_top_rpn_proposals_fused, mask_rcnn_loss_from_targets
+        from detectron2_amd.structures import crop_and_resize_batch
+
+        self.w, self.grads = w, grads
+
+        def part_a():
+            done = find_top_rpn_proposals_fused(w.anchor_levels, w.rpn_logits, w.rpn_deltas, w.image_sizes, 0.7, 2000,
+                                                1000, 0.0, True, defer=True)
+            labels = [w.anchor_matcher.match_boxes(w.gt[i], w.anchors) for i in range(w.n_img)]
+            return done, labels
+
+        def part_b():
+            lab = [w.proposal_matcher.match_boxes(w.gt[i], w.props_with_gt[i]) for i in range(w.n_img)]
+            yb = w.box_pooler(w.feats, w.box_lists)
+            ym = w.mask_pooler(w.feats, w.mask_lists)
+            tg = crop_and_resize_batch(w.gt_masks, [b.tensor for b in w.mask_lists], 28, w.fg_gt_index, w.crop_status)
+            loss, _ = mask_rcnn_loss_from_targets(w.mask_logits, w.fg_classes, tg)
+            for f in w.feats:
+                f.grad = None
+            w.mask_logits.grad = None
+            torch.autograd.backward([yb, ym, loss], [w.gbox, w.gmask, None])
+            return lab, loss
+
+        self.ga, self.out_a = self._capture(part_a)
+        self.gb, self.out_b = self._capture(part_b)
+
+    @staticmethod
+    def _capture(fn):
+        import gc
+
+        gc.collect()  # no autograd graph of an eager step may survive into the capture (its AccumulateGrad nodes are
+        # bound to the default stream and would pull the capture onto it)
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                fn()
+        cur.wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = fn()
+        return g, out
+
+    def __call__(self):
+        self.ga.replay()
+        props = self.out_a[0]()  # the one host sync of the step
+        g = self.grads
+        n_early = g.ready_after("roi_heads.box_head") if g is not None else 0
+        for i in range(n_early):
+            g.reduce(i)  # RCCL, on its own stream: overlaps graph B's pooler backward
+        self.gb.replay()
+        if g is not None:
+            for i in range(n_early, g.num_buckets):
+                g.reduce(i)
+            g.finish()
+        return props
 
 
 def _threads():
@@ -459,12 +536,29 @@ def bench_maskrcnn(args, ctx):
         step(w, None, grads)
     sw = Stopwatch(dist, dev)
     KERN = "pool_bwd_staged_r7"
-    _dc.lib().d2amd_timing_select(KERN.encode())  # HIP events around the roofline kernel only, in the timed region
-    dom_timer = Timer(only=("backward",))
-    sw.start()
-    for _ in range(args.steps):
-        step(w, dom_timer, grads)
-    elapsed = sw.stop()
+    use_graph = not args.no_graph
+    if use_graph:
+        gstep = GraphedStep(w, grads)
+        for _ in range(3):
+            gstep()
+        sw.start()
+        for _ in range(args.steps):
+            gstep()
+        elapsed = sw.stop()
+        # events inside a replayed graph cannot be read: the roofline kernel is timed by the library's launch-stream
+        # events in an eager pass of the same steps right after the timed region
+        _dc.lib().d2amd_timing_select(KERN.encode())
+        dom_timer = Timer(only=("backward",))
+        for _ in range(args.steps):
+            step(w, dom_timer, grads)
+        torch.cuda.synchronize()
+    else:
+        _dc.lib().d2amd_timing_select(KERN.encode())  # HIP events around the roofline kernel only, in the timed region
+        dom_timer = Timer(only=("backward",))
+        sw.start()
+        for _ in range(args.steps):
+            step(w, dom_timer, grads)
+        elapsed = sw.stop()
     ktimes = read_kernel_times([KERN])
     knames = ["pool_bwd_staged_r7", "pool_bwd_staged_r14", "pool_fwd_r7", "pool_fwd_r14", "nms_mask", "nms_reduce"]
     _dc.lib().d2amd_timing_select(",".join(knames).encode())
@@ -503,8 +597,9 @@ def bench_maskrcnn(args, ctx):
                 "traffic_note": "PMC bytes of the box-head pooler backward (records + tile lists + tile gather)",
                 "alg_bytes_per_launch": int(kb), "ms_per_launch": round(k_ms, 4), "launches_timed": k_n,
                 "alg_bytes_note": "SURVEY 8(d) ROIAlign bwd: s*K*C*R^2 (dY) + 2*s*sum_l N*C*H_l*W_l (zero fill + write of dX)",
-                "timing": "HIP events recorded by the library on the kernel's launch stream right around the launch, "
-                          "mean over the timed steps",
+                "timing": "HIP events recorded by the library on the kernel's launch stream right around the launch, mean over "
+                          + ("an eager pass of the same number of steps right after the timed region (the timed region "
+                             "replays HIP graphs, inside which events cannot be read)" if use_graph else "the timed steps"),
                 "kernels_ms": {k: round(v[0], 4) for k, v in ktimes.items()}}
     else:
         per = alg["backward"]
@@ -521,6 +616,8 @@ def bench_maskrcnn(args, ctx):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "maskrcnn_r50fpn_train_hotpath_bs2_800x1344 (BASELINE configs[1]; configs[2] at n_gpus 8)",
                    "layout": args.layout, "global_batch": world * w.n_img, "ops_per_step": counts,
+                   "launch": ("2 HIP graphs per step (RPN half | ROI-head half + backward), one host sync between them"
+                              if use_graph else "eager: every op launched from Python"),
                    "parallelism": f"dp{world}: images sharded, no data-path collective; "
                                   + (grads_description(grads) if grads is not None else
                                      "no gradient all-reduce (world size 1, like DDP)")},

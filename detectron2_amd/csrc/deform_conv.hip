@@ -591,8 +591,8 @@ static int bwd_host(const DcnShape& s, const void* x, const void* offset, const 
                     const void* gout, void* gin, void* goffset, void* gmask, void* gweight, void* gbias,
                     const DcnWs& w, hipStream_t st) {
   if (s.B == 0) {
-    if (gweight) D2_HIP_OK(hipMemsetAsync(gweight, 0, (size_t)s.Co * s.Cg * s.K2 * sizeof(T), st));
-    if (gbias) D2_HIP_OK(hipMemsetAsync(gbias, 0, (size_t)s.Co * sizeof(T), st));
+    if (gweight) { const int zrc = zero_async(gweight, (size_t)s.Co * s.Cg * s.K2 * sizeof(T), st); if (zrc) return zrc; }
+    if (gbias) { const int zrc = zero_async(gbias, (size_t)s.Co * sizeof(T), st); if (zrc) return zrc; }
     return D2AMD_OK;
   }
   constexpr bool is32 = sizeof(T) == 4;
@@ -603,7 +603,7 @@ static int bwd_host(const DcnShape& s, const void* x, const void* offset, const 
   if (need_data) {
     rc = launch_transpose<T, T>((const T*)gout, (T*)w.gout_nhwc, s.B, s.Co, s.L, st);
     if (rc) return rc;
-    D2_HIP_OK(hipMemsetAsync(w.gx, 0, (size_t)s.B * s.H * s.W * s.C * 4, st));
+    { const int zrc = zero_async(w.gx, (size_t)s.B * s.H * s.W * s.C * 4, st); if (zrc) return zrc; }
     float* goff_f = goffset ? (is32 ? (float*)goffset : w.goff) : nullptr;
     float* gmask_f = (gmask && mask) ? (is32 ? (float*)gmask : w.gmask) : nullptr;
     bool tc_done = false;
@@ -651,7 +651,7 @@ static int bwd_host(const DcnShape& s, const void* x, const void* offset, const 
     }
   }
   if (gweight) {
-    D2_HIP_OK(hipMemsetAsync(w.gwr, 0, (size_t)s.Co * s.Cg * s.K2 * 4, st));
+    { const int zrc = zero_async(w.gwr, (size_t)s.Co * s.Cg * s.K2 * 4, st); if (zrc) return zrc; }
     const int nblk = dcn_num_blocks(s.C, s.Cg, s.cpg, WG_BN);
     const int co_tiles = cdiv(s.Cog, WG_BM);
     constexpr int BK = Mma<T>::BK;

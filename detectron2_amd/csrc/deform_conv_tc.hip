@@ -671,7 +671,7 @@ static int tc_launch_fwd2(const DcnShape& s, const TcPlan& pl, const TcArgs& a, 
   TcArgs a2 = a;
   if (sp) {
     D2_HIP_OK(hipMalloc(&a2.stamps, (size_t)grid * 4 * 8));
-    D2_HIP_OK(hipMemsetAsync(a2.stamps, 0, (size_t)grid * 4 * 8, st));
+    { const int zrc = zero_async(a2.stamps, (size_t)grid * 4 * 8, st); if (zrc) return zrc; }
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (NWM * NWN + NWN)), pl.lds, st, s, a2);
   D2_LAUNCH_OK();
@@ -1378,8 +1378,8 @@ int dcn_tc_backward_data(const DcnShape& s, const TcBwPlan& pl, const void* x_nh
     a.tiles_y = pl.tiles_y; a.tiles_x = pl.tiles_x; a.csplit = pl.csplit_patch;
     a.R = pl.R; a.PHt = pl.PHt; a.PWt = pl.PWt;
     if (a.csplit > 1) {
-      if (goff) D2_HIP_OK(hipMemsetAsync(goff, 0, (size_t)s.B * s.DG * 2 * s.K2 * s.L * 4, st));
-      if (gmask) D2_HIP_OK(hipMemsetAsync(gmask, 0, (size_t)s.B * s.DG * s.K2 * s.L * 4, st));
+      if (goff) { const int zrc = zero_async(goff, (size_t)s.B * s.DG * 2 * s.K2 * s.L * 4, st); if (zrc) return zrc; }
+      if (gmask) { const int zrc = zero_async(gmask, (size_t)s.B * s.DG * s.K2 * s.L * 4, st); if (zrc) return zrc; }
     }
     const long total = (long)s.B * pl.tiles_y * pl.tiles_x * s.DG * a.csplit;
     D2_CHECK_ARG(total < (1l << 30), "deform_conv: too many tiles");
@@ -1399,8 +1399,8 @@ int dcn_tc_backward_data(const DcnShape& s, const TcBwPlan& pl, const void* x_nh
   a.tiles_y = pl.tiles_y; a.tiles_x = pl.tiles_x; a.csplit = pl.csplit;
   { const char* e = getenv("D2AMD_DCN_ABLATE_BWD"); a.ablate = e ? atoi(e) : 0; }
   if (pl.csplit > 1) {  // channel shares accumulate d(offset) / d(mask) with atomics
-    if (goff) D2_HIP_OK(hipMemsetAsync(goff, 0, (size_t)s.B * s.DG * 2 * s.K2 * s.L * 4, st));
-    if (gmask) D2_HIP_OK(hipMemsetAsync(gmask, 0, (size_t)s.B * s.DG * s.K2 * s.L * 4, st));
+    if (goff) { const int zrc = zero_async(goff, (size_t)s.B * s.DG * 2 * s.K2 * s.L * 4, st); if (zrc) return zrc; }
+    if (gmask) { const int zrc = zero_async(gmask, (size_t)s.B * s.DG * s.K2 * s.L * 4, st); if (zrc) return zrc; }
   }
   const long total = (long)s.B * pl.tiles_y * pl.tiles_x * s.DG * pl.csplit;
   D2_CHECK_ARG(total < (1l << 30), "deform_conv: too many tiles");

@@ -192,7 +192,7 @@ static int match_impl(const float* gt, int M, const float* boxes, const float* q
       return D2AMD_EWORKSPACE;
     }
     rowmax = (uint32_t*)workspace;
-    D2_HIP_OK(hipMemsetAsync(rowmax, 0, (size_t)M * 4, s));
+    { const int zrc = zero_async(rowmax, (size_t)M * 4, s); if (zrc) return zrc; }
   }
   if (q)
     hipLaunchKernelGGL((match_pass1_kernel<false>), dim3(grid), dim3(MT_BLOCK), 0, s, nullptr, M, nullptr, N, q, cfg,

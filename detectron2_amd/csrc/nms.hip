@@ -638,9 +638,12 @@ __device__ __forceinline__ void nms_reduce_body(const u64* __restrict__ mask,
 constexpr int FIN_THREADS = 1024;
 __device__ __forceinline__ void nms_finalize_small_body(
     const u64* __restrict__ keepbits, const int* __restrict__ rankpos, const int* __restrict__ order, int n,
-    int64_t* __restrict__ keep_out, const int* __restrict__ counters, int64_t* __restrict__ result) {
+    int64_t* __restrict__ keep_out, const int* __restrict__ counters, int64_t* __restrict__ result,
+    const float* __restrict__ scores) {
   __shared__ uint8_t flags[RANK_MAX_N];
   __shared__ int wave_tot[FIN_THREADS / 64];
+  __shared__ int s_finite;
+  if (threadIdx.x == 0) s_finite = 0;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   for (int p = tid; p < n; p += FIN_THREADS) {
     const bool kept = (keepbits[p >> 6] >> (p & 63)) & 1ull;
@@ -670,10 +673,17 @@ __device__ __forceinline__ void nms_finalize_small_body(
   __syncthreads();
   int off = incl - cnt;
   for (int w = 0; w < wid; w++) off += wave_tot[w];
+  int fin = 0;
 #pragma unroll
   for (int q = 0; q < CH; q++)
-    if ((fl >> q) & 1u) keep_out[off++] = (int64_t)ord[q];
-  if (tid == FIN_THREADS - 1) { result[0] = off; result[1] = counters[1]; }
+    if ((fl >> q) & 1u) {
+      keep_out[off++] = (int64_t)ord[q];
+      fin += scores[ord[q]] > -INFINITY ? 1 : 0;
+    }
+  if (fin) atomicAdd(&s_finite, fin);
+  __syncthreads();
+  // result: {kept, error flags, kept with a score > -inf (callers park invalid rows at -inf: they sort last), 0}
+  if (tid == FIN_THREADS - 1) { result[0] = off; result[1] = counters[1]; result[2] = s_finite; result[3] = 0; }
 }
 
 __global__ void nms_scatter_flags_kernel(const u64* __restrict__ keepbits, const int* __restrict__ rankpos, int n,
@@ -686,35 +696,56 @@ __global__ void nms_scatter_flags_kernel(const u64* __restrict__ keepbits, const
 }
 
 constexpr int COMPACT_BLOCK = 1024;
+constexpr int COMPACT_CH = 16;  // consecutive ranks per thread and pass: 100,000 boxes = 7 passes (r01: 98 passes, 110 us)
 __global__ __launch_bounds__(COMPACT_BLOCK) void nms_compact_kernel(const uint8_t* __restrict__ flag_r,
                                                                     const int* __restrict__ order, int n,
                                                                     int64_t* __restrict__ keep_out,
                                                                     const int* __restrict__ counters,
-                                                                    int64_t* __restrict__ result) {
+                                                                    int64_t* __restrict__ result,
+                                                                    const float* __restrict__ scores) {
   __shared__ int wave_cnt[COMPACT_BLOCK / 64];
-  __shared__ int base_s;
+  __shared__ int s_finite;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  if (tid == 0) base_s = 0;
-  __syncthreads();
-  for (int start = 0; start < n; start += COMPACT_BLOCK) {
-    int r = start + tid;
-    bool f = r < n && flag_r[r];
-    u64 bal = __ballot(f);
-    int within = __builtin_popcountll(bal & ((1ull << lane) - 1ull));
-    if (lane == 0) wave_cnt[wid] = __builtin_popcountll(bal);
-    __syncthreads();
-    int off = base_s;
-    for (int k = 0; k < wid; k++) off += wave_cnt[k];
-    if (f) keep_out[off + within] = (int64_t)order[r];
-    __syncthreads();
-    if (tid == 0) {
-      int t = 0;
-      for (int k = 0; k < COMPACT_BLOCK / 64; k++) t += wave_cnt[k];
-      base_s += t;
+  if (tid == 0) s_finite = 0;
+  int base = 0, fin = 0;
+  for (int start = 0; start < n; start += COMPACT_BLOCK * COMPACT_CH) {
+    const int r0 = start + tid * COMPACT_CH;
+    uint32_t fl = 0;
+    int cnt = 0;
+#pragma unroll
+    for (int q = 0; q < COMPACT_CH; q++) {
+      const bool f = r0 + q < n && flag_r[min(r0 + q, n - 1)];
+      fl |= f ? (1u << q) : 0u;
+      cnt += f ? 1 : 0;
     }
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o);
+      if (lane >= o) incl += v;
+    }
+    __syncthreads();  // wave_cnt of the previous pass has been read
+    if (lane == 63) wave_cnt[wid] = incl;
     __syncthreads();
+    int off = base + incl - cnt, tot = 0;
+#pragma unroll
+    for (int k = 0; k < COMPACT_BLOCK / 64; k++) {
+      const int t = wave_cnt[k];
+      if (k < wid) off += t;
+      tot += t;
+    }
+#pragma unroll
+    for (int q = 0; q < COMPACT_CH; q++)
+      if ((fl >> q) & 1u) {
+        const int o = order[r0 + q];
+        keep_out[off++] = (int64_t)o;
+        fin += scores[o] > -INFINITY ? 1 : 0;
+      }
+    base += tot;
   }
-  if (tid == 0) { result[0] = base_s; result[1] = counters[1]; }
+  if (fin) atomicAdd(&s_finite, fin);
+  __syncthreads();
+  if (tid == 0) { result[0] = base; result[1] = counters[1]; result[2] = s_finite; result[3] = 0; }
 }
 
 // ---- batched launch: blockIdx.z = image --------------------------------------------------------
@@ -777,7 +808,7 @@ __global__ __launch_bounds__(RED_THREADS) void nms_reduce_kernel(const NmsBatch 
 }
 __global__ __launch_bounds__(FIN_THREADS) void nms_finalize_small_kernel(const NmsBatch B) {
   const NmsImg& I = B.img[blockIdx.z];
-  nms_finalize_small_body(I.w.keepbits, I.rankpos, I.w.order, I.n, I.keep_out, I.w.counters, I.result);
+  nms_finalize_small_body(I.w.keepbits, I.rankpos, I.w.order, I.n, I.keep_out, I.w.counters, I.result, I.scores);
 }
 
 }  // namespace d2amd
@@ -923,7 +954,7 @@ extern "C" int d2amd_nms_batched(int count, const float* const* boxes, const flo
     for (int k = k0; k < count && k < k0 + NMS_MAX_BATCH; k++) {
       D2_CHECK_ARG(n[k] >= 0 && result[k], "nms_batched: bad image %d", k);
       if (n[k] == 0) {
-        D2_HIP_OK(hipMemsetAsync(result[k], 0, 16, s));
+        { const int zrc = zero_async(result[k], 32, s); if (zrc) return zrc; }
         continue;
       }
       D2_CHECK_ARG(n[k] <= RANK_MAX_N, "nms_batched: image %d has %lld boxes (> %d): use d2amd_nms", k,
@@ -951,7 +982,7 @@ extern "C" int d2amd_nms(const float* boxes, const float* scores, const int64_t*
   D2_CHECK_ARG(n >= 0 && n < (1ll << 31) - 64, "nms: bad n %lld", (long long)n);
   D2_CHECK_ARG(result, "nms: null result");
   if (n == 0) {
-    D2_HIP_OK(hipMemsetAsync(result, 0, 16, s));
+    { const int zrc = zero_async(result, 32, s); if (zrc) return zrc; }
     return D2AMD_OK;
   }
   NmsBatch B;
@@ -966,7 +997,7 @@ extern "C" int d2amd_nms(const float* boxes, const float* scores, const int64_t*
   NmsWorkspace& w = I.w;
   const int N = (int)n;
   const int T = 256;
-  D2_HIP_OK(hipMemsetAsync(w.keepbits, 0, w.zero_bytes, s));
+  { const int zrc = zero_async(w.keepbits, w.zero_bytes, s); if (zrc) return zrc; }
   hipLaunchKernelGGL(nms_init_kernel, dim3(cdiv(N, T)), dim3(T), 0, s, w.iota, N);
   D2_LAUNCH_OK();
   size_t tb = w.sort_temp_bytes;
@@ -991,7 +1022,7 @@ extern "C" int d2amd_nms(const float* boxes, const float* scores, const int64_t*
   hipLaunchKernelGGL(nms_scatter_flags_kernel, dim3(cdiv(N, T)), dim3(T), 0, s, w.keepbits, I.rankpos, N, w.flag_r);
   D2_LAUNCH_OK();
   hipLaunchKernelGGL(nms_compact_kernel, dim3(1), dim3(COMPACT_BLOCK), 0, s, w.flag_r, w.order, N, keep_out,
-                     w.counters, result);
+                     w.counters, result, scores);
   D2_LAUNCH_OK();
   return D2AMD_OK;
 }

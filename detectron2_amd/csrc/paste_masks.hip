@@ -87,7 +87,7 @@ template <typename T>
 static int launch_paste(const void* masks, const float* boxes, int n, int mh, int mw, int img_h, int img_w,
                         float threshold, uint8_t* out, hipStream_t s) {
   const size_t lds = (size_t)mh * mw * sizeof(float);
-  D2_HIP_OK(hipMemsetAsync(out, 0, (size_t)n * img_h * img_w, s));
+  { const int zrc = zero_async(out, (size_t)n * img_h * img_w, s); if (zrc) return zrc; }
   dim3 grid(cdiv(img_h, PASTE_ROWS), n);
   hipLaunchKernelGGL((paste_region_kernel<T>), grid, dim3(PASTE_BLOCK), lds, s, (const T*)masks, boxes, mh, mw, img_h,
                      img_w, threshold, out);

@@ -227,7 +227,7 @@ static int bwd_impl(const void* grad_output, const float* rois, void* grad_input
     return D2AMD_EWORKSPACE;
   }
   float* acc = is32 ? (float*)grad_input : (float*)workspace;
-  D2_HIP_OK(hipMemsetAsync(acc, 0, (size_t)numel * 4, s));
+  { const int zrc = zero_async(acc, (size_t)numel * 4, s); if (zrc) return zrc; }
   const long total = (long)K * C * PH * PW;
   if (total > 0) {
     const bool sep_ok = !rotated && PH <= SEP_MAXP && PW <= SEP_MAXP;

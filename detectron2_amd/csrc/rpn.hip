@@ -237,7 +237,7 @@ extern "C" int d2amd_rpn_select_proposals(const float* logits, const float* delt
     }
     uint32_t* sel = (uint32_t*)workspace;
     int* cnt = (int*)((char*)workspace + off_cnt);
-    D2_HIP_OK(hipMemsetAsync(flags_out, 0, sizeof(int), s));
+    { const int zrc = zero_async(flags_out, sizeof(int), s); if (zrc) return zrc; }
     int rc = topk_select(in, false, 0.f, sel, cnt, (char*)workspace + off_tk, workspace_bytes - off_tk, s);
     if (rc) return rc;
     const long nt = (long)N * k;
@@ -253,7 +253,7 @@ extern "C" int d2amd_rpn_select_proposals(const float* logits, const float* delt
     set_error("rpn_select_proposals: workspace too small (%zu < %zu)", workspace_bytes, w.total);
     return D2AMD_EWORKSPACE;
   }
-  D2_HIP_OK(hipMemsetAsync(flags_out, 0, sizeof(int), s));
+  { const int zrc = zero_async(flags_out, sizeof(int), s); if (zrc) return zrc; }
   hipLaunchKernelGGL(rpn_keys_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, logits, N, Atot, lv, w.k0, w.v0);
   D2_LAUNCH_OK();
   int seg_bits = 1;

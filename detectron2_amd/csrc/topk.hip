@@ -474,7 +474,7 @@ int topk_select(const TopkInput& in, bool use_thr, float xmin, uint32_t* sel, in
   P.maxblk = w.maxblk;
   P.reps = w.reps;
   P.tickets = w.tickets;
-  D2_HIP_OK(hipMemsetAsync(ws, 0, w.zero_bytes, s));
+  { const int zrc = zero_async(ws, w.zero_bytes, s); if (zrc) return zrc; }
   dim3 grid(w.maxblk, in.N * in.L), block(TK_THREADS);
   const dim3 segs(in.N * in.L);
   hipLaunchKernelGGL(tk_hist_kernel<0>, grid, block, 0, s, P, w.st, w.hist);

@@ -43,7 +43,7 @@ def _nms_launch(boxes, scores, idxs, iou_threshold, rotated, stream_ptr=None):
         ws_bytes = L.d2amd_nms_workspace_bytes(n, max_per_class, int(rotated))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=boxes.device)
         keep = torch.empty(n, dtype=torch.int64, device=boxes.device)
-        result = torch.empty(2, dtype=torch.int64, device=boxes.device)
+        result = torch.empty(4, dtype=torch.int64, device=boxes.device)
         _C.check(L.d2amd_nms(_C.ptr(boxes), _C.ptr(scores), _C.ptr(idxs), n, float(iou_threshold), int(rotated),
                              max_per_class, _C.ptr(keep), _C.ptr(result), _C.ptr(ws), ws_bytes,
                              stream_ptr if stream_ptr is not None else _C.stream()))
@@ -64,7 +64,7 @@ def nms_impl(boxes, scores, idxs, iou_threshold, rotated):
         assert boxes.dim() == 2 and boxes.shape[1] == (5 if rotated else 4), boxes.shape
         return torch.empty((0,), dtype=torch.int64, device=boxes.device)
     keep, result, _hold = _nms_launch(boxes, scores, idxs, iou_threshold, rotated)
-    num, flags = result.tolist()  # the only host sync of the NMS pipeline
+    num, flags = result[:2].tolist()  # the only host sync of the NMS pipeline
     return _nms_finish(keep, num, flags)
 
 
@@ -83,7 +83,7 @@ def _nms_images_batched(inputs, iou_threshold, rotated, defer=False):
     hold = []
     arr = lambda vals: (ct.c_void_p * cnt)(*vals)
     with _C.on_device(dev):
-        result = torch.empty((cnt, 2), dtype=torch.int64, device=dev)
+        result = torch.empty((cnt, 4), dtype=torch.int64, device=dev)
         pb, ps, pi, pk, pr, pw = [], [], [], [], [], []
         ns, wb, keeps = [], [], []
         for k, (boxes, scores, idxs) in enumerate(inputs):
@@ -103,15 +103,22 @@ def _nms_images_batched(inputs, iou_threshold, rotated, defer=False):
             keeps.append(keep)
             pb.append(boxes.data_ptr()); ps.append(scores.data_ptr())
             pi.append(idxs.data_ptr() if idxs is not None else None)
-            pk.append(keep.data_ptr()); pr.append(result.data_ptr() + 16 * k); pw.append(ws.data_ptr())
+            pk.append(keep.data_ptr()); pr.append(result.data_ptr() + 32 * k); pw.append(ws.data_ptr())
             ns.append(n); wb.append(nbytes)
         _C.check(L.d2amd_nms_batched(cnt, arr(pb), arr(ps), arr(pi), (ct.c_int64 * cnt)(*ns), float(iou_threshold),
                                      int(rotated), None, arr(pk), arr(pr), arr(pw), (ct.c_size_t * cnt)(*wb),
                                      _C.stream()))
-    def finish():
-        counts = result.tolist()  # the only host sync; `hold` keeps inputs / workspaces alive until here
+    def finish(with_finite=False, extra=None):
+        """with_finite: also return, per image, how many kept boxes have a score > -inf; extra: a device tensor of
+        int64 values read in the same host transfer (returned as a list)."""
+        flat = result.flatten() if extra is None else torch.cat([result.flatten(), extra.flatten().to(torch.int64)])
+        vals = flat.tolist()  # the only host sync; `hold` keeps inputs / workspaces alive until here
+        counts = [vals[4 * k:4 * k + 4] for k in range(cnt)]
         hold.clear()
-        return [_nms_finish(keep, num, flags) for keep, (num, flags) in zip(keeps, counts)]
+        kept = [_nms_finish(keep, c[0], c[1]) for keep, c in zip(keeps, counts)]
+        if not with_finite and extra is None:
+            return kept
+        return kept, [c[2] for c in counts], vals[4 * cnt:]
 
     return finish if defer else finish()
 
@@ -127,7 +134,7 @@ def nms_images(inputs, iou_threshold, rotated=False, defer=False):
     join into the current stream.  Either way the kept counts are read with ONE sync."""
     global _BATCH_MAX
     if not inputs:
-        return (lambda: []) if defer else []
+        return (lambda with_finite=False, extra=None: ([], [], []) if (with_finite or extra is not None) else []) if defer else []
     if _BATCH_MAX is None:
         _BATCH_MAX = int(_C.lib().d2amd_nms_batched_max_boxes())
     dev = inputs[0][0].device
@@ -171,16 +178,24 @@ def nms_images(inputs, iou_threshold, rotated=False, defer=False):
     live = [it for it in launched if it is not None]
     stacked = torch.stack([it[0][1] for it in live]) if live else None
 
-    def finish():
-        counts = stacked.tolist() if live else []  # ONE host sync
-        out, j = [], 0
+    def finish(with_finite=False, extra=None):
+        flat = stacked.flatten() if live else torch.zeros(0, dtype=torch.int64, device=dev)
+        if extra is not None:
+            flat = torch.cat([flat, extra.flatten().to(torch.int64)])
+        vals = flat.tolist() if (live or extra is not None) else []  # ONE host sync
+        out, fin, j = [], [], 0
         for (boxes, _s, _i), it in zip(inputs, launched):
             if it is None:
                 out.append(torch.empty((0,), dtype=torch.int64, device=boxes.device))
+                fin.append(0)
             else:
-                out.append(_nms_finish(it[0][0], *counts[j]))
+                c = vals[4 * j:4 * j + 4]
+                out.append(_nms_finish(it[0][0], c[0], c[1]))
+                fin.append(c[2])
                 j += 1
-        return out
+        if not with_finite and extra is None:
+            return out
+        return out, fin, vals[4 * len(live):]
 
     return finish if defer else finish()
 

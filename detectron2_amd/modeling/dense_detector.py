@@ -95,17 +95,18 @@ def dense_detector_inference_fused(anchors, pred_logits, pred_anchor_deltas, ima
                                    topk_candidates: int, nms_thresh: float, max_detections: int,
                                    weights=(1.0, 1.0, 1.0, 1.0), scale_clamp: float = _DEFAULT_SCALE_CLAMP):
     """-> list of N `Detections` (pred_boxes: Boxes, scores, pred_classes), score-descending, at most
-    max_detections each (retinanet.py:297-309).  Two host syncs per batch (NMS counts, valid counts)."""
+    max_detections each (retinanet.py:297-309).  One host sync per batch."""
     boxes, scores, classes, valid, _, rank = dense_select_predictions(
         anchors, pred_logits, pred_anchor_deltas, score_thresh, topk_candidates, weights, scale_clamp, return_logits=True)
     n = boxes.shape[0]
     # rows past a level's count are zero-area boxes with score -inf: they neither suppress nor get suppressed, sort last.
     # The NMS ranks by the selected LOGITS (same order as the scores, but independent of the exp() rounding)
-    keeps = batched_nms_images([(boxes[i], rank[i], classes[i]) for i in range(n)], nms_thresh)  # sync 1
-    keeps = [k[:max_detections] for k in keeps]
-    counts = torch.stack([valid[i][k].sum() for i, k in enumerate(keeps)]).tolist() if n else []  # sync 2
+    # (rows past a level's count carry logit -inf: the NMS reports how many kept boxes have a finite ranking score,
+    # and those sort last -- no second transfer for the valid counts)
+    keeps, n_finite, _ = batched_nms_images([(boxes[i], rank[i], classes[i]) for i in range(n)], nms_thresh,
+                                            defer=True)(with_finite=True) if n else ([], [], [])  # the one sync
     out = []
     for i, k in enumerate(keeps):
-        k = k[:counts[i]]
+        k = k[:min(max_detections, n_finite[i])]
         out.append(Detections(tuple(image_sizes[i]), Boxes(boxes[i][k]), scores[i][k], classes[i][k]))
     return out

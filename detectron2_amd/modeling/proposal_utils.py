@@ -7,7 +7,7 @@
   filter (d2amd_rpn_select_proposals, one call) -> per-image, per-level NMS of all images on overlapping
   HIP streams (batched_nms_images) -> the post_nms_topk best per image.
 The reference loops over levels and images in Python with a device->host sync per image (`.item()`,
-NMS result size); here there are two syncs per batch (NMS counts, valid counts).
+NMS result size); here there is one sync per batch (NMS counts + valid counts + non-finite flag in one transfer).
 Results are equal to the reference's up to the rounding of exp() in the decode (the selection and NMS
 run on identical inputs otherwise); ties between equal logits resolve towards the lower anchor index."""
 import ctypes
@@ -75,21 +75,29 @@ def rpn_select_proposals(anchors: List[torch.Tensor], pred_objectness_logits: Li
 
 def find_top_rpn_proposals_fused(anchors, pred_objectness_logits, pred_anchor_deltas, image_sizes, nms_thresh: float,
                                  pre_nms_topk: int, post_nms_topk: int, min_box_size: float, training: bool,
-                                 weights=(1.0, 1.0, 1.0, 1.0), scale_clamp: float = _DEFAULT_SCALE_CLAMP):
-    """-> list of N `Proposals` (proposal_boxes: Boxes, objectness_logits), sorted by objectness."""
+                                 weights=(1.0, 1.0, 1.0, 1.0), scale_clamp: float = _DEFAULT_SCALE_CLAMP,
+                                 defer: bool = False):
+    """-> list of N `Proposals` (proposal_boxes: Boxes, objectness_logits), sorted by objectness.
+    ONE host sync per batch: the kept counts, the number of kept boxes that are valid proposals (invalid rows are
+    parked at score -inf and sort last: the NMS reports how many kept boxes have a finite score) and the non-finite
+    flag come back in a single transfer.  defer=True enqueues everything and returns a callable that performs that
+    sync and builds the list: work that does not depend on the proposals (the anchor labelling of the same RPN
+    iteration, rpn.py:431-480) can be enqueued in between."""
     boxes, scores, valid, level_ids, flags = rpn_select_proposals(
         anchors, pred_objectness_logits, pred_anchor_deltas, image_sizes, pre_nms_topk, min_box_size, weights,
         scale_clamp)
     n = boxes.shape[0]
     # invalid rows are zero-area boxes with score -inf: they neither suppress nor get suppressed and sort last
-    keeps = batched_nms_images([(boxes[i], scores[i], level_ids) for i in range(n)], nms_thresh)  # sync 1
-    keeps = [k[:post_nms_topk] for k in keeps]
-    nvalid = [valid[i][k].sum() for i, k in enumerate(keeps)]
-    counts = torch.stack(nvalid + [flags[0].to(torch.int64)]).tolist() if n else []  # sync 2
-    if n and counts[-1] and training:
-        raise FloatingPointError("Predicted boxes or scores contain Inf/NaN. Training has diverged.")
-    out = []
-    for i, k in enumerate(keeps):
-        k = k[:counts[i]]
-        out.append(Proposals(tuple(image_sizes[i]), Boxes(boxes[i][k]), scores[i][k]))
-    return out
+    nms_done = batched_nms_images([(boxes[i], scores[i], level_ids) for i in range(n)], nms_thresh, defer=True)
+
+    def finish():
+        keeps, n_finite, (bad,) = nms_done(with_finite=True, extra=flags) if n else ([], [], (0,))  # the one sync
+        if n and bad and training:
+            raise FloatingPointError("Predicted boxes or scores contain Inf/NaN. Training has diverged.")
+        out = []
+        for i, k in enumerate(keeps):
+            k = k[:min(post_nms_topk, n_finite[i])]
+            out.append(Proposals(tuple(image_sizes[i]), Boxes(boxes[i][k]), scores[i][k]))
+        return out
+
+    return finish if defer else finish()

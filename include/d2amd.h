@@ -227,7 +227,8 @@ int d2amd_dense_select_predictions(const float* const* logits, const float* cons
  *   suppression: IoU >  iou_threshold (rotated=0, torchvision CPU semantics)
  *                IoU >= iou_threshold (rotated=1, nms_rotated_cpu.cpp:54); compare in double.
  *   keep_out [n] int64: kept ORIGINAL indices in decreasing score order (ties: lower index
- *            first);  result [2] int64 (device): {number kept, error flags}.  error flag bit 0:
+ *            first);  result [4] int64 (device): {number kept, error flags, number kept whose score is > -inf,
+ *            0} (callers that park invalid rows at score -inf read the third word: those rows sort last).  error flag bit 0:
  *            a category has more than `max_per_class` boxes, bit 1: category id out of range.
  *   max_per_class: upper bound on boxes in one category (sizes the suppression bitmask);
  *            <= 0 means "unknown" = n.   Category ids must lie in [0, 65535].
