@@ -50,6 +50,7 @@ struct NmsWorkspace {
   int* rk_cnt;        // [chunks][2][n64] partial rank counts (brute-force ranking path)
   void* rk_keys;      // [n padded to RK_GROUP] 16-B key records (brute-force ranking path)
   uint8_t* flag_r;    // [n] kept flag in rank order              (radix path)
+  int* blk_cnt;       // [n / 1024 + 1] kept flags per compaction workgroup (radix path)
   int* seg_start;     // [65536]
   void* sort_temp;
   size_t sort_temp_bytes;
@@ -99,6 +100,7 @@ static void carve(NmsWorkspace& w, void* base, int64_t n, int wcap) {
   w.rk_keys = take(n <= RANK_MAX_N ? (size_t)(n + RK_GROUP) * 16 : 0);
   w.rk_cnt = (int*)take(n <= RANK_MAX_N ? (size_t)((n + RK_JC - 1) / RK_JC) * 2 * n64 * 4 : 0);
   w.flag_r = (uint8_t*)take(n);
+  w.blk_cnt = (int*)take((size_t)(n / 1024 + 2) * 4);
   w.seg_start = (int*)take(65536 * 4);
   w.sort_temp_bytes = sort_temp_bytes(n);
   w.sort_temp = take(w.sort_temp_bytes);
@@ -695,57 +697,63 @@ __global__ void nms_scatter_flags_kernel(const u64* __restrict__ keepbits, const
   flag_r[r] = kept ? 1 : 0;
 }
 
+// Ordered compaction of the kept flags (rank order) for the large-n path, in two launches over n / 1024 workgroups:
+// counts per workgroup, then every workgroup sums the counts before it and scatters.  (One workgroup walking all
+// 100,000 ranks took 110-140 us per image, r02 profile.)
 constexpr int COMPACT_BLOCK = 1024;
-constexpr int COMPACT_CH = 16;  // consecutive ranks per thread and pass: 100,000 boxes = 7 passes (r01: 98 passes, 110 us)
+__global__ __launch_bounds__(COMPACT_BLOCK) void nms_compact_count_kernel(const uint8_t* __restrict__ flag_r, int n,
+                                                                          int* __restrict__ blk_cnt,
+                                                                          int64_t* __restrict__ result) {
+  const int r = blockIdx.x * COMPACT_BLOCK + threadIdx.x;
+  const int c = __syncthreads_count(r < n && flag_r[min(r, n - 1)]);
+  if (threadIdx.x == 0) {
+    blk_cnt[blockIdx.x] = c;
+    if (blockIdx.x == 0) result[2] = 0;  // kept boxes with a score > -inf: accumulated by the scatter launch
+  }
+}
 __global__ __launch_bounds__(COMPACT_BLOCK) void nms_compact_kernel(const uint8_t* __restrict__ flag_r,
                                                                     const int* __restrict__ order, int n,
+                                                                    const int* __restrict__ blk_cnt,
                                                                     int64_t* __restrict__ keep_out,
                                                                     const int* __restrict__ counters,
                                                                     int64_t* __restrict__ result,
                                                                     const float* __restrict__ scores) {
   __shared__ int wave_cnt[COMPACT_BLOCK / 64];
-  __shared__ int s_finite;
+  __shared__ int s_red[COMPACT_BLOCK / 64];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  if (tid == 0) s_finite = 0;
-  int base = 0, fin = 0;
-  for (int start = 0; start < n; start += COMPACT_BLOCK * COMPACT_CH) {
-    const int r0 = start + tid * COMPACT_CH;
-    uint32_t fl = 0;
-    int cnt = 0;
+  // workgroups before this one
+  int before = 0;
+  for (int j = tid; j < (int)blockIdx.x; j += COMPACT_BLOCK) before += blk_cnt[j];
 #pragma unroll
-    for (int q = 0; q < COMPACT_CH; q++) {
-      const bool f = r0 + q < n && flag_r[min(r0 + q, n - 1)];
-      fl |= f ? (1u << q) : 0u;
-      cnt += f ? 1 : 0;
-    }
-    int incl = cnt;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int v = __shfl_up(incl, o);
-      if (lane >= o) incl += v;
-    }
-    __syncthreads();  // wave_cnt of the previous pass has been read
-    if (lane == 63) wave_cnt[wid] = incl;
-    __syncthreads();
-    int off = base + incl - cnt, tot = 0;
-#pragma unroll
-    for (int k = 0; k < COMPACT_BLOCK / 64; k++) {
-      const int t = wave_cnt[k];
-      if (k < wid) off += t;
-      tot += t;
-    }
-#pragma unroll
-    for (int q = 0; q < COMPACT_CH; q++)
-      if ((fl >> q) & 1u) {
-        const int o = order[r0 + q];
-        keep_out[off++] = (int64_t)o;
-        fin += scores[o] > -INFINITY ? 1 : 0;
-      }
-    base += tot;
-  }
-  if (fin) atomicAdd(&s_finite, fin);
+  for (int o = 32; o >= 1; o >>= 1) before += __shfl_xor(before, o);
+  if (lane == 0) s_red[wid] = before;
+  const int r = blockIdx.x * COMPACT_BLOCK + tid;
+  const bool f = r < n && flag_r[min(r, n - 1)];
+  const unsigned long long bal = __ballot(f);
+  if (lane == 0) wave_cnt[wid] = __builtin_popcountll(bal);
   __syncthreads();
-  if (tid == 0) { result[0] = base; result[1] = counters[1]; result[2] = s_finite; result[3] = 0; }
+  int off = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < COMPACT_BLOCK / 64; k++) {
+    off += s_red[k];
+    if (k < wid) off += wave_cnt[k];
+    tot += wave_cnt[k];
+  }
+  bool fin = false;
+  if (f) {
+    const int o = order[r];
+    keep_out[off + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = (int64_t)o;
+    fin = scores[o] > -INFINITY;
+  }
+  const int nfin = __syncthreads_count(fin);
+  if (tid == 0) {
+    if (nfin) atomicAdd((unsigned long long*)&result[2], (unsigned long long)nfin);
+    if (blockIdx.x == gridDim.x - 1) {
+      int base = 0;
+      for (int k = 0; k < COMPACT_BLOCK / 64; k++) base += s_red[k];
+      result[0] = base + tot; result[1] = counters[1]; result[3] = 0;
+    }
+  }
 }
 
 // ---- batched launch: blockIdx.z = image --------------------------------------------------------
@@ -1021,8 +1029,11 @@ extern "C" int d2amd_nms(const float* boxes, const float* scores, const int64_t*
   if (rc != D2AMD_OK) return rc;
   hipLaunchKernelGGL(nms_scatter_flags_kernel, dim3(cdiv(N, T)), dim3(T), 0, s, w.keepbits, I.rankpos, N, w.flag_r);
   D2_LAUNCH_OK();
-  hipLaunchKernelGGL(nms_compact_kernel, dim3(1), dim3(COMPACT_BLOCK), 0, s, w.flag_r, w.order, N, keep_out,
-                     w.counters, result, scores);
+  hipLaunchKernelGGL(nms_compact_count_kernel, dim3(cdiv(N, COMPACT_BLOCK)), dim3(COMPACT_BLOCK), 0, s, w.flag_r, N, w.blk_cnt,
+                     result);
+  D2_LAUNCH_OK();
+  hipLaunchKernelGGL(nms_compact_kernel, dim3(cdiv(N, COMPACT_BLOCK)), dim3(COMPACT_BLOCK), 0, s, w.flag_r, w.order, N,
+                     w.blk_cnt, keep_out, w.counters, result, scores);
   D2_LAUNCH_OK();
   return D2AMD_OK;
 }

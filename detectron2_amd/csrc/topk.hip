@@ -348,14 +348,18 @@ __global__ __launch_bounds__(TK_THREADS) void tk_compact_kernel(TkParams P, SegS
 }
 
 // Final ordering of the <= k selected (key : index) pairs of a segment.  One workgroup bitonic-sorts a RUN of up to
-// TK_RUN pairs in LDS (128 KB); a segment with more (RetinaNet with TOPK_CANDIDATES_TEST 20000: BASELINE configs[3])
+// TK_RUN pairs in LDS (<= 128 KB); a segment with more (RetinaNet with TOPK_CANDIDATES_TEST 20000: BASELINE configs[3])
 // is cut into runs, every run is sorted by its own workgroup and written back, and tk_merge_kernel places every
 // element at  rank = position in its run + sum over the other runs of #elements below it  (binary searches; the
 // 64-bit keys are unique, so the ranks are a permutation).
-constexpr int TK_RUN = 16384;
+constexpr int TK_RUN_MAX = 16384;  // one run in LDS: 128 KB
+// run length of a launch whose largest segment selects kmax pairs: one run while it fits, else 4,096 -- a 16,384-pair
+// bitonic sort walks 16 pairs per thread through 105 steps (250 us for RetinaNet's 20,000 per level, r02 profile);
+// five 4,096 runs sorted by five workgroups + the rank merge take a quarter of that
+static inline int tk_run_for(int kmax) { return kmax <= 4096 ? TK_RUN_MAX : 4096; }  // (<= 4,096: one run)
 
 __global__ __launch_bounds__(1024) void tk_sort_kernel(TkParams P, const SegState* __restrict__ st,
-                                                      unsigned long long* __restrict__ cand, int kmax,
+                                                      unsigned long long* __restrict__ cand, int kmax, int TK_RUN,
                                                       uint32_t* __restrict__ sel, int* __restrict__ cnt_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long sk[];
   const int seg = blockIdx.x, l = seg % P.in.L, img = seg / P.in.L;
@@ -395,7 +399,7 @@ __global__ __launch_bounds__(1024) void tk_sort_kernel(TkParams P, const SegStat
 }
 
 __global__ __launch_bounds__(256) void tk_merge_kernel(TkParams P, const SegState* __restrict__ st,
-                                                      const unsigned long long* __restrict__ cand, int kmax,
+                                                      const unsigned long long* __restrict__ cand, int kmax, int TK_RUN,
                                                       uint32_t* __restrict__ sel) {
   const int seg = blockIdx.x, l = seg % P.in.L, img = seg / P.in.L;
   const int total = st[seg].cnt;
@@ -486,17 +490,18 @@ int topk_select(const TopkInput& in, bool use_thr, float xmin, uint32_t* sel, in
   hipLaunchKernelGGL(tk_ties_kernel, grid, block, 0, s, P, w.st, w.blk_ties);
   if (!w.tickets) hipLaunchKernelGGL(tk_ties_scan_kernel, segs, block, 0, s, P, w.st, w.blk_ties);
   hipLaunchKernelGGL(tk_compact_kernel, grid, block, 0, s, P, w.st, w.blk_ties, w.cand, w.kmax);
+  const int run = tk_run_for(w.kmax);
   int pow2 = 1;
-  while (pow2 < w.kmax && pow2 < TK_RUN) pow2 <<= 1;
+  while (pow2 < w.kmax && pow2 < run) pow2 <<= 1;
   if ((size_t)pow2 * 8 > 64 * 1024)  // dynamic LDS beyond the default limit
     D2_HIP_OK(hipFuncSetAttribute((const void*)tk_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pow2 * 8));
-  const int runs = (w.kmax + TK_RUN - 1) / TK_RUN;
+  const int runs = (w.kmax + run - 1) / run;
   hipLaunchKernelGGL(tk_sort_kernel, dim3(in.N * in.L, runs), dim3(1024), (size_t)pow2 * 8, s, P, w.st, w.cand, w.kmax,
-                     sel, cnt);
+                     run, sel, cnt);
   D2_LAUNCH_OK();
   if (runs > 1) {
     hipLaunchKernelGGL(tk_merge_kernel, dim3(in.N * in.L, cdiv(w.kmax, 1024)), dim3(256), 0, s, P, w.st, w.cand, w.kmax,
-                       sel);
+                       run, sel);
     D2_LAUNCH_OK();
   }
   return D2AMD_OK;
