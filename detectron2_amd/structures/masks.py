@@ -4,6 +4,7 @@ and `crop_and_resize`, the Mask R-CNN training-target rasteriser (SURVEY 8(a) a1
 import ctypes
 from typing import List, Optional
 
+import numpy as np
 import torch
 
 from .. import _C
@@ -102,3 +103,139 @@ def crop_and_resize_batch(gt_masks: List["BitMasks"], boxes: List[torch.Tensor],
                 n_img, vp(ms), ci([int(m.shape[0]) for m in ms]), vp(bs), vp(ix) if ix is not None else None, ci(nb),
                 int(h), int(w), int(mask_size), _C.ptr(out), _C.ptr(status), _C.stream()))
     return out.view(torch.bool)
+
+
+class PolygonMasks:
+    """The polygon mask container of detectron2/structures/masks.py:265-420 (COCO's default mask format): a list of
+    instances, each a list of flat float64 polygons [x0, y0, x1, y1, ...], held on the HOST like the reference's
+    (`to()` is a no-op, `device` is cpu).  What differs is `crop_and_resize` -- the Mask R-CNN training-target
+    rasteriser: the reference rasterises instance by instance on the CPU (pycocotools) and copies the result to the
+    device; here the polygons are packed once per container into three device arrays and ONE kernel
+    (d2amd_polygon_crop_and_resize) rasterises all boxes -- with an optional per-box instance index, so that
+    `gt_masks[matched_idx].crop_and_resize(proposal_boxes, M)` needs no re-packing of the selected polygons."""
+
+    def __init__(self, polygons):
+        if not isinstance(polygons, list):
+            raise ValueError("Cannot create PolygonMasks: Expect a list of list of polygons per image. "
+                             "Got '{}' instead.".format(type(polygons)))
+        self.polygons: List[List[np.ndarray]] = [self._instance(inst) for inst in polygons]
+        self._packed = {}  # device -> (coords, poly_offsets, inst_offsets)
+
+    @staticmethod
+    def _instance(polys):
+        if not isinstance(polys, list):
+            raise ValueError("Cannot create polygons: Expect a list of polygons per instance. "
+                             "Got '{}' instead.".format(type(polys)))
+        out = []
+        for t in polys:
+            a = np.asarray(t.cpu().numpy() if isinstance(t, torch.Tensor) else t).astype("float64")
+            if len(a) % 2 != 0 or len(a) < 6:
+                raise ValueError(f"Cannot create a polygon from {len(a)} coordinates.")
+            out.append(a)
+        return out
+
+    def to(self, *args, **kwargs) -> "PolygonMasks":
+        return self
+
+    @property
+    def device(self) -> torch.device:
+        return torch.device("cpu")
+
+    def __len__(self) -> int:
+        return len(self.polygons)
+
+    def __iter__(self):
+        return iter(self.polygons)
+
+    def __repr__(self) -> str:
+        return self.__class__.__name__ + "(num_instances={})".format(len(self.polygons))
+
+    def __getitem__(self, item) -> "PolygonMasks":
+        """int -> one instance; slice / list[int] / int64 vector / bool vector -> the selected instances."""
+        if isinstance(item, int):
+            chosen = [self.polygons[item]]
+        elif isinstance(item, slice):
+            chosen = self.polygons[item]
+        elif isinstance(item, list):
+            chosen = [self.polygons[i] for i in item]
+        elif isinstance(item, torch.Tensor):
+            if item.dtype == torch.bool:
+                assert item.dim() == 1, item.shape
+                ids = item.nonzero().squeeze(1).cpu().numpy().tolist()
+            elif item.dtype in (torch.int32, torch.int64):
+                ids = item.cpu().numpy().tolist()
+            else:
+                raise ValueError("Unsupported tensor dtype={} for indexing!".format(item.dtype))
+            chosen = [self.polygons[i] for i in ids]
+        else:
+            raise ValueError("Unsupported index {} for PolygonMasks".format(type(item)))
+        return PolygonMasks(chosen)
+
+    def nonempty(self) -> torch.Tensor:
+        return torch.from_numpy(np.asarray([1 if len(inst) > 0 else 0 for inst in self.polygons], dtype=bool))
+
+    def get_bounding_boxes(self):
+        """Tight boxes around the polygons (masks.py:322-336: float32, zeros for an instance without polygons)."""
+        from .boxes import Boxes
+
+        boxes = torch.zeros(len(self.polygons), 4, dtype=torch.float32)
+        for i, inst in enumerate(self.polygons):
+            if inst:
+                xy = np.concatenate([p.reshape(-1, 2) for p in inst]).astype(np.float32)
+                lo, hi = xy.min(0), np.maximum(xy.max(0), 0)
+                boxes[i] = torch.from_numpy(np.concatenate([lo, hi]))
+        return Boxes(boxes)
+
+    def area(self) -> torch.Tensor:
+        """Shoelace area per instance (masks.py:422-441)."""
+        out = []
+        for inst in self.polygons:
+            a = 0.0
+            for p in inst:
+                x, y = p[0::2], p[1::2]
+                a += 0.5 * np.abs(np.dot(x, np.roll(y, 1)) - np.dot(y, np.roll(x, 1)))
+            out.append(a)
+        return torch.tensor(out)
+
+    # ---- the hot-path part ---------------------------------------------------------------------------------
+    def _pack(self, device):
+        """(coords f64, poly_offsets i64, inst_offsets i64) on `device`, built once per container and device."""
+        key = str(device)
+        if key not in self._packed:
+            flat = [p for inst in self.polygons for p in inst]
+            coords = np.concatenate(flat) if flat else np.zeros(0, np.float64)
+            poly_off = np.zeros(len(flat) + 1, np.int64)
+            np.cumsum([len(p) for p in flat], out=poly_off[1:])
+            inst_off = np.zeros(len(self.polygons) + 1, np.int64)
+            np.cumsum([len(inst) for inst in self.polygons], out=inst_off[1:])
+            self._packed[key] = tuple(torch.from_numpy(a).to(device) for a in (coords, poly_off, inst_off))
+        return self._packed[key]
+
+    def crop_and_resize(self, boxes: torch.Tensor, mask_size: int) -> torch.Tensor:
+        """(N, mask_size, mask_size) bool on boxes.device: instance i rasterised inside boxes[i] (masks.py:396-420)."""
+        assert len(boxes) == len(self), "{} != {}".format(len(boxes), len(self))
+        return self._crop(boxes, None, mask_size, None)
+
+    def crop_and_resize_indexed(self, boxes: torch.Tensor, index: torch.Tensor, mask_size: int,
+                                status: torch.Tensor = None) -> torch.Tensor:
+        """`self[index].crop_and_resize(boxes, mask_size)` without building the selected container: box k is
+        rasterised from instance index[k].  An index outside [0, len(self)) sets bit 0 of `status` (int32[1] on the
+        device, optional)."""
+        assert len(boxes) == len(index), "{} != {}".format(len(boxes), len(index))
+        return self._crop(boxes, index, mask_size, status)
+
+    def _crop(self, boxes, index, mask_size, status):
+        _C.require_gpu(boxes, op="PolygonMasks.crop_and_resize")
+        dev = boxes.device
+        n = int(boxes.shape[0])
+        out = torch.empty((n, mask_size, mask_size), dtype=torch.uint8, device=dev)
+        if n == 0:
+            return out.view(torch.bool)
+        coords, poly_off, inst_off = self._pack(dev)
+        b = boxes.detach().to(dtype=torch.float32).contiguous()
+        idx = None if index is None else index.detach().to(device=dev, dtype=torch.int64).contiguous()
+        with _C.on_device(dev):
+            _C.check(_C.lib().d2amd_polygon_crop_and_resize(_C.ptr(coords), _C.ptr(poly_off), _C.ptr(inst_off), len(self),
+                                                            _C.ptr(b), _C.ptr(idx), n, int(mask_size), _C.ptr(out),
+                                                            _C.ptr(status), _C.stream()))
+        return out.view(torch.bool)

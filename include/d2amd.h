@@ -280,6 +280,22 @@ int d2amd_bitmask_crop_and_resize_batch(int num_images, const uint8_t* const* ma
                                         const int* n_boxes, int H, int W, int mask_size, uint8_t* out, int* status,
                                         void* stream);
 
+/* ---- PolygonMasks.crop_and_resize (detectron2/structures/masks.py:396-420 + rasterize_polygons_within_box :39-86 +
+ * polygons_to_bitmask :20-36 = pycocotools frPyObjects / merge / decode): Mask R-CNN's training targets from COCO
+ * polygons (the default MASK_FORMAT), rasterised on the device.
+ *   coords        [total] float64 (device): x0, y0, x1, y1, ... of all polygons, concatenated
+ *   poly_offsets  [P + 1] int64 (device): polygon p = coords[poly_offsets[p] .. poly_offsets[p + 1])
+ *   inst_offsets  [n_instances + 1] int64 (device): instance i = polygons [inst_offsets[i], inst_offsets[i + 1])
+ *   boxes [n_boxes,4] fp32 xyxy; index [n_boxes] int64 or NULL: box k crops instance index[k] (the matched ground
+ *   truth of a sampled proposal), NULL: instance k (then n_boxes == n_instances)
+ *   out [n_boxes, M, M] uint8 0/1.  status [1] int32 (device, zeroed by the caller, may be NULL): bit 0 an index
+ *   outside [0, n_instances), bit 1 a polygon with more than 4,096 vertices (skipped), bit 2 a boundary walk of
+ *   2^30 points (skipped).  mask_size <= 64.  The rasteriser restates cocoapi's published algorithm (pycocotools is
+ *   not part of the reference tree: parity with it is unpinned). */
+int d2amd_polygon_crop_and_resize(const double* coords, const int64_t* poly_offsets, const int64_t* inst_offsets,
+                                  int n_instances, const float* boxes, const int64_t* index, int n_boxes,
+                                  int mask_size, uint8_t* out, int* status, void* stream);
+
 /* ---- Mask-head glue.  detectron2/modeling/roi_heads/mask_head.py:31-158.
  * logits [B,C,HW] `dtype` (HW = Hmask*Wmask, contiguous NCHW), classes [B] int64 or NULL (class-agnostic,
  * C == 1), gt_masks [B,HW] uint8 / bool storage (the output of d2amd_bitmask_crop_and_resize).

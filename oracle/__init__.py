@@ -218,3 +218,35 @@ def deform_conv_backward(x, offset, weight, grad_out, mask=None, with_bias=False
                                    co, kh, kw, s[0], s[1], p[0], p[1], d[0], d[1], groups,
                                    deformable_groups, _p(gi), _p(go), _p(gm), _p(gw), _p(gb))
     return dict(grad_input=gi, grad_offset=go, grad_mask=gm, grad_weight=gw, grad_bias=gb)
+
+
+def polygons_to_bitmask(polygons, height, width):
+    """detectron2/structures/masks.py:20-36 with pycocotools restated (orc_poly_to_mask): the union of the polygons'
+    masks; polygons = list of flat (x0, y0, x1, y1, ...) arrays (double)."""
+    out = np.zeros((height, width), np.uint8)
+    for p in polygons:
+        xy = np.ascontiguousarray(np.asarray(p, np.float64).reshape(-1))
+        lib().orc_poly_to_mask(xy.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), len(xy) // 2, int(height), int(width),
+                               _p(out, _u8p))
+    return out.astype(bool)
+
+
+def rasterize_polygons_within_box(polygons, box, mask_size):
+    """masks.py:39-86, operation for operation: shift by the box origin, scale by mask_size / max(extent, 0.1) (the
+    box is float32 as `box.numpy()` gives it, the polygons float64), rasterise on a mask_size x mask_size grid."""
+    box = np.asarray(box, np.float32)
+    w, h = box[2] - box[0], box[3] - box[1]
+    polys = [np.array(p, np.float64).reshape(-1).copy() for p in polygons]
+    for p in polys:
+        p[0::2] = p[0::2] - box[0]
+        p[1::2] = p[1::2] - box[1]
+    ratio_h = mask_size / max(h, 0.1)
+    ratio_w = mask_size / max(w, 0.1)
+    if ratio_h == ratio_w:
+        for p in polys:
+            p *= ratio_h
+    else:
+        for p in polys:
+            p[0::2] *= ratio_w
+            p[1::2] *= ratio_h
+    return polygons_to_bitmask(polys, mask_size, mask_size)

@@ -1037,3 +1037,67 @@ void orc_matcher(const float* q, int M, int N, const float* thr, const signed ch
     }
   }
 }
+
+/* ------------------------------------------------------------------------------------ */
+/* Polygon rasterisation: detectron2/structures/masks.py:20-36 (polygons_to_bitmask) calls pycocotools
+ * `mask_util.frPyObjects` + `merge` + `decode`.  pycocotools is a third-party dependency that is NOT in
+ * /root/reference (setup.py install_requires "pycocotools>=2.0.2") and not installed here: PARITY UNPINNED.
+ * This restates the published algorithm of cocoapi `common/maskApi.c` (pycocotools 2.0.x): rleFrPoly -- upsample by
+ * 5, walk every edge densely with the rounded-slope stepping, keep the points where the x coordinate changes as
+ * y-boundary crossings, downsample, sort the column-major positions x*h + y, take differences as run lengths
+ * (zero-length runs merge) -- then rleMerge (union) and rleDecode (column-major runs starting with 0).
+ * A pixel with column-major index t is therefore set iff an ODD number of crossings has position <= t; the union of
+ * several polygons is the OR of their masks.  Anchored on the reference's own known answer
+ * tests/structures/test_masks.py:31-38 (an integer box polygon fills exactly [x0, x1) x [y0, y1)).
+ * out: uint8 (h, w) row-major, OR-ed into (the caller zeroes it); xy: k vertices (x, y) in double. */
+static int orc_int_of(double v) { /* (int) of a double as x86 does it: NaN / out of range -> INT_MIN */
+  if (!(v > -2147483649.0 && v < 2147483648.0)) return (int)0x80000000;
+  return (int)v;
+}
+int orc_poly_to_mask(const double* xy, int k, int h, int w, uint8_t* out) {
+  if (k <= 0 || h <= 0 || w <= 0) return 0;
+  const double scale = 5;
+  int* x = (int*)malloc(sizeof(int) * (size_t)(k + 1));
+  int* y = (int*)malloc(sizeof(int) * (size_t)(k + 1));
+  for (int j = 0; j < k; j++) x[j] = orc_int_of(scale * xy[j * 2 + 0] + .5);
+  x[k] = x[0];
+  for (int j = 0; j < k; j++) y[j] = orc_int_of(scale * xy[j * 2 + 1] + .5);
+  y[k] = y[0];
+  size_t m = 0;
+  for (int j = 0; j < k; j++) {
+    long ax = labs((long)x[j] - x[j + 1]), ay = labs((long)y[j] - y[j + 1]);
+    m += (size_t)(ax > ay ? ax : ay) + 1;
+  }
+  int* u = (int*)malloc(sizeof(int) * m);
+  int* v = (int*)malloc(sizeof(int) * m);
+  m = 0;
+  for (int j = 0; j < k; j++) {
+    int xs = x[j], xe = x[j + 1], ys = y[j], ye = y[j + 1], dx, dy, t, d, flip;
+    double s;
+    dx = abs(xe - xs); dy = abs(ys - ye);
+    flip = (dx >= dy && xs > xe) || (dx < dy && ys > ye);
+    if (flip) { t = xs; xs = xe; xe = t; t = ys; ys = ye; ye = t; }
+    s = dx >= dy ? (double)(ye - ys) / dx : (double)(xe - xs) / dy;
+    if (dx >= dy) for (d = 0; d <= dx; d++) {
+      t = flip ? dx - d : d; u[m] = t + xs; v[m] = orc_int_of(ys + s * t + .5); m++;
+    } else for (d = 0; d <= dy; d++) {
+      t = flip ? dy - d : d; v[m] = t + ys; u[m] = orc_int_of(xs + s * t + .5); m++;
+    }
+  }
+  /* y-boundary crossings, downsampled; toggle counts per column-major position */
+  unsigned* cnt = (unsigned*)calloc((size_t)h * w + 1, sizeof(unsigned));
+  for (size_t j = 1; j < m; j++) if (u[j] != u[j - 1]) {
+    double xd = (double)(u[j] < u[j - 1] ? u[j] : u[j] - 1); xd = (xd + .5) / scale - .5;
+    if (floor(xd) != xd || xd < 0 || xd > w - 1) continue;
+    double yd = (double)(v[j] < v[j - 1] ? v[j] : v[j - 1]); yd = (yd + .5) / scale - .5;
+    if (yd < 0) yd = 0; else if (yd > h) yd = h; yd = ceil(yd);
+    cnt[(size_t)((int)xd) * h + (int)yd]++;
+  }
+  unsigned par = 0;
+  for (int t = 0; t < h * w; t++) {  /* column-major: t = col * h + row */
+    par ^= cnt[t] & 1u;
+    if (par) out[(size_t)(t % h) * w + (t / h)] = 1;
+  }
+  free(x); free(y); free(u); free(v); free(cnt);
+  return 0;
+}

@@ -443,3 +443,28 @@ def test_logit_lower_bound_is_the_exact_threshold():
     assert np.isnan(odd.logit_lower_bound(1.0)) and np.isnan(odd.logit_lower_bound(1.5))
     assert odd.logit_lower_bound(-0.1) == -np.inf
     assert odd.sigmoid32(odd.logit_lower_bound(0.0)) > 0
+
+
+def test_polygon_rasteriser_restatement_known_answers():
+    """oracle.polygons_to_bitmask (cocoapi rleFrPoly restated; pycocotools itself is not available: parity unpinned)
+    against the reference's own known answer -- tests/structures/test_masks.py:31-38: the polygon of an integer box,
+    rasterised on a 4 x 4 grid, has exactly that box as its bounding box (here: fills [x0, x1) x [y0, y1)) -- and
+    against structural properties of the algorithm (union of polygons, translation by whole pixels)."""
+    for box in ([1, 0, 4, 4], [1, 1, 3, 4], [0, 0, 0, 0]):
+        b = np.array(box, np.float64)
+        m = oracle.polygons_to_bitmask([b[[0, 1, 2, 1, 2, 3, 0, 3]]], 4, 4)
+        exp = np.zeros((4, 4), bool)
+        exp[box[1]:box[3], box[0]:box[2]] = True
+        assert np.array_equal(m, exp)
+    rng = np.random.default_rng(0)
+    a = rng.uniform(2, 26, 14)
+    b2 = rng.uniform(2, 26, 10)
+    ma, mb = oracle.polygons_to_bitmask([a], 32, 32), oracle.polygons_to_bitmask([b2], 32, 32)
+    assert np.array_equal(oracle.polygons_to_bitmask([a, b2], 32, 32), ma | mb)        # rleMerge = union
+    shifted = a.copy()
+    shifted[0::2] += 3
+    shifted[1::2] += 2
+    ms = oracle.polygons_to_bitmask([shifted], 32, 32)
+    assert np.array_equal(ms[2:, 3:], ma[:-2, :-3]) and ma.sum() > 20                   # whole-pixel translation
+    # rasterize_polygons_within_box: a box equal to the frame is the identity transform
+    assert np.array_equal(oracle.rasterize_polygons_within_box([a], [0, 0, 32, 32], 32), ma)
