@@ -768,14 +768,12 @@ def bench_dcn(args, ctx):
     for tag, nblk, ch, h, wd in DCN_STAGES:
         for b in range(nblk):
             mod = ModulatedDeformConv(ch, ch, 3, padding=1, bias=False).to(dev).to(dtype)
+            # NCHW, the layout of the reference's DeformBottleneckBlock (resnet.py:303-327) and of this library's DCN
+            # entry points (they keep their own NHWC copy of x / dY in the workspace)
             x = torch.randn(n_img, ch, h, wd, generator=gen).to(dev).to(dtype)
-            if args.layout == "nhwc":
-                x = x.contiguous(memory_format=torch.channels_last)
             off = (torch.randn(n_img, 18, h, wd, generator=gen) * 2).to(dev).to(dtype)
             msk = torch.sigmoid(torch.randn(n_img, 9, h, wd, generator=gen)).to(dev).to(dtype)
             gy = torch.randn(n_img, ch, h, wd, generator=gen).to(dev).to(dtype)
-            if args.layout == "nhwc":
-                gy = gy.contiguous(memory_format=torch.channels_last)
             blocks.append((tag, mod, x.requires_grad_(True), off.requires_grad_(True), msk.requires_grad_(True), gy))
             flops_fwd += 2.0 * ch * ch * 9 * n_img * h * wd
 
@@ -832,7 +830,7 @@ def bench_dcn(args, ctx):
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "dcnv2_r50_res3-5_13_blocks_fwd+bwd_bs2_800x1344 (BASELINE configs[4])",
-                   "layout": args.layout, "global_batch": world * n_img,
+                   "layout": "nchw", "global_batch": world * n_img,
                    "gflop_per_step": round(3 * flops_fwd / 1e9, 1),
                    "parallelism": f"dp{world}: images sharded; DCN weight gradients reduce with the model's (not in this step)"},
         "roofline": roof, "ops": ops,

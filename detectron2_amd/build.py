@@ -34,6 +34,7 @@ SOURCES = {
     "mask_targets.hip": ["-ffp-contract=off"],
     "mask_head.hip": [],
     "polygon_masks.hip": ["-ffp-contract=off"],
+    "layout.hip": [],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall",
           "-Wno-unused-function", "-Wno-unused-variable", "-fhip-fp32-correctly-rounded-divide-sqrt"]

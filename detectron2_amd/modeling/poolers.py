@@ -106,6 +106,35 @@ def _ptr_array(tensors):
     return arr
 
 
+def _transpose(src, dst, batch, rows, cols):
+    with _C.on_device(src.device):
+        _C.check(_C.lib().d2amd_transpose_batched(_C.ptr(src), _C.ptr(dst), batch, rows, cols, src.element_size(),
+                                                  _C.stream()))
+    return dst
+
+
+def _to_nhwc(t):
+    """The channels_last twin of a 4-D tensor.  NCHW-contiguous 2- / 4-byte tensors go through the library's tiled
+    transpose (d2amd_transpose_batched); torch's permuting copy is the fallback for anything else."""
+    if t.dim() != 4 or t.is_contiguous(memory_format=torch.channels_last):
+        return t if t.dim() != 4 else t
+    n, c, h, w = t.shape
+    if t.is_cuda and t.is_contiguous() and t.element_size() in (2, 4) and t.numel() and not t.requires_grad:
+        return _transpose(t, torch.empty_like(t, memory_format=torch.channels_last), n, c, h * w)
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+def _to_nchw(t):
+    """The NCHW-contiguous twin of a 4-D tensor (inverse of _to_nhwc)."""
+    if t.dim() != 4 or t.is_contiguous():
+        return t
+    n, c, h, w = t.shape
+    if (t.is_cuda and t.is_contiguous(memory_format=torch.channels_last) and t.element_size() in (2, 4) and t.numel()
+            and not t.requires_grad):
+        return _transpose(t, torch.empty(t.shape, dtype=t.dtype, device=t.device), n, h * w, c)
+    return t.contiguous()
+
+
 _NHWC_CACHE = {}  # id(feature tensor) -> (weakref, version, channels_last copy)
 
 
@@ -118,7 +147,7 @@ def _staged_nhwc(f):
     ent = _NHWC_CACHE.get(id(base))
     if ent is not None and ent[0]() is base and ent[1] == base._version:
         return ent[2]
-    cl = f.detach().contiguous(memory_format=torch.channels_last)
+    cl = _to_nhwc(f.detach())
     for k in [k for k, e in _NHWC_CACHE.items() if e[0]() is None]:  # copies of features that no longer exist
         del _NHWC_CACHE[k]
     if len(_NHWC_CACHE) >= 16:
@@ -162,7 +191,8 @@ def _forget_aliases(token):
 class _FusedROIPool(Function):
     @staticmethod
     @disable_torch_compiler
-    def forward(ctx, rois, cfg, chain, *feats):  # chain: None, or the token its aliases are remembered under
+    def forward(ctx, rois, cfg, chain, head, *feats):  # chain: None, or the token its aliases are remembered under;
+        # head: the inputs are the caller's tensors (not aliases of an earlier pooler)
         # rois: the (M, 5) pooler-format tensor, or a tuple of per-image (n_i, 4) fp32 HIP box tensors -- then the
         # conversion happens inside the same C call (d2amd_roi_pooler_forward_box_lists: no torch.cat, one call less)
         box_lists = None
@@ -202,10 +232,11 @@ class _FusedROIPool(Function):
         ctx.save_for_backward(rois)
         ctx.cfg, ctx.hw, ctx.nc, ctx.layout = cfg, hw, (n, c), layout
         ctx.needs = [f.requires_grad for f in feats]
-        ctx.chain = chain
+        ctx.chain, ctx.head = chain, head
         ctx.set_materialize_grads(False)  # unused outputs (the aliases of the last pooler of a chain) arrive as None
+        ctx.nchw_caller = _layout_of(feats[0]) == _C.NCHW  # gradients go back in the caller's layout
         if nchw_in:
-            out = out.contiguous()  # NCHW-contiguous result, as the caller's layout implies
+            out = _to_nchw(out)  # NCHW-contiguous result, as the caller's layout implies
         if chain is not None:
             # the features come back as outputs: autograd turns a returned input into a view whose gradient arrives
             # in backward() below -- the hook a later pooler of the same features chains onto (module docstring)
@@ -221,13 +252,17 @@ class _FusedROIPool(Function):
         if ctx.chain is not None:
             _forget_aliases(ctx.chain)
         if grad_output is None:  # only the alias outputs were used downstream: their gradient passes through
-            return (None, None, None) + tuple(h if need else None for h, need in zip(held, ctx.needs))
+            thru = (lambda t: _to_nchw(t) if t is not None else None) if (ctx.nchw_caller and ctx.head) else (lambda t: t)
+            return (None, None, None, None) + tuple(thru(h) if need else None for h, need in zip(held, ctx.needs))
         # The tile-gather backward is an NHWC kernel.  NCHW features take it too: dY (small) is
         # re-laid out once and the gradients are returned channels_last-strided, which autograd
         # accepts for NCHW inputs (values are identical; consumers restride on demand).  This
         # replaces the v0 NCHW path (per-level atomics into an fp32 buffer: 3.1 ms vs 0.2 ms).
-        g = grad_output.contiguous(memory_format=torch.channels_last)
+        g = _to_nhwc(grad_output.detach())
         p = _params(cfg, (n, c), hw, _C.dtype_code(g), _C.NHWC)
+        # the head of a chain (its inputs are the caller's tensors, not another pooler's aliases) hands NCHW callers
+        # NCHW gradients; inside a chain the buffers stay in the tile gather's layout
+        back = (lambda t: _to_nchw(t)) if (ctx.nchw_caller and ctx.head) else (lambda t: t)
         # per-ROI records + per-tile ROI lists (one wave per 8x8 tile bins the ROIs once per call)
         ws_bytes = _C.lib().d2amd_roi_pooler_backward_workspace_bytes(ctypes.byref(p), k)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=g.device)
@@ -242,7 +277,7 @@ class _FusedROIPool(Function):
                                                                    _ptr_array(held), k, _C.ptr(ws), ws_bytes,
                                                                    _C.stream())
                 if rc == 0:
-                    return (None, None, None) + tuple(h if need else None for h, need in zip(held, ctx.needs))
+                    return (None, None, None, None) + tuple(back(h) if need else None for h, need in zip(held, ctx.needs))
                 if rc != _C.EUNSUPPORTED:
                     _C.check(rc)
             grads = [torch.empty((n, c, h, w), dtype=g.dtype, device=g.device, memory_format=torch.channels_last)
@@ -252,7 +287,7 @@ class _FusedROIPool(Function):
         for i, h in enumerate(held):  # partial / differently laid out alias gradients: plain sum
             if h is not None:
                 grads[i] = grads[i] + h
-        return (None, None, None) + tuple(gr if need else None for gr, need in zip(grads, ctx.needs))
+        return (None, None, None, None) + tuple(back(gr) if need else None for gr, need in zip(grads, ctx.needs))
 
 
 class ROIPooler(nn.Module):
@@ -299,9 +334,10 @@ class ROIPooler(nn.Module):
         """One fused launch; in training the call is chained to earlier / later poolers of the same features."""
         chain = torch.is_grad_enabled() and all(t.requires_grad for t in x)
         if not chain:
-            return _FusedROIPool.apply(rois, cfg, None, *x)
+            return _FusedROIPool.apply(rois, cfg, None, True, *x)
         token = object()
-        res = _FusedROIPool.apply(rois, cfg, token, *_chained_inputs(x))
+        ins = _chained_inputs(x)
+        res = _FusedROIPool.apply(rois, cfg, token, all(a is b for a, b in zip(ins, x)), *ins)
         _remember_aliases(x, res[1:], token)
         return res[0]
 

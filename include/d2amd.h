@@ -55,6 +55,12 @@ void d2amd_timing_select(const char* names_csv); /* comma-separated kernel names
 void d2amd_timing_enable(int mask); /* legacy: bit 0 pool_bwd_*_r7 fine, 1 coarse, 2 / 3 the same for _r14; 0 = off */
 int d2amd_timing_read(const char* kernel, double* total_ms, int* launches);
 
+/* ---- layout conversion: batched 2-D transpose [batch][rows][cols] -> [batch][cols][rows] of 2- or 4-byte elements.
+ * NCHW -> NHWC: rows = C, cols = H*W; NHWC -> NCHW: rows = H*W, cols = C.  What the Python layer uses to bring an
+ * unmodified (NCHW) model's feature maps, pooled results and gradients in and out of the NHWC kernels; the reference
+ * has no counterpart (torchvision's ops are NCHW throughout). */
+int d2amd_transpose_batched(const void* src, void* dst, int batch, int rows, int cols, int element_size, void* stream);
+
 /* ---- ROIAlign (axis-aligned).  Replaces torchvision.ops.roi_align as called from
  * detectron2/layers/roi_align.py:58-65 (forward) and its autograd backward.
  * input  [N,C,H,W] `dtype`, `layout`; rois [K,5] fp32 (b, x1, y1, x2, y2);

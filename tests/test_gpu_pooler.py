@@ -372,3 +372,39 @@ def test_inverted_roi_with_fixed_sampling_ratio_forward_backward_adjoint(fused):
     assert rel_err(y.detach().cpu().numpy(), want_y) < 1e-4
     y.backward(torch.from_numpy(g).to(DEV))
     assert rel_err(xt.grad.cpu().numpy(), want_g) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_transpose_entry_and_nchw_callers_get_nchw_back(dtype):
+    """d2amd_transpose_batched == torch's permuting copy (odd sizes, both element sizes); an NCHW caller of the fused
+    pooler gets an NCHW-contiguous result and NCHW-contiguous gradients (a channels_last caller: channels_last)."""
+    from detectron2_amd.modeling.poolers import _to_nchw, _to_nhwc
+
+    torch.manual_seed(0)
+    for shape in [(2, 256, 50, 84), (3, 37, 13, 21), (1, 8, 1, 5), (4, 130, 7, 7)]:
+        t = torch.randn(shape, device=DEV).to(dtype)
+        cl = _to_nhwc(t)
+        assert cl.is_contiguous(memory_format=torch.channels_last) and torch.equal(cl, t)
+        assert torch.equal(cl.permute(0, 2, 3, 1).contiguous(), t.permute(0, 2, 3, 1).contiguous())
+        back = _to_nchw(cl)
+        assert back.is_contiguous() and torch.equal(back, t)
+    rng = np.random.default_rng(12)
+    feats, boxes = make_inputs(rng, 2, 32, 96, 128, 20)
+    pooler = ROIPooler(7, SCALES, 0, "ROIAlignV2")
+    bl = [Boxes(torch.from_numpy(b).to(DEV)) for b in boxes]
+    res = {}
+    for layout in ("nchw", "nhwc"):
+        xs = [torch.from_numpy(f).to(DEV).to(dtype) for f in feats]
+        if layout == "nhwc":
+            xs = [x.contiguous(memory_format=torch.channels_last) for x in xs]
+        xs = [x.requires_grad_(True) for x in xs]
+        y = pooler(xs, bl)
+        y.backward(torch.ones_like(y))
+        mf = torch.contiguous_format if layout == "nchw" else torch.channels_last
+        assert y.is_contiguous(memory_format=mf)
+        assert all(x.grad.is_contiguous(memory_format=mf) for x in xs)
+        res[layout] = (y.detach().float(), [x.grad.float() for x in xs])
+    tol = 1e-5 if dtype == torch.float32 else 2.0 ** -7
+    assert (res["nchw"][0] - res["nhwc"][0]).abs().max() <= tol * res["nhwc"][0].abs().max()
+    for a, b in zip(res["nchw"][1], res["nhwc"][1]):
+        assert (a - b).abs().max() <= tol * b.abs().max() + 1e-6
