@@ -103,6 +103,7 @@ int dcn_tc_forward(const DcnShape& s, const TcPlan& pl, const void* x_nhwc, cons
 
 struct TcBwPlan {
   bool ok;
+  bool gather;  // dX by column gather (no atomics): dcn_tc_backward_data_gather
   int tiles_y, tiles_x, csplit;
   int R, PHt, PWt, csplit_patch;  // LDS-patch variant: displacement margin (-1: all-atomics kernel), patch size
   size_t lds, lds_patch, wp_bytes;
@@ -112,6 +113,22 @@ template <typename T>
 int dcn_tc_backward_data(const DcnShape& s, const TcBwPlan& pl, const void* x_nhwc, const void* offset,
                          const void* mask, const void* weight, const void* gout_nhwc, float* gx, float* goff,
                          float* gmask, void* wp, hipStream_t st);
+
+// workspace of the column-gather backward (deform_conv_tc.hip)
+struct DcnGatherWs {
+  void* col;    // [P][K2][C] I/O dtype
+  int* cnt;     // [B*H*W + 1] entries per input pixel, then the overflow counter
+  void* lists;  // [B*H*W][128] {sample id, weight}
+  void* ovf;    // [P*K2*4] overflow entries (16 B each): room for every corner of every sample
+};
+static inline size_t dcn_gather_col_bytes(const DcnShape& s, size_t es) { return (size_t)s.P * s.K2 * s.C * es; }
+static inline size_t dcn_gather_cnt_bytes(const DcnShape& s) { return ((size_t)s.B * s.H * s.W + 1) * 4; }
+static inline size_t dcn_gather_list_bytes(const DcnShape& s) { return (size_t)s.B * s.H * s.W * 128 * 8; }
+static inline size_t dcn_gather_ovf_bytes(const DcnShape& s) { return (size_t)s.P * s.K2 * 4 * 16; }
+template <typename T>
+int dcn_tc_backward_data_gather(const DcnShape& s, const TcBwPlan& pl, const void* x_nhwc, const void* offset,
+                                const void* mask, const void* weight, const void* gout_nhwc, void* gx_t, float* goff,
+                                float* gmask, void* wp, const DcnGatherWs& gw, hipStream_t st);
 
 struct TcBwwPlan {
   bool ok;

@@ -498,6 +498,9 @@ __global__ __launch_bounds__(256) void dcn_bias_grad_kernel(const T* __restrict_
 static size_t al(size_t x) { return (x + 255) / 256 * 256; }
 
 struct DcnWs {
+  DcnGatherWs gather;  // column-gather backward (16-bit MFMA path, deformable_groups == 1)
+  void* gx_t;          // its dX in the I/O dtype, NHWC
+  bool use_gather;
   void *x_nhwc, *wr, *wt, *gout_nhwc;
   float *gx, *goff, *gmask, *gwr;
   int dtype;
@@ -530,6 +533,15 @@ static DcnWs carve_ws(const DcnShape& s, int dtype, bool backward, void* base) {
     w.goff = (float*)take((size_t)s.B * s.DG * 2 * s.K2 * s.L * 4);
     w.gmask = (float*)take((size_t)s.B * s.DG * s.K2 * s.L * 4);
     w.gwr = (float*)take((size_t)s.Co * s.Cg * s.K2 * 4);
+    const TcBwPlan bp = dcn_tc_plan_bwd(s, dtype);
+    w.use_gather = bp.ok && bp.gather;
+    if (w.use_gather) {
+      w.gather.col = take(dcn_gather_col_bytes(s, es));
+      w.gather.cnt = (int*)take(dcn_gather_cnt_bytes(s));
+      w.gather.lists = take(dcn_gather_list_bytes(s));
+      w.gather.ovf = take(dcn_gather_ovf_bytes(s));
+      w.gx_t = take((size_t)s.B * s.H * s.W * s.C * es);
+    }
   }
   w.total = off;
   return w;
@@ -603,13 +615,22 @@ static int bwd_host(const DcnShape& s, const void* x, const void* offset, const 
   if (need_data) {
     rc = launch_transpose<T, T>((const T*)gout, (T*)w.gout_nhwc, s.B, s.Co, s.L, st);
     if (rc) return rc;
-    { const int zrc = zero_async(w.gx, (size_t)s.B * s.H * s.W * s.C * 4, st); if (zrc) return zrc; }
     float* goff_f = goffset ? (is32 ? (float*)goffset : w.goff) : nullptr;
     float* gmask_f = (gmask && mask) ? (is32 ? (float*)gmask : w.gmask) : nullptr;
-    bool tc_done = false;
+    bool tc_done = false, gathered = false;
     if constexpr (!is32) {
       const TcBwPlan bp = dcn_tc_plan_bwd(s, sizeof(T) == 2 ? (int)w.dtype : D2AMD_F32);
-      if (bp.ok) {  // 16-bit MFMA path with the LDS patch (deform_conv_tc.hip); w.wt holds its packed weights
+      if (bp.ok && w.use_gather) {  // column gather: dX written once per pixel in the I/O dtype, no atomics, no zero fill
+        rc = dcn_tc_backward_data_gather<T>(s, bp, w.x_nhwc, offset, mask, weight, w.gout_nhwc, gin ? w.gx_t : nullptr,
+                                            goff_f, gmask_f, w.wt, w.gather, st);
+        if (rc) return rc;
+        tc_done = gathered = true;
+      }
+    }
+    if (!gathered) { const int zrc = zero_async(w.gx, (size_t)s.B * s.H * s.W * s.C * 4, st); if (zrc) return zrc; }
+    if constexpr (!is32) {
+      const TcBwPlan bp = dcn_tc_plan_bwd(s, sizeof(T) == 2 ? (int)w.dtype : D2AMD_F32);
+      if (bp.ok && !gathered) {  // 16-bit MFMA path with global atomics (deform_conv_tc.hip); w.wt holds its packed weights
         rc = dcn_tc_backward_data<T>(s, bp, w.x_nhwc, offset, mask, weight, w.gout_nhwc, w.gx, goff_f, gmask_f, w.wt, st);
         if (rc) return rc;
         tc_done = true;
@@ -632,7 +653,8 @@ static int bwd_host(const DcnShape& s, const void* x, const void* offset, const 
                          (const T*)offset, (const T*)mask, (const T*)w.wt, (const T*)w.gout_nhwc, w.gx, goff_f, gmask_f);
     D2_LAUNCH_OK();
     if (gin) {
-      rc = launch_transpose<float, T>(w.gx, (T*)gin, s.B, s.H * s.W, s.C, st);
+      if (gathered) rc = launch_transpose<T, T>((const T*)w.gx_t, (T*)gin, s.B, s.H * s.W, s.C, st);
+      else rc = launch_transpose<float, T>(w.gx, (T*)gin, s.B, s.H * s.W, s.C, st);
       if (rc) return rc;
     }
     if (!is32) {

@@ -779,6 +779,7 @@ struct BwPair { float wgt; uint32_t eofs; };  // weight * mask of a (position, c
 struct BwArgs {
   const void *x, *offset, *mask, *wp, *gout;  // x NHWC, gout NHWC [P][Co], wp = tc_pack_weight_t layout
   float *gx, *goff, *gmask;                   // gx fp32 NHWC (zero-filled), goff / gmask fp32 NCHW-like
+  void* dcol;  // column-gather path: dcol[(position * K2 + tap) * C + channel] in the I/O dtype (then gx is null)
   int tiles_y, tiles_x, total, csplit;  // csplit: workgroups per (tile, deformable group), each a share of the channel chunks
   int ablate;  // profiling only: 1 no MFMA, 2 no phase A, 4 no phase B, 16 phase B without the atomics
 };
@@ -951,6 +952,26 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_tc_kernel(DcnShape s, BwA
           }
       }
       __syncthreads();
+      // ---- (3b) column-gather path: the dcol tile leaves as 16-bit rows col[position][tap][channel chunk] (128 B each)
+      if (a.dcol) {
+        const int n = tid >> 2, q = tid & 3;  // position, 16-channel quarter of the chunk
+        const int ho = ty * 8 + (n >> 3), wo = tx * 8 + (n & 7);
+        if (ho < s.Ho && wo < s.Wo) {
+          const long pp = ((long)b * s.Ho + ho) * s.Wo + wo;
+          const float* cp = &Cs[n * BW_CPITCH + 16 * q];
+          T* dst = (T*)a.dcol + (pp * s.K2 + tap) * s.C + cabs + 16 * q;
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            const float4 d0 = *reinterpret_cast<const float4*>(cp + 8 * h), d1 = *reinterpret_cast<const float4*>(cp + 8 * h + 4);
+            const float f[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+            uint32_t wv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+              wv[u] = (uint32_t)from_f32<T>(f[2 * u]).v | ((uint32_t)from_f32<T>(f[2 * u + 1]).v << 16);
+            *reinterpret_cast<raw16*>(dst + 8 * h) = raw16{wv[0], wv[1], wv[2], wv[3]};
+          }
+        }
+      }
       // ---- (4) phase A: d(offset), d(mask).  thread = (position n, channels q*8.. and (q+4)*8..)
       if ((a.goff || a.gmask) && !(a.ablate & 2)) {
         const int n = tid >> 2, q = tid & 3;
@@ -1329,6 +1350,9 @@ TcBwPlan dcn_tc_plan_bwd(const DcnShape& s, int dtype) {
   }
   pl.lds = (size_t)s.K2 * 64 * 3 * 4;
   pl.wp_bytes = (size_t)s.Co * s.Cg * s.K2 * 2;
+  // column-gather dX (no atomics): one deformable group, C = 64 * {1, 2, 4, 8}, sample ids fit 32 bits
+  pl.gather = s.DG == 1 && (s.C == 64 || s.C == 128 || s.C == 256 || s.C == 512) && (long)s.P * s.K2 < (1l << 31) &&
+      getenv("D2AMD_DCN_BWD_ATOMICS") == nullptr;
   // LDS patch variant (dcn_bwd_data_patch_kernel): the largest displacement margin R whose patch fits ~48 KB
   pl.R = -1; pl.PHt = pl.PWt = 0;
   {
@@ -1359,6 +1383,232 @@ TcBwPlan dcn_tc_plan_bwd(const DcnShape& s, int dtype) {
   pl.ok = true;
   return pl;
 }
+
+
+// =====================================================================================================
+// Backward w.r.t. the input WITHOUT atomics: column gather (r02).
+// The kernel above spends 310 of its 535 us (res3) in device-scope fp32 atomics: 4 corners x 9 taps x C channels per
+// position, retired at ~0.75 lane-ops / clk / CU.  Here dX is GATHERED, like the pooler backward:
+//   (a) dcn_bin_samples_kernel: every sample (position, tap) appends {sample id, weight * mask} to the list of each
+//       of its <= 4 corner PIXELS (one int atomic per corner -- 36 per position instead of 36 x C);
+//   (b) dcn_bwd_data_tc_kernel with `dcol`: the same MFMA stages write the dcol tile as 16-bit rows
+//       col[position][tap][C] (the column buffer of the reference's design, but 16-bit, backward only, and never read
+//       by a GEMM) and still produce d(offset) / d(mask); phase B (the atomics) is gone;
+//   (c) dcn_gather_dx_kernel: one wave per input pixel sorts its list by sample id (fixed summation order:
+//       deterministic) and accumulates  dX[pixel, :] = sum_e w_e * col[sample_e, :]  in fp32 registers, every pixel
+//       written once in the I/O dtype.  HBM / L2 bound: 36 rows of C x 2 B per pixel on average.
+// Pixels that collect more than DG_CAP entries (adversarial offsets) park the excess in an overflow array that the
+// gather scans when it is non-empty.  deformable_groups == 1 (R50's DCN); other shapes keep the kernel above.
+constexpr int DG_CAP = 128;  // list entries per pixel: 2 per lane
+struct __attribute__((aligned(8))) DgEntry { uint32_t sample; float w; };
+struct __attribute__((aligned(16))) DgOverflow { uint32_t pix, sample; float w; uint32_t pad; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void dcn_bin_samples_kernel(DcnShape s, const T* __restrict__ offset,
+                                                             const T* __restrict__ mask, int* __restrict__ cnt,
+                                                             DgEntry* __restrict__ lists, int* __restrict__ ovf_cnt,
+                                                             DgOverflow* __restrict__ ovf) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long)s.P * s.K2) return;
+  const int tap = (int)(t % s.K2);
+  const long pp = t / s.K2;
+  const int b = (int)(pp / s.L), l = (int)(pp - (long)b * s.L);
+  const int ho = l / s.Wo, wo = l - ho * s.Wo;
+  const int i = tap / s.kw, j = tap - i * s.kw;
+  // the table of dcn_bwd_data_tc_kernel, operation for operation (deformable group 0)
+  const long obase = (long)b * 2 * s.K2;
+  const float off_h = to_f32(offset[(obase + 2 * tap) * s.L + l]);
+  const float off_w = to_f32(offset[(obase + 2 * tap + 1) * s.L + l]);
+  const float m = mask ? to_f32(mask[((long)b * s.K2 + tap) * s.L + l]) : 1.f;
+  const float h_im = (float)(ho * s.sh - s.ph + i * s.dh) + off_h;
+  const float w_im = (float)(wo * s.sw - s.pw + j * s.dw) + off_w;
+  if (!(h_im > -1.f && w_im > -1.f && h_im < (float)s.H && w_im < (float)s.W)) return;
+  const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+  const int h_high = h_low + 1, w_high = w_low + 1;
+  const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+  const float hh = 1.f - lh, hw = 1.f - lw;
+  const int ys[4] = {h_low, h_low, h_high, h_high}, xs[4] = {w_low, w_high, w_low, w_high};
+  const float ws[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    if (ys[c] < 0 || ys[c] > s.H - 1 || xs[c] < 0 || xs[c] > s.W - 1) continue;
+    const float wg = ws[c] * m;
+    if (wg == 0.f) continue;  // contributes nothing (the atomics kernel skips it too)
+    const uint32_t pix = (uint32_t)(((long)b * s.H + ys[c]) * s.W + xs[c]);
+    const int slot = atomicAdd(&cnt[pix], 1);
+    if (slot < DG_CAP) {
+      lists[(long)pix * DG_CAP + slot] = DgEntry{(uint32_t)t, wg};
+    } else {
+      const int o = atomicAdd(ovf_cnt, 1);
+      ovf[o] = DgOverflow{pix, (uint32_t)t, wg, 0u};  // sized for every corner of every sample: never lost
+    }
+  }
+}
+
+// RL = lanes per column row = C / 8: every lane loads 16 B (8 channels), a wave instruction covers 64 / RL list entries
+// (C = 128: four rows of 256 B per load; 4-byte loads per lane ran at 2.6 TB/s, r02 profile).  Lane group g = lane / RL
+// takes entries g, g + EPW, ...; the groups' partial sums are added in a fixed order at the end.
+template <typename T, int RL>
+__global__ __launch_bounds__(256) void dcn_gather_dx_kernel(int npix, int C, const int* __restrict__ cnt,
+                                                           const DgEntry* __restrict__ lists,
+                                                           const int* __restrict__ ovf_cnt,
+                                                           const DgOverflow* __restrict__ ovf,
+                                                           const T* __restrict__ col, T* __restrict__ gx) {
+  constexpr int EPW = 64 / RL;  // entries per wave instruction
+  const int lane = threadIdx.x & 63;
+  const long pix = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pix >= npix) return;  // uniform per wave
+  const int n = min(cnt[pix], DG_CAP);
+  // two entries per lane; sort the <= 128 (sample, weight) pairs by sample id: lane i holds elements i and i + 64
+  const DgEntry* lp = lists + pix * DG_CAP;
+  uint32_t k0 = 0xffffffffu, k1 = 0xffffffffu;
+  float w0 = 0.f, w1 = 0.f;
+  if (lane < n) { const DgEntry e = lp[lane]; k0 = e.sample; w0 = e.w; }
+  if (lane + 64 < n) { const DgEntry e = lp[lane + 64]; k1 = e.sample; w1 = e.w; }
+  if (n > 1) {  // uniform.  bitonic sort over 128 virtual positions p = lane (k0) / lane + 64 (k1)
+    for (int kk = 2; kk <= 128; kk <<= 1) {
+      for (int j = kk >> 1; j > 0; j >>= 1) {
+        if (j == 64) {  // partner of position lane is position lane + 64: inside the lane (kk == 128: ascending)
+          if (k0 > k1) { const uint32_t tk = k0; k0 = k1; k1 = tk; const float tw = w0; w0 = w1; w1 = tw; }
+        } else {
+          const uint32_t p0k = (uint32_t)__shfl_xor((int)k0, j), p1k = (uint32_t)__shfl_xor((int)k1, j);
+          const float p0w = __shfl_xor(w0, j), p1w = __shfl_xor(w1, j);
+          const bool lower = (lane & j) == 0;
+          const bool up0 = (lane & kk) == 0, up1 = ((lane + 64) & kk) == 0;  // ascending blocks
+          // an element keeps the smaller key if it is the lower partner of an ascending block (or the upper of a
+          // descending one)
+          const bool take_min0 = lower == up0, take_min1 = lower == up1;
+          if (take_min0 ? (p0k < k0) : (p0k > k0)) { k0 = p0k; w0 = p0w; }
+          if (take_min1 ? (p1k < k1) : (p1k > k1)) { k1 = p1k; w1 = p1w; }
+        }
+      }
+    }
+  }
+  const int grp = lane / RL, sub = lane - grp * RL;
+  float acc[8];
+#pragma unroll
+  for (int v = 0; v < 8; v++) acc[v] = 0.f;
+  const T* cbase = col + (long)sub * 8;
+  // entry e of the sorted list lives in lane e (k0 / w0) or lane e - 64 (k1 / w1)
+  auto entry = [&](int e, uint32_t& sk, float& sw) __attribute__((always_inline)) {
+    const int src = e & 63;
+    const uint32_t a0 = (uint32_t)__shfl((int)k0, src), a1 = (uint32_t)__shfl((int)k1, src);
+    const float b0 = __shfl(w0, src), b1 = __shfl(w1, src);
+    sk = e < 64 ? a0 : a1;
+    sw = e < 64 ? b0 : b1;
+  };
+  constexpr int UN = 2;  // rows in flight per lane group
+  for (int e0 = 0; e0 < n; e0 += EPW * UN) {
+    raw16 q[UN];
+    float wv[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      const int e = e0 + u * EPW + grp;
+      uint32_t sk;
+      entry(min(e, n - 1), sk, wv[u]);
+      if (e >= n) wv[u] = 0.f;
+      q[u] = *reinterpret_cast<const raw16*>(cbase + (long)sk * C);
+    }
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      float f[8];
+      tc_unpack(q[u], f, T{});
+#pragma unroll
+      for (int v = 0; v < 8; v++) acc[v] += wv[u] * f[v];
+    }
+  }
+  const int novf = *ovf_cnt;
+  if (novf > 0) {  // uniform: some pixel collected more than DG_CAP entries (order of these additions: as stored)
+    for (int o0 = 0; o0 < novf; o0 += 64) {
+      const int o = o0 + lane;
+      DgOverflow e{0xffffffffu, 0u, 0.f, 0u};
+      if (o < novf) e = ovf[o];
+      unsigned long long hit = __ballot(e.pix == (uint32_t)pix);
+      while (hit) {
+        const int src = __builtin_ctzll(hit);
+        hit &= hit - 1;
+        const uint32_t sk = (uint32_t)__shfl((int)e.sample, src);
+        const float sw = __shfl(e.w, src);
+        if (grp == 0) {
+          float f[8];
+          tc_unpack(*reinterpret_cast<const raw16*>(cbase + (long)sk * C), f, T{});
+#pragma unroll
+          for (int v = 0; v < 8; v++) acc[v] += sw * f[v];
+        }
+      }
+    }
+  }
+  // the lane groups' partial sums, added in a fixed order (group 0 + 1, then + the pair above, ...)
+#pragma unroll
+  for (int d = RL; d < 64; d <<= 1) {
+#pragma unroll
+    for (int v = 0; v < 8; v++) acc[v] += __shfl_xor(acc[v], d);
+  }
+  if (grp == 0) {
+    uint32_t wv[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) wv[u] = (uint32_t)from_f32<T>(acc[2 * u]).v | ((uint32_t)from_f32<T>(acc[2 * u + 1]).v << 16);
+    *reinterpret_cast<raw16*>(gx + pix * C + (long)sub * 8) = raw16{wv[0], wv[1], wv[2], wv[3]};
+  }
+}
+
+template <typename T>
+int dcn_tc_backward_data_gather(const DcnShape& s, const TcBwPlan& pl, const void* x_nhwc, const void* offset,
+                                const void* mask, const void* weight, const void* gout_nhwc, void* gx_t, float* goff,
+                                float* gmask, void* wp, const DcnGatherWs& gw, hipStream_t st) {
+  const long npix = (long)s.B * s.H * s.W;
+  {  // per-call state: pixel counters + the overflow counter (one region)
+    const int zrc = zero_async(gw.cnt, (size_t)(npix + 1) * 4, st);
+    if (zrc) return zrc;
+  }
+  int* ovf_cnt = gw.cnt + npix;
+  const long nsamp = (long)s.P * s.K2;
+  hipLaunchKernelGGL((dcn_bin_samples_kernel<T>), dim3(cdiv(nsamp, 256)), dim3(256), 0, st, s, (const T*)offset,
+                     (const T*)mask, gw.cnt, (DgEntry*)gw.lists, ovf_cnt, (DgOverflow*)gw.ovf);
+  D2_LAUNCH_OK();
+  {
+    const long groups16 = (long)s.G * s.K2 * (s.Cg / 64) * 2 * (s.Cog / 16) * 64;
+    const int blocks = cdiv(groups16, 256) > 8192 ? 8192 : cdiv(groups16, 256);
+    hipLaunchKernelGGL((tc_pack_weight_t_kernel<T>), dim3(blocks), dim3(256), 0, st, (const T*)weight, (T*)wp, s.G,
+                       s.Cog, s.Cg, s.K2);
+    D2_LAUNCH_OK();
+  }
+  BwArgs a{};
+  a.x = x_nhwc; a.offset = offset; a.mask = mask; a.wp = wp; a.gout = gout_nhwc;
+  a.gx = nullptr; a.goff = goff; a.gmask = gmask; a.dcol = gw.col;
+  a.tiles_y = pl.tiles_y; a.tiles_x = pl.tiles_x; a.csplit = pl.csplit;
+  if (pl.csplit > 1) {
+    if (goff) { const int zrc = zero_async(goff, (size_t)s.B * s.DG * 2 * s.K2 * s.L * 4, st); if (zrc) return zrc; }
+    if (gmask) { const int zrc = zero_async(gmask, (size_t)s.B * s.DG * s.K2 * s.L * 4, st); if (zrc) return zrc; }
+  }
+  const long total = (long)s.B * pl.tiles_y * pl.tiles_x * s.DG * pl.csplit;
+  D2_CHECK_ARG(total < (1l << 30), "deform_conv: too many tiles");
+  a.total = (int)total;
+  const bool timed = timing_begin("dcn_bwd_data", st);
+  hipLaunchKernelGGL((dcn_bwd_data_tc_kernel<T>), dim3((a.total + 7) / 8 * 8), dim3(256), pl.lds, st, s, a);
+  if (timed) timing_end("dcn_bwd_data", st);
+  D2_LAUNCH_OK();
+  if (gx_t) {
+    const bool timed2 = timing_begin("dcn_bwd_gather", st);
+    const dim3 grid((unsigned)cdiv(npix, 4));
+    switch (s.C / 64) {
+      case 1: hipLaunchKernelGGL((dcn_gather_dx_kernel<T, 8>), grid, dim3(256), 0, st, (int)npix, s.C, gw.cnt, (const DgEntry*)gw.lists, ovf_cnt, (const DgOverflow*)gw.ovf, (const T*)gw.col, (T*)gx_t); break;
+      case 2: hipLaunchKernelGGL((dcn_gather_dx_kernel<T, 16>), grid, dim3(256), 0, st, (int)npix, s.C, gw.cnt, (const DgEntry*)gw.lists, ovf_cnt, (const DgOverflow*)gw.ovf, (const T*)gw.col, (T*)gx_t); break;
+      case 4: hipLaunchKernelGGL((dcn_gather_dx_kernel<T, 32>), grid, dim3(256), 0, st, (int)npix, s.C, gw.cnt, (const DgEntry*)gw.lists, ovf_cnt, (const DgOverflow*)gw.ovf, (const T*)gw.col, (T*)gx_t); break;
+      case 8: hipLaunchKernelGGL((dcn_gather_dx_kernel<T, 64>), grid, dim3(256), 0, st, (int)npix, s.C, gw.cnt, (const DgEntry*)gw.lists, ovf_cnt, (const DgOverflow*)gw.ovf, (const T*)gw.col, (T*)gx_t); break;
+      default: set_error("deform_conv: column gather needs C in {64, 128, 256, 512}"); return D2AMD_EUNSUPPORTED;
+    }
+    if (timed2) timing_end("dcn_bwd_gather", st);
+    D2_LAUNCH_OK();
+  }
+  return D2AMD_OK;
+}
+template int dcn_tc_backward_data_gather<bf16_t>(const DcnShape&, const TcBwPlan&, const void*, const void*, const void*,
+                                                 const void*, const void*, void*, float*, float*, void*,
+                                                 const DcnGatherWs&, hipStream_t);
+template int dcn_tc_backward_data_gather<f16_t>(const DcnShape&, const TcBwPlan&, const void*, const void*, const void*,
+                                                const void*, const void*, void*, float*, float*, void*,
+                                                const DcnGatherWs&, hipStream_t);
 
 template <typename T>
 int dcn_tc_backward_data(const DcnShape& s, const TcBwPlan& pl, const void* x_nhwc, const void* offset,

@@ -49,7 +49,7 @@ const char* d2amd_last_error(void);       /* last error message of this thread (
  * recorded by the caller cannot see).  For every selected kernel name, HIP events are recorded on the LAUNCH stream
  * right before / after each launch; d2amd_timing_read waits for them and returns the summed duration and the number
  * of launches since the last select / enable.  Names: "pool_bwd_staged_r7" / "_r14" (tile-gather backward of the
- * fused pooler, pooled size <= 7 / larger), "pool_fwd_r7" / "_r14", "dcn_fwd", "dcn_bwd_data", "dcn_bwd_weight",
+ * fused pooler, pooled size <= 7 / larger), "pool_fwd_r7" / "_r14", "dcn_fwd", "dcn_bwd_data", "dcn_bwd_gather", "dcn_bwd_weight",
  * "nms_mask", "nms_reduce".  Off by default (no events, no cost). */
 void d2amd_timing_select(const char* names_csv); /* comma-separated kernel names; NULL or "" = none */
 void d2amd_timing_enable(int mask); /* legacy: bit 0 pool_bwd_*_r7 fine, 1 coarse, 2 / 3 the same for _r14; 0 = off */
