@@ -215,3 +215,33 @@ def test_res4_shape_zero_offset_is_conv2d():
     ref.backward(go.bfloat16().float())
     assert rel_err(x.grad.float().cpu().numpy(), xr.grad.cpu().numpy()) < 2e-2
     assert rel_err(w.grad.float().cpu().numpy(), wr.grad.cpu().numpy()) < 2e-2
+
+
+# ------------------------------------------------------------------ column-gather backward (no atomics)
+def test_bwd_gather_overflow_and_atomics_path_agree():
+    """Every sample of the map lands next to ONE pixel (offsets = target - base position): that pixel collects
+    P x 9 entries, far beyond the 128-entry list -> the overflow array of the column-gather backward; the result
+    still matches the oracle, and the all-atomics kernel (D2AMD_DCN_BWD_ATOMICS, the r01 default) within tolerance."""
+    B, C, Co, H, W = 1, 64, 64, 12, 14
+    x, off, msk, w, bias, go, kw = make_case(31, B, C, Co, H, W, dtype=torch.float16)
+    hh, ww = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    for tap in range(9):
+        i, j = tap // 3, tap % 3
+        off[0, 2 * tap] = (5.3 - (hh - 1 + i)).to(off.dtype)      # h_im = 5.3 for every position and tap
+        off[0, 2 * tap + 1] = (6.6 - (ww - 1 + j)).to(off.dtype)  # w_im = 6.6
+    case = (x, off, msk, w, bias, go, kw)
+    check(case, TOL[torch.float16])
+    with env(D2AMD_DCN_BWD_ATOMICS=1):
+        a = run_gpu(*case)
+    g = run_gpu(*case)
+    for k in ("grad_input", "grad_offset", "grad_mask", "grad_weight"):
+        assert rel_err(a[k], g[k]) < TOL[torch.float16], k
+
+
+def test_bwd_gather_is_deterministic():
+    """The gather sums a pixel's list in ascending sample order: bit-identical gradients run to run (the atomics
+    kernel it replaces was not)."""
+    case = make_case(32, 2, 128, 128, 25, 42, dtype=torch.bfloat16, off_scale=2.0)
+    r = [run_gpu(*case) for _ in range(3)]
+    for k in ("grad_input", "grad_offset", "grad_mask"):
+        assert np.array_equal(r[0][k], r[1][k]) and np.array_equal(r[0][k], r[2][k]), k
