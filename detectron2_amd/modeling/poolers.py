@@ -15,10 +15,10 @@ CHAINED BACKWARD.  Mask R-CNN pools the same FPN features twice per iteration (b
 roi_heads.py:780-846), so autograd sums two dense gradients per level with an elementwise kernel (r01: 4 launches,
 274 MB of extra traffic per step).  Here the fused pooler also returns its feature inputs as (alias) outputs and
 remembers them; a later pooler call on the SAME feature tensors (same objects, unmodified) pools from the aliases.
-Its gradient then reaches the first pooler's backward as the gradient of those alias outputs, and the first
-pooler ADDS its own contribution into that buffer inside the tile gather (d2amd_roi_pooler_backward_accumulate):
-no separate sum, empty tiles untouched.  Values are those of autograd's sum.  Plain autograd semantics otherwise:
-a pooler whose result is unused simply contributes no gradient.
+In the backward pass the later pooler hands its work to the first one (whose node is its autograd parent through the
+aliases) instead of launching; the first pooler's backward writes its own gradient and lets the deferred tile
+gathers ADD to it (d2amd_roi_pooler_backward_accumulate): no separate sum, empty tiles untouched, values = autograd's
+sum.  A pooler whose result is unused contributes nothing, as in plain autograd.
 """
 import ctypes
 import math
@@ -160,16 +160,35 @@ _ALIASES = {}  # id(feature tensor) -> (weakref to it, its version, alias output
 _ALIAS_CAP = 16
 
 
+_DEFERRED = {}     # token of a pooler call -> tile-gather work handed to it by the later poolers of its chain
+_PLACEHOLDER = {}  # (dtype, device) -> zero scalar whose zero-stride expansions stand in for deferred gradients
+
+
+def _placeholder(shape, dtype, device):
+    z = _PLACEHOLDER.get((dtype, device))
+    if z is None:
+        z = _PLACEHOLDER[(dtype, device)] = torch.zeros((), dtype=dtype, device=device)
+    return z.expand(shape)
+
+
+def _is_placeholder(t):
+    z = _PLACEHOLDER.get((t.dtype, t.device))
+    return z is not None and t.data_ptr() == z.data_ptr() and all(st == 0 for st in t.stride())
+
+
 def _chained_inputs(x):
-    """The tensors to pool from: the remembered alias outputs of an earlier pooler call on exactly these feature
-    tensors, or x itself."""
-    out = []
+    """(tensors to pool from, token of the pooler that produced them): the remembered alias outputs of an earlier pooler
+    call on exactly these feature tensors, or (x itself, None)."""
+    out, tokens = [], set()
     for f in x:
         ent = _ALIASES.get(id(f))
         if ent is None or ent[0]() is not f or ent[1] != f._version:
-            return list(x)
+            return list(x), None
         out.append(ent[2])
-    return out
+        tokens.add(id(ent[3]))
+    if len(tokens) != 1:
+        return list(x), None
+    return out, _ALIASES[id(x[0])][3]
 
 
 def _remember_aliases(x, aliases, token):
@@ -191,8 +210,9 @@ def _forget_aliases(token):
 class _FusedROIPool(Function):
     @staticmethod
     @disable_torch_compiler
-    def forward(ctx, rois, cfg, chain, head, *feats):  # chain: None, or the token its aliases are remembered under;
-        # head: the inputs are the caller's tensors (not aliases of an earlier pooler)
+    def forward(ctx, rois, cfg, chain, head, upstream, *feats):
+        # chain: None, or the token this call's aliases are remembered under; head: the inputs are the caller's
+        # tensors; upstream: (not head) the token of the pooler whose aliases are this call's inputs
         # rois: the (M, 5) pooler-format tensor, or a tuple of per-image (n_i, 4) fp32 HIP box tensors -- then the
         # conversion happens inside the same C call (d2amd_roi_pooler_forward_box_lists: no torch.cat, one call less)
         box_lists = None
@@ -232,7 +252,7 @@ class _FusedROIPool(Function):
         ctx.save_for_backward(rois)
         ctx.cfg, ctx.hw, ctx.nc, ctx.layout = cfg, hw, (n, c), layout
         ctx.needs = [f.requires_grad for f in feats]
-        ctx.chain, ctx.head = chain, head
+        ctx.chain, ctx.head, ctx.upstream, ctx.dtype = chain, head, upstream, xs[0].dtype
         ctx.set_materialize_grads(False)  # unused outputs (the aliases of the last pooler of a chain) arrive as None
         ctx.nchw_caller = _layout_of(feats[0]) == _C.NCHW  # gradients go back in the caller's layout
         if nchw_in:
@@ -246,48 +266,65 @@ class _FusedROIPool(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_output, *held):
+        """A chain of poolers over the same features runs ONE sequence of tile gathers, in the head's backward (the head
+        is the pooler that took the caller's tensors; it runs last): a later pooler of the chain does not launch --
+        it hands its work (dY, rois, configuration) to the pooler whose aliases it consumed and returns zero-stride
+        placeholders as the aliases' gradients.  The head then writes its own gradient plainly (every tile once,
+        empty tiles zero-filled) and the deferred ones ADD to it (d2amd_roi_pooler_backward_accumulate: tiles no ROI
+        touches are neither read nor written).  The poolers with more ROIs come first in Mask R-CNN (box head, then
+        mask head), so the accumulating launches are the small ones."""
         (rois,) = ctx.saved_tensors
-        cfg, hw, (n, c), layout = ctx.cfg, ctx.hw, ctx.nc, ctx.layout
-        k = rois.shape[0]
+        cfg, hw, (n, c) = ctx.cfg, ctx.hw, ctx.nc
+        works = []
         if ctx.chain is not None:
             _forget_aliases(ctx.chain)
-        if grad_output is None:  # only the alias outputs were used downstream: their gradient passes through
-            thru = (lambda t: _to_nchw(t) if t is not None else None) if (ctx.nchw_caller and ctx.head) else (lambda t: t)
-            return (None, None, None, None) + tuple(thru(h) if need else None for h, need in zip(held, ctx.needs))
-        # The tile-gather backward is an NHWC kernel.  NCHW features take it too: dY (small) is
-        # re-laid out once and the gradients are returned channels_last-strided, which autograd
-        # accepts for NCHW inputs (values are identical; consumers restride on demand).  This
-        # replaces the v0 NCHW path (per-level atomics into an fp32 buffer: 3.1 ms vs 0.2 ms).
-        g = _to_nhwc(grad_output.detach())
-        p = _params(cfg, (n, c), hw, _C.dtype_code(g), _C.NHWC)
-        # the head of a chain (its inputs are the caller's tensors, not another pooler's aliases) hands NCHW callers
-        # NCHW gradients; inside a chain the buffers stay in the tile gather's layout
-        back = (lambda t: _to_nchw(t)) if (ctx.nchw_caller and ctx.head) else (lambda t: t)
-        # per-ROI records + per-tile ROI lists (one wave per 8x8 tile bins the ROIs once per call)
-        ws_bytes = _C.lib().d2amd_roi_pooler_backward_workspace_bytes(ctypes.byref(p), k)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=g.device)
-        # gradients that arrived for the alias outputs (a later pooler of the same features, or any other consumer
-        # of them): add into them in place when every level has one in the tile gather's layout
-        chained = (len(held) == len(hw) and all(
-            h is not None and h.dtype == g.dtype and h.device == g.device and tuple(h.shape) == (n, c) + tuple(s)
-            and h.is_contiguous(memory_format=torch.channels_last) for h, s in zip(held, hw)))
-        with _C.on_device(g.device):
-            if chained:
-                rc = _C.lib().d2amd_roi_pooler_backward_accumulate(ctypes.byref(p), _C.ptr(g), _C.ptr(rois),
-                                                                   _ptr_array(held), k, _C.ptr(ws), ws_bytes,
-                                                                   _C.stream())
-                if rc == 0:
-                    return (None, None, None, None) + tuple(back(h) if need else None for h, need in zip(held, ctx.needs))
-                if rc != _C.EUNSUPPORTED:
+            works = _DEFERRED.pop(ctx.chain, [])
+        if grad_output is not None:
+            works.insert(0, (_to_nhwc(grad_output.detach()), rois, cfg))  # own work first: the plain write
+        real = [h for h in held if h is not None and not _is_placeholder(h)]  # a foreign consumer of the aliases
+        if not ctx.head:
+            if works:
+                _DEFERRED.setdefault(ctx.upstream, []).extend(works)
+            if real:  # keep real gradients flowing; the deferred work is added upstream
+                return (None, None, None, None, None) + tuple(h if need else None for h, need in zip(held, ctx.needs))
+            ph = [(_placeholder((n, c) + tuple(s), ctx.dtype, rois.device) if works else None) for s in hw]
+            return (None, None, None, None, None) + tuple(g if need else None for g, need in zip(ph, ctx.needs))
+        # ---- head: launch everything
+        back = _to_nchw if ctx.nchw_caller else (lambda t: t)
+        grads = None
+        if real:
+            grads = [h if (h is not None and not _is_placeholder(h)) else None for h in held]
+            if any(g is None or not g.is_contiguous(memory_format=torch.channels_last) for g in grads):
+                grads = [(_to_nhwc(g) if g is not None else torch.zeros((n, c) + tuple(s), dtype=ctx.dtype,
+                                                                        device=rois.device,
+                                                                        memory_format=torch.channels_last))
+                         for g, s in zip(grads, hw)]
+        L = _C.lib()
+        for g, r, wcfg in works:
+            k = r.shape[0]
+            p = _params(wcfg, (n, c), hw, _C.dtype_code(g), _C.NHWC)
+            # per-ROI records + per-tile ROI lists (one wave per 8x8 tile bins the ROIs once per call)
+            ws_bytes = L.d2amd_roi_pooler_backward_workspace_bytes(ctypes.byref(p), k)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=g.device)
+            with _C.on_device(g.device):
+                if grads is None:
+                    grads = [torch.empty((n, c, h, w), dtype=g.dtype, device=g.device, memory_format=torch.channels_last)
+                             for (h, w) in hw]
+                    _C.check(L.d2amd_roi_pooler_backward(ctypes.byref(p), _C.ptr(g), _C.ptr(r), _ptr_array(grads), k,
+                                                         _C.ptr(ws), ws_bytes, _C.stream()))
+                    continue
+                rc = L.d2amd_roi_pooler_backward_accumulate(ctypes.byref(p), _C.ptr(g), _C.ptr(r), _ptr_array(grads), k,
+                                                            _C.ptr(ws), ws_bytes, _C.stream())
+                if rc == _C.EUNSUPPORTED:  # configuration outside the staged tile gather: fresh buffers + a sum
+                    extra = [torch.empty_like(t) for t in grads]
+                    _C.check(L.d2amd_roi_pooler_backward(ctypes.byref(p), _C.ptr(g), _C.ptr(r), _ptr_array(extra), k,
+                                                         _C.ptr(ws), ws_bytes, _C.stream()))
+                    grads = [a + b for a, b in zip(grads, extra)]
+                else:
                     _C.check(rc)
-            grads = [torch.empty((n, c, h, w), dtype=g.dtype, device=g.device, memory_format=torch.channels_last)
-                     for (h, w) in hw]
-            _C.check(_C.lib().d2amd_roi_pooler_backward(ctypes.byref(p), _C.ptr(g), _C.ptr(rois),
-                                                        _ptr_array(grads), k, _C.ptr(ws), ws_bytes, _C.stream()))
-        for i, h in enumerate(held):  # partial / differently laid out alias gradients: plain sum
-            if h is not None:
-                grads[i] = grads[i] + h
-        return (None, None, None, None) + tuple(back(gr) if need else None for gr, need in zip(grads, ctx.needs))
+        if grads is None:
+            return (None, None, None, None, None) + (None,) * len(hw)
+        return (None, None, None, None, None) + tuple(back(g) if need else None for g, need in zip(grads, ctx.needs))
 
 
 class ROIPooler(nn.Module):
@@ -334,10 +371,13 @@ class ROIPooler(nn.Module):
         """One fused launch; in training the call is chained to earlier / later poolers of the same features."""
         chain = torch.is_grad_enabled() and all(t.requires_grad for t in x)
         if not chain:
-            return _FusedROIPool.apply(rois, cfg, None, True, *x)
+            return _FusedROIPool.apply(rois, cfg, None, True, None, *x)
         token = object()
-        ins = _chained_inputs(x)
-        res = _FusedROIPool.apply(rois, cfg, token, all(a is b for a, b in zip(ins, x)), *ins)
+        ins, upstream = _chained_inputs(x)
+        if upstream is None and len(_DEFERRED) > 8:
+            _DEFERRED.clear()  # work deferred to poolers whose backward never ran (pruned graphs): drop it
+        _placeholder((1,), x[0].dtype, x[0].device)  # exists before any backward (and before a graph capture)
+        res = _FusedROIPool.apply(rois, cfg, token, upstream is None, upstream, *ins)
         _remember_aliases(x, res[1:], token)
         return res[0]
 

@@ -24,9 +24,9 @@ def per_kernel(d, sub):
     w = sum(v["sum_KiB"] for k, v in d["kernels_write"].items() if sub in k) / N
     return {"FETCH_SIZE_KiB_per_launch": f, "WRITE_SIZE_KiB_per_launch": w, "hbm_bytes_per_launch": int((2 * f + w) * 1024)}
 d = json.load(open("$OUT/pmc_roi_align_chain_bwd.json"))
-# the roofline kernel alone: the 7x7 tile gather (accumulate mode: it adds to the mask pooler's gradient)
-out["ops"]["roi_align_box_bwd"] = dict(per_kernel(d, "pool_bwd_mfma_kernel<d2amd::bf16_t, 8>"), note="pool_bwd_mfma_kernel<bf16_t, 8> alone, inside the chained backward (accumulate mode)")
-out["ops"]["roi_align_mask_bwd"] = dict(per_kernel(d, "pool_bwd_mfma_kernel<d2amd::bf16_t, 16>"), note="pool_bwd_mfma_kernel<bf16_t, 16> alone (plain write incl. empty tiles' zero fill by tile_lists_kernel, not counted here)")
+# the roofline kernel alone: the 7x7 tile gather (head of the chain)
+out["ops"]["roi_align_box_bwd"] = dict(per_kernel(d, "pool_bwd_mfma_kernel<d2amd::bf16_t, 8>"), note="pool_bwd_mfma_kernel<bf16_t, 8> alone, inside the chained backward (the head of the chain: plain write of every non-empty tile; empty tiles are zero-filled by tile_lists_kernel, not counted here)")
+out["ops"]["roi_align_mask_bwd"] = dict(per_kernel(d, "pool_bwd_mfma_kernel<d2amd::bf16_t, 16>"), note="pool_bwd_mfma_kernel<bf16_t, 16> alone, accumulate mode (adds to the box pooler's gradient; tiles no ROI touches are neither read nor written)")
 out["ops"]["backward_poolers_all_kernels"] = {k: d[k] for k in ("FETCH_SIZE_KiB_per_launch", "WRITE_SIZE_KiB_per_launch", "hbm_bytes_per_launch")}
 for op in ("roi_align_box_fwd", "roi_align_mask_fwd", "mask_targets"):
     e = json.load(open("$OUT/pmc_%s.json" % op))
