@@ -32,6 +32,19 @@ __device__ __forceinline__ float mt_iou(float4 a, float area1, float4 b) {
   return 0.f;
 }
 
+// the same expression when no operand is NaN (torch.min / max then equal fminf / fmaxf): 4 instructions instead of 20.
+// Callers check the boxes once per thread / ground-truth chunk and take mt_iou for anything containing a NaN.
+__device__ __forceinline__ float mt_iou_fast(float4 a, float area1, float4 b, float area2) {
+  float w = fminf(a.z, b.z) - fmaxf(a.x, b.x);
+  float h = fminf(a.w, b.w) - fmaxf(a.y, b.y);
+  if (w < 0) w = 0;
+  if (h < 0) h = 0;
+  const float inter = w * h;
+  if (inter > 0) return inter / (area1 + area2 - inter);
+  return 0.f;
+}
+__device__ __forceinline__ bool mt_has_nan(float4 v) { return v.x != v.x || v.y != v.y || v.z != v.z || v.w != v.w; }
+
 struct MatchCfg {
   float thr[D2AMD_MATCHER_MAX_THRESHOLDS];
   int8_t lab[D2AMD_MATCHER_MAX_THRESHOLDS + 1];
@@ -68,26 +81,33 @@ __global__ __launch_bounds__(MT_BLOCK) void match_pass1_kernel(const float4* __r
   __shared__ float4 g4[MT_CHUNK];
   __shared__ float garea[MT_CHUNK];
   __shared__ uint32_t rmax[MT_CHUNK];
+  __shared__ int s_gt_nan;
   const int tid = threadIdx.x, lane = tid & 63;
   const long n = (long)blockIdx.x * MT_BLOCK + tid;
   const bool valid = n < N;
   float4 b = make_float4(0, 0, 0, 0);
   if (FUSED && valid) b = boxes[n];
+  const float barea = (b.z - b.x) * (b.w - b.y);
+  const bool bnan = mt_has_nan(b);
   float best = 0.f;
   int besti = 0;
   bool have = false;
   for (int m0 = 0; m0 < M; m0 += MT_CHUNK) {
     const int mc = min(MT_CHUNK, M - m0);
     __syncthreads();
+    if (tid == 0) s_gt_nan = 0;
+    __syncthreads();
     for (int i = tid; i < mc; i += MT_BLOCK) {
       if (FUSED) {
         const float4 a = gt[m0 + i];
         g4[i] = a;
         garea[i] = (a.z - a.x) * (a.w - a.y);
+        if (mt_has_nan(a)) s_gt_nan = 1;
       }
       rmax[i] = 0u;
     }
     __syncthreads();
+    const bool slow = bnan || s_gt_nan != 0;  // a NaN coordinate somewhere: torch.min / max propagate it
     // MT_U ground-truth boxes per step: their IoUs, LDS reads and wave reductions are independent chains the
     // hardware overlaps (one box per step was a ~500-cycle dependent chain: 7 us even for 1,000 predictions)
     for (int i0 = 0; i0 < mc; i0 += MT_U) {
@@ -96,7 +116,8 @@ __global__ __launch_bounds__(MT_BLOCK) void match_pass1_kernel(const float4* __r
       for (int u = 0; u < MT_U; u++) {
         const int i = min(i0 + u, mc - 1);
         v[u] = 0.f;
-        if (valid) v[u] = FUSED ? mt_iou(g4[i], garea[i], b) : q[(long)(m0 + i) * N + n];
+        if (valid) v[u] = FUSED ? (slow ? mt_iou(g4[i], garea[i], b) : mt_iou_fast(g4[i], garea[i], b, barea))
+                                : q[(long)(m0 + i) * N + n];
       }
 #pragma unroll
       for (int u = 0; u < MT_U; u++) {
@@ -107,6 +128,8 @@ __global__ __launch_bounds__(MT_BLOCK) void match_pass1_kernel(const float4* __r
         }
       }
       if (rowmax) {  // uniform.  row maxima: wave max, then one LDS atomic per wave and box
+        // (tried: every lane with a non-zero quality issuing its own LDS atomicMax -- slower, 397 vs 229 us at
+        // M = 256, scripts/matcher_scan.py: conflicting ds_max serialise)
         uint32_t k[MT_U];
         unsigned long long any = 0ull;
 #pragma unroll
@@ -153,30 +176,38 @@ __global__ __launch_bounds__(MT_BLOCK) void match_pass2_kernel(const float4* __r
   __shared__ float4 g4[MT_CHUNK];
   __shared__ float garea[MT_CHUNK];
   __shared__ uint32_t rmax[MT_CHUNK];
+  __shared__ int s_gt_nan;
   const int tid = threadIdx.x;
   const long n = (long)blockIdx.x * MT_BLOCK + tid;
   const bool valid = n < N;
   float4 b = make_float4(0, 0, 0, 0);
   if (FUSED && valid) b = boxes[n];
+  const float barea = (b.z - b.x) * (b.w - b.y);
+  const bool bnan = mt_has_nan(b);
   bool hit = false;
   for (int m0 = 0; m0 < M; m0 += MT_CHUNK) {
     const int mc = min(MT_CHUNK, M - m0);
+    __syncthreads();
+    if (tid == 0) s_gt_nan = 0;
     __syncthreads();
     for (int i = tid; i < mc; i += MT_BLOCK) {
       if (FUSED) {
         const float4 a = gt[m0 + i];
         g4[i] = a;
         garea[i] = (a.z - a.x) * (a.w - a.y);
+        if (mt_has_nan(a)) s_gt_nan = 1;
       }
       rmax[i] = rowmax[m0 + i];
     }
     __syncthreads();
+    const bool slow = bnan || s_gt_nan != 0;
     if (valid) {
       for (int i0 = 0; i0 < mc; i0 += MT_U) {
 #pragma unroll
         for (int u = 0; u < MT_U; u++) {
           const int i = min(i0 + u, mc - 1);  // (a repeated last box only repeats its own test)
-          const float v = FUSED ? mt_iou(g4[i], garea[i], b) : q[(long)(m0 + i) * N + n];
+          const float v = FUSED ? (slow ? mt_iou(g4[i], garea[i], b) : mt_iou_fast(g4[i], garea[i], b, barea))
+                                : q[(long)(m0 + i) * N + n];
           // float equality like the reference (NaN never equal); the key of a non-negative value is its bits
           if (v == v && mt_key(v) == rmax[i] && rmax[i] != 0xffffffffu) hit = true;
         }
