@@ -86,6 +86,9 @@ def parse(argv=None):
                     help="test hook: launcher + process group + gradient all-reduce + timing reduction only, no "
                          "hot-path op (runs without a GPU with --backend gloo); the JSON line says so")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="plumbing check on a 1-GPU box: create the process group and issue the gradient all-reduce even "
+                         "at world size 1 (RCCL init, async collectives between the HIP graphs, barrier-bracketed timing)")
     a = ap.parse_args(argv)
     dflt = {"maskrcnn_train": (200, 20), "retinanet_100k": (30, 5), "dcn_r50": (20, 3)}[a.workload]
     a.steps = dflt[0] if a.steps is None else a.steps
@@ -376,7 +379,7 @@ class GraphedStep:
                 f.grad = None
             w.mask_logits.grad = None
             torch.autograd.backward([yb, ym, loss], [w.gbox, w.gmask, None])
-            return lab, loss
+            return lab, loss.detach()  # no reference into the captured autograd graph survives the capture
 
         self.ga, self.out_a = self._capture(part_a)
         self.gb, self.out_b = self._capture(part_b)
@@ -633,14 +636,14 @@ def bench_maskrcnn(args, ctx):
 def make_gradient_buckets(args, dev, dist, world):
     from detectron2_amd.sharding import MASK_RCNN_R50_FPN_GRADIENTS, GradientBuckets
 
-    if dist is None or world == 1 or args.grad_allreduce == "off":
+    if dist is None or (world == 1 and not args.force_dist) or args.grad_allreduce == "off":
         return None
     g = dict(MASK_RCNN_R50_FPN_GRADIENTS)
     names = [n for n, _ in MASK_RCNN_R50_FPN_GRADIENTS]
     # three buckets in gradient-ready order: ROI heads | RPN head + FPN + res5 | res4 + res3 (34 / 38 / 17 MB in bf16)
     layout = [[(n, g[n]) for n in names[0:3]], [(n, g[n]) for n in names[3:6]], [(n, g[n]) for n in names[6:8]]]
     wire = torch.bfloat16 if args.grad_allreduce == "bf16" else None
-    return GradientBuckets(layout, dev, dist, torch.float32, wire)
+    return GradientBuckets(layout, dev, dist, torch.float32, wire, reduce_single_rank=args.force_dist)
 
 
 def grads_description(grads):
@@ -922,10 +925,11 @@ def main():
         assert args.plumbing_only, "--backend gloo only serves --plumbing-only"
         dev = torch.device("cpu")
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
         if gpu:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:

@@ -114,8 +114,9 @@ class GradientBuckets:
     average.  With `dist` = None (one process) both are no-ops, like DDP at world size 1."""
 
     def __init__(self, buckets: Sequence[Sequence[Tuple[str, int]]], device, dist=None, grad_dtype=torch.float32,
-                 wire_dtype: Optional[torch.dtype] = None):
+                 wire_dtype: Optional[torch.dtype] = None, reduce_single_rank: bool = False):
         self.dist, self.device = dist, device
+        self.reduce_single_rank = reduce_single_rank  # issue the collectives at world size 1 too (plumbing checks)
         self.world = dist.get_world_size() if dist is not None else 1
         self.grad_dtype, self.wire_dtype = grad_dtype, wire_dtype or grad_dtype
         self.layout: List[List[Tuple[str, int]]] = [list(b) for b in buckets if len(b)]
@@ -148,7 +149,7 @@ class GradientBuckets:
         return done
 
     def reduce(self, i: int):
-        if self.dist is None or self.world == 1:
+        if self.dist is None or (self.world == 1 and not self.reduce_single_rank):
             return
         if self.wire[i] is not self.grads[i]:
             self.wire[i].copy_(self.grads[i])  # compress (fp16_compress_hook: cast before the all-reduce)
