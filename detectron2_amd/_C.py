@@ -31,6 +31,12 @@ class DcnParams(ctypes.Structure):
         "dil_w", "groups", "deformable_groups", "dtype")]
 
 
+class NmsGather(ctypes.Structure):
+    """d2amd_nms_gather (include/d2amd.h)"""
+    _fields_ = [("count", ctypes.c_int), ("src", ctypes.c_void_p * 4), ("dst", ctypes.c_void_p * 4),
+                ("row_bytes", ctypes.c_int * 4)]
+
+
 class PoolerParams(ctypes.Structure):
     _fields_ = ([(n, ctypes.c_int) for n in ("num_levels", "N", "C")] +
                 [("H", ctypes.c_int * 8), ("W", ctypes.c_int * 8), ("spatial_scale", ctypes.c_float * 8)] +
@@ -72,6 +78,9 @@ _SIGNATURES = {
     "d2amd_rpn_select_workspace_bytes": (_sz, [_i, _i]),
     "d2amd_rpn_select_proposals": (_i, [_vp, _vp, _vp, _i, _i, ctypes.POINTER(_i), _i, ctypes.POINTER(_i), _i, _f,
                                         ctypes.POINTER(_f), _f, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "d2amd_rpn_select_proposals_levels": (_i, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i,
+                                               ctypes.POINTER(_i), _i, ctypes.POINTER(_i), _i, _f, ctypes.POINTER(_f),
+                                               _f, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "d2amd_dense_select_workspace_bytes": (_sz, [_i, ctypes.POINTER(_i), _i, _i, _i]),
     "d2amd_dense_select_predictions": (_i, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i,
                                             ctypes.POINTER(_i), _i, _i, _f, _i, ctypes.POINTER(_f), _f, _vp, _vp, _vp,
@@ -80,6 +89,10 @@ _SIGNATURES = {
     "d2amd_nms": (_i, [_vp, _vp, _vp, _i64, _d, _i, _i64, _vp, _vp, _vp, _sz, _vp]),
     "d2amd_nms_batched": (_i, [_i, _vp, _vp, _vp, _vp, _d, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "d2amd_nms_batched_max_boxes": (_i, []),
+    "d2amd_nms_runs": (_i, [_vp, _vp, _vp, _i64, ctypes.POINTER(_i), _i, _i, _d, _i, _i64, _vp, _vp, _vp, _sz, _vp,
+                            _vp]),
+    "d2amd_nms_batched_runs": (_i, [_i, _vp, _vp, _vp, _vp, ctypes.POINTER(_i), _i, _i, _d, _i, _vp, _vp, _vp, _vp,
+                                    _vp, _vp, _vp]),
     "d2amd_paste_masks": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _i, _vp]),
     "d2amd_bitmask_crop_and_resize": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "d2amd_bitmask_crop_and_resize_indexed": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),

@@ -32,6 +32,7 @@ typedef unsigned long long u64;
 constexpr int RK_GROUP = 8;  // keys per scalar-load group of the ranking kernel (2 x s_load_dwordx16)
 constexpr int RK_JC = 512;   // keys per chunk: one (64-box block, chunk) task is ~2.5k VALU instructions per wave
 constexpr int RANK_MAX_N = 12288;  // brute-force ranking up to here (index must fit 16 bits)
+constexpr int NMS_MAX_RUNS = 8;    // pre-sorted runs a caller may describe (RPN / dense detectors: one per feature level)
 
 struct NmsWorkspace {
   float* keys_out;    // [n] sorted scores                        (radix path)
@@ -52,6 +53,7 @@ struct NmsWorkspace {
   uint8_t* flag_r;    // [n] kept flag in rank order              (radix path)
   int* blk_cnt;       // [n / 1024 + 1] kept flags per compaction workgroup (radix path)
   int* seg_start;     // [65536]
+  int* run_cnt;       // [NMS_MAX_RUNS] entries of a run with a score > -inf (pre-sorted runs path)
   void* sort_temp;
   size_t sort_temp_bytes;
   size_t zero_bytes;  // keepbits + counters
@@ -102,6 +104,7 @@ static void carve(NmsWorkspace& w, void* base, int64_t n, int wcap) {
   w.flag_r = (uint8_t*)take(n);
   w.blk_cnt = (int*)take((size_t)(n / 1024 + 2) * 4);
   w.seg_start = (int*)take(65536 * 4);
+  w.run_cnt = (int*)take(NMS_MAX_RUNS * 4);
   w.sort_temp_bytes = sort_temp_bytes(n);
   w.sort_temp = take(w.sort_temp_bytes);
   w.total = off;
@@ -251,6 +254,252 @@ __device__ __forceinline__ void nms_segments_body(const uint32_t* __restrict__ c
   }
 }
 
+// ---- step 1c: ORDER from pre-sorted runs ----------------------------------------------------------
+// The NMS callers of this path (find_top_rpn_proposals, DenseDetector inference) hand over candidates that the
+// top-k selection has just sorted: the array is a sequence of RUNS (one per feature level), and inside a run the
+// entries that are not parked at score -inf are in order (descending score, equal scores in array order).  Ranking
+// such an input from scratch (n^2 key compares, 26 us for 2 x 8,819; or two radix sorts for 100,000) is wasted work:
+// the global score rank of an entry is its position among the live entries of its own run plus, for every other
+// run, the number of live entries that precede it there -- one binary search per other run.
+//   nms_runs_scan:  per run, the live entries' keys compacted in order (cs), every entry's count of live
+//                   predecessors in its run (vr), the live count (run_cnt); also zeroes the reduction's accumulators
+//   nms_runs_rank:  rank -> order[]; parked entries follow all live ones in array order (what ranking them by
+//                   (score, index) gives); with runs == categories the class-major position IS the array position,
+//                   so the box records and segment starts are written here and nothing else is left of step 1.
+// Scores are compared through the same order-preserving integer key as everywhere else (NaN first, -0 below +0).
+// A run that is not in order is detected (flag bit 2 of the result's flags): the host then ranks from scratch.
+struct NmsRuns { int n_runs, are_cls; int off[NMS_MAX_RUNS + 1]; };
+
+__device__ __forceinline__ uint32_t run_key(float s) {  // ascending = descending score
+  uint32_t u = __float_as_uint(s);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return ~u;
+}
+constexpr uint32_t RUN_KEY_PARKED = 0xff800000u;  // run_key(-inf)
+
+constexpr int RUNS_SCAN_THREADS = 1024, RUNS_SCAN_WAVES = RUNS_SCAN_THREADS / 64;
+// One workgroup per run, RUNS_SCAN_ROWS rows of 1,024 consecutive entries per pass (coalesced: entry = row * 1,024 +
+// thread).  A row's live entries are ballot-counted per wave; ONE exclusive scan over the [row][wave] counts (in
+// that order = array order) gives every wave of every row its base.  (A thread owning consecutive entries needs
+// no such table but loads with a stride: 31-41 us for a run of 20,000.)
+template <int RUNS_SCAN_ROWS>
+__device__ __forceinline__ void nms_runs_scan_body(const float* __restrict__ scores, const NmsRuns& R,
+                                                   uint32_t* __restrict__ cs, int* __restrict__ vr,
+                                                   int* __restrict__ run_cnt, uint32_t* __restrict__ zero,
+                                                   int zero_words) {
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  for (int q = blockIdx.x * RUNS_SCAN_THREADS + tid; q < zero_words; q += gridDim.x * RUNS_SCAN_THREADS) zero[q] = 0u;
+  const int r = blockIdx.x;
+  if (r >= R.n_runs) return;
+  const int lo = R.off[r], hi = R.off[r + 1];
+  constexpr int CELLS = RUNS_SCAN_ROWS * RUNS_SCAN_WAVES;  // <= 256
+  __shared__ int cell[CELLS + 1];
+  int base = 0;
+  for (int c = lo; c < hi; c += RUNS_SCAN_THREADS * RUNS_SCAN_ROWS) {  // uniform trip count
+    uint32_t key[RUNS_SCAN_ROWS];
+    unsigned long long bal[RUNS_SCAN_ROWS];
+#pragma unroll
+    for (int k = 0; k < RUNS_SCAN_ROWS; k++) {
+      const int i = c + k * RUNS_SCAN_THREADS + tid;
+      key[k] = i < hi ? run_key(scores[i]) : RUN_KEY_PARKED;
+    }
+    __syncthreads();  // cell[] of the previous pass has been read
+#pragma unroll
+    for (int k = 0; k < RUNS_SCAN_ROWS; k++) {
+      bal[k] = __ballot(key[k] != RUN_KEY_PARKED);
+      if (lane == 0) cell[k * RUNS_SCAN_WAVES + wid] = __builtin_popcountll(bal[k]);
+    }
+    __syncthreads();
+    if (wid == 0) {  // exclusive scan of the CELLS counts: 64 lanes x CELLS / 64 consecutive cells
+      constexpr int PER = (CELLS + 63) / 64;
+      int v[PER], sum = 0;
+#pragma unroll
+      for (int q = 0; q < PER; q++) { v[q] = lane * PER + q < CELLS ? cell[lane * PER + q] : 0; sum += v[q]; }
+      int incl = sum;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += y;
+      }
+      int run = incl - sum;
+#pragma unroll
+      for (int q = 0; q < PER; q++) {
+        if (lane * PER + q < CELLS) cell[lane * PER + q] = run;
+        run += v[q];
+      }
+      if (lane == 63) cell[CELLS] = incl;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < RUNS_SCAN_ROWS; k++) {
+      const int i = c + k * RUNS_SCAN_THREADS + tid;
+      if (i < hi) {
+        const int pos = base + cell[k * RUNS_SCAN_WAVES + wid] + __builtin_popcountll(bal[k] & ((1ull << lane) - 1ull));
+        vr[i] = pos;
+        if (key[k] != RUN_KEY_PARKED) cs[lo + pos] = key[k];
+      }
+    }
+    base += cell[CELLS];
+  }
+  if (tid == 0) run_cnt[r] = base;
+}
+
+// Two-level search: every 2^shift-th live key of every run is staged in LDS (<= 12,288 samples: shift = 0, i.e. ALL
+// keys, for the inputs of the batched path); a search first narrows to one 2^shift window there, then finishes in
+// global memory inside that window (<= 2 cache lines).  A plain binary search over the runs is a chain of log2(run)
+// dependent misses per run -- the keys were written by another workgroup a moment ago, every probe goes to memory:
+// 12-20 us.  The searches of the different runs advance together (independent probes per step).
+constexpr int RUNS_SAMPLES = 12288;  // 48 KB: every key of the batched path (n <= 12,288 - 8) is a sample
+template <int BW>
+__device__ __forceinline__ void nms_runs_rank_body(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                                   int n, const NmsRuns& R, const uint32_t* __restrict__ cs,
+                                                   const int* __restrict__ vr, const int* __restrict__ run_cnt,
+                                                   int* __restrict__ order, int* __restrict__ rankpos,
+                                                   uint32_t* __restrict__ cls_s, float* __restrict__ boxes_s,
+                                                   int* __restrict__ seg_start, int* __restrict__ counters,
+                                                   int records) {
+  __shared__ uint32_t samp[RUNS_SAMPLES];
+  __shared__ int s_sbase[NMS_MAX_RUNS + 1], s_cnt[NMS_MAX_RUNS], s_off[NMS_MAX_RUNS + 1];
+  if (blockIdx.x * blockDim.x >= n) return;  // uniform (batched launch: the grid is sized for the largest image)
+  int shift = 0;
+  while ((n >> shift) + NMS_MAX_RUNS > RUNS_SAMPLES) shift++;  // uniform
+  // (the run table goes through LDS: indexing the kernel-argument struct with a per-lane run number makes the
+  // compiler copy the struct to scratch memory)
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int q = 0; q <= NMS_MAX_RUNS; q++) s_off[q] = R.off[q];
+    int acc = 0;
+    for (int q = 0; q < NMS_MAX_RUNS; q++) {
+      const int c = q < R.n_runs ? run_cnt[q] : 0;
+      s_cnt[q] = c;
+      s_sbase[q] = acc;
+      acc += (c + (1 << shift) - 1) >> shift;
+    }
+    s_sbase[NMS_MAX_RUNS] = acc;
+  }
+  __syncthreads();
+  {  // sample e = sample j of run q; 8 independent loads in flight per thread (a plain loop issues one at a time)
+    constexpr int SU = 8;
+    const int total = s_sbase[NMS_MAX_RUNS];
+    for (int e0 = threadIdx.x; e0 < total; e0 += blockDim.x * SU) {
+      uint32_t val[SU];
+#pragma unroll
+      for (int u = 0; u < SU; u++) {
+        const int e = min(e0 + u * (int)blockDim.x, total - 1);
+        int q = 0;
+#pragma unroll
+        for (int t = 1; t < NMS_MAX_RUNS; t++)
+          if (e >= s_sbase[t]) q = t;
+        val[u] = cs[s_off[q] + ((e - s_sbase[q]) << shift)];
+      }
+#pragma unroll
+      for (int u = 0; u < SU; u++)
+        if (e0 + u * (int)blockDim.x < total) samp[e0 + u * blockDim.x] = val[u];
+    }
+  }
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int r = 0;
+#pragma unroll
+  for (int q = 1; q < NMS_MAX_RUNS; q++)
+    if (i >= s_off[q] && q < R.n_runs) r = q;
+  const uint32_t key = run_key(scores[i]);
+  const int mine = vr[i];
+  int rank;
+  if (key != RUN_KEY_PARKED) {
+    // in order inside the run?  (equal keys are fine: array order is the tie order)
+    if (mine > 0 && cs[s_off[r] + mine - 1] > key) atomicOr(&counters[1], 4);
+    rank = mine;
+    // per other run: the number of its live keys that precede mine = first position whose key is > bound, where
+    // earlier runs win ties (lower array index: keys <= key count) and later runs lose them (keys < key count).
+    // (All loops over q are fully unrolled with the run number a constant: lo / hi / probe stay in registers.)
+    int lo[NMS_MAX_RUNS], hi[NMS_MAX_RUNS];
+    int most = 0;  // uniform: samples of the longest run
+#pragma unroll
+    for (int q = 0; q < NMS_MAX_RUNS; q++) {
+      const bool search = q < R.n_runs && q != r && !(q > r && key == 0u);  // (no key is strictly better than key 0)
+      lo[q] = 0;
+      hi[q] = search ? s_sbase[q + 1] - s_sbase[q] : 0;
+      most = max(most, s_sbase[q + 1] - s_sbase[q]);
+    }
+    for (int span = most; span > 0; span >>= 1) {  // first sample > bound, all runs together
+      uint32_t probe[NMS_MAX_RUNS];
+#pragma unroll
+      for (int q = 0; q < NMS_MAX_RUNS; q++)
+        if (q < R.n_runs) probe[q] = samp[min(s_sbase[q] + ((lo[q] + hi[q]) >> 1), RUNS_SAMPLES - 1)];
+#pragma unroll
+      for (int q = 0; q < NMS_MAX_RUNS; q++) {
+        if (q < R.n_runs) {
+          const int mid = (lo[q] + hi[q]) >> 1;
+          const uint32_t bound = q < r ? key : key - 1u;
+          const bool go = lo[q] < hi[q];
+          if (go && probe[q] <= bound) lo[q] = mid + 1;
+          else if (go) hi[q] = mid;
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NMS_MAX_RUNS; q++) {  // sample index a = lo[q] -> the window ((a - 1) << shift, a << shift]
+      const int a = lo[q];
+      lo[q] = a > 0 ? ((a - 1) << shift) + 1 : 0;
+      hi[q] = a > 0 ? min(a << shift, s_cnt[q]) : 0;
+    }
+    for (int step = 0; step < shift; step++) {  // the windows hold < 2^shift candidates
+      uint32_t probe[NMS_MAX_RUNS];
+#pragma unroll
+      for (int q = 0; q < NMS_MAX_RUNS; q++)  // unconditional (clamped) loads: all in flight together
+        if (q < R.n_runs) probe[q] = cs[min(R.off[q] + ((lo[q] + hi[q]) >> 1), n - 1)];
+#pragma unroll
+      for (int q = 0; q < NMS_MAX_RUNS; q++) {
+        if (q < R.n_runs) {
+          const int mid = (lo[q] + hi[q]) >> 1;
+          const uint32_t bound = q < r ? key : key - 1u;
+          const bool go = lo[q] < hi[q];
+          if (go && probe[q] <= bound) lo[q] = mid + 1;
+          else if (go) hi[q] = mid;
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NMS_MAX_RUNS; q++) rank += lo[q];
+  } else {
+    int live_total = 0, live_before = 0;
+#pragma unroll
+    for (int q = 0; q < NMS_MAX_RUNS; q++) {
+      const int c = s_cnt[q];
+      live_total += c;
+      if (q < r) live_before += c;
+    }
+    rank = live_total + (i - (live_before + mine));  // parked entries: after every live one, in array order
+  }
+  order[rank] = i;
+  if (!R.are_cls) {
+    // no categories (records == 1): segment order == rank order, one segment; categories by the caller's class
+    // ids (records == 0): the class sort that follows places the records
+    if (records) {
+      store_box_record<BW>(boxes_s, rank, boxes + (long)i * BW, 0u);
+      if (i == 0) { seg_start[0] = 0; counters[0] = 1; }
+    }
+  } else {  // class-major order == array order
+    rankpos[i] = rank;
+    cls_s[i] = (uint32_t)r;
+    store_box_record<BW>(boxes_s, i, boxes + (long)i * BW, (uint32_t)r);
+    if (i == s_off[r]) {
+      const int pos = atomicAdd(&counters[0], 1);
+      seg_start[pos] = i;
+    }
+  }
+}
+
+// order[] entries as indices: a run that was announced as sorted but is not (flag 4) leaves ranks that are no
+// permutation -- slots of order[] may then hold anything.  The results are unspecified in that case (the host redoes
+// the image), but nothing may be read out of bounds.
+__device__ __forceinline__ int order_at(const int* __restrict__ order, int r, int n) {
+  const int o = order[r];
+  return (unsigned)o < (unsigned)n ? o : 0;
+}
+
 // ---- step 1b helpers (radix path) ---------------------------------------------------------------
 __global__ void nms_init_kernel(int* iota, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -261,7 +510,7 @@ __global__ void nms_gather_cls_kernel(const int64_t* __restrict__ idxs, const in
                                       uint32_t* __restrict__ cls_r, int* counters) {
   int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
-  int64_t c = idxs[order[r]];
+  int64_t c = idxs[order_at(order, r, n)];
   if (c < 0 || c > 65535) { atomicOr(&counters[1], 2); c = 0; }
   cls_r[r] = (uint32_t)c;
 }
@@ -274,7 +523,7 @@ __global__ void nms_gather_boxes_kernel(const float* __restrict__ boxes, const i
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   int r = rankpos ? rankpos[p] : p;
-  int src = order[r];
+  int src = order_at(order, r, n);
   store_box_record<BW>(boxes_s, p, boxes + (long)src * BW, cls_s ? cls_s[p] : 0u);
   bool start = cls_s ? (p == 0 || cls_s[p] != cls_s[p - 1]) : (p == 0);
   if (start) {
@@ -337,27 +586,28 @@ struct ColGroup { float v[4][BOX_REC]; };  // 4 column records = 2 x s_load_dwor
 // division by cvt/cvt/mul/cmp.  max/min: with finite operands (a < b) ? b : a equals v_max_f32 except for the
 // sign of a zero, which cannot change a `> thr` outcome.  Anything else (a non-finite coordinate in the tile,
 // denom outside (0, inf), an out-of-range threshold) takes the literal formula.
+// Returns false when the tile lies beyond the last column block that shares a category with the row block: such
+// words are never read by the reduction (it walks the blocks of the rows' own segment only), and neither is any
+// tile further right -- the caller's loop over w stops there.
 template <bool FAST, bool TIE_UP>
-__device__ __forceinline__ void nms_mask_body(const float* __restrict__ boxes_s, int use_cls, int n, int wcap,
-                                                      double thr, double mid, u64* __restrict__ mask,
-                                                      u64* __restrict__ diagT, u64* __restrict__ w1T,
-                                                      u64* __restrict__ w2T) {
-  const int rb = blockIdx.x, w = blockIdx.y;
+__device__ __forceinline__ bool nms_mask_tile(const float* __restrict__ boxes_s, int use_cls, int n, int wcap, int rb,
+                                              int w, double thr, double mid, u64* __restrict__ mask,
+                                              u64* __restrict__ diagT, u64* __restrict__ w1T,
+                                              u64* __restrict__ w2T) {
   const int lane = threadIdx.x;
   const int cb = rb + w;
   const int row = rb * 64 + lane;
   const int col0 = cb * 64;
   const int nblocks = (n + 63) >> 6;
-  if (cb >= nblocks || w >= wcap) return;  // never read by the reduction (or: batched grid larger than this image)
+  if (cb >= nblocks || w >= wcap) return false;  // (or: batched grid larger than this image)
   u64 word = 0;
-  bool live = true;
   if (use_cls) {
     // categories ascend along the sorted sequence: tile is empty unless ranges touch
     const uint32_t row_last = __float_as_uint(boxes_s[(long)min(rb * 64 + 63, n - 1) * BOX_REC + 5]);
     const uint32_t col_first = __float_as_uint(boxes_s[(long)col0 * BOX_REC + 5]);
-    live = col_first <= row_last;
+    if (col_first > row_last) return false;
   }
-  if (live) {
+  {
     const int rrow = min(row, n - 1), rcol = min(col0 + lane, n - 1);
     const float4 rbx = reinterpret_cast<const float4*>(boxes_s)[rrow * 2];
     const float4 rex = reinterpret_cast<const float4*>(boxes_s)[rrow * 2 + 1];
@@ -425,27 +675,40 @@ __device__ __forceinline__ void nms_mask_body(const float* __restrict__ boxes_s,
     if (row >= n) word = 0;
   }
   store_mask_words(word, row, col0, lane, w, n, wcap, mask, diagT, w1T, w2T);
+  return true;
+}
+
+// grid = (row blocks, min(wcap, MASK_GRID_Y)): a workgroup walks the tiles w = blockIdx.y, + gridDim.y, ... of its
+// row block up to the last live one.  The host only knows an UPPER BOUND of the largest category (wcap sizes the
+// row pitch of the mask); how far a row block really reaches is read from the records here, so a generous bound
+// costs address space, not launches.
+constexpr int MASK_GRID_Y = 64;
+template <bool FAST, bool TIE_UP>
+__device__ __forceinline__ void nms_mask_body(const float* __restrict__ boxes_s, int use_cls, int n, int wcap,
+                                              double thr, double mid, u64* __restrict__ mask,
+                                              u64* __restrict__ diagT, u64* __restrict__ w1T, u64* __restrict__ w2T) {
+  for (int w = blockIdx.y; w < wcap; w += gridDim.y)
+    if (!nms_mask_tile<FAST, TIE_UP>(boxes_s, use_cls, n, wcap, blockIdx.x, w, thr, mid, mask, diagT, w1T, w2T)) break;
 }
 
 // Rotated tile: the polygon clip is not symmetric in floating point and the reference evaluates
 // iou(kept box, later box) (nms_rotated_cpu.cpp:45-54): rows are the earlier boxes, so that is the order
 // used here, once per pair (the transposed words come from the bit transpose of the same results).
-__device__ __forceinline__ void nms_mask_rot_body(const float* __restrict__ boxes_s, int n, int wcap,
-                                                          double thr, u64* __restrict__ mask,
-                                                          u64* __restrict__ diagT, u64* __restrict__ w1T,
-                                                          u64* __restrict__ w2T) {
-  const int rb = blockIdx.x, w = blockIdx.y;
+__device__ __forceinline__ bool nms_mask_rot_tile(const float* __restrict__ boxes_s, int n, int wcap, int rb, int w,
+                                                  double thr, u64* __restrict__ mask, u64* __restrict__ diagT,
+                                                  u64* __restrict__ w1T, u64* __restrict__ w2T,
+                                                  RotIouScratch<64>& S) {
   const int lane = threadIdx.x;
   const int cb = rb + w;
   const int row = rb * 64 + lane;
   const int col0 = cb * 64;
   const int nblocks = (n + 63) >> 6;
-  if (cb >= nblocks || w >= wcap) return;
+  if (cb >= nblocks || w >= wcap) return false;
   u64 word = 0;
   const uint32_t row_last = __float_as_uint(boxes_s[(long)min(rb * 64 + 63, n - 1) * BOX_REC + 5]);
   const uint32_t col_first = __float_as_uint(boxes_s[(long)col0 * BOX_REC + 5]);
-  if (col_first <= row_last) {
-    __shared__ RotIouScratch<64> S;
+  if (col_first > row_last) return false;  // (see nms_mask_tile)
+  {
     const int rrow = min(row, n - 1), rcol = min(col0 + lane, n - 1);
     float rbx[5], cbx[5];
 #pragma unroll
@@ -466,6 +729,14 @@ __device__ __forceinline__ void nms_mask_rot_body(const float* __restrict__ boxe
     }
   }
   store_mask_words(word, row, col0, lane, w, n, wcap, mask, diagT, w1T, w2T);
+  return true;
+}
+__device__ __forceinline__ void nms_mask_rot_body(const float* __restrict__ boxes_s, int n, int wcap, double thr,
+                                                  u64* __restrict__ mask, u64* __restrict__ diagT,
+                                                  u64* __restrict__ w1T, u64* __restrict__ w2T) {
+  __shared__ RotIouScratch<64> S;
+  for (int w = blockIdx.y; w < wcap; w += gridDim.y)
+    if (!nms_mask_rot_tile(boxes_s, n, wcap, blockIdx.x, w, thr, mask, diagT, w1T, w2T, S)) break;
 }
 
 // ---- step 3: greedy reduction ----------------------------------------------------------------
@@ -636,23 +907,46 @@ __device__ __forceinline__ void nms_reduce_body(const u64* __restrict__ mask,
 }
 
 // ---- step 4: compaction ------------------------------------------------------------------------
+// optional: rows `src` of up to 4 caller arrays copied to position `dst` (keep order) while the kept index is written
+// -- what the callers would otherwise do with one torch index kernel per array after their host sync
+__device__ __forceinline__ void gather_rows(const d2amd_nms_gather& G, int src, int dst) {
+  for (int t = 0; t < G.count; t++) {
+    const int words = G.row_bytes[t] >> 2;
+    const uint32_t* a = (const uint32_t*)G.src[t] + (long)src * words;
+    uint32_t* b = (uint32_t*)G.dst[t] + (long)dst * words;
+    for (int q = 0; q < words; q++) b[q] = a[q];
+  }
+}
+
 // small n: one workgroup does scatter-to-rank-order and ordered compaction out of LDS
 constexpr int FIN_THREADS = 1024;
 __device__ __forceinline__ void nms_finalize_small_body(
     const u64* __restrict__ keepbits, const int* __restrict__ rankpos, const int* __restrict__ order, int n,
     int64_t* __restrict__ keep_out, const int* __restrict__ counters, int64_t* __restrict__ result,
-    const float* __restrict__ scores) {
+    const float* __restrict__ scores, const d2amd_nms_gather& G) {
   __shared__ uint8_t flags[RANK_MAX_N];
+  __shared__ int s_keep[RANK_MAX_N];  // kept indices in keep order (read by the gather pass)
   __shared__ int wave_tot[FIN_THREADS / 64];
   __shared__ int s_finite;
   if (threadIdx.x == 0) s_finite = 0;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  for (int p = tid; p < n; p += FIN_THREADS) {
-    const bool kept = (keepbits[p >> 6] >> (p & 63)) & 1ull;
-    flags[rankpos ? rankpos[p] : p] = kept ? 1 : 0;
+  constexpr int CH = RANK_MAX_N / FIN_THREADS;  // 12 consecutive ranks per thread
+  {  // kept bit of every segment position -> rank order; the (clamped) loads of all 12 positions in flight together
+    u64 kb[CH];
+    int rp[CH];
+#pragma unroll
+    for (int q = 0; q < CH; q++) {
+      const int p = min(tid + q * FIN_THREADS, n - 1);
+      kb[q] = keepbits[p >> 6];
+      rp[q] = rankpos ? rankpos[p] : p;
+    }
+#pragma unroll
+    for (int q = 0; q < CH; q++) {
+      const int p = tid + q * FIN_THREADS;
+      if (p < n) flags[min(max(rp[q], 0), n - 1)] = (kb[q] >> (p & 63)) & 1ull ? 1 : 0;
+    }
   }
   __syncthreads();
-  constexpr int CH = RANK_MAX_N / FIN_THREADS;  // 12 consecutive ranks per thread
   const int r0 = tid * CH;
   int ord[CH];
   int cnt = 0;
@@ -660,7 +954,7 @@ __device__ __forceinline__ void nms_finalize_small_body(
 #pragma unroll
   for (int q = 0; q < CH; q++) {
     const int r = r0 + q;
-    ord[q] = order[min(r, n - 1)];  // unconditional (clamped) loads, all in flight together
+    ord[q] = order_at(order, min(r, n - 1), n);  // unconditional (clamped) loads, all in flight together
     const bool f = r < n && flags[min(r, n - 1)];
     fl |= f ? (1u << q) : 0u;
     cnt += f ? 1 : 0;
@@ -676,16 +970,46 @@ __device__ __forceinline__ void nms_finalize_small_body(
   int off = incl - cnt;
   for (int w = 0; w < wid; w++) off += wave_tot[w];
   int fin = 0;
+  float sc[CH];
+#pragma unroll
+  for (int q = 0; q < CH; q++) sc[q] = scores[ord[q]];  // unconditional: 12 loads in flight (ord is clamped)
 #pragma unroll
   for (int q = 0; q < CH; q++)
     if ((fl >> q) & 1u) {
+      if (G.count) s_keep[off] = ord[q];
       keep_out[off++] = (int64_t)ord[q];
-      fin += scores[ord[q]] > -INFINITY ? 1 : 0;
+      fin += sc[q] > -INFINITY ? 1 : 0;
     }
   if (fin) atomicAdd(&s_finite, fin);
   __syncthreads();
   // result: {kept, error flags, kept with a score > -inf (callers park invalid rows at -inf: they sort last), 0}
   if (tid == FIN_THREADS - 1) { result[0] = off; result[1] = counters[1]; result[2] = s_finite; result[3] = 0; }
+  if (G.count) {
+    // rows of the caller's arrays in keep order: one 4-byte word per thread and step, all rows in parallel (copying
+    // a row where its index is written chains 12 rows x (load, store) per thread: 40 us)
+    __shared__ int s_total;
+    if (tid == FIN_THREADS - 1) s_total = off;
+    __syncthreads();  // (also orders the keep_out stores above before the loads below: same workgroup)
+    const int total = s_total;
+    for (int t = 0; t < G.count; t++) {
+      const int words = G.row_bytes[t] >> 2, cells = total * words;
+      const uint32_t* a = (const uint32_t*)G.src[t];
+      uint32_t* b = (uint32_t*)G.dst[t];
+      constexpr int GU = 4;  // independent loads in flight per thread
+      for (int e0 = tid; e0 < cells; e0 += FIN_THREADS * GU) {
+        uint32_t val[GU];
+#pragma unroll
+        for (int u = 0; u < GU; u++) {
+          const int e = min(e0 + u * FIN_THREADS, cells - 1);
+          const int j = e / words, q = e - j * words;
+          val[u] = a[(long)s_keep[j] * words + q];
+        }
+#pragma unroll
+        for (int u = 0; u < GU; u++)
+          if (e0 + u * FIN_THREADS < cells) b[e0 + u * FIN_THREADS] = val[u];
+      }
+    }
+  }
 }
 
 __global__ void nms_scatter_flags_kernel(const u64* __restrict__ keepbits, const int* __restrict__ rankpos, int n,
@@ -717,7 +1041,8 @@ __global__ __launch_bounds__(COMPACT_BLOCK) void nms_compact_kernel(const uint8_
                                                                     int64_t* __restrict__ keep_out,
                                                                     const int* __restrict__ counters,
                                                                     int64_t* __restrict__ result,
-                                                                    const float* __restrict__ scores) {
+                                                                    const float* __restrict__ scores,
+                                                                    const d2amd_nms_gather G) {
   __shared__ int wave_cnt[COMPACT_BLOCK / 64];
   __shared__ int s_red[COMPACT_BLOCK / 64];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -741,8 +1066,10 @@ __global__ __launch_bounds__(COMPACT_BLOCK) void nms_compact_kernel(const uint8_
   }
   bool fin = false;
   if (f) {
-    const int o = order[r];
-    keep_out[off + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = (int64_t)o;
+    const int o = order_at(order, r, n);
+    const int at = off + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+    keep_out[at] = (int64_t)o;
+    if (G.count) gather_rows(G, o, at);
     fin = scores[o] > -INFINITY;
   }
   const int nfin = __syncthreads_count(fin);
@@ -771,11 +1098,13 @@ struct NmsImg {
   int64_t* result;
   const int* rankpos;      // null without categories: segment order == rank order
   const uint32_t* cls_s;
+  d2amd_nms_gather gather; // rows of caller arrays to copy in keep order (count 0: none)
 };
 struct NmsBatch {
   double thr, mid;
   u64* dbg;
   int count;
+  NmsRuns runs;  // n_runs == 0: no pre-sorted runs
   NmsImg img[NMS_MAX_BATCH];
 };
 
@@ -794,6 +1123,20 @@ __global__ void nms_rank_scatter_kernel(const NmsBatch B) {
   const NmsImg& I = B.img[blockIdx.z];
   nms_rank_scatter_body<BW>(I.boxes, (const uint4*)I.w.rk_keys, I.n, I.w.rk_cnt, I.rk_chunks, I.w.order, I.w.rankpos,
                             I.w.cls_s, I.w.boxes_s);
+}
+template <int PER>
+__global__ __launch_bounds__(RUNS_SCAN_THREADS) void nms_runs_scan_kernel(const NmsBatch B) {
+  const NmsImg& I = B.img[blockIdx.z];
+  nms_runs_scan_body<PER>(I.scores, B.runs, (uint32_t*)I.w.keys_out, (int*)I.w.cls_r, I.w.run_cnt, (uint32_t*)I.w.keepbits,
+                     (int)(I.w.zero_bytes / 4));
+}
+constexpr int RUNS_RANK_THREADS = 1024;  // every workgroup stages all samples: few, large workgroups
+template <int BW>
+__global__ __launch_bounds__(RUNS_RANK_THREADS) void nms_runs_rank_kernel(const NmsBatch B) {
+  const NmsImg& I = B.img[blockIdx.z];
+  nms_runs_rank_body<BW>(I.boxes, I.scores, I.n, B.runs, (const uint32_t*)I.w.keys_out, (const int*)I.w.cls_r,
+                         I.w.run_cnt, I.w.order, I.w.rankpos, I.w.cls_s, I.w.boxes_s, I.w.seg_start, I.w.counters,
+                         I.idxs ? 0 : 1);
 }
 __global__ void nms_segments_kernel(const NmsBatch B) {
   const NmsImg& I = B.img[blockIdx.z];
@@ -816,7 +1159,8 @@ __global__ __launch_bounds__(RED_THREADS) void nms_reduce_kernel(const NmsBatch 
 }
 __global__ __launch_bounds__(FIN_THREADS) void nms_finalize_small_kernel(const NmsBatch B) {
   const NmsImg& I = B.img[blockIdx.z];
-  nms_finalize_small_body(I.w.keepbits, I.rankpos, I.w.order, I.n, I.keep_out, I.w.counters, I.result, I.scores);
+  nms_finalize_small_body(I.w.keepbits, I.rankpos, I.w.order, I.n, I.keep_out, I.w.counters, I.result, I.scores,
+                          I.gather);
 }
 
 }  // namespace d2amd
@@ -853,7 +1197,9 @@ static int nms_mask_reduce(NmsBatch& B, int rotated, bool any_cls, hipStream_t s
     nb_max = std::max(nb_max, (B.img[k].n + 63) / 64);
     wcap_max = std::max(wcap_max, B.img[k].wcap);
   }
-  const dim3 mgrid(nb_max, wcap_max, B.count);
+  // ~8,000 waves per image keep the chip busy; beyond that more workgroups per row block only add dispatches
+  const int gy = std::max(std::min(wcap_max, 8), std::min(std::min(wcap_max, MASK_GRID_Y), cdiv(8192, std::max(nb_max, 1))));
+  const dim3 mgrid(nb_max, gy, B.count);
   const bool timed_mask = timing_begin("nms_mask", s);
   if (rotated) {
     hipLaunchKernelGGL(nms_mask_rot_kernel, mgrid, dim3(64), 0, s, B);
@@ -902,6 +1248,19 @@ static int nms_run_small(NmsBatch& B, int rotated, hipStream_t s) {
     chunks_max = std::max(chunks_max, B.img[k].rk_chunks);
     any_cls |= B.img[k].idxs != nullptr;
   }
+  const dim3 ngrid(cdiv(n_max, T), 1, B.count);
+  // pre-sorted runs: the order comes from one scan + one binary-search kernel.  (Runs + the caller's class ids on
+  // this path would still need the class-major positions: the brute-force ranking below provides both.)
+  const bool by_runs = B.runs.n_runs > 0 && (B.runs.are_cls || !any_cls);
+  if (by_runs) {
+    hipLaunchKernelGGL(nms_runs_scan_kernel<4>, dim3(B.runs.n_runs, 1, B.count), dim3(RUNS_SCAN_THREADS), 0, s, B);
+    D2_LAUNCH_OK();
+    const dim3 rgrid(cdiv(n_max, RUNS_RANK_THREADS), 1, B.count);
+    if (rotated) hipLaunchKernelGGL((nms_runs_rank_kernel<5>), rgrid, dim3(RUNS_RANK_THREADS), 0, s, B);
+    else hipLaunchKernelGGL((nms_runs_rank_kernel<4>), rgrid, dim3(RUNS_RANK_THREADS), 0, s, B);
+    D2_LAUNCH_OK();
+    any_cls = B.runs.are_cls != 0;
+  } else {
   const int npad = cdiv(n_max, RK_GROUP) * RK_GROUP;
   hipLaunchKernelGGL(nms_prep_kernel, dim3(cdiv(npad, T), 1, B.count), dim3(T), 0, s, B);
   D2_LAUNCH_OK();
@@ -909,13 +1268,13 @@ static int nms_run_small(NmsBatch& B, int rotated, hipStream_t s) {
   if (rotated) hipLaunchKernelGGL((nms_rank_kernel<5>), rk_grid, dim3(RK_THREADS), 0, s, B);
   else hipLaunchKernelGGL((nms_rank_kernel<4>), rk_grid, dim3(RK_THREADS), 0, s, B);
   D2_LAUNCH_OK();
-  const dim3 ngrid(cdiv(n_max, T), 1, B.count);
   if (rotated) hipLaunchKernelGGL((nms_rank_scatter_kernel<5>), ngrid, dim3(T), 0, s, B);
   else hipLaunchKernelGGL((nms_rank_scatter_kernel<4>), ngrid, dim3(T), 0, s, B);
   D2_LAUNCH_OK();
   if (any_cls) {
     hipLaunchKernelGGL(nms_segments_kernel, ngrid, dim3(T), 0, s, B);
     D2_LAUNCH_OK();
+  }
   }
   const int rc = nms_mask_reduce(B, rotated, any_cls, s);
   if (rc != D2AMD_OK) return rc;
@@ -948,17 +1307,29 @@ static int nms_fill_img(NmsImg& I, const float* boxes, const float* scores, cons
   return D2AMD_OK;
 }
 
-extern "C" int d2amd_nms_batched(int count, const float* const* boxes, const float* const* scores,
-                                 const int64_t* const* idxs, const int64_t* n, double iou_threshold, int rotated,
-                                 const int64_t* max_per_class, int64_t* const* keep_out, int64_t* const* result,
-                                 void* const* workspace, const size_t* workspace_bytes, void* stream) {
-  hipStream_t s = (hipStream_t)stream;
+static int nms_gather_arg(d2amd_nms_gather& G, const d2amd_nms_gather& in) {
+  D2_CHECK_ARG(in.count >= 0 && in.count <= 4, "nms: gather of %d arrays (max 4)", in.count);
+  for (int t = 0; t < in.count; t++)
+    D2_CHECK_ARG(in.src[t] && in.dst[t] && in.row_bytes[t] > 0 && in.row_bytes[t] % 4 == 0,
+                 "nms: gather array %d: null pointer or a row size that is not a multiple of 4 bytes", t);
+  G = in;
+  return D2AMD_OK;
+}
+
+// `runs` (optional): the inputs are sequences of pre-sorted runs (see step 1c); runs->are_cls: the runs are the
+// categories (idxs must be null)
+static int nms_batched_impl(int count, const float* const* boxes, const float* const* scores,
+                            const int64_t* const* idxs, const int64_t* n, double iou_threshold, int rotated,
+                            const int64_t* max_per_class, int64_t* const* keep_out, int64_t* const* result,
+                            void* const* workspace, const size_t* workspace_bytes, const NmsRuns* runs,
+                            const d2amd_nms_gather* gather, hipStream_t s) {
   D2_CHECK_ARG(count >= 0 && boxes && scores && n && keep_out && result && workspace && workspace_bytes,
                "nms_batched: null pointer");
   for (int k0 = 0; k0 < count; k0 += NMS_MAX_BATCH) {
     NmsBatch B;
     memset(&B, 0, sizeof(B));
     B.thr = iou_threshold;
+    if (runs) B.runs = *runs;
     for (int k = k0; k < count && k < k0 + NMS_MAX_BATCH; k++) {
       D2_CHECK_ARG(n[k] >= 0 && result[k], "nms_batched: bad image %d", k);
       if (n[k] == 0) {
@@ -967,10 +1338,22 @@ extern "C" int d2amd_nms_batched(int count, const float* const* boxes, const flo
       }
       D2_CHECK_ARG(n[k] <= RANK_MAX_N, "nms_batched: image %d has %lld boxes (> %d): use d2amd_nms", k,
                    (long long)n[k], RANK_MAX_N);
-      const int rc = nms_fill_img(B.img[B.count], boxes[k], scores[k], idxs ? idxs[k] : nullptr, n[k],
+      D2_CHECK_ARG(!runs || n[k] == runs->off[runs->n_runs], "nms_batched: image %d has %lld boxes, the runs cover %d",
+                   k, (long long)n[k], runs ? runs->off[runs->n_runs] : 0);
+      NmsImg& I = B.img[B.count];
+      const int rc = nms_fill_img(I, boxes[k], scores[k], idxs ? idxs[k] : nullptr, n[k],
                                   max_per_class ? max_per_class[k] : 0, keep_out[k], result[k], workspace[k],
                                   workspace_bytes[k]);
       if (rc != D2AMD_OK) return rc;
+      if (runs && runs->are_cls) {
+        D2_CHECK_ARG(I.idxs == nullptr, "nms_batched: runs are the categories: idxs must be null");
+        I.rankpos = I.w.rankpos;
+        I.cls_s = I.w.cls_s;
+      }
+      if (gather) {
+        const int grc = nms_gather_arg(I.gather, gather[k]);
+        if (grc) return grc;
+      }
       B.count++;
     }
     if (B.count) {
@@ -981,51 +1364,115 @@ extern "C" int d2amd_nms_batched(int count, const float* const* boxes, const flo
   return D2AMD_OK;
 }
 
+static int nms_runs_arg(NmsRuns& R, const int* run_offsets, int n_runs, int runs_are_categories) {
+  D2_CHECK_ARG(run_offsets && n_runs >= 1 && n_runs <= NMS_MAX_RUNS, "nms: %d pre-sorted runs (1..%d)", n_runs,
+               NMS_MAX_RUNS);
+  memset(&R, 0, sizeof(R));
+  R.n_runs = n_runs;
+  R.are_cls = runs_are_categories ? 1 : 0;
+  D2_CHECK_ARG(run_offsets[0] == 0, "nms: run_offsets must start at 0");
+  for (int r = 0; r <= n_runs; r++) {
+    D2_CHECK_ARG(r == 0 || run_offsets[r] >= run_offsets[r - 1], "nms: run_offsets must not decrease");
+    R.off[r] = run_offsets[r];
+  }
+  for (int r = n_runs + 1; r <= NMS_MAX_RUNS; r++) R.off[r] = run_offsets[n_runs];
+  return D2AMD_OK;
+}
+
+extern "C" int d2amd_nms_batched(int count, const float* const* boxes, const float* const* scores,
+                                 const int64_t* const* idxs, const int64_t* n, double iou_threshold, int rotated,
+                                 const int64_t* max_per_class, int64_t* const* keep_out, int64_t* const* result,
+                                 void* const* workspace, const size_t* workspace_bytes, void* stream) {
+  return nms_batched_impl(count, boxes, scores, idxs, n, iou_threshold, rotated, max_per_class, keep_out, result,
+                          workspace, workspace_bytes, nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int d2amd_nms_batched_runs(int count, const float* const* boxes, const float* const* scores,
+                                      const int64_t* const* idxs, const int64_t* n, const int* run_offsets,
+                                      int n_runs, int runs_are_categories, double iou_threshold, int rotated,
+                                      const int64_t* max_per_class, int64_t* const* keep_out,
+                                      int64_t* const* result, void* const* workspace, const size_t* workspace_bytes,
+                                      const d2amd_nms_gather* gather, void* stream) {
+  NmsRuns R;
+  const int rc = nms_runs_arg(R, run_offsets, n_runs, runs_are_categories);
+  if (rc) return rc;
+  D2_CHECK_ARG(!(runs_are_categories && idxs), "nms_batched_runs: runs are the categories: idxs must be null");
+  return nms_batched_impl(count, boxes, scores, idxs, n, iou_threshold, rotated, max_per_class, keep_out, result,
+                          workspace, workspace_bytes, &R, gather, (hipStream_t)stream);
+}
+
 extern "C" int d2amd_nms_batched_max_boxes(void) { return RANK_MAX_N; }
 
-extern "C" int d2amd_nms(const float* boxes, const float* scores, const int64_t* idxs, int64_t n,
-                         double iou_threshold, int rotated, int64_t max_per_class, int64_t* keep_out,
-                         int64_t* result, void* workspace, size_t workspace_bytes, void* stream) {
-  hipStream_t s = (hipStream_t)stream;
+static int nms_impl(const float* boxes, const float* scores, const int64_t* idxs, int64_t n, double iou_threshold,
+                    int rotated, int64_t max_per_class, int64_t* keep_out, int64_t* result, void* workspace,
+                    size_t workspace_bytes, const NmsRuns* runs, const d2amd_nms_gather* gather, hipStream_t s) {
   D2_CHECK_ARG(n >= 0 && n < (1ll << 31) - 64, "nms: bad n %lld", (long long)n);
   D2_CHECK_ARG(result, "nms: null result");
   if (n == 0) {
     { const int zrc = zero_async(result, 32, s); if (zrc) return zrc; }
     return D2AMD_OK;
   }
+  D2_CHECK_ARG(!runs || n == runs->off[runs->n_runs], "nms: %lld boxes, the runs cover %d", (long long)n,
+               runs ? runs->off[runs->n_runs] : 0);
   NmsBatch B;
   memset(&B, 0, sizeof(B));
   B.thr = iou_threshold;
   B.count = 1;
+  if (runs) B.runs = *runs;
   NmsImg& I = B.img[0];
   int rc = nms_fill_img(I, boxes, scores, idxs, n, max_per_class, keep_out, result, workspace, workspace_bytes);
   if (rc != D2AMD_OK) return rc;
+  if (gather) {
+    rc = nms_gather_arg(I.gather, *gather);
+    if (rc) return rc;
+  }
+  const bool run_cls = runs && runs->are_cls;
+  if (run_cls) {
+    D2_CHECK_ARG(idxs == nullptr, "nms: runs are the categories: idxs must be null");
+    I.rankpos = I.w.rankpos;
+    I.cls_s = I.w.cls_s;
+  }
   if (n <= RANK_MAX_N) return nms_run_small(B, rotated, s);
-  // ---- large inputs: radix sorts instead of the brute-force ranking ----
+  // ---- large inputs: radix sorts (or the runs' binary searches) instead of the brute-force ranking ----
   NmsWorkspace& w = I.w;
   const int N = (int)n;
   const int T = 256;
-  { const int zrc = zero_async(w.keepbits, w.zero_bytes, s); if (zrc) return zrc; }
-  hipLaunchKernelGGL(nms_init_kernel, dim3(cdiv(N, T)), dim3(T), 0, s, w.iota, N);
-  D2_LAUNCH_OK();
-  size_t tb = w.sort_temp_bytes;
-  D2_HIP_OK(rocprim::radix_sort_pairs_desc(w.sort_temp, tb, scores, w.keys_out, w.iota, w.order, (unsigned)N, 0, 32,
-                                           s, false));
+  if (runs) {  // order[] from the pre-sorted runs (the scan also zeroes the accumulators)
+    hipLaunchKernelGGL(nms_runs_scan_kernel<16>, dim3(std::max(runs->n_runs, 16), 1, 1), dim3(RUNS_SCAN_THREADS), 0, s, B);
+    D2_LAUNCH_OK();
+    const dim3 rgrid(cdiv(N, RUNS_RANK_THREADS), 1, 1);
+    if (rotated) hipLaunchKernelGGL((nms_runs_rank_kernel<5>), rgrid, dim3(RUNS_RANK_THREADS), 0, s, B);
+    else hipLaunchKernelGGL((nms_runs_rank_kernel<4>), rgrid, dim3(RUNS_RANK_THREADS), 0, s, B);
+    D2_LAUNCH_OK();
+  } else {
+    { const int zrc = zero_async(w.keepbits, w.zero_bytes, s); if (zrc) return zrc; }
+    hipLaunchKernelGGL(nms_init_kernel, dim3(cdiv(N, T)), dim3(T), 0, s, w.iota, N);
+    D2_LAUNCH_OK();
+    size_t tb = w.sort_temp_bytes;
+    D2_HIP_OK(rocprim::radix_sort_pairs_desc(w.sort_temp, tb, scores, w.keys_out, w.iota, w.order, (unsigned)N, 0, 32,
+                                             s, false));
+  }
   if (idxs) {
+    if (runs) {  // the class sort's values
+      hipLaunchKernelGGL(nms_init_kernel, dim3(cdiv(N, T)), dim3(T), 0, s, w.iota, N);
+      D2_LAUNCH_OK();
+    }
     hipLaunchKernelGGL(nms_gather_cls_kernel, dim3(cdiv(N, T)), dim3(T), 0, s, idxs, w.order, N, w.cls_r, w.counters);
     D2_LAUNCH_OK();
-    tb = w.sort_temp_bytes;
+    size_t tb = w.sort_temp_bytes;
     D2_HIP_OK(rocprim::radix_sort_pairs(w.sort_temp, tb, w.cls_r, w.cls_s, w.iota, w.rankpos, (unsigned)N, 0, 16, s,
                                         false));
   }
-  if (rotated)
-    hipLaunchKernelGGL((nms_gather_boxes_kernel<5>), dim3(cdiv(N, T)), dim3(T), 0, s, boxes, w.order, I.rankpos,
-                       I.cls_s, N, w.boxes_s, w.seg_start, w.counters);
-  else
-    hipLaunchKernelGGL((nms_gather_boxes_kernel<4>), dim3(cdiv(N, T)), dim3(T), 0, s, boxes, w.order, I.rankpos,
-                       I.cls_s, N, w.boxes_s, w.seg_start, w.counters);
-  D2_LAUNCH_OK();
-  rc = nms_mask_reduce(B, rotated, idxs != nullptr, s);
+  if (!runs || idxs) {  // (runs without class ids: the rank kernel has written the records)
+    if (rotated)
+      hipLaunchKernelGGL((nms_gather_boxes_kernel<5>), dim3(cdiv(N, T)), dim3(T), 0, s, boxes, w.order, I.rankpos,
+                         I.cls_s, N, w.boxes_s, w.seg_start, w.counters);
+    else
+      hipLaunchKernelGGL((nms_gather_boxes_kernel<4>), dim3(cdiv(N, T)), dim3(T), 0, s, boxes, w.order, I.rankpos,
+                         I.cls_s, N, w.boxes_s, w.seg_start, w.counters);
+    D2_LAUNCH_OK();
+  }
+  rc = nms_mask_reduce(B, rotated, idxs != nullptr || run_cls, s);
   if (rc != D2AMD_OK) return rc;
   hipLaunchKernelGGL(nms_scatter_flags_kernel, dim3(cdiv(N, T)), dim3(T), 0, s, w.keepbits, I.rankpos, N, w.flag_r);
   D2_LAUNCH_OK();
@@ -1033,7 +1480,26 @@ extern "C" int d2amd_nms(const float* boxes, const float* scores, const int64_t*
                      result);
   D2_LAUNCH_OK();
   hipLaunchKernelGGL(nms_compact_kernel, dim3(cdiv(N, COMPACT_BLOCK)), dim3(COMPACT_BLOCK), 0, s, w.flag_r, w.order, N,
-                     w.blk_cnt, keep_out, w.counters, result, scores);
+                     w.blk_cnt, keep_out, w.counters, result, scores, I.gather);
   D2_LAUNCH_OK();
   return D2AMD_OK;
+}
+
+extern "C" int d2amd_nms(const float* boxes, const float* scores, const int64_t* idxs, int64_t n,
+                         double iou_threshold, int rotated, int64_t max_per_class, int64_t* keep_out,
+                         int64_t* result, void* workspace, size_t workspace_bytes, void* stream) {
+  return nms_impl(boxes, scores, idxs, n, iou_threshold, rotated, max_per_class, keep_out, result, workspace,
+                  workspace_bytes, nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int d2amd_nms_runs(const float* boxes, const float* scores, const int64_t* idxs, int64_t n,
+                              const int* run_offsets, int n_runs, int runs_are_categories, double iou_threshold,
+                              int rotated, int64_t max_per_class, int64_t* keep_out, int64_t* result,
+                              void* workspace, size_t workspace_bytes, const d2amd_nms_gather* gather,
+                              void* stream) {
+  NmsRuns R;
+  const int rc = nms_runs_arg(R, run_offsets, n_runs, runs_are_categories);
+  if (rc) return rc;
+  return nms_impl(boxes, scores, idxs, n, iou_threshold, rotated, max_per_class, keep_out, result, workspace,
+                  workspace_bytes, &R, gather, (hipStream_t)stream);
 }

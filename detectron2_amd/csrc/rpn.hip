@@ -49,9 +49,18 @@ __global__ __launch_bounds__(256) void rpn_keys_kernel(const float* __restrict__
 
 __device__ __forceinline__ bool rpn_finite(float v) { return fabsf(v) <= 3.402823466e+38f; }
 
+// per-level views of the RPN head outputs: level l of image i starts at logits[l] + i * stride[l] (deltas: float4 units).
+// The concatenated entry point fills them with offsets into its [N, Atot] arrays (stride = Atot), the per-level entry
+// point with the head's own per-level tensors (stride = A_l) -- no torch.cat of 2 x 268,569 x (1 + 4 + 4) floats.
+struct RpnPtrs {
+  const float* logits[D2AMD_RPN_MAX_LEVELS];
+  const float4* deltas[D2AMD_RPN_MAX_LEVELS];
+  const float4* anchors[D2AMD_RPN_MAX_LEVELS];
+  long stride[D2AMD_RPN_MAX_LEVELS];
+};
+
 __global__ __launch_bounds__(256) void rpn_decode_kernel(
-    const float* __restrict__ logits, const float4* __restrict__ deltas, const float4* __restrict__ anchors,
-    const uint32_t* __restrict__ sorted_vals, const uint32_t* __restrict__ sel, int N, int Atot, RpnLevels lv,
+    RpnPtrs P, const uint32_t* __restrict__ sorted_vals, const uint32_t* __restrict__ sel, int N, int Atot, RpnLevels lv,
     RpnImages im, float wx, float wy, float ww,
     float wh, float scale_clamp, float min_size, float4* __restrict__ boxes, float* __restrict__ scores,
     uint8_t* __restrict__ valid, int64_t* __restrict__ level_ids, int* __restrict__ flags) {
@@ -66,10 +75,11 @@ __global__ __launch_bounds__(256) void rpn_decode_kernel(
   const int r = j - lv.koff[l];
   // the sort is keyed by (image, level): segment (img, l) starts at img * Atot + aoff[l]
   // radix-select path: sel holds the rank-ordered anchor index inside the level; sort path: the sorted values
-  const int a = sel ? lv.aoff[l] + (int)sel[(long)img * Ktot + j] : (int)sorted_vals[(long)img * Atot + lv.aoff[l] + r];
-  const float score = logits[(long)img * Atot + a];
-  const float4 b = anchors[a];
-  const float4 d = deltas[(long)img * Atot + a];
+  // (index inside the level)
+  const int a = sel ? (int)sel[(long)img * Ktot + j] : (int)sorted_vals[(long)img * Atot + lv.aoff[l] + r] - lv.aoff[l];
+  const float score = P.logits[l][(long)img * P.stride[l] + a];
+  const float4 b = P.anchors[l][a];
+  const float4 d = P.deltas[l][(long)img * P.stride[l] + a];
   // box_regression.py:88-116, fp32
   const float widths = b.z - b.x, heights = b.w - b.y;
   const float ctr_x = b.x + 0.5f * widths, ctr_y = b.y + 0.5f * heights;
@@ -185,45 +195,35 @@ extern "C" size_t d2amd_rpn_select_workspace_bytes(int N, int Atot) {
   return a > b ? a : b;
 }
 
-extern "C" int d2amd_rpn_select_proposals(const float* logits, const float* deltas, const float* anchors, int N,
-                                          int Atot, const int* level_sizes, int L, const int* image_hw,
-                                          int pre_nms_topk, float min_box_size, const float* weights,
-                                          float scale_clamp, float* boxes_out, float* scores_out, uint8_t* valid_out,
-                                          int64_t* level_out, int* flags_out, void* workspace, size_t workspace_bytes,
-                                          void* stream) {
-  D2_CHECK_ARG(N >= 0 && N <= D2AMD_POOLER_MAX_IMAGES, "rpn_select_proposals: %d images (max %d)", N,
-               D2AMD_POOLER_MAX_IMAGES);
-  D2_CHECK_ARG(L >= 1 && L <= D2AMD_RPN_MAX_LEVELS && level_sizes && image_hw && weights,
-               "rpn_select_proposals: bad level / image description");
-  D2_CHECK_ARG(pre_nms_topk > 0, "rpn_select_proposals: pre_nms_topk must be positive");
+// shared body: `concat` = the [N, Atot] logits of the concatenated entry point (the full-sort A/B path needs them)
+static int rpn_select_impl(const RpnPtrs& P, const float* concat, int N, int Atot, const int* level_sizes, int L,
+                           const int* image_hw, int pre_nms_topk, float min_box_size, const float* weights,
+                           float scale_clamp, float* boxes_out, float* scores_out, uint8_t* valid_out,
+                           int64_t* level_out, int* flags_out, void* workspace, size_t workspace_bytes,
+                           hipStream_t s) {
   RpnLevels lv{};
   lv.L = L;
   long a = 0, k = 0;
   for (int l = 0; l < L; l++) {
-    D2_CHECK_ARG(level_sizes[l] >= 0, "rpn_select_proposals: negative level size");
     lv.aoff[l] = (int)a; lv.koff[l] = (int)k;
     a += level_sizes[l];
     k += level_sizes[l] < pre_nms_topk ? level_sizes[l] : pre_nms_topk;
   }
   for (int l = L; l <= D2AMD_RPN_MAX_LEVELS; l++) { lv.aoff[l] = (int)a; lv.koff[l] = (int)k; }
-  D2_CHECK_ARG(a == Atot, "rpn_select_proposals: level sizes sum to %ld, expected %d", a, Atot);
-  D2_CHECK_ARG((long)N * Atot < (1l << 31) && (long)N * L < 65536, "rpn_select_proposals: too many anchors");
   if (N == 0 || k == 0) return D2AMD_OK;
-  D2_CHECK_ARG(logits && deltas && anchors && boxes_out && scores_out && valid_out && level_out && flags_out,
-               "rpn_select_proposals: null pointer");
+  D2_CHECK_ARG(boxes_out && scores_out && valid_out && level_out && flags_out, "rpn_select_proposals: null pointer");
   RpnImages im{};
   im.n = N;
   for (int i = 0; i < N; i++) { im.h[i] = image_hw[2 * i]; im.w[i] = image_hw[2 * i + 1]; }
-  hipStream_t s = (hipStream_t)stream;
   const long n = (long)N * Atot;
   static const bool use_sort = getenv("D2AMD_RPN_SORT") != nullptr;  // A/B switch: the first (full radix sort) path
-  if (pre_nms_topk <= TOPK_MAX_K && !use_sort) {
+  if (pre_nms_topk <= TOPK_MAX_K && !(use_sort && concat)) {
     // radix-select top-k per (image, level), then decode of the selected anchors
     TopkInput in{};
     in.N = N; in.L = L;
     for (int l = 0; l < L; l++) {
-      in.ptr[l] = logits + lv.aoff[l];
-      in.stride[l] = Atot;
+      in.ptr[l] = P.logits[l];
+      in.stride[l] = P.stride[l];
       in.size[l] = level_sizes[l];
       in.k[l] = lv.koff[l + 1] - lv.koff[l];
       in.koff[l] = lv.koff[l];
@@ -241,32 +241,100 @@ extern "C" int d2amd_rpn_select_proposals(const float* logits, const float* delt
     int rc = topk_select(in, false, 0.f, sel, cnt, (char*)workspace + off_tk, workspace_bytes - off_tk, s);
     if (rc) return rc;
     const long nt = (long)N * k;
-    hipLaunchKernelGGL(rpn_decode_kernel, dim3(cdiv(nt, 256)), dim3(256), 0, s, logits, (const float4*)deltas,
-                       (const float4*)anchors, (const uint32_t*)nullptr, (const uint32_t*)sel, N, Atot, lv, im,
-                       weights[0], weights[1], weights[2], weights[3], scale_clamp, min_box_size, (float4*)boxes_out,
-                       scores_out, valid_out, level_out, flags_out);
+    hipLaunchKernelGGL(rpn_decode_kernel, dim3(cdiv(nt, 256)), dim3(256), 0, s, P, (const uint32_t*)nullptr,
+                       (const uint32_t*)sel, N, Atot, lv, im, weights[0], weights[1], weights[2], weights[3],
+                       scale_clamp, min_box_size, (float4*)boxes_out, scores_out, valid_out, level_out, flags_out);
     D2_LAUNCH_OK();
     return D2AMD_OK;
   }
+  D2_CHECK_ARG(concat, "rpn_select_proposals: pre_nms_topk %d exceeds %d (per-level inputs: use the concatenated entry)",
+               pre_nms_topk, TOPK_MAX_K);
   RpnWs w = rpn_carve(n, workspace);
   if (workspace == nullptr || workspace_bytes < w.total) {
     set_error("rpn_select_proposals: workspace too small (%zu < %zu)", workspace_bytes, w.total);
     return D2AMD_EWORKSPACE;
   }
   { const int zrc = zero_async(flags_out, sizeof(int), s); if (zrc) return zrc; }
-  hipLaunchKernelGGL(rpn_keys_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, logits, N, Atot, lv, w.k0, w.v0);
+  hipLaunchKernelGGL(rpn_keys_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, concat, N, Atot, lv, w.k0, w.v0);
   D2_LAUNCH_OK();
   int seg_bits = 1;
   while ((1 << seg_bits) < N * L) seg_bits++;
   D2_HIP_OK(rocprim::radix_sort_pairs(w.temp, w.temp_bytes, w.k0, w.k1, w.v0, w.v1, (size_t)n, 0u,
                                       (unsigned)(32 + seg_bits), s, false));
   const long nt = (long)N * k;
-  hipLaunchKernelGGL(rpn_decode_kernel, dim3(cdiv(nt, 256)), dim3(256), 0, s, logits, (const float4*)deltas,
-                     (const float4*)anchors, w.v1, (const uint32_t*)nullptr, N, Atot, lv, im, weights[0], weights[1],
-                     weights[2], weights[3],
-                     scale_clamp, min_box_size, (float4*)boxes_out, scores_out, valid_out, level_out, flags_out);
+  hipLaunchKernelGGL(rpn_decode_kernel, dim3(cdiv(nt, 256)), dim3(256), 0, s, P, w.v1, (const uint32_t*)nullptr, N,
+                     Atot, lv, im, weights[0], weights[1], weights[2], weights[3], scale_clamp, min_box_size,
+                     (float4*)boxes_out, scores_out, valid_out, level_out, flags_out);
   D2_LAUNCH_OK();
   return D2AMD_OK;
+}
+
+static int rpn_check_layout(int N, const int* level_sizes, int L, const int* image_hw, int pre_nms_topk,
+                            const float* weights, long& atot) {
+  D2_CHECK_ARG(N >= 0 && N <= D2AMD_POOLER_MAX_IMAGES, "rpn_select_proposals: %d images (max %d)", N,
+               D2AMD_POOLER_MAX_IMAGES);
+  D2_CHECK_ARG(L >= 1 && L <= D2AMD_RPN_MAX_LEVELS && level_sizes && image_hw && weights,
+               "rpn_select_proposals: bad level / image description");
+  D2_CHECK_ARG(pre_nms_topk > 0, "rpn_select_proposals: pre_nms_topk must be positive");
+  atot = 0;
+  for (int l = 0; l < L; l++) {
+    D2_CHECK_ARG(level_sizes[l] >= 0, "rpn_select_proposals: negative level size");
+    atot += level_sizes[l];
+  }
+  D2_CHECK_ARG((long)N * atot < (1l << 31) && (long)N * L < 65536, "rpn_select_proposals: too many anchors");
+  return D2AMD_OK;
+}
+
+extern "C" int d2amd_rpn_select_proposals(const float* logits, const float* deltas, const float* anchors, int N,
+                                          int Atot, const int* level_sizes, int L, const int* image_hw,
+                                          int pre_nms_topk, float min_box_size, const float* weights,
+                                          float scale_clamp, float* boxes_out, float* scores_out, uint8_t* valid_out,
+                                          int64_t* level_out, int* flags_out, void* workspace, size_t workspace_bytes,
+                                          void* stream) {
+  long a = 0;
+  const int rc = rpn_check_layout(N, level_sizes, L, image_hw, pre_nms_topk, weights, a);
+  if (rc) return rc;
+  D2_CHECK_ARG(a == Atot, "rpn_select_proposals: level sizes sum to %ld, expected %d", a, Atot);
+  D2_CHECK_ARG(N == 0 || Atot == 0 || (logits && deltas && anchors), "rpn_select_proposals: null pointer");
+  RpnPtrs P{};
+  long off = 0;
+  for (int l = 0; l < L; l++) {
+    P.logits[l] = logits + off;
+    P.deltas[l] = (const float4*)deltas + off;
+    P.anchors[l] = (const float4*)anchors + off;
+    P.stride[l] = Atot;
+    off += level_sizes[l];
+  }
+  return rpn_select_impl(P, logits, N, Atot, level_sizes, L, image_hw, pre_nms_topk, min_box_size, weights, scale_clamp,
+                         boxes_out, scores_out, valid_out, level_out, flags_out, workspace, workspace_bytes,
+                         (hipStream_t)stream);
+}
+
+// The same selection on the RPN head's per-level outputs as they are (rpn.py:431-449: pred_objectness_logits[l]
+// [N, A_l], pred_anchor_deltas[l] [N, A_l, 4], anchors[l] [A_l, 4]; all fp32, contiguous): no concatenation.
+extern "C" int d2amd_rpn_select_proposals_levels(const float* const* logits, const float* const* deltas,
+                                                 const float* const* anchors, int N, const int* level_sizes, int L,
+                                                 const int* image_hw, int pre_nms_topk, float min_box_size,
+                                                 const float* weights, float scale_clamp, float* boxes_out,
+                                                 float* scores_out, uint8_t* valid_out, int64_t* level_out,
+                                                 int* flags_out, void* workspace, size_t workspace_bytes,
+                                                 void* stream) {
+  long a = 0;
+  const int rc = rpn_check_layout(N, level_sizes, L, image_hw, pre_nms_topk, weights, a);
+  if (rc) return rc;
+  D2_CHECK_ARG(logits && deltas && anchors, "rpn_select_proposals_levels: null pointer");
+  RpnPtrs P{};
+  for (int l = 0; l < L; l++) {
+    D2_CHECK_ARG(level_sizes[l] == 0 || N == 0 || (logits[l] && deltas[l] && anchors[l]),
+                 "rpn_select_proposals_levels: null level %d", l);
+    P.logits[l] = logits[l];
+    P.deltas[l] = (const float4*)deltas[l];
+    P.anchors[l] = (const float4*)anchors[l];
+    P.stride[l] = level_sizes[l];
+  }
+  return rpn_select_impl(P, nullptr, N, (int)a, level_sizes, L, image_hw, pre_nms_topk, min_box_size, weights,
+                         scale_clamp, boxes_out, scores_out, valid_out, level_out, flags_out, workspace,
+                         workspace_bytes, (hipStream_t)stream);
 }
 
 static int dense_layout(int N, const int* level_anchors, int L, int num_classes, int topk, TopkInput& in, RpnLevels& lv) {

@@ -169,12 +169,13 @@ __global__ __launch_bounds__(TK_THREADS) void tk_hist_kernel(TkParams P, SegStat
   for (int i = tid; i < TK_BINS; i += TK_THREADS)
     if (h[i]) atomicAdd(&gh[i], h[i]);
   if (!P.tickets) return;  // tk_scan_kernel follows
-  __threadfence();
+  // (no device-scope fence: bins and ticket are device-scope atomics, performed at the memory side of the L2s, and
+  // the scan reads the bins with device-scope loads -- see tk_segment_barrier; a fence costs an L2 write-back here)
+  __builtin_amdgcn_s_waitcnt(0);  // this wave's bin atomics have been acknowledged
   __syncthreads();
   if (tid == 0) s_last = atomicAdd(&S->done[PASS], 1) == nblk - 1;
   __syncthreads();
   if (!s_last) return;
-  __threadfence();
   tk_scan_bins<PASS>(P, S, gh, l);
 }
 
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(TK_THREADS) void tk_ties_kernel(TkParams P, SegStat
   if (tid == 0) {
     __hip_atomic_store(&bt[blockIdx.x], red[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (P.tickets) {
-      __threadfence();
+      __builtin_amdgcn_s_waitcnt(0);  // the count above is a device-scope atomic store: acknowledged = visible
       s_last = atomicAdd(&S->done[3], 1) == nblk - 1;
     } else {
       s_last = 0;  // tk_ties_scan_kernel follows
@@ -246,7 +247,6 @@ __global__ __launch_bounds__(TK_THREADS) void tk_ties_kernel(TkParams P, SegStat
   }
   __syncthreads();
   if (!s_last) return;
-  __threadfence();
   tk_ties_scan(bt, nblk);
 }
 
@@ -259,6 +259,86 @@ __global__ __launch_bounds__(TK_THREADS) void tk_ties_scan_kernel(TkParams P, Se
   tk_ties_scan(blk_ties + (long)seg * P.maxblk, (int)((size + span - 1) / span));
 }
 
+// what the three histogram passes found for a segment
+struct TkSel {
+  uint32_t T;    // key of the k-th best candidate
+  int c_lt;      // candidates strictly better than T
+  int need;      // ties at T to take
+  bool take_all; // fewer candidates than k: all of them
+  bool ordered;  // more ties than needed: the ones with the lowest element index
+};
+struct TkCompactLds {
+  int wcnt[TK_ITEMS][TK_THREADS / 64];
+  int lds4[TK_THREADS / 64];
+  int base_lt, base_tie;
+};
+
+// compaction of one TK_CHUNK of a segment (values already loaded): writes its selected (key : index) pairs.
+// `before` = ties in the chunks before this one (ordered mode), advanced by this chunk's ties.
+__device__ __forceinline__ void tk_compact_chunk(const TkParams& P, const TkSel& Z, SegState* S,
+                                                 const float (&v)[TK_ITEMS], const bool (&ok)[TK_ITEMS], long base,
+                                                 unsigned long long* __restrict__ out, int& before, TkCompactLds& L) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint32_t keys[TK_ITEMS];
+  unsigned lt_bits = 0, tie_bits = 0;  // bit j: element j of this thread is strictly better / a tie
+  unsigned long long bal[TK_ITEMS];
+#pragma unroll
+  for (int j = 0; j < TK_ITEMS; j++) {
+    uint32_t key = 0;
+    const bool c = ok[j] && tk_key(P, v[j], key);
+    keys[j] = key;
+    if (c && (Z.take_all || key < Z.T)) lt_bits |= 1u << j;
+    const bool tie = c && !Z.take_all && key == Z.T;
+    if (tie) tie_bits |= 1u << j;
+    if (Z.ordered) {  // uniform
+      bal[j] = __ballot(tie);
+      if (lane == 0) L.wcnt[j][wave] = __builtin_popcountll(bal[j]);
+    }
+  }
+  if (!__syncthreads_or((lt_bits | tie_bits) != 0u)) return;  // uniform: nothing selected in this chunk (the usual case)
+  // one atomic per workgroup and counter (2,000 returning atomics on ONE address serialise in L2: 20 us)
+  int tot_lt, tot_tie = 0;
+  const int my_lt = tk_block_excl_scan(__builtin_popcount(lt_bits), L.lds4, tot_lt);
+  int my_tie = 0;
+  if (!Z.ordered) my_tie = tk_block_excl_scan(__builtin_popcount(tie_bits), L.lds4, tot_tie);
+  if (tid == 0) {
+    L.base_lt = tot_lt ? atomicAdd(&S->cnt_lt, tot_lt) : 0;
+    L.base_tie = tot_tie ? atomicAdd(&S->cnt_tie, tot_tie) : 0;
+  }
+  __syncthreads();
+  {
+    int p_lt = L.base_lt + my_lt, p_tie = Z.c_lt + L.base_tie + my_tie;
+#pragma unroll
+    for (int j = 0; j < TK_ITEMS; j++) {
+      const long i = base + (long)j * TK_THREADS + tid;
+      const unsigned long long e = ((unsigned long long)keys[j] << 32) | (uint32_t)i;
+      if (lt_bits & (1u << j)) out[p_lt++] = e;
+      else if (!Z.ordered && (tie_bits & (1u << j))) out[p_tie++] = e;
+    }
+  }
+  if (!Z.ordered) return;
+  // rank of a tie in element-index order: rows j ascending, inside a row waves then lanes ascending
+  // (wcnt is complete: the scans above contain workgroup barriers)
+#pragma unroll
+  for (int j = 0; j < TK_ITEMS; j++) {
+    int row_before = 0, row_total = 0;
+#pragma unroll
+    for (int w = 0; w < TK_THREADS / 64; w++) {
+      const int c = L.wcnt[j][w];
+      if (w < wave) row_before += c;
+      row_total += c;
+    }
+    if (tie_bits & (1u << j)) {
+      const int rank = before + row_before + __builtin_popcountll(bal[j] & ((1ull << lane) - 1ull));
+      if (rank < Z.need) {
+        const long i = base + (long)j * TK_THREADS + tid;
+        out[Z.c_lt + rank] = ((unsigned long long)keys[j] << 32) | (uint32_t)i;
+      }
+    }
+    before += row_total;
+  }
+}
+
 __global__ __launch_bounds__(TK_THREADS) void tk_compact_kernel(TkParams P, SegState* __restrict__ st,
                                                                const int* __restrict__ blk_ties,
                                                                unsigned long long* __restrict__ cand, int kmax) {
@@ -268,83 +348,167 @@ __global__ __launch_bounds__(TK_THREADS) void tk_compact_kernel(TkParams P, SegS
   const long base0 = (long)blockIdx.x * span;
   if (base0 >= size) return;
   SegState* S = st + seg;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const bool take_all = S->take_all != 0;
-  const uint32_t T = S->prefix;
-  const int c_lt = S->c_lt, need = S->need;
-  const bool ordered = !take_all && S->ties_total > need;  // uniform
+  TkSel Z;
+  Z.take_all = S->take_all != 0;
+  Z.T = S->prefix;
+  Z.c_lt = S->c_lt; Z.need = S->need;
+  Z.ordered = !Z.take_all && S->ties_total > Z.need;  // uniform
   const float* x = P.in.ptr[l] + (long)img * P.in.stride[l];
   unsigned long long* out = cand + (long)seg * kmax;
-  __shared__ int wcnt[TK_ITEMS][TK_THREADS / 64];
-  __shared__ int lds4[TK_THREADS / 64];
-  __shared__ int s_base_lt, s_base_tie;
-  int before = ordered ? blk_ties[(long)seg * P.maxblk + blockIdx.x] : 0;  // ties in the workgroups before this one
+  __shared__ TkCompactLds L;
+  int before = Z.ordered ? blk_ties[(long)seg * P.maxblk + blockIdx.x] : 0;  // ties in the workgroups before this one
   for (int rep = 0; rep < P.reps; rep++) {
-  const long base = base0 + (long)rep * TK_CHUNK;
-  if (base >= size) break;  // uniform
-  __syncthreads();          // the previous chunk's readers of wcnt / s_base_* are done
-  uint32_t keys[TK_ITEMS];
-  unsigned lt_bits = 0, tie_bits = 0;  // bit j: element j of this thread is strictly better / a tie
-  unsigned long long bal[TK_ITEMS];
+    const long base = base0 + (long)rep * TK_CHUNK;
+    if (base >= size) break;  // uniform
+    __syncthreads();          // the previous chunk's readers of L are done
+    float v[TK_ITEMS];
+    bool ok[TK_ITEMS];
+    tk_load(x, base, size, v, ok);
+    tk_compact_chunk(P, Z, S, v, ok, base, out, before, L);
+  }
+}
+
+// ---- all of the above in ONE launch, for launches whose workgroups are co-resident (the RPN: 138 workgroups) ----
+// Five dependent launches of ~140 workgroups spend most of their 18-20 us each on what surrounds the arithmetic:
+// launch, the first load round trip, the ticket, the last workgroup's scan, the next launch.  Here every workgroup
+// loads its chunk ONCE (16 values per thread stay in registers through all passes), and the workgroups of a segment
+// meet at a segment-wide barrier (a counter in memory) after each histogram flush; after the barrier EVERY workgroup
+// scans the segment's bins itself -- same inputs, same result -- so nothing is broadcast and no SegState travels
+// between passes.  Precondition (host): reps == 1 and the whole grid fits on the device at once, so that spinning
+// workgroups cannot starve the ones they wait for.
+struct TkScanOut { int bin, before, total; };
+
+template <int BINS>
+__device__ __forceinline__ TkScanOut tk_scan_local(const int* gh, int k_rem, int* lds4, int* s_pair) {
+  const int tid = threadIdx.x;
+  constexpr int PER = BINS / TK_THREADS;
+  int loc[PER], sum = 0;
+#pragma unroll
+  for (int j = 0; j < PER; j++) { loc[j] = ld_agent(&gh[tid * PER + j]); sum += loc[j]; }
+  int total;
+  int run = tk_block_excl_scan(sum, lds4, total);
+  if (tid == 0) { s_pair[0] = -1; s_pair[1] = 0; }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < PER; j++) {
+    if (run < k_rem && run + loc[j] >= k_rem) { s_pair[0] = tid * PER + j; s_pair[1] = run; }
+    run += loc[j];
+  }
+  __syncthreads();
+  TkScanOut o;
+  o.bin = s_pair[0]; o.before = s_pair[1]; o.total = total;
+  __syncthreads();  // s_pair is reused by the next scan
+  return o;
+}
+
+// All workgroups of the segment have arrived.  Everything the workgroups exchange (histogram bins, tie counts, the
+// counter itself) is written and read with DEVICE-SCOPE ATOMICS, which are performed at the memory side of the XCDs'
+// L2s: no release / acquire fence is needed for them, and none is used -- on this part a device-scope fence writes the
+// XCD's L2 back and invalidates it (the eight L2s are not coherent with each other), ~10 us per fence with 140
+// workgroups doing it at once, which is what made the first fused version slower than five launches.  What is needed
+// is that this workgroup's atomics have completed before its arrival is counted: s_waitcnt(0) in every wave, then the
+// workgroup barrier, then the arrival.
+__device__ __forceinline__ void tk_segment_barrier(int* counter, int nblk) {
+  __builtin_amdgcn_s_waitcnt(0);  // every outstanding memory operation of this wave has been acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nblk) __builtin_amdgcn_s_sleep(2);
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(TK_THREADS) void tk_fused_kernel(TkParams P, SegState* __restrict__ st, int* __restrict__ hist,
+                                                             int* __restrict__ blk_ties,
+                                                             unsigned long long* __restrict__ cand, int kmax) {
+  const int seg = blockIdx.y, l = seg % P.in.L, img = seg / P.in.L;
+  const int size = P.in.size[l];
+  const long base = (long)blockIdx.x * TK_CHUNK;
+  if (base >= size) return;
+  const int nblk = (size + TK_CHUNK - 1) / TK_CHUNK;
+  SegState* S = st + seg;
+  const int tid = threadIdx.x;
+  __shared__ int h[TK_BINS];
+  __shared__ int lds4[TK_THREADS / 64];
+  __shared__ int s_pair[2];
+  __shared__ TkCompactLds L;
+  const float* x = P.in.ptr[l] + (long)img * P.in.stride[l];
   float v[TK_ITEMS];
   bool ok[TK_ITEMS];
   tk_load(x, base, size, v, ok);
+  uint32_t keys[TK_ITEMS];
+  unsigned cand_bits = 0;
 #pragma unroll
   for (int j = 0; j < TK_ITEMS; j++) {
-    uint32_t key = 0;
-    const bool c = ok[j] && tk_key(P, v[j], key);
-    keys[j] = key;
-    if (c && (take_all || key < T)) lt_bits |= 1u << j;
-    const bool tie = c && !take_all && key == T;
-    if (tie) tie_bits |= 1u << j;
-    if (ordered) {  // uniform
-      bal[j] = __ballot(tie);
-      if (lane == 0) wcnt[j][wave] = __builtin_popcountll(bal[j]);
-    }
+    keys[j] = 0;
+    if (ok[j] && tk_key(P, v[j], keys[j])) cand_bits |= 1u << j;
   }
-  if (!__syncthreads_or((lt_bits | tie_bits) != 0u)) continue;  // uniform: nothing selected in this chunk (the usual case)
-  // one atomic per workgroup and counter (2,000 returning atomics on ONE address serialise in L2: 20 us)
-  int tot_lt, tot_tie = 0;
-  const int my_lt = tk_block_excl_scan(__builtin_popcount(lt_bits), lds4, tot_lt);
-  int my_tie = 0;
-  if (!ordered) my_tie = tk_block_excl_scan(__builtin_popcount(tie_bits), lds4, tot_tie);
-  if (tid == 0) {
-    s_base_lt = tot_lt ? atomicAdd(&S->cnt_lt, tot_lt) : 0;
-    s_base_tie = tot_tie ? atomicAdd(&S->cnt_tie, tot_tie) : 0;
-  }
+  int* gh = hist + (long)seg * 3 * TK_BINS;
+  TkSel Z{};
+  int k_rem = P.in.k[l];
+  uint32_t prefix = 0;
+  // ---- pass 0: key >> 21 ------------------------------------------------------------------------
+  for (int i = tid; i < TK_BINS; i += TK_THREADS) h[i] = 0;
   __syncthreads();
-  {
-    int p_lt = s_base_lt + my_lt, p_tie = c_lt + s_base_tie + my_tie;
 #pragma unroll
-    for (int j = 0; j < TK_ITEMS; j++) {
-      const long i = base + (long)j * TK_THREADS + tid;
-      const unsigned long long e = ((unsigned long long)keys[j] << 32) | (uint32_t)i;
-      if (lt_bits & (1u << j)) out[p_lt++] = e;
-      else if (!ordered && (tie_bits & (1u << j))) out[p_tie++] = e;
-    }
-  }
-  if (!ordered) continue;
-  // rank of a tie in element-index order: rows j ascending, inside a row waves then lanes ascending
-  // (wcnt is complete: the scans above contain workgroup barriers)
+  for (int j = 0; j < TK_ITEMS; j++)
+    if (cand_bits & (1u << j)) atomicAdd(&h[keys[j] >> 21], 1);
+  __syncthreads();
+  for (int i = tid; i < TK_BINS; i += TK_THREADS)
+    if (h[i]) atomicAdd(&gh[i], h[i]);
+  tk_segment_barrier(&S->done[0], nblk);
+  TkScanOut o = tk_scan_local<2048>(gh, k_rem, lds4, s_pair);
+  const int total = o.total;
+  Z.take_all = total < k_rem;  // not enough candidates: everything is selected (uniform)
+  if (!Z.take_all) {
+    prefix = (uint32_t)o.bin; Z.c_lt = o.before; k_rem -= o.before;
+    // ---- pass 1: (key >> 10) & 2047 where key >> 21 == prefix -----------------------------------
+    for (int i = tid; i < TK_BINS; i += TK_THREADS) h[i] = 0;
+    __syncthreads();
 #pragma unroll
-  for (int j = 0; j < TK_ITEMS; j++) {
-    int row_before = 0, row_total = 0;
+    for (int j = 0; j < TK_ITEMS; j++)
+      if ((cand_bits & (1u << j)) && (keys[j] >> 21) == prefix) atomicAdd(&h[(keys[j] >> 10) & 2047u], 1);
+    __syncthreads();
+    for (int i = tid; i < TK_BINS; i += TK_THREADS)
+      if (h[i]) atomicAdd(&gh[TK_BINS + i], h[i]);
+    tk_segment_barrier(&S->done[1], nblk);
+    o = tk_scan_local<2048>(gh + TK_BINS, k_rem, lds4, s_pair);
+    prefix = (prefix << 11) | (uint32_t)o.bin; Z.c_lt += o.before; k_rem -= o.before;
+    // ---- pass 2: key & 1023 where key >> 10 == prefix -------------------------------------------
+    for (int i = tid; i < 1024; i += TK_THREADS) h[i] = 0;
+    __syncthreads();
 #pragma unroll
-    for (int w = 0; w < TK_THREADS / 64; w++) {
-      const int v = wcnt[j][w];
-      if (w < wave) row_before += v;
-      row_total += v;
-    }
-    if (tie_bits & (1u << j)) {
-      const int rank = before + row_before + __builtin_popcountll(bal[j] & ((1ull << lane) - 1ull));
-      if (rank < need) {
-        const long i = base + (long)j * TK_THREADS + tid;
-        out[c_lt + rank] = ((unsigned long long)keys[j] << 32) | (uint32_t)i;
-      }
-    }
-    before += row_total;
+    for (int j = 0; j < TK_ITEMS; j++)
+      if ((cand_bits & (1u << j)) && (keys[j] >> 10) == prefix) atomicAdd(&h[keys[j] & 1023u], 1);
+    __syncthreads();
+    for (int i = tid; i < 1024; i += TK_THREADS)
+      if (h[i]) atomicAdd(&gh[2 * TK_BINS + i], h[i]);
+    tk_segment_barrier(&S->done[2], nblk);
+    o = tk_scan_local<1024>(gh + 2 * TK_BINS, k_rem, lds4, s_pair);
+    prefix = (prefix << 10) | (uint32_t)o.bin; Z.c_lt += o.before;
+    Z.need = k_rem - o.before;
+    Z.T = prefix;
+    const int ties_total = ld_agent(&gh[2 * TK_BINS + o.bin]);
+    Z.ordered = ties_total > Z.need;
   }
+  if (blockIdx.x == 0 && tid == 0) S->cnt = Z.take_all ? total : P.in.k[l];  // read by tk_sort_kernel
+  // ---- ties in element-index order: the ties of the workgroups before this one ---------------------------------
+  int before = 0;
+  if (Z.ordered) {  // uniform over the segment
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < TK_ITEMS; j++) c += ((cand_bits & (1u << j)) && keys[j] == Z.T) ? 1 : 0;
+    int tot;
+    (void)tk_block_excl_scan(c, lds4, tot);
+    int* bt = blk_ties + (long)seg * P.maxblk;
+    if (tid == 0) __hip_atomic_store(&bt[blockIdx.x], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    tk_segment_barrier(&S->done[3], nblk);
+    int mine = 0;
+    for (int j = tid; j < (int)blockIdx.x; j += TK_THREADS) mine += ld_agent(&bt[j]);
+    (void)tk_block_excl_scan(mine, lds4, before);
+    __syncthreads();
   }
+  tk_compact_chunk(P, Z, S, v, ok, base, cand + (long)seg * kmax, before, L);
 }
 
 // Final ordering of the <= k selected (key : index) pairs of a segment.  One workgroup bitonic-sorts a RUN of up to
@@ -374,22 +538,25 @@ __global__ __launch_bounds__(1024) void tk_sort_kernel(TkParams P, const SegStat
   unsigned long long* in = cand + (long)seg * kmax + lo;
   for (int i = tid; i < p2; i += 1024) sk[i] = i < n ? in[i] : ~0ull;
   __syncthreads();
-  // element i is handled by thread i % 1024: for j < 64 the partner i ^ j belongs to the same wave, whose LDS
-  // accesses are ordered -- only the steps with j >= 64 need the workgroup barrier (15 of the 66 steps of 2,048)
+  // One compare-exchange PAIR per thread and step (pair q of step j: i = q with a zero bit inserted at log2(j),
+  // partner i | j) -- every thread works in every step; indexing by element left half of them idle and cost two
+  // dependent LDS round trips per step.  The 64 pairs of a wave cover one aligned block of 128 elements for every
+  // j <= 64, so those steps only need the wave's own LDS ordering; the workgroup barrier is needed around the steps
+  // with j >= 128 (14 of the 66 steps of 2,048).
+  const int half = p2 >> 1;
   for (int k2 = 2; k2 <= p2; k2 <<= 1) {
     for (int j = k2 >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < p2; i += 1024) {
-        const int ix = i ^ j;
-        if (ix > i) {
-          const unsigned long long a = sk[i], b = sk[ix];
-          const bool up = (i & k2) == 0;
-          if ((a > b) == up) { sk[i] = b; sk[ix] = a; }
-        }
+      for (int q = tid; q < half; q += 1024) {
+        const int i = ((q & ~(j - 1)) << 1) | (q & (j - 1)), ix = i | j;
+        const unsigned long long a = sk[i], b = sk[ix];
+        const bool up = (i & k2) == 0;
+        if ((a > b) == up) { sk[i] = b; sk[ix] = a; }
       }
-      if (j >= 64 || (j == 1 && (k2 << 1) > 64)) __syncthreads();  // uniform
+      if (j >= 128 || (j == 1 && k2 >= 128)) __syncthreads();  // uniform
       else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
   }
+  __syncthreads();  // (short runs end on wave-ordered steps; the copy-out below reads across waves)
   if (total <= TK_RUN) {  // single run: done
     uint32_t* o = sel + (long)img * P.in.koff[P.in.L] + P.in.koff[l];
     for (int i = tid; i < n; i += 1024) o[i] = (uint32_t)sk[i];
@@ -481,6 +648,21 @@ int topk_select(const TopkInput& in, bool use_thr, float xmin, uint32_t* sel, in
   { const int zrc = zero_async(ws, w.zero_bytes, s); if (zrc) return zrc; }
   dim3 grid(w.maxblk, in.N * in.L), block(TK_THREADS);
   const dim3 segs(in.N * in.L);
+  // one launch when every workgroup of the grid is resident at once (see tk_fused_kernel): two 256-thread
+  // workgroups per CU are always possible (8 KB + 1 KB LDS, < 128 VGPRs)
+  static const int resident = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return 2 * cus;
+  }();
+  static const bool no_fused = getenv("D2AMD_TOPK_MULTI") != nullptr;  // A/B switch: the multi-launch path
+  long live_wgs = 0;  // workgroups that do not exit at once (the grid is sized for the largest segment)
+  for (int l = 0; l < in.L; l++) live_wgs += (long)in.N * ((in.size[l] + TK_CHUNK - 1) / TK_CHUNK);
+  if (w.tickets && w.reps == 1 && live_wgs <= resident && !no_fused) {
+    hipLaunchKernelGGL(tk_fused_kernel, grid, block, 0, s, P, w.st, w.hist, w.blk_ties, w.cand, w.kmax);
+    D2_LAUNCH_OK();
+  } else {
   hipLaunchKernelGGL(tk_hist_kernel<0>, grid, block, 0, s, P, w.st, w.hist);
   if (!w.tickets) hipLaunchKernelGGL(tk_scan_kernel<0>, segs, block, 0, s, P, w.st, w.hist);
   hipLaunchKernelGGL(tk_hist_kernel<1>, grid, block, 0, s, P, w.st, w.hist);
@@ -490,6 +672,7 @@ int topk_select(const TopkInput& in, bool use_thr, float xmin, uint32_t* sel, in
   hipLaunchKernelGGL(tk_ties_kernel, grid, block, 0, s, P, w.st, w.blk_ties);
   if (!w.tickets) hipLaunchKernelGGL(tk_ties_scan_kernel, segs, block, 0, s, P, w.st, w.blk_ties);
   hipLaunchKernelGGL(tk_compact_kernel, grid, block, 0, s, P, w.st, w.blk_ties, w.cand, w.kmax);
+  }
   const int run = tk_run_for(w.kmax);
   int pow2 = 1;
   while (pow2 < w.kmax && pow2 < run) pow2 <<= 1;

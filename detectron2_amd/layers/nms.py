@@ -40,14 +40,24 @@ def batched_nms_rotated(boxes: torch.Tensor, scores: torch.Tensor, idxs: torch.T
     return torch.ops.d2amd.batched_nms_rotated(boxes, scores, idxs, iou_threshold)
 
 
-def batched_nms_images(inputs, iou_threshold: float, defer: bool = False):
+def batched_nms_images(inputs, iou_threshold: float, defer: bool = False, runs=None, gather=None,
+                       result_buffer=None):
     """`batched_nms` of every image of a batch: inputs = [(boxes [n,4], scores [n], idxs [n]), ...] ->
     list of kept-index tensors (each as `batched_nms` would return).  Replaces the per-image loop +
     per-image host sync of find_top_rpn_proposals (proposal_generator/proposal_utils.py:118-135) and
     DenseDetector._decode_multi_level_predictions / inference (meta_arch/dense_detector.py:186-260):
     the images' device pipelines overlap on separate HIP streams and there is one sync per batch.
     defer=True enqueues everything and returns a callable that performs that sync and returns the list: work that does
-    not depend on the NMS (e.g. the anchor-labelling IoU of the same RPN iteration) can be enqueued in between."""
+    not depend on the NMS (e.g. the anchor-labelling IoU of the same RPN iteration) can be enqueued in between.
+    runs = (run_offsets, runs_are_categories): the rows of every image are pre-sorted runs -- the per-level top-k lists
+    both callers have just built (rows parked at score -inf excepted); the order is then merged from the runs instead
+    of ranked from scratch, with identical results (include/d2amd.h: d2amd_nms_runs).
+    gather (with runs and defer): per image, up to 4 tensors [n, ...]; their kept rows, in keep order, are written while
+    the kept indices are (no `x[keep]` launches after the sync): `.gathered` of the returned callable.
+    result_buffer: an int32 device tensor of 8 * len(inputs) + k words owned by the caller, whose last k words its own
+    kernels have written (status flags): results and those words reach the host in one transfer; the callable then
+    always returns (kept, finite counts, the k words)."""
     for b, _s, _i in inputs:
         assert b.shape[-1] == 4
-    return nms_images([(b.float(), s, i) for b, s, i in inputs], iou_threshold, False, defer)
+    return nms_images([(b.float(), s, i) for b, s, i in inputs], iou_threshold, False, defer, runs, gather,
+                      result_buffer)

@@ -20,9 +20,53 @@ _DEFS = {
 }
 
 
-def _nms_launch(boxes, scores, idxs, iou_threshold, rotated, stream_ptr=None):
+def _runs_arg(runs):
+    """(run_offsets, runs_are_categories) -> ctypes arguments of the d2amd_nms*_runs entries."""
+    off, are_cls = runs
+    off = [int(v) for v in off]
+    return (_C.ctypes.c_int * len(off))(*off), len(off) - 1, int(bool(are_cls))
+
+
+def _gather_arg(srcs):
+    """tensors [n, ...] whose kept rows the NMS copies in keep order -> (d2amd_nms_gather, sources, destinations)"""
+    assert 1 <= len(srcs) <= 4, "gather: 1..4 arrays"
+    g = _C.NmsGather()
+    g.count = len(srcs)
+    src = [t.detach().contiguous() for t in srcs]
+    dst = [torch.empty_like(t) for t in src]
+    for t, (a, b) in enumerate(zip(src, dst)):
+        rb = a.element_size() * (a[0].numel() if a.shape[0] else 1)
+        assert rb % 4 == 0, "gather: rows must be a multiple of 4 bytes"
+        g.src[t], g.dst[t], g.row_bytes[t] = a.data_ptr(), b.data_ptr(), rb
+    return g, src, dst
+
+
+def _regather(srcs, dsts, keep, num):
+    """the gather of a redone image (general entry: no fused gather)"""
+    for a, b in zip(srcs, dsts):
+        b[:num] = a[keep[:num]]
+
+
+def _runs_categories(runs, device):
+    """the category ids a `runs_are_categories` input stands for (general-path fallback)"""
+    off = torch.tensor(runs[0], dtype=torch.int64)
+    return torch.repeat_interleave(torch.arange(len(off) - 1, dtype=torch.int64), off[1:] - off[:-1]).to(device)
+
+
+# Boxes per category the suppression bitmask of a large input (n > 16,384) is pitched for without looking at the data.
+# The reference path never needed such a bound (torchvision's mask is n x n / 64 words); sizing it from the data took a
+# host sync + torch.unique (a device merge sort: 18 % of the RetinaNet selection's GPU time in the r02 profile).
+# Now: launch with this bound, and only if a category turns out larger (error flag 1, read with the result anyway)
+# run again with the exact size.  The mask kernel stops at the last live tile of a row block, so the bound costs
+# address space (n x 257 words), not work.
+_OPTIMISTIC_PER_CLASS = 16384
+
+
+def _nms_launch(boxes, scores, idxs, iou_threshold, rotated, stream_ptr=None, runs=None, exact_bound=False,
+                gather=None):
     """Allocate the outputs / workspace of one NMS on torch's current stream and enqueue the device
-    pipeline (d2amd_nms) on `stream_ptr` (default: the current stream).  No host sync."""
+    pipeline (d2amd_nms) on `stream_ptr` (default: the current stream).  No host sync.
+    runs = (run_offsets, runs_are_categories): the input is a sequence of pre-sorted runs (d2amd_nms_runs)."""
     bw = 5 if rotated else 4
     assert boxes.dim() == 2 and boxes.shape[1] == bw, boxes.shape
     n = boxes.shape[0]
@@ -35,18 +79,29 @@ def _nms_launch(boxes, scores, idxs, iou_threshold, rotated, stream_ptr=None):
         idxs = idxs.detach().to(torch.int64).contiguous()
         assert idxs.shape[0] == n
         if n > 16384:
-            # the suppression bitmask is n x (largest category / 64) words: size it from the data
-            # (one extra host sync, only for very large inputs)
-            max_per_class = int(torch.unique(idxs, return_counts=True)[1].max().item())
+            # the suppression bitmask is n x (largest category / 64) words
+            if exact_bound:  # second attempt: size it from the data (one extra host sync)
+                max_per_class = int(torch.unique(idxs, return_counts=True)[1].max().item())
+            else:
+                max_per_class = _OPTIMISTIC_PER_CLASS
+    elif runs is not None and runs[1] and n > 16384:
+        max_per_class = max(int(b) - int(a) for a, b in zip(runs[0][:-1], runs[0][1:]))  # the runs are the categories
     L = _C.lib()
     with _C.on_device(boxes.device):
         ws_bytes = L.d2amd_nms_workspace_bytes(n, max_per_class, int(rotated))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=boxes.device)
         keep = torch.empty(n, dtype=torch.int64, device=boxes.device)
         result = torch.empty(4, dtype=torch.int64, device=boxes.device)
-        _C.check(L.d2amd_nms(_C.ptr(boxes), _C.ptr(scores), _C.ptr(idxs), n, float(iou_threshold), int(rotated),
-                             max_per_class, _C.ptr(keep), _C.ptr(result), _C.ptr(ws), ws_bytes,
-                             stream_ptr if stream_ptr is not None else _C.stream()))
+        st = stream_ptr if stream_ptr is not None else _C.stream()
+        if runs is None:
+            _C.check(L.d2amd_nms(_C.ptr(boxes), _C.ptr(scores), _C.ptr(idxs), n, float(iou_threshold), int(rotated),
+                                 max_per_class, _C.ptr(keep), _C.ptr(result), _C.ptr(ws), ws_bytes, st))
+        else:
+            off, n_runs, are_cls = _runs_arg(runs)
+            _C.check(L.d2amd_nms_runs(_C.ptr(boxes), _C.ptr(scores), _C.ptr(idxs), n, off, n_runs, are_cls,
+                                      float(iou_threshold), int(rotated), max_per_class, _C.ptr(keep),
+                                      _C.ptr(result), _C.ptr(ws), ws_bytes,
+                                      _C.ctypes.byref(gather) if gather is not None else None, st))
     return keep, result, (boxes, scores, idxs, ws)  # the inputs / workspace must outlive the launch
 
 
@@ -58,6 +113,19 @@ def _nms_finish(keep, num, flags):
     return keep[:num]
 
 
+def _nms_redo(boxes, scores, idxs, iou_threshold, rotated, runs, flags):
+    """Second attempt of one image after the result flags said the first launch's assumptions did not hold:
+    flag 4 = a run was not in order (rank from scratch), flag 1 = a category exceeds the optimistic bitmask pitch
+    (size it from the data).  Its own host sync; -> (keep, num, flags, num_finite)."""
+    if (flags & 4) or runs is None:
+        if runs is not None and runs[1]:
+            idxs = _runs_categories(runs, boxes.device)
+        runs = None
+    keep, result, _hold = _nms_launch(boxes, scores, idxs, iou_threshold, rotated, runs=runs, exact_bound=True)
+    num, flags, fin = result[:3].tolist()
+    return keep, num, flags, fin
+
+
 def nms_impl(boxes, scores, idxs, iou_threshold, rotated):
     """Shared driver of nms / batched_nms / nms_rotated / batched_nms_rotated (d2amd_nms)."""
     if boxes.shape[0] == 0:  # nothing to compute on any device (nms.py:125-126)
@@ -65,6 +133,8 @@ def nms_impl(boxes, scores, idxs, iou_threshold, rotated):
         return torch.empty((0,), dtype=torch.int64, device=boxes.device)
     keep, result, _hold = _nms_launch(boxes, scores, idxs, iou_threshold, rotated)
     num, flags = result[:2].tolist()  # the only host sync of the NMS pipeline
+    if (flags & 1) and idxs is not None and boxes.shape[0] > 16384:  # a category beyond the optimistic pitch
+        keep, num, flags, _ = _nms_redo(_hold[0], _hold[1], _hold[2], iou_threshold, rotated, None, flags)
     return _nms_finish(keep, num, flags)
 
 
@@ -72,7 +142,7 @@ _SIDE_STREAMS = {}
 _BATCH_MAX = None
 
 
-def _nms_images_batched(inputs, iou_threshold, rotated, defer=False):
+def _nms_images_batched(inputs, iou_threshold, rotated, defer=False, runs=None, gather=None, result_buffer=None):
     """All images through d2amd_nms_batched: one launch per pipeline stage for the whole batch, one
     [count, 2] result tensor, one host sync."""
     ct = _C.ctypes
@@ -81,9 +151,19 @@ def _nms_images_batched(inputs, iou_threshold, rotated, defer=False):
     bw = 5 if rotated else 4
     cnt = len(inputs)
     hold = []
+    gathered = []  # per image: (sources, destinations) of the fused gather
+    assert gather is None or runs is not None, "gather: only with pre-sorted runs (d2amd_nms*_runs)"
     arr = lambda vals: (ct.c_void_p * cnt)(*vals)
     with _C.on_device(dev):
-        result = torch.empty((cnt, 4), dtype=torch.int64, device=dev)
+        # result_buffer: the caller's int32 buffer, 8 words per image for the results + its own status words behind
+        # them (written by the caller's kernels): everything the host needs comes back in ONE transfer, with no
+        # torch.cat / dtype conversion launches in front of it
+        if result_buffer is not None:
+            assert result_buffer.dtype == torch.int32 and result_buffer.is_contiguous() and \
+                result_buffer.numel() >= 8 * cnt and result_buffer.device == dev
+            result = result_buffer[:8 * cnt].view(torch.int64).view(cnt, 4)
+        else:
+            result = torch.empty((cnt, 4), dtype=torch.int64, device=dev)
         pb, ps, pi, pk, pr, pw = [], [], [], [], [], []
         ns, wb, keeps = [], [], []
         for k, (boxes, scores, idxs) in enumerate(inputs):
@@ -105,26 +185,54 @@ def _nms_images_batched(inputs, iou_threshold, rotated, defer=False):
             pi.append(idxs.data_ptr() if idxs is not None else None)
             pk.append(keep.data_ptr()); pr.append(result.data_ptr() + 32 * k); pw.append(ws.data_ptr())
             ns.append(n); wb.append(nbytes)
-        _C.check(L.d2amd_nms_batched(cnt, arr(pb), arr(ps), arr(pi), (ct.c_int64 * cnt)(*ns), float(iou_threshold),
-                                     int(rotated), None, arr(pk), arr(pr), arr(pw), (ct.c_size_t * cnt)(*wb),
-                                     _C.stream()))
+        if runs is None:
+            _C.check(L.d2amd_nms_batched(cnt, arr(pb), arr(ps), arr(pi), (ct.c_int64 * cnt)(*ns),
+                                         float(iou_threshold), int(rotated), None, arr(pk), arr(pr), arr(pw),
+                                         (ct.c_size_t * cnt)(*wb), _C.stream()))
+        else:
+            off, n_runs, are_cls = _runs_arg(runs)
+            garr = None
+            if gather is not None:
+                gs = [_gather_arg(g) for g in gather]
+                garr = (_C.NmsGather * cnt)(*[g[0] for g in gs])
+                gathered.extend((g[1], g[2]) for g in gs)
+            _C.check(L.d2amd_nms_batched_runs(cnt, arr(pb), arr(ps), None if are_cls else arr(pi),
+                                              (ct.c_int64 * cnt)(*ns), off, n_runs, are_cls, float(iou_threshold),
+                                              int(rotated), None, arr(pk), arr(pr), arr(pw),
+                                              (ct.c_size_t * cnt)(*wb), garr, _C.stream()))
     def finish(with_finite=False, extra=None):
         """with_finite: also return, per image, how many kept boxes have a score > -inf; extra: a device tensor of
         int64 values read in the same host transfer (returned as a list)."""
-        flat = result.flatten() if extra is None else torch.cat([result.flatten(), extra.flatten().to(torch.int64)])
-        vals = flat.tolist()  # the only host sync; `hold` keeps inputs / workspaces alive until here
+        if result_buffer is not None:  # (values are < 2^31: the low words; the tail = the caller's status words)
+            assert extra is None
+            v32 = result_buffer.tolist()  # the only host sync; `hold` keeps inputs / workspaces alive until here
+            vals = v32[0:8 * cnt:2] + v32[8 * cnt:]
+        else:
+            flat = result.flatten() if extra is None else torch.cat([result.flatten(), extra.flatten().to(torch.int64)])
+            vals = flat.tolist()  # the only host sync; `hold` keeps inputs / workspaces alive until here
         counts = [vals[4 * k:4 * k + 4] for k in range(cnt)]
+        kept = []
+        for k, (keep, c) in enumerate(zip(keeps, counts)):
+            if c[1] & 4:  # a run was not in order: rank this image from scratch (general entry, its own sync)
+                keep, c[0], c[1], c[2] = _nms_redo(hold[k][0], hold[k][1], hold[k][2], iou_threshold, rotated, runs, c[1])
+                if gathered:
+                    _regather(gathered[k][0], gathered[k][1], keep, c[0])
+            kept.append(_nms_finish(keep, c[0], c[1]))
         hold.clear()
-        kept = [_nms_finish(keep, c[0], c[1]) for keep, c in zip(keeps, counts)]
-        if not with_finite and extra is None:
+        if not with_finite and extra is None and result_buffer is None:
             return kept
         return kept, [c[2] for c in counts], vals[4 * cnt:]
 
+    finish.gathered = [g[1] for g in gathered]  # per image: the arrays' rows in keep order (valid up to the kept count)
     return finish if defer else finish()
 
 
-def nms_images(inputs, iou_threshold, rotated=False, defer=False):
+def nms_images(inputs, iou_threshold, rotated=False, defer=False, runs=None, gather=None, result_buffer=None):
     """NMS of every image of a batch in one call: `inputs` = [(boxes, scores, idxs | None), ...].
+    runs = (run_offsets, runs_are_categories), the same for every image: the rows are pre-sorted runs (per-level
+    top-k lists; d2amd_nms_runs) -- with runs_are_categories the idxs of `inputs` are ignored (pass None).
+    gather (with runs and defer): per image, up to 4 tensors [n, ...] whose kept rows are wanted in keep order; the
+    returned callable carries them as `.gathered` (per image, full length: valid up to the kept count).
     defer=True: everything is enqueued and a callable is returned; calling it performs the one host sync and returns
     the kept indices -- the caller can enqueue independent work (e.g. the anchor labelling IoU) in between.
     The reference runs the RPN / RetinaNet NMS in a per-image Python loop, each iteration ending in a
@@ -139,7 +247,8 @@ def nms_images(inputs, iou_threshold, rotated=False, defer=False):
         _BATCH_MAX = int(_C.lib().d2amd_nms_batched_max_boxes())
     dev = inputs[0][0].device
     if all(b.shape[0] <= _BATCH_MAX and b.device == dev for b, _s, _i in inputs):
-        return _nms_images_batched(inputs, iou_threshold, rotated, defer)
+        return _nms_images_batched(inputs, iou_threshold, rotated, defer, runs, gather, result_buffer)
+    extra_tail = None if result_buffer is None else result_buffer[8 * len(inputs):]  # (large inputs: separate transfers)
     cur = torch.cuda.current_stream(dev)
     pool = _SIDE_STREAMS.setdefault(dev.index, [])
     # every dtype / layout conversion of every image runs on `cur` BEFORE the fork event: the side streams wait for
@@ -151,11 +260,13 @@ def nms_images(inputs, iou_threshold, rotated=False, defer=False):
         prepared.append((boxes.detach().float().contiguous(), scores.detach().float().contiguous(),
                          None if idxs is None else idxs.detach().to(torch.int64).contiguous()))
     inputs = prepared
+    assert gather is None or runs is not None, "gather: only with pre-sorted runs (d2amd_nms*_runs)"
+    gathered = [_gather_arg(g) for g in gather] if gather is not None else []  # (allocated on `cur` before the fork)
     fork = torch.cuda.Event()
     fork.record(cur)  # fork point: after the conversions, before any NMS kernel of this call
     launched = []
     k = 0
-    for boxes, scores, idxs in inputs:
+    for img, (boxes, scores, idxs) in enumerate(inputs):
         if boxes.shape[0] == 0:
             launched.append(None)
             continue
@@ -166,10 +277,15 @@ def nms_images(inputs, iou_threshold, rotated=False, defer=False):
                 pool.append(torch.cuda.Stream(device=dev))
             st = pool[(k - 1) % len(pool)]
             st.wait_event(fork)  # inputs are ready; does not wait for the images launched above
-        res = _nms_launch(boxes, scores, idxs, iou_threshold, rotated, stream_ptr=_C.ctypes.c_void_p(st.cuda_stream))
+        res = _nms_launch(boxes, scores, None if (runs is not None and runs[1]) else idxs, iou_threshold, rotated,
+                          stream_ptr=_C.ctypes.c_void_p(st.cuda_stream), runs=runs,
+                          gather=gathered[img][0] if gathered else None)
         if st is not cur:  # allocated on `cur`'s pool, used on `st`: tell the caching allocator
             for t in (res[0], res[1]) + tuple(x for x in res[2] if x is not None):
                 t.record_stream(st)
+            if gathered:
+                for t in gathered[img][1] + gathered[img][2]:
+                    t.record_stream(st)
         launched.append((res, st))
         k += 1
     for item in launched:
@@ -179,24 +295,32 @@ def nms_images(inputs, iou_threshold, rotated=False, defer=False):
     stacked = torch.stack([it[0][1] for it in live]) if live else None
 
     def finish(with_finite=False, extra=None):
+        if extra_tail is not None:
+            extra = extra_tail
         flat = stacked.flatten() if live else torch.zeros(0, dtype=torch.int64, device=dev)
         if extra is not None:
             flat = torch.cat([flat, extra.flatten().to(torch.int64)])
         vals = flat.tolist() if (live or extra is not None) else []  # ONE host sync
         out, fin, j = [], [], 0
-        for (boxes, _s, _i), it in zip(inputs, launched):
+        for img, ((boxes, _s, _i), it) in enumerate(zip(inputs, launched)):
             if it is None:
                 out.append(torch.empty((0,), dtype=torch.int64, device=boxes.device))
                 fin.append(0)
             else:
                 c = vals[4 * j:4 * j + 4]
-                out.append(_nms_finish(it[0][0], c[0], c[1]))
+                keep = it[0][0]
+                if (c[1] & 4) or ((c[1] & 1) and boxes.shape[0] > 16384):  # (see _nms_redo)
+                    keep, c[0], c[1], c[2] = _nms_redo(boxes, _s, _i, iou_threshold, rotated, runs, c[1])
+                    if gathered:
+                        _regather(gathered[img][1], gathered[img][2], keep, c[0])
+                out.append(_nms_finish(keep, c[0], c[1]))
                 fin.append(c[2])
                 j += 1
         if not with_finite and extra is None:
             return out
         return out, fin, vals[4 * len(live):]
 
+    finish.gathered = [g[2] for g in gathered]
     return finish if defer else finish()
 
 

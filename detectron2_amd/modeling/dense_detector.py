@@ -70,11 +70,11 @@ def dense_select_predictions(anchors: List[torch.Tensor], pred_logits: List[torc
     boxes = torch.empty((n, ktot, 4), dtype=torch.float32, device=dev)
     scores = torch.empty((n, ktot), dtype=torch.float32, device=dev)
     classes = torch.empty((n, ktot), dtype=torch.int64, device=dev)
-    valid = torch.empty((n, ktot), dtype=torch.uint8, device=dev)
+    valid = torch.empty((n, ktot), dtype=torch.bool, device=dev)  # written as 0 / 1 bytes
     counts = torch.zeros((n, nl), dtype=torch.int32, device=dev)
     sel_logits = torch.empty((n, ktot), dtype=torch.float32, device=dev) if return_logits else None
     if n == 0 or ktot == 0:
-        out = (boxes, scores, classes, valid.bool(), counts)
+        out = (boxes, scores, classes, valid, counts)
         return out + (sel_logits,) if return_logits else out
     L = _C.lib()
     lv = (ctypes.c_int * nl)(*sizes)
@@ -87,7 +87,7 @@ def dense_select_predictions(anchors: List[torch.Tensor], pred_logits: List[torc
                                                   _C.ptr(scores), _C.ptr(classes), _C.ptr(valid), _C.ptr(counts),
                                                   _C.ptr(sel_logits) if return_logits else None, _C.ptr(ws),
                                                   ws_bytes, _C.stream()))
-    out = (boxes, scores, classes, valid.bool(), counts)
+    out = (boxes, scores, classes, valid, counts)
     return out + (sel_logits,) if return_logits else out
 
 
@@ -103,10 +103,19 @@ def dense_detector_inference_fused(anchors, pred_logits, pred_anchor_deltas, ima
     # The NMS ranks by the selected LOGITS (same order as the scores, but independent of the exp() rounding)
     # (rows past a level's count carry logit -inf: the NMS reports how many kept boxes have a finite ranking score,
     # and those sort last -- no second transfer for the valid counts)
-    keeps, n_finite, _ = batched_nms_images([(boxes[i], rank[i], classes[i]) for i in range(n)], nms_thresh,
-                                            defer=True)(with_finite=True) if n else ([], [], [])  # the one sync
+    # (the rows are the per-level top-k lists, each in logit order: large inputs merge the order from those runs)
+    run_offsets = [0]
+    for a, lg in zip(anchors, pred_logits):
+        run_offsets.append(run_offsets[-1] + min(int(a.shape[0]) * int(lg.shape[-1]), topk_candidates))
+    if n == 0:
+        return []
+    nms_done = batched_nms_images([(boxes[i], rank[i], classes[i]) for i in range(n)], nms_thresh, defer=True,
+                                  runs=(run_offsets, False),
+                                  gather=[(boxes[i], scores[i], classes[i]) for i in range(n)])
+    keeps, n_finite, _ = nms_done(with_finite=True)  # the one sync
     out = []
     for i, k in enumerate(keeps):
-        k = k[:min(max_detections, n_finite[i])]
-        out.append(Detections(tuple(image_sizes[i]), Boxes(boxes[i][k]), scores[i][k], classes[i][k]))
+        m = min(max_detections, n_finite[i], len(k))  # the kept rows arrive in keep order: views, no index launch
+        kb, ks, kc = nms_done.gathered[i]
+        out.append(Detections(tuple(image_sizes[i]), Boxes(kb[:m]), ks[:m], kc[:m]))
     return out

@@ -38,7 +38,7 @@ class Proposals:
 def rpn_select_proposals(anchors: List[torch.Tensor], pred_objectness_logits: List[torch.Tensor],
                          pred_anchor_deltas: List[torch.Tensor], image_sizes: List[Tuple[int, int]],
                          pre_nms_topk: int, min_box_size: float, weights=(1.0, 1.0, 1.0, 1.0),
-                         scale_clamp: float = _DEFAULT_SCALE_CLAMP):
+                         scale_clamp: float = _DEFAULT_SCALE_CLAMP, flags_out: torch.Tensor = None):
     """Steps 1-2 of find_top_rpn_proposals + decode + clip + validity for all images.
     anchors[l] [A_l,4]; pred_objectness_logits[l] [N,A_l]; pred_anchor_deltas[l] [N,A_l,4].
     Returns boxes [N,K,4], scores [N,K], valid [N,K] bool, level_ids [K] int64, flags [1] int32 (device)."""
@@ -46,31 +46,46 @@ def rpn_select_proposals(anchors: List[torch.Tensor], pred_objectness_logits: Li
     sizes = [int(a.shape[0]) for a in anchors]
     n = int(pred_objectness_logits[0].shape[0])
     dev = anchors[0].device
-    logits = torch.cat([t.detach().float() for t in pred_objectness_logits], dim=1).contiguous()
-    deltas = torch.cat([t.detach().float() for t in pred_anchor_deltas], dim=1).contiguous()
-    anc = torch.cat([a.detach().float() for a in anchors], dim=0).contiguous()
+    # the head's per-level tensors go to the device as they are (no torch.cat: 2 x 268,569 x 9 floats per call)
+    logits = [t.detach().float().contiguous() for t in pred_objectness_logits]
+    deltas = [t.detach().float().contiguous() for t in pred_anchor_deltas]
+    anc = [a.detach().float().contiguous() for a in anchors]
     atot = sum(sizes)
-    assert logits.shape == (n, atot) and deltas.shape == (n, atot, 4) and len(image_sizes) == n
+    for l, s_l in enumerate(sizes):
+        assert logits[l].shape == (n, s_l) and deltas[l].shape == (n, s_l, 4) and anc[l].shape == (s_l, 4), \
+            (l, logits[l].shape, deltas[l].shape, anc[l].shape)
+    assert len(image_sizes) == n
     k = sum(min(s, pre_nms_topk) for s in sizes)
     boxes = torch.empty((n, k, 4), dtype=torch.float32, device=dev)
     scores = torch.empty((n, k), dtype=torch.float32, device=dev)
-    valid = torch.empty((n, k), dtype=torch.uint8, device=dev)
+    valid = torch.empty((n, k), dtype=torch.bool, device=dev)  # written as 0 / 1 bytes
     level_ids = torch.empty((k,), dtype=torch.int64, device=dev)
-    flags = torch.zeros((1,), dtype=torch.int32, device=dev)
+    # zeroed by the call (flags_out: the caller's int32[1], e.g. a word of its result buffer)
+    flags = flags_out if flags_out is not None else torch.empty((1,), dtype=torch.int32, device=dev)
     if n == 0 or k == 0:
-        return boxes, scores, valid.bool(), level_ids, flags
+        return boxes, scores, valid, level_ids, flags.zero_()
     L = _C.lib()
-    lv = (ctypes.c_int * len(sizes))(*sizes)
+    nl = len(sizes)
+    lv = (ctypes.c_int * nl)(*sizes)
     hw = (ctypes.c_int * (2 * n))(*[int(v) for s in image_sizes for v in s])
     wts = (ctypes.c_float * 4)(*[float(v) for v in weights])
+    parr = lambda ts: (ctypes.c_void_p * nl)(*[t.data_ptr() for t in ts])
     with _C.on_device(dev):
         ws_bytes = L.d2amd_rpn_select_workspace_bytes(n, atot)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        _C.check(L.d2amd_rpn_select_proposals(_C.ptr(logits), _C.ptr(deltas), _C.ptr(anc), n, atot, lv, len(sizes), hw,
-                                              int(pre_nms_topk), float(min_box_size), wts, float(scale_clamp),
-                                              _C.ptr(boxes), _C.ptr(scores), _C.ptr(valid), _C.ptr(level_ids),
-                                              _C.ptr(flags), _C.ptr(ws), ws_bytes, _C.stream()))
-    return boxes, scores, valid.bool(), level_ids, flags
+        if pre_nms_topk <= 65536:
+            _C.check(L.d2amd_rpn_select_proposals_levels(parr(logits), parr(deltas), parr(anc), n, lv, nl, hw,
+                                                         int(pre_nms_topk), float(min_box_size), wts,
+                                                         float(scale_clamp), _C.ptr(boxes), _C.ptr(scores),
+                                                         _C.ptr(valid), _C.ptr(level_ids), _C.ptr(flags), _C.ptr(ws),
+                                                         ws_bytes, _C.stream()))
+        else:  # beyond the radix select's k: the full-sort path works on the concatenated arrays
+            cl, cd, ca = torch.cat(logits, dim=1), torch.cat(deltas, dim=1), torch.cat(anc, dim=0)
+            _C.check(L.d2amd_rpn_select_proposals(_C.ptr(cl), _C.ptr(cd), _C.ptr(ca), n, atot, lv, nl, hw,
+                                                  int(pre_nms_topk), float(min_box_size), wts, float(scale_clamp),
+                                                  _C.ptr(boxes), _C.ptr(scores), _C.ptr(valid), _C.ptr(level_ids),
+                                                  _C.ptr(flags), _C.ptr(ws), ws_bytes, _C.stream()))
+    return boxes, scores, valid, level_ids, flags
 
 
 def find_top_rpn_proposals_fused(anchors, pred_objectness_logits, pred_anchor_deltas, image_sizes, nms_thresh: float,
@@ -83,21 +98,31 @@ def find_top_rpn_proposals_fused(anchors, pred_objectness_logits, pred_anchor_de
     flag come back in a single transfer.  defer=True enqueues everything and returns a callable that performs that
     sync and builds the list: work that does not depend on the proposals (the anchor labelling of the same RPN
     iteration, rpn.py:431-480) can be enqueued in between."""
+    n = int(pred_objectness_logits[0].shape[0])
+    # one int32 buffer for everything the host reads back: 8 words per image of NMS results + the non-finite flag
+    res = torch.empty(8 * n + 1, dtype=torch.int32, device=anchors[0].device)
     boxes, scores, valid, level_ids, flags = rpn_select_proposals(
         anchors, pred_objectness_logits, pred_anchor_deltas, image_sizes, pre_nms_topk, min_box_size, weights,
-        scale_clamp)
-    n = boxes.shape[0]
-    # invalid rows are zero-area boxes with score -inf: they neither suppress nor get suppressed and sort last
-    nms_done = batched_nms_images([(boxes[i], scores[i], level_ids) for i in range(n)], nms_thresh, defer=True)
+        scale_clamp, flags_out=res[8 * n:])
+    # invalid rows are zero-area boxes with score -inf: they neither suppress nor get suppressed and sort last.
+    # The rows of an image are the per-level top-k lists, each already in score order, and the NMS is per level:
+    # the order is merged from those runs (runs = categories) instead of ranked from scratch
+    run_offsets = [0]
+    for a in anchors:
+        run_offsets.append(run_offsets[-1] + min(int(a.shape[0]), pre_nms_topk))
+    nms_done = batched_nms_images([(boxes[i], scores[i], None) for i in range(n)], nms_thresh, defer=True,
+                                  runs=(run_offsets, True), gather=[(boxes[i], scores[i]) for i in range(n)],
+                                  result_buffer=res)
 
     def finish():
-        keeps, n_finite, (bad,) = nms_done(with_finite=True, extra=flags) if n else ([], [], (0,))  # the one sync
+        keeps, n_finite, (bad,) = nms_done(with_finite=True) if n else ([], [], (0,))  # the one sync
         if n and bad and training:
             raise FloatingPointError("Predicted boxes or scores contain Inf/NaN. Training has diverged.")
         out = []
         for i, k in enumerate(keeps):
-            k = k[:min(post_nms_topk, n_finite[i])]
-            out.append(Proposals(tuple(image_sizes[i]), Boxes(boxes[i][k]), scores[i][k]))
+            m = min(post_nms_topk, n_finite[i], len(k))  # the kept rows arrive in keep order: views, no index launch
+            kb, ks = nms_done.gathered[i]
+            out.append(Proposals(tuple(image_sizes[i]), Boxes(kb[:m]), ks[:m]))
         return out
 
     return finish if defer else finish()

@@ -198,6 +198,16 @@ int d2amd_rpn_select_proposals(const float* logits, const float* deltas, const f
                                float min_box_size, const float* weights, float scale_clamp, float* boxes_out,
                                float* scores_out, uint8_t* valid_out, int64_t* level_out, int* flags_out,
                                void* workspace, size_t workspace_bytes, void* stream);
+/* The same selection on the RPN head's per-level outputs as rpn.py:431-449 holds them -- logits[l] [N, A_l],
+ * deltas[l] [N, A_l, 4], anchors[l] [A_l, 4], fp32 and contiguous, device pointers in host arrays of length L
+ * (level_sizes[l] = A_l): no concatenated copy of the inputs.  Same outputs, same workspace
+ * (d2amd_rpn_select_workspace_bytes(N, sum of level_sizes)); pre_nms_topk <= 65536. */
+int d2amd_rpn_select_proposals_levels(const float* const* logits, const float* const* deltas,
+                                      const float* const* anchors, int N, const int* level_sizes, int L,
+                                      const int* image_hw, int pre_nms_topk, float min_box_size,
+                                      const float* weights, float scale_clamp, float* boxes_out, float* scores_out,
+                                      uint8_t* valid_out, int64_t* level_out, int* flags_out, void* workspace,
+                                      size_t workspace_bytes, void* stream);
 
 /* ---- Dense-detector (RetinaNet) prediction selection in front of NMS, all images and levels in one call.
  * Replaces meta_arch/dense_detector.py:186-245 (_decode_per_level_predictions per level and image: `scores >
@@ -255,6 +265,35 @@ int d2amd_nms_batched(int count, const float* const* boxes, const float* const* 
                       const int64_t* max_per_class, int64_t* const* keep_out, int64_t* const* result,
                       void* const* workspace, const size_t* workspace_bytes, void* stream);
 int d2amd_nms_batched_max_boxes(void);
+/* The same NMS for callers whose input is already ordered in RUNS -- find_top_rpn_proposals and DenseDetector
+ * inference hand over the per-level top-k lists the selection has just sorted (proposal_utils.py:62-80,
+ * dense_detector.py:207-223): run r = rows [run_offsets[r], run_offsets[r+1]) (host array of n_runs + 1 ints,
+ * run_offsets[n_runs] == n; n_runs <= 8), and inside a run the rows whose score is not -inf are in decreasing score
+ * order, equal scores in row order (rows at -inf -- parked invalid rows -- may sit anywhere).  The global order is then
+ * obtained by binary searches between the runs instead of an n^2 ranking / two radix sorts; results are identical to
+ * d2amd_nms / d2amd_nms_batched on the same input.  runs_are_categories = 1: the category of a row is the index of its
+ * run (idxs must be NULL) -- the RPN's per-level NMS.  A run that is not in order sets error flag bit 2 (value 4) in
+ * result[1]: keep_out is then unspecified and the caller must use the general entry.
+ * gather (optional, NULL: none; one struct per image for the batched entry): up to 4 device arrays with n rows of
+ * row_bytes[t] bytes each (a multiple of 4) whose kept rows are copied, in keep order, to dst[t] while keep_out is
+ * written: dst[t] row j = src[t] row keep_out[j] for j < result[0] -- the `boxes[keep]`, `scores[keep]`,
+ * `classes[keep]` gathers both callers issue after their host sync (proposal_utils.py:127-134,
+ * dense_detector.py:254-259), without the extra launches.  (Unspecified, like keep_out, when flag 4 is set.) */
+typedef struct {
+  int count;
+  const void* src[4];
+  void* dst[4];
+  int row_bytes[4];
+} d2amd_nms_gather;
+int d2amd_nms_runs(const float* boxes, const float* scores, const int64_t* idxs, int64_t n, const int* run_offsets,
+                   int n_runs, int runs_are_categories, double iou_threshold, int rotated, int64_t max_per_class,
+                   int64_t* keep_out, int64_t* result, void* workspace, size_t workspace_bytes,
+                   const d2amd_nms_gather* gather, void* stream);
+int d2amd_nms_batched_runs(int count, const float* const* boxes, const float* const* scores,
+                           const int64_t* const* idxs, const int64_t* n, const int* run_offsets, int n_runs,
+                           int runs_are_categories, double iou_threshold, int rotated, const int64_t* max_per_class,
+                           int64_t* const* keep_out, int64_t* const* result, void* const* workspace,
+                           const size_t* workspace_bytes, const d2amd_nms_gather* gather, void* stream);
 
 /* ---- paste_masks_in_image.  detectron2/layers/mask_ops.py:74-147.
  * masks [n,mh,mw] `mask_dtype`; boxes [n,4] fp32; out [n,img_h,img_w] uint8:

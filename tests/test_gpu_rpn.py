@@ -100,3 +100,50 @@ def test_rpn_full_size_pipeline_and_nonfinite():
         find_top_rpn_proposals_fused(A, Lg, D, hw, 0.7, 2000, 1000, 0.0, True)
     res = find_top_rpn_proposals_fused(A, Lg, D, hw, 0.7, 2000, 1000, 0.0, False)
     assert torch.isfinite(res[1].proposal_boxes.tensor).all() and len(res[1]) > 0
+
+
+def test_concatenated_entry_equals_the_per_level_entry(golden_dir):
+    """d2amd_rpn_select_proposals (levels concatenated, [N, Atot]) and d2amd_rpn_select_proposals_levels (the head's
+    per-level tensors, what the Python mirror calls) are one implementation behind two layouts: identical outputs."""
+    import ctypes
+
+    from detectron2_amd import _C
+
+    g, anchors, logits, deltas, hw = _golden(golden_dir)
+    topk, minsz = int(g["pre_nms_topk"]), float(g["min_box_size"])
+    A, Lg, D = _dev(anchors), _dev(logits), _dev(deltas)
+    exp = rpn_select_proposals(A, Lg, D, hw, topk, minsz)
+    n, sizes = Lg[0].shape[0], [a.shape[0] for a in A]
+    atot, k = sum(sizes), sum(min(s, topk) for s in sizes)
+    cl, cd, ca = torch.cat(Lg, 1).contiguous(), torch.cat(D, 1).contiguous(), torch.cat(A, 0).contiguous()
+    boxes = torch.empty((n, k, 4), device=DEV)
+    scores = torch.empty((n, k), device=DEV)
+    valid = torch.empty((n, k), dtype=torch.bool, device=DEV)
+    lv = torch.empty((k,), dtype=torch.int64, device=DEV)
+    flags = torch.empty((1,), dtype=torch.int32, device=DEV)
+    L = _C.lib()
+    ws_bytes = L.d2amd_rpn_select_workspace_bytes(n, atot)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=DEV)
+    _C.check(L.d2amd_rpn_select_proposals(
+        _C.ptr(cl), _C.ptr(cd), _C.ptr(ca), n, atot, (ctypes.c_int * len(sizes))(*sizes), len(sizes),
+        (ctypes.c_int * (2 * n))(*[int(v) for s_ in hw for v in s_]), topk, minsz, (ctypes.c_float * 4)(1, 1, 1, 1),
+        float(np.log(1000.0 / 16)), _C.ptr(boxes), _C.ptr(scores), _C.ptr(valid), _C.ptr(lv), _C.ptr(flags),
+        _C.ptr(ws), ws_bytes, _C.stream()))
+    for got, want in zip((boxes, scores, valid, lv, flags), exp):
+        assert torch.equal(got, want)
+
+
+def test_multi_launch_selection_path_still_agrees():
+    """The RPN's selection runs as one fused launch when its workgroups are co-resident (csrc/topk.hip:
+    tk_fused_kernel); D2AMD_TOPK_MULTI=1 forces the launch-per-pass path that larger inputs take.  Both must pass the
+    oracle / reference comparisons of this file and the dense detector's tie tests."""
+    import subprocess
+    import sys
+
+    if os.environ.get("D2AMD_TOPK_MULTI"):
+        pytest.skip("already the child")
+    env = dict(os.environ, D2AMD_TOPK_MULTI="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_gpu_rpn.py",
+                        "tests/test_gpu_dense.py", "-k", "oracle or reference or ties or tie"],
+                       env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
