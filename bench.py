@@ -82,6 +82,10 @@ def parse(argv=None):
     ap.add_argument("--no-graph", action="store_true",
                     help="maskrcnn_train: launch every op eagerly in the timed region (default: the two sync-free halves "
                          "of the step are captured once in HIP graphs and replayed)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="maskrcnn_train: issue the independent branches of the step (proposal path | anchor labelling; "
+                         "box pooling | mask pooling | mask targets + loss | proposal labelling) on ONE stream instead "
+                         "of forking them onto side streams (detectron2_amd/streams.py)")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="test hook: launcher + process group + gradient all-reduce + timing reduction only, no "
                          "hot-path op (runs without a GPU with --backend gloo); the JSON line says so")
@@ -181,6 +185,7 @@ class Workload:
         n_img = len(image_ids)
         gens = [image_generator(seed, i) for i in image_ids]
         self.dev, self.n_img, self.image_ids, self.dtype, self.layout = dev, n_img, list(image_ids), dtype, layout
+        self.overlap = True  # independent branches of the step on separate HIP streams (--no-overlap: one stream)
         self.feats = []
         for (h, w) in FEAT_HW:
             f = torch.stack([torch.rand(C, h, w, generator=g) * 2 - 1 for g in gens]).to(dtype).to(dev)
@@ -306,9 +311,24 @@ def read_kernel_times(names):
 
 
 # ------------------------------------------------------------------------------------ maskrcnn_train
+def roi_branches(w):
+    """The forward of the ROI heads as four independent branches (fork_join): box pooling | mask pooling | mask
+    targets + mask loss | proposal labelling."""
+    from detectron2_amd.modeling import mask_rcnn_loss_from_targets
+    from detectron2_amd.structures import crop_and_resize_batch
+
+    def mask_loss():
+        tg = crop_and_resize_batch(w.gt_masks, [b.tensor for b in w.mask_lists], 28, w.fg_gt_index, w.crop_status)
+        return mask_rcnn_loss_from_targets(w.mask_logits, w.fg_classes, tg)
+
+    return (lambda: w.box_pooler(w.feats, w.box_lists), lambda: w.mask_pooler(w.feats, w.mask_lists), mask_loss,
+            lambda: [w.proposal_matcher.match_boxes(w.gt[i], w.props_with_gt[i]) for i in range(w.n_img)])
+
+
 def step(w, t=None, grads=None):
     from detectron2_amd.modeling import find_top_rpn_proposals_fused, mask_rcnn_loss_from_targets
     from detectron2_amd.modeling import poolers as _poolers
+    from detectron2_amd.streams import fork_join
     from detectron2_amd.structures import crop_and_resize_batch
 
     run = (lambda name, fn: t.run(name, fn)) if t is not None else (lambda name, fn: fn())
@@ -318,19 +338,28 @@ def step(w, t=None, grads=None):
     # RPN: the proposal path is enqueued first (selection + decode + NMS of both images), its one host sync is
     # deferred past the anchor labelling, which does not depend on the proposals (RPN.forward computes the two in either
     # order: rpn.py label_and_sample_anchors / predict_proposals): the device works through both while the host waits
-    rpn_done = run("rpn_proposals", lambda: find_top_rpn_proposals_fused(
-        w.anchor_levels, w.rpn_logits, w.rpn_deltas, w.image_sizes, 0.7, 2000, 1000, 0.0, True, defer=True))
-    for i in range(w.n_img):
-        run("match_anchors", lambda: w.anchor_matcher.match_boxes(w.gt[i], w.anchors))
+    if t is None and w.overlap:  # independent branches on separate streams (detectron2_amd/streams.py)
+        rpn_done, _labels = fork_join(
+            lambda: find_top_rpn_proposals_fused(w.anchor_levels, w.rpn_logits, w.rpn_deltas, w.image_sizes, 0.7, 2000,
+                                                 1000, 0.0, True, defer=True),
+            lambda: [w.anchor_matcher.match_boxes(w.gt[i], w.anchors) for i in range(w.n_img)])
+    else:
+        rpn_done = run("rpn_proposals", lambda: find_top_rpn_proposals_fused(
+            w.anchor_levels, w.rpn_logits, w.rpn_deltas, w.image_sizes, 0.7, 2000, 1000, 0.0, True, defer=True))
+        for i in range(w.n_img):
+            run("match_anchors", lambda: w.anchor_matcher.match_boxes(w.gt[i], w.anchors))
     props = run("rpn_proposals_sync", rpn_done)
     # ROI heads: proposal labelling (the sampled lists themselves are fixed inputs: subsample_labels is out of scope)
-    for i in range(w.n_img):
-        run("match_proposals", lambda: w.proposal_matcher.match_boxes(w.gt[i], w.props_with_gt[i]))
-    yb = run("roi_align_box_fwd", lambda: w.box_pooler(w.feats, w.box_lists))
-    ym = run("roi_align_mask_fwd", lambda: w.mask_pooler(w.feats, w.mask_lists))
-    tg = run("mask_targets", lambda: crop_and_resize_batch(
-        w.gt_masks, [b.tensor for b in w.mask_lists], 28, w.fg_gt_index, w.crop_status))
-    loss, _stats = run("mask_loss_fwd", lambda: mask_rcnn_loss_from_targets(w.mask_logits, w.fg_classes, tg))
+    if t is None and w.overlap:
+        yb, ym, (loss, _stats), _lab = fork_join(*roi_branches(w))
+    else:
+        for i in range(w.n_img):
+            run("match_proposals", lambda: w.proposal_matcher.match_boxes(w.gt[i], w.props_with_gt[i]))
+        yb = run("roi_align_box_fwd", lambda: w.box_pooler(w.feats, w.box_lists))
+        ym = run("roi_align_mask_fwd", lambda: w.mask_pooler(w.feats, w.mask_lists))
+        tg = run("mask_targets", lambda: crop_and_resize_batch(
+            w.gt_masks, [b.tensor for b in w.mask_lists], 28, w.fg_gt_index, w.crop_status))
+        loss, _stats = run("mask_loss_fwd", lambda: mask_rcnn_loss_from_targets(w.mask_logits, w.fg_classes, tg))
     # N > 1: the ROI heads' weight gradients exist before the poolers' backward runs -> their bucket's all-reduce
     # overlaps it; the remaining buckets (RPN head, FPN, backbone) follow the feature gradients
     n_early = grads.ready_after("roi_heads.box_head") if grads is not None else 0
@@ -363,18 +392,25 @@ class GraphedStep:
 
         self.w, self.grads = w, grads
 
+        from detectron2_amd.streams import fork_join
+
         def part_a():
-            done = find_top_rpn_proposals_fused(w.anchor_levels, w.rpn_logits, w.rpn_deltas, w.image_sizes, 0.7, 2000,
-                                                1000, 0.0, True, defer=True)
-            labels = [w.anchor_matcher.match_boxes(w.gt[i], w.anchors) for i in range(w.n_img)]
+            rpn = lambda: find_top_rpn_proposals_fused(w.anchor_levels, w.rpn_logits, w.rpn_deltas, w.image_sizes, 0.7,
+                                                       2000, 1000, 0.0, True, defer=True)
+            lab = lambda: [w.anchor_matcher.match_boxes(w.gt[i], w.anchors) for i in range(w.n_img)]
+            done, labels = fork_join(rpn, lab) if w.overlap else (rpn(), lab())
             return done, labels
 
         def part_b():
-            lab = [w.proposal_matcher.match_boxes(w.gt[i], w.props_with_gt[i]) for i in range(w.n_img)]
-            yb = w.box_pooler(w.feats, w.box_lists)
-            ym = w.mask_pooler(w.feats, w.mask_lists)
-            tg = crop_and_resize_batch(w.gt_masks, [b.tensor for b in w.mask_lists], 28, w.fg_gt_index, w.crop_status)
-            loss, _ = mask_rcnn_loss_from_targets(w.mask_logits, w.fg_classes, tg)
+            if w.overlap:
+                yb, ym, (loss, _), lab = fork_join(*roi_branches(w))
+            else:
+                lab = [w.proposal_matcher.match_boxes(w.gt[i], w.props_with_gt[i]) for i in range(w.n_img)]
+                yb = w.box_pooler(w.feats, w.box_lists)
+                ym = w.mask_pooler(w.feats, w.mask_lists)
+                tg = crop_and_resize_batch(w.gt_masks, [b.tensor for b in w.mask_lists], 28, w.fg_gt_index,
+                                           w.crop_status)
+                loss, _ = mask_rcnn_loss_from_targets(w.mask_logits, w.fg_classes, tg)
             for f in w.feats:
                 f.grad = None
             w.mask_logits.grad = None
@@ -534,6 +570,7 @@ def bench_maskrcnn(args, ctx):
     dtype = {"bf16": torch.bfloat16, "fp32": torch.float32, "fp16": torch.float16}[args.dtype]
     # weak scaling: 2 images per GPU; rank r owns images [2r, 2r+1] of the global synthetic batch
     w = Workload(dev, dtype, args.layout, image_ids=global_image_ids(IMAGES_PER_GPU, rank, world))
+    w.overlap = not args.no_overlap
     grads = make_gradient_buckets(args, dev, dist, world)
     for _ in range(args.warmup):
         step(w, None, grads)
@@ -621,6 +658,9 @@ def bench_maskrcnn(args, ctx):
                    "layout": args.layout, "global_batch": world * w.n_img, "ops_per_step": counts,
                    "launch": ("2 HIP graphs per step (RPN half | ROI-head half + backward), one host sync between them"
                               if use_graph else "eager: every op launched from Python"),
+                   "streams": ("independent branches forked onto side streams (proposal path | anchor labelling; box "
+                               "pooling | mask pooling | mask targets + loss | proposal labelling), joined before the "
+                               "backward" if w.overlap else "one stream"),
                    "parallelism": f"dp{world}: images sharded, no data-path collective; "
                                   + (grads_description(grads) if grads is not None else
                                      "no gradient all-reduce (world size 1, like DDP)")},

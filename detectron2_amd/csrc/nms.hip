@@ -361,6 +361,10 @@ __device__ __forceinline__ void nms_runs_rank_body(const float* __restrict__ box
   __shared__ uint32_t samp[RUNS_SAMPLES];
   __shared__ int s_sbase[NMS_MAX_RUNS + 1], s_cnt[NMS_MAX_RUNS], s_off[NMS_MAX_RUNS + 1];
   if (blockIdx.x * blockDim.x >= n) return;  // uniform (batched launch: the grid is sized for the largest image)
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  // this entry's own score and in-run position: requested first, they arrive while the samples are staged
+  const float my_score = scores[min(i, n - 1)];
+  const int mine = vr[min(i, n - 1)];
   int shift = 0;
   while ((n >> shift) + NMS_MAX_RUNS > RUNS_SAMPLES) shift++;  // uniform
   // (the run table goes through LDS: indexing the kernel-argument struct with a per-lane run number makes the
@@ -379,7 +383,7 @@ __device__ __forceinline__ void nms_runs_rank_body(const float* __restrict__ box
   }
   __syncthreads();
   {  // sample e = sample j of run q; 8 independent loads in flight per thread (a plain loop issues one at a time)
-    constexpr int SU = 8;
+    constexpr int SU = 12;  // (12,288 samples / 1,024 threads: one batch)
     const int total = s_sbase[NMS_MAX_RUNS];
     for (int e0 = threadIdx.x; e0 < total; e0 += blockDim.x * SU) {
       uint32_t val[SU];
@@ -398,18 +402,20 @@ __device__ __forceinline__ void nms_runs_rank_body(const float* __restrict__ box
     }
   }
   __syncthreads();
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   int r = 0;
 #pragma unroll
   for (int q = 1; q < NMS_MAX_RUNS; q++)
     if (i >= s_off[q] && q < R.n_runs) r = q;
-  const uint32_t key = run_key(scores[i]);
-  const int mine = vr[i];
+  const uint32_t key = run_key(my_score);
   int rank;
   if (key != RUN_KEY_PARKED) {
-    // in order inside the run?  (equal keys are fine: array order is the tie order)
-    if (mine > 0 && cs[s_off[r] + mine - 1] > key) atomicOr(&counters[1], 4);
+    // in order inside the run?  (equal keys are fine: array order is the tie order; with shift == 0 every key is
+    // a sample: the predecessor comes from LDS)
+    if (mine > 0) {
+      const uint32_t prev = shift == 0 ? samp[s_sbase[r] + mine - 1] : cs[s_off[r] + mine - 1];
+      if (prev > key) atomicOr(&counters[1], 4);
+    }
     rank = mine;
     // per other run: the number of its live keys that precede mine = first position whose key is > bound, where
     // earlier runs win ties (lower array index: keys <= key count) and later runs lose them (keys < key count).

@@ -1754,7 +1754,10 @@ static long pool_ntiles(const d2amd_pooler_params* p) {
 template <typename T>
 static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_output, const float* rois,
                               void* const* grad_inputs, int K, void* workspace, size_t workspace_bytes,
-                              hipStream_t s, bool accumulate) {
+                              hipStream_t s, bool accumulate, int phase = 0) {
+  // phase 0: everything; 1: only the binning (records, per-tile ROI lists, work queues -- depends on the ROIs alone
+  // in accumulate mode, so a caller can run it beside other work); 2: only the gather, after a phase-1 call with the
+  // same arguments and workspace
   constexpr int VEC = V16<T>::N;
   const bool vec = (p->C % VEC == 0) && all_aligned16((const void* const*)grad_inputs, p->num_levels, grad_output);
   const int cg = vec ? p->C / VEC : p->C;
@@ -1815,7 +1818,7 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
     Q.zero_fill = vec ? 1 : 0;
   }
   const int qints = queues ? QCTR + 8 * (Q.cap[0] + Q.cap[1]) : 0;
-  if (K > 0) {
+  if (K > 0 && phase != 2) {
     hipLaunchKernelGGL(roi_records_kernel, dim3(cdiv(K, 256)), dim3(256), 0, s, L0, rois, rec, Q.mem, qints);
     D2_LAUNCH_OK();
     if (lists) {
@@ -1824,6 +1827,7 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
       D2_LAUNCH_OK();
     }
   }
+  if (phase == 1) return D2AMD_OK;
   // profiling switches: D2AMD_BWD_CFG = "<fine GROUPS><fine RS><coarse GROUPS><coarse RS>", e.g. 1122
   static const int cfg = getenv("D2AMD_BWD_CFG") ? atoi(getenv("D2AMD_BWD_CFG")) : 1222;
   const int fg = cfg / 1000 % 10, fr = cfg / 100 % 10, cgp = cfg / 10 % 10, cr = cfg % 10;
@@ -2094,7 +2098,7 @@ extern "C" size_t d2amd_roi_pooler_backward_workspace_bytes(const d2amd_pooler_p
 
 static int pooler_backward_entry(const d2amd_pooler_params* p, const void* grad_output, const float* rois,
                                  void* const* grad_inputs, int K, void* workspace, size_t workspace_bytes,
-                                 void* stream, bool accumulate) {
+                                 void* stream, bool accumulate, int phase = 0) {
   int rc = check_pooler(p, "roi_pooler_backward");
   if (rc) return rc;
   D2_CHECK_ARG(K >= 0, "roi_pooler_backward: bad K");
@@ -2107,7 +2111,7 @@ static int pooler_backward_entry(const d2amd_pooler_params* p, const void* grad_
   if ((long)p->N * p->C == 0) return D2AMD_OK;
   return D2_DISPATCH_DTYPE(p->dtype, [&]() -> int {
     return pool_bwd_nhwc_impl<scalar_t>(p, grad_output, rois, grad_inputs, K, workspace, workspace_bytes,
-                                        (hipStream_t)stream, accumulate);
+                                        (hipStream_t)stream, accumulate, phase);
   });
 }
 
@@ -2121,4 +2125,12 @@ extern "C" int d2amd_roi_pooler_backward_accumulate(const d2amd_pooler_params* p
                                                     const float* rois, void* const* grad_inputs, int K,
                                                     void* workspace, size_t workspace_bytes, void* stream) {
   return pooler_backward_entry(p, grad_output, rois, grad_inputs, K, workspace, workspace_bytes, stream, true);
+}
+
+extern "C" int d2amd_roi_pooler_backward_accumulate_phase(const d2amd_pooler_params* p, const void* grad_output,
+                                                          const float* rois, void* const* grad_inputs, int K,
+                                                          void* workspace, size_t workspace_bytes, int phase,
+                                                          void* stream) {
+  D2_CHECK_ARG(phase == 1 || phase == 2, "roi_pooler_backward_accumulate_phase: phase must be 1 (bin) or 2 (gather)");
+  return pooler_backward_entry(p, grad_output, rois, grad_inputs, K, workspace, workspace_bytes, stream, true, phase);
 }

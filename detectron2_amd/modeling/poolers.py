@@ -252,6 +252,22 @@ class _FusedROIPool(Function):
         ctx.save_for_backward(rois)
         ctx.cfg, ctx.hw, ctx.nc, ctx.layout = cfg, hw, (n, c), layout
         ctx.needs = [f.requires_grad for f in feats]
+        # A chained, non-head pooler's backward ADDS to the head's gradient: its binning (per-ROI records, per-tile
+        # ROI lists, work queues) depends on the ROIs alone, so it is done HERE, beside the forward kernels (on
+        # whatever stream the forward runs), instead of between the two tile gathers of the backward (15 us of small
+        # kernels on the critical path).  Unused if the backward never comes or this work ends up writing first.
+        ctx.binned = None
+        if chain is not None and not head and layout == _C.NHWC and k > 0 and any(ctx.needs):
+            L = _C.lib()
+            ws_bytes = L.d2amd_roi_pooler_backward_workspace_bytes(ctypes.byref(p), k)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=xs[0].device)
+            with _C.on_device(xs[0].device):  # (pointers: only their alignment class matters to the binning)
+                rc = L.d2amd_roi_pooler_backward_accumulate_phase(ctypes.byref(p), _C.ptr(out), _C.ptr(rois),
+                                                                  _ptr_array(xs), k, _C.ptr(ws), ws_bytes, 1, _C.stream())
+            if rc == 0:
+                ctx.binned = (ws, ws_bytes)
+            elif rc != _C.EUNSUPPORTED:
+                _C.check(rc)
         ctx.chain, ctx.head, ctx.upstream, ctx.dtype = chain, head, upstream, xs[0].dtype
         ctx.set_materialize_grads(False)  # unused outputs (the aliases of the last pooler of a chain) arrive as None
         ctx.nchw_caller = _layout_of(feats[0]) == _C.NCHW  # gradients go back in the caller's layout
@@ -280,7 +296,7 @@ class _FusedROIPool(Function):
             _forget_aliases(ctx.chain)
             works = _DEFERRED.pop(ctx.chain, [])
         if grad_output is not None:
-            works.insert(0, (_to_nhwc(grad_output.detach()), rois, cfg))  # own work first: the plain write
+            works.insert(0, (_to_nhwc(grad_output.detach()), rois, cfg, ctx.binned))  # own work first: the plain write
         real = [h for h in held if h is not None and not _is_placeholder(h)]  # a foreign consumer of the aliases
         if not ctx.head:
             if works:
@@ -300,21 +316,34 @@ class _FusedROIPool(Function):
                                                                         memory_format=torch.channels_last))
                          for g, s in zip(grads, hw)]
         L = _C.lib()
-        for g, r, wcfg in works:
-            k = r.shape[0]
-            p = _params(wcfg, (n, c), hw, _C.dtype_code(g), _C.NHWC)
-            # per-ROI records + per-tile ROI lists (one wave per 8x8 tile bins the ROIs once per call)
-            ws_bytes = L.d2amd_roi_pooler_backward_workspace_bytes(ctypes.byref(p), k)
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=g.device)
-            with _C.on_device(g.device):
-                if grads is None:
-                    grads = [torch.empty((n, c, h, w), dtype=g.dtype, device=g.device, memory_format=torch.channels_last)
-                             for (h, w) in hw]
+        dev = rois.device
+        plain_first = grads is None and bool(works)  # the first work writes every tile; everything else adds
+        if plain_first:
+            g0 = works[0][0]
+            grads = [torch.empty((n, c, h, w), dtype=g0.dtype, device=dev, memory_format=torch.channels_last)
+                     for (h, w) in hw]
+        with _C.on_device(dev):
+            for j, (g, r, wcfg, binned) in enumerate(works):
+                k = r.shape[0]
+                p = _params(wcfg, (n, c), hw, _C.dtype_code(g), _C.NHWC)
+                if plain_first and j == 0:
+                    # per-ROI records + per-tile ROI lists (one wave per 8x8 tile bins the ROIs once per call)
+                    ws_bytes = L.d2amd_roi_pooler_backward_workspace_bytes(ctypes.byref(p), k)
+                    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
                     _C.check(L.d2amd_roi_pooler_backward(ctypes.byref(p), _C.ptr(g), _C.ptr(r), _ptr_array(grads), k,
                                                          _C.ptr(ws), ws_bytes, _C.stream()))
                     continue
-                rc = L.d2amd_roi_pooler_backward_accumulate(ctypes.byref(p), _C.ptr(g), _C.ptr(r), _ptr_array(grads), k,
-                                                            _C.ptr(ws), ws_bytes, _C.stream())
+                if binned is not None:  # binned beside its forward (maybe on another stream): gather only
+                    ws, ws_bytes = binned
+                    ws.record_stream(torch.cuda.current_stream(dev))
+                    rc = L.d2amd_roi_pooler_backward_accumulate_phase(ctypes.byref(p), _C.ptr(g), _C.ptr(r),
+                                                                      _ptr_array(grads), k, _C.ptr(ws), ws_bytes, 2,
+                                                                      _C.stream())
+                else:
+                    ws_bytes = L.d2amd_roi_pooler_backward_workspace_bytes(ctypes.byref(p), k)
+                    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+                    rc = L.d2amd_roi_pooler_backward_accumulate(ctypes.byref(p), _C.ptr(g), _C.ptr(r),
+                                                                _ptr_array(grads), k, _C.ptr(ws), ws_bytes, _C.stream())
                 if rc == _C.EUNSUPPORTED:  # configuration outside the staged tile gather: fresh buffers + a sum
                     extra = [torch.empty_like(t) for t in grads]
                     _C.check(L.d2amd_roi_pooler_backward(ctypes.byref(p), _C.ptr(g), _C.ptr(r), _ptr_array(extra), k,

@@ -1,0 +1,61 @@
+"""Fork / join of independent op sequences on HIP streams.
+
+The detection hot path has branches that do not depend on each other inside one iteration -- the RPN's proposal
+selection + NMS and its anchor labelling (proposal_generator/rpn.py:431-480 computes the two from the same head
+outputs, in either order); the box head's and the mask head's pooling and the mask targets
+(roi_heads/roi_heads.py:700-760).  The reference issues them one after the other on one stream.  Several of these
+kernels cannot fill 256 CUs on their own (the NMS reduction is 10 workgroups, a sort 10, a compaction 2): run on
+separate streams the device overlaps them with their neighbours -- also inside a captured HIP graph, where the fork /
+join events become graph edges and cost nothing at replay.
+
+    box, mask = fork_join(lambda: box_pooler(feats, boxes), lambda: mask_pooler(feats, fg_boxes))
+
+Everything a branch allocates is allocated on ITS stream: the results may be used on the current stream after the join
+(it waits for every branch), and they must be kept alive by the caller until that work is enqueued (the usual rule of
+`Tensor.record_stream`; the results are recorded for the current stream here)."""
+from typing import Callable, List
+
+import torch
+
+_POOL = {}
+
+
+def _streams(device: torch.device, n: int) -> List["torch.cuda.Stream"]:
+    pool = _POOL.setdefault(device.index, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[:n]
+
+
+def _record(obj, stream):
+    if isinstance(obj, torch.Tensor):
+        if obj.is_cuda:
+            obj.record_stream(stream)
+    elif isinstance(obj, (list, tuple)):
+        for o in obj:
+            _record(o, stream)
+    elif hasattr(obj, "tensor") and isinstance(obj.tensor, torch.Tensor):
+        _record(obj.tensor, stream)
+
+
+def fork_join(*branches: Callable[[], object], device: torch.device = None) -> list:
+    """Run branch 0 on the current stream and every other branch on its own side stream, all starting from the
+    current point of the current stream; return their results once everything has been ENQUEUED (no host sync): work
+    enqueued on the current stream afterwards sees all of it."""
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    cur = torch.cuda.current_stream(device)
+    if len(branches) <= 1:
+        return [b() for b in branches]
+    side = _streams(device, len(branches) - 1)
+    for st in side:
+        st.wait_stream(cur)  # fork: the branch sees everything enqueued so far
+    out = [None] * len(branches)
+    for i, st in enumerate(side, start=1):
+        with torch.cuda.stream(st):
+            out[i] = branches[i]()
+    out[0] = branches[0]()
+    for i, st in enumerate(side, start=1):
+        cur.wait_stream(st)  # join
+        _record(out[i], cur)
+    return out
