@@ -7,6 +7,8 @@ for wl in maskrcnn_train retinanet_100k dcn_r50; do
   timeout 900 python bench.py --workload $wl > $O/bench_$wl.json 2> $O/bench_$wl.err; echo "rc=$? $wl"
 done
 timeout 600 python bench.py --layout nchw --no-cpu-baseline > $O/bench_maskrcnn_train_nchw.json 2> $O/bench_nchw.err
+timeout 600 python bench.py --no-overlap --no-cpu-baseline > $O/bench_maskrcnn_train_one_stream.json 2> $O/bench_one_stream.err
+timeout 600 python bench.py --no-graph --no-cpu-baseline > $O/bench_maskrcnn_train_eager.json 2> $O/bench_eager.err
 export TMPDIR=/tmp
 for wl in maskrcnn_train retinanet_100k dcn_r50; do
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_$wl -o $wl -- python $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 10 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/prof_$wl.log 2>&1)
@@ -15,7 +17,7 @@ for wl in maskrcnn_train retinanet_100k dcn_r50; do
 done
 python - <<PY
 import json
-for wl in ("maskrcnn_train", "retinanet_100k", "dcn_r50", "maskrcnn_train_nchw"):
+for wl in ("maskrcnn_train", "retinanet_100k", "dcn_r50", "maskrcnn_train_nchw", "maskrcnn_train_one_stream", "maskrcnn_train_eager"):
     try:
         d = json.load(open("$O/bench_%s.json" % wl))
         r = d.get("roofline", {})
