@@ -1360,6 +1360,52 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
     return nb;
   };
 
+  // PAIRED items (PB == 8, the box head): a typical window is 3 x 3 ... 4 x 4 bins, i.e. ONE of the item's two 16-bin
+  // k steps -- and the cost of an item is its fixed part (barrier, bookkeeping, weight image, staging: ~2,700 cycles
+  // for 4 MFMAs).  Two consecutive list entries whose whole windows have <= 16 bins therefore share an item: entry A
+  // in k step 0 (bins 0-15: staged by r0, weight image by waves 0-3), entry B in k step 1 (r1, waves 4-7).
+  auto bins_of = [&](const Window& w, int c) __attribute__((always_inline)) {
+    return min(w.rpc, w.nph - c * w.rpc) * w.npw;  // 0 for an empty window
+  };
+  auto issue_loads16 = [&](int li, const Window& w, int nb, raw16& r) __attribute__((always_inline)) {
+    if (nb > 0) {  // uniform.  chunk 0 of a one-chunk window: bin sb of its nb <= 16 bins
+      const T* gk = gout + (long)S.list[li] * PH * PW * C + cofs;
+      const int j0 = min(sb, nb - 1);
+      const int q0 = (int)((j0 + 0.5f) * w.rnpw);  // j0 / npw
+      const unsigned b0 = __umul24(w.ph_lo + q0, PW) + w.pw_lo + j0 - __umul24(q0, w.npw);
+      r = *reinterpret_cast<const raw16*>(gk + __umul24(b0, C));
+    }
+  };
+  // half h (k step h) of the weight image of a paired item: waves 4 h .. 4 h + 3, always written (zeros past nb:
+  // the k step is contracted whenever the OTHER half has bins)
+  auto build_wimg_half = [&](int buf, int h, int slot, const Window& w, int nb) __attribute__((always_inline)) {
+    const int px = lane, kq = (tid >> 6) * 4, r = px >> 3, cx = px & 7;
+    if ((kq >> 4) != h) return;  // uniform per wave
+    const int kl = kq & 15;
+    int q = (int)((kl + 0.5f) * w.rnpw);
+    int pi = kl - (int)__umul24(q, w.npw);
+    const float* wyp = &S.WyT[((slot << lg) + w.ph_lo) * TILE + r];
+    const float* wxp = &S.Wx[((slot << 3) + cx) * PB + w.pw_lo];
+    uint16_t hi[4], lo[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const float wv = kl + j < nb ? wyp[q * TILE] * wxp[pi] : 0.f;
+      if (++pi == w.npw) { pi = 0; q++; }
+      if constexpr (sizeof(T) == 2 && __is_same(T, bf16_t)) {
+        const __bf16 hh = (__bf16)wv;
+        const __bf16 ll = (__bf16)(wv - (float)hh);
+        hi[j] = __builtin_bit_cast(uint16_t, hh);
+        lo[j] = __builtin_bit_cast(uint16_t, ll);
+      } else {
+        const _Float16 hh = (_Float16)wv;
+        const _Float16 ll = (_Float16)(wv - (float)hh);
+        hi[j] = __builtin_bit_cast(uint16_t, hh);
+        lo[j] = __builtin_bit_cast(uint16_t, ll);
+      }
+    }
+    *reinterpret_cast<uint2*>(&M.Whi[buf][px][kq]) = uint2{(uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16)};
+    *reinterpret_cast<uint2*>(&M.Wlo[buf][px][kq]) = uint2{(uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16)};
+  };
   // weight image of item (entry slot, window w, chunk c) -> buffer buf: thread = (pixel, 4 consecutive bins).
   // hi = w rounded to the I/O dtype, lo = (w - hi) rounded (hardware conversions: v_cvt_pk_bf16_f32 / v_cvt_f16_f32)
   auto build_wimg = [&](int buf, int slot, const Window& w, int c) __attribute__((always_inline)) {
@@ -1474,14 +1520,33 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
     compute_round(EPR);
     __syncthreads();
     raw16 r0 = raw16{0u, 0u, 0u, 0u}, r1 = raw16{0u, 0u, 0u, 0u};
-    Window wc = window_of(0);
-    int nb_cur;
+    const raw16 z16 = raw16{0u, 0u, 0u, 0u};
+    // pairing needs the weights of entry e + 2 to be complete one barrier before entry e is contracted: true for
+    // EPR = 4 (PB == 8), not for the larger poolers (whose windows rarely have <= 16 bins anyway)
+    const bool pairing = PB == 8 && !(L.ablate & 8);
+    // the item being prepared / contracted: entry e chunk c with window wc (nb_cur bins), and -- paired -- entry e + 1
+    Window wc = window_of(0), wp = wc;
+    int nb_cur, nb_pair = -1;  // nb_pair >= 0: the item is a pair, entry e + 1 has nb_pair bins
     {
-      const int nb = issue_loads(0, wc, 0, r0, r1);
-      build_wimg(0, 0, wc, 0);
-      const raw16 z = raw16{0u, 0u, 0u, 0u};
-      S.D[0][sb][lp] = sb < nb ? r0 : z;            // rows past nb: zeros (their weights are 0, stale bits might be NaN)
-      if (nb > 16) S.D[0][sb + 16][lp] = sb + 16 < nb ? r1 : z;  // uniform; the second k step is not read otherwise
+      const int nb = bins_of(wc, 0);
+      if (pairing && wc.nitems == 1 && nb <= 16 && 1 < nlist) {
+        wp = window_of(1 % NSLOT);
+        const int nbp = bins_of(wp, 0);
+        if (wp.nitems == 1 && nbp <= 16) nb_pair = nbp;
+      }
+      if (nb_pair >= 0) {
+        issue_loads16(0, wc, nb, r0);
+        issue_loads16(1, wp, nb_pair, r1);
+        build_wimg_half(0, 0, 0, wc, nb);
+        build_wimg_half(0, 1, 1 % NSLOT, wp, nb_pair);
+        S.D[0][sb][lp] = sb < nb ? r0 : z16;
+        S.D[0][sb + 16][lp] = sb < nb_pair ? r1 : z16;
+      } else {
+        (void)issue_loads(0, wc, 0, r0, r1);
+        build_wimg(0, 0, wc, 0);
+        S.D[0][sb][lp] = sb < nb ? r0 : z16;            // rows past nb: zeros (their weights are 0, stale bits might be NaN)
+        if (nb > 16) S.D[0][sb + 16][lp] = sb + 16 < nb ? r1 : z16;  // uniform; the second k step is not read otherwise
+      }
       nb_cur = nb;
     }
     int e = 0, c = 0, db = 0;
@@ -1489,31 +1554,55 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
       STAMP();
       __syncthreads();  // D[db] and the weights of e (and e + 1) are complete; everyone is done with D[db ^ 1]
       STAMP();
-      // next item: the next chunk of this entry's window, or the first chunk of the next entry
+      // next item: the next chunk of this entry's window, or the first chunk of the entry after this item's last one
+      const bool paired = nb_pair >= 0;
       int e2 = e, c2 = c + 1;
-      Window wn = wc;
-      if (c2 >= wc.nitems) { e2 = e + 1; c2 = 0; }
+      Window wn = wc, wn2 = wc;
+      if (paired) { e2 = e + 2; c2 = 0; }
+      else if (c2 >= wc.nitems) { e2 = e + 1; c2 = 0; }
       const bool have_next = e2 < nlist;
-      int nb2 = 0;
+      int nb2 = 0, nb2p = -1;
       if (have_next) {
         if (e2 != e) wn = window_of(e2 % NSLOT);
-        nb2 = issue_loads(e2, wn, c2, r0, r1);
+        nb2 = bins_of(wn, c2);
+        if (pairing && c2 == 0 && wn.nitems == 1 && nb2 <= 16 && e2 + 1 < nlist) {
+          wn2 = window_of((e2 + 1) % NSLOT);
+          const int nbp = bins_of(wn2, 0);
+          if (wn2.nitems == 1 && nbp <= 16) nb2p = nbp;
+        }
+        if (nb2p >= 0) {
+          issue_loads16(e2, wn, nb2, r0);
+          issue_loads16(e2 + 1, wn2, nb2p, r1);
+        } else {
+          (void)issue_loads(e2, wn, c2, r0, r1);
+        }
       }
       STAMP();
-      if (c == 0 && (e & (EPR - 1)) == 0) compute_round(e + 2 * EPR);  // overlaps the loads
+      // axis weights two rounds ahead, started by the first entry of a round (overlaps the loads)
+      if (c == 0 && (e & (EPR - 1)) == 0) compute_round(e + 2 * EPR);
+      else if (paired && ((e + 1) & (EPR - 1)) == 0) compute_round(e + 1 + 2 * EPR);
       STAMP();
-      // contraction of item (e, c) on the matrix cores, then the weight image of the next item
-      contract(db, nb_cur);
+      // contraction of the item on the matrix cores, then the weight image of the next item
+      contract(db, paired ? (nb_pair > 0 ? 16 + nb_pair : nb_cur) : nb_cur);
       STAMP();
-      if (have_next) build_wimg(db ^ 1, e2 % NSLOT, wn, c2);
+      if (have_next) {
+        if (nb2p >= 0) {
+          build_wimg_half(db ^ 1, 0, e2 % NSLOT, wn, nb2);
+          build_wimg_half(db ^ 1, 1, (e2 + 1) % NSLOT, wn2, nb2p);
+        } else {
+          build_wimg(db ^ 1, e2 % NSLOT, wn, c2);
+        }
+      }
       STAMP();
       if (!have_next) break;
-      {
-        const raw16 z = raw16{0u, 0u, 0u, 0u};
-        S.D[db ^ 1][sb][lp] = sb < nb2 ? r0 : z;
-        if (nb2 > 16) S.D[db ^ 1][sb + 16][lp] = sb + 16 < nb2 ? r1 : z;
+      if (nb2p >= 0) {
+        S.D[db ^ 1][sb][lp] = sb < nb2 ? r0 : z16;
+        S.D[db ^ 1][sb + 16][lp] = sb < nb2p ? r1 : z16;
+      } else {
+        S.D[db ^ 1][sb][lp] = sb < nb2 ? r0 : z16;
+        if (nb2 > 16) S.D[db ^ 1][sb + 16][lp] = sb + 16 < nb2 ? r1 : z16;
       }
-      e = e2; c = c2; wc = wn; db ^= 1; nb_cur = nb2;
+      e = e2; c = c2; wc = wn; wp = wn2; db ^= 1; nb_cur = nb2; nb_pair = nb2p;
     }
   }
 #ifdef D2AMD_PROFILE
