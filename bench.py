@@ -83,9 +83,9 @@ def parse(argv=None):
                     help="maskrcnn_train: launch every op eagerly in the timed region (default: the two sync-free halves "
                          "of the step are captured once in HIP graphs and replayed)")
     ap.add_argument("--no-overlap", action="store_true",
-                    help="maskrcnn_train: issue the independent branches of the step (proposal path | anchor labelling; "
-                         "box pooling | mask pooling | mask targets + loss | proposal labelling) on ONE stream instead "
-                         "of forking them onto side streams (detectron2_amd/streams.py)")
+                    help="maskrcnn_train: issue the independent branches of the step (anchor labelling | proposal path; "
+                         "both poolers | proposal labelling + mask targets + loss) on ONE stream instead of forking "
+                         "them onto side streams (detectron2_amd/streams.py)")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="test hook: launcher + process group + gradient all-reduce + timing reduction only, no "
                          "hot-path op (runs without a GPU with --backend gloo); the JSON line says so")
@@ -312,17 +312,33 @@ def read_kernel_times(names):
 
 # ------------------------------------------------------------------------------------ maskrcnn_train
 def roi_branches(w):
-    """The forward of the ROI heads as four independent branches (fork_join): box pooling | mask pooling | mask
-    targets + mask loss | proposal labelling."""
+    """The forward of the ROI heads as two branches (fork_join): both poolers | proposal labelling + mask targets +
+    mask loss.  (Measured layouts, captured graph B incl. the backward, scripts/graph_split2.py: one stream 304-314 us,
+    four branches 322-333 -- the poolers and the target rasteriser each fill the chip and only slow each other down --
+    this one 278-280.)  -> ((box features, mask features), (loss, stats))"""
     from detectron2_amd.modeling import mask_rcnn_loss_from_targets
     from detectron2_amd.structures import crop_and_resize_batch
 
-    def mask_loss():
+    def poolers():
+        return w.box_pooler(w.feats, w.box_lists), w.mask_pooler(w.feats, w.mask_lists)
+
+    def labels_and_loss():
+        _lab = [w.proposal_matcher.match_boxes(w.gt[i], w.props_with_gt[i]) for i in range(w.n_img)]
         tg = crop_and_resize_batch(w.gt_masks, [b.tensor for b in w.mask_lists], 28, w.fg_gt_index, w.crop_status)
         return mask_rcnn_loss_from_targets(w.mask_logits, w.fg_classes, tg)
 
-    return (lambda: w.box_pooler(w.feats, w.box_lists), lambda: w.mask_pooler(w.feats, w.mask_lists), mask_loss,
-            lambda: [w.proposal_matcher.match_boxes(w.gt[i], w.props_with_gt[i]) for i in range(w.n_img)])
+    return poolers, labels_and_loss
+
+
+def rpn_branches(w):
+    """Anchor labelling | proposal path.  The labelling goes FIRST (= on the current stream): 180 us for the captured
+    half against 203 us the other way round and 207-210 us on one stream (scripts/graph_split2.py; the proposal path
+    alone is 156 us of 10-workgroup kernels, the labelling 60 us)."""
+    from detectron2_amd.modeling import find_top_rpn_proposals_fused
+
+    return (lambda: [w.anchor_matcher.match_boxes(w.gt[i], w.anchors) for i in range(w.n_img)],
+            lambda: find_top_rpn_proposals_fused(w.anchor_levels, w.rpn_logits, w.rpn_deltas, w.image_sizes, 0.7, 2000,
+                                                 1000, 0.0, True, defer=True))
 
 
 def step(w, t=None, grads=None):
@@ -339,10 +355,7 @@ def step(w, t=None, grads=None):
     # deferred past the anchor labelling, which does not depend on the proposals (RPN.forward computes the two in either
     # order: rpn.py label_and_sample_anchors / predict_proposals): the device works through both while the host waits
     if t is None and w.overlap:  # independent branches on separate streams (detectron2_amd/streams.py)
-        rpn_done, _labels = fork_join(
-            lambda: find_top_rpn_proposals_fused(w.anchor_levels, w.rpn_logits, w.rpn_deltas, w.image_sizes, 0.7, 2000,
-                                                 1000, 0.0, True, defer=True),
-            lambda: [w.anchor_matcher.match_boxes(w.gt[i], w.anchors) for i in range(w.n_img)])
+        _labels, rpn_done = fork_join(*rpn_branches(w))
     else:
         rpn_done = run("rpn_proposals", lambda: find_top_rpn_proposals_fused(
             w.anchor_levels, w.rpn_logits, w.rpn_deltas, w.image_sizes, 0.7, 2000, 1000, 0.0, True, defer=True))
@@ -351,7 +364,7 @@ def step(w, t=None, grads=None):
     props = run("rpn_proposals_sync", rpn_done)
     # ROI heads: proposal labelling (the sampled lists themselves are fixed inputs: subsample_labels is out of scope)
     if t is None and w.overlap:
-        yb, ym, (loss, _stats), _lab = fork_join(*roi_branches(w))
+        (yb, ym), (loss, _stats) = fork_join(*roi_branches(w))
     else:
         for i in range(w.n_img):
             run("match_proposals", lambda: w.proposal_matcher.match_boxes(w.gt[i], w.props_with_gt[i]))
@@ -395,15 +408,17 @@ class GraphedStep:
         from detectron2_amd.streams import fork_join
 
         def part_a():
-            rpn = lambda: find_top_rpn_proposals_fused(w.anchor_levels, w.rpn_logits, w.rpn_deltas, w.image_sizes, 0.7,
-                                                       2000, 1000, 0.0, True, defer=True)
-            lab = lambda: [w.anchor_matcher.match_boxes(w.gt[i], w.anchors) for i in range(w.n_img)]
-            done, labels = fork_join(rpn, lab) if w.overlap else (rpn(), lab())
+            lab, rpn = rpn_branches(w)
+            if w.overlap:
+                labels, done = fork_join(lab, rpn)
+            else:
+                done, labels = rpn(), lab()
             return done, labels
 
         def part_b():
+            lab = None
             if w.overlap:
-                yb, ym, (loss, _), lab = fork_join(*roi_branches(w))
+                (yb, ym), (loss, _) = fork_join(*roi_branches(w))
             else:
                 lab = [w.proposal_matcher.match_boxes(w.gt[i], w.props_with_gt[i]) for i in range(w.n_img)]
                 yb = w.box_pooler(w.feats, w.box_lists)
@@ -658,9 +673,9 @@ def bench_maskrcnn(args, ctx):
                    "layout": args.layout, "global_batch": world * w.n_img, "ops_per_step": counts,
                    "launch": ("2 HIP graphs per step (RPN half | ROI-head half + backward), one host sync between them"
                               if use_graph else "eager: every op launched from Python"),
-                   "streams": ("independent branches forked onto side streams (proposal path | anchor labelling; box "
-                               "pooling | mask pooling | mask targets + loss | proposal labelling), joined before the "
-                               "backward" if w.overlap else "one stream"),
+                   "streams": ("independent branches forked onto side streams (anchor labelling | proposal path; both "
+                               "poolers | proposal labelling + mask targets + loss), joined before the backward"
+                               if w.overlap else "one stream"),
                    "parallelism": f"dp{world}: images sharded, no data-path collective; "
                                   + (grads_description(grads) if grads is not None else
                                      "no gradient all-reduce (world size 1, like DDP)")},

@@ -6,9 +6,15 @@ outputs, in either order); the box head's and the mask head's pooling and the ma
 (roi_heads/roi_heads.py:700-760).  The reference issues them one after the other on one stream.  Several of these
 kernels cannot fill 256 CUs on their own (the NMS reduction is 10 workgroups, a sort 10, a compaction 2): run on
 separate streams the device overlaps them with their neighbours -- also inside a captured HIP graph, where the fork /
-join events become graph edges and cost nothing at replay.
+join events become graph edges and cost nothing at replay (scripts/probes/probe_graph_branches.hip: two 100 us
+kernels of 8 or 256 workgroups take 132 us as forked graph branches, 208 us on one stream).
 
-    box, mask = fork_join(lambda: box_pooler(feats, boxes), lambda: mask_pooler(feats, fg_boxes))
+    labels, proposals_done = fork_join(lambda: [matcher.match_boxes(gt_i, anchors) for gt_i in gt_boxes],
+                                       lambda: find_top_rpn_proposals_fused(..., defer=True))
+
+What pays is putting SMALL-grid chains beside something else; kernels that fill the chip on their own (the two
+poolers, the mask-target rasteriser) only slow each other down when forked (bench.py: roi_branches / rpn_branches hold
+the measured layouts).  Which branch stays on the current stream matters too (branch 0 does).
 
 Everything a branch allocates is allocated on ITS stream: the results may be used on the current stream after the join
 (it waits for every branch), and they must be kept alive by the caller until that work is enqueued (the usual rule of
