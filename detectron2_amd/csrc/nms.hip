@@ -54,6 +54,7 @@ struct NmsWorkspace {
   int* blk_cnt;       // [n / 1024 + 1] kept flags per compaction workgroup (radix path)
   int* seg_start;     // [65536]
   int* run_cnt;       // [NMS_MAX_RUNS] entries of a run with a score > -inf (pre-sorted runs path)
+  int* seg_end;       // [NMS_MAX_RUNS] end of segment i of seg_start (runs = categories: known without a search)
   void* sort_temp;
   size_t sort_temp_bytes;
   size_t zero_bytes;  // keepbits + counters
@@ -105,6 +106,7 @@ static void carve(NmsWorkspace& w, void* base, int64_t n, int wcap) {
   w.blk_cnt = (int*)take((size_t)(n / 1024 + 2) * 4);
   w.seg_start = (int*)take(65536 * 4);
   w.run_cnt = (int*)take(NMS_MAX_RUNS * 4);
+  w.seg_end = (int*)take(NMS_MAX_RUNS * 4);
   w.sort_temp_bytes = sort_temp_bytes(n);
   w.sort_temp = take(w.sort_temp_bytes);
   w.total = off;
@@ -356,8 +358,8 @@ __device__ __forceinline__ void nms_runs_rank_body(const float* __restrict__ box
                                                    const int* __restrict__ vr, const int* __restrict__ run_cnt,
                                                    int* __restrict__ order, int* __restrict__ rankpos,
                                                    uint32_t* __restrict__ cls_s, float* __restrict__ boxes_s,
-                                                   int* __restrict__ seg_start, int* __restrict__ counters,
-                                                   int records) {
+                                                   int* __restrict__ seg_start, int* __restrict__ seg_end,
+                                                   int* __restrict__ counters, int records) {
   __shared__ uint32_t samp[RUNS_SAMPLES];
   __shared__ int s_sbase[NMS_MAX_RUNS + 1], s_cnt[NMS_MAX_RUNS], s_off[NMS_MAX_RUNS + 1];
   if (blockIdx.x * blockDim.x >= n) return;  // uniform (batched launch: the grid is sized for the largest image)
@@ -494,6 +496,7 @@ __device__ __forceinline__ void nms_runs_rank_body(const float* __restrict__ box
     if (i == s_off[r]) {
       const int pos = atomicAdd(&counters[0], 1);
       seg_start[pos] = i;
+      seg_end[pos] = s_off[r + 1];
     }
   }
 }
@@ -773,7 +776,8 @@ __device__ __forceinline__ void nms_reduce_body(const u64* __restrict__ mask,
                                                                  const u64* __restrict__ w2T,
                                                                  const uint32_t* __restrict__ cls_s, int n, int wcap,
                                                                  int max_per_class, const int* __restrict__ seg_start,
-                                                                 int* counters, u64* keepbits, u64* dbg) {
+                                                                 const int* __restrict__ seg_end, int* counters,
+                                                                 u64* keepbits, u64* dbg) {
   extern __shared__ __attribute__((aligned(16))) u64 removed[];  // [wcap]
   __shared__ u64 dt_s[RED_WIN * 64], wt_s[RED_WIN * 64], wu_s[RED_WIN * 64];
   __shared__ u64 kept_s[RED_WIN];
@@ -785,7 +789,9 @@ __device__ __forceinline__ void nms_reduce_body(const u64* __restrict__ mask,
     if (dbg && seg == 0 && tid == 0) dbg[120] = wall_clock64();
     int s = cls_s ? seg_start[seg] : 0;
     int e = n;
-    if (cls_s) {
+    if (cls_s && seg_end) {
+      e = seg_end[seg];  // runs = categories: written next to the start (the search below is 11 dependent loads)
+    } else if (cls_s) {
       // upper bound of this category in the ascending cls_s (uniform work, done by every lane)
       uint32_t c = cls_s[s];
       int lo = s, hi = n;
@@ -1141,8 +1147,8 @@ template <int BW>
 __global__ __launch_bounds__(RUNS_RANK_THREADS) void nms_runs_rank_kernel(const NmsBatch B) {
   const NmsImg& I = B.img[blockIdx.z];
   nms_runs_rank_body<BW>(I.boxes, I.scores, I.n, B.runs, (const uint32_t*)I.w.keys_out, (const int*)I.w.cls_r,
-                         I.w.run_cnt, I.w.order, I.w.rankpos, I.w.cls_s, I.w.boxes_s, I.w.seg_start, I.w.counters,
-                         I.idxs ? 0 : 1);
+                         I.w.run_cnt, I.w.order, I.w.rankpos, I.w.cls_s, I.w.boxes_s, I.w.seg_start, I.w.seg_end,
+                         I.w.counters, I.idxs ? 0 : 1);
 }
 __global__ void nms_segments_kernel(const NmsBatch B) {
   const NmsImg& I = B.img[blockIdx.z];
@@ -1160,8 +1166,8 @@ __global__ __launch_bounds__(64) void nms_mask_rot_kernel(const NmsBatch B) {
 }
 __global__ __launch_bounds__(RED_THREADS) void nms_reduce_kernel(const NmsBatch B) {
   const NmsImg& I = B.img[blockIdx.z];
-  nms_reduce_body(I.w.mask, I.w.diagT, I.w.w1T, I.w.w2T, I.cls_s, I.n, I.wcap, I.mpc, I.w.seg_start, I.w.counters,
-                  I.w.keepbits, blockIdx.z == 0 ? B.dbg : nullptr);
+  nms_reduce_body(I.w.mask, I.w.diagT, I.w.w1T, I.w.w2T, I.cls_s, I.n, I.wcap, I.mpc, I.w.seg_start,
+                  B.runs.are_cls ? I.w.seg_end : nullptr, I.w.counters, I.w.keepbits, blockIdx.z == 0 ? B.dbg : nullptr);
 }
 __global__ __launch_bounds__(FIN_THREADS) void nms_finalize_small_kernel(const NmsBatch B) {
   const NmsImg& I = B.img[blockIdx.z];

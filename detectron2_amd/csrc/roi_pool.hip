@@ -556,6 +556,23 @@ __global__ __launch_bounds__(64 * LISTS_WAVES) void tile_lists_kernel(PoolLevels
   }
 }
 
+// The zero fill of the tiles no ROI touches as its own launch: for a binning that ran ahead of the backward (beside
+// the forward, in accumulate mode: no gradient tensor existed yet) and is now used for a WRITING gather.
+__global__ __launch_bounds__(64 * LISTS_WAVES) void zero_empty_tiles_kernel(PoolLevels L, int ntiles,
+                                                                           const int* __restrict__ tile_cnt, int esize) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile = blockIdx.x * LISTS_WAVES + wave;
+  if (tile >= ntiles || tile_cnt[tile] != 0) return;
+  const TileGeom g = tile_geom(L, tile);
+  const int H = L.H[g.lvl], W = L.W[g.lvl];
+  const int rows = min(8, H - g.y0), cols = min(8, W - g.x0);
+  const long px = (long)L.C * esize, rowbytes = cols * px;
+  char* base = (char*)L.data[g.lvl] + (((long)g.n * H + g.y0) * W + g.x0) * px;
+  for (int r = 0; r < rows; r++)
+    for (long o = lane * 16; o < rowbytes; o += 64 * 16)
+      *reinterpret_cast<uint4*>(base + (long)r * W * px + o) = uint4{0u, 0u, 0u, 0u};
+}
+
 // total weight the `grid` samples of bin p put on pixel `pix` along one axis
 // (axis_tap in closed form: a valid sample at y puts max(0, 1 - |clamp(y, 0, size - 1) - pix|) on pixel pix --
 // for y in [lo, lo + 1) that is 1 - l on lo and l on lo + 1, at / beyond the last pixel and below 0 the full weight
@@ -1845,8 +1862,9 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
                               void* const* grad_inputs, int K, void* workspace, size_t workspace_bytes,
                               hipStream_t s, bool accumulate, int phase = 0) {
   // phase 0: everything; 1: only the binning (records, per-tile ROI lists, work queues -- depends on the ROIs alone
-  // in accumulate mode, so a caller can run it beside other work); 2: only the gather, after a phase-1 call with the
-  // same arguments and workspace
+  // in accumulate mode, so a caller can run it beside other work); 2: only the gather, ADDING, after a phase-1 call
+  // with the same arguments and workspace; 3: the same but WRITING: the tiles without ROIs are zero-filled by their
+  // own small launch, every other tile is written once (= what phase 0 without `accumulate` produces)
   constexpr int VEC = V16<T>::N;
   const bool vec = (p->C % VEC == 0) && all_aligned16((const void* const*)grad_inputs, p->num_levels, grad_output);
   const int cg = vec ? p->C / VEC : p->C;
@@ -1866,7 +1884,7 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
   int* tile_cnt = lists ? (int*)((char*)workspace + off_cnt) : nullptr;
   TileEntry* tile_list = lists ? (TileEntry*)((char*)workspace + off_list) : nullptr;
   PoolLevels L0 = make_levels(p, (const void* const*)grad_inputs, K);
-  L0.accumulate = accumulate ? 1 : 0;
+  L0.accumulate = (accumulate && phase != 3) ? 1 : 0;
   // work queues (see tile_lists_kernel): capacity per XCD = the tiles the 4x4-block deal gives it
   TileQueues Q{};
   const size_t off_q = off_list + pool_al((size_t)ntiles * TILE_CAP * sizeof(TileEntry));
@@ -1881,7 +1899,7 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
     set_error("roi_pooler_backward_accumulate: needs the staged tile gather (16-B aligned channel vectors, work queues)");
     return D2AMD_EUNSUPPORTED;
   }
-  if (accumulate && K == 0) return D2AMD_OK;  // nothing to add
+  if (accumulate && K == 0 && phase != 3) return D2AMD_OK;  // nothing to add
   if (queues) {
     int per[2][8] = {};
     int base[2] = {0, 0};
@@ -1907,7 +1925,13 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
     Q.zero_fill = vec ? 1 : 0;
   }
   const int qints = queues ? QCTR + 8 * (Q.cap[0] + Q.cap[1]) : 0;
-  if (K > 0 && phase != 2) {
+  if (phase == 3) {  // (binned in accumulate mode: empty tiles were neither queued nor written)
+    D2_CHECK_ARG(lists && vec, "roi_pooler_backward: phase 3 without per-tile lists");
+    hipLaunchKernelGGL(zero_empty_tiles_kernel, dim3(cdiv(ntiles, LISTS_WAVES)), dim3(64 * LISTS_WAVES), 0, s, L0,
+                       (int)ntiles, (const int*)tile_cnt, (int)sizeof(T));
+    D2_LAUNCH_OK();
+  }
+  if (K > 0 && phase < 2) {
     hipLaunchKernelGGL(roi_records_kernel, dim3(cdiv(K, 256)), dim3(256), 0, s, L0, rois, rec, Q.mem, qints);
     D2_LAUNCH_OK();
     if (lists) {
@@ -2216,10 +2240,10 @@ extern "C" int d2amd_roi_pooler_backward_accumulate(const d2amd_pooler_params* p
   return pooler_backward_entry(p, grad_output, rois, grad_inputs, K, workspace, workspace_bytes, stream, true);
 }
 
-extern "C" int d2amd_roi_pooler_backward_accumulate_phase(const d2amd_pooler_params* p, const void* grad_output,
-                                                          const float* rois, void* const* grad_inputs, int K,
-                                                          void* workspace, size_t workspace_bytes, int phase,
-                                                          void* stream) {
-  D2_CHECK_ARG(phase == 1 || phase == 2, "roi_pooler_backward_accumulate_phase: phase must be 1 (bin) or 2 (gather)");
+extern "C" int d2amd_roi_pooler_backward_phase(const d2amd_pooler_params* p, const void* grad_output,
+                                               const float* rois, void* const* grad_inputs, int K, void* workspace,
+                                               size_t workspace_bytes, int phase, void* stream) {
+  D2_CHECK_ARG(phase >= 1 && phase <= 3, "roi_pooler_backward_phase: phase must be 1 (bin), 2 (gather, adding) or 3 "
+               "(gather, writing)");
   return pooler_backward_entry(p, grad_output, rois, grad_inputs, K, workspace, workspace_bytes, stream, true, phase);
 }

@@ -142,6 +142,23 @@ _SIDE_STREAMS = {}
 _BATCH_MAX = None
 
 
+_PINNED = {}
+
+
+def _pinned_int32(n):
+    """a pinned host buffer of n int32 for one in-flight result transfer (hipHostMalloc is slow: they are recycled once
+    nobody holds them any more -- a captured graph keeps its buffer through the closure that reads it)"""
+    import sys
+
+    pool = _PINNED.setdefault(n, [])
+    for t in pool:
+        if sys.getrefcount(t) <= 3:  # the pool's reference, the loop variable, getrefcount's argument
+            return t
+    t = torch.empty(n, dtype=torch.int32, pin_memory=True)
+    pool.append(t)
+    return t
+
+
 def _nms_images_batched(inputs, iou_threshold, rotated, defer=False, runs=None, gather=None, result_buffer=None):
     """All images through d2amd_nms_batched: one launch per pipeline stage for the whole batch, one
     [count, 2] result tensor, one host sync."""
@@ -200,12 +217,27 @@ def _nms_images_batched(inputs, iou_threshold, rotated, defer=False, runs=None, 
                                               (ct.c_int64 * cnt)(*ns), off, n_runs, are_cls, float(iou_threshold),
                                               int(rotated), None, arr(pk), arr(pr), arr(pw),
                                               (ct.c_size_t * cnt)(*wb), garr, _C.stream()))
+    # result_buffer: the copy to the host is ENQUEUED here, into pinned memory, right behind the kernels (inside a
+    # captured graph: a memcpy node); the host then only waits for the stream -- a blocking .tolist() is a
+    # synchronous hipMemcpy of its own after that wait
+    mirror = None
+    if result_buffer is not None:
+        mirror = _pinned_int32(result_buffer.numel())
+        mirror.copy_(result_buffer, non_blocking=True)
+        mirror_stream = torch.cuda.current_stream(dev)
+
     def finish(with_finite=False, extra=None):
         """with_finite: also return, per image, how many kept boxes have a score > -inf; extra: a device tensor of
         int64 values read in the same host transfer (returned as a list)."""
         if result_buffer is not None:  # (values are < 2^31: the low words; the tail = the caller's status words)
             assert extra is None
-            v32 = result_buffer.tolist()  # the only host sync; `hold` keeps inputs / workspaces alive until here
+            # the only host sync (`hold` keeps inputs / workspaces alive until here): the stream the copy was enqueued
+            # on -- and the current one: a replayed graph runs where it is launched, not where it was captured
+            mirror_stream.synchronize()
+            cur = torch.cuda.current_stream(dev)
+            if cur != mirror_stream:
+                cur.synchronize()
+            v32 = mirror.tolist()
             vals = v32[0:8 * cnt:2] + v32[8 * cnt:]
         else:
             flat = result.flatten() if extra is None else torch.cat([result.flatten(), extra.flatten().to(torch.int64)])

@@ -207,6 +207,20 @@ def _forget_aliases(token):
         del _ALIASES[k]
 
 
+import os as _os
+
+# Where the binning of the backward runs: "none" = in the backward, in front of each tile gather; "chained" / "all" =
+# beside the forward of the chained / of every pooler (d2amd_roi_pooler_backward_phase: it depends on the ROIs alone).
+# Measured inside the captured step (bench.py, same box, ms/step): none 0.524 / 0.526, chained 0.530 / 0.523, all 0.538 /
+# 0.534 -- on one stream the small binning kernels cost the same wherever they sit, and the writing variant adds a
+# zero-fill launch; the early binning only pays for a caller that puts the forward on its own stream.  Default: none.
+_PREBIN_MODE = _os.environ.get("D2AMD_PREBIN", "none")
+
+
+def _PREBIN(head):
+    return _PREBIN_MODE == "all" or (_PREBIN_MODE == "chained" and not head)
+
+
 class _FusedROIPool(Function):
     @staticmethod
     @disable_torch_compiler
@@ -252,18 +266,18 @@ class _FusedROIPool(Function):
         ctx.save_for_backward(rois)
         ctx.cfg, ctx.hw, ctx.nc, ctx.layout = cfg, hw, (n, c), layout
         ctx.needs = [f.requires_grad for f in feats]
-        # A chained, non-head pooler's backward ADDS to the head's gradient: its binning (per-ROI records, per-tile
-        # ROI lists, work queues) depends on the ROIs alone, so it is done HERE, beside the forward kernels (on
-        # whatever stream the forward runs), instead of between the two tile gathers of the backward (15 us of small
-        # kernels on the critical path).  Unused if the backward never comes or this work ends up writing first.
+        # The binning of the backward (per-ROI records, per-tile ROI lists, work queues) depends on the ROIs alone: it
+        # CAN be done here, beside the forward kernels (on whatever stream the forward runs), instead of in front of
+        # the tile gathers of the backward; the gather that uses it later either adds (phase 2) or writes (phase 3: +
+        # a zero fill of the untouched tiles).  Off by default: see _PREBIN_MODE.
         ctx.binned = None
-        if chain is not None and not head and layout == _C.NHWC and k > 0 and any(ctx.needs):
+        if layout == _C.NHWC and k > 0 and any(ctx.needs_input_grad[5:]) and _PREBIN(head):  # (False under no_grad)
             L = _C.lib()
             ws_bytes = L.d2amd_roi_pooler_backward_workspace_bytes(ctypes.byref(p), k)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=xs[0].device)
             with _C.on_device(xs[0].device):  # (pointers: only their alignment class matters to the binning)
-                rc = L.d2amd_roi_pooler_backward_accumulate_phase(ctypes.byref(p), _C.ptr(out), _C.ptr(rois),
-                                                                  _ptr_array(xs), k, _C.ptr(ws), ws_bytes, 1, _C.stream())
+                rc = L.d2amd_roi_pooler_backward_phase(ctypes.byref(p), _C.ptr(out), _C.ptr(rois), _ptr_array(xs), k,
+                                                       _C.ptr(ws), ws_bytes, 1, _C.stream())
             if rc == 0:
                 ctx.binned = (ws, ws_bytes)
             elif rc != _C.EUNSUPPORTED:
@@ -327,6 +341,13 @@ class _FusedROIPool(Function):
                 k = r.shape[0]
                 p = _params(wcfg, (n, c), hw, _C.dtype_code(g), _C.NHWC)
                 if plain_first and j == 0:
+                    if binned is not None:  # binned beside its forward: zero fill of the untouched tiles + gather
+                        ws, ws_bytes = binned
+                        ws.record_stream(torch.cuda.current_stream(dev))
+                        _C.check(L.d2amd_roi_pooler_backward_phase(ctypes.byref(p), _C.ptr(g), _C.ptr(r),
+                                                                   _ptr_array(grads), k, _C.ptr(ws), ws_bytes, 3,
+                                                                   _C.stream()))
+                        continue
                     # per-ROI records + per-tile ROI lists (one wave per 8x8 tile bins the ROIs once per call)
                     ws_bytes = L.d2amd_roi_pooler_backward_workspace_bytes(ctypes.byref(p), k)
                     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
@@ -336,9 +357,8 @@ class _FusedROIPool(Function):
                 if binned is not None:  # binned beside its forward (maybe on another stream): gather only
                     ws, ws_bytes = binned
                     ws.record_stream(torch.cuda.current_stream(dev))
-                    rc = L.d2amd_roi_pooler_backward_accumulate_phase(ctypes.byref(p), _C.ptr(g), _C.ptr(r),
-                                                                      _ptr_array(grads), k, _C.ptr(ws), ws_bytes, 2,
-                                                                      _C.stream())
+                    rc = L.d2amd_roi_pooler_backward_phase(ctypes.byref(p), _C.ptr(g), _C.ptr(r), _ptr_array(grads), k,
+                                                           _C.ptr(ws), ws_bytes, 2, _C.stream())
                 else:
                     ws_bytes = L.d2amd_roi_pooler_backward_workspace_bytes(ctypes.byref(p), k)
                     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)

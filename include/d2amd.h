@@ -132,13 +132,15 @@ int d2amd_roi_pooler_backward(const d2amd_pooler_params* p, const void* grad_out
 int d2amd_roi_pooler_backward_accumulate(const d2amd_pooler_params* p, const void* grad_output, const float* rois,
                                          void* const* grad_inputs, int K, void* workspace, size_t workspace_bytes,
                                          void* stream);
-/* The same in two calls: phase 1 bins the ROIs (per-ROI records, per-tile ROI lists, work queues: reads `rois` only,
- * writes the workspace only), phase 2 runs the gather of a workspace phase 1 has filled -- same arguments in both.
- * Phase 1 may be enqueued on another stream, beside the gather of the pooler whose gradient this one adds to (it
- * neither reads nor writes grad_inputs); the caller orders phase 2 after both. */
-int d2amd_roi_pooler_backward_accumulate_phase(const d2amd_pooler_params* p, const void* grad_output, const float* rois,
-                                               void* const* grad_inputs, int K, void* workspace,
-                                               size_t workspace_bytes, int phase, void* stream);
+/* The backward in two calls: phase 1 bins the ROIs (per-ROI records, per-tile ROI lists, work queues: reads `rois`
+ * only, writes the workspace only -- it may run on another stream, long before the gradient exists: beside the
+ * pooler's forward); a later call with the same arguments and workspace runs the gather: phase 2 ADDS to grad_inputs
+ * (= d2amd_roi_pooler_backward_accumulate), phase 3 WRITES it (= d2amd_roi_pooler_backward: tiles no ROI touches are
+ * zero-filled by a small launch of their own).  In phase 1 grad_output / grad_inputs may be any pointers of the same
+ * alignment class as the later ones (only `& 15` is looked at).  D2AMD_EUNSUPPORTED as for the accumulate entry. */
+int d2amd_roi_pooler_backward_phase(const d2amd_pooler_params* p, const void* grad_output, const float* rois,
+                                    void* const* grad_inputs, int K, void* workspace, size_t workspace_bytes,
+                                    int phase, void* stream);
 
 /* ---- ROIAlignRotated.  Replaces torch.ops.detectron2.roi_align_rotated_forward/backward
  * (vision.cpp:118-119; csrc/ROIAlignRotated/ROIAlignRotated.h:50-113).

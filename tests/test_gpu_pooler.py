@@ -408,3 +408,37 @@ def test_transpose_entry_and_nchw_callers_get_nchw_back(dtype):
     assert (res["nchw"][0] - res["nhwc"][0]).abs().max() <= tol * res["nhwc"][0].abs().max()
     for a, b in zip(res["nchw"][1], res["nhwc"][1]):
         assert (a - b).abs().max() <= tol * b.abs().max() + 1e-6
+
+
+def test_binning_beside_the_forward_gives_the_same_gradients(monkeypatch):
+    """d2amd_roi_pooler_backward_phase: binning in phase 1 (here: right after the forward), gather in phase 2 (adding)
+    / phase 3 (writing + zero fill of the untouched tiles) == the one-call backward, bit for bit, for a chain of two
+    poolers over the same features (box 7x7 + mask 14x14)."""
+    from detectron2_amd.modeling import poolers as P
+
+    g = torch.Generator().manual_seed(5)
+    feats0 = [torch.randn(2, 64, s, s + 8, generator=g).to(torch.bfloat16).to(DEV).contiguous(
+        memory_format=torch.channels_last) for s in (64, 32, 16, 8)]
+
+    def boxes(n, seed):
+        gg = torch.Generator().manual_seed(seed)
+        c = torch.rand(n, 2, generator=gg) * 200 + 20
+        wh = torch.rand(n, 2, generator=gg) * 150 + 4
+        return Boxes(torch.cat([c - wh / 2, c + wh / 2], 1).to(DEV))
+
+    bl, ml = [boxes(96, 1), boxes(80, 2)], [boxes(24, 3), boxes(20, 4)]
+    scales = [1 / 4, 1 / 8, 1 / 16, 1 / 32]
+    res = {}
+    for mode in ("none", "chained", "all"):
+        monkeypatch.setattr(P, "_PREBIN_MODE", mode)
+        feats = [f.clone().requires_grad_(True) for f in feats0]
+        yb = ROIPooler(7, scales, 0, "ROIAlignV2")(feats, bl)
+        ym = ROIPooler(14, scales, 0, "ROIAlignV2")(feats, ml)
+        gb = torch.Generator().manual_seed(9)
+        torch.autograd.backward([yb, ym], [torch.randn(yb.shape, generator=gb).to(yb.dtype).to(DEV).contiguous(
+            memory_format=torch.channels_last), torch.randn(ym.shape, generator=gb).to(ym.dtype).to(DEV).contiguous(
+            memory_format=torch.channels_last)])
+        res[mode] = [f.grad.clone() for f in feats]
+    for mode in ("chained", "all"):
+        for a, b in zip(res["none"], res[mode]):
+            assert torch.equal(a, b), mode
