@@ -254,15 +254,18 @@ class _FusedROIPool(Function):
         mf = torch.channels_last if layout == _C.NHWC else torch.contiguous_format
         out = torch.empty((k, c, ph, pw), dtype=xs[0].dtype, device=xs[0].device, memory_format=mf)
         with _C.on_device(xs[0].device):
+            # (K ints for the ROI processing order of the forward: include/d2amd.h, d2amd_roi_pooler_forward_ordered)
+            order = torch.empty(max(k, 1), dtype=torch.int32, device=xs[0].device)
             if box_lists is None:
-                _C.check(_C.lib().d2amd_roi_pooler_forward(ctypes.byref(p), _ptr_array(xs), _C.ptr(rois), _C.ptr(out), k,
-                                                           _C.stream()))
+                _C.check(_C.lib().d2amd_roi_pooler_forward_ordered(ctypes.byref(p), _ptr_array(xs), _C.ptr(rois),
+                                                                   _C.ptr(out), k, _C.ptr(order), 4 * max(k, 1),
+                                                                   _C.stream()))
             else:
                 n_img = len(box_lists)
                 counts = (ctypes.c_int * n_img)(*[int(b.shape[0]) for b in box_lists])
-                _C.check(_C.lib().d2amd_roi_pooler_forward_box_lists(ctypes.byref(p), _ptr_array(xs),
-                                                                     _ptr_array(box_lists), counts, n_img,
-                                                                     _C.ptr(rois), _C.ptr(out), _C.stream()))
+                _C.check(_C.lib().d2amd_roi_pooler_forward_box_lists_ordered(
+                    ctypes.byref(p), _ptr_array(xs), _ptr_array(box_lists), counts, n_img, _C.ptr(rois), _C.ptr(out),
+                    _C.ptr(order), 4 * max(k, 1), _C.stream()))
         ctx.save_for_backward(rois)
         ctx.cfg, ctx.hw, ctx.nc, ctx.layout = cfg, hw, (n, c), layout
         ctx.needs = [f.requires_grad for f in feats]

@@ -116,6 +116,18 @@ int d2amd_roi_pooler_forward(const d2amd_pooler_params* p, const void* const* in
 int d2amd_roi_pooler_forward_box_lists(const d2amd_pooler_params* p, const void* const* inputs,
                                        const float* const* boxes, const int* counts, int num_images,
                                        float* rois_out, void* output, void* stream);
+/* Both forwards with a ROI PROCESSING ORDER: the ROIs are sorted by (level, image, Morton code of their centre's 8-px
+ * tile) by one small launch (which also converts the box lists), and each XCD pools one contiguous range of that
+ * order -- neighbours in the feature map share that XCD's L2 instead of being fetched by all eight.  Results are
+ * identical (row k of the output is ROI k).  workspace: d2amd_roi_pooler_forward_workspace_bytes(K); without it, for
+ * K > 4096 or more than 32 images the list order is used. */
+size_t d2amd_roi_pooler_forward_workspace_bytes(int K);
+int d2amd_roi_pooler_forward_ordered(const d2amd_pooler_params* p, const void* const* inputs, const float* rois,
+                                     void* output, int K, void* workspace, size_t workspace_bytes, void* stream);
+int d2amd_roi_pooler_forward_box_lists_ordered(const d2amd_pooler_params* p, const void* const* inputs,
+                                               const float* const* boxes, const int* counts, int num_images,
+                                               float* rois_out, void* output, void* workspace,
+                                               size_t workspace_bytes, void* stream);
 size_t d2amd_roi_pooler_workspace_bytes(int K); /* backward, minimum: per-ROI records (48 B each) */
 /* backward, recommended: records + per-tile ROI lists (one wave per 8x8 tile bins the ROIs once per call;
  * with the minimum size every tile workgroup scans all K records itself, ~2 us per 512 records and tile) */
