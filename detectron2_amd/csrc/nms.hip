@@ -54,7 +54,6 @@ struct NmsWorkspace {
   int* blk_cnt;       // [n / 1024 + 1] kept flags per compaction workgroup (radix path)
   int* seg_start;     // [65536]
   int* run_cnt;       // [NMS_MAX_RUNS] entries of a run with a score > -inf (pre-sorted runs path)
-  int* seg_end;       // [NMS_MAX_RUNS] end of segment i of seg_start (runs = categories: known without a search)
   void* sort_temp;
   size_t sort_temp_bytes;
   size_t zero_bytes;  // keepbits + counters
@@ -103,10 +102,9 @@ static void carve(NmsWorkspace& w, void* base, int64_t n, int wcap) {
   w.rk_keys = take(n <= RANK_MAX_N ? (size_t)(n + RK_GROUP) * 16 : 0);
   w.rk_cnt = (int*)take(n <= RANK_MAX_N ? (size_t)((n + RK_JC - 1) / RK_JC) * 2 * n64 * 4 : 0);
   w.flag_r = (uint8_t*)take(n);
-  w.blk_cnt = (int*)take((size_t)(n / 1024 + 2) * 4);
+  w.blk_cnt = (int*)take((size_t)(n / 1024 + 2) * 8);  // (8 B per chunk: the direct finalize publishes two counts)
   w.seg_start = (int*)take(65536 * 4);
-  w.run_cnt = (int*)take(NMS_MAX_RUNS * 4);
-  w.seg_end = (int*)take(NMS_MAX_RUNS * 4);
+  w.run_cnt = (int*)take(64 * 4);  // [0, 8): live entries per run; [16, 16 + 12): "a run is not in order" per order workgroup
   w.sort_temp_bytes = sort_temp_bytes(n);
   w.sort_temp = take(w.sort_temp_bytes);
   w.total = off;
@@ -288,9 +286,10 @@ template <int RUNS_SCAN_ROWS>
 __device__ __forceinline__ void nms_runs_scan_body(const float* __restrict__ scores, const NmsRuns& R,
                                                    uint32_t* __restrict__ cs, int* __restrict__ vr,
                                                    int* __restrict__ run_cnt, uint32_t* __restrict__ zero,
-                                                   int zero_words) {
+                                                   int zero_words, int* __restrict__ blk_zero, int blk_words) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   for (int q = blockIdx.x * RUNS_SCAN_THREADS + tid; q < zero_words; q += gridDim.x * RUNS_SCAN_THREADS) zero[q] = 0u;
+  if (blockIdx.x == 0 && tid < blk_words && blk_zero) blk_zero[tid] = 0;  // (direct finalize's chunk counts)
   const int r = blockIdx.x;
   if (r >= R.n_runs) return;
   const int lo = R.off[r], hi = R.off[r + 1];
@@ -358,8 +357,8 @@ __device__ __forceinline__ void nms_runs_rank_body(const float* __restrict__ box
                                                    const int* __restrict__ vr, const int* __restrict__ run_cnt,
                                                    int* __restrict__ order, int* __restrict__ rankpos,
                                                    uint32_t* __restrict__ cls_s, float* __restrict__ boxes_s,
-                                                   int* __restrict__ seg_start, int* __restrict__ seg_end,
-                                                   int* __restrict__ counters, int records) {
+                                                   int* __restrict__ seg_start, int* __restrict__ counters,
+                                                   int records) {
   __shared__ uint32_t samp[RUNS_SAMPLES];
   __shared__ int s_sbase[NMS_MAX_RUNS + 1], s_cnt[NMS_MAX_RUNS], s_off[NMS_MAX_RUNS + 1];
   if (blockIdx.x * blockDim.x >= n) return;  // uniform (batched launch: the grid is sized for the largest image)
@@ -496,9 +495,189 @@ __device__ __forceinline__ void nms_runs_rank_body(const float* __restrict__ box
     if (i == s_off[r]) {
       const int pos = atomicAdd(&counters[0], 1);
       seg_start[pos] = i;
-      seg_end[pos] = s_off[r + 1];
     }
   }
+}
+
+// ---- step 1c for the batched path (n <= RANK_MAX_N): scan AND rank in one launch -------------------------------------
+// Every workgroup of 1,024 threads loads ALL n scores (coalesced; it staged all keys anyway), compacts the live keys
+// in LDS by one flat scan -- runs are contiguous, so the compacted list of run r is the slice [g(off[r]), g(off[r+1]))
+// of the flat compaction, g(i) = live entries before i -- and ranks the 1,024 entries of its own row.  No scan
+// launch, no dependent load of the runs' counts, nothing written to and read back from memory in between
+// (scan 5 us + rank 17 us -> one kernel).  It also zeroes the reduction's accumulators (plain stores: nothing else in
+// this launch touches them) and reports "a run is not in order" through a per-workgroup word.
+// Workgroups of 256 threads (35 of them for 8,819 entries): with 1,024-thread workgroups the kernel ran on 9 CUs and
+// was bound by their VALUs (the 11-step search of 4 other runs is ~1,100 instructions per entry: 22 us); a workgroup
+// walks the n keys twice (count, then place: the second pass re-reads them from cache) instead of holding them.
+constexpr int ORDER_THREADS = 256, ORDER_ROWS = RANK_MAX_N / ORDER_THREADS, ORDER_WAVES = ORDER_THREADS / 64;
+template <int BW>
+__device__ __forceinline__ void nms_runs_order_small_body(
+    const float* __restrict__ boxes, const float* __restrict__ scores, int n, const NmsRuns& R,
+    int* __restrict__ order, int* __restrict__ rankpos, uint32_t* __restrict__ cls_s, float* __restrict__ boxes_s,
+    uint32_t* __restrict__ zero, int zero_words, int* __restrict__ blk_zero, int blk_words,
+    int* __restrict__ blk_flag, int records) {
+  __shared__ uint32_t samp[RANK_MAX_N], s_raw[RANK_MAX_N];  // live keys compacted / all keys in array order
+  __shared__ int cell[ORDER_ROWS * ORDER_WAVES + 1];
+  __shared__ int s_sbase[NMS_MAX_RUNS + 1], s_off[NMS_MAX_RUNS + 1];
+  __shared__ int s_bad;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (blockIdx.x * ORDER_THREADS >= n) return;  // uniform (batched launch: the grid is sized for the largest image)
+  for (int q = blockIdx.x * ORDER_THREADS + tid; q < zero_words; q += gridDim.x * ORDER_THREADS) zero[q] = 0u;
+  if (blockIdx.x == 0 && tid < blk_words) blk_zero[tid] = 0;
+  // my own entry's box: requested first, it arrives while the keys are compacted
+  const int i = blockIdx.x * ORDER_THREADS + tid;
+  const long bi = min(i, n - 1);
+  float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float b5 = 0.f;
+  if (BW == 4) {
+    b4 = *reinterpret_cast<const float4*>(boxes + bi * 4);
+  } else {
+    const float* bp = boxes + bi * BW;
+    b4 = make_float4(bp[0], bp[1], bp[2], bp[3]);
+    b5 = bp[4];
+  }
+  if (tid == 0) {
+    s_bad = 0;
+#pragma unroll
+    for (int q = 0; q <= NMS_MAX_RUNS; q++) s_off[q] = R.off[q];
+  }
+  const int rows = (n + ORDER_THREADS - 1) / ORDER_THREADS;  // uniform, <= ORDER_ROWS
+  // The keys go through LDS in array order first: ALL rows are requested at once (every value is used exactly once,
+  // by its LDS store -- kept in registers for two passes the compiler re-loaded them row by row: 10+ dependent round
+  // trips, 11 us of a 25 us kernel), both passes then read LDS.
+  {
+    float sv[ORDER_ROWS];
+#pragma unroll
+    for (int k = 0; k < ORDER_ROWS; k++) {
+      const int j = k * ORDER_THREADS + tid;
+      sv[k] = (k < rows && j < n) ? scores[j] : -INFINITY;
+    }
+#pragma unroll
+    for (int k = 0; k < ORDER_ROWS; k++)
+      if (k < rows) s_raw[k * ORDER_THREADS + tid] = run_key(sv[k]);  // (-inf: parked)
+  }
+  __syncthreads();
+  for (int k = 0; k < rows; k++) {  // pass 1: live entries per (row, wave)
+    const unsigned long long bal = __ballot(s_raw[k * ORDER_THREADS + tid] != RUN_KEY_PARKED);
+    if (lane == 0) cell[k * ORDER_WAVES + wid] = __builtin_popcountll(bal);
+  }
+  __syncthreads();
+  const int cells = rows * ORDER_WAVES;
+  if (wid == 0) {  // exclusive scan of the counts (row-major = array order)
+    constexpr int PER = (ORDER_ROWS * ORDER_WAVES + 63) / 64;
+    int v[PER], sum = 0;
+#pragma unroll
+    for (int q = 0; q < PER; q++) { v[q] = lane * PER + q < cells ? cell[lane * PER + q] : 0; sum += v[q]; }
+    int incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int y = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += y;
+    }
+    int run = incl - sum;
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+      if (lane * PER + q < cells) cell[lane * PER + q] = run;
+      run += v[q];
+    }
+    if (lane == 63) cell[ORDER_ROWS * ORDER_WAVES] = incl;
+  }
+  __syncthreads();
+  const int live_total = cell[ORDER_ROWS * ORDER_WAVES];
+  int g_mine = 0;
+  uint32_t keyv = RUN_KEY_PARKED;
+  for (int k = 0; k < rows; k++) {  // pass 2: the flat compaction in LDS
+    const uint32_t kk = s_raw[k * ORDER_THREADS + tid];
+    const bool live = kk != RUN_KEY_PARKED;
+    const unsigned long long bal = __ballot(live);
+    const int g = cell[k * ORDER_WAVES + wid] + __builtin_popcountll(bal & ((1ull << lane) - 1ull));  // live before j
+    if (live) samp[g] = kk;
+    if (k == (int)blockIdx.x) { g_mine = g; keyv = kk; }
+  }
+  // start of run q in the flat compaction = live entries before off[q]: wave q % 4 recounts the 64 entries around
+  // off[q] (comparing every entry of every row with every run start was 6 us)
+  {
+#pragma unroll
+    for (int q = 0; q <= NMS_MAX_RUNS; q++) {
+      const int oq = R.off[q];  // (constant index: an SGPR)
+      if ((q & (ORDER_WAVES - 1)) != wid) continue;  // uniform per wave
+      if (oq >= n) {
+        if (lane == 0) s_sbase[q] = live_total;  // (a run that starts at the end: empty)
+      } else {
+        const int j = (oq & ~63) + lane;  // (rows are whole: s_raw holds "parked" behind n)
+        const bool live = s_raw[j] != RUN_KEY_PARKED;
+        const unsigned long long bal = __ballot(live);
+        if (lane == 0)
+          s_sbase[q] = cell[(oq >> 8) * ORDER_WAVES + ((oq >> 6) & (ORDER_WAVES - 1))] +
+              __builtin_popcountll(bal & ((1ull << (oq & 63)) - 1ull));
+      }
+    }
+  }
+  __syncthreads();
+  if (i < n) {
+    int r = 0;
+#pragma unroll
+    for (int q = 1; q < NMS_MAX_RUNS; q++)
+      if (i >= s_off[q] && q < R.n_runs) r = q;
+    int rank;
+    if (keyv != RUN_KEY_PARKED) {
+      const int mine = g_mine - s_sbase[r];
+      if (mine > 0 && samp[g_mine - 1] > keyv) s_bad = 1;  // in order inside the run?  (equal keys: array order)
+      rank = mine;
+      // per other run: the number of its live keys that precede mine (see nms_runs_rank_body), all runs together
+      int lo[NMS_MAX_RUNS], hi[NMS_MAX_RUNS], sb[NMS_MAX_RUNS + 1];
+      int most = 0;
+#pragma unroll
+      for (int q = 0; q <= NMS_MAX_RUNS; q++) sb[q] = s_sbase[q];  // (registers: not re-read from LDS per probe)
+#pragma unroll
+      for (int q = 0; q < NMS_MAX_RUNS; q++) {
+        const bool search = q < R.n_runs && q != r && !(q > r && keyv == 0u);
+        lo[q] = 0;
+        hi[q] = search ? sb[q + 1] - sb[q] : 0;
+        most = max(most, q < R.n_runs ? sb[q + 1] - sb[q] : 0);
+      }
+      for (int span = most; span > 0; span >>= 1) {
+        uint32_t probe[NMS_MAX_RUNS];
+#pragma unroll
+        for (int q = 0; q < NMS_MAX_RUNS; q++)
+          if (q < R.n_runs) probe[q] = samp[min(sb[q] + ((lo[q] + hi[q]) >> 1), RANK_MAX_N - 1)];
+#pragma unroll
+        for (int q = 0; q < NMS_MAX_RUNS; q++) {
+          if (q < R.n_runs) {
+            const int mid = (lo[q] + hi[q]) >> 1;
+            const uint32_t bound = q < r ? keyv : keyv - 1u;
+            const bool go = lo[q] < hi[q];
+            if (go && probe[q] <= bound) lo[q] = mid + 1;
+            else if (go) hi[q] = mid;
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < NMS_MAX_RUNS; q++) rank += lo[q];
+    } else {
+      rank = live_total + (i - g_mine);  // parked entries: after every live one, in array order
+    }
+    order[rank] = i;
+    const bool to_rank = !R.are_cls;  // no categories: segment order == rank order; runs = categories: == array order
+    if (R.are_cls || records) {
+      const int p = to_rank ? rank : i;
+      const uint32_t cls = to_rank ? 0u : (uint32_t)r;
+      float* d = boxes_s + (long)p * BOX_REC;
+      if (BW == 4) {
+        const float area = (b4.z - b4.x) * (b4.w - b4.y);
+        const bool fin = (fabsf(b4.x) < INFINITY) && (fabsf(b4.y) < INFINITY) && (fabsf(b4.z) < INFINITY) &&
+                         (fabsf(b4.w) < INFINITY);
+        reinterpret_cast<float4*>(d)[0] = b4;
+        reinterpret_cast<float4*>(d)[1] = make_float4(area, __uint_as_float(cls), __uint_as_float(fin ? 0u : 1u), 0.f);
+      } else {
+        reinterpret_cast<float4*>(d)[0] = b4;
+        reinterpret_cast<float4*>(d)[1] = make_float4(b5, __uint_as_float(cls), 0.f, 0.f);
+      }
+      if (!to_rank) { rankpos[i] = rank; cls_s[i] = cls; }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) blk_flag[blockIdx.x] = s_bad ? 4 : 0;
 }
 
 // order[] entries as indices: a run that was announced as sorted but is not (flag 4) leaves ranks that are no
@@ -776,7 +955,7 @@ __device__ __forceinline__ void nms_reduce_body(const u64* __restrict__ mask,
                                                                  const u64* __restrict__ w2T,
                                                                  const uint32_t* __restrict__ cls_s, int n, int wcap,
                                                                  int max_per_class, const int* __restrict__ seg_start,
-                                                                 const int* __restrict__ seg_end, int* counters,
+                                                                 const NmsRuns& R, bool runs, int* counters,
                                                                  u64* keepbits, u64* dbg) {
   extern __shared__ __attribute__((aligned(16))) u64 removed[];  // [wcap]
   __shared__ u64 dt_s[RED_WIN * 64], wt_s[RED_WIN * 64], wu_s[RED_WIN * 64];
@@ -784,14 +963,21 @@ __device__ __forceinline__ void nms_reduce_body(const u64* __restrict__ mask,
   __shared__ int flag_s[1 + RED_GROUPS];  // [0] blocks resolved by wave 0; [1 + g] blocks pushed by pusher g
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int grp = wid - 1;  // pushers only
-  const int nseg = cls_s ? counters[0] : 1;
+  // runs = categories: the segments are the runs, known from the kernel arguments -- no count / start / end loads
+  // (three dependent round trips) and no search (11 more) in front of the block loop
+  // (the run table is read with constant indices only: a dynamic index -- or a pointer -- into the kernel-argument
+  // struct makes the compiler copy the struct to scratch memory: 560 us)
+  const int nseg = runs ? R.n_runs : (cls_s ? counters[0] : 1);
   for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
     if (dbg && seg == 0 && tid == 0) dbg[120] = wall_clock64();
-    int s = cls_s ? seg_start[seg] : 0;
-    int e = n;
-    if (cls_s && seg_end) {
-      e = seg_end[seg];  // runs = categories: written next to the start (the search below is 11 dependent loads)
+    int s = 0, e = n;
+    if (runs) {
+#pragma unroll
+      for (int q = 0; q < NMS_MAX_RUNS; q++)
+        if (q == seg) { s = R.off[q]; e = R.off[q + 1]; }
+      if (e <= s) continue;  // (an empty run)
     } else if (cls_s) {
+      s = seg_start[seg];
       // upper bound of this category in the ascending cls_s (uniform work, done by every lane)
       uint32_t c = cls_s[s];
       int lo = s, hi = n;
@@ -930,20 +1116,46 @@ __device__ __forceinline__ void gather_rows(const d2amd_nms_gather& G, int src, 
   }
 }
 
-// small n: one workgroup does scatter-to-rank-order and ordered compaction out of LDS
+// small n: one workgroup does scatter-to-rank-order and ordered compaction out of LDS.
+// The kernel is a chain of dependent memory round trips (~2 us each: everything it reads was written by other
+// workgroups a moment ago), so the point is to have few of them:
+//   general:  {keepbits, rankpos} -> LDS flags | order -> scores | payload -> stores           (4 round trips)
+//   DIRECT (runs = categories: the class-major position of a row is the row, so order[r] is also where its kept
+//            bit sits):  order -> {kept bit, score} | payload -> stores                          (3 round trips)
+// (the first version of the gather added a pass over LDS indices and made it 5).
 constexpr int FIN_THREADS = 1024;
+template <int W, int CH>
+__device__ __forceinline__ void fin_copy_rows(const uint32_t* __restrict__ a, uint32_t* __restrict__ b,
+                                              const int (&ord)[CH], uint32_t fl, int at) {
+  uint32_t val[CH][W];
+#pragma unroll
+  for (int q = 0; q < CH; q++)
+#pragma unroll
+    for (int j = 0; j < W; j++) val[q][j] = a[(long)ord[q] * W + j];
+#pragma unroll
+  for (int q = 0; q < CH; q++)
+    if ((fl >> q) & 1u) {
+#pragma unroll
+      for (int j = 0; j < W; j++) b[(long)at * W + j] = val[q][j];
+      at++;
+    }
+}
+template <bool DIRECT>
 __device__ __forceinline__ void nms_finalize_small_body(
     const u64* __restrict__ keepbits, const int* __restrict__ rankpos, const int* __restrict__ order, int n,
     int64_t* __restrict__ keep_out, const int* __restrict__ counters, int64_t* __restrict__ result,
-    const float* __restrict__ scores, const d2amd_nms_gather& G) {
-  __shared__ uint8_t flags[RANK_MAX_N];
-  __shared__ int s_keep[RANK_MAX_N];  // kept indices in keep order (read by the gather pass)
+    const float* __restrict__ scores, const d2amd_nms_gather& G, const int* __restrict__ blk_flag) {
+  __shared__ uint8_t flags[DIRECT ? 4 : RANK_MAX_N];
   __shared__ int wave_tot[FIN_THREADS / 64];
   __shared__ int s_finite;
   if (threadIdx.x == 0) s_finite = 0;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   constexpr int CH = RANK_MAX_N / FIN_THREADS;  // 12 consecutive ranks per thread
-  {  // kept bit of every segment position -> rank order; the (clamped) loads of all 12 positions in flight together
+  const int r0 = tid * CH;
+  int ord[CH];
+#pragma unroll
+  for (int q = 0; q < CH; q++) ord[q] = order_at(order, min(r0 + q, n - 1), n);  // (clamped) loads, all in flight
+  if (!DIRECT) {  // kept bit of every segment position -> rank order; the loads of all 12 positions in flight together
     u64 kb[CH];
     int rp[CH];
 #pragma unroll
@@ -957,17 +1169,21 @@ __device__ __forceinline__ void nms_finalize_small_body(
       const int p = tid + q * FIN_THREADS;
       if (p < n) flags[min(max(rp[q], 0), n - 1)] = (kb[q] >> (p & 63)) & 1ull ? 1 : 0;
     }
+    __syncthreads();
   }
-  __syncthreads();
-  const int r0 = tid * CH;
-  int ord[CH];
+  float sc[CH];
+  uint32_t kw[CH];
+#pragma unroll
+  for (int q = 0; q < CH; q++) {
+    sc[q] = scores[ord[q]];  // unconditional: 12 loads in flight (ord is clamped)
+    if (DIRECT) kw[q] = reinterpret_cast<const uint32_t*>(keepbits)[ord[q] >> 5];
+  }
   int cnt = 0;
   uint32_t fl = 0;
 #pragma unroll
   for (int q = 0; q < CH; q++) {
     const int r = r0 + q;
-    ord[q] = order_at(order, min(r, n - 1), n);  // unconditional (clamped) loads, all in flight together
-    const bool f = r < n && flags[min(r, n - 1)];
+    const bool f = r < n && (DIRECT ? ((kw[q] >> (ord[q] & 31)) & 1u) != 0u : flags[min(r, n - 1)] != 0);
     fl |= f ? (1u << q) : 0u;
     cnt += f ? 1 : 0;
   }
@@ -981,46 +1197,102 @@ __device__ __forceinline__ void nms_finalize_small_body(
   __syncthreads();
   int off = incl - cnt;
   for (int w = 0; w < wid; w++) off += wave_tot[w];
+  const int off0 = off;
   int fin = 0;
-  float sc[CH];
-#pragma unroll
-  for (int q = 0; q < CH; q++) sc[q] = scores[ord[q]];  // unconditional: 12 loads in flight (ord is clamped)
 #pragma unroll
   for (int q = 0; q < CH; q++)
     if ((fl >> q) & 1u) {
-      if (G.count) s_keep[off] = ord[q];
       keep_out[off++] = (int64_t)ord[q];
       fin += sc[q] > -INFINITY ? 1 : 0;
     }
   if (fin) atomicAdd(&s_finite, fin);
+  // rows of the caller's arrays in keep order: this thread's 12 candidate rows are loaded UNCONDITIONALLY (ord is
+  // clamped; loads under a per-row branch were issued one divergent branch at a time: 46 us), the kept ones stored
+  for (int t = 0; t < G.count; t++) {
+    const int words = G.row_bytes[t] >> 2;
+    const uint32_t* a = (const uint32_t*)G.src[t];
+    uint32_t* b = (uint32_t*)G.dst[t];
+    if (words == 1) fin_copy_rows<1, CH>(a, b, ord, fl, off0);
+    else if (words == 2) fin_copy_rows<2, CH>(a, b, ord, fl, off0);
+    else if (words == 4) fin_copy_rows<4, CH>(a, b, ord, fl, off0);
+    else {
+      int at = off0;
+      for (int q = 0; q < CH; q++)
+        if ((fl >> q) & 1u) {
+          for (int j = 0; j < words; j++) b[(long)at * words + j] = a[(long)ord[q] * words + j];
+          at++;
+        }
+    }
+  }
   __syncthreads();
   // result: {kept, error flags, kept with a score > -inf (callers park invalid rows at -inf: they sort last), 0}
-  if (tid == FIN_THREADS - 1) { result[0] = off; result[1] = counters[1]; result[2] = s_finite; result[3] = 0; }
-  if (G.count) {
-    // rows of the caller's arrays in keep order: one 4-byte word per thread and step, all rows in parallel (copying
-    // a row where its index is written chains 12 rows x (load, store) per thread: 40 us)
-    __shared__ int s_total;
-    if (tid == FIN_THREADS - 1) s_total = off;
-    __syncthreads();  // (also orders the keep_out stores above before the loads below: same workgroup)
-    const int total = s_total;
-    for (int t = 0; t < G.count; t++) {
-      const int words = G.row_bytes[t] >> 2, cells = total * words;
-      const uint32_t* a = (const uint32_t*)G.src[t];
-      uint32_t* b = (uint32_t*)G.dst[t];
-      constexpr int GU = 4;  // independent loads in flight per thread
-      for (int e0 = tid; e0 < cells; e0 += FIN_THREADS * GU) {
-        uint32_t val[GU];
+  if (tid == FIN_THREADS - 1) {
+    int fl2 = counters[1];
+    if (blk_flag)
+      for (int q = 0; q < (n + 255) / 256; q++) fl2 |= blk_flag[q];
+    result[0] = off; result[1] = fl2; result[2] = s_finite; result[3] = 0;
+  }
+}
+
+// DIRECT mode across workgroups.  One workgroup doing all of it is bound by its CU's vector L1: every load here is a
+// gather (one cache line per lane = 64 L1 cycles per wave-load), 12,288 ranks x (score, kept bit, 5 payload words)
+// through ONE L1 is ~25 us whatever the number of round trips.  Here: 1,024 ranks per workgroup (one per thread), a
+// workgroup publishes {kept, kept with a finite score} of its chunk and sums what the workgroups before it have
+// published (decoupled look-back on device-scope atomics; the <= 12 workgroups of an image are co-resident).
+__device__ __forceinline__ void nms_finalize_direct_body(
+    const u64* __restrict__ keepbits, const int* __restrict__ order, int n, int64_t* __restrict__ keep_out,
+    const int* __restrict__ counters, int64_t* __restrict__ result, const float* __restrict__ scores,
+    const d2amd_nms_gather& G, int* __restrict__ blk_cnt, const int* __restrict__ blk_flag) {
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = blockIdx.x * FIN_THREADS + tid;
+  if (blockIdx.x * FIN_THREADS >= n) return;  // uniform (batched launch: the grid is sized for the largest image)
+  const int o = order_at(order, min(r, n - 1), n);
+  const uint32_t kw = reinterpret_cast<const uint32_t*>(keepbits)[o >> 5];
+  const float sc = scores[o];
+  const bool f = r < n && ((kw >> (o & 31)) & 1u) != 0u;
+  const bool fin = f && sc > -INFINITY;
+  __shared__ int wave_cnt[FIN_THREADS / 64], wave_fin[FIN_THREADS / 64];
+  __shared__ int s_before[2];
+  const unsigned long long bal = __ballot(f), balf = __ballot(fin);
+  if (lane == 0) { wave_cnt[wid] = __builtin_popcountll(bal); wave_fin[wid] = __builtin_popcountll(balf); }
+  __syncthreads();
+  int cnt = 0, cfin = 0, before_w = 0;
 #pragma unroll
-        for (int u = 0; u < GU; u++) {
-          const int e = min(e0 + u * FIN_THREADS, cells - 1);
-          const int j = e / words, q = e - j * words;
-          val[u] = a[(long)s_keep[j] * words + q];
-        }
-#pragma unroll
-        for (int u = 0; u < GU; u++)
-          if (e0 + u * FIN_THREADS < cells) b[e0 + u * FIN_THREADS] = val[u];
-      }
+  for (int w = 0; w < FIN_THREADS / 64; w++) {
+    if (w < wid) before_w += wave_cnt[w];
+    cnt += wave_cnt[w];
+    cfin += wave_fin[w];
+  }
+  // publish {kept + 1, finite} of this chunk (0 = not there yet), then add up the chunks before this one
+  if (tid == 0)
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(blk_cnt) + blockIdx.x,
+                       ((unsigned long long)(unsigned)cfin << 32) | (unsigned)(cnt + 1), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  if (wid == 0) {
+    int bk = 0, bf = 0;
+    for (int j = lane; j < (int)blockIdx.x; j += 64) {
+      unsigned long long v;
+      while (((v = __hip_atomic_load(reinterpret_cast<unsigned long long*>(blk_cnt) + j, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT)) & 0xffffffffull) == 0ull)
+        __builtin_amdgcn_s_sleep(1);
+      bk += (int)(v & 0xffffffffull) - 1;
+      bf += (int)(v >> 32);
     }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { bk += __shfl_xor(bk, d); bf += __shfl_xor(bf, d); }
+    if (lane == 0) { s_before[0] = bk; s_before[1] = bf; }
+  }
+  __syncthreads();
+  const int at = s_before[0] + before_w + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+  if (f) {
+    keep_out[at] = (int64_t)o;
+    if (G.count) gather_rows(G, o, at);
+  }
+  if (blockIdx.x == (unsigned)((n + FIN_THREADS - 1) / FIN_THREADS) - 1 && tid == 0) {
+    int fl2 = counters[1];
+    if (blk_flag)
+      for (int q = 0; q < (n + 255) / 256; q++) fl2 |= blk_flag[q];
+    result[0] = s_before[0] + cnt; result[1] = fl2; result[2] = s_before[1] + cfin; result[3] = 0;
   }
 }
 
@@ -1117,6 +1389,7 @@ struct NmsBatch {
   u64* dbg;
   int count;
   NmsRuns runs;  // n_runs == 0: no pre-sorted runs
+  int order_flags;  // 1: nms_runs_order_small_kernel ran -- its per-workgroup "not in order" words join the flags
   NmsImg img[NMS_MAX_BATCH];
 };
 
@@ -1140,15 +1413,22 @@ template <int PER>
 __global__ __launch_bounds__(RUNS_SCAN_THREADS) void nms_runs_scan_kernel(const NmsBatch B) {
   const NmsImg& I = B.img[blockIdx.z];
   nms_runs_scan_body<PER>(I.scores, B.runs, (uint32_t*)I.w.keys_out, (int*)I.w.cls_r, I.w.run_cnt, (uint32_t*)I.w.keepbits,
-                     (int)(I.w.zero_bytes / 4));
+                          (int)(I.w.zero_bytes / 4), I.n <= RANK_MAX_N ? I.w.blk_cnt : nullptr, 2 * (I.n / 1024 + 2));
+}
+template <int BW>
+__global__ __launch_bounds__(ORDER_THREADS) void nms_runs_order_small_kernel(const NmsBatch B) {
+  const NmsImg& I = B.img[blockIdx.z];
+  nms_runs_order_small_body<BW>(I.boxes, I.scores, I.n, B.runs, I.w.order, I.w.rankpos, I.w.cls_s, I.w.boxes_s,
+                                (uint32_t*)I.w.keepbits, (int)(I.w.zero_bytes / 4), I.w.blk_cnt, 2 * (I.n / 1024 + 2),
+                                I.w.run_cnt + 16, I.idxs ? 0 : 1);
 }
 constexpr int RUNS_RANK_THREADS = 1024;  // every workgroup stages all samples: few, large workgroups
 template <int BW>
 __global__ __launch_bounds__(RUNS_RANK_THREADS) void nms_runs_rank_kernel(const NmsBatch B) {
   const NmsImg& I = B.img[blockIdx.z];
   nms_runs_rank_body<BW>(I.boxes, I.scores, I.n, B.runs, (const uint32_t*)I.w.keys_out, (const int*)I.w.cls_r,
-                         I.w.run_cnt, I.w.order, I.w.rankpos, I.w.cls_s, I.w.boxes_s, I.w.seg_start, I.w.seg_end,
-                         I.w.counters, I.idxs ? 0 : 1);
+                         I.w.run_cnt, I.w.order, I.w.rankpos, I.w.cls_s, I.w.boxes_s, I.w.seg_start, I.w.counters,
+                         I.idxs ? 0 : 1);
 }
 __global__ void nms_segments_kernel(const NmsBatch B) {
   const NmsImg& I = B.img[blockIdx.z];
@@ -1167,12 +1447,18 @@ __global__ __launch_bounds__(64) void nms_mask_rot_kernel(const NmsBatch B) {
 __global__ __launch_bounds__(RED_THREADS) void nms_reduce_kernel(const NmsBatch B) {
   const NmsImg& I = B.img[blockIdx.z];
   nms_reduce_body(I.w.mask, I.w.diagT, I.w.w1T, I.w.w2T, I.cls_s, I.n, I.wcap, I.mpc, I.w.seg_start,
-                  B.runs.are_cls ? I.w.seg_end : nullptr, I.w.counters, I.w.keepbits, blockIdx.z == 0 ? B.dbg : nullptr);
+                  B.runs, B.runs.are_cls != 0, I.w.counters, I.w.keepbits, blockIdx.z == 0 ? B.dbg : nullptr);
 }
+__global__ __launch_bounds__(FIN_THREADS) void nms_finalize_direct_kernel(const NmsBatch B) {
+  const NmsImg& I = B.img[blockIdx.z];
+  nms_finalize_direct_body(I.w.keepbits, I.w.order, I.n, I.keep_out, I.w.counters, I.result, I.scores, I.gather,
+                           I.w.blk_cnt, B.order_flags ? I.w.run_cnt + 16 : nullptr);
+}
+template <bool DIRECT>
 __global__ __launch_bounds__(FIN_THREADS) void nms_finalize_small_kernel(const NmsBatch B) {
   const NmsImg& I = B.img[blockIdx.z];
-  nms_finalize_small_body(I.w.keepbits, I.rankpos, I.w.order, I.n, I.keep_out, I.w.counters, I.result, I.scores,
-                          I.gather);
+  nms_finalize_small_body<DIRECT>(I.w.keepbits, I.rankpos, I.w.order, I.n, I.keep_out, I.w.counters, I.result,
+                                  I.scores, I.gather, B.order_flags ? I.w.run_cnt + 16 : nullptr);
 }
 
 }  // namespace d2amd
@@ -1264,12 +1550,11 @@ static int nms_run_small(NmsBatch& B, int rotated, hipStream_t s) {
   // pre-sorted runs: the order comes from one scan + one binary-search kernel.  (Runs + the caller's class ids on
   // this path would still need the class-major positions: the brute-force ranking below provides both.)
   const bool by_runs = B.runs.n_runs > 0 && (B.runs.are_cls || !any_cls);
-  if (by_runs) {
-    hipLaunchKernelGGL(nms_runs_scan_kernel<4>, dim3(B.runs.n_runs, 1, B.count), dim3(RUNS_SCAN_THREADS), 0, s, B);
-    D2_LAUNCH_OK();
-    const dim3 rgrid(cdiv(n_max, RUNS_RANK_THREADS), 1, B.count);
-    if (rotated) hipLaunchKernelGGL((nms_runs_rank_kernel<5>), rgrid, dim3(RUNS_RANK_THREADS), 0, s, B);
-    else hipLaunchKernelGGL((nms_runs_rank_kernel<4>), rgrid, dim3(RUNS_RANK_THREADS), 0, s, B);
+  if (by_runs) {  // scan + rank + records + zeroing: one launch
+    B.order_flags = 1;
+    const dim3 ogrid(cdiv(n_max, ORDER_THREADS), 1, B.count);
+    if (rotated) hipLaunchKernelGGL((nms_runs_order_small_kernel<5>), ogrid, dim3(ORDER_THREADS), 0, s, B);
+    else hipLaunchKernelGGL((nms_runs_order_small_kernel<4>), ogrid, dim3(ORDER_THREADS), 0, s, B);
     D2_LAUNCH_OK();
     any_cls = B.runs.are_cls != 0;
   } else {
@@ -1290,7 +1575,10 @@ static int nms_run_small(NmsBatch& B, int rotated, hipStream_t s) {
   }
   const int rc = nms_mask_reduce(B, rotated, any_cls, s);
   if (rc != D2AMD_OK) return rc;
-  hipLaunchKernelGGL(nms_finalize_small_kernel, dim3(1, 1, B.count), dim3(FIN_THREADS), 0, s, B);
+  if (by_runs && B.runs.are_cls)  // class-major position == row: order[r] is also the kept bit's position
+    hipLaunchKernelGGL(nms_finalize_direct_kernel, dim3(cdiv(n_max, FIN_THREADS), 1, B.count), dim3(FIN_THREADS), 0, s, B);
+  else
+    hipLaunchKernelGGL(nms_finalize_small_kernel<false>, dim3(1, 1, B.count), dim3(FIN_THREADS), 0, s, B);
   D2_LAUNCH_OK();
   return D2AMD_OK;
 }

@@ -2,7 +2,7 @@
 # One GPU visit for the round's evidence: full GPU suite, the three bench workloads (+ NCHW), rocprofv3 kernel stats of
 # each.  Everything lands in gpurun_out/$1/ (copy what is to be judged into profiles/).
 O=gpurun_out/${1:-round}; mkdir -p $O
-(time python -m pytest tests -m gpu -x -q) > $O/pytest_gpu.log 2>&1; tail -2 $O/pytest_gpu.log
+(time timeout 900 python -m pytest tests -m gpu -x -q) > $O/pytest_gpu.log 2>&1; tail -2 $O/pytest_gpu.log
 for wl in maskrcnn_train retinanet_100k dcn_r50; do
   timeout 900 python bench.py --workload $wl > $O/bench_$wl.json 2> $O/bench_$wl.err; echo "rc=$? $wl"
 done

@@ -187,3 +187,51 @@ def test_C_shim_has_the_reference_extension_surface():
     with pytest.raises(RuntimeError):  # CPU tensors: AT_ERROR("Not compiled with GPU support") / TORCH_CHECK
         shim.deform_conv_forward(torch.zeros(1, 1, 3, 3), torch.zeros(1, 1, 3, 3), torch.zeros(1, 18, 3, 3),
                                  torch.zeros(1), torch.zeros(1), torch.zeros(1), 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 64)
+
+
+def test_no_kernel_spills_to_scratch_memory(tmp_path):
+    """Every gfx950 kernel of libd2amd.so (rocprim's aside) has private_segment_fixed_size 0.  Twice in round 2 a
+    change that looked harmless put a kernel on scratch memory and made it 5-20 x slower without failing anything:
+    a 16-way unrolled search under the default 128-VGPR cap (spills), and a pointer / per-lane index into the by-value
+    kernel-argument struct (the compiler then copies the struct to the stack).  The metadata is in the code objects."""
+    import shutil
+    import struct
+    import subprocess
+
+    readelf = shutil.which("llvm-readelf") or "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not os.path.exists(readelf):
+        pytest.skip("llvm-readelf not available")
+    from detectron2_amd import build as d2build
+
+    data = open(d2build.LIB, "rb").read()
+    magic, pos, kernels = b"__CLANG_OFFLOAD_BUNDLE__", 0, {}
+    while True:
+        off = data.find(magic, pos)
+        if off < 0:
+            break
+        pos = off + len(magic)
+        (n,) = struct.unpack_from("<Q", data, off + 24)
+        p = off + 32
+        for _ in range(n):
+            o, sz, ts = struct.unpack_from("<QQQ", data, p)
+            triple = data[p + 24:p + 24 + ts]
+            p += 24 + ts
+            if b"gfx950" not in triple or sz == 0:
+                continue
+            co = tmp_path / f"co_{off}.elf"
+            co.write_bytes(data[off + o:off + o + sz])
+            out = subprocess.run([readelf, "--notes", str(co)], capture_output=True, text=True).stdout
+            name = None
+            for line in out.splitlines():
+                line = line.strip()
+                if line.startswith(".name:"):
+                    name = line.split(":", 1)[1].strip()
+                elif line.startswith(".private_segment_fixed_size:") and name is not None:
+                    kernels[name] = int(line.split(":", 1)[1])
+    ours = {k: v for k, v in kernels.items() if "d2amd" in k and "rocprim" not in k}
+    assert len(ours) > 100, len(ours)  # the parse found the kernels
+    # known: the register-gather fallback of the pooler backward (v2-v7 kernel, kept for channel counts that are not
+    # 16-B vectorisable: <= 228 B under its 128-VGPR cap) and the polygon rasteriser (20 B)
+    known = ("pool_bwd_nhwc_kernel", "polygon_crop_kernel")
+    spilled = {k: v for k, v in ours.items() if v != 0 and not any(n in k for n in known)}
+    assert not spilled, spilled
