@@ -1726,40 +1726,65 @@ __global__ __launch_bounds__(1024) void roi_order_kernel(PoolLevels L, ImgBoxes 
                                                         int* __restrict__ perm) {
   __shared__ int hist[ROI_BUCKETS];  // counts, then exclusive offsets
   __shared__ int wtot[16];
+  __shared__ float s_scale[POOL_MAX_LEVELS];
+  __shared__ int s_sh[POOL_MAX_LEVELS];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  for (int i = tid; i < ROI_BUCKETS; i += 1024) hist[i] = 0;
-  __syncthreads();
   constexpr int PER = ROI_ORDER_MAX / 1024;
   int bucket[PER], at[PER];
   int lb = 0, ib = 0;  // bits of the level / image number (uniform)
   while ((1 << lb) < L.num_levels) lb++;
   while ((1 << ib) < L.N) ib++;
   const int hb = min(5, (14 - lb - ib) >> 1);  // bits per cell coordinate (L.N <= 32, levels <= 8: >= 3)
+  const int used = 1 << (lb + ib + 2 * hb);    // buckets in use (<= ROI_BUCKETS)
+  // the boxes first: their round trip overlaps the zeroing
+  float4 bx[PER];
+  int bimg[PER];
+#pragma unroll
+  for (int q = 0; q < PER; q++) {
+    const int k = tid + q * 1024;
+    bx[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    bimg[q] = 0;
+    if (k < K) {
+      if (LISTS) {
+        int b = 0;
+        for (int i = 0; i < e.n; i++) b += (k >= e.end[i]) ? 1 : 0;
+        bx[q] = reinterpret_cast<const float4*>(e.ptr[b])[k - (b ? e.end[b - 1] : 0)];
+        bimg[q] = b;
+      } else {
+        const float* r = rois + (long)k * 5;
+        bimg[q] = (int)r[0];
+        bx[q] = make_float4(r[1], r[2], r[3], r[4]);
+      }
+    }
+  }
+  for (int i = tid; i < used; i += 1024) hist[i] = 0;
+  if (tid < POOL_MAX_LEVELS) {  // per level: scale and cell size 2^sh feature pixels (the larger side spans < 2^hb cells)
+    int hmax = 1, sh = 0;
+    float sc = 0.f;
+#pragma unroll
+    for (int l = 0; l < POOL_MAX_LEVELS; l++)
+      if (l == tid) { hmax = max(L.H[l], L.W[l]); sc = L.scale[l]; }
+    while ((hmax >> sh) >= (1 << hb)) sh++;
+    s_scale[tid] = sc;
+    s_sh[tid] = sh;
+  }
+  __syncthreads();
 #pragma unroll
   for (int q = 0; q < PER; q++) {
     const int k = tid + q * 1024;
     bucket[q] = -1;
     if (k < K) {
-      float box[4];
-      int img;
+      const float4 v = bx[q];
+      const int img = bimg[q];
       if (LISTS) {
-        int b = 0;
-        for (int i = 0; i < e.n; i++) b += (k >= e.end[i]) ? 1 : 0;
-        const float4 v = reinterpret_cast<const float4*>(e.ptr[b])[k - (b ? e.end[b - 1] : 0)];
         float* o = rois + (long)k * 5;
-        o[0] = (float)b; o[1] = v.x; o[2] = v.y; o[3] = v.z; o[4] = v.w;
-        box[0] = v.x; box[1] = v.y; box[2] = v.z; box[3] = v.w;
-        img = b;
-      } else {
-        const float* r = rois + (long)k * 5;
-        img = (int)r[0];
-        box[0] = r[1]; box[1] = r[2]; box[2] = r[3]; box[3] = r[4];
+        o[0] = (float)img; o[1] = v.x; o[2] = v.y; o[3] = v.z; o[4] = v.w;
       }
+      const float box[4] = {v.x, v.y, v.z, v.w};
       int lvl = assign_level(box, L);
       if (lvl < 0) lvl = L.num_levels - 1;  // no level: pooled as zeros, anywhere
-      const float sc = L.scale[lvl];
-      int sh = 0;  // cell size 2^sh feature pixels: the level's larger side spans < 2^hb cells
-      while ((max(L.H[lvl], L.W[lvl]) >> sh) >= (1 << hb)) sh++;
+      const float sc = s_scale[lvl];
+      const int sh = s_sh[lvl];
       const int tx = min(max((int)((box[0] + box[2]) * 0.5f * sc) >> sh, 0), (1 << hb) - 1);
       const int ty = min(max((int)((box[1] + box[3]) * 0.5f * sc) >> sh, 0), (1 << hb) - 1);
       int mort = 0;
@@ -1774,7 +1799,7 @@ __global__ __launch_bounds__(1024) void roi_order_kernel(PoolLevels L, ImgBoxes 
   constexpr int BPT = ROI_BUCKETS / 1024;
   int c[BPT], sum = 0;
 #pragma unroll
-  for (int j = 0; j < BPT; j++) { c[j] = hist[tid * BPT + j]; sum += c[j]; }
+  for (int j = 0; j < BPT; j++) { c[j] = tid * BPT + j < used ? hist[tid * BPT + j] : 0; sum += c[j]; }
   int incl = sum;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -1786,7 +1811,10 @@ __global__ __launch_bounds__(1024) void roi_order_kernel(PoolLevels L, ImgBoxes 
   int run = incl - sum;
   for (int w = 0; w < wid; w++) run += wtot[w];
 #pragma unroll
-  for (int j = 0; j < BPT; j++) { hist[tid * BPT + j] = run; run += c[j]; }
+  for (int j = 0; j < BPT; j++) {
+    if (tid * BPT + j < used) hist[tid * BPT + j] = run;
+    run += c[j];
+  }
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < PER; q++)
