@@ -116,3 +116,41 @@ def test_large_nms_side_streams_outside_capture_still_work():
     k1 = batched_nms_images(inp, 0.5)
     k2 = batched_nms_images(inp, 0.5)
     assert torch.equal(k1[0], k2[0]) and torch.equal(k1[0], k1[1])
+
+
+def test_forked_branches_eager_and_captured():
+    """detectron2_amd.streams.fork_join: the RPN's proposal path and its anchor labelling on two streams -- same
+    results as one after the other, eagerly and as the forked branches of a captured graph (bench.py's graph A)."""
+    from detectron2_amd.streams import fork_join
+
+    torch.manual_seed(1)
+    sizes = [5000, 1200, 300]
+    anchors, logits, deltas = [], [], []
+    for l, a in enumerate(sizes):
+        c = torch.rand(a, 2) * torch.tensor([320.0, 256.0])
+        wh = 24.0 * 2 ** l * torch.exp(torch.rand(a, 2) - 0.5)
+        anchors.append(torch.cat([c - wh / 2, c + wh / 2], 1).to(DEV))
+        logits.append((torch.randn(2, a) + torch.arange(a) * 1e-6).to(DEV))
+        deltas.append((torch.randn(2, a, 4) * 0.2).to(DEV))
+    hw = [(256, 320)] * 2
+    gt = [torch.tensor([[10.0, 20, 100, 120], [150, 60, 300, 200]], device=DEV),
+          torch.tensor([[40.0, 40, 90, 200]], device=DEV)]
+    mt = Matcher([0.3, 0.7], [0, -1, 1], allow_low_quality_matches=True)
+    allanc = torch.cat(anchors)
+    rpn = lambda: find_top_rpn_proposals_fused(anchors, logits, deltas, hw, 0.7, 400, 150, 0.0, True, defer=True)
+    lab = lambda: [mt.match_boxes(g, allanc) for g in gt]
+    want_p, want_l = rpn()(), lab()
+
+    def same(props, labels):
+        for a, b in zip(props, want_p):
+            assert torch.equal(a.proposal_boxes.tensor, b.proposal_boxes.tensor)
+            assert torch.equal(a.objectness_logits, b.objectness_logits)
+        for (m, l), (wm, wl) in zip(labels, want_l):
+            assert torch.equal(m, wm) and torch.equal(l, wl)
+
+    labels, done = fork_join(lab, rpn)
+    same(done(), labels)
+    g, (labels, done) = _capture(lambda: fork_join(lab, rpn))
+    for _ in range(3):
+        g.replay()
+        same(done(), labels)
