@@ -1869,20 +1869,36 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_weight_tc_kernel(DcnShape s, B
       if (k + 1 < k_hi) compute(k + 1, e1, g1, a1);
     }
   }
-  // ---- fp32 atomics into gwr[g][tap][co][ci]
-  float* dst = a.gwr + (((long)g * s.K2 + tap) * s.Cog) * s.Cg + (cabs - g * s.Cg);
+  // ---- the 4 waves of the workgroup hold partial sums of the SAME 64 x 64 tile (4 consecutive position chunks: the
+  // split over positions is what fills the chip -- 36 tiles for res3).  They are added up in LDS first and each wave
+  // sends one quarter of the tile to memory: a quarter of the device-scope fp32 atomics (9.4 M per call before,
+  // whatever the shape; the kernel time grows with the number of chunks: 92 / 127 / 210 / 395 us at 16 / 32 / 64 / 128
+  // chunks for all blocks).  143 -> 128 us on average over the 13 blocks of R50.
+  // (Also tried in r02: materialising the column once -- [b][tap][c][L], position-contiguous like dY -- and
+  // contracting from it with 16-B loads only: column writer 55 us + contraction 80 us, L2-bandwidth bound at 32
+  // flop/B per wave; not faster than gathering inside the contraction, removed.)
+  __shared__ float red[4][4096];
 #pragma unroll
   for (int m = 0; m < 2; m++)
 #pragma unroll
     for (int n = 0; n < 2; n++)
 #pragma unroll
-      for (int q = 0; q < 16; q++) {
-        const int co = co0 + m * 32 + frag_row(q, lane);
-        if (co < s.Cog) {
-          if (AB & 16) { if (acc[m][n][q] == 123.456f) dst[0] = 1.f; }
-          else atomicAdd(dst + (long)co * s.Cg + n * 32 + n32, acc[m][n][q]);
-        }
+      for (int q = 0; q < 16; q++) red[wid][((m * 2 + n) * 16 + q) * 64 + lane] = acc[m][n][q];
+  __syncthreads();
+  {
+    const int m = wid >> 1, n = wid & 1;  // this wave's quarter: block (m, n) of the tile
+    float* dst = a.gwr + (((long)g * s.K2 + tap) * s.Cog) * s.Cg + (cabs - g * s.Cg);
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      const int e = (wid * 16 + q) * 64 + lane;
+      const float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+      const int co = co0 + m * 32 + frag_row(q, lane);
+      if (co < s.Cog) {
+        if (AB & 16) { if (v == 123.456f) dst[0] = 1.f; }
+        else atomicAdd(dst + (long)co * s.Cg + n * 32 + n32, v);
       }
+    }
+  }
 }
 
 TcBwwPlan dcn_tc_plan_bww(const DcnShape& s, int dtype) {
