@@ -97,9 +97,9 @@ _SIGNATURES = {
     "d2amd_nms": (_i, [_vp, _vp, _vp, _i64, _d, _i, _i64, _vp, _vp, _vp, _sz, _vp]),
     "d2amd_nms_batched": (_i, [_i, _vp, _vp, _vp, _vp, _d, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "d2amd_nms_batched_max_boxes": (_i, []),
-    "d2amd_nms_runs": (_i, [_vp, _vp, _vp, _i64, ctypes.POINTER(_i), _i, _i, _d, _i, _i64, _vp, _vp, _vp, _sz, _vp,
+    "d2amd_nms_runs": (_i, [_vp, _vp, _vp, _i64, ctypes.POINTER(_i), _i, _i, _i, _d, _i, _i64, _vp, _vp, _vp, _sz, _vp,
                             _vp]),
-    "d2amd_nms_batched_runs": (_i, [_i, _vp, _vp, _vp, _vp, ctypes.POINTER(_i), _i, _i, _d, _i, _vp, _vp, _vp, _vp,
+    "d2amd_nms_batched_runs": (_i, [_i, _vp, _vp, _vp, _vp, ctypes.POINTER(_i), _i, _i, _i, _d, _i, _vp, _vp, _vp, _vp,
                                     _vp, _vp, _vp]),
     "d2amd_paste_masks": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _i, _vp]),
     "d2amd_bitmask_crop_and_resize": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),

@@ -268,7 +268,7 @@ __device__ __forceinline__ void nms_segments_body(const uint32_t* __restrict__ c
 //                   so the box records and segment starts are written here and nothing else is left of step 1.
 // Scores are compared through the same order-preserving integer key as everywhere else (NaN first, -0 below +0).
 // A run that is not in order is detected (flag bit 2 of the result's flags): the host then ranks from scratch.
-struct NmsRuns { int n_runs, are_cls; int off[NMS_MAX_RUNS + 1]; };
+struct NmsRuns { int n_runs, are_cls; int off[NMS_MAX_RUNS + 1]; int cat_bits; };  // cat_bits: host only (class sort)
 
 __device__ __forceinline__ uint32_t run_key(float s) {  // ascending = descending score
   uint32_t u = __float_as_uint(s);
@@ -1664,7 +1664,7 @@ static int nms_batched_impl(int count, const float* const* boxes, const float* c
   return D2AMD_OK;
 }
 
-static int nms_runs_arg(NmsRuns& R, const int* run_offsets, int n_runs, int runs_are_categories) {
+static int nms_runs_arg(NmsRuns& R, const int* run_offsets, int n_runs, int runs_are_categories, int num_categories) {
   D2_CHECK_ARG(run_offsets && n_runs >= 1 && n_runs <= NMS_MAX_RUNS, "nms: %d pre-sorted runs (1..%d)", n_runs,
                NMS_MAX_RUNS);
   memset(&R, 0, sizeof(R));
@@ -1676,6 +1676,11 @@ static int nms_runs_arg(NmsRuns& R, const int* run_offsets, int n_runs, int runs
     R.off[r] = run_offsets[r];
   }
   for (int r = n_runs + 1; r <= NMS_MAX_RUNS; r++) R.off[r] = run_offsets[n_runs];
+  D2_CHECK_ARG(num_categories >= 0 && num_categories <= 65536, "nms: num_categories %d not in [0, 65536]", num_categories);
+  R.cat_bits = 0;
+  if (num_categories > 0)
+    while ((1 << R.cat_bits) < num_categories) R.cat_bits++;
+  if (num_categories == 1) R.cat_bits = 1;
   return D2AMD_OK;
 }
 
@@ -1689,12 +1694,12 @@ extern "C" int d2amd_nms_batched(int count, const float* const* boxes, const flo
 
 extern "C" int d2amd_nms_batched_runs(int count, const float* const* boxes, const float* const* scores,
                                       const int64_t* const* idxs, const int64_t* n, const int* run_offsets,
-                                      int n_runs, int runs_are_categories, double iou_threshold, int rotated,
-                                      const int64_t* max_per_class, int64_t* const* keep_out,
+                                      int n_runs, int runs_are_categories, int num_categories, double iou_threshold,
+                                      int rotated, const int64_t* max_per_class, int64_t* const* keep_out,
                                       int64_t* const* result, void* const* workspace, const size_t* workspace_bytes,
                                       const d2amd_nms_gather* gather, void* stream) {
   NmsRuns R;
-  const int rc = nms_runs_arg(R, run_offsets, n_runs, runs_are_categories);
+  const int rc = nms_runs_arg(R, run_offsets, n_runs, runs_are_categories, num_categories);
   if (rc) return rc;
   D2_CHECK_ARG(!(runs_are_categories && idxs), "nms_batched_runs: runs are the categories: idxs must be null");
   return nms_batched_impl(count, boxes, scores, idxs, n, iou_threshold, rotated, max_per_class, keep_out, result,
@@ -1760,8 +1765,10 @@ static int nms_impl(const float* boxes, const float* scores, const int64_t* idxs
     hipLaunchKernelGGL(nms_gather_cls_kernel, dim3(cdiv(N, T)), dim3(T), 0, s, idxs, w.order, N, w.cls_r, w.counters);
     D2_LAUNCH_OK();
     size_t tb = w.sort_temp_bytes;
-    D2_HIP_OK(rocprim::radix_sort_pairs(w.sort_temp, tb, w.cls_r, w.cls_s, w.iota, w.rankpos, (unsigned)N, 0, 16, s,
-                                        false));
+    // (a caller that knows its number of categories -- 80 classes: 7 bits -- saves the sort its second 8-bit pass)
+    const unsigned cat_bits = runs && runs->cat_bits > 0 ? (unsigned)runs->cat_bits : 16u;
+    D2_HIP_OK(rocprim::radix_sort_pairs(w.sort_temp, tb, w.cls_r, w.cls_s, w.iota, w.rankpos, (unsigned)N, 0, cat_bits,
+                                        s, false));
   }
   if (!runs || idxs) {  // (runs without class ids: the rank kernel has written the records)
     if (rotated)
@@ -1793,12 +1800,13 @@ extern "C" int d2amd_nms(const float* boxes, const float* scores, const int64_t*
 }
 
 extern "C" int d2amd_nms_runs(const float* boxes, const float* scores, const int64_t* idxs, int64_t n,
-                              const int* run_offsets, int n_runs, int runs_are_categories, double iou_threshold,
-                              int rotated, int64_t max_per_class, int64_t* keep_out, int64_t* result,
+                              const int* run_offsets, int n_runs, int runs_are_categories, int num_categories,
+                              double iou_threshold, int rotated, int64_t max_per_class, int64_t* keep_out,
+                              int64_t* result,
                               void* workspace, size_t workspace_bytes, const d2amd_nms_gather* gather,
                               void* stream) {
   NmsRuns R;
-  const int rc = nms_runs_arg(R, run_offsets, n_runs, runs_are_categories);
+  const int rc = nms_runs_arg(R, run_offsets, n_runs, runs_are_categories, num_categories);
   if (rc) return rc;
   return nms_impl(boxes, scores, idxs, n, iou_threshold, rotated, max_per_class, keep_out, result, workspace,
                   workspace_bytes, &R, gather, (hipStream_t)stream);

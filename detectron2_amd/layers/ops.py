@@ -21,10 +21,11 @@ _DEFS = {
 
 
 def _runs_arg(runs):
-    """(run_offsets, runs_are_categories) -> ctypes arguments of the d2amd_nms*_runs entries."""
-    off, are_cls = runs
+    """(run_offsets, runs_are_categories[, num_categories]) -> ctypes arguments of the d2amd_nms*_runs entries."""
+    off, are_cls = runs[0], runs[1]
+    ncat = int(runs[2]) if len(runs) > 2 and runs[2] else 0
     off = [int(v) for v in off]
-    return (_C.ctypes.c_int * len(off))(*off), len(off) - 1, int(bool(are_cls))
+    return (_C.ctypes.c_int * len(off))(*off), len(off) - 1, int(bool(are_cls)), ncat
 
 
 def _gather_arg(srcs):
@@ -97,8 +98,8 @@ def _nms_launch(boxes, scores, idxs, iou_threshold, rotated, stream_ptr=None, ru
             _C.check(L.d2amd_nms(_C.ptr(boxes), _C.ptr(scores), _C.ptr(idxs), n, float(iou_threshold), int(rotated),
                                  max_per_class, _C.ptr(keep), _C.ptr(result), _C.ptr(ws), ws_bytes, st))
         else:
-            off, n_runs, are_cls = _runs_arg(runs)
-            _C.check(L.d2amd_nms_runs(_C.ptr(boxes), _C.ptr(scores), _C.ptr(idxs), n, off, n_runs, are_cls,
+            off, n_runs, are_cls, ncat = _runs_arg(runs)
+            _C.check(L.d2amd_nms_runs(_C.ptr(boxes), _C.ptr(scores), _C.ptr(idxs), n, off, n_runs, are_cls, ncat,
                                       float(iou_threshold), int(rotated), max_per_class, _C.ptr(keep),
                                       _C.ptr(result), _C.ptr(ws), ws_bytes,
                                       _C.ctypes.byref(gather) if gather is not None else None, st))
@@ -207,15 +208,15 @@ def _nms_images_batched(inputs, iou_threshold, rotated, defer=False, runs=None, 
                                          float(iou_threshold), int(rotated), None, arr(pk), arr(pr), arr(pw),
                                          (ct.c_size_t * cnt)(*wb), _C.stream()))
         else:
-            off, n_runs, are_cls = _runs_arg(runs)
+            off, n_runs, are_cls, ncat = _runs_arg(runs)
             garr = None
             if gather is not None:
                 gs = [_gather_arg(g) for g in gather]
                 garr = (_C.NmsGather * cnt)(*[g[0] for g in gs])
                 gathered.extend((g[1], g[2]) for g in gs)
             _C.check(L.d2amd_nms_batched_runs(cnt, arr(pb), arr(ps), None if are_cls else arr(pi),
-                                              (ct.c_int64 * cnt)(*ns), off, n_runs, are_cls, float(iou_threshold),
-                                              int(rotated), None, arr(pk), arr(pr), arr(pw),
+                                              (ct.c_int64 * cnt)(*ns), off, n_runs, are_cls, ncat,
+                                              float(iou_threshold), int(rotated), None, arr(pk), arr(pr), arr(pw),
                                               (ct.c_size_t * cnt)(*wb), garr, _C.stream()))
     # result_buffer: the copy to the host is ENQUEUED here, into pinned memory, right behind the kernels (inside a
     # captured graph: a memcpy node); the host then only waits for the stream -- a blocking .tolist() is a
@@ -261,7 +262,7 @@ def _nms_images_batched(inputs, iou_threshold, rotated, defer=False, runs=None, 
 
 def nms_images(inputs, iou_threshold, rotated=False, defer=False, runs=None, gather=None, result_buffer=None):
     """NMS of every image of a batch in one call: `inputs` = [(boxes, scores, idxs | None), ...].
-    runs = (run_offsets, runs_are_categories), the same for every image: the rows are pre-sorted runs (per-level
+    runs = (run_offsets, runs_are_categories[, num_categories]), the same for every image: the rows are pre-sorted runs (per-level
     top-k lists; d2amd_nms_runs) -- with runs_are_categories the idxs of `inputs` are ignored (pass None).
     gather (with runs and defer): per image, up to 4 tensors [n, ...] whose kept rows are wanted in keep order; the
     returned callable carries them as `.gathered` (per image, full length: valid up to the kept count).

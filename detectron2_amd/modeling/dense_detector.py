@@ -110,7 +110,7 @@ def dense_detector_inference_fused(anchors, pred_logits, pred_anchor_deltas, ima
     if n == 0:
         return []
     nms_done = batched_nms_images([(boxes[i], rank[i], classes[i]) for i in range(n)], nms_thresh, defer=True,
-                                  runs=(run_offsets, False),
+                                  runs=(run_offsets, False, int(pred_logits[0].shape[-1])),
                                   gather=[(boxes[i], scores[i], classes[i]) for i in range(n)])
     keeps, n_finite, _ = nms_done(with_finite=True)  # the one sync
     out = []

@@ -306,13 +306,16 @@ typedef struct {
   void* dst[4];
   int row_bytes[4];
 } d2amd_nms_gather;
+/* num_categories: 0 = unknown, else the category ids are < num_categories (the class sort of large inputs then
+ * covers only the bits in use: 80 classes = one 8-bit pass instead of two; ids beyond it are the caller's error). */
 int d2amd_nms_runs(const float* boxes, const float* scores, const int64_t* idxs, int64_t n, const int* run_offsets,
-                   int n_runs, int runs_are_categories, double iou_threshold, int rotated, int64_t max_per_class,
-                   int64_t* keep_out, int64_t* result, void* workspace, size_t workspace_bytes,
+                   int n_runs, int runs_are_categories, int num_categories, double iou_threshold, int rotated,
+                   int64_t max_per_class, int64_t* keep_out, int64_t* result, void* workspace, size_t workspace_bytes,
                    const d2amd_nms_gather* gather, void* stream);
 int d2amd_nms_batched_runs(int count, const float* const* boxes, const float* const* scores,
                            const int64_t* const* idxs, const int64_t* n, const int* run_offsets, int n_runs,
-                           int runs_are_categories, double iou_threshold, int rotated, const int64_t* max_per_class,
+                           int runs_are_categories, int num_categories, double iou_threshold, int rotated,
+                           const int64_t* max_per_class,
                            int64_t* const* keep_out, int64_t* const* result, void* const* workspace,
                            const size_t* workspace_bytes, const d2amd_nms_gather* gather, void* stream);
 
