@@ -968,6 +968,12 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints its version banner to the C
+    # stdout when the first communicator is created, and the buffer is flushed at exit: behind the JSON line), so the
+    # real stdout is kept aside for that line and file descriptor 1 is pointed at stderr for everything else.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks")
     gpu = args.backend == "nccl"
@@ -995,7 +1001,8 @@ def main():
     else:
         out = {"maskrcnn_train": bench_maskrcnn, "retinanet_100k": bench_retinanet, "dcn_r50": bench_dcn}[args.workload](args, ctx)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
