@@ -8,14 +8,16 @@
 //      ~8 us at n = 8,819) and scatters itself straight to its class-major / score-descending
 //      slot; this replaces two radix sorts + three gather kernels (rocPRIM takes its merge-sort
 //      path at this size: 8 launches, ~90 us).  Larger n: stable radix sort by score, then by
-//      category (16 bits), then gathers.
+//      category (16 bits), then gathers.  Callers whose input consists of pre-sorted RUNS (the per-level top-k
+//      lists of the RPN / dense detectors: d2amd_nms_runs) get the order from a merge instead -- step 1c below;
+//      for the RPN (runs = categories, n <= 12,288) the whole pipeline is 4 launches.
 //   2. wavefront bitmask kernel: one 64-lane wave per 64x64 tile of the (sorted) IoU matrix,
 //        lane = row box, one uint64 word per lane; only tiles on/above the diagonal whose
 //        category ranges overlap are evaluated (pair count = sum_c n_c^2/2, not N^2/2).
 //        Diagonal tiles also emit the TRANSPOSED word (which earlier boxes of the tile suppress
 //        this one), which turns step 3's diagonal resolution into a lane-parallel fixed point.
 //   3. greedy reduction: one workgroup per category segment; see nms_reduce_kernel.
-//   4. ordered compaction back to rank order -> original indices, count.
+//   4. ordered compaction back to rank order -> original indices, count (+ the kept rows of up to 4 caller arrays).
 // Bit-exactness: IoU arithmetic is evaluated exactly as torchvision's CPU nms / the reference's
 // nms_rotated_cpu.cpp (fp32, no FMA contraction, IEEE divide, threshold compare in double).
 #pragma clang fp contract(off)

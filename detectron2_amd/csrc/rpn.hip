@@ -3,8 +3,9 @@
 //             modeling/box_regression.py:71-116 (Box2BoxTransform.apply_deltas) and
 //             proposal_generator/proposal_utils.py:62-120 (per-level logits.topk + gather, isfinite
 //             filter, Boxes.clip, Boxes.nonempty) -- a Python loop over levels plus one over images.
-// Here: one stable radix sort of (image, level | objectness) keys ranks every anchor inside its
-// (image, level) segment; one kernel then decodes ONLY the pre_nms_topk selected anchors per segment
+// Here: a segmented radix select (topk.hip; pre_nms_topk > 65,536: one stable radix sort of (image, level |
+// objectness) keys) ranks the best anchors of every (image, level) segment -- on the head's per-level tensors as
+// they are, or on concatenated arrays --; one kernel then decodes ONLY the pre_nms_topk selected anchors per segment
 // (the reference decodes all 268,569 per image and throws 97 % away), clips them to the image and
 // flags the valid ones.  No host sync; the NMS that follows takes the outputs as they are (invalid
 // rows are parked as zero-area boxes with score -inf, which neither suppress nor get suppressed).

@@ -11,7 +11,10 @@
 //        the lowest element index are taken: the selection is deterministic;
 //   5.   one compaction pass writes the <= k selected (key, index) pairs;
 //   6.   one workgroup per segment orders them in LDS (bitonic, 64-bit keys = score key : index).
-// Every pass reads 4 B per element (HBM bound); nothing synchronises with the host.
+// Every pass reads 4 B per element (HBM bound); nothing synchronises with the host.  Launches whose workgroups are
+// all resident at once (the RPN: 138) run steps 1-5 as ONE kernel (tk_fused_kernel): the chunk stays in registers and
+// the workgroups of a segment meet at barriers built on device-scope atomics -- without device-scope fences, which
+// write the XCD's L2 back on this part.
 #include <cmath>
 
 #include "topk.h"
