@@ -442,3 +442,36 @@ def test_binning_beside_the_forward_gives_the_same_gradients(monkeypatch):
     for mode in ("chained", "all"):
         for a, b in zip(res["none"], res[mode]):
             assert torch.equal(a, b), mode
+
+
+def test_ordered_forward_is_the_list_order_forward():
+    """d2amd_roi_pooler_forward_ordered (ROIs pooled in a spatial processing order, K >= 512) and
+    d2amd_roi_pooler_forward (list order) write the same rows, bit for bit: row k is ROI k either way."""
+    import ctypes
+
+    from detectron2_amd import _C
+    from detectron2_amd.modeling import poolers as P
+
+    rng = np.random.default_rng(3)
+    hw = [(100, 168), (50, 84), (25, 42), (13, 21)]
+    _, boxes = make_inputs(rng, 2, 1, 400, 672, 350)  # 700 ROIs
+    n, c = 2, 64
+    xs = [torch.randn(n, c, h, w, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+          for h, w in hw]
+    rois = torch.cat([torch.cat([torch.full((len(b), 1), float(i)), torch.from_numpy(b)], 1)
+                      for i, b in enumerate(boxes)]).float().to(DEV).contiguous()
+    k = rois.shape[0]
+    pooler = ROIPooler(7, SCALES, 0, "ROIAlignV2")
+    cfg = ((7, 7), tuple(SCALES), 0, True, pooler.min_level, pooler.max_level, pooler.canonical_box_size,
+           pooler.canonical_level)
+    p = P._params(cfg, (n, c), hw, _C.dtype_code(xs[0]), _C.NHWC)
+    L = _C.lib()
+    out_a = torch.zeros((k, c, 7, 7), dtype=torch.bfloat16, device=DEV).contiguous(memory_format=torch.channels_last)
+    out_b = torch.zeros_like(out_a)
+    order = torch.empty(k, dtype=torch.int32, device=DEV)
+    _C.check(L.d2amd_roi_pooler_forward(ctypes.byref(p), P._ptr_array(xs), _C.ptr(rois), _C.ptr(out_a), k, _C.stream()))
+    _C.check(L.d2amd_roi_pooler_forward_ordered(ctypes.byref(p), P._ptr_array(xs), _C.ptr(rois), _C.ptr(out_b), k,
+                                                _C.ptr(order), 4 * k, _C.stream()))
+    assert torch.equal(out_a, out_b)
+    perm = order.cpu().numpy()
+    assert sorted(perm.tolist()) == list(range(k))  # a permutation of the ROIs
