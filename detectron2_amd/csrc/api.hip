@@ -20,14 +20,16 @@ void set_error(const char* fmt, ...) {
 
 namespace d2amd {
 // head bytes up to 16-B alignment, 16-B vector stores, tail bytes
-__global__ void zero_bytes_kernel(uint8_t* __restrict__ p, size_t head, size_t nvec, size_t tail) {
+__global__ void zero_bytes_kernel(uint8_t* __restrict__ p, size_t head, size_t nvec, size_t tail, int* word) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+  if (word != nullptr && t == 0) *word = 0;
   if (t < head) p[t] = 0;
   uint4* v = reinterpret_cast<uint4*>(p + head);
   for (size_t i = t; i < nvec; i += stride) v[i] = uint4{0u, 0u, 0u, 0u};
   if (t < tail) p[head + nvec * 16 + t] = 0;
 }
-int zero_async(void* ptr, size_t bytes, hipStream_t s) {
+int zero_async(void* ptr, size_t bytes, hipStream_t s, int* word) {
+  if (bytes == 0 && word != nullptr) { ptr = word; bytes = sizeof(int); word = nullptr; }
   if (bytes == 0) return D2AMD_OK;
   D2_CHECK_ARG(ptr != nullptr, "zero_async: null pointer");
   size_t head = (16 - ((uintptr_t)ptr & 15)) & 15;
@@ -35,7 +37,7 @@ int zero_async(void* ptr, size_t bytes, hipStream_t s) {
   const size_t nvec = (bytes - head) / 16, tail = bytes - head - nvec * 16;
   const size_t blocks = (nvec + 255) / 256;
   hipLaunchKernelGGL(zero_bytes_kernel, dim3((unsigned)(blocks < 1 ? 1 : (blocks < 8192 ? blocks : 8192))), dim3(256), 0, s,
-                     (uint8_t*)ptr, head, nvec, tail);
+                     (uint8_t*)ptr, head, nvec, tail, word);
   D2_LAUNCH_OK();
   return D2AMD_OK;
 }

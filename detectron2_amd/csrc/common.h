@@ -16,7 +16,8 @@ void set_error(const char* fmt, ...);
 // per-call state of multi-kernel ops: under stream capture a memset becomes a graph memset node, and replaying those
 // (ROCm 7.2) did not reliably re-zero the state of the radix select (scripts/graph_dbg.py: replay 2+ of a captured
 // d2amd_rpn_select_proposals selected different rows); a kernel node replays like every other launch.
-int zero_async(void* ptr, size_t bytes, hipStream_t s);
+// `word`: one more int (anywhere) cleared by the same launch
+int zero_async(void* ptr, size_t bytes, hipStream_t s, int* word = nullptr);
 
 // kernel timing aid (api.hip): events on the launch stream around selected kernels when enabled
 bool timing_begin(const char* name, hipStream_t s);

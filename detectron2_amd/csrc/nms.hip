@@ -34,6 +34,7 @@ typedef unsigned long long u64;
 constexpr int RK_GROUP = 8;  // keys per scalar-load group of the ranking kernel (2 x s_load_dwordx16)
 constexpr int RK_JC = 512;   // keys per chunk: one (64-box block, chunk) task is ~2.5k VALU instructions per wave
 constexpr int RANK_MAX_N = 12288;  // brute-force ranking up to here (index must fit 16 bits)
+constexpr int CS_THREADS = 1024, CS_WAVES = CS_THREADS / 64, CS_MAX_WGS = 128;  // counting sort (large inputs)
 constexpr int NMS_MAX_RUNS = 8;    // pre-sorted runs a caller may describe (RPN / dense detectors: one per feature level)
 
 struct NmsWorkspace {
@@ -58,6 +59,7 @@ struct NmsWorkspace {
   int* run_cnt;       // [NMS_MAX_RUNS] entries of a run with a score > -inf (pre-sorted runs path)
   void* sort_temp;
   size_t sort_temp_bytes;
+  int* cs_hist;  // counting sort: [workgroups][256] digit counts
   size_t zero_bytes;  // keepbits + counters
   size_t total;
 };
@@ -109,6 +111,7 @@ static void carve(NmsWorkspace& w, void* base, int64_t n, int wcap) {
   w.run_cnt = (int*)take(64 * 4);  // [0, 8): live entries per run; [16, 16 + 12): "a run is not in order" per order workgroup
   w.sort_temp_bytes = sort_temp_bytes(n);
   w.sort_temp = take(w.sort_temp_bytes);
+  w.cs_hist = (int*)take(n <= RANK_MAX_N ? 0 : (size_t)CS_MAX_WGS * 256 * 4);
   w.total = off;
 }
 
@@ -720,6 +723,157 @@ __global__ void nms_gather_boxes_kernel(const float* __restrict__ boxes, const i
     int pos = atomicAdd(&counters[0], 1);
     seg_start[pos] = p;
   }
+}
+
+// ---- stable counting sort on one 8-bit digit (large inputs: the class sort, the score sort) -----------------------
+// Two launches per digit.  cs_hist_kernel: every workgroup owns a contiguous range of the input and writes its digit
+// histogram (the first pass also MAKES the keys: class ids through order[], or the descending-orderable score bits).
+// cs_place_kernel: a workgroup derives its digit bases from the histogram table (digits below + the same digit in the
+// workgroups before it), then walks its range 1,024 elements at a time: lanes with equal digits find each other with
+// 8 ballots (position among them = the rank inside the wave), the 16 waves' digit counts are prefix-summed per digit
+// in LDS, and every element lands at  base[digit] + waves before + rank in wave  -- stable by construction (workgroup,
+// tile, wave and lane order are all input order).  16-bit class ids take two passes, 32-bit scores four (LSD).
+struct CsPass {
+  const uint32_t* keys_in;  // null in cs_hist_kernel of the first pass: keys are made (-> keys_made)
+  const int* vals_in;       // null: the element's own position
+  uint32_t* keys_out;
+  int* vals_out;
+  int n, shift, per_wg;
+  int* hist;  // [workgroups][256]
+  const int64_t* idxs;  // first pass of the class sort: key = idxs[order[i]] ...
+  const int* order;
+  const float* scores;  // ... of the score sort: key = ~orderable(scores[i]) (ascending key = descending score)
+  uint32_t* keys_made;
+  int* counters;
+};
+
+__global__ __launch_bounds__(CS_THREADS) void cs_hist_kernel(CsPass a) {
+  __shared__ int h[256];
+  const int tid = threadIdx.x, g = blockIdx.x;
+  if (tid < 256) h[tid] = 0;
+  __syncthreads();
+  const int lo = g * a.per_wg, hi = min(a.n, lo + a.per_wg);
+  for (int i = lo + tid; i < hi; i += CS_THREADS) {
+    uint32_t k;
+    if (a.keys_in) {
+      k = a.keys_in[i];
+    } else {
+      if (a.idxs) {
+        int64_t c = a.idxs[order_at(a.order, i, a.n)];
+        if (c < 0 || c > 65535) { atomicOr(&a.counters[1], 2); c = 0; }
+        k = (uint32_t)c;
+      } else {
+        uint32_t u = __float_as_uint(a.scores[i]);
+        u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+        k = ~u;
+      }
+      a.keys_made[i] = k;
+    }
+    atomicAdd(&h[(k >> a.shift) & 255u], 1);
+  }
+  __syncthreads();
+  if (tid < 256) a.hist[g * 256 + tid] = h[tid];
+}
+
+__global__ __launch_bounds__(CS_THREADS) void cs_place_kernel(CsPass a) {
+  __shared__ int base[256], sc[256], wc[CS_WAVES][256], off[CS_WAVES][256];
+  const int tid = threadIdx.x, g = blockIdx.x, G = gridDim.x, lane = tid & 63, w = tid >> 6;
+  for (int i = tid; i < CS_WAVES * 256; i += CS_THREADS) (&wc[0][0])[i] = 0;
+  // digit totals and the counts of the workgroups before this one: 4 threads per digit, each a quarter of the rows
+  // (up to 128 dependent-looking loads per thread otherwise: 15 us of latency)
+  if (tid < 256) { sc[tid] = 0; base[tid] = 0; }
+  __syncthreads();
+  {
+    const int c = tid & 255;
+    int tot = 0, bef = 0;
+#pragma unroll 4
+    for (int j = tid >> 8; j < G; j += CS_THREADS / 256) {
+      const int v = a.hist[j * 256 + c];
+      tot += v;
+      bef += j < g ? v : 0;
+    }
+    atomicAdd(&sc[c], tot);
+    atomicAdd(&base[c], bef);
+  }
+  __syncthreads();
+  const int before = tid < 256 ? base[tid] : 0;
+  if (w == 0) {  // exclusive scan of the 256 digit totals: 4 per lane + a wave scan
+    const int v0 = sc[4 * lane], v1 = sc[4 * lane + 1], v2 = sc[4 * lane + 2], v3 = sc[4 * lane + 3];
+    const int sum = v0 + v1 + v2 + v3;
+    int incl = sum;
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d);
+      if (lane >= d) incl += t;
+    }
+    const int ex = incl - sum;
+    sc[4 * lane] = ex; sc[4 * lane + 1] = ex + v0; sc[4 * lane + 2] = ex + v0 + v1; sc[4 * lane + 3] = ex + v0 + v1 + v2;
+  }
+  __syncthreads();
+  if (tid < 256) base[tid] = sc[tid] + before;
+  __syncthreads();
+  const int lo = g * a.per_wg, hi = min(a.n, lo + a.per_wg);
+  for (int t0 = lo; t0 < hi; t0 += CS_THREADS) {  // uniform
+    const int i = t0 + tid;
+    const bool act = i < hi;
+    const uint32_t k = act ? a.keys_in[i] : 0u;
+    const uint32_t d = (k >> a.shift) & 255u;
+    u64 m = __ballot(act);
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+      const bool bit = (d >> b) & 1u;
+      const u64 bal = __ballot(act && bit);
+      m &= bit ? bal : ~bal;
+    }
+    const int rin = __popcll(m & ((1ull << lane) - 1ull));
+    if (act && rin == 0) wc[w][d] = __popcll(m);
+    __syncthreads();
+    if (tid < 256) {
+      int run = base[tid];
+#pragma unroll
+      for (int x = 0; x < CS_WAVES; x++) {
+        const int v = wc[x][tid];
+        wc[x][tid] = 0;
+        off[x][tid] = run;
+        run += v;
+      }
+      base[tid] = run;
+    }
+    __syncthreads();
+    if (act) {
+      const int pos = off[w][d] + rin;
+      a.keys_out[pos] = k;
+      a.vals_out[pos] = a.vals_in ? a.vals_in[i] : i;
+    }
+  }
+}
+
+// LSD passes over `bits` key bits.  made: where the first pass stores the keys it makes; (tmp_k, tmp_v) the ping-pong
+// partner of (out_k, out_v), which hold the result.  All five buffers are distinct, n elements each.
+static int cs_sort(CsPass a, int bits, uint32_t* made, uint32_t* tmp_k, int* tmp_v, uint32_t* out_k, int* out_v,
+                   hipStream_t s) {
+  const int passes = (bits + 7) / 8;
+  const int wgs0 = std::min(CS_MAX_WGS, cdiv(a.n, CS_THREADS));
+  a.per_wg = cdiv(cdiv(a.n, wgs0), CS_THREADS) * CS_THREADS;
+  const int wgs = cdiv(a.n, a.per_wg);
+  a.keys_made = made;
+  const uint32_t* in_k = nullptr;
+  const int* in_v = nullptr;
+  for (int p = 0; p < passes; p++) {
+    const bool to_out = ((passes - 1 - p) & 1) == 0;
+    a.shift = 8 * p;
+    a.keys_in = in_k;
+    a.vals_in = in_v;
+    a.keys_out = to_out ? out_k : tmp_k;
+    a.vals_out = to_out ? out_v : tmp_v;
+    hipLaunchKernelGGL(cs_hist_kernel, dim3(wgs), dim3(CS_THREADS), 0, s, a);
+    D2_LAUNCH_OK();
+    if (p == 0) a.keys_in = made;
+    hipLaunchKernelGGL(cs_place_kernel, dim3(wgs), dim3(CS_THREADS), 0, s, a);
+    D2_LAUNCH_OK();
+    in_k = a.keys_out;
+    in_v = a.vals_out;
+  }
+  return D2AMD_OK;
 }
 
 // ---- step 2: wavefront bitmask ------------------------------------------------------------
@@ -1744,6 +1898,7 @@ static int nms_impl(const float* boxes, const float* scores, const int64_t* idxs
   NmsWorkspace& w = I.w;
   const int N = (int)n;
   const int T = 256;
+  static const bool use_rocprim = getenv("D2AMD_NMS_ROCPRIM") != nullptr;  // A/B switch: the library radix sorts
   if (runs) {  // order[] from the pre-sorted runs (the scan also zeroes the accumulators)
     hipLaunchKernelGGL(nms_runs_scan_kernel<16>, dim3(std::max(runs->n_runs, 16), 1, 1), dim3(RUNS_SCAN_THREADS), 0, s, B);
     D2_LAUNCH_OK();
@@ -1753,24 +1908,38 @@ static int nms_impl(const float* boxes, const float* scores, const int64_t* idxs
     D2_LAUNCH_OK();
   } else {
     { const int zrc = zero_async(w.keepbits, w.zero_bytes, s); if (zrc) return zrc; }
-    hipLaunchKernelGGL(nms_init_kernel, dim3(cdiv(N, T)), dim3(T), 0, s, w.iota, N);
-    D2_LAUNCH_OK();
-    size_t tb = w.sort_temp_bytes;
-    D2_HIP_OK(rocprim::radix_sort_pairs_desc(w.sort_temp, tb, scores, w.keys_out, w.iota, w.order, (unsigned)N, 0, 32,
-                                             s, false));
-  }
-  if (idxs) {
-    if (runs) {  // the class sort's values
+    if (use_rocprim) {
       hipLaunchKernelGGL(nms_init_kernel, dim3(cdiv(N, T)), dim3(T), 0, s, w.iota, N);
       D2_LAUNCH_OK();
+      size_t tb = w.sort_temp_bytes;
+      D2_HIP_OK(rocprim::radix_sort_pairs_desc(w.sort_temp, tb, scores, w.keys_out, w.iota, w.order, (unsigned)N, 0,
+                                               32, s, false));
+    } else {  // four 8-bit passes; rankpos / cls_r are free until the class sort
+      CsPass a{};
+      a.n = N; a.hist = w.cs_hist; a.scores = scores; a.counters = w.counters;
+      rc = cs_sort(a, 32, (uint32_t*)w.rankpos, w.cls_r, w.iota, (uint32_t*)w.keys_out, w.order, s);
+      if (rc) return rc;
     }
-    hipLaunchKernelGGL(nms_gather_cls_kernel, dim3(cdiv(N, T)), dim3(T), 0, s, idxs, w.order, N, w.cls_r, w.counters);
-    D2_LAUNCH_OK();
-    size_t tb = w.sort_temp_bytes;
+  }
+  if (idxs) {
     // (a caller that knows its number of categories -- 80 classes: 7 bits -- saves the sort its second 8-bit pass)
     const unsigned cat_bits = runs && runs->cat_bits > 0 ? (unsigned)runs->cat_bits : 16u;
-    D2_HIP_OK(rocprim::radix_sort_pairs(w.sort_temp, tb, w.cls_r, w.cls_s, w.iota, w.rankpos, (unsigned)N, 0, cat_bits,
-                                        s, false));
+    if (use_rocprim) {
+      if (runs) {  // the class sort's values
+        hipLaunchKernelGGL(nms_init_kernel, dim3(cdiv(N, T)), dim3(T), 0, s, w.iota, N);
+        D2_LAUNCH_OK();
+      }
+      hipLaunchKernelGGL(nms_gather_cls_kernel, dim3(cdiv(N, T)), dim3(T), 0, s, idxs, w.order, N, w.cls_r, w.counters);
+      D2_LAUNCH_OK();
+      size_t tb = w.sort_temp_bytes;
+      D2_HIP_OK(rocprim::radix_sort_pairs(w.sort_temp, tb, w.cls_r, w.cls_s, w.iota, w.rankpos, (unsigned)N, 0,
+                                          cat_bits, s, false));
+    } else {  // stable by class over the score order: rankpos[p] = rank of the element at class-major position p
+      CsPass a{};
+      a.n = N; a.hist = w.cs_hist; a.idxs = idxs; a.order = w.order; a.counters = w.counters;
+      rc = cs_sort(a, (int)cat_bits, w.cls_r, (uint32_t*)w.keys_out, w.iota, w.cls_s, w.rankpos, s);
+      if (rc) return rc;
+    }
   }
   if (!runs || idxs) {  // (runs without class ids: the rank kernel has written the records)
     if (rotated)

@@ -238,8 +238,7 @@ static int rpn_select_impl(const RpnPtrs& P, const float* concat, int N, int Ato
     }
     uint32_t* sel = (uint32_t*)workspace;
     int* cnt = (int*)((char*)workspace + off_cnt);
-    { const int zrc = zero_async(flags_out, sizeof(int), s); if (zrc) return zrc; }
-    int rc = topk_select(in, false, 0.f, sel, cnt, (char*)workspace + off_tk, workspace_bytes - off_tk, s);
+    int rc = topk_select(in, false, 0.f, sel, cnt, (char*)workspace + off_tk, workspace_bytes - off_tk, s, flags_out);
     if (rc) return rc;
     const long nt = (long)N * k;
     hipLaunchKernelGGL(rpn_decode_kernel, dim3(cdiv(nt, 256)), dim3(256), 0, s, P, (const uint32_t*)nullptr,

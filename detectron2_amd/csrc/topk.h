@@ -26,8 +26,9 @@ size_t topk_workspace_bytes(const TopkInput& in);
 //             equivalent bound on the value itself: logit_lower_bound().
 // Outputs: sel [N][Ktot] element index inside its level (rows [koff[l], koff[l] + cnt) of a segment are valid),
 //          cnt [N][L] selected count per segment.  Nothing synchronises with the host.
+// `clear_word`: one caller-owned int cleared by the launch that clears the workspace (saves the caller a launch).
 int topk_select(const TopkInput& in, bool use_thr, float xmin, uint32_t* sel, int* cnt, void* ws, size_t ws_bytes,
-                hipStream_t s);
+                hipStream_t s, int* clear_word = nullptr);
 
 // Smallest fp32 logit x whose sigmoid exceeds the fp32 threshold `thr` in exact arithmetic:
 // sigmoid(x) > thr  <=>  x > log(thr / (1 - thr)), evaluated once on the host in double.  thr >= 1: none (NaN);
