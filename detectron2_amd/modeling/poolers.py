@@ -218,17 +218,7 @@ _PREBIN_MODE = _os.environ.get("D2AMD_PREBIN", "none")
 
 
 def _PREBIN(head):
-    return _PREBIN_MODE in ("all", "side") or (_PREBIN_MODE == "chained" and not head)
-
-
-_BIN_STREAMS = {}
-
-
-def _bin_stream(device):
-    st = _BIN_STREAMS.get(device.index)
-    if st is None:
-        st = _BIN_STREAMS[device.index] = torch.cuda.Stream(device=device)
-    return st
+    return _PREBIN_MODE == "all" or (_PREBIN_MODE == "chained" and not head)
 
 
 class _FusedROIPool(Function):
@@ -288,28 +278,13 @@ class _FusedROIPool(Function):
             L = _C.lib()
             ws_bytes = L.d2amd_roi_pooler_backward_workspace_bytes(ctypes.byref(p), k)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=xs[0].device)
-            ev = None
-            if _PREBIN_MODE == "side":
-                # on the binning stream, behind the forward kernels (they write `rois` from the box lists): the
-                # binning then runs beside whatever the caller enqueues next; the backward waits for `ev`
-                cur, st = torch.cuda.current_stream(xs[0].device), _bin_stream(xs[0].device)
-                st.wait_stream(cur)
-                for t in (ws, rois, out):
-                    t.record_stream(st)
-                with torch.cuda.stream(st), _C.on_device(xs[0].device):
-                    rc = L.d2amd_roi_pooler_backward_phase(ctypes.byref(p), _C.ptr(out), _C.ptr(rois), _ptr_array(xs),
-                                                           k, _C.ptr(ws), ws_bytes, 1, _C.stream())
-                ev = st.record_event()
-            else:
-                with _C.on_device(xs[0].device):  # (pointers: only their alignment class matters to the binning)
-                    rc = L.d2amd_roi_pooler_backward_phase(ctypes.byref(p), _C.ptr(out), _C.ptr(rois), _ptr_array(xs),
-                                                           k, _C.ptr(ws), ws_bytes, 1, _C.stream())
+            with _C.on_device(xs[0].device):  # (pointers: only their alignment class matters to the binning)
+                rc = L.d2amd_roi_pooler_backward_phase(ctypes.byref(p), _C.ptr(out), _C.ptr(rois), _ptr_array(xs), k,
+                                                       _C.ptr(ws), ws_bytes, 1, _C.stream())
             if rc == 0:
-                ctx.binned = (ws, ws_bytes, ev)
+                ctx.binned = (ws, ws_bytes)
             elif rc != _C.EUNSUPPORTED:
                 _C.check(rc)
-            if rc != 0 and ev is not None:
-                cur.wait_event(ev)  # nothing was enqueued that the backward would wait for: join here
         ctx.chain, ctx.head, ctx.upstream, ctx.dtype = chain, head, upstream, xs[0].dtype
         ctx.set_materialize_grads(False)  # unused outputs (the aliases of the last pooler of a chain) arrive as None
         ctx.nchw_caller = _layout_of(feats[0]) == _C.NCHW  # gradients go back in the caller's layout
@@ -370,10 +345,8 @@ class _FusedROIPool(Function):
                 p = _params(wcfg, (n, c), hw, _C.dtype_code(g), _C.NHWC)
                 if plain_first and j == 0:
                     if binned is not None:  # binned beside its forward: zero fill of the untouched tiles + gather
-                        ws, ws_bytes, ev = binned
+                        ws, ws_bytes = binned
                         ws.record_stream(torch.cuda.current_stream(dev))
-                        if ev is not None:
-                            torch.cuda.current_stream(dev).wait_event(ev)
                         _C.check(L.d2amd_roi_pooler_backward_phase(ctypes.byref(p), _C.ptr(g), _C.ptr(r),
                                                                    _ptr_array(grads), k, _C.ptr(ws), ws_bytes, 3,
                                                                    _C.stream()))
@@ -385,10 +358,8 @@ class _FusedROIPool(Function):
                                                          _C.ptr(ws), ws_bytes, _C.stream()))
                     continue
                 if binned is not None:  # binned beside its forward (maybe on another stream): gather only
-                    ws, ws_bytes, ev = binned
+                    ws, ws_bytes = binned
                     ws.record_stream(torch.cuda.current_stream(dev))
-                    if ev is not None:
-                        torch.cuda.current_stream(dev).wait_event(ev)
                     rc = L.d2amd_roi_pooler_backward_phase(ctypes.byref(p), _C.ptr(g), _C.ptr(r), _ptr_array(grads), k,
                                                            _C.ptr(ws), ws_bytes, 2, _C.stream())
                 else:
