@@ -82,8 +82,6 @@ def parse(argv=None):
     ap.add_argument("--no-graph", action="store_true",
                     help="maskrcnn_train: launch every op eagerly in the timed region (default: the two sync-free halves "
                          "of the step are captured once in HIP graphs and replayed)")
-    ap.add_argument("--one-piece-b", action="store_true",
-                    help="A/B switch: graph B as one HIP graph instead of a forward and a backward piece")
     ap.add_argument("--no-overlap", action="store_true",
                     help="maskrcnn_train: issue the independent branches of the step (anchor labelling | proposal path; "
                          "both poolers | proposal labelling + mask targets + loss) on ONE stream instead of forking "
@@ -188,7 +186,6 @@ class Workload:
         gens = [image_generator(seed, i) for i in image_ids]
         self.dev, self.n_img, self.image_ids, self.dtype, self.layout = dev, n_img, list(image_ids), dtype, layout
         self.overlap = True  # independent branches of the step on separate HIP streams (--no-overlap: one stream)
-        self.split_b = True  # graph B launched as two pieces (--one-piece-b: one graph)
         self.feats = []
         for (h, w) in FEAT_HW:
             f = torch.stack([torch.rand(C, h, w, generator=g) * 2 - 1 for g in gens]).to(dtype).to(dev)
@@ -418,7 +415,7 @@ class GraphedStep:
                 done, labels = rpn(), lab()
             return done, labels
 
-        def part_b_forward():
+        def part_b():
             lab = None
             if w.overlap:
                 (yb, ym), (loss, _) = fork_join(*roi_branches(w))
@@ -429,9 +426,6 @@ class GraphedStep:
                 tg = crop_and_resize_batch(w.gt_masks, [b.tensor for b in w.mask_lists], 28, w.fg_gt_index,
                                            w.crop_status)
                 loss, _ = mask_rcnn_loss_from_targets(w.mask_logits, w.fg_classes, tg)
-            return lab, yb, ym, loss
-
-        def part_b_backward(lab, yb, ym, loss):
             for f in w.feats:
                 f.grad = None
             w.mask_logits.grad = None
@@ -439,13 +433,7 @@ class GraphedStep:
             return lab, loss.detach()  # no reference into the captured autograd graph survives the capture
 
         self.ga, self.out_a = self._capture(part_a)
-        # graph B in two pieces (forward; backward) on one memory pool: the host enqueues the backward's ~15 nodes
-        # while the forward piece already runs -- a graph launch costs the host ~1 us per node before its first kernel
-        # starts, and graph B's launch sits on the critical path behind the step's one host sync
-        self.gb = self._capture_pair(part_b_forward, part_b_backward) if w.split_b else None
-        if self.gb is None:
-            g, self.out_b = self._capture(lambda: part_b_backward(*part_b_forward()))
-            self.gb = (g,)
+        self.gb, self.out_b = self._capture(part_b)
 
     @staticmethod
     def _capture(fn):
@@ -466,27 +454,6 @@ class GraphedStep:
             out = fn()
         return g, out
 
-    @staticmethod
-    def _capture_pair(first, second):
-        import gc
-
-        gc.collect()
-        cur = torch.cuda.current_stream()
-        side = torch.cuda.Stream()
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                second(*first())
-        cur.wait_stream(side)
-        torch.cuda.synchronize()
-        g0, g1 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g0):
-            mid = first()
-        with torch.cuda.graph(g1, pool=g0.pool()):
-            second(*mid)
-        del mid
-        return g0, g1
-
     def __call__(self):
         self.ga.replay()
         props = self.out_a[0]()  # the one host sync of the step
@@ -494,8 +461,7 @@ class GraphedStep:
         n_early = g.ready_after("roi_heads.box_head") if g is not None else 0
         for i in range(n_early):
             g.reduce(i)  # RCCL, on its own stream: overlaps graph B's pooler backward
-        for piece in self.gb:
-            piece.replay()
+        self.gb.replay()
         if g is not None:
             for i in range(n_early, g.num_buckets):
                 g.reduce(i)
@@ -620,7 +586,6 @@ def bench_maskrcnn(args, ctx):
     # weak scaling: 2 images per GPU; rank r owns images [2r, 2r+1] of the global synthetic batch
     w = Workload(dev, dtype, args.layout, image_ids=global_image_ids(IMAGES_PER_GPU, rank, world))
     w.overlap = not args.no_overlap
-    w.split_b = not args.one_piece_b
     grads = make_gradient_buckets(args, dev, dist, world)
     for _ in range(args.warmup):
         step(w, None, grads)

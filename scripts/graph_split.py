@@ -22,18 +22,15 @@ def t(fn, n=200):
     return (time.perf_counter() - t0) / n * 1e6
 
 
-import os  # noqa: E402
-
 for overlap in (True, False):
     w = bench.Workload(dev, torch.bfloat16, "nhwc")
     w.overlap = overlap
-    w.split_b = os.environ.get("ONE_PIECE_B") is None
     for _ in range(3):
         bench.step(w)
     g = bench.GraphedStep(w, None)
     a_only = t(lambda: g.ga.replay())
     a_sync = t(lambda: (g.ga.replay(), g.out_a[0]()))
-    b_only = t(lambda: [p.replay() for p in g.gb])
+    b_only = t(lambda: g.gb.replay())
     full = t(g)
     print(f"overlap={overlap}: graph A {a_only:.1f} us (with the result read {a_sync:.1f}), graph B {b_only:.1f} us, "
           f"step {full:.1f} us (A + B = {a_only + b_only:.1f})")
