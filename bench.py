@@ -186,6 +186,7 @@ class Workload:
         gens = [image_generator(seed, i) for i in image_ids]
         self.dev, self.n_img, self.image_ids, self.dtype, self.layout = dev, n_img, list(image_ids), dtype, layout
         self.overlap = True  # independent branches of the step on separate HIP streams (--no-overlap: one stream)
+        self.current_first = os.environ.get("SIDE_FIRST") is None  # ROI half: the poolers' branch is enqueued first
         self.feats = []
         for (h, w) in FEAT_HW:
             f = torch.stack([torch.rand(C, h, w, generator=g) * 2 - 1 for g in gens]).to(dtype).to(dev)
@@ -364,7 +365,7 @@ def step(w, t=None, grads=None):
     props = run("rpn_proposals_sync", rpn_done)
     # ROI heads: proposal labelling (the sampled lists themselves are fixed inputs: subsample_labels is out of scope)
     if t is None and w.overlap:
-        (yb, ym), (loss, _stats) = fork_join(*roi_branches(w))
+        (yb, ym), (loss, _stats) = fork_join(*roi_branches(w), current_first=w.current_first)
     else:
         for i in range(w.n_img):
             run("match_proposals", lambda: w.proposal_matcher.match_boxes(w.gt[i], w.props_with_gt[i]))
@@ -418,7 +419,7 @@ class GraphedStep:
         def part_b():
             lab = None
             if w.overlap:
-                (yb, ym), (loss, _) = fork_join(*roi_branches(w))
+                (yb, ym), (loss, _) = fork_join(*roi_branches(w), current_first=w.current_first)
             else:
                 lab = [w.proposal_matcher.match_boxes(w.gt[i], w.props_with_gt[i]) for i in range(w.n_img)]
                 yb = w.box_pooler(w.feats, w.box_lists)

@@ -44,10 +44,14 @@ def _record(obj, stream):
         _record(obj.tensor, stream)
 
 
-def fork_join(*branches: Callable[[], object], device: torch.device = None) -> list:
+def fork_join(*branches: Callable[[], object], device: torch.device = None, current_first: bool = False) -> list:
     """Run branch 0 on the current stream and every other branch on its own side stream, all starting from the
     current point of the current stream; return their results once everything has been ENQUEUED (no host sync): work
-    enqueued on the current stream afterwards sees all of it."""
+    enqueued on the current stream afterwards sees all of it.
+
+    The side branches are enqueued before branch 0 unless `current_first`.  The order matters to a captured graph too:
+    hipGraphLaunch hands the nodes to the device in capture order, a couple of microseconds apiece, so the branch
+    captured last starts that much later -- capture the critical branch first."""
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device())
     cur = torch.cuda.current_stream(device)
@@ -57,10 +61,13 @@ def fork_join(*branches: Callable[[], object], device: torch.device = None) -> l
     for st in side:
         st.wait_stream(cur)  # fork: the branch sees everything enqueued so far
     out = [None] * len(branches)
+    if current_first:
+        out[0] = branches[0]()
     for i, st in enumerate(side, start=1):
         with torch.cuda.stream(st):
             out[i] = branches[i]()
-    out[0] = branches[0]()
+    if not current_first:
+        out[0] = branches[0]()
     for i, st in enumerate(side, start=1):
         cur.wait_stream(st)  # join
         _record(out[i], cur)
