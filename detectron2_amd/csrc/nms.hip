@@ -7,8 +7,10 @@
 //      64-bit composite keys (category | ~score | index) precede its own (n^2 compares from LDS,
 //      ~8 us at n = 8,819) and scatters itself straight to its class-major / score-descending
 //      slot; this replaces two radix sorts + three gather kernels (rocPRIM takes its merge-sort
-//      path at this size: 8 launches, ~90 us).  Larger n: stable radix sort by score, then by
-//      category (16 bits), then gathers.  Callers whose input consists of pre-sorted RUNS (the per-level top-k
+//      path at this size: 8 launches, ~90 us).  Larger n: stable counting-sort passes (cs_sort below: 8 bits per
+//      pass, two launches each) by score, then by category (16 bits, or the caller's category count), then
+//      gathers -- 25 us for the 7-bit class sort of 100,000 boxes against 49 us of rocPRIM's radix sort, which
+//      this file no longer uses.  Callers whose input consists of pre-sorted RUNS (the per-level top-k
 //      lists of the RPN / dense detectors: d2amd_nms_runs) get the order from a merge instead -- step 1c below;
 //      for the RPN (runs = categories, n <= 12,288) the whole pipeline is 4 launches.
 //   2. wavefront bitmask kernel: one 64-lane wave per 64x64 tile of the (sorted) IoU matrix,
@@ -22,7 +24,6 @@
 // nms_rotated_cpu.cpp (fp32, no FMA contraction, IEEE divide, threshold compare in double).
 #pragma clang fp contract(off)
 #include <cstring>
-#include <rocprim/rocprim.hpp>
 
 #include "common.h"
 #include "rotated_iou.h"
@@ -38,10 +39,10 @@ constexpr int CS_THREADS = 1024, CS_WAVES = CS_THREADS / 64, CS_MAX_WGS = 128;  
 constexpr int NMS_MAX_RUNS = 8;    // pre-sorted runs a caller may describe (RPN / dense detectors: one per feature level)
 
 struct NmsWorkspace {
-  float* keys_out;    // [n] sorted scores                        (radix path)
-  int* iota;          // [n] 0..n-1                               (radix path)
+  float* keys_out;    // [n] sort keys, ping-pong partner         (large inputs)
+  int* iota;          // [n] sort values, ping-pong partner       (large inputs)
   int* order;         // [n] rank -> original index
-  uint32_t* cls_r;    // [n] category in rank order               (radix path)
+  uint32_t* cls_r;    // [n] category in rank order               (large inputs)
   uint32_t* cls_s;    // [n] category in segment order
   int* rankpos;       // [n] segment position -> rank
   float* boxes_s;     // [n64 * 8] boxes in segment order (aligned: float4; rotated: 5 of 8 floats)
@@ -57,8 +58,6 @@ struct NmsWorkspace {
   int* blk_cnt;       // [n / 1024 + 1] kept flags per compaction workgroup (radix path)
   int* seg_start;     // [65536]
   int* run_cnt;       // [NMS_MAX_RUNS] entries of a run with a score > -inf (pre-sorted runs path)
-  void* sort_temp;
-  size_t sort_temp_bytes;
   int* cs_hist;  // counting sort: [workgroups][256] digit counts
   size_t zero_bytes;  // keepbits + counters
   size_t total;
@@ -71,16 +70,6 @@ static int wcap_for(int64_t n, int64_t max_per_class) {
   int64_t nblocks = (n + 63) / 64;
   int64_t w = (m + 63) / 64 + 1;
   return (int)(w < nblocks ? w : nblocks);
-}
-
-static size_t sort_temp_bytes(int64_t n) {
-  if (n <= RANK_MAX_N) return 0;
-  size_t a = 0, b = 0;
-  (void)rocprim::radix_sort_pairs_desc(nullptr, a, (const float*)nullptr, (float*)nullptr, (const int*)nullptr,
-                                 (int*)nullptr, (unsigned)n, 0, 32, (hipStream_t)0, false);
-  (void)rocprim::radix_sort_pairs(nullptr, b, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const int*)nullptr,
-                            (int*)nullptr, (unsigned)n, 0, 16, (hipStream_t)0, false);
-  return a > b ? a : b;
 }
 
 static void carve(NmsWorkspace& w, void* base, int64_t n, int wcap) {
@@ -109,8 +98,6 @@ static void carve(NmsWorkspace& w, void* base, int64_t n, int wcap) {
   w.blk_cnt = (int*)take((size_t)(n / 1024 + 2) * 8);  // (8 B per chunk: the direct finalize publishes two counts)
   w.seg_start = (int*)take(65536 * 4);
   w.run_cnt = (int*)take(64 * 4);  // [0, 8): live entries per run; [16, 16 + 12): "a run is not in order" per order workgroup
-  w.sort_temp_bytes = sort_temp_bytes(n);
-  w.sort_temp = take(w.sort_temp_bytes);
   w.cs_hist = (int*)take(n <= RANK_MAX_N ? 0 : (size_t)CS_MAX_WGS * 256 * 4);
   w.total = off;
 }
@@ -693,21 +680,7 @@ __device__ __forceinline__ int order_at(const int* __restrict__ order, int r, in
   return (unsigned)o < (unsigned)n ? o : 0;
 }
 
-// ---- step 1b helpers (radix path) ---------------------------------------------------------------
-__global__ void nms_init_kernel(int* iota, int n) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) iota[i] = i;
-}
-
-__global__ void nms_gather_cls_kernel(const int64_t* __restrict__ idxs, const int* __restrict__ order, int n,
-                                      uint32_t* __restrict__ cls_r, int* counters) {
-  int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= n) return;
-  int64_t c = idxs[order_at(order, r, n)];
-  if (c < 0 || c > 65535) { atomicOr(&counters[1], 2); c = 0; }
-  cls_r[r] = (uint32_t)c;
-}
-
+// ---- step 1b helpers (large inputs) ----------------------------------------------------------------
 // boxes into segment order (+ segment starts).  BW = 4 (xyxy) or 5 (cxcywha); stored stride 4 / 8.
 template <int BW>
 __global__ void nms_gather_boxes_kernel(const float* __restrict__ boxes, const int* __restrict__ order,
@@ -1894,11 +1867,10 @@ static int nms_impl(const float* boxes, const float* scores, const int64_t* idxs
     I.cls_s = I.w.cls_s;
   }
   if (n <= RANK_MAX_N) return nms_run_small(B, rotated, s);
-  // ---- large inputs: radix sorts (or the runs' binary searches) instead of the brute-force ranking ----
+  // ---- large inputs: counting-sort passes (or the runs' binary searches) instead of the brute-force ranking ----
   NmsWorkspace& w = I.w;
   const int N = (int)n;
   const int T = 256;
-  static const bool use_rocprim = getenv("D2AMD_NMS_ROCPRIM") != nullptr;  // A/B switch: the library radix sorts
   if (runs) {  // order[] from the pre-sorted runs (the scan also zeroes the accumulators)
     hipLaunchKernelGGL(nms_runs_scan_kernel<16>, dim3(std::max(runs->n_runs, 16), 1, 1), dim3(RUNS_SCAN_THREADS), 0, s, B);
     D2_LAUNCH_OK();
@@ -1908,38 +1880,18 @@ static int nms_impl(const float* boxes, const float* scores, const int64_t* idxs
     D2_LAUNCH_OK();
   } else {
     { const int zrc = zero_async(w.keepbits, w.zero_bytes, s); if (zrc) return zrc; }
-    if (use_rocprim) {
-      hipLaunchKernelGGL(nms_init_kernel, dim3(cdiv(N, T)), dim3(T), 0, s, w.iota, N);
-      D2_LAUNCH_OK();
-      size_t tb = w.sort_temp_bytes;
-      D2_HIP_OK(rocprim::radix_sort_pairs_desc(w.sort_temp, tb, scores, w.keys_out, w.iota, w.order, (unsigned)N, 0,
-                                               32, s, false));
-    } else {  // four 8-bit passes; rankpos / cls_r are free until the class sort
-      CsPass a{};
-      a.n = N; a.hist = w.cs_hist; a.scores = scores; a.counters = w.counters;
-      rc = cs_sort(a, 32, (uint32_t*)w.rankpos, w.cls_r, w.iota, (uint32_t*)w.keys_out, w.order, s);
-      if (rc) return rc;
-    }
+    CsPass a{};  // score order: four 8-bit passes; rankpos / cls_r are free until the class sort
+    a.n = N; a.hist = w.cs_hist; a.scores = scores; a.counters = w.counters;
+    rc = cs_sort(a, 32, (uint32_t*)w.rankpos, w.cls_r, w.iota, (uint32_t*)w.keys_out, w.order, s);
+    if (rc) return rc;
   }
   if (idxs) {
     // (a caller that knows its number of categories -- 80 classes: 7 bits -- saves the sort its second 8-bit pass)
     const unsigned cat_bits = runs && runs->cat_bits > 0 ? (unsigned)runs->cat_bits : 16u;
-    if (use_rocprim) {
-      if (runs) {  // the class sort's values
-        hipLaunchKernelGGL(nms_init_kernel, dim3(cdiv(N, T)), dim3(T), 0, s, w.iota, N);
-        D2_LAUNCH_OK();
-      }
-      hipLaunchKernelGGL(nms_gather_cls_kernel, dim3(cdiv(N, T)), dim3(T), 0, s, idxs, w.order, N, w.cls_r, w.counters);
-      D2_LAUNCH_OK();
-      size_t tb = w.sort_temp_bytes;
-      D2_HIP_OK(rocprim::radix_sort_pairs(w.sort_temp, tb, w.cls_r, w.cls_s, w.iota, w.rankpos, (unsigned)N, 0,
-                                          cat_bits, s, false));
-    } else {  // stable by class over the score order: rankpos[p] = rank of the element at class-major position p
-      CsPass a{};
-      a.n = N; a.hist = w.cs_hist; a.idxs = idxs; a.order = w.order; a.counters = w.counters;
-      rc = cs_sort(a, (int)cat_bits, w.cls_r, (uint32_t*)w.keys_out, w.iota, w.cls_s, w.rankpos, s);
-      if (rc) return rc;
-    }
+    CsPass a{};  // stable by class over the score order: rankpos[p] = rank of the element at class-major position p
+    a.n = N; a.hist = w.cs_hist; a.idxs = idxs; a.order = w.order; a.counters = w.counters;
+    rc = cs_sort(a, (int)cat_bits, w.cls_r, (uint32_t*)w.keys_out, w.iota, w.cls_s, w.rankpos, s);
+    if (rc) return rc;
   }
   if (!runs || idxs) {  // (runs without class ids: the rank kernel has written the records)
     if (rotated)

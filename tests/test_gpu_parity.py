@@ -272,6 +272,23 @@ def test_batched_nms_bit_exact(n, ncls):
     assert torch.equal(bt, b0)  # inputs not modified (test_nms.py:26-28)
 
 
+def test_batched_nms_large_ties_and_wide_class_ids():
+    """Beyond the brute-force ranking (n > 12,288) the order comes from the library's own stable counting sort
+    (csrc/nms.hip: cs_sort): four 8-bit passes over the score bits, two over 16-bit class ids.  Tied scores must keep
+    index order through every pass, and class ids above 255 exercise the second class digit."""
+    rng = np.random.default_rng(1234)
+    n = 20000
+    b = _boxes(rng, n, 300.0)
+    s = (rng.integers(0, 997, n).astype(np.float32) - 300.0) / 256.0  # ~20 ties per value, both signs, exact in fp32
+    idx = rng.integers(0, 40000, n)
+    idx[: n // 2] = rng.integers(0, 300, n // 2)  # populated classes on both sides of the 8-bit digit boundary
+    for thr in (0.5,):
+        got = batched_nms(cu(b), cu(s), torch.from_numpy(idx).to(DEV), thr).cpu().numpy()
+        assert np.array_equal(got, oracle.batched_nms(b, s, idx, thr))
+    got = nms(cu(b), cu(s), 0.6).cpu().numpy()
+    assert np.array_equal(got, oracle.nms(b, s, 0.6))
+
+
 def test_batched_nms_config4_100k():
     """BASELINE config 4: 100k candidates, 80 classes.  Bit-exact vs oracle (per-class greedy)."""
     rng = np.random.default_rng(4)
