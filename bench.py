@@ -334,7 +334,8 @@ def roi_branches(w):
 def rpn_branches(w):
     """Anchor labelling | proposal path.  The labelling goes FIRST (= on the current stream): 180 us for the captured
     half against 203 us the other way round and 207-210 us on one stream (scripts/graph_split2.py; the proposal path
-    alone is 156 us of 10-workgroup kernels, the labelling 60 us)."""
+    alone is 156 us of 10-workgroup kernels, the labelling 60 us).  With the ranked selection that is 159.5 us; forking
+    after the selection instead (find_top_rpn_proposals_fused: beside_nms, what the step does) 156.5 us."""
     from detectron2_amd.modeling import find_top_rpn_proposals_fused
 
     return (lambda: [w.anchor_matcher.match_boxes(w.gt[i], w.anchors) for i in range(w.n_img)],
@@ -356,7 +357,8 @@ def step(w, t=None, grads=None):
     # deferred past the anchor labelling, which does not depend on the proposals (RPN.forward computes the two in either
     # order: rpn.py label_and_sample_anchors / predict_proposals): the device works through both while the host waits
     if t is None and w.overlap:  # independent branches on separate streams (detectron2_amd/streams.py)
-        _labels, rpn_done = fork_join(*rpn_branches(w))
+        rpn_done = find_top_rpn_proposals_fused(w.anchor_levels, w.rpn_logits, w.rpn_deltas, w.image_sizes, 0.7, 2000,
+                                                1000, 0.0, True, defer=True, beside_nms=rpn_branches(w)[0])
     else:
         rpn_done = run("rpn_proposals", lambda: find_top_rpn_proposals_fused(
             w.anchor_levels, w.rpn_logits, w.rpn_deltas, w.image_sizes, 0.7, 2000, 1000, 0.0, True, defer=True))
@@ -410,7 +412,11 @@ class GraphedStep:
 
         def part_a():
             lab, rpn = rpn_branches(w)
-            if w.overlap:
+            if w.overlap and not os.environ.get("RPN_FORK_AT_START"):  # labelling beside the NMS only: 156.5 vs 159.5 us
+                done = find_top_rpn_proposals_fused(w.anchor_levels, w.rpn_logits, w.rpn_deltas, w.image_sizes, 0.7,
+                                                    2000, 1000, 0.0, True, defer=True, beside_nms=lab)
+                labels = done.beside
+            elif w.overlap:
                 labels, done = fork_join(lab, rpn)
             else:
                 done, labels = rpn(), lab()

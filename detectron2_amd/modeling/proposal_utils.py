@@ -91,13 +91,18 @@ def rpn_select_proposals(anchors: List[torch.Tensor], pred_objectness_logits: Li
 def find_top_rpn_proposals_fused(anchors, pred_objectness_logits, pred_anchor_deltas, image_sizes, nms_thresh: float,
                                  pre_nms_topk: int, post_nms_topk: int, min_box_size: float, training: bool,
                                  weights=(1.0, 1.0, 1.0, 1.0), scale_clamp: float = _DEFAULT_SCALE_CLAMP,
-                                 defer: bool = False):
+                                 defer: bool = False, beside_nms=None):
     """-> list of N `Proposals` (proposal_boxes: Boxes, objectness_logits), sorted by objectness.
     ONE host sync per batch: the kept counts, the number of kept boxes that are valid proposals (invalid rows are
     parked at score -inf and sort last: the NMS reports how many kept boxes have a finite score) and the non-finite
     flag come back in a single transfer.  defer=True enqueues everything and returns a callable that performs that
     sync and builds the list: work that does not depend on the proposals (the anchor labelling of the same RPN
-    iteration, rpn.py:431-480) can be enqueued in between."""
+    iteration, rpn.py:431-480) can be enqueued in between.
+    beside_nms: a callable enqueuing such independent work; it runs on a side stream BESIDE THE NMS (forked after the
+    selection + decode, joined before this function returns; its result is `.beside` of the returned callable /
+    ignored without defer).  The selection kernels are latency-bound chains of few workgroups that slow down when
+    chip-filling kernels run next to them (fused select 27 -> 35 us, decode 5 -> 13 us beside the anchor matcher); the
+    NMS reduction (10 workgroups walking their lists) does not.  Captured RPN half of bench.py: 159.5 -> 156.5 us."""
     n = int(pred_objectness_logits[0].shape[0])
     # one int32 buffer for everything the host reads back: 8 words per image of NMS results + the non-finite flag
     res = torch.empty(8 * n + 1, dtype=torch.int32, device=anchors[0].device)
@@ -110,9 +115,18 @@ def find_top_rpn_proposals_fused(anchors, pred_objectness_logits, pred_anchor_de
     run_offsets = [0]
     for a in anchors:
         run_offsets.append(run_offsets[-1] + min(int(a.shape[0]), pre_nms_topk))
-    nms_done = batched_nms_images([(boxes[i], scores[i], None) for i in range(n)], nms_thresh, defer=True,
+    def nms():
+        return batched_nms_images([(boxes[i], scores[i], None) for i in range(n)], nms_thresh, defer=True,
                                   runs=(run_offsets, True), gather=[(boxes[i], scores[i]) for i in range(n)],
                                   result_buffer=res)
+
+    beside = None
+    if beside_nms is not None:
+        from ..streams import fork_join
+
+        nms_done, beside = fork_join(nms, beside_nms, device=res.device, current_first=True)
+    else:
+        nms_done = nms()
 
     def finish():
         keeps, n_finite, (bad,) = nms_done(with_finite=True) if n else ([], [], (0,))  # the one sync
@@ -125,4 +139,5 @@ def find_top_rpn_proposals_fused(anchors, pred_objectness_logits, pred_anchor_de
             out.append(Proposals(tuple(image_sizes[i]), Boxes(kb[:m]), ks[:m]))
         return out
 
+    finish.beside = beside
     return finish if defer else finish()

@@ -154,3 +154,14 @@ def test_forked_branches_eager_and_captured():
     for _ in range(3):
         g.replay()
         same(done(), labels)
+    # the same work forked after the selection, beside the NMS only (what bench.py's step does), and branch 0 first
+    beside = lambda: find_top_rpn_proposals_fused(anchors, logits, deltas, hw, 0.7, 400, 150, 0.0, True, defer=True,
+                                                  beside_nms=lab)
+    done = beside()
+    same(done(), done.beside)
+    g, done = _capture(beside)
+    for _ in range(3):
+        g.replay()
+        same(done(), done.beside)
+    done, labels = fork_join(rpn, lab, current_first=True)
+    same(done(), labels)
