@@ -186,7 +186,6 @@ class Workload:
         gens = [image_generator(seed, i) for i in image_ids]
         self.dev, self.n_img, self.image_ids, self.dtype, self.layout = dev, n_img, list(image_ids), dtype, layout
         self.overlap = True  # independent branches of the step on separate HIP streams (--no-overlap: one stream)
-        self.current_first = os.environ.get("SIDE_FIRST") is None  # ROI half: the poolers' branch is enqueued first
         self.feats = []
         for (h, w) in FEAT_HW:
             f = torch.stack([torch.rand(C, h, w, generator=g) * 2 - 1 for g in gens]).to(dtype).to(dev)
@@ -316,7 +315,8 @@ def roi_branches(w):
     """The forward of the ROI heads as two branches (fork_join): both poolers | proposal labelling + mask targets +
     mask loss.  (Measured layouts, captured graph B incl. the backward, scripts/graph_split2.py: one stream 304-314 us,
     four branches 322-333 -- the poolers and the target rasteriser each fill the chip and only slow each other down --
-    this one 278-280.)  -> ((box features, mask features), (loss, stats))"""
+    this one 278-280; with the poolers' branch captured FIRST -- fork_join(current_first=True): a graph's nodes reach the
+    device in capture order -- 288 instead of 296 on a slower box.)  -> ((box features, mask features), (loss, stats))"""
     from detectron2_amd.modeling import mask_rcnn_loss_from_targets
     from detectron2_amd.structures import crop_and_resize_batch
 
@@ -367,7 +367,7 @@ def step(w, t=None, grads=None):
     props = run("rpn_proposals_sync", rpn_done)
     # ROI heads: proposal labelling (the sampled lists themselves are fixed inputs: subsample_labels is out of scope)
     if t is None and w.overlap:
-        (yb, ym), (loss, _stats) = fork_join(*roi_branches(w), current_first=w.current_first)
+        (yb, ym), (loss, _stats) = fork_join(*roi_branches(w), current_first=True)
     else:
         for i in range(w.n_img):
             run("match_proposals", lambda: w.proposal_matcher.match_boxes(w.gt[i], w.props_with_gt[i]))
@@ -412,12 +412,10 @@ class GraphedStep:
 
         def part_a():
             lab, rpn = rpn_branches(w)
-            if w.overlap and not os.environ.get("RPN_FORK_AT_START"):  # labelling beside the NMS only: 156.5 vs 159.5 us
+            if w.overlap:  # labelling beside the NMS only: 156.5 us, forked at the start 159.5 us
                 done = find_top_rpn_proposals_fused(w.anchor_levels, w.rpn_logits, w.rpn_deltas, w.image_sizes, 0.7,
                                                     2000, 1000, 0.0, True, defer=True, beside_nms=lab)
                 labels = done.beside
-            elif w.overlap:
-                labels, done = fork_join(lab, rpn)
             else:
                 done, labels = rpn(), lab()
             return done, labels
@@ -425,7 +423,7 @@ class GraphedStep:
         def part_b():
             lab = None
             if w.overlap:
-                (yb, ym), (loss, _) = fork_join(*roi_branches(w), current_first=w.current_first)
+                (yb, ym), (loss, _) = fork_join(*roi_branches(w), current_first=True)
             else:
                 lab = [w.proposal_matcher.match_boxes(w.gt[i], w.props_with_gt[i]) for i in range(w.n_img)]
                 yb = w.box_pooler(w.feats, w.box_lists)
