@@ -36,7 +36,8 @@ struct SegState {
   int done[4];      // workgroups finished per pass (0-2: histogram passes, 3: tie count)
   int cnt_lt, cnt_tie;
   int cnt;          // selected = min(k, total)
-  int pad[2];
+  int c_def;        // candidates better than the bucket of pass 1 (key >> 10 < prefix): placed by a scan, see blk_def
+  int pad[1];
 };
 static_assert(sizeof(SegState) == 64, "SegState layout");
 
@@ -48,6 +49,11 @@ struct TkParams {
   int tickets;     // 1: the last workgroup of a segment (atomic ticket) scans; 0: separate scan launches
   int reps;        // consecutive TK_CHUNK chunks per workgroup (keeps the workgroups of a segment <= ~256: every
                    // workgroup takes a ticket on ONE address per pass, and 3,000 returning atomics there cost 0.3 ms)
+  int* blk_def;    // [segments][maxblk], large segments only (else null).  Pass 2 counts, per workgroup, the candidates
+                   // that are selected whatever the last 10 key bits decide (key >> 10 < the 21-bit prefix); the scan
+                   // launch turns the counts into offsets and the compaction places those candidates WITHOUT
+                   // reserving through a returning atomic (thousands of them on one counter serialise).  Segments
+                   // that select everything skip pass 2 and keep the counter.
 };
 
 // The key is the order-preserving image of the STORED value.  Dense detectors store class logits and the reference
@@ -98,8 +104,9 @@ template <typename TT>
 __device__ __forceinline__ TT ld_agent(const TT* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // scan of a segment's bins (ascending key = best first) by one 256-thread workgroup: narrows the key prefix
+// (-> true: pass 0 found fewer candidates than k, all of them are selected)
 template <int PASS>
-__device__ __forceinline__ void tk_scan_bins(const TkParams& P, SegState* S, const int* gh, int l) {
+__device__ __forceinline__ bool tk_scan_bins(const TkParams& P, SegState* S, const int* gh, int l) {
   const int tid = threadIdx.x;
   const uint32_t prefix = PASS > 0 ? S->prefix : 0u;
   constexpr int BINS = PASS == 2 ? 1024 : 2048, PER = BINS / TK_THREADS;
@@ -114,7 +121,7 @@ __device__ __forceinline__ void tk_scan_bins(const TkParams& P, SegState* S, con
   int k_rem = PASS == 0 ? P.in.k[l] : S->k_rem;
   if (PASS == 0 && s_total < k_rem) {  // not enough candidates: everything is selected (uniform)
     if (tid == 0) { S->total = s_total; S->take_all = 1; S->cnt = s_total; }
-    return;
+    return true;
   }
 #pragma unroll
   for (int j = 0; j < PER; j++) {
@@ -127,10 +134,12 @@ __device__ __forceinline__ void tk_scan_bins(const TkParams& P, SegState* S, con
     if (PASS == 0) { S->total = s_total; S->cnt = k_rem; S->prefix = (uint32_t)b; }
     else if (PASS == 1) S->prefix = (prefix << 11) | (uint32_t)b;
     else S->prefix = (prefix << 10) | (uint32_t)b;
+    if (PASS == 2) S->c_def = S->c_lt;
     S->c_lt = (PASS == 0 ? 0 : S->c_lt) + s_before;
     S->k_rem = k_rem - s_before;
     if (PASS == 2) { S->ties_total = ld_agent(&gh[b]); S->need = k_rem - s_before; }
   }
+  return false;
 }
 
 // PASS 0: bins = key >> 21 of all candidates; 1: (key >> 10) & 2047 where key >> 21 == prefix; 2: key & 1023 where
@@ -147,9 +156,11 @@ __global__ __launch_bounds__(TK_THREADS) void tk_hist_kernel(TkParams P, SegStat
   const int tid = threadIdx.x;
   if (PASS > 0 && S->take_all) return;  // written by the previous launch
   __shared__ int h[TK_BINS];
-  __shared__ int s_last;
+  __shared__ int s_last, s_def;
   for (int i = tid; i < TK_BINS; i += TK_THREADS) h[i] = 0;
+  if (tid == 0) s_def = 0;
   __syncthreads();
+  int n_def = 0;
   const uint32_t prefix = PASS > 0 ? S->prefix : 0u;
   const float* x = P.in.ptr[l] + (long)img * P.in.stride[l];
   for (int rep = 0; rep < P.reps; rep++) {
@@ -164,10 +175,19 @@ __global__ __launch_bounds__(TK_THREADS) void tk_hist_kernel(TkParams P, SegStat
       if (!ok[j] || !tk_key(P, v[j], key)) continue;
       if (PASS == 0) atomicAdd(&h[key >> 21], 1);
       else if (PASS == 1) { if ((key >> 21) == prefix) atomicAdd(&h[(key >> 10) & 2047u], 1); }
-      else { if ((key >> 10) == prefix) atomicAdd(&h[key & 1023u], 1); }
+      else {
+        if ((key >> 10) == prefix) atomicAdd(&h[key & 1023u], 1);
+        n_def += (key >> 10) < prefix ? 1 : 0;
+      }
     }
   }
+  if (PASS == 2 && P.blk_def != nullptr) {  // uniform
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) n_def += __shfl_xor(n_def, d, 64);
+    if ((tid & 63) == 0 && n_def) atomicAdd(&s_def, n_def);
+  }
   __syncthreads();
+  if (PASS == 2 && P.blk_def != nullptr && tid == 0) P.blk_def[(long)seg * P.maxblk + blockIdx.x] = s_def;
   int* gh = hist + ((long)seg * 3 + PASS) * TK_BINS;
   for (int i = tid; i < TK_BINS; i += TK_THREADS)
     if (h[i]) atomicAdd(&gh[i], h[i]);
@@ -182,15 +202,6 @@ __global__ __launch_bounds__(TK_THREADS) void tk_hist_kernel(TkParams P, SegStat
   tk_scan_bins<PASS>(P, S, gh, l);
 }
 
-// separate launch of the bin scan (large segments: thousands of tickets on one address would serialise in L2)
-template <int PASS>
-__global__ __launch_bounds__(TK_THREADS) void tk_scan_kernel(TkParams P, SegState* __restrict__ st, int* __restrict__ hist) {
-  const int seg = blockIdx.x, l = seg % P.in.L;
-  SegState* S = st + seg;
-  if (P.in.size[l] == 0 || (PASS > 0 && S->take_all)) return;
-  tk_scan_bins<PASS>(P, S, hist + ((long)seg * 3 + PASS) * TK_BINS, l);
-}
-
 // exclusive prefix of the per-workgroup tie counts of one segment (one 256-thread workgroup; thread t owns a run)
 __device__ __forceinline__ void tk_ties_scan(int* bt, int nblk) {
   const int tid = threadIdx.x;
@@ -202,6 +213,20 @@ __device__ __forceinline__ void tk_ties_scan(int* bt, int nblk) {
   int tot;
   int run = tk_block_excl_scan(sum, lds4, tot);
   for (int i = lo; i < hi; i++) { const int v = ld_agent(&bt[i]); bt[i] = run; run += v; }
+}
+
+// separate launch of the bin scan (large segments: thousands of tickets on one address would serialise in L2)
+template <int PASS>
+__global__ __launch_bounds__(TK_THREADS) void tk_scan_kernel(TkParams P, SegState* __restrict__ st, int* __restrict__ hist) {
+  const int seg = blockIdx.x, l = seg % P.in.L;
+  SegState* S = st + seg;
+  if (P.in.size[l] == 0 || (PASS > 0 && S->take_all)) return;
+  (void)tk_scan_bins<PASS>(P, S, hist + ((long)seg * 3 + PASS) * TK_BINS, l);
+  if (PASS == 2 && P.blk_def != nullptr) {  // pass 2's per-workgroup counts -> offsets (TkParams::blk_def); uniform
+    const long span = (long)TK_CHUNK * P.reps;
+    __syncthreads();
+    tk_ties_scan(P.blk_def + (long)seg * P.maxblk, (int)((P.in.size[l] + span - 1) / span));
+  }
 }
 
 // per workgroup: number of ties (key == T); last workgroup: exclusive prefix over the workgroups of the segment
@@ -342,6 +367,58 @@ __device__ __forceinline__ void tk_compact_chunk(const TkParams& P, const TkSel&
   }
 }
 
+// The usual (not tie-ordered) case for one chunk whose values are already loaded (`lim`: elements of the segment from
+// `base` on; >= TK_CHUNK for an inner chunk).  A selected candidate is one of
+//   definite   (scan_mode) key >> 10 below the 21-bit prefix: placed at the workgroup's scanned offset + rank, no
+//              atomic (TkParams::blk_def);
+//   late       better than T inside the last bucket (scan_mode), or any better-than-T candidate (otherwise): a
+//              reservation on the segment's counter -- rare in scan_mode;
+//   tie        key == T: all taken here (not ordered), behind the c_lt better ones.
+__device__ __forceinline__ void tk_compact_cls(const TkParams& P, const TkSel& Z, SegState* S,
+                                               const float (&v)[TK_ITEMS], long base, long lim,
+                                               unsigned long long* __restrict__ out, TkCompactLds& L, bool scan_mode,
+                                               int c_def, int& def_pos) {
+  const int tid = threadIdx.x;
+  unsigned df = 0u, lt = 0u, tie = 0u;
+  const uint32_t pre = Z.T >> 10;
+#pragma unroll
+  for (int j = 0; j < TK_ITEMS; j++) {
+    const uint32_t key = topk_desc_key(v[j]);
+    const bool ok = j * TK_THREADS + tid < lim && (!P.use_thr || v[j] >= P.xmin);  // (tk_key)
+    const bool sel = ok && (Z.take_all || key < Z.T);
+    const bool is_def = sel && scan_mode && (key >> 10) < pre;
+    df |= (unsigned)is_def << j;
+    lt |= (unsigned)(sel && !is_def) << j;
+    tie |= (unsigned)(ok && !sel && key == Z.T) << j;
+  }
+  const int n_def = __builtin_popcount(df);
+  const int n_rare = __builtin_popcount(lt) + (__builtin_popcount(tie) << 16);  // (<= 4,096 each per workgroup)
+  if (!__syncthreads_or((n_def | n_rare) != 0)) return;  // uniform
+  int tot_def = 0, my_def = 0, tot_rare = 0, my_rare = 0;
+  if (scan_mode) my_def = tk_block_excl_scan(n_def, L.lds4, tot_def);  // uniform
+  const bool rare = __syncthreads_or(n_rare != 0);  // uniform
+  if (rare) {
+    my_rare = tk_block_excl_scan(n_rare, L.lds4, tot_rare);
+    if (tid == 0) {
+      L.base_lt = (tot_rare & 0xffff) ? atomicAdd(&S->cnt_lt, tot_rare & 0xffff) : 0;
+      L.base_tie = (tot_rare >> 16) ? atomicAdd(&S->cnt_tie, tot_rare >> 16) : 0;
+    }
+    __syncthreads();
+  }
+  int p_def = def_pos + my_def;
+  int p_late = rare ? c_def + L.base_lt + (my_rare & 0xffff) : 0;
+  int p_tie = rare ? Z.c_lt + L.base_tie + (my_rare >> 16) : 0;
+  def_pos += tot_def;
+  if ((df | lt | tie) == 0u) return;  // (a thread selects ~1 % of its values)
+#pragma unroll
+  for (int j = 0; j < TK_ITEMS; j++) {
+    const unsigned long long e = ((unsigned long long)topk_desc_key(v[j]) << 32) | (uint32_t)(base + j * TK_THREADS + tid);
+    if (df & (1u << j)) out[p_def++] = e;
+    else if (lt & (1u << j)) out[p_late++] = e;
+    else if (tie & (1u << j)) out[p_tie++] = e;
+  }
+}
+
 __global__ __launch_bounds__(TK_THREADS) void tk_compact_kernel(TkParams P, SegState* __restrict__ st,
                                                                const int* __restrict__ blk_ties,
                                                                unsigned long long* __restrict__ cand, int kmax) {
@@ -359,7 +436,36 @@ __global__ __launch_bounds__(TK_THREADS) void tk_compact_kernel(TkParams P, SegS
   const float* x = P.in.ptr[l] + (long)img * P.in.stride[l];
   unsigned long long* out = cand + (long)seg * kmax;
   __shared__ TkCompactLds L;
-  int before = Z.ordered ? blk_ties[(long)seg * P.maxblk + blockIdx.x] : 0;  // ties in the workgroups before this one
+  if (!Z.ordered) {  // uniform
+    const bool scan_mode = P.blk_def != nullptr && !Z.take_all;  // (pass 2 does not run for a take-all segment)
+    int def_pos = scan_mode ? P.blk_def[(long)seg * P.maxblk + blockIdx.x] : 0;
+    const int c_def = scan_mode ? S->c_def : 0;
+    // the next chunk's 16 loads are issued before this chunk's barriers.  (Measured on RetinaNet's 2 x 16.1M logits:
+    // 90 us with a reservation per chunk, 55-69 us for every variant since -- one reservation per 4 chunks, none at
+    // all, with and without this prefetch -- against 25-29 us for the histogram passes over the same data, which have
+    // no barrier in their chunk loop.  What bounds this kernel is not identified yet: DESIGN.md 3.7b.)
+    const int tid = threadIdx.x;
+    auto load = [&](long base, float (&v)[TK_ITEMS]) {
+      const long last = (long)size - 1 - base;  // >= 0
+#pragma unroll
+      for (int j = 0; j < TK_ITEMS; j++) v[j] = x[base + min((long)(j * TK_THREADS + tid), last)];
+    };
+    float cur[TK_ITEMS], nxt[TK_ITEMS];
+    load(base0, cur);
+    for (int rep = 0; rep < P.reps; rep++) {
+      const long base = base0 + (long)rep * TK_CHUNK;
+      if (base >= size) break;  // uniform
+      const bool more = rep + 1 < P.reps && base + TK_CHUNK < size;  // uniform
+      if (more) load(base + TK_CHUNK, nxt);
+      if (rep) __syncthreads();  // the previous chunk's readers of L are done
+      tk_compact_cls(P, Z, S, cur, base, (long)size - base, out, L, scan_mode, c_def, def_pos);
+      if (!more) break;
+#pragma unroll
+      for (int j = 0; j < TK_ITEMS; j++) cur[j] = nxt[j];
+    }
+    return;
+  }
+  int before = blk_ties[(long)seg * P.maxblk + blockIdx.x];  // ties in the workgroups before this one
   for (int rep = 0; rep < P.reps; rep++) {
     const long base = base0 + (long)rep * TK_CHUNK;
     if (base >= size) break;  // uniform
@@ -632,7 +738,7 @@ __global__ __launch_bounds__(256) void tk_merge_kernel(TkParams P, const SegStat
   }
 }
 
-struct TkWs { SegState* st; int* hist; int* blk_ties; unsigned long long* cand; size_t zero_bytes, total; int maxblk, kmax, reps, tickets; };
+struct TkWs { SegState* st; int* hist; int* blk_ties; int* blk_def; unsigned long long* cand; size_t zero_bytes, total; int maxblk, kmax, reps, tickets; };
 static size_t tk_al(size_t x) { return (x + 255) / 256 * 256; }
 static TkWs tk_carve(const TopkInput& in, void* base) {
   TkWs w{};
@@ -643,7 +749,9 @@ static TkWs tk_carve(const TopkInput& in, void* base) {
   // small segments (RPN): few workgroups, the last one of a segment scans (tickets) -- saves 4 launches; large ones
   // (RetinaNet: 3,000 chunks per segment): one chunk per workgroup for occupancy, separate scan launches
   w.tickets = chunks <= 256;
-  w.reps = w.tickets ? 1 : (chunks + 1023) / 1024;  // ~1,000 workgroups per large segment: amortises the LDS histogram
+  // <= ~1,000 workgroups per large segment (amortises the LDS histogram), each of >= 4 chunks (the compaction loads one
+  // chunk ahead)
+  w.reps = w.tickets ? 1 : std::max(4, (chunks + 1023) / 1024);
   w.maxblk = (chunks + w.reps - 1) / w.reps;
   w.kmax = kmax;
   size_t off = 0;
@@ -652,6 +760,7 @@ static TkWs tk_carve(const TopkInput& in, void* base) {
   w.hist = (int*)take(ns * 3 * TK_BINS * sizeof(int));
   w.zero_bytes = off;  // states + histograms are zeroed per call
   w.blk_ties = (int*)take(ns * w.maxblk * sizeof(int));
+  w.blk_def = w.tickets ? nullptr : (int*)take(ns * w.maxblk * sizeof(int));
   w.cand = (unsigned long long*)take(ns * kmax * sizeof(unsigned long long));
   w.total = off;
   return w;
@@ -685,6 +794,7 @@ int topk_select(const TopkInput& in, bool use_thr, float xmin, uint32_t* sel, in
   P.maxblk = w.maxblk;
   P.reps = w.reps;
   P.tickets = w.tickets;
+  P.blk_def = w.blk_def;
   { const int zrc = zero_async(ws, w.zero_bytes, s, clear_word); if (zrc) return zrc; }
   dim3 grid(w.maxblk, in.N * in.L), block(TK_THREADS);
   const dim3 segs(in.N * in.L);
