@@ -1,0 +1,257 @@
+// Proposal labelling + sampling for the ROI heads, whole batch, FIXED output size, no host sync.
+//   replaces  roi_heads/roi_heads.py:219-295 (ROIHeads.label_and_sample_proposals): add_ground_truth_to_proposals
+//             (proposal_generator/proposal_utils.py:138-205), pairwise_iou (structures/boxes.py:312-358), Matcher
+//             (modeling/matcher.py:62-102, allow_low_quality_matches=False as roi_heads.py:176-180 builds it),
+//             _sample_proposals (roi_heads.py:181-216) and subsample_labels (modeling/sampling.py:9-54)
+// The reference runs this per image with data-dependent shapes: two nonzero() syncs inside subsample_labels, two
+// randperm sorts, index gathers, two .item() reads for the logger.  The ROI heads of a captured training step cannot
+// wait for the host, so this version has a fixed shape: S = batch_size_per_image rows per image -- the sampled
+// foreground candidates first, then the background ones, then padding (class -1, index -1, zero box) -- and the two
+// counts stay on the device.  The number of valid proposals of an image is read from device words (the NMS result
+// buffer of find_top_rpn_proposals_fused), so nothing between the RPN and the poolers needs the host.
+//
+// Sampling rule = detectron2_amd/modeling/sampling.py: one uniform key per candidate, the num_pos smallest keys among
+// the positives and the num_neg smallest among the negatives (a uniform random subset of each; ties by candidate
+// index).  The keys come from the caller (torch.rand: the random stream stays torch's).  Output order inside a group:
+// ascending key -- the reference's order is a random permutation, i.e. not defined.
+//
+// One 1,024-thread workgroup per image: candidates (<= LS_MAX, 4 per thread) keep their running best match in registers
+// while the ground truth streams through LDS; rank = number of same-group candidates with a smaller (key, index),
+// counted against LDS (n^2 compares of 1,100 candidates: ~1 us).  Matching arithmetic: matcher_core.h (bit-exact with
+// d2amd_match_boxes; -ffp-contract=off).
+#pragma clang fp contract(off)
+#include <cstring>
+
+#include "common.h"
+#include "matcher_core.h"
+
+namespace d2amd {
+
+constexpr int LS_THREADS = 1024, LS_PER = 4, LS_MAX = LS_THREADS * LS_PER, LS_GT_CHUNK = 512;
+constexpr int LS_MAX_IMAGES = 16;  // per launch
+
+struct LsImage {
+  const float4* props;
+  const int64_t* limits;
+  const float4* gt;
+  const int64_t* gt_classes;
+  const float* keys;
+  int max_props, n_limits, num_gt;
+};
+
+struct LsBatch {
+  LsImage img[LS_MAX_IMAGES];
+  MatchCfg cfg;
+  int S, pos_max, append_gt;
+  int64_t num_classes;
+  float4* boxes;
+  int64_t *classes, *gt_index, *index;
+  int* counts;
+};
+
+__global__ __launch_bounds__(LS_THREADS) void label_sample_kernel(const LsBatch B) {
+  __shared__ float s_key[LS_MAX];
+  __shared__ int8_t s_grp[LS_MAX];  // 0 positive, 1 negative, 2 neither / not a candidate
+  __shared__ float4 s_gt[LS_GT_CHUNK];
+  __shared__ float s_garea[LS_GT_CHUNK];
+  __shared__ int s_n, s_gt_nan, s_cnt[2];
+  const int tid = threadIdx.x, image = blockIdx.x;
+  // (constant indices only into the kernel-argument struct: a dynamic one makes the compiler copy it to scratch)
+  LsImage I = B.img[0];
+#pragma unroll
+  for (int q = 1; q < LS_MAX_IMAGES; q++)
+    if (q == image) I = B.img[q];
+  if (tid == 0) {
+    long n = I.max_props;
+    for (int l = 0; l < I.n_limits; l++) {
+      const long v = (long)I.limits[l];
+      n = v < n ? v : n;
+    }
+    s_n = (int)(n < 0 ? 0 : n);
+    s_cnt[0] = s_cnt[1] = 0;
+  }
+  __syncthreads();
+  const int n = s_n, G = I.num_gt;
+  const int ncand = n + (B.append_gt ? G : 0);
+  // ---- candidates of this thread: c = tid + k * LS_THREADS
+  float4 box[LS_PER];
+  float area[LS_PER], best[LS_PER];
+  int besti[LS_PER];
+  bool have[LS_PER], bnan[LS_PER];
+#pragma unroll
+  for (int k = 0; k < LS_PER; k++) {
+    const int c = tid + k * LS_THREADS;
+    box[k] = make_float4(0, 0, 0, 0);
+    if (c < n) box[k] = I.props[c];
+    else if (c < ncand) box[k] = I.gt[c - n];
+    area[k] = (box[k].z - box[k].x) * (box[k].w - box[k].y);
+    bnan[k] = mt_has_nan(box[k]);
+    best[k] = 0.f; besti[k] = 0; have[k] = false;
+  }
+  // ---- pairwise_iou + Matcher: first maximal ground truth per candidate (torch.max over dim 0; NaN is maximal)
+  for (int m0 = 0; m0 < G; m0 += LS_GT_CHUNK) {
+    const int mc = min(LS_GT_CHUNK, G - m0);
+    __syncthreads();
+    if (tid == 0) s_gt_nan = 0;
+    __syncthreads();
+    for (int i = tid; i < mc; i += LS_THREADS) {
+      const float4 a = I.gt[m0 + i];
+      s_gt[i] = a;
+      s_garea[i] = (a.z - a.x) * (a.w - a.y);
+      if (mt_has_nan(a)) s_gt_nan = 1;
+    }
+    __syncthreads();
+    const bool gnan = s_gt_nan != 0;
+    for (int i = 0; i < mc; i++) {
+      const float4 g = s_gt[i];
+      const float ga = s_garea[i];
+#pragma unroll
+      for (int k = 0; k < LS_PER; k++) {
+        if (tid + k * LS_THREADS >= ncand) continue;
+        const float v = (gnan || bnan[k]) ? mt_iou(g, ga, box[k]) : mt_iou_fast(g, ga, box[k], area[k]);
+        const bool better = !have[k] || (v > best[k]) || (v != v && best[k] == best[k]);
+        if (better) { best[k] = v; besti[k] = m0 + i; have[k] = true; }
+      }
+    }
+  }
+  // ---- _sample_proposals: class per candidate, group, key
+  int64_t cls[LS_PER];
+  int npos = 0, nneg = 0;
+#pragma unroll
+  for (int k = 0; k < LS_PER; k++) {
+    const int c = tid + k * LS_THREADS;
+    int grp = 2;
+    cls[k] = -1;
+    if (c < ncand) {
+      if (G > 0) {
+        const int8_t lab = mt_label(best[k], B.cfg);
+        cls[k] = lab == 0 ? B.num_classes : (lab == -1 ? (int64_t)-1 : I.gt_classes[besti[k]]);
+      } else {
+        cls[k] = B.num_classes;  // roi_heads.py:207: no ground truth -> every proposal is background
+      }
+      grp = cls[k] == B.num_classes ? 1 : (cls[k] == -1 ? 2 : 0);  // sampling.py:39-40
+      s_key[c] = I.keys[c < n ? c : I.max_props + (c - n)];
+    }
+    if (c < LS_MAX) s_grp[c] = (int8_t)grp;
+    npos += grp == 0;
+    nneg += grp == 1;
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    npos += __shfl_xor(npos, d, 64);
+    nneg += __shfl_xor(nneg, d, 64);
+  }
+  if ((tid & 63) == 0) {
+    if (npos) atomicAdd(&s_cnt[0], npos);
+    if (nneg) atomicAdd(&s_cnt[1], nneg);
+  }
+  __syncthreads();
+  const int num_pos = min(s_cnt[0], B.pos_max);      // sampling.py:42-44
+  const int num_neg = min(s_cnt[1], B.S - num_pos);  // sampling.py:45-47
+  // ---- rank inside the group by (key, index); the selected ones go to their slot
+  float4* ob = B.boxes + (long)image * B.S;
+  int64_t* oc = B.classes + (long)image * B.S;
+  int64_t* og = B.gt_index + (long)image * B.S;
+  int64_t* oi = B.index + (long)image * B.S;
+#pragma unroll
+  for (int k = 0; k < LS_PER; k++) {
+    const int c = tid + k * LS_THREADS;
+    if (c >= ncand) continue;
+    const int grp = s_grp[c];
+    if (grp == 2) continue;
+    const float key = s_key[c];
+    const int want = grp == 0 ? num_pos : num_neg;
+    int rank = 0;
+    for (int j = 0; j < ncand && rank < want; j++) {
+      const float kj = s_key[j];
+      rank += (s_grp[j] == grp && (kj < key || (kj == key && j < c))) ? 1 : 0;
+    }
+    if (rank >= want) continue;
+    const int slot = (grp == 0 ? 0 : num_pos) + rank;
+    ob[slot] = box[k];
+    oc[slot] = cls[k];
+    og[slot] = besti[k];
+    oi[slot] = c;
+  }
+  for (int t = num_pos + num_neg + tid; t < B.S; t += LS_THREADS) {  // padding
+    ob[t] = make_float4(0, 0, 0, 0);
+    oc[t] = -1;
+    og[t] = 0;
+    oi[t] = -1;
+  }
+  if (tid == 0) {
+    B.counts[2 * image] = num_pos;
+    B.counts[2 * image + 1] = num_pos + num_neg;
+  }
+}
+
+}  // namespace d2amd
+
+using namespace d2amd;
+
+extern "C" int d2amd_label_and_sample_max_candidates(void) { return LS_MAX; }
+
+extern "C" int d2amd_label_and_sample_proposals(const d2amd_sample_image* images, int count, const float* thresholds,
+                                                const int8_t* labels, int T, int batch_size_per_image,
+                                                int max_positives, int64_t num_classes, int append_gt,
+                                                float* boxes_out, int64_t* classes_out, int64_t* gt_index_out,
+                                                int64_t* index_out, int32_t* counts_out, void* stream) {
+  D2_CHECK_ARG(count >= 0 && (count == 0 || images != nullptr), "label_and_sample: bad image list");
+  D2_CHECK_ARG(T >= 0 && T <= D2AMD_MATCHER_MAX_THRESHOLDS && labels != nullptr && (T == 0 || thresholds != nullptr),
+               "label_and_sample: %d thresholds (max %d)", T, D2AMD_MATCHER_MAX_THRESHOLDS);
+  D2_CHECK_ARG(batch_size_per_image > 0 && max_positives >= 0 && max_positives <= batch_size_per_image &&
+                   num_classes >= 0,
+               "label_and_sample: bad sampling parameters");
+  if (count == 0) return D2AMD_OK;
+  D2_CHECK_ARG(boxes_out && classes_out && gt_index_out && index_out && counts_out, "label_and_sample: null output");
+  LsBatch B;
+  std::memset(&B, 0, sizeof(B));
+  B.cfg.T = T;
+  for (int k = 0; k < T; k++) {
+    D2_CHECK_ARG(thresholds[k] > 0.f && (k == 0 || thresholds[k - 1] <= thresholds[k]),
+                 "label_and_sample: thresholds must be positive and ascending");
+    B.cfg.thr[k] = thresholds[k];
+  }
+  for (int k = 0; k <= T; k++) {
+    D2_CHECK_ARG(labels[k] >= -1 && labels[k] <= 1, "label_and_sample: labels must be in {-1, 0, 1}");
+    B.cfg.lab[k] = labels[k];
+  }
+  B.S = batch_size_per_image;
+  B.pos_max = max_positives;  // the caller's int(num_samples * positive_fraction), sampling.py:42
+  B.append_gt = append_gt != 0;
+  B.num_classes = num_classes;
+  for (int i0 = 0; i0 < count; i0 += LS_MAX_IMAGES) {
+    const int c = count - i0 < LS_MAX_IMAGES ? count - i0 : LS_MAX_IMAGES;
+    for (int i = 0; i < c; i++) {
+      const d2amd_sample_image& s = images[i0 + i];
+      D2_CHECK_ARG(s.max_proposals >= 0 && s.num_gt >= 0 && s.n_limits >= 0 && s.n_limits <= 4,
+                   "label_and_sample: image %d: bad sizes", i0 + i);
+      if ((long)s.max_proposals + (append_gt ? s.num_gt : 0) > LS_MAX) {
+        set_error("label_and_sample: image %d has %d + %d candidates (max %d)", i0 + i, s.max_proposals, s.num_gt,
+                  LS_MAX);
+        return D2AMD_EUNSUPPORTED;
+      }
+      D2_CHECK_ARG((s.max_proposals == 0 || s.proposals) && (s.n_limits == 0 || s.limits) &&
+                       (s.num_gt == 0 || (s.gt_boxes && s.gt_classes)) &&
+                       (s.max_proposals + s.num_gt == 0 || s.keys),
+                   "label_and_sample: image %d: null pointer", i0 + i);
+      LsImage& I = B.img[i];
+      I.props = (const float4*)s.proposals;
+      I.limits = s.limits;
+      I.gt = (const float4*)s.gt_boxes;
+      I.gt_classes = s.gt_classes;
+      I.keys = s.keys;
+      I.max_props = s.max_proposals;
+      I.n_limits = s.n_limits;
+      I.num_gt = s.num_gt;
+    }
+    B.boxes = (float4*)boxes_out + (long)i0 * B.S;
+    B.classes = classes_out + (long)i0 * B.S;
+    B.gt_index = gt_index_out + (long)i0 * B.S;
+    B.index = index_out + (long)i0 * B.S;
+    B.counts = counts_out + 2 * i0;
+    hipLaunchKernelGGL(label_sample_kernel, dim3(c), dim3(LS_THREADS), 0, (hipStream_t)stream, B);
+    D2_LAUNCH_OK();
+  }
+  return D2AMD_OK;
+}

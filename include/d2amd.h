@@ -178,6 +178,37 @@ int d2amd_pairwise_iou(const float* boxes1, int n, const float* boxes2, int m, i
 int d2amd_box_iou_rotated(const float* boxes1, int n, const float* boxes2, int m, float* out,
                           void* stream);
 
+/* ---- proposal labelling + sampling for the ROI heads: ROIHeads.label_and_sample_proposals
+ * (detectron2/modeling/roi_heads/roi_heads.py:219-295) = add_ground_truth_to_proposals
+ * (proposal_generator/proposal_utils.py:138-205) + pairwise_iou + Matcher (allow_low_quality_matches=False,
+ * roi_heads.py:176-180) + _sample_proposals (roi_heads.py:181-216) + subsample_labels (modeling/sampling.py:9-54), for
+ * a batch, with a FIXED output shape and no host sync (the ROI half of a captured step cannot wait for the host).
+ * Per image: candidates = the first n proposals, n = min(max_proposals, limits[0 .. n_limits)) with `limits` DEVICE
+ * int64 words (e.g. the kept / finite counts d2amd_nms_batched_runs left in its result buffer; n_limits <= 4, may be
+ * 0), followed by the ground-truth boxes when append_gt.  keys: one uniform random fp32 per candidate SLOT --
+ * [max_proposals] for the proposals, then [num_gt] for the appended boxes (no NaN).  Sampling rule: the
+ * min(#positives, max_positives) smallest keys among the positives (class not in {-1, num_classes}), then the
+ * min(#negatives, batch_size_per_image - sampled positives) smallest among the negatives; ties by candidate index.
+ * Outputs, batch_size_per_image rows per image: positives first, then negatives (ascending key inside a group), then
+ * padding -- boxes_out [count][S][4] (zero), classes_out [count][S] (ground-truth class, num_classes for background,
+ * -1), gt_index_out [count][S] (the matched ground truth: matched_idxs[sampled_idxs]; 0 for padding / no ground
+ * truth), index_out [count][S] (candidate index = the reference's sampled_idxs; -1), counts_out [count][2] =
+ * (positives, rows).  thresholds / labels: Matcher's constructor arguments (host), as for d2amd_match_boxes.
+ * max_proposals + num_gt <= d2amd_label_and_sample_max_candidates() per image, else D2AMD_EUNSUPPORTED. */
+typedef struct {
+  const float* proposals;    /* [max_proposals][4] fp32 xyxy, 16-byte aligned */
+  const int64_t* limits;     /* [n_limits] device words, or NULL */
+  const float* gt_boxes;     /* [num_gt][4], 16-byte aligned */
+  const int64_t* gt_classes; /* [num_gt] */
+  const float* keys;         /* [max_proposals + num_gt] */
+  int max_proposals, n_limits, num_gt;
+} d2amd_sample_image;
+int d2amd_label_and_sample_max_candidates(void);
+int d2amd_label_and_sample_proposals(const d2amd_sample_image* images, int count, const float* thresholds,
+                                     const int8_t* labels, int T, int batch_size_per_image, int max_positives,
+                                     int64_t num_classes, int append_gt, float* boxes_out, int64_t* classes_out,
+                                     int64_t* gt_index_out, int64_t* index_out, int32_t* counts_out, void* stream);
+
 /* ---- anchor / proposal matching.  Matcher.__call__ + set_low_quality_matches_
  * (detectron2/modeling/matcher.py:62-127) fused with pairwise_iou (structures/boxes.py:312-358), as called
  * from proposal_generator/rpn.py:307-364 and roi_heads/roi_heads.py:257-295: the M x N matrix is never

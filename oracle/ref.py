@@ -59,11 +59,10 @@ def py_boxes():
     return _load_by_path("_d2ref_boxes", "detectron2/structures/boxes.py")
 
 
-def py_matcher():
-    """detectron2/modeling/matcher.py.  Its only non-torch import is `nonzero_tuple` from
-    detectron2.layers (layers/wrappers.py:150-162: `x.nonzero().unbind(1)` outside scripting); the
-    package itself is not importable here, so a stub module providing exactly that helper is
-    registered for the duration of the load."""
+def _load_with_layers_stub(name, relpath):
+    """Load a reference module whose only non-torch import is `nonzero_tuple` from detectron2.layers
+    (layers/wrappers.py:150-162: `x.nonzero().unbind(1)` outside scripting); the package itself is not importable
+    here, so a stub module providing exactly that helper is registered for the duration of the load."""
     saved = {k: sys.modules.get(k) for k in ("detectron2", "detectron2.layers")}
     pkg, layers = types.ModuleType("detectron2"), types.ModuleType("detectron2.layers")
 
@@ -76,13 +75,23 @@ def py_matcher():
     pkg.layers = layers
     sys.modules["detectron2"], sys.modules["detectron2.layers"] = pkg, layers
     try:
-        return _load_by_path("_d2ref_matcher", "detectron2/modeling/matcher.py")
+        return _load_by_path(name, relpath)
     finally:
         for k, v in saved.items():
             if v is None:
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+
+
+def py_matcher():
+    """detectron2/modeling/matcher.py."""
+    return _load_with_layers_stub("_d2ref_matcher", "detectron2/modeling/matcher.py")
+
+
+def py_sampling():
+    """detectron2/modeling/sampling.py (subsample_labels)."""
+    return _load_with_layers_stub("_d2ref_sampling", "detectron2/modeling/sampling.py")
 
 
 def _with_stubs(stubs, fn):

@@ -292,6 +292,55 @@ def paste_device_path_golden():
     print("paste_masks_full.npz written", int((soft > 0).sum()))
 
 
+def label_sample_golden():
+    """ROIHeads.label_and_sample_proposals (roi_heads.py:219-295) with the reference's own pairwise_iou, Matcher and
+    subsample_labels.  The ROIHeads class itself needs the whole package; the lines around those calls are restated
+    here: the concatenation of add_ground_truth_to_proposals (proposal_utils.py:196-203) and the relabelling of
+    _sample_proposals (roi_heads.py:199-208).  The random draw of subsample_labels is kept as (sizes, index sets)."""
+    import torch
+
+    from oracle import ref
+
+    bx, mt, sp = ref.py_boxes(), ref.py_matcher(), ref.py_sampling()
+    rng = np.random.default_rng(20260923)
+    torch.manual_seed(7)
+    cases = {  # name: (proposals, ground truth, thresholds, labels, batch per image, positive fraction)
+        "typical": (1000, 7, [0.5], [0, 1], 512, 0.25),
+        "no_gt": (300, 0, [0.5], [0, 1], 512, 0.25),
+        "few": (40, 3, [0.5], [0, 1], 512, 0.25),
+        "many_positives": (900, 12, [0.3], [0, 1], 256, 0.25),
+        "ignore_band": (800, 9, [0.3, 0.7], [0, -1, 1], 512, 0.5),
+    }
+    d = {}
+    for name, (n, G, thr, lab, S, frac) in cases.items():
+        g = rng.uniform(0, 600, (G, 4)).astype(np.float32)
+        g[:, 2:] = g[:, :2] + rng.uniform(30, 300, (G, 2)).astype(np.float32)
+        p = rng.uniform(0, 700, (n, 4)).astype(np.float32)
+        p[:, 2:] = p[:, :2] + rng.uniform(8, 320, (n, 2)).astype(np.float32)
+        if G:  # jittered copies of the ground truth: the positives
+            k = n // 3 if name != "many_positives" else (2 * n) // 3
+            src = g[rng.integers(0, G, k)]
+            p[:k] = src + rng.normal(0, 12, (k, 4)).astype(np.float32)
+            p[k] = g[0]  # an exact duplicate of a ground-truth box
+        gc = rng.integers(0, 80, G).astype(np.int64)
+        cand = torch.cat([torch.from_numpy(p), torch.from_numpy(g)])  # proposal_utils.py:196-203
+        q = bx.pairwise_iou(bx.Boxes(torch.from_numpy(g)), bx.Boxes(cand))
+        midx, mlab = mt.Matcher(thr, lab, allow_low_quality_matches=False)(q)
+        if G:  # roi_heads.py:199-205
+            cls = torch.from_numpy(gc)[midx]
+            cls[mlab == 0] = 80
+            cls[mlab == -1] = -1
+        else:  # :207
+            cls = torch.zeros_like(midx) + 80
+        pos, neg = sp.subsample_labels(cls, S, frac, 80)
+        d.update({f"{name}_proposals": p, f"{name}_gt": g, f"{name}_gt_classes": gc,
+                  f"{name}_cfg": np.array([len(thr)] + thr + lab + [S, frac], np.float64),
+                  f"{name}_matched_idxs": midx.numpy(), f"{name}_matched_labels": mlab.numpy().astype(np.int8),
+                  f"{name}_classes": cls.numpy(), f"{name}_ref_pos": pos.numpy(), f"{name}_ref_neg": neg.numpy()})
+        print(name, "candidates", len(cand), "sampled", len(pos), "+", len(neg))
+    np.savez_compressed(os.path.join(OUT, "label_sample.npz"), **d)
+
+
 if __name__ == "__main__":
     import sys
 
@@ -301,7 +350,10 @@ if __name__ == "__main__":
         paste_device_path_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "dense_detector":
         dense_detector_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "label_sample":
+        label_sample_golden()
     else:
         main()
         mask_head_golden()
         dense_detector_golden()
+        label_sample_golden()
