@@ -123,6 +123,8 @@ _SIGNATURES = {
     "d2amd_mask_rcnn_loss_workspace_bytes": (_sz, [_i]),
     "d2amd_mask_rcnn_loss_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "d2amd_mask_rcnn_loss_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "d2amd_mask_rcnn_loss_forward_masked": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "d2amd_mask_rcnn_loss_backward_masked": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "d2amd_deform_conv_workspace_bytes": (_sz, [ctypes.POINTER(DcnParams), _i]),
     "d2amd_deform_conv_forward": (_i, [ctypes.POINTER(DcnParams), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "d2amd_deform_conv_backward": (_i, [ctypes.POINTER(DcnParams)] + [_vp] * 11 + [_sz, _vp]),

@@ -20,7 +20,9 @@ struct MaskPartial { float loss; int incorrect, positive, false_pos, false_neg, 
 __device__ __forceinline__ float log_sigmoid_f(float x) { return fminf(x, 0.f) - log1pf(expf(-fabsf(x))); }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
 
-template <typename T>
+// MASKED: rows whose class is outside [0, C) are IGNORED (no loss, no statistics; `bad` then counts the ignored rows)
+// instead of reported -- the fixed-shape lists of d2amd_label_and_sample_proposals carry background / padding rows
+template <typename T, bool MASKED>
 __global__ __launch_bounds__(256) void mask_loss_partial_kernel(const T* __restrict__ logits,
                                                                const int64_t* __restrict__ cls,
                                                                const uint8_t* __restrict__ gt, int C, int HW,
@@ -55,9 +57,14 @@ __global__ __launch_bounds__(256) void mask_loss_partial_kernel(const T* __restr
     }
     __syncthreads();
   }
-  if (tid == 0) part[b] = MaskPartial{bad ? 0.f : sl[0], si[0][0], si[1][0], si[2][0], si[3][0], bad ? 1 : 0};
+  if (tid == 0) {
+    if (MASKED && bad) part[b] = MaskPartial{0.f, 0, 0, 0, 0, 1};
+    else part[b] = MaskPartial{bad ? 0.f : sl[0], si[0][0], si[1][0], si[2][0], si[3][0], bad ? 1 : 0};
+  }
 }
 
+// MASKED: mean over the rows that count (B - ignored; 0 rows -> loss 0), stats_out[5] = that number of rows
+template <bool MASKED>
 __global__ __launch_bounds__(256) void mask_loss_final_kernel(const MaskPartial* __restrict__ part, int B, int HW,
                                                              float* __restrict__ loss_out,
                                                              int64_t* __restrict__ stats_out) {
@@ -84,7 +91,13 @@ __global__ __launch_bounds__(256) void mask_loss_final_kernel(const MaskPartial*
     __syncthreads();
   }
   if (tid == 0) {
-    *loss_out = (float)(sl[0] / ((double)B * (double)HW));  // reduction="mean"
+    if (MASKED) {
+      const long rows = (long)B - si[4][0];
+      *loss_out = rows > 0 ? (float)(sl[0] / ((double)rows * (double)HW)) : 0.f;
+      stats_out[5] = rows;
+    } else {
+      *loss_out = (float)(sl[0] / ((double)B * (double)HW));  // reduction="mean"
+    }
 #pragma unroll
     for (int q = 0; q < 5; q++) stats_out[q] = si[q][0];
   }
@@ -108,6 +121,42 @@ __global__ __launch_bounds__(256) void mask_loss_backward_kernel(const T* __rest
   struct __attribute__((aligned(VEC * sizeof(T)))) Pack { T e[VEC]; };
   Pack o;
   if (want == c) {
+    const float g = *grad_loss * inv_n;
+#pragma unroll
+    for (int q = 0; q < VEC; q++) {
+      const float xv = to_f32(logits[plane * HW + i0 + q]);
+      const float tv = gt[b * HW + i0 + q] ? 1.f : 0.f;
+      o.e[q] = from_f32<T>((sigmoid_f(xv) - tv) * g);
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < VEC; q++) o.e[q] = from_f32<T>(0.f);
+  }
+  *reinterpret_cast<Pack*>(grad + plane * HW + i0) = o;
+}
+
+// the same with the mean taken over `*rows` rows, a number only the device knows (stats_out[5] of the masked forward);
+// rows of an ignored class get zeros like any other plane that is not the row's class plane
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void mask_loss_backward_masked_kernel(const T* __restrict__ logits,
+                                                                       const int64_t* __restrict__ cls,
+                                                                       const uint8_t* __restrict__ gt,
+                                                                       const float* __restrict__ grad_loss,
+                                                                       const int64_t* __restrict__ rows, int C, int HW,
+                                                                       long nvec, T* __restrict__ grad) {
+  const long v = (long)blockIdx.x * 256 + threadIdx.x;
+  if (v >= nvec) return;
+  const int per_plane = HW / VEC;
+  const long plane = v / per_plane;
+  const int i0 = (int)(v - plane * per_plane) * VEC;
+  const long b = plane / C;
+  const int c = (int)(plane - b * C);
+  const long want = cls ? cls[b] : 0;
+  struct __attribute__((aligned(VEC * sizeof(T)))) Pack { T e[VEC]; };
+  Pack o;
+  if (want == c) {
+    const long r = *rows;
+    const float inv_n = r > 0 ? (float)(1.0 / ((double)r * (double)HW)) : 0.f;  // (the host's expression, on the device)
     const float g = *grad_loss * inv_n;
 #pragma unroll
     for (int q = 0; q < VEC; q++) {
@@ -159,9 +208,10 @@ extern "C" int d2amd_mask_rcnn_inference(const void* logits, const int64_t* clas
 
 extern "C" size_t d2amd_mask_rcnn_loss_workspace_bytes(int B) { return (size_t)(B > 0 ? B : 1) * sizeof(MaskPartial); }
 
-extern "C" int d2amd_mask_rcnn_loss_forward(const void* logits, const int64_t* gt_classes, const uint8_t* gt_masks,
-                                            int B, int C, int HW, int dtype, float* loss_out, int64_t* stats_out,
-                                            void* workspace, size_t workspace_bytes, void* stream) {
+template <bool MASKED>
+static int mask_loss_forward_impl(const void* logits, const int64_t* gt_classes, const uint8_t* gt_masks, int B, int C,
+                                  int HW, int dtype, float* loss_out, int64_t* stats_out, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
   D2_CHECK_ARG(B > 0 && C > 0 && HW > 0, "mask_rcnn_loss_forward: bad shape (the empty case is the caller's)");
   D2_CHECK_ARG(gt_classes != nullptr || C == 1, "mask_rcnn_loss_forward: class-specific logits need gt_classes");
   D2_CHECK_ARG(logits && gt_masks && loss_out && stats_out, "mask_rcnn_loss_forward: null pointer");
@@ -172,13 +222,29 @@ extern "C" int d2amd_mask_rcnn_loss_forward(const void* logits, const int64_t* g
   MaskPartial* part = (MaskPartial*)workspace;
   hipStream_t s = (hipStream_t)stream;
   return D2_DISPATCH_DTYPE(dtype, [&]() -> int {
-    hipLaunchKernelGGL(mask_loss_partial_kernel<scalar_t>, dim3(B), dim3(256), 0, s, (const scalar_t*)logits, gt_classes,
-                       gt_masks, C, HW, part);
+    hipLaunchKernelGGL((mask_loss_partial_kernel<scalar_t, MASKED>), dim3(B), dim3(256), 0, s, (const scalar_t*)logits,
+                       gt_classes, gt_masks, C, HW, part);
     D2_LAUNCH_OK();
-    hipLaunchKernelGGL(mask_loss_final_kernel, dim3(1), dim3(256), 0, s, part, B, HW, loss_out, stats_out);
+    hipLaunchKernelGGL(mask_loss_final_kernel<MASKED>, dim3(1), dim3(256), 0, s, part, B, HW, loss_out, stats_out);
     D2_LAUNCH_OK();
     return D2AMD_OK;
   });
+}
+
+extern "C" int d2amd_mask_rcnn_loss_forward(const void* logits, const int64_t* gt_classes, const uint8_t* gt_masks,
+                                            int B, int C, int HW, int dtype, float* loss_out, int64_t* stats_out,
+                                            void* workspace, size_t workspace_bytes, void* stream) {
+  return mask_loss_forward_impl<false>(logits, gt_classes, gt_masks, B, C, HW, dtype, loss_out, stats_out, workspace,
+                                       workspace_bytes, stream);
+}
+
+extern "C" int d2amd_mask_rcnn_loss_forward_masked(const void* logits, const int64_t* gt_classes,
+                                                   const uint8_t* gt_masks, int B, int C, int HW, int dtype,
+                                                   float* loss_out, int64_t* stats_out, void* workspace,
+                                                   size_t workspace_bytes, void* stream) {
+  D2_CHECK_ARG(gt_classes != nullptr, "mask_rcnn_loss_forward_masked: the classes carry the mask");
+  return mask_loss_forward_impl<true>(logits, gt_classes, gt_masks, B, C, HW, dtype, loss_out, stats_out, workspace,
+                                      workspace_bytes, stream);
 }
 
 extern "C" int d2amd_mask_rcnn_loss_backward(const void* logits, const int64_t* gt_classes, const uint8_t* gt_masks,
@@ -203,6 +269,35 @@ extern "C" int d2amd_mask_rcnn_loss_backward(const void* logits, const int64_t* 
     } else {
       hipLaunchKernelGGL((mask_loss_backward_kernel<scalar_t, 1>), dim3((unsigned)nblk), dim3(256), 0, s,
                          (const scalar_t*)logits, gt_classes, gt_masks, grad_loss, C, HW, nvec, inv_n,
+                         (scalar_t*)grad_logits);
+    }
+    D2_LAUNCH_OK();
+    return D2AMD_OK;
+  });
+}
+
+extern "C" int d2amd_mask_rcnn_loss_backward_masked(const void* logits, const int64_t* gt_classes,
+                                                    const uint8_t* gt_masks, const float* grad_loss,
+                                                    const int64_t* rows, int B, int C, int HW, int dtype,
+                                                    void* grad_logits, void* stream) {
+  D2_CHECK_ARG(B >= 0 && C > 0 && HW > 0, "mask_rcnn_loss_backward_masked: bad shape");
+  if (B == 0) return D2AMD_OK;
+  D2_CHECK_ARG(logits && gt_classes && gt_masks && grad_loss && rows && grad_logits,
+               "mask_rcnn_loss_backward_masked: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  return D2_DISPATCH_DTYPE(dtype, [&]() -> int {
+    constexpr int VEC = 16 / (int)sizeof(scalar_t);
+    const bool vec = HW % VEC == 0 && ((uintptr_t)grad_logits & 15) == 0;
+    const long n = (long)B * C * HW, nvec = vec ? n / VEC : n;
+    const long nblk = (nvec + 255) / 256;
+    D2_CHECK_ARG(nblk < (1l << 31), "mask_rcnn_loss_backward_masked: tensor too large");
+    if (vec) {
+      hipLaunchKernelGGL((mask_loss_backward_masked_kernel<scalar_t, VEC>), dim3((unsigned)nblk), dim3(256), 0, s,
+                         (const scalar_t*)logits, gt_classes, gt_masks, grad_loss, rows, C, HW, nvec,
+                         (scalar_t*)grad_logits);
+    } else {
+      hipLaunchKernelGGL((mask_loss_backward_masked_kernel<scalar_t, 1>), dim3((unsigned)nblk), dim3(256), 0, s,
+                         (const scalar_t*)logits, gt_classes, gt_masks, grad_loss, rows, C, HW, nvec,
                          (scalar_t*)grad_logits);
     }
     D2_LAUNCH_OK();

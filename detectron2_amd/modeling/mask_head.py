@@ -49,10 +49,51 @@ class _MaskLoss(torch.autograd.Function):
         return grad, None, None
 
 
-def mask_rcnn_loss_from_targets(pred_mask_logits: torch.Tensor, gt_classes, gt_masks: torch.Tensor):
+class _MaskLossMasked(torch.autograd.Function):
+    """_MaskLoss over the rows whose class lies in [0, C) (d2amd_mask_rcnn_loss_forward_masked / _backward_masked).
+    NOT YET RUN ON A GPU: written after round 2's GPU budget was spent; a separate Function so that the validated one
+    above is untouched."""
+
+    @staticmethod
+    def forward(ctx, logits, gt_classes, gt_masks):
+        b, c, h, w = logits.shape
+        x = logits.contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        stats = torch.empty(6, dtype=torch.int64, device=x.device)
+        L = _C.lib()
+        ws_bytes = L.d2amd_mask_rcnn_loss_workspace_bytes(b)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+        with _C.on_device(x.device):
+            _C.check(L.d2amd_mask_rcnn_loss_forward_masked(_C.ptr(x), _C.ptr(gt_classes), _C.ptr(gt_masks), b, c, h * w,
+                                                           _C.dtype_code(x), _C.ptr(loss), _C.ptr(stats), _C.ptr(ws),
+                                                           ctypes.c_size_t(ws_bytes), _C.stream()))
+        ctx.save_for_backward(x, gt_classes, gt_masks)
+        ctx.rows = stats.detach()[5:].clone()  # the row count stays on the device; the backward reads it there
+        ctx.mark_non_differentiable(stats)
+        return loss, stats
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_loss, _grad_stats):
+        x, gt_classes, gt_masks = ctx.saved_tensors
+        b, c, h, w = x.shape
+        g = grad_loss.detach().to(dtype=torch.float32).contiguous()
+        grad = torch.empty_like(x)
+        with _C.on_device(x.device):
+            _C.check(_C.lib().d2amd_mask_rcnn_loss_backward_masked(
+                _C.ptr(x), _C.ptr(gt_classes), _C.ptr(gt_masks), _C.ptr(g), _C.ptr(ctx.rows), b, c, h * w,
+                _C.dtype_code(x), _C.ptr(grad), _C.stream()))
+        return grad, None, None
+
+
+def mask_rcnn_loss_from_targets(pred_mask_logits: torch.Tensor, gt_classes, gt_masks: torch.Tensor,
+                                ignore_invalid_rows: bool = False):
     """Fused core of `mask_rcnn_loss`: (B, C, M, M) logits, (B,) int64 gt classes (ignored / may be None when
     C == 1), (B, M, M) bool targets -> (loss fp32 scalar, stats int64[5] on the device:
-    #incorrect, #positive, #false positive, #false negative, #rows with a class outside [0, C))."""
+    #incorrect, #positive, #false positive, #false negative, #rows with a class outside [0, C)).
+    ignore_invalid_rows (NOT YET RUN ON A GPU, see include/d2amd.h): rows with a class outside [0, C) -- background and
+    padding rows of `label_and_sample_proposals_fixed` -- do not count (mean over the others, zero gradient);
+    stats int64[6]: [4] = ignored rows, [5] = rows that count."""
     _C.require_gpu(pred_mask_logits, gt_masks, op="mask_rcnn_loss")
     b, c = pred_mask_logits.shape[:2]
     assert pred_mask_logits.size(2) == pred_mask_logits.size(3), "Mask prediction must be square!"
@@ -68,6 +109,9 @@ def mask_rcnn_loss_from_targets(pred_mask_logits: torch.Tensor, gt_classes, gt_m
     if c != 1:
         cls = gt_classes.to(device=pred_mask_logits.device, dtype=torch.int64).contiguous()
         assert cls.shape == (b,), cls.shape
+    if ignore_invalid_rows:
+        assert cls is not None, "ignore_invalid_rows: the classes carry the mask (class-specific logits)"
+        return _MaskLossMasked.apply(pred_mask_logits, cls, t)
     return _MaskLoss.apply(pred_mask_logits, cls, t)
 
 

@@ -418,6 +418,19 @@ int d2amd_mask_rcnn_loss_forward(const void* logits, const int64_t* gt_classes, 
 int d2amd_mask_rcnn_loss_backward(const void* logits, const int64_t* gt_classes, const uint8_t* gt_masks,
                                   const float* grad_loss, int B, int C, int HW, int dtype, void* grad_logits,
                                   void* stream);
+/* The same over the rows that COUNT: a row whose class is outside [0, C) -- the background (num_classes) and padding
+ * (-1) rows of d2amd_label_and_sample_proposals' fixed-size lists -- is ignored instead of reported: no loss, no
+ * statistics, zero gradient; the mean is taken over the other rows (mask_head.py:47-113 on the foreground subset
+ * select_foreground_proposals would have made, roi_heads.py:37-75).  stats_out[6]: [4] = ignored rows, [5] = rows
+ * that count; no row -> loss 0 (the reference: `pred_mask_logits.sum() * 0`).  The backward reads the row count from
+ * the DEVICE (`rows` = &stats_out[5]): nothing here needs the host.  NOT YET RUN ON A GPU (written after round 2's
+ * GPU budget was spent; the instruction streams of the entries above are unchanged by its addition). */
+int d2amd_mask_rcnn_loss_forward_masked(const void* logits, const int64_t* gt_classes, const uint8_t* gt_masks, int B,
+                                        int C, int HW, int dtype, float* loss_out, int64_t* stats_out,
+                                        void* workspace, size_t workspace_bytes, void* stream);
+int d2amd_mask_rcnn_loss_backward_masked(const void* logits, const int64_t* gt_classes, const uint8_t* gt_masks,
+                                         const float* grad_loss, const int64_t* rows, int B, int C, int HW, int dtype,
+                                         void* grad_logits, void* stream);
 
 /* ---- deformable convolution v1 / v2.  Replaces detectron2._C.deform_conv_forward,
  * deform_conv_backward_input, deform_conv_backward_filter, modulated_deform_conv_forward,

@@ -4,6 +4,7 @@
                           accuracy / false positive / false negative :88-95, BCE with logits, mean :112)
   mask_rcnn_loss_grad  <- autograd of the above: (sigmoid(x) - t) * g / numel in the class plane, 0 elsewhere
   mask_rcnn_inference  <- mask_head.py:116-158 (gather of the predicted-class plane + sigmoid)
+  mask_rcnn_loss_masked / _grad <- the same on the rows whose class is valid (the foreground subset of fixed-size lists)
 Evaluated in float64 (the reference computes in fp32; parity bar 1e-5 relative on the loss, 1e-6 absolute on
 probabilities / gradients).  Pinned against the reference's own functions run on CPU (loaded with import stubs
 by oracle/ref.py::py_mask_head) through tests/golden/mask_head.npz."""
@@ -47,6 +48,29 @@ def mask_rcnn_loss_grad(logits, gt_classes, gt_masks, grad_loss=1.0):
         out[:, 0] = g
     else:
         out[np.arange(b), np.asarray(gt_classes, np.int64)] = g
+    return out
+
+
+def mask_rcnn_loss_masked(logits, gt_classes, gt_masks):
+    """The loss over the rows whose class lies in [0, C): what mask_rcnn_loss (mask_head.py:47-113) computes on the
+    foreground subset select_foreground_proposals (roi_heads.py:37-75) hands it, for fixed-size lists that carry
+    background (class C) and padding (-1) rows.  -> (loss, stats, rows that count); no row -> 0 (mask_head.py:71-72)."""
+    logits = np.asarray(logits, np.float64)
+    cls = np.asarray(gt_classes, np.int64)
+    ok = (cls >= 0) & (cls < logits.shape[1])
+    if not ok.any():
+        return 0.0, {"counts": np.zeros(4, np.int64)}, 0
+    loss, stats = mask_rcnn_loss(logits[ok], cls[ok], np.asarray(gt_masks)[ok])
+    return loss, stats, int(ok.sum())
+
+
+def mask_rcnn_loss_masked_grad(logits, gt_classes, gt_masks, grad_loss=1.0):
+    logits = np.asarray(logits, np.float64)
+    cls = np.asarray(gt_classes, np.int64)
+    ok = (cls >= 0) & (cls < logits.shape[1])
+    out = np.zeros_like(logits)
+    if ok.any():
+        out[ok] = mask_rcnn_loss_grad(logits[ok], cls[ok], np.asarray(gt_masks)[ok], grad_loss)
     return out
 
 

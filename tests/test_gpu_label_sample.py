@@ -131,3 +131,44 @@ def test_too_many_candidates_is_reported():
     g = torch.zeros((1, 4), device=DEV)
     with pytest.raises(RuntimeError, match="candidates"):
         label_and_sample_proposals_fixed([p], [g], [torch.zeros(1, dtype=torch.int64, device=DEV)])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_masked_mask_loss(dtype):
+    """mask_rcnn_loss_from_targets(ignore_invalid_rows=True) on a fixed-size list == the validated loss on the
+    foreground rows alone (value, statistics, gradient), zero gradient in the ignored rows; with no ignored row it is
+    bit-identical to the unmasked entry; with no row at all the loss is 0."""
+    from detectron2_amd.modeling import mask_rcnn_loss_from_targets
+    from oracle import mask_head as omh
+
+    rng = np.random.default_rng(23)
+    B, C, M = 40, 80, 28
+    xn = (rng.standard_normal((B, C, M, M)) * 2).astype(np.float32)
+    t = rng.random((B, M, M)) < 0.4
+    cls = rng.integers(0, C, B)
+    cls[15:30] = C
+    cls[30:] = -1
+    x = cu(xn).to(dtype).requires_grad_(True)
+    loss, stats = mask_rcnn_loss_from_targets(x, cu(cls), cu(t), ignore_invalid_rows=True)
+    (loss * 0.5).backward()
+    xs = x.detach()[:15].clone().requires_grad_(True)
+    want, wstats = mask_rcnn_loss_from_targets(xs, cu(cls[:15]), cu(t[:15]))
+    (want * 0.5).backward()
+    assert torch.equal(loss, want)  # same rows, same fixed-order reduction
+    assert stats.tolist() == wstats.tolist()[:4] + [25, 15]
+    assert torch.equal(x.grad[:15], xs.grad) and not bool(x.grad[15:].any())
+    ol, _os, rows = omh.mask_rcnn_loss_masked(x.detach().float().cpu().numpy(), cls, t)
+    assert rows == 15 and abs(float(loss) - ol) <= 1e-5 * abs(ol)
+    # every row counts: the masked entry is the unmasked one
+    cls2 = rng.integers(0, C, B)
+    a = x.detach().clone().requires_grad_(True)
+    b = x.detach().clone().requires_grad_(True)
+    la, sa = mask_rcnn_loss_from_targets(a, cu(cls2), cu(t), ignore_invalid_rows=True)
+    lb, sb = mask_rcnn_loss_from_targets(b, cu(cls2), cu(t))
+    la.backward(); lb.backward()
+    assert torch.equal(la, lb) and sa.tolist() == sb.tolist() + [B] and torch.equal(a.grad, b.grad)
+    # no row counts
+    z = x.detach().clone().requires_grad_(True)
+    lz, sz = mask_rcnn_loss_from_targets(z, cu(np.full(B, C)), cu(t), ignore_invalid_rows=True)
+    lz.backward()
+    assert float(lz) == 0.0 and sz.tolist() == [0, 0, 0, 0, B, 0] and not bool(z.grad.any())

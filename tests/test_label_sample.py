@@ -92,3 +92,23 @@ def test_only_the_valid_proposals_count(golden):
     for k in out:
         assert np.array_equal(out[k], short[k]), k
     assert (out["index"] < n + len(g)).all()
+
+
+def test_masked_mask_loss_oracle_is_the_loss_of_the_foreground_subset():
+    """oracle.mask_head.mask_rcnn_loss_masked on a fixed-size list (foreground prefix, background and padding rows) ==
+    the pinned mask_rcnn_loss on the foreground rows alone; gradient rows of ignored rows are zero."""
+    from oracle import mask_head as omh
+
+    rng = np.random.default_rng(17)
+    B, C, M = 24, 80, 28
+    x = rng.standard_normal((B, C, M, M)) * 2
+    t = rng.random((B, M, M)) < 0.4
+    cls = rng.integers(0, C, B)
+    cls[9:17] = C   # background rows
+    cls[17:] = -1   # padding
+    loss, stats, rows = omh.mask_rcnn_loss_masked(x, cls, t)
+    want, wstats = omh.mask_rcnn_loss(x[:9], cls[:9], t[:9])
+    assert rows == 9 and loss == want and np.array_equal(stats["counts"], wstats["counts"])
+    g = omh.mask_rcnn_loss_masked_grad(x, cls, t, 0.5)
+    assert np.array_equal(g[:9], omh.mask_rcnn_loss_grad(x[:9], cls[:9], t[:9], 0.5)) and not g[9:].any()
+    assert omh.mask_rcnn_loss_masked(x, np.full(B, C), t)[0] == 0.0
