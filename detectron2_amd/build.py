@@ -30,6 +30,7 @@ SOURCES = {
     "deform_conv_tc.hip": [],
     "matcher.hip": ["-ffp-contract=off"],
     "label_sample.hip": ["-ffp-contract=off"],
+    "subsample.hip": ["-ffp-contract=off"],
     "rpn.hip": ["-ffp-contract=off"],
     "topk.hip": ["-ffp-contract=off"],
     "mask_targets.hip": ["-ffp-contract=off"],

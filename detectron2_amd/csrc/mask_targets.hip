@@ -176,6 +176,9 @@ __global__ __launch_bounds__(CROP_THREADS) void bitmask_crop_kernel(CropBatch B,
       }
     }
     __syncthreads();
+  } else {
+    __syncthreads();  // s_undecided is written by thread pw and read by every thread below (and a stale 0 from an
+                      // earlier workgroup would make some waves skip the loop's barriers)
   }
   // ---- tier 2: the reference's order, for the bins tier 1 left open (all of them when the band does not fit) ----
   for (int pw = 0; pw < M; pw++) {

@@ -251,7 +251,9 @@ def _nms_images_batched(inputs, iou_threshold, rotated, defer=False, runs=None, 
                 if gathered:
                     _regather(gathered[k][0], gathered[k][1], keep, c[0])
             kept.append(_nms_finish(keep, c[0], c[1]))
-        hold.clear()
+        if not defer:
+            hold.clear()  # (a deferred closure may be called once per replay of a captured graph: the inputs and
+            # workspaces the captured kernels read, and the redo path above, stay alive as long as the closure does)
         if not with_finite and extra is None and result_buffer is None:
             return kept
         return kept, [c[2] for c in counts], vals[4 * cnt:]

@@ -156,6 +156,11 @@ def _staged_nhwc(f):
     return cl
 
 
+import threading as _threading
+
+# the tables below are shared by the forward (caller's thread) and the backward (autograd engine threads; several of
+# them under DataParallel / multi-threaded backward): every access holds this lock
+_TABLE_LOCK = _threading.RLock()
 _ALIASES = {}  # id(feature tensor) -> (weakref to it, its version, alias output of the last pooler that took it, token)
 _ALIAS_CAP = 16
 
@@ -180,31 +185,34 @@ def _chained_inputs(x):
     """(tensors to pool from, token of the pooler that produced them): the remembered alias outputs of an earlier pooler
     call on exactly these feature tensors, or (x itself, None)."""
     out, tokens = [], set()
-    for f in x:
-        ent = _ALIASES.get(id(f))
-        if ent is None or ent[0]() is not f or ent[1] != f._version:
+    with _TABLE_LOCK:
+        for f in x:
+            ent = _ALIASES.get(id(f))
+            if ent is None or ent[0]() is not f or ent[1] != f._version:
+                return list(x), None
+            out.append(ent[2])
+            tokens.add(id(ent[3]))
+        if len(tokens) != 1:
             return list(x), None
-        out.append(ent[2])
-        tokens.add(id(ent[3]))
-    if len(tokens) != 1:
-        return list(x), None
-    return out, _ALIASES[id(x[0])][3]
+        return out, _ALIASES[id(x[0])][3]
 
 
 def _remember_aliases(x, aliases, token):
     import weakref
-    for k in [k for k, e in _ALIASES.items() if e[0]() is None]:  # features that no longer exist
-        del _ALIASES[k]
-    if len(_ALIASES) + len(x) > _ALIAS_CAP:
-        _ALIASES.clear()
-    for f, a in zip(x, aliases):
-        _ALIASES[id(f)] = (weakref.ref(f), f._version, a, token)
+    with _TABLE_LOCK:
+        for k in [k for k, e in _ALIASES.items() if e[0]() is None]:  # features that no longer exist
+            del _ALIASES[k]
+        if len(_ALIASES) + len(x) > _ALIAS_CAP:
+            _ALIASES.clear()
+        for f, a in zip(x, aliases):
+            _ALIASES[id(f)] = (weakref.ref(f), f._version, a, token)
 
 
 def _forget_aliases(token):
     """The node that produced these aliases has run its backward: nothing may chain onto it any more."""
-    for k in [k for k, e in _ALIASES.items() if e[3] is token]:
-        del _ALIASES[k]
+    with _TABLE_LOCK:
+        for k in [k for k, e in _ALIASES.items() if e[3] is token]:
+            del _ALIASES[k]
 
 
 import os as _os
@@ -311,13 +319,15 @@ class _FusedROIPool(Function):
         works = []
         if ctx.chain is not None:
             _forget_aliases(ctx.chain)
-            works = _DEFERRED.pop(ctx.chain, [])
+            with _TABLE_LOCK:
+                works = _DEFERRED.pop(ctx.chain, [])
         if grad_output is not None:
             works.insert(0, (_to_nhwc(grad_output.detach()), rois, cfg, ctx.binned))  # own work first: the plain write
         real = [h for h in held if h is not None and not _is_placeholder(h)]  # a foreign consumer of the aliases
         if not ctx.head:
             if works:
-                _DEFERRED.setdefault(ctx.upstream, []).extend(works)
+                with _TABLE_LOCK:
+                    _DEFERRED.setdefault(ctx.upstream, []).extend(works)
             if real:  # keep real gradients flowing; the deferred work is added upstream
                 return (None, None, None, None, None) + tuple(h if need else None for h, need in zip(held, ctx.needs))
             ph = [(_placeholder((n, c) + tuple(s), ctx.dtype, rois.device) if works else None) for s in hw]
@@ -327,11 +337,13 @@ class _FusedROIPool(Function):
         grads = None
         if real:
             grads = [h if (h is not None and not _is_placeholder(h)) else None for h in held]
-            if any(g is None or not g.is_contiguous(memory_format=torch.channels_last) for g in grads):
-                grads = [(_to_nhwc(g) if g is not None else torch.zeros((n, c) + tuple(s), dtype=ctx.dtype,
-                                                                        device=rois.device,
-                                                                        memory_format=torch.channels_last))
-                         for g, s in zip(grads, hw)]
+            # the tile gathers below ADD in place: never into the tensors autograd handed over (other nodes may hold
+            # the same buffers) -- a channels_last gradient is cloned, any other layout is copied by the conversion
+            grads = [(torch.zeros((n, c) + tuple(s), dtype=ctx.dtype, device=rois.device,
+                                  memory_format=torch.channels_last) if g is None else
+                      g.clone(memory_format=torch.channels_last) if g.is_contiguous(memory_format=torch.channels_last)
+                      else _to_nhwc(g))
+                     for g, s in zip(grads, hw)]
         L = _C.lib()
         dev = rois.device
         plain_first = grads is None and bool(works)  # the first work writes every tile; everything else adds

@@ -1,38 +1,91 @@
 """`subsample_labels` -- detectron2/modeling/sampling.py:9-54, the last step of anchor / proposal labelling
-(rpn.py:307-364, roi_heads.py:257-295).  Same contract: (pos_idx, neg_idx), at most
-`int(num_samples * positive_fraction)` random positives, the rest filled with random negatives, fewer if there are not
-enough; indices are int64 on the labels' device.
+(rpn.py:287-364, roi_heads.py:181-295) -- on the device: d2amd_subsample_labels
+(csrc/subsample.hip; include/d2amd.h).
 
-The result is RNG-defined (the reference draws two `torch.randperm`s on the device), so there is no bit-level parity to
-hold -- what must hold is the distribution: every subset of the right size equally likely.  This version draws ONE
-uniform key per element and takes the smallest keys of each class (a uniform random subset), with ONE host sync (the
-two class counts) instead of the reference's two `nonzero` syncs and two device sorts inside `randperm`.  Plain
-PyTorch on purpose: there is no arithmetic here to put on the matrix cores, and the random stream is torch's
-(`generator` / the global seed), so runs reproduce under `torch.manual_seed` like the reference's."""
+The reference's result is RNG-defined (two `torch.randperm` draws behind two `nonzero` host syncs), so there is no
+bit-level parity with it to hold; what must hold is the contract -- at most `int(num_samples * positive_fraction)`
+positives, the rest filled with negatives, fewer if there are not enough, int64 indices on the labels' device -- and
+the distribution: every subset of the right size equally likely.  Rule here (the same in label_sample.hip and
+oracle/sampling.py): ONE uniform key per element (torch.rand: `generator` / the global seed, so runs reproduce under
+`torch.manual_seed` like the reference's), the smallest keys of each group, ties towards the lower index; GIVEN the
+keys the result is exact and checked bit for bit against the oracle (tests/test_gpu_subsample.py).
+
+Three entries:
+  subsample_labels(labels, ...)          the reference's signature and variable-size result: ONE host read (the two
+                                         sample sizes) instead of two nonzero syncs
+  subsample_labels_batch(labels[N,n])    fixed shape, no host sync: index lists padded with -1 + counts on the device
+  subsample_anchor_labels_(labels[N,n])  RPN._subsample_labels (rpn.py:287-305) for the batch: the int8 label vectors
+                                         rewritten to -1 / 0 / 1 in place, no host sync (a captured step can hold it)
+There is no CPU path: a CPU tensor raises NotImplementedError like every op of this package."""
 import torch
 
-__all__ = ["subsample_labels", "label_and_sample_proposals_fixed"]
+from .. import _C
+
+__all__ = ["subsample_labels", "subsample_labels_batch", "subsample_anchor_labels_", "label_and_sample_proposals_fixed"]
+
+
+def _subsample_device(labels2d, keys, num_samples, max_pos, bg_label, want_idx, labels_out):
+    N, n = labels2d.shape
+    dev = labels2d.device
+    pos = torch.empty((N, max_pos), dtype=torch.int64, device=dev) if want_idx else None
+    neg = torch.empty((N, num_samples), dtype=torch.int64, device=dev) if want_idx else None
+    counts = torch.empty((N, 2), dtype=torch.int32, device=dev)
+    L = _C.lib()
+    with _C.on_device(dev):
+        ws_bytes = L.d2amd_subsample_labels_workspace_bytes(N, n, num_samples, max_pos)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        _C.check(L.d2amd_subsample_labels(_C.ptr(labels2d), labels2d.element_size(), N, n, _C.ptr(keys), num_samples,
+                                          max_pos, int(bg_label), _C.ptr(pos), _C.ptr(neg), _C.ptr(counts),
+                                          _C.ptr(labels_out), _C.ptr(ws), ws_bytes, _C.stream()))
+    return pos, neg, counts
+
+
+def _prep(labels, keys, generator, op):
+    _C.require_gpu(labels, keys, op=op)
+    if labels.dtype not in (torch.int8, torch.int64):
+        labels = labels.to(torch.int64)
+    labels = labels.detach().contiguous()
+    if keys is None:
+        keys = torch.rand(labels.shape, device=labels.device, generator=generator)
+    keys = keys.detach().float().contiguous()
+    assert keys.shape == labels.shape, (keys.shape, labels.shape)
+    return labels, keys
+
+
+def subsample_labels_batch(labels: torch.Tensor, num_samples: int, positive_fraction: float, bg_label: int,
+                           keys: torch.Tensor = None, generator: torch.Generator = None):
+    """labels [N, n] (int8 or int64): `subsample_labels` of every row, fixed shape, nothing waits for the host.
+    -> (pos_idx [N, int(num_samples * positive_fraction)], neg_idx [N, num_samples]) int64 padded with -1 (valid
+    entries first, ascending (key, index)), counts [N, 2] int32 = (sampled positives, sampled negatives)."""
+    assert labels.dim() == 2, labels.shape
+    labels, keys = _prep(labels, keys, generator, "subsample_labels_batch")
+    return _subsample_device(labels, keys, int(num_samples), int(num_samples * positive_fraction), bg_label, True, None)
+
+
+def subsample_anchor_labels_(labels: torch.Tensor, num_samples: int, positive_fraction: float,
+                             keys: torch.Tensor = None, generator: torch.Generator = None):
+    """RPN._subsample_labels (rpn.py:287-305) for a batch: labels [N, n] int8 in {-1, 0, 1} (Matcher labels) are
+    rewritten IN PLACE to -1 except at the sampled positives (1) and negatives (0).  Returns (labels, counts [N, 2]
+    int32 on the device); no host sync."""
+    assert labels.dim() == 2 and labels.dtype == torch.int8 and labels.is_contiguous(), (labels.shape, labels.dtype)
+    lab, keys = _prep(labels, keys, generator, "subsample_anchor_labels_")
+    _, _, counts = _subsample_device(lab, keys, int(num_samples), int(num_samples * positive_fraction), 0, False, lab)
+    return labels, counts
 
 
 def subsample_labels(labels: torch.Tensor, num_samples: int, positive_fraction: float, bg_label: int,
-                     generator: torch.Generator = None):
-    """labels (N,): -1 ignore, bg_label negative, anything else positive.  Returns (pos_idx, neg_idx)."""
+                     generator: torch.Generator = None, keys: torch.Tensor = None):
+    """labels (N,): -1 ignore, bg_label negative, anything else positive.  Returns (pos_idx, neg_idx) int64 -- the
+    reference's signature (modeling/sampling.py:9-54); one host read for the two result sizes."""
     assert labels.dim() == 1, labels.shape
-    n = labels.numel()
-    dev = labels.device
-    if n == 0:
-        e = torch.empty(0, dtype=torch.int64, device=dev)
+    _C.require_gpu(labels, op="subsample_labels")
+    if labels.numel() == 0:
+        e = torch.empty(0, dtype=torch.int64, device=labels.device)
         return e, e.clone()
-    pos_mask = (labels != -1) & (labels != bg_label)
-    neg_mask = labels == bg_label
-    counts = torch.stack([pos_mask.sum(), neg_mask.sum()]).tolist()  # the one host sync
-    num_pos = min(counts[0], int(num_samples * positive_fraction))
-    num_neg = min(counts[1], num_samples - num_pos)
-    key = torch.rand(n, device=dev, generator=generator)
-    two = torch.full((), 2.0, device=dev)  # sorts after every real key
-    pos_idx = torch.topk(torch.where(pos_mask, key, two), num_pos, largest=False, sorted=False).indices
-    neg_idx = torch.topk(torch.where(neg_mask, key, two), num_neg, largest=False, sorted=False).indices
-    return pos_idx, neg_idx
+    pos, neg, counts = subsample_labels_batch(labels[None], num_samples, positive_fraction, bg_label, keys=None if
+                                              keys is None else keys[None], generator=generator)
+    num_pos, num_neg = counts[0].tolist()  # the one host sync (the result's shape)
+    return pos[0, :num_pos], neg[0, :num_neg]
 
 
 def label_and_sample_proposals_fixed(proposal_boxes, gt_boxes, gt_classes, limits=None, keys=None,
@@ -54,8 +107,6 @@ def label_and_sample_proposals_fixed(proposal_boxes, gt_boxes, gt_classes, limit
     gt_index [N, S] (matched ground truth), index [N, S] (candidate index into [proposals[:n]; gt], -1 = padding),
     counts [N, 2] int32 = (positives, rows).  Positives first, then negatives, then padding; S = batch_size_per_image."""
     import ctypes
-
-    from .. import _C
 
     n_img = len(proposal_boxes)
     assert len(gt_boxes) == n_img and len(gt_classes) == n_img

@@ -175,16 +175,28 @@ class PolygonMasks:
         return torch.from_numpy(np.asarray([1 if len(inst) > 0 else 0 for inst in self.polygons], dtype=bool))
 
     def get_bounding_boxes(self):
-        """Tight boxes around the polygons (masks.py:322-336: float32, zeros for an instance without polygons)."""
+        """Tight boxes around the polygons (masks.py:322-336: float32; the minimum starts at +inf and the maximum at
+        0, so an instance without polygons gets [inf, inf, 0, 0] like the reference's)."""
         from .boxes import Boxes
 
         boxes = torch.zeros(len(self.polygons), 4, dtype=torch.float32)
         for i, inst in enumerate(self.polygons):
+            lo, hi = np.full(2, np.inf, np.float32), np.zeros(2, np.float32)
             if inst:
                 xy = np.concatenate([p.reshape(-1, 2) for p in inst]).astype(np.float32)
-                lo, hi = xy.min(0), np.maximum(xy.max(0), 0)
-                boxes[i] = torch.from_numpy(np.concatenate([lo, hi]))
+                lo, hi = np.minimum(lo, xy.min(0)), np.maximum(hi, xy.max(0))
+            boxes[i] = torch.from_numpy(np.concatenate([lo, hi]))
         return Boxes(boxes)
+
+    @staticmethod
+    def cat(polymasks_list):
+        """masks.py:446-465 (what Instances.cat calls for gt_masks)."""
+        import itertools
+
+        assert isinstance(polymasks_list, (list, tuple))
+        assert len(polymasks_list) > 0
+        assert all(isinstance(pm, PolygonMasks) for pm in polymasks_list)
+        return type(polymasks_list[0])(list(itertools.chain.from_iterable(pm.polygons for pm in polymasks_list)))
 
     def area(self) -> torch.Tensor:
         """Shoelace area per instance (masks.py:422-441)."""

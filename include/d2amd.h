@@ -209,6 +209,25 @@ int d2amd_label_and_sample_proposals(const d2amd_sample_image* images, int count
                                      int64_t num_classes, int append_gt, float* boxes_out, int64_t* classes_out,
                                      int64_t* gt_index_out, int64_t* index_out, int32_t* counts_out, void* stream);
 
+/* ---- subsample_labels (detectron2/modeling/sampling.py:9-54) for a batch, on the device, FIXED output shape, no
+ * host sync -- the reference pays two nonzero() syncs and two randperm sorts per image.  Callers:
+ * RPN._subsample_labels (proposal_generator/rpn.py:287-305: 268,569 anchor labels per image -> 256, label vector
+ * rewritten to -1 / 0 / 1) and ROIHeads._sample_proposals (roi_heads/roi_heads.py:181-216).
+ * labels [N][n] int8 (label_bytes 1: the Matcher's labels) or int64 (label_bytes 8: classes): -1 ignore, bg_label
+ * negative, anything else positive.  keys [N][n] fp32, one uniform random number per element (no NaN): the sample is
+ * the min(#positives, max_positives) SMALLEST keys among the positives, then the min(#negatives, num_samples - sampled
+ * positives) smallest among the negatives, ties towards the lower index -- a uniform random subset of each group, the
+ * random stream is the caller's.  max_positives = int(num_samples * positive_fraction) (sampling.py:42).
+ * Outputs (each may be NULL): pos_idx_out [N][max_positives], neg_idx_out [N][num_samples] int64 element indices in
+ * ascending (key, index) order, padded with -1; counts_out [N][2] = (sampled positives, sampled negatives);
+ * labels_out [N][n] int8 = -1 everywhere, 1 at the sampled positives, 0 at the sampled negatives (rpn.py:300-304;
+ * may alias `labels` when those are int8).  num_samples <= 65,536. */
+size_t d2amd_subsample_labels_workspace_bytes(int N, int64_t n, int num_samples, int max_positives);
+int d2amd_subsample_labels(const void* labels, int label_bytes, int N, int64_t n, const float* keys, int num_samples,
+                           int max_positives, int64_t bg_label, int64_t* pos_idx_out, int64_t* neg_idx_out,
+                           int32_t* counts_out, int8_t* labels_out, void* workspace, size_t workspace_bytes,
+                           void* stream);
+
 /* ---- anchor / proposal matching.  Matcher.__call__ + set_low_quality_matches_
  * (detectron2/modeling/matcher.py:62-127) fused with pairwise_iou (structures/boxes.py:312-358), as called
  * from proposal_generator/rpn.py:307-364 and roi_heads/roi_heads.py:257-295: the M x N matrix is never

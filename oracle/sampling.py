@@ -44,6 +44,30 @@ def sample_sizes(classes, num_samples, positive_fraction, bg_label):
     return num_pos, min(neg, num_samples - num_pos)
 
 
+def subsample_labels_keys(labels, keys, num_samples, positive_fraction, bg_label):
+    """subsample_labels (sampling.py:9-54) with the randomness made explicit: `keys` = one uniform number per element;
+    the num_pos smallest keys among the positives and the num_neg smallest among the negatives (ties towards the lower
+    index), each list in ascending (key, index) order -- the rule of csrc/subsample.hip (d2amd_subsample_labels).
+    -> (pos_idx int64, neg_idx int64)."""
+    labels = np.asarray(labels).reshape(-1).astype(np.int64)
+    keys = np.asarray(keys, np.float32).reshape(-1)
+    assert labels.shape == keys.shape
+    num_pos, num_neg = sample_sizes(labels, num_samples, positive_fraction, bg_label)
+    order = np.lexsort((np.arange(len(labels)), keys))
+    is_pos = ((labels != -1) & (labels != bg_label))[order]
+    is_neg = (labels == bg_label)[order]
+    return order[is_pos][:num_pos].astype(np.int64), order[is_neg][:num_neg].astype(np.int64)
+
+
+def subsample_anchor_labels(labels, keys, num_samples, positive_fraction):
+    """RPN._subsample_labels (proposal_generator/rpn.py:287-305) on one label vector, keys explicit."""
+    pos, neg = subsample_labels_keys(labels, keys, num_samples, positive_fraction, 0)
+    out = np.full(np.asarray(labels).reshape(-1).shape, -1, np.int8)  # rpn.py:300
+    out[pos] = 1  # :301
+    out[neg] = 0  # :302
+    return out
+
+
 def label_and_sample_fixed(proposals, n_valid, gt_boxes, gt_classes, keys, thresholds=(0.5,), labels=(0, 1),
                            batch_size_per_image=512, positive_fraction=0.25, num_classes=80, append_gt=True):
     """proposals [max_p, 4] of which the first n_valid count; keys [max_p + G].  -> dict of fixed-size arrays:

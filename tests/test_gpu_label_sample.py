@@ -1,11 +1,7 @@
 """d2amd_label_and_sample_proposals (csrc/label_sample.hip) against oracle/sampling.py: bit-exact (indices, classes,
-matched ground truth, counts, boxes) for the same keys.
-
-NOT YET RUN ON A GPU: the kernel was written after round 2's GPU budget was spent (it builds for gfx950 without scratch
-memory; nothing in the package calls it yet).  The file is therefore opt-in -- D2AMD_RUN_UNVALIDATED=1 -- so that the
-round's GPU suite reports what was actually validated.  First thing to run next round:
-    D2AMD_RUN_UNVALIDATED=1 python -m pytest tests/test_gpu_label_sample.py -x -q
-"""
+matched ground truth, counts, boxes) for the same keys; the mask loss over the rows that count
+(d2amd_mask_rcnn_loss_forward_masked / _backward_masked) against oracle/mask_head.py.
+First run on a GPU at the start of round 3 (profiles/r03/first_run_label_sample_masked_loss.log: 8 passed)."""
 import os
 
 import numpy as np
@@ -14,9 +10,7 @@ import torch
 
 from oracle import sampling as osp
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(not os.environ.get("D2AMD_RUN_UNVALIDATED"),
-                                 reason="written without GPU access at the end of round 2 (see the module docstring)")]
+pytestmark = pytest.mark.gpu
 
 DEV = torch.device("cuda", 0)
 CASES = ["typical", "no_gt", "few", "many_positives", "ignore_band"]

@@ -143,3 +143,22 @@ def test_crop_and_resize_batch_equals_per_image_loop():
            for b, g in zip(boxes, counts_m)]
     got2 = crop_and_resize_batch(bms, bt2, M)
     assert torch.equal(got2, torch.cat([m.crop_and_resize(b, M) for m, b in zip(bms, bt2)]))
+
+
+@pytest.mark.parametrize("h,w,box", [
+    (1900, 48, [2.0, 3.0, 44.0, 1890.0]),     # bin rows of > 62 pixel rows: the band's row table does not fit
+    (40, 2300, [1.0, 2.0, 2290.0, 37.0]),     # a band wider than 2,048 columns
+    (1900, 2300, [5.0, 5.0, 2200.0, 1850.0]), # both
+])
+def test_crop_and_resize_rois_beyond_the_band_tables(h, w, box):
+    """ROIs taller than ~1,800 px or wider than 2,048 px skip the tier-1 tables: every bin goes through the
+    sequential tier (the path that had an unsynchronised read of the per-bin flags); repeated so that workgroups
+    follow ones that left the flags decided."""
+    rng = np.random.default_rng(h + w)
+    masks = blob_masks(rng, 2, h, w)
+    boxes = np.array([box, [3.0, 3.0, 30.0, 30.0]], np.float32)  # the second ROI takes the tier-1 path
+    bm = BitMasks(torch.from_numpy(masks).to(DEV))
+    bt = torch.from_numpy(boxes).to(DEV)
+    want = reference_pipeline(masks, boxes, 28)
+    for _ in range(3):
+        assert np.array_equal(bm.crop_and_resize(bt, 28).cpu().numpy(), want)

@@ -403,8 +403,29 @@ def test_nms_rotated_bit_exact(golden_dir):
     hs = _distinct_scores(rng, 300)
     k1, k2 = nms(cu(hb), cu(hs), 0.5).cpu().numpy(), nms_rotated(cu(rb), cu(hs), 0.5).cpu().numpy()
     assert len(set(k1) ^ set(k2)) <= 2
-    # scripting path of the registered op (test_nms_rotated.py:153-168)
-    scripted = torch.jit.script(lambda b, s: torch.ops.detectron2.nms_rotated(b, s, 0.5)) if False else None
+
+
+class _RotatedNmsModule(torch.nn.Module):
+    """The module of the reference's scriptability test (tests/layers/test_nms_rotated.py:153-168)."""
+
+    def forward(self, boxes, scores, threshold: float):
+        return nms_rotated(boxes, scores, threshold)
+
+
+def test_nms_rotated_module_is_scriptable_with_identical_results():
+    """test_nms_rotated.py:161-168 (`torch.jit.script(module)` must succeed on the device), plus: scripted == eager
+    == oracle."""
+    m = _RotatedNmsModule().to(DEV)
+    scripted = torch.jit.script(m)
+    rng = np.random.default_rng(18)
+    n = 300
+    b = np.stack([rng.uniform(0, 120, n), rng.uniform(0, 120, n), rng.uniform(2, 50, n), rng.uniform(2, 50, n),
+                  rng.uniform(-180, 180, n)], 1).astype(np.float32)
+    s = _distinct_scores(rng, n)
+    for thr in (0.3, 0.5):
+        a, c = m(cu(b), cu(s), thr), scripted(cu(b), cu(s), thr)
+        assert torch.equal(a, c) and a.dtype == torch.int64
+        assert np.array_equal(a.cpu().numpy(), oracle.nms_rotated(b, s, thr))
 
 
 def test_nms_category_id_out_of_range_raises():

@@ -235,3 +235,25 @@ def test_no_kernel_spills_to_scratch_memory(tmp_path):
     known = ("pool_bwd_nhwc_kernel", "polygon_crop_kernel")
     spilled = {k: v for k, v in ours.items() if v != 0 and not any(n in k for n in known)}
     assert not spilled, spilled
+
+
+def test_polygon_masks_host_logic_follows_the_reference():
+    """PolygonMasks.get_bounding_boxes (masks.py:322-336: [inf, inf, 0, 0] for an instance without polygons) and
+    PolygonMasks.cat (masks.py:446-465, what Instances.cat calls for gt_masks): pure host code, no GPU."""
+    import numpy as np
+    import torch
+
+    from detectron2_amd.structures import PolygonMasks
+
+    a = PolygonMasks([[np.array([1.0, 2.0, 30.0, 4.0, 20.0, 40.5])], [np.array([5.0, 5.0, 9.0, 5.0, 9.0, 9.0]),
+                                                                       np.array([-3.0, 1.0, 2.0, 1.0, 2.0, 12.0])]])
+    b = PolygonMasks([[]])
+    bb = a.get_bounding_boxes().tensor
+    assert bb.dtype == torch.float32 and bb.tolist() == [[1.0, 2.0, 30.0, 40.5], [-3.0, 1.0, 9.0, 12.0]]
+    eb = b.get_bounding_boxes().tensor
+    assert eb[0, :2].tolist() == [float("inf")] * 2 and eb[0, 2:].tolist() == [0.0, 0.0]
+    c = PolygonMasks.cat([a, b, a])
+    assert isinstance(c, PolygonMasks) and len(c) == 5 and len(c.polygons[2]) == 0
+    assert all(np.array_equal(x, y) for x, y in zip(c.polygons[3], a.polygons[0]))
+    with pytest.raises(AssertionError):
+        PolygonMasks.cat([])
