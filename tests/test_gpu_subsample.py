@@ -115,8 +115,9 @@ def test_uniform_and_reproducible_on_the_device():
     pos, neg, counts = subsample_labels_batch(batch, 32, 0.25, 80, generator=gen)
     assert bool((counts == torch.tensor([8, 24], device=DEV, dtype=torch.int32)).all())
     hits = torch.zeros(lab.numel(), device=DEV)
-    hits.index_add_(0, pos.reshape(-1), torch.ones(pos.numel(), device=DEV))
-    hits.index_add_(0, neg.reshape(-1), torch.ones(neg.numel(), device=DEV))
+    assert bool((pos >= 0).all()) and bool((neg[:, :24] >= 0).all()) and bool((neg[:, 24:] == -1).all())
+    for idx in (pos.reshape(-1), neg[:, :24].reshape(-1)):
+        hits.index_add_(0, idx, torch.ones(idx.numel(), device=DEV))
     hits = hits.cpu()
     is_pos, is_neg = (lab != -1) & (lab != 80), lab == 80
     assert (hits[is_pos] / runs - 8 / 40).abs().max() < 0.04 and (hits[is_neg] / runs - 24 / 200).abs().max() < 0.03
