@@ -48,8 +48,14 @@ struct PoolLevels {
   const void* tile_list;  // backward: [tile][TILE_CAP] TileEntry in ROI order (valid when tile_cnt[tile] <= TILE_CAP)
   unsigned long long* wgstamps;  // profiling only (D2AMD_POOL_STAMPS): per workgroup {start, lists done, loop done, end, #ROIs}
   int tab_off;       // forward: 1 = no 32-bit tap table (a level holds >= 2^32 elements per image)
-  const int* queue;  // backward: per-XCD work queues of this launch (tile_lists_kernel), [8][qcap]; nullptr: static order
+  const int2* queue;  // backward: per-XCD work queues of this launch (tile_lists_kernel), [8][qcap] slots {tile | #ROIs
+                      // << 24, part | parts << 8 | scratch slot << 16}; x = -1: unused; nullptr: static order
   int qcap;
+  float* part_scratch;  // split tiles (tile_lists_kernel): fp32 partial accumulators, [slot][16][2][512] floats per slab ...
+  int* part_tickets;    // ... and one arrival counter per split tile (at its first scratch slot)
+  int* qctr;         // backward: the queues' counters (TileQueues::mem); non-null: persistent workgroups FETCH their tiles
+                     // (take counter per XCD, then the other XCDs' queues) instead of serving slot blockIdx >> 3
+  int qsteal;        // how many OTHER XCDs' queues a persistent workgroup tries once its own is empty (0: none)
   int accumulate;    // backward: 1 = grad_input already holds a gradient (another pooler's): add to it, skip empty tiles
   const int* perm;   // forward: ROI processing order (roi_order_kernel), nullptr: workgroup b pools ROI b
 };
@@ -367,7 +373,20 @@ constexpr int LPP = 32;          // lanes (16-B channel groups) per pixel; 256 t
 constexpr int LCH = 512;         // ROIs scanned per list-building pass
 constexpr int MAXP = SEP_MAXP;   // 32: one lane per bin along an axis
 constexpr int CT = 256;          // threads per row-split of a group: 8 pixel columns x 32 channel lanes
-constexpr int QCTR = 32;         // work-queue counters: [pass][xcd] heads, then [pass][xcd] tails
+constexpr int QCTR = 320;        // work-queue counters: [pass][xcd] heads (0..15), [pass][xcd] tails (16..31) of the
+                                 // binning; from QTAKE on, one 128-B line per XCD queue with the TAKE counter of the
+                                 // persistent tile workgroups (all eight in one line: every fetch of the chip queued
+                                 // up behind one memory channel)
+constexpr int QTAKE = 64, QTAKE_PITCH = 32;  // (word 1 of a queue's line: scratch slots handed out to its split tiles)
+// SPLIT TILES.  A tile's ROI list is walked by one workgroup, one item after the other; the box head's heaviest p4 tile
+// holds 33 ROIs = 46-57 us of a kernel whose work, spread evenly, takes 49 us.  Lists longer than SPLIT_MIN entries are
+// cut into PARTS of <= PART_LEN entries, each a queue entry of its own on the tile's XCD queue; a part leaves its fp32
+// accumulators in a scratch slot and takes a ticket, the workgroup that draws the last ticket adds the parts IN PART
+// ORDER (deterministic) and writes the tile.  Nobody waits for anybody.
+constexpr int PART_LEN = 8, SPLIT_MIN = 11, MAX_PARTS = 8;
+constexpr int SCR_PER_XCD_MAX = 96;  // scratch slots per XCD queue (64 px x C fp32 each: 48 MB at C = 256)
+constexpr int SPLIT_MAX_SLABS = 4;   // channel slabs (of 256 channels, 16-bit) a split tile may have: one ticket each
+constexpr int QTICKETS = 8 * SCR_PER_XCD_MAX * SPLIT_MAX_SLABS;
 
 // Per-ROI record written once per backward call by roi_records_kernel: what a tile workgroup needs
 // to decide "does this ROI touch my tile" with a few integer compares (the first versions evaluated
@@ -410,9 +429,9 @@ __device__ __forceinline__ bool footprint_rect(const RoiGeom& g, int H, int W, i
 
 // Also resets the work queues of the backward launches (counters = 0, slots = -1 "no tile").
 __global__ void roi_records_kernel(PoolLevels L, const float* __restrict__ rois, RoiRec* __restrict__ rec,
-                                   int* __restrict__ qmem, int qints) {
+                                   int* __restrict__ qmem, int qzero, int qints) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  for (int i = k; i < qints; i += gridDim.x * blockDim.x) qmem[i] = i < QCTR ? 0 : -1;
+  for (int i = k; i < qints; i += gridDim.x * blockDim.x) qmem[i] = i < qzero ? 0 : -1;  // counters + tickets | slots
   if (k >= L.K) return;
   const float* r = rois + (long)k * 5;
   RoiRec o{};
@@ -473,11 +492,18 @@ struct TileQueues {
   int* mem;                        // QCTR counters, then pass 0 queues [8][cap[0]], then pass 1 queues [8][cap[1]]
   int cap[2], thr[2];
   int pass_base[POOL_MAX_LEVELS];  // pass-local tile id of the first tile of each level
+  int deal_shift[POOL_MAX_LEVELS]; // level l is dealt to the XCDs in blocks of (1 << shift) x (1 << shift) tiles
+  int qbase;                       // ints from mem to the first queue slot (counters, then the split tiles' tickets)
+  int scr_per_xcd;                 // scratch slots a queue's split tiles may take (0: lists are never split)
   unsigned coarse_mask;            // bit l: level l belongs to pass 1
   int esize, zero_fill;            // element size; 1: empty tiles are zero-filled here (16-B aligned rows)
 };
-__host__ __device__ __forceinline__ int tile_xcd(int lvl, int n, int ty, int tx, int tiles_x) {
-  return ((ty >> 2) * ((tiles_x + 3) >> 2) + (tx >> 2) + 3 * n + 5 * lvl) & 7;
+// 4x4-tile blocks keep the dY rows of neighbouring tiles in ONE L2 -- right for the fine levels (thousands of tiles,
+// 2-4 ROIs each).  A coarse level has few tiles with LONG lists (p4 of the bench: 154 tiles, 17 ROIs on average): dealt
+// in 4x4 blocks, 16 of them land on one queue and the XCDs end 12 us apart; those levels are dealt tile by tile
+// (shift 0) or in 2x2 blocks (shift 1): host, pool_deal_shift().
+__host__ __device__ __forceinline__ int tile_xcd(int lvl, int n, int ty, int tx, int tiles_x, int shift) {
+  return ((ty >> shift) * ((tiles_x + (1 << shift) - 1) >> shift) + (tx >> shift) + 3 * n + 5 * lvl) & 7;
 }
 
 // L.tile_base here numbers ALL tiles of all levels (make_levels); the two backward launches map their
@@ -539,24 +565,36 @@ __global__ __launch_bounds__(64 * LISTS_WAVES) void tile_lists_kernel(PoolLevels
   // Queue slots: ONE atomic per workgroup and counter.  A returning atomic per tile on the 16 counters of a launch
   // (8 XCDs x heavy / light) serialised in L2 at ~0.1 us each: 2,500 tiles -> 16 us of this kernel.
   __shared__ int s_key[LISTS_WAVES];   // counter index of the wave's tile ([heavy / light][pass][xcd]), -1: none
+  __shared__ int s_np[LISTS_WAVES];    // queue entries of the wave's tile (> 1: a split list)
   __shared__ int s_slot[LISTS_WAVES];  // queue position handed to the wave
-  int key = -1, pass = 0, x = 0;
+  int key = -1, pass = 0, x = 0, np = 1, sbase = 0;
   bool heavy = false;
   if (push) {
     pass = (Q.coarse_mask >> g.lvl) & 1;
-    x = tile_xcd(g.lvl, g.n, g.y0 >> 3, g.x0 >> 3, (W + 7) >> 3);
+    int shift = Q.deal_shift[0];
+#pragma unroll
+    for (int l = 1; l < POOL_MAX_LEVELS; l++)
+      if (l == g.lvl) shift = Q.deal_shift[l];
+    x = tile_xcd(g.lvl, g.n, g.y0 >> 3, g.x0 >> 3, (W + 7) >> 3, shift);
     heavy = cnt >= Q.thr[pass];
     key = (heavy ? 0 : 16) + pass * 8 + x;
+    if (pass == 0 && Q.scr_per_xcd > 0 && cnt > SPLIT_MIN && cnt <= TILE_CAP) {  // uniform per wave
+      const int want = min((cnt + PART_LEN - 1) / PART_LEN, MAX_PARTS);
+      int got = 0;
+      if (lane == 0) got = atomicAdd(Q.mem + QTAKE + QTAKE_PITCH * x + 1, want);  // (never handed back: a list that
+      got = __shfl(got, 0, 64);                                                   // finds the budget spent stays whole)
+      if (got + want <= Q.scr_per_xcd) { np = want; sbase = x * Q.scr_per_xcd + got; heavy = true; key = pass * 8 + x; }
+    }
   }
-  if (lane == 0) s_key[wave] = key;
+  if (lane == 0) { s_key[wave] = key; s_np[wave] = np; }
   __syncthreads();
   if (threadIdx.x < LISTS_WAVES) {  // lane t of wave 0 serves wave t's tile
     const int mine = s_key[threadIdx.x];
     int rank = 0, total = 0, first = LISTS_WAVES;
     for (int q = 0; q < LISTS_WAVES; q++) {
       const bool same = mine >= 0 && s_key[q] == mine;
-      if (same && q < (int)threadIdx.x) rank++;
-      if (same) { total++; first = min(first, q); }
+      if (same && q < (int)threadIdx.x) rank += s_np[q];
+      if (same) { total += s_np[q]; first = min(first, q); }
     }
     int basepos = 0;
     if (mine >= 0 && first == (int)threadIdx.x) basepos = atomicAdd(Q.mem + mine, total);
@@ -567,9 +605,11 @@ __global__ __launch_bounds__(64 * LISTS_WAVES) void tile_lists_kernel(PoolLevels
   __syncthreads();
   if (push && lane == 0) {
     const int u = Q.pass_base[g.lvl] + (tile - L.tile_base[g.lvl]);  // tile id inside its launch
-    int* q = Q.mem + QCTR + (pass ? 8 * Q.cap[0] : 0) + x * Q.cap[pass];
+    int2* q = reinterpret_cast<int2*>(Q.mem + Q.qbase) + (pass ? 8 * Q.cap[0] : 0) + x * Q.cap[pass];
     const int at = s_slot[wave];
-    q[heavy ? at : Q.cap[pass] - 1 - at] = (min(cnt, 127) << 24) | u;  // positive: -1 marks an unused slot (127 > TILE_CAP)
+    const int e = (min(cnt, 127) << 24) | u;  // positive: -1 marks an unused slot (127 > TILE_CAP)
+    for (int part = 0; part < np; part++)     // (np == 1: the whole list)
+      q[heavy ? at + part : Q.cap[pass] - 1 - at] = int2{e, part | (np << 8) | (sbase << 16)};
   }
 }
 
@@ -625,7 +665,7 @@ __global__ __launch_bounds__(CT * RS * GROUPS, 4) void pool_bwd_nhwc_kernel(Pool
   int logical, slab, tile, qcnt = -1;
   if (L.queue) {  // work queue of this XCD (tile_lists_kernel): heavy tiles first, empty tiles never arrive
     const int j = (int)(blockIdx.x >> 3);
-    const int e = L.queue[(long)(blockIdx.x & 7) * L.qcap + j / nslab];
+    const int e = L.queue[(long)(blockIdx.x & 7) * L.qcap + j / nslab].x;  // (lists are split for the MFMA kernel only)
     if (e < 0) return;
     logical = (int)blockIdx.x;
     slab = j % nslab;
@@ -951,7 +991,7 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_staged_kernel(PoolLevels L
   int logical, slab, tile, qcnt = -1;
   if (L.queue) {
     const int j = (int)(blockIdx.x >> 3);
-    const int e = L.queue[(long)(blockIdx.x & 7) * L.qcap + j / nslab];
+    const int e = L.queue[(long)(blockIdx.x & 7) * L.qcap + j / nslab].x;  // (lists are split for the MFMA kernel only)
     if (e < 0) return;
     logical = (int)blockIdx.x;
     slab = j % nslab;
@@ -1259,19 +1299,65 @@ struct __attribute__((aligned(16))) MfmaShared {
   uint16_t Wlo[2][TILE * TILE][WPITCH];
 };
 
-template <typename T, int PB>
+template <typename T, int PB, bool DYN = true>
 __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, const RoiRec* __restrict__ rec,
                                                                    const T* __restrict__ gout, int nslab,
                                                                    int total_blocks, PoolTileIds ids) {
   constexpr int NT = 2 * CT, TR = TILE / 2, VEC = 8;
   __shared__ StagedShared<T> S;
   __shared__ MfmaShared M;
-  const int tid = threadIdx.x, lane = tid & 63;
-  int logical, slab, tile, qcnt = -1;
-  if (L.queue) {
+  __shared__ int s_fetch[8];
+  // PERSISTENT workgroups (L.qctr): the grid is one wave of resident workgroups, each of which fetches tile after
+  // tile -- from the queue of its own XCD (blockIdx & 7: heavy tiles first) until that is empty, then from the other
+  // XCDs' queues.  With one workgroup per queue slot (the first version) the XCDs ended 12 us apart (4x4-tile blocks
+  // of a coarse level are 16 long lists on ONE queue: 40.9 .. 53.9 us of work per resident slot) and every slot lost
+  // ~2 us per tile between a workgroup's end and the dispatch of the next (profiles/r03/pool_bwd_*_timeline_static.txt).
+  constexpr bool dynamic = DYN;  // (host: L.queue and L.qctr are set)
+  if (threadIdx.x == 0) s_fetch[3] = 0;  // queues found empty so far, starting at the home XCD's (thread 0's)
+  for (int round = 0;; round++) {
+  // (the thread index passes through an opaque move per tile: everything derived from it is then recomputed per tile
+  // like in the one-tile kernel instead of being hoisted out of this loop and held in registers across it -- the body
+  // runs at its 128-VGPR cap, the hoisted values spilled to scratch)
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63;
+  int logical, slab, tile, qcnt = -1, pinfo = 1 << 8;  // pinfo: part | parts << 8 | scratch slot << 16
+  if (dynamic) {
+    if (round) __syncthreads();  // the previous tile's readers of the shared buffers (and of s_fetch) are done
+    if (tid == 0) {
+      int e = -1, sl = 0, lg2 = 0, steal = s_fetch[3];
+      while (steal <= L.qsteal) {
+        const int q = ((int)blockIdx.x + steal) & 7;
+        const int i = atomicAdd(L.qctr + QTAKE + QTAKE_PITCH * q, 1);
+        const int nh = L.qctr[q], nl = L.qctr[16 + q];  // final: tile_lists_kernel is an earlier launch
+        const int ent = i / nslab;
+        if (ent < nh + nl) {
+          const int slot = ent < nh ? ent : L.qcap - 1 - (ent - nh);  // heavy from the front, light from the back
+          const int2 e2 = L.queue[(long)q * L.qcap + slot];
+          e = e2.x;
+          s_fetch[4] = e2.y;
+          sl = i - ent * nslab;
+          lg2 = ((slot * nslab + sl) << 3) | q;  // the workgroup id the static mapping gives this (slot, slab)
+          break;
+        }
+        steal++;
+      }
+      s_fetch[0] = e; s_fetch[1] = sl; s_fetch[2] = lg2; s_fetch[3] = steal;
+    }
+    __syncthreads();
+    const int e = s_fetch[0];
+    if (e < 0) return;  // every queue is empty (uniform)
+    slab = s_fetch[1];
+    logical = s_fetch[2];
+    pinfo = s_fetch[4];
+    tile = e & 0xffffff;
+    qcnt = (int)((unsigned)e >> 24);
+  } else if (L.queue) {
     const int j = (int)(blockIdx.x >> 3);
-    const int e = L.queue[(long)(blockIdx.x & 7) * L.qcap + j / nslab];
+    const int2 e2 = L.queue[(long)(blockIdx.x & 7) * L.qcap + j / nslab];
+    const int e = e2.x;
     if (e < 0) return;
+    pinfo = e2.y;
     logical = (int)blockIdx.x;
     slab = j % nslab;
     tile = e & 0xffffff;
@@ -1283,9 +1369,10 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
     slab = logical % nslab;
     tile = logical / nslab;
   }
-  unsigned long long* wst = (L.wgstamps && tid == 0) ? L.wgstamps + 5 * (size_t)logical : nullptr;
-  if (wst) wst[0] = wall_clock64();
-  unsigned long long wst_list = 0;
+  // profiling stamps (D2AMD_POOL_STAMPS): written where they are taken, the row re-derived from uniform values each
+  // time -- a pointer and a clock value held across the tile cost 4 VGPRs of a kernel at its cap
+#define WST(k, v) do { if (L.wgstamps && tid == 0) L.wgstamps[5 * (size_t)logical + (k)] = (v); } while (0)
+  WST(0, wall_clock64());
   int wst_n = 0;
   int lvl = 0;
 #pragma unroll
@@ -1302,7 +1389,7 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
   const int rh = tid / CT, col = (tid >> 5) & 7, lp = tid & 31;  // row half / pixel column / channel lane
   const int cg = slab * LPP + lp;
   const bool cg_ok = cg < CG;
-  const long cofs = (long)min(cg, CG - 1) * VEC;
+  const int cofs = min(cg, CG - 1) * VEC;  // (< C <= 8192)
   const int sb = tid >> 5;  // staging: this thread moves bins sb and sb + 16 of an item (channel lane lp)
 #undef STAMP
 #ifdef D2AMD_PROFILE
@@ -1507,9 +1594,12 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
     const int gtile = ids.first[lvl] + (tile - L.tile_base[lvl]);
     const int c = qcnt >= 0 ? qcnt : L.tile_cnt[gtile];
     if (c <= TILE_CAP) {
-      tl_cnt = c;
-      if (tid < c) {
-        const TileEntry e = ((const TileEntry*)L.tile_list)[(long)gtile * TILE_CAP + tid];
+      // a part of a split list walks entries [lo, hi) of it (parts == 1: all of them)
+      const int part = pinfo & 0xff, parts = (pinfo >> 8) & 0xff;
+      const int len = (c + parts - 1) / parts, lo = part * len, hi = min(c, lo + len);
+      tl_cnt = max(hi - lo, 0);
+      if (tid < tl_cnt) {
+        const TileEntry e = ((const TileEntry*)L.tile_list)[(long)gtile * TILE_CAP + lo + tid];
         S.list[tid] = e.roi;
         S.geo[tid] = e.g;
       }
@@ -1541,7 +1631,7 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
       }
       nlist = run;
     }
-    if (wst) { wst_list = wall_clock64(); wst_n += nlist; }
+    if (L.wgstamps) { WST(1, wall_clock64()); wst_n += nlist; }
     if (nlist == 0) continue;  // uniform
     __syncthreads();           // list complete
     if (!prelist) {
@@ -1642,17 +1732,45 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
 #ifdef D2AMD_PROFILE
   if (dbg_on) { L.dbg[127] = dbg_n; L.dbg[126] = 0; L.dbg[125] = __builtin_readcyclecounter() - L.dbg[0]; }
 #endif
-  if (wst) { wst[1] = wst_list; wst[2] = wall_clock64(); wst[4] = (unsigned long long)wst_n; }
+  WST(2, wall_clock64());
+  // ---- split list: this part's accumulators go to its scratch slot; the last part to arrive adds all parts in part
+  // order and writes the tile.  Stores / loads / the ticket are device-scope relaxed atomics (performed at the memory
+  // side, visible to every XCD once acknowledged -- the protocol of topk.hip's segment barriers); nothing waits.
+  if (((pinfo >> 8) & 0xff) > 1) {  // uniform
+    const int part = pinfo & 0xff, parts = (pinfo >> 8) & 0xff, sbase = (int)((unsigned)pinfo >> 16);
+    const size_t slot_floats = (size_t)nslab * 32 * NT;
+    float* mine = L.part_scratch + ((size_t)(sbase + part) * nslab + slab) * 32 * NT + tid;
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+      for (int r = 0; r < 16; r++)
+        __hip_atomic_store(mine + (mt * 16 + r) * NT, acc[mt][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_waitcnt(0);  // acknowledged = visible
+    __syncthreads();
+    if (tid == 0)
+      s_fetch[5] = __hip_atomic_fetch_add(L.part_tickets + sbase * SPLIT_MAX_SLABS + slab, 1, __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_fetch[5] != parts - 1) {  // uniform: another part finishes this tile
+      WST(3, wall_clock64());
+      WST(4, (unsigned long long)wst_n | (unsigned long long)(blockIdx.x & 7) << 32 | 1ull << 40);  // (bit 40: a part)
+      if (!dynamic) break;
+      continue;
+    }
+    const float* all = L.part_scratch + ((size_t)sbase * nslab + slab) * 32 * NT + tid;
+#pragma unroll
+    for (int i = 0; i < 32; i++) acc[i >> 4][i & 15] = 0.f;
+    for (int q = 0; q < parts; q++) {
+      float v[32];
+#pragma unroll
+      for (int i = 0; i < 32; i++)
+        v[i] = __hip_atomic_load(all + (size_t)q * slot_floats + i * NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int i = 0; i < 32; i++) acc[i >> 4][i & 15] += v[i];
+    }
+  }
   // ---- epilogue: accumulators (lane = channel, registers = pixels) -> LDS [pixel][channel] in the I/O dtype ->
   // 16-B channel vectors per pixel (every pixel of grad_input is written exactly once)
-  // accumulate mode: the rows this thread will store are fetched now, under the LDS transpose below
-  raw16 held[TR];
-  if (L.accumulate && cg_ok && x0 + col < W) {
-    const T* gi = (const T*)L.data[lvl] + (((long)n * H + y0 + rh * TR) * W + x0 + col) * C + cofs;
-#pragma unroll
-    for (int i = 0; i < TR; i++)
-      held[i] = *reinterpret_cast<const raw16*>(gi + (long)min(i, H - 1 - (y0 + rh * TR)) * W * C);
-  }
   __syncthreads();  // everyone is done with D
   T* obuf = reinterpret_cast<T*>(&S.D[0][0][0]);  // 64 pixels x 256 channels x 2 B = the two D buffers
   if (slab * (LPP * VEC) + 32 * wave < C) {
@@ -1664,26 +1782,52 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
         obuf[px * (LPP * VEC) + 32 * wave + (lane & 31)] = from_f32<T>(acc[mt][r]);
       }
   }
-  __syncthreads();
-  if (cg_ok && x0 + col < W) {
-    T* gi = (T*)L.data[lvl] + (((long)n * H + y0 + rh * TR) * W + x0 + col) * C + cofs;
+  // Two copies of the store loop, one per mode (L.accumulate is uniform): the rows an accumulating thread adds to are
+  // loaded, used and dead inside ONE block.  Defined under one `if` and used under another they were live around the
+  // whole tile loop for the register allocator (16 VGPRs of a kernel at its cap: spilled to scratch).
+  if (L.accumulate) {
+    // the rows this thread will store are fetched now (the accumulators are dead) and fly under the barrier
+    // (loaded unconditionally from clamped -- valid -- addresses: a conditional definition that is used under a
+    // second condition behind the barrier is a loop-carried value again)
+    raw16 held[TR];
+    const bool mine = cg_ok && x0 + col < W;
+    T* gi = (T*)L.data[lvl] + (((long)n * H + y0 + rh * TR) * W + min(x0 + col, W - 1)) * C + cofs;
 #pragma unroll
-    for (int i = 0; i < TR; i++) {
-      if (y0 + rh * TR + i >= H) break;
-      const int px = (rh * TR + i) * TILE + col;
-      raw16 v = *reinterpret_cast<const raw16*>(obuf + px * (LPP * VEC) + lp * VEC);
-      if (L.accumulate) {  // uniform: round(held + round(own)), what autograd's add of two gradients gives
-        float a[VEC], b[VEC];
+    for (int i = 0; i < TR; i++)
+      held[i] = *reinterpret_cast<const raw16*>(gi + (long)max(min(i, H - 1 - (y0 + rh * TR)), -(rh * TR)) * W * C);
+    __syncthreads();
+    if (mine) {
+#pragma unroll
+      for (int i = 0; i < TR; i++) {
+        if (y0 + rh * TR + i >= H) break;
+        const int px = (rh * TR + i) * TILE + col;
+        const raw16 v = *reinterpret_cast<const raw16*>(obuf + px * (LPP * VEC) + lp * VEC);
+        float a[VEC], b[VEC];  // round(held + round(own)), what autograd's add of two gradients gives
         unpack16(held[i], a, T{});
         unpack16(v, b, T{});
 #pragma unroll
         for (int q = 0; q < VEC; q++) a[q] += b[q];
-        v = pack16(a, T{});
+        *reinterpret_cast<raw16*>(gi + (long)i * W * C) = pack16(a, T{});
       }
-      *reinterpret_cast<raw16*>(gi + (long)i * W * C) = v;
+    }
+  } else {
+    __syncthreads();
+    if (cg_ok && x0 + col < W) {
+      T* gi = (T*)L.data[lvl] + (((long)n * H + y0 + rh * TR) * W + x0 + col) * C + cofs;
+#pragma unroll
+      for (int i = 0; i < TR; i++) {
+        if (y0 + rh * TR + i >= H) break;
+        const int px = (rh * TR + i) * TILE + col;
+        *reinterpret_cast<raw16*>(gi + (long)i * W * C) =
+            *reinterpret_cast<const raw16*>(obuf + px * (LPP * VEC) + lp * VEC);
+      }
     }
   }
-  if (wst) wst[3] = wall_clock64();
+  WST(3, wall_clock64());
+  WST(4, (unsigned long long)wst_n | (unsigned long long)(blockIdx.x & 7) << 32);  // #ROIs, + the XCD that ran the tile
+#undef WST
+  if (!dynamic) break;
+  }  // next tile
 }
 
 // ---- convert_boxes_to_pooler_format (poolers.py:62-104) in one launch, no host sync -----------------
@@ -1846,7 +1990,7 @@ static PoolLevels make_levels(const d2amd_pooler_params* p, const void* const* d
   L.min_level = p->min_level; L.max_level = p->max_level; L.canonical_level = p->canonical_level;
   L.canonical_size = p->canonical_box_size;
   { const char* e = getenv("D2AMD_ABLATE"); L.ablate = e ? atoi(e) : 0; }
-  L.dbg = nullptr; L.dbg_block = -1; L.wgstamps = nullptr; L.tile_cnt = nullptr; L.tile_list = nullptr; L.queue = nullptr; L.qcap = 0; L.tab_off = 0;
+  L.dbg = nullptr; L.dbg_block = -1; L.wgstamps = nullptr; L.tile_cnt = nullptr; L.tile_list = nullptr; L.queue = nullptr; L.qcap = 0; L.qctr = nullptr; L.qsteal = 0; L.part_scratch = nullptr; L.part_tickets = nullptr; L.tab_off = 0;
   int base = 0;
   for (int l = 0; l < p->num_levels; l++) {
     L.data[l] = data[l]; L.H[l] = p->H[l]; L.W[l] = p->W[l]; L.scale[l] = p->spatial_scale[l];
@@ -1966,6 +2110,24 @@ static SideStream* side_stream() {
   return &table[dev];
 }
 
+// workgroups of `fn` (block size `threads`, static LDS) that are resident at once on the current device
+static long resident_workgroups(const void* fn, int threads) {
+  struct Ent { const void* fn; int dev; long n; };
+  static Ent cache[16];
+  static int used = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  for (int i = 0; i < used; i++)
+    if (cache[i].fn == fn && cache[i].dev == dev) return cache[i].n;
+  int cus = 0, per = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, fn, threads, 0) != hipSuccess) return 0;
+  const long n = (long)cus * per;
+  if (used < 16) cache[used++] = Ent{fn, dev, n};
+  return n;
+}
+static bool stamp_path_static() { return getenv("D2AMD_POOL_STAMPS_STATIC") != nullptr; }
+
 // levels with at most this many tiles take the GROUPS > 1 kernel (few tiles <=> long ROI lists)
 constexpr int COARSE_TILES = 512;
 
@@ -1978,6 +2140,11 @@ static void launch_bwd(const PoolLevels& L, const RoiRec* rec, const void* gout,
 }
 
 static size_t pool_al(size_t x) { return (x + 255) / 256 * 256; }
+// counters, tickets of the split tiles, then 8 queues of 64-bit slots: at most one slot per tile + the parts of the
+// split ones (<= SCR_PER_XCD_MAX per queue)
+static size_t pool_queue_bytes(long ntiles) {
+  return pool_al((size_t)(QCTR + QTICKETS) * sizeof(int) + (size_t)8 * (ntiles + SCR_PER_XCD_MAX) * sizeof(int2));
+}
 static long pool_ntiles(const d2amd_pooler_params* p) {
   long n = 0;
   for (int l = 0; l < p->num_levels; l++) n += (long)cdiv(p->H[l], TILE) * cdiv(p->W[l], TILE) * p->N;
@@ -2018,7 +2185,7 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
   long nblocks4 = 0;
   for (int l = 0; l < p->num_levels; l++) nblocks4 += (long)cdiv(cdiv(p->H[l], TILE), 4) * cdiv(cdiv(p->W[l], TILE), 4) * p->N;
   const bool queues = lists && nblocks4 <= 8192 && ntiles < (1l << 24) &&
-      workspace_bytes >= off_q + (size_t)(QCTR + 8 * ntiles) * sizeof(int) && getenv("D2AMD_POOL_NOQUEUE") == nullptr;
+      workspace_bytes >= off_q + pool_queue_bytes(ntiles) && getenv("D2AMD_POOL_NOQUEUE") == nullptr;
   // one launch of the LDS-staged kernel for all levels (16-B channel vectors + work queues), else the two-launch
   // register-gather kernels
   const bool staged = queues && vec && getenv("D2AMD_POOL_NOSTAGED") == nullptr;
@@ -2027,6 +2194,11 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
     return D2AMD_EUNSUPPORTED;
   }
   if (accumulate && K == 0 && phase != 3) return D2AMD_OK;  // nothing to add
+  // lists are split only for the kernel that can add the parts: the 16-bit MFMA tile gather
+  static const bool no_mfma_env = getenv("D2AMD_POOL_NOMFMA") != nullptr;
+  const bool split_capable = staged && sizeof(T) == 2 && !no_mfma_env && p->C % 32 == 0 && p->C <= 8192 &&
+      nslab <= SPLIT_MAX_SLABS;
+  const size_t slot_bytes = (size_t)nslab * 32 * (2 * CT) * sizeof(float);  // 16 accumulators x 2 tiles x 512 threads
   if (queues) {
     int per[2][8] = {};
     int base[2] = {0, 0};
@@ -2036,12 +2208,24 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
       if (pass) Q.coarse_mask |= 1u << l;
       Q.pass_base[l] = base[pass];
       base[pass] += ty * tx * p->N;
+      static const int deal_env = getenv("D2AMD_POOL_DEAL") ? atoi(getenv("D2AMD_POOL_DEAL")) : -1;  // A/B: fixed shift
+      const int sh = deal_env >= 0 ? (deal_env > 2 ? 2 : deal_env) : (ty * tx * p->N <= 512 ? 0 : ty * tx * p->N <= 2048 ? 1 : 2);
+      Q.deal_shift[l] = sh;
+      const int bs = 1 << sh;
       for (int n = 0; n < p->N; n++)
-        for (int by = 0; by < ty; by += 4)
-          for (int bx = 0; bx < tx; bx += 4)
-            per[pass][tile_xcd(l, n, by, bx, tx)] += min(4, ty - by) * min(4, tx - bx);
+        for (int by = 0; by < ty; by += bs)
+          for (int bx = 0; bx < tx; bx += bs)
+            per[pass][tile_xcd(l, n, by, bx, tx, sh)] += min(bs, ty - by) * min(bs, tx - bx);
     }
     for (int x = 0; x < 8; x++) { Q.cap[0] = max(Q.cap[0], per[0][x]); Q.cap[1] = max(Q.cap[1], per[1][x]); }
+    // split lists (the MFMA tile gather only): scratch behind the queues, if the caller's workspace has it
+    static const bool no_split = getenv("D2AMD_POOL_NOSPLIT") != nullptr;
+    const int sx = min(SCR_PER_XCD_MAX, max(16, Q.cap[0] / 3));
+    if (split_capable && !no_split && workspace_bytes >= off_q + pool_queue_bytes(ntiles) + (size_t)8 * sx * slot_bytes) {
+      Q.scr_per_xcd = sx;
+      Q.cap[0] += sx;  // a queue holds at most one entry per tile + the parts
+    }
+    Q.qbase = QCTR + QTICKETS;
     static const int thr_s = getenv("D2AMD_POOL_QTHR") ? atoi(getenv("D2AMD_POOL_QTHR")) : 6;
     static const int thr_f0 = getenv("D2AMD_POOL_QTHR_FINE") ? atoi(getenv("D2AMD_POOL_QTHR_FINE")) : 4;
     const int thr_f = staged ? thr_s : thr_f0;
@@ -2051,7 +2235,9 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
     Q.esize = (int)sizeof(T);
     Q.zero_fill = vec ? 1 : 0;
   }
-  const int qints = queues ? QCTR + 8 * (Q.cap[0] + Q.cap[1]) : 0;
+  const int qzero = QCTR + QTICKETS;
+  const int qints = queues ? qzero + 2 * 8 * (Q.cap[0] + Q.cap[1]) : 0;
+  D2_CHECK_ARG(!queues || (size_t)qints * sizeof(int) <= pool_queue_bytes(ntiles), "roi_pooler_backward: queue layout");
   if (phase == 3) {  // (binned in accumulate mode: empty tiles were neither queued nor written)
     D2_CHECK_ARG(lists && vec, "roi_pooler_backward: phase 3 without per-tile lists");
     hipLaunchKernelGGL(zero_empty_tiles_kernel, dim3(cdiv(ntiles, LISTS_WAVES)), dim3(64 * LISTS_WAVES), 0, s, L0,
@@ -2059,7 +2245,7 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
     D2_LAUNCH_OK();
   }
   if (K > 0 && phase < 2) {
-    hipLaunchKernelGGL(roi_records_kernel, dim3(cdiv(K, 256)), dim3(256), 0, s, L0, rois, rec, Q.mem, qints);
+    hipLaunchKernelGGL(roi_records_kernel, dim3(cdiv(K, 256)), dim3(256), 0, s, L0, rois, rec, Q.mem, qzero, qints);
     D2_LAUNCH_OK();
     if (lists) {
       hipLaunchKernelGGL(tile_lists_kernel, dim3(cdiv(ntiles, LISTS_WAVES)), dim3(64 * LISTS_WAVES), 0, s, L0, rec, (int)ntiles, tile_cnt,
@@ -2080,10 +2266,13 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
     for (int l = 0; l < p->num_levels; l++) ids.first[l] = L0.tile_base[l];
     L.tile_cnt = tile_cnt;
     L.tile_list = tile_list;
-    L.queue = Q.mem + QCTR;
+    L.queue = reinterpret_cast<const int2*>(Q.mem + Q.qbase);
     L.qcap = Q.cap[0];
+    L.part_tickets = Q.mem + QCTR;
+    L.part_scratch = (float*)((char*)workspace + off_q + pool_queue_bytes(ntiles));
     const long total = 8l * L.qcap * nslab;
     if (total == 0) return D2AMD_OK;
+    static const bool static_slots = getenv("D2AMD_POOL_STATIC") != nullptr;  // A/B: one workgroup per queue slot
     D2_CHECK_ARG(total < (1l << 30), "roi_pooler_backward: too many tiles");
     const char* stamp_path = getenv("D2AMD_POOL_STAMPS");  // profiling only: per-workgroup timeline dump
     if (stamp_path) {
@@ -2107,15 +2296,24 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
       static const bool no_mfma = getenv("D2AMD_POOL_NOMFMA") != nullptr;
       mfma = !no_mfma && p->C % 32 == 0 && p->C <= 8192;
       if (mfma) {
-        if (pmax <= 8)
-          hipLaunchKernelGGL((pool_bwd_mfma_kernel<T, 8>), dim3((unsigned)total), dim3(2 * CT), 0, s, L, rec,
-                             (const T*)grad_output, nslab, (int)total, ids);
-        else if (pmax <= 16)
-          hipLaunchKernelGGL((pool_bwd_mfma_kernel<T, 16>), dim3((unsigned)total), dim3(2 * CT), 0, s, L, rec,
-                             (const T*)grad_output, nslab, (int)total, ids);
-        else
-          hipLaunchKernelGGL((pool_bwd_mfma_kernel<T, 32>), dim3((unsigned)total), dim3(2 * CT), 0, s, L, rec,
-                             (const T*)grad_output, nslab, (int)total, ids);
+        // persistent workgroups: one resident wave of them (a multiple of 8: every XCD gets the same number), each
+        // fetching tiles until all queues are empty; never more than there are queue slots
+        if (!static_slots && !stamp_path_static()) L.qctr = Q.mem;
+        static const int steal_env = getenv("D2AMD_POOL_STEAL") ? atoi(getenv("D2AMD_POOL_STEAL")) : 0;
+        L.qsteal = steal_env < 0 ? 0 : steal_env > 7 ? 7 : steal_env;
+        auto launch = [&](auto dyn_fn, auto static_fn) {
+          if (L.qctr) {
+            const long r = resident_workgroups((const void*)dyn_fn, 2 * CT) & ~7l;
+            const unsigned grid = (unsigned)(r >= 8 && r < total ? r : total);
+            hipLaunchKernelGGL(dyn_fn, dim3(grid), dim3(2 * CT), 0, s, L, rec, (const T*)grad_output, nslab, (int)total, ids);
+          } else {
+            hipLaunchKernelGGL(static_fn, dim3((unsigned)total), dim3(2 * CT), 0, s, L, rec, (const T*)grad_output, nslab,
+                               (int)total, ids);
+          }
+        };
+        if (pmax <= 8) launch(pool_bwd_mfma_kernel<T, 8, true>, pool_bwd_mfma_kernel<T, 8, false>);
+        else if (pmax <= 16) launch(pool_bwd_mfma_kernel<T, 16, true>, pool_bwd_mfma_kernel<T, 16, false>);
+        else launch(pool_bwd_mfma_kernel<T, 32, true>, pool_bwd_mfma_kernel<T, 32, false>);
       }
     }
     if (mfma) {
@@ -2179,7 +2377,7 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
     long total = (long)base * nslab;
     if (total == 0) continue;
     if (queues) {
-      L.queue = Q.mem + QCTR + (pass ? 8 * Q.cap[0] : 0);
+      L.queue = reinterpret_cast<const int2*>(Q.mem + Q.qbase) + (pass ? 8 * Q.cap[0] : 0);
       L.qcap = Q.cap[pass];
       total = 8l * L.qcap * nslab;  // workgroups of this launch (stamps are indexed by workgroup)
     }
@@ -2395,8 +2593,11 @@ extern "C" size_t d2amd_roi_pooler_backward_workspace_bytes(const d2amd_pooler_p
   const size_t need = (size_t)(K > 0 ? K : 1) * sizeof(RoiRec);
   if (check_pooler(p, "roi_pooler_backward_workspace_bytes")) return need;
   const long ntiles = pool_ntiles(p);
+  // ... + the scratch slots of split tile lists (16-bit I/O; see SPLIT TILES)
+  const int vecn = 8, nslab = cdiv(cdiv(p->C, vecn), LPP);
+  const size_t scratch = p->dtype == D2AMD_F32 ? 0 : (size_t)8 * SCR_PER_XCD_MAX * nslab * 32 * (2 * CT) * sizeof(float);
   return pool_al(need) + pool_al((size_t)ntiles * 4) + pool_al((size_t)ntiles * TILE_CAP * sizeof(TileEntry)) +
-      pool_al((size_t)(QCTR + 8 * ntiles) * sizeof(int)) + 256;
+      pool_queue_bytes(ntiles) + scratch + 256;
 }
 
 static int pooler_backward_entry(const d2amd_pooler_params* p, const void* grad_output, const float* rois,

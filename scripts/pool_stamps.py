@@ -23,7 +23,9 @@ for ps, name in ((0, "fine levels"), (1, "coarse levels")):
     t0 = d[:, 1].min()
     st, ls, lp, en = [(d[:, i] - t0) / 100.0 for i in (1, 2, 3, 4)]
     ls = np.where(d[:, 2] > 0, ls, st)
-    n = d[:, 5]
+    n = d[:, 5] & 0xffffffff  # (bits 32+: the XCD whose workgroup ran the tile; the row index & 7 = the queue's XCD)
+    stolen = ((d[:, 5] >> 32) & 7) != (d[:, 0] & 7)
+    print(f'  tiles taken from another XCD\'s queue: {int(stolen.sum())}')
     print(f"{which} {name}: {len(d)} workgroups, span {en.max():.1f} us; ROIs/tile mean {n.mean():.2f} max {n.max()} zero {np.mean(n == 0):.2f}")
     print(f"  start p50 {np.median(st):.1f} p90 {np.percentile(st, 90):.1f} max {st.max():.1f}")
     for nm, a, b in (("scan", st, ls), ("rois", ls, lp), ("write", lp, en), ("total", st, en)):

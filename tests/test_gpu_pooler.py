@@ -475,3 +475,41 @@ def test_ordered_forward_is_the_list_order_forward():
     assert torch.equal(out_a, out_b)
     perm = order.cpu().numpy()
     assert sorted(perm.tolist()) == list(range(k))  # a permutation of the ROIs
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("out,per_tile", [(7, 14), (7, 40), (14, 26), (7, 64), (7, 150)])
+def test_backward_with_long_roi_lists_on_single_tiles(dtype, out, per_tile):
+    """Clustered proposals: `per_tile` ROIs of one size around the same point of each image, so that a few 8 x 8 tiles
+    of ONE level carry lists of that length -- 14: walked whole (<= SPLIT_MIN would be 11: 2 parts), 26 / 40 / 64: cut
+    into 4 / 5 / 8 parts whose fp32 partial sums meet in scratch memory (the last part to arrive adds them in part
+    order), 150: beyond the per-tile list capacity (in-kernel scan, never split) -- plus background ROIs on all levels.
+    16-bit I/O (the MFMA tile gather) against the oracle's backward of the same 16-bit gradient; twice: bit-identical."""
+    rng = np.random.default_rng(out * 1000 + per_tile)
+    C, img_h, img_w = 64, 320, 448
+    feats, boxes = make_inputs(rng, 2, C, img_h, img_w, 40)
+    for i in range(2):
+        # ROIs of ~180 px (level p3/p4 of the 224-canonical rule) centred within 6 px of one point
+        c = rng.uniform([150, 120], [300, 200])
+        ctr = c + rng.uniform(-6, 6, (per_tile, 2))
+        wh = rng.uniform(150, 210, (per_tile, 2))
+        b = np.concatenate([ctr - wh / 2, ctr + wh / 2], 1)
+        b[:, 0::2] = b[:, 0::2].clip(0, img_w)
+        b[:, 1::2] = b[:, 1::2].clip(0, img_h)
+        boxes[i] = np.concatenate([boxes[i], b.astype(np.float32)])
+    bl = [Boxes(torch.from_numpy(b).to(DEV)) for b in boxes]
+    pooler = ROIPooler(out, SCALES, 0, "ROIAlignV2")
+    k = sum(len(b) for b in boxes)
+    g = torch.from_numpy(rng.standard_normal((k, C, out, out)).astype(np.float32)).to(DEV).to(dtype) \
+        .contiguous(memory_format=torch.channels_last)
+    runs = []
+    for _ in range(2):
+        xs = [torch.from_numpy(f).to(DEV).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+              for f in feats]
+        pooler(xs, bl).backward(g)
+        runs.append([x.grad.clone() for x in xs])
+    assert all(torch.equal(a, b) for a, b in zip(*runs))
+    _, gins, lv = oracle_pooler(feats, boxes, out, 0, True, grad=g.float().cpu().numpy())
+    tol = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    for l in range(4):
+        assert rel_err(runs[0][l].float().cpu().numpy(), gins[l]) < tol, (l, int((lv == l).sum()))
