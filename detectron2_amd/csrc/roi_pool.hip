@@ -383,7 +383,10 @@ constexpr int QTAKE = 64, QTAKE_PITCH = 32;  // (word 1 of a queue's line: scrat
 // cut into PARTS of <= PART_LEN entries, each a queue entry of its own on the tile's XCD queue; a part leaves its fp32
 // accumulators in a scratch slot and takes a ticket, the workgroup that draws the last ticket adds the parts IN PART
 // ORDER (deterministic) and writes the tile.  Nobody waits for anybody.
-constexpr int PART_LEN = 8, SPLIT_MIN = 11, MAX_PARTS = 8;
+// WHICH lists are split must not depend on the order in which the binning workgroups run (the parts' sums are added in
+// part order, an unsplit list's items one after the other: the same tile must take the same route in every run), so the
+// scratch budget is handed out in TILE ORDER by the last binning workgroup to finish (tile_lists_kernel).
+constexpr int PART_LEN = 12, SPLIT_MIN = 24, MAX_PARTS = 6;
 constexpr int SCR_PER_XCD_MAX = 96;  // scratch slots per XCD queue (64 px x C fp32 each: 48 MB at C = 256)
 constexpr int SPLIT_MAX_SLABS = 4;   // channel slabs (of 256 channels, 16-bit) a split tile may have: one ticket each
 constexpr int QTICKETS = 8 * SCR_PER_XCD_MAX * SPLIT_MAX_SLABS;
@@ -494,7 +497,7 @@ struct TileQueues {
   int pass_base[POOL_MAX_LEVELS];  // pass-local tile id of the first tile of each level
   int deal_shift[POOL_MAX_LEVELS]; // level l is dealt to the XCDs in blocks of (1 << shift) x (1 << shift) tiles
   int qbase;                       // ints from mem to the first queue slot (counters, then the split tiles' tickets)
-  int scr_per_xcd;                 // scratch slots a queue's split tiles may take (0: lists are never split)
+  int scr_total;                   // scratch slots the split lists of a launch may take (0: lists are never split)
   unsigned coarse_mask;            // bit l: level l belongs to pass 1
   int esize, zero_fill;            // element size; 1: empty tiles are zero-filled here (16-B aligned rows)
 };
@@ -546,8 +549,8 @@ __global__ __launch_bounds__(64 * LISTS_WAVES) void tile_lists_kernel(PoolLevels
         cnt += __builtin_popcountll(bal);
       }
     }
-    if (lane == 0) tile_cnt[tile] = cnt;
-  }
+    if (lane == 0) __hip_atomic_store(&tile_cnt[tile], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (the planner
+  }                                                                                                     // reads it)
   if (Q.mem == nullptr) return;  // uniform
   const int H = L.H[g.lvl], W = L.W[g.lvl];
   bool push = live;
@@ -578,13 +581,8 @@ __global__ __launch_bounds__(64 * LISTS_WAVES) void tile_lists_kernel(PoolLevels
     x = tile_xcd(g.lvl, g.n, g.y0 >> 3, g.x0 >> 3, (W + 7) >> 3, shift);
     heavy = cnt >= Q.thr[pass];
     key = (heavy ? 0 : 16) + pass * 8 + x;
-    if (pass == 0 && Q.scr_per_xcd > 0 && cnt > SPLIT_MIN && cnt <= TILE_CAP) {  // uniform per wave
-      const int want = min((cnt + PART_LEN - 1) / PART_LEN, MAX_PARTS);
-      int got = 0;
-      if (lane == 0) got = atomicAdd(Q.mem + QTAKE + QTAKE_PITCH * x + 1, want);  // (never handed back: a list that
-      got = __shfl(got, 0, 64);                                                   // finds the budget spent stays whole)
-      if (got + want <= Q.scr_per_xcd) { np = want; sbase = x * Q.scr_per_xcd + got; heavy = true; key = pass * 8 + x; }
-    }
+    // a list long enough to be split is queued by the planner below (the last workgroup), not here
+    if (pass == 0 && Q.scr_total > 0 && cnt > SPLIT_MIN && cnt <= TILE_CAP) { push = false; key = -1; }
   }
   if (lane == 0) { s_key[wave] = key; s_np[wave] = np; }
   __syncthreads();
@@ -610,6 +608,61 @@ __global__ __launch_bounds__(64 * LISTS_WAVES) void tile_lists_kernel(PoolLevels
     const int e = (min(cnt, 127) << 24) | u;  // positive: -1 marks an unused slot (127 > TILE_CAP)
     for (int part = 0; part < np; part++)     // (np == 1: the whole list)
       q[heavy ? at + part : Q.cap[pass] - 1 - at] = int2{e, part | (np << 8) | (sbase << 16)};
+  }
+  if (Q.scr_total <= 0) return;  // uniform
+  // ---- split planner: the LAST workgroup to get here (every count is then visible: device-scope stores, acknowledged
+  // before the ticket) walks the tiles in tile order, hands scratch slots to the lists longer than SPLIT_MIN until the
+  // budget is spent -- a function of the counts alone -- and queues them: np parts, or whole if the budget is spent
+  __shared__ int s_last, s_scan[LISTS_WAVES], s_run;
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (threadIdx.x == 0)
+    s_last = __hip_atomic_fetch_add(Q.mem + QTAKE + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+  if (threadIdx.x == 0) s_run = 0;
+  __syncthreads();
+  if (!s_last) return;  // uniform
+  constexpr int PT = 64 * LISTS_WAVES;
+  for (int t0 = 0; t0 < ntiles; t0 += PT) {
+    const int t = t0 + (int)threadIdx.x;
+    int c = 0;
+    if (t < ntiles) c = __hip_atomic_load(&tile_cnt[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    TileGeom tg{};
+    bool cand = c > SPLIT_MIN && c <= TILE_CAP;
+    if (cand) {
+      tg = tile_geom(L, t);
+      cand = ((Q.coarse_mask >> tg.lvl) & 1) == 0;
+    }
+    const int want = cand ? min((c + PART_LEN - 1) / PART_LEN, MAX_PARTS) : 0;
+    // exclusive scan of `want` in tile order: inside the wave, then over the 16 waves, then the running total
+    int incl = want;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int y = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += y;
+    }
+    if (lane == 63) s_scan[wave] = incl;
+    __syncthreads();
+    int before = s_run;
+    for (int w2 = 0; w2 < wave; w2++) before += s_scan[w2];
+    const int mybase = before + incl - want;
+    if (cand) {
+      const bool fits = mybase + want <= Q.scr_total;  // monotone in tile order: once spent, spent for all later tiles
+      const int n_parts = fits ? want : 1;
+      const int W2 = L.W[tg.lvl];
+      int shift = Q.deal_shift[0];
+#pragma unroll
+      for (int l = 1; l < POOL_MAX_LEVELS; l++)
+        if (l == tg.lvl) shift = Q.deal_shift[l];
+      const int xq = tile_xcd(tg.lvl, tg.n, tg.y0 >> 3, tg.x0 >> 3, (W2 + 7) >> 3, shift);
+      const int at = atomicAdd(Q.mem + xq, n_parts);  // heavy end of the XCD's queue (pass 0)
+      const int u = Q.pass_base[tg.lvl] + (t - L.tile_base[tg.lvl]);
+      int2* q = reinterpret_cast<int2*>(Q.mem + Q.qbase) + xq * Q.cap[0];
+      for (int part = 0; part < n_parts; part++)
+        q[at + part] = int2{(c << 24) | u, part | (n_parts << 8) | ((fits ? mybase : 0) << 16)};
+    }
+    __syncthreads();
+    if (threadIdx.x == PT - 1) s_run = before + incl;  // (the last thread's inclusive total of this chunk)
+    __syncthreads();
   }
 }
 
@@ -2143,7 +2196,7 @@ static size_t pool_al(size_t x) { return (x + 255) / 256 * 256; }
 // counters, tickets of the split tiles, then 8 queues of 64-bit slots: at most one slot per tile + the parts of the
 // split ones (<= SCR_PER_XCD_MAX per queue)
 static size_t pool_queue_bytes(long ntiles) {
-  return pool_al((size_t)(QCTR + QTICKETS) * sizeof(int) + (size_t)8 * (ntiles + SCR_PER_XCD_MAX) * sizeof(int2));
+  return pool_al((size_t)(QCTR + QTICKETS) * sizeof(int) + (size_t)8 * (ntiles + 8 * SCR_PER_XCD_MAX) * sizeof(int2));
 }
 static long pool_ntiles(const d2amd_pooler_params* p) {
   long n = 0;
@@ -2220,10 +2273,10 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
     for (int x = 0; x < 8; x++) { Q.cap[0] = max(Q.cap[0], per[0][x]); Q.cap[1] = max(Q.cap[1], per[1][x]); }
     // split lists (the MFMA tile gather only): scratch behind the queues, if the caller's workspace has it
     static const bool no_split = getenv("D2AMD_POOL_NOSPLIT") != nullptr;
-    const int sx = min(SCR_PER_XCD_MAX, max(16, Q.cap[0] / 3));
-    if (split_capable && !no_split && workspace_bytes >= off_q + pool_queue_bytes(ntiles) + (size_t)8 * sx * slot_bytes) {
-      Q.scr_per_xcd = sx;
-      Q.cap[0] += sx;  // a queue holds at most one entry per tile + the parts
+    const int sx = 8 * min(SCR_PER_XCD_MAX, max(16, Q.cap[0] / 3));
+    if (split_capable && !no_split && workspace_bytes >= off_q + pool_queue_bytes(ntiles) + (size_t)sx * slot_bytes) {
+      Q.scr_total = sx;
+      Q.cap[0] += sx;  // a queue holds at most one entry per tile + (all on one XCD) every part
     }
     Q.qbase = QCTR + QTICKETS;
     static const int thr_s = getenv("D2AMD_POOL_QTHR") ? atoi(getenv("D2AMD_POOL_QTHR")) : 6;

@@ -481,10 +481,11 @@ def test_ordered_forward_is_the_list_order_forward():
 @pytest.mark.parametrize("out,per_tile", [(7, 14), (7, 40), (14, 26), (7, 64), (7, 150)])
 def test_backward_with_long_roi_lists_on_single_tiles(dtype, out, per_tile):
     """Clustered proposals: `per_tile` ROIs of one size around the same point of each image, so that a few 8 x 8 tiles
-    of ONE level carry lists of that length -- 14: walked whole (<= SPLIT_MIN would be 11: 2 parts), 26 / 40 / 64: cut
-    into 4 / 5 / 8 parts whose fp32 partial sums meet in scratch memory (the last part to arrive adds them in part
-    order), 150: beyond the per-tile list capacity (in-kernel scan, never split) -- plus background ROIs on all levels.
-    16-bit I/O (the MFMA tile gather) against the oracle's backward of the same 16-bit gradient; twice: bit-identical."""
+    of ONE level carry lists of about that length -- 14: walked whole; 26 / 40 / 64: longer than SPLIT_MIN (24), cut into
+    parts of <= 12 entries whose fp32 partial sums meet in scratch memory (the last part to arrive adds them in part
+    order); 150: beyond the per-tile list capacity (in-kernel scan, never split) -- plus background ROIs on all levels.
+    16-bit I/O (the MFMA tile gather) against the oracle's backward of the same 16-bit gradient; twice: bit-identical
+    (which lists are split is decided in tile order, not in arrival order)."""
     rng = np.random.default_rng(out * 1000 + per_tile)
     C, img_h, img_w = 64, 320, 448
     feats, boxes = make_inputs(rng, 2, C, img_h, img_w, 40)
