@@ -79,6 +79,12 @@ def parse(argv=None):
                     help="N > 1, maskrcnn_train: wire dtype of the gradient all-reduce (bf16 = the reference's "
                          "fp16_compress_hook idea, fp32 = plain DDP) or off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--disconnected", action="store_true",
+                    help="maskrcnn_train: the round-2 step -- the ROI heads pool FIXED sampled lists and the RPN's "
+                         "proposals feed nothing; two HIP graphs with one host sync between them.  Default: the "
+                         "connected step (RPN -> sampler -> poolers, counts on the device) replayed as ONE graph")
+    ap.add_argument("--no-extra-workloads", action="store_true",
+                    help="default run (maskrcnn_train, 1 GPU): do not append the short retinanet_100k / dcn_r50 runs")
     ap.add_argument("--no-graph", action="store_true",
                     help="maskrcnn_train: launch every op eagerly in the timed region (default: the two sync-free halves "
                          "of the step are captured once in HIP graphs and replayed)")
@@ -246,6 +252,10 @@ class Workload:
         self.mask_logits = torch.cat([torch.randn(128, 80, 28, 28, generator=g) for g in gens]).to(dtype).to(dev) \
             .requires_grad_(True)
         self.crop_status = torch.zeros(1, dtype=torch.int32, device=dev)
+        # connected step: the ROI heads' inputs come from the RPN of the same step (label_and_sample_proposals_fixed):
+        # 512 rows per image (box head), of which the first 128 feed the mask head (positives come first)
+        self.gt_classes = [torch.randint(0, 80, (N_GT,), generator=g).to(dev) for g in gens]
+        self.connected = False
 
     # algorithmic (compulsory) bytes per op, SURVEY.md 8(d)
     def alg_bytes(self):
@@ -269,6 +279,8 @@ class Workload:
         d["match_proposals"] = self.n_img * (16 * (n + 1032) + 9 * 1032)
         d["rpn_proposals"] = self.n_img * m * (4 + 4)                    # logits read by the select passes (>= 2x)
         d["mask_loss_fwd"] = 256 * 784 * (s + 1)
+        d["label_and_sample_anchors"] = d["match_anchors"] + self.n_img * m * (1 + 4 + 1)  # + labels, keys in, labels out
+        d["label_and_sample_proposals"] = self.n_img * (16 * (n + 1000) + 4 * (n + 1000) + 512 * 44)
         return d
 
 
@@ -343,7 +355,8 @@ def rpn_branches(w):
                                                  1000, 0.0, True, defer=True))
 
 
-def step(w, t=None, grads=None):
+def disconnected_step(w, t=None, grads=None):
+    """The round-2 step (--disconnected): the ROI half pools FIXED lists, the RPN's proposals feed nothing."""
     from detectron2_amd.modeling import find_top_rpn_proposals_fused, mask_rcnn_loss_from_targets
     from detectron2_amd.modeling import poolers as _poolers
     from detectron2_amd.streams import fork_join
@@ -390,6 +403,149 @@ def step(w, t=None, grads=None):
         f.grad = None
     w.mask_logits.grad = None
     return props
+
+
+ROI_BATCH, ROI_POS_FRACTION, RPN_BATCH, RPN_POS_FRACTION, MASK_ROWS = 512, 0.25, 256, 0.5, 128
+
+
+def anchor_labels(w, keys=None):
+    """RPN.label_and_sample_anchors (rpn.py:307-364) for the batch: fused IoU + Matcher of every image's ground truth
+    against the 268,569 anchors in ONE launch per pass, then _subsample_labels (256 per image, in place) -- all on the
+    device.  -> (labels [N, A] int8 in {-1, 0, 1}, matched ground-truth index [N, A], counts [N, 2])"""
+    from detectron2_amd.modeling import subsample_anchor_labels_
+
+    matches, labels = w.anchor_matcher.match_boxes_batch(w.gt, w.anchors)
+    labels, counts = subsample_anchor_labels_(labels, RPN_BATCH, RPN_POS_FRACTION, keys=keys)
+    return labels, matches, counts
+
+
+def connected_forward(w, run=None, rpn_keys=None, roi_keys=None, sync=False):
+    """The training hot path with the ROI heads fed by the RPN of the same step (GeneralizedRCNN.forward: rpn.py:431-480
+    -> roi_heads.py:220-295 -> poolers.py:206): RPN selection + NMS (anchor labelling + sampling beside the NMS) ->
+    label_and_sample_proposals on the NMS's device-side counts -> box pooler on the 512 sampled rows per image, mask
+    pooler + mask targets + masked mask loss on their first 128 rows.  Nothing waits for the host.
+    sync=True (tests / A-B): the reference's data flow instead -- ONE host sync after the NMS, exact-size proposal
+    lists into the sampler -- which must give the same bits for the same keys."""
+    from detectron2_amd.modeling import (find_top_rpn_proposals_fused, label_and_sample_proposals_fixed,
+                                         mask_rcnn_loss_from_targets)
+    from detectron2_amd.streams import fork_join
+    from detectron2_amd.structures import Boxes, crop_and_resize_batch
+
+    bare = run is None  # no per-op events: the independent branches may go to side streams
+    run = run or (lambda name, fn: fn())
+    n = w.n_img
+    if w.overlap and bare:
+        done = find_top_rpn_proposals_fused(w.anchor_levels, w.rpn_logits, w.rpn_deltas, w.image_sizes, 0.7, 2000, 1000,
+                                            0.0, True, defer=True, beside_nms=lambda: anchor_labels(w, rpn_keys))
+        anchors_out = done.beside
+    else:
+        done = run("rpn_proposals", lambda: find_top_rpn_proposals_fused(
+            w.anchor_levels, w.rpn_logits, w.rpn_deltas, w.image_sizes, 0.7, 2000, 1000, 0.0, True, defer=True))
+        anchors_out = run("label_and_sample_anchors", lambda: anchor_labels(w, rpn_keys))
+    if roi_keys is None:
+        roi_keys = [torch.rand(1000 + N_GT, device=w.dev) for _ in range(n)]
+    if sync:
+        props = done()  # the host sync of the reference's data flow
+        pb = [p.proposal_boxes.tensor for p in props]
+        keys = [torch.cat([roi_keys[i][:pb[i].shape[0]], roi_keys[i][1000:]]) for i in range(n)]
+        samp = label_and_sample_proposals_fixed(pb, w.gt, w.gt_classes, keys=keys, batch_size_per_image=ROI_BATCH,
+                                                positive_fraction=ROI_POS_FRACTION, num_classes=80)
+    else:
+        dp = done.device
+        samp = run("label_and_sample_proposals", lambda: label_and_sample_proposals_fixed(
+            dp.boxes, w.gt, w.gt_classes, limits=dp.limits, limit_stride=2, keys=roi_keys,
+            batch_size_per_image=ROI_BATCH, positive_fraction=ROI_POS_FRACTION, num_classes=80))
+    box_lists = [Boxes(samp["boxes"][i]) for i in range(n)]
+    mask_boxes = [samp["boxes"][i, :MASK_ROWS] for i in range(n)]
+    mask_lists = [Boxes(b) for b in mask_boxes]
+
+    def poolers():
+        return (run("roi_align_box_fwd", lambda: w.box_pooler(w.feats, box_lists)),
+                run("roi_align_mask_fwd", lambda: w.mask_pooler(w.feats, mask_lists)))
+
+    def targets_and_loss():
+        idx = [samp["gt_index"][i, :MASK_ROWS].contiguous() for i in range(n)]
+        cls = samp["classes"][:, :MASK_ROWS].reshape(-1)
+        tg = run("mask_targets", lambda: crop_and_resize_batch(w.gt_masks, mask_boxes, 28, idx, w.crop_status))
+        # background / padding rows among the 128 do not count (class 80 / -1): masked loss, row count on the device
+        return run("mask_loss_fwd", lambda: mask_rcnn_loss_from_targets(w.mask_logits, cls, tg,
+                                                                        ignore_invalid_rows=True))
+
+    if w.overlap and bare:
+        (yb, ym), (loss, stats) = fork_join(poolers, targets_and_loss, current_first=True)
+    else:
+        (yb, ym), (loss, stats) = poolers(), targets_and_loss()
+    return {"anchors": anchors_out, "sample": samp, "box_features": yb, "mask_features": ym, "loss": loss,
+            "stats": stats, "done": done}
+
+
+def connected_step(w, t=None, grads=None):
+    """One eager pass of the connected step (per-op events when `t`), forward + ONE backward."""
+    from detectron2_amd.modeling import poolers as _poolers
+
+    _poolers._NHWC_CACHE.clear()
+    run = (lambda name, fn: fn()) if t is None else (lambda name, fn: t.run(name, fn))
+    out = connected_forward(w, None if t is None else run)
+    n_early = grads.ready_after("roi_heads.box_head") if grads is not None else 0
+    if grads is not None:
+        run("allreduce_issue", lambda: [grads.reduce(i) for i in range(n_early)])
+    run("backward", lambda: torch.autograd.backward([out["box_features"], out["mask_features"], out["loss"]],
+                                                    [w.gbox, w.gmask, None]))
+    if grads is not None:
+        run("allreduce_issue", lambda: [grads.reduce(i) for i in range(n_early, grads.num_buckets)])
+        run("allreduce_wait", grads.finish)
+    for f in w.feats:
+        f.grad = None
+    w.mask_logits.grad = None
+    return out
+
+
+class GraphedConnectedStep:
+    """The connected step as ONE HIP graph: RPN half, samplers, ROI-head half and the backward in one hipGraphLaunch,
+    no host read anywhere in it.  N > 1: the graph is cut in front of the backward so that the ROI heads' gradient
+    bucket can be handed to RCCL there (two launches, still no host sync)."""
+
+    def __init__(self, w, grads):
+        self.w, self.grads = w, grads
+        self.split = grads is not None
+
+        def fwd():
+            self.out = connected_forward(w)
+            return self.out["loss"].detach()
+
+        def bwd():
+            for f in w.feats:
+                f.grad = None
+            w.mask_logits.grad = None
+            torch.autograd.backward([self.out["box_features"], self.out["mask_features"], self.out["loss"]],
+                                    [w.gbox, w.gmask, None])
+
+        def whole():
+            loss = fwd()
+            bwd()
+            self.out = None  # no reference into the captured autograd graph survives the capture
+            return loss
+
+        if self.split:
+            self.gf, self.loss = GraphedStep._capture(fwd, backward=bwd)
+            self.gb = self.gf.second
+        else:
+            self.g, self.loss = GraphedStep._capture(whole)
+
+    def __call__(self):
+        g = self.grads
+        if not self.split:
+            self.g.replay()
+            return self.loss
+        self.gf.replay()
+        n_early = g.ready_after("roi_heads.box_head")
+        for i in range(n_early):
+            g.reduce(i)
+        self.gb.replay()
+        for i in range(n_early, g.num_buckets):
+            g.reduce(i)
+        g.finish()
+        return self.loss
 
 
 class GraphedStep:
@@ -441,7 +597,9 @@ class GraphedStep:
         self.gb, self.out_b = self._capture(part_b)
 
     @staticmethod
-    def _capture(fn):
+    def _capture(fn, backward=None):
+        """backward: a second callable captured as its own graph right behind `fn`'s, in the same memory pool (it
+        consumes the autograd graph `fn` built); returned as `.second` of the first graph."""
         import gc
 
         gc.collect()  # no autograd graph of an eager step may survive into the capture (its AccumulateGrad nodes are
@@ -452,11 +610,17 @@ class GraphedStep:
         with torch.cuda.stream(side):
             for _ in range(3):
                 fn()
+                if backward is not None:
+                    backward()
         cur.wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             out = fn()
+        if backward is not None:
+            g.second = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g.second, pool=g.pool()):
+                backward()
         return g, out
 
     def __call__(self):
@@ -507,11 +671,23 @@ def cpu_baseline_maskrcnn(w):
     dl = [x[:1].cpu().numpy() for x in w.rpn_deltas]
     pg = w.props_with_gt[0].cpu().numpy()
 
+    from oracle import sampling as osp
+
+    krng = np.random.default_rng(0)
+    akeys, pkeys = krng.random(an.shape[0], dtype=np.float32), krng.random(pg.shape[0], dtype=np.float32)
+    gcls = w.gt_classes[0].cpu().numpy()
+
     def per_image():
         q = oracle.pairwise_iou(gt, an)
-        oracle.matcher(q, [0.3, 0.7], [0, -1, 1], True)
+        _idx, lab = oracle.matcher(q, [0.3, 0.7], [0, -1, 1], True)
+        if w.connected:
+            osp.subsample_anchor_labels(lab, akeys, RPN_BATCH, RPN_POS_FRACTION)
         orpn.find_top_rpn_proposals(anchors_l, lg, dl, [(IMG_H, IMG_W)], 0.7, 2000, 1000, 0.0)
-        oracle.matcher(oracle.pairwise_iou(gt, pg), [0.5], [0, 1], False)
+        if w.connected:  # pairwise_iou + Matcher + subsample_labels of the proposals (+ appended ground truth)
+            osp.label_and_sample_fixed(pg[:-N_GT], len(pg) - N_GT, gt, gcls, pkeys, [0.5], [0, 1], ROI_BATCH,
+                                       ROI_POS_FRACTION, 80)
+        else:
+            oracle.matcher(oracle.pairwise_iou(gt, pg), [0.5], [0, 1], False)
 
     t_img = _median_time(per_image)
     jobs = []
@@ -591,14 +767,16 @@ def bench_maskrcnn(args, ctx):
     # weak scaling: 2 images per GPU; rank r owns images [2r, 2r+1] of the global synthetic batch
     w = Workload(dev, dtype, args.layout, image_ids=global_image_ids(IMAGES_PER_GPU, rank, world))
     w.overlap = not args.no_overlap
+    w.connected = not args.disconnected
     grads = make_gradient_buckets(args, dev, dist, world)
+    step = connected_step if w.connected else disconnected_step
     for _ in range(args.warmup):
         step(w, None, grads)
     sw = Stopwatch(dist, dev)
     KERN = "pool_bwd_staged_r7"
     use_graph = not args.no_graph
     if use_graph:
-        gstep = GraphedStep(w, grads)
+        gstep = GraphedConnectedStep(w, grads) if w.connected else GraphedStep(w, grads)
         for _ in range(3):
             gstep()
         sw.start()
@@ -643,8 +821,11 @@ def bench_maskrcnn(args, ctx):
             e["GBps"] = round(alg[k] / 1e6 / max(e["ms_per_step"], 1e-9), 1)
             e["frac_hbm_peak"] = round(e["GBps"] / HBM_PEAK_GBS, 4)
         ops[k] = e
-    dom_ms_timed = dom_timer.totals_ms()["backward"] / args.steps
-    ops["backward"]["ms_per_step_timed_region"] = round(dom_ms_timed, 4)
+    # (the eager pass behind the graphs, NOT the timed region; its first step pays one-off costs and is left out)
+    dom_pairs = dom_timer.pairs["backward"]
+    dom_pairs = dom_pairs[1:] if len(dom_pairs) > 1 else dom_pairs
+    dom_ms_timed = sum(a.elapsed_time(b) for a, b in dom_pairs) / len(dom_pairs)
+    ops["backward"]["ms_per_step_eager_after_graphs" if use_graph else "ms_per_step_timed_region"] = round(dom_ms_timed, 4)
     if args.layout == "nhwc" and KERN in ktimes:
         k_ms, k_n = ktimes[KERN]
         kb = alg["roi_align_box_bwd"]
@@ -654,13 +835,19 @@ def bench_maskrcnn(args, ctx):
                 "achieved": round(kb / 1e6 / k_ms, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(kb / 1e6 / k_ms / HBM_PEAK_GBS, 4),
                 "traffic": pmc_traffic("roi_align_box_bwd", args.layout),
-                "traffic_note": "PMC bytes of the box-head pooler backward (records + tile lists + tile gather)",
+                "traffic_note": "PMC bytes of the box-head pooler backward (records + tile lists + tile gather): LESS than the "
+                                "algorithmic figure, which charges a zero fill and a write of every gradient byte (SURVEY "
+                                "8(d)); the tile gather writes each byte once and zero-fills nothing it writes -- "
+                                "frac_traffic = these bytes / the kernel's time / peak is the fraction of HBM bandwidth the "
+                                "kernel really uses",
                 "alg_bytes_per_launch": int(kb), "ms_per_launch": round(k_ms, 4), "launches_timed": k_n,
                 "alg_bytes_note": "SURVEY 8(d) ROIAlign bwd: s*K*C*R^2 (dY) + 2*s*sum_l N*C*H_l*W_l (zero fill + write of dX)",
                 "timing": "HIP events recorded by the library on the kernel's launch stream right around the launch, mean over "
                           + ("an eager pass of the same number of steps right after the timed region (the timed region "
                              "replays HIP graphs, inside which events cannot be read)" if use_graph else "the timed steps"),
                 "kernels_ms": {k: round(v[0], 4) for k, v in ktimes.items()}}
+        if roof["traffic"]:
+            roof["frac_traffic"] = round(roof["traffic"] / 1e6 / k_ms / HBM_PEAK_GBS, 4)
     else:
         per = alg["backward"]
         roof = {"bound": "hbm", "kernel": "backward (both poolers' tile gather + mask loss backward)",
@@ -676,10 +863,17 @@ def bench_maskrcnn(args, ctx):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "maskrcnn_r50fpn_train_hotpath_bs2_800x1344 (BASELINE configs[1]; configs[2] at n_gpus 8)",
                    "layout": args.layout, "global_batch": world * w.n_img, "ops_per_step": counts,
-                   "launch": ("2 HIP graphs per step (RPN half | ROI-head half + backward), one host sync between them"
+                   "step": ("connected: RPN selection + NMS -> label_and_sample_proposals on the NMS's device-side counts -> "
+                            "box pooler on the 512 sampled rows / image, mask pooler + targets + masked loss on their "
+                            "first 128 rows; anchor labelling + sampling beside the NMS; no host read inside the step"
+                            if w.connected else "disconnected (round 2): fixed ROI lists, the RPN's proposals feed nothing"),
+                   "launch": (("ONE HIP graph per step (one hipGraphLaunch, no host sync)" if grads is None else
+                               "2 HIP graphs per step (forward | backward, cut for the gradient all-reduce), no host sync")
+                              if use_graph and w.connected else
+                              "2 HIP graphs per step (RPN half | ROI-head half + backward), one host sync between them"
                               if use_graph else "eager: every op launched from Python"),
-                   "streams": ("independent branches forked onto side streams (anchor labelling | proposal path; both "
-                               "poolers | proposal labelling + mask targets + loss), joined before the backward"
+                   "streams": ("independent branches forked onto side streams (anchor labelling + sampling beside the NMS; "
+                               "both poolers | mask targets + loss), joined before the backward"
                                if w.overlap else "one stream"),
                    "parallelism": f"dp{world}: images sharded, no data-path collective; "
                                   + (grads_description(grads) if grads is not None else
@@ -1005,6 +1199,20 @@ def main():
         out = bench_plumbing(args, ctx)
     else:
         out = {"maskrcnn_train": bench_maskrcnn, "retinanet_100k": bench_retinanet, "dcn_r50": bench_dcn}[args.workload](args, ctx)
+        # The default run also carries BASELINE configs[3] and [4] (a few steps each, no CPU leg) so that the driver's
+        # ONE line records them: `extra_workloads` = their own metric / value / ms_per_step / roofline.
+        if args.workload == "maskrcnn_train" and world == 1 and not args.no_extra_workloads and not args.force_dist:
+            import copy
+
+            extra = {}
+            for name, fn, steps, warm in (("retinanet_100k", bench_retinanet, 20, 3), ("dcn_r50", bench_dcn, 10, 2)):
+                a2 = copy.copy(args)
+                a2.workload, a2.steps, a2.warmup, a2.no_cpu_baseline = name, steps, warm, True
+                torch.cuda.synchronize()
+                r = fn(a2, ctx)
+                extra[name] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype",
+                                                 "config", "roofline") if k in r}
+            out["extra_workloads"] = extra
     if rank == 0:
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()

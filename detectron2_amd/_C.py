@@ -41,7 +41,7 @@ class SampleImage(ctypes.Structure):
     """d2amd_sample_image (include/d2amd.h)"""
     _fields_ = [("proposals", ctypes.c_void_p), ("limits", ctypes.c_void_p), ("gt_boxes", ctypes.c_void_p),
                 ("gt_classes", ctypes.c_void_p), ("keys", ctypes.c_void_p), ("max_proposals", ctypes.c_int),
-                ("n_limits", ctypes.c_int), ("num_gt", ctypes.c_int)]
+                ("n_limits", ctypes.c_int), ("num_gt", ctypes.c_int), ("limit_stride", ctypes.c_int)]
 
 
 class PoolerParams(ctypes.Structure):
@@ -88,6 +88,9 @@ _SIGNATURES = {
     "d2amd_matcher_workspace_bytes": (_sz, [_i]),
     "d2amd_match_boxes": (_i, [_vp, _i, _vp, _i, ctypes.POINTER(_f), ctypes.POINTER(ctypes.c_int8), _i, _i, _vp, _vp,
                                _vp, _sz, _vp]),
+    "d2amd_match_boxes_batch_workspace_bytes": (_sz, [ctypes.POINTER(_i), _i]),
+    "d2amd_match_boxes_batch": (_i, [ctypes.POINTER(_vp), ctypes.POINTER(_i), _i, _vp, _i, ctypes.POINTER(_f),
+                                     ctypes.POINTER(ctypes.c_int8), _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "d2amd_label_and_sample_max_candidates": (_i, []),
     "d2amd_label_and_sample_proposals": (_i, [ctypes.POINTER(SampleImage), _i, ctypes.POINTER(_f),
                                               ctypes.POINTER(ctypes.c_int8), _i, _i, _i, _i64, _i, _vp, _vp, _vp, _vp,

@@ -36,7 +36,7 @@ struct LsImage {
   const float4* gt;
   const int64_t* gt_classes;
   const float* keys;
-  int max_props, n_limits, num_gt;
+  int max_props, n_limits, num_gt, limit_stride;
 };
 
 struct LsBatch {
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(LS_THREADS) void label_sample_kernel(const LsBatch 
   if (tid == 0) {
     long n = I.max_props;
     for (int l = 0; l < I.n_limits; l++) {
-      const long v = (long)I.limits[l];
+      const long v = (long)I.limits[(long)l * I.limit_stride];
       n = v < n ? v : n;
     }
     s_n = (int)(n < 0 ? 0 : n);
@@ -244,6 +244,7 @@ extern "C" int d2amd_label_and_sample_proposals(const d2amd_sample_image* images
       I.max_props = s.max_proposals;
       I.n_limits = s.n_limits;
       I.num_gt = s.num_gt;
+      I.limit_stride = s.limit_stride > 1 ? s.limit_stride : 1;
     }
     B.boxes = (float4*)boxes_out + (long)i0 * B.S;
     B.classes = classes_out + (long)i0 * B.S;

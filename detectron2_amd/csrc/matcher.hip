@@ -25,14 +25,37 @@ __device__ __forceinline__ uint32_t mt_key(float v) { return v != v ? 0xffffffff
 constexpr int MT_BLOCK = 256;
 constexpr int MT_CHUNK = 512;  // ground-truth boxes staged per LDS pass
 constexpr int MT_U = 8;        // ground-truth boxes evaluated together per prediction
+constexpr int MT_MAX_IMAGES = 16;  // images per launch of the batched entry (blockIdx.y)
+
+// The ground truth of a batch of images matched against the SAME predictions (the RPN's anchors: rpn.py:331-353 loops
+// over the images in Python, one pairwise_iou + Matcher each): image blockIdx.y takes gt[y] / M[y] and writes row y.
+struct MtBatch {
+  const float4* gt[MT_MAX_IMAGES];
+  int M[MT_MAX_IMAGES];
+  long out_stride;  // elements between the images' rows of matches / labels
+  int rm_stride;    // words between the images' row maxima
+};
+// (constant indices only into the kernel-argument struct: a dynamic one makes the compiler copy it to scratch)
+__device__ __forceinline__ void mt_image(const MtBatch& B, int img, const float4*& gt, int& M) {
+  gt = B.gt[0]; M = B.M[0];
+#pragma unroll
+  for (int q = 1; q < MT_MAX_IMAGES; q++)
+    if (q == img) { gt = B.gt[q]; M = B.M[q]; }
+}
 
 // FUSED: IoU from boxes; else values from the row-major M x N matrix `q`
 template <bool FUSED>
-__global__ __launch_bounds__(MT_BLOCK) void match_pass1_kernel(const float4* __restrict__ gt, int M,
+__global__ __launch_bounds__(MT_BLOCK) void match_pass1_kernel(const MtBatch B,
                                                               const float4* __restrict__ boxes, int N,
                                                               const float* __restrict__ q, MatchCfg cfg,
                                                               int64_t* __restrict__ matches, int8_t* __restrict__ labels,
                                                               uint32_t* __restrict__ rowmax) {
+  const float4* gt;
+  int M;
+  mt_image(B, blockIdx.y, gt, M);
+  matches += (long)blockIdx.y * B.out_stride;
+  labels += (long)blockIdx.y * B.out_stride;
+  if (rowmax) rowmax += (long)blockIdx.y * B.rm_stride;
   __shared__ float4 g4[MT_CHUNK];
   __shared__ float garea[MT_CHUNK];
   __shared__ uint32_t rmax[MT_CHUNK];
@@ -123,11 +146,16 @@ __global__ __launch_bounds__(MT_BLOCK) void match_pass1_kernel(const float4* __r
 // ground truth equals that ground truth's row maximum (ties included; a row maximum of 0 matches every
 // prediction with quality 0, exactly like the reference's `==` + nonzero)
 template <bool FUSED>
-__global__ __launch_bounds__(MT_BLOCK) void match_pass2_kernel(const float4* __restrict__ gt, int M,
+__global__ __launch_bounds__(MT_BLOCK) void match_pass2_kernel(const MtBatch B,
                                                               const float4* __restrict__ boxes, int N,
                                                               const float* __restrict__ q,
                                                               const uint32_t* __restrict__ rowmax,
                                                               int8_t* __restrict__ labels) {
+  const float4* gt;
+  int M;
+  mt_image(B, blockIdx.y, gt, M);
+  labels += (long)blockIdx.y * B.out_stride;
+  rowmax += (long)blockIdx.y * B.rm_stride;
   __shared__ float4 g4[MT_CHUNK];
   __shared__ float garea[MT_CHUNK];
   __shared__ uint32_t rmax[MT_CHUNK];
@@ -177,13 +205,10 @@ __global__ void match_fill_kernel(int64_t* matches, int8_t* labels, int N, int8_
   if (n < N) { matches[n] = 0; labels[n] = lab0; }
 }
 
-static int match_impl(const float* gt, int M, const float* boxes, const float* q, int N, const float* thresholds,
-                      const int8_t* labels, int T, int allow_low, int64_t* matches, int8_t* match_labels,
-                      void* workspace, size_t workspace_bytes, hipStream_t s) {
-  D2_CHECK_ARG(M >= 0 && N >= 0, "match: negative size");
+static int match_cfg(const float* thresholds, const int8_t* labels, int T, MatchCfg& cfg) {
   D2_CHECK_ARG(T >= 0 && T <= D2AMD_MATCHER_MAX_THRESHOLDS && labels != nullptr && (T == 0 || thresholds != nullptr),
                "match: %d thresholds (max %d)", T, D2AMD_MATCHER_MAX_THRESHOLDS);
-  MatchCfg cfg{};
+  cfg = MatchCfg{};
   cfg.T = T;
   for (int k = 0; k < T; k++) {
     D2_CHECK_ARG(thresholds[k] > 0.f && (k == 0 || thresholds[k - 1] <= thresholds[k]),
@@ -194,39 +219,66 @@ static int match_impl(const float* gt, int M, const float* boxes, const float* q
     D2_CHECK_ARG(labels[k] >= -1 && labels[k] <= 1, "match: labels must be in {-1, 0, 1}");
     cfg.lab[k] = labels[k];
   }
-  if (N == 0) return D2AMD_OK;
+  return D2AMD_OK;
+}
+
+// `count` images (<= MT_MAX_IMAGES per launch) against the same N predictions: gt[i] [M[i], 4]; outputs [count][N].
+// q (matrix mode): one image.  A ground-truth-free image takes the same kernels (no box: index 0, labels[0]:
+// matcher.py:80-90).
+static int match_impl(const float* const* gt, const int* M, int count, const float* boxes, const float* q, int N,
+                      const float* thresholds, const int8_t* labels, int T, int allow_low, int64_t* matches,
+                      int8_t* match_labels, void* workspace, size_t workspace_bytes, hipStream_t s) {
+  D2_CHECK_ARG(count >= 0 && N >= 0, "match: negative size");
+  MatchCfg cfg;
+  { const int rc = match_cfg(thresholds, labels, T, cfg); if (rc) return rc; }
+  if (N == 0 || count == 0) return D2AMD_OK;
   D2_CHECK_ARG(matches && match_labels, "match: null output");
+  int mmax = 0;
+  for (int i = 0; i < count; i++) {
+    D2_CHECK_ARG(M[i] >= 0, "match: negative size");
+    D2_CHECK_ARG(M[i] == 0 || q != nullptr || (gt[i] != nullptr && boxes != nullptr), "match: null input");
+    mmax = M[i] > mmax ? M[i] : mmax;
+  }
   const int grid = cdiv(N, MT_BLOCK);
-  if (M == 0) {  // matcher.py:80-90: no ground truth -> index 0, labels[0]
+  if (mmax == 0 && count == 1) {  // no ground truth -> index 0, labels[0]
     hipLaunchKernelGGL(match_fill_kernel, dim3(grid), dim3(MT_BLOCK), 0, s, matches, match_labels, N, cfg.lab[0]);
     D2_LAUNCH_OK();
     return D2AMD_OK;
   }
-  D2_CHECK_ARG(q != nullptr || (gt != nullptr && boxes != nullptr), "match: null input");
+  const int rm_stride = (mmax + 63) / 64 * 64;
   uint32_t* rowmax = nullptr;
-  if (allow_low) {
-    if (workspace == nullptr || workspace_bytes < (size_t)M * 4) {
-      set_error("match: workspace too small (%zu < %zu)", workspace_bytes, (size_t)M * 4);
+  if (allow_low && mmax > 0) {
+    const size_t need = (size_t)count * rm_stride * 4;
+    if (workspace == nullptr || workspace_bytes < need) {
+      set_error("match: workspace too small (%zu < %zu)", workspace_bytes, need);
       return D2AMD_EWORKSPACE;
     }
     rowmax = (uint32_t*)workspace;
-    { const int zrc = zero_async(rowmax, (size_t)M * 4, s); if (zrc) return zrc; }
+    { const int zrc = zero_async(rowmax, need, s); if (zrc) return zrc; }
   }
-  if (q)
-    hipLaunchKernelGGL((match_pass1_kernel<false>), dim3(grid), dim3(MT_BLOCK), 0, s, nullptr, M, nullptr, N, q, cfg,
-                       matches, match_labels, rowmax);
-  else
-    hipLaunchKernelGGL((match_pass1_kernel<true>), dim3(grid), dim3(MT_BLOCK), 0, s, (const float4*)gt, M,
-                       (const float4*)boxes, N, nullptr, cfg, matches, match_labels, rowmax);
-  D2_LAUNCH_OK();
-  if (allow_low) {
+  for (int i0 = 0; i0 < count; i0 += MT_MAX_IMAGES) {
+    const int c = count - i0 < MT_MAX_IMAGES ? count - i0 : MT_MAX_IMAGES;
+    MtBatch B{};
+    for (int i = 0; i < c; i++) { B.gt[i] = (const float4*)gt[i0 + i]; B.M[i] = M[i0 + i]; }
+    B.out_stride = N;
+    B.rm_stride = rm_stride;
+    int64_t* mo = matches + (long)i0 * N;
+    int8_t* lo = match_labels + (long)i0 * N;
+    uint32_t* rm = rowmax ? rowmax + (long)i0 * rm_stride : nullptr;
     if (q)
-      hipLaunchKernelGGL((match_pass2_kernel<false>), dim3(grid), dim3(MT_BLOCK), 0, s, nullptr, M, nullptr, N, q,
-                         rowmax, match_labels);
+      hipLaunchKernelGGL((match_pass1_kernel<false>), dim3(grid, c), dim3(MT_BLOCK), 0, s, B, nullptr, N, q, cfg, mo, lo, rm);
     else
-      hipLaunchKernelGGL((match_pass2_kernel<true>), dim3(grid), dim3(MT_BLOCK), 0, s, (const float4*)gt, M,
-                         (const float4*)boxes, N, nullptr, rowmax, match_labels);
+      hipLaunchKernelGGL((match_pass1_kernel<true>), dim3(grid, c), dim3(MT_BLOCK), 0, s, B, (const float4*)boxes, N,
+                         nullptr, cfg, mo, lo, rm);
     D2_LAUNCH_OK();
+    if (rm) {
+      if (q)
+        hipLaunchKernelGGL((match_pass2_kernel<false>), dim3(grid, c), dim3(MT_BLOCK), 0, s, B, nullptr, N, q, rm, lo);
+      else
+        hipLaunchKernelGGL((match_pass2_kernel<true>), dim3(grid, c), dim3(MT_BLOCK), 0, s, B, (const float4*)boxes, N,
+                           nullptr, rm, lo);
+      D2_LAUNCH_OK();
+    }
   }
   return D2AMD_OK;
 }
@@ -235,19 +287,37 @@ static int match_impl(const float* gt, int M, const float* boxes, const float* q
 
 using namespace d2amd;
 
-extern "C" size_t d2amd_matcher_workspace_bytes(int M) { return (size_t)(M > 0 ? M : 1) * 4; }
+extern "C" size_t d2amd_matcher_workspace_bytes(int M) { return (size_t)((M > 0 ? M : 1) + 63) / 64 * 64 * 4; }
 
 extern "C" int d2amd_match_boxes(const float* gt_boxes, int M, const float* boxes, int N, const float* thresholds,
                                  const int8_t* labels, int T, int allow_low_quality, int64_t* matches,
                                  int8_t* match_labels, void* workspace, size_t workspace_bytes, void* stream) {
-  return match_impl(gt_boxes, M, boxes, nullptr, N, thresholds, labels, T, allow_low_quality, matches, match_labels,
-                    workspace, workspace_bytes, (hipStream_t)stream);
+  D2_CHECK_ARG(M >= 0, "match: negative size");
+  return match_impl(&gt_boxes, &M, 1, boxes, nullptr, N, thresholds, labels, T, allow_low_quality, matches,
+                    match_labels, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" size_t d2amd_match_boxes_batch_workspace_bytes(const int* M, int count) {
+  int mmax = 1;
+  for (int i = 0; i < count; i++) mmax = M[i] > mmax ? M[i] : mmax;
+  return (size_t)(count > 0 ? count : 1) * ((mmax + 63) / 64 * 64) * 4;
+}
+
+extern "C" int d2amd_match_boxes_batch(const float* const* gt_boxes, const int* M, int count, const float* boxes, int N,
+                                       const float* thresholds, const int8_t* labels, int T, int allow_low_quality,
+                                       int64_t* matches, int8_t* match_labels, void* workspace, size_t workspace_bytes,
+                                       void* stream) {
+  D2_CHECK_ARG(count == 0 || (gt_boxes != nullptr && M != nullptr), "match_boxes_batch: null image list");
+  return match_impl(gt_boxes, M, count, boxes, nullptr, N, thresholds, labels, T, allow_low_quality, matches,
+                    match_labels, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int d2amd_match_quality_matrix(const float* quality, int M, int N, const float* thresholds,
                                           const int8_t* labels, int T, int allow_low_quality, int64_t* matches,
                                           int8_t* match_labels, void* workspace, size_t workspace_bytes, void* stream) {
   D2_CHECK_ARG(quality != nullptr || (long)M * N == 0, "match_quality_matrix: null matrix");
-  return match_impl(nullptr, M, nullptr, quality, N, thresholds, labels, T, allow_low_quality, matches, match_labels,
+  D2_CHECK_ARG(M >= 0, "match: negative size");
+  const float* none = nullptr;
+  return match_impl(&none, &M, 1, nullptr, quality, N, thresholds, labels, T, allow_low_quality, matches, match_labels,
                     workspace, workspace_bytes, (hipStream_t)stream);
 }

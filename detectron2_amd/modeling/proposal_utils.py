@@ -35,6 +35,24 @@ class Proposals:
         return len(self.proposal_boxes)
 
 
+class DeviceProposals:
+    """The proposals of a batch with their counts left on the device (no host sync): per image `boxes`
+    [post_nms_topk, 4] / `logits` [post_nms_topk] in objectness order, valid up to min(post_nms_topk, limits[0],
+    limits[2]) -- `limits[i]` is the NMS result row {kept, flags, finite, 0} (int64 words, limit_stride 2) -- and
+    `nonfinite_flag` (int32[1]; non-zero: predicted boxes or scores contained Inf / NaN, what the synchronous path
+    raises FloatingPointError for: check it after the step)."""
+
+    def __init__(self, boxes, logits, limits, nonfinite_flag, image_sizes):
+        self.boxes, self.logits, self.limits, self.nonfinite_flag = boxes, logits, limits, nonfinite_flag
+        self.image_sizes = image_sizes
+
+    def counts(self):
+        """the valid lengths as a device tensor [N] (int64; torch ops, no sync)"""
+        cap = self.boxes[0].shape[0] if self.boxes else 0
+        lim = torch.stack(self.limits)
+        return torch.minimum(lim[:, 0], lim[:, 2]).clamp(min=0, max=cap)
+
+
 def rpn_select_proposals(anchors: List[torch.Tensor], pred_objectness_logits: List[torch.Tensor],
                          pred_anchor_deltas: List[torch.Tensor], image_sizes: List[Tuple[int, int]],
                          pre_nms_topk: int, min_box_size: float, weights=(1.0, 1.0, 1.0, 1.0),
@@ -140,4 +158,10 @@ def find_top_rpn_proposals_fused(anchors, pred_objectness_logits, pred_anchor_de
         return out
 
     finish.beside = beside
+    # what the ROI heads of a captured step read instead of calling finish(): fixed-size lists whose valid length the
+    # DEVICE knows (label_and_sample_proposals_fixed(limits=..., limit_stride=2))
+    finish.device = DeviceProposals(
+        [nms_done.gathered[i][0][:post_nms_topk] for i in range(n)] if n else [],
+        [nms_done.gathered[i][1][:post_nms_topk] for i in range(n)] if n else [],
+        list(res[:8 * n].view(torch.int64).view(n, 4)) if n else [], res[8 * n:], [tuple(s) for s in image_sizes])
     return finish if defer else finish()

@@ -88,7 +88,7 @@ def subsample_labels(labels: torch.Tensor, num_samples: int, positive_fraction: 
     return pos[0, :num_pos], neg[0, :num_neg]
 
 
-def label_and_sample_proposals_fixed(proposal_boxes, gt_boxes, gt_classes, limits=None, keys=None,
+def label_and_sample_proposals_fixed(proposal_boxes, gt_boxes, gt_classes, limits=None, keys=None, limit_stride=1,
                                      thresholds=(0.5,), labels=(0, 1), batch_size_per_image: int = 512,
                                      positive_fraction: float = 0.25, num_classes: int = 80,
                                      proposal_append_gt: bool = True, generator: torch.Generator = None):
@@ -97,7 +97,9 @@ def label_and_sample_proposals_fixed(proposal_boxes, gt_boxes, gt_classes, limit
 
     proposal_boxes: per image a [max_p_i, 4] fp32 HIP tensor (e.g. `finish.gathered[i][0]` of
     `batched_nms_images(..., gather=...)`: rows in keep order, valid up to a count the DEVICE knows);
-    limits: per image None or an int64 HIP tensor of up to 4 words -- the image uses min(max_p_i, words) proposals;
+    limits: per image None or an int64 HIP tensor -- the image uses min(max_p_i, the limit words) proposals; the words
+    are limits[0], limits[limit_stride], ... (up to 4).  The NMS result row of find_top_rpn_proposals_fused is
+    {kept, flags, finite, 0}: pass the row with limit_stride = 2 (kept and finite; `DeviceProposals.limits`);
     gt_boxes / gt_classes: per image [G_i, 4] fp32 / [G_i] int64 HIP tensors (Matcher thresholds / labels as
     roi_heads.py:176-180 builds them: [0.5] / [0, 1], no low-quality matches);
     keys: per image [max_p_i + G_i] uniform fp32 (default: torch.rand with `generator`).
@@ -130,13 +132,16 @@ def label_and_sample_proposals_fixed(proposal_boxes, gt_boxes, gt_classes, limit
         k = keys[i] if keys is not None else torch.rand(p.shape[0] + g.shape[0], device=dev, generator=generator)
         k = k.detach().float().contiguous().reshape(-1)
         assert k.shape[0] == p.shape[0] + g.shape[0], (k.shape, p.shape, g.shape)
-        lim = None if limits is None or limits[i] is None else limits[i].detach().to(torch.int64).contiguous().reshape(-1)
+        lim = None if limits is None or limits[i] is None else limits[i].detach().reshape(-1)
+        assert lim is None or (lim.dtype == torch.int64 and lim.is_contiguous()), "limits: contiguous int64 words"
         hold += [p, g, c, k, lim]
         imgs[i].proposals, imgs[i].gt_boxes, imgs[i].gt_classes, imgs[i].keys = (
             _C.ptr(p).value, _C.ptr(g).value, _C.ptr(c).value, _C.ptr(k).value)
         imgs[i].limits = None if lim is None else _C.ptr(lim).value
         imgs[i].max_proposals, imgs[i].num_gt = int(p.shape[0]), int(g.shape[0])
-        imgs[i].n_limits = 0 if lim is None else int(lim.shape[0])
+        st = max(int(limit_stride), 1)
+        imgs[i].n_limits = 0 if lim is None else min(4, (int(lim.shape[0]) + st - 1) // st)
+        imgs[i].limit_stride = st
     T = len(thresholds)
     thr = (ctypes.c_float * max(T, 1))(*[float(t) for t in thresholds])
     lab = (ctypes.c_int8 * (T + 1))(*[int(v) for v in labels])

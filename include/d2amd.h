@@ -184,8 +184,8 @@ int d2amd_box_iou_rotated(const float* boxes1, int n, const float* boxes2, int m
  * roi_heads.py:176-180) + _sample_proposals (roi_heads.py:181-216) + subsample_labels (modeling/sampling.py:9-54), for
  * a batch, with a FIXED output shape and no host sync (the ROI half of a captured step cannot wait for the host).
  * Per image: candidates = the first n proposals, n = min(max_proposals, limits[0 .. n_limits)) with `limits` DEVICE
- * int64 words (e.g. the kept / finite counts d2amd_nms_batched_runs left in its result buffer; n_limits <= 4, may be
- * 0), followed by the ground-truth boxes when append_gt.  keys: one uniform random fp32 per candidate SLOT --
+ * int64 words `limit_stride` apart (e.g. the kept / finite counts d2amd_nms_batched_runs left in its result row
+ * {kept, flags, finite, 0}: n_limits 2, limit_stride 2; n_limits <= 4, may be 0), followed by the ground-truth boxes when append_gt.  keys: one uniform random fp32 per candidate SLOT --
  * [max_proposals] for the proposals, then [num_gt] for the appended boxes (no NaN).  Sampling rule: the
  * min(#positives, max_positives) smallest keys among the positives (class not in {-1, num_classes}), then the
  * min(#negatives, batch_size_per_image - sampled positives) smallest among the negatives; ties by candidate index.
@@ -202,6 +202,7 @@ typedef struct {
   const int64_t* gt_classes; /* [num_gt] */
   const float* keys;         /* [max_proposals + num_gt] */
   int max_proposals, n_limits, num_gt;
+  int limit_stride;          /* words between the limits: limits[0], limits[limit_stride], ... (0 or 1: contiguous) */
 } d2amd_sample_image;
 int d2amd_label_and_sample_max_candidates(void);
 int d2amd_label_and_sample_proposals(const d2amd_sample_image* images, int count, const float* thresholds,
@@ -242,6 +243,15 @@ size_t d2amd_matcher_workspace_bytes(int M);
 int d2amd_match_boxes(const float* gt_boxes, int M, const float* boxes, int N, const float* thresholds,
                       const int8_t* labels, int T, int allow_low_quality, int64_t* matches,
                       int8_t* match_labels, void* workspace, size_t workspace_bytes, void* stream);
+/* The same for a batch of images against the SAME boxes (the RPN's anchors; proposal_generator/rpn.py:331-353 loops over
+ * the images in Python): gt_boxes (host array of `count` device pointers) [M[i]][4], M (host) [count]; outputs
+ * matches [count][N], match_labels [count][N] -- ONE launch per pass for the batch.  workspace:
+ * d2amd_match_boxes_batch_workspace_bytes(M, count) (row maxima, allow_low_quality only). */
+size_t d2amd_match_boxes_batch_workspace_bytes(const int* M, int count);
+int d2amd_match_boxes_batch(const float* const* gt_boxes, const int* M, int count, const float* boxes, int N,
+                            const float* thresholds, const int8_t* labels, int T, int allow_low_quality,
+                            int64_t* matches, int8_t* match_labels, void* workspace, size_t workspace_bytes,
+                            void* stream);
 int d2amd_match_quality_matrix(const float* quality, int M, int N, const float* thresholds,
                                const int8_t* labels, int T, int allow_low_quality, int64_t* matches,
                                int8_t* match_labels, void* workspace, size_t workspace_bytes, void* stream);

@@ -11,11 +11,11 @@ import bench  # noqa: E402
 dev = torch.device("cuda:0")
 w = bench.Workload(dev, torch.bfloat16, "nhwc")
 for _ in range(3):
-    bench.step(w)
+    bench.disconnected_step(w)
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
     for _ in range(3):
-        bench.step(w)
+        bench.disconnected_step(w)
     torch.cuda.synchronize()
 rows = []
 for e in prof.key_averages(group_by_stack_n=12):

@@ -26,7 +26,7 @@ for overlap in (True, False):
     w = bench.Workload(dev, torch.bfloat16, "nhwc")
     w.overlap = overlap
     for _ in range(3):
-        bench.step(w)
+        bench.disconnected_step(w)
     g = bench.GraphedStep(w, None)
     a_only = t(lambda: g.ga.replay())
     a_sync = t(lambda: (g.ga.replay(), g.out_a[0]()))

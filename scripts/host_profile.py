@@ -6,17 +6,17 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 w = bench.Workload(torch.device("cuda", 0), torch.bfloat16, "nhwc")
 for _ in range(5):
-    bench.step(w)
+    bench.disconnected_step(w)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(50):
-    bench.step(w)
+    bench.disconnected_step(w)
 torch.cuda.synchronize()
 print("ms/step (wall)", round((time.perf_counter() - t0) / 50 * 1e3, 4))
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(50):
-    bench.step(w)
+    bench.disconnected_step(w)
 torch.cuda.synchronize()
 pr.disable()
 s = io.StringIO()

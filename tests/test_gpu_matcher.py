@@ -73,3 +73,34 @@ def test_matcher_rpn_full_size():
     m, l = mr.match_boxes(gt, w.props[0])
     em, el = oracle.matcher(oracle.pairwise_iou(gt.cpu().numpy(), w.props[0].cpu().numpy()), [0.5], [0, 1], False)
     assert np.array_equal(m.cpu().numpy(), em) and np.array_equal(l.cpu().numpy(), el)
+
+
+@pytest.mark.parametrize("low", [True, False])
+def test_match_boxes_batch_equals_the_per_image_loop(low):
+    """d2amd_match_boxes_batch: the ground truth of several images (different counts, one image without any, more images
+    than one launch holds) against the SAME boxes == the reference's per-image loop (rpn.py:331-353), bit for bit,
+    and == the oracle."""
+    rng = np.random.default_rng(17 + low)
+    n = 20000
+    a = rng.uniform(0, 600, (n, 4)).astype(np.float32)
+    a[:, 2:] = a[:, :2] + rng.uniform(4, 200, (n, 2)).astype(np.float32)
+    counts = [5, 0, 40, 1, 17] + [3] * 14  # 19 images: two launches
+    gts = []
+    for i, m in enumerate(counts):
+        g = rng.uniform(0, 600, (m, 4)).astype(np.float32)
+        g[:, 2:] = g[:, :2] + rng.uniform(10, 250, (m, 2)).astype(np.float32)
+        if m:
+            g[0] = a[100 + i]  # an exact match, shared by a row maximum
+        gts.append(g)
+    mt = Matcher([0.3, 0.7], [0, -1, 1], allow_low_quality_matches=low)
+    at = torch.from_numpy(a).to(DEV)
+    m, l = mt.match_boxes_batch([torch.from_numpy(g).to(DEV) for g in gts], at)
+    assert tuple(m.shape) == tuple(l.shape) == (len(counts), n) and m.dtype == torch.int64 and l.dtype == torch.int8
+    for i, g in enumerate(gts):
+        em, el = mt.match_boxes(torch.from_numpy(g).to(DEV).reshape(-1, 4), at)
+        assert torch.equal(m[i], em) and torch.equal(l[i], el), i
+        if i < 5:
+            om, ol = oracle.matcher(oracle.pairwise_iou(g, a), [0.3, 0.7], [0, -1, 1], low)
+            assert np.array_equal(m[i].cpu().numpy(), om) and np.array_equal(l[i].cpu().numpy(), ol), i
+    e = mt.match_boxes_batch([], at)
+    assert tuple(e[0].shape) == (0, n)
