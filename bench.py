@@ -419,6 +419,14 @@ def anchor_labels(w, keys=None):
     return labels, matches, counts
 
 
+def step_keys(w):
+    """Every random key of a step in ONE launch: [N, 268,569] for the anchor sampler, [N, 1,000 + G] for the proposal
+    sampler (torch's generator: inside a captured graph the Philox offset advances per replay)."""
+    na = w.anchors.shape[0]
+    k = torch.rand(w.n_img, na + 1000 + N_GT, device=w.dev)
+    return k[:, :na], [k[i, na:] for i in range(w.n_img)]
+
+
 def connected_forward(w, run=None, rpn_keys=None, roi_keys=None, sync=False):
     """The training hot path with the ROI heads fed by the RPN of the same step (GeneralizedRCNN.forward: rpn.py:431-480
     -> roi_heads.py:220-295 -> poolers.py:206): RPN selection + NMS (anchor labelling + sampling beside the NMS) ->
@@ -434,16 +442,32 @@ def connected_forward(w, run=None, rpn_keys=None, roi_keys=None, sync=False):
     bare = run is None  # no per-op events: the independent branches may go to side streams
     run = run or (lambda name, fn: fn())
     n = w.n_img
+    keys_ready = None
     if w.overlap and bare:
+        # side branch beside the NMS: the step's keys first (an event tells the main path when), then anchor labelling +
+        # sampling; joined at the END of the forward -- it outlasts the NMS by ~25 us and nothing needs it before
+        def side():
+            nonlocal rpn_keys, roi_keys, keys_ready
+            if roi_keys is None or rpn_keys is None:
+                rk, ok = step_keys(w)
+                rpn_keys = rk if rpn_keys is None else rpn_keys
+                roi_keys = ok if roi_keys is None else roi_keys
+                keys_ready = torch.cuda.Event()
+                keys_ready.record()
+            return anchor_labels(w, rpn_keys)
+
         done = find_top_rpn_proposals_fused(w.anchor_levels, w.rpn_logits, w.rpn_deltas, w.image_sizes, 0.7, 2000, 1000,
-                                            0.0, True, defer=True, beside_nms=lambda: anchor_labels(w, rpn_keys))
+                                            0.0, True, defer=True, beside_nms=side, join_beside=False)
         anchors_out = done.beside
+        if keys_ready is not None:
+            torch.cuda.current_stream().wait_event(keys_ready)
     else:
+        if roi_keys is None or rpn_keys is None:
+            rk, ok = step_keys(w)
+            rpn_keys, roi_keys = (rk if rpn_keys is None else rpn_keys), (ok if roi_keys is None else roi_keys)
         done = run("rpn_proposals", lambda: find_top_rpn_proposals_fused(
             w.anchor_levels, w.rpn_logits, w.rpn_deltas, w.image_sizes, 0.7, 2000, 1000, 0.0, True, defer=True))
         anchors_out = run("label_and_sample_anchors", lambda: anchor_labels(w, rpn_keys))
-    if roi_keys is None:
-        roi_keys = [torch.rand(1000 + N_GT, device=w.dev) for _ in range(n)]
     if sync:
         props = done()  # the host sync of the reference's data flow
         pb = [p.proposal_boxes.tensor for p in props]
@@ -473,6 +497,7 @@ def connected_forward(w, run=None, rpn_keys=None, roi_keys=None, sync=False):
 
     if w.overlap and bare:
         (yb, ym), (loss, stats) = fork_join(poolers, targets_and_loss, current_first=True)
+        done.join_beside()  # the anchor labels are part of the forward's result
     else:
         (yb, ym), (loss, stats) = poolers(), targets_and_loss()
     return {"anchors": anchors_out, "sample": samp, "box_features": yb, "mask_features": ym, "loss": loss,

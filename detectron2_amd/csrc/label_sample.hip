@@ -16,9 +16,13 @@
 // ascending key -- the reference's order is a random permutation, i.e. not defined.
 //
 // One 1,024-thread workgroup per image: candidates (<= LS_MAX, 4 per thread) keep their running best match in registers
-// while the ground truth streams through LDS; rank = number of same-group candidates with a smaller (key, index),
-// counted against LDS (n^2 compares of 1,100 candidates: ~1 us).  Matching arithmetic: matcher_core.h (bit-exact with
-// d2amd_match_boxes; -ffp-contract=off).
+// while the ground truth streams through LDS.  rank = number of same-group candidates with a smaller (key, index): the
+// candidates are counting-sorted in LDS by (group, bucket of the key) -- 256 buckets per group, bucket = the key's
+// position in [0, 1) -- so a candidate's rank is the number of candidates in the buckets below its own plus the few
+// bucket mates it beats (any key distribution is handled: equal keys share a bucket, the worst case is one bucket
+// holding everybody).  The first versions compared every candidate with every other one: 1,016^2 x ~6 instructions on
+// ONE compute unit = 62 us (199 us with one dependent LDS load per compare), the longest op of the connected step
+// (gpurun_out/r3h, r3j).  Matching arithmetic: matcher_core.h (bit-exact with d2amd_match_boxes; -ffp-contract=off).
 #pragma clang fp contract(off)
 #include <cstring>
 
@@ -29,6 +33,8 @@ namespace d2amd {
 
 constexpr int LS_THREADS = 1024, LS_PER = 4, LS_MAX = LS_THREADS * LS_PER, LS_GT_CHUNK = 512;
 constexpr int LS_MAX_IMAGES = 16;  // per launch
+constexpr int LS_BUCKETS = 256;    // key buckets per group of the rank's counting sort
+static_assert(2 * LS_BUCKETS <= LS_THREADS && LS_MAX <= 65536, "label_sample bucket sort layout");
 
 struct LsImage {
   const float4* props;
@@ -50,11 +56,12 @@ struct LsBatch {
 };
 
 __global__ __launch_bounds__(LS_THREADS) void label_sample_kernel(const LsBatch B) {
-  __shared__ float s_key[LS_MAX];
-  __shared__ int8_t s_grp[LS_MAX];  // 0 positive, 1 negative, 2 neither / not a candidate
+  __shared__ float s_key[LS_MAX];       // key of candidate c
+  __shared__ uint16_t s_order[LS_MAX];  // candidate ids in (group, bucket) order
+  __shared__ int s_bcnt[2 * LS_BUCKETS], s_bstart[2 * LS_BUCKETS + 1], s_wsum[LS_THREADS / 64];
   __shared__ float4 s_gt[LS_GT_CHUNK];
   __shared__ float s_garea[LS_GT_CHUNK];
-  __shared__ int s_n, s_gt_nan, s_cnt[2];
+  __shared__ int s_n, s_gt_nan;
   const int tid = threadIdx.x, image = blockIdx.x;
   // (constant indices only into the kernel-argument struct: a dynamic one makes the compiler copy it to scratch)
   LsImage I = B.img[0];
@@ -68,7 +75,6 @@ __global__ __launch_bounds__(LS_THREADS) void label_sample_kernel(const LsBatch 
       n = v < n ? v : n;
     }
     s_n = (int)(n < 0 ? 0 : n);
-    s_cnt[0] = s_cnt[1] = 0;
   }
   __syncthreads();
   const int n = s_n, G = I.num_gt;
@@ -114,14 +120,20 @@ __global__ __launch_bounds__(LS_THREADS) void label_sample_kernel(const LsBatch 
       }
     }
   }
-  // ---- _sample_proposals: class per candidate, group, key
+  // ---- _sample_proposals: class per candidate, group, key; counting sort by (group, key bucket)
+  if (tid < 2 * LS_BUCKETS) s_bcnt[tid] = 0;
+  __syncthreads();
   int64_t cls[LS_PER];
-  int npos = 0, nneg = 0;
+  float key[LS_PER];
+  int bkt[LS_PER], at[LS_PER];  // bucket (group * LS_BUCKETS + key bucket; -1: not sampled from), arrival in the bucket
 #pragma unroll
   for (int k = 0; k < LS_PER; k++) {
     const int c = tid + k * LS_THREADS;
     int grp = 2;
     cls[k] = -1;
+    key[k] = 0.f;
+    bkt[k] = -1;
+    at[k] = 0;
     if (c < ncand) {
       if (G > 0) {
         const int8_t lab = mt_label(best[k], B.cfg);
@@ -130,24 +142,42 @@ __global__ __launch_bounds__(LS_THREADS) void label_sample_kernel(const LsBatch 
         cls[k] = B.num_classes;  // roi_heads.py:207: no ground truth -> every proposal is background
       }
       grp = cls[k] == B.num_classes ? 1 : (cls[k] == -1 ? 2 : 0);  // sampling.py:39-40
-      s_key[c] = I.keys[c < n ? c : I.max_props + (c - n)];
+      key[k] = I.keys[c < n ? c : I.max_props + (c - n)];
+      s_key[c] = key[k];
+      if (grp < 2) {
+        // monotone in the key (equal keys -> equal bucket; anything outside [0, 1) lands in the end buckets)
+        const float f = key[k] * (float)LS_BUCKETS;
+        const int b = f >= (float)(LS_BUCKETS - 1) ? LS_BUCKETS - 1 : (f > 0.f ? (int)f : 0);
+        bkt[k] = grp * LS_BUCKETS + b;
+        at[k] = atomicAdd(&s_bcnt[bkt[k]], 1);
+      }
     }
-    if (c < LS_MAX) s_grp[c] = (int8_t)grp;
-    npos += grp == 0;
-    nneg += grp == 1;
-  }
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) {
-    npos += __shfl_xor(npos, d, 64);
-    nneg += __shfl_xor(nneg, d, 64);
-  }
-  if ((tid & 63) == 0) {
-    if (npos) atomicAdd(&s_cnt[0], npos);
-    if (nneg) atomicAdd(&s_cnt[1], nneg);
   }
   __syncthreads();
-  const int num_pos = min(s_cnt[0], B.pos_max);      // sampling.py:42-44
-  const int num_neg = min(s_cnt[1], B.S - num_pos);  // sampling.py:45-47
+  {  // exclusive scan of the 512 bucket counts (threads 0 .. 511: wave scans + the 8 wave totals)
+    const int lane = tid & 63, wv = tid >> 6;
+    const int v = tid < 2 * LS_BUCKETS ? s_bcnt[tid] : 0;
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int y = __shfl_up(x, d, 64);
+      if (lane >= d) x += y;
+    }
+    if (lane == 63) s_wsum[wv] = x;
+    __syncthreads();
+    int base = 0;
+    for (int q = 0; q < wv; q++) base += s_wsum[q];
+    if (tid < 2 * LS_BUCKETS) s_bstart[tid] = base + x - v;
+    if (tid == 2 * LS_BUCKETS - 1) s_bstart[2 * LS_BUCKETS] = base + x;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < LS_PER; k++)
+    if (bkt[k] >= 0) s_order[s_bstart[bkt[k]] + at[k]] = (uint16_t)(tid + k * LS_THREADS);
+  __syncthreads();
+  const int n_pos_all = s_bstart[LS_BUCKETS], n_neg_all = s_bstart[2 * LS_BUCKETS] - n_pos_all;
+  const int num_pos = min(n_pos_all, B.pos_max);      // sampling.py:42-44
+  const int num_neg = min(n_neg_all, B.S - num_pos);  // sampling.py:45-47
   // ---- rank inside the group by (key, index); the selected ones go to their slot
   float4* ob = B.boxes + (long)image * B.S;
   int64_t* oc = B.classes + (long)image * B.S;
@@ -155,19 +185,20 @@ __global__ __launch_bounds__(LS_THREADS) void label_sample_kernel(const LsBatch 
   int64_t* oi = B.index + (long)image * B.S;
 #pragma unroll
   for (int k = 0; k < LS_PER; k++) {
+    if (bkt[k] < 0) continue;
     const int c = tid + k * LS_THREADS;
-    if (c >= ncand) continue;
-    const int grp = s_grp[c];
-    if (grp == 2) continue;
-    const float key = s_key[c];
-    const int want = grp == 0 ? num_pos : num_neg;
-    int rank = 0;
-    for (int j = 0; j < ncand && rank < want; j++) {
+    const bool pos = bkt[k] < LS_BUCKETS;
+    const int want = pos ? num_pos : num_neg;
+    const int lo = s_bstart[bkt[k]], hi = s_bstart[bkt[k] + 1];
+    int rank = lo - (pos ? 0 : n_pos_all);  // same-group candidates in the buckets below
+    if (rank >= want) continue;
+    for (int p2 = lo; p2 < hi; p2++) {  // bucket mates: a handful for uniform keys
+      const int j = s_order[p2];
       const float kj = s_key[j];
-      rank += (s_grp[j] == grp && (kj < key || (kj == key && j < c))) ? 1 : 0;
+      rank += (kj < key[k] || (kj == key[k] && j < c)) ? 1 : 0;
     }
     if (rank >= want) continue;
-    const int slot = (grp == 0 ? 0 : num_pos) + rank;
+    const int slot = (pos ? 0 : num_pos) + rank;
     ob[slot] = box[k];
     oc[slot] = cls[k];
     og[slot] = besti[k];

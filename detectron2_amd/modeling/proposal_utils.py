@@ -109,7 +109,7 @@ def rpn_select_proposals(anchors: List[torch.Tensor], pred_objectness_logits: Li
 def find_top_rpn_proposals_fused(anchors, pred_objectness_logits, pred_anchor_deltas, image_sizes, nms_thresh: float,
                                  pre_nms_topk: int, post_nms_topk: int, min_box_size: float, training: bool,
                                  weights=(1.0, 1.0, 1.0, 1.0), scale_clamp: float = _DEFAULT_SCALE_CLAMP,
-                                 defer: bool = False, beside_nms=None):
+                                 defer: bool = False, beside_nms=None, join_beside: bool = True):
     """-> list of N `Proposals` (proposal_boxes: Boxes, objectness_logits), sorted by objectness.
     ONE host sync per batch: the kept counts, the number of kept boxes that are valid proposals (invalid rows are
     parked at score -inf and sort last: the NMS reports how many kept boxes have a finite score) and the non-finite
@@ -120,7 +120,10 @@ def find_top_rpn_proposals_fused(anchors, pred_objectness_logits, pred_anchor_de
     selection + decode, joined before this function returns; its result is `.beside` of the returned callable /
     ignored without defer).  The selection kernels are latency-bound chains of few workgroups that slow down when
     chip-filling kernels run next to them (fused select 27 -> 35 us, decode 5 -> 13 us beside the anchor matcher); the
-    NMS reduction (10 workgroups walking their lists) does not.  Captured RPN half of bench.py: 159.5 -> 156.5 us."""
+    NMS reduction (10 workgroups walking their lists) does not.  Captured RPN half of bench.py: 159.5 -> 156.5 us.
+    join_beside=False (with defer): the side branch is NOT joined here -- `.join_beside()` of the returned callable does
+    it, whenever its results are needed (bench.py's connected step: at the end of the forward; the anchor labelling +
+    sampling take longer than the NMS, and nothing before the losses reads them)."""
     n = int(pred_objectness_logits[0].shape[0])
     # one int32 buffer for everything the host reads back: 8 words per image of NMS results + the non-finite flag
     res = torch.empty(8 * n + 1, dtype=torch.int32, device=anchors[0].device)
@@ -142,9 +145,10 @@ def find_top_rpn_proposals_fused(anchors, pred_objectness_logits, pred_anchor_de
     if beside_nms is not None:
         from ..streams import fork_join
 
-        nms_done, beside = fork_join(nms, beside_nms, device=res.device, current_first=True)
+        nms_done, beside, *late = fork_join(nms, beside_nms, device=res.device, current_first=True,
+                                            defer_join=not join_beside)
     else:
-        nms_done = nms()
+        nms_done, late = nms(), []
 
     def finish():
         keeps, n_finite, (bad,) = nms_done(with_finite=True) if n else ([], [], (0,))  # the one sync
@@ -158,6 +162,7 @@ def find_top_rpn_proposals_fused(anchors, pred_objectness_logits, pred_anchor_de
         return out
 
     finish.beside = beside
+    finish.join_beside = late[0] if late else (lambda: None)
     # what the ROI heads of a captured step read instead of calling finish(): fixed-size lists whose valid length the
     # DEVICE knows (label_and_sample_proposals_fixed(limits=..., limit_stride=2))
     finish.device = DeviceProposals(

@@ -44,19 +44,25 @@ def _record(obj, stream):
         _record(obj.tensor, stream)
 
 
-def fork_join(*branches: Callable[[], object], device: torch.device = None, current_first: bool = False) -> list:
+def fork_join(*branches: Callable[[], object], device: torch.device = None, current_first: bool = False,
+              defer_join: bool = False) -> list:
     """Run branch 0 on the current stream and every other branch on its own side stream, all starting from the
     current point of the current stream; return their results once everything has been ENQUEUED (no host sync): work
     enqueued on the current stream afterwards sees all of it.
 
     The side branches are enqueued before branch 0 unless `current_first`.  The order matters to a captured graph too:
     hipGraphLaunch hands the nodes to the device in capture order, a couple of microseconds apiece, so the branch
-    captured last starts that much later -- capture the critical branch first."""
+    captured last starts that much later -- capture the critical branch first.
+
+    defer_join: do not join here; the returned list gets one more element, a callable `join()` that makes the
+    CURRENT stream (at the time it is called) wait for the side branches -- for a side branch whose results are only
+    needed much later than branch 0's (the anchor labelling beside the NMS: the ROI heads need the proposals, nobody
+    needs the anchor labels before the losses).  The side branches' results must not be touched before `join()`."""
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device())
     cur = torch.cuda.current_stream(device)
     if len(branches) <= 1:
-        return [b() for b in branches]
+        return [b() for b in branches] + ([lambda: None] if defer_join else [])
     side = _streams(device, len(branches) - 1)
     for st in side:
         st.wait_stream(cur)  # fork: the branch sees everything enqueued so far
@@ -68,7 +74,14 @@ def fork_join(*branches: Callable[[], object], device: torch.device = None, curr
             out[i] = branches[i]()
     if not current_first:
         out[0] = branches[0]()
-    for i, st in enumerate(side, start=1):
-        cur.wait_stream(st)  # join
-        _record(out[i], cur)
+
+    def join():
+        now = torch.cuda.current_stream(device)
+        for i, st in enumerate(side, start=1):
+            now.wait_stream(st)
+            _record(out[i], now)
+
+    if defer_join:
+        return out + [join]
+    join()
     return out

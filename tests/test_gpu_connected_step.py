@@ -56,7 +56,8 @@ def test_device_counts_path_equals_the_host_sync_path(workload):
     dev_res, out = _run(w, rpn_keys, roi_keys, sync=False)
     props = out["done"]()  # (the sync the step itself never makes)
     del out
-    sync_res, _ = _run(w, rpn_keys, roi_keys, sync=True)
+    sync_res, out = _run(w, rpn_keys, roi_keys, sync=True)
+    del out
     _same(dev_res, sync_res)
     # the device-side counts are the ones the host path reads
     dp_counts = [min(1000, len(p)) for p in props]
@@ -89,7 +90,8 @@ def test_one_graph_replay_equals_the_eager_step(workload):
     step's bits; with in-graph torch.rand keys the replays differ from each other only through the keys."""
     w = workload
     rpn_keys, roi_keys = _keys(5, w.n_img)
-    want, _ = _run(w, rpn_keys, roi_keys, sync=False)
+    want, out = _run(w, rpn_keys, roi_keys, sync=False)
+    del out  # (no autograd graph of an eager step may be alive during the capture: bench.GraphedStep._capture)
     holder = {}
 
     def whole():
