@@ -26,8 +26,9 @@ import torch
 _POOL = {}
 
 
-def _streams(device: torch.device, n: int) -> List["torch.cuda.Stream"]:
-    pool = _POOL.setdefault(device.index, [])
+def _streams(device: torch.device, n: int, late: bool = False) -> List["torch.cuda.Stream"]:
+    # (branches whose join is deferred get streams of their own: a later fork_join must not queue behind them)
+    pool = _POOL.setdefault((device.index, late), [])
     while len(pool) < n:
         pool.append(torch.cuda.Stream(device=device))
     return pool[:n]
@@ -63,7 +64,7 @@ def fork_join(*branches: Callable[[], object], device: torch.device = None, curr
     cur = torch.cuda.current_stream(device)
     if len(branches) <= 1:
         return [b() for b in branches] + ([lambda: None] if defer_join else [])
-    side = _streams(device, len(branches) - 1)
+    side = _streams(device, len(branches) - 1, late=defer_join)
     for st in side:
         st.wait_stream(cur)  # fork: the branch sees everything enqueued so far
     out = [None] * len(branches)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3, visit j: kernel stats + trace of the connected one-graph step
-cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp PYTHONPATH=$PWD; REPO=$PWD; OUT=$REPO/gpurun_out/r3k; mkdir -p $OUT
-timeout 600 python -m pytest tests/test_gpu_label_sample.py tests/test_gpu_connected_step.py -q -m gpu 2>&1 | tail -5
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp PYTHONPATH=$PWD; REPO=$PWD; OUT=$REPO/gpurun_out/r3l; mkdir -p $OUT
+timeout 600 python -m pytest tests/test_gpu_label_sample.py tests/test_gpu_connected_step.py tests/test_gpu_graph.py tests/test_gpu_rpn.py -q -m gpu 2>&1 | tail -5
 timeout 300 python bench.py --no-cpu-baseline --no-extra-workloads > $OUT/bench.json 2>$OUT/bench.err; python -c "import json; d=json.load(open('$OUT/bench.json')); print(d['ms_per_step'], d['roofline']['kernels_ms'])"
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra-workloads > $OUT/prof.log 2>&1
