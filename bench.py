@@ -808,6 +808,7 @@ def bench_maskrcnn(args, ctx):
         for _ in range(args.steps):
             gstep()
         elapsed = sw.stop()
+        allreduce_info = measure_allreduce(args, w, grads, sw, elapsed, dist, world) if grads is not None else None
         # events inside a replayed graph cannot be read: the roofline kernel is timed by the library's launch-stream
         # events in an eager pass of the same steps right after the timed region
         _dc.lib().d2amd_timing_select(KERN.encode())
@@ -822,6 +823,7 @@ def bench_maskrcnn(args, ctx):
         for _ in range(args.steps):
             step(w, dom_timer, grads)
         elapsed = sw.stop()
+        allreduce_info = None
     ktimes = read_kernel_times([KERN])
     knames = ["pool_bwd_staged_r7", "pool_bwd_staged_r14", "pool_fwd_r7", "pool_fwd_r14", "nms_mask", "nms_reduce"]
     _dc.lib().d2amd_timing_select(",".join(knames).encode())
@@ -907,9 +909,56 @@ def bench_maskrcnn(args, ctx):
         "ops": ops,
         "ops_note": f"per-op times: separate untimed pass of {bsteps} steps with HIP events around every op",
     }
+    if allreduce_info is not None:
+        out["allreduce"] = allreduce_info
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline_maskrcnn(w)
     return out
+
+
+def measure_allreduce(args, w, grads, sw, elapsed, dist, world):
+    """N > 1 (or --force-dist): what the gradient all-reduce costs the step, separated from the data path.
+    `value` of the line includes the collective (it is part of a training step); this block adds the same step WITHOUT
+    it (`value_data_path`: the hot path's own weak scaling), the collective's exposed time inside the step, its time
+    and bandwidth alone, and a value check (every rank contributes rank + 1: the average must be (world + 1) / 2).
+    The backbone backward that would hide buckets 2 and 3 in a full model is outside the hot path: they are exposed here
+    by construction, so `value` at N > 1 is the worst case for this collective."""
+    dev = w.dev
+    rank = dist.get_rank()
+    for g in grads.grads:
+        g.fill_(float(rank + 1))
+    for i in range(grads.num_buckets):
+        grads.reduce(i)
+    grads.finish()
+    torch.cuda.synchronize()
+    ok = all(abs(float(g[0]) - (world + 1) / 2.0) < 1e-3 and abs(float(g[-1]) - (world + 1) / 2.0) < 1e-3 for g in grads.grads)
+    sw.start()
+    for _ in range(args.steps):
+        for i in range(grads.num_buckets):
+            grads.reduce(i)
+        grads.finish()
+    t_alone = sw.stop() / args.steps
+    plain = GraphedConnectedStep(w, None) if w.connected else GraphedStep(w, None)
+    for _ in range(3):
+        plain()
+    sw.start()
+    for _ in range(args.steps):
+        plain()
+    t_plain = sw.stop() / args.steps
+    t_step = elapsed / args.steps
+    wire = grads.wire_bytes()
+    XGMI_LINK_GBS, XGMI_LINKS = 153.0, 7  # MI355X_MICROARCH.md: 7 xGMI links x ~153 GB/s per GPU, point to point
+    bus = wire * 2.0 * (world - 1) / world if world > 1 else wire
+    return {"backend": dist.get_backend(), "world": world, "values_ok": bool(ok),
+            "wire_MB": round(wire / 1e6, 1), "buckets": grads.num_buckets,
+            "alone_ms": round(t_alone * 1e3, 4), "bus_GBps_alone": round(bus / 1e9 / max(t_alone, 1e-9), 1),
+            "xgmi_peak_GBps_ring_per_link": XGMI_LINK_GBS, "xgmi_peak_GBps_all_links": XGMI_LINK_GBS * XGMI_LINKS,
+            "ms_per_step_data_path": round(t_plain * 1e3, 4),
+            "value_data_path": round(world * w.n_img / t_plain, 2),
+            "exposed_ms": round(max(t_step - t_plain, 0.0) * 1e3, 4),
+            "note": "value = the step WITH the collective; value_data_path = the same step without it (the hot path's own "
+                    "scaling); exposed_ms = what the collective adds to the step; bus_GBps_alone = 2 (p - 1) / p x wire "
+                    "bytes / its time alone (p = 1: wire bytes / time: RCCL's local copy)"}
 
 
 def make_gradient_buckets(args, dev, dist, world):

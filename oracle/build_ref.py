@@ -24,7 +24,40 @@ SOURCES = [
 ]
 
 
+# The reference's own PYTHON modules that tests run (the callers of the hot path: SURVEY 8 row g1 -- poolers.py,
+# proposal_utils.py, mask_head.py, mask_ops.py, structures/masks.py and what they need).  Byte-compiled where they lie
+# into oracle/_ref/py/*.pyc -- a build product like libd2ref.so, git-ignored, never the source -- so that the GPU box,
+# which has no /root/reference, can load them (oracle/ref.py: _load_by_path falls back to the .pyc).
+PY_MODULES = [
+    "detectron2/layers/mask_ops.py", "detectron2/structures/boxes.py", "detectron2/structures/instances.py",
+    "detectron2/structures/masks.py", "detectron2/modeling/matcher.py", "detectron2/modeling/sampling.py",
+    "detectron2/modeling/box_regression.py", "detectron2/modeling/poolers.py",
+    "detectron2/modeling/proposal_generator/proposal_utils.py", "detectron2/modeling/roi_heads/mask_head.py",
+    "detectron2/modeling/meta_arch/dense_detector.py",
+]
+PY_OUT = os.path.join(OUT_DIR, "py")
+
+
+def pyc_path(relpath):
+    return os.path.join(PY_OUT, relpath.replace("/", "__") + "c")
+
+
+def build_py(force=False):
+    """-> True if every module's bytecode is in place."""
+    if not os.path.isdir(os.path.join(REF, "detectron2")):
+        return all(os.path.exists(pyc_path(m)) for m in PY_MODULES)
+    import py_compile
+
+    os.makedirs(PY_OUT, exist_ok=True)
+    for m in PY_MODULES:
+        src, dst = os.path.join(REF, m), pyc_path(m)
+        if force or not os.path.exists(dst) or os.path.getmtime(dst) < os.path.getmtime(src):
+            py_compile.compile(src, cfile=dst, doraise=True, invalidation_mode=py_compile.PycInvalidationMode.UNCHECKED_HASH)
+    return True
+
+
 def build(force=False, verbose=True):
+    build_py(force)
     if not os.path.isdir(CSRC):
         return False
     if os.path.exists(OUT) and not force:

@@ -5,6 +5,7 @@
 * ``py_mask_ops()`` / ``py_boxes()``: the reference's own Python modules loaded by file path
   from /root/reference (only exists in the build container; used to generate tests/golden/).
 """
+import importlib.machinery
 import importlib.util
 import os
 import sys
@@ -22,6 +23,14 @@ def have_compiled():
 
 def have_tree():
     return os.path.isdir(os.path.join(REF_ROOT, "detectron2", "layers"))
+
+
+def have_py():
+    """The reference's Python modules are loadable: from the tree, or from the bytecode oracle/build_ref.py staged in
+    oracle/_ref/py/ (what the GPU box has)."""
+    from . import build_ref
+
+    return have_tree() or all(os.path.exists(build_ref.pyc_path(m)) for m in build_ref.PY_MODULES)
 
 
 def compiled():
@@ -42,7 +51,15 @@ def compiled():
 
 def _load_by_path(name, relpath):
     path = os.path.join(REF_ROOT, relpath)
-    spec = importlib.util.spec_from_file_location(name, path)
+    if os.path.exists(path):
+        spec = importlib.util.spec_from_file_location(name, path)
+    else:  # no tree here (the GPU box): the bytecode build_ref.build_py() compiled from the same file
+        from . import build_ref
+
+        pyc = build_ref.pyc_path(relpath)
+        if not os.path.exists(pyc):
+            raise FileNotFoundError(f"reference module {relpath}: neither {path} nor {pyc}")
+        spec = importlib.util.spec_from_loader(name, importlib.machinery.SourcelessFileLoader(name, pyc))
     mod = importlib.util.module_from_spec(spec)
     sys.modules[name] = mod
     spec.loader.exec_module(mod)
@@ -225,3 +242,72 @@ def py_dense_detector():
                                                     "detectron2/modeling/meta_arch/dense_detector.py"))
     sys.modules.pop("detectron2.modeling.meta_arch.dense_detector", None)
     return mod, br.Box2BoxTransform, structs.Boxes, structs.Instances
+
+
+def py_callers(layers_impl):
+    """the reference's OWN callers of the hot path -- modeling/poolers.py (ROIPooler),
+    proposal_generator/proposal_utils.py (find_top_rpn_proposals), roi_heads/mask_head.py (mask_rcnn_loss /
+    mask_rcnn_inference), structures/masks.py (BitMasks) + layers/mask_ops.py -- loaded unchanged, with the names they
+    import from `detectron2.layers` resolved by `layers_impl` (the replacement: detectron2_amd.layers).  The pure-torch
+    helpers of layers/wrappers.py (cat, nonzero_tuple, shapes_to_tensor, move_device_like) are restated here; Boxes /
+    Instances are the reference's own classes (pure torch).  -> a namespace of the loaded classes / functions."""
+    import torch
+
+    boxes_mod = py_boxes()
+    inst_mod = _load_by_path("_d2ref_instances", "detectron2/structures/instances.py")
+    names = ("detectron2", "detectron2.config", "detectron2.layers", "detectron2.layers.wrappers",
+             "detectron2.layers.roi_align", "detectron2.structures", "detectron2.structures.boxes", "detectron2.utils",
+             "detectron2.utils.events", "detectron2.utils.registry", "detectron2.utils.tracing", "detectron2.utils.memory",
+             "torchvision", "torchvision.ops", "pycocotools", "pycocotools.mask", "fvcore", "fvcore.nn",
+             "fvcore.nn.weight_init")
+    m = {n: types.ModuleType(n) for n in names}
+    for n in ("detectron2", "detectron2.layers", "detectron2.structures", "detectron2.utils", "torchvision", "pycocotools",
+              "fvcore", "fvcore.nn"):
+        m[n].__path__ = []
+    L = m["detectron2.layers"]
+    for k in ("ROIAlign", "ROIAlignRotated", "batched_nms", "nms", "paste_masks_in_image"):
+        setattr(L, k, getattr(layers_impl, k))
+    L.cat = lambda ts, dim=0: ts[0] if len(ts) == 1 else torch.cat(ts, dim)          # wrappers.py:65-72
+    L.nonzero_tuple = lambda x: (x.unsqueeze(0) if x.dim() == 0 else x).nonzero().unbind(1)  # :158-169
+    L.shapes_to_tensor = lambda x, device=None: torch.as_tensor(x, device=device)   # :20-41 (eager branch)
+    L.move_device_like = lambda src, dst: src.to(dst.device)                          # :172-177
+    L.Conv2d, L.ConvTranspose2d, L.ShapeSpec = torch.nn.Conv2d, torch.nn.ConvTranspose2d, object
+    L.get_norm = lambda *a, **k: None
+    m["detectron2.layers.wrappers"].move_device_like = L.move_device_like
+    m["detectron2.layers.roi_align"].ROIAlign = layers_impl.ROIAlign
+    m["detectron2.config"].configurable = lambda f=None, **k: f
+    S = m["detectron2.structures"]
+    S.Boxes, S.Instances = boxes_mod.Boxes, inst_mod.Instances
+    m["detectron2.structures.boxes"].Boxes = boxes_mod.Boxes
+    rec = _EventRecorder()
+    m["detectron2.utils.events"].get_event_storage = lambda: rec
+
+    class Registry:
+        def __init__(self, name):
+            self.name = name
+
+        def register(self, obj=None):
+            return obj if obj is not None else (lambda o: o)
+
+    m["detectron2.utils.registry"].Registry = Registry
+    m["detectron2.utils.tracing"].assert_fx_safe = lambda cond, msg: cond
+    m["detectron2.utils.tracing"].is_fx_tracing = lambda: False
+    m["detectron2.utils.memory"].retry_if_cuda_oom = lambda f: f
+    m["torchvision.ops"].RoIPool = type("RoIPool", (torch.nn.Module,), {})
+    for a, b in (("detectron2", "layers"), ("detectron2", "structures"), ("detectron2", "utils"), ("detectron2", "config"),
+                 ("torchvision", "ops"), ("pycocotools", "mask"), ("fvcore", "nn")):
+        setattr(m[a], b, m[a + "." + b])
+    m["fvcore.nn"].weight_init = m["fvcore.nn.weight_init"]
+
+    def load():
+        ns = types.SimpleNamespace()
+        ns.poolers = _load_by_path("_d2ref_poolers", "detectron2/modeling/poolers.py")
+        ns.proposal_utils = _load_by_path("_d2ref_proposal_utils_g1", "detectron2/modeling/proposal_generator/proposal_utils.py")
+        ns.mask_head = _load_by_path("_d2ref_mask_head_g1", "detectron2/modeling/roi_heads/mask_head.py")
+        ns.mask_ops = _load_by_path("_d2ref_mask_ops_g1", "detectron2/layers/mask_ops.py")
+        ns.masks = _load_by_path("detectron2.structures.masks", "detectron2/structures/masks.py")  # (relative import)
+        sys.modules.pop("detectron2.structures.masks", None)
+        ns.Boxes, ns.Instances, ns.events = boxes_mod.Boxes, inst_mod.Instances, rec
+        return ns
+
+    return _with_stubs(m, load)
