@@ -89,7 +89,9 @@ def test_polygon_masks_container_contract():
     assert len(pm[torch.tensor([True, False, True, False, False, True])]) == 3
     assert pm.nonempty().tolist() == [True] * 5 + [False]
     bb = pm.get_bounding_boxes().tensor
-    assert bb.shape == (6, 4) and torch.all(bb[5] == 0) and torch.all(bb[:5, 2:] > bb[:5, :2])
+    # (an instance without polygons: [inf, inf, 0, 0], like the reference's masks.py:327-336)
+    assert bb.shape == (6, 4) and bb[5].tolist() == [float("inf"), float("inf"), 0.0, 0.0]
+    assert torch.all(bb[:5, 2:] > bb[:5, :2])
     assert repr(pm) == "PolygonMasks(num_instances=6)"
     empty = PolygonMasks([]).crop_and_resize(torch.zeros(0, 4, device=DEV), 28)
     assert tuple(empty.shape) == (0, 28, 28) and empty.dtype == torch.bool

@@ -43,9 +43,9 @@ def test_reference_roipooler_runs_on_this_roialign_and_equals_the_fused_pooler(R
 
     g = torch.Generator().manual_seed(3)
     scales = [1 / 4, 1 / 8, 1 / 16, 1 / 32]
-    feats = [torch.randn(2, 32, 256 // s, 320 // s, generator=g).to(dtype).to(DEV).contiguous(
+    feats = [torch.randn(2, 32, 640 // s, 800 // s, generator=g).to(dtype).to(DEV).contiguous(
         memory_format=torch.channels_last) for s in (4, 8, 16, 32)]
-    bl = [_boxes(g, 150, 320, 256).to(DEV) for _ in range(2)]
+    bl = [_boxes(g, 150, 800, 640, 8, 640).to(DEV) for _ in range(2)]
     ref_pooler = R.poolers.ROIPooler(out, scales, 0, "ROIAlignV2")
     own_pooler = ROIPooler(out, scales, 0, "ROIAlignV2")
     xr = [f.clone().requires_grad_(True) for f in feats]
