@@ -282,11 +282,28 @@ def test_dcn_full_size_per_element_bounds(stage, C, H, W):
     ye = y.detach().numpy()
     ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(ye), 1e-30))) - 7)  # bf16: 8 significant bits
     bound = 2 * ulp + 8 * 2.0 ** -9 * np.sqrt(s2.numpy())
+    bad = {}
     err = np.abs(got["out"] - ye)
-    assert (err <= bound).all(), (stage, "out", float((err / bound).max()), int((err > bound).sum()))
+    if not (err <= bound).all():
+        bad["out"] = (float((err / bound).max()), int((err > bound).sum()))
+    # d(offset) is one-sided where a sampling coordinate is EXACTLY an integer (bf16 offsets make that common) or on the
+    # validity border: the reference's coordinate weights (deform_conv_cuda_kernel.cu:785-840, what the C oracle and the
+    # kernels follow) and grid_sample's autograd pick different sides there; those elements are left to the C-oracle
+    # tests above
+    hh = torch.arange(H).view(1, 1, H, 1) - 1.0
+    ww = torch.arange(W).view(1, 1, 1, W) - 1.0
+    of = off.float().view(B, 9, 2, H, W)
+    ti = torch.arange(9).view(1, 9, 1, 1)
+    ph, pw = hh + (ti // 3) + of[:, :, 0], ww + (ti % 3) + of[:, :, 1]
+    regular = ((ph != ph.floor()) & (pw != pw.floor())).view(B, 9, 1, H, W).expand(B, 9, 2, H, W).reshape(B, 18, H, W).numpy()
     for k, ref_t in (("grad_input", xr.grad), ("grad_offset", orr.grad), ("grad_mask", mr.grad), ("grad_weight", wr.grad),
                      ("grad_bias", br.grad)):
         e = ref_t.numpy()
         b2 = 2.0 ** -7 * np.abs(e) + 2.0 ** -6 * np.sqrt((e.astype(np.float64) ** 2).mean())
         d = np.abs(got[k] - e)
-        assert (d <= b2).all(), (stage, k, float((d / b2).max()), int((d > b2).sum()))
+        ok = d <= b2
+        if k == "grad_offset":
+            ok = ok | ~regular
+        if not ok.all():
+            bad[k] = (float((d / b2)[~ok].max()), int((~ok).sum()), int(ok.size))
+    assert not bad, (stage, bad)
