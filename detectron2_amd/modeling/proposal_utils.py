@@ -91,18 +91,13 @@ def rpn_select_proposals(anchors: List[torch.Tensor], pred_objectness_logits: Li
     with _C.on_device(dev):
         ws_bytes = L.d2amd_rpn_select_workspace_bytes(n, atot)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        if pre_nms_topk <= 65536:
-            _C.check(L.d2amd_rpn_select_proposals_levels(parr(logits), parr(deltas), parr(anc), n, lv, nl, hw,
-                                                         int(pre_nms_topk), float(min_box_size), wts,
-                                                         float(scale_clamp), _C.ptr(boxes), _C.ptr(scores),
-                                                         _C.ptr(valid), _C.ptr(level_ids), _C.ptr(flags), _C.ptr(ws),
-                                                         ws_bytes, _C.stream()))
-        else:  # beyond the radix select's k: the full-sort path works on the concatenated arrays
-            cl, cd, ca = torch.cat(logits, dim=1), torch.cat(deltas, dim=1), torch.cat(anc, dim=0)
-            _C.check(L.d2amd_rpn_select_proposals(_C.ptr(cl), _C.ptr(cd), _C.ptr(ca), n, atot, lv, nl, hw,
-                                                  int(pre_nms_topk), float(min_box_size), wts, float(scale_clamp),
-                                                  _C.ptr(boxes), _C.ptr(scores), _C.ptr(valid), _C.ptr(level_ids),
-                                                  _C.ptr(flags), _C.ptr(ws), ws_bytes, _C.stream()))
+        # (pre_nms_topk > 65,536 per level: D2AMD_EUNSUPPORTED -> RuntimeError; the reference's configurations use
+        # 1,000 .. 12,000)
+        _C.check(L.d2amd_rpn_select_proposals_levels(parr(logits), parr(deltas), parr(anc), n, lv, nl, hw,
+                                                     int(pre_nms_topk), float(min_box_size), wts,
+                                                     float(scale_clamp), _C.ptr(boxes), _C.ptr(scores),
+                                                     _C.ptr(valid), _C.ptr(level_ids), _C.ptr(flags), _C.ptr(ws),
+                                                     ws_bytes, _C.stream()))
     return boxes, scores, valid, level_ids, flags
 
 

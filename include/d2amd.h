@@ -270,7 +270,7 @@ int d2amd_match_quality_matrix(const float* quality, int M, int N, const float* 
  *   boxes [N,Ktot,4], scores [N,Ktot], valid [N,Ktot] uint8 (finite and both sides > min_box_size after the
  *   clip; invalid rows hold a zero box and score -inf), level [Ktot] int64, flags [1] int32 (bit 0: a
  *   non-finite box or score was seen -- the reference raises FloatingPointError in training).
- * The selection is a segmented radix select (csrc/topk.hip) for pre_nms_topk <= 65536, a full radix sort above.
+ * The selection is a segmented radix select (csrc/topk.hip); pre_nms_topk > 65536 per level: D2AMD_EUNSUPPORTED.
  * Nothing synchronises with the host. */
 #define D2AMD_RPN_MAX_LEVELS 8
 size_t d2amd_rpn_select_workspace_bytes(int N, int Atot);
