@@ -256,6 +256,7 @@ class Workload:
         # 512 rows per image (box head), of which the first 128 feed the mask head (positives come first)
         self.gt_classes = [torch.randint(0, 80, (N_GT,), generator=g).to(dev) for g in gens]
         self.connected = False
+        self.loss_grad = torch.ones((), device=dev)  # d(total loss) / d(mask loss): passed in, not filled per step
 
     # algorithmic (compulsory) bytes per op, SURVEY.md 8(d)
     def alg_bytes(self):
@@ -457,7 +458,8 @@ def connected_forward(w, run=None, rpn_keys=None, roi_keys=None, sync=False):
             return anchor_labels(w, rpn_keys)
 
         done = find_top_rpn_proposals_fused(w.anchor_levels, w.rpn_logits, w.rpn_deltas, w.image_sizes, 0.7, 2000, 1000,
-                                            0.0, True, defer=True, beside_nms=side, join_beside=False)
+                                            0.0, True, defer=True, beside_nms=side, join_beside=False,
+                                            host_result=sync)
         anchors_out = done.beside
         if keys_ready is not None:
             torch.cuda.current_stream().wait_event(keys_ready)
@@ -515,7 +517,7 @@ def connected_step(w, t=None, grads=None):
     if grads is not None:
         run("allreduce_issue", lambda: [grads.reduce(i) for i in range(n_early)])
     run("backward", lambda: torch.autograd.backward([out["box_features"], out["mask_features"], out["loss"]],
-                                                    [w.gbox, w.gmask, None]))
+                                                    [w.gbox, w.gmask, w.loss_grad]))
     if grads is not None:
         run("allreduce_issue", lambda: [grads.reduce(i) for i in range(n_early, grads.num_buckets)])
         run("allreduce_wait", grads.finish)
@@ -543,7 +545,7 @@ class GraphedConnectedStep:
                 f.grad = None
             w.mask_logits.grad = None
             torch.autograd.backward([self.out["box_features"], self.out["mask_features"], self.out["loss"]],
-                                    [w.gbox, w.gmask, None])
+                                    [w.gbox, w.gmask, w.loss_grad])
 
         def whole():
             loss = fwd()

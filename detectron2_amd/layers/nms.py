@@ -41,7 +41,7 @@ def batched_nms_rotated(boxes: torch.Tensor, scores: torch.Tensor, idxs: torch.T
 
 
 def batched_nms_images(inputs, iou_threshold: float, defer: bool = False, runs=None, gather=None,
-                       result_buffer=None):
+                       result_buffer=None, host_mirror: bool = True):
     """`batched_nms` of every image of a batch: inputs = [(boxes [n,4], scores [n], idxs [n]), ...] ->
     list of kept-index tensors (each as `batched_nms` would return).  Replaces the per-image loop +
     per-image host sync of find_top_rpn_proposals (proposal_generator/proposal_utils.py:118-135) and
@@ -56,8 +56,9 @@ def batched_nms_images(inputs, iou_threshold: float, defer: bool = False, runs=N
     the kept indices are (no `x[keep]` launches after the sync): `.gathered` of the returned callable.
     result_buffer: an int32 device tensor of 8 * len(inputs) + k words owned by the caller, whose last k words its own
     kernels have written (status flags): results and those words reach the host in one transfer; the callable then
-    always returns (kept, finite counts, the k words)."""
+    always returns (kept, finite counts, the k words).  host_mirror=False: no transfer is enqueued (the caller reads the
+    buffer on the device; calling the callable then costs a synchronous read)."""
     for b, _s, _i in inputs:
         assert b.shape[-1] == 4
     return nms_images([(b.float(), s, i) for b, s, i in inputs], iou_threshold, False, defer, runs, gather,
-                      result_buffer)
+                      result_buffer, host_mirror)

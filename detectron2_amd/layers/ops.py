@@ -160,7 +160,8 @@ def _pinned_int32(n):
     return t
 
 
-def _nms_images_batched(inputs, iou_threshold, rotated, defer=False, runs=None, gather=None, result_buffer=None):
+def _nms_images_batched(inputs, iou_threshold, rotated, defer=False, runs=None, gather=None, result_buffer=None,
+                        host_mirror=True):
     """All images through d2amd_nms_batched: one launch per pipeline stage for the whole batch, one
     [count, 2] result tensor, one host sync."""
     ct = _C.ctypes
@@ -222,7 +223,8 @@ def _nms_images_batched(inputs, iou_threshold, rotated, defer=False, runs=None, 
     # captured graph: a memcpy node); the host then only waits for the stream -- a blocking .tolist() is a
     # synchronous hipMemcpy of its own after that wait
     mirror = None
-    if result_buffer is not None:
+    if result_buffer is not None and host_mirror:  # (host_mirror=False: the caller reads the counts on the DEVICE; a
+        # finish() call still works, through a synchronous read)
         mirror = _pinned_int32(result_buffer.numel())
         mirror.copy_(result_buffer, non_blocking=True)
         mirror_stream = torch.cuda.current_stream(dev)
@@ -230,7 +232,11 @@ def _nms_images_batched(inputs, iou_threshold, rotated, defer=False, runs=None, 
     def finish(with_finite=False, extra=None):
         """with_finite: also return, per image, how many kept boxes have a score > -inf; extra: a device tensor of
         int64 values read in the same host transfer (returned as a list)."""
-        if result_buffer is not None:  # (values are < 2^31: the low words; the tail = the caller's status words)
+        if result_buffer is not None and mirror is None:
+            assert extra is None
+            v32 = result_buffer.tolist()
+            vals = v32[0:8 * cnt:2] + v32[8 * cnt:]
+        elif result_buffer is not None:  # (values are < 2^31: the low words; the tail = the caller's status words)
             assert extra is None
             # the only host sync (`hold` keeps inputs / workspaces alive until here): the stream the copy was enqueued
             # on -- and the current one: a replayed graph runs where it is launched, not where it was captured
@@ -262,7 +268,8 @@ def _nms_images_batched(inputs, iou_threshold, rotated, defer=False, runs=None, 
     return finish if defer else finish()
 
 
-def nms_images(inputs, iou_threshold, rotated=False, defer=False, runs=None, gather=None, result_buffer=None):
+def nms_images(inputs, iou_threshold, rotated=False, defer=False, runs=None, gather=None, result_buffer=None,
+               host_mirror=True):
     """NMS of every image of a batch in one call: `inputs` = [(boxes, scores, idxs | None), ...].
     runs = (run_offsets, runs_are_categories[, num_categories]), the same for every image: the rows are pre-sorted runs (per-level
     top-k lists; d2amd_nms_runs) -- with runs_are_categories the idxs of `inputs` are ignored (pass None).
@@ -282,7 +289,7 @@ def nms_images(inputs, iou_threshold, rotated=False, defer=False, runs=None, gat
         _BATCH_MAX = int(_C.lib().d2amd_nms_batched_max_boxes())
     dev = inputs[0][0].device
     if all(b.shape[0] <= _BATCH_MAX and b.device == dev for b, _s, _i in inputs):
-        return _nms_images_batched(inputs, iou_threshold, rotated, defer, runs, gather, result_buffer)
+        return _nms_images_batched(inputs, iou_threshold, rotated, defer, runs, gather, result_buffer, host_mirror)
     extra_tail = None if result_buffer is None else result_buffer[8 * len(inputs):]  # (large inputs: separate transfers)
     cur = torch.cuda.current_stream(dev)
     pool = _SIDE_STREAMS.setdefault(dev.index, [])

@@ -34,11 +34,14 @@ class _MaskLoss(torch.autograd.Function):
                                                     ctypes.c_size_t(ws_bytes), _C.stream()))
         ctx.save_for_backward(x, gt_classes, gt_masks)
         ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)  # (no zero-fill launch for the statistics' "gradient")
         return loss, stats
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad_loss, _grad_stats):
+        if grad_loss is None:
+            return None, None, None
         x, gt_classes, gt_masks = ctx.saved_tensors
         b, c, h, w = x.shape
         g = grad_loss.detach().to(dtype=torch.float32).contiguous()
@@ -50,9 +53,8 @@ class _MaskLoss(torch.autograd.Function):
 
 
 class _MaskLossMasked(torch.autograd.Function):
-    """_MaskLoss over the rows whose class lies in [0, C) (d2amd_mask_rcnn_loss_forward_masked / _backward_masked).
-    NOT YET RUN ON A GPU: written after round 2's GPU budget was spent; a separate Function so that the validated one
-    above is untouched."""
+    """_MaskLoss over the rows whose class lies in [0, C) (d2amd_mask_rcnn_loss_forward_masked / _backward_masked):
+    the background / padding rows of the fixed-size lists of `label_and_sample_proposals_fixed` do not count."""
 
     @staticmethod
     def forward(ctx, logits, gt_classes, gt_masks):
@@ -70,11 +72,14 @@ class _MaskLossMasked(torch.autograd.Function):
         ctx.save_for_backward(x, gt_classes, gt_masks)
         ctx.rows = stats.detach()[5:].clone()  # the row count stays on the device; the backward reads it there
         ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)
         return loss, stats
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad_loss, _grad_stats):
+        if grad_loss is None:
+            return None, None, None
         x, gt_classes, gt_masks = ctx.saved_tensors
         b, c, h, w = x.shape
         g = grad_loss.detach().to(dtype=torch.float32).contiguous()
@@ -91,7 +96,7 @@ def mask_rcnn_loss_from_targets(pred_mask_logits: torch.Tensor, gt_classes, gt_m
     """Fused core of `mask_rcnn_loss`: (B, C, M, M) logits, (B,) int64 gt classes (ignored / may be None when
     C == 1), (B, M, M) bool targets -> (loss fp32 scalar, stats int64[5] on the device:
     #incorrect, #positive, #false positive, #false negative, #rows with a class outside [0, C)).
-    ignore_invalid_rows (NOT YET RUN ON A GPU, see include/d2amd.h): rows with a class outside [0, C) -- background and
+    ignore_invalid_rows: rows with a class outside [0, C) -- background and
     padding rows of `label_and_sample_proposals_fixed` -- do not count (mean over the others, zero gradient);
     stats int64[6]: [4] = ignored rows, [5] = rows that count."""
     _C.require_gpu(pred_mask_logits, gt_masks, op="mask_rcnn_loss")

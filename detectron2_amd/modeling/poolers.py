@@ -223,6 +223,7 @@ import os as _os
 # 0.534 -- on one stream the small binning kernels cost the same wherever they sit, and the writing variant adds a
 # zero-fill launch; the early binning only pays for a caller that puts the forward on its own stream.  Default: none.
 _PREBIN_MODE = _os.environ.get("D2AMD_PREBIN", "none")
+_SIDE_BINNING = _os.environ.get("D2AMD_SIDE_BINNING", "1") != "0"  # A/B switch: the later gathers' binning beside the first
 
 
 def _PREBIN(head):
@@ -352,9 +353,37 @@ class _FusedROIPool(Function):
             grads = [torch.empty((n, c, h, w), dtype=g0.dtype, device=dev, memory_format=torch.channels_last)
                      for (h, w) in hw]
         with _C.on_device(dev):
+            # The binning of the chain's LATER gathers (records, per-tile lists, queues: ~20 us of small launches each,
+            # a function of the ROIs alone) runs on a side stream beside the first gather instead of between the gathers.
+            if len(works) > 1 and grads is not None and _SIDE_BINNING:
+                from ..streams import _streams
+
+                cur = torch.cuda.current_stream(dev)
+                side = _streams(dev, 1, late=True)[0]
+                forked = False
+                for j in range(1, len(works)):
+                    g, r, wcfg, binned = works[j]
+                    if binned is not None or r.shape[0] == 0:
+                        continue
+                    if not forked:
+                        side.wait_stream(cur)
+                        forked = True
+                    p = _params(wcfg, (n, c), hw, _C.dtype_code(g), _C.NHWC)
+                    with torch.cuda.stream(side):
+                        ws_bytes = L.d2amd_roi_pooler_backward_workspace_bytes(ctypes.byref(p), r.shape[0])
+                        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+                        rc = L.d2amd_roi_pooler_backward_phase(ctypes.byref(p), _C.ptr(g), _C.ptr(r), _ptr_array(grads),
+                                                               r.shape[0], _C.ptr(ws), ws_bytes, 1, _C.stream())
+                    if rc == 0:
+                        works[j] = (g, r, wcfg, (ws, ws_bytes, side))
+                    elif rc != _C.EUNSUPPORTED:
+                        _C.check(rc)
             for j, (g, r, wcfg, binned) in enumerate(works):
                 k = r.shape[0]
                 p = _params(wcfg, (n, c), hw, _C.dtype_code(g), _C.NHWC)
+                if binned is not None and len(binned) == 3:  # binned on the side stream above: join it here
+                    torch.cuda.current_stream(dev).wait_stream(binned[2])
+                    binned = binned[:2]
                 if plain_first and j == 0:
                     if binned is not None:  # binned beside its forward: zero fill of the untouched tiles + gather
                         ws, ws_bytes = binned

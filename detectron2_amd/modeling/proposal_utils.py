@@ -104,7 +104,8 @@ def rpn_select_proposals(anchors: List[torch.Tensor], pred_objectness_logits: Li
 def find_top_rpn_proposals_fused(anchors, pred_objectness_logits, pred_anchor_deltas, image_sizes, nms_thresh: float,
                                  pre_nms_topk: int, post_nms_topk: int, min_box_size: float, training: bool,
                                  weights=(1.0, 1.0, 1.0, 1.0), scale_clamp: float = _DEFAULT_SCALE_CLAMP,
-                                 defer: bool = False, beside_nms=None, join_beside: bool = True):
+                                 defer: bool = False, beside_nms=None, join_beside: bool = True,
+                                 host_result: bool = True):
     """-> list of N `Proposals` (proposal_boxes: Boxes, objectness_logits), sorted by objectness.
     ONE host sync per batch: the kept counts, the number of kept boxes that are valid proposals (invalid rows are
     parked at score -inf and sort last: the NMS reports how many kept boxes have a finite score) and the non-finite
@@ -116,6 +117,8 @@ def find_top_rpn_proposals_fused(anchors, pred_objectness_logits, pred_anchor_de
     ignored without defer).  The selection kernels are latency-bound chains of few workgroups that slow down when
     chip-filling kernels run next to them (fused select 27 -> 35 us, decode 5 -> 13 us beside the anchor matcher); the
     NMS reduction (10 workgroups walking their lists) does not.  Captured RPN half of bench.py: 159.5 -> 156.5 us.
+    host_result=False: no device-to-host transfer of the counts is enqueued (a step that reads them on the device:
+    `.device` of the returned callable).
     join_beside=False (with defer): the side branch is NOT joined here -- `.join_beside()` of the returned callable does
     it, whenever its results are needed (bench.py's connected step: at the end of the forward; the anchor labelling +
     sampling take longer than the NMS, and nothing before the losses reads them)."""
@@ -134,7 +137,7 @@ def find_top_rpn_proposals_fused(anchors, pred_objectness_logits, pred_anchor_de
     def nms():
         return batched_nms_images([(boxes[i], scores[i], None) for i in range(n)], nms_thresh, defer=True,
                                   runs=(run_offsets, True), gather=[(boxes[i], scores[i]) for i in range(n)],
-                                  result_buffer=res)
+                                  result_buffer=res, host_mirror=host_result)
 
     beside = None
     if beside_nms is not None:
