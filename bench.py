@@ -475,19 +475,17 @@ def connected_forward(w, run=None, rpn_keys=None, roi_keys=None, sync=False):
         pb = [p.proposal_boxes.tensor for p in props]
         keys = [torch.cat([roi_keys[i][:pb[i].shape[0]], roi_keys[i][1000:]]) for i in range(n)]
         samp = label_and_sample_proposals_fixed(pb, w.gt, w.gt_classes, keys=keys, batch_size_per_image=ROI_BATCH,
-                                                positive_fraction=ROI_POS_FRACTION, num_classes=80)
+                                                positive_fraction=ROI_POS_FRACTION, num_classes=80, head_rows=MASK_ROWS)
     else:
         dp = done.device
         samp = run("label_and_sample_proposals", lambda: label_and_sample_proposals_fixed(
             dp.boxes, w.gt, w.gt_classes, limits=dp.limits, limit_stride=2, keys=roi_keys,
-            batch_size_per_image=ROI_BATCH, positive_fraction=ROI_POS_FRACTION, num_classes=80))
-    box_lists = [Boxes(samp["boxes"][i]) for i in range(n)]
+            batch_size_per_image=ROI_BATCH, positive_fraction=ROI_POS_FRACTION, num_classes=80, head_rows=MASK_ROWS))
     mask_boxes = [samp["boxes"][i, :MASK_ROWS] for i in range(n)]
-    mask_lists = [Boxes(b) for b in mask_boxes]
 
-    def poolers():
-        return (run("roi_align_box_fwd", lambda: w.box_pooler(w.feats, box_lists)),
-                run("roi_align_mask_fwd", lambda: w.mask_pooler(w.feats, mask_lists)))
+    def poolers():  # (the sampler wrote its rows in pooler format: no conversion launch in front of either pooler)
+        return (run("roi_align_box_fwd", lambda: w.box_pooler.pool_rois(w.feats, samp["rois"])),
+                run("roi_align_mask_fwd", lambda: w.mask_pooler.pool_rois(w.feats, samp["head_rois"])))
 
     def targets_and_loss():
         idx = [samp["gt_index"][i, :MASK_ROWS].contiguous() for i in range(n)]

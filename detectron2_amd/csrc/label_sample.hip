@@ -53,7 +53,24 @@ struct LsBatch {
   float4* boxes;
   int64_t *classes, *gt_index, *index;
   int* counts;
+  float *rois, *head_rois;  // optional: the rows in pooler format (image, x1, y1, x2, y2); the first head_rows of each image
+  int head_rows, image0;    // image0: batch index of this launch's first image
 };
+
+// row `slot` of image `image` in pooler format (convert_boxes_to_pooler_format, poolers.py:62-104): what the box pooler
+// (all rows) and the mask pooler (the first head_rows rows of every image: the positives come first) take as they are --
+// no conversion launch between the sampler and the poolers
+__device__ __forceinline__ void ls_write_rois(const LsBatch& B, int image, int slot, float4 b) {
+  const float fi = (float)(B.image0 + image);
+  if (B.rois) {
+    float* r = B.rois + ((long)(B.image0 + image) * B.S + slot) * 5;
+    r[0] = fi; r[1] = b.x; r[2] = b.y; r[3] = b.z; r[4] = b.w;
+  }
+  if (B.head_rois && slot < B.head_rows) {
+    float* r = B.head_rois + ((long)(B.image0 + image) * B.head_rows + slot) * 5;
+    r[0] = fi; r[1] = b.x; r[2] = b.y; r[3] = b.z; r[4] = b.w;
+  }
+}
 
 __global__ __launch_bounds__(LS_THREADS) void label_sample_kernel(const LsBatch B) {
   __shared__ float s_key[LS_MAX];       // key of candidate c
@@ -199,12 +216,14 @@ __global__ __launch_bounds__(LS_THREADS) void label_sample_kernel(const LsBatch 
     }
     if (rank >= want) continue;
     const int slot = (pos ? 0 : num_pos) + rank;
+    ls_write_rois(B, image, slot, box[k]);
     ob[slot] = box[k];
     oc[slot] = cls[k];
     og[slot] = besti[k];
     oi[slot] = c;
   }
   for (int t = num_pos + num_neg + tid; t < B.S; t += LS_THREADS) {  // padding
+    ls_write_rois(B, image, t, make_float4(0, 0, 0, 0));
     ob[t] = make_float4(0, 0, 0, 0);
     oc[t] = -1;
     og[t] = 0;
@@ -226,7 +245,8 @@ extern "C" int d2amd_label_and_sample_proposals(const d2amd_sample_image* images
                                                 const int8_t* labels, int T, int batch_size_per_image,
                                                 int max_positives, int64_t num_classes, int append_gt,
                                                 float* boxes_out, int64_t* classes_out, int64_t* gt_index_out,
-                                                int64_t* index_out, int32_t* counts_out, void* stream) {
+                                                int64_t* index_out, int32_t* counts_out, float* rois_out,
+                                                float* head_rois_out, int head_rows, void* stream) {
   D2_CHECK_ARG(count >= 0 && (count == 0 || images != nullptr), "label_and_sample: bad image list");
   D2_CHECK_ARG(T >= 0 && T <= D2AMD_MATCHER_MAX_THRESHOLDS && labels != nullptr && (T == 0 || thresholds != nullptr),
                "label_and_sample: %d thresholds (max %d)", T, D2AMD_MATCHER_MAX_THRESHOLDS);
@@ -251,6 +271,10 @@ extern "C" int d2amd_label_and_sample_proposals(const d2amd_sample_image* images
   B.pos_max = max_positives;  // the caller's int(num_samples * positive_fraction), sampling.py:42
   B.append_gt = append_gt != 0;
   B.num_classes = num_classes;
+  D2_CHECK_ARG(head_rows >= 0 && head_rows <= batch_size_per_image, "label_and_sample: bad head_rows");
+  B.rois = rois_out;
+  B.head_rois = head_rows > 0 ? head_rois_out : nullptr;
+  B.head_rows = head_rows;
   for (int i0 = 0; i0 < count; i0 += LS_MAX_IMAGES) {
     const int c = count - i0 < LS_MAX_IMAGES ? count - i0 : LS_MAX_IMAGES;
     for (int i = 0; i < c; i++) {
@@ -282,6 +306,7 @@ extern "C" int d2amd_label_and_sample_proposals(const d2amd_sample_image* images
     B.gt_index = gt_index_out + (long)i0 * B.S;
     B.index = index_out + (long)i0 * B.S;
     B.counts = counts_out + 2 * i0;
+    B.image0 = i0;
     hipLaunchKernelGGL(label_sample_kernel, dim3(c), dim3(LS_THREADS), 0, (hipStream_t)stream, B);
     D2_LAUNCH_OK();
   }

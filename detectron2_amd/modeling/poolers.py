@@ -223,6 +223,11 @@ import os as _os
 # 0.534 -- on one stream the small binning kernels cost the same wherever they sit, and the writing variant adds a
 # zero-fill launch; the early binning only pays for a caller that puts the forward on its own stream.  Default: none.
 _PREBIN_MODE = _os.environ.get("D2AMD_PREBIN", "none")
+# The forward can pool the ROIs in a spatial PROCESSING ORDER (d2amd_roi_pooler_forward_ordered: counting sort by level /
+# image / cell): the box head's HBM fetch drops from 1.7 x to 1.07 x the features at equal kernel time -- but the ordering
+# launch is one workgroup, 10-15 us, in front of the pooling kernel on the step's critical path: 0.521 / 0.527 ms per step
+# with it, 0.498 / 0.500 without (same box, gpurun_out/r3s).  Off unless D2AMD_FWD_ORDER=1.
+_FWD_ORDERED = _os.environ.get("D2AMD_FWD_ORDER", "0") == "1"
 _SIDE_BINNING = _os.environ.get("D2AMD_SIDE_BINNING", "1") != "0"  # A/B switch: the later gathers' binning beside the first
 
 
@@ -263,18 +268,28 @@ class _FusedROIPool(Function):
         mf = torch.channels_last if layout == _C.NHWC else torch.contiguous_format
         out = torch.empty((k, c, ph, pw), dtype=xs[0].dtype, device=xs[0].device, memory_format=mf)
         with _C.on_device(xs[0].device):
-            # (K ints for the ROI processing order of the forward: include/d2amd.h, d2amd_roi_pooler_forward_ordered)
-            order = torch.empty(max(k, 1), dtype=torch.int32, device=xs[0].device)
-            if box_lists is None:
-                _C.check(_C.lib().d2amd_roi_pooler_forward_ordered(ctypes.byref(p), _ptr_array(xs), _C.ptr(rois),
-                                                                   _C.ptr(out), k, _C.ptr(order), 4 * max(k, 1),
-                                                                   _C.stream()))
+            if _FWD_ORDERED:
+                # (K ints for the ROI processing order of the forward: include/d2amd.h, d2amd_roi_pooler_forward_ordered)
+                order = torch.empty(max(k, 1), dtype=torch.int32, device=xs[0].device)
+                if box_lists is None:
+                    _C.check(_C.lib().d2amd_roi_pooler_forward_ordered(ctypes.byref(p), _ptr_array(xs), _C.ptr(rois),
+                                                                       _C.ptr(out), k, _C.ptr(order), 4 * max(k, 1),
+                                                                       _C.stream()))
+                else:
+                    n_img = len(box_lists)
+                    counts = (ctypes.c_int * n_img)(*[int(b.shape[0]) for b in box_lists])
+                    _C.check(_C.lib().d2amd_roi_pooler_forward_box_lists_ordered(
+                        ctypes.byref(p), _ptr_array(xs), _ptr_array(box_lists), counts, n_img, _C.ptr(rois), _C.ptr(out),
+                        _C.ptr(order), 4 * max(k, 1), _C.stream()))
+            elif box_lists is None:
+                _C.check(_C.lib().d2amd_roi_pooler_forward(ctypes.byref(p), _ptr_array(xs), _C.ptr(rois), _C.ptr(out), k,
+                                                           _C.stream()))
             else:
                 n_img = len(box_lists)
                 counts = (ctypes.c_int * n_img)(*[int(b.shape[0]) for b in box_lists])
-                _C.check(_C.lib().d2amd_roi_pooler_forward_box_lists_ordered(
+                _C.check(_C.lib().d2amd_roi_pooler_forward_box_lists(
                     ctypes.byref(p), _ptr_array(xs), _ptr_array(box_lists), counts, n_img, _C.ptr(rois), _C.ptr(out),
-                    _C.ptr(order), 4 * max(k, 1), _C.stream()))
+                    _C.stream()))
         ctx.save_for_backward(rois)
         ctx.cfg, ctx.hw, ctx.nc, ctx.layout = cfg, hw, (n, c), layout
         ctx.needs = [f.requires_grad for f in feats]
@@ -481,6 +496,17 @@ class ROIPooler(nn.Module):
             return False
         lay, dt = _layout_of(x[0]), x[0].dtype
         return all(_layout_of(t) == lay and t.dtype == dt and t.shape[:2] == x[0].shape[:2] for t in x)
+
+    def pool_rois(self, x: List[torch.Tensor], rois: torch.Tensor):
+        """forward() for boxes that already are in pooler format: rois (M, 5) fp32 = (image index, x1, y1, x2, y2), what
+        `convert_boxes_to_pooler_format` returns and `label_and_sample_proposals_fixed` writes ("rois" / "head_rois") --
+        no conversion launch in front of the pooling kernel."""
+        assert rois.dim() == 2 and rois.shape[1] == 5 and rois.dtype == torch.float32 and rois.is_contiguous()
+        assert self._fusable(x), "pool_rois: multi-level ROIAlign on HIP tensors of one layout / dtype only"
+        cfg = (tuple(self.output_size), tuple(self.scales), int(self.sampling_ratio),
+               self.pooler_type == "ROIAlignV2", self.min_level, self.max_level, self.canonical_box_size,
+               self.canonical_level)
+        return self._pool_fused(rois.detach(), cfg, x)
 
     def forward(self, x: List[torch.Tensor], box_lists):
         """x: list of NCHW feature maps (scales as constructed); box_lists: N Boxes / RotatedBoxes (image

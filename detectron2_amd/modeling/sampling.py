@@ -91,7 +91,8 @@ def subsample_labels(labels: torch.Tensor, num_samples: int, positive_fraction: 
 def label_and_sample_proposals_fixed(proposal_boxes, gt_boxes, gt_classes, limits=None, keys=None, limit_stride=1,
                                      thresholds=(0.5,), labels=(0, 1), batch_size_per_image: int = 512,
                                      positive_fraction: float = 0.25, num_classes: int = 80,
-                                     proposal_append_gt: bool = True, generator: torch.Generator = None):
+                                     proposal_append_gt: bool = True, generator: torch.Generator = None,
+                                     head_rows: int = 0):
     """`ROIHeads.label_and_sample_proposals` (roi_heads/roi_heads.py:219-295) for a batch with a FIXED output shape and
     no host sync -- d2amd_label_and_sample_proposals (include/d2amd.h), one workgroup per image.
 
@@ -107,7 +108,9 @@ def label_and_sample_proposals_fixed(proposal_boxes, gt_boxes, gt_classes, limit
 
     -> dict of HIP tensors: boxes [N, S, 4], classes [N, S] (class, num_classes = background, -1 = padding),
     gt_index [N, S] (matched ground truth), index [N, S] (candidate index into [proposals[:n]; gt], -1 = padding),
-    counts [N, 2] int32 = (positives, rows).  Positives first, then negatives, then padding; S = batch_size_per_image."""
+    counts [N, 2] int32 = (positives, rows).  Positives first, then negatives, then padding; S = batch_size_per_image.
+    Also "rois" [N * S, 5] (pooler format: image, x1, y1, x2, y2 -- `ROIPooler.pool_rois` takes it as it is) and, with
+    head_rows > 0, "head_rois" [N * head_rows, 5]: the first head_rows rows of every image (the mask head's)."""
     import ctypes
 
     n_img = len(proposal_boxes)
@@ -118,7 +121,12 @@ def label_and_sample_proposals_fixed(proposal_boxes, gt_boxes, gt_classes, limit
            "classes": torch.empty((n_img, S), dtype=torch.int64, device=dev),
            "gt_index": torch.empty((n_img, S), dtype=torch.int64, device=dev),
            "index": torch.empty((n_img, S), dtype=torch.int64, device=dev),
-           "counts": torch.empty((n_img, 2), dtype=torch.int32, device=dev)}
+           "counts": torch.empty((n_img, 2), dtype=torch.int32, device=dev),
+           "rois": torch.empty((n_img * S, 5), dtype=torch.float32, device=dev)}
+    H = int(head_rows)
+    assert 0 <= H <= S
+    if H:
+        out["head_rois"] = torch.empty((n_img * H, 5), dtype=torch.float32, device=dev)
     if n_img == 0:
         return out
     imgs = (_C.SampleImage * n_img)()
@@ -149,6 +157,6 @@ def label_and_sample_proposals_fixed(proposal_boxes, gt_boxes, gt_classes, limit
         _C.check(_C.lib().d2amd_label_and_sample_proposals(
             imgs, n_img, thr, lab, T, S, int(S * positive_fraction), int(num_classes), int(bool(proposal_append_gt)),
             _C.ptr(out["boxes"]), _C.ptr(out["classes"]), _C.ptr(out["gt_index"]), _C.ptr(out["index"]),
-            _C.ptr(out["counts"]), _C.stream()))
+            _C.ptr(out["counts"]), _C.ptr(out["rois"]), _C.ptr(out.get("head_rois")), H, _C.stream()))
     out["_hold"] = hold  # inputs stay alive until the caller drops the result (the launch is asynchronous)
     return out

@@ -194,6 +194,10 @@ int d2amd_box_iou_rotated(const float* boxes1, int n, const float* boxes2, int m
  * -1), gt_index_out [count][S] (the matched ground truth: matched_idxs[sampled_idxs]; 0 for padding / no ground
  * truth), index_out [count][S] (candidate index = the reference's sampled_idxs; -1), counts_out [count][2] =
  * (positives, rows).  thresholds / labels: Matcher's constructor arguments (host), as for d2amd_match_boxes.
+ * rois_out (optional) [count * S][5]: the same rows in pooler format (image index, x1, y1, x2, y2:
+ * convert_boxes_to_pooler_format, modeling/poolers.py:62-104), head_rois_out (optional) [count * head_rows][5]: the first
+ * head_rows rows of every image (the mask head's rows: positives come first) -- what d2amd_roi_pooler_forward takes
+ * as they are.
  * max_proposals + num_gt <= d2amd_label_and_sample_max_candidates() per image, else D2AMD_EUNSUPPORTED. */
 typedef struct {
   const float* proposals;    /* [max_proposals][4] fp32 xyxy, 16-byte aligned */
@@ -208,7 +212,8 @@ int d2amd_label_and_sample_max_candidates(void);
 int d2amd_label_and_sample_proposals(const d2amd_sample_image* images, int count, const float* thresholds,
                                      const int8_t* labels, int T, int batch_size_per_image, int max_positives,
                                      int64_t num_classes, int append_gt, float* boxes_out, int64_t* classes_out,
-                                     int64_t* gt_index_out, int64_t* index_out, int32_t* counts_out, void* stream);
+                                     int64_t* gt_index_out, int64_t* index_out, int32_t* counts_out, float* rois_out,
+                                     float* head_rois_out, int head_rows, void* stream);
 
 /* ---- subsample_labels (detectron2/modeling/sampling.py:9-54) for a batch, on the device, FIXED output shape, no
  * host sync -- the reference pays two nonzero() syncs and two randperm sorts per image.  Callers:

@@ -31,6 +31,14 @@ def _same(got, want, i):
     for k in ("counts", "index", "classes", "gt_index", "boxes"):
         g = got[k][i].cpu().numpy()
         assert np.array_equal(g, want[k]), (k, i)
+    # the same rows in pooler format (image index, box): what ROIPooler.pool_rois takes
+    S = got["boxes"].shape[1]
+    r = got["rois"].view(-1, S, 5)[i].cpu().numpy()
+    assert np.array_equal(r[:, 1:], want["boxes"]) and (r[:, 0] == i).all(), i
+    if "head_rois" in got:
+        H = got["head_rois"].shape[0] // got["boxes"].shape[0]
+        h = got["head_rois"].view(-1, H, 5)[i].cpu().numpy()
+        assert np.array_equal(h[:, 1:], want["boxes"][:H]) and (h[:, 0] == i).all(), i
 
 
 @pytest.fixture(scope="module")
@@ -59,7 +67,8 @@ def test_batch_of_golden_cases(golden):
         out = label_and_sample_proposals_fixed([cu(p) for p in props], [cu(g).reshape(-1, 4) for g in gts],
                                                [cu(c) for c in gcs], limits=[cu(l) for l in lims],
                                                keys=[cu(k) for k in keys], thresholds=thr, labels=lab,
-                                               batch_size_per_image=S, positive_fraction=frac, num_classes=80)
+                                               batch_size_per_image=S, positive_fraction=frac, num_classes=80,
+                                               head_rows=S // 4)
         for i in range(len(group)):
             want = osp.label_and_sample_fixed(props[i], ns[i], gts[i], gcs[i], keys[i], thr, lab, S, frac, 80)
             _same(out, want, i)
