@@ -28,7 +28,6 @@ struct RpnLevels {
 };
 struct RpnImages { int n; int h[D2AMD_POOLER_MAX_IMAGES], w[D2AMD_POOLER_MAX_IMAGES]; };
 
-__device__ __forceinline__ bool rpn_finite(float v) { return fabsf(v) <= 3.402823466e+38f; }
 
 // per-level views of the RPN head outputs: level l of image i starts at logits[l] + i * stride[l] (deltas: float4 units).
 // The concatenated entry point fills them with offsets into its [N, Atot] arrays (stride = Atot), the per-level entry
@@ -61,27 +60,8 @@ __global__ __launch_bounds__(256) void rpn_decode_kernel(
   const float score = P.logits[l][(long)img * P.stride[l] + a];
   const float4 b = P.anchors[l][a];
   const float4 d = P.deltas[l][(long)img * P.stride[l] + a];
-  // box_regression.py:88-116, fp32
-  const float widths = b.z - b.x, heights = b.w - b.y;
-  const float ctr_x = b.x + 0.5f * widths, ctr_y = b.y + 0.5f * heights;
-  const float dx = d.x / wx, dy = d.y / wy;
-  float dw = d.z / ww, dh = d.w / wh;
-  dw = dw != dw ? dw : fminf(dw, scale_clamp);  // torch.clamp(max=) propagates NaN
-  dh = dh != dh ? dh : fminf(dh, scale_clamp);
-  const float pcx = dx * widths + ctr_x, pcy = dy * heights + ctr_y;
-  const float pw = expf(dw) * widths, ph = expf(dh) * heights;
-  float x1 = pcx - 0.5f * pw, y1 = pcy - 0.5f * ph, x2 = pcx + 0.5f * pw, y2 = pcy + 0.5f * ph;
-  // proposal_utils.py:98-112: finite filter, clip (structures/boxes.py:196-209), nonempty (boxes.py:211-223)
-  const bool fin = rpn_finite(x1) && rpn_finite(y1) && rpn_finite(x2) && rpn_finite(y2) && rpn_finite(score);
-  if (!fin) atomicOr(flags, 1);
-  const float W = (float)im.w[img], H = (float)im.h[img];
-  x1 = fminf(fmaxf(x1, 0.f), W); y1 = fminf(fmaxf(y1, 0.f), H);
-  x2 = fminf(fmaxf(x2, 0.f), W); y2 = fminf(fmaxf(y2, 0.f), H);
-  const bool ok = fin && (x2 - x1 > min_size) && (y2 - y1 > min_size);
-  boxes[t] = ok ? make_float4(x1, y1, x2, y2) : make_float4(0.f, 0.f, 0.f, 0.f);
-  scores[t] = ok ? score : -__builtin_inff();
-  valid[t] = ok ? 1 : 0;
-  if (img == 0) level_ids[j] = l;
+  rpn_decode_row(b, d, score, (float)im.w[img], (float)im.h[img], wx, wy, ww, wh, scale_clamp, min_size, t, j, l,
+                 img == 0, boxes, scores, valid, level_ids, flags);
 }
 
 // ---- dense detectors (RetinaNet / FCOS-style heads): meta_arch/dense_detector.py:186-245 ---------------------
@@ -208,8 +188,20 @@ static int rpn_select_impl(const RpnPtrs& P, const float* concat, int N, int Ato
   }
   uint32_t* sel = (uint32_t*)workspace;
   int* cnt = (int*)((char*)workspace + off_cnt);
-  int rc = topk_select(in, false, 0.f, sel, cnt, (char*)workspace + off_tk, workspace_bytes - off_tk, s, flags_out);
+  // the rank stage decodes the anchors it places (topk.h: TopkRpnEpilogue) when it can; else the decode launch below
+  TopkRpnEpilogue E{};
+  bool decoded = false;
+  if (N <= 16) {
+    for (int l = 0; l < L; l++) { E.deltas[l] = P.deltas[l]; E.anchors[l] = P.anchors[l]; }
+    for (int i = 0; i < N; i++) { E.img_h[i] = im.h[i]; E.img_w[i] = im.w[i]; }
+    E.wx = weights[0]; E.wy = weights[1]; E.ww = weights[2]; E.wh = weights[3];
+    E.scale_clamp = scale_clamp; E.min_size = min_box_size;
+    E.boxes = (float4*)boxes_out; E.scores = scores_out; E.valid = valid_out; E.level_ids = level_out; E.flags = flags_out;
+  }
+  int rc = topk_select(in, false, 0.f, sel, cnt, (char*)workspace + off_tk, workspace_bytes - off_tk, s, flags_out,
+                       N <= 16 ? &E : nullptr, &decoded);
   if (rc) return rc;
+  if (decoded) return D2AMD_OK;
   const long nt = (long)N * k;
   hipLaunchKernelGGL(rpn_decode_kernel, dim3(cdiv(nt, 256)), dim3(256), 0, s, P, (const uint32_t*)nullptr,
                      (const uint32_t*)sel, N, Atot, lv, im, weights[0], weights[1], weights[2], weights[3],

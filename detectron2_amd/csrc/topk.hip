@@ -680,9 +680,11 @@ __global__ __launch_bounds__(1024) void tk_sort_kernel(TkParams P, const SegStat
 // LDS broadcast read) and add their partial counts in LDS.  320 workgroups for 10 segments of 2,000 instead of the 10
 // of the bitonic sort, and no barrier chain: 66 dependent steps there, one pass here.
 constexpr int TK_RANK_MAX = 2048;
+template <bool RPN>
 __global__ __launch_bounds__(256) void tk_rank_kernel(TkParams P, const SegState* __restrict__ st,
                                                      const unsigned long long* __restrict__ cand, int kmax,
-                                                     uint32_t* __restrict__ sel, int* __restrict__ cnt_out) {
+                                                     uint32_t* __restrict__ sel, int* __restrict__ cnt_out,
+                                                     const TopkRpnEpilogue E) {
   __shared__ __attribute__((aligned(16))) unsigned long long sk[TK_RANK_MAX];
   __shared__ int rk[64];
   const int seg = blockIdx.x, l = seg % P.in.L, img = seg / P.in.L, tid = threadIdx.x;
@@ -707,7 +709,26 @@ __global__ __launch_bounds__(256) void tk_rank_kernel(TkParams P, const SegState
   __syncthreads();
   if (tid < 64 && me < n) {
     uint32_t* o = sel + (long)img * P.in.koff[P.in.L] + P.in.koff[l];
-    o[rk[tid]] = (uint32_t)mine;
+    const int r = rk[tid];
+    o[r] = (uint32_t)mine;
+    if (RPN) {  // decode the anchor this pair selects, into row r of its segment
+      // (constant indices only into the kernel-argument structs)
+      const float4* dl = E.deltas[0];
+      const float4* an = E.anchors[0];
+      const float* lg = P.in.ptr[0];
+      long stride = P.in.stride[0];
+#pragma unroll
+      for (int q = 1; q < TOPK_MAX_LEVELS; q++)
+        if (q == l) { dl = E.deltas[q]; an = E.anchors[q]; lg = P.in.ptr[q]; stride = P.in.stride[q]; }
+      int W = E.img_w[0], H = E.img_h[0];
+#pragma unroll
+      for (int q = 1; q < 16; q++)
+        if (q == img) { W = E.img_w[q]; H = E.img_h[q]; }
+      const int a = (int)(uint32_t)mine, j = P.in.koff[l] + r;
+      rpn_decode_row(an[a], dl[(long)img * stride + a], lg[(long)img * stride + a], (float)W, (float)H, E.wx, E.wy, E.ww,
+                     E.wh, E.scale_clamp, E.min_size, (long)img * P.in.koff[P.in.L] + j, j, l, img == 0, E.boxes,
+                     E.scores, E.valid, E.level_ids, E.flags);
+    }
   }
 }
 
@@ -779,7 +800,8 @@ float logit_lower_bound(float thr) {
 size_t topk_workspace_bytes(const TopkInput& in) { return tk_carve(in, nullptr).total + 256; }
 
 int topk_select(const TopkInput& in, bool use_thr, float xmin, uint32_t* sel, int* cnt, void* ws, size_t ws_bytes,
-                hipStream_t s, int* clear_word) {
+                hipStream_t s, int* clear_word, const TopkRpnEpilogue* rpn, bool* rpn_done) {
+  if (rpn_done) *rpn_done = false;
   D2_CHECK_ARG(in.L >= 1 && in.L <= TOPK_MAX_LEVELS && in.N >= 1, "topk_select: bad segment layout");
   const TkWs w = tk_carve(in, ws);
   if (ws == nullptr || ws_bytes < w.total) {
@@ -824,8 +846,15 @@ int topk_select(const TopkInput& in, bool use_thr, float xmin, uint32_t* sel, in
   hipLaunchKernelGGL(tk_compact_kernel, grid, block, 0, s, P, w.st, w.blk_ties, w.cand, w.kmax);
   }
   if (w.kmax <= TK_RANK_MAX && !no_fused) {  // (the A/B switch also keeps the bitonic sort under test)
-    hipLaunchKernelGGL(tk_rank_kernel, dim3(in.N * in.L, cdiv(w.kmax, 64)), dim3(256), 0, s, P, w.st, w.cand, w.kmax,
-                       sel, cnt);
+    static const bool no_epi = getenv("D2AMD_RPN_NO_FUSED_DECODE") != nullptr;  // A/B switch
+    if (rpn && rpn_done && in.N <= 16 && !no_epi) {
+      hipLaunchKernelGGL(tk_rank_kernel<true>, dim3(in.N * in.L, cdiv(w.kmax, 64)), dim3(256), 0, s, P, w.st, w.cand,
+                         w.kmax, sel, cnt, *rpn);
+      *rpn_done = true;
+    } else {
+      hipLaunchKernelGGL(tk_rank_kernel<false>, dim3(in.N * in.L, cdiv(w.kmax, 64)), dim3(256), 0, s, P, w.st, w.cand,
+                         w.kmax, sel, cnt, TopkRpnEpilogue{});
+    }
     D2_LAUNCH_OK();
     return D2AMD_OK;
   }
