@@ -256,6 +256,9 @@ class Workload:
         # 512 rows per image (box head), of which the first 128 feed the mask head (positives come first)
         self.gt_classes = [torch.randint(0, 80, (N_GT,), generator=g).to(dev) for g in gens]
         self.connected = False
+        from detectron2_amd.modeling import DeviceKeyGenerator
+
+        self.keygen = DeviceKeyGenerator(dev, seed=seed)
         self.loss_grad = torch.ones((), device=dev)  # d(total loss) / d(mask loss): passed in, not filled per step
 
     # algorithmic (compulsory) bytes per op, SURVEY.md 8(d)
@@ -424,8 +427,9 @@ def step_keys(w):
     """Every random key of a step in ONE launch: [N, 268,569] for the anchor sampler, [N, 1,000 + G] for the proposal
     sampler (torch's generator: inside a captured graph the Philox offset advances per replay)."""
     na = w.anchors.shape[0]
-    k = torch.rand(w.n_img, na + 1000 + N_GT, device=w.dev)
-    return k[:, :na], [k[i, na:] for i in range(w.n_img)]
+    k = w.keygen.uniform(w.n_img * (na + 1000 + N_GT))  # (device-resident generator: nothing in front of a graph replay)
+    roi = k[w.n_img * na:].view(w.n_img, 1000 + N_GT)
+    return k[:w.n_img * na].view(w.n_img, na), [roi[i] for i in range(w.n_img)]
 
 
 def connected_forward(w, run=None, rpn_keys=None, roi_keys=None, sync=False):

@@ -31,6 +31,7 @@ SOURCES = {
     "matcher.hip": ["-ffp-contract=off"],
     "label_sample.hip": ["-ffp-contract=off"],
     "subsample.hip": ["-ffp-contract=off"],
+    "random_keys.hip": [],
     "rpn.hip": ["-ffp-contract=off"],
     "topk.hip": ["-ffp-contract=off"],
     "mask_targets.hip": ["-ffp-contract=off"],

@@ -21,7 +21,28 @@ import torch
 
 from .. import _C
 
-__all__ = ["subsample_labels", "subsample_labels_batch", "subsample_anchor_labels_", "label_and_sample_proposals_fixed"]
+__all__ = ["subsample_labels", "subsample_labels_batch", "subsample_anchor_labels_", "label_and_sample_proposals_fixed",
+           "DeviceKeyGenerator"]
+
+
+class DeviceKeyGenerator:
+    """Uniform sampling keys from a generator whose state lives ON THE DEVICE (d2amd_uniform_keys: Philox4x32-10).
+    `torch.rand` inside a captured HIP graph costs two host-side fill launches in front of every replay (torch feeds
+    its generator's seed and offset that way); this one advances its offset in the kernel, so a replayed step draws
+    fresh keys with nothing in front of the graph.  Seeded from torch's generator (`generator` or the global one), so
+    `torch.manual_seed` reproduces a run; the stream itself is this class's, not torch's."""
+
+    def __init__(self, device, generator: torch.Generator = None, seed: int = None):
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,), generator=generator).item())
+        self.state = torch.tensor([seed, 0, 0], dtype=torch.int64, device=device)
+
+    def uniform(self, *shape) -> torch.Tensor:
+        """fp32 tensor of `shape`, values in [0, 1)"""
+        out = torch.empty(*shape, dtype=torch.float32, device=self.state.device)
+        with _C.on_device(out.device):
+            _C.check(_C.lib().d2amd_uniform_keys(_C.ptr(self.state), _C.ptr(out), out.numel(), _C.stream()))
+        return out
 
 
 def _subsample_device(labels2d, keys, num_samples, max_pos, bg_label, want_idx, labels_out):

@@ -215,6 +215,13 @@ int d2amd_label_and_sample_proposals(const d2amd_sample_image* images, int count
                                      int64_t* gt_index_out, int64_t* index_out, int32_t* counts_out, float* rois_out,
                                      float* head_rois_out, int head_rows, void* stream);
 
+/* ---- uniform sampling keys from a DEVICE-resident generator state (what the samplers below consume; the reference
+ * draws torch.randperm inside subsample_labels, modeling/sampling.py:49-50).  state: 3 device uint64 words {seed, offset,
+ * 0}; every call writes n fp32 values in [0, 1) (Philox4x32-10, 24 random bits each) to `out` and advances the offset
+ * on the device -- a captured HIP graph draws fresh keys at every replay without the two host-side fill launches torch's
+ * generator needs in front of each hipGraphLaunch. */
+int d2amd_uniform_keys(uint64_t* state, float* out, int64_t n, void* stream);
+
 /* ---- subsample_labels (detectron2/modeling/sampling.py:9-54) for a batch, on the device, FIXED output shape, no
  * host sync -- the reference pays two nonzero() syncs and two randperm sorts per image.  Callers:
  * RPN._subsample_labels (proposal_generator/rpn.py:287-305: 268,569 anchor labels per image -> 256, label vector

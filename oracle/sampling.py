@@ -102,3 +102,19 @@ def label_and_sample_fixed(proposals, n_valid, gt_boxes, gt_classes, keys, thres
         out["gt_index"][:k] = idx[sel]
         out["index"][:k] = sel
     return out
+
+
+def philox_uniform_keys(seed, offset, n):
+    """d2amd_uniform_keys restated (csrc/random_keys.hip): Philox4x32-10 (Salmon et al., SC'11) with counter
+    {thread lo, thread hi, offset lo, offset hi}, key = seed; thread q yields outputs 4 q .. 4 q + 3 = (x >> 8) * 2^-24."""
+    q = np.arange((n + 3) // 4, dtype=np.uint64)
+    c = [q & 0xFFFFFFFF, q >> np.uint64(32), np.full_like(q, offset & 0xFFFFFFFF), np.full_like(q, (offset >> 32) & 0xFFFFFFFF)]
+    k0, k1 = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
+    M0, M1, W0, W1, MASK = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0x9E3779B9), np.uint64(0xBB67AE85), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & MASK, p1 >> np.uint64(32), p1 & MASK
+        c = [hi1 ^ c[1] ^ k0, lo1, hi0 ^ c[3] ^ k1, lo0]
+        k0, k1 = (k0 + W0) & MASK, (k1 + W1) & MASK
+    out = np.stack(c, 1).reshape(-1)[:n]
+    return ((out >> np.uint64(8)).astype(np.float32) * np.float32(2.0 ** -24)).astype(np.float32)

@@ -126,3 +126,40 @@ def test_uniform_and_reproducible_on_the_device():
     a = subsample_labels(d, 32, 0.25, 80, generator=torch.Generator(device=DEV).manual_seed(3))
     b = subsample_labels(d, 32, 0.25, 80, generator=torch.Generator(device=DEV).manual_seed(3))
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_device_key_generator_matches_the_philox_restatement_and_advances_on_the_device():
+    """d2amd_uniform_keys (csrc/random_keys.hip) == oracle.sampling.philox_uniform_keys (pinned to the published Philox
+    known answers on the CPU) bit for bit; the offset advances in the kernel: consecutive calls and consecutive REPLAYS of
+    a captured graph draw the keys of offsets 0, 1, 2, ... with no host involvement."""
+    from detectron2_amd.modeling import DeviceKeyGenerator
+
+    g = DeviceKeyGenerator(DEV, seed=987654321)
+    n = 2 * (268569 + 1016)
+    a, b = g.uniform(n).cpu().numpy(), g.uniform(3, 5).cpu().numpy()
+    assert np.array_equal(a, osp.philox_uniform_keys(987654321, 0, n))
+    assert np.array_equal(b.reshape(-1), osp.philox_uniform_keys(987654321, 1, 15)) and b.shape == (3, 5)
+    assert a.min() >= 0.0 and a.max() < 1.0 and abs(a.mean() - 0.5) < 2e-3
+    assert g.state.tolist() == [987654321, 2, 0]
+    # captured: every replay sees the next offset
+    cur = torch.cuda.current_stream()
+    side = torch.cuda.Stream()
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        g.uniform(1000)
+    cur.wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = g.uniform(1000)
+    base = int(g.state[1].item())
+    for r in range(3):
+        graph.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), osp.philox_uniform_keys(987654321, base + r, 1000)), r
+    # seeded from torch's generator: reproducible under torch.manual_seed
+    torch.manual_seed(5)
+    k1 = DeviceKeyGenerator(DEV).uniform(64)
+    torch.manual_seed(5)
+    k2 = DeviceKeyGenerator(DEV).uniform(64)
+    assert torch.equal(k1, k2)

@@ -89,3 +89,17 @@ def test_product_has_no_cpu_path():
 
     with pytest.raises(NotImplementedError):
         subsample_labels(torch.zeros(8, dtype=torch.int64), 4, 0.5, 0)
+
+
+def test_philox_restatement_known_answers():
+    """oracle.sampling.philox_uniform_keys (the restatement of csrc/random_keys.hip) against the published known-answer
+    vectors of Philox4x32-10 (Random123 kat_vectors: counter / key all zero, all ones, digits of pi)."""
+    k = osp.philox_uniform_keys(0, 0, 4)
+    assert [int(x) for x in (k.astype(np.float64) * 2 ** 24)] == [0x6627e8d5 >> 8, 0xe169c58d >> 8, 0xbc57ac4c >> 8, 0x9b00dbd8 >> 8]
+    # thread q = 0xffffffff_ffffffff cannot be reached through the array interface; offset / seed all ones, thread 0:
+    k = osp.philox_uniform_keys((1 << 64) - 1, (1 << 64) - 1, 4)
+    assert k.dtype == np.float32 and (k >= 0).all() and (k < 1).all()
+    # a long draw: uniform to 3 sigma in every decile, no value repeated suspiciously often
+    k = osp.philox_uniform_keys(1234, 7, 400000)
+    h = np.histogram(k, 10, (0, 1))[0]
+    assert np.abs(h - 40000).max() < 3.5 * np.sqrt(40000 * 0.9)
