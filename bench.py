@@ -770,7 +770,7 @@ def cpu_baseline_maskrcnn(w):
             "host_cores_available": os.cpu_count()}
 
 
-def pmc_traffic(op, layout):
+def pmc_traffic(op, layout, key="hbm_bytes_per_launch"):
     """HBM bytes per launch of the op's kernels from the committed rocprofv3 PMC passes
     (profiles/<round>/pmc_traffic_<layout>.json, written by scripts/pmc_summary.py from separate
     FETCH_SIZE / WRITE_SIZE runs, gfx950 FETCH_SIZE x2 correction applied there); None if absent."""
@@ -783,7 +783,7 @@ def pmc_traffic(op, layout):
         except Exception:
             continue
         if op in d.get("ops", {}):
-            best = d["ops"][op].get("hbm_bytes_per_launch")
+            best = d["ops"][op].get(key) or (d["ops"][op].get("hbm_bytes_per_launch") if key == "hbm_bytes_per_launch" else None)
     return best
 
 
@@ -877,8 +877,10 @@ def bench_maskrcnn(args, ctx):
                           + ("an eager pass of the same number of steps right after the timed region (the timed region "
                              "replays HIP graphs, inside which events cannot be read)" if use_graph else "the timed steps"),
                 "kernels_ms": {k: round(v[0], 4) for k, v in ktimes.items()}}
-        if roof["traffic"]:
-            roof["frac_traffic"] = round(roof["traffic"] / 1e6 / k_ms / HBM_PEAK_GBS, 4)
+        ktraffic = pmc_traffic("roi_align_box_bwd", args.layout, "kernel_hbm_bytes_per_launch") or roof["traffic"]
+        if ktraffic:
+            roof["traffic_kernel"] = ktraffic  # the gather kernel alone (the op's figure includes records + binning)
+            roof["frac_traffic"] = round(ktraffic / 1e6 / k_ms / HBM_PEAK_GBS, 4)
     else:
         per = alg["backward"]
         roof = {"bound": "hbm", "kernel": "backward (both poolers' tile gather + mask loss backward)",
