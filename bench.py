@@ -56,6 +56,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_BF16_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
+L1_PEAK_GBS = 37700.0      # aggregate vector-L1 rate: 64 B / clk / CU x 256 CUs x 2.3 GHz
 STRIDES = (4, 8, 16, 32)
 FEAT_HW = ((200, 336), (100, 168), (50, 84), (25, 42))  # 800x1344 padded input
 ANCHOR_HW = FEAT_HW + ((13, 21),)
@@ -1105,12 +1106,14 @@ def bench_dcn(args, ctx):
     for tag, nblk, ch, h, wd in DCN_STAGES:
         for b in range(nblk):
             mod = ModulatedDeformConv(ch, ch, 3, padding=1, bias=False).to(dev).to(dtype)
-            # NCHW, the layout of the reference's DeformBottleneckBlock (resnet.py:303-327) and of this library's DCN
-            # entry points (they keep their own NHWC copy of x / dY in the workspace)
-            x = torch.randn(n_img, ch, h, wd, generator=gen).to(dev).to(dtype)
+            # --layout nhwc (default): channels_last activations and gradients, the kernels' native layout (a model run
+            # with memory_format=torch.channels_last; d2amd_dcn_params.layout = NHWC: no transposes in or out);
+            # --layout nchw: the reference's DeformBottleneckBlock layout (resnet.py:303-327), transposed per call
+            mf = torch.channels_last if (args.layout == "nhwc" and dtype != torch.float32) else torch.contiguous_format
+            x = torch.randn(n_img, ch, h, wd, generator=gen).to(dev).to(dtype).contiguous(memory_format=mf)
             off = (torch.randn(n_img, 18, h, wd, generator=gen) * 2).to(dev).to(dtype)
             msk = torch.sigmoid(torch.randn(n_img, 9, h, wd, generator=gen)).to(dev).to(dtype)
-            gy = torch.randn(n_img, ch, h, wd, generator=gen).to(dev).to(dtype)
+            gy = torch.randn(n_img, ch, h, wd, generator=gen).to(dev).to(dtype).contiguous(memory_format=mf)
             blocks.append((tag, mod, x.requires_grad_(True), off.requires_grad_(True), msk.requires_grad_(True), gy))
             flops_fwd += 2.0 * ch * ch * 9 * n_img * h * wd
 
@@ -1160,6 +1163,15 @@ def bench_dcn(args, ctx):
                 "timing": "HIP events recorded by the library on the kernel's launch stream, mean over the timed steps",
                 "kernels_ms": {k: round(v[0], 4) for k, v in ktimes.items()},
                 "kernels_frac_mfma": {k: round(per_launch / 1e9 / v[0] / MFMA_BF16_TFLOPS, 4) for k, v in ktimes.items()}}
+        # the other bound of these kernels: the deformable GATHER.  Every (position, tap) reads 4 corners x C channels x
+        # 2 B through the CUs' vector L1 (the sampled pixels are served by L2; nothing of it is HBM-compulsory): the
+        # kernel cannot be faster than those bytes at the aggregate L1 rate (64 B/clk/CU: 37.7 TB/s,
+        # MI355X_MICROARCH.md) -- 310 / 155 / 77 MB for res3 / res4 / res5, a 2-8 us floor that sits ABOVE the MFMA floor
+        gather_bytes = sum(n_img * h * wd * 9 * 4 * ch * 2 * nblk for _t, nblk, ch, h, wd in DCN_STAGES) / len(blocks)
+        roof["gather_floor"] = {"bytes_per_launch": int(gather_bytes), "peak_GBps": L1_PEAK_GBS,
+                                "floor_ms": round(gather_bytes / 1e6 / L1_PEAK_GBS, 4),
+                                "frac_of_floor": {k: round(gather_bytes / 1e6 / L1_PEAK_GBS / v[0], 4)
+                                                  for k, v in ktimes.items() if k != "dcn_bwd_gather"}}
     ops = {k: {"ms_per_step": round(v / bsteps, 4), "launches_per_step": timer.counts()[k] // bsteps}
            for k, v in timer.totals_ms().items()}
     out = {
@@ -1168,7 +1180,7 @@ def bench_dcn(args, ctx):
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "dcnv2_r50_res3-5_13_blocks_fwd+bwd_bs2_800x1344 (BASELINE configs[4])",
-                   "layout": "nchw", "global_batch": world * n_img,
+                   "layout": args.layout if dtype != torch.float32 else "nchw", "global_batch": world * n_img,
                    "gflop_per_step": round(3 * flops_fwd / 1e9, 1),
                    "parallelism": f"dp{world}: images sharded; DCN weight gradients reduce with the model's (not in this step)"},
         "roofline": roof, "ops": ops,

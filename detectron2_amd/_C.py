@@ -28,7 +28,7 @@ _sz = ctypes.c_size_t
 class DcnParams(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in (
         "B", "C", "H", "W", "Co", "kh", "kw", "stride_h", "stride_w", "pad_h", "pad_w", "dil_h",
-        "dil_w", "groups", "deformable_groups", "dtype")]
+        "dil_w", "groups", "deformable_groups", "dtype", "layout")]
 
 
 class NmsGather(ctypes.Structure):

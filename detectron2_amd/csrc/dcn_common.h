@@ -99,7 +99,8 @@ struct TcPlan {
 TcPlan dcn_tc_plan_fwd(const DcnShape& s, int dtype);
 template <typename T>
 int dcn_tc_forward(const DcnShape& s, const TcPlan& pl, const void* x_nhwc, const void* offset, const void* mask,
-                   const void* weight, const void* bias, void* out, void* wp, float* partial, hipStream_t st);
+                   const void* weight, const void* bias, void* out, void* wp, float* partial, hipStream_t st,
+                   bool out_nhwc = false);
 
 struct TcBwPlan {
   bool ok;

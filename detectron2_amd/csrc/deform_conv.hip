@@ -501,6 +501,7 @@ struct DcnWs {
   DcnGatherWs gather;  // column-gather backward (16-bit MFMA path, deformable_groups == 1)
   void* gx_t;          // its dX in the I/O dtype, NHWC
   bool use_gather;
+  bool nhwc;  // the caller's x / out / grads are channels_last (d2amd_dcn_params::layout)
   void *x_nhwc, *wr, *wt, *gout_nhwc;
   float *gx, *goff, *gmask, *gwr;
   int dtype;
@@ -576,6 +577,14 @@ template <typename T>
 static int fwd_host(const DcnShape& s, const void* x, const void* offset, const void* mask, const void* weight,
                     const void* bias, void* out, const DcnWs& w, hipStream_t st) {
   if (s.B == 0) return D2AMD_OK;
+  if (w.nhwc) {  // a channels_last caller: x is what the kernels read, out is written [position][Co]
+    if constexpr (sizeof(T) == 2) {
+      if (w.tc.ok)
+        return dcn_tc_forward<T>(s, w.tc, x, offset, mask, weight, bias, out, w.tc_wp, w.tc_partial, st, true);
+    }
+    set_error("deform_conv_forward: NHWC input is served by the 16-bit MFMA path only (this shape / dtype is not)");
+    return D2AMD_EUNSUPPORTED;
+  }
   int rc = launch_transpose<T, T>((const T*)x, (T*)w.x_nhwc, s.B, s.C, s.H * s.W, st);
   if (rc) return rc;
   if constexpr (sizeof(T) == 2) {
@@ -609,7 +618,62 @@ static int bwd_host(const DcnShape& s, const void* x, const void* offset, const 
   }
   constexpr bool is32 = sizeof(T) == 4;
   const bool vec = vec_ok(s);
-  int rc = launch_transpose<T, T>((const T*)x, (T*)w.x_nhwc, s.B, s.C, s.H * s.W, st);
+  int rc = 0;
+  if (w.nhwc) {
+    // A channels_last caller (d2amd_dcn_params::layout = NHWC): x and grad_out ARE what the kernels read, the column
+    // gather writes grad_input in place -- 3 of the 4 transposes of a block's forward + backward are gone; the
+    // weight-gradient kernel still reads dY position-major per channel: one transpose into the workspace.
+    if constexpr (is32) {
+      set_error("deform_conv_backward: NHWC is served by the 16-bit MFMA path only");
+      return D2AMD_EUNSUPPORTED;
+    } else {
+      const TcBwPlan bp = dcn_tc_plan_bwd(s, (int)w.dtype);
+      const TcBwwPlan wp = dcn_tc_plan_bww(s, (int)w.dtype);
+      if (!(bp.ok && w.use_gather && wp.ok)) {
+        set_error("deform_conv_backward: NHWC is served by the 16-bit MFMA path only (this shape is not)");
+        return D2AMD_EUNSUPPORTED;
+      }
+      const bool need_data = gin || goffset || (gmask && mask);
+      if (need_data) {
+        float* goff_f = goffset ? w.goff : nullptr;
+        float* gmask_f = (gmask && mask) ? w.gmask : nullptr;
+        rc = dcn_tc_backward_data_gather<T>(s, bp, x, offset, mask, weight, gout, gin, goff_f, gmask_f, w.wt, w.gather, st);
+        if (rc) return rc;
+        if (goffset) {
+          const long n = (long)s.B * s.DG * 2 * s.K2 * s.L;
+          hipLaunchKernelGGL((cvt_kernel<T>), dim3(cdiv(n, 256) > 8192 ? 8192 : cdiv(n, 256)), dim3(256), 0, st, w.goff,
+                             (T*)goffset, n);
+          D2_LAUNCH_OK();
+        }
+        if (gmask && mask) {
+          const long n = (long)s.B * s.DG * s.K2 * s.L;
+          hipLaunchKernelGGL((cvt_kernel<T>), dim3(cdiv(n, 256) > 8192 ? 8192 : cdiv(n, 256)), dim3(256), 0, st, w.gmask,
+                             (T*)gmask, n);
+          D2_LAUNCH_OK();
+        }
+      }
+      if (gweight || gbias) {
+        rc = launch_transpose<T, T>((const T*)gout, (T*)w.gout_nhwc, s.B, s.L, s.Co, st);  // -> [b][Co][l]
+        if (rc) return rc;
+      }
+      if (gweight) {
+        { const int zrc = zero_async(w.gwr, (size_t)s.Co * s.Cg * s.K2 * 4, st); if (zrc) return zrc; }
+        rc = dcn_tc_backward_weight<T>(s, wp, x, offset, mask, w.gout_nhwc, w.gwr, st);
+        if (rc) return rc;
+        const long nw = (long)s.Co * s.Cg * s.K2;
+        hipLaunchKernelGGL((unpack_gw_kernel<T>), dim3(cdiv(nw, 256) > 4096 ? 4096 : cdiv(nw, 256)), dim3(256), 0, st,
+                           w.gwr, (T*)gweight, s.G, s.Cog, s.Cg, s.K2);
+        D2_LAUNCH_OK();
+      }
+      if (gbias) {
+        hipLaunchKernelGGL((dcn_bias_grad_kernel<T>), dim3(s.Co), dim3(256), 0, st, (const T*)w.gout_nhwc, (T*)gbias, s.B,
+                           s.Co, s.L);
+        D2_LAUNCH_OK();
+      }
+      return D2AMD_OK;
+    }
+  }
+  rc = launch_transpose<T, T>((const T*)x, (T*)w.x_nhwc, s.B, s.C, s.H * s.W, st);
   if (rc) return rc;
   const bool need_data = gin || goffset || (gmask && mask);
   if (need_data) {
@@ -734,6 +798,8 @@ extern "C" int d2amd_deform_conv_forward(const d2amd_dcn_params* p, const void* 
   if (s.B == 0) return D2AMD_OK;
   D2_CHECK_ARG(x && offset && weight && out && workspace, "deform_conv_forward: null pointer");
   DcnWs w = carve_ws(s, p->dtype, false, workspace);
+  D2_CHECK_ARG(p->layout == D2AMD_NCHW || p->layout == D2AMD_NHWC, "deform_conv_forward: bad layout %d", p->layout);
+  w.nhwc = p->layout == D2AMD_NHWC;
   if (workspace_bytes < w.total) {
     set_error("deform_conv_forward: workspace too small (%zu < %zu)", workspace_bytes, w.total);
     return D2AMD_EWORKSPACE;
@@ -752,6 +818,8 @@ extern "C" int d2amd_deform_conv_backward(const d2amd_dcn_params* p, const void*
   if (rc) return rc;
   D2_CHECK_ARG(s.B == 0 || (x && offset && weight && grad_out && workspace), "deform_conv_backward: null pointer");
   DcnWs w = carve_ws(s, p->dtype, true, workspace);
+  D2_CHECK_ARG(p->layout == D2AMD_NCHW || p->layout == D2AMD_NHWC, "deform_conv_backward: bad layout %d", p->layout);
+  w.nhwc = p->layout == D2AMD_NHWC;
   if (s.B > 0 && workspace_bytes < w.total) {
     set_error("deform_conv_backward: workspace too small (%zu < %zu)", workspace_bytes, w.total);
     return D2AMD_EWORKSPACE;

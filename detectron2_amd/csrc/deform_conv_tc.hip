@@ -44,6 +44,7 @@ struct TcArgs {
   float* partial;
   int n_pt, n_cot, ksplit, NCH, S, total;  // NCH: channel chunks (16*NKS channels) per conv group
   int ablate;  // profiling only (D2AMD_DCN_ABLATE): 1 no gather loads, 2 no combine, 4 no MFMA, 8 no weight copy
+  int out_nhwc;  // 1: out (and the fp32 partials) are [position][Co] (a channels_last caller) instead of [b][Co][l]
   unsigned long long* stamps;  // profiling only (D2AMD_DCN_STAMPS): per workgroup {start, after tables, after loop, end} (100 MHz)
 };
 
@@ -351,7 +352,10 @@ __global__ __launch_bounds__(64 * (NWM * NWN + NG)) void dcn_fwd_tc_kernel(DcnSh
   }
   if (p < s.P && !(a.ablate & 16)) {
     const int b = p / s.L, l = p - b * s.L;
-    const long obase = ((long)b * s.Co + (long)g * s.Cog) * s.L + l;
+    // NCHW: element (co, position) at (b Co + co) L + l; NHWC (a.out_nhwc): at position * Co + co -- a lane's four
+    // consecutive accumulator rows are four consecutive channels there
+    const long obase = a.out_nhwc ? (long)p * s.Co + (long)g * s.Cog : ((long)b * s.Co + (long)g * s.Cog) * s.L + l;
+    const long cstride = a.out_nhwc ? 1 : s.L;
     T* outp = (T*)a.out;
     float* part = a.partial + (a.ksplit > 1 ? (long)kz * s.B * s.Co * s.L : 0l);
 #pragma unroll
@@ -360,7 +364,7 @@ __global__ __launch_bounds__(64 * (NWM * NWN + NG)) void dcn_fwd_tc_kernel(DcnSh
       for (int r = 0; r < 16; r++) {
         const int co = cot * BM + (wm * MT + m) * 32 + frag_row(r, lane);
         if (co < s.Cog) {
-          const long o = obase + (long)co * s.L;
+          const long o = obase + (long)co * cstride;
           if (a.ksplit == 1) outp[o] = from_f32<T>(acc[m][r]);
           else part[o] = acc[m][r];
         }
@@ -570,7 +574,9 @@ __global__ __launch_bounds__(64, 2) void dcn_fwd_wave_kernel(DcnShape s, TcArgs 
     }
   }
   if (pvalid && !(WAB & 16)) {
-    const long obase = ((long)b * s.Co + (long)g * s.Cog) * s.L + l;
+    const long obase = a.out_nhwc ? ((long)b * s.L + l) * s.Co + (long)g * s.Cog
+                                  : ((long)b * s.Co + (long)g * s.Cog) * s.L + l;
+    const long cstride = a.out_nhwc ? 1 : s.L;
     T* outp = (T*)a.out;
     float* part = a.partial + (a.ksplit > 1 ? (long)kz * s.B * s.Co * s.L : 0l);
 #pragma unroll
@@ -579,7 +585,7 @@ __global__ __launch_bounds__(64, 2) void dcn_fwd_wave_kernel(DcnShape s, TcArgs 
       for (int r = 0; r < 16; r++) {
         const int co = cot * BM + m * 32 + frag_row(r, lane);
         if (co < s.Cog) {
-          const long o = obase + (long)co * s.L;
+          const long o = obase + (long)co * cstride;
           if (a.ksplit == 1) outp[o] = from_f32<T>(acc[m][r]);
           else part[o] = acc[m][r];
         }
@@ -591,11 +597,12 @@ __global__ __launch_bounds__(64, 2) void dcn_fwd_wave_kernel(DcnShape s, TcArgs 
 // out[i] = sum_kz partial[kz][i] (+ bias[co]) in a fixed order
 template <typename T>
 __global__ __launch_bounds__(256) void tc_reduce_partial_kernel(const float* __restrict__ partial, const T* __restrict__ bias,
-                                                               T* __restrict__ out, long n, int ksplit, int Co, int L) {
+                                                               T* __restrict__ out, long n, int ksplit, int Co, int L,
+                                                               int nhwc) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     float v = 0.f;
     for (int k = 0; k < ksplit; k++) v += partial[(long)k * n + i];
-    if (bias) v += to_f32(bias[(i / L) % Co]);
+    if (bias) v += to_f32(bias[nhwc ? i % Co : (i / L) % Co]);
     out[i] = from_f32<T>(v);
   }
 }
@@ -697,7 +704,8 @@ static int tc_launch_fwd(const DcnShape& s, const TcPlan& pl, const TcArgs& a, h
 
 template <typename T>
 int dcn_tc_forward(const DcnShape& s, const TcPlan& pl, const void* x_nhwc, const void* offset, const void* mask,
-                   const void* weight, const void* bias, void* out, void* wp, float* partial, hipStream_t st) {
+                   const void* weight, const void* bias, void* out, void* wp, float* partial, hipStream_t st,
+                   bool out_nhwc) {
   {
     const long groups16 = (long)s.G * pl.n_cot * pl.S * (pl.BM / 32) * pl.NKS * 64;
     const int blocks = cdiv(groups16, 256) > 8192 ? 8192 : cdiv(groups16, 256);
@@ -709,6 +717,7 @@ int dcn_tc_forward(const DcnShape& s, const TcPlan& pl, const void* x_nhwc, cons
   a.x = x_nhwc; a.offset = offset; a.mask = mask; a.wp = wp; a.bias = bias; a.out = out; a.partial = partial;
   a.n_pt = pl.n_pt; a.n_cot = pl.n_cot; a.ksplit = pl.ksplit; a.NCH = pl.NCH; a.S = pl.S;
   { const char* e = getenv("D2AMD_DCN_ABLATE"); a.ablate = e ? atoi(e) : 0; }
+  a.out_nhwc = out_nhwc ? 1 : 0;
   const long total = (long)pl.n_pt * pl.n_cot * s.G * pl.ksplit;
   D2_CHECK_ARG(total < (1l << 30), "deform_conv: too many tiles");
   a.total = (int)total;
@@ -737,16 +746,16 @@ int dcn_tc_forward(const DcnShape& s, const TcPlan& pl, const void* x_nhwc, cons
     const long n = (long)s.B * s.Co * s.L;
     const int blocks = cdiv(n, 256) > 4096 ? 4096 : cdiv(n, 256);
     hipLaunchKernelGGL((tc_reduce_partial_kernel<T>), dim3(blocks), dim3(256), 0, st, (const float*)partial,
-                       (const T*)bias, (T*)out, n, pl.ksplit, s.Co, s.L);
+                       (const T*)bias, (T*)out, n, pl.ksplit, s.Co, s.L, out_nhwc ? 1 : 0);
     D2_LAUNCH_OK();
   }
   return D2AMD_OK;
 }
 
 template int dcn_tc_forward<bf16_t>(const DcnShape&, const TcPlan&, const void*, const void*, const void*, const void*,
-                                    const void*, void*, void*, float*, hipStream_t);
+                                    const void*, void*, void*, float*, hipStream_t, bool);
 template int dcn_tc_forward<f16_t>(const DcnShape&, const TcPlan&, const void*, const void*, const void*, const void*,
-                                   const void*, void*, void*, float*, hipStream_t);
+                                   const void*, void*, void*, float*, hipStream_t, bool);
 
 // =====================================================================================================
 // Backward w.r.t. input / offset / mask, 16-bit path.

@@ -16,12 +16,19 @@ from .. import _C
 from .wrappers import _NewEmptyTensorOp
 
 
-def _params(x, weight, stride, padding, dilation, groups, deformable_groups):
+def _params(x, weight, stride, padding, dilation, groups, deformable_groups, layout=_C.NCHW):
     return _C.DcnParams(
         B=x.shape[0], C=x.shape[1], H=x.shape[2], W=x.shape[3], Co=weight.shape[0], kh=weight.shape[2],
         kw=weight.shape[3], stride_h=stride[0], stride_w=stride[1], pad_h=padding[0], pad_w=padding[1],
         dil_h=dilation[0], dil_w=dilation[1], groups=groups, deformable_groups=deformable_groups,
-        dtype=_C.dtype_code(x))
+        dtype=_C.dtype_code(x), layout=layout)
+
+
+def _is_nhwc(x):
+    """A 16-bit channels_last activation (a `model.to(memory_format=torch.channels_last)` caller): the kernels' native
+    layout -- d2amd_dcn_params.layout = NHWC skips the transposes in and out."""
+    return (x.dim() == 4 and x.dtype in (torch.float16, torch.bfloat16) and x.shape[1] > 1 and
+            x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous())
 
 
 def _conv_out_extent(size, pad, dil, kernel, stride):
@@ -74,11 +81,26 @@ def _dcn_forward(x, offset, mask, weight, bias, stride, padding, dilation, group
     _C.require_gpu(x, offset, mask, weight, bias, op="deform_conv")
     out_size = _output_size(x, weight, padding, dilation, stride)
     _check_shapes(x, offset, mask, weight, out_size, groups, deformable_groups)
+    L = _C.lib()
+    if _is_nhwc(x):  # channels_last in, channels_last out (D2AMD_EUNSUPPORTED: not an MFMA-path shape -> NCHW below)
+        x_ = x.detach()
+        offset_, mask_, weight_, bias_ = _same_dtype(x_, offset, mask, weight, bias)
+        out = torch.empty(out_size, dtype=x_.dtype, device=x_.device, memory_format=torch.channels_last)
+        p = _params(x_, weight_, stride, padding, dilation, groups, deformable_groups, _C.NHWC)
+        with _C.on_device(x_.device):
+            ws_bytes = L.d2amd_deform_conv_workspace_bytes(ctypes.byref(p), 0)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x_.device)
+            rc = L.d2amd_deform_conv_forward(ctypes.byref(p), _C.ptr(x_), _C.ptr(offset_), _C.ptr(mask_),
+                                             _C.ptr(weight_), _C.ptr(bias_), _C.ptr(out), _C.ptr(ws), ws_bytes,
+                                             _C.stream())
+        if rc == 0:
+            return out
+        if rc != _C.EUNSUPPORTED:
+            _C.check(rc)
     x_ = x.detach().contiguous()
     offset_, mask_, weight_, bias_ = _same_dtype(x_, offset, mask, weight, bias)
     out = x_.new_empty(out_size)
     p = _params(x_, weight_, stride, padding, dilation, groups, deformable_groups)
-    L = _C.lib()
     with _C.on_device(x_.device):
         ws_bytes = L.d2amd_deform_conv_workspace_bytes(ctypes.byref(p), 0)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x_.device)
@@ -91,6 +113,27 @@ def _dcn_forward(x, offset, mask, weight, bias, stride, padding, dilation, group
 def _dcn_backward(x, offset, mask, weight, grad_output, stride, padding, dilation, groups, deformable_groups,
                   need_input, need_weight, with_bias):
     _C.require_gpu(grad_output, op="deform_conv backward")
+    L = _C.lib()
+    if _is_nhwc(x):  # channels_last activations: gradients in and out stay channels_last
+        x_ = x.detach()
+        offset_, mask_, weight_ = _same_dtype(x_, offset, mask, weight)
+        go = grad_output.detach().to(x_.dtype).contiguous(memory_format=torch.channels_last)
+        gi = torch.empty_like(x_) if need_input else None  # (preserves channels_last)
+        goff = torch.empty_like(offset_) if need_input else None
+        gm = torch.empty_like(mask_) if (need_input and mask_ is not None) else None
+        gw = torch.empty_like(weight_) if need_weight else None
+        gb = x_.new_empty(weight_.shape[0]) if with_bias else None
+        p = _params(x_, weight_, stride, padding, dilation, groups, deformable_groups, _C.NHWC)
+        with _C.on_device(x_.device):
+            ws_bytes = L.d2amd_deform_conv_workspace_bytes(ctypes.byref(p), 1)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x_.device)
+            rc = L.d2amd_deform_conv_backward(
+                ctypes.byref(p), _C.ptr(x_), _C.ptr(offset_), _C.ptr(mask_), _C.ptr(weight_), _C.ptr(go), _C.ptr(gi),
+                _C.ptr(goff), _C.ptr(gm), _C.ptr(gw), _C.ptr(gb), _C.ptr(ws), ws_bytes, _C.stream())
+        if rc == 0:
+            return gi, goff, gm, gw, gb
+        if rc != _C.EUNSUPPORTED:
+            _C.check(rc)
     x_ = x.detach().contiguous()
     offset_, mask_, weight_, go = _same_dtype(x_, offset, mask, weight, grad_output)
     gi = torch.empty_like(x_) if need_input else None
@@ -99,7 +142,6 @@ def _dcn_backward(x, offset, mask, weight, grad_output, stride, padding, dilatio
     gw = torch.empty_like(weight_) if need_weight else None
     gb = x_.new_empty(weight_.shape[0]) if with_bias else None
     p = _params(x_, weight_, stride, padding, dilation, groups, deformable_groups)
-    L = _C.lib()
     with _C.on_device(x_.device):
         ws_bytes = L.d2amd_deform_conv_workspace_bytes(ctypes.byref(p), 1)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x_.device)

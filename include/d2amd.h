@@ -482,6 +482,10 @@ int d2amd_mask_rcnn_loss_backward_masked(const void* logits, const int64_t* gt_c
 typedef struct d2amd_dcn_params {
   int B, C, H, W, Co, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, groups,
       deformable_groups, dtype;
+  int layout; /* D2AMD_NCHW (the reference's), or D2AMD_NHWC: x / out / grad_out / grad_input are [B,H,W,C]-contiguous
+               * (torch.channels_last) -- the kernels' native layout: no transpose in, no transpose out; offset, mask
+               * and the weights keep their NCHW / OIHW layout.  NHWC is served by the 16-bit MFMA path only
+               * (D2AMD_EUNSUPPORTED otherwise: the caller converts). */
 } d2amd_dcn_params;
 size_t d2amd_deform_conv_workspace_bytes(const d2amd_dcn_params* p, int backward);
 int d2amd_deform_conv_forward(const d2amd_dcn_params* p, const void* x, const void* offset,

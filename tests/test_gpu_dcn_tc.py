@@ -307,3 +307,28 @@ def test_dcn_full_size_per_element_bounds(stage, C, H, W):
         if not ok.all():
             bad[k] = (float((d / b2)[~ok].max()), int((~ok).sum()), int(ok.size))
     assert not bad, (stage, bad)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,C,Co,H,W", [(2, 128, 128, 18, 21), (1, 256, 192, 13, 11), (2, 64, 512, 9, 10)])
+def test_channels_last_entry_equals_the_nchw_entry(dtype, B, C, Co, H, W):
+    """d2amd_dcn_params.layout = NHWC (a channels_last model: x, out, grad_out, grad_input [B, H, W, C]-contiguous): the
+    same kernels without the transposes in and out -- outputs and every gradient BIT-identical to the NCHW entry's, and
+    channels_last themselves; shapes outside the MFMA path (C = 96) fall back to the NCHW entry transparently."""
+    x, off, msk, w, bias, go, kw = make_case(50 + C, B, C, Co, H, W, dtype=dtype)
+    a = (kw["stride"], kw["padding"], kw["dilation"], kw["groups"], kw["deformable_groups"])
+    res = {}
+    for name, mf in (("nchw", torch.contiguous_format), ("nhwc", torch.channels_last)):
+        xt = x.to(DEV).contiguous(memory_format=mf).requires_grad_(True)
+        ot, mt, wt, bt = [t.to(DEV).requires_grad_(True) for t in (off, msk, w, bias)]
+        y = layers.modulated_deform_conv(xt, ot, mt, wt, bt, *a)
+        y.backward(go.to(DEV).contiguous(memory_format=mf))
+        assert y.is_contiguous(memory_format=mf) and xt.grad.is_contiguous(memory_format=mf), name
+        res[name] = [y.detach(), xt.grad, ot.grad, mt.grad, wt.grad, bt.grad]
+    for i, (p, q) in enumerate(zip(res["nchw"], res["nhwc"])):
+        assert torch.equal(p, q), i
+    case = make_case(77, 1, 96, 96, 10, 12, dtype=dtype)  # not an MFMA-path shape: served through the NCHW entry
+    xt = case[0].to(DEV).contiguous(memory_format=torch.channels_last)
+    y = layers.modulated_deform_conv(xt, case[1].to(DEV), case[2].to(DEV), case[3].to(DEV), case[4].to(DEV), *a)
+    exp = run_oracle(*case, backward=False)["out"]
+    assert rel_err(y.float().cpu().numpy(), exp) < TOL[dtype]
