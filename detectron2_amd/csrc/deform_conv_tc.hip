@@ -358,6 +358,22 @@ __global__ __launch_bounds__(64 * (NWM * NWN + NG)) void dcn_fwd_tc_kernel(DcnSh
     const long cstride = a.out_nhwc ? 1 : s.L;
     T* outp = (T*)a.out;
     float* part = a.partial + (a.ksplit > 1 ? (long)kz * s.B * s.Co * s.L : 0l);
+    if (a.out_nhwc && a.ksplit == 1 && (s.Cog & 3) == 0 && (s.Co & 3) == 0) {
+      // channels_last output: accumulator rows 4 q .. 4 q + 3 of a lane are 4 consecutive channels of its position
+#pragma unroll
+      for (int m = 0; m < MT; m++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int co = cot * BM + (wm * MT + m) * 32 + frag_row(4 * q, lane);
+          if (co < s.Cog) {  // (Cog % 4 == 0: the four rows are in range together)
+            const float v4[4] = {acc[m][4 * q], acc[m][4 * q + 1], acc[m][4 * q + 2], acc[m][4 * q + 3]};
+            vec4<T> pk;
+            pack4(v4, pk);
+            *reinterpret_cast<vec4<T>*>(outp + obase + co) = pk;
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int m = 0; m < MT; m++) {
 #pragma unroll
@@ -369,6 +385,7 @@ __global__ __launch_bounds__(64 * (NWM * NWN + NG)) void dcn_fwd_tc_kernel(DcnSh
           else part[o] = acc[m][r];
         }
       }
+    }
     }
   }
   if (stamp) stamp[3] = wall_clock64();

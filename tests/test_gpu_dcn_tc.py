@@ -313,8 +313,8 @@ def test_dcn_full_size_per_element_bounds(stage, C, H, W):
 @pytest.mark.parametrize("B,C,Co,H,W", [(2, 128, 128, 18, 21), (1, 256, 192, 13, 11), (2, 64, 512, 9, 10)])
 def test_channels_last_entry_equals_the_nchw_entry(dtype, B, C, Co, H, W):
     """d2amd_dcn_params.layout = NHWC (a channels_last model: x, out, grad_out, grad_input [B, H, W, C]-contiguous): the
-    same kernels without the transposes in and out -- outputs and every gradient BIT-identical to the NCHW entry's, and
-    channels_last themselves; shapes outside the MFMA path (C = 96) fall back to the NCHW entry transparently."""
+    same kernels without the transposes in and out -- output and grad_input BIT-identical to the NCHW entry's (the other
+    gradients to the rounding of their atomically accumulated partial sums), and channels_last themselves; shapes outside the MFMA path (C = 96) fall back to the NCHW entry transparently."""
     x, off, msk, w, bias, go, kw = make_case(50 + C, B, C, Co, H, W, dtype=dtype)
     a = (kw["stride"], kw["padding"], kw["dilation"], kw["groups"], kw["deformable_groups"])
     res = {}
@@ -326,7 +326,10 @@ def test_channels_last_entry_equals_the_nchw_entry(dtype, B, C, Co, H, W):
         assert y.is_contiguous(memory_format=mf) and xt.grad.is_contiguous(memory_format=mf), name
         res[name] = [y.detach(), xt.grad, ot.grad, mt.grad, wt.grad, bt.grad]
     for i, (p, q) in enumerate(zip(res["nchw"], res["nhwc"])):
-        assert torch.equal(p, q), i
+        if i < 2:  # the output and grad_input (column gather: no atomics) are deterministic: the same bits
+            assert torch.equal(p, q), i
+        else:      # d offset / d mask / dW / d bias accumulate fp32 partial sums with atomics: run-to-run rounding
+            assert (p.float() - q.float()).abs().max() <= 2e-3 * p.float().abs().max() + 1e-6, i
     case = make_case(77, 1, 96, 96, 10, 12, dtype=dtype)  # not an MFMA-path shape: served through the NCHW entry
     xt = case[0].to(DEV).contiguous(memory_format=torch.channels_last)
     y = layers.modulated_deform_conv(xt, case[1].to(DEV), case[2].to(DEV), case[3].to(DEV), case[4].to(DEV), *a)
