@@ -1723,6 +1723,10 @@ struct BwwArgs {
 
 // AB: compile-time ablation for profiling (D2AMD_DCN_ABLATE_BWW selects the instantiation): 1 no gather loads,
 // 2 no combine / LDS transpose, 4 no MFMA, 8 no dY loads, 16 no atomics, 32 no table loads
+#ifndef D2AMD_BWW_DEPTH
+#define D2AMD_BWW_DEPTH 2
+#endif
+constexpr int BWW_DEPTH = D2AMD_BWW_DEPTH;
 template <typename T, int AB>
 __global__ __launch_bounds__(256, 2) void dcn_bwd_weight_tc_kernel(DcnShape s, BwwArgs a) {
   typedef Mma<T> M;
@@ -1874,25 +1878,35 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_weight_tc_kernel(DcnShape s, B
     asm volatile("" ::: "memory");
   };
 
+  // D k-steps in flight per wave: the gathers of k + 1 .. k + D - 1 are outstanding while k is combined and contracted,
+  // the offset / mask rows are requested D steps ahead of the k-step that builds its table from them.  A wave is a chain
+  // offsets -> addresses -> gather -> combine -> MFMA with two dependent memory round trips per k-step and only two waves
+  // per SIMD to hide them (256 VGPRs each): with D = 2 (the first version) a k-step took ~3,300 cycles for ~600 cycles of
+  // instruction issue.  Measured (round 3, D2AMD_BWW_DEPTH): D = 3 (256 VGPRs, no spill) 128.9 us against 127.5 us at
+  // D = 2 over the 13 R50 blocks, D = 4 spills -- the outstanding loads are not what the k-step waits for; D stays 2.
+  constexpr int D = BWW_DEPTH;
   if (k_lo < k_hi) {
-    Raw r1, r2;
-    Ent e0, e1;
-    raw16 g0[2][4], g1[2][4], a0[2], a1[2];
-    load_raw(k_lo, r1);
-    build(k_lo, r1, e0);
-    load_raw(k_lo + 1, r1);
-    load_raw(k_lo + 2, r2);
-    issue(k_lo, e0, g0, a0);
-    for (int k = k_lo; k < k_hi; k += 2) {
-      // k + 1 (clamped past the end: harmless re-computation of the last k-step, never accumulated)
-      build(k + 1, r1, e1);
-      load_raw(k + 3, r1);
-      issue(k + 1, e1, g1, a1);
-      compute(k, e0, g0, a0);
-      build(k + 2, r2, e0);
-      load_raw(k + 4, r2);
-      issue(k + 2, e0, g0, a0);
-      if (k + 1 < k_hi) compute(k + 1, e1, g1, a1);
+    Raw rw[D];
+    Ent en[D];
+    raw16 gq[D][2][4], aq[D][2];
+#pragma unroll
+    for (int i = 0; i < D; i++) load_raw(k_lo + i, rw[i]);
+#pragma unroll
+    for (int i = 0; i < D - 1; i++) {
+      build(k_lo + i, rw[i], en[i]);
+      load_raw(k_lo + i + D, rw[i]);
+      issue(k_lo + i, en[i], gq[i], aq[i]);
+    }
+    for (int k = k_lo; k < k_hi; k += D) {
+#pragma unroll
+      for (int u = 0; u < D; u++) {
+        if (k + u >= k_hi) break;  // uniform
+        const int sj = (u + D - 1) % D;  // slot of step k + u + D - 1 = the slot step k + u - 1 has just left
+        build(k + u + D - 1, rw[sj], en[sj]);
+        load_raw(k + u + 2 * D - 1, rw[sj]);
+        issue(k + u + D - 1, en[sj], gq[sj], aq[sj]);
+        compute(k + u, en[u], gq[u], aq[u]);
+      }
     }
   }
   // ---- the 4 waves of the workgroup hold partial sums of the SAME 64 x 64 tile (4 consecutive position chunks: the
