@@ -134,10 +134,11 @@ int dcn_tc_backward_data_gather(const DcnShape& s, const TcBwPlan& pl, const voi
 struct TcBwwPlan {
   bool ok;
   int n_cot, n_cit, pch, ksteps_per_image;
+  size_t partial_bytes;  // the partial tiles the kernel writes: one 64 x 64 fp32 slot per workgroup
 };
 TcBwwPlan dcn_tc_plan_bww(const DcnShape& s, int dtype);
 template <typename T>
 int dcn_tc_backward_weight(const DcnShape& s, const TcBwwPlan& pl, const void* x_nhwc, const void* offset,
-                           const void* mask, const void* gout_nchw, float* gwr, hipStream_t st);
+                           const void* mask, const void* gout_nchw, float* partials, void* grad_weight, hipStream_t st);
 
 }  // namespace d2amd

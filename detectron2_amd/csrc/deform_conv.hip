@@ -533,7 +533,11 @@ static DcnWs carve_ws(const DcnShape& s, int dtype, bool backward, void* base) {
     w.gx = (float*)take((size_t)s.B * s.H * s.W * s.C * 4);
     w.goff = (float*)take((size_t)s.B * s.DG * 2 * s.K2 * s.L * 4);
     w.gmask = (float*)take((size_t)s.B * s.DG * s.K2 * s.L * 4);
-    w.gwr = (float*)take((size_t)s.Co * s.Cg * s.K2 * 4);
+    {  // fp32 staging of the weight gradient: [g][tap][co][ci] (generic kernels: atomics), or the MFMA kernel's partial tiles
+      const TcBwwPlan wp = dcn_tc_plan_bww(s, dtype);
+      const size_t stage = (size_t)s.Co * s.Cg * s.K2 * 4;
+      w.gwr = (float*)take(wp.ok && wp.partial_bytes > stage ? wp.partial_bytes : stage);
+    }
     const TcBwPlan bp = dcn_tc_plan_bwd(s, dtype);
     w.use_gather = bp.ok && bp.gather;
     if (w.use_gather) {
@@ -657,13 +661,8 @@ static int bwd_host(const DcnShape& s, const void* x, const void* offset, const 
         if (rc) return rc;
       }
       if (gweight) {
-        { const int zrc = zero_async(w.gwr, (size_t)s.Co * s.Cg * s.K2 * 4, st); if (zrc) return zrc; }
-        rc = dcn_tc_backward_weight<T>(s, wp, x, offset, mask, w.gout_nhwc, w.gwr, st);
+        rc = dcn_tc_backward_weight<T>(s, wp, x, offset, mask, w.gout_nhwc, w.gwr, gweight, st);
         if (rc) return rc;
-        const long nw = (long)s.Co * s.Cg * s.K2;
-        hipLaunchKernelGGL((unpack_gw_kernel<T>), dim3(cdiv(nw, 256) > 4096 ? 4096 : cdiv(nw, 256)), dim3(256), 0, st,
-                           w.gwr, (T*)gweight, s.G, s.Cog, s.Cg, s.K2);
-        D2_LAUNCH_OK();
       }
       if (gbias) {
         hipLaunchKernelGGL((dcn_bias_grad_kernel<T>), dim3(s.Co), dim3(256), 0, st, (const T*)w.gout_nhwc, (T*)gbias, s.B,
@@ -737,39 +736,40 @@ static int bwd_host(const DcnShape& s, const void* x, const void* offset, const 
     }
   }
   if (gweight) {
-    { const int zrc = zero_async(w.gwr, (size_t)s.Co * s.Cg * s.K2 * 4, st); if (zrc) return zrc; }
-    const int nblk = dcn_num_blocks(s.C, s.Cg, s.cpg, WG_BN);
-    const int co_tiles = cdiv(s.Cog, WG_BM);
-    constexpr int BK = Mma<T>::BK;
-    // split positions so that the launch has >= ~2048 workgroups; chunks are multiples of BK
-    long base = (long)nblk * co_tiles * s.K2;
-    int nchunks = (int)((2048 + base - 1) / base);
-    int pchunk = cdiv(cdiv(s.P, nchunks), BK) * BK;
-    if (pchunk < BK) pchunk = BK;
-    nchunks = cdiv(s.P, pchunk);
-    dim3 grid(nchunks, nblk * co_tiles, s.K2);
-    D2_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "deform_conv: too many channel blocks");
     bool tc_w = false;
     if constexpr (!is32) {
       const TcBwwPlan wp = dcn_tc_plan_bww(s, (int)w.dtype);
-      if (wp.ok) {  // 16-bit MFMA path (deform_conv_tc.hip)
-        rc = dcn_tc_backward_weight<T>(s, wp, w.x_nhwc, offset, mask, gout, w.gwr, st);
+      if (wp.ok) {  // 16-bit MFMA path (deform_conv_tc.hip): partial tiles + an ordered sum, no atomics, no zero fill
+        rc = dcn_tc_backward_weight<T>(s, wp, w.x_nhwc, offset, mask, gout, w.gwr, gweight, st);
         if (rc) return rc;
         tc_w = true;
       }
     }
-    if (tc_w) {
-    } else if (vec)
-      hipLaunchKernelGGL((dcn_bwd_weight_kernel<T, true>), grid, dim3(WG_THREADS), 0, st, s, (const T*)w.x_nhwc,
-                         (const T*)offset, (const T*)mask, (const T*)gout, w.gwr, pchunk, nblk);
-    else
-      hipLaunchKernelGGL((dcn_bwd_weight_kernel<T, false>), grid, dim3(WG_THREADS), 0, st, s, (const T*)w.x_nhwc,
-                         (const T*)offset, (const T*)mask, (const T*)gout, w.gwr, pchunk, nblk);
-    D2_LAUNCH_OK();
-    const long nw = (long)s.Co * s.Cg * s.K2;
-    hipLaunchKernelGGL((unpack_gw_kernel<T>), dim3(cdiv(nw, 256) > 4096 ? 4096 : cdiv(nw, 256)), dim3(256), 0, st,
-                       w.gwr, (T*)gweight, s.G, s.Cog, s.Cg, s.K2);
-    D2_LAUNCH_OK();
+    if (!tc_w) {
+      { const int zrc = zero_async(w.gwr, (size_t)s.Co * s.Cg * s.K2 * 4, st); if (zrc) return zrc; }
+      const int nblk = dcn_num_blocks(s.C, s.Cg, s.cpg, WG_BN);
+      const int co_tiles = cdiv(s.Cog, WG_BM);
+      constexpr int BK = Mma<T>::BK;
+      // split positions so that the launch has >= ~2048 workgroups; chunks are multiples of BK
+      long base = (long)nblk * co_tiles * s.K2;
+      int nchunks = (int)((2048 + base - 1) / base);
+      int pchunk = cdiv(cdiv(s.P, nchunks), BK) * BK;
+      if (pchunk < BK) pchunk = BK;
+      nchunks = cdiv(s.P, pchunk);
+      dim3 grid(nchunks, nblk * co_tiles, s.K2);
+      D2_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "deform_conv: too many channel blocks");
+      if (vec)
+        hipLaunchKernelGGL((dcn_bwd_weight_kernel<T, true>), grid, dim3(WG_THREADS), 0, st, s, (const T*)w.x_nhwc,
+                           (const T*)offset, (const T*)mask, (const T*)gout, w.gwr, pchunk, nblk);
+      else
+        hipLaunchKernelGGL((dcn_bwd_weight_kernel<T, false>), grid, dim3(WG_THREADS), 0, st, s, (const T*)w.x_nhwc,
+                           (const T*)offset, (const T*)mask, (const T*)gout, w.gwr, pchunk, nblk);
+      D2_LAUNCH_OK();
+      const long nw = (long)s.Co * s.Cg * s.K2;
+      hipLaunchKernelGGL((unpack_gw_kernel<T>), dim3(cdiv(nw, 256) > 4096 ? 4096 : cdiv(nw, 256)), dim3(256), 0, st,
+                         w.gwr, (T*)gweight, s.G, s.Cog, s.Cg, s.K2);
+      D2_LAUNCH_OK();
+    }
   }
   if (gbias) {
     hipLaunchKernelGGL((dcn_bias_grad_kernel<T>), dim3(s.Co), dim3(256), 0, st, (const T*)gout, (T*)gbias, s.B, s.Co,

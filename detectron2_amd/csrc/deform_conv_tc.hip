@@ -1717,7 +1717,7 @@ namespace d2amd {
 // unpack_gw_kernel like the generic path.
 struct BwwArgs {
   const void *x, *offset, *mask, *gout;  // x NHWC; gout NCHW [B][Co][L]
-  float* gwr;                            // [g][tap][co][ci] fp32, zero-filled
+  float* gwr;                            // partial tiles [tile][chunk of 4 waves][64 co][64 ci] fp32 (see the epilogue)
   int n_cot, n_cit, pch, total, ksteps_per_image;
 };
 
@@ -1925,19 +1925,44 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_weight_tc_kernel(DcnShape s, B
 #pragma unroll
       for (int q = 0; q < 16; q++) red[wid][((m * 2 + n) * 16 + q) * 64 + lane] = acc[m][n][q];
   __syncthreads();
+  // Round 3: the workgroup's sum goes to ITS OWN 64 x 64 slot of a partial-tile array with plain 128-B row stores and
+  // unpack_gw_partials_kernel adds the slots of a tile in chunk order while it converts -- no device-scope fp32 atomics
+  // (2.4 M per call, ~36 us of the kernel in the r01 ablation, more with more chunks), no zero fill of the staging
+  // buffer, and a weight gradient that is bit-identical run to run.
   {
     const int m = wid >> 1, n = wid & 1;  // this wave's quarter: block (m, n) of the tile
-    float* dst = a.gwr + (((long)g * s.K2 + tap) * s.Cog) * s.Cg + (cabs - g * s.Cg);
+    const long tile = (((long)g * s.K2 + tap) * a.n_cot + cot) * a.n_cit + cit;
+    float* dst = a.gwr + (tile * (a.pch >> 2) + (pc >> 2)) * 4096;
 #pragma unroll
     for (int q = 0; q < 16; q++) {
       const int e = (wid * 16 + q) * 64 + lane;
       const float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
-      const int co = co0 + m * 32 + frag_row(q, lane);
-      if (co < s.Cog) {
-        if (AB & 16) { if (v == 123.456f) dst[0] = 1.f; }
-        else atomicAdd(dst + (long)co * s.Cg + n * 32 + n32, v);
-      }
+      const int row = m * 32 + frag_row(q, lane);  // output channel inside the tile (rows past Cog are never read)
+      if (AB & 16) { if (v == 123.456f) dst[0] = 1.f; }
+      else dst[row * 64 + n * 32 + n32] = v;
     }
+  }
+}
+
+// grad_weight (Co, Cg, K2) T = the partial tiles of dcn_bwd_weight_tc_kernel summed in chunk order.  One thread per
+// (tile, row, column): the partials are read as coalesced rows.
+template <typename T>
+__global__ __launch_bounds__(256) void unpack_gw_partials_kernel(const float* __restrict__ part, T* __restrict__ gw, int G,
+                                                                int Cog, int Cg, int K2, int n_cot, int n_cit, int nch4) {
+  const long n = (long)G * K2 * n_cot * n_cit * 4096;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int col = (int)(i & 63), row = (int)((i >> 6) & 63);
+    long t = i >> 12;
+    const int cit = (int)(t % n_cit); t /= n_cit;
+    const int cot = (int)(t % n_cot); t /= n_cot;
+    const int tap = (int)(t % K2);
+    const int g = (int)(t / K2);
+    const int co = cot * 64 + row, ci = cit * 64 + col;
+    if (co >= Cog || ci >= Cg) continue;
+    const float* p = part + (i >> 12) * (long)nch4 * 4096 + (i & 4095);
+    float v = 0.f;
+    for (int c = 0; c < nch4; c++) v += p[(long)c * 4096];
+    gw[(((long)g * Cog + co) * Cg + ci) * K2 + tap] = from_f32<T>(v);
   }
 }
 
@@ -1960,13 +1985,14 @@ TcBwwPlan dcn_tc_plan_bww(const DcnShape& s, int dtype) {
   const char* e = getenv("D2AMD_DCN_BWW_PCH");  // profiling switch
   if (e && atoi(e) > 0) pch = (atoi(e) + 3) / 4 * 4;
   pl.pch = (int)pch;
+  pl.partial_bytes = (size_t)tiles * (pch / 4) * 4096 * sizeof(float);
   pl.ok = true;
   return pl;
 }
 
 template <typename T>
 int dcn_tc_backward_weight(const DcnShape& s, const TcBwwPlan& pl, const void* x_nhwc, const void* offset,
-                           const void* mask, const void* gout_nchw, float* gwr, hipStream_t st) {
+                           const void* mask, const void* gout_nchw, float* gwr, void* grad_weight, hipStream_t st) {
   BwwArgs a{};
   a.x = x_nhwc; a.offset = offset; a.mask = mask; a.gout = gout_nchw; a.gwr = gwr;
   a.n_cot = pl.n_cot; a.n_cit = pl.n_cit; a.pch = pl.pch; a.ksteps_per_image = pl.ksteps_per_image;
@@ -1992,12 +2018,16 @@ int dcn_tc_backward_weight(const DcnShape& s, const TcBwwPlan& pl, const void* x
   }
   if (timed) timing_end("dcn_bwd_weight", st);
   D2_LAUNCH_OK();
+  const long n = (long)s.G * s.K2 * pl.n_cot * pl.n_cit * 4096;
+  hipLaunchKernelGGL((unpack_gw_partials_kernel<T>), dim3(cdiv(n, 256) > 8192 ? 8192 : cdiv(n, 256)), dim3(256), 0, st,
+                     (const float*)gwr, (T*)grad_weight, s.G, s.Cog, s.Cg, s.K2, pl.n_cot, pl.n_cit, pl.pch / 4);
+  D2_LAUNCH_OK();
   return D2AMD_OK;
 }
 
 template int dcn_tc_backward_weight<bf16_t>(const DcnShape&, const TcBwwPlan&, const void*, const void*, const void*,
-                                            const void*, float*, hipStream_t);
+                                            const void*, float*, void*, hipStream_t);
 template int dcn_tc_backward_weight<f16_t>(const DcnShape&, const TcBwwPlan&, const void*, const void*, const void*,
-                                           const void*, float*, hipStream_t);
+                                           const void*, float*, void*, hipStream_t);
 
 }  // namespace d2amd
