@@ -644,12 +644,15 @@ class GraphedStep:
                     backward()
         cur.wait_stream(side)
         torch.cuda.synchronize()
+        # thread_local: with a process group alive, RCCL's watchdog thread polls its events (hipEventQuery) whenever
+        # it likes; under the default global capture mode that call fails with "operation not permitted when stream is
+        # capturing" and takes the process down (seen once in ~10 runs at world size 1)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             out = fn()
         if backward is not None:
             g.second = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g.second, pool=g.pool()):
+            with torch.cuda.graph(g.second, pool=g.pool(), capture_error_mode="thread_local"):
                 backward()
         return g, out
 
@@ -1297,7 +1300,7 @@ def main():
             import copy
 
             extra = {}
-            for name, fn, steps, warm in (("retinanet_100k", bench_retinanet, 20, 3), ("dcn_r50", bench_dcn, 10, 2)):
+            for name, fn, steps, warm in (("retinanet_100k", bench_retinanet, 50, 20), ("dcn_r50", bench_dcn, 10, 3)):
                 a2 = copy.copy(args)
                 a2.workload, a2.steps, a2.warmup, a2.no_cpu_baseline = name, steps, warm, True
                 torch.cuda.synchronize()
