@@ -43,7 +43,8 @@ struct PoolLevels {
   float canonical_size;
   unsigned long long* dbg;  // profiling only (D2AMD_PROFILE builds): cycle stamps of one workgroup
   int dbg_block;
-  int ablate;  // profiling only (D2AMD_ABLATE): bit0 skip gather, bit1 skip weights, bit2 skip list scan
+  int ablate;  // profiling only (D2AMD_ABLATE): bit0 skip gather, bit1 skip weights, bit2 skip list scan; MFMA tile
+               // gather: bit3 no pairing, bit4 no loads of dY, bit5 no weight images, bit6 no items (empty lists), bit7 no stores
   const int* tile_cnt;    // backward: per tile, number of ROIs that touch it (nullptr: tiles scan the records)
   const void* tile_list;  // backward: [tile][TILE_CAP] TileEntry in ROI order (valid when tile_cnt[tile] <= TILE_CAP)
   unsigned long long* wgstamps;  // profiling only (D2AMD_POOL_STAMPS): per workgroup {start, lists done, loop done, end, #ROIs}
@@ -55,7 +56,8 @@ struct PoolLevels {
   int* part_tickets;    // ... and one arrival counter per split tile (at its first scratch slot)
   int* qctr;         // backward: the queues' counters (TileQueues::mem); non-null: persistent workgroups FETCH their tiles
                      // (take counter per XCD, then the other XCDs' queues) instead of serving slot blockIdx >> 3
-  int qsteal;        // how many OTHER XCDs' queues a persistent workgroup tries once its own is empty (0: none)
+  int qsteal;        // how many OTHER XCDs' queues a persistent workgroup tries once its own is empty (0: none);
+                     // < 0: no take counters, a fixed stride through the own XCD's queue
   int accumulate;    // backward: 1 = grad_input already holds a gradient (another pooler's): add to it, skip empty tiles
   const int* perm;   // forward: ROI processing order (roi_order_kernel), nullptr: workgroup b pools ROI b
 };
@@ -101,6 +103,25 @@ __device__ __forceinline__ void unpack16(const raw16& r, float (&f)[8], f16_t) {
 __device__ __forceinline__ raw16 pack16(const float (&f)[4], float) {
   return raw16{__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3])};
 }
+// (bf16 by bit arithmetic, what from_f32<bf16_t> was before it went to the hardware converter: the LDS-staged fallback
+// kernel below sits at its register cap and spills 3 VGPRs with the other instruction mix)
+__device__ __forceinline__ uint32_t bf16_rne_bits(float x) {
+  uint32_t u = __float_as_uint(x);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40;
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+__device__ __forceinline__ raw16 pack16_staged(const float (&f)[8], bf16_t) {
+  uint32_t w[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) w[i] = bf16_rne_bits(f[2 * i]) | (bf16_rne_bits(f[2 * i + 1]) << 16);
+  return raw16{w[0], w[1], w[2], w[3]};
+}
+template <typename T>
+__device__ __forceinline__ raw16 pack16(const float (&f)[8], T);
+__device__ __forceinline__ raw16 pack16(const float (&f)[4], float);
+template <typename T, int N>
+__device__ __forceinline__ raw16 pack16_staged(const float (&f)[N], T t) { return pack16(f, t); }
 template <typename T>
 __device__ __forceinline__ raw16 pack16(const float (&f)[8], T) {
   uint32_t w[4];
@@ -1307,11 +1328,11 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_staged_kernel(PoolLevels L
       if (L.accumulate) {  // uniform: grad = round(held + round(own)), what autograd's add of two gradients gives
         float held[VEC], own[VEC];
         unpack16(*reinterpret_cast<const raw16*>(gi + (long)i * W * C), held, T{});
-        unpack16(pack16(acc[i], T{}), own, T{});
+        unpack16(pack16_staged(acc[i], T{}), own, T{});
 #pragma unroll
         for (int q = 0; q < VEC; q++) acc[i][q] = held[q] + own[q];
       }
-      *reinterpret_cast<raw16*>(gi + (long)i * W * C) = pack16(acc[i], T{});
+      *reinterpret_cast<raw16*>(gi + (long)i * W * C) = pack16_staged(acc[i], T{});
     }
   }
   if (wst) wst[3] = wall_clock64();
@@ -1366,6 +1387,31 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
   // of a coarse level are 16 long lists on ONE queue: 40.9 .. 53.9 us of work per resident slot) and every slot lost
   // ~2 us per tile between a workgroup's end and the dispatch of the next (profiles/r03/pool_bwd_*_timeline_static.txt).
   constexpr bool dynamic = DYN;  // (host: L.queue and L.qctr are set)
+  // STRIDE mode (L.qsteal < 0; an experiment, D2AMD_POOL_STRIDE=1): workgroup j of XCD q serves entries j, j + G,
+  // j + 2 G ... of q's queue (G = workgroups per XCD) -- no take counter.  The entry of the next round is fetched
+  // (scalar load) at the top of a tile and its ROI list during the epilogue.
+  const bool stride = dynamic && L.qsteal < 0;  // uniform
+  int nx_e = -1, nx_pinfo = 0, nx_sl = 0, nx_lg = 0;  // (uniform) stride: the entry of the NEXT round
+  bool pre_list = false;                              // (uniform) stride: this tile's list is already in S.list / S.geo
+  auto fetch_strided = [&](int r, int& e, int& pi, int& sl, int& lg2) __attribute__((always_inline)) {
+    // (constant address space: scalar loads, issued here and waited for where the values are used -- the queues and
+    // their counts were written by earlier launches)
+    typedef const int __attribute__((address_space(4))) * cint_p;
+    typedef const unsigned long long __attribute__((address_space(4))) * cu64_p;
+    const int q = (int)(blockIdx.x & 7);
+    const int i = (int)(blockIdx.x >> 3) + r * (int)(gridDim.x >> 3);
+    cint_p ctr = (cint_p)(unsigned long long)L.qctr;
+    const int nh = ctr[q], nl = ctr[16 + q];
+    const int ent = nslab == 1 ? i : i / nslab;
+    e = -1; pi = 1 << 8; sl = 0; lg2 = 0;
+    if (ent < nh + nl) {
+      const int slot = ent < nh ? ent : L.qcap - 1 - (ent - nh);
+      const unsigned long long e2 = ((cu64_p)(unsigned long long)L.queue)[(long)q * L.qcap + slot];
+      e = (int)(unsigned)e2; pi = (int)(unsigned)(e2 >> 32);
+      sl = i - ent * nslab;
+      lg2 = ((slot * nslab + sl) << 3) | q;
+    }
+  };
   if (threadIdx.x == 0) s_fetch[3] = 0;  // queues found empty so far, starting at the home XCD's (thread 0's)
   for (int round = 0;; round++) {
   // (the thread index passes through an opaque move per tile: everything derived from it is then recomputed per tile
@@ -1375,7 +1421,16 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
   asm volatile("" : "+v"(tid));
   const int lane = tid & 63;
   int logical, slab, tile, qcnt = -1, pinfo = 1 << 8;  // pinfo: part | parts << 8 | scratch slot << 16
-  if (dynamic) {
+  if (dynamic && stride) {
+    if (round) __syncthreads();  // the previous tile's readers of the shared buffers are done; its prefetched list is in
+    int e;
+    if (round == 0) fetch_strided(0, e, pinfo, slab, logical);
+    else { e = nx_e; pinfo = nx_pinfo; slab = nx_sl; logical = nx_lg; }
+    if (e < 0) return;  // (uniform)
+    fetch_strided(round + 1, nx_e, nx_pinfo, nx_sl, nx_lg);
+    tile = e & 0xffffff;
+    qcnt = (int)((unsigned)e >> 24);
+  } else if (dynamic) {
     if (round) __syncthreads();  // the previous tile's readers of the shared buffers (and of s_fetch) are done
     if (tid == 0) {
       int e = -1, sl = 0, lg2 = 0, steal = s_fetch[3];
@@ -1454,7 +1509,10 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
 #endif
   STAMP();
 
-  // wave w accumulates channels [32 w, 32 w + 32) of the slab: acc[mt] = pixels of tile rows 4 mt .. 4 mt + 3
+  // wave w accumulates channels [32 w, 32 w + 32) of the slab, TRANSPOSED (the staged dY is the A operand, the weight
+  // image the B operand): acc[mt] = [32 channels] x [pixels of tile rows 4 mt .. 4 mt + 3]; lane = pixel, a register
+  // quad = 4 consecutive channels -- the epilogue packs a quad into ONE 8-B LDS write (lane = channel, register =
+  // pixel needed 32 2-B writes per lane: 2.5 us per tile, a quarter of the average tile)
   f32x16_t acc[2];
 #pragma unroll
   for (int i = 0; i < 16; i++) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
@@ -1518,7 +1576,7 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
     const int pa = w.ph_lo + c * w.rpc;
     const int nb = min(w.rpc, w.ph_lo + w.nph - pa) * w.npw;  // bins of this item (<= WINCAP); 0 for an empty window
     const T* gk = gout + (long)S.list[li] * PH * PW * C + cofs;
-    if (nb > 0) {  // uniform
+    if (nb > 0 && !(L.ablate & 16)) {  // uniform
       // 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate): bin index < 1024, C <= 8192 (checked by the host)
       const int j0 = min(sb, nb - 1);
       const int q0 = (int)((j0 + 0.5f) * w.rnpw);  // j0 / npw
@@ -1542,7 +1600,7 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
     return min(w.rpc, w.nph - c * w.rpc) * w.npw;  // 0 for an empty window
   };
   auto issue_loads16 = [&](int li, const Window& w, int nb, raw16& r) __attribute__((always_inline)) {
-    if (nb > 0) {  // uniform.  chunk 0 of a one-chunk window: bin sb of its nb <= 16 bins
+    if (nb > 0 && !(L.ablate & 16)) {  // uniform.  chunk 0 of a one-chunk window: bin sb of its nb <= 16 bins
       const T* gk = gout + (long)S.list[li] * PH * PW * C + cofs;
       const int j0 = min(sb, nb - 1);
       const int q0 = (int)((j0 + 0.5f) * w.rnpw);  // j0 / npw
@@ -1554,7 +1612,7 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
   // the k step is contracted whenever the OTHER half has bins)
   auto build_wimg_half = [&](int buf, int h, int slot, const Window& w, int nb) __attribute__((always_inline)) {
     const int px = lane, kq = (tid >> 6) * 4, r = px >> 3, cx = px & 7;
-    if ((kq >> 4) != h) return;  // uniform per wave
+    if ((kq >> 4) != h || (L.ablate & 32)) return;  // uniform per wave
     const int kl = kq & 15;
     int q = (int)((kl + 0.5f) * w.rnpw);
     int pi = kl - (int)__umul24(q, w.npw);
@@ -1588,7 +1646,7 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
     const int px = lane, kq = (tid >> 6) * 4, r = px >> 3, cx = px & 7;
     const int pa = w.ph_lo + c * w.rpc;
     const int nb = min(w.rpc, w.ph_lo + w.nph - pa) * w.npw;
-    if (kq >= ((nb + 15) & ~15)) return;  // uniform per wave
+    if (kq >= ((nb + 15) & ~15) || (L.ablate & 32)) return;  // uniform per wave
     int q = (int)((kq + 0.5f) * w.rnpw);  // kq / npw; the following bins advance (q, pi) incrementally
     int pi = kq - (int)__umul24(q, w.npw);
     const float* wyp = &S.WyT[((slot << lg) + pa) * TILE + r];
@@ -1636,8 +1694,8 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
         const int px = 32 * mt + (lane & 31);
         const s16x8_t ah = *reinterpret_cast<const s16x8_t*>(&M.Whi[buf][px][16 * ks + 8 * kh]);
         const s16x8_t al = *reinterpret_cast<const s16x8_t*>(&M.Wlo[buf][px][16 * ks + 8 * kh]);
-        acc[mt] = pool_mma(ah, b, acc[mt], T{});
-        acc[mt] = pool_mma(al, b, acc[mt], T{});
+        acc[mt] = pool_mma(b, ah, acc[mt], T{});
+        acc[mt] = pool_mma(b, al, acc[mt], T{});
       }
     }
   };
@@ -1651,7 +1709,7 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
       const int part = pinfo & 0xff, parts = (pinfo >> 8) & 0xff;
       const int len = (c + parts - 1) / parts, lo = part * len, hi = min(c, lo + len);
       tl_cnt = max(hi - lo, 0);
-      if (tid < tl_cnt) {
+      if (!pre_list && tid < tl_cnt) {
         const TileEntry e = ((const TileEntry*)L.tile_list)[(long)gtile * TILE_CAP + lo + tid];
         S.list[tid] = e.roi;
         S.geo[tid] = e.g;
@@ -1685,6 +1743,7 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
       nlist = run;
     }
     if (L.wgstamps) { WST(1, wall_clock64()); wst_n += nlist; }
+    if (L.ablate & 64) nlist = 0;
     if (nlist == 0) continue;  // uniform
     __syncthreads();           // list complete
     if (!prelist) {
@@ -1785,7 +1844,34 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
 #ifdef D2AMD_PROFILE
   if (dbg_on) { L.dbg[127] = dbg_n; L.dbg[126] = 0; L.dbg[125] = __builtin_readcyclecounter() - L.dbg[0]; }
 #endif
-  WST(2, wall_clock64());
+#define WST2_AT(k) do { if (L.wgstamps && ((L.ablate >> 8) & 7) == (k)) WST(2, wall_clock64()); } while (0)
+  WST2_AT(0);  // (D2AMD_ABLATE bits 8-10 move the "loop done" stamp down the epilogue: 1 = behind its first barrier,
+               // 2 = behind the LDS writes, 3 = behind the second barrier, 4 = behind the global stores)
+  // ---- stride mode: the ROI list of the NEXT tile is loaded now and lands in S.list / S.geo behind the epilogue.
+  // Issued unconditionally from a clamped (valid) address and stored under a uniform count: a value defined under one
+  // condition and used under another is live around the whole tile loop for the register allocator.
+  int pf_cnt = 0;  // (uniform) entries to store; 0: nothing prefetched
+  uint4 pf0 = uint4{0u, 0u, 0u, 0u}, pf1 = pf0;  // a TileEntry as two 16-B words (a struct copy went through scratch)
+  if constexpr (DYN) {
+    long pf_at = 0;
+    if (stride && nx_e >= 0 && L.tile_cnt && ((pinfo >> 8) & 0xff) <= 1) {
+      const int ntile = nx_e & 0xffffff, nc = (int)((unsigned)nx_e >> 24);
+      int nlvl = 0;
+#pragma unroll
+      for (int l = 1; l < POOL_MAX_LEVELS; l++)
+        if (l < L.num_levels && ntile >= L.tile_base[l]) nlvl = l;
+      if (nc <= TILE_CAP) {
+        const int part = nx_pinfo & 0xff, parts = (nx_pinfo >> 8) & 0xff;
+        const int len = (nc + parts - 1) / parts, lo = part * len, hi = min(nc, lo + len);
+        pf_cnt = max(hi - lo, 0);
+        pf_at = (long)(ids.first[nlvl] + (ntile - L.tile_base[nlvl])) * TILE_CAP + lo;
+      }
+    }
+    pre_list = pf_cnt > 0;
+    const uint4* pfp = reinterpret_cast<const uint4*>((const TileEntry*)L.tile_list + pf_at + min(tid, max(pf_cnt - 1, 0)));
+    pf0 = pfp[0];
+    pf1 = pfp[1];
+  }
   // ---- split list: this part's accumulators go to its scratch slot; the last part to arrive adds all parts in part
   // order and writes the tile.  Stores / loads / the ticket are device-scope relaxed atomics (performed at the memory
   // side, visible to every XCD once acknowledged -- the protocol of topk.hip's segment barriers); nothing waits.
@@ -1806,7 +1892,7 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
     __syncthreads();
     if (s_fetch[5] != parts - 1) {  // uniform: another part finishes this tile
       WST(3, wall_clock64());
-      WST(4, (unsigned long long)wst_n | (unsigned long long)(blockIdx.x & 7) << 32 | 1ull << 40);  // (bit 40: a part)
+      WST(4, (unsigned long long)wst_n | (unsigned long long)blockIdx.x << 32 | 1ull << 56);  // (bit 56: a part)
       if (!dynamic) break;
       continue;
     }
@@ -1825,16 +1911,25 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
   // ---- epilogue: accumulators (lane = channel, registers = pixels) -> LDS [pixel][channel] in the I/O dtype ->
   // 16-B channel vectors per pixel (every pixel of grad_input is written exactly once)
   __syncthreads();  // everyone is done with D
+  WST2_AT(1);
   T* obuf = reinterpret_cast<T*>(&S.D[0][0][0]);  // 64 pixels x 256 channels x 2 B = the two D buffers
+  // (a pixel's 32 16-B chunks are stored at chunk ^ (pixel & 31): the 32 lanes of a half-wave write the SAME chunk of
+  // 32 different pixels, 512 B apart -- one bank group without the swizzle)
   if (slab * (LPP * VEC) + 32 * wave < C) {
 #pragma unroll
-    for (int mt = 0; mt < 2; mt++)
+    for (int mt = 0; mt < 2; mt++) {
+      const int px = 32 * mt + (lane & 31);
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int px = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        obuf[px * (LPP * VEC) + 32 * wave + (lane & 31)] = from_f32<T>(acc[mt][r]);
+      for (int g = 0; g < 4; g++) {
+        const int ch = 32 * wave + 8 * g + 4 * (lane >> 5);  // 4 consecutive channels: half a 16-B chunk
+        uint2 w;
+        w.x = (uint32_t)from_f32<T>(acc[mt][4 * g]).v | ((uint32_t)from_f32<T>(acc[mt][4 * g + 1]).v << 16);
+        w.y = (uint32_t)from_f32<T>(acc[mt][4 * g + 2]).v | ((uint32_t)from_f32<T>(acc[mt][4 * g + 3]).v << 16);
+        *reinterpret_cast<uint2*>(obuf + px * (LPP * VEC) + (((ch >> 3) ^ (px & 31)) << 3) + (ch & 4)) = w;
       }
+    }
   }
+  WST2_AT(2);
   // Two copies of the store loop, one per mode (L.accumulate is uniform): the rows an accumulating thread adds to are
   // loaded, used and dead inside ONE block.  Defined under one `if` and used under another they were live around the
   // whole tile loop for the register allocator (16 VGPRs of a kernel at its cap: spilled to scratch).
@@ -1849,12 +1944,12 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
     for (int i = 0; i < TR; i++)
       held[i] = *reinterpret_cast<const raw16*>(gi + (long)max(min(i, H - 1 - (y0 + rh * TR)), -(rh * TR)) * W * C);
     __syncthreads();
-    if (mine) {
+    if (mine && !(L.ablate & 128)) {
 #pragma unroll
       for (int i = 0; i < TR; i++) {
         if (y0 + rh * TR + i >= H) break;
         const int px = (rh * TR + i) * TILE + col;
-        const raw16 v = *reinterpret_cast<const raw16*>(obuf + px * (LPP * VEC) + lp * VEC);
+        const raw16 v = *reinterpret_cast<const raw16*>(obuf + px * (LPP * VEC) + ((lp ^ (px & 31)) * VEC));
         float a[VEC], b[VEC];  // round(held + round(own)), what autograd's add of two gradients gives
         unpack16(held[i], a, T{});
         unpack16(v, b, T{});
@@ -1865,20 +1960,32 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
     }
   } else {
     __syncthreads();
-    if (cg_ok && x0 + col < W) {
+    WST2_AT(3);
+    if (cg_ok && x0 + col < W && !(L.ablate & 128)) {
       T* gi = (T*)L.data[lvl] + (((long)n * H + y0 + rh * TR) * W + x0 + col) * C + cofs;
 #pragma unroll
       for (int i = 0; i < TR; i++) {
         if (y0 + rh * TR + i >= H) break;
         const int px = (rh * TR + i) * TILE + col;
         *reinterpret_cast<raw16*>(gi + (long)i * W * C) =
-            *reinterpret_cast<const raw16*>(obuf + px * (LPP * VEC) + lp * VEC);
+            *reinterpret_cast<const raw16*>(obuf + px * (LPP * VEC) + ((lp ^ (px & 31)) * VEC));
       }
     }
   }
+  WST2_AT(4);
+  if constexpr (DYN) {
+    if (tid < pf_cnt) {  // (the list of this tile is dead since the barrier in front of the epilogue)
+      S.list[tid] = (int)pf1.z;  // TileEntry = {HitGeo (6 words), roi, pad}
+      HitGeo g;
+      g.start_h = __uint_as_float(pf0.x); g.start_w = __uint_as_float(pf0.y); g.bin_h = __uint_as_float(pf0.z);
+      g.bin_w = __uint_as_float(pf0.w); g.inv = __uint_as_float(pf1.x); g.grid = (int)pf1.y;
+      S.geo[tid] = g;
+    }
+  }
   WST(3, wall_clock64());
-  WST(4, (unsigned long long)wst_n | (unsigned long long)(blockIdx.x & 7) << 32);  // #ROIs, + the XCD that ran the tile
+  WST(4, (unsigned long long)wst_n | (unsigned long long)blockIdx.x << 32);  // #ROIs, + the workgroup that ran the tile (& 7: its XCD)
 #undef WST
+#undef WST2_AT
   if (!dynamic) break;
   }  // next tile
 }
@@ -2354,6 +2461,11 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
         if (!static_slots && !stamp_path_static()) L.qctr = Q.mem;
         static const int steal_env = getenv("D2AMD_POOL_STEAL") ? atoi(getenv("D2AMD_POOL_STEAL")) : 0;
         L.qsteal = steal_env < 0 ? 0 : steal_env > 7 ? 7 : steal_env;
+        // D2AMD_POOL_STRIDE=1 (experiment): no take counters -- workgroup j of an XCD walks its queue with a fixed
+        // stride, next entry and next list prefetched.  Measured: the gap between tiles halves (1.14 -> 0.56 us) but the
+        // unsorted queue leaves the workgroups 25 us apart at the end (takes: 10 us): 90.8 us against 74.3
+        static const bool stride_env = getenv("D2AMD_POOL_STRIDE") && atoi(getenv("D2AMD_POOL_STRIDE")) == 1;
+        if (stride_env && steal_env <= 0) L.qsteal = -1;
         auto launch = [&](auto dyn_fn, auto static_fn) {
           if (L.qctr) {
             const long r = resident_workgroups((const void*)dyn_fn, 2 * CT) & ~7l;

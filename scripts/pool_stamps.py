@@ -35,3 +35,19 @@ for ps, name in ((0, "fine levels"), (1, "coarse levels")):
         m = n == k
         if m.any():
             print(f"  tiles with {k} ROIs: {m.sum()}, total mean {(en - st)[m].mean():.2f} us, rois-phase mean {(lp - ls)[m].mean():.2f}")
+    # chains of the persistent workgroups (bits 32..55 of the last stamp = blockIdx.x): busy time, gaps between tiles
+    wg = (d[:, 5] >> 32) & 0xffffff
+    if len(np.unique(wg)) > 8:
+        busy, gaps, ends, cnts = [], [], [], []
+        for b in np.unique(wg):
+            m = wg == b
+            o = np.argsort(st[m])
+            s_, e_ = st[m][o], en[m][o]
+            busy.append((e_ - s_).sum()); ends.append(e_.max()); cnts.append(m.sum())
+            gaps += list(s_[1:] - e_[:-1])
+        busy, ends, gaps, cnts = map(np.array, (busy, ends, gaps, cnts))
+        print(f"  per workgroup ({len(busy)}): tiles mean {cnts.mean():.2f} max {cnts.max()}; busy mean {busy.mean():.1f} p90 {np.percentile(busy, 90):.1f} max {busy.max():.1f} us; "
+              f"last end mean {ends.mean():.1f} p10 {np.percentile(ends, 10):.1f} max {ends.max():.1f}; gap between tiles mean {gaps.mean():.2f} p90 {np.percentile(gaps, 90):.2f} max {gaps.max():.2f} us")
+        for q in range(8):
+            m = (wg & 7) == q
+            print(f"    XCD {q}: {m.sum()} tiles, rois {n[m].sum()}, busy sum {(en - st)[m].sum():.0f} us, first start {st[m].min():.1f} last end {en[m].max():.1f}")
