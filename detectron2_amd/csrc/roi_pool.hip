@@ -56,8 +56,7 @@ struct PoolLevels {
   int* part_tickets;    // ... and one arrival counter per split tile (at its first scratch slot)
   int* qctr;         // backward: the queues' counters (TileQueues::mem); non-null: persistent workgroups FETCH their tiles
                      // (take counter per XCD, then the other XCDs' queues) instead of serving slot blockIdx >> 3
-  int qsteal;        // how many OTHER XCDs' queues a persistent workgroup tries once its own is empty (0: none);
-                     // < 0: no take counters, a fixed stride through the own XCD's queue
+  int qsteal;        // how many OTHER XCDs' queues a persistent workgroup tries once its own is empty (0: none)
   int accumulate;    // backward: 1 = grad_input already holds a gradient (another pooler's): add to it, skip empty tiles
   const int* perm;   // forward: ROI processing order (roi_order_kernel), nullptr: workgroup b pools ROI b
 };
@@ -1387,31 +1386,10 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
   // of a coarse level are 16 long lists on ONE queue: 40.9 .. 53.9 us of work per resident slot) and every slot lost
   // ~2 us per tile between a workgroup's end and the dispatch of the next (profiles/r03/pool_bwd_*_timeline_static.txt).
   constexpr bool dynamic = DYN;  // (host: L.queue and L.qctr are set)
-  // STRIDE mode (L.qsteal < 0; an experiment, D2AMD_POOL_STRIDE=1): workgroup j of XCD q serves entries j, j + G,
-  // j + 2 G ... of q's queue (G = workgroups per XCD) -- no take counter.  The entry of the next round is fetched
-  // (scalar load) at the top of a tile and its ROI list during the epilogue.
-  const bool stride = dynamic && L.qsteal < 0;  // uniform
-  int nx_e = -1, nx_pinfo = 0, nx_sl = 0, nx_lg = 0;  // (uniform) stride: the entry of the NEXT round
-  bool pre_list = false;                              // (uniform) stride: this tile's list is already in S.list / S.geo
-  auto fetch_strided = [&](int r, int& e, int& pi, int& sl, int& lg2) __attribute__((always_inline)) {
-    // (constant address space: scalar loads, issued here and waited for where the values are used -- the queues and
-    // their counts were written by earlier launches)
-    typedef const int __attribute__((address_space(4))) * cint_p;
-    typedef const unsigned long long __attribute__((address_space(4))) * cu64_p;
-    const int q = (int)(blockIdx.x & 7);
-    const int i = (int)(blockIdx.x >> 3) + r * (int)(gridDim.x >> 3);
-    cint_p ctr = (cint_p)(unsigned long long)L.qctr;
-    const int nh = ctr[q], nl = ctr[16 + q];
-    const int ent = nslab == 1 ? i : i / nslab;
-    e = -1; pi = 1 << 8; sl = 0; lg2 = 0;
-    if (ent < nh + nl) {
-      const int slot = ent < nh ? ent : L.qcap - 1 - (ent - nh);
-      const unsigned long long e2 = ((cu64_p)(unsigned long long)L.queue)[(long)q * L.qcap + slot];
-      e = (int)(unsigned)e2; pi = (int)(unsigned)(e2 >> 32);
-      sl = i - ent * nslab;
-      lg2 = ((slot * nslab + sl) << 3) | q;
-    }
-  };
+  // (Tried and dropped, profiles/r03/pool_bwd/README.md: the take for the NEXT tile issued when the item loop ends and
+  // resolved behind the epilogue's second barrier, the next ROI list loaded while the pixels are stored -- the gap between
+  // tiles went 1.11 -> 0.44 us and the epilogue 1.53 -> 2.59 us: every wait of a wave is "wait for all my memory
+  // operations" (vmcnt counts loads, stores and returning atomics in order), so the latency only moves.)
   if (threadIdx.x == 0) s_fetch[3] = 0;  // queues found empty so far, starting at the home XCD's (thread 0's)
   for (int round = 0;; round++) {
   // (the thread index passes through an opaque move per tile: everything derived from it is then recomputed per tile
@@ -1421,22 +1399,18 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
   asm volatile("" : "+v"(tid));
   const int lane = tid & 63;
   int logical, slab, tile, qcnt = -1, pinfo = 1 << 8;  // pinfo: part | parts << 8 | scratch slot << 16
-  if (dynamic && stride) {
-    if (round) __syncthreads();  // the previous tile's readers of the shared buffers are done; its prefetched list is in
-    int e;
-    if (round == 0) fetch_strided(0, e, pinfo, slab, logical);
-    else { e = nx_e; pinfo = nx_pinfo; slab = nx_sl; logical = nx_lg; }
-    if (e < 0) return;  // (uniform)
-    fetch_strided(round + 1, nx_e, nx_pinfo, nx_sl, nx_lg);
-    tile = e & 0xffffff;
-    qcnt = (int)((unsigned)e >> 24);
-  } else if (dynamic) {
+  if (dynamic) {
     if (round) __syncthreads();  // the previous tile's readers of the shared buffers (and of s_fetch) are done
     if (tid == 0) {
       int e = -1, sl = 0, lg2 = 0, steal = s_fetch[3];
       while (steal <= L.qsteal) {
         const int q = ((int)blockIdx.x + steal) & 7;
-        const int i = atomicAdd(L.qctr + QTAKE + QTAKE_PITCH * q, 1);
+        // the FIRST tile of a workgroup is entry blockIdx >> 3 of its own queue, without a take: 64 workgroups hitting
+        // one counter in the same microsecond are served one after the other (~0.1 us each); the counter hands out the
+        // entries from G = workgroups per XCD on
+        const int G = (int)(gridDim.x >> 3);
+        const int i = round == 0 && steal == 0 ? (int)(blockIdx.x >> 3)
+                                               : G + atomicAdd(L.qctr + QTAKE + QTAKE_PITCH * q, 1);
         const int nh = L.qctr[q], nl = L.qctr[16 + q];  // final: tile_lists_kernel is an earlier launch
         const int ent = i / nslab;
         if (ent < nh + nl) {
@@ -1709,10 +1683,15 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
       const int part = pinfo & 0xff, parts = (pinfo >> 8) & 0xff;
       const int len = (c + parts - 1) / parts, lo = part * len, hi = min(c, lo + len);
       tl_cnt = max(hi - lo, 0);
-      if (!pre_list && tid < tl_cnt) {
-        const TileEntry e = ((const TileEntry*)L.tile_list)[(long)gtile * TILE_CAP + lo + tid];
-        S.list[tid] = e.roi;
-        S.geo[tid] = e.g;
+      if (tid < tl_cnt) {
+        // (two 16-B loads, then the stores: as a struct copy the compiler split it into three loads, each waited for)
+        const uint4* ep = reinterpret_cast<const uint4*>((const TileEntry*)L.tile_list + (long)gtile * TILE_CAP + lo + tid);
+        const uint4 e0 = ep[0], e1 = ep[1];
+        S.list[tid] = (int)e1.z;  // TileEntry = {HitGeo (6 words), roi, pad}
+        HitGeo g;
+        g.start_h = __uint_as_float(e0.x); g.start_w = __uint_as_float(e0.y); g.bin_h = __uint_as_float(e0.z);
+        g.bin_w = __uint_as_float(e0.w); g.inv = __uint_as_float(e1.x); g.grid = (int)e1.y;
+        S.geo[tid] = g;
       }
     }
   }
@@ -1847,31 +1826,6 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
 #define WST2_AT(k) do { if (L.wgstamps && ((L.ablate >> 8) & 7) == (k)) WST(2, wall_clock64()); } while (0)
   WST2_AT(0);  // (D2AMD_ABLATE bits 8-10 move the "loop done" stamp down the epilogue: 1 = behind its first barrier,
                // 2 = behind the LDS writes, 3 = behind the second barrier, 4 = behind the global stores)
-  // ---- stride mode: the ROI list of the NEXT tile is loaded now and lands in S.list / S.geo behind the epilogue.
-  // Issued unconditionally from a clamped (valid) address and stored under a uniform count: a value defined under one
-  // condition and used under another is live around the whole tile loop for the register allocator.
-  int pf_cnt = 0;  // (uniform) entries to store; 0: nothing prefetched
-  uint4 pf0 = uint4{0u, 0u, 0u, 0u}, pf1 = pf0;  // a TileEntry as two 16-B words (a struct copy went through scratch)
-  if constexpr (DYN) {
-    long pf_at = 0;
-    if (stride && nx_e >= 0 && L.tile_cnt && ((pinfo >> 8) & 0xff) <= 1) {
-      const int ntile = nx_e & 0xffffff, nc = (int)((unsigned)nx_e >> 24);
-      int nlvl = 0;
-#pragma unroll
-      for (int l = 1; l < POOL_MAX_LEVELS; l++)
-        if (l < L.num_levels && ntile >= L.tile_base[l]) nlvl = l;
-      if (nc <= TILE_CAP) {
-        const int part = nx_pinfo & 0xff, parts = (nx_pinfo >> 8) & 0xff;
-        const int len = (nc + parts - 1) / parts, lo = part * len, hi = min(nc, lo + len);
-        pf_cnt = max(hi - lo, 0);
-        pf_at = (long)(ids.first[nlvl] + (ntile - L.tile_base[nlvl])) * TILE_CAP + lo;
-      }
-    }
-    pre_list = pf_cnt > 0;
-    const uint4* pfp = reinterpret_cast<const uint4*>((const TileEntry*)L.tile_list + pf_at + min(tid, max(pf_cnt - 1, 0)));
-    pf0 = pfp[0];
-    pf1 = pfp[1];
-  }
   // ---- split list: this part's accumulators go to its scratch slot; the last part to arrive adds all parts in part
   // order and writes the tile.  Stores / loads / the ticket are device-scope relaxed atomics (performed at the memory
   // side, visible to every XCD once acknowledged -- the protocol of topk.hip's segment barriers); nothing waits.
@@ -1973,15 +1927,6 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
     }
   }
   WST2_AT(4);
-  if constexpr (DYN) {
-    if (tid < pf_cnt) {  // (the list of this tile is dead since the barrier in front of the epilogue)
-      S.list[tid] = (int)pf1.z;  // TileEntry = {HitGeo (6 words), roi, pad}
-      HitGeo g;
-      g.start_h = __uint_as_float(pf0.x); g.start_w = __uint_as_float(pf0.y); g.bin_h = __uint_as_float(pf0.z);
-      g.bin_w = __uint_as_float(pf0.w); g.inv = __uint_as_float(pf1.x); g.grid = (int)pf1.y;
-      S.geo[tid] = g;
-    }
-  }
   WST(3, wall_clock64());
   WST(4, (unsigned long long)wst_n | (unsigned long long)blockIdx.x << 32);  // #ROIs, + the workgroup that ran the tile (& 7: its XCD)
 #undef WST
@@ -2461,11 +2406,9 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
         if (!static_slots && !stamp_path_static()) L.qctr = Q.mem;
         static const int steal_env = getenv("D2AMD_POOL_STEAL") ? atoi(getenv("D2AMD_POOL_STEAL")) : 0;
         L.qsteal = steal_env < 0 ? 0 : steal_env > 7 ? 7 : steal_env;
-        // D2AMD_POOL_STRIDE=1 (experiment): no take counters -- workgroup j of an XCD walks its queue with a fixed
-        // stride, next entry and next list prefetched.  Measured: the gap between tiles halves (1.14 -> 0.56 us) but the
-        // unsorted queue leaves the workgroups 25 us apart at the end (takes: 10 us): 90.8 us against 74.3
-        static const bool stride_env = getenv("D2AMD_POOL_STRIDE") && atoi(getenv("D2AMD_POOL_STRIDE")) == 1;
-        if (stride_env && steal_env <= 0) L.qsteal = -1;
+        // (tried and dropped, profiles/r03/pool_bwd/README.md: no take counters at all -- workgroup j of an XCD walking
+        // its queue with a fixed stride: the gap between tiles halves, but the unsorted queue leaves the workgroups 25 us
+        // apart at the end (takes: 10 us): 90.8 us against 74.3)
         auto launch = [&](auto dyn_fn, auto static_fn) {
           if (L.qctr) {
             const long r = resident_workgroups((const void*)dyn_fn, 2 * CT) & ~7l;
