@@ -462,6 +462,9 @@ def connected_forward(w, run=None, rpn_keys=None, roi_keys=None, sync=False):
                 keys_ready.record()
             return anchor_labels(w, rpn_keys)
 
+        # (forking this branch at the very START of the step instead was measured -- D2AMD_BENCH_FORK experiments,
+        # gpurun_out/r3z*: 0.465-0.48 against 0.458 ms; the branch the graph does not launch on starts ~10 us late, and
+        # the matcher slows the selection's latency-bound chain)
         done = find_top_rpn_proposals_fused(w.anchor_levels, w.rpn_logits, w.rpn_deltas, w.image_sizes, 0.7, 2000, 1000,
                                             0.0, True, defer=True, beside_nms=side, join_beside=False,
                                             host_result=sync)
@@ -494,7 +497,7 @@ def connected_forward(w, run=None, rpn_keys=None, roi_keys=None, sync=False):
 
     def targets_and_loss():
         idx = [samp["gt_index"][i, :MASK_ROWS].contiguous() for i in range(n)]
-        cls = samp["classes"][:, :MASK_ROWS].reshape(-1)
+        cls = samp["head_classes"].reshape(-1)  # (contiguous: written by the sampler, no copy launch on this branch)
         tg = run("mask_targets", lambda: crop_and_resize_batch(w.gt_masks, mask_boxes, 28, idx, w.crop_status))
         # background / padding rows among the 128 do not count (class 80 / -1): masked loss, row count on the device
         return run("mask_loss_fwd", lambda: mask_rcnn_loss_from_targets(w.mask_logits, cls, tg,

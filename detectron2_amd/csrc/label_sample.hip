@@ -54,6 +54,7 @@ struct LsBatch {
   int64_t *classes, *gt_index, *index;
   int* counts;
   float *rois, *head_rois;  // optional: the rows in pooler format (image, x1, y1, x2, y2); the first head_rows of each image
+  int64_t* head_classes;    // optional: the classes of those first head_rows rows, [image][head_rows] contiguous
   int head_rows, image0;    // image0: batch index of this launch's first image
 };
 
@@ -219,6 +220,7 @@ __global__ __launch_bounds__(LS_THREADS) void label_sample_kernel(const LsBatch 
     ls_write_rois(B, image, slot, box[k]);
     ob[slot] = box[k];
     oc[slot] = cls[k];
+    if (B.head_classes && slot < B.head_rows) B.head_classes[(long)(B.image0 + image) * B.head_rows + slot] = cls[k];
     og[slot] = besti[k];
     oi[slot] = c;
   }
@@ -226,6 +228,7 @@ __global__ __launch_bounds__(LS_THREADS) void label_sample_kernel(const LsBatch 
     ls_write_rois(B, image, t, make_float4(0, 0, 0, 0));
     ob[t] = make_float4(0, 0, 0, 0);
     oc[t] = -1;
+    if (B.head_classes && t < B.head_rows) B.head_classes[(long)(B.image0 + image) * B.head_rows + t] = -1;
     og[t] = 0;
     oi[t] = -1;
   }
@@ -246,7 +249,8 @@ extern "C" int d2amd_label_and_sample_proposals(const d2amd_sample_image* images
                                                 int max_positives, int64_t num_classes, int append_gt,
                                                 float* boxes_out, int64_t* classes_out, int64_t* gt_index_out,
                                                 int64_t* index_out, int32_t* counts_out, float* rois_out,
-                                                float* head_rois_out, int head_rows, void* stream) {
+                                                float* head_rois_out, int64_t* head_classes_out, int head_rows,
+                                                void* stream) {
   D2_CHECK_ARG(count >= 0 && (count == 0 || images != nullptr), "label_and_sample: bad image list");
   D2_CHECK_ARG(T >= 0 && T <= D2AMD_MATCHER_MAX_THRESHOLDS && labels != nullptr && (T == 0 || thresholds != nullptr),
                "label_and_sample: %d thresholds (max %d)", T, D2AMD_MATCHER_MAX_THRESHOLDS);
@@ -274,6 +278,7 @@ extern "C" int d2amd_label_and_sample_proposals(const d2amd_sample_image* images
   D2_CHECK_ARG(head_rows >= 0 && head_rows <= batch_size_per_image, "label_and_sample: bad head_rows");
   B.rois = rois_out;
   B.head_rois = head_rows > 0 ? head_rois_out : nullptr;
+  B.head_classes = head_rows > 0 ? head_classes_out : nullptr;
   B.head_rows = head_rows;
   for (int i0 = 0; i0 < count; i0 += LS_MAX_IMAGES) {
     const int c = count - i0 < LS_MAX_IMAGES ? count - i0 : LS_MAX_IMAGES;

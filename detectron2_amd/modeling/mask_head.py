@@ -69,8 +69,9 @@ class _MaskLossMasked(torch.autograd.Function):
             _C.check(L.d2amd_mask_rcnn_loss_forward_masked(_C.ptr(x), _C.ptr(gt_classes), _C.ptr(gt_masks), b, c, h * w,
                                                            _C.dtype_code(x), _C.ptr(loss), _C.ptr(stats), _C.ptr(ws),
                                                            ctypes.c_size_t(ws_bytes), _C.stream()))
-        ctx.save_for_backward(x, gt_classes, gt_masks)
-        ctx.rows = stats.detach()[5:].clone()  # the row count stays on the device; the backward reads it there
+        # the row count stays on the device; the backward reads it out of `stats` (saved: autograd's version check
+        # refuses a backward after an in-place change -- a copy of the one word was a launch at the end of the forward)
+        ctx.save_for_backward(x, gt_classes, gt_masks, stats)
         ctx.mark_non_differentiable(stats)
         ctx.set_materialize_grads(False)
         return loss, stats
@@ -80,13 +81,14 @@ class _MaskLossMasked(torch.autograd.Function):
     def backward(ctx, grad_loss, _grad_stats):
         if grad_loss is None:
             return None, None, None
-        x, gt_classes, gt_masks = ctx.saved_tensors
+        x, gt_classes, gt_masks, stats = ctx.saved_tensors
         b, c, h, w = x.shape
         g = grad_loss.detach().to(dtype=torch.float32).contiguous()
         grad = torch.empty_like(x)
         with _C.on_device(x.device):
             _C.check(_C.lib().d2amd_mask_rcnn_loss_backward_masked(
-                _C.ptr(x), _C.ptr(gt_classes), _C.ptr(gt_masks), _C.ptr(g), _C.ptr(ctx.rows), b, c, h * w,
+                _C.ptr(x), _C.ptr(gt_classes), _C.ptr(gt_masks), _C.ptr(g), ctypes.c_void_p(stats.data_ptr() + 40), b, c,
+                h * w,
                 _C.dtype_code(x), _C.ptr(grad), _C.stream()))
         return grad, None, None
 

@@ -228,11 +228,12 @@ _PREBIN_MODE = _os.environ.get("D2AMD_PREBIN", "none")
 # launch is one workgroup, 10-15 us, in front of the pooling kernel on the step's critical path: 0.521 / 0.527 ms per step
 # with it, 0.498 / 0.500 without (same box, gpurun_out/r3s).  Off unless D2AMD_FWD_ORDER=1.
 _FWD_ORDERED = _os.environ.get("D2AMD_FWD_ORDER", "0") == "1"
+_JOIN_EARLY = _os.environ.get("D2AMD_JOIN_EARLY", "0") == "1"
 _SIDE_BINNING = _os.environ.get("D2AMD_SIDE_BINNING", "1") != "0"  # A/B switch: the later gathers' binning beside the first
 
 
 def _PREBIN(head):
-    return _PREBIN_MODE == "all" or (_PREBIN_MODE == "chained" and not head)
+    return _PREBIN_MODE in ("all", "side") or (_PREBIN_MODE == "chained" and not head)
 
 
 class _FusedROIPool(Function):
@@ -301,12 +302,26 @@ class _FusedROIPool(Function):
         if layout == _C.NHWC and k > 0 and any(ctx.needs_input_grad[5:]) and _PREBIN(head):  # (False under no_grad)
             L = _C.lib()
             ws_bytes = L.d2amd_roi_pooler_backward_workspace_bytes(ctypes.byref(p), k)
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=xs[0].device)
+            side = None
+            if _PREBIN_MODE == "side":  # on a stream of its own, forked here, joined in front of the tile gather
+                from ..streams import _streams
+
+                dev = xs[0].device
+                side = _streams(dev, 2, late=True)[1]  # (late stream 0: a caller's deferred fork_join branch)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                rois.record_stream(side)
             with _C.on_device(xs[0].device):  # (pointers: only their alignment class matters to the binning)
-                rc = L.d2amd_roi_pooler_backward_phase(ctypes.byref(p), _C.ptr(out), _C.ptr(rois), _ptr_array(xs), k,
-                                                       _C.ptr(ws), ws_bytes, 1, _C.stream())
+                if side is None:
+                    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=xs[0].device)
+                    rc = L.d2amd_roi_pooler_backward_phase(ctypes.byref(p), _C.ptr(out), _C.ptr(rois), _ptr_array(xs),
+                                                           k, _C.ptr(ws), ws_bytes, 1, _C.stream())
+                else:
+                    with torch.cuda.stream(side):
+                        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+                        rc = L.d2amd_roi_pooler_backward_phase(ctypes.byref(p), _C.ptr(out), _C.ptr(rois),
+                                                               _ptr_array(xs), k, _C.ptr(ws), ws_bytes, 1, _C.stream())
             if rc == 0:
-                ctx.binned = (ws, ws_bytes)
+                ctx.binned = (ws, ws_bytes) if side is None else (ws, ws_bytes, side)
             elif rc != _C.EUNSUPPORTED:
                 _C.check(rc)
         ctx.chain, ctx.head, ctx.upstream, ctx.dtype = chain, head, upstream, xs[0].dtype
@@ -393,6 +408,11 @@ class _FusedROIPool(Function):
                         works[j] = (g, r, wcfg, (ws, ws_bytes, side))
                     elif rc != _C.EUNSUPPORTED:
                         _C.check(rc)
+            if _JOIN_EARLY:  # A/B: every side binning joined in front of the FIRST gather (one parent per later gather)
+                for j, (g, r, wcfg, binned) in enumerate(works):
+                    if binned is not None and len(binned) == 3:
+                        torch.cuda.current_stream(dev).wait_stream(binned[2])
+                        works[j] = (g, r, wcfg, binned[:2])
             for j, (g, r, wcfg, binned) in enumerate(works):
                 k = r.shape[0]
                 p = _params(wcfg, (n, c), hw, _C.dtype_code(g), _C.NHWC)

@@ -131,7 +131,8 @@ def label_and_sample_proposals_fixed(proposal_boxes, gt_boxes, gt_classes, limit
     gt_index [N, S] (matched ground truth), index [N, S] (candidate index into [proposals[:n]; gt], -1 = padding),
     counts [N, 2] int32 = (positives, rows).  Positives first, then negatives, then padding; S = batch_size_per_image.
     Also "rois" [N * S, 5] (pooler format: image, x1, y1, x2, y2 -- `ROIPooler.pool_rois` takes it as it is) and, with
-    head_rows > 0, "head_rois" [N * head_rows, 5]: the first head_rows rows of every image (the mask head's)."""
+    head_rows > 0, "head_rois" [N * head_rows, 5]: the first head_rows rows of every image (the mask head's), and
+    "head_classes" [N, head_rows]: their classes, contiguous."""
     import ctypes
 
     n_img = len(proposal_boxes)
@@ -148,6 +149,7 @@ def label_and_sample_proposals_fixed(proposal_boxes, gt_boxes, gt_classes, limit
     assert 0 <= H <= S
     if H:
         out["head_rois"] = torch.empty((n_img * H, 5), dtype=torch.float32, device=dev)
+        out["head_classes"] = torch.empty((n_img, H), dtype=torch.int64, device=dev)
     if n_img == 0:
         return out
     imgs = (_C.SampleImage * n_img)()
@@ -178,6 +180,7 @@ def label_and_sample_proposals_fixed(proposal_boxes, gt_boxes, gt_classes, limit
         _C.check(_C.lib().d2amd_label_and_sample_proposals(
             imgs, n_img, thr, lab, T, S, int(S * positive_fraction), int(num_classes), int(bool(proposal_append_gt)),
             _C.ptr(out["boxes"]), _C.ptr(out["classes"]), _C.ptr(out["gt_index"]), _C.ptr(out["index"]),
-            _C.ptr(out["counts"]), _C.ptr(out["rois"]), _C.ptr(out.get("head_rois")), H, _C.stream()))
+            _C.ptr(out["counts"]), _C.ptr(out["rois"]), _C.ptr(out.get("head_rois")), _C.ptr(out.get("head_classes")), H,
+            _C.stream()))
     out["_hold"] = hold  # inputs stay alive until the caller drops the result (the launch is asynchronous)
     return out

@@ -197,7 +197,8 @@ int d2amd_box_iou_rotated(const float* boxes1, int n, const float* boxes2, int m
  * rois_out (optional) [count * S][5]: the same rows in pooler format (image index, x1, y1, x2, y2:
  * convert_boxes_to_pooler_format, modeling/poolers.py:62-104), head_rois_out (optional) [count * head_rows][5]: the first
  * head_rows rows of every image (the mask head's rows: positives come first) -- what d2amd_roi_pooler_forward takes
- * as they are.
+ * as they are; head_classes_out (optional) [count][head_rows]: classes_out of those rows, contiguous (what the mask loss
+ * takes as it is: a strided slice of classes_out would cost the caller a copy launch).
  * max_proposals + num_gt <= d2amd_label_and_sample_max_candidates() per image, else D2AMD_EUNSUPPORTED. */
 typedef struct {
   const float* proposals;    /* [max_proposals][4] fp32 xyxy, 16-byte aligned */
@@ -213,7 +214,7 @@ int d2amd_label_and_sample_proposals(const d2amd_sample_image* images, int count
                                      const int8_t* labels, int T, int batch_size_per_image, int max_positives,
                                      int64_t num_classes, int append_gt, float* boxes_out, int64_t* classes_out,
                                      int64_t* gt_index_out, int64_t* index_out, int32_t* counts_out, float* rois_out,
-                                     float* head_rois_out, int head_rows, void* stream);
+                                     float* head_rois_out, int64_t* head_classes_out, int head_rows, void* stream);
 
 /* ---- uniform sampling keys from a DEVICE-resident generator state (what the samplers below consume; the reference
  * draws torch.randperm inside subsample_labels, modeling/sampling.py:49-50).  state: 3 device uint64 words {seed, offset,

@@ -1,5 +1,7 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp PYTHONPATH=$PWD
-timeout 600 python -m pytest tests/test_gpu_pooler.py tests/test_gpu_graph.py tests/test_gpu_connected_step.py tests/test_gpu_reference_callers.py -q -p no:cacheprovider -x 2>&1 | tail -2
-D2AMD_POOL_STEAL=2 timeout 600 python -m pytest tests/test_gpu_pooler.py -q -p no:cacheprovider -x 2>&1 | tail -2
-for rep in 1 2; do timeout 120 python scripts/pool_bwd_ab.py head 2>&1 | tail -1; done
+for rep in 1 2 3; do
+D2AMD_BENCH_FORK=nms timeout 300 python bench.py --no-cpu-baseline --no-extra-workloads 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('fork=nms', d['ms_per_step'])"
+D2AMD_BENCH_FORK=start timeout 300 python bench.py --no-cpu-baseline --no-extra-workloads 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('fork=start side first', d['ms_per_step'])"
+D2AMD_BENCH_FORK=start D2AMD_BENCH_FORK_ORDER=main timeout 300 python bench.py --no-cpu-baseline --no-extra-workloads 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('fork=start main first', d['ms_per_step'])"
+done
