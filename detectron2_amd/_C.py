@@ -10,7 +10,7 @@ import os
 import torch  # must be imported first: libd2amd.so binds to the HIP runtime torch already loaded
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libd2amd.so")
+LIB_PATH = os.environ.get("D2AMD_LIB_PATH") or os.path.join(_HERE, "lib", "libd2amd.so")  # (override: same-box A/B of two builds)
 _lib = None
 
 F32, F16, BF16 = 0, 1, 2
