@@ -501,7 +501,16 @@ __device__ __forceinline__ void nms_runs_rank_body(const float* __restrict__ box
 // Workgroups of 256 threads (35 of them for 8,819 entries): with 1,024-thread workgroups the kernel ran on 9 CUs and
 // was bound by their VALUs (the 11-step search of 4 other runs is ~1,100 instructions per entry: 22 us); a workgroup
 // walks the n keys twice (count, then place: the second pass re-reads them from cache) instead of holding them.
-constexpr int ORDER_THREADS = 256, ORDER_ROWS = RANK_MAX_N / ORDER_THREADS, ORDER_WAVES = ORDER_THREADS / 64;
+// Workgroup size of the order kernel.  Every workgroup stages ALL keys and walks all rows of ORDER_THREADS keys twice
+// (ballot + scan, compaction) before it ranks its own ORDER_THREADS entries: with 256 threads that was 2 x 28 dependent
+// LDS passes for the RPN's ~7,000 boxes per image, with 1,024 it is 2 x 7 -- the connected step went 0.418 -> 0.401 /
+// 0.392 ms on one box (512 threads: 0.403 / 0.405).
+#ifndef D2AMD_ORDER_THREADS
+#define D2AMD_ORDER_THREADS 1024
+#endif
+constexpr int ORDER_THREADS = D2AMD_ORDER_THREADS, ORDER_ROWS = RANK_MAX_N / ORDER_THREADS, ORDER_WAVES = ORDER_THREADS / 64;
+constexpr int ORDER_LG = ORDER_THREADS == 256 ? 8 : ORDER_THREADS == 512 ? 9 : 10;
+static_assert((1 << ORDER_LG) == ORDER_THREADS, "ORDER_THREADS: 256, 512 or 1024");
 template <int BW>
 __device__ __forceinline__ void nms_runs_order_small_body(
     const float* __restrict__ boxes, const float* __restrict__ scores, int n, const NmsRuns& R,
@@ -600,7 +609,7 @@ __device__ __forceinline__ void nms_runs_order_small_body(
         const bool live = s_raw[j] != RUN_KEY_PARKED;
         const unsigned long long bal = __ballot(live);
         if (lane == 0)
-          s_sbase[q] = cell[(oq >> 8) * ORDER_WAVES + ((oq >> 6) & (ORDER_WAVES - 1))] +
+          s_sbase[q] = cell[(oq >> ORDER_LG) * ORDER_WAVES + ((oq >> 6) & (ORDER_WAVES - 1))] +
               __builtin_popcountll(bal & ((1ull << (oq & 63)) - 1ull));
       }
     }
@@ -1358,7 +1367,7 @@ __device__ __forceinline__ void nms_finalize_small_body(
   if (tid == FIN_THREADS - 1) {
     int fl2 = counters[1];
     if (blk_flag)
-      for (int q = 0; q < (n + 255) / 256; q++) fl2 |= blk_flag[q];
+      for (int q = 0; q < (n + ORDER_THREADS - 1) / ORDER_THREADS; q++) fl2 |= blk_flag[q];
     result[0] = off; result[1] = fl2; result[2] = s_finite; result[3] = 0;
   }
 }
@@ -1420,7 +1429,7 @@ __device__ __forceinline__ void nms_finalize_direct_body(
   if (blockIdx.x == (unsigned)((n + FIN_THREADS - 1) / FIN_THREADS) - 1 && tid == 0) {
     int fl2 = counters[1];
     if (blk_flag)
-      for (int q = 0; q < (n + 255) / 256; q++) fl2 |= blk_flag[q];
+      for (int q = 0; q < (n + ORDER_THREADS - 1) / ORDER_THREADS; q++) fl2 |= blk_flag[q];
     result[0] = s_before[0] + cnt; result[1] = fl2; result[2] = s_before[1] + cfin; result[3] = 0;
   }
 }
