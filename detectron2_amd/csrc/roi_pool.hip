@@ -1372,254 +1372,6 @@ struct __attribute__((aligned(16))) MfmaShared {
   uint16_t Wlo[2][TILE * TILE][WPITCH];
 };
 
-// ------------------------------------------------------------------------------------------------
-// FORWARD, NHWC, 16-bit I/O, on the matrix cores (r03).  The VALU forward gathers every bin's taps lane by lane: a
-// pixel of the ROI's footprint is requested again by every neighbouring bin (L1 serves 367 MB per launch of the box
-// head for 109 MB of compulsory bytes), each lane waits for 3-4 dependent batches of 4 loads per bin (SQ counters: 53 %
-// of the wave cycles in s_waitcnt, 43 % VALU busy: unpack + FMA per tap), and a workgroup needs ~26 us per ROI.
-// Pooling an ROI is a small GEMM too:  out[bin][c] = sum over the footprint pixels p of  Wt[bin][p] . X[p][c],
-// Wt[bin][p] = wy[ph][y(p)] wx[pw][x(p)] / count from the separable tables the VALU kernel uses (sep_build).  Here the
-// workgroup reads every footprint pixel ONCE (coalesced 16-B channel vectors, a chunk of 32 pixels ahead of the
-// contraction), builds the chunk's weight image [bin][pixel] as a high and a low 16-bit part (like the backward) and
-// contracts on v_mfma_f32_32x32x16: wave w owns channels [32 w, 32 w + 32) for the <= 64 bins of the workgroup (a
-// range of whole bin rows: blockIdx.y), staged X is the A operand through ds_read_b64_tr_b16, the weight image the B
-// operand, accumulators [channel][bin] -- the backward's contraction with bins and pixels swapped.  The epilogue is
-// the backward's (swizzled 8-B LDS writes, 16-B row stores).  ROIs whose bins span more than SEP_SPAN pixels take the
-// direct per-sample path of the VALU kernel (same workgroup).
-#ifndef D2AMD_FWD_DEPTH
-#define D2AMD_FWD_DEPTH 2
-#endif
-struct __attribute__((aligned(16))) FwdMfmaShared {
-  raw16 X[2][WINCAP][LPP];  // [buffer][pixel of the chunk][channel lane]; both buffers = the epilogue's [64 bins][256 ch]
-};
-template <typename T>
-__global__ __launch_bounds__(2 * CT, 4) void pool_fwd_mfma_kernel(PoolLevels L, const float* __restrict__ rois,
-                                                                 T* __restrict__ out, int rows_per_split) {
-  constexpr int NT = 2 * CT, VEC = 8, KC = WINCAP, TR = TILE / 2;
-  __shared__ SepShared S;
-  __shared__ FwdMfmaShared F;
-  __shared__ MfmaShared M;
-  __shared__ int s_fp[8];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int k = fwd_roi_of(L, (int)blockIdx.x, (int)gridDim.x);
-  const int lvl = __builtin_amdgcn_readfirstlane(assign_level(rois + (long)k * 5 + 1, L));
-  const int C = L.C, PH = L.PH, PW = L.PW;
-  const int ph_lo = (int)blockIdx.y * rows_per_split, ph_hi = min(PH, ph_lo + rows_per_split);
-  if (ph_lo >= ph_hi) return;
-  // profiling stamps (D2AMD_POOL_STAMPS): {start, tables + footprint, chunk loop done, chunks | level << 32}
-  unsigned long long* wst = (L.wgstamps && tid == 0 && blockIdx.z == 0) ? L.wgstamps + 5 * ((size_t)blockIdx.y * gridDim.x + k) : nullptr;
-  if (wst) wst[0] = wall_clock64();
-  int wst_chunks = 0;
-  const int slab = (int)blockIdx.z;                  // 256 channels per workgroup
-  const int b_lo = ph_lo * PW, nbins = (ph_hi - ph_lo) * PW;  // <= 64 (host)
-  T* outk = out + (long)k * PH * PW * C;
-  const int rh = tid / CT, col = (tid >> 5) & 7, lp = tid & 31;
-  const int cg = slab * LPP + lp, CG = C / VEC;
-  const bool cg_ok = cg < CG;
-  const int cofs = min(cg, CG - 1) * VEC;
-  if (lvl < 0) {  // reference: row of the zero-initialised output that no level fills
-    if (cg_ok)
-      for (int b = tid >> 5; b < nbins; b += NT / 32)
-        *reinterpret_cast<raw16*>(outk + (long)(b_lo + b) * C + cofs) = raw16{0u, 0u, 0u, 0u};
-    return;
-  }
-  const int H = L.H[lvl], W = L.W[lvl];
-  const float scale = L.scale[lvl];
-  const T* in = (const T*)L.data[lvl];
-  sep_build<false>(S, rois, k, scale, PH, PW, L.sr, L.aligned, H, W);
-  if (!S.ok) {  // a bin spans more than SEP_SPAN pixels: per-sample taps for this ROI (all channels: slab 0 does it)
-    if (slab == 0) fwd_direct_range<T, true>(in, rois, out, k, 0, C, C, H, W, PH, PW, scale, L.sr, L.aligned, b_lo, b_lo + nbins);
-    return;
-  }
-  if (tid == 0) {  // footprint of the bin rows [ph_lo, ph_hi) x all bin columns (bins without a valid sample: span 0)
-    int y0 = 0x7fffffff, y1 = -1, x0 = 0x7fffffff, x1 = -1;
-    int t0[2] = {0x7fffffff, 0x7fffffff}, t1[2] = {-1, -1};  // pixel rows the bins of accumulator tile 0 / 1 touch
-    for (int q = ph_lo; q < ph_hi; q++)
-      if (S.spany[q] > 0) {
-        const int f = S.firsty[q], l = f + S.spany[q] - 1;
-        y0 = min(y0, f); y1 = max(y1, l);
-        const int ba = (q - ph_lo) * PW, bb = ba + PW - 1;  // bins of this bin row
-        if (ba < 32) { t0[0] = min(t0[0], f); t1[0] = max(t1[0], l); }
-        if (bb >= 32) { t0[1] = min(t0[1], f); t1[1] = max(t1[1], l); }
-      }
-    for (int q = 0; q < PW; q++)
-      if (S.spanx[q] > 0) { x0 = min(x0, S.firstx[q]); x1 = max(x1, S.firstx[q] + S.spanx[q] - 1); }
-    const bool any = y1 >= 0 && x1 >= 0;
-    s_fp[0] = any ? y0 : 0; s_fp[1] = any ? y1 - y0 + 1 : 0; s_fp[2] = any ? x0 : 0; s_fp[3] = any ? x1 - x0 + 1 : 0;
-    s_fp[4] = t0[0]; s_fp[5] = t1[0]; s_fp[6] = t0[1]; s_fp[7] = t1[1];
-  }
-  __syncthreads();
-  const int fy_lo = s_fp[0], fh = s_fp[1], fx_lo = s_fp[2], fw = s_fp[3];
-  const int ty0[2] = {s_fp[4], s_fp[6]}, ty1[2] = {s_fp[5], s_fp[7]};
-  if (wst) wst[1] = wall_clock64();
-  const T* inb = in + (long)S.batch * H * W * C + cofs;
-  const float inv = S.inv_count;
-  // this thread's bin of the weight image and its table rows (fixed for the whole ROI)
-  const int wb = tid >> 3, wq = (tid & 7) * 4;
-  const bool wb_ok = wb < nbins;
-  const int wph = ph_lo + (wb_ok ? wb / PW : 0), wpw = wb_ok ? wb % PW : 0;
-  const int wfy = S.firsty[wph], wsy = wb_ok ? S.spany[wph] : 0, wfx = S.firstx[wpw], wsx = wb_ok ? S.spanx[wpw] : 0;
-  const float* wyrow = S.wy + wph * SEP_SPAN;
-  const float* wxrow = S.wx + wpw * SEP_SPAN;
-  const int sb = tid >> 5;  // staging: this thread moves slots sb and sb + 16 of a chunk (channel lane lp)
-
-  f32x16_t acc[2];
-#pragma unroll
-  for (int i = 0; i < 16; i++) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
-  const bool wave_ok = slab * (LPP * VEC) + 32 * wave < C;
-
-  // The footprint is walked in CHUNKS OF WHOLE PIXEL ROWS: a chunk = rpc = 32 / fws consecutive rows of a strip of
-  // fws <= 32 columns (wider footprints: several strips), slot s of a chunk = (row s / fws, column s % fws).  A thread's
-  // slots keep their (row offset, column) for the whole strip: nothing is divided inside the chunk loop, the column
-  // weights of the thread's four weight-image entries are registers, and a chunk only looks up its rows' weights.
-  // (The first version numbered the footprint's pixels consecutively: ~180 VALU instructions per chunk and wave went
-  // into index arithmetic and the dense weight image -- twice the VALU kernel's work per ROI; 57 against 45 us.)
-  constexpr int D = D2AMD_FWD_DEPTH;
-  const int nstrip = (fw + KC - 1) / KC;
-  for (int strip = 0; strip < nstrip && fh > 0; strip++) {
-    const int fx0 = fx_lo + strip * KC, fws = min(KC, fw - strip * KC);
-    const int rpc = KC / fws, nb = rpc * fws;  // rows, slots per chunk
-    const int nch = (fh + rpc - 1) / rpc;
-    wst_chunks += nch;
-    // staging slots of this thread
-    const int d0 = sb / fws, x0s = sb - d0 * fws, d1 = (sb + 16) / fws, x1s = sb + 16 - d1 * fws;
-    const bool v0 = sb < nb && cg_ok, v1 = sb + 16 < nb && cg_ok;
-    // (slots past the chunk and rows past the footprint read a clamped -- valid -- pixel and are zeroed at the store)
-    const T* q0 = inb + ((long)fy_lo * W + fx0 + min(x0s, fws - 1)) * C;
-    const T* q1 = inb + ((long)fy_lo * W + fx0 + min(x1s, fws - 1)) * C;
-    const int dd0 = min(d0, rpc - 1), dd1 = min(d1, rpc - 1);
-    const long rowstep = (long)W * C;
-    // weight-image slots of this thread: row offset and column weight (x 1 / count) of wq .. wq + 3
-    int wd[4];
-    float wxv[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int sl = wq + j, dj = sl / fws, xj = sl - dj * fws;
-      const int dx = fx0 + xj - wfx;
-      wd[j] = dj;
-      wxv[j] = (sl < nb && (unsigned)dx < (unsigned)wsx) ? wxrow[dx] * inv : 0.f;
-    }
-    auto issue_x = [&](int c, raw16& r0, raw16& r1) __attribute__((always_inline)) {
-      r0 = *reinterpret_cast<const raw16*>(q0 + (long)min(c * rpc + dd0, fh - 1) * rowstep);
-      r1 = *reinterpret_cast<const raw16*>(q1 + (long)min(c * rpc + dd1, fh - 1) * rowstep);
-    };
-    auto store_x = [&](int buf, int c, const raw16& r0, const raw16& r1) __attribute__((always_inline)) {
-      const raw16 z16 = raw16{0u, 0u, 0u, 0u};  // slots past the chunk / the footprint: zeros (stale bits may be NaN)
-      F.X[buf][sb][lp] = (v0 && c * rpc + d0 < fh) ? r0 : z16;
-      F.X[buf][sb + 16][lp] = (v1 && c * rpc + d1 < fh) ? r1 : z16;
-    };
-    // weight image of chunk c -> buffer buf: thread = (bin, 4 consecutive slots); hi = w rounded to the I/O dtype,
-    // lo = (w - hi) rounded
-    auto build_w = [&](int buf, int c) __attribute__((always_inline)) {
-      uint32_t hw[2] = {0u, 0u}, lw[2] = {0u, 0u};
-      const int yc = fy_lo + c * rpc - wfy;  // chunk's first row relative to the bin's first
-      if (yc + rpc > 0 && yc < wsy) {  // the bin's rows meet the chunk's
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const int dy = yc + wd[j];
-          const float wv = ((unsigned)dy < (unsigned)wsy && c * rpc + wd[j] < fh) ? wyrow[min(max(dy, 0), SEP_SPAN - 1)] * wxv[j] : 0.f;
-          uint16_t hi, lo;
-          if constexpr (__is_same(T, bf16_t)) {
-            const __bf16 h = (__bf16)wv;
-            const __bf16 l = (__bf16)(wv - (float)h);
-            hi = __builtin_bit_cast(uint16_t, h);
-            lo = __builtin_bit_cast(uint16_t, l);
-          } else {
-            const _Float16 h = (_Float16)wv;
-            const _Float16 l = (_Float16)(wv - (float)h);
-            hi = __builtin_bit_cast(uint16_t, h);
-            lo = __builtin_bit_cast(uint16_t, l);
-          }
-          hw[j >> 1] |= (uint32_t)hi << (16 * (j & 1));
-          lw[j >> 1] |= (uint32_t)lo << (16 * (j & 1));
-        }
-      }
-      *reinterpret_cast<uint2*>(&M.Whi[buf][wb][wq]) = uint2{hw[0], hw[1]};
-      *reinterpret_cast<uint2*>(&M.Wlo[buf][wb][wq]) = uint2{lw[0], lw[1]};
-    };
-    // contraction of one chunk: acc[mt] ([32 channels] x [bins 32 mt ..]) += X[buf]^T . (Whi + Wlo)[buf]^T; a tile of
-    // bins none of whose pixel rows lie in the chunk is skipped (its weight image is all zeros)
-    auto contract = [&](int buf, int c) __attribute__((always_inline)) {
-      if (!wave_ok) return;  // uniform per wave
-      const int ya = fy_lo + c * rpc, yb = ya + rpc - 1;
-      const char* ximg = reinterpret_cast<const char*>(&F.X[buf][0][0]);
-      const int kh = lane >> 5;
-      const int tr_off = ((lane & 15) >> 2) * (LPP * 16) + (32 * wave + 16 * ((lane >> 4) & 1) + (lane & 3) * 4) * 2;
-#pragma unroll
-      for (int ks = 0; ks < KC / 16; ks++) {
-        if (ks * 16 >= nb) break;  // uniform
-        const char* bp = ximg + (16 * ks + 8 * kh) * (LPP * 16) + tr_off;
-        const s16x4_t t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)bp);
-        const s16x4_t t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(bp + 4 * (LPP * 16)));
-        const s16x8_t xa = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-        for (int mt = 0; mt < 2; mt++) {
-          if (ty1[mt] < ya || ty0[mt] > yb) continue;  // uniform
-          const int bin = 32 * mt + (lane & 31);
-          const s16x8_t wh = *reinterpret_cast<const s16x8_t*>(&M.Whi[buf][bin][16 * ks + 8 * kh]);
-          const s16x8_t wl = *reinterpret_cast<const s16x8_t*>(&M.Wlo[buf][bin][16 * ks + 8 * kh]);
-          acc[mt] = pool_mma(xa, wh, acc[mt], T{});
-          acc[mt] = pool_mma(xa, wl, acc[mt], T{});
-        }
-      }
-    };
-    if (strip) __syncthreads();  // the last chunk of the previous strip has been contracted
-    raw16 rq[D][2];
-#pragma unroll
-    for (int i = 0; i < D; i++) issue_x(min(i, nch - 1), rq[i][0], rq[i][1]);
-    build_w(0, 0);
-    store_x(0, 0, rq[0][0], rq[0][1]);
-    if (D < nch) issue_x(D, rq[0][0], rq[0][1]);
-    int db = 0;
-    for (int c = 0; c < nch; c += D) {
-#pragma unroll
-      for (int u = 0; u < D; u++) {
-        const int cc = c + u;
-        if (cc >= nch) break;  // uniform
-        __syncthreads();  // X[db] and W[db] are complete; everyone is done with the other buffers
-        contract(db, cc);
-        if (cc + 1 < nch) {  // uniform
-          const int sl = (u + 1) % D;  // register slot of chunk cc + 1 (c is a multiple of D; constant once unrolled)
-          build_w(db ^ 1, cc + 1);
-          store_x(db ^ 1, cc + 1, rq[sl][0], rq[sl][1]);
-          if (cc + 1 + D < nch) issue_x(cc + 1 + D, rq[sl][0], rq[sl][1]);
-        }
-        db ^= 1;
-      }
-    }
-  }
-  if (wst) { wst[2] = wall_clock64(); wst[4] = (unsigned long long)lvl | (unsigned long long)wst_chunks << 8 | (unsigned long long)(fh * fw) << 20; }
-  // ---- epilogue: accumulators (lane = bin, a register quad = 4 consecutive channels) -> LDS [bin][channel] in the I/O
-  // dtype (a bin's 32 16-B chunks at chunk ^ (bin & 31): see the backward) -> 16-B channel vectors per bin
-  __syncthreads();  // everyone is done with X
-  T* obuf = reinterpret_cast<T*>(&F.X[0][0][0]);
-  if (wave_ok) {
-#pragma unroll
-    for (int mt = 0; mt < 2; mt++) {
-      const int bin = 32 * mt + (lane & 31);
-#pragma unroll
-      for (int g = 0; g < 4; g++) {
-        const int ch = 32 * wave + 8 * g + 4 * (lane >> 5);
-        uint2 w;
-        w.x = (uint32_t)from_f32<T>(acc[mt][4 * g]).v | ((uint32_t)from_f32<T>(acc[mt][4 * g + 1]).v << 16);
-        w.y = (uint32_t)from_f32<T>(acc[mt][4 * g + 2]).v | ((uint32_t)from_f32<T>(acc[mt][4 * g + 3]).v << 16);
-        *reinterpret_cast<uint2*>(obuf + bin * (LPP * VEC) + (((ch >> 3) ^ (bin & 31)) << 3) + (ch & 4)) = w;
-      }
-    }
-  }
-  __syncthreads();
-  if (cg_ok) {
-#pragma unroll
-    for (int i = 0; i < TR; i++) {
-      const int bin = (rh * TR + i) * TILE + col;
-      if (bin < nbins)
-        *reinterpret_cast<raw16*>(outk + (long)(b_lo + bin) * C + cofs) =
-            *reinterpret_cast<const raw16*>(obuf + bin * (LPP * VEC) + ((lp ^ (bin & 31)) * VEC));
-    }
-  }
-  if (wst) wst[3] = wall_clock64();
-}
-
 template <typename T, int PB, bool DYN = true>
 __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, const RoiRec* __restrict__ rec,
                                                                    const T* __restrict__ gout, int nslab,
@@ -2408,18 +2160,12 @@ static int pool_fwd_impl(const d2amd_pooler_params* p, const void* const* inputs
       // 4 loads in flight per lane and <= 84 VGPRs: three 512-thread workgroups per CU instead of two (8 loads, 108
       // VGPRs): 48.3 -> 43.6 us (box), 34.9 -> 30.2 us (mask); D2AMD_FWD_VARIANT=1 selects the previous shape (A/B)
       static const bool wide = getenv("D2AMD_FWD_VARIANT") && atoi(getenv("D2AMD_FWD_VARIANT")) == 1;
-      static const bool fwd_mfma = getenv("D2AMD_POOL_FWD_MFMA") && atoi(getenv("D2AMD_POOL_FWD_MFMA")) == 1;
-      bool done_mfma = false;
-      if constexpr (sizeof(T) == 2) {
-        if (fwd_mfma && p->C % 32 == 0 && p->pooled_w <= 64 && Lf.tab_off == 0) {
-          const int rps = 64 / p->pooled_w;  // whole bin rows per workgroup: <= 64 bins
-          const dim3 mgrid(K, cdiv(p->pooled_h, rps), cdiv(p->C, 256));
-          hipLaunchKernelGGL((pool_fwd_mfma_kernel<T>), mgrid, dim3(2 * CT), 0, s, Lf, rois, (T*)output, rps);
-          done_mfma = true;
-        }
-      }
-      if (done_mfma) {
-      } else if (wide)
+      // (Tried in round 3 and removed, commit eb0e005: the forward as a GEMM on the matrix cores -- the ROI's footprint
+      // staged once in chunks of pixel rows, weight image [bin][pixel] as hi + lo 16-bit parts, the backward's
+      // contraction with bins and pixels swapped.  Within 1 ulp of this kernel on every case, and a workgroup needs
+      // the same ~21 us per ROI (4.8 us tables + 13.5 chunks x 1.13 us) -- but with 57 KB of LDS and 100 VGPRs two
+      // workgroups fit a CU where this kernel runs four: 57-65 us against 44 us for the box head.)
+      if (wide)
         hipLaunchKernelGGL((pool_fwd_nhwc_kernel<T, VEC, 512>), grid, dim3(512), 0, s, Lf, rois, (T*)output, nsplit);
       else
         hipLaunchKernelGGL((pool_fwd_nhwc_kernel<T, VEC, 512, 4, 6>), grid, dim3(512), 0, s, Lf, rois, (T*)output, nsplit);
