@@ -465,8 +465,8 @@ int d2amd_mask_rcnn_loss_backward(const void* logits, const int64_t* gt_classes,
  * statistics, zero gradient; the mean is taken over the other rows (mask_head.py:47-113 on the foreground subset
  * select_foreground_proposals would have made, roi_heads.py:37-75).  stats_out[6]: [4] = ignored rows, [5] = rows
  * that count; no row -> loss 0 (the reference: `pred_mask_logits.sum() * 0`).  The backward reads the row count from
- * the DEVICE (`rows` = &stats_out[5]): nothing here needs the host.  NOT YET RUN ON A GPU (written after round 2's
- * GPU budget was spent; the instruction streams of the entries above are unchanged by its addition). */
+ * the DEVICE (`rows` = &stats_out[5]): nothing here needs the host (tests/test_gpu_label_sample.py,
+ * tests/test_gpu_connected_step.py). */
 int d2amd_mask_rcnn_loss_forward_masked(const void* logits, const int64_t* gt_classes, const uint8_t* gt_masks, int B,
                                         int C, int HW, int dtype, float* loss_out, int64_t* stats_out,
                                         void* workspace, size_t workspace_bytes, void* stream);
