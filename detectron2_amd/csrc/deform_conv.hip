@@ -476,6 +476,16 @@ __global__ void cvt_kernel(const float* __restrict__ src, T* __restrict__ dst, l
     dst[i] = from_f32<T>(src[i]);
 }
 
+// two conversions in one launch (the offset and the mask gradient of a backward call: a launch is ~4.6 us of a step of
+// small kernels)
+template <typename T>
+__global__ void cvt2_kernel(const float* __restrict__ a, T* __restrict__ da, long na, const float* __restrict__ b,
+                            T* __restrict__ db, long nb) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < na + nb; i += (long)gridDim.x * blockDim.x) {
+    if (i < na) da[i] = from_f32<T>(a[i]);
+    else db[i - na] = from_f32<T>(b[i - na]);
+  }
+}
 // d(bias)[co] = sum_{b,l} dY[b][co][l]: one workgroup per output channel
 template <typename T>
 __global__ __launch_bounds__(256) void dcn_bias_grad_kernel(const T* __restrict__ gout, T* __restrict__ gb, int B, int Co,
@@ -533,16 +543,17 @@ static DcnWs carve_ws(const DcnShape& s, int dtype, bool backward, void* base) {
     w.gx = (float*)take((size_t)s.B * s.H * s.W * s.C * 4);
     w.goff = (float*)take((size_t)s.B * s.DG * 2 * s.K2 * s.L * 4);
     w.gmask = (float*)take((size_t)s.B * s.DG * s.K2 * s.L * 4);
+    const TcBwPlan bp = dcn_tc_plan_bwd(s, dtype);
+    w.use_gather = bp.ok && bp.gather;
+    // (the gather's pixel counters sit right behind the two accumulators: one zero launch covers the three regions)
+    if (w.use_gather) w.gather.cnt = (int*)take(dcn_gather_cnt_bytes(s));
     {  // fp32 staging of the weight gradient: [g][tap][co][ci] (generic kernels: atomics), or the MFMA kernel's partial tiles
       const TcBwwPlan wp = dcn_tc_plan_bww(s, dtype);
       const size_t stage = (size_t)s.Co * s.Cg * s.K2 * 4;
       w.gwr = (float*)take(wp.ok && wp.partial_bytes > stage ? wp.partial_bytes : stage);
     }
-    const TcBwPlan bp = dcn_tc_plan_bwd(s, dtype);
-    w.use_gather = bp.ok && bp.gather;
     if (w.use_gather) {
       w.gather.col = take(dcn_gather_col_bytes(s, es));
-      w.gather.cnt = (int*)take(dcn_gather_cnt_bytes(s));
       w.gather.lists = take(dcn_gather_list_bytes(s));
       w.gather.ovf = take(dcn_gather_ovf_bytes(s));
       w.gx_t = take((size_t)s.B * s.H * s.W * s.C * es);
@@ -570,6 +581,16 @@ static int check_params(const d2amd_dcn_params* p, DcnShape& s, const char* who)
   s = make_shape(p);
   D2_CHECK_ARG(s.Ho >= 1 && s.Wo >= 1, "Calculated output size: (%d x %d). Output size is too small", s.Ho, s.Wo);
   D2_CHECK_ARG((long)s.B * s.H * s.W < (1l << 31), "%s: too many pixels for 32-bit indexing", who);
+  return D2AMD_OK;
+}
+
+template <typename T>
+static int cvt_grads(const DcnShape& s, const DcnWs& w, void* goffset, void* gmask, hipStream_t st) {
+  const long no = goffset ? (long)s.B * s.DG * 2 * s.K2 * s.L : 0, nm = gmask ? (long)s.B * s.DG * s.K2 * s.L : 0;
+  if (no + nm == 0) return D2AMD_OK;
+  const long blocks = cdiv(no + nm, 256) > 8192 ? 8192 : cdiv(no + nm, 256);
+  hipLaunchKernelGGL((cvt2_kernel<T>), dim3(blocks), dim3(256), 0, st, w.goff, (T*)goffset, no, w.gmask, (T*)gmask, nm);
+  D2_LAUNCH_OK();
   return D2AMD_OK;
 }
 
@@ -643,18 +664,8 @@ static int bwd_host(const DcnShape& s, const void* x, const void* offset, const 
         float* gmask_f = (gmask && mask) ? w.gmask : nullptr;
         rc = dcn_tc_backward_data_gather<T>(s, bp, x, offset, mask, weight, gout, gin, goff_f, gmask_f, w.wt, w.gather, st);
         if (rc) return rc;
-        if (goffset) {
-          const long n = (long)s.B * s.DG * 2 * s.K2 * s.L;
-          hipLaunchKernelGGL((cvt_kernel<T>), dim3(cdiv(n, 256) > 8192 ? 8192 : cdiv(n, 256)), dim3(256), 0, st, w.goff,
-                             (T*)goffset, n);
-          D2_LAUNCH_OK();
-        }
-        if (gmask && mask) {
-          const long n = (long)s.B * s.DG * s.K2 * s.L;
-          hipLaunchKernelGGL((cvt_kernel<T>), dim3(cdiv(n, 256) > 8192 ? 8192 : cdiv(n, 256)), dim3(256), 0, st, w.gmask,
-                             (T*)gmask, n);
-          D2_LAUNCH_OK();
-        }
+        rc = cvt_grads<T>(s, w, goffset, (gmask && mask) ? gmask : nullptr, st);
+        if (rc) return rc;
       }
       if (gweight || gbias) {
         rc = launch_transpose<T, T>((const T*)gout, (T*)w.gout_nhwc, s.B, s.L, s.Co, st);  // -> [b][Co][l]
@@ -721,18 +732,8 @@ static int bwd_host(const DcnShape& s, const void* x, const void* offset, const 
       if (rc) return rc;
     }
     if (!is32) {
-      if (goffset) {
-        const long n = (long)s.B * s.DG * 2 * s.K2 * s.L;
-        hipLaunchKernelGGL((cvt_kernel<T>), dim3(cdiv(n, 256) > 8192 ? 8192 : cdiv(n, 256)), dim3(256), 0, st, w.goff,
-                           (T*)goffset, n);
-        D2_LAUNCH_OK();
-      }
-      if (gmask && mask) {
-        const long n = (long)s.B * s.DG * s.K2 * s.L;
-        hipLaunchKernelGGL((cvt_kernel<T>), dim3(cdiv(n, 256) > 8192 ? 8192 : cdiv(n, 256)), dim3(256), 0, st, w.gmask,
-                           (T*)gmask, n);
-        D2_LAUNCH_OK();
-      }
+      rc = cvt_grads<T>(s, w, goffset, (gmask && mask) ? gmask : nullptr, st);
+      if (rc) return rc;
     }
   }
   if (gweight) {

@@ -1583,9 +1583,21 @@ int dcn_tc_backward_data_gather(const DcnShape& s, const TcBwPlan& pl, const voi
                                 const void* mask, const void* weight, const void* gout_nhwc, void* gx_t, float* goff,
                                 float* gmask, void* wp, const DcnGatherWs& gw, hipStream_t st) {
   const long npix = (long)s.B * s.H * s.W;
-  {  // per-call state: pixel counters + the overflow counter (one region)
-    const int zrc = zero_async(gw.cnt, (size_t)(npix + 1) * 4, st);
+  bool goff_zeroed = false;
+  {  // per-call state: pixel counters + the overflow counter (one region) -- and, when the tiles of a pixel are split
+    // over channel groups (csplit > 1: atomics), the fp32 accumulators of the offset / mask gradient, which the
+    // workspace keeps right in front of the counters: ONE zero launch instead of three
+    char* z0 = (char*)gw.cnt;
+    const char* z1 = (const char*)gw.cnt + (size_t)(npix + 1) * 4;
+    bool merged = false;
+    if (pl.csplit > 1 && goff && gmask && (char*)goff < (char*)gmask && (char*)gmask < z0 &&
+        (size_t)(z0 - (char*)goff) <= (size_t)s.B * s.DG * 3 * s.K2 * s.L * 4 + 1024) {
+      z0 = (char*)goff;
+      merged = true;
+    }
+    const int zrc = zero_async(z0, (size_t)(z1 - z0), st);
     if (zrc) return zrc;
+    if (merged) { goff_zeroed = true; }
   }
   int* ovf_cnt = gw.cnt + npix;
   const long nsamp = (long)s.P * s.K2;
@@ -1603,7 +1615,7 @@ int dcn_tc_backward_data_gather(const DcnShape& s, const TcBwPlan& pl, const voi
   a.x = x_nhwc; a.offset = offset; a.mask = mask; a.wp = wp; a.gout = gout_nhwc;
   a.gx = nullptr; a.goff = goff; a.gmask = gmask; a.dcol = gw.col;
   a.tiles_y = pl.tiles_y; a.tiles_x = pl.tiles_x; a.csplit = pl.csplit;
-  if (pl.csplit > 1) {
+  if (pl.csplit > 1 && !goff_zeroed) {
     if (goff) { const int zrc = zero_async(goff, (size_t)s.B * s.DG * 2 * s.K2 * s.L * 4, st); if (zrc) return zrc; }
     if (gmask) { const int zrc = zero_async(gmask, (size_t)s.B * s.DG * s.K2 * s.L * 4, st); if (zrc) return zrc; }
   }
