@@ -134,6 +134,7 @@ int dcn_tc_backward_data_gather(const DcnShape& s, const TcBwPlan& pl, const voi
 struct TcBwwPlan {
   bool ok;
   int n_cot, n_cit, pch, ksteps_per_image;
+  int share, pchw;       // cooperative kernel: output-channel tiles per workgroup (0: the wave-autonomous kernel), chunks
   size_t partial_bytes;  // the partial tiles the kernel writes: one 64 x 64 fp32 slot per workgroup
 };
 TcBwwPlan dcn_tc_plan_bww(const DcnShape& s, int dtype);

@@ -1956,6 +1956,207 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_weight_tc_kernel(DcnShape s, B
   }
 }
 
+// ---- cooperative form (r03): SH waves of a workgroup own SH OUTPUT-CHANNEL TILES of the same (tap, input-channel tile,
+// position range) and share the deformable column.  In the kernel above every wave gathers the column tile of its
+// k-step for itself -- the same [16 positions x 64 channels] tile is gathered Co / 64 times (2 / 4 / 8 for res3 / 4 / 5),
+// and the ablation puts 63 + 20 + 13 of the kernel's 165 us (res3, r01) on the gather loads, the bilinear combine and
+// the offset / mask table.  Here the k-steps of a range are dealt to the SH waves in batches of SH: wave j gathers
+// k-step j of the batch into ITS LDS slot (the same transposed [channel][position] image), one barrier, then every
+// wave contracts all SH k-steps of the batch with its own dY rows: one gather per SH x 4 MFMAs instead of per 4.
+// SH = min(4, Co / 64 per group) (2: two gather groups per workgroup over different position ranges, summed in LDS).
+template <typename T, int SH>
+__global__ __launch_bounds__(256, 2) void dcn_bwd_weight_coop_kernel(DcnShape s, BwwArgs a) {
+  typedef Mma<T> M;
+  constexpr int NG = 4 / SH;   // gather groups per workgroup
+  constexpr int TPITCH = 10;   // dwords per channel row of a transposed column tile: 16 positions x 2 B + 8 B pad
+  __shared__ float red[4][4096];  // the epilogue's sum over the gather groups; the main loop's column tiles live in it
+  uint32_t (*tb)[4][64 * TPITCH] = reinterpret_cast<uint32_t (*)[4][64 * TPITCH]>(&red[0][0]);  // [buffer][wave][channel row]
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int gi = wid / SH, mem = wid % SH;
+  const int per_xcd = (a.total + 7) >> 3;
+  const int logical = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if (logical >= a.total) return;  // (the whole workgroup)
+  int r = logical;
+  const int pcw = r % a.pch; r /= a.pch;
+  const int cit = r % a.n_cit; r /= a.n_cit;
+  const int ncg = a.n_cot / SH;
+  const int cotg = r % ncg; r /= ncg;
+  const int tap = r % s.K2;
+  const int g = r / s.K2;
+  if (g >= s.G) return;
+  const int cot = cotg * SH + mem;
+  const int cabs = g * s.Cg + cit * 64;  // first absolute input channel of the column tile
+  const int dgi = cabs / s.cpg;
+  const int co0 = cot * 64;              // first output channel (inside the group) of this wave's tile
+  const long nk = (long)s.B * a.ksteps_per_image;
+  const int nchunks = a.pch * NG, pc = pcw * NG + gi;
+  const int k_lo = (int)((long)pc * nk / nchunks), k_hi = (int)((long)(pc + 1) * nk / nchunks);
+  const int len_max = (int)((nk + nchunks - 1) / nchunks);
+  const int nbatch = (len_max + SH - 1) / SH;  // the same for every group of the workgroup: one barrier per batch
+
+  const T* offset = (const T*)a.offset;
+  const T* mask = (const T*)a.mask;
+  const char* xb = (const char*)a.x;
+  const T* gout = (const T*)a.gout;
+  const uint32_t pix = (uint32_t)s.C * (uint32_t)sizeof(T);
+  const int pos = lane & 15, cq = lane >> 4;     // gather role: position in the k-step, channel quarter
+  const int n32 = lane & 31, khalf = lane >> 5;  // MFMA role
+  const int ti = tap / s.kw, tj = tap - ti * s.kw;
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; m++)
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+#pragma unroll
+      for (int q = 0; q < 16; q++) acc[m][n][q] = 0.f;
+
+  struct Raw { float oh, ow, mk; };
+  auto load_raw = [&](int k, Raw& rw) __attribute__((always_inline)) {
+    k = min(k, (int)nk - 1);
+    const int b = k / a.ksteps_per_image, l = min((k - b * a.ksteps_per_image) * 16 + pos, s.L - 1);
+    const long obase = ((long)b * s.DG + dgi) * 2 * s.K2;
+    rw.oh = to_f32(offset[(obase + 2 * tap) * s.L + l]);
+    rw.ow = to_f32(offset[(obase + 2 * tap + 1) * s.L + l]);
+    rw.mk = mask ? to_f32(mask[(((long)b * s.DG + dgi) * s.K2 + tap) * s.L + l]) : 1.f;
+  };
+  struct Ent { uint32_t off[4]; float w[4]; };
+  auto build = [&](int k, const Raw& rw, Ent& e) __attribute__((always_inline)) {
+    k = min(k, (int)nk - 1);
+    const int b = k / a.ksteps_per_image, l = (k - b * a.ksteps_per_image) * 16 + pos;
+#pragma unroll
+    for (int t = 0; t < 4; t++) { e.off[t] = 0u; e.w[t] = 0.f; }
+    const int lc = min(l, s.L - 1);
+    const int ho = lc / s.Wo, wo = lc - ho * s.Wo;
+    const float h_im = (float)(ho * s.sh - s.ph + ti * s.dh) + rw.oh;
+    const float w_im = (float)(wo * s.sw - s.pw + tj * s.dw) + rw.ow;
+    if (l < s.L && h_im > -1.f && w_im > -1.f && h_im < (float)s.H && w_im < (float)s.W) {
+      const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+      const int h_high = h_low + 1, w_high = w_low + 1;
+      const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+      const float hh = 1.f - lh, hw = 1.f - lw, m = rw.mk;
+      const long rowbase = (long)b * s.H;
+      if (h_low >= 0 && w_low >= 0) { e.off[0] = (uint32_t)((rowbase + h_low) * s.W + w_low) * pix; e.w[0] = hh * hw * m; }
+      if (h_low >= 0 && w_high <= s.W - 1) { e.off[1] = (uint32_t)((rowbase + h_low) * s.W + w_high) * pix; e.w[1] = hh * lw * m; }
+      if (h_high <= s.H - 1 && w_low >= 0) { e.off[2] = (uint32_t)((rowbase + h_high) * s.W + w_low) * pix; e.w[2] = lh * hw * m; }
+      if (h_high <= s.H - 1 && w_high <= s.W - 1) { e.off[3] = (uint32_t)((rowbase + h_high) * s.W + w_high) * pix; e.w[3] = lh * lw * m; }
+    }
+  };
+  // the gather of a k-step: 2 items (this lane's position x channels (it * 4 + cq) * 8 ..) x 4 corners
+  auto issue_gather = [&](const Ent& e, raw16 (&gr)[2][4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+      const uint32_t cofs = (uint32_t)(cabs + (it * 4 + cq) * 8) * (uint32_t)sizeof(T);
+#pragma unroll
+      for (int c = 0; c < 4; c++) gr[it][c] = *reinterpret_cast<const raw16*>(xb + (e.off[c] + cofs));
+    }
+  };
+  // the dY fragments of k-step k for this wave's output-channel tile (window clamped to the row: see the kernel above)
+  auto issue_a = [&](int k, raw16 (&ar)[2]) __attribute__((always_inline)) {
+    k = min(k, (int)nk - 1);
+    const int b = k / a.ksteps_per_image, l0 = (k - b * a.ksteps_per_image) * 16;
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+      const int co = min(co0 + m * 32 + n32, s.Cog - 1);
+      const int lw = min(l0 + khalf * 8, s.L - 8);
+      ar[m] = *reinterpret_cast<const raw16*>(gout + ((long)b * s.Co + (long)g * s.Cog + co) * s.L + lw);
+    }
+  };
+  // combine + transpose into this wave's slot: tbuf[channel][position]
+  auto combine = [&](uint32_t* tbuf, const Ent& e, const raw16 (&gr)[2][4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+      float v[8];
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        float f[8];
+        tc_unpack(gr[it][c], f, T{});
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = c == 0 ? e.w[c] * f[u] : v[u] + e.w[c] * f[u];
+      }
+      const raw16 pk = tc_pack(v, T{});
+      uint16_t* row = reinterpret_cast<uint16_t*>(tbuf) + ((it * 4 + cq) * 8) * (TPITCH * 2) + pos;
+#pragma unroll
+      for (int u = 0; u < 8; u++) row[u * (TPITCH * 2)] = (uint16_t)(u & 1 ? pk[u >> 1] >> 16 : pk[u >> 1] & 0xffffu);
+    }
+  };
+  auto mma_step = [&](const uint32_t* tbuf, int k, const raw16 (&ar)[2]) __attribute__((always_inline)) {
+    const int kk = min(k, (int)nk - 1);
+    const int lq = (kk - (kk / a.ksteps_per_image) * a.ksteps_per_image) * 16 + khalf * 8;
+    const int sh = lq - min(lq, s.L - 8);  // 0 inside the row; >= 8: nothing valid
+    raw16 af[2];
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+      unsigned long long lo = (unsigned long long)ar[m].x | ((unsigned long long)ar[m].y << 32);
+      unsigned long long hi = (unsigned long long)ar[m].z | ((unsigned long long)ar[m].w << 32);
+      if (sh >= 8) { lo = 0ull; hi = 0ull; }
+      else if (sh >= 4) { lo = sh == 4 ? hi : hi >> (16 * (sh - 4)); hi = 0ull; }
+      else if (sh > 0) { lo = (lo >> (16 * sh)) | (hi << (64 - 16 * sh)); hi = hi >> (16 * sh); }
+      af[m] = raw16{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+    }
+#pragma unroll
+    for (int n = 0; n < 2; n++) {
+      const uint32_t* rp = tbuf + (n * 32 + n32) * TPITCH + khalf * 4;
+      const uint2 lo = *reinterpret_cast<const uint2*>(rp);
+      const uint2 hi = *reinterpret_cast<const uint2*>(rp + 2);
+      const raw16 bq = {lo.x, lo.y, hi.x, hi.y};
+      const typename M::frag bfr = __builtin_bit_cast(typename M::frag, bq);
+#pragma unroll
+      for (int m = 0; m < 2; m++) acc[m][n] = M::mma(__builtin_bit_cast(typename M::frag, af[m]), bfr, acc[m][n]);
+    }
+  };
+
+  // batch b: k-steps k_lo + b * SH + j, j < SH; this wave gathers j = mem
+  Raw rw;
+  Ent en;
+  raw16 gq[2][4], aq[SH][2];
+  load_raw(k_lo + mem, rw);
+  build(k_lo + mem, rw, en);
+  issue_gather(en, gq);
+  load_raw(k_lo + SH + mem, rw);
+#pragma unroll
+  for (int j = 0; j < SH; j++) issue_a(k_lo + j, aq[j]);
+  for (int b = 0; b < nbatch; b++) {
+    const int kb = k_lo + b * SH;
+    uint32_t* mine = tb[b & 1][wid];
+    if (kb + mem < k_hi) combine(mine, en, gq);  // (uniform per wave; a k-step past the range is skipped by everyone)
+    // the gather of the next batch goes out before this one is contracted
+    build(kb + SH + mem, rw, en);
+    issue_gather(en, gq);
+    load_raw(kb + 2 * SH + mem, rw);
+    __syncthreads();  // the batch's SH column tiles are in LDS (buffer b & 1; b + 1 writes the other one)
+#pragma unroll
+    for (int j = 0; j < SH; j++)
+      if (kb + j < k_hi) mma_step(tb[b & 1][gi * SH + j], kb + j, aq[j]);  // uniform
+#pragma unroll
+    for (int j = 0; j < SH; j++) issue_a(kb + SH + j, aq[j]);
+  }
+  // ---- partial tile of (this output-channel tile, this workgroup's position range): the NG gather groups hold the same
+  // tiles over different ranges and are summed through LDS; plain row stores, the unpack kernel adds the workgroups'
+  // slots of a tile in order
+  __syncthreads();  // (the column tiles share the LDS of `red`: everyone is done reading them)
+#pragma unroll
+  for (int m = 0; m < 2; m++)
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+#pragma unroll
+      for (int q = 0; q < 16; q++) red[wid][((m * 2 + n) * 16 + q) * 64 + lane] = acc[m][n][q];
+  __syncthreads();
+  if (wid < SH) {
+    const long tile = (((long)g * s.K2 + tap) * a.n_cot + (cotg * SH + wid)) * a.n_cit + cit;
+    float* dst = a.gwr + (tile * a.pch + pcw) * 4096;
+#pragma unroll
+    for (int mn = 0; mn < 4; mn++)
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        const int e = (mn * 16 + q) * 64 + lane;
+        float v = red[wid][e];
+        if (NG == 2) v += red[SH + wid][e];
+        dst[((mn >> 1) * 32 + frag_row(q, lane)) * 64 + (mn & 1) * 32 + n32] = v;
+      }
+  }
+}
+
 // grad_weight (Co, Cg, K2) T = the partial tiles of dcn_bwd_weight_tc_kernel summed in chunk order.  One thread per
 // (tile, row, column): the partials are read as coalesced rows.
 template <typename T>
@@ -1998,6 +2199,19 @@ TcBwwPlan dcn_tc_plan_bww(const DcnShape& s, int dtype) {
   if (e && atoi(e) > 0) pch = (atoi(e) + 3) / 4 * 4;
   pl.pch = (int)pch;
   pl.partial_bytes = (size_t)tiles * (pch / 4) * 4096 * sizeof(float);
+  // cooperative kernel: SH output-channel tiles per workgroup share the column gather (A/B: D2AMD_DCN_BWW_COOP=0)
+  pl.share = 0;
+  static const bool no_coop = getenv("D2AMD_DCN_BWW_COOP") && atoi(getenv("D2AMD_DCN_BWW_COOP")) == 0;
+  if (!no_coop && pl.n_cot % 2 == 0) {
+    pl.share = pl.n_cot % 4 == 0 ? 4 : 2;
+    const int ng = 4 / pl.share;
+    const long wg_tiles = tiles / pl.share;             // (tap, ci tile, group of SH co tiles)
+    long pchw = (576 + wg_tiles - 1) / wg_tiles;        // ~2 workgroups per CU
+    if (pchw * ng > nk / 4) pchw = nk / 4 / ng > 0 ? nk / 4 / ng : 1;  // at least 4 k-steps per gather group
+    if (e && atoi(e) > 0) pchw = atoi(e);
+    pl.pchw = (int)pchw;
+    pl.partial_bytes = (size_t)tiles * pchw * 4096 * sizeof(float);
+  }
   pl.ok = true;
   return pl;
 }
@@ -2008,6 +2222,23 @@ int dcn_tc_backward_weight(const DcnShape& s, const TcBwwPlan& pl, const void* x
   BwwArgs a{};
   a.x = x_nhwc; a.offset = offset; a.mask = mask; a.gout = gout_nchw; a.gwr = gwr;
   a.n_cot = pl.n_cot; a.n_cit = pl.n_cit; a.pch = pl.pch; a.ksteps_per_image = pl.ksteps_per_image;
+  if (pl.share) {
+    a.pch = pl.pchw;
+    const long wgs = (long)s.G * s.K2 * (pl.n_cot / pl.share) * pl.n_cit * pl.pchw;
+    D2_CHECK_ARG(wgs < (1l << 30), "deform_conv: too many tiles");
+    a.total = (int)wgs;
+    const int cgrid = (a.total + 7) / 8 * 8;
+    const bool timed_c = timing_begin("dcn_bwd_weight", st);
+    if (pl.share == 4) hipLaunchKernelGGL((dcn_bwd_weight_coop_kernel<T, 4>), dim3(cgrid), dim3(256), 0, st, s, a);
+    else hipLaunchKernelGGL((dcn_bwd_weight_coop_kernel<T, 2>), dim3(cgrid), dim3(256), 0, st, s, a);
+    if (timed_c) timing_end("dcn_bwd_weight", st);
+    D2_LAUNCH_OK();
+    const long n2 = (long)s.G * s.K2 * pl.n_cot * pl.n_cit * 4096;
+    hipLaunchKernelGGL((unpack_gw_partials_kernel<T>), dim3(cdiv(n2, 256) > 8192 ? 8192 : cdiv(n2, 256)), dim3(256), 0, st,
+                       (const float*)gwr, (T*)grad_weight, s.G, s.Cog, s.Cg, s.K2, pl.n_cot, pl.n_cit, pl.pchw);
+    D2_LAUNCH_OK();
+    return D2AMD_OK;
+  }
   const long waves = (long)s.G * s.K2 * pl.n_cot * pl.n_cit * pl.pch;
   D2_CHECK_ARG(waves / 4 < (1l << 30), "deform_conv: too many tiles");
   a.total = (int)(waves / 4);
