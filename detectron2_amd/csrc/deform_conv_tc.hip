@@ -2084,15 +2084,17 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_weight_coop_kernel(DcnShape s,
     const int kk = min(k, (int)nk - 1);
     const int lq = (kk - (kk / a.ksteps_per_image) * a.ksteps_per_image) * 16 + khalf * 8;
     const int sh = lq - min(lq, s.L - 8);  // 0 inside the row; >= 8: nothing valid
-    raw16 af[2];
+    raw16 af[2] = {ar[0], ar[1]};
+    if (__builtin_amdgcn_ballot_w64(sh != 0) != 0ull) {  // (uniform: only the last k-step of an image row range shifts)
 #pragma unroll
-    for (int m = 0; m < 2; m++) {
-      unsigned long long lo = (unsigned long long)ar[m].x | ((unsigned long long)ar[m].y << 32);
-      unsigned long long hi = (unsigned long long)ar[m].z | ((unsigned long long)ar[m].w << 32);
-      if (sh >= 8) { lo = 0ull; hi = 0ull; }
-      else if (sh >= 4) { lo = sh == 4 ? hi : hi >> (16 * (sh - 4)); hi = 0ull; }
-      else if (sh > 0) { lo = (lo >> (16 * sh)) | (hi << (64 - 16 * sh)); hi = hi >> (16 * sh); }
-      af[m] = raw16{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+      for (int m = 0; m < 2; m++) {
+        unsigned long long lo = (unsigned long long)ar[m].x | ((unsigned long long)ar[m].y << 32);
+        unsigned long long hi = (unsigned long long)ar[m].z | ((unsigned long long)ar[m].w << 32);
+        if (sh >= 8) { lo = 0ull; hi = 0ull; }
+        else if (sh >= 4) { lo = sh == 4 ? hi : hi >> (16 * (sh - 4)); hi = 0ull; }
+        else if (sh > 0) { lo = (lo >> (16 * sh)) | (hi << (64 - 16 * sh)); hi = hi >> (16 * sh); }
+        af[m] = raw16{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+      }
     }
 #pragma unroll
     for (int n = 0; n < 2; n++) {
@@ -2206,7 +2208,8 @@ TcBwwPlan dcn_tc_plan_bww(const DcnShape& s, int dtype) {
     pl.share = pl.n_cot % 4 == 0 ? 4 : 2;
     const int ng = 4 / pl.share;
     const long wg_tiles = tiles / pl.share;             // (tap, ci tile, group of SH co tiles)
-    long pchw = (576 + wg_tiles - 1) / wg_tiles;        // ~2 workgroups per CU
+    // ~2 workgroups per CU (share 2: ~4 -- measured per stage, res3 106.5 us at 64 chunks against 114.8 at 32)
+    long pchw = (576 * ng + wg_tiles - 1) / wg_tiles;
     if (pchw * ng > nk / 4) pchw = nk / 4 / ng > 0 ? nk / 4 / ng : 1;  // at least 4 k-steps per gather group
     if (e && atoi(e) > 0) pchw = atoi(e);
     pl.pchw = (int)pchw;
