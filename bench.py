@@ -1160,7 +1160,7 @@ def bench_dcn(args, ctx):
                 "kernel": {"dcn_fwd": "dcn_fwd_wave_kernel / dcn_fwd_tc_kernel (gather + MFMA, no column buffer)",
                            "dcn_bwd_data": "dcn_bwd_data_tc_kernel (dcol = W^T dY on MFMA -> 16-bit column rows, + d offset / d mask)",
                            "dcn_bwd_gather": "dcn_gather_dx_kernel (dX = per-pixel gather of the column rows; HBM/L2 bound, no flops counted)",
-                           "dcn_bwd_weight": "dcn_bwd_weight_tc_kernel (dW = dY col^T on MFMA)"}[dom],
+                           "dcn_bwd_weight": "dcn_bwd_weight_coop_kernel (dW = dY col^T on MFMA; 2 / 4 output-channel tiles share a column gather)"}[dom],
                 "achieved": round(per_launch / 1e9 / k_ms, 1), "peak": MFMA_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(per_launch / 1e9 / k_ms / MFMA_BF16_TFLOPS, 4), "traffic": pmc_traffic(dom, args.layout),
                 "alg_flops_per_launch": per_launch, "ms_per_launch": round(k_ms, 4), "launches_timed": k_n,
