@@ -94,7 +94,7 @@ _SIGNATURES = {
     "d2amd_label_and_sample_max_candidates": (_i, []),
     "d2amd_label_and_sample_proposals": (_i, [ctypes.POINTER(SampleImage), _i, ctypes.POINTER(_f),
                                               ctypes.POINTER(ctypes.c_int8), _i, _i, _i, _i64, _i, _vp, _vp, _vp, _vp,
-                                              _vp, _vp, _vp, _vp, _i, _vp]),
+                                              _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "d2amd_uniform_keys": (_i, [_vp, _vp, _i64, _vp]),
     "d2amd_subsample_labels_workspace_bytes": (_sz, [_i, _i64, _i, _i]),
     "d2amd_subsample_labels": (_i, [_vp, _i, _i, _i64, _vp, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

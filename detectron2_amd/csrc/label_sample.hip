@@ -28,6 +28,7 @@
 
 #include "common.h"
 #include "matcher_core.h"
+#include "philox.h"
 
 namespace d2amd {
 
@@ -43,6 +44,7 @@ struct LsImage {
   const int64_t* gt_classes;
   const float* keys;
   int max_props, n_limits, num_gt, limit_stride;
+  long key_base;  // keys drawn in the kernel (LsBatch::key_state): index of this image's first key in the call's draw
 };
 
 struct LsBatch {
@@ -55,6 +57,10 @@ struct LsBatch {
   int* counts;
   float *rois, *head_rois;  // optional: the rows in pooler format (image, x1, y1, x2, y2); the first head_rows of each image
   int64_t* head_classes;    // optional: the classes of those first head_rows rows, [image][head_rows] contiguous
+  unsigned long long* key_state;  // optional: {seed, offset, ticket} of a device-resident generator (random_keys.hip) --
+                                  // the keys are then DRAWN HERE (key c of image i = output key_base_i + c of
+                                  // d2amd_uniform_keys at that state) and the last workgroup advances the offset
+  int key_images;                 // workgroups of the whole call (the ticket's target)
   int head_rows, image0;    // image0: batch index of this launch's first image
 };
 
@@ -96,6 +102,8 @@ __global__ __launch_bounds__(LS_THREADS) void label_sample_kernel(const LsBatch 
   }
   __syncthreads();
   const int n = s_n, G = I.num_gt;
+  unsigned long long kseed = 0ull, koffset = 0ull;  // (uniform) keys drawn here: the generator's state at this call
+  if (B.key_state) { kseed = B.key_state[0]; koffset = B.key_state[1]; }
   const int ncand = n + (B.append_gt ? G : 0);
   // ---- candidates of this thread: c = tid + k * LS_THREADS
   float4 box[LS_PER];
@@ -160,7 +168,8 @@ __global__ __launch_bounds__(LS_THREADS) void label_sample_kernel(const LsBatch 
         cls[k] = B.num_classes;  // roi_heads.py:207: no ground truth -> every proposal is background
       }
       grp = cls[k] == B.num_classes ? 1 : (cls[k] == -1 ? 2 : 0);  // sampling.py:39-40
-      key[k] = I.keys[c < n ? c : I.max_props + (c - n)];
+      const int kc = c < n ? c : I.max_props + (c - n);
+      key[k] = B.key_state ? philox_key(kseed, koffset, I.key_base + kc) : I.keys[kc];
       s_key[c] = key[k];
       if (grp < 2) {
         // monotone in the key (equal keys -> equal bucket; anything outside [0, 1) lands in the end buckets)
@@ -236,6 +245,14 @@ __global__ __launch_bounds__(LS_THREADS) void label_sample_kernel(const LsBatch 
     B.counts[2 * image] = num_pos;
     B.counts[2 * image + 1] = num_pos + num_neg;
   }
+  // the last workgroup of the CALL to finish advances the generator (every other one has read the offset: it finished)
+  if (B.key_state && tid == 0) {
+    const unsigned long long t = atomicAdd(&B.key_state[2], 1ull);
+    if (t == (unsigned long long)B.key_images - 1ull) {
+      B.key_state[1] = koffset + 1ull;
+      B.key_state[2] = 0ull;
+    }
+  }
 }
 
 }  // namespace d2amd
@@ -250,7 +267,7 @@ extern "C" int d2amd_label_and_sample_proposals(const d2amd_sample_image* images
                                                 float* boxes_out, int64_t* classes_out, int64_t* gt_index_out,
                                                 int64_t* index_out, int32_t* counts_out, float* rois_out,
                                                 float* head_rois_out, int64_t* head_classes_out, int head_rows,
-                                                void* stream) {
+                                                uint64_t* key_state, void* stream) {
   D2_CHECK_ARG(count >= 0 && (count == 0 || images != nullptr), "label_and_sample: bad image list");
   D2_CHECK_ARG(T >= 0 && T <= D2AMD_MATCHER_MAX_THRESHOLDS && labels != nullptr && (T == 0 || thresholds != nullptr),
                "label_and_sample: %d thresholds (max %d)", T, D2AMD_MATCHER_MAX_THRESHOLDS);
@@ -280,6 +297,9 @@ extern "C" int d2amd_label_and_sample_proposals(const d2amd_sample_image* images
   B.head_rois = head_rows > 0 ? head_rois_out : nullptr;
   B.head_classes = head_rows > 0 ? head_classes_out : nullptr;
   B.head_rows = head_rows;
+  B.key_state = (unsigned long long*)key_state;
+  B.key_images = count;
+  long key_base = 0;
   for (int i0 = 0; i0 < count; i0 += LS_MAX_IMAGES) {
     const int c = count - i0 < LS_MAX_IMAGES ? count - i0 : LS_MAX_IMAGES;
     for (int i = 0; i < c; i++) {
@@ -293,7 +313,7 @@ extern "C" int d2amd_label_and_sample_proposals(const d2amd_sample_image* images
       }
       D2_CHECK_ARG((s.max_proposals == 0 || s.proposals) && (s.n_limits == 0 || s.limits) &&
                        (s.num_gt == 0 || (s.gt_boxes && s.gt_classes)) &&
-                       (s.max_proposals + s.num_gt == 0 || s.keys),
+                       (s.max_proposals + s.num_gt == 0 || s.keys || key_state),
                    "label_and_sample: image %d: null pointer", i0 + i);
       LsImage& I = B.img[i];
       I.props = (const float4*)s.proposals;
@@ -305,6 +325,8 @@ extern "C" int d2amd_label_and_sample_proposals(const d2amd_sample_image* images
       I.n_limits = s.n_limits;
       I.num_gt = s.num_gt;
       I.limit_stride = s.limit_stride > 1 ? s.limit_stride : 1;
+      I.key_base = key_base;
+      key_base += (long)s.max_proposals + s.num_gt;
     }
     B.boxes = (float4*)boxes_out + (long)i0 * B.S;
     B.classes = classes_out + (long)i0 * B.S;

@@ -11,22 +11,9 @@
 // counter = {thread index lo, hi, offset lo, hi}, key = seed.  u32 -> [0, 1): (x >> 8) * 2^-24 (24 random bits: every
 // value is exactly representable, 0 included, 1 excluded -- the convention of torch.rand for fp32).
 #include "common.h"
+#include "philox.h"
 
 namespace d2amd {
-
-__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
-  const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
-  c[0] = hi1 ^ c[1] ^ k0; c[1] = lo1; c[2] = hi0 ^ c[3] ^ k1; c[3] = lo0;
-}
-
-__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-#pragma unroll
-  for (int r = 0; r < 10; r++) {
-    philox_round(c, k0, k1);
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-}
 
 // state: [0] seed, [1] offset (in units of 4 outputs per thread-slot), [2] ticket of the running launch
 __global__ __launch_bounds__(256) void uniform_keys_kernel(unsigned long long* __restrict__ state, float* __restrict__ out,

@@ -113,7 +113,7 @@ def label_and_sample_proposals_fixed(proposal_boxes, gt_boxes, gt_classes, limit
                                      thresholds=(0.5,), labels=(0, 1), batch_size_per_image: int = 512,
                                      positive_fraction: float = 0.25, num_classes: int = 80,
                                      proposal_append_gt: bool = True, generator: torch.Generator = None,
-                                     head_rows: int = 0):
+                                     head_rows: int = 0, keygen: "DeviceKeyGenerator" = None):
     """`ROIHeads.label_and_sample_proposals` (roi_heads/roi_heads.py:219-295) for a batch with a FIXED output shape and
     no host sync -- d2amd_label_and_sample_proposals (include/d2amd.h), one workgroup per image.
 
@@ -124,7 +124,10 @@ def label_and_sample_proposals_fixed(proposal_boxes, gt_boxes, gt_classes, limit
     {kept, flags, finite, 0}: pass the row with limit_stride = 2 (kept and finite; `DeviceProposals.limits`);
     gt_boxes / gt_classes: per image [G_i, 4] fp32 / [G_i] int64 HIP tensors (Matcher thresholds / labels as
     roi_heads.py:176-180 builds them: [0.5] / [0, 1], no low-quality matches);
-    keys: per image [max_p_i + G_i] uniform fp32 (default: torch.rand with `generator`).
+    keys: per image [max_p_i + G_i] uniform fp32 (default: torch.rand with `generator`);
+    keygen (instead of keys): a `DeviceKeyGenerator` -- the keys are drawn INSIDE the sampler's kernel from its
+    device-resident state (image i's keys are outputs sum_{j<i}(max_p_j + G_j) ... of one `keygen.uniform` draw, and the
+    generator advances as by one draw): no key launch, and in a captured step no cross-stream wait for one.
     Sampling rule: `subsample_labels` above (smallest keys per group), ties by candidate index.
 
     -> dict of HIP tensors: boxes [N, S, 4], classes [N, S] (class, num_classes = background, -1 = padding),
@@ -160,14 +163,17 @@ def label_and_sample_proposals_fixed(proposal_boxes, gt_boxes, gt_classes, limit
         c = gt_classes[i].detach().to(torch.int64).contiguous().reshape(-1)
         _C.require_gpu(p, g, c, op="label_and_sample_proposals")
         assert c.shape[0] == g.shape[0], (c.shape, g.shape)
-        k = keys[i] if keys is not None else torch.rand(p.shape[0] + g.shape[0], device=dev, generator=generator)
-        k = k.detach().float().contiguous().reshape(-1)
-        assert k.shape[0] == p.shape[0] + g.shape[0], (k.shape, p.shape, g.shape)
+        if keys is None and keygen is not None:
+            k = None
+        else:
+            k = keys[i] if keys is not None else torch.rand(p.shape[0] + g.shape[0], device=dev, generator=generator)
+            k = k.detach().float().contiguous().reshape(-1)
+            assert k.shape[0] == p.shape[0] + g.shape[0], (k.shape, p.shape, g.shape)
         lim = None if limits is None or limits[i] is None else limits[i].detach().reshape(-1)
         assert lim is None or (lim.dtype == torch.int64 and lim.is_contiguous()), "limits: contiguous int64 words"
         hold += [p, g, c, k, lim]
         imgs[i].proposals, imgs[i].gt_boxes, imgs[i].gt_classes, imgs[i].keys = (
-            _C.ptr(p).value, _C.ptr(g).value, _C.ptr(c).value, _C.ptr(k).value)
+            _C.ptr(p).value, _C.ptr(g).value, _C.ptr(c).value, None if k is None else _C.ptr(k).value)
         imgs[i].limits = None if lim is None else _C.ptr(lim).value
         imgs[i].max_proposals, imgs[i].num_gt = int(p.shape[0]), int(g.shape[0])
         st = max(int(limit_stride), 1)
@@ -181,6 +187,6 @@ def label_and_sample_proposals_fixed(proposal_boxes, gt_boxes, gt_classes, limit
             imgs, n_img, thr, lab, T, S, int(S * positive_fraction), int(num_classes), int(bool(proposal_append_gt)),
             _C.ptr(out["boxes"]), _C.ptr(out["classes"]), _C.ptr(out["gt_index"]), _C.ptr(out["index"]),
             _C.ptr(out["counts"]), _C.ptr(out["rois"]), _C.ptr(out.get("head_rois")), _C.ptr(out.get("head_classes")), H,
-            _C.stream()))
+            _C.ptr(keygen.state) if (keys is None and keygen is not None) else None, _C.stream()))
     out["_hold"] = hold  # inputs stay alive until the caller drops the result (the launch is asynchronous)
     return out

@@ -199,6 +199,11 @@ int d2amd_box_iou_rotated(const float* boxes1, int n, const float* boxes2, int m
  * head_rows rows of every image (the mask head's rows: positives come first) -- what d2amd_roi_pooler_forward takes
  * as they are; head_classes_out (optional) [count][head_rows]: classes_out of those rows, contiguous (what the mask loss
  * takes as it is: a strided slice of classes_out would cost the caller a copy launch).
+ * key_state (optional): the {seed, offset, ticket} words of a device-resident generator (d2amd_uniform_keys below).
+ * The keys are then drawn INSIDE the kernel -- images[i].keys is ignored; key c of image i is output
+ * (sum of max_proposals + num_gt of the images before i) + c of d2amd_uniform_keys at that state -- and the call
+ * advances the generator like one d2amd_uniform_keys call: a captured step needs no key launch (and no cross-stream
+ * wait for one) in front of the sampler.
  * max_proposals + num_gt <= d2amd_label_and_sample_max_candidates() per image, else D2AMD_EUNSUPPORTED. */
 typedef struct {
   const float* proposals;    /* [max_proposals][4] fp32 xyxy, 16-byte aligned */
@@ -214,7 +219,8 @@ int d2amd_label_and_sample_proposals(const d2amd_sample_image* images, int count
                                      const int8_t* labels, int T, int batch_size_per_image, int max_positives,
                                      int64_t num_classes, int append_gt, float* boxes_out, int64_t* classes_out,
                                      int64_t* gt_index_out, int64_t* index_out, int32_t* counts_out, float* rois_out,
-                                     float* head_rois_out, int64_t* head_classes_out, int head_rows, void* stream);
+                                     float* head_rois_out, int64_t* head_classes_out, int head_rows,
+                                     uint64_t* key_state, void* stream);
 
 /* ---- uniform sampling keys from a DEVICE-resident generator state (what the samplers below consume; the reference
  * draws torch.randperm inside subsample_labels, modeling/sampling.py:49-50).  state: 3 device uint64 words {seed, offset,

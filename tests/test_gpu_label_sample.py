@@ -104,6 +104,58 @@ def test_random_batches(seed):
         _same(out, want, i)
 
 
+def test_keys_drawn_inside_the_kernel():
+    """keygen=DeviceKeyGenerator: the sampler draws its keys itself from the generator's device-resident state.  Same
+    results as with the explicit keys of one `uniform` draw at that state (image i's keys = the outputs behind those
+    of the images before it), also for more images than one launch holds and inside a replayed graph; the generator
+    advances by one draw per call.  (The generator itself is pinned to Philox4x32-10's known answers in
+    tests/test_sampling.py / test_gpu_subsample.py.)"""
+    from detectron2_amd.modeling import DeviceKeyGenerator, label_and_sample_proposals_fixed
+    from oracle.sampling import philox_uniform_keys
+
+    rng = np.random.default_rng(11)
+    for n_img in (2, 19):
+        props, gts, gcs = [], [], []
+        for i in range(n_img):
+            G, n = int(rng.integers(0, 30)), int(rng.integers(1, 1500))
+            g = rng.uniform(0, 900, (G, 4)).astype(np.float32)
+            g[:, 2:] = g[:, :2] + rng.uniform(20, 300, (G, 2)).astype(np.float32)
+            p = rng.uniform(0, 1000, (n, 4)).astype(np.float32)
+            p[:, 2:] = p[:, :2] + rng.uniform(5, 320, (n, 2)).astype(np.float32)
+            if G:
+                p[:n // 2] = g[rng.integers(0, G, n // 2)] + rng.normal(0, 10, (n // 2, 4)).astype(np.float32)
+            props.append(cu(p)); gts.append(cu(g).reshape(-1, 4)); gcs.append(cu(rng.integers(0, 80, G).astype(np.int64)))
+        sizes = [int(p.shape[0] + g.shape[0]) for p, g in zip(props, gts)]
+        gen = DeviceKeyGenerator(DEV, seed=1234 + n_img)
+        for draw in range(2):  # two calls: the second one at offset 1
+            flat = cu(philox_uniform_keys(1234 + n_img, draw, sum(sizes)))  # the oracle's restatement of that draw
+            keys, at = [], 0
+            for sz in sizes:
+                keys.append(flat[at:at + sz]); at += sz
+            want = label_and_sample_proposals_fixed(props, gts, gcs, keys=keys, head_rows=64)
+            got = label_and_sample_proposals_fixed(props, gts, gcs, keygen=gen, head_rows=64)
+            for k in ("boxes", "classes", "gt_index", "index", "counts", "rois", "head_rois", "head_classes"):
+                assert torch.equal(got[k], want[k]), (n_img, draw, k)
+            assert gen.state.tolist() == [1234 + n_img, draw + 1, 0]
+    # replayed: every replay draws the next keys
+    gen = DeviceKeyGenerator(DEV, seed=77)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        label_and_sample_proposals_fixed(props[:2], gts[:2], gcs[:2], keygen=gen)
+    torch.cuda.current_stream().wait_stream(st)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = label_and_sample_proposals_fixed(props[:2], gts[:2], gcs[:2], keygen=gen)
+    seen = []
+    for rep in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        seen.append(out["index"].clone())
+        assert int(gen.state[1]) == 2 + rep
+    assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
+
+
 def test_agrees_with_the_two_step_path():
     """Same labels as Matcher.match_boxes on the concatenated candidates (the fused matcher the eager step uses)."""
     from detectron2_amd.modeling import Matcher, label_and_sample_proposals_fixed
