@@ -137,6 +137,9 @@ def test_keys_drawn_inside_the_kernel():
             for k in ("boxes", "classes", "gt_index", "index", "counts", "rois", "head_rois", "head_classes"):
                 assert torch.equal(got[k], want[k]), (n_img, draw, k)
             assert gen.state.tolist() == [1234 + n_img, draw + 1, 0]
+            # the mask head's rows are the leading rows of every image
+            assert torch.equal(got["head_classes"], got["classes"][:, :64])
+            assert torch.equal(got["head_rois"].view(n_img, 64, 5), got["rois"].view(n_img, -1, 5)[:, :64])
     # replayed: every replay draws the next keys
     gen = DeviceKeyGenerator(DEV, seed=77)
     st = torch.cuda.Stream()
