@@ -1,4 +1,14 @@
 #!/bin/bash
-cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp PYTHONPATH=$PWD
-for seed in 1 2 3 4 5 6; do PYTHONHASHSEED=$seed timeout 600 python -m pytest tests -m gpu -q -p no:cacheprovider -x 2>&1 | tail -1; done
-for i in 1 2 3 4; do timeout 300 python -m pytest tests/test_gpu_dist.py tests/test_gpu_connected_step.py -q -p no:cacheprovider 2>&1 | tail -1; done
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp PYTHONPATH=$PWD; R=$PWD
+PREV=$PWD/detectron2_amd/lib/libd2amd_prev.so
+cd /tmp
+for v in prev new; do
+  [ $v = prev ] && export D2AMD_LIB_PATH=$PREV || unset D2AMD_LIB_PATH
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pp_$v -o p -- python $R/scripts/pool_bwd_ab.py $v > /dev/null 2>&1
+  python - <<PY
+import csv,glob
+f=glob.glob("/tmp/pp_$v/**/*kernel_stats.csv",recursive=True)[0]
+for r in csv.DictReader(open(f)):
+    if "tile_lists" in r["Name"] or "roi_records" in r["Name"]: print("$v", r["Calls"], round(float(r["AverageNs"])/1e3,2), round(float(r["MinNs"])/1e3,2), r["Name"][:40])
+PY
+done
