@@ -406,7 +406,10 @@ constexpr int QTAKE = 64, QTAKE_PITCH = 32;  // (word 1 of a queue's line: scrat
 // WHICH lists are split must not depend on the order in which the binning workgroups run (the parts' sums are added in
 // part order, an unsplit list's items one after the other: the same tile must take the same route in every run), so the
 // scratch budget is handed out in TILE ORDER by the last binning workgroup to finish (tile_lists_kernel).
-constexpr int PART_LEN = 12, SPLIT_MIN = 24, MAX_PARTS = 6;
+// (Late round 3: for the bench's lists -- longest 33 -- cutting at 24 changes neither gather (65.1 / 38.9 us with and
+// without, same box) while the planner costs the binning kernel 4.3 us of its 17.9 on the step's critical path.  Lists
+// are cut from 40 entries on now, and the planner only runs when a binning wave has SEEN such a list.)
+constexpr int PART_LEN = 16, SPLIT_MIN = 40, MAX_PARTS = 6;
 constexpr int SCR_PER_XCD_MAX = 96;  // scratch slots per XCD queue (64 px x C fp32 each: 48 MB at C = 256)
 constexpr int SPLIT_MAX_SLABS = 4;   // channel slabs (of 256 channels, 16-bit) a split tile may have: one ticket each
 constexpr int QTICKETS = 8 * SCR_PER_XCD_MAX * SPLIT_MAX_SLABS;
@@ -602,7 +605,10 @@ __global__ __launch_bounds__(64 * LISTS_WAVES) void tile_lists_kernel(PoolLevels
     heavy = cnt >= Q.thr[pass];
     key = (heavy ? 0 : 16) + pass * 8 + x;
     // a list long enough to be split is queued by the planner below (the last workgroup), not here
-    if (pass == 0 && Q.scr_total > 0 && cnt > SPLIT_MIN && cnt <= TILE_CAP) { push = false; key = -1; }
+    if (pass == 0 && Q.scr_total > 0 && cnt > SPLIT_MIN && cnt <= TILE_CAP) {
+      push = false; key = -1;
+      if (lane == 0) atomicOr(Q.mem + QTAKE + 2, 1);  // (device scope; acknowledged before the ticket below)
+    }
   }
   if (lane == 0) { s_key[wave] = key; s_np[wave] = np; }
   __syncthreads();
@@ -641,6 +647,7 @@ __global__ __launch_bounds__(64 * LISTS_WAVES) void tile_lists_kernel(PoolLevels
   if (threadIdx.x == 0) s_run = 0;
   __syncthreads();
   if (!s_last) return;  // uniform
+  if (__hip_atomic_load(Q.mem + QTAKE + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;  // no long list
   constexpr int PT = 64 * LISTS_WAVES;
   for (int t0 = 0; t0 < ntiles; t0 += PT) {
     const int t = t0 + (int)threadIdx.x;
