@@ -680,8 +680,12 @@ __global__ __launch_bounds__(1024) void tk_sort_kernel(TkParams P, const SegStat
 // LDS broadcast read) and add their partial counts in LDS.  320 workgroups for 10 segments of 2,000 instead of the 10
 // of the bitonic sort, and no barrier chain: 66 dependent steps there, one pass here.
 constexpr int TK_RANK_MAX = 2048;
+#ifndef D2AMD_TK_RANK_THREADS
+#define D2AMD_TK_RANK_THREADS 1024
+#endif
+constexpr int TK_RANK_THREADS = D2AMD_TK_RANK_THREADS, TK_RANK_WAVES = TK_RANK_THREADS / 64;
 template <bool RPN>
-__global__ __launch_bounds__(256) void tk_rank_kernel(TkParams P, const SegState* __restrict__ st,
+__global__ __launch_bounds__(TK_RANK_THREADS) void tk_rank_kernel(TkParams P, const SegState* __restrict__ st,
                                                      const unsigned long long* __restrict__ cand, int kmax,
                                                      uint32_t* __restrict__ sel, int* __restrict__ cnt_out,
                                                      const TopkRpnEpilogue E) {
@@ -693,11 +697,12 @@ __global__ __launch_bounds__(256) void tk_rank_kernel(TkParams P, const SegState
   const int base = blockIdx.y * 64;
   if (base >= n) return;  // uniform
   const unsigned long long* in = cand + (long)seg * kmax;
-  const int np = (n + 7) & ~7;  // a quarter is a whole number of key pairs; the padding ranks above every key
-  for (int i = tid; i < np; i += 256) sk[i] = i < n ? in[i] : ~0ull;
+  // a wave's share is a whole number of key pairs; the padding ranks above every key
+  const int np = (n + 2 * TK_RANK_WAVES - 1) / (2 * TK_RANK_WAVES) * (2 * TK_RANK_WAVES);
+  for (int i = tid; i < np; i += TK_RANK_THREADS) sk[i] = i < n ? in[i] : ~0ull;
   if (tid < 64) rk[tid] = 0;
   __syncthreads();
-  const int lane = tid & 63, w = tid >> 6, q = np >> 2, me = base + lane;
+  const int lane = tid & 63, w = tid >> 6, q = np / TK_RANK_WAVES, me = base + lane;
   const unsigned long long mine = sk[min(me, np - 1)];
   const ulonglong2* p = reinterpret_cast<const ulonglong2*>(sk + w * q);
   int r = 0;
@@ -848,11 +853,11 @@ int topk_select(const TopkInput& in, bool use_thr, float xmin, uint32_t* sel, in
   if (w.kmax <= TK_RANK_MAX && !no_fused) {  // (the A/B switch also keeps the bitonic sort under test)
     static const bool no_epi = getenv("D2AMD_RPN_NO_FUSED_DECODE") != nullptr;  // A/B switch
     if (rpn && rpn_done && in.N <= 16 && !no_epi) {
-      hipLaunchKernelGGL(tk_rank_kernel<true>, dim3(in.N * in.L, cdiv(w.kmax, 64)), dim3(256), 0, s, P, w.st, w.cand,
+      hipLaunchKernelGGL(tk_rank_kernel<true>, dim3(in.N * in.L, cdiv(w.kmax, 64)), dim3(TK_RANK_THREADS), 0, s, P, w.st, w.cand,
                          w.kmax, sel, cnt, *rpn);
       *rpn_done = true;
     } else {
-      hipLaunchKernelGGL(tk_rank_kernel<false>, dim3(in.N * in.L, cdiv(w.kmax, 64)), dim3(256), 0, s, P, w.st, w.cand,
+      hipLaunchKernelGGL(tk_rank_kernel<false>, dim3(in.N * in.L, cdiv(w.kmax, 64)), dim3(TK_RANK_THREADS), 0, s, P, w.st, w.cand,
                          w.kmax, sel, cnt, TopkRpnEpilogue{});
     }
     D2_LAUNCH_OK();
