@@ -1,7 +1,7 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp PYTHONPATH=$PWD; R=$PWD
 PREV=$PWD/detectron2_amd/lib/libd2amd_prev.so
-timeout 600 python -m pytest tests/test_gpu_rpn.py tests/test_gpu_subsample.py tests/test_gpu_parity.py -q -p no:cacheprovider -x 2>&1 | tail -1
+timeout 600 python -m pytest tests/test_gpu_label_sample.py tests/test_gpu_connected_step.py -q -p no:cacheprovider -x 2>&1 | tail -1
 cd /tmp
 for v in prev new; do
   [ $v = prev ] && export D2AMD_LIB_PATH=$PREV || unset D2AMD_LIB_PATH
@@ -10,6 +10,6 @@ for v in prev new; do
 import csv,glob
 f=glob.glob("/tmp/pp_$v/**/*kernel_stats.csv",recursive=True)[0]
 for r in csv.DictReader(open(f)):
-    if "tk_rank" in r["Name"]: print("$v", r["Calls"], round(float(r["AverageNs"])/1e3,2), round(float(r["MinNs"])/1e3,2), r["Name"][:40])
+    if "label_sample" in r["Name"]: print("$v", r["Calls"], round(float(r["AverageNs"])/1e3,2), round(float(r["MinNs"])/1e3,2), r["Name"][:40])
 PY
 done
