@@ -34,6 +34,13 @@ PY_MODULES = [
     "detectron2/modeling/box_regression.py", "detectron2/modeling/poolers.py",
     "detectron2/modeling/proposal_generator/proposal_utils.py", "detectron2/modeling/roi_heads/mask_head.py",
     "detectron2/modeling/meta_arch/dense_detector.py",
+    "detectron2/layers/deform_conv.py", "detectron2/layers/wrappers.py",
+    "detectron2/structures/rotated_boxes.py", "projects/PointRend/point_rend/point_features.py",
+    # the reference's OWN unit tests of the hot-path operators (tests/test_gpu_reference_tests.py runs them, unmodified,
+    # against this package's operator surface)
+    "tests/layers/test_roi_align.py", "tests/layers/test_roi_align_rotated.py", "tests/layers/test_nms.py",
+    "tests/layers/test_nms_rotated.py", "tests/layers/test_deformable.py", "tests/structures/test_rotated_boxes.py",
+    "tests/structures/test_boxes.py", "tests/modeling/test_roi_pooler.py", "tests/modeling/test_matcher.py",
 ]
 PY_OUT = os.path.join(OUT_DIR, "py")
 
@@ -48,6 +55,7 @@ def build_py(force=False):
         return all(os.path.exists(pyc_path(m)) for m in PY_MODULES)
     import py_compile
 
+
     os.makedirs(PY_OUT, exist_ok=True)
     for m in PY_MODULES:
         src, dst = os.path.join(REF, m), pyc_path(m)
@@ -56,8 +64,71 @@ def build_py(force=False):
     return True
 
 
+DCN_OUT = os.path.join(OUT_DIR, "_d2ref_C.so")
+DCN_SOURCES = [
+    os.path.join(CSRC, "deformable", "deform_conv_cuda.cu"),
+    os.path.join(CSRC, "deformable", "deform_conv_cuda_kernel.cu"),
+    os.path.join(HERE, "ref_dcn_binding.cpp"),
+]
+# The two .cu files use five CUDA runtime names (deform_conv_cuda_kernel.cu:483-522 and its four twins); hipcc takes
+# the <<<>>> launches as they are.  The include shims (oracle/ref_shim/, ours) map the two CUDA-only torch headers.
+DCN_RENAMES = ["cudaStream_t=hipStream_t", "cudaError_t=hipError_t", "cudaGetLastError=hipGetLastError",
+               "cudaSuccess=hipSuccess", "cudaGetErrorString=hipGetErrorString"]
+
+
+def build_dcn(force=False, verbose=True):
+    """The reference's OWN deformable-convolution kernels (csrc/deformable/*.cu: the only upstream implementation of
+    DCN backward) compiled WHERE THEY LIE as HIP for gfx950 into oracle/_ref/_d2ref_C.so -- a CHECKER: a pybind11
+    module with detectron2._C's five DCN entry points (oracle/ref_dcn_binding.cpp), under which the reference's own
+    layers/deform_conv.py runs (oracle/ref.py: py_deform_conv).  No hipify pass (it writes next to its inputs): hipcc
+    -x hip + five -D renames + two shim headers.  hipcc cross-compiles without a GPU.  -> True if the module exists."""
+    if not os.path.isdir(CSRC):
+        return os.path.exists(DCN_OUT)
+    shims = [os.path.join(HERE, "ref_shim", "c10", "cuda", "CUDAGuard.h"),
+             os.path.join(HERE, "ref_shim", "ATen", "cuda", "Atomic.cuh")]
+    if os.path.exists(DCN_OUT) and not force:
+        if os.path.getmtime(DCN_OUT) >= max(os.path.getmtime(s) for s in DCN_SOURCES + shims):
+            return True
+    import sysconfig
+
+    import torch
+    from torch.utils import cpp_extension
+
+    os.makedirs(OUT_DIR, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    abi = int(torch._C._GLIBCXX_USE_CXX11_ABI)
+    flags = ["-x", "hip", "--offload-arch=gfx950", "-O2", "-fPIC", "-std=c++17", "-w", "-DWITH_HIP",
+             "-DTORCH_EXTENSION_NAME=_d2ref_C", f"-D_GLIBCXX_USE_CXX11_ABI={abi}"]
+    flags += cpp_extension.COMMON_HIP_FLAGS + cpp_extension.COMMON_HIPCC_FLAGS
+    flags += ["-D" + r for r in DCN_RENAMES]
+    flags += ["-I" + os.path.join(HERE, "ref_shim"), "-I" + CSRC, "-I" + sysconfig.get_paths()["include"]]
+    flags += ["-I" + p for p in cpp_extension.include_paths()]
+
+    def cc(src):
+        obj = os.path.join(OUT_DIR, "dcn_" + os.path.basename(src).rsplit(".", 1)[0] + ".o")
+        cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=3) as ex:
+        objs = list(ex.map(cc, DCN_SOURCES))
+    libdir = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cmd = [hipcc, "-shared", "-o", DCN_OUT] + objs + [
+        "-L" + libdir, "-ltorch", "-ltorch_cpu", "-ltorch_hip", "-lc10", "-lc10_hip", "-ltorch_python",
+        "-Wl,-rpath," + libdir]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    for o in objs:
+        os.remove(o)
+    return True
+
+
 def build(force=False, verbose=True):
     build_py(force)
+    build_dcn(force, verbose)
     if not os.path.isdir(CSRC):
         return False
     if os.path.exists(OUT) and not force:
@@ -98,4 +169,4 @@ def build(force=False, verbose=True):
 
 if __name__ == "__main__":
     ok = build(force="--force" in sys.argv)
-    print("built" if ok else "reference tree not found; skipped", OUT)
+    print("built" if ok else "reference tree not found; skipped", OUT, DCN_OUT)

@@ -311,3 +311,71 @@ def py_callers(layers_impl):
         return ns
 
     return _with_stubs(m, load)
+
+
+_REF_DCN = os.path.join(_HERE, "_ref", "_d2ref_C.so")
+
+
+def have_dcn():
+    return os.path.exists(_REF_DCN)
+
+
+def compiled_dcn():
+    """The reference's own csrc/deformable/*.cu compiled as HIP for gfx950 (oracle/build_ref.py: build_dcn) -- a
+    pybind11 module with detectron2._C's five DCN entry points (vision.cpp:86-102).  GPU CHECKER only."""
+    if "_d2ref_C" in sys.modules:
+        return sys.modules["_d2ref_C"]
+    if not have_dcn():
+        from . import build_ref
+
+        if not build_ref.build_dcn(verbose=False):
+            raise RuntimeError("compiled reference DCN unavailable (no oracle/_ref/_d2ref_C.so, no reference tree)")
+    import torch  # noqa: F401  (libtorch must be loaded first)
+
+    spec = importlib.util.spec_from_file_location("_d2ref_C", _REF_DCN)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    sys.modules["_d2ref_C"] = mod
+    return mod
+
+
+def py_deform_conv():
+    """detectron2/layers/deform_conv.py -- the reference's own autograd Functions and modules (_DeformConv,
+    _ModulatedDeformConv, DeformConv, ModulatedDeformConv) -- loaded unchanged with `detectron2._C` = compiled_dcn(),
+    `.wrappers` = the reference's own layers/wrappers.py, torchvision's deform_conv2d (its CPU forward, not installed)
+    stubbed to raise.  What this gives: the reference's DCN forward AND backward exactly as upstream runs them on a GPU
+    (deform_conv.py:62-133, 221-281 -> deform_conv_cuda.cu:272-1221)."""
+    names = ("detectron2", "detectron2.layers", "detectron2.utils", "detectron2.utils.develop", "detectron2.utils.env",
+             "torchvision", "torchvision.ops")
+    m = {n: types.ModuleType(n) for n in names}
+    for n in ("detectron2", "detectron2.layers", "detectron2.utils", "torchvision"):
+        m[n].__path__ = []
+    import torch
+
+    m["detectron2.utils.env"].TORCH_VERSION = tuple(int(x) for x in torch.__version__.split(".")[:2])
+
+    def _no_tv(*a, **k):
+        raise NotImplementedError("torchvision is not installed: the reference's CPU DCN forward cannot run here")
+
+    m["torchvision.ops"].deform_conv2d = _no_tv
+
+    def _dummy(name, *a):
+        raise ImportError(name)
+
+    m["detectron2.utils.develop"].create_dummy_class = lambda name, *a: (lambda *x, **k: _dummy(name))
+    m["detectron2.utils.develop"].create_dummy_func = lambda name, *a: (lambda *x, **k: _dummy(name))
+    m["detectron2"]._C = compiled_dcn()
+    m["detectron2._C"] = m["detectron2"]._C
+    m["detectron2"].layers, m["detectron2"].utils = m["detectron2.layers"], m["detectron2.utils"]
+    m["detectron2.utils"].develop, m["detectron2.utils"].env = m["detectron2.utils.develop"], m["detectron2.utils.env"]
+    m["torchvision"].ops = m["torchvision.ops"]
+
+    def load():
+        w = _load_by_path("detectron2.layers.wrappers", "detectron2/layers/wrappers.py")
+        m["detectron2.layers"].wrappers = w
+        mod = _load_by_path("detectron2.layers.deform_conv", "detectron2/layers/deform_conv.py")
+        sys.modules.pop("detectron2.layers.deform_conv", None)
+        sys.modules.pop("detectron2.layers.wrappers", None)
+        return mod
+
+    return _with_stubs(m, load)

@@ -30,3 +30,50 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def need_reference(available, what):
+    """Tests that run the REAL reference (oracle/_ref/, git-ignored; or /root/reference) must not become silent skips on
+    a checkout that lacks it: absence FAILS unless D2AMD_NO_REFERENCE=1 states the reference is legitimately absent."""
+    if available:
+        return
+    if os.environ.get("D2AMD_NO_REFERENCE") == "1":
+        pytest.skip(f"D2AMD_NO_REFERENCE=1: {what} not available")
+    pytest.fail(f"{what} missing: run `python -m oracle.build_ref` where /root/reference exists, or set "
+                "D2AMD_NO_REFERENCE=1 where it legitimately does not")
+
+
+# ----------------------------------------------------------------------------------------------- per-element bounds
+_RATIOS = {}
+
+
+def record_ratio(tag, ratio):
+    """max |d| / bound of a comparison; D2AMD_DUMP_RATIOS=<file> writes them all at the end of the session (the margins
+    quoted in DESIGN 5 come from such a file, committed under profiles/)."""
+    _RATIOS[tag] = max(float(ratio), _RATIOS.get(tag, 0.0))
+
+
+def pytest_sessionfinish(session, exitstatus):
+    path = os.environ.get("D2AMD_DUMP_RATIOS")
+    if path and _RATIOS:
+        import json
+
+        with open(path, "w") as f:
+            json.dump(_RATIOS, f, indent=1, sort_keys=True)
+
+
+def assert_close_fp32(got, exp, tag="", rel=1e-4, floor=1e-6):
+    """north_star's float bar, per ELEMENT: |got - exp| <= rel |exp| + floor max|exp| (the floor is what an fp32 sum of
+    O(1) terms that cancels can be held to; a max-norm `max|d| / max|exp|` lets a wrong small-magnitude element pass)."""
+    import numpy as np
+
+    got, exp = np.asarray(got, np.float64), np.asarray(exp, np.float64)
+    assert got.shape == exp.shape, (tag, got.shape, exp.shape)
+    if exp.size == 0:
+        return
+    bound = rel * np.abs(exp) + floor * max(float(np.abs(exp).max()), 1e-30)
+    d = np.abs(got - exp)
+    r = float((d / bound).max())
+    if tag:
+        record_ratio(tag, r)
+    assert r <= 1.0, f"{tag}: {int((d > bound).sum())} of {d.size} elements out of bound, worst |d| / bound = {r:.3g}"

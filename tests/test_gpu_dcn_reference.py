@@ -1,0 +1,170 @@
+"""DCN forward AND backward pinned to the REFERENCE's own implementation ("backward is parity-unpinned" --
+closed here).  The only upstream implementation of grad_input / grad_offset / grad_mask / grad_weight / grad_bias is
+detectron2/layers/csrc/deformable/deform_conv_cuda.cu:446-824,985-1221 + deform_conv_cuda_kernel.cu:216-452,785-1066,
+driven by layers/deform_conv.py:62-133,221-281.  oracle/build_ref.py:build_dcn() compiles those files where they lie
+as HIP for gfx950 into oracle/_ref/_d2ref_C.so -- a CHECKER (test infrastructure; nothing under detectron2_amd/ may load
+it: tests/test_sampling.py::test_product_has_no_cpu_path) -- and oracle/ref.py:py_deform_conv() runs the reference's own
+Python on top of it.  Two kinds of test:
+
+* LIVE: the reference runs on this GPU next to the product's kernels, every element of every tensor, small shapes and
+  the BASELINE configs[4] block shapes (2 images, res3 / res4 / res5).  Needs oracle/_ref/ (git-ignored, travels with
+  the working tree); its absence is a FAILURE unless D2AMD_NO_REFERENCE=1 says the reference tree is legitimately absent.
+* GOLDEN: tests/golden/dcn_reference_gpu.npz, written by tests/golden/make_dcn_reference_gpu.py from the same reference
+  build on an MI355X; always runs (small cases: every element; full size: 16,384 sampled elements per tensor).
+
+Bounds.  fp32 product path: |d| <= 1e-4 |ref| + 1e-6 max|ref| per element (north_star: "within 1e-4 rel").  16-bit
+paths (inputs rounded to the I/O dtype, reference run in fp32 on the rounded inputs): |d| <= a |ref| + b rms(ref) per
+element with (a, b) = (2^-7, 2^-6) for bf16 and (2^-10, 2^-9) for fp16 -- one output rounding plus the 16-bit rounding
+of the MFMA operands (gathered columns, dcol) of a sum of 9 Ci ... 2 P independent terms."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import _dcn_cases as dc
+from conftest import need_reference, record_ratio
+from detectron2_amd import layers
+from oracle import ref
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "dcn_reference_gpu.npz")
+AB = {torch.bfloat16: (2.0 ** -7, 2.0 ** -6), torch.float16: (2.0 ** -10, 2.0 ** -9)}
+
+
+def _dump(tag, key, ratio):
+    record_ratio(f"dcn_ref/{tag}/{key}", ratio)
+
+
+def require_reference():
+    need_reference(ref.have_dcn() and ref.have_py(), "oracle/_ref/_d2ref_C.so (the reference's own DCN kernels)")
+    return ref.py_deform_conv()
+
+
+def bound_fp32(refv):
+    return 1e-4 * np.abs(refv) + 1e-6 * float(np.abs(refv).max())
+
+
+def bound_16(refv, dtype, rms=None):
+    a, b = AB[dtype]
+    rms = float(np.sqrt((refv.astype(np.float64) ** 2).mean())) if rms is None else rms
+    return a * np.abs(refv) + b * rms
+
+
+def compare(tag, got, exp, bound_fn):
+    bad = {}
+    for k in exp:
+        assert got[k].shape == exp[k].shape, (tag, k)
+        b = bound_fn(exp[k])
+        d = np.abs(got[k].astype(np.float64) - exp[k])
+        r = float((d / np.maximum(b, 1e-300)).max())
+        _dump(tag, k, r)
+        if not (d <= b).all():
+            bad[k] = (r, int((d > b).sum()), int(d.size))
+    assert not bad, (tag, bad)
+
+
+def product(case, dtype=torch.float32, channels_last=False):
+    return dc.run_module(layers.modulated_deform_conv, layers.deform_conv, case, DEV, dtype, channels_last)
+
+
+# ------------------------------------------------------------------------------------------------------- live
+@pytest.mark.parametrize("name", list(dc.SMALL))
+def test_small_fp32_vs_reference_live(name):
+    m = require_reference()
+    case = dc.make_small(name)
+    exp = dc.run_module(m.modulated_deform_conv, m.deform_conv, case, DEV)
+    compare(f"live_fp32/{name}", product(case), exp, bound_fp32)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("name", list(dc.SMALL))
+def test_small_16bit_vs_reference_live(name, dtype):
+    m = require_reference()
+    case = dc.make_small(name, rounding=dtype)
+    exp = dc.run_module(m.modulated_deform_conv, m.deform_conv, case, DEV)
+    compare(f"live_{dtype}/{name}", product(case, dtype), exp, lambda e: bound_16(e, dtype))
+
+
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("name", list(dc.FULL))
+def test_full_size_16bit_vs_reference_live(name, dtype, layout):
+    """BASELINE configs[4] block shapes, every element of out / dX / d offset / d mask / dW / d bias, both entries of the
+    16-bit MFMA path (the NCHW one and the channels_last one bench.py's dcn_r50 workload times)."""
+    m = require_reference()
+    case = dc.make_full(name, rounding=dtype)
+    exp = dc.run_module(m.modulated_deform_conv, m.deform_conv, case, DEV)
+    got = product(case, dtype, channels_last=(layout == "nhwc"))
+    compare(f"live_full_{dtype}_{layout}/{name}", got, exp, lambda e: bound_16(e, dtype))
+
+
+@pytest.mark.parametrize("name", list(dc.FULL))
+def test_full_size_fp32_vs_reference_live(name):
+    m = require_reference()
+    case = dc.make_full(name, rounding=torch.bfloat16)
+    exp = dc.run_module(m.modulated_deform_conv, m.deform_conv, case, DEV)
+    compare(f"live_full_fp32/{name}", product(case), exp, bound_fp32)
+
+
+def test_reference_fp16_path_is_no_closer_to_exact_than_ours():
+    """Context for the 16-bit bounds: the reference's OWN fp16 kernels (half columns, half atomics) against its fp32
+    run on the same fp16-rounded inputs, next to the product's fp16 path -- ours is at least as close on every tensor
+    (measured by rms error)."""
+    m = require_reference()
+    case = dc.make_small("v2_base", rounding=torch.float16)
+    exact = dc.run_module(m.modulated_deform_conv, m.deform_conv, case, DEV)
+    theirs = dc.run_module(m.modulated_deform_conv, m.deform_conv, case, DEV, torch.float16)
+    ours = product(case, torch.float16)
+    for k in exact:
+        rms = lambda a: float(np.sqrt(((a.astype(np.float64) - exact[k]) ** 2).mean()))
+        _dump("ref_fp16_vs_exact", k, rms(theirs[k]) / max(rms(ours[k]), 1e-30))
+        assert rms(ours[k]) <= 1.5 * rms(theirs[k]) + 1e-7, (k, rms(ours[k]), rms(theirs[k]))
+
+
+# ------------------------------------------------------------------------------------------------------ golden
+@pytest.fixture(scope="module")
+def golden():
+    assert os.path.exists(GOLDEN), "tests/golden/dcn_reference_gpu.npz missing (tests/golden/make_dcn_reference_gpu.py)"
+    return np.load(GOLDEN)
+
+
+def _small_golden(golden, name, case):
+    assert abs(float(golden[f"small/{name}/checksum"]) - dc.input_checksum(case)) < 1e-6 * dc.input_checksum(case), \
+        "the seeded inputs differ from the ones the golden file was generated from"
+    return {k: golden[f"small/{name}/{k}"] for k in dc.KEYS if f"small/{name}/{k}" in golden.files}
+
+
+@pytest.mark.parametrize("name", list(dc.SMALL))
+def test_small_fp32_vs_reference_golden(golden, name):
+    case = dc.make_small(name)
+    compare(f"golden_fp32/{name}", product(case), _small_golden(golden, name, case), bound_fp32)
+
+
+@pytest.mark.parametrize("dtype,tag", [(torch.bfloat16, "bf16"), (torch.float16, "f16")])
+@pytest.mark.parametrize("name", list(dc.FULL))
+def test_full_size_16bit_vs_reference_golden(golden, name, dtype, tag):
+    case = dc.make_full(name, rounding=dtype)
+    cs = dc.input_checksum(case)
+    assert abs(float(golden[f"full/{tag}/{name}/checksum"]) - cs) < 1e-6 * cs
+    got = product(case, dtype, channels_last=True)
+    bad = {}
+    for k in dc.KEYS:
+        vals, stats = golden[f"full/{tag}/{name}/{k}/values"], golden[f"full/{tag}/{name}/{k}/stats"]
+        idx = dc.sample_indices(name, k, got[k].size)
+        g = got[k].reshape(-1)[idx].astype(np.float64)
+        rms = float(np.sqrt(stats[1] / got[k].size))
+        b = bound_16(vals, dtype, rms=rms)
+        d = np.abs(g - vals)
+        _dump(f"golden_full_{tag}/{name}", k, float((d / b).max()))
+        if not (d <= b).all():
+            bad[k] = (float((d / b).max()), int((d > b).sum()))
+        # whole-tensor checksum: the sum of all elements agrees to the accumulated per-element bound
+        n = got[k].size
+        cs_bound = AB[dtype][1] * rms * np.sqrt(n) * 4 + AB[dtype][0] * abs(stats[0])
+        cs_err = abs(float(got[k].astype(np.float64).sum()) - stats[0])
+        _dump(f"golden_full_{tag}/{name}", k + "_sum", cs_err / cs_bound)
+        if cs_err > cs_bound:
+            bad[k + "_sum"] = (cs_err / cs_bound,)
+    assert not bad, (name, tag, bad)

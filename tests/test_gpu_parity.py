@@ -19,6 +19,7 @@ from detectron2_amd.layers import (DeformConv, ModulatedDeformConv, ROIAlign, RO
 from detectron2_amd.structures import Boxes, pairwise_intersection, pairwise_ioa, pairwise_iou
 
 from _torch_ref import dcn_torch
+from conftest import assert_close_fp32
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -64,11 +65,11 @@ def test_roi_align_forward_backward_fp32(layout, out, sr, aligned):
     y = op(xin, cu(rois))
     exp = oracle.roi_align_forward(x, rois, out, 0.25, sr, aligned)
     assert y.shape == exp.shape
-    assert rel_err(y.detach().cpu().numpy(), exp) < 1e-4
+    assert_close_fp32(y.detach().cpu().numpy(), exp, "parity:67")
     g = rng.standard_normal(exp.shape).astype(np.float32)
     y.backward(cu(g))
     gexp = oracle.roi_align_backward(g, rois, x.shape, 0.25, sr, aligned)
-    assert rel_err(xt.grad.cpu().numpy(), gexp) < 1e-4
+    assert_close_fp32(xt.grad.cpu().numpy(), gexp, "parity:71")
 
 
 def test_roi_align_known_answers_gpu():
@@ -120,9 +121,9 @@ def test_roi_align_rotated_golden_and_oracle(golden_dir):
     for sr in (0, 2):
         xt = cu(d["x"]).requires_grad_(True)
         y = ROIAlignRotated((7, 7), 0.5, sr)(xt, cu(d["rois"]))
-        assert rel_err(y.detach().cpu().numpy(), d[f"out_sr{sr}"]) < 1e-4
+        assert_close_fp32(y.detach().cpu().numpy(), d[f"out_sr{sr}"], "parity:123")
         y.backward(cu(d["grad"]))
-        assert rel_err(xt.grad.cpu().numpy(), d[f"gin_sr{sr}"]) < 1e-4
+        assert_close_fp32(xt.grad.cpu().numpy(), d[f"gin_sr{sr}"], "parity:125")
     # channels_last + known answers test_roi_align_rotated.py:30-71
     x = torch.arange(25, dtype=torch.float32, device=DEV).reshape(1, 1, 5, 5)
     exp = np.array([[4.5, 5.0, 5.5, 6.0], [7.0, 7.5, 8.0, 8.5], [9.5, 10.0, 10.5, 11.0], [12.0, 12.5, 13.0, 13.5]])
@@ -134,7 +135,7 @@ def test_roi_align_rotated_golden_and_oracle(golden_dir):
     a = ROIAlignRotated((7, 7), 0.5, 2)(cu(xr), cu(rr))
     b = ROIAlignRotated((7, 7), 0.5, 2)(cu(xr).contiguous(memory_format=torch.channels_last), cu(rr))
     assert rel_err(b.cpu().numpy(), a.cpu().numpy()) < 1e-5
-    assert rel_err(a.cpu().numpy(), oracle.roi_align_rotated_forward(xr, rr, (7, 7), 0.5, 2)) < 1e-4
+    assert_close_fp32(a.cpu().numpy(), oracle.roi_align_rotated_forward(xr, rr, (7, 7), 0.5, 2), "parity:137")
 
 
 def test_roi_align_equals_rotated_zero_angle_gpu():
@@ -178,7 +179,7 @@ def test_roi_align_full_size_properties():
     # sampled oracle check (32 ROIs, 8 channels)
     sel = rng.choice(K, 32, replace=False)
     exp = oracle.roi_align_forward(x[:, :8].cpu().numpy(), rois_np[sel], (7, 7), 0.25, 0, True)
-    assert rel_err(y1[sel][:, :8].cpu().numpy(), exp) < 1e-4
+    assert_close_fp32(y1[sel][:, :8].cpu().numpy(), exp, "parity:181")
     # NHWC bf16 == NCHW fp32 on the same bf16-rounded input, to bf16 precision
     xb = x.to(torch.bfloat16)
     yb = op(xb.contiguous(memory_format=torch.channels_last), rois)
@@ -229,7 +230,11 @@ def test_box_iou_rotated_bit_exact(golden_dir):
     # known answers /root/reference/tests/structures/test_rotated_boxes.py
     f = lambda a, b: pairwise_iou_rotated(cu(np.array(a, np.float32)), cu(np.array(b, np.float32))).cpu().numpy()
     assert np.allclose(f([[0.5, 0.5, 1, 1, 0]], [[0.25, 0.5, 0.5, 1, 0]]), 0.5)
-    assert np.allclose(f([[1, 1, 2, 2, 0]], [[1, 1, 2, 2, 45]]), 2 * (np.sqrt(2) - 1) * 2 / (8 - 2 * (np.sqrt(2) - 1) * 2), atol=1e-5) or True
+    # 45 degrees: /root/reference/tests/structures/test_rotated_boxes.py:277-290 (both 0.5), and a square against its own
+    # 45-degree turn: a regular octagon of area 8 (sqrt 2 - 1) inside two squares of area 4 -> 1 / sqrt 2
+    r2 = float(np.sqrt(2))
+    assert np.allclose(f([[1, 1, r2, r2, 45], [1, 1, 2 * r2, 2 * r2, -45]], [[1, 1, 2, 2, 0]]), [[0.5], [0.5]], atol=1e-6)
+    assert np.allclose(f([[1, 1, 2, 2, 0]], [[1, 1, 2, 2, 45]]), 8 * (r2 - 1) / (8 - 8 * (r2 - 1)), atol=1e-5)
     assert np.allclose(f([[5, 5, 10, 6, 55]], [[5, 5, 10, 6, -35]]), 36 / 84, atol=1e-5)
     assert f([[160.0, 153.0, 230.0, 23.0, -37.0]], [[-0.122, 197.5, 0.122, 155.5, 90.0]])[0, 0] < 1e-4
     # shape with a huge M (test_rotated_boxes.py:71-76 uses 5 x 1,289,035)
@@ -546,16 +551,16 @@ def test_deform_conv_fwd_bwd_fp32(modulated, B, C, Co, H, W, groups, dg, stride,
     mt = cu(msk).requires_grad_(True) if modulated else None
     y = mod(xt, ot, mt) if modulated else mod(xt, ot)
     exp = oracle.deform_conv_forward(x, off, w, mask=msk, bias=bias, **kw)
-    assert rel_err(y.detach().cpu().numpy(), exp) < 1e-4
+    assert_close_fp32(y.detach().cpu().numpy(), exp, "parity:553")
     go = rng.standard_normal(exp.shape).astype(np.float32)
     y.backward(cu(go))
     g = oracle.deform_conv_backward(x, off, w, go, mask=msk, with_bias=modulated, **kw)
-    assert rel_err(xt.grad.cpu().numpy(), g["grad_input"]) < 1e-4
-    assert rel_err(ot.grad.cpu().numpy(), g["grad_offset"]) < 1e-4
-    assert rel_err(mod.weight.grad.cpu().numpy(), g["grad_weight"]) < 1e-4
+    assert_close_fp32(xt.grad.cpu().numpy(), g["grad_input"], "parity:557")
+    assert_close_fp32(ot.grad.cpu().numpy(), g["grad_offset"], "parity:558")
+    assert_close_fp32(mod.weight.grad.cpu().numpy(), g["grad_weight"], "parity:559")
     if modulated:
-        assert rel_err(mt.grad.cpu().numpy(), g["grad_mask"]) < 1e-4
-        assert rel_err(mod.bias.grad.cpu().numpy(), g["grad_bias"]) < 1e-4
+        assert_close_fp32(mt.grad.cpu().numpy(), g["grad_mask"], "parity:561")
+        assert_close_fp32(mod.bias.grad.cpu().numpy(), g["grad_bias"], "parity:562")
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -597,11 +602,11 @@ def test_deform_conv_zero_offset_equals_conv2d_full_size():
     one = torch.ones(B, 9, H, W, device=DEV)
     y = layers.modulated_deform_conv(x, off, one, w, None, 1, 1, 1, 1, 1)
     ref = torch.nn.functional.conv2d(x, w, padding=1)
-    assert rel_err(y.cpu().numpy(), ref.cpu().numpy()) < 1e-4
+    assert_close_fp32(y.cpu().numpy(), ref.cpu().numpy(), "parity:604")
     y1 = layers.deform_conv(x, off, w, 1, 1, 1, 1, 1)
-    assert rel_err(y1.cpu().numpy(), ref.cpu().numpy()) < 1e-4
+    assert_close_fp32(y1.cpu().numpy(), ref.cpu().numpy(), "parity:606")
     yh = layers.modulated_deform_conv(x, off, 0.5 * one, w, None, 1, 1, 1, 1, 1)
-    assert rel_err(yh.cpu().numpy(), 0.5 * ref.cpu().numpy()) < 1e-4
+    assert_close_fp32(yh.cpu().numpy(), 0.5 * ref.cpu().numpy(), "parity:608")
     xb, wb = x.bfloat16(), w.bfloat16()
     yb = layers.modulated_deform_conv(xb, off.bfloat16(), one.bfloat16(), wb, None, 1, 1, 1, 1, 1)
     refb = torch.nn.functional.conv2d(xb.float(), wb.float(), padding=1)

@@ -12,13 +12,22 @@ import torch
 import detectron2_amd.layers as d2l
 from oracle import ref
 
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not ref.have_py(), reason="reference modules not staged "
-                                                                         "(python -m oracle.build_ref)")]
+import os
+
+pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda", 0)
 
 
 @pytest.fixture(scope="module")
 def R():
+    """oracle/_ref/ is git-ignored and travels with the working tree: a checkout without it must not turn this file into
+    a silent skip.  Missing reference modules FAIL unless D2AMD_NO_REFERENCE=1 states that the reference tree is
+    legitimately absent on this machine."""
+    if not ref.have_py():
+        if os.environ.get("D2AMD_NO_REFERENCE") == "1":
+            pytest.skip("D2AMD_NO_REFERENCE=1: reference modules not staged")
+        pytest.fail("oracle/_ref/py/*.pyc missing: run `python -m oracle.build_ref` where /root/reference exists, "
+                    "or set D2AMD_NO_REFERENCE=1 where it legitimately does not")
     return ref.py_callers(d2l)
 
 

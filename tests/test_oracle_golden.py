@@ -302,8 +302,10 @@ def test_deform_conv_fwd_bwd_vs_torch_autograd(modulated, groups, dg):
 
 
 # ---------------------------------------------------------------- live compiled reference
-@pytest.mark.skipif(not (ref.have_compiled() or ref.have_tree()), reason="compiled reference unavailable")
 def test_live_against_compiled_reference():
+    from conftest import need_reference
+
+    need_reference(ref.have_compiled() or ref.have_tree(), "oracle/_ref/libd2ref.so (compiled reference)")
     ops = ref.compiled()
     rng = np.random.default_rng(11)
     n = 200

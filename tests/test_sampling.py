@@ -41,10 +41,12 @@ def test_sizes_membership_and_fill_rule(n_pos, n_neg, num, frac, exp):
             assert len(rest) == 0 or keys[rest].min() >= keys[idx].max()
 
 
-@pytest.mark.skipif(not ref.have_tree(), reason="needs /root/reference")
 @pytest.mark.parametrize("n_pos,n_neg,num,frac,exp", CASES)
 def test_same_sizes_and_groups_as_the_reference_function(n_pos, n_neg, num, frac, exp):
     """The reference's own subsample_labels on the same labels: same result sizes, members of the same groups."""
+    from conftest import need_reference
+
+    need_reference(ref.have_py(), "the reference's modeling/sampling.py (oracle/_ref/py)")
     rs = ref.py_sampling()
     lab = _labels(n_pos, n_neg, 40, seed=3)
     rp, rn = rs.subsample_labels(torch.from_numpy(lab), num, frac, 0)
