@@ -83,6 +83,8 @@ _SIGNATURES = {
                                              _i, _vp]),
     "d2amd_roi_align_rotated_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp, _vp]),
     "d2amd_roi_align_rotated_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp, _sz, _vp]),
+    "d2amd_roi_align_f64_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _d, _i, _i, _i, _vp, _vp]),
+    "d2amd_roi_align_f64_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _d, _i, _i, _i, _vp]),
     "d2amd_pairwise_iou": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp]),
     "d2amd_box_iou_rotated": (_i, [_vp, _i, _vp, _i, _vp, _vp]),
     "d2amd_matcher_workspace_bytes": (_sz, [_i]),

@@ -255,6 +255,111 @@ static int bwd_impl(const void* grad_output, const float* rois, void* grad_input
   return D2AMD_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// fp64 entries (d2amd_roi_align_f64_*): the reference's ops are instantiated for double
+// (ROIAlignRotated_cuda.cu: AT_DISPATCH_FLOATING_TYPES_AND_HALF, torchvision likewise) and its tests
+// gradcheck them in double (tests/layers/test_roi_align_rotated.py:107-172).  Not a performance path:
+// one thread per output element, every quantity double as ROIAlignRotated_cpu.cpp:27-129,201-416
+// with T = double (axis-aligned: the pixel model of layers/roi_align.py:15-35), ROIs double (the
+// reference casts them to the input dtype, roi_align.py:60), NCHW, double atomics in the backward.
+struct RoiGeom64 {
+  int batch, grid_w, grid_h;
+  double start_w, start_h, bin_w, bin_h, center_w, center_h, cos_t, sin_t;
+  bool bad;
+};
+template <bool ROT>
+__device__ __forceinline__ RoiGeom64 roi_geom64(const double* __restrict__ rois, int k, double scale, int PH, int PW,
+                                                int sr, int aligned) {
+  RoiGeom64 g;
+  g.bad = false;
+  double roi_w, roi_h;
+  if (ROT) {
+    const double* r = rois + (long)k * 6;
+    g.batch = (int)r[0];
+    g.center_w = r[1] * scale - 0.5;
+    g.center_h = r[2] * scale - 0.5;
+    roi_w = r[3] * scale;
+    roi_h = r[4] * scale;
+    const double theta = r[5] * 3.14159265358979323846 / 180.0;
+    g.cos_t = cos(theta);
+    g.sin_t = sin(theta);
+    g.bad = !(roi_w >= 0.0 && roi_h >= 0.0);
+    g.start_h = -roi_h / 2.0;
+    g.start_w = -roi_w / 2.0;
+  } else {
+    const double* r = rois + (long)k * 5;
+    g.batch = (int)r[0];
+    const double off = aligned ? 0.5 : 0.0;
+    g.start_w = r[1] * scale - off;
+    g.start_h = r[2] * scale - off;
+    roi_w = (r[3] * scale - off) - g.start_w;
+    roi_h = (r[4] * scale - off) - g.start_h;
+    if (!aligned) { roi_w = fmax(roi_w, 1.0); roi_h = fmax(roi_h, 1.0); }
+    g.center_w = g.center_h = 0.0;
+    g.cos_t = 1.0;
+    g.sin_t = 0.0;
+  }
+  g.bin_h = roi_h / (double)PH;
+  g.bin_w = roi_w / (double)PW;
+  g.grid_h = sr > 0 ? sr : (int)ceil(roi_h / (double)PH);
+  g.grid_w = sr > 0 ? sr : (int)ceil(roi_w / (double)PW);
+  return g;
+}
+struct Tap64 { int lo, hi; double wlo, whi; bool valid; };
+__device__ __forceinline__ Tap64 axis_tap64(double y, int size) {
+  Tap64 t;
+  t.valid = !(y < -1.0 || y > (double)size);
+  if (y < 0.0) y = 0.0;
+  int lo = (int)y, hi;
+  if (lo >= size - 1) { hi = lo = size - 1; y = (double)lo; } else { hi = lo + 1; }
+  const double l = y - (double)lo;
+  t.lo = lo; t.hi = hi; t.whi = l; t.wlo = 1.0 - l;
+  return t;
+}
+
+// BWD = false: data = input [N,C,H,W], res = output [K,C,PH,PW];  BWD = true: data = grad_output, res = grad_input (zeroed)
+template <bool ROT, bool BWD>
+__global__ __launch_bounds__(256) void roi_align_f64_kernel(const double* __restrict__ data, const double* __restrict__ rois,
+                                                           double* __restrict__ res, int C, int H, int W, int K, int PH,
+                                                           int PW, double scale, int sr, int aligned, int* status) {
+  const long total = (long)K * C * PH * PW;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int pw = (int)(idx % PW), ph = (int)((idx / PW) % PH), c = (int)((idx / PW / PH) % C), k = (int)(idx / PW / PH / C);
+    const RoiGeom64 g = roi_geom64<ROT>(rois, k, scale, PH, PW, sr, aligned);
+    if (ROT && g.bad) {
+      if (!BWD) { if (status) atomicOr(status, 1); res[idx] = 0.0; }
+      continue;
+    }
+    const double count = (double)max(g.grid_h * g.grid_w, 1);
+    const long plane = (long)H * W;
+    const long base = ((long)g.batch * C + c) * plane;
+    const double go = BWD ? data[idx] : 0.0;
+    double acc = 0.0;
+    for (int iy = 0; iy < g.grid_h; iy++) {
+      const double yy = g.start_h + (double)ph * g.bin_h + ((double)iy + 0.5) * g.bin_h / (double)g.grid_h;
+      for (int ix = 0; ix < g.grid_w; ix++) {
+        const double xx = g.start_w + (double)pw * g.bin_w + ((double)ix + 0.5) * g.bin_w / (double)g.grid_w;
+        const double y = ROT ? yy * g.cos_t - xx * g.sin_t + g.center_h : yy;
+        const double x = ROT ? yy * g.sin_t + xx * g.cos_t + g.center_w : xx;
+        const Tap64 ty = axis_tap64(y, H), tx = axis_tap64(x, W);
+        if (!(ty.valid && tx.valid)) continue;
+        const long o1 = base + (long)ty.lo * W + tx.lo, o2 = base + (long)ty.lo * W + tx.hi;
+        const long o3 = base + (long)ty.hi * W + tx.lo, o4 = base + (long)ty.hi * W + tx.hi;
+        if (BWD) {
+          atomicAdd(res + o1, go * (ty.wlo * tx.wlo) / count);
+          atomicAdd(res + o2, go * (ty.wlo * tx.whi) / count);
+          atomicAdd(res + o3, go * (ty.whi * tx.wlo) / count);
+          atomicAdd(res + o4, go * (ty.whi * tx.whi) / count);
+        } else {
+          acc += (ty.wlo * tx.wlo) * data[o1] + (ty.wlo * tx.whi) * data[o2] + (ty.whi * tx.wlo) * data[o3] +
+                 (ty.whi * tx.whi) * data[o4];
+        }
+      }
+    }
+    if (!BWD) res[idx] = acc / count;
+  }
+}
+
 static int check_common(const char* who, int N, int C, int H, int W, int K, int PH, int PW, int dtype, int layout) {
   D2_CHECK_ARG(N >= 0 && C >= 0 && H >= 0 && W >= 0 && K >= 0 && PH > 0 && PW > 0, "%s: bad shape", who);
   D2_CHECK_ARG(layout == D2AMD_NCHW || layout == D2AMD_NHWC, "%s: bad layout %d", who, layout);
@@ -339,4 +444,48 @@ extern "C" int d2amd_roi_align_rotated_backward(const void* grad_output, const f
     return bwd_impl<scalar_t>(grad_output, rois, grad_input, N, C, H, W, K, pooled_h, pooled_w, spatial_scale,
                               sampling_ratio, 1, layout, true, workspace, workspace_bytes, (hipStream_t)stream);
   });
+}
+
+extern "C" int d2amd_roi_align_f64_forward(const double* input, const double* rois, double* output, int N, int C, int H,
+                                           int W, int K, int pooled_h, int pooled_w, double spatial_scale,
+                                           int sampling_ratio, int aligned, int rotated, int* status, void* stream) {
+  int rc = check_common("roi_align_f64_forward", N, C, H, W, K, pooled_h, pooled_w, D2AMD_F32, D2AMD_NCHW);
+  if (rc) return rc;
+  const long total = (long)K * C * pooled_h * pooled_w;
+  if (total == 0) return D2AMD_OK;
+  D2_CHECK_ARG(input && rois && output, "roi_align_f64_forward: null pointer");
+  const int gsz = grid_for(total, 256);
+  hipStream_t s = (hipStream_t)stream;
+  if (rotated)
+    hipLaunchKernelGGL((roi_align_f64_kernel<true, false>), dim3(gsz), dim3(256), 0, s, input, rois, output, C, H, W, K,
+                       pooled_h, pooled_w, spatial_scale, sampling_ratio, 1, status);
+  else
+    hipLaunchKernelGGL((roi_align_f64_kernel<false, false>), dim3(gsz), dim3(256), 0, s, input, rois, output, C, H, W, K,
+                       pooled_h, pooled_w, spatial_scale, sampling_ratio, aligned, nullptr);
+  D2_LAUNCH_OK();
+  return D2AMD_OK;
+}
+
+extern "C" int d2amd_roi_align_f64_backward(const double* grad_output, const double* rois, double* grad_input, int N,
+                                            int C, int H, int W, int K, int pooled_h, int pooled_w,
+                                            double spatial_scale, int sampling_ratio, int aligned, int rotated,
+                                            void* stream) {
+  int rc = check_common("roi_align_f64_backward", N, C, H, W, K, pooled_h, pooled_w, D2AMD_F32, D2AMD_NCHW);
+  if (rc) return rc;
+  const long numel = (long)N * C * H * W;
+  if (numel == 0) return D2AMD_OK;
+  D2_CHECK_ARG(grad_input && (K == 0 || (grad_output && rois)), "roi_align_f64_backward: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  { const int zrc = zero_async(grad_input, (size_t)numel * 8, s); if (zrc) return zrc; }
+  const long total = (long)K * C * pooled_h * pooled_w;
+  if (total == 0) return D2AMD_OK;
+  const int gsz = grid_for(total, 256);
+  if (rotated)
+    hipLaunchKernelGGL((roi_align_f64_kernel<true, true>), dim3(gsz), dim3(256), 0, s, grad_output, rois, grad_input, C,
+                       H, W, K, pooled_h, pooled_w, spatial_scale, sampling_ratio, 1, nullptr);
+  else
+    hipLaunchKernelGGL((roi_align_f64_kernel<false, true>), dim3(gsz), dim3(256), 0, s, grad_output, rois, grad_input, C,
+                       H, W, K, pooled_h, pooled_w, spatial_scale, sampling_ratio, aligned, nullptr);
+  D2_LAUNCH_OK();
+  return D2AMD_OK;
 }

@@ -386,6 +386,10 @@ def _box_iou_rotated(boxes1, boxes2):
 def _roi_align_rotated_forward(input, rois, spatial_scale, pooled_height, pooled_width, sampling_ratio):
     _C.require_gpu(input, rois, op="roi_align_rotated_forward")
     assert rois.dim() == 2 and rois.shape[1] == 6
+    if input.dtype == torch.float64:  # the reference's double instantiation (gradcheck): d2amd_roi_align_f64_*
+        from .roi_align import f64_forward
+
+        return f64_forward(input, rois, pooled_height, pooled_width, spatial_scale, sampling_ratio, True, True)
     x, layout = _prep_input(input.detach())
     r = rois.detach().float().contiguous()
     n, c, h, w = x.shape
@@ -409,6 +413,11 @@ def _roi_align_rotated_forward(input, rois, spatial_scale, pooled_height, pooled
 def _roi_align_rotated_backward(grad, rois, spatial_scale, pooled_height, pooled_width, batch_size, channels,
                                 height, width, sampling_ratio):
     _C.require_gpu(grad, rois, op="roi_align_rotated_backward")
+    if grad.dtype == torch.float64:
+        from .roi_align import f64_backward
+
+        return f64_backward(grad, rois, (batch_size, channels, height, width), pooled_height, pooled_width,
+                            spatial_scale, sampling_ratio, True, True)
     layout = _C.NHWC if (grad.dim() == 4 and not grad.is_contiguous()
                          and grad.is_contiguous(memory_format=torch.channels_last)) else _C.NCHW
     g = grad.detach() if layout == _C.NHWC else grad.detach().contiguous()

@@ -34,12 +34,49 @@ def _empty_like_layout(x, shape, layout):
     return torch.empty(shape, dtype=x.dtype, device=x.device)
 
 
+def f64_forward(input, rois, ph, pw, spatial_scale, sampling_ratio, aligned, rotated):
+    """Double-precision entry (d2amd_roi_align_f64_forward): everything double, ROIs cast to the input dtype as the
+    reference does (roi_align.py:60), NCHW.  The gradcheck path of the reference's tests, not a tuned one."""
+    x = input.detach().contiguous()
+    r = rois.detach().to(torch.float64).contiguous()
+    n, c, h, w = x.shape
+    out = torch.empty((r.shape[0], c, ph, pw), dtype=torch.float64, device=x.device)
+    if out.numel() == 0:
+        return out
+    status = torch.zeros(1, dtype=torch.int32, device=x.device) if rotated else None
+    with _C.on_device(x.device):
+        _C.check(_C.lib().d2amd_roi_align_f64_forward(
+            _C.ptr(x), _C.ptr(r), _C.ptr(out), n, c, h, w, r.shape[0], ph, pw, float(spatial_scale),
+            int(sampling_ratio), int(bool(aligned)), int(bool(rotated)), _C.ptr(status), _C.stream()))
+    if rotated and int(status.item()) != 0:  # ROIAlignRotated_cpu.cpp:236-238
+        raise RuntimeError("ROIs in ROIAlignRotated do not have non-negative size!")
+    return out
+
+
+def f64_backward(grad, rois, shape, ph, pw, spatial_scale, sampling_ratio, aligned, rotated):
+    g = grad.detach().to(torch.float64).contiguous()
+    r = rois.detach().to(torch.float64).contiguous()
+    n, c, h, w = shape
+    gin = torch.empty(shape, dtype=torch.float64, device=g.device)
+    if gin.numel() == 0:
+        return gin
+    with _C.on_device(g.device):
+        _C.check(_C.lib().d2amd_roi_align_f64_backward(
+            _C.ptr(g), _C.ptr(r), _C.ptr(gin), n, c, h, w, r.shape[0], ph, pw, float(spatial_scale),
+            int(sampling_ratio), int(bool(aligned)), int(bool(rotated)), _C.stream()))
+    return gin
+
+
 class _ROIAlign(Function):
     @staticmethod
     @disable_torch_compiler
     def forward(ctx, input, rois, output_size, spatial_scale, sampling_ratio, aligned):
         _C.require_gpu(input, rois, op="roi_align")
         ph, pw = _pair(output_size)
+        if input.dtype == torch.float64:
+            ctx.save_for_backward(rois.detach())
+            ctx.cfg = (ph, pw, float(spatial_scale), int(sampling_ratio), bool(aligned), tuple(input.shape), "f64")
+            return f64_forward(input, rois, ph, pw, spatial_scale, sampling_ratio, aligned, False)
         x, layout = _prep_input(input)
         rois = rois.detach().float().contiguous()
         n, c, h, w = x.shape
@@ -58,6 +95,8 @@ class _ROIAlign(Function):
     def backward(ctx, grad_output):
         (rois,) = ctx.saved_tensors
         ph, pw, scale, sr, aligned, shape, layout = ctx.cfg
+        if layout == "f64":
+            return f64_backward(grad_output, rois, shape, ph, pw, scale, sr, aligned, False), None, None, None, None, None
         n, c, h, w = shape
         k = rois.shape[0]
         fused = max(ph, pw) <= 32  # tile-gather backward (NHWC kernel; NCHW inputs get channels_last grads)

@@ -169,6 +169,20 @@ int d2amd_roi_align_rotated_backward(const void* grad_output, const float* rois,
                                      int sampling_ratio, int dtype, int layout, void* workspace,
                                      size_t workspace_bytes, void* stream);
 
+/* ---- ROIAlign / ROIAlignRotated in DOUBLE precision.  The reference instantiates its ops for double
+ * (ROIAlignRotated_cuda.cu:360,421: AT_DISPATCH_FLOATING_TYPES_AND_HALF; torchvision.ops.roi_align likewise) and
+ * its tests gradcheck them there (tests/layers/test_roi_align_rotated.py:107-172).  input / output / rois are
+ * all double (the reference casts the ROIs to the input dtype, layers/roi_align.py:60), NCHW; rotated != 0:
+ * rois [K,6] and `aligned` is ignored; `status` as d2amd_roi_align_rotated_forward.  A correctness path
+ * (one thread per output element), not a tuned one. */
+int d2amd_roi_align_f64_forward(const double* input, const double* rois, double* output, int N, int C,
+                                int H, int W, int K, int pooled_h, int pooled_w, double spatial_scale,
+                                int sampling_ratio, int aligned, int rotated, int* status, void* stream);
+int d2amd_roi_align_f64_backward(const double* grad_output, const double* rois, double* grad_input,
+                                 int N, int C, int H, int W, int K, int pooled_h, int pooled_w,
+                                 double spatial_scale, int sampling_ratio, int aligned, int rotated,
+                                 void* stream);
+
 /* ---- pairwise box IoU.  detectron2/structures/boxes.py:312-377 (pairwise_iou / _ioa /
  * _intersection): boxes1 [n,4], boxes2 [m,4] fp32 xyxy -> out [n,m] fp32. */
 int d2amd_pairwise_iou(const float* boxes1, int n, const float* boxes2, int m, int mode,

@@ -12,7 +12,8 @@ Python on top of it.  Two kinds of test:
 * GOLDEN: tests/golden/dcn_reference_gpu.npz, written by tests/golden/make_dcn_reference_gpu.py from the same reference
   build on an MI355X; always runs (small cases: every element; full size: 16,384 sampled elements per tensor).
 
-Bounds.  fp32 product path: |d| <= 1e-4 |ref| + 1e-6 max|ref| per element (north_star: "within 1e-4 rel").  16-bit
+Bounds.  fp32 product path: |d| <= 1e-4 |ref| + 1e-6 max|ref| per element (north_star: "within 1e-4 rel"; 4e-6 for the
+full-size fp32 case, whose dW sums 33,600 positions in fp32 on both sides).  16-bit
 paths (inputs rounded to the I/O dtype, reference run in fp32 on the rounded inputs): |d| <= a |ref| + b rms(ref) per
 element with (a, b) = (2^-7, 2^-6) for bf16 and (2^-10, 2^-9) for fp16 -- one output rounding plus the 16-bit rounding
 of the MFMA operands (gathered columns, dcol) of a sum of 9 Ci ... 2 P independent terms."""
@@ -23,7 +24,7 @@ import pytest
 import torch
 
 import _dcn_cases as dc
-from conftest import need_reference, record_ratio
+from conftest import SUM_FLOOR, need_reference, record_ratio
 from detectron2_amd import layers
 from oracle import ref
 
@@ -42,8 +43,8 @@ def require_reference():
     return ref.py_deform_conv()
 
 
-def bound_fp32(refv):
-    return 1e-4 * np.abs(refv) + 1e-6 * float(np.abs(refv).max())
+def bound_fp32(refv, floor=1e-6):
+    return 1e-4 * np.abs(refv) + floor * float(np.abs(refv).max())
 
 
 def bound_16(refv, dtype, rms=None):
@@ -105,7 +106,9 @@ def test_full_size_fp32_vs_reference_live(name):
     m = require_reference()
     case = dc.make_full(name, rounding=torch.bfloat16)
     exp = dc.run_module(m.modulated_deform_conv, m.deform_conv, case, DEV)
-    compare(f"live_full_fp32/{name}", product(case), exp, bound_fp32)
+    # dW / d bias sum 33,600 ... 2,100 positions in fp32 in BOTH implementations (rocBLAS + per-image adds there, split-K
+    # partial tiles here): sqrt(n) 2^-24 of the term magnitude each -> SUM_FLOOR (measured worst 1.34 x the 1e-6 floor)
+    compare(f"live_full_fp32/{name}", product(case), exp, lambda e: bound_fp32(e, SUM_FLOOR))
 
 
 def test_reference_fp16_path_is_no_closer_to_exact_than_ours():

@@ -104,3 +104,14 @@ def test_match_boxes_batch_equals_the_per_image_loop(low):
             assert np.array_equal(m[i].cpu().numpy(), om) and np.array_equal(l[i].cpu().numpy(), ol), i
     e = mt.match_boxes_batch([], at)
     assert tuple(e[0].shape) == (0, n)
+
+
+def test_reference_known_answer():
+    """/root/reference/tests/modeling/test_matcher.py:11-24, eager half (its TorchScript half is export: out of scope):
+    the RPN matcher of config/defaults.py (IOU_THRESHOLDS [0.3, 0.7], IOU_LABELS [0, -1, 1], low-quality matches) on the
+    test's 3 x 4 quality matrix."""
+    mt = Matcher([0.3, 0.7], [0, -1, 1], allow_low_quality_matches=True)
+    q = torch.tensor([[0.15, 0.45, 0.2, 0.6], [0.3, 0.65, 0.05, 0.1], [0.05, 0.4, 0.25, 0.4]], device=DEV)
+    matches, labels = mt(q)
+    assert matches.tolist() == [1, 1, 2, 0] and matches.dtype == torch.int64
+    assert labels.tolist() == [-1, 1, 0, 1] and labels.dtype == torch.int8

@@ -19,7 +19,7 @@ from detectron2_amd.layers import (DeformConv, ModulatedDeformConv, ROIAlign, RO
 from detectron2_amd.structures import Boxes, pairwise_intersection, pairwise_ioa, pairwise_iou
 
 from _torch_ref import dcn_torch
-from conftest import assert_close_fp32
+from conftest import ROI_FLOOR, SUM_FLOOR, assert_close_fp32
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -65,11 +65,11 @@ def test_roi_align_forward_backward_fp32(layout, out, sr, aligned):
     y = op(xin, cu(rois))
     exp = oracle.roi_align_forward(x, rois, out, 0.25, sr, aligned)
     assert y.shape == exp.shape
-    assert_close_fp32(y.detach().cpu().numpy(), exp, "parity:67")
+    assert_close_fp32(y.detach().cpu().numpy(), exp, "parity:67", floor=ROI_FLOOR)
     g = rng.standard_normal(exp.shape).astype(np.float32)
     y.backward(cu(g))
     gexp = oracle.roi_align_backward(g, rois, x.shape, 0.25, sr, aligned)
-    assert_close_fp32(xt.grad.cpu().numpy(), gexp, "parity:71")
+    assert_close_fp32(xt.grad.cpu().numpy(), gexp, "parity:71", floor=ROI_FLOOR)
 
 
 def test_roi_align_known_answers_gpu():
@@ -121,9 +121,9 @@ def test_roi_align_rotated_golden_and_oracle(golden_dir):
     for sr in (0, 2):
         xt = cu(d["x"]).requires_grad_(True)
         y = ROIAlignRotated((7, 7), 0.5, sr)(xt, cu(d["rois"]))
-        assert_close_fp32(y.detach().cpu().numpy(), d[f"out_sr{sr}"], "parity:123")
+        assert_close_fp32(y.detach().cpu().numpy(), d[f"out_sr{sr}"], "parity:123", floor=ROI_FLOOR)
         y.backward(cu(d["grad"]))
-        assert_close_fp32(xt.grad.cpu().numpy(), d[f"gin_sr{sr}"], "parity:125")
+        assert_close_fp32(xt.grad.cpu().numpy(), d[f"gin_sr{sr}"], "parity:125", floor=ROI_FLOOR)
     # channels_last + known answers test_roi_align_rotated.py:30-71
     x = torch.arange(25, dtype=torch.float32, device=DEV).reshape(1, 1, 5, 5)
     exp = np.array([[4.5, 5.0, 5.5, 6.0], [7.0, 7.5, 8.0, 8.5], [9.5, 10.0, 10.5, 11.0], [12.0, 12.5, 13.0, 13.5]])
@@ -135,7 +135,7 @@ def test_roi_align_rotated_golden_and_oracle(golden_dir):
     a = ROIAlignRotated((7, 7), 0.5, 2)(cu(xr), cu(rr))
     b = ROIAlignRotated((7, 7), 0.5, 2)(cu(xr).contiguous(memory_format=torch.channels_last), cu(rr))
     assert rel_err(b.cpu().numpy(), a.cpu().numpy()) < 1e-5
-    assert_close_fp32(a.cpu().numpy(), oracle.roi_align_rotated_forward(xr, rr, (7, 7), 0.5, 2), "parity:137")
+    assert_close_fp32(a.cpu().numpy(), oracle.roi_align_rotated_forward(xr, rr, (7, 7), 0.5, 2), "parity:137", floor=ROI_FLOOR)
 
 
 def test_roi_align_equals_rotated_zero_angle_gpu():
@@ -179,7 +179,7 @@ def test_roi_align_full_size_properties():
     # sampled oracle check (32 ROIs, 8 channels)
     sel = rng.choice(K, 32, replace=False)
     exp = oracle.roi_align_forward(x[:, :8].cpu().numpy(), rois_np[sel], (7, 7), 0.25, 0, True)
-    assert_close_fp32(y1[sel][:, :8].cpu().numpy(), exp, "parity:181")
+    assert_close_fp32(y1[sel][:, :8].cpu().numpy(), exp, "parity:181", floor=ROI_FLOOR)
     # NHWC bf16 == NCHW fp32 on the same bf16-rounded input, to bf16 precision
     xb = x.to(torch.bfloat16)
     yb = op(xb.contiguous(memory_format=torch.channels_last), rois)
@@ -602,11 +602,11 @@ def test_deform_conv_zero_offset_equals_conv2d_full_size():
     one = torch.ones(B, 9, H, W, device=DEV)
     y = layers.modulated_deform_conv(x, off, one, w, None, 1, 1, 1, 1, 1)
     ref = torch.nn.functional.conv2d(x, w, padding=1)
-    assert_close_fp32(y.cpu().numpy(), ref.cpu().numpy(), "parity:604")
+    assert_close_fp32(y.cpu().numpy(), ref.cpu().numpy(), "parity:604", floor=SUM_FLOOR)
     y1 = layers.deform_conv(x, off, w, 1, 1, 1, 1, 1)
-    assert_close_fp32(y1.cpu().numpy(), ref.cpu().numpy(), "parity:606")
+    assert_close_fp32(y1.cpu().numpy(), ref.cpu().numpy(), "parity:606", floor=SUM_FLOOR)
     yh = layers.modulated_deform_conv(x, off, 0.5 * one, w, None, 1, 1, 1, 1, 1)
-    assert_close_fp32(yh.cpu().numpy(), 0.5 * ref.cpu().numpy(), "parity:608")
+    assert_close_fp32(yh.cpu().numpy(), 0.5 * ref.cpu().numpy(), "parity:608", floor=SUM_FLOOR)
     xb, wb = x.bfloat16(), w.bfloat16()
     yb = layers.modulated_deform_conv(xb, off.bfloat16(), one.bfloat16(), wb, None, 1, 1, 1, 1, 1)
     refb = torch.nn.functional.conv2d(xb.float(), wb.float(), padding=1)

@@ -15,7 +15,7 @@ from detectron2_amd.structures import Boxes
 
 from test_tile_gather_math import assign_levels_restated
 
-from conftest import assert_close_fp32, record_ratio
+from conftest import ROI_FLOOR, SUM_FLOOR, assert_close_fp32, record_ratio
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -80,10 +80,10 @@ def test_fused_pooler_fp32_vs_oracle(layout, out, sr, ptype):
     exp, gexp, lv = oracle_pooler(feats, boxes, out, sr, aligned, g)
     assert len(set(lv.tolist())) == 4, "test inputs must hit every level"
     assert y.shape == exp.shape
-    assert_close_fp32(y.detach().cpu().numpy(), exp, "pooler:81")
+    assert_close_fp32(y.detach().cpu().numpy(), exp, "pooler:81", floor=ROI_FLOOR)
     y.backward(torch.from_numpy(g).to(DEV))
     for x, ge in zip(xs, gexp):
-        assert_close_fp32(x.grad.cpu().numpy(), ge, "pooler:84")
+        assert_close_fp32(x.grad.cpu().numpy(), ge, "pooler:84", floor=ROI_FLOOR)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -371,9 +371,9 @@ def test_inverted_roi_with_fixed_sampling_ratio_forward_backward_adjoint(fused):
         y = ROIPooler(7, SCALES, 2, "ROIAlignV2", canonical_box_size=100000)(feats, [Boxes(torch.from_numpy(boxes).to(DEV))])
     else:
         y = ROIAlign((7, 7), 0.25, 2, True)(xt, torch.from_numpy(rois).to(DEV))
-    assert_close_fp32(y.detach().cpu().numpy(), want_y, "pooler:372")
+    assert_close_fp32(y.detach().cpu().numpy(), want_y, "pooler:372", floor=ROI_FLOOR)
     y.backward(torch.from_numpy(g).to(DEV))
-    assert_close_fp32(xt.grad.cpu().numpy(), want_g, "pooler:374")
+    assert_close_fp32(xt.grad.cpu().numpy(), want_g, "pooler:374", floor=ROI_FLOOR)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
@@ -524,11 +524,15 @@ def test_pooler_full_size_per_element_vs_oracle():
     256 mask-head rows) -- forward of both poolers and the ONE backward that runs `pool_bwd_mfma_kernel` for both (the
     mask pooler's gradient chained into the box pooler's tile gather), checked on 32 of the 256 channels (every 8th: four
     of each wave's 32) against oracle.roi_align_forward / roi_align_backward per level, element by element:
-      forward   |d| <= 1 ulp_bf16(|y|) + 1e-6 max|y|       (fp32 taps of exact bf16 features, one output rounding)
+      forward   |d| <= 1 ulp_bf16(|y|) + 2^-14 max|y|
       backward  |d| <= 1 ulp_bf16(|g|) + 2^-13 A + 1e-6 max|g|,  A = the same scatter of |dY| (the weights are >= 0, so
-                A = sum |w dY| exactly): one output rounding + the 16-bit hi / lo split of the MFMA weight image
-                (2^-16 relative per term) + fp32 accumulation; 3e-2-of-the-maximum bars cannot see a dropped ROI on
-                a pixel that many ROIs cover, this does."""
+                A = sum |w dY| exactly).
+    Terms: one output rounding to bf16; sample coordinates are fp32 in the reference and here -- an ulp of a coordinate
+    of ~300 px is 3e-5 px and two correct fp32 evaluation orders differ by that much times the feature slope (the
+    reference's own fp32 order is 1.1e-5 max|y| from the fp64 value: tests/test_oracle_golden.py::
+    test_fp32_roi_align_distance_from_fp64), hence 2^-14 max|y| forward and 2^-14 of A backward; the 16-bit hi / lo
+    split of the MFMA weight image adds 2^-16 A; fp32 accumulation.  A dropped or doubled ROI, tap or bin is O(2^-3) of
+    these magnitudes on the pixels it touches: 3e-2-of-the-maximum bars cannot see that on a pixel many ROIs cover."""
     import bench
 
     dev = torch.device("cuda", 0)
@@ -539,11 +543,11 @@ def test_pooler_full_size_per_element_vs_oracle():
     counts = samp["counts"].cpu().numpy()
     assert (counts[:, 1] == bench.ROI_BATCH).all(), counts  # (no padding rows in this workload)
     ch = np.arange(0, 256, 8)
-    feats = [f.detach().float().cpu().numpy()[:, ch] for f in w.feats]
-    feats = [np.ascontiguousarray(f) for f in feats]
+    feats = [np.ascontiguousarray(f.detach().float().cpu().numpy()[:, ch]) for f in w.feats]
     ulp = lambda v: 2.0 ** (np.floor(np.log2(np.maximum(np.abs(v), 1e-30))) - 7)
     exp_grads = [np.zeros_like(f) for f in feats]
     abs_grads = [np.zeros_like(f) for f in feats]
+    bad = {}
     for name, rois_t, y_t, g_t, R in (("box", samp["rois"], out["box_features"], w.gbox, 7),
                                       ("mask", samp["head_rois"], out["mask_features"], w.gmask, 14)):
         rois = rois_t.cpu().numpy()
@@ -555,9 +559,11 @@ def test_pooler_full_size_per_element_vs_oracle():
             sel = np.nonzero(lv == l)[0]
             exp = oracle.roi_align_forward(f, rois[sel], (R, R), SCALES[l], 0, True)
             d = np.abs(got[sel] - exp)
-            bound = ulp(exp) + 1e-6 * np.abs(exp).max()
-            record_ratio(f"pooler_full/{name}_fwd_l{l}", float((d / bound).max()))
-            assert (d <= bound).all(), (name, l, float((d / bound).max()), int((d > bound).sum()), d.size)
+            bound = ulp(exp) + 2.0 ** -14 * np.abs(exp).max()
+            r = float((d / bound).max())
+            record_ratio(f"pooler_full/{name}_fwd_l{l}", r)
+            if r > 1:
+                bad[f"{name}_fwd_l{l}"] = (r, int((d > bound).sum()), d.size)
             gs = np.ascontiguousarray(g[sel])
             exp_grads[l] += oracle.roi_align_backward(gs, rois[sel], f.shape, SCALES[l], 0, True)
             abs_grads[l] += oracle.roi_align_backward(np.abs(gs), rois[sel], f.shape, SCALES[l], 0, True)
@@ -567,6 +573,10 @@ def test_pooler_full_size_per_element_vs_oracle():
         e = exp_grads[l]
         bound = ulp(e) + 2.0 ** -13 * abs_grads[l] + 1e-6 * np.abs(e).max()
         d = np.abs(got - e)
-        record_ratio(f"pooler_full/bwd_l{l}", float((d / bound).max()))
-        assert (d <= bound).all(), (l, float((d / bound).max()), int((d > bound).sum()), d.size)
-        assert (got[abs_grads[l] == 0] == 0).all(), l  # pixels no ROI touches are written as exact zeros
+        r = float((d / bound).max())
+        record_ratio(f"pooler_full/bwd_l{l}", r)
+        if r > 1:
+            bad[f"bwd_l{l}"] = (r, int((d > bound).sum()), d.size)
+        if not (got[abs_grads[l] == 0] == 0).all():  # pixels no ROI touches are written as exact zeros
+            bad[f"bwd_l{l}_zeros"] = int((got[abs_grads[l] == 0] != 0).sum())
+    assert not bad, bad

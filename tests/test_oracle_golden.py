@@ -470,3 +470,79 @@ def test_polygon_rasteriser_restatement_known_answers():
     assert np.array_equal(ms[2:, 3:], ma[:-2, :-3]) and ma.sum() > 20                   # whole-pixel translation
     # rasterize_polygons_within_box: a box equal to the frame is the identity transform
     assert np.array_equal(oracle.rasterize_polygons_within_box([a], [0, 0, 32, 32], 32), ma)
+
+
+# ---------------------------------------------------------------- DCN: the restatement pinned to the reference's kernels
+def test_deform_conv_forward_and_backward_vs_reference_gpu_goldens(golden_dir):
+    """SURVEY 8(c) called DCN backward "parity-unpinned" (no CPU implementation, no gradient test upstream).  The golden
+    file holds what the reference's OWN kernels (csrc/deformable/*.cu compiled as HIP by oracle/build_ref.py:build_dcn,
+    driven by the reference's own layers/deform_conv.py) produced on an MI355X for the cases of tests/_dcn_cases.py
+    (tests/golden/make_dcn_reference_gpu.py).  The C restatement -- oracle.deform_conv_forward / _backward, what every
+    other DCN test compares the HIP kernels with -- must reproduce every element of every tensor: out, grad_input,
+    grad_offset, grad_mask, grad_weight, grad_bias; v1 and v2; conv groups, deformable groups, stride, dilation,
+    padding, 5x5 taps, far offsets.  Bound per element: 1e-4 |ref| + 1e-6 max|ref|."""
+    import _dcn_cases as dc
+    from conftest import assert_close_fp32
+
+    g = np.load(os.path.join(golden_dir, "dcn_reference_gpu.npz"))
+    for name in dc.SMALL:
+        case = dc.make_small(name)
+        cs = dc.input_checksum(case)
+        assert abs(float(g[f"small/{name}/checksum"]) - cs) < 1e-6 * cs, "seeded inputs differ from the golden file's"
+        f = lambda t: None if t is None else t.numpy()
+        kw = case["kw"]
+        out = oracle.deform_conv_forward(f(case["x"]), f(case["offset"]), f(case["weight"]), mask=f(case["mask"]),
+                                         bias=f(case["bias"]), **kw)
+        assert_close_fp32(out, g[f"small/{name}/out"], f"oracle_dcn/{name}/out")
+        grads = oracle.deform_conv_backward(f(case["x"]), f(case["offset"]), f(case["weight"]), f(case["grad_out"]),
+                                            mask=f(case["mask"]), with_bias=case["mask"] is not None, **kw)
+        for k, v in grads.items():
+            if v is not None:
+                assert_close_fp32(v, g[f"small/{name}/{k}"], f"oracle_dcn/{name}/{k}")
+
+
+def test_fp32_roi_align_distance_from_fp64():
+    """Evidence for tests/conftest.py: ROI_FLOOR.  The reference's ROIAlign arithmetic in fp32 (the oracle, operation
+    for operation as ROIAlignRotated_cpu.cpp:27-129 at angle 0) against an fp64 evaluation of the same fp32 ROIs: the
+    sample coordinates are fp32 products / sums of ~100-px numbers, so the fp32 result sits ~1e-5 max|y| from the
+    exact one.  No fp32 implementation with a different (equally valid) rounding order can be held closer to the oracle
+    than the oracle is to the truth: the per-element floor for ROIAlign is 1e-5 max|ref|, not 1e-6."""
+    rng = np.random.default_rng(436)
+    H, W, R, g, scale = 128, 160, 14, 2, 0.25
+    f = rng.standard_normal((1, 4, H, W)).astype(np.float32)
+    s = np.exp(rng.uniform(np.log(8), np.log(400), 24))
+    cx, cy = rng.uniform(0, 640, 24), rng.uniform(0, 512, 24)
+    rois = np.stack([np.zeros(24), cx - s / 2, cy - s / 2, cx + s / 2, cy + s / 2], 1).astype(np.float32)
+    got = oracle.roi_align_forward(f, rois, (R, R), scale, g, True)
+    f64 = f.astype(np.float64)
+    exp = np.zeros((24, 4, R, R))
+    for k, (b, x1, y1, x2, y2) in enumerate(rois.astype(np.float64)):
+        sx, sy = x1 * scale - 0.5, y1 * scale - 0.5
+        bw, bh = (x2 * scale - x1 * scale) / R, (y2 * scale - y1 * scale) / R
+        for ph in range(R):
+            for pw in range(R):
+                acc = np.zeros(4)
+                for iy in range(g):
+                    y = sy + ph * bh + (iy + 0.5) * bh / g
+                    for ix in range(g):
+                        x = sx + pw * bw + (ix + 0.5) * bw / g
+                        if y < -1 or y > H or x < -1 or x > W:
+                            continue
+                        yy, xx = max(y, 0.0), max(x, 0.0)
+                        yl, xl = int(yy), int(xx)
+                        if yl >= H - 1:
+                            yh = yl = H - 1
+                            yy = float(yl)
+                        else:
+                            yh = yl + 1
+                        if xl >= W - 1:
+                            xh = xl = W - 1
+                            xx = float(xl)
+                        else:
+                            xh = xl + 1
+                        ly, lx = yy - yl, xx - xl
+                        acc += ((1 - ly) * (1 - lx) * f64[0, :, yl, xl] + (1 - ly) * lx * f64[0, :, yl, xh] +
+                                ly * (1 - lx) * f64[0, :, yh, xl] + ly * lx * f64[0, :, yh, xh])
+                exp[k, :, ph, pw] = acc / (g * g)
+    d = np.abs(got - exp).max() / np.abs(exp).max()
+    assert 1e-6 < d < 1e-4, d  # ~1e-5: far above the 1e-6 a pure summation-order difference would give
