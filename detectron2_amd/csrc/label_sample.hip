@@ -300,21 +300,26 @@ extern "C" int d2amd_label_and_sample_proposals(const d2amd_sample_image* images
   B.key_state = (unsigned long long*)key_state;
   B.key_images = count;
   long key_base = 0;
+  // EVERY image is validated before the first launch: a call that fails must not have launched a partial set of
+  // workgroups (with key_state set they would leave the arrival ticket non-zero, and the generator's offset would stop
+  // advancing for every later call -- the same keys redrawn silently)
+  for (int i = 0; i < count; i++) {
+    const d2amd_sample_image& s = images[i];
+    D2_CHECK_ARG(s.max_proposals >= 0 && s.num_gt >= 0 && s.n_limits >= 0 && s.n_limits <= 4,
+                 "label_and_sample: image %d: bad sizes", i);
+    if ((long)s.max_proposals + (append_gt ? s.num_gt : 0) > LS_MAX) {
+      set_error("label_and_sample: image %d has %d + %d candidates (max %d)", i, s.max_proposals, s.num_gt, LS_MAX);
+      return D2AMD_EUNSUPPORTED;
+    }
+    D2_CHECK_ARG((s.max_proposals == 0 || s.proposals) && (s.n_limits == 0 || s.limits) &&
+                     (s.num_gt == 0 || (s.gt_boxes && s.gt_classes)) &&
+                     (s.max_proposals + s.num_gt == 0 || s.keys || key_state),
+                 "label_and_sample: image %d: null pointer", i);
+  }
   for (int i0 = 0; i0 < count; i0 += LS_MAX_IMAGES) {
     const int c = count - i0 < LS_MAX_IMAGES ? count - i0 : LS_MAX_IMAGES;
     for (int i = 0; i < c; i++) {
       const d2amd_sample_image& s = images[i0 + i];
-      D2_CHECK_ARG(s.max_proposals >= 0 && s.num_gt >= 0 && s.n_limits >= 0 && s.n_limits <= 4,
-                   "label_and_sample: image %d: bad sizes", i0 + i);
-      if ((long)s.max_proposals + (append_gt ? s.num_gt : 0) > LS_MAX) {
-        set_error("label_and_sample: image %d has %d + %d candidates (max %d)", i0 + i, s.max_proposals, s.num_gt,
-                  LS_MAX);
-        return D2AMD_EUNSUPPORTED;
-      }
-      D2_CHECK_ARG((s.max_proposals == 0 || s.proposals) && (s.n_limits == 0 || s.limits) &&
-                       (s.num_gt == 0 || (s.gt_boxes && s.gt_classes)) &&
-                       (s.max_proposals + s.num_gt == 0 || s.keys || key_state),
-                   "label_and_sample: image %d: null pointer", i0 + i);
       LsImage& I = B.img[i];
       I.props = (const float4*)s.proposals;
       I.limits = s.limits;

@@ -1368,7 +1368,9 @@ __device__ __forceinline__ void nms_finalize_small_body(
     int fl2 = counters[1];
     if (blk_flag)
       for (int q = 0; q < (n + ORDER_THREADS - 1) / ORDER_THREADS; q++) fl2 |= blk_flag[q];
-    result[0] = off; result[1] = fl2; result[2] = s_finite; result[3] = 0;
+    // a raised flag means the host redoes / rejects this image; a DEVICE-side consumer of the counts (the connected
+    // step's sampler reads min(kept, finite)) must then see NO proposals rather than rows of a wrong order
+    result[0] = off; result[1] = fl2; result[2] = fl2 ? 0 : s_finite; result[3] = 0;
   }
 }
 
@@ -1430,7 +1432,7 @@ __device__ __forceinline__ void nms_finalize_direct_body(
     int fl2 = counters[1];
     if (blk_flag)
       for (int q = 0; q < (n + ORDER_THREADS - 1) / ORDER_THREADS; q++) fl2 |= blk_flag[q];
-    result[0] = s_before[0] + cnt; result[1] = fl2; result[2] = s_before[1] + cfin; result[3] = 0;
+    result[0] = s_before[0] + cnt; result[1] = fl2; result[2] = fl2 ? 0 : s_before[1] + cfin; result[3] = 0;  // (as above)
   }
 }
 

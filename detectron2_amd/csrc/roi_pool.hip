@@ -1857,6 +1857,10 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
       if (!dynamic) break;
       continue;
     }
+    // every part has drawn its ticket: re-arm it, so that a second gather over the same binned workspace (retain_graph,
+    // a C-ABI caller running phase 2 twice after one phase 1) finds it at 0 again instead of never finishing the tile
+    if (tid == 0)
+      __hip_atomic_store(L.part_tickets + sbase * SPLIT_MAX_SLABS + slab, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const float* all = L.part_scratch + ((size_t)sbase * nslab + slab) * 32 * NT + tid;
 #pragma unroll
     for (int i = 0; i < 32; i++) acc[i >> 4][i & 15] = 0.f;

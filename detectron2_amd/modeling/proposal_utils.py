@@ -40,7 +40,10 @@ class DeviceProposals:
     [post_nms_topk, 4] / `logits` [post_nms_topk] in objectness order, valid up to min(post_nms_topk, limits[0],
     limits[2]) -- `limits[i]` is the NMS result row {kept, flags, finite, 0} (int64 words, limit_stride 2) -- and
     `nonfinite_flag` (int32[1]; non-zero: predicted boxes or scores contained Inf / NaN, what the synchronous path
-    raises FloatingPointError for: check it after the step)."""
+    raises FloatingPointError for: check it after the step).  limits[i][1] != 0 (NMS flags: the synchronous path redoes
+    or rejects that image) comes with limits[i][2] = 0: such an image contributes no proposals on the device path.
+    `find_top_rpn_proposals_fused(...).device` is None when the NMS did not run as the batched pipeline (more than
+    12,288 boxes in an image, mixed devices): its counts are then not in this buffer."""
 
     def __init__(self, boxes, logits, limits, nonfinite_flag, image_sizes):
         self.boxes, self.logits, self.limits, self.nonfinite_flag = boxes, logits, limits, nonfinite_flag
@@ -163,8 +166,14 @@ def find_top_rpn_proposals_fused(anchors, pred_objectness_logits, pred_anchor_de
     finish.join_beside = late[0] if late else (lambda: None)
     # what the ROI heads of a captured step read instead of calling finish(): fixed-size lists whose valid length the
     # DEVICE knows (label_and_sample_proposals_fixed(limits=..., limit_stride=2))
-    finish.device = DeviceProposals(
-        [nms_done.gathered[i][0][:post_nms_topk] for i in range(n)] if n else [],
-        [nms_done.gathered[i][1][:post_nms_topk] for i in range(n)] if n else [],
-        list(res[:8 * n].view(torch.int64).view(n, 4)) if n else [], res[8 * n:], [tuple(s) for s in image_sizes])
+    # Only the batched NMS pipeline fills `res` (<= RANK_MAX_N = 12,288 boxes per image, one device): the per-image
+    # fallback keeps its results in its own buffers, so there is nothing a device-side consumer could read -> None.
+    # A raised NMS flag (limits[i][1] != 0: the host path redoes or rejects that image) zeroes the image's `finite`
+    # word on the device, i.e. min(kept, finite) = 0 proposals -- never rows of a wrong order.
+    finish.device = None
+    if n == 0 or getattr(nms_done, "result_on_device", False):
+        finish.device = DeviceProposals(
+            [nms_done.gathered[i][0][:post_nms_topk] for i in range(n)] if n else [],
+            [nms_done.gathered[i][1][:post_nms_topk] for i in range(n)] if n else [],
+            list(res[:8 * n].view(torch.int64).view(n, 4)) if n else [], res[8 * n:], [tuple(s) for s in image_sizes])
     return finish if defer else finish()

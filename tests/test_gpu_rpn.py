@@ -147,3 +147,34 @@ def test_multi_launch_selection_path_still_agrees():
                         "tests/test_gpu_dense.py", "-k", "oracle or reference or ties or tie"],
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_device_proposals_exist_only_when_the_batched_nms_filled_the_result_buffer():
+    """`find_top_rpn_proposals_fused(..., defer=True).device` hands the proposal lists + their device-side counts to a
+    sync-free consumer (bench.py's connected step).  The counts live in the batched NMS pipeline's result buffer: with
+    more than 12,288 boxes per image (here 5 x 3,000) the NMS runs per image into its own buffers and `.device` must be
+    None instead of pointing at memory nobody wrote; with the RPN's 8,819 it must agree with the synchronous result."""
+    torch.manual_seed(4)
+    sizes = [20000, 10000, 6000, 4000, 3000]
+    H, W = 800, 1344
+    A, Lg, D = [], [], []
+    for l, a in enumerate(sizes):
+        s = 32.0 * 2 ** l
+        c = torch.rand(a, 2) * torch.tensor([W, H])
+        wh = s * torch.exp(torch.rand(a, 2) - 0.5)
+        A.append(torch.cat([c - wh / 2, c + wh / 2], 1).to(DEV))
+        Lg.append((torch.randn(2, a) + torch.arange(a) * 1e-7).to(DEV))
+        D.append((torch.randn(2, a, 4) * 0.2).to(DEV))
+    hw = [(H, W)] * 2
+    big = find_top_rpn_proposals_fused(A, Lg, D, hw, 0.7, 3000, 1000, 0.0, True, defer=True, host_result=False)
+    assert big.device is None
+    assert len(big()) == 2 and all(0 < len(p) <= 1000 for p in big())
+    small = find_top_rpn_proposals_fused(A, Lg, D, hw, 0.7, 2000, 1000, 0.0, True, defer=True)
+    dp = small.device
+    assert dp is not None and int(dp.nonfinite_flag.item()) == 0
+    counts = dp.counts().tolist()
+    props = small()
+    assert counts == [len(p) for p in props]
+    for i, p in enumerate(props):
+        assert torch.equal(dp.boxes[i][:counts[i]], p.proposal_boxes.tensor)
+        assert int(dp.limits[i][1]) == 0  # no NMS flag
