@@ -64,7 +64,7 @@ IMG_H, IMG_W = 800, 1344
 C = 256
 IMAGES_PER_GPU = 2
 N_GT = 16
-WORKLOADS = ("maskrcnn_train", "retinanet_100k", "dcn_r50")
+WORKLOADS = ("maskrcnn_train", "retinanet_100k", "dcn_r50", "maskrcnn_infer", "rrpn_micro")
 
 
 def parse(argv=None):
@@ -101,7 +101,8 @@ def parse(argv=None):
                     help="plumbing check on a 1-GPU box: create the process group and issue the gradient all-reduce even "
                          "at world size 1 (RCCL init, async collectives between the HIP graphs, barrier-bracketed timing)")
     a = ap.parse_args(argv)
-    dflt = {"maskrcnn_train": (200, 20), "retinanet_100k": (30, 5), "dcn_r50": (20, 3)}[a.workload]
+    dflt = {"maskrcnn_train": (200, 20), "retinanet_100k": (30, 5), "dcn_r50": (20, 3), "maskrcnn_infer": (30, 5),
+            "rrpn_micro": (20, 3)}[a.workload]
     a.steps = dflt[0] if a.steps is None else a.steps
     a.warmup = dflt[1] if a.warmup is None else a.warmup
     return a
@@ -781,6 +782,32 @@ def cpu_baseline_maskrcnn(w):
             "host_cores_available": os.cpu_count()}
 
 
+def pmc_source(op=None, layout="nhwc"):
+    """Where `roofline.traffic` comes from: the committed PMC summary that holds the op (newest round wins) and the
+    commit that last touched it -- the driver's run does NOT re-measure traffic (counters need their own rocprofv3
+    passes); the figure is replayed from that file."""
+    import glob
+    import subprocess
+
+    src = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_traffic_{layout}.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if op is None or op in d.get("ops", {}):
+            src = f
+    if src is None:
+        return None
+    rel = os.path.relpath(src, ROOT)
+    try:
+        commit = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h", "--", rel], capture_output=True,
+                                text=True, timeout=10).stdout.strip() or None
+    except Exception:
+        commit = None
+    return {"file": rel, "commit": commit, "measured_in_this_run": False}
+
+
 def pmc_traffic(op, layout, key="hbm_bytes_per_launch"):
     """HBM bytes per launch of the op's kernels from the committed rocprofv3 PMC passes
     (profiles/<round>/pmc_traffic_<layout>.json, written by scripts/pmc_summary.py from separate
@@ -823,6 +850,15 @@ def bench_maskrcnn(args, ctx):
         for _ in range(args.steps):
             gstep()
         elapsed = sw.stop()
+        # The contract's timed region is the window above (`value` / `ms_per_step`).  Boxes differ by +-7 % and a window
+        # is ~0.1 s: four more windows of the same K steps give the spread printed beside it (`ms_per_step_windows`).
+        windows = [elapsed / args.steps * 1e3]
+        if world == 1:
+            for _ in range(4):
+                sw.start()
+                for _ in range(args.steps):
+                    gstep()
+                windows.append(sw.stop() / args.steps * 1e3)
         allreduce_info = measure_allreduce(args, w, grads, sw, elapsed, dist, world) if grads is not None else None
         # events inside a replayed graph cannot be read: the roofline kernel is timed by the library's launch-stream
         # events in an eager pass of the same steps right after the timed region
@@ -839,6 +875,7 @@ def bench_maskrcnn(args, ctx):
             step(w, dom_timer, grads)
         elapsed = sw.stop()
         allreduce_info = None
+        windows = [elapsed / args.steps * 1e3]
     ktimes = read_kernel_times([KERN])
     knames = ["pool_bwd_staged_r7", "pool_bwd_staged_r14", "pool_fwd_r7", "pool_fwd_r14", "nms_mask", "nms_reduce"]
     _dc.lib().d2amd_timing_select(",".join(knames).encode())
@@ -877,6 +914,7 @@ def bench_maskrcnn(args, ctx):
                 "achieved": round(kb / 1e6 / k_ms, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(kb / 1e6 / k_ms / HBM_PEAK_GBS, 4),
                 "traffic": pmc_traffic("roi_align_box_bwd", args.layout),
+                "traffic_source": pmc_source("roi_align_box_bwd", args.layout),
                 "traffic_note": "PMC bytes of the box-head pooler backward (records + tile lists + tile gather): LESS than the "
                                 "algorithmic figure, which charges a zero fill and a write of every gradient byte (SURVEY "
                                 "8(d)); the tile gather writes each byte once and zero-fills nothing it writes -- "
@@ -904,6 +942,10 @@ def bench_maskrcnn(args, ctx):
         "metric": "img/s through the Mask R-CNN R50-FPN detection hot path (training ops), 1333x800 bs=2/GPU",
         "value": round(world * w.n_img * args.steps / elapsed, 2), "unit": "img/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
+        "ms_per_step_windows": {"n": len(windows), "min": round(min(windows), 4),
+                                "median": round(sorted(windows)[len(windows) // 2], 4), "max": round(max(windows), 4),
+                                "note": "windows of `steps` replays each; the first one is the contract's timed region "
+                                        "(`value`, `ms_per_step`)"},
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "maskrcnn_r50fpn_train_hotpath_bs2_800x1344 (BASELINE configs[1]; configs[2] at n_gpus 8)",
                    "layout": args.layout, "global_batch": world * w.n_img, "ops_per_step": counts,
@@ -1054,7 +1096,10 @@ def bench_retinanet(args, ctx):
             "traffic": None}
     if dom:
         k_ms, k_n = ktimes[dom]
-        kb = n_img * alg_img  # one launch serves the images of the batch
+        # 100k candidates per image exceed the batched pipeline's 12,288 (RANK_MAX_N): batched_nms_images runs ONE
+        # LAUNCH PER IMAGE on side streams (layers/ops.py: nms_images) -- bytes and pairs per launch are one image's
+        per_launch_images = 1 if n_box > 12288 else n_img
+        kb = per_launch_images * alg_img
         roof = {"bound": "hbm",
                 "kernel": {"nms_mask": "nms_mask_kernel (wavefront suppression bitmask, per class)",
                            "nms_reduce": "nms_reduce_kernel (greedy reduction over the bitmask)"}[dom],
@@ -1064,7 +1109,8 @@ def bench_retinanet(args, ctx):
                 "alg_bytes_note": "SURVEY 8(d) NMS: 16N boxes + bitmask write+read 2*8*sum_c n_c*ceil(n_c/64) + 8*N_keep; "
                                   "the kernel is VALU/LDS bound (IoU tests), so this fraction is small by construction: "
                                   "see pairs_per_s",
-                "pairs_per_s": round(n_img * pairs / (k_ms / 1e3), 1),
+                "images_per_launch": per_launch_images,
+                "pairs_per_s": round(per_launch_images * pairs / (k_ms / 1e3), 1),
                 "timing": "HIP events recorded by the library on the kernel's launch stream, mean over the timed steps",
                 "kernels_ms": {k: round(v[0], 4) for k, v in ktimes.items()}}
     out = {
@@ -1300,20 +1346,27 @@ def main():
     if args.plumbing_only:
         out = bench_plumbing(args, ctx)
     else:
-        out = {"maskrcnn_train": bench_maskrcnn, "retinanet_100k": bench_retinanet, "dcn_r50": bench_dcn}[args.workload](args, ctx)
-        # The default run also carries BASELINE configs[3] and [4] (a few steps each, no CPU leg) so that the driver's
-        # ONE line records them: `extra_workloads` = their own metric / value / ms_per_step / roofline.
+        import bench_extra
+
+        fns = {"maskrcnn_train": bench_maskrcnn, "retinanet_100k": bench_retinanet, "dcn_r50": bench_dcn,
+               "maskrcnn_infer": bench_extra.bench_maskrcnn_infer, "rrpn_micro": bench_extra.bench_rrpn_micro}
+        out = fns[args.workload](args, ctx)
+        # The default run also carries BASELINE configs[3] and [4] and the two SURVEY 8(d) workloads of bench_extra.py (a
+        # few steps each, no CPU leg) so that the driver's ONE line records them: `extra_workloads` = their own metric /
+        # value / ms_per_step / roofline.
         if args.workload == "maskrcnn_train" and world == 1 and not args.no_extra_workloads and not args.force_dist:
             import copy
 
             extra = {}
-            for name, fn, steps, warm in (("retinanet_100k", bench_retinanet, 50, 20), ("dcn_r50", bench_dcn, 10, 3)):
+            for name, fn, steps, warm in (("retinanet_100k", bench_retinanet, 50, 20), ("dcn_r50", bench_dcn, 10, 3),
+                                          ("maskrcnn_infer", bench_extra.bench_maskrcnn_infer, 20, 5),
+                                          ("rrpn_micro", bench_extra.bench_rrpn_micro, 10, 3)):
                 a2 = copy.copy(args)
                 a2.workload, a2.steps, a2.warmup, a2.no_cpu_baseline = name, steps, warm, True
                 torch.cuda.synchronize()
                 r = fn(a2, ctx)
                 extra[name] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype",
-                                                 "config", "roofline") if k in r}
+                                                 "config", "roofline", "ops") if k in r}
             out["extra_workloads"] = extra
     if rank == 0:
         json_out.write(json.dumps(out) + "\n")

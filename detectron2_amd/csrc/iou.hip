@@ -136,8 +136,10 @@ extern "C" int d2amd_box_iou_rotated(const float* boxes1, int n, const float* bo
   // (box_iou_rotated_cuda.cu:89-100) -- here only grid.y is bounded (65535 * ROT_ROWS rows)
   D2_CHECK_ARG(cdiv(n, ROT_ROWS) <= 65535, "box_iou_rotated: n too large (%d)", n);
   dim3 grid(cdiv(m, ROT_BLOCK), cdiv(n, ROT_ROWS));
+  const bool timed = timing_begin("iou_rotated", (hipStream_t)stream);
   hipLaunchKernelGGL(box_iou_rotated_kernel, grid, dim3(ROT_BLOCK), 0, (hipStream_t)stream, boxes1, n,
                      boxes2, m, out);
+  if (timed) timing_end("iou_rotated", (hipStream_t)stream);
   D2_LAUNCH_OK();
   return D2AMD_OK;
 }

@@ -87,10 +87,12 @@ template <typename T>
 static int launch_paste(const void* masks, const float* boxes, int n, int mh, int mw, int img_h, int img_w,
                         float threshold, uint8_t* out, hipStream_t s) {
   const size_t lds = (size_t)mh * mw * sizeof(float);
+  const bool timed = timing_begin("paste_masks", s);  // (the whole op: zero fill + region kernel)
   { const int zrc = zero_async(out, (size_t)n * img_h * img_w, s); if (zrc) return zrc; }
   dim3 grid(cdiv(img_h, PASTE_ROWS), n);
   hipLaunchKernelGGL((paste_region_kernel<T>), grid, dim3(PASTE_BLOCK), lds, s, (const T*)masks, boxes, mh, mw, img_h,
                      img_w, threshold, out);
+  if (timed) timing_end("paste_masks", s);
   D2_LAUNCH_OK();
   return D2AMD_OK;
 }

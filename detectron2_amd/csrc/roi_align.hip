@@ -193,12 +193,14 @@ static int fwd_impl(const void* input, const float* rois, void* output, int N, i
   const long total = (long)K * C * PH * PW;
   const int gsz = grid_for(total, 256);
   if (rotated) {
+    const bool timed = timing_begin("roi_align_rot_fwd", s);
     if (nhwc)
       hipLaunchKernelGGL((roi_align_fwd_direct_kernel<T, true, true>), dim3(gsz), dim3(256), 0, s, in, rois, out, C,
                          H, W, K, PH, PW, scale, sr, aligned, status);
     else
       hipLaunchKernelGGL((roi_align_fwd_direct_kernel<T, true, false>), dim3(gsz), dim3(256), 0, s, in, rois, out,
                          C, H, W, K, PH, PW, scale, sr, aligned, status);
+    if (timed) timing_end("roi_align_rot_fwd", s);
     D2_LAUNCH_OK();
     return D2AMD_OK;
   }
@@ -227,6 +229,7 @@ static int bwd_impl(const void* grad_output, const float* rois, void* grad_input
     return D2AMD_EWORKSPACE;
   }
   float* acc = is32 ? (float*)grad_input : (float*)workspace;
+  const bool timed = rotated && timing_begin("roi_align_rot_bwd", s);  // (the whole op: zero fill, scatter, conversion)
   { const int zrc = zero_async(acc, (size_t)numel * 4, s); if (zrc) return zrc; }
   const long total = (long)K * C * PH * PW;
   if (total > 0) {
@@ -252,6 +255,7 @@ static int bwd_impl(const void* grad_output, const float* rois, void* grad_input
     hipLaunchKernelGGL((f32_to_T_kernel<T>), dim3(grid_for(numel, 256)), dim3(256), 0, s, acc, (T*)grad_input, numel);
     D2_LAUNCH_OK();
   }
+  if (timed) timing_end("roi_align_rot_bwd", s);
   return D2AMD_OK;
 }
 

@@ -50,7 +50,8 @@ const char* d2amd_last_error(void);       /* last error message of this thread (
  * right before / after each launch; d2amd_timing_read waits for them and returns the summed duration and the number
  * of launches since the last select / enable.  Names: "pool_bwd_staged_r7" / "_r14" (tile-gather backward of the
  * fused pooler, pooled size <= 7 / larger), "pool_fwd_r7" / "_r14", "dcn_fwd", "dcn_bwd_data", "dcn_bwd_gather", "dcn_bwd_weight",
- * "nms_mask", "nms_reduce".  Off by default (no events, no cost). */
+ * "nms_mask", "nms_reduce" (axis-aligned and rotated), "paste_masks" (zero fill + region kernel), "iou_rotated",
+ * "roi_align_rot_fwd", "roi_align_rot_bwd" (zero fill + scatter + conversion).  Off by default (no events, no cost). */
 void d2amd_timing_select(const char* names_csv); /* comma-separated kernel names; NULL or "" = none */
 void d2amd_timing_enable(int mask); /* legacy: bit 0 pool_bwd_*_r7 fine, 1 coarse, 2 / 3 the same for _r14; 0 = off */
 int d2amd_timing_read(const char* kernel, double* total_ms, int* launches);
