@@ -774,12 +774,65 @@ def cpu_baseline_maskrcnn(w):
 
     t_mask = _median_time(mask_part, runs=3)
     sec = t_img * w.n_img + t_pool + t_mask
-    return {"value": round(w.n_img / sec, 4), "unit": "img/s", "cores": T, "kind": "port",
+    try:
+        refpy = cpu_reference_python(w)
+    except Exception as e:  # (a reported baseline must never take the line down)
+        refpy = {"error": repr(e)}
+    return {"value": round(w.n_img / sec, 4), "unit": "img/s", "cores": T, "kind": "port", "reference_python": refpy,
             "sample": f"the full step, unsampled, median of 5 runs: per-image ops (IoU+Matcher x2, RPN top-k/decode/NMS) "
                       f"of image 0 on 1 thread x {w.n_img} images = {t_img * w.n_img:.3f} s; both poolers fwd+bwd, all "
                       f"ROIs x 256 channels in channel slabs on {T} threads = {t_pool:.3f} s; mask targets + loss "
                       f"fwd/bwd (1 thread, 3 runs) = {t_mask:.3f} s",
             "host_cores_available": os.cpu_count()}
+
+
+def cpu_reference_python(w):
+    """The REFERENCE's own Python on the host's cores, where it runs without torchvision: image 0's `pairwise_iou` +
+    `Matcher` (structures/boxes.py:312-358, modeling/matcher.py) for anchors and proposals, `subsample_labels`
+    (modeling/sampling.py) and `find_top_rpn_proposals` (proposal_utils.py:22-135; its batched_nms = torchvision, absent
+    here: the C port is bound in, and the decode feeding it is Box2BoxTransform.apply_deltas restated in torch).  Loaded
+    by oracle/ref.py from the tree or the staged bytecode; torch threads = all cores; medians of 3.  The ROIAlign-backed
+    reference functions (ROIPooler, BitMasks.crop_and_resize, mask_rcnn_loss) need torchvision and cannot run."""
+    import oracle
+    from oracle import ref
+
+    if not ref.have_py():
+        return None
+    torch.set_num_threads(os.cpu_count() or 1)
+    boxes_mod, mt, sp = ref.py_boxes(), ref.py_matcher(), ref.py_sampling()
+    Boxes = boxes_mod.Boxes
+
+    def nms(b, s, i, t):
+        return torch.from_numpy(oracle.batched_nms(b.numpy(), s.numpy(), i.numpy(), t))
+
+    pu = ref.py_proposal_utils(nms)
+    gt, an, pg = w.gt[0].cpu(), w.anchors.cpu(), w.props_with_gt[0].cpu()
+    am, pm = mt.Matcher([0.3, 0.7], [0, -1, 1], True), mt.Matcher([0.5], [0, 1], False)
+    labels = {}
+
+    def match():
+        _i, labels["a"] = am(boxes_mod.pairwise_iou(Boxes(gt), Boxes(an)))
+        pm(boxes_mod.pairwise_iou(Boxes(gt), Boxes(pg)))
+
+    t_match = _median_time(match, runs=3)
+    t_samp = _median_time(lambda: sp.subsample_labels(labels["a"].clone(), RPN_BATCH, RPN_POS_FRACTION, 0), runs=3)
+    props = []
+    for a, d in zip(w.anchor_levels, w.rpn_deltas):
+        a, d = a.cpu(), d[:1].cpu()
+        wd, ht = a[:, 2] - a[:, 0], a[:, 3] - a[:, 1]
+        cx, cy = a[:, 0] + 0.5 * wd, a[:, 1] + 0.5 * ht
+        dw, dh = d[..., 2].clamp(max=math.log(1000.0 / 16)), d[..., 3].clamp(max=math.log(1000.0 / 16))
+        pcx, pcy = d[..., 0] * wd + cx, d[..., 1] * ht + cy
+        pw, ph = torch.exp(dw) * wd, torch.exp(dh) * ht
+        props.append(torch.stack([pcx - 0.5 * pw, pcy - 0.5 * ph, pcx + 0.5 * pw, pcy + 0.5 * ph], -1))
+    lg = [x[:1].cpu() for x in w.rpn_logits]
+    t_rpn = _median_time(lambda: pu.find_top_rpn_proposals(props, lg, [(IMG_H, IMG_W)], 0.7, 2000, 1000, 0.0, True), runs=3)
+    return {"kind": "reference", "cores": os.cpu_count(), "unit": "s per image",
+            "pairwise_iou+Matcher (anchors 16 x 268,569 and proposals 16 x 1,032)": round(t_match, 4),
+            "subsample_labels (268,569 anchor labels)": round(t_samp, 4),
+            "find_top_rpn_proposals (2000 / 1000, NMS = the C port)": round(t_rpn, 4),
+            "note": "the reference's own Python (oracle/ref.py), image 0, medians of 3 after a warm-up; beside the port's "
+                    "figure in `sample`, not part of `value`"}
 
 
 def pmc_source(op=None, layout="nhwc"):
