@@ -143,6 +143,7 @@ def bench_maskrcnn_infer(args, ctx):
         t = B.Timer()
         for _ in range(min(args.steps, 10)):
             infer_step(w, t.run)
+        torch.cuda.synchronize()
     if rank != 0:
         return None
     n_img = len(ids)
@@ -270,6 +271,7 @@ def bench_rrpn_micro(args, ctx):
     t = B.Timer()
     for _ in range(min(args.steps, 10)):
         rrpn_step(w, t.run)
+    torch.cuda.synchronize()
     if rank != 0:
         return None
     n_img = len(ids)

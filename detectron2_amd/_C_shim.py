@@ -65,8 +65,10 @@ def deform_conv_forward(input, weight, offset, output, columns, ones, kW, kH, dW
                         group, deformable_group, im2col_step):
     _need_gpu(input, weight, offset)
     assert tuple(weight.shape[2:]) == (kH, kW), "kernel size does not match the weight"
-    y = _dcn_forward(input, offset, None, weight, None, (dH, dW), (padH, padW), (dilationH, dilationW), group,
-                         deformable_group)
+    # (the reference's `columns` argument is per-image scratch its C++ resizes and overwrites, deform_conv_cuda.cu:346-353:
+    # its contents are not part of the contract; the saved-column entry is d2amd_deform_conv_forward_columns)
+    y, _cols = _dcn_forward(input, offset, None, weight, None, (dH, dW), (padH, padW), (dilationH, dilationW), group,
+                            deformable_group)
     _into(output, y)
     return 1
 
@@ -95,8 +97,8 @@ def modulated_deform_conv_forward(input, weight, bias, ones, offset, mask, outpu
                                   stride_w, pad_h, pad_w, dilation_h, dilation_w, group, deformable_group, with_bias):
     _need_gpu(input, weight, offset)
     assert tuple(weight.shape[2:]) == (kernel_h, kernel_w), "kernel size does not match the weight"
-    y = _dcn_forward(input, offset, mask, weight, bias if with_bias else None, (stride_h, stride_w), (pad_h, pad_w),
-                         (dilation_h, dilation_w), group, deformable_group)
+    y, _cols = _dcn_forward(input, offset, mask, weight, bias if with_bias else None, (stride_h, stride_w), (pad_h, pad_w),
+                            (dilation_h, dilation_w), group, deformable_group)
     _into(output, y)
 
 

@@ -28,6 +28,7 @@ SOURCES = {
     "roi_pool.hip": [],
     "deform_conv.hip": [],
     "deform_conv_tc.hip": [],
+    "dcn_bww_gemm.hip": [],
     "matcher.hip": ["-ffp-contract=off"],
     "label_sample.hip": ["-ffp-contract=off"],
     "subsample.hip": ["-ffp-contract=off"],

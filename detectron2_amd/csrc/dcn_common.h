@@ -100,7 +100,18 @@ TcPlan dcn_tc_plan_fwd(const DcnShape& s, int dtype);
 template <typename T>
 int dcn_tc_forward(const DcnShape& s, const TcPlan& pl, const void* x_nhwc, const void* offset, const void* mask,
                    const void* weight, const void* bias, void* out, void* wp, float* partial, hipStream_t st,
-                   bool out_nhwc = false);
+                   bool out_nhwc = false, void* col_out = nullptr);
+
+// weight gradient from the column the forward saved (dcn_bww_gemm.hip): dense split-K GEMM
+struct BwwGemmPlan {
+  bool ok;
+  int Q, n_mt, n_nt, ksplit, kchunk;   // Q = K2 * C / 32 column chunks; 128 x 128 output tiles; K range per workgroup
+  size_t col_bytes, partial_bytes;
+};
+BwwGemmPlan dcn_bww_gemm_plan(const DcnShape& s, int dtype);
+template <typename T>
+int dcn_bww_gemm(const DcnShape& s, const BwwGemmPlan& pl, const void* dy_nhwc, const void* col, float* partials,
+                 void* grad_weight, hipStream_t st);
 
 struct TcBwPlan {
   bool ok;

@@ -518,6 +518,7 @@ struct DcnWs {
   void* tc_wp;        // fragment-ordered weights of the 16-bit MFMA path
   float* tc_partial;  // fp32 partial outputs when its reduction is split
   TcPlan tc;
+  void* col_saved;    // the column the training forward saved / the backward is handed (d2amd_deform_conv_*_saved)
   size_t total;
 };
 
@@ -549,8 +550,11 @@ static DcnWs carve_ws(const DcnShape& s, int dtype, bool backward, void* base) {
     if (w.use_gather) w.gather.cnt = (int*)take(dcn_gather_cnt_bytes(s));
     {  // fp32 staging of the weight gradient: [g][tap][co][ci] (generic kernels: atomics), or the MFMA kernel's partial tiles
       const TcBwwPlan wp = dcn_tc_plan_bww(s, dtype);
-      const size_t stage = (size_t)s.Co * s.Cg * s.K2 * 4;
-      w.gwr = (float*)take(wp.ok && wp.partial_bytes > stage ? wp.partial_bytes : stage);
+      const BwwGemmPlan gp = dcn_bww_gemm_plan(s, dtype);  // (the saved-column GEMM's split-K partial tiles)
+      size_t stage = (size_t)s.Co * s.Cg * s.K2 * 4;
+      if (wp.ok && wp.partial_bytes > stage) stage = wp.partial_bytes;
+      if (gp.ok && gp.partial_bytes > stage) stage = gp.partial_bytes;
+      w.gwr = (float*)take(stage);
     }
     if (w.use_gather) {
       w.gather.col = take(dcn_gather_col_bytes(s, es));
@@ -605,7 +609,7 @@ static int fwd_host(const DcnShape& s, const void* x, const void* offset, const 
   if (w.nhwc) {  // a channels_last caller: x is what the kernels read, out is written [position][Co]
     if constexpr (sizeof(T) == 2) {
       if (w.tc.ok)
-        return dcn_tc_forward<T>(s, w.tc, x, offset, mask, weight, bias, out, w.tc_wp, w.tc_partial, st, true);
+        return dcn_tc_forward<T>(s, w.tc, x, offset, mask, weight, bias, out, w.tc_wp, w.tc_partial, st, true, w.col_saved);
     }
     set_error("deform_conv_forward: NHWC input is served by the 16-bit MFMA path only (this shape / dtype is not)");
     return D2AMD_EUNSUPPORTED;
@@ -614,7 +618,8 @@ static int fwd_host(const DcnShape& s, const void* x, const void* offset, const 
   if (rc) return rc;
   if constexpr (sizeof(T) == 2) {
     if (w.tc.ok)
-      return dcn_tc_forward<T>(s, w.tc, w.x_nhwc, offset, mask, weight, bias, out, w.tc_wp, w.tc_partial, st);
+      return dcn_tc_forward<T>(s, w.tc, w.x_nhwc, offset, mask, weight, bias, out, w.tc_wp, w.tc_partial, st, false,
+                               w.col_saved);
   }
   const long nw = (long)s.Co * s.Cg * s.K2;
   hipLaunchKernelGGL((repack_weight_kernel<T>), dim3(cdiv(nw, 256) > 4096 ? 4096 : cdiv(nw, 256)), dim3(256), 0, st,
@@ -667,11 +672,16 @@ static int bwd_host(const DcnShape& s, const void* x, const void* offset, const 
         rc = cvt_grads<T>(s, w, goffset, (gmask && mask) ? gmask : nullptr, st);
         if (rc) return rc;
       }
-      if (gweight || gbias) {
+      const BwwGemmPlan gp = dcn_bww_gemm_plan(s, (int)w.dtype);
+      const bool gemm_w = gweight && w.col_saved && gp.ok;  // dW = dY^T col from the column the forward saved
+      if ((gweight && !gemm_w) || gbias) {
         rc = launch_transpose<T, T>((const T*)gout, (T*)w.gout_nhwc, s.B, s.L, s.Co, st);  // -> [b][Co][l]
         if (rc) return rc;
       }
-      if (gweight) {
+      if (gemm_w) {
+        rc = dcn_bww_gemm<T>(s, gp, gout, w.col_saved, w.gwr, gweight, st);
+        if (rc) return rc;
+      } else if (gweight) {
         rc = dcn_tc_backward_weight<T>(s, wp, x, offset, mask, w.gout_nhwc, w.gwr, gweight, st);
         if (rc) return rc;
       }
@@ -739,8 +749,20 @@ static int bwd_host(const DcnShape& s, const void* x, const void* offset, const 
   if (gweight) {
     bool tc_w = false;
     if constexpr (!is32) {
+      const BwwGemmPlan gp = dcn_bww_gemm_plan(s, (int)w.dtype);
+      if (w.col_saved && gp.ok) {  // dW = dY^T col from the column the forward saved (dY as [P][Co])
+        if (!need_data) {
+          rc = launch_transpose<T, T>((const T*)gout, (T*)w.gout_nhwc, s.B, s.Co, s.L, st);
+          if (rc) return rc;
+        }
+        rc = dcn_bww_gemm<T>(s, gp, w.gout_nhwc, w.col_saved, w.gwr, gweight, st);
+        if (rc) return rc;
+        tc_w = true;
+      }
+    }
+    if constexpr (!is32) {
       const TcBwwPlan wp = dcn_tc_plan_bww(s, (int)w.dtype);
-      if (wp.ok) {  // 16-bit MFMA path (deform_conv_tc.hip): partial tiles + an ordered sum, no atomics, no zero fill
+      if (!tc_w && wp.ok) {  // 16-bit MFMA path (deform_conv_tc.hip): partial tiles + an ordered sum, no atomics, no zero fill
         rc = dcn_tc_backward_weight<T>(s, wp, w.x_nhwc, offset, mask, gout, w.gwr, gweight, st);
         if (rc) return rc;
         tc_w = true;
@@ -790,15 +812,16 @@ extern "C" size_t d2amd_deform_conv_workspace_bytes(const d2amd_dcn_params* p, i
   return carve_ws(s, p->dtype, backward != 0, nullptr).total + 256;
 }
 
-extern "C" int d2amd_deform_conv_forward(const d2amd_dcn_params* p, const void* x, const void* offset,
-                                         const void* mask, const void* weight, const void* bias, void* out,
-                                         void* workspace, size_t workspace_bytes, void* stream) {
+static int dcn_forward_impl(const d2amd_dcn_params* p, const void* x, const void* offset, const void* mask,
+                            const void* weight, const void* bias, void* out, void* columns, void* workspace,
+                            size_t workspace_bytes, void* stream) {
   DcnShape s;
   int rc = check_params(p, s, "deform_conv_forward");
   if (rc) return rc;
   if (s.B == 0) return D2AMD_OK;
   D2_CHECK_ARG(x && offset && weight && out && workspace, "deform_conv_forward: null pointer");
   DcnWs w = carve_ws(s, p->dtype, false, workspace);
+  w.col_saved = columns;
   D2_CHECK_ARG(p->layout == D2AMD_NCHW || p->layout == D2AMD_NHWC, "deform_conv_forward: bad layout %d", p->layout);
   w.nhwc = p->layout == D2AMD_NHWC;
   if (workspace_bytes < w.total) {
@@ -810,15 +833,39 @@ extern "C" int d2amd_deform_conv_forward(const d2amd_dcn_params* p, const void* 
   });
 }
 
-extern "C" int d2amd_deform_conv_backward(const d2amd_dcn_params* p, const void* x, const void* offset,
-                                          const void* mask, const void* weight, const void* grad_out,
-                                          void* grad_input, void* grad_offset, void* grad_mask, void* grad_weight,
-                                          void* grad_bias, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int d2amd_deform_conv_forward(const d2amd_dcn_params* p, const void* x, const void* offset,
+                                         const void* mask, const void* weight, const void* bias, void* out,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+  return dcn_forward_impl(p, x, offset, mask, weight, bias, out, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" size_t d2amd_deform_conv_columns_bytes(const d2amd_dcn_params* p) {
+  DcnShape s;
+  if (check_params(p, s, "deform_conv_columns_bytes")) return 0;
+  if (s.B == 0) return 0;
+  const BwwGemmPlan gp = dcn_bww_gemm_plan(s, p->dtype);
+  return gp.ok ? gp.col_bytes : 0;
+}
+
+extern "C" int d2amd_deform_conv_forward_columns(const d2amd_dcn_params* p, const void* x, const void* offset,
+                                                 const void* mask, const void* weight, const void* bias, void* out,
+                                                 void* columns, void* workspace, size_t workspace_bytes,
+                                                 void* stream) {
+  D2_CHECK_ARG(columns == nullptr || d2amd_deform_conv_columns_bytes(p) > 0,
+               "deform_conv_forward_columns: this shape / dtype keeps no column (d2amd_deform_conv_columns_bytes = 0)");
+  return dcn_forward_impl(p, x, offset, mask, weight, bias, out, columns, workspace, workspace_bytes, stream);
+}
+
+static int dcn_backward_impl(const d2amd_dcn_params* p, const void* x, const void* offset, const void* mask,
+                             const void* weight, const void* grad_out, const void* columns, void* grad_input,
+                             void* grad_offset, void* grad_mask, void* grad_weight, void* grad_bias, void* workspace,
+                             size_t workspace_bytes, void* stream) {
   DcnShape s;
   int rc = check_params(p, s, "deform_conv_backward");
   if (rc) return rc;
   D2_CHECK_ARG(s.B == 0 || (x && offset && weight && grad_out && workspace), "deform_conv_backward: null pointer");
   DcnWs w = carve_ws(s, p->dtype, true, workspace);
+  w.col_saved = const_cast<void*>(columns);
   D2_CHECK_ARG(p->layout == D2AMD_NCHW || p->layout == D2AMD_NHWC, "deform_conv_backward: bad layout %d", p->layout);
   w.nhwc = p->layout == D2AMD_NHWC;
   if (s.B > 0 && workspace_bytes < w.total) {
@@ -829,4 +876,21 @@ extern "C" int d2amd_deform_conv_backward(const d2amd_dcn_params* p, const void*
     return bwd_host<scalar_t>(s, x, offset, mask, weight, grad_out, grad_input, grad_offset, grad_mask, grad_weight,
                               grad_bias, w, (hipStream_t)stream);
   });
+}
+
+extern "C" int d2amd_deform_conv_backward(const d2amd_dcn_params* p, const void* x, const void* offset,
+                                          const void* mask, const void* weight, const void* grad_out,
+                                          void* grad_input, void* grad_offset, void* grad_mask, void* grad_weight,
+                                          void* grad_bias, void* workspace, size_t workspace_bytes, void* stream) {
+  return dcn_backward_impl(p, x, offset, mask, weight, grad_out, nullptr, grad_input, grad_offset, grad_mask,
+                           grad_weight, grad_bias, workspace, workspace_bytes, stream);
+}
+
+extern "C" int d2amd_deform_conv_backward_columns(const d2amd_dcn_params* p, const void* x, const void* offset,
+                                                  const void* mask, const void* weight, const void* grad_out,
+                                                  const void* columns, void* grad_input, void* grad_offset,
+                                                  void* grad_mask, void* grad_weight, void* grad_bias, void* workspace,
+                                                  size_t workspace_bytes, void* stream) {
+  return dcn_backward_impl(p, x, offset, mask, weight, grad_out, columns, grad_input, grad_offset, grad_mask,
+                           grad_weight, grad_bias, workspace, workspace_bytes, stream);
 }

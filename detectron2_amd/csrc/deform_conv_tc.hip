@@ -46,6 +46,9 @@ struct TcArgs {
   int ablate;  // profiling only (D2AMD_DCN_ABLATE): 1 no gather loads, 2 no combine, 4 no MFMA, 8 no weight copy
   int out_nhwc;  // 1: out (and the fp32 partials) are [position][Co] (a channels_last caller) instead of [b][Co][l]
   unsigned long long* stamps;  // profiling only (D2AMD_DCN_STAMPS): per workgroup {start, after tables, after loop, end} (100 MHz)
+  void* col_out;  // training forward: the gathered column (mask folded in, I/O dtype) is ALSO stored, for the weight
+                  // gradient's GEMM -- [tap][channel chunk of 16 NKS][position][16 NKS channels] (a stage's tile of a
+                  // workgroup is one contiguous block); written by the workgroups of output-channel tile 0 only
 };
 
 // Column buffer: per 32-position tile, 2*NKS "subs" (kstep, k-half) of 32 consecutive 16-B slots each, at a
@@ -158,8 +161,11 @@ __global__ __launch_bounds__(256) void tc_pack_weight_kernel(const T* __restrict
 // overlaps the matrix pipe with VALU when the two alternate in its own instruction stream, which hipcc
 // does not produce for this loop; a matrix wave and a gather wave resident on the same SIMD overlap
 // by construction.  One s_barrier per stage orders column/weight buffer hand-off (double buffered).
+// (4-wave workgroups with 32-channel stages are planned at THREE per CU -- dcn_tc_plan_fwd -- i.e. <= 168 VGPRs: the
+// bound is stated so that an extra live value in the gather path cannot silently cost a third of the occupancy)
 template <typename T, int MT, int NWM, int NWN, int NG, int NKS>
-__global__ __launch_bounds__(64 * (NWM * NWN + NG)) void dcn_fwd_tc_kernel(DcnShape s, TcArgs a) {
+__global__ __launch_bounds__(64 * (NWM * NWN + NG), (NKS == 2 && NWM * NWN + NG == 4) ? 3 : 1)
+void dcn_fwd_tc_kernel(DcnShape s, TcArgs a) {
   typedef Mma<T> M;
   typedef TcB<NKS> BL;
   constexpr int NMW = NWM * NWN, NT = 64 * (NMW + NG), BM = 32 * MT * NWM, BN = 32 * NWN;
@@ -234,6 +240,8 @@ __global__ __launch_bounds__(64 * (NWM * NWN + NG)) void dcn_fwd_tc_kernel(DcnSh
         }
       }
     };
+    char* const col_dst = (a.col_out && cot == 0) ? (char*)a.col_out : nullptr;  // uniform
+    int cst = 0;  // the stage (tap * NCH + chunk) of the tile being combined: set by the caller of combine()
     auto combine = [&](int buf, const raw16 (&raw)[ITEMS][4], const float (&w)[ITEMS][4]) __attribute__((always_inline)) {
       raw16* Bb = Bs + buf * BSLOTS;
       if (a.ablate & 2) {
@@ -257,25 +265,33 @@ __global__ __launch_bounds__(64 * (NWM * NWN + NG)) void dcn_fwd_tc_kernel(DcnSh
 #pragma unroll
           for (int u = 0; u < 8; u++) v[u] = c == 0 ? wc * f[u] : v[u] + wc * f[u];
         }
-        Bb[BL::slot(n >> 5, sub, n & 31)] = tc_pack(v, T{});
+        const raw16 packed = tc_pack(v, T{});
+        Bb[BL::slot(n >> 5, sub, n & 31)] = packed;
+        // (uniform pointer test and uniform base; the lane's offset is its item index: (n CHUNK + 8 sub) elements = 16 i
+        // bytes -- 64 lanes store 1 KB contiguous)
+        if (col_dst && p0 + n < s.P)
+          *reinterpret_cast<raw16*>(col_dst + ((size_t)cst * s.P + (size_t)p0) * (CHUNK * sizeof(T)) + (size_t)i * 16) = packed;
       }
     };
     // the gathers run TWO stages ahead of the matrix waves (register double buffer), so the L2
     // latency of stage j+2 hides behind the combine of stage j+1
     issue(s_lo, graw[0], gw[0]);
     if (nst > 1) issue(s_lo + 1, graw[1], gw[1]);
+    cst = s_lo;
     combine(0, graw[0], gw[0]);
     if (nst > 2) issue(s_lo + 2, graw[0], gw[0]);
     __syncthreads();  // barrier #1: stage 0 staged
     // iteration j (matrix waves compute stage j): stage j+1 -> buffer (j+1)&1; registers (j+1)&1
     for (int j = 0; j < nst; j += 2) {
       if (j + 1 < nst) {
+        cst = s_lo + j + 1;
         combine(1, graw[1], gw[1]);
         if (j + 3 < nst) issue(s_lo + j + 3, graw[1], gw[1]);
       }
       __syncthreads();
       if (j + 1 < nst) {
         if (j + 2 < nst) {
+          cst = s_lo + j + 2;
           combine(0, graw[0], gw[0]);
           if (j + 4 < nst) issue(s_lo + j + 4, graw[0], gw[0]);
         }
@@ -722,7 +738,7 @@ static int tc_launch_fwd(const DcnShape& s, const TcPlan& pl, const TcArgs& a, h
 template <typename T>
 int dcn_tc_forward(const DcnShape& s, const TcPlan& pl, const void* x_nhwc, const void* offset, const void* mask,
                    const void* weight, const void* bias, void* out, void* wp, float* partial, hipStream_t st,
-                   bool out_nhwc) {
+                   bool out_nhwc, void* col_out) {
   {
     const long groups16 = (long)s.G * pl.n_cot * pl.S * (pl.BM / 32) * pl.NKS * 64;
     const int blocks = cdiv(groups16, 256) > 8192 ? 8192 : cdiv(groups16, 256);
@@ -735,6 +751,7 @@ int dcn_tc_forward(const DcnShape& s, const TcPlan& pl, const void* x_nhwc, cons
   a.n_pt = pl.n_pt; a.n_cot = pl.n_cot; a.ksplit = pl.ksplit; a.NCH = pl.NCH; a.S = pl.S;
   { const char* e = getenv("D2AMD_DCN_ABLATE"); a.ablate = e ? atoi(e) : 0; }
   a.out_nhwc = out_nhwc ? 1 : 0;
+  a.col_out = (col_out && !pl.wave && pl.NKS == 2 && s.G == 1 && s.DG == 1) ? col_out : nullptr;  // (dcn_bww_gemm_plan)
   const long total = (long)pl.n_pt * pl.n_cot * s.G * pl.ksplit;
   D2_CHECK_ARG(total < (1l << 30), "deform_conv: too many tiles");
   a.total = (int)total;
@@ -770,9 +787,9 @@ int dcn_tc_forward(const DcnShape& s, const TcPlan& pl, const void* x_nhwc, cons
 }
 
 template int dcn_tc_forward<bf16_t>(const DcnShape&, const TcPlan&, const void*, const void*, const void*, const void*,
-                                    const void*, void*, void*, float*, hipStream_t, bool);
+                                    const void*, void*, void*, float*, hipStream_t, bool, void*);
 template int dcn_tc_forward<f16_t>(const DcnShape&, const TcPlan&, const void*, const void*, const void*, const void*,
-                                   const void*, void*, void*, float*, hipStream_t, bool);
+                                   const void*, void*, void*, float*, hipStream_t, bool, void*);
 
 // =====================================================================================================
 // Backward w.r.t. input / offset / mask, 16-bit path.

@@ -77,7 +77,19 @@ def _same_dtype(ref, *ts):
     return [None if t is None else t.detach().to(ref.dtype).contiguous() for t in ts]
 
 
-def _dcn_forward(x, offset, mask, weight, bias, stride, padding, dilation, groups, deformable_groups):
+def _columns(L, p, device, wanted):
+    """The column buffer the training forward keeps for the weight gradient (d2amd_deform_conv_columns_bytes: 0 when
+    the shape / dtype is not served) -- the reference's `columns` scratch tensor (deform_conv.py:97-98,248-254) as a
+    saved activation."""
+    if not wanted:
+        return None
+    n = L.d2amd_deform_conv_columns_bytes(ctypes.byref(p))
+    return torch.empty(n, dtype=torch.uint8, device=device) if n else None
+
+
+def _dcn_forward(x, offset, mask, weight, bias, stride, padding, dilation, groups, deformable_groups,
+                 save_columns=False):
+    """-> (out, columns | None).  save_columns: the weight gradient will be asked for."""
     _C.require_gpu(x, offset, mask, weight, bias, op="deform_conv")
     out_size = _output_size(x, weight, padding, dilation, stride)
     _check_shapes(x, offset, mask, weight, out_size, groups, deformable_groups)
@@ -88,13 +100,14 @@ def _dcn_forward(x, offset, mask, weight, bias, stride, padding, dilation, group
         out = torch.empty(out_size, dtype=x_.dtype, device=x_.device, memory_format=torch.channels_last)
         p = _params(x_, weight_, stride, padding, dilation, groups, deformable_groups, _C.NHWC)
         with _C.on_device(x_.device):
+            cols = _columns(L, p, x_.device, save_columns)
             ws_bytes = L.d2amd_deform_conv_workspace_bytes(ctypes.byref(p), 0)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x_.device)
-            rc = L.d2amd_deform_conv_forward(ctypes.byref(p), _C.ptr(x_), _C.ptr(offset_), _C.ptr(mask_),
-                                             _C.ptr(weight_), _C.ptr(bias_), _C.ptr(out), _C.ptr(ws), ws_bytes,
-                                             _C.stream())
+            rc = L.d2amd_deform_conv_forward_columns(ctypes.byref(p), _C.ptr(x_), _C.ptr(offset_), _C.ptr(mask_),
+                                                     _C.ptr(weight_), _C.ptr(bias_), _C.ptr(out), _C.ptr(cols),
+                                                     _C.ptr(ws), ws_bytes, _C.stream())
         if rc == 0:
-            return out
+            return out, cols
         if rc != _C.EUNSUPPORTED:
             _C.check(rc)
     x_ = x.detach().contiguous()
@@ -102,16 +115,17 @@ def _dcn_forward(x, offset, mask, weight, bias, stride, padding, dilation, group
     out = x_.new_empty(out_size)
     p = _params(x_, weight_, stride, padding, dilation, groups, deformable_groups)
     with _C.on_device(x_.device):
+        cols = _columns(L, p, x_.device, save_columns)
         ws_bytes = L.d2amd_deform_conv_workspace_bytes(ctypes.byref(p), 0)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x_.device)
-        _C.check(L.d2amd_deform_conv_forward(ctypes.byref(p), _C.ptr(x_), _C.ptr(offset_), _C.ptr(mask_),
-                                             _C.ptr(weight_), _C.ptr(bias_), _C.ptr(out), _C.ptr(ws), ws_bytes,
-                                             _C.stream()))
-    return out
+        _C.check(L.d2amd_deform_conv_forward_columns(ctypes.byref(p), _C.ptr(x_), _C.ptr(offset_), _C.ptr(mask_),
+                                                     _C.ptr(weight_), _C.ptr(bias_), _C.ptr(out), _C.ptr(cols),
+                                                     _C.ptr(ws), ws_bytes, _C.stream()))
+    return out, cols
 
 
 def _dcn_backward(x, offset, mask, weight, grad_output, stride, padding, dilation, groups, deformable_groups,
-                  need_input, need_weight, with_bias):
+                  need_input, need_weight, with_bias, columns=None):
     _C.require_gpu(grad_output, op="deform_conv backward")
     L = _C.lib()
     if _is_nhwc(x):  # channels_last activations: gradients in and out stay channels_last
@@ -127,9 +141,10 @@ def _dcn_backward(x, offset, mask, weight, grad_output, stride, padding, dilatio
         with _C.on_device(x_.device):
             ws_bytes = L.d2amd_deform_conv_workspace_bytes(ctypes.byref(p), 1)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x_.device)
-            rc = L.d2amd_deform_conv_backward(
-                ctypes.byref(p), _C.ptr(x_), _C.ptr(offset_), _C.ptr(mask_), _C.ptr(weight_), _C.ptr(go), _C.ptr(gi),
-                _C.ptr(goff), _C.ptr(gm), _C.ptr(gw), _C.ptr(gb), _C.ptr(ws), ws_bytes, _C.stream())
+            rc = L.d2amd_deform_conv_backward_columns(
+                ctypes.byref(p), _C.ptr(x_), _C.ptr(offset_), _C.ptr(mask_), _C.ptr(weight_), _C.ptr(go),
+                _C.ptr(columns), _C.ptr(gi), _C.ptr(goff), _C.ptr(gm), _C.ptr(gw), _C.ptr(gb), _C.ptr(ws), ws_bytes,
+                _C.stream())
         if rc == 0:
             return gi, goff, gm, gw, gb
         if rc != _C.EUNSUPPORTED:
@@ -145,9 +160,9 @@ def _dcn_backward(x, offset, mask, weight, grad_output, stride, padding, dilatio
     with _C.on_device(x_.device):
         ws_bytes = L.d2amd_deform_conv_workspace_bytes(ctypes.byref(p), 1)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x_.device)
-        _C.check(L.d2amd_deform_conv_backward(
-            ctypes.byref(p), _C.ptr(x_), _C.ptr(offset_), _C.ptr(mask_), _C.ptr(weight_), _C.ptr(go), _C.ptr(gi),
-            _C.ptr(goff), _C.ptr(gm), _C.ptr(gw), _C.ptr(gb), _C.ptr(ws), ws_bytes, _C.stream()))
+        _C.check(L.d2amd_deform_conv_backward_columns(
+            ctypes.byref(p), _C.ptr(x_), _C.ptr(offset_), _C.ptr(mask_), _C.ptr(weight_), _C.ptr(go), _C.ptr(columns),
+            _C.ptr(gi), _C.ptr(goff), _C.ptr(gm), _C.ptr(gw), _C.ptr(gb), _C.ptr(ws), ws_bytes, _C.stream()))
     return gi, goff, gm, gw, gb
 
 
@@ -166,7 +181,9 @@ class _DeformConv(Function):
         ctx.stride, ctx.padding, ctx.dilation = ctx.geom[:3]
         ctx.groups, ctx.deformable_groups, ctx.im2col_step = groups, deformable_groups, im2col_step
         ctx.save_for_backward(input, offset, weight)
-        return _dcn_forward(input, offset, None, weight, None, *ctx.geom)
+        out, ctx.columns = _dcn_forward(input, offset, None, weight, None, *ctx.geom,
+                                        save_columns=bool(ctx.needs_input_grad[2]))
+        return out
 
     @staticmethod
     @once_differentiable
@@ -176,7 +193,8 @@ class _DeformConv(Function):
         input, offset, weight = ctx.saved_tensors
         wants = ctx.needs_input_grad
         gi, goff, _, gw, _ = _dcn_backward(input, offset, None, weight, grad_output, *ctx.geom,
-                                           wants[0] or wants[1], wants[2], False)
+                                           wants[0] or wants[1], wants[2], False, columns=ctx.columns)
+        ctx.columns = None
         return (gi, goff, gw) + (None,) * 6
 
     _output_size = staticmethod(_output_size)
@@ -195,7 +213,9 @@ class _ModulatedDeformConv(Function):
         ctx.geom = (_pair(stride), _pair(padding), _pair(dilation), groups, deformable_groups)
         if any(t.requires_grad for t in (input, offset, mask, weight)):
             ctx.save_for_backward(input, offset, mask, weight)
-        return _dcn_forward(input, offset, mask, weight, bias, *ctx.geom)
+        out, ctx.columns = _dcn_forward(input, offset, mask, weight, bias, *ctx.geom,
+                                        save_columns=bool(weight.requires_grad))
+        return out
 
     @staticmethod
     @once_differentiable
@@ -203,7 +223,9 @@ class _ModulatedDeformConv(Function):
         if not grad_output.is_cuda:
             raise NotImplementedError("Deformable Conv is not supported on CPUs!")
         input, offset, mask, weight = ctx.saved_tensors
-        grads = _dcn_backward(input, offset, mask, weight, grad_output, *ctx.geom, True, True, ctx.with_bias)
+        grads = _dcn_backward(input, offset, mask, weight, grad_output, *ctx.geom, True, True, ctx.with_bias,
+                              columns=ctx.columns)
+        ctx.columns = None
         return tuple(grads) + (None,) * 5
 
 

@@ -520,6 +520,24 @@ int d2amd_deform_conv_backward(const d2amd_dcn_params* p, const void* x, const v
                                void* grad_weight, void* grad_bias, void* workspace,
                                size_t workspace_bytes, void* stream);
 
+/* ---- the column buffer as a SAVED ACTIVATION.  The reference's Python hands `columns` scratch tensors to
+ * _C.deform_conv_forward / modulated_deform_conv_forward (layers/deform_conv.py:97-98,248-254; the C++ resizes and
+ * refills them per image, deform_conv_cuda.cu:346-353,916-918) and recomputes the im2col in the backward
+ * (:1160-1179).  Here the training forward can KEEP the column it gathers -- 16-bit, modulation mask folded in,
+ * [kh*kw * C/32 chunks][B*Ho*Wo positions][32 channels]; d2amd_deform_conv_columns_bytes = its size (77 MB for an R50
+ * res3 block of 2 images: sized for 288 GB of HBM), 0 when the shape / dtype is not served (fp32, groups > 1,
+ * deformable_groups > 1, C % 64 != 0: pass columns = NULL) -- and the backward's weight gradient becomes a dense
+ * split-K GEMM dW = dY^T col on MFMA instead of a second gather.  columns = NULL in either call = the plain entry. */
+size_t d2amd_deform_conv_columns_bytes(const d2amd_dcn_params* p);
+int d2amd_deform_conv_forward_columns(const d2amd_dcn_params* p, const void* x, const void* offset,
+                                      const void* mask, const void* weight, const void* bias, void* out,
+                                      void* columns, void* workspace, size_t workspace_bytes, void* stream);
+int d2amd_deform_conv_backward_columns(const d2amd_dcn_params* p, const void* x, const void* offset,
+                                       const void* mask, const void* weight, const void* grad_out,
+                                       const void* columns, void* grad_input, void* grad_offset, void* grad_mask,
+                                       void* grad_weight, void* grad_bias, void* workspace,
+                                       size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -335,3 +335,44 @@ def test_channels_last_entry_equals_the_nchw_entry(dtype, B, C, Co, H, W):
     y = layers.modulated_deform_conv(xt, case[1].to(DEV), case[2].to(DEV), case[3].to(DEV), case[4].to(DEV), *a)
     exp = run_oracle(*case, backward=False)["out"]
     assert rel_err(y.float().cpu().numpy(), exp) < TOL[dtype]
+
+
+# ------------------------------------------------------------------ saved column -> weight gradient as a GEMM
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,C,Co,H,W", [(2, 128, 128, 18, 21), (1, 256, 96, 13, 11), (3, 64, 264, 9, 10), (2, 64, 64, 40, 37)])
+def test_saved_column_weight_gradient(dtype, B, C, Co, H, W):
+    """The training forward keeps the column it gathers (d2amd_deform_conv_forward_columns) and the weight gradient is
+    the dense split-K GEMM dW = dY^T col of dcn_bww_gemm.hip instead of a second gather: the same dW as the
+    re-gathering kernel (D2AMD_DCN_NO_SAVED_COL=1) up to the rounding of a 16-bit output and as the oracle within the
+    16-bit bar; bit-identical run to run (ordered split-K sum, no atomics); ragged Co (96, 264: partial row tiles),
+    P not a multiple of the 32-position K step, several K ranges (P = 2,960 > one 256-position chunk)."""
+    import ctypes
+
+    from detectron2_amd import _C
+    from detectron2_amd.layers.deform_conv import _params
+
+    case = make_case(60 + C + Co, B, C, Co, H, W, dtype=dtype)
+    x, off, msk, w = case[0], case[1], case[2], case[3]
+    p = _params(x, w, (1, 1), (1, 1), (1, 1), 1, 1)
+    p.dtype = _C.dtype_code(x.to(DEV))
+    assert _C.lib().d2amd_deform_conv_columns_bytes(ctypes.byref(p)) == 9 * C * B * H * W * 2
+    a = run_gpu(*case)
+    b = run_gpu(*case)
+    assert np.array_equal(a["grad_weight"], b["grad_weight"])
+    with env(D2AMD_DCN_NO_SAVED_COL=1):
+        assert _C.lib().d2amd_deform_conv_columns_bytes(ctypes.byref(p)) == 0
+        c = run_gpu(*case)
+    assert rel_err(a["grad_weight"], c["grad_weight"]) < TOL[dtype] / 4
+    for k in ("out", "grad_input", "grad_offset", "grad_mask"):
+        assert np.array_equal(a[k], c[k]), k  # nothing else changes
+    exp = run_oracle(*case)
+    assert rel_err(a["grad_weight"], exp["grad_weight"]) < TOL[dtype]
+
+
+def test_columns_are_not_kept_when_the_weight_needs_no_gradient():
+    x, off, msk, w, bias, go, kw = make_case(71, 1, 64, 64, 9, 10)
+    xt, ot, mt = [t.to(DEV).requires_grad_(True) for t in (x, off, msk)]
+    y = layers.modulated_deform_conv(xt, ot, mt, w.to(DEV), None, 1, 1, 1, 1, 1)
+    assert y.grad_fn is not None and getattr(y.grad_fn, "columns", None) is None
+    y.backward(go.to(DEV))
+    assert xt.grad is not None
