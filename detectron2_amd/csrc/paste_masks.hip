@@ -1,7 +1,7 @@
 // paste_masks_in_image: rasterise N soft masks (e.g. 28x28) into N full-image binary masks.
 // Replaces detectron2/layers/mask_ops.py:17-147 (grid build + F.grid_sample + threshold +
-// index_put) with a zero fill + ONE kernel over the box regions: no fp32 grid tensor (8 B/px), no fp32
-// sampled image (4 B/px) -- only the compulsory 1 B/px output is written.
+// index_put) with ONE kernel that writes every output byte once (box regions sampled, the rest zeros): no fp32 grid
+// tensor (8 B/px), no fp32 sampled image (4 B/px), no separate zero fill -- only the compulsory 1 B/px output.
 // Bit-exact vs the reference's CPU path: same region rule (skip_empty=True, one mask per chunk,
 // mask_ops.py:38-43,116-119) and the same fp32 evaluation order as ATen's CPU grid_sampler
 // (see oracle/d2_oracle.c, orc_paste_sample).  Compiled with FP contraction off; the FMAs
@@ -18,10 +18,24 @@ constexpr int PASTE_ROWS = 8;  // image rows per workgroup: 8 rows x 32 column l
 // N x H x W pixels).  The first version gave every thread 16 consecutive pixels of the flattened image: a wave
 // whose 1,024 pixels touched a box row evaluated the sampling path for all 16 of its iterations while the lanes
 // outside the box columns idled -- 36 of its 55 us (zero fill alone: 18 us, profiles/r01/v8_paste_bench.txt).
-// Now: (1) the whole output is zero-filled (hipMemsetAsync: 15 us for 107 MB, the writes land in the 256 MB
-// Infinity Cache), (2) this kernel visits only the box REGIONS, densely: workgroup = 8 image rows of one mask,
-// lane = (row, column mod 32), the row terms (gy, iy, row weights) once per thread, then a walk over the
-// region's columns.  Same fp32 evaluation order as before (bit-exact vs ATen's CPU grid_sampler).
+// r01-r03: (1) the whole output zero-filled (15 us for 107 MB), (2) this kernel over the box REGIONS only, densely:
+// workgroup = 8 image rows of one mask, lane = (row, column mod 32), the row terms (gy, iy, row weights) once per
+// thread, then a walk over the region's columns: 28.6 us per image of 100 detections = 0.47 of the HBM peak, the
+// region pixels written twice.  r04: the same workgroups also write the zeros of their rows (paste_zero_span) -- one
+// launch, every byte once.  Same fp32 evaluation order as before (bit-exact vs ATen's CPU grid_sampler).
+// zero `n` bytes at `p` with the 32 lanes of one image row's half-wave: single bytes up to the first 16-B boundary,
+// 16-B stores, single bytes behind the last one (rows are img_w bytes apart: any alignment)
+__device__ __forceinline__ void paste_zero_span(uint8_t* p, int n, int lane32) {
+  if (n <= 0) return;
+  const int head = min(n, (int)((16u - (unsigned)(reinterpret_cast<uintptr_t>(p) & 15u)) & 15u));
+  if (lane32 < head) p[lane32] = 0;
+  const int body = (n - head) >> 4;
+  uint4* q = reinterpret_cast<uint4*>(p + head);
+  for (int i = lane32; i < body; i += 32) q[i] = make_uint4(0u, 0u, 0u, 0u);
+  const int done = head + (body << 4);
+  if (lane32 < n - done) p[done + lane32] = 0;
+}
+
 template <typename T>
 __global__ __launch_bounds__(PASTE_BLOCK) void paste_region_kernel(
     const T* __restrict__ masks, const float* __restrict__ boxes, int mh, int mw, int img_h, int img_w,
@@ -45,11 +59,24 @@ __global__ __launch_bounds__(PASTE_BLOCK) void paste_region_kernel(
   fy1 = fy1 > (float)img_h ? (float)img_h : fy1;
   const int rx0 = (int)fx0, ry0 = (int)fy0, rx1 = (int)fx1, ry1 = (int)fy1;
   const int row0 = blockIdx.x * PASTE_ROWS;
-  if (row0 >= ry1 || row0 + PASTE_ROWS <= ry0 || rx1 <= rx0) return;  // uniform: no region pixel in these rows
-  for (int i = threadIdx.x; i < mh * mw; i += PASTE_BLOCK) smask[i] = to_f32(masks[(long)n * mh * mw + i]);
-  __syncthreads();
-  const int py = row0 + (threadIdx.x >> 5);
-  if (py < ry0 || py >= ry1) return;
+  const bool has_region = !(row0 >= ry1 || row0 + PASTE_ROWS <= ry0 || rx1 <= rx0);  // uniform
+  if (has_region) {
+    for (int i = threadIdx.x; i < mh * mw; i += PASTE_BLOCK) smask[i] = to_f32(masks[(long)n * mh * mw + i]);
+    __syncthreads();
+  }
+  // EVERY output byte is written exactly once, by this launch: the region's pixels by the sampling walk below,
+  // everything else of the row as zeros (16-B stores) -- there is no separate zero fill of the 107 MB any more
+  const int py = row0 + (threadIdx.x >> 5), lane32 = threadIdx.x & 31;
+  if (py >= img_h) return;
+  {
+    uint8_t* zrow = out + ((long)n * img_h + py) * img_w;
+    if (!has_region || py < ry0 || py >= ry1) {
+      paste_zero_span(zrow, img_w, lane32);
+      return;
+    }
+    paste_zero_span(zrow, rx0, lane32);
+    paste_zero_span(zrow + rx1, img_w - rx1, lane32);
+  }
   const float sx = (float)mw / 2.f, sy = (float)mh / 2.f;
   const float dxw = x1 - x0, dyh = y1 - y0;
   const float gy = ((float)py + 0.5f - y0) / dyh * 2.f - 1.f;
@@ -87,8 +114,7 @@ template <typename T>
 static int launch_paste(const void* masks, const float* boxes, int n, int mh, int mw, int img_h, int img_w,
                         float threshold, uint8_t* out, hipStream_t s) {
   const size_t lds = (size_t)mh * mw * sizeof(float);
-  const bool timed = timing_begin("paste_masks", s);  // (the whole op: zero fill + region kernel)
-  { const int zrc = zero_async(out, (size_t)n * img_h * img_w, s); if (zrc) return zrc; }
+  const bool timed = timing_begin("paste_masks", s);
   dim3 grid(cdiv(img_h, PASTE_ROWS), n);
   hipLaunchKernelGGL((paste_region_kernel<T>), grid, dim3(PASTE_BLOCK), lds, s, (const T*)masks, boxes, mh, mw, img_h,
                      img_w, threshold, out);

@@ -363,8 +363,9 @@ def test_saved_column_weight_gradient(dtype, B, C, Co, H, W):
         assert _C.lib().d2amd_deform_conv_columns_bytes(ctypes.byref(p)) == 0
         c = run_gpu(*case)
     assert rel_err(a["grad_weight"], c["grad_weight"]) < TOL[dtype] / 4
-    for k in ("out", "grad_input", "grad_offset", "grad_mask"):
-        assert np.array_equal(a[k], c[k]), k  # nothing else changes
+    assert np.array_equal(a["out"], c["out"])  # nothing else changes (small maps split the channel chunks of the data
+    for k in ("grad_input", "grad_offset", "grad_mask"):  # gradient over workgroups that add with atomics: run-to-run rounding)
+        assert rel_err(a[k], c[k]) < TOL[dtype] / 4, k
     exp = run_oracle(*case)
     assert rel_err(a["grad_weight"], exp["grad_weight"]) < TOL[dtype]
 
