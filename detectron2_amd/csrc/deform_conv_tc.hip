@@ -851,14 +851,24 @@ __global__ __launch_bounds__(256) void tc_pack_weight_t_kernel(const T* __restri
 
 constexpr int BW_CPITCH = 68;  // floats per position row of the dcol tile (16-B aligned rows, spread banks)
 
-template <typename T>
+// r04 -- a stage used to be a chain of exposed latencies (5 us per (64-channel chunk, tap) stage, 18 stages per res3
+// workgroup, two workgroups per CU): offset / mask loads -> table -> MFMA operand loads -> MFMAs -> LDS meet -> corner
+// gathers of phase A -> VALU -> barrier.  Now (a) the tables of ALL taps are built once per workgroup into LDS (they do
+// not depend on the channel chunk: the offset / mask round trip left the stage loop); (b) the 4 corner gathers of phase A
+// are issued at the TOP of the stage from the thread's own table entry (thread = (position, corner) in both places), so
+// they fly under the MFMA section; (c) KHT > 0 (one conv group, Cog / 32 = KHT in {4, 8}): the wave's dY fragments --
+// the same for every stage of the workgroup -- are loaded once and stay in registers.
+// DCOL: the column-gather mode (a.dcol set, a.gx null: no phase B).  A separate instantiation because phase B's unrolled
+// pair walk keeps ~64 loop-invariant LDS addresses in VGPRs (scripts/vgpr_liveness.py): in the one-kernel version they
+// put BOTH modes at the 256-VGPR cap.
+template <typename T, int KHT, bool DCOL>
 __global__ __launch_bounds__(256, 2) void dcn_bwd_data_tc_kernel(DcnShape s, BwArgs a) {
   typedef Mma<T> M;
   extern __shared__ __attribute__((aligned(16))) unsigned char bw_smem[];
-  __shared__ __attribute__((aligned(16))) BwEntry ent[64];
   __shared__ __attribute__((aligned(8))) BwPair pairs[256];
   __shared__ __attribute__((aligned(16))) float Cs[64 * BW_CPITCH];
   float* red = reinterpret_cast<float*>(bw_smem);  // [K2][64][3]
+  BwEntry* ent_all = reinterpret_cast<BwEntry*>(bw_smem + (((size_t)s.K2 * 64 * 3 * 4 + 15) & ~(size_t)15));  // [K2][64]
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int per_xcd = (a.total + 7) >> 3;
@@ -892,15 +902,9 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_tc_kernel(DcnShape s, BwA
   const bool validE = hoE < s.Ho && woE < s.Wo;
   const int lE = hoE * s.Wo + woE;
 
-  const int nchunk = s.cpg >> 6;
-  const int c_lo = dgi * s.cpg + 64 * (int)((long)cz * nchunk / a.csplit);
-  const int c_hi = dgi * s.cpg + 64 * (int)((long)(cz + 1) * nchunk / a.csplit);
-  for (int cabs = c_lo; cabs < c_hi; cabs += 64) {
-    const int g = cabs / s.Cg, c64 = (cabs - g * s.Cg) >> 6;
-    for (int tap = 0; tap < s.K2; tap++) {
-      // ---- (1) tables of this tap: every thread evaluates the sample of its position (4 threads per
-      //          position, one per corner), writes its pair record; corner 0 also writes the entry
-      {
+  // ---- (0) tables of every tap, once: thread (position nE, corner cE) evaluates the sample of its position; the
+  //          corner-0 thread writes the entry
+  for (int tap = 0; tap < s.K2; tap++) {
         BwEntry e;
 #pragma unroll
         for (int t = 0; t < 4; t++) { e.pix[t] = 0u; e.w[t] = 0.f; }
@@ -926,10 +930,48 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_tc_kernel(DcnShape s, BwA
             if (h_high <= s.H - 1 && w_high <= s.W - 1) { e.pix[3] = (uint32_t)((rowbase + h_high) * s.W + w_high); e.w[3] = lh * lw; e.flags |= 8u; }
           }
         }
-        if (cE == 0) ent[nE] = e;
+        if (cE == 0) ent_all[tap * 64 + nE] = e;
+  }
+  __syncthreads();  // (also orders the zeroing of `red` above against its first use)
+
+  const bool doA = (a.goff || a.gmask) && !(a.ablate & 2);  // uniform
+  const raw16 zero = {0u, 0u, 0u, 0u};
+  // (c) the wave's dY fragments (B operand: its 32 positions x its K half), loaded once
+  raw16 bh[KHT > 0 ? KHT : 1];
+  if constexpr (KHT > 0) {
+    const T* gsrc0 = gout + pB * s.Co + (lane >> 5) * 8 + khalf * KHT * 16;
+#pragma unroll
+    for (int u = 0; u < KHT; u++) bh[u] = validB ? *reinterpret_cast<const raw16*>(gsrc0 + u * 16) : zero;
+  }
+
+  const int nchunk = s.cpg >> 6;
+  const int c_lo = dgi * s.cpg + 64 * (int)((long)cz * nchunk / a.csplit);
+  const int c_hi = dgi * s.cpg + 64 * (int)((long)(cz + 1) * nchunk / a.csplit);
+  for (int cabs = c_lo; cabs < c_hi; cabs += 64) {
+    const int g = cabs / s.Cg, c64 = (cabs - g * s.Cg) >> 6;
+    for (int tap = 0; tap < s.K2; tap++) {
+      // ---- (1) this thread's table entry (its own position nE; corner cE for the pair record of phase B), and the
+      //          corner gathers of phase A, issued now
+      const BwEntry e = ent_all[tap * 64 + nE];
+      if (!DCOL && a.gx) {
         const float wsel = cE == 0 ? e.w[0] : cE == 1 ? e.w[1] : cE == 2 ? e.w[2] : e.w[3];
         const uint32_t psel = cE == 0 ? e.pix[0] : cE == 1 ? e.pix[1] : cE == 2 ? e.pix[2] : e.pix[3];
         pairs[tid] = BwPair{wsel * e.m, psel * (uint32_t)s.C};
+      }
+      raw16 raw[2][4];
+      const bool gatherA = doA && (e.flags & 16u);
+      auto issue_gather = [&](int h) __attribute__((always_inline)) {
+        const uint32_t cofs = (uint32_t)(cabs + (cE + 4 * h) * 8) * (uint32_t)sizeof(T);
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+          raw[h][c] = *reinterpret_cast<const raw16*>(xb + ((size_t)e.pix[c] * pixbytes + cofs));
+      };
+      // (both 8-channel halves up front when the registers allow -- KHT == 4: 256 VGPRs, no spill --, otherwise the
+      // second half behind the MFMA section, where the weight fragments are dead)
+      constexpr bool EARLY_BOTH = DCOL && KHT == 4;
+      if (DCOL && gatherA) {  // (the atomics mode sits at its register cap: it gathers where it always did, in phase A)
+        issue_gather(0);
+        if (EARLY_BOTH) issue_gather(1);
       }
       // ---- (2) dcol tile by MFMA: rows = the 64 channels of the chunk (2 M-tiles), cols = this wave's 32
       //          positions, K = this wave half's share of the group's output channels
@@ -941,8 +983,30 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_tc_kernel(DcnShape s, BwA
       if (!(a.ablate & 1)) {
         const raw16* wsrc = wp + ((((size_t)g * s.K2 + tap) * (s.Cg >> 6) + c64) * 2 * KS) * 64 + lane;
         const T* gsrc = gout + pB * s.Co + (long)g * s.Cog + (lane >> 5) * 8;
-        const raw16 zero = {0u, 0u, 0u, 0u};
         constexpr int KB = 2;
+        if constexpr (KHT > 0) {
+          // weights in groups of KB k-steps, one group ahead; dY from the registers; fully unrolled (static indices)
+          raw16 aw[2][2][KB];
+          const int kw0 = khalf * KHT;
+          auto ldA = [&](int i, raw16 (&A)[2][KB]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < KB; u++) {
+              A[0][u] = wsrc[(size_t)(kw0 + i + u) * 64];
+              A[1][u] = wsrc[(size_t)(KS + kw0 + i + u) * 64];
+            }
+          };
+          ldA(0, aw[0]);
+#pragma unroll
+          for (int i = 0; i < KHT; i += KB) {
+            if (i + KB < KHT) ldA(i + KB, aw[((i / KB) + 1) & 1]);
+#pragma unroll
+            for (int u = 0; u < KB; u++) {
+              const typename M::frag bq = __builtin_bit_cast(typename M::frag, bh[i + u]);
+              acc[0] = M::mma(__builtin_bit_cast(typename M::frag, aw[(i / KB) & 1][0][u]), bq, acc[0]);
+              acc[1] = M::mma(__builtin_bit_cast(typename M::frag, aw[(i / KB) & 1][1][u]), bq, acc[1]);
+            }
+          }
+        } else {
         raw16 af[2][2][KB], bf[2][KB];
         auto ld = [&](int k0, raw16 (&A)[2][KB], raw16 (&Bq)[KB]) __attribute__((always_inline)) {
 #pragma unroll
@@ -972,7 +1036,9 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_tc_kernel(DcnShape s, BwA
             mm(k0 + KB, k_hi, af[1], bf[1]);
           }
         }
+        }
       }
+      if (DCOL && !EARLY_BOTH && gatherA) issue_gather(1);
       // ---- (3) the two K halves meet in LDS: Cs[position][channel]
       if (khalf == 0) {
 #pragma unroll
@@ -996,7 +1062,7 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_tc_kernel(DcnShape s, BwA
       }
       __syncthreads();
       // ---- (3b) column-gather path: the dcol tile leaves as 16-bit rows col[position][tap][channel chunk] (128 B each)
-      if (a.dcol) {
+      if (DCOL) {
         const int n = tid >> 2, q = tid & 3;  // position, 16-channel quarter of the chunk
         const int ho = ty * 8 + (n >> 3), wo = tx * 8 + (n & 7);
         if (ho < s.Ho && wo < s.Wo) {
@@ -1016,20 +1082,12 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_tc_kernel(DcnShape s, BwA
         }
       }
       // ---- (4) phase A: d(offset), d(mask).  thread = (position n, channels q*8.. and (q+4)*8..)
-      if ((a.goff || a.gmask) && !(a.ablate & 2)) {
-        const int n = tid >> 2, q = tid & 3;
-        const BwEntry& e = ent[n];
+      if (doA) {
+        const int n = nE, q = cE;  // (the thread that issued the gathers above)
         const uint32_t flags = e.flags;
         float s_h = 0.f, s_w = 0.f, s_m = 0.f;
         if (flags & 16u) {
-          raw16 raw[2][4];
-#pragma unroll
-          for (int h = 0; h < 2; h++) {
-            const uint32_t cofs = (uint32_t)(cabs + (q + 4 * h) * 8) * (uint32_t)sizeof(T);
-#pragma unroll
-            for (int c = 0; c < 4; c++)
-              raw[h][c] = *reinterpret_cast<const raw16*>(xb + ((size_t)e.pix[c] * pixbytes + cofs));
-          }
+          if (!DCOL) { issue_gather(0); issue_gather(1); }
           const float lh = e.lh, lw = e.lw, hh = 1.f - lh, hw = 1.f - lw, m = e.m;
           const float w0 = e.w[0], w1 = e.w[1], w2 = e.w[2], w3 = e.w[3];
 #pragma unroll
@@ -1066,7 +1124,7 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_tc_kernel(DcnShape s, BwA
         }
       }
       // ---- (5) phase B: dX.  wave instruction = one (position, corner) pair x 64 channels
-      if (a.gx && !(a.ablate & 4)) {
+      if (!DCOL && a.gx && !(a.ablate & 4)) {
         float* gxc = a.gx + cabs + lane;
         constexpr int UB = 8;
         for (int it0 = 0; it0 < 64; it0 += UB) {
@@ -1374,6 +1432,25 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_patch_kernel(DcnShape s, 
   }
 }
 
+// KHT instantiation by shape: the dY fragments stay in registers for one conv group and Cog / 32 in {4, 8}
+template <typename T>
+static int launch_bwd_data_tc(const DcnShape& s, const BwArgs& a, int grid, size_t lds, hipStream_t st) {
+  const int KH = s.Cog / 32;
+  const bool hoist = s.G == 1 && getenv("D2AMD_DCN_BWD_NO_HOIST") == nullptr;
+  auto launch = [&](auto kern) -> int {
+    if (lds > 48 * 1024)
+      D2_HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, s, a);
+    return D2AMD_OK;
+  };
+  if (a.dcol) {
+    if (hoist && KH == 4) return launch(dcn_bwd_data_tc_kernel<T, 4, true>);
+    if (hoist && KH == 8) return launch(dcn_bwd_data_tc_kernel<T, 8, true>);
+    return launch(dcn_bwd_data_tc_kernel<T, 0, true>);
+  }
+  return launch(dcn_bwd_data_tc_kernel<T, 0, false>);
+}
+
 TcBwPlan dcn_tc_plan_bwd(const DcnShape& s, int dtype) {
   TcBwPlan pl{};
   pl.ok = false;
@@ -1391,7 +1468,7 @@ TcBwPlan dcn_tc_plan_bwd(const DcnShape& s, int dtype) {
     if (e && atoi(e) >= 1) cs = atoi(e) < nchunk ? atoi(e) : nchunk;
     pl.csplit = cs;
   }
-  pl.lds = (size_t)s.K2 * 64 * 3 * 4;
+  pl.lds = (((size_t)s.K2 * 64 * 3 * 4 + 15) & ~(size_t)15) + (size_t)s.K2 * 64 * sizeof(BwEntry);  // red + the tables of all taps
   pl.wp_bytes = (size_t)s.Co * s.Cg * s.K2 * 2;
   // column-gather dX (no atomics): one deformable group, C = 64 * {1, 2, 4, 8}, sample ids fit 32 bits
   pl.gather = s.DG == 1 && (s.C == 64 || s.C == 128 || s.C == 256 || s.C == 512) && (long)s.P * s.K2 < (1l << 31) &&
@@ -1640,7 +1717,7 @@ int dcn_tc_backward_data_gather(const DcnShape& s, const TcBwPlan& pl, const voi
   D2_CHECK_ARG(total < (1l << 30), "deform_conv: too many tiles");
   a.total = (int)total;
   const bool timed = timing_begin("dcn_bwd_data", st);
-  hipLaunchKernelGGL((dcn_bwd_data_tc_kernel<T>), dim3((a.total + 7) / 8 * 8), dim3(256), pl.lds, st, s, a);
+  { const int lrc = launch_bwd_data_tc<T>(s, a, (a.total + 7) / 8 * 8, pl.lds, st); if (lrc) return lrc; }
   if (timed) timing_end("dcn_bwd_data", st);
   D2_LAUNCH_OK();
   if (gx_t) {
@@ -1712,7 +1789,7 @@ int dcn_tc_backward_data(const DcnShape& s, const TcBwPlan& pl, const void* x_nh
   a.total = (int)total;
   const int grid = (a.total + 7) / 8 * 8;
   const bool timed = timing_begin("dcn_bwd_data", st);
-  hipLaunchKernelGGL((dcn_bwd_data_tc_kernel<T>), dim3(grid), dim3(256), pl.lds, st, s, a);
+  { const int lrc = launch_bwd_data_tc<T>(s, a, grid, pl.lds, st); if (lrc) return lrc; }
   if (timed) timing_end("dcn_bwd_data", st);
   D2_LAUNCH_OK();
   return D2AMD_OK;
