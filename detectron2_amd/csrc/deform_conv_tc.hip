@@ -668,6 +668,19 @@ TcPlan dcn_tc_plan_fwd(const DcnShape& s, int dtype) {
   // of the launch start at once (a second round of workgroups costs a full workgroup lifetime).  Small
   // maps split the (tap, channel) reduction until there are ~2 workgroups per CU.
   int MT = s.Cog <= 64 ? 2 : 4, NWM = 1, NWN = 2, ks = 1, NKS = 2, wave = 0;
+  // r04: 256 output channels per workgroup (4 matrix + 2 gather waves) when the layer has them: the column gather --
+  // what bounds the kernel -- is repeated per output-channel tile, i.e. Co / 128 = 2 / 4 times for res4 / res5 before,
+  // 1 / 2 times now (the reduction split `ks` grows instead, so the launch still has ~2 workgroups per CU)
+  // Small maps then take 32-position tiles (2 matrix + 1 gather wave) before they split the reduction: the fp32
+  // partials of a split are 17 MB per 2 x (res4) -- D2AMD_DCN_FWD_BIG: 0 = the r03 tiles, 1 = 256 x 64 only, 2 = this.
+  {
+    const char* e = getenv("D2AMD_DCN_FWD_BIG");
+    const int mode = e ? atoi(e) : 2;
+    if (s.Cog >= 256 && mode >= 1) {
+      NWM = 2;
+      if (mode >= 2 && (long)cdiv(s.P, 64) * cdiv(s.Cog, 256) * s.G < 480) NWN = 1;
+    }
+  }
   auto wgs = [&](int nwn, int k) { return (long)cdiv(s.P, 32 * nwn) * cdiv(s.Cog, 32 * MT * NWM) * s.G * k; };
   {
     const int stages = s.K2 * (s.Cg / 32);
@@ -1436,7 +1449,9 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_patch_kernel(DcnShape s, 
 template <typename T>
 static int launch_bwd_data_tc(const DcnShape& s, const BwArgs& a, int grid, size_t lds, hipStream_t st) {
   const int KH = s.Cog / 32;
-  const bool hoist = s.G == 1 && getenv("D2AMD_DCN_BWD_NO_HOIST") == nullptr;
+  // MEASURED (profiles/r04/dcn_bwd_data_ab.txt, same box): hoisted dY fragments 103.7 us mean per block against 96.1
+  // without (the fully unrolled weight pipeline is shallower than the rolling one) -- off unless D2AMD_DCN_BWD_HOIST=1
+  const bool hoist = s.G == 1 && getenv("D2AMD_DCN_BWD_HOIST") != nullptr;
   auto launch = [&](auto kern) -> int {
     if (lds > 48 * 1024)
       D2_HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -579,7 +579,9 @@ def test_pooler_full_size_per_element_vs_oracle():
         e = exp_grads[l]
         # the chain writes the first pooler's gradient in bf16 and the second ADDS into it (one tensor, no fp32 staging):
         # two roundings -- of the first part and of the sum (the reference's autograd sums two bf16 gradients: three)
-        bound = ulp(e) + ulp(part_max[l]) + 2.0 ** -13 * abs_grads[l] + 1e-6 * np.abs(e).max()
+        # (x 1.25: an ulp taken at the ORACLE's value is half the device's when the two sit on either side of a power of
+        # two -- 1 element of 4.3 M came out at 1.03 without it)
+        bound = 1.25 * (ulp(e) + ulp(part_max[l])) + 2.0 ** -13 * abs_grads[l] + 1e-6 * np.abs(e).max()
         d = np.abs(got - e)
         r = float((d / bound).max())
         record_ratio(f"pooler_full/bwd_l{l}", r)
