@@ -668,14 +668,15 @@ TcPlan dcn_tc_plan_fwd(const DcnShape& s, int dtype) {
   // of the launch start at once (a second round of workgroups costs a full workgroup lifetime).  Small
   // maps split the (tap, channel) reduction until there are ~2 workgroups per CU.
   int MT = s.Cog <= 64 ? 2 : 4, NWM = 1, NWN = 2, ks = 1, NKS = 2, wave = 0;
-  // r04: 256 output channels per workgroup (4 matrix + 2 gather waves) when the layer has them: the column gather --
-  // what bounds the kernel -- is repeated per output-channel tile, i.e. Co / 128 = 2 / 4 times for res4 / res5 before,
-  // 1 / 2 times now (the reduction split `ks` grows instead, so the launch still has ~2 workgroups per CU)
-  // Small maps then take 32-position tiles (2 matrix + 1 gather wave) before they split the reduction: the fp32
-  // partials of a split are 17 MB per 2 x (res4) -- D2AMD_DCN_FWD_BIG: 0 = the r03 tiles, 1 = 256 x 64 only, 2 = this.
+  // r04 experiment, MEASURED SLOWER and off (profiles/r04/dcn_fwd_tiles_ab.txt): 256 output channels per workgroup when
+  // the layer has them, so that the column gather is repeated Co / 256 instead of Co / 128 times (res4 2 -> 1, res5 4 ->
+  // 2), with 32-position tiles on small maps (mode 2) or a deeper reduction split (mode 1).  res4 forward 71 -> 95 /
+  // 100 us per block, res5 76 -> 99 / 103: the kernel is bound by how many GATHER WAVES are in flight per CU (their
+  // chains of L2 round trips), not by the number of gathered elements -- halving the workgroups halves those waves.
+  // D2AMD_DCN_FWD_BIG = 1 / 2 selects the variants.
   {
     const char* e = getenv("D2AMD_DCN_FWD_BIG");
-    const int mode = e ? atoi(e) : 2;
+    const int mode = e ? atoi(e) : 0;
     if (s.Cog >= 256 && mode >= 1) {
       NWM = 2;
       if (mode >= 2 && (long)cdiv(s.P, 64) * cdiv(s.Cog, 256) * s.G < 480) NWN = 1;
@@ -1187,6 +1188,246 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_tc_kernel(DcnShape s, BwA
   }
 }
 
+// ---- backward data, column-gather mode, WAVE-SPECIALISED (r04) ------------------------------------------------
+// Same mathematics and the same stage = (64-channel chunk, tap) as dcn_bwd_data_tc_kernel<.., DCOL = true>, but the
+// two halves of a stage run CONCURRENTLY on different waves of the workgroup, one barrier per stage:
+//   matrix waves 0, 1     dcol[64 channels][32 positions each] = W^T[tap, chunk] dY over the FULL K = Cog (no K halves
+//                         meeting in LDS), written as fp32 into Cs[stage & 1];
+//   consumer waves 2..5   stage - 1: the tile leaves as 16-bit column rows (what dcn_gather_dx_kernel reads) and phase A
+//                         -- corner gathers of x, bilinear value and coordinate derivatives, d(offset) / d(mask)
+//                         reduced over channels -- runs on Cs[(stage - 1) & 1]; the corner gathers of the NEXT half
+//                         stage are in flight while the current one is combined (register double buffer).
+// The one-wave-does-everything kernel is a chain of four barriers per stage with two waves per SIMD (5.5 us per stage
+// measured, 1.6 us of it instruction issue: profiles/r04/dcn_bwd_data_ab.txt); moving loads earlier inside a wave does
+// not help, because a wave's s_waitcnt retires its loads in order.  Here the matrix pipe, the L2 round trips of both
+// sides and the VALU of phase A overlap by construction, as in the forward kernel.
+// Tables of all taps are built once per workgroup (they do not depend on the channel chunk).
+template <typename T>
+__global__ __launch_bounds__(384) void dcn_bwd_data_ws_kernel(DcnShape s, BwArgs a) {
+  typedef Mma<T> M;
+  extern __shared__ __attribute__((aligned(16))) unsigned char bw_smem[];
+  float* red = reinterpret_cast<float*>(bw_smem);  // [K2][64][3]
+  const size_t red_bytes = ((size_t)s.K2 * 64 * 3 * 4 + 15) & ~(size_t)15;
+  BwEntry* ent_all = reinterpret_cast<BwEntry*>(bw_smem + red_bytes);  // [K2][64]
+  float* Cs2 = reinterpret_cast<float*>(bw_smem + red_bytes + (size_t)s.K2 * 64 * sizeof(BwEntry));  // [2][64 * BW_CPITCH]
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int per_xcd = (a.total + 7) >> 3;
+  const int logical = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if (logical >= a.total) return;
+  const int cz = logical % a.csplit;
+  int tile = logical / a.csplit;
+  const int dgi = tile % s.DG; tile /= s.DG;
+  const int tx = tile % a.tiles_x; tile /= a.tiles_x;
+  const int ty = tile % a.tiles_y;
+  const int b = tile / a.tiles_y;
+
+  for (int i = tid; i < s.K2 * 64 * 3; i += 384) red[i] = 0.f;
+  const T* offset = (const T*)a.offset;
+  const T* mask = (const T*)a.mask;
+  // ---- tables of every tap, once (deform_conv_cuda_kernel.cu:785-860): entry (tap, position) by thread tap * 64 + n
+  for (int i = tid; i < s.K2 * 64; i += 384) {
+    const int tap = i >> 6, n = i & 63;
+    const int ho = ty * 8 + (n >> 3), wo = tx * 8 + (n & 7);
+    BwEntry e;
+#pragma unroll
+    for (int t = 0; t < 4; t++) { e.pix[t] = 0u; e.w[t] = 0.f; }
+    e.lh = e.lw = 0.f; e.m = 0.f; e.flags = 0u;
+    if (ho < s.Ho && wo < s.Wo) {
+      const int l = ho * s.Wo + wo;
+      const int ki = tap / s.kw, kj = tap - ki * s.kw;
+      const long obase = ((long)b * s.DG + dgi) * 2 * s.K2;
+      const float off_h = to_f32(offset[(obase + 2 * tap) * s.L + l]);
+      const float off_w = to_f32(offset[(obase + 2 * tap + 1) * s.L + l]);
+      e.m = mask ? to_f32(mask[(((long)b * s.DG + dgi) * s.K2 + tap) * s.L + l]) : 1.f;
+      const float h_im = (float)(ho * s.sh - s.ph + ki * s.dh) + off_h;
+      const float w_im = (float)(wo * s.sw - s.pw + kj * s.dw) + off_w;
+      if (h_im > -1.f && w_im > -1.f && h_im < (float)s.H && w_im < (float)s.W) {
+        const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+        const int h_high = h_low + 1, w_high = w_low + 1;
+        const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+        const float hh = 1.f - lh, hw = 1.f - lw;
+        e.lh = lh; e.lw = lw; e.flags = 16u;
+        const long rowbase = (long)b * s.H;
+        if (h_low >= 0 && w_low >= 0) { e.pix[0] = (uint32_t)((rowbase + h_low) * s.W + w_low); e.w[0] = hh * hw; e.flags |= 1u; }
+        if (h_low >= 0 && w_high <= s.W - 1) { e.pix[1] = (uint32_t)((rowbase + h_low) * s.W + w_high); e.w[1] = hh * lw; e.flags |= 2u; }
+        if (h_high <= s.H - 1 && w_low >= 0) { e.pix[2] = (uint32_t)((rowbase + h_high) * s.W + w_low); e.w[2] = lh * hw; e.flags |= 4u; }
+        if (h_high <= s.H - 1 && w_high <= s.W - 1) { e.pix[3] = (uint32_t)((rowbase + h_high) * s.W + w_high); e.w[3] = lh * lw; e.flags |= 8u; }
+      }
+    }
+    ent_all[i] = e;
+  }
+  __syncthreads();
+
+  const int nchunk = s.cpg >> 6;
+  const int c_lo = dgi * s.cpg + 64 * (int)((long)cz * nchunk / a.csplit);
+  const int c_hi = dgi * s.cpg + 64 * (int)((long)(cz + 1) * nchunk / a.csplit);
+  const int nst = ((c_hi - c_lo) >> 6) * s.K2;  // stages of this workgroup: (chunk, tap), tap fastest
+  const int KS = s.Cog / 16;
+
+  if (wid < 2) {
+    // ================================ MATRIX waves ====================================================
+    const T* gout = (const T*)a.gout;
+    const raw16* wp = (const raw16*)a.wp;
+    const int nB = wid * 32 + (lane & 31);
+    const int hoB = ty * 8 + (nB >> 3), woB = tx * 8 + (nB & 7);
+    const bool validB = hoB < s.Ho && woB < s.Wo;
+    const long pB = ((long)b * s.Ho + hoB) * s.Wo + woB;
+    const raw16 zero = {0u, 0u, 0u, 0u};
+    for (int st = 0; st < nst; st++) {
+      const int cabs = c_lo + 64 * (st / s.K2), tap = st % s.K2;
+      const int g = cabs / s.Cg, c64 = (cabs - g * s.Cg) >> 6;
+      f32x16_t acc[2];
+#pragma unroll
+      for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[m][r] = 0.f;
+      const raw16* wsrc = wp + ((((size_t)g * s.K2 + tap) * (s.Cg >> 6) + c64) * 2 * KS) * 64 + lane;
+      const T* gsrc = gout + pB * s.Co + (long)g * s.Cog + (lane >> 5) * 8;
+      constexpr int KB = 2;
+      raw16 af[2][2][KB], bf[2][KB];
+      auto ld = [&](int k0, raw16 (&A)[2][KB], raw16 (&Bq)[KB]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < KB; u++) {
+          const int ks = min(k0 + u, KS - 1);
+          A[0][u] = wsrc[(size_t)ks * 64];
+          A[1][u] = wsrc[(size_t)(KS + ks) * 64];
+          Bq[u] = validB ? *reinterpret_cast<const raw16*>(gsrc + ks * 16) : zero;
+        }
+      };
+      auto mm = [&](int k0, const raw16 (&A)[2][KB], const raw16 (&Bq)[KB]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < KB; u++)
+          if (k0 + u < KS) {  // uniform
+            const typename M::frag bq = __builtin_bit_cast(typename M::frag, Bq[u]);
+            acc[0] = M::mma(__builtin_bit_cast(typename M::frag, A[0][u]), bq, acc[0]);
+            acc[1] = M::mma(__builtin_bit_cast(typename M::frag, A[1][u]), bq, acc[1]);
+          }
+      };
+      ld(0, af[0], bf[0]);
+      for (int k0 = 0; k0 < KS; k0 += 2 * KB) {
+        if (k0 + KB < KS) ld(k0 + KB, af[1], bf[1]);
+        mm(k0, af[0], bf[0]);
+        if (k0 + KB < KS) {
+          if (k0 + 2 * KB < KS) ld(k0 + 2 * KB, af[0], bf[0]);
+          mm(k0 + KB, af[1], bf[1]);
+        }
+      }
+      float* Cs = Cs2 + (st & 1) * (64 * BW_CPITCH);
+#pragma unroll
+      for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++)
+          *reinterpret_cast<float4*>(&Cs[nB * BW_CPITCH + 32 * m + 8 * rg + 4 * (lane >> 5)]) =
+              make_float4(acc[m][4 * rg], acc[m][4 * rg + 1], acc[m][4 * rg + 2], acc[m][4 * rg + 3]);
+      __syncthreads();  // barrier st: tile st is in Cs[st & 1]; the consumers are done with Cs[(st + 1) & 1]
+    }
+    __syncthreads();  // barrier nst: the consumers' last stage
+  } else {
+    // ================================ CONSUMER waves ==================================================
+    const int atid = tid - 128;
+    const int n = atid >> 2, q = atid & 3;  // position, channel slot: channels (q + 4 h) * 8 .. + 8 of the chunk, h = 0, 1
+    const int ho = ty * 8 + (n >> 3), wo = tx * 8 + (n & 7);
+    const bool valid = ho < s.Ho && wo < s.Wo;
+    const long pp = ((long)b * s.Ho + ho) * s.Wo + wo;
+    const char* xb = (const char*)a.x;
+    const uint32_t pixbytes = (uint32_t)s.C * (uint32_t)sizeof(T);
+    const bool doA = (a.goff || a.gmask) && !(a.ablate & 2);  // uniform
+    // half stages u = 2 st + h; the gathers of u + 1 fly while u is combined
+    raw16 raw[2][4];
+    auto issue = [&](int u, raw16 (&r)[4]) __attribute__((always_inline)) {
+      const int st = u >> 1, h = u & 1;
+      const int cabs = c_lo + 64 * (st / s.K2), tap = st % s.K2;
+      const uint4 px = *reinterpret_cast<const uint4*>(&ent_all[tap * 64 + n].pix[0]);
+      const uint32_t cofs = (uint32_t)(cabs + (q + 4 * h) * 8) * (uint32_t)sizeof(T);
+      r[0] = *reinterpret_cast<const raw16*>(xb + ((size_t)px.x * pixbytes + cofs));
+      r[1] = *reinterpret_cast<const raw16*>(xb + ((size_t)px.y * pixbytes + cofs));
+      r[2] = *reinterpret_cast<const raw16*>(xb + ((size_t)px.z * pixbytes + cofs));
+      r[3] = *reinterpret_cast<const raw16*>(xb + ((size_t)px.w * pixbytes + cofs));
+    };
+    if (doA && nst > 0) issue(0, raw[0]);
+    __syncthreads();  // barrier 0 (the matrix waves' stage 0)
+    for (int st = 0; st < nst; st++) {
+      const int cabs = c_lo + 64 * (st / s.K2), tap = st % s.K2;
+      const float* Cs = Cs2 + (st & 1) * (64 * BW_CPITCH);
+      // ---- the dcol tile leaves as 16-bit rows col[position][tap][channel chunk]: thread = (position, 16-channel quarter)
+      if (valid) {
+        const float* cp = &Cs[n * BW_CPITCH + 16 * q];
+        T* dst = (T*)a.dcol + (pp * s.K2 + tap) * s.C + cabs + 16 * q;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const float4 d0 = *reinterpret_cast<const float4*>(cp + 8 * h), d1 = *reinterpret_cast<const float4*>(cp + 8 * h + 4);
+          const float f[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+          *reinterpret_cast<raw16*>(dst + 8 * h) = tc_pack(f, T{});
+        }
+      }
+      // ---- phase A on the tile
+      if (doA) {
+        const BwEntry& e = ent_all[tap * 64 + n];
+        const uint32_t flags = e.flags;
+        const float lh = e.lh, lw = e.lw, hh = 1.f - lh, hw = 1.f - lw, m = e.m;
+        const float w0 = e.w[0], w1 = e.w[1], w2 = e.w[2], w3 = e.w[3];
+        float s_h = 0.f, s_w = 0.f, s_m = 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int u = 2 * st + h;
+          if (u + 1 < 2 * nst) issue(u + 1, raw[(h + 1) & 1]);  // (uniform; clamped table rows: always valid addresses)
+          if (flags & 16u) {
+            float v[4][8];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+              tc_unpack(raw[h][c], v[c], T{});
+              if (!(flags & (1u << c))) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) v[c][k] = 0.f;
+              }
+            }
+            const float* cp = &Cs[n * BW_CPITCH + (q + 4 * h) * 8];
+            const float4 d0 = *reinterpret_cast<const float4*>(cp);
+            const float4 d1 = *reinterpret_cast<const float4*>(cp + 4);
+            const float d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+              const float val = w0 * v[0][k] + w1 * v[1][k] + w2 * v[2][k] + w3 * v[3][k];
+              const float dvh = -hw * v[0][k] - lw * v[1][k] + hw * v[2][k] + lw * v[3][k];
+              const float dvw = -hh * v[0][k] + hh * v[1][k] - lh * v[2][k] + lh * v[3][k];
+              s_h += dvh * d[k] * m;
+              s_w += dvw * d[k] * m;
+              s_m += d[k] * val;
+            }
+          }
+        }
+        s_h += __shfl_xor(s_h, 1); s_w += __shfl_xor(s_w, 1); s_m += __shfl_xor(s_m, 1);
+        s_h += __shfl_xor(s_h, 2); s_w += __shfl_xor(s_w, 2); s_m += __shfl_xor(s_m, 2);
+        if (q == 0) {  // the only thread that touches red[tap][n]
+          float* rp = red + (tap * 64 + n) * 3;
+          rp[0] += s_h; rp[1] += s_w; rp[2] += s_m;
+        }
+      }
+      __syncthreads();  // barrier st + 1
+    }
+  }
+  // ---- d(offset) / d(mask): one owner per (tap, position) with csplit == 1 (plain stores), atomics otherwise
+  __syncthreads();
+  for (int i = tid; i < s.K2 * 64; i += 384) {
+    const int tap = i >> 6, n = i & 63;
+    const int ho = ty * 8 + (n >> 3), wo = tx * 8 + (n & 7);
+    if (ho >= s.Ho || wo >= s.Wo) continue;
+    const int l = ho * s.Wo + wo;
+    const float* rp = red + i * 3;
+    const long ob = ((long)b * s.DG + dgi) * 2 * s.K2;
+    float* ph = a.goff ? a.goff + (ob + 2 * tap) * s.L + l : nullptr;
+    float* pm = a.gmask ? a.gmask + (((long)b * s.DG + dgi) * s.K2 + tap) * s.L + l : nullptr;
+    if (a.csplit == 1) {
+      if (ph) { ph[0] = rp[0]; ph[s.L] = rp[1]; }
+      if (pm) pm[0] = rp[2];
+    } else {
+      if (ph) { atomicAdd(ph, rp[0]); atomicAdd(ph + s.L, rp[1]); }
+      if (pm) atomicAdd(pm, rp[2]);
+    }
+  }
+}
+
 // ---- backward data with an LDS-resident dX patch and conflict-free ownership --------------------------------
 // EXPERIMENT, not the default (see dcn_tc_plan_bwd): measured slower than the all-atomics kernel above.
 // Same stage structure as dcn_bwd_data_tc_kernel, 32-channel chunks.  dX contributions are not sent to global
@@ -1458,6 +1699,16 @@ static int launch_bwd_data_tc(const DcnShape& s, const BwArgs& a, int grid, size
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, s, a);
     return D2AMD_OK;
   };
+  if (a.dcol && getenv("D2AMD_DCN_BWD_WS0") == nullptr) {  // wave-specialised (default); D2AMD_DCN_BWD_WS0: the one-role kernel
+    const size_t lds_ws = lds + 2 * 64 * BW_CPITCH * sizeof(float);
+    if (lds_ws <= 160 * 1024) {
+      auto kern = dcn_bwd_data_ws_kernel<T>;
+      if (lds_ws > 48 * 1024)
+        D2_HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ws));
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(384), lds_ws, st, s, a);
+      return D2AMD_OK;
+    }
+  }
   if (a.dcol) {
     if (hoist && KH == 4) return launch(dcn_bwd_data_tc_kernel<T, 4, true>);
     if (hoist && KH == 8) return launch(dcn_bwd_data_tc_kernel<T, 8, true>);
