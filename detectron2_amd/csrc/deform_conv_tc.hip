@@ -1202,8 +1202,9 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_tc_kernel(DcnShape s, BwA
 // not help, because a wave's s_waitcnt retires its loads in order.  Here the matrix pipe, the L2 round trips of both
 // sides and the VALU of phase A overlap by construction, as in the forward kernel.
 // Tables of all taps are built once per workgroup (they do not depend on the channel chunk).
-template <typename T>
-__global__ __launch_bounds__(384) void dcn_bwd_data_ws_kernel(DcnShape s, BwArgs a) {
+// GK: k-steps per operand request of the matrix waves; Cog / 16 is a multiple of it (8 for Cog % 128 == 0, else 2).
+template <typename T, int GK>
+__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) void dcn_bwd_data_ws_kernel(DcnShape s, BwArgs a) {
   typedef Mma<T> M;
   extern __shared__ __attribute__((aligned(16))) unsigned char bw_smem[];
   float* red = reinterpret_cast<float*>(bw_smem);  // [K2][64][3]
@@ -1274,43 +1275,48 @@ __global__ __launch_bounds__(384) void dcn_bwd_data_ws_kernel(DcnShape s, BwArgs
     const bool validB = hoB < s.Ho && woB < s.Wo;
     const long pB = ((long)b * s.Ho + hoB) * s.Wo + woB;
     const raw16 zero = {0u, 0u, 0u, 0u};
-    for (int st = 0; st < nst; st++) {
+    // Operand fragments come straight from L2 (weights pre-packed in fragment order, dY as [position][Co]).  r04, first
+    // version: two k-steps in flight -> Cog / 32 DEPENDENT L2 round trips per stage; alone (consumers ablated) the matrix
+    // side took 48 of the kernel's 86 us (profiles/r04/dcn_bwd_data_ws_ablation.txt).  Now a group of GK = 8 k-steps (the
+    // whole stage for Cog = 128) is requested at once, and the next group -- of this stage or of the NEXT one -- is
+    // requested as soon as the MFMAs have consumed the registers, i.e. before the tile is written and the barrier is
+    // waited for: one exposed round trip per group, none at stage boundaries.
+    raw16 ga[2][GK], gb[GK];
+    const int ngrp = KS / GK;
+    auto issue_group = [&](int st, int kg) __attribute__((always_inline)) {
       const int cabs = c_lo + 64 * (st / s.K2), tap = st % s.K2;
       const int g = cabs / s.Cg, c64 = (cabs - g * s.Cg) >> 6;
+      const raw16* wsrc = wp + ((((size_t)g * s.K2 + tap) * (s.Cg >> 6) + c64) * 2 * KS) * 64 + lane;
+      const T* gsrc = gout + pB * s.Co + (long)g * s.Cog + (lane >> 5) * 8;
+      // (KS is a multiple of GK: no clamping, the addresses are base + constant -- base registers and immediate offsets
+      // instead of an address pair per load)
+      const raw16* w0 = wsrc + (size_t)(kg * GK) * 64;
+      const raw16* w1 = wsrc + (size_t)(KS + kg * GK) * 64;
+      const T* g0 = gsrc + kg * GK * 16;
+#pragma unroll
+      for (int u = 0; u < GK; u++) {
+        ga[0][u] = w0[u * 64];
+        ga[1][u] = w1[u * 64];
+        gb[u] = validB ? *reinterpret_cast<const raw16*>(g0 + u * 16) : zero;
+      }
+    };
+    if (!(a.ablate & 1)) issue_group(0, 0);
+    for (int st = 0; st < nst; st++) {
       f32x16_t acc[2];
 #pragma unroll
       for (int m = 0; m < 2; m++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[m][r] = 0.f;
-      const raw16* wsrc = wp + ((((size_t)g * s.K2 + tap) * (s.Cg >> 6) + c64) * 2 * KS) * 64 + lane;
-      const T* gsrc = gout + pB * s.Co + (long)g * s.Cog + (lane >> 5) * 8;
-      constexpr int KB = 2;
-      raw16 af[2][2][KB], bf[2][KB];
-      auto ld = [&](int k0, raw16 (&A)[2][KB], raw16 (&Bq)[KB]) __attribute__((always_inline)) {
+      if (!(a.ablate & 1)) {  // (profiling: D2AMD_DCN_ABLATE_BWD bit 0 = no operand loads / MFMAs)
+        for (int kg = 0; kg < ngrp; kg++) {
 #pragma unroll
-        for (int u = 0; u < KB; u++) {
-          const int ks = min(k0 + u, KS - 1);
-          A[0][u] = wsrc[(size_t)ks * 64];
-          A[1][u] = wsrc[(size_t)(KS + ks) * 64];
-          Bq[u] = validB ? *reinterpret_cast<const raw16*>(gsrc + ks * 16) : zero;
-        }
-      };
-      auto mm = [&](int k0, const raw16 (&A)[2][KB], const raw16 (&Bq)[KB]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int u = 0; u < KB; u++)
-          if (k0 + u < KS) {  // uniform
-            const typename M::frag bq = __builtin_bit_cast(typename M::frag, Bq[u]);
-            acc[0] = M::mma(__builtin_bit_cast(typename M::frag, A[0][u]), bq, acc[0]);
-            acc[1] = M::mma(__builtin_bit_cast(typename M::frag, A[1][u]), bq, acc[1]);
+          for (int u = 0; u < GK; u++) {
+            const typename M::frag bq = __builtin_bit_cast(typename M::frag, gb[u]);
+            acc[0] = M::mma(__builtin_bit_cast(typename M::frag, ga[0][u]), bq, acc[0]);
+            acc[1] = M::mma(__builtin_bit_cast(typename M::frag, ga[1][u]), bq, acc[1]);
           }
-      };
-      ld(0, af[0], bf[0]);
-      for (int k0 = 0; k0 < KS; k0 += 2 * KB) {
-        if (k0 + KB < KS) ld(k0 + KB, af[1], bf[1]);
-        mm(k0, af[0], bf[0]);
-        if (k0 + KB < KS) {
-          if (k0 + 2 * KB < KS) ld(k0 + 2 * KB, af[0], bf[0]);
-          mm(k0 + KB, af[1], bf[1]);
+          if (kg + 1 < ngrp) issue_group(st, kg + 1);
+          else if (st + 1 < nst) issue_group(st + 1, 0);
         }
       }
       float* Cs = Cs2 + (st & 1) * (64 * BW_CPITCH);
@@ -1351,7 +1357,7 @@ __global__ __launch_bounds__(384) void dcn_bwd_data_ws_kernel(DcnShape s, BwArgs
       const int cabs = c_lo + 64 * (st / s.K2), tap = st % s.K2;
       const float* Cs = Cs2 + (st & 1) * (64 * BW_CPITCH);
       // ---- the dcol tile leaves as 16-bit rows col[position][tap][channel chunk]: thread = (position, 16-channel quarter)
-      if (valid) {
+      if (valid && !(a.ablate & 8)) {  // (bit 3 = no column store)
         const float* cp = &Cs[n * BW_CPITCH + 16 * q];
         T* dst = (T*)a.dcol + (pp * s.K2 + tap) * s.C + cabs + 16 * q;
 #pragma unroll
@@ -1371,7 +1377,7 @@ __global__ __launch_bounds__(384) void dcn_bwd_data_ws_kernel(DcnShape s, BwArgs
 #pragma unroll
         for (int h = 0; h < 2; h++) {
           const int u = 2 * st + h;
-          if (u + 1 < 2 * nst) issue(u + 1, raw[(h + 1) & 1]);  // (uniform; clamped table rows: always valid addresses)
+          if (u + 1 < 2 * nst && !(a.ablate & 32)) issue(u + 1, raw[(h + 1) & 1]);  // (uniform; always valid addresses; bit 5 = no gathers)
           if (flags & 16u) {
             float v[4][8];
 #pragma unroll
@@ -1702,11 +1708,13 @@ static int launch_bwd_data_tc(const DcnShape& s, const BwArgs& a, int grid, size
   if (a.dcol && getenv("D2AMD_DCN_BWD_WS0") == nullptr) {  // wave-specialised (default); D2AMD_DCN_BWD_WS0: the one-role kernel
     const size_t lds_ws = lds + 2 * 64 * BW_CPITCH * sizeof(float);
     if (lds_ws <= 160 * 1024) {
-      auto kern = dcn_bwd_data_ws_kernel<T>;
-      if (lds_ws > 48 * 1024)
-        D2_HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ws));
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(384), lds_ws, st, s, a);
-      return D2AMD_OK;
+      auto go = [&](auto kern) -> int {
+        if (lds_ws > 48 * 1024)
+          D2_HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ws));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(384), lds_ws, st, s, a);
+        return D2AMD_OK;
+      };
+      return (s.Cog / 16) % 8 == 0 ? go(dcn_bwd_data_ws_kernel<T, 8>) : go(dcn_bwd_data_ws_kernel<T, 2>);
     }
   }
   if (a.dcol) {
@@ -1729,7 +1737,12 @@ TcBwPlan dcn_tc_plan_bwd(const DcnShape& s, int dtype) {
     const long tiles = (long)s.B * pl.tiles_y * pl.tiles_x * s.DG;
     const int nchunk = s.cpg / 64;
     int cs = 1;
-    while (cs < nchunk && tiles * cs < 1024) cs++;
+    // (the wave-specialised gather-mode kernel runs two 6-wave workgroups per CU = 512 slots: res3's 546 tiles stay
+    // whole -- tables once per tile, d(offset) / d(mask) by plain stores, no zero fill; the one-role kernels fill 1,024)
+    const bool ws = s.DG == 1 && (s.C == 64 || s.C == 128 || s.C == 256 || s.C == 512) && getenv("D2AMD_DCN_BWD_ATOMICS") == nullptr &&
+        getenv("D2AMD_DCN_BWD_WS0") == nullptr;
+    const long want = ws ? 512 : 1024;
+    while (cs < nchunk && tiles * cs < want) cs++;
     const char* e = getenv("D2AMD_DCN_CSPLIT");  // profiling switch
     if (e && atoi(e) >= 1) cs = atoi(e) < nchunk ? atoi(e) : nchunk;
     pl.csplit = cs;
@@ -1974,6 +1987,7 @@ int dcn_tc_backward_data_gather(const DcnShape& s, const TcBwPlan& pl, const voi
   BwArgs a{};
   a.x = x_nhwc; a.offset = offset; a.mask = mask; a.wp = wp; a.gout = gout_nhwc;
   a.gx = nullptr; a.goff = goff; a.gmask = gmask; a.dcol = gw.col;
+  { const char* e = getenv("D2AMD_DCN_ABLATE_BWD"); a.ablate = e ? atoi(e) : 0; }
   a.tiles_y = pl.tiles_y; a.tiles_x = pl.tiles_x; a.csplit = pl.csplit;
   if (pl.csplit > 1 && !goff_zeroed) {
     if (goff) { const int zrc = zero_async(goff, (size_t)s.B * s.DG * 2 * s.K2 * s.L * 4, st); if (zrc) return zrc; }

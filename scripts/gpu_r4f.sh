@@ -3,13 +3,13 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp PYTHONPATH=$PWD; REPO=$PWD; TAG=${TAG:-r4f}; OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT
 timeout 1500 python -m pytest tests/test_gpu_dcn_tc.py tests/test_gpu_dcn_reference.py "tests/test_gpu_pooler.py::test_pooler_full_size_per_element_vs_oracle" -m gpu -q -p no:cacheprovider > $OUT/pytest_dcn.log 2>&1; echo "pytest rc=$?"; tail -5 $OUT/pytest_dcn.log
 run() { name=$1; shift; env "$@" timeout 300 python bench.py --workload dcn_r50 --no-cpu-baseline > $OUT/bench_dcn_$name.json 2> $OUT/bench_dcn_$name.err; }
-run big2 X=1
-run big0 D2AMD_DCN_FWD_BIG=0
-run big1 D2AMD_DCN_FWD_BIG=1
-run ks112 D2AMD_DCN_BWW_KSPLIT=112
+run ws X=1
+run ws0 D2AMD_DCN_BWD_WS0=1
+run ws_again X=2
+run ws0_again D2AMD_DCN_BWD_WS0=1
 python - <<PY
 import json
-for n in ("big2","big0","big1","ks112"):
+for n in ("ws","ws0","ws_again","ws0_again"):
     try:
         d=json.load(open("$OUT/bench_dcn_%s.json"%n)); print(n, d["ms_per_step"], d["roofline"]["kernels_ms"], {k:v["ms_per_step"] for k,v in d["ops"].items()})
     except Exception as e: print(n,"failed",e)
