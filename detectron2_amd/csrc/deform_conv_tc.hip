@@ -1202,9 +1202,9 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_tc_kernel(DcnShape s, BwA
 // not help, because a wave's s_waitcnt retires its loads in order.  Here the matrix pipe, the L2 round trips of both
 // sides and the VALU of phase A overlap by construction, as in the forward kernel.
 // Tables of all taps are built once per workgroup (they do not depend on the channel chunk).
-// GK: k-steps per operand request of the matrix waves; Cog / 16 is a multiple of it (8 for Cog % 128 == 0, else 2).
+// GK: k-steps per operand request of the matrix waves; Cog / 16 is a multiple of it (4 for Cog % 64 == 0, else 2).
 template <typename T, int GK>
-__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) void dcn_bwd_data_ws_kernel(DcnShape s, BwArgs a) {
+__global__ __launch_bounds__(384) void dcn_bwd_data_ws_kernel(DcnShape s, BwArgs a) {
   typedef Mma<T> M;
   extern __shared__ __attribute__((aligned(16))) unsigned char bw_smem[];
   float* red = reinterpret_cast<float*>(bw_smem);  // [K2][64][3]
@@ -1277,8 +1277,8 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const raw16 zero = {0u, 0u, 0u, 0u};
     // Operand fragments come straight from L2 (weights pre-packed in fragment order, dY as [position][Co]).  r04, first
     // version: two k-steps in flight -> Cog / 32 DEPENDENT L2 round trips per stage; alone (consumers ablated) the matrix
-    // side took 48 of the kernel's 86 us (profiles/r04/dcn_bwd_data_ws_ablation.txt).  Now a group of GK = 8 k-steps (the
-    // whole stage for Cog = 128) is requested at once, and the next group -- of this stage or of the NEXT one -- is
+    // side took 48 of the kernel's 86 us (profiles/r04/dcn_bwd_data_ws_ablation.txt).  Now a group of GK k-steps is
+    // requested at once, and the next group -- of this stage or of the NEXT one -- is
     // requested as soon as the MFMAs have consumed the registers, i.e. before the tile is written and the barrier is
     // waited for: one exposed round trip per group, none at stage boundaries.
     raw16 ga[2][GK], gb[GK];
@@ -1714,7 +1714,10 @@ static int launch_bwd_data_tc(const DcnShape& s, const BwArgs& a, int grid, size
         hipLaunchKernelGGL(kern, dim3(grid), dim3(384), lds_ws, st, s, a);
         return D2AMD_OK;
       };
-      return (s.Cog / 16) % 8 == 0 ? go(dcn_bwd_data_ws_kernel<T, 8>) : go(dcn_bwd_data_ws_kernel<T, 2>);
+      // (MEASURED, profiles/r04/dcn_bwd_data_ws_ablation.txt: GK = 8 needs 168 VGPRs = exactly 3 waves per SIMD, which
+      // the compiler only meets under amdgpu_waves_per_eu(3, 3) -- and then schedules the CONSUMER path worse: kernel
+      // 86 -> 111 us.  GK = 4 stays at the consumers' 124 VGPRs: 80 us.)
+      return (s.Cog / 16) % 4 == 0 ? go(dcn_bwd_data_ws_kernel<T, 4>) : go(dcn_bwd_data_ws_kernel<T, 2>);
     }
   }
   if (a.dcol) {
@@ -1741,7 +1744,10 @@ TcBwPlan dcn_tc_plan_bwd(const DcnShape& s, int dtype) {
     // whole -- tables once per tile, d(offset) / d(mask) by plain stores, no zero fill; the one-role kernels fill 1,024)
     const bool ws = s.DG == 1 && (s.C == 64 || s.C == 128 || s.C == 256 || s.C == 512) && getenv("D2AMD_DCN_BWD_ATOMICS") == nullptr &&
         getenv("D2AMD_DCN_BWD_WS0") == nullptr;
-    const long want = ws ? 512 : 1024;
+    // (MEASURED: sizing for 512 slots leaves res3's 546 whole-tile workgroups in TWO rounds of full-length workgroups --
+    // 1,092 half-length ones fill 2.13 rounds = 1.5 full lengths: bwd_res3 1.02 -> 1.29 ms per step.  1,024 stays.)
+    const long want = 1024;
+    (void)ws;
     while (cs < nchunk && tiles * cs < want) cs++;
     const char* e = getenv("D2AMD_DCN_CSPLIT");  // profiling switch
     if (e && atoi(e) >= 1) cs = atoi(e) < nchunk ? atoi(e) : nchunk;
