@@ -51,6 +51,19 @@ elif op.startswith("dcn_"):  # dcn_fwd_res3 / dcn_bwd_res4 ...: DCNv2 at the R50
         g = torch.randn_like(y)
         for _ in range(N):
             torch.autograd.grad([y], [x, off, msk, mod.weight], [g], retain_graph=True)
+elif op == "paste_masks":  # SURVEY 8(d) paste micro: 100 masks of 28x28 -> 100 x 800 x 1333 bool
+    from detectron2_amd.layers import paste_masks_in_image
+    g = torch.Generator().manual_seed(7)
+    masks = torch.rand(100, 28, 28, generator=g).to(dev)
+    bx = bench.make_boxes(g, 100, 16, 600).to(dev)
+    for _ in range(N):
+        paste_masks_in_image(masks, bx, (800, 1333), 0.5)
+elif op == "iou_rotated":  # SURVEY 8(d) rotated IoU: 16 x 268,569 (RRPN matching)
+    import bench_extra
+    from detectron2_amd.layers import pairwise_iou_rotated
+    bench_extra.rotated_inputs(w)
+    for _ in range(N):
+        pairwise_iou_rotated(w.rot_gt[0], w.rot_anchors)
 elif op == "match_rpn":
     from detectron2_amd.modeling import Matcher
     mt = Matcher([0.3, 0.7], [0, -1, 1], allow_low_quality_matches=True)
