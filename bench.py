@@ -1159,6 +1159,7 @@ def bench_retinanet(args, ctx):
                            "nms_reduce": "nms_reduce_kernel (greedy reduction over the bitmask)"}[dom],
                 "achieved": round(kb / 1e6 / k_ms, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(kb / 1e6 / k_ms / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("retinanet_" + dom, "nhwc"),
+                "traffic_source": pmc_source("retinanet_" + dom, "nhwc"),
                 "alg_bytes_per_launch": int(kb), "ms_per_launch": round(k_ms, 4), "launches_timed": k_n,
                 "alg_bytes_note": "SURVEY 8(d) NMS: 16N boxes + bitmask write+read 2*8*sum_c n_c*ceil(n_c/64) + 8*N_keep; "
                                   "the kernel is VALU/LDS bound (IoU tests), so this fraction is small by construction: "
@@ -1262,11 +1263,16 @@ def bench_dcn(args, ctx):
         k_ms, k_n = ktimes[dom]
         roof = {"bound": "mfma",
                 "kernel": {"dcn_fwd": "dcn_fwd_wave_kernel / dcn_fwd_tc_kernel (gather + MFMA, no column buffer)",
-                           "dcn_bwd_data": "dcn_bwd_data_tc_kernel (dcol = W^T dY on MFMA -> 16-bit column rows, + d offset / d mask)",
+                           "dcn_bwd_data": "dcn_bwd_data_ws_kernel (wave-specialised: dcol = W^T dY on MFMA by the matrix waves -> "
+                                           "16-bit column rows + d offset / d mask by the consumer waves)",
                            "dcn_bwd_gather": "dcn_gather_dx_kernel (dX = per-pixel gather of the column rows; HBM/L2 bound, no flops counted)",
-                           "dcn_bwd_weight": "dcn_bwd_weight_coop_kernel (dW = dY col^T on MFMA; 2 / 4 output-channel tiles share a column gather)"}[dom],
+                           "dcn_bwd_weight": "dcn_bww_gemm_kernel (dW = dY^T col: dense split-K MFMA GEMM over the column the forward saved)"}[dom],
                 "achieved": round(per_launch / 1e9 / k_ms, 1), "peak": MFMA_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(per_launch / 1e9 / k_ms / MFMA_BF16_TFLOPS, 4), "traffic": pmc_traffic(dom, args.layout),
+                "traffic_source": pmc_source(dom, args.layout),
+                "traffic_all_kernels": {k: pmc_traffic(k, args.layout) for k in ktimes},
+                "sq_counters": "profiles/r04/dcn_sq_counters.json (waves parked in s_waitcnt / barriers 55-60 % of their "
+                               "cycles, VALU issuing 14-19 %: latency-bound, neither pipe saturated)",
                 "alg_flops_per_launch": per_launch, "ms_per_launch": round(k_ms, 4), "launches_timed": k_n,
                 "alg_flops_note": "SURVEY 8(d) DCN: 2*Co*Ci*kh*kw*N*Ho*Wo per block and GEMM (9.9 GFLOP for 2 images, "
                                   "identical for res3/res4/res5); mean over the 13 blocks' launches",

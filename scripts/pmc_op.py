@@ -46,11 +46,12 @@ elif op.startswith("dcn_"):  # dcn_fwd_res3 / dcn_bwd_res4 ...: DCNv2 at the R50
     if "_fwd_" in op:
         for _ in range(N):
             mod(x.detach(), off.detach(), msk.detach())
-    else:
-        y = mod(x, off, msk)
-        g = torch.randn_like(y)
+    else:  # forward + backward per iteration (the backward consumes the column its forward saved); the summary drops
+        g = None  # the forward's kernels by name
         for _ in range(N):
-            torch.autograd.grad([y], [x, off, msk, mod.weight], [g], retain_graph=True)
+            y = mod(x, off, msk)
+            g = torch.randn_like(y) if g is None else g
+            torch.autograd.grad([y], [x, off, msk, mod.weight], [g])
 elif op == "paste_masks":  # SURVEY 8(d) paste micro: 100 masks of 28x28 -> 100 x 800 x 1333 bool
     from detectron2_amd.layers import paste_masks_in_image
     g = torch.Generator().manual_seed(7)

@@ -677,3 +677,30 @@ def test_batched_nms_and_paste_masks_are_scriptable_with_identical_results():
     sb = scale_boxes(pb, scale)
     assert torch.allclose((sb[:, 2:] - sb[:, :2]), (pb[:, 2:] - pb[:, :2]) * scale, rtol=1e-5)
     assert torch.allclose((sb[:, 2:] + sb[:, :2]), (pb[:, 2:] + pb[:, :2]), rtol=1e-5)
+
+
+def test_fp16_rois_are_not_rounded_to_the_feature_dtype_and_what_that_changes():
+    """The reference casts the ROIs to the input dtype before the op (layers/roi_align.py:60): with fp16 features an ROI
+    coordinate of 1,200 px is then a multiple of 1 px, one of 300 px a multiple of 0.25 px.  This package keeps the ROIs
+    in fp32 (SURVEY 7 sanctions it for bf16 and the same policy is applied to fp16).  Stated here by how much
+    that differs on the same inputs: the op equals the oracle on the UNROUNDED boxes to the fp16 output rounding, and
+    the oracle on fp16-rounded boxes -- what the reference computes -- is up to several 1e-2 of the feature range away
+    for large image coordinates (and identical for boxes that are exact in fp16)."""
+    rng = np.random.default_rng(77)
+    N, C, H, W = 1, 8, 200, 336                      # p2 of an 800 x 1344 image
+    x = rng.uniform(-1, 1, (N, C, H, W)).astype(np.float16)
+    rois = random_rois(rng, 64, N, W, H, 0.25, 16.0)  # image coordinates up to 1,344: fp16 ulp 0.5 .. 1 px
+    xt = torch.from_numpy(x).to(DEV)
+    y = ROIAlign((7, 7), 0.25, 0, True)(xt, torch.from_numpy(rois).to(DEV)).float().cpu().numpy()
+    exact = oracle.roi_align_forward(x.astype(np.float32), rois, (7, 7), 0.25, 0, True)
+    assert np.abs(y - exact).max() <= 2.0 ** -10 * np.abs(exact).max() + 1e-4     # fp16 output rounding only
+    rounded = rois.copy()
+    rounded[:, 1:] = rois[:, 1:].astype(np.float16).astype(np.float32)
+    ref_like = oracle.roi_align_forward(x.astype(np.float32), rounded, (7, 7), 0.25, 0, True)
+    gap = float(np.abs(ref_like - exact).max())
+    assert 1e-3 < gap < 0.5, gap      # a real, bounded difference: the reference's own result moves by this much
+    exact_in_fp16 = np.round(rois * 4) / 4
+    exact_in_fp16[:, 1:] = np.clip(exact_in_fp16[:, 1:], 0, 500)   # < 512: quarter pixels are exact in fp16
+    y2 = ROIAlign((7, 7), 0.25, 0, True)(xt, torch.from_numpy(exact_in_fp16.astype(np.float32)).to(DEV)).float().cpu().numpy()
+    same = oracle.roi_align_forward(x.astype(np.float32), exact_in_fp16.astype(np.float16).astype(np.float32), (7, 7), 0.25, 0, True)
+    assert np.abs(y2 - same).max() <= 2.0 ** -10 * np.abs(same).max() + 1e-4
