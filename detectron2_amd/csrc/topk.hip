@@ -15,6 +15,10 @@
 // all resident at once (the RPN: 138) run steps 1-5 as ONE kernel (tk_fused_kernel): the chunk stays in registers and
 // the workgroups of a segment meet at barriers built on device-scope atomics -- without device-scope fences, which
 // write the XCD's L2 back on this part.
+// LARGE segments (more than 256 chunks = 1 M scores: RetinaNet's class logits) read the scores TWICE instead (r04, see
+// "large segments" below): pass 0 (tk_hist0_span_kernel), then ONE gather pass that writes what pass 0 already proves
+// selected and collects the k-th candidate's 11-bit bucket into a small pool, whose radix select (remaining key bits,
+// then the element index) never touches the scores again.
 #include <cmath>
 
 #include "topk.h"
@@ -29,12 +33,12 @@ constexpr int TK_BINS = 2048;
 struct SegState {
   uint32_t prefix;  // key bits resolved so far
   int k_rem;        // still to take from the current bucket
+  int cnt_lt, cnt_tie;  // output reservations (adjacent and 8-byte aligned: tk_gather_kernel advances both with one atomic)
   int c_lt;         // candidates strictly better than the current bucket
   int total;        // candidates of the segment
   int take_all;     // fewer candidates than k: all of them are selected
   int ties_total, need;
   int done[4];      // workgroups finished per pass (0-2: histogram passes, 3: tie count)
-  int cnt_lt, cnt_tie;
   int cnt;          // selected = min(k, total)
   int c_def;        // candidates better than the bucket of pass 1 (key >> 10 < prefix): placed by a scan, see blk_def
   int pad[1];
@@ -49,6 +53,7 @@ struct TkParams {
   int tickets;     // 1: the last workgroup of a segment (atomic ticket) scans; 0: separate scan launches
   int reps;        // consecutive TK_CHUNK chunks per workgroup (keeps the workgroups of a segment <= ~256: every
                    // workgroup takes a ticket on ONE address per pass, and 3,000 returning atomics there cost 0.3 ms)
+  unsigned long long* stamps;  // profiling only (D2AMD_TOPK_STAMPS): [workgroup][6] wall-clock stamps of tk_gather_kernel
   int* blk_def;    // [segments][maxblk], large segments only (else null).  Pass 2 counts, per workgroup, the candidates
                    // that are selected whatever the last 10 key bits decide (key >> 10 < the 21-bit prefix); the scan
                    // launch turns the counts into offsets and the compaction places those candidates WITHOUT
@@ -155,31 +160,42 @@ __global__ __launch_bounds__(TK_THREADS) void tk_hist_kernel(TkParams P, SegStat
   SegState* S = st + seg;
   const int tid = threadIdx.x;
   if (PASS > 0 && S->take_all) return;  // written by the previous launch
-  __shared__ int h[TK_BINS];
+  // PASS 0 counts EVERY candidate, and a score distribution puts most of a wave's 64 values into a handful of bins:
+  // lanes adding to the same LDS word are served one after the other.  Four copies of the bins, one per lane & 3 (8
+  // words of padding between them: the same bin of two copies lies in different banks), quarter that.
+  constexpr int COPIES = PASS == 0 ? 4 : 1, CPITCH = TK_BINS + 8;
+  __shared__ int h[COPIES * CPITCH];
   __shared__ int s_last, s_def;
-  for (int i = tid; i < TK_BINS; i += TK_THREADS) h[i] = 0;
+  for (int i = tid; i < COPIES * CPITCH; i += TK_THREADS) h[i] = 0;
   if (tid == 0) s_def = 0;
   __syncthreads();
+  int* hc = h + (PASS == 0 ? (tid & 3) * CPITCH : 0);
   int n_def = 0;
   const uint32_t prefix = PASS > 0 ? S->prefix : 0u;
   const float* x = P.in.ptr[l] + (long)img * P.in.stride[l];
+  float v[TK_ITEMS], nv[TK_ITEMS];
+  bool ok[TK_ITEMS], nok[TK_ITEMS];
+  tk_load(x, base0, size, v, ok);
   for (int rep = 0; rep < P.reps; rep++) {
     const long base = base0 + (long)rep * TK_CHUNK;
-    if (base >= size) break;
-    float v[TK_ITEMS];
-    bool ok[TK_ITEMS];
-    tk_load(x, base, size, v, ok);
+    // the next chunk's loads are in flight while this one is counted (the resident workgroups otherwise alternate
+    // between a load phase and a count phase in lock step: the memory system idles during the second)
+    const bool more = rep + 1 < P.reps && base + TK_CHUNK < size;  // uniform
+    if (more) tk_load(x, base + TK_CHUNK, size, nv, nok);
 #pragma unroll
     for (int j = 0; j < TK_ITEMS; j++) {
       uint32_t key;
       if (!ok[j] || !tk_key(P, v[j], key)) continue;
-      if (PASS == 0) atomicAdd(&h[key >> 21], 1);
+      if (PASS == 0) atomicAdd(&hc[key >> 21], 1);
       else if (PASS == 1) { if ((key >> 21) == prefix) atomicAdd(&h[(key >> 10) & 2047u], 1); }
       else {
         if ((key >> 10) == prefix) atomicAdd(&h[key & 1023u], 1);
         n_def += (key >> 10) < prefix ? 1 : 0;
       }
     }
+    if (!more) break;
+#pragma unroll
+    for (int j = 0; j < TK_ITEMS; j++) { v[j] = nv[j]; ok[j] = nok[j]; }
   }
   if (PASS == 2 && P.blk_def != nullptr) {  // uniform
 #pragma unroll
@@ -189,8 +205,11 @@ __global__ __launch_bounds__(TK_THREADS) void tk_hist_kernel(TkParams P, SegStat
   __syncthreads();
   if (PASS == 2 && P.blk_def != nullptr && tid == 0) P.blk_def[(long)seg * P.maxblk + blockIdx.x] = s_def;
   int* gh = hist + ((long)seg * 3 + PASS) * TK_BINS;
-  for (int i = tid; i < TK_BINS; i += TK_THREADS)
-    if (h[i]) atomicAdd(&gh[i], h[i]);
+  for (int i = tid; i < TK_BINS; i += TK_THREADS) {
+    int c = h[i];
+    if (PASS == 0) c += h[CPITCH + i] + h[2 * CPITCH + i] + h[3 * CPITCH + i];
+    if (c) atomicAdd(&gh[i], c);
+  }
   if (!P.tickets) return;  // tk_scan_kernel follows
   // (no device-scope fence: bins and ticket are device-scope atomics, performed at the memory side of the L2s, and
   // the scan reads the bins with device-scope loads -- see tk_segment_barrier; a fence costs an L2 write-back here)
@@ -487,13 +506,27 @@ __global__ __launch_bounds__(TK_THREADS) void tk_compact_kernel(TkParams P, SegS
 // workgroups cannot starve the ones they wait for.
 struct TkScanOut { int bin, before, total; };
 
-template <int BINS>
+// (AGENT: the bins were written by other workgroups of THIS launch -- device-scope loads, performed at the memory side;
+// bins of an earlier launch are read with plain loads: 7,390 workgroups x 2,048 device-scope loads of the same 80 KB
+// made the first gather pass 98 us long)
+template <int BINS, bool AGENT = true>
 __device__ __forceinline__ TkScanOut tk_scan_local(const int* gh, int k_rem, int* lds4, int* s_pair) {
   const int tid = threadIdx.x;
   constexpr int PER = BINS / TK_THREADS;
   int loc[PER], sum = 0;
+  if (AGENT) {
 #pragma unroll
-  for (int j = 0; j < PER; j++) { loc[j] = ld_agent(&gh[tid * PER + j]); sum += loc[j]; }
+    for (int j = 0; j < PER; j++) { loc[j] = ld_agent(&gh[tid * PER + j]); sum += loc[j]; }
+  } else {
+    static_assert(PER == 8 || PER == 4, "two or one 16-B loads per thread");
+    const int4* g4 = reinterpret_cast<const int4*>(gh + tid * PER);
+#pragma unroll
+    for (int j = 0; j < PER / 4; j++) {
+      const int4 q = g4[j];
+      loc[4 * j] = q.x; loc[4 * j + 1] = q.y; loc[4 * j + 2] = q.z; loc[4 * j + 3] = q.w;
+      sum += q.x + q.y + q.z + q.w;
+    }
+  }
   int total;
   int run = tk_block_excl_scan(sum, lds4, total);
   if (tid == 0) { s_pair[0] = -1; s_pair[1] = 0; }
@@ -764,8 +797,550 @@ __global__ __launch_bounds__(256) void tk_merge_kernel(TkParams P, const SegStat
   }
 }
 
-struct TkWs { SegState* st; int* hist; int* blk_ties; int* blk_def; unsigned long long* cand; size_t zero_bytes, total; int maxblk, kmax, reps, tickets; };
+// ---- large segments (RetinaNet: 3,000 chunks per segment), r04: TWO reads of the scores instead of four / five ------------
+// The legacy chain above reads every score in pass 0, 1, 2, (ties,) and the compaction: 129 MB x 4-5 per RetinaNet batch of
+// two images, 164 us for a selection of 200,000 pairs (profiles/r03/final/retinanet_100k_kernel_stats.csv).  Pass 0 alone
+// already says in WHICH 11-bit bucket b0 the k-th best candidate lies, how many candidates are better than the bucket
+// (c_lt < k) and how many it holds (M).  So the second read of the scores is the last one:
+//   tk_gather_kernel  every workgroup scans pass 0's bins itself (same bins -> same b0; no scan launch), then writes
+//                     the candidates of better buckets straight into the selection ("definite": they are selected
+//                     whatever the lower key bits say) and the candidates of bucket b0 into the segment's POOL as
+//                     (key : index) pairs.  A workgroup loads its 4 chunks (64 values per thread) in one go and makes
+//                     ONE reservation per counter.
+//   tk_pool1_kernel / tk_pool_kernel
+//                     the k - c_lt best of the M pool pairs: radix select on the remaining 21 key bits and -- only if
+//                     there are more ties at the k-th key than needed -- on the element index (the pair as ONE 53-bit
+//                     value: lower index first, as the reference's stable order; pairs are unique, so the select
+//                     always ends with "take the whole bucket").  M is ~k for smooth score distributions (an 11-bit
+//                     bucket is 19-25 % of the value wide): pools of <= 24,576 pairs are selected by one 1,024-thread
+//                     workgroup per segment, pairs in registers; larger ones by 16 co-resident workgroups per segment
+//                     with segment barriers (tk_segment_barrier).  The pool holds tk_pool_cap(k) pairs; a larger bucket
+//                     (all scores nearly equal: an untrained head) is selected by the same kernel FROM THE SCORES
+//                     (filtering bucket b0 on the fly: slow -- 16 workgroups per segment -- but exact and bounded).
+// Measured (selection alone, 2 x 16.1 M logits, k = 20,000 x 5 levels, one box): 0.263 ms with the five-read chain,
+// 0.144 ms with this one (pass 0 34 us, gather ~30 us, pool 13 us, sort 36 us, LDS-staged rank merge 10 us).
+constexpr int TK_GSPAN = 8;        // chunks per workgroup of the gather pass (32,768 scores)
+constexpr int TK_GGROUP = 2;       // chunks per load group: 32 values per thread, two groups in flight
+constexpr int TK_STAGE = 1024;     // staged pairs per list and workgroup (3 % of its scores)
+constexpr int TK_POOL_G_MAX = 32;  // workgroups per segment of the pool kernel (D2AMD_TOPK_POOL_G)
+constexpr int TK_POOL_U = 8;       // pool pairs per thread and batch
+constexpr int TK_POOL_PASSES = 5;  // 53 bits = 21 key bits + 32 index bits: digits of 11, 11, 11, 11, 9 bits
+static inline int tk_pool_cap(int size, int k) { return std::min(size, std::max(4 * k, 131072)); }
+struct TkPool {
+  unsigned long long* mem;  // [N][sum of cap]: pool of segment (img, l) at img * per_img + off[l]
+  int* hist;                // [segments][TK_POOL_PASSES][TK_BINS], then [segments][8] counters (barriers 0-4, 7: output)
+  int cap[TOPK_MAX_LEVELS];
+  long off[TOPK_MAX_LEVELS];
+  long per_img;
+  int no_small;             // D2AMD_TOPK_POOL_NO_SMALL (A/B and test switch): every pool goes to tk_pool_kernel
+};
+
+// Pass 0 of the large segments: the same counts as tk_hist_kernel<0> (bins = key >> 21 of every candidate), laid out like
+// the gather pass: 8-chunk spans, 32 values per thread and group through immediate offsets, the next group in flight
+// while this one is counted, no per-element bounds test or branch -- a value that is no candidate (below the bound)
+// is counted in a spare word of the bins' padding.  (tk_hist_kernel<0> on the 2 x 16.1 M logits: 15 VALU + 9 SALU
+// instructions per element and wave, 45 us; with four lane-interleaved copies of the bins 37 us.)
+// LDS layout: what bounds the pass is lanes of a wave adding to the SAME LDS word (a score distribution puts a third of
+// the values into one bin): COPIES copies of the bins, one per lane % COPIES, and -- a workgroup counts at most 32,768
+// values -- 16-bit counters, bins b and b + 1,024 (the two signs: rarely both popular) sharing a word, so that 16 copies
+// are 66 KB.
+// VEC: a lane loads 16 B (four consecutive scores; 1 KB per wave and load instead of 256 B) -- needs 16-B aligned segments.
+template <int COPIES, bool VEC>
+__global__ __launch_bounds__(TK_THREADS) void tk_hist0_span_kernel(TkParams P, int* __restrict__ hist) {
+  const int seg = blockIdx.y, l = seg % P.in.L, img = seg / P.in.L;
+  const int size = P.in.size[l];
+  constexpr long SPAN = (long)TK_GSPAN * TK_CHUNK;
+  static_assert(SPAN < 65536, "16-bit counters");
+  const long base0 = (long)blockIdx.x * SPAN;
+  if (base0 >= size) return;
+  const int tid = threadIdx.x;
+  constexpr int WORDS = TK_BINS / 2, CPITCH = WORDS + 8;  // (word WORDS of a copy: values that are no candidates)
+  __shared__ uint32_t h[COPIES * CPITCH];
+  for (int i = tid; i < COPIES * CPITCH; i += TK_THREADS) h[i] = 0u;
+  __syncthreads();
+  uint32_t* hc = h + (tid % COPIES) * CPITCH;
+  const float* x = P.in.ptr[l] + (long)img * P.in.stride[l];
+  const bool thr = P.use_thr != 0;
+  const float xmin = P.xmin;
+  auto count = [&](float val) __attribute__((always_inline)) {
+    const uint32_t b = topk_desc_key(val) >> 21;
+    const bool c = !thr || val >= xmin;
+    atomicAdd(&hc[c ? (b & (WORDS - 1)) : (uint32_t)WORDS], b >= (uint32_t)WORDS ? 0x10000u : 1u);
+  };
+  if (base0 + SPAN <= size) {  // uniform: every group of the span is complete
+    constexpr int NV = TK_GGROUP * TK_ITEMS, G = TK_GSPAN / TK_GGROUP;
+    float va[NV], vb[NV];
+    auto load = [&](float (&v)[NV], int gi) __attribute__((always_inline)) {
+      if (VEC) {
+        const float4* xb = reinterpret_cast<const float4*>(x + base0 + (long)gi * (TK_GGROUP * TK_CHUNK)) + tid;
+#pragma unroll
+        for (int q = 0; q < NV / 4; q++) {
+          const float4 t = xb[q * TK_THREADS];
+          v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+        }
+      } else {
+        const float* xb = x + base0 + (long)gi * (TK_GGROUP * TK_CHUNK) + tid;
+#pragma unroll
+        for (int j = 0; j < NV; j++) v[j] = xb[j * TK_THREADS];
+      }
+    };
+    load(va, 0);
+#pragma unroll 1
+    for (int gi = 0; gi < G; gi++) {
+      if (gi + 1 < G) load(vb, gi + 1);
+#pragma unroll
+      for (int j = 0; j < NV; j++) count(va[j]);
+#pragma unroll
+      for (int j = 0; j < NV; j++) va[j] = vb[j];
+    }
+  } else {  // the segment's last span
+    for (long base = base0; base < size; base += TK_CHUNK) {
+      float v[TK_ITEMS];
+      bool ok[TK_ITEMS];
+      tk_load(x, base, size, v, ok);
+#pragma unroll
+      for (int j = 0; j < TK_ITEMS; j++)
+        if (ok[j]) count(v[j]);
+    }
+  }
+  __syncthreads();
+  int* gh = hist + (long)seg * 3 * TK_BINS;
+  for (int i = tid; i < WORDS; i += TK_THREADS) {
+    uint32_t lo = 0u, hi = 0u;
+#pragma unroll
+    for (int c = 0; c < COPIES; c++) { const uint32_t w = h[c * CPITCH + i]; lo += w & 0xffffu; hi += w >> 16; }
+    if (lo) atomicAdd(&gh[i], (int)lo);
+    if (hi) atomicAdd(&gh[i + WORDS], (int)hi);
+  }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(TK_THREADS, 4) void tk_gather_kernel(TkParams P, SegState* __restrict__ st,
+                                                                 const int* __restrict__ hist,
+                                                                 unsigned long long* __restrict__ cand, int kmax,
+                                                                 const TkPool Q) {
+  const int seg = blockIdx.y, l = seg % P.in.L, img = seg / P.in.L;
+  const int size = P.in.size[l];
+  constexpr long SPAN = (long)TK_GSPAN * TK_CHUNK;
+  const long base0 = (long)blockIdx.x * SPAN;
+  // a segment that selects a large share of its scores ("dense", decided below from pass 0's bins; a small segment by
+  // nature) is handed out chunk by chunk when the grid has a workgroup per chunk: its workgroups stay for the scan
+  const int chunks = (size + TK_CHUNK - 1) / TK_CHUNK;
+  const bool by_chunk_possible = chunks <= (int)gridDim.x;
+  if (base0 >= size && !(by_chunk_possible && (int)blockIdx.x < chunks)) return;
+  SegState* S = st + seg;
+  const int tid = threadIdx.x;
+  __shared__ int lds4[TK_THREADS / 64];
+  __shared__ int s_pair[2], s_base[2], s_cnt[2];
+  __shared__ unsigned long long stage[2][TK_STAGE];
+  const float* x = P.in.ptr[l] + (long)img * P.in.stride[l];
+  unsigned long long* out_def = cand + (long)seg * kmax;
+  int cap = Q.cap[0];
+  long poff = Q.off[0];
+#pragma unroll
+  for (int q = 1; q < TOPK_MAX_LEVELS; q++)
+    if (q == l) { cap = Q.cap[q]; poff = Q.off[q]; }
+  unsigned long long* out_pool = Q.mem + (long)img * Q.per_img + poff;
+#define TKST(k) do { if (P.stamps && tid == 0) P.stamps[((size_t)seg * gridDim.x + blockIdx.x) * 6 + (k)] = wall_clock64(); } while (0)
+  TKST(0);
+  const bool whole = base0 + SPAN <= size;  // uniform: the span exists and every group of it is complete
+  constexpr int NV = TK_GGROUP * TK_ITEMS;  // values per thread and group
+  // group gi of the span: one base address, immediate offsets (a clamped index per load costs a 64-bit address each)
+  // (VEC: 16 B per lane -- value j of a thread is element (j >> 2) * 1,024 + 4 tid + (j & 3) of the group)
+  auto load = [&](float (&v)[NV], int gi) __attribute__((always_inline)) {
+    if (VEC) {
+      const float4* xb = reinterpret_cast<const float4*>(x + base0 + (long)gi * (TK_GGROUP * TK_CHUNK)) + tid;
+#pragma unroll
+      for (int q = 0; q < NV / 4; q++) {
+        const float4 t = xb[q * TK_THREADS];
+        v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+      }
+    } else {
+      const float* xb = x + base0 + (long)gi * (TK_GGROUP * TK_CHUNK) + tid;
+#pragma unroll
+      for (int j = 0; j < NV; j++) v[j] = xb[j * TK_THREADS];
+    }
+  };
+  float va[NV], vb[NV];
+  if (whole) load(va, 0);  // (flies while the bins are scanned)
+  // ---- what pass 0 found: every workgroup scans the bins itself
+  uint32_t b0 = 0;
+  float x0;  // no selected element is below it
+  bool take_all, pool_on = false, bucket_def = false, dense_seg;
+  {
+    const int k = P.in.k[l];
+    const TkScanOut o = tk_scan_local<2048, false>(hist + (long)seg * 3 * TK_BINS, k, lds4, s_pair);
+    take_all = o.total < k;  // fewer candidates than k: all of them are selected
+    int M = 0, k_rem = 0;
+    if (!take_all) {
+      b0 = (uint32_t)o.bin;
+      k_rem = k - o.before;
+      M = hist[(long)seg * 3 * TK_BINS + o.bin];
+      bucket_def = M == k_rem;           // the whole bucket is selected: no pool
+      pool_on = !bucket_def && M <= cap;  // else: tk_pool_kernel reads the scores
+      // the value whose key is the bucket's worst, (b0 << 21) | 0x1fffff: topk_desc_key inverted
+      const uint32_t m = ~((b0 << 21) | 0x1fffffu);
+      x0 = __uint_as_float((m & 0x80000000u) ? (m ^ 0x80000000u) : ~m);
+    } else {
+      x0 = !P.use_thr ? -__builtin_inff() : (P.xmin != P.xmin) ? __builtin_inff() : P.xmin;
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+      S->total = o.total; S->take_all = take_all ? 1 : 0; S->cnt = take_all ? o.total : k;
+      S->prefix = b0; S->c_lt = take_all ? 0 : o.before; S->k_rem = bucket_def ? 0 : k_rem;
+      S->ties_total = bucket_def ? 0 : M; S->need = pool_on ? 1 : 0;
+    }
+    // dense: a span's expected share of either list would not fit the staging list (60 %: the share is not uniform)
+    const long n_list = take_all ? o.total : max(o.before + (bucket_def ? M : 0), pool_on ? M : 0);
+    dense_seg = n_list * SPAN > (long)size * (TK_STAGE * 6 / 10);
+    if (tid < 2) s_cnt[tid] = 0;
+    __syncthreads();
+  }
+  TKST(1);
+  // exact class of a value: 1 = definite (selected whatever the lower key bits say), 2 = pool, 0 = neither
+  auto cls = [&](float val, uint32_t& key) __attribute__((always_inline)) {
+    key = 0;
+    const bool c = tk_key(P, val, key);
+    const uint32_t b = key >> 21;
+    const bool d = c && (take_all || b < b0 || (bucket_def && b == b0));
+    return d ? 1 : (c && pool_on && b == b0) ? 2 : 0;
+  };
+  // SPARSE (a workgroup of a large segment selects ~0.3 % of its values): a selected element is appended to a staging
+  // list in LDS right where it is found, behind a wave-uniform test that is ONE float compare per element -- a selected
+  // element is not below x0 (NaN passes and is classified exactly); 84 % of a wave's 64-element rows hold none.  The
+  // lists go out as contiguous runs after ONE reservation per workgroup.  (Measured on the way, 2 x 16.1 M RetinaNet
+  // logits: classify twice around a block scan 94 us; exact class of every element 87 us -- 73 issue cycles per element
+  // and wave; float pretest 83 us, of which 8 us per workgroup waiting for its turn at the segment's counters: 739
+  // workgroups x 2 returning atomics on one line, all at the same moment, and the load and compute phases of the
+  // resident workgroups alternating in lock step.  Hence 16-chunk spans, double-buffered groups and one packed atomic.)
+  auto sift = [&](const float (&v)[NV], int gi) __attribute__((always_inline)) {
+    // (the element index is built from an opaque copy of the thread index: derived from `tid` the values tid | j << 8
+    // were hoisted out of the loop and held in a register each)
+    uint32_t ebase = (uint32_t)(base0 + (long)gi * (TK_GGROUP * TK_CHUNK)) + (uint32_t)tid * (VEC ? 4u : 1u);
+    asm volatile("" : "+v"(ebase));
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+      if (__ballot(!(v[j] < x0)) != 0ull) {  // uniform per wave
+        uint32_t key;
+        const int c = cls(v[j], key);
+        if (c != 0) {
+          const int pos = atomicAdd(&s_cnt[c - 1], 1);
+          if (pos < TK_STAGE)
+            stage[c - 1][pos] = ((unsigned long long)key << 32) | (ebase + (VEC ? (j >> 2) * (4 * TK_THREADS) + (j & 3) : j * TK_THREADS));
+        }
+      }
+    }
+  };
+  // DENSE: one chunk (values re-loaded where the sparse attempt held them), block scan + one reservation per list
+  auto dense_chunk = [&](long base) __attribute__((always_inline)) {
+    float w[TK_ITEMS];
+    const int lc = (int)min((long)size - base, (long)TK_CHUNK);
+#pragma unroll
+    for (int j = 0; j < TK_ITEMS; j++) w[j] = x[base + min(j * TK_THREADS + tid, lc - 1)];
+    int m = 0;
+#pragma unroll
+    for (int j = 0; j < TK_ITEMS; j++) {
+      uint32_t key;
+      const int c = j * TK_THREADS + tid < lc ? cls(w[j], key) : 0;
+      m += c == 1 ? 1 : c == 2 ? 0x10000 : 0;
+    }
+    int tot;
+    const int my = tk_block_excl_scan(m, lds4, tot);
+    if (tid == 0) {
+      s_base[0] = (tot & 0xffff) ? atomicAdd(&S->cnt_lt, tot & 0xffff) : 0;
+      s_base[1] = (tot >> 16) ? atomicAdd(&S->cnt_tie, tot >> 16) : 0;
+    }
+    __syncthreads();
+    int p_def = s_base[0] + (my & 0xffff), p_pl = s_base[1] + (my >> 16);
+#pragma unroll
+    for (int j = 0; j < TK_ITEMS; j++) {
+      uint32_t key;
+      const int c = j * TK_THREADS + tid < lc ? cls(w[j], key) : 0;
+      const unsigned long long e = ((unsigned long long)key << 32) | (uint32_t)(base + j * TK_THREADS + tid);
+      if (c == 1) out_def[p_def++] = e;
+      else if (c == 2) out_pool[p_pl++] = e;
+    }
+    __syncthreads();  // s_base / lds4 are reused
+  };
+  if (dense_seg && by_chunk_possible) {  // uniform over the segment: workgroup = chunk
+    TKST(5);
+    dense_chunk((long)blockIdx.x * TK_CHUNK);
+    TKST(4);
+    return;
+  }
+  if (base0 >= size) return;  // (stayed for a chunk-wise hand-out that did not happen)
+  if (whole && !dense_seg) {
+    constexpr int G = TK_GSPAN / TK_GGROUP;
+#pragma unroll 1
+    for (int gi = 0; gi < G; gi++) {  // the next group's loads are in flight while this one is sifted
+      if (gi + 1 < G) load(vb, gi + 1);
+      sift(va, gi);
+      // (a copy, not a second sift of vb in the same iteration: around the back edge the compiler's wait counts made
+      // that one wait for the group issued AFTER it as well)
+#pragma unroll
+      for (int j = 0; j < NV; j++) va[j] = vb[j];
+    }
+    __syncthreads();
+    TKST(2);
+    const int t_def = s_cnt[0], t_pl = s_cnt[1];
+    if (t_def <= TK_STAGE && t_pl <= TK_STAGE) {  // uniform
+      if (t_def + t_pl == 0) return;
+      if (tid == 0) {  // cnt_lt (low word) and cnt_tie (high word) advance together
+        const unsigned long long r = atomicAdd(reinterpret_cast<unsigned long long*>(&S->cnt_lt),
+                                               (unsigned long long)t_def | ((unsigned long long)t_pl << 32));
+        s_base[0] = (int)(uint32_t)r; s_base[1] = (int)(r >> 32);
+      }
+      __syncthreads();
+      TKST(3);
+      for (int i = tid; i < t_def; i += TK_THREADS) out_def[s_base[0] + i] = stage[0][i];
+      for (int i = tid; i < t_pl; i += TK_THREADS) out_pool[s_base[1] + i] = stage[1][i];
+      TKST(4);
+      return;
+    }
+    // a list overflowed (the selected scores are clustered): nothing has been written yet, the span is walked again
+  }
+  TKST(5);
+  // the segment's last, partial span; a dense segment with more chunks than the grid is wide; the overflow above
+  for (long base = base0; base < min((long)size, base0 + SPAN); base += TK_CHUNK) dense_chunk(base);  // uniform
+  TKST(4);
+#undef TKST
+}
+
+struct SegState;
+__device__ __forceinline__ bool tk_pool_is_small(const SegState* S);
+__global__ __launch_bounds__(TK_THREADS) void tk_pool_kernel(TkParams P, const SegState* __restrict__ st,
+                                                            unsigned long long* __restrict__ cand, int kmax,
+                                                            const TkPool Q) {
+  const int TK_POOL_G = (int)gridDim.x;  // workgroups per segment
+  const int seg = blockIdx.y, l = seg % P.in.L, img = seg / P.in.L, ns = P.in.N * P.in.L;
+  const int size = P.in.size[l];
+  if (size == 0) return;
+  const SegState* S = st + seg;
+  int k_rem = S->k_rem;
+  if (S->take_all || k_rem == 0) return;  // (uniform over the segment: every selected candidate was definite)
+  if (tk_pool_is_small(S) && !Q.no_small) return;  // tk_pool1_kernel's
+  const int M = S->ties_total, c_lt = S->c_lt;
+  const uint32_t b0 = S->prefix;
+  const bool from_pool = S->need != 0;
+  const int tid = threadIdx.x;
+  long poff = Q.off[0];
+#pragma unroll
+  for (int q = 1; q < TOPK_MAX_LEVELS; q++)
+    if (q == l) poff = Q.off[q];
+  const unsigned long long* pool = Q.mem + (long)img * Q.per_img + poff;
+  const float* x = P.in.ptr[l] + (long)img * P.in.stride[l];
+  const long n_src = from_pool ? M : size;
+  constexpr unsigned long long MASK53 = (1ull << 53) - 1ull;
+  // pair i of the source, reduced to the 53 bits below the bucket (-> false: not a pair of bucket b0)
+  auto fetch = [&](long i, unsigned long long& v) -> bool {
+    if (from_pool) { v = pool[i] & MASK53; return true; }
+    uint32_t key = 0;
+    const bool c = tk_key(P, x[i], key) && (key >> 21) == b0;
+    v = (((unsigned long long)key << 32) | (uint32_t)i) & MASK53;
+    return c;
+  };
+  __shared__ int h[TK_BINS];
+  __shared__ int lds4[TK_THREADS / 64];
+  __shared__ int s_pair[2], s_base;
+  int* gh = Q.hist + (long)seg * TK_POOL_PASSES * TK_BINS;
+  int* ctr = Q.hist + (long)ns * TK_POOL_PASSES * TK_BINS + seg * 8;
+  unsigned long long prefix = 0ull;  // the resolved high bits of the 53
+  int shift = 53;                    // ... = bits [52 : shift]
+  for (int pass = 0; pass < TK_POOL_PASSES; pass++) {
+    const int width = pass == TK_POOL_PASSES - 1 ? 9 : 11;
+    const int hi = shift;
+    shift -= width;
+    const uint32_t dmask = (1u << width) - 1u;
+    for (int i = tid; i < TK_BINS; i += TK_THREADS) h[i] = 0;
+    __syncthreads();
+    for (long b = (long)blockIdx.x * (TK_THREADS * TK_POOL_U); b < n_src; b += (long)TK_POOL_G * (TK_THREADS * TK_POOL_U)) {
+      unsigned long long vv[TK_POOL_U];
+      bool ok[TK_POOL_U];
+#pragma unroll
+      for (int u = 0; u < TK_POOL_U; u++) {
+        const long i = b + u * TK_THREADS + tid;
+        ok[u] = fetch(min(i, n_src - 1), vv[u]) && i < n_src;
+      }
+#pragma unroll
+      for (int u = 0; u < TK_POOL_U; u++)
+        if (ok[u] && (hi >= 53 || (vv[u] >> hi) == prefix)) atomicAdd(&h[(uint32_t)(vv[u] >> shift) & dmask], 1);
+    }
+    __syncthreads();
+    for (int i = tid; i < TK_BINS; i += TK_THREADS)
+      if (h[i]) atomicAdd(&gh[pass * TK_BINS + i], h[i]);
+    tk_segment_barrier(&ctr[pass], TK_POOL_G);
+    const TkScanOut o = tk_scan_local<2048>(gh + pass * TK_BINS, k_rem, lds4, s_pair);
+    const int in_bin = ld_agent(&gh[pass * TK_BINS + o.bin]);
+    prefix = (prefix << width) | (unsigned long long)o.bin;
+    k_rem -= o.before;
+    if (in_bin == k_rem) break;  // the whole bucket is taken (uniform; at the latest in the last pass: pairs are unique)
+  }
+  // ---- the selected pairs: (v >> shift) <= prefix, behind the c_lt definite ones ----------------------------------
+  unsigned long long* out = cand + (long)seg * kmax + c_lt;
+  const unsigned long long top = (unsigned long long)b0 << 53;
+  for (long b = (long)blockIdx.x * (TK_THREADS * TK_POOL_U); b < n_src; b += (long)TK_POOL_G * (TK_THREADS * TK_POOL_U)) {
+    unsigned long long vv[TK_POOL_U];
+    unsigned sel = 0u;
+#pragma unroll
+    for (int u = 0; u < TK_POOL_U; u++) {
+      const long i = b + u * TK_THREADS + tid;
+      const bool c = fetch(min(i, n_src - 1), vv[u]) && i < n_src;
+      sel |= (unsigned)(c && (vv[u] >> shift) <= prefix) << u;
+    }
+    const int n = __builtin_popcount(sel);
+    if (!__syncthreads_or(n != 0)) continue;  // uniform
+    int tot;
+    const int my = tk_block_excl_scan(n, lds4, tot);
+    if (tid == 0) s_base = atomicAdd(&ctr[7], tot);
+    __syncthreads();
+    int p = s_base + my;
+#pragma unroll
+    for (int u = 0; u < TK_POOL_U; u++)
+      if (sel & (1u << u)) out[p++] = top | vv[u];
+    __syncthreads();  // s_base is reused
+  }
+}
+
+
+// The rank merge with the OTHER runs of the segment staged in LDS (RetinaNet: 4 x 4,096 pairs = 128 KB): the 12-step
+// binary searches read LDS instead of 48 dependent global loads per element (tk_merge_kernel: 33 us for 10 x 20,000).
+// A workgroup covers 1,024 consecutive elements of ONE run (TK_RUN is a multiple of 1,024).
+__global__ __launch_bounds__(1024) void tk_merge_lds_kernel(TkParams P, const SegState* __restrict__ st,
+                                                           const unsigned long long* __restrict__ cand, int kmax,
+                                                           int TK_RUN, uint32_t* __restrict__ sel) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long others[];  // [runs - 1][TK_RUN]
+  const int seg = blockIdx.x, l = seg % P.in.L, img = seg / P.in.L;
+  const int total = st[seg].cnt;
+  if (total <= TK_RUN) return;  // tk_sort_kernel wrote the result
+  const int i0 = blockIdx.y * 1024;
+  if (i0 >= total) return;
+  const int runs = (total + TK_RUN - 1) / TK_RUN, own = i0 / TK_RUN, tid = threadIdx.x;
+  const unsigned long long* base = cand + (long)seg * kmax;
+  for (int r = 0; r < runs; r++) {
+    if (r == own) continue;
+    const int n = min(total - r * TK_RUN, TK_RUN);
+    unsigned long long* dst = others + (long)(r < own ? r : r - 1) * TK_RUN;
+    for (int i = tid; i < n; i += 1024) dst[i] = base[(long)r * TK_RUN + i];
+  }
+  const int i = i0 + tid;
+  const unsigned long long key = base[min(i, total - 1)];
+  __syncthreads();
+  if (i >= total) return;
+  int rank = i - own * TK_RUN;
+  for (int r = 0; r < runs; r++) {
+    if (r == own) continue;
+    const unsigned long long* run = others + (long)(r < own ? r : r - 1) * TK_RUN;
+    int lo = 0, hi = min(total - r * TK_RUN, TK_RUN);  // first position whose key is >= key (keys are unique)
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (run[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    rank += lo;
+  }
+  uint32_t* o = sel + (long)img * P.in.koff[P.in.L] + P.in.koff[l];
+  o[rank] = (uint32_t)key;
+}
+
+// The usual pool (M <= 24,576 pairs: smooth score distributions give M ~ k) is selected by ONE 1,024-thread workgroup per
+// segment with the pairs in registers and the digit histograms in LDS: no segment barrier, no device-scope traffic -- the
+// 16-workgroup version above spent ~8 us per digit on those (20 us for two digits + compaction on the bench's pools).
+// tk_pool_kernel keeps the segments this one leaves (larger pools, buckets read from the scores).
+constexpr int TK_P1_THREADS = 1024, TK_P1_U = 24;
+__device__ __forceinline__ bool tk_pool_is_small(const SegState* S) { return S->need != 0 && S->ties_total <= TK_P1_THREADS * TK_P1_U; }
+
+// exclusive prefix of one int per thread over the 1,024-thread workgroup
+__device__ __forceinline__ int tk_p1_excl_scan(int v, int* wsum, int& total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int y = __shfl_up(x, d, 64);
+    if (lane >= d) x += y;
+  }
+  __syncthreads();  // wsum may still be read from a previous call
+  if (lane == 63) wsum[w] = x;
+  __syncthreads();
+  int base = 0;
+  total = 0;
+#pragma unroll
+  for (int i = 0; i < TK_P1_THREADS / 64; i++) {
+    const int t = wsum[i];
+    if (i < w) base += t;
+    total += t;
+  }
+  return base + x - v;
+}
+
+__global__ __launch_bounds__(TK_P1_THREADS) void tk_pool1_kernel(TkParams P, const SegState* __restrict__ st,
+                                                                unsigned long long* __restrict__ cand, int kmax,
+                                                                const TkPool Q) {
+  const int seg = blockIdx.x, l = seg % P.in.L, img = seg / P.in.L;
+  if (P.in.size[l] == 0) return;
+  const SegState* S = st + seg;
+  int k_rem = S->k_rem;
+  if (S->take_all || k_rem == 0 || !tk_pool_is_small(S) || Q.no_small) return;  // uniform
+  const int M = S->ties_total, c_lt = S->c_lt;
+  const int tid = threadIdx.x;
+  long poff = Q.off[0];
+#pragma unroll
+  for (int q = 1; q < TOPK_MAX_LEVELS; q++)
+    if (q == l) poff = Q.off[q];
+  const unsigned long long* pool = Q.mem + (long)img * Q.per_img + poff;
+  constexpr unsigned long long MASK53 = (1ull << 53) - 1ull;
+  unsigned long long v[TK_P1_U];  // (invalid: all ones -- matches no prefix and is never selected)
+#pragma unroll
+  for (int u = 0; u < TK_P1_U; u++) {
+    const int i = u * TK_P1_THREADS + tid;
+    v[u] = i < M ? (pool[i] & MASK53) : ~0ull;
+  }
+  __shared__ int h[TK_BINS];
+  __shared__ int wsum[TK_P1_THREADS / 64];
+  __shared__ int s_pair[2];
+  unsigned long long prefix = 0ull;
+  int shift = 53;
+  for (int pass = 0; pass < TK_POOL_PASSES; pass++) {
+    const int width = pass == TK_POOL_PASSES - 1 ? 9 : 11;
+    const int hi = shift;
+    shift -= width;
+    const uint32_t dmask = (1u << width) - 1u;
+    h[tid] = 0; h[tid + TK_P1_THREADS] = 0;
+    if (tid == 0) { s_pair[0] = -1; s_pair[1] = 0; }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < TK_P1_U; u++)
+      if ((v[u] >> 53) == 0ull && (hi >= 53 || (v[u] >> hi) == prefix)) atomicAdd(&h[(uint32_t)(v[u] >> shift) & dmask], 1);
+    __syncthreads();
+    const int l0 = h[2 * tid], l1 = h[2 * tid + 1];
+    int total;
+    const int run = tk_p1_excl_scan(l0 + l1, wsum, total);
+    if (run < k_rem && run + l0 >= k_rem) { s_pair[0] = 2 * tid; s_pair[1] = run; }
+    else if (run + l0 < k_rem && run + l0 + l1 >= k_rem) { s_pair[0] = 2 * tid + 1; s_pair[1] = run + l0; }
+    __syncthreads();
+    const int bin = s_pair[0], before = s_pair[1];
+    const int in_bin = h[bin];
+    __syncthreads();  // h / s_pair are rewritten by the next pass
+    prefix = (prefix << width) | (unsigned long long)bin;
+    k_rem -= before;
+    if (in_bin == k_rem) break;  // the whole bucket is taken (uniform; at the latest in the last pass: pairs are unique)
+  }
+  unsigned long long* out = cand + (long)seg * kmax + c_lt;
+  const unsigned long long top = (unsigned long long)S->prefix << 53;
+  int n = 0;
+#pragma unroll
+  for (int u = 0; u < TK_P1_U; u++) n += ((v[u] >> 53) == 0ull && (v[u] >> shift) <= prefix) ? 1 : 0;
+  int total;
+  int p = tk_p1_excl_scan(n, wsum, total);
+#pragma unroll
+  for (int u = 0; u < TK_P1_U; u++)
+    if ((v[u] >> 53) == 0ull && (v[u] >> shift) <= prefix) out[p++] = top | v[u];
+}
+
+struct TkWs { SegState* st; int* hist; int* blk_ties; int* blk_def; unsigned long long* cand; size_t zero_bytes, total; int maxblk, kmax, reps, tickets; TkPool pool; };
 static size_t tk_al(size_t x) { return (x + 255) / 256 * 256; }
+static int maxsize_of(const TopkInput& in) {
+  int m = 0;
+  for (int l = 0; l < in.L; l++) m = in.size[l] > m ? in.size[l] : m;
+  return m;
+}
 static TkWs tk_carve(const TopkInput& in, void* base) {
   TkWs w{};
   const long ns = (long)in.N * in.L;
@@ -784,10 +1359,22 @@ static TkWs tk_carve(const TopkInput& in, void* base) {
   auto take = [&](size_t b) { void* r = base ? (char*)base + off : nullptr; off += tk_al(b); return r; };
   w.st = (SegState*)take(ns * sizeof(SegState));
   w.hist = (int*)take(ns * 3 * TK_BINS * sizeof(int));
+  if (!w.tickets)  // large segments: the pool kernel's histograms and counters (see tk_pool_kernel)
+    w.pool.hist = (int*)take(((size_t)ns * TK_POOL_PASSES * TK_BINS + (size_t)ns * 8) * sizeof(int));
   w.zero_bytes = off;  // states + histograms are zeroed per call
   w.blk_ties = (int*)take(ns * w.maxblk * sizeof(int));
   w.blk_def = w.tickets ? nullptr : (int*)take(ns * w.maxblk * sizeof(int));
   w.cand = (unsigned long long*)take(ns * kmax * sizeof(unsigned long long));
+  if (!w.tickets) {
+    long per = 0;
+    for (int l = 0; l < in.L; l++) {
+      w.pool.cap[l] = tk_pool_cap(in.size[l], in.k[l]);
+      w.pool.off[l] = per;
+      per += w.pool.cap[l];
+    }
+    w.pool.per_img = per;
+    w.pool.mem = (unsigned long long*)take((size_t)in.N * per * sizeof(unsigned long long));
+  }
   w.total = off;
   return w;
 }
@@ -840,6 +1427,57 @@ int topk_select(const TopkInput& in, bool use_thr, float xmin, uint32_t* sel, in
     hipLaunchKernelGGL(tk_fused_kernel, grid, block, 0, s, P, w.st, w.hist, w.blk_ties, w.cand, w.kmax);
     D2_LAUNCH_OK();
   } else {
+  // large segments: two reads of the scores (tk_gather_kernel / tk_pool_kernel).  D2AMD_TOPK_LEGACY: the five-read
+  // chain below (A/B and test switch).  The pool kernel's workgroups wait for each other per segment: 32 of them fit
+  // on the device many times over, and the dispatcher hands out workgroups in order (segments are consecutive).
+  static const bool legacy = getenv("D2AMD_TOPK_LEGACY") != nullptr;
+  static const int pool_g = [] {
+    const int g = getenv("D2AMD_TOPK_POOL_G") ? atoi(getenv("D2AMD_TOPK_POOL_G")) : 16;
+    return g < 1 ? 1 : g > TK_POOL_G_MAX ? TK_POOL_G_MAX : g;
+  }();
+  if (!w.tickets && !legacy && pool_g <= resident) {
+    const dim3 ggrid(cdiv(cdiv(maxsize_of(in), TK_CHUNK), TK_GSPAN), in.N * in.L);
+    // 16-B loads: every segment starts on a 16-B boundary (spans start at multiples of 32,768 elements)
+    static const bool no_vec = getenv("D2AMD_TOPK_NO_VEC") != nullptr;  // A/B and test switch
+    bool vec = !no_vec;
+    for (int l = 0; l < in.L; l++) vec = vec && ((uintptr_t)in.ptr[l] % 16 == 0) && (in.stride[l] % 4 == 0 || in.N == 1);
+    static const bool old_hist0 = getenv("D2AMD_TOPK_OLD_HIST0") != nullptr;  // A/B switch
+    if (old_hist0) hipLaunchKernelGGL(tk_hist_kernel<0>, grid, block, 0, s, P, w.st, w.hist);
+    else {
+      static const int copies = getenv("D2AMD_TOPK_HIST_COPIES") ? atoi(getenv("D2AMD_TOPK_HIST_COPIES")) : 8;
+      if (copies <= 4) hipLaunchKernelGGL((tk_hist0_span_kernel<4, false>), ggrid, block, 0, s, P, w.hist);
+      else if (!vec) hipLaunchKernelGGL((tk_hist0_span_kernel<8, false>), ggrid, block, 0, s, P, w.hist);
+      else hipLaunchKernelGGL((tk_hist0_span_kernel<8, true>), ggrid, block, 0, s, P, w.hist);
+    }
+    const char* stamp_path = getenv("D2AMD_TOPK_STAMPS");  // profiling only: per-workgroup stamps of the gather pass
+    const size_t stamp_n = (size_t)grid.x * grid.y * 6;
+    if (stamp_path) {
+      D2_HIP_OK(hipMalloc(&P.stamps, stamp_n * 8));
+      D2_HIP_OK(hipMemsetAsync(P.stamps, 0, stamp_n * 8, s));
+    }
+    if (vec) hipLaunchKernelGGL(tk_gather_kernel<true>, ggrid, block, 0, s, P, w.st, w.hist, w.cand, w.kmax, w.pool);
+    else hipLaunchKernelGGL(tk_gather_kernel<false>, ggrid, block, 0, s, P, w.st, w.hist, w.cand, w.kmax, w.pool);
+    if (stamp_path) {
+      D2_HIP_OK(hipStreamSynchronize(s));
+      unsigned long long* h = (unsigned long long*)malloc(stamp_n * 8);
+      D2_HIP_OK(hipMemcpy(h, P.stamps, stamp_n * 8, hipMemcpyDeviceToHost));
+      FILE* f = fopen(stamp_path, "w");
+      if (f) {
+        for (size_t i = 0; i < stamp_n / 6; i++)
+          if (h[6 * i])
+            fprintf(f, "%zu %llu %llu %llu %llu %llu %llu\n", i, h[6 * i], h[6 * i + 1], h[6 * i + 2], h[6 * i + 3], h[6 * i + 4], h[6 * i + 5]);
+        fclose(f);
+      }
+      free(h);
+      (void)hipFree(P.stamps);
+      P.stamps = nullptr;
+    }
+    static const bool no_small = getenv("D2AMD_TOPK_POOL_NO_SMALL") != nullptr;
+    TkPool Q = w.pool;
+    Q.no_small = no_small ? 1 : 0;
+    hipLaunchKernelGGL(tk_pool1_kernel, segs, dim3(TK_P1_THREADS), 0, s, P, w.st, w.cand, w.kmax, Q);
+    hipLaunchKernelGGL(tk_pool_kernel, dim3(pool_g, in.N * in.L), block, 0, s, P, w.st, w.cand, w.kmax, Q);
+  } else {
   hipLaunchKernelGGL(tk_hist_kernel<0>, grid, block, 0, s, P, w.st, w.hist);
   if (!w.tickets) hipLaunchKernelGGL(tk_scan_kernel<0>, segs, block, 0, s, P, w.st, w.hist);
   hipLaunchKernelGGL(tk_hist_kernel<1>, grid, block, 0, s, P, w.st, w.hist);
@@ -849,6 +1487,7 @@ int topk_select(const TopkInput& in, bool use_thr, float xmin, uint32_t* sel, in
   hipLaunchKernelGGL(tk_ties_kernel, grid, block, 0, s, P, w.st, w.blk_ties);
   if (!w.tickets) hipLaunchKernelGGL(tk_ties_scan_kernel, segs, block, 0, s, P, w.st, w.blk_ties);
   hipLaunchKernelGGL(tk_compact_kernel, grid, block, 0, s, P, w.st, w.blk_ties, w.cand, w.kmax);
+  }
   }
   if (w.kmax <= TK_RANK_MAX && !no_fused) {  // (the A/B switch also keeps the bitonic sort under test)
     static const bool no_epi = getenv("D2AMD_RPN_NO_FUSED_DECODE") != nullptr;  // A/B switch
@@ -873,8 +1512,20 @@ int topk_select(const TopkInput& in, bool use_thr, float xmin, uint32_t* sel, in
                      run, sel, cnt);
   D2_LAUNCH_OK();
   if (runs > 1) {
-    hipLaunchKernelGGL(tk_merge_kernel, dim3(in.N * in.L, cdiv(w.kmax, 1024)), dim3(256), 0, s, P, w.st, w.cand, w.kmax,
-                       run, sel);
+    const size_t others = (size_t)(runs - 1) * run * 8;
+    static const bool no_lds_merge = getenv("D2AMD_TOPK_MERGE_GLOBAL") != nullptr;  // A/B switch
+    if (others <= 128 * 1024 && run % 1024 == 0 && !no_lds_merge) {
+      static bool attr_set = false;
+      if (!attr_set) {
+        D2_HIP_OK(hipFuncSetAttribute((const void*)tk_merge_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(tk_merge_lds_kernel, dim3(in.N * in.L, cdiv(w.kmax, 1024)), dim3(1024), others, s, P, w.st, w.cand,
+                         w.kmax, run, sel);
+    } else {
+      hipLaunchKernelGGL(tk_merge_kernel, dim3(in.N * in.L, cdiv(w.kmax, 1024)), dim3(256), 0, s, P, w.st, w.cand, w.kmax,
+                         run, sel);
+    }
     D2_LAUNCH_OK();
   }
   return D2AMD_OK;
