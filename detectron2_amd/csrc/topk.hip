@@ -662,7 +662,14 @@ constexpr int TK_RUN_MAX = 16384;  // one run in LDS: 128 KB
 // run length of a launch whose largest segment selects kmax pairs: one run while it fits, else 4,096 -- a 16,384-pair
 // bitonic sort walks 16 pairs per thread through 105 steps (250 us for RetinaNet's 20,000 per level, r02 profile);
 // five 4,096 runs sorted by five workgroups + the rank merge take a quarter of that
-static inline int tk_run_for(int kmax) { return kmax <= 4096 ? TK_RUN_MAX : 4096; }  // (<= 4,096: one run)
+static inline int tk_run_for(int kmax) {  // (<= 4,096: one run)
+  static const int run_env = getenv("D2AMD_TOPK_RUN") ? atoi(getenv("D2AMD_TOPK_RUN")) : 0;  // A/B switch: 1024 / 2048 / 4096
+  // 2,048 while the other runs of a segment fit tk_merge_lds_kernel's LDS (k <= 20,480: RetinaNet's 20,000), else 4,096.
+  // Measured for 10 x 20,000: sort + merge 36.2 + 9.9 us with 4,096, 21.1 + 15.1 with 2,048, 14.7 + 24.0 with 1,024.
+  const int dflt = (long)((kmax + 2047) / 2048 - 1) * 2048 * 8 <= 152 * 1024 ? 2048 : 4096;
+  const int run = (run_env == 1024 || run_env == 2048 || run_env == 4096) ? run_env : dflt;
+  return kmax <= 4096 ? TK_RUN_MAX : run;
+}
 
 __global__ __launch_bounds__(1024) void tk_sort_kernel(TkParams P, const SegState* __restrict__ st,
                                                       unsigned long long* __restrict__ cand, int kmax, int TK_RUN,
@@ -818,7 +825,7 @@ __global__ __launch_bounds__(256) void tk_merge_kernel(TkParams P, const SegStat
 //                     (all scores nearly equal: an untrained head) is selected by the same kernel FROM THE SCORES
 //                     (filtering bucket b0 on the fly: slow -- 16 workgroups per segment -- but exact and bounded).
 // Measured (selection alone, 2 x 16.1 M logits, k = 20,000 x 5 levels, one box): 0.263 ms with the five-read chain,
-// 0.144 ms with this one (pass 0 34 us, gather ~30 us, pool 13 us, sort 36 us, LDS-staged rank merge 10 us).
+// 0.135 ms with this one (pass 0 34 us, gather ~30 us, pool 13 us, sort 21 us, LDS-staged rank merge 15 us).
 constexpr int TK_GSPAN = 8;        // chunks per workgroup of the gather pass (32,768 scores)
 constexpr int TK_GGROUP = 2;       // chunks per load group: 32 values per thread, two groups in flight
 constexpr int TK_STAGE = 1024;     // staged pairs per list and workgroup (3 % of its scores)
@@ -1514,10 +1521,10 @@ int topk_select(const TopkInput& in, bool use_thr, float xmin, uint32_t* sel, in
   if (runs > 1) {
     const size_t others = (size_t)(runs - 1) * run * 8;
     static const bool no_lds_merge = getenv("D2AMD_TOPK_MERGE_GLOBAL") != nullptr;  // A/B switch
-    if (others <= 128 * 1024 && run % 1024 == 0 && !no_lds_merge) {
+    if (others <= 152 * 1024 && run % 1024 == 0 && !no_lds_merge) {
       static bool attr_set = false;
       if (!attr_set) {
-        D2_HIP_OK(hipFuncSetAttribute((const void*)tk_merge_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        D2_HIP_OK(hipFuncSetAttribute((const void*)tk_merge_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
         attr_set = true;
       }
       hipLaunchKernelGGL(tk_merge_lds_kernel, dim3(in.N * in.L, cdiv(w.kmax, 1024)), dim3(1024), others, s, P, w.st, w.cand,
