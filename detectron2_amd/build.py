@@ -40,8 +40,16 @@ SOURCES = {
     "polygon_masks.hip": ["-ffp-contract=off"],
     "layout.hip": [],
 }
+# -packed-fp32-ops: no v_pk_{fma,mul,add}_f32.  MEASURED (profiles/r04/LOG.md, "packed fp32 ops beside an MFMA kernel"):
+# the DCN data-gradient kernel, whose consumer waves the compiler had vectorised into packed fp32 math, produced wrong
+# d(offset) sums in lanes 48-63 of a wave (the last of the four 16-lane passes) in about every second call -- but only
+# while ANOTHER kernel full of MFMAs (the weight-gradient GEMM, on a second stream) was running on the same CUs, never
+# alone; without the packed ops 80 calls were bit-identical.  The hazard is not one the compiler's recogniser knows,
+# so the library does without the instructions everywhere: any of its kernels may share a CU with somebody's GEMM.
+# Same-box A/B of the two builds: headline 0.3999 / 0.4023 ms with, 0.4021 / 0.4001 without; dcn_r50 unchanged.
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall",
-          "-Wno-unused-function", "-Wno-unused-variable", "-fhip-fp32-correctly-rounded-divide-sqrt"]
+          "-Wno-unused-function", "-Wno-unused-variable", "-fhip-fp32-correctly-rounded-divide-sqrt",
+          "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 
 
 def _hipcc():

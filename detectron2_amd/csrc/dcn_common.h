@@ -137,10 +137,20 @@ static inline size_t dcn_gather_col_bytes(const DcnShape& s, size_t es) { return
 static inline size_t dcn_gather_cnt_bytes(const DcnShape& s) { return ((size_t)s.B * s.H * s.W + 1) * 4; }
 static inline size_t dcn_gather_list_bytes(const DcnShape& s) { return (size_t)s.B * s.H * s.W * 128 * 8; }
 static inline size_t dcn_gather_ovf_bytes(const DcnShape& s) { return (size_t)s.P * s.K2 * 4 * 16; }
+// Optional second stream of one backward call (deform_conv.hip: dcn_side()).  The sample binning -- needed by the column
+// gather only -- and whatever `work` enqueues (the weight-gradient GEMM: it reads dY and the saved column, nothing of the
+// data path) run there beside the data-gradient kernel, which is a latency chain that leaves the chip half idle.
+struct DcnSide {
+  hipStream_t stream;
+  hipEvent_t fork, bin, join;
+  int (*work)(void* ctx, hipStream_t side);  // enqueued on `stream` behind the binning (may be null)
+  void* ctx;
+};
 template <typename T>
 int dcn_tc_backward_data_gather(const DcnShape& s, const TcBwPlan& pl, const void* x_nhwc, const void* offset,
                                 const void* mask, const void* weight, const void* gout_nhwc, void* gx_t, float* goff,
-                                float* gmask, void* wp, const DcnGatherWs& gw, hipStream_t st);
+                                float* gmask, void* wp, const DcnGatherWs& gw, hipStream_t st,
+                                const DcnSide* side = nullptr);
 
 struct TcBwwPlan {
   bool ok;

@@ -637,6 +637,33 @@ static int fwd_host(const DcnShape& s, const void* x, const void* offset, const 
   return D2AMD_OK;
 }
 
+// the second stream of a backward call (DcnSide), one per device, created on first use.  D2AMD_DCN_NO_SIDE: none.
+static DcnSide* dcn_side() {
+  static DcnSide table[64];
+  static bool made[64] = {};
+  static const bool off = getenv("D2AMD_DCN_NO_SIDE") != nullptr;
+  int dev = 0;
+  if (off || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!made[dev]) {
+    DcnSide t{};
+    if (hipStreamCreateWithFlags(&t.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&t.bin, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&t.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+    table[dev] = t;
+    made[dev] = true;
+  }
+  return &table[dev];
+}
+
+template <typename T>
+struct BwwGemmCall { const DcnShape* s; const BwwGemmPlan* gp; const void* gout; const void* col; float* gwr; void* gweight; };
+template <typename T>
+static int bww_gemm_on(void* ctx, hipStream_t side) {
+  const BwwGemmCall<T>* c = (const BwwGemmCall<T>*)ctx;
+  return dcn_bww_gemm<T>(*c->s, *c->gp, c->gout, c->col, c->gwr, c->gweight, side);
+}
+
 template <typename T>
 static int bwd_host(const DcnShape& s, const void* x, const void* offset, const void* mask, const void* weight,
                     const void* gout, void* gin, void* goffset, void* gmask, void* gweight, void* gbias,
@@ -664,21 +691,40 @@ static int bwd_host(const DcnShape& s, const void* x, const void* offset, const 
         return D2AMD_EUNSUPPORTED;
       }
       const bool need_data = gin || goffset || (gmask && mask);
+      const BwwGemmPlan gp = dcn_bww_gemm_plan(s, (int)w.dtype);
+      const bool gemm_w = gweight && w.col_saved && gp.ok;  // dW = dY^T col from the column the forward saved
+      bool gemm_done = false;
       if (need_data) {
         float* goff_f = goffset ? w.goff : nullptr;
         float* gmask_f = (gmask && mask) ? w.gmask : nullptr;
-        rc = dcn_tc_backward_data_gather<T>(s, bp, x, offset, mask, weight, gout, gin, goff_f, gmask_f, w.wt, w.gather, st);
+        // second stream: the sample binning and the weight-gradient GEMM (dY and the saved column in, its own partial
+        // tiles and grad_weight out: nothing the data path touches) run beside the data-gradient kernel
+        DcnSide* sd = dcn_side();
+        DcnSide side{};
+        BwwGemmCall<T> call{&s, &gp, gout, w.col_saved, w.gwr, gweight};
+        static const int side_mode = getenv("D2AMD_DCN_SIDE_MODE") ? atoi(getenv("D2AMD_DCN_SIDE_MODE")) : 3;  // A/B: 1 = binning only, 2 = GEMM only
+        if (sd) {
+          side = *sd;
+          side.work = (gemm_w && (side_mode & 2)) ? bww_gemm_on<T> : nullptr;
+          side.ctx = &call;
+          side.fork = (side_mode & 1) ? side.fork : nullptr;  // (null: the binning stays on the caller's stream)
+        }
+        rc = dcn_tc_backward_data_gather<T>(s, bp, x, offset, mask, weight, gout, gin, goff_f, gmask_f, w.wt, w.gather, st,
+                                            sd ? &side : nullptr);
         if (rc) return rc;
         rc = cvt_grads<T>(s, w, goffset, (gmask && mask) ? gmask : nullptr, st);
         if (rc) return rc;
+        if (sd) {
+          D2_HIP_OK(hipStreamWaitEvent(st, side.join, 0));
+          gemm_done = side.work != nullptr;
+        }
       }
-      const BwwGemmPlan gp = dcn_bww_gemm_plan(s, (int)w.dtype);
-      const bool gemm_w = gweight && w.col_saved && gp.ok;  // dW = dY^T col from the column the forward saved
       if ((gweight && !gemm_w) || gbias) {
         rc = launch_transpose<T, T>((const T*)gout, (T*)w.gout_nhwc, s.B, s.L, s.Co, st);  // -> [b][Co][l]
         if (rc) return rc;
       }
-      if (gemm_w) {
+      if (gemm_done) {
+      } else if (gemm_w) {
         rc = dcn_bww_gemm<T>(s, gp, gout, w.col_saved, w.gwr, gweight, st);
         if (rc) return rc;
       } else if (gweight) {

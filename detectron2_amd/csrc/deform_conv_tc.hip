@@ -1960,7 +1960,7 @@ __global__ __launch_bounds__(256) void dcn_gather_dx_kernel(int npix, int C, con
 template <typename T>
 int dcn_tc_backward_data_gather(const DcnShape& s, const TcBwPlan& pl, const void* x_nhwc, const void* offset,
                                 const void* mask, const void* weight, const void* gout_nhwc, void* gx_t, float* goff,
-                                float* gmask, void* wp, const DcnGatherWs& gw, hipStream_t st) {
+                                float* gmask, void* wp, const DcnGatherWs& gw, hipStream_t st, const DcnSide* side) {
   const long npix = (long)s.B * s.H * s.W;
   bool goff_zeroed = false;
   {  // per-call state: pixel counters + the overflow counter (one region) -- and, when the tiles of a pixel are split
@@ -1980,9 +1980,22 @@ int dcn_tc_backward_data_gather(const DcnShape& s, const TcBwPlan& pl, const voi
   }
   int* ovf_cnt = gw.cnt + npix;
   const long nsamp = (long)s.P * s.K2;
-  hipLaunchKernelGGL((dcn_bin_samples_kernel<T>), dim3(cdiv(nsamp, 256)), dim3(256), 0, st, s, (const T*)offset,
+  // the binning (behind the zero fill of its counters) -- on the side stream when there is one: only the column gather
+  // at the end of this function reads the lists
+  hipStream_t bst = st;
+  if (side) {
+    D2_HIP_OK(hipEventRecord(side->bin, st));  // (the fork point)
+    D2_HIP_OK(hipStreamWaitEvent(side->stream, side->bin, 0));
+    if (side->fork) bst = side->stream;
+  }
+  hipLaunchKernelGGL((dcn_bin_samples_kernel<T>), dim3(cdiv(nsamp, 256)), dim3(256), 0, bst, s, (const T*)offset,
                      (const T*)mask, gw.cnt, (DgEntry*)gw.lists, ovf_cnt, (DgOverflow*)gw.ovf);
   D2_LAUNCH_OK();
+  if (side) {
+    D2_HIP_OK(hipEventRecord(side->bin, side->stream));
+    if (side->work) { const int wrc = side->work(side->ctx, side->stream); if (wrc) return wrc; }
+    D2_HIP_OK(hipEventRecord(side->join, side->stream));
+  }
   {
     const long groups16 = (long)s.G * s.K2 * (s.Cg / 64) * 2 * (s.Cog / 16) * 64;
     const int blocks = cdiv(groups16, 256) > 8192 ? 8192 : cdiv(groups16, 256);
@@ -2006,6 +2019,7 @@ int dcn_tc_backward_data_gather(const DcnShape& s, const TcBwPlan& pl, const voi
   { const int lrc = launch_bwd_data_tc<T>(s, a, (a.total + 7) / 8 * 8, pl.lds, st); if (lrc) return lrc; }
   if (timed) timing_end("dcn_bwd_data", st);
   D2_LAUNCH_OK();
+  if (side) D2_HIP_OK(hipStreamWaitEvent(st, side->bin, 0));  // (also when nothing gathers: the counters are reused)
   if (gx_t) {
     const bool timed2 = timing_begin("dcn_bwd_gather", st);
     const dim3 grid((unsigned)cdiv(npix, 4));
@@ -2023,10 +2037,10 @@ int dcn_tc_backward_data_gather(const DcnShape& s, const TcBwPlan& pl, const voi
 }
 template int dcn_tc_backward_data_gather<bf16_t>(const DcnShape&, const TcBwPlan&, const void*, const void*, const void*,
                                                  const void*, const void*, void*, float*, float*, void*,
-                                                 const DcnGatherWs&, hipStream_t);
+                                                 const DcnGatherWs&, hipStream_t, const DcnSide*);
 template int dcn_tc_backward_data_gather<f16_t>(const DcnShape&, const TcBwPlan&, const void*, const void*, const void*,
                                                 const void*, const void*, void*, float*, float*, void*,
-                                                const DcnGatherWs&, hipStream_t);
+                                                const DcnGatherWs&, hipStream_t, const DcnSide*);
 
 template <typename T>
 int dcn_tc_backward_data(const DcnShape& s, const TcBwPlan& pl, const void* x_nhwc, const void* offset,

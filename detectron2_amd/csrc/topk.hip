@@ -1060,7 +1060,7 @@ __global__ __launch_bounds__(TK_THREADS, 4) void tk_gather_kernel(TkParams P, Se
     int p_def = s_base[0] + (my & 0xffff), p_pl = s_base[1] + (my >> 16);
 #pragma unroll
     for (int j = 0; j < TK_ITEMS; j++) {
-      uint32_t key;
+      uint32_t key = 0;
       const int c = j * TK_THREADS + tid < lc ? cls(w[j], key) : 0;
       const unsigned long long e = ((unsigned long long)key << 32) | (uint32_t)(base + j * TK_THREADS + tid);
       if (c == 1) out_def[p_def++] = e;

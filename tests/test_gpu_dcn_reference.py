@@ -62,7 +62,9 @@ def compare(tag, got, exp, bound_fn):
         r = float((d / np.maximum(b, 1e-300)).max())
         _dump(tag, k, r)
         if not (d <= b).all():
-            bad[k] = (r, int((d > b).sum()), int(d.size))
+            where = np.argwhere(d > b)[:6]
+            bad[k] = (r, int((d > b).sum()), int(d.size),
+                      [(tuple(int(q) for q in i), float(got[k][tuple(i)]), float(exp[k][tuple(i)])) for i in where])
     assert not bad, (tag, bad)
 
 

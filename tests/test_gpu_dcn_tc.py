@@ -377,3 +377,23 @@ def test_columns_are_not_kept_when_the_weight_needs_no_gradient():
     assert y.grad_fn is not None and getattr(y.grad_fn, "columns", None) is None
     y.backward(go.to(DEV))
     assert xt.grad is not None
+
+
+def test_backward_is_repeatable_beside_its_own_weight_gradient_gemm():
+    """The channels_last backward runs the sample binning and the weight-gradient GEMM on a second stream beside the
+    data-gradient kernel (deform_conv.hip: dcn_side).  Every output of 12 forward + backward calls of the res3 block is
+    bit-identical to the first call's -- with the compiler's packed fp32 math in the data-gradient kernel, d(offset)
+    differed in a few 4-position groups in about every second call (round 4; build.py: -packed-fp32-ops)."""
+    import _dcn_cases as dc
+    from detectron2_amd import layers
+
+    for dt in (torch.bfloat16, torch.float16):
+        case = dc.make_full("res3", rounding=dt)
+        first = None
+        for it in range(12):
+            out = dc.run_module(layers.modulated_deform_conv, layers.deform_conv, case, "cuda", dt, True)
+            if first is None:
+                first = out
+                continue
+            for k in out:
+                assert np.array_equal(out[k], first[k]), (str(dt), it, k, int((out[k] != first[k]).sum()))

@@ -258,3 +258,41 @@ def test_polygon_masks_host_logic_follows_the_reference():
     assert all(np.array_equal(x, y) for x, y in zip(c.polygons[3], a.polygons[0]))
     with pytest.raises(AssertionError):
         PolygonMasks.cat([])
+
+
+def test_no_packed_fp32_instructions_in_the_library(tmp_path):
+    """detectron2_amd/build.py compiles with -packed-fp32-ops (no v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): measured in
+    round 4, a kernel whose fp32 math the compiler had packed produced wrong sums in lanes 48-63 while an MFMA kernel of
+    another stream shared its CUs (profiles/r04/LOG.md).  The disassembly of every gfx950 code object holds none."""
+    import shutil
+    import struct
+    import subprocess
+
+    objdump = shutil.which("llvm-objdump") or "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    from detectron2_amd import build as d2build
+
+    data = open(d2build.LIB, "rb").read()
+    magic, pos, found, objects = b"__CLANG_OFFLOAD_BUNDLE__", 0, 0, 0
+    while True:
+        off = data.find(magic, pos)
+        if off < 0:
+            break
+        pos = off + len(magic)
+        (n,) = struct.unpack_from("<Q", data, off + 24)
+        p = off + 32
+        for _ in range(n):
+            o, sz, ts = struct.unpack_from("<QQQ", data, p)
+            triple = data[p + 24:p + 24 + ts]
+            p += 24 + ts
+            if b"gfx950" not in triple or sz == 0:
+                continue
+            co = tmp_path / f"co_{off}.elf"
+            co.write_bytes(data[off + o:off + o + sz])
+            out = subprocess.run([objdump, "-d", "--mcpu=gfx950", str(co)], capture_output=True, text=True).stdout
+            objects += 1
+            assert "v_mfma" in out or "s_endpgm" in out  # the disassembly worked
+            found += sum(out.count(op) for op in ("v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32"))
+    assert objects >= 10, objects
+    assert found == 0, found
