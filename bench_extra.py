@@ -24,6 +24,7 @@ import bench as B
 
 # ---------------------------------------------------------------------------------------------- maskrcnn_infer
 INFER_PRE_NMS, INFER_POST_NMS, INFER_SCORE_THRESH, INFER_NMS, INFER_DETS = 1000, 1000, 0.05, 0.5, 100
+INFER_LOOP = os.environ.get("D2AMD_BENCH_INFER_LOOP", "0") == "1"  # A/B: the reference's per-image box-head inference
 ORIG_H, ORIG_W = 800, 1333   # the image size detector_postprocess pastes at (BASELINE: 1333x800 inputs)
 
 
@@ -97,13 +98,20 @@ def infer_step(w, run=None):
     box_feats = run("roi_align_box_fwd", lambda: w.box_pooler(w.feats_nograd, [Boxes(b) for b in pboxes]))
 
     def detect():
-        dets = []
-        for i in range(n):
-            scores = torch.softmax(w.cls_logits[i], dim=1)                     # fast_rcnn.py:predict_probs
-            boxes = _apply_deltas(w.box_deltas[i], pboxes[i])                  # predict_boxes
-            dets.append(fast_rcnn_inference_single_image(boxes, scores, (B.IMG_H, B.IMG_W), INFER_SCORE_THRESH,
-                                                         INFER_NMS, INFER_DETS))
-        return dets
+        # predict_probs / predict_boxes over the batch (fast_rcnn.py:FastRCNNOutputLayers: one softmax, one apply_deltas,
+        # split per image), then fast_rcnn_inference: fused (d2amd_fast_rcnn_filter + ONE batched NMS: two host syncs per
+        # batch) or -- D2AMD_BENCH_INFER_LOOP=1, the A/B -- the reference's per-image data flow on this package's ops
+        probs = torch.softmax(torch.cat([w.cls_logits[i] for i in range(n)]), dim=1)
+        boxes = _apply_deltas(torch.cat([w.box_deltas[i] for i in range(n)]), torch.cat(pboxes))
+        rows = [int(p.shape[0]) for p in pboxes]
+        probs, boxes = probs.split(rows), boxes.reshape(boxes.shape[0], -1).split(rows)
+        if INFER_LOOP:
+            return [fast_rcnn_inference_single_image(boxes[i].reshape(rows[i], -1, 4), probs[i], (B.IMG_H, B.IMG_W),
+                                                     INFER_SCORE_THRESH, INFER_NMS, INFER_DETS) for i in range(n)]
+        from detectron2_amd.modeling import fast_rcnn_inference_fused
+        res, _rows = fast_rcnn_inference_fused(boxes, probs, [(B.IMG_H, B.IMG_W)] * n, INFER_SCORE_THRESH, INFER_NMS,
+                                               INFER_DETS)
+        return [(r.pred_boxes.tensor, r.scores, r.pred_classes, r.num_candidates) for r in res]
 
     dets = run("fast_rcnn_inference", detect)
     mask_feats = run("roi_align_mask_fwd", lambda: w.mask_pooler(w.feats_nograd, [Boxes(d[0]) for d in dets]))
@@ -173,7 +181,8 @@ def bench_maskrcnn_infer(args, ctx):
         "config": {"workload": "maskrcnn_r50fpn_inference_hotpath_bs2_800x1344 (SURVEY 8(d): paste / box-head NMS rows)",
                    "layout": args.layout, "global_batch": world * n_img, "proposals_per_image": INFER_POST_NMS,
                    "candidates_above_score_thresh": [d[3] for d in out["detections"]], "detections": ndet,
-                   "paste_size": [ORIG_H, ORIG_W], "execution": "eager, host syncs where the reference has them",
+                   "paste_size": [ORIG_H, ORIG_W], "execution": ("eager; box-head inference per image as the reference (A/B)" if INFER_LOOP else
+                                 "eager; box-head inference fused over the batch (2 host syncs), the other syncs where the reference has them"),
                    "parallelism": f"dp{world}: images sharded, replicas only (inference, no collective)"},
         "roofline": roof,
         "ops": {k: {"ms_per_step": round(v, 4)} for k, v in t.totals_ms().items()},

@@ -1,0 +1,201 @@
+// Box-head inference in front of the per-class NMS (the caller between the box pooler and batched_nms on the Mask R-CNN
+// inference path):
+//   replaces  detectron2/modeling/roi_heads/fast_rcnn.py:134-158 (fast_rcnn_inference_single_image up to the NMS: the
+//             finite-row mask [two reductions + boolean index], Boxes.clip over all R*K boxes, `scores > thresh`,
+//             `nonzero` [a host sync per image], two boolean-mask gathers) for ALL images of the batch, without a sync.
+// Three small launches: per-row candidate counts (a wave per row), an exclusive scan of them per image, the ordered
+// write -- the candidates come out in torch.nonzero's row-major (row, class) order, which is what makes batched_nms'
+// result (keep order among equal scores) the reference's.  Nothing here is arithmetic: compares, a clamp, copies.
+// Roofline: HBM; bytes = R * (K + 1 + 4 K_box) * 4 read twice (count, write) + 36 B per candidate.
+#include "common.h"
+
+namespace d2amd {
+
+constexpr int BH_WAVES = 16;  // rows per workgroup (a wave per row)
+
+struct BhImages {
+  const float* boxes[D2AMD_POOLER_MAX_IMAGES];   // [R_i][Kb * 4]
+  const float* scores[D2AMD_POOLER_MAX_IMAGES];  // [R_i][K + 1]
+  int rows[D2AMD_POOLER_MAX_IMAGES];
+  int row_base[D2AMD_POOLER_MAX_IMAGES + 1];     // prefix of rows: an image's slice of the per-row arrays
+  float h[D2AMD_POOLER_MAX_IMAGES], w[D2AMD_POOLER_MAX_IMAGES];
+  long cap_base[D2AMD_POOLER_MAX_IMAGES + 1];    // prefix of rows * K: an image's slice of the candidate arrays
+  int n, K, Kb;
+  float thr;
+};
+
+__device__ __forceinline__ bool bh_finite(float v) { return fabsf(v) <= 3.402823466e+38f; }  // (false for NaN / inf)
+
+// the image of this workgroup's rows (constant indices only into the by-value struct)
+__device__ __forceinline__ void bh_image(const BhImages& I, int img, const float*& boxes, const float*& scores, int& rows,
+                                         int& row_base, long& cap_base, float& h, float& w) {
+  boxes = I.boxes[0]; scores = I.scores[0]; rows = I.rows[0]; row_base = I.row_base[0]; cap_base = I.cap_base[0];
+  h = I.h[0]; w = I.w[0];
+#pragma unroll
+  for (int q = 1; q < D2AMD_POOLER_MAX_IMAGES; q++)
+    if (q == img) {
+      boxes = I.boxes[q]; scores = I.scores[q]; rows = I.rows[q]; row_base = I.row_base[q]; cap_base = I.cap_base[q];
+      h = I.h[q]; w = I.w[q];
+    }
+}
+
+// fast_rcnn.py:134-137 + :148: rowcnt[row] = #classes with score > thr of a row whose boxes and scores are all finite
+__global__ __launch_bounds__(64 * BH_WAVES) void bh_count_kernel(const BhImages I, int* __restrict__ rowcnt) {
+  const int img = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float *boxes, *scores;
+  int rows, row_base; long cap_base; float h, w;
+  bh_image(I, img, boxes, scores, rows, row_base, cap_base, h, w);
+  const int r = blockIdx.x * BH_WAVES + wave;
+  if (r >= rows) return;  // uniform per wave
+  const float* s = scores + (long)r * (I.K + 1);
+  const float* b = boxes + (long)r * (I.Kb * 4);
+  bool fin = true;
+  int cnt = 0;
+  for (int k = lane; k <= I.K; k += 64) {
+    const float v = s[k];
+    fin = fin && bh_finite(v);
+    cnt += (k < I.K && v > I.thr) ? 1 : 0;
+  }
+  for (int k = lane; k < I.Kb * 4; k += 64) fin = fin && bh_finite(b[k]);
+  const bool all_fin = __ballot(!fin) == 0ull;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
+  if (lane == 0) rowcnt[row_base + r] = all_fin ? cnt : -1;  // (-1: a dropped row)
+}
+
+// exclusive scans of an image's row counts and of its kept-row flags (one 1,024-thread workgroup per image; the two
+// travel as one 64-bit sum); counts[img] = the candidates.  rowidx[row] = the row's index among the rows that are not
+// dropped: what the reference reports as `filter_inds[:, 0]` (it indexes boxes[valid_mask], fast_rcnn.py:135-137)
+__global__ __launch_bounds__(1024) void bh_scan_kernel(const BhImages I, const int* __restrict__ rowcnt,
+                                                       int* __restrict__ rowoff, int* __restrict__ rowidx,
+                                                       int64_t* __restrict__ counts) {
+  const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float *boxes, *scores;
+  int rows, row_base; long cap_base; float h, w;
+  bh_image(I, img, boxes, scores, rows, row_base, cap_base, h, w);
+  __shared__ long long wsum[16];
+  __shared__ long long s_run;
+  if (tid == 0) s_run = 0;
+  __syncthreads();
+  for (int r0 = 0; r0 < rows; r0 += 1024) {  // uniform
+    const int r = r0 + tid;
+    const int c = r < rows ? rowcnt[row_base + r] : -1;
+    const long long v = c >= 0 ? ((long long)c | (1ll << 32)) : 0ll;  // candidates | kept row << 32
+    long long x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const long long y = __shfl_up(x, d, 64);
+      if (lane >= d) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    long long base = s_run, total = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const long long t = wsum[i];
+      if (i < wave) base += t;
+      total += t;
+    }
+    if (r < rows) {
+      const long long e = base + x - v;
+      rowoff[row_base + r] = (int)(e & 0xffffffffll);
+      rowidx[row_base + r] = (int)(e >> 32);
+    }
+    __syncthreads();
+    if (tid == 0) s_run += total;
+    __syncthreads();
+  }
+  if (tid == 0) counts[img] = s_run & 0xffffffffll;
+}
+
+// fast_rcnn.py:141-158: the candidates of a row, classes ascending, at the row's offset: clipped box (Boxes.clip:
+// x to [0, w], y to [0, h]), score, class, row
+__global__ __launch_bounds__(64 * BH_WAVES) void bh_write_kernel(const BhImages I, const int* __restrict__ rowcnt,
+                                                                 const int* __restrict__ rowoff,
+                                                                 const int* __restrict__ rowidx,
+                                                                 float4* __restrict__ out_boxes, float* __restrict__ out_scores,
+                                                                 int64_t* __restrict__ out_classes,
+                                                                 int64_t* __restrict__ out_rows) {
+  const int img = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float *boxes, *scores;
+  int rows, row_base; long cap_base; float h, w;
+  bh_image(I, img, boxes, scores, rows, row_base, cap_base, h, w);
+  const int r = blockIdx.x * BH_WAVES + wave;
+  if (r >= rows) return;  // uniform per wave
+  if (rowcnt[row_base + r] <= 0) return;  // (no candidate, or a dropped row)
+  const int ridx = rowidx[row_base + r];
+  const float* s = scores + (long)r * (I.K + 1);
+  const float* b = boxes + (long)r * (I.Kb * 4);
+  long pos = cap_base + rowoff[row_base + r];
+  for (int k0 = 0; k0 < I.K; k0 += 64) {  // uniform
+    const int k = k0 + lane;
+    const float v = k < I.K ? s[k] : 0.f;
+    const bool c = k < I.K && v > I.thr;
+    const unsigned long long bal = __ballot(c);
+    if (c) {
+      const long p = pos + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+      const float* bk = b + (I.Kb == 1 ? 0 : k * 4);
+      out_boxes[p] = make_float4(fminf(fmaxf(bk[0], 0.f), w), fminf(fmaxf(bk[1], 0.f), h), fminf(fmaxf(bk[2], 0.f), w),
+                                 fminf(fmaxf(bk[3], 0.f), h));
+      out_scores[p] = v;
+      out_classes[p] = k;
+      out_rows[p] = ridx;
+    }
+    pos += __builtin_popcountll(bal);
+  }
+}
+
+}  // namespace d2amd
+
+using namespace d2amd;
+
+extern "C" size_t d2amd_fast_rcnn_filter_workspace_bytes(const int* rows, int num_images) {
+  long total = 0;
+  for (int i = 0; i < num_images; i++) total += rows[i] > 0 ? rows[i] : 0;
+  return (size_t)(3 * total + 64) * sizeof(int);
+}
+
+extern "C" int d2amd_fast_rcnn_filter(const float* const* boxes, const float* const* scores, const int* rows,
+                                      int num_images, int num_classes, int num_bbox_reg_classes, const int* image_hw,
+                                      float score_thresh, float* out_boxes, float* out_scores, int64_t* out_classes,
+                                      int64_t* out_rows, int64_t* counts, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+  D2_CHECK_ARG(num_images >= 0 && num_images <= D2AMD_POOLER_MAX_IMAGES, "fast_rcnn_filter: %d images (max %d)",
+               num_images, D2AMD_POOLER_MAX_IMAGES);
+  if (num_images == 0) return D2AMD_OK;
+  D2_CHECK_ARG(num_classes >= 1 && (num_bbox_reg_classes == 1 || num_bbox_reg_classes == num_classes),
+               "fast_rcnn_filter: %d classes, boxes for %d", num_classes, num_bbox_reg_classes);
+  D2_CHECK_ARG(boxes && scores && rows && image_hw && counts && workspace, "fast_rcnn_filter: null pointer");
+  D2_CHECK_ARG(workspace_bytes >= d2amd_fast_rcnn_filter_workspace_bytes(rows, num_images),
+               "fast_rcnn_filter: workspace too small");
+  BhImages I{};
+  I.n = num_images; I.K = num_classes; I.Kb = num_bbox_reg_classes; I.thr = score_thresh;
+  int max_rows = 0;
+  for (int i = 0; i < num_images; i++) {
+    D2_CHECK_ARG(rows[i] >= 0 && (rows[i] == 0 || (boxes[i] && scores[i])), "fast_rcnn_filter: image %d: bad rows / pointers", i);
+    D2_CHECK_ARG((long)rows[i] * num_classes < (1l << 31), "fast_rcnn_filter: too many (row, class) pairs");
+    I.boxes[i] = boxes[i]; I.scores[i] = scores[i]; I.rows[i] = rows[i];
+    I.h[i] = (float)image_hw[2 * i]; I.w[i] = (float)image_hw[2 * i + 1];
+    I.row_base[i + 1] = I.row_base[i] + rows[i];
+    I.cap_base[i + 1] = I.cap_base[i] + (long)rows[i] * num_classes;
+    max_rows = rows[i] > max_rows ? rows[i] : max_rows;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  int* rowcnt = (int*)workspace;
+  int* rowoff = rowcnt + I.row_base[num_images];
+  int* rowidx = rowoff + I.row_base[num_images];
+  if (max_rows == 0) {
+    const int zrc = zero_async(counts, (size_t)num_images * 8, st);
+    return zrc;
+  }
+  D2_CHECK_ARG(out_boxes && out_scores && out_classes && out_rows, "fast_rcnn_filter: null output");
+  const dim3 grid(cdiv(max_rows, BH_WAVES), num_images);
+  hipLaunchKernelGGL(bh_count_kernel, grid, dim3(64 * BH_WAVES), 0, st, I, rowcnt);
+  D2_LAUNCH_OK();
+  hipLaunchKernelGGL(bh_scan_kernel, dim3(num_images), dim3(1024), 0, st, I, (const int*)rowcnt, rowoff, rowidx, counts);
+  D2_LAUNCH_OK();
+  hipLaunchKernelGGL(bh_write_kernel, grid, dim3(64 * BH_WAVES), 0, st, I, (const int*)rowcnt, (const int*)rowoff,
+                     (const int*)rowidx, (float4*)out_boxes, out_scores, out_classes, out_rows);
+  D2_LAUNCH_OK();
+  return D2AMD_OK;
+}

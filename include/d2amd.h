@@ -459,6 +459,26 @@ int d2amd_polygon_crop_and_resize(const double* coords, const int64_t* poly_offs
                                   int n_instances, const float* boxes, const int64_t* index, int n_boxes,
                                   int mask_size, uint8_t* out, int* status, void* stream);
 
+/* ---- Box-head inference in front of the per-class NMS (csrc/box_head.hip) ---------------------------------------------
+ * Replaces detectron2/modeling/roi_heads/fast_rcnn.py:134-158 (fast_rcnn_inference_single_image up to `batched_nms`)
+ * for a whole batch, without the reference's per-image host sync (`filter_mask.nonzero()`, :150):
+ *   boxes[i]  [rows[i]][num_bbox_reg_classes * 4] fp32 (predict_boxes; num_bbox_reg_classes = 1: class-agnostic),
+ *   scores[i] [rows[i]][num_classes + 1] fp32 (predict_probs: the last column is the background),
+ *   image_hw  [num_images][2] = (height, width) the boxes are clipped to (Boxes.clip: x to [0, w], y to [0, h]).
+ * A row with a non-finite box coordinate or score is dropped as a whole (:134-137).  The candidates -- (row, class)
+ * pairs with score > score_thresh -- come out in torch.nonzero's order (row-major), image i's from row
+ * sum_{j<i} rows[j] * num_classes on (worst-case slices: nothing overflows):
+ *   out_boxes [.][4] (clipped), out_scores [.], out_classes [.] int64, out_rows [.] int64 (`filter_inds[:, 0]`: the row's
+ *   index among the rows of its image that were NOT dropped -- the reference indexes boxes[valid_mask]), counts [num_images] int64 -- all on the device; rows past an image's count are not written.
+ * workspace: d2amd_fast_rcnn_filter_workspace_bytes(rows, num_images).  num_images <= D2AMD_POOLER_MAX_IMAGES.
+ * The caller then runs d2amd_nms_batched over the first counts[i] rows of every slice (class = category) and keeps the
+ * first topk_per_image of its result (:161-164). */
+size_t d2amd_fast_rcnn_filter_workspace_bytes(const int* rows, int num_images);
+int d2amd_fast_rcnn_filter(const float* const* boxes, const float* const* scores, const int* rows, int num_images,
+                           int num_classes, int num_bbox_reg_classes, const int* image_hw, float score_thresh,
+                           float* out_boxes, float* out_scores, int64_t* out_classes, int64_t* out_rows,
+                           int64_t* counts, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- Mask-head glue.  detectron2/modeling/roi_heads/mask_head.py:31-158.
  * logits [B,C,HW] `dtype` (HW = Hmask*Wmask, contiguous NCHW), classes [B] int64 or NULL (class-agnostic,
  * C == 1), gt_masks [B,HW] uint8 / bool storage (the output of d2amd_bitmask_crop_and_resize).

@@ -33,7 +33,7 @@ PY_MODULES = [
     "detectron2/structures/masks.py", "detectron2/modeling/matcher.py", "detectron2/modeling/sampling.py",
     "detectron2/modeling/box_regression.py", "detectron2/modeling/poolers.py",
     "detectron2/modeling/proposal_generator/proposal_utils.py", "detectron2/modeling/roi_heads/mask_head.py",
-    "detectron2/modeling/meta_arch/dense_detector.py",
+    "detectron2/modeling/meta_arch/dense_detector.py", "detectron2/modeling/roi_heads/fast_rcnn.py",
     "detectron2/layers/deform_conv.py", "detectron2/layers/wrappers.py",
     "detectron2/structures/rotated_boxes.py", "projects/PointRend/point_rend/point_features.py",
     # the reference's OWN unit tests of the hot-path operators (tests/test_gpu_reference_tests.py runs them, unmodified,

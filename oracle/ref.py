@@ -214,6 +214,37 @@ def py_mask_head():
     return mod
 
 
+def py_fast_rcnn(batched_nms):
+    """detectron2/modeling/roi_heads/fast_rcnn.py (fast_rcnn_inference / fast_rcnn_inference_single_image) with
+    detectron2.layers.batched_nms = the given function (torchvision is not installed).  The module-level imports the
+    two functions do not use (configurable, the federated-loss helper, the loss functions, the event storage) are stubbed;
+    Boxes / Instances are the reference's own (pure torch)."""
+    import torch
+
+    names = ("detectron2", "detectron2.config", "detectron2.data", "detectron2.data.detection_utils", "detectron2.layers",
+             "detectron2.modeling", "detectron2.modeling.box_regression", "detectron2.structures", "detectron2.utils",
+             "detectron2.utils.events")
+    pkg, cfg, data, du, layers, modeling, boxreg, structs, utils, events = (types.ModuleType(n) for n in names)
+    for m in (pkg, data, modeling, utils):
+        m.__path__ = []
+    cfg.configurable = lambda f=None, **k: f if f is not None else (lambda g: g)
+    du.get_fed_loss_cls_weights = lambda *a, **k: None
+    layers.ShapeSpec = object
+    layers.batched_nms = batched_nms
+    layers.cat = lambda ts, dim=0: torch.cat(ts, dim)
+    layers.cross_entropy = torch.nn.functional.cross_entropy
+    layers.nonzero_tuple = lambda x: x.nonzero().unbind(1)
+    # (Box2BoxTransform is a torch.jit.script class: it needs its source, which the GPU box does not have -- and the
+    # two inference functions never touch it)
+    boxreg.Box2BoxTransform = object
+    boxreg._dense_box_regression_loss = None
+    structs.Boxes = py_boxes().Boxes
+    structs.Instances = _load_by_path("_d2ref_instances", "detectron2/structures/instances.py").Instances
+    events.get_event_storage = lambda: _EventRecorder()
+    stubs = dict(zip(names, (pkg, cfg, data, du, layers, modeling, boxreg, structs, utils, events)))
+    return _with_stubs(stubs, lambda: _load_by_path("_d2ref_fast_rcnn", "detectron2/modeling/roi_heads/fast_rcnn.py"))
+
+
 def py_dense_detector():
     """detectron2/modeling/meta_arch/dense_detector.py (DenseDetector._decode_per_level_predictions /
     _decode_multi_level_predictions).  Loaded under its real dotted name so that its relative import of

@@ -1,0 +1,105 @@
+"""GPU parity of the fused box-head inference (csrc/box_head.hip + d2amd_nms_batched behind
+detectron2_amd.modeling.fast_rcnn_inference_fused) against oracle/fast_rcnn.py (numpy restatement of
+roi_heads/fast_rcnn.py:118-170, pinned to the reference's own source in tests/test_oracle_golden.py) and against the
+reference's OWN function run unmodified on this package's batched_nms on the GPU.  Bar: bit-exact -- the kept boxes,
+scores, classes, row indices and their ORDER."""
+import numpy as np
+import pytest
+import torch
+
+from _fast_rcnn_cases import CASES, make
+from conftest import need_reference
+from detectron2_amd import layers
+from detectron2_amd.modeling import fast_rcnn_inference_fused
+from oracle import fast_rcnn as ofr
+from oracle import ref
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def run_fused(case):
+    boxes, scores, shapes, thr, nms, topk = make(case)
+    res, rows = fast_rcnn_inference_fused([torch.from_numpy(b).to(DEV) for b in boxes],
+                                          [torch.from_numpy(s).to(DEV) for s in scores], shapes, thr, nms, topk)
+    return (boxes, scores, shapes, thr, nms, topk), res, rows
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_fused_vs_oracle(case):
+    (boxes, scores, shapes, thr, nms, topk), res, rows = run_fused(case)
+    assert len(res) == len(boxes)
+    total = 0
+    for i in range(len(boxes)):
+        wb, ws, wc, wr = ofr.fast_rcnn_inference_single_image(boxes[i], scores[i], shapes[i], thr, nms, topk)
+        assert res[i].image_size == tuple(shapes[i])
+        assert np.array_equal(res[i].pred_classes.cpu().numpy(), wc), (case, i)
+        assert np.array_equal(rows[i].cpu().numpy(), wr), (case, i)
+        assert np.array_equal(res[i].scores.cpu().numpy(), ws), (case, i)
+        assert np.array_equal(res[i].pred_boxes.tensor.cpu().numpy(), wb), (case, i)
+        total += len(ws)
+    if case == "none_pass":
+        assert total == 0
+    elif case != "ragged":
+        assert total > 0
+
+
+@pytest.mark.parametrize("case", ["maskrcnn", "agnostic", "nonfinite", "ties"])
+def test_fused_vs_the_references_own_function_on_the_gpu(case):
+    """fast_rcnn.py's fast_rcnn_inference, loaded unmodified (bytecode staged by oracle/build_ref.py), running on HIP
+    tensors with `detectron2.layers.batched_nms` = this package's: the per-image loop with its two host syncs per image
+    gives the same detections as the fused batch call."""
+    need_reference(ref.have_py(), "oracle/_ref/py (the reference's fast_rcnn.py)")
+    m = ref.py_fast_rcnn(layers.batched_nms)
+    (boxes, scores, shapes, thr, nms, topk), res, rows = run_fused(case)
+    inst, kept = m.fast_rcnn_inference([torch.from_numpy(b).to(DEV) for b in boxes],
+                                       [torch.from_numpy(s).to(DEV) for s in scores], shapes, thr, nms, topk)
+    for i in range(len(boxes)):
+        assert torch.equal(inst[i].pred_boxes.tensor, res[i].pred_boxes.tensor)
+        assert torch.equal(inst[i].scores, res[i].scores)
+        assert torch.equal(inst[i].pred_classes, res[i].pred_classes)
+        assert torch.equal(kept[i], rows[i])
+
+
+def test_filter_counts_and_order_without_the_nms():
+    """The filter alone (the C entry): counts and the row-major candidate order of torch.nonzero, for the worst-case
+    slices layout."""
+    import ctypes
+
+    from detectron2_amd import _C
+
+    boxes, scores, shapes, thr, _, _ = make("nonfinite", seed=3)
+    n = len(boxes)
+    K = scores[0].shape[1] - 1
+    rows = [b.shape[0] for b in boxes]
+    base = np.concatenate([[0], np.cumsum([r * K for r in rows])]).astype(np.int64)
+    bx = [torch.from_numpy(b).to(DEV) for b in boxes]
+    sc = [torch.from_numpy(s).to(DEV) for s in scores]
+    ob = torch.empty((int(base[-1]), 4), device=DEV)
+    os_ = torch.empty(int(base[-1]), device=DEV)
+    oc = torch.empty(int(base[-1]), dtype=torch.int64, device=DEV)
+    orow = torch.empty(int(base[-1]), dtype=torch.int64, device=DEV)
+    cnt = torch.zeros(n, dtype=torch.int64, device=DEV)
+    L = _C.lib()
+    rows_c = (ctypes.c_int * n)(*rows)
+    ws_bytes = L.d2amd_fast_rcnn_filter_workspace_bytes(rows_c, n)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=DEV)
+    hw = (ctypes.c_int * (2 * n))(*[int(v) for s in shapes for v in s])
+    ptrs = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+    _C.check(L.d2amd_fast_rcnn_filter(ptrs(bx), ptrs(sc), rows_c, n, K, K, hw, float(thr), _C.ptr(ob), _C.ptr(os_), _C.ptr(oc),
+                                      _C.ptr(orow), _C.ptr(cnt), _C.ptr(ws), ws_bytes, _C.stream()))
+    for i in range(n):
+        valid = np.isfinite(boxes[i]).all(1) & np.isfinite(scores[i]).all(1)
+        assert 0 < (~valid).sum() < rows[i]
+        m = (scores[i][:, :-1] > np.float32(thr)) & valid[:, None]
+        inds = np.argwhere(m)
+        c = int(cnt[i])
+        assert c == len(inds)
+        sl = slice(int(base[i]), int(base[i]) + c)
+        assert np.array_equal(orow[sl].cpu().numpy(), (np.cumsum(valid) - 1)[inds[:, 0]])  # index among the kept rows
+        assert np.array_equal(oc[sl].cpu().numpy(), inds[:, 1])
+        assert np.array_equal(os_[sl].cpu().numpy(), scores[i][:, :-1][m])
+        h, w = shapes[i]
+        want = boxes[i].reshape(rows[i], K, 4)[m].copy()
+        want[:, 0::2] = np.clip(want[:, 0::2], 0, w); want[:, 1::2] = np.clip(want[:, 1::2], 0, h)
+        assert np.array_equal(ob[sl].cpu().numpy(), want)

@@ -546,3 +546,32 @@ def test_fp32_roi_align_distance_from_fp64():
                 exp[k, :, ph, pw] = acc / (g * g)
     d = np.abs(got - exp).max() / np.abs(exp).max()
     assert 1e-6 < d < 1e-4, d  # ~1e-5: far above the 1e-6 a pure summation-order difference would give
+
+
+@pytest.mark.parametrize("case", ["maskrcnn", "agnostic", "ragged", "nonfinite", "all_pass", "none_pass", "ties"])
+def test_fast_rcnn_inference_vs_reference_source(case):
+    """oracle/fast_rcnn.py against the reference's OWN roi_heads/fast_rcnn.py (fast_rcnn_inference_single_image, loaded
+    unmodified from the staged bytecode) on the CPU; `detectron2.layers.batched_nms` is torchvision's upstream -- not
+    installed here -- so both sides use the oracle's port of it (pinned above to the reference's known answers): what
+    this pins is everything around the NMS (finite-row mask, clip, threshold, nonzero order, the three gathers)."""
+    import torch
+    from _fast_rcnn_cases import make
+    from conftest import need_reference
+    from oracle import fast_rcnn as ofr
+    from oracle import ref
+
+    need_reference(ref.have_py(), "oracle/_ref/py (the reference's fast_rcnn.py)")
+
+    def bnms(b, s, i, t):
+        return torch.from_numpy(oracle.batched_nms(b.numpy(), s.numpy(), i.numpy().astype(np.int64), t))
+
+    m = ref.py_fast_rcnn(bnms)
+    boxes, scores, shapes, thr, nms, topk = make(case)
+    for i in range(len(boxes)):
+        inst, kept = m.fast_rcnn_inference_single_image(torch.from_numpy(boxes[i]), torch.from_numpy(scores[i]), shapes[i],
+                                                        thr, nms, topk)
+        wb, ws, wc, wr = ofr.fast_rcnn_inference_single_image(boxes[i], scores[i], shapes[i], thr, nms, topk)
+        assert np.array_equal(inst.pred_boxes.tensor.numpy(), wb)
+        assert np.array_equal(inst.scores.numpy(), ws)
+        assert np.array_equal(inst.pred_classes.numpy(), wc)
+        assert np.array_equal(kept.numpy(), wr)
