@@ -269,7 +269,7 @@ def bench_rrpn_micro(args, ctx):
     w.rot_pooler = ROIPooler(7, [1.0 / s for s in B.STRIDES], 0, "ROIAlignRotated")
     for _ in range(args.warmup):
         iou, keep, y = rrpn_step(w)
-    knames = ["iou_rotated", "nms_mask", "nms_reduce", "roi_align_rot_fwd", "roi_align_rot_bwd"]
+    knames = ["iou_rotated", "nms_mask", "nms_reduce", "roi_align_rot_fwd", "roi_align_rot_bwd", "pool_rot_fwd", "pool_rot_bwd"]
     _dc.lib().d2amd_timing_select(",".join(knames).encode())
     sw = Stopwatch(dist, dev)
     sw.start()

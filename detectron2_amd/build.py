@@ -26,6 +26,7 @@ SOURCES = {
     "paste_masks.hip": ["-ffp-contract=off"],
     "roi_align.hip": [],
     "roi_pool.hip": [],
+    "roi_pool_rot.hip": [],
     "deform_conv.hip": [],
     "deform_conv_tc.hip": [],
     "dcn_bww_gemm.hip": [],

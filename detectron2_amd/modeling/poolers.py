@@ -9,7 +9,8 @@ reference's per-level `nonzero` (host sync) -> ROIAlign -> `index_put_` loop:
     deterministic tile gather that writes every grad element once in the I/O dtype;
   * NCHW features: fused NCHW forward; backward re-lays dY out as NHWC, runs the same tile gather
     and returns channels_last-strided gradients.
-`pooler_type` "ROIAlignRotated" keeps the per-level loop; "ROIPool" is not part of the hot path.
+`pooler_type` "ROIAlignRotated" is fused for channels_last features (csrc/roi_pool_rot.hip: one launch per direction), and
+keeps the per-level loop otherwise; "ROIPool" is not part of the hot path.
 
 CHAINED BACKWARD.  Mask R-CNN pools the same FPN features twice per iteration (box head 7x7, mask head 14x14:
 roi_heads.py:780-846), so autograd sums two dense gradients per level with an elementwise kernel (r01: 4 launches,
@@ -229,6 +230,7 @@ _PREBIN_MODE = _os.environ.get("D2AMD_PREBIN", "none")
 # with it, 0.498 / 0.500 without (same box, gpurun_out/r3s).  Off unless D2AMD_FWD_ORDER=1.
 _FWD_ORDERED = _os.environ.get("D2AMD_FWD_ORDER", "0") == "1"
 _JOIN_EARLY = _os.environ.get("D2AMD_JOIN_EARLY", "0") == "1"
+_ROT_POOLER_LOOP = _os.environ.get("D2AMD_ROT_POOLER_LOOP", "0") == "1"  # A/B switch: rotated pooler level by level
 _SIDE_BINNING = _os.environ.get("D2AMD_SIDE_BINNING", "1") != "0"  # A/B switch: the later gathers' binning beside the first
 
 
@@ -455,6 +457,53 @@ class _FusedROIPool(Function):
         return (None, None, None, None, None) + tuple(back(g) if need else None for g, need in zip(grads, ctx.needs))
 
 
+class _FusedRotatedPool(Function):
+    """Multi-level ROIAlignRotated in one launch per direction (csrc/roi_pool_rot.hip).  rois: (M, 6) fp32 pooler-format
+    rotated boxes (image index, cx, cy, w, h, angle); features NHWC (channels_last) of one dtype."""
+
+    @staticmethod
+    @disable_torch_compiler
+    def forward(ctx, rois, cfg, *feats):
+        _C.require_gpu(rois, *feats, op="ROIPooler (ROIAlignRotated)")
+        xs = list(feats)
+        n, c = xs[0].shape[:2]
+        hw = [tuple(x.shape[2:]) for x in xs]
+        k = rois.shape[0]
+        p = _params(cfg, (n, c), hw, _C.dtype_code(xs[0]), _C.NHWC)
+        ph, pw = cfg[0]
+        out = torch.empty((k, c, ph, pw), dtype=xs[0].dtype, device=xs[0].device, memory_format=torch.channels_last)
+        status = torch.zeros(1, dtype=torch.int32, device=xs[0].device)
+        if k > 0:
+            with _C.on_device(xs[0].device):
+                _C.check(_C.lib().d2amd_roi_pooler_rotated_forward(ctypes.byref(p), _ptr_array(xs), _C.ptr(rois),
+                                                                   _C.ptr(out), k, _C.ptr(status), _C.stream()))
+            # ROIAlignRotated_cpu.cpp:236-238 asserts non-negative sizes; reading the status word is one host sync, as the
+            # per-level op's (layers/ops.py) -- the reference's device forward ends in a device synchronisation
+            if int(status.item()) != 0:
+                raise RuntimeError("ROIs in ROIAlignRotated do not have non-negative size!")
+        ctx.save_for_backward(rois)
+        ctx.cfg, ctx.hw, ctx.nc, ctx.dtype = cfg, hw, (n, c), xs[0].dtype
+        ctx.needs = [f.requires_grad for f in feats]
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        (rois,) = ctx.saved_tensors
+        cfg, hw, (n, c) = ctx.cfg, ctx.hw, ctx.nc
+        g = _to_nhwc(grad_output.detach())
+        dev = rois.device
+        grads = [torch.empty((n, c, h, w), dtype=ctx.dtype, device=dev, memory_format=torch.channels_last) for (h, w) in hw]
+        p = _params(cfg, (n, c), hw, _C.dtype_code(g), _C.NHWC)
+        L = _C.lib()
+        with _C.on_device(dev):
+            ws_bytes = L.d2amd_roi_pooler_rotated_backward_workspace_bytes(ctypes.byref(p))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            _C.check(L.d2amd_roi_pooler_rotated_backward(ctypes.byref(p), _C.ptr(g), _C.ptr(rois), _ptr_array(grads),
+                                                         rois.shape[0], _C.ptr(ws), ws_bytes, _C.stream()))
+        return (None, None) + tuple(gr if need else None for gr, need in zip(grads, ctx.needs))
+
+
 class ROIPooler(nn.Module):
     """Region of interest feature map pooler over one or more feature maps (poolers.py:114-263)."""
 
@@ -517,6 +566,14 @@ class ROIPooler(nn.Module):
         lay, dt = _layout_of(x[0]), x[0].dtype
         return all(_layout_of(t) == lay and t.dtype == dt and t.shape[:2] == x[0].shape[:2] for t in x)
 
+    def _fusable_rotated(self, x):
+        if self.pooler_type != "ROIAlignRotated" or len(x) > 8 or _ROT_POOLER_LOOP:
+            return False
+        if not all(t.is_cuda and t.dim() == 4 for t in x) or x[0].dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            return False
+        dt = x[0].dtype
+        return all(_layout_of(t) == _C.NHWC and t.dtype == dt and t.shape[:2] == x[0].shape[:2] for t in x)
+
     def pool_rois(self, x: List[torch.Tensor], rois: torch.Tensor):
         """forward() for boxes that already are in pooler format: rois (M, 5) fp32 = (image index, x1, y1, x2, y2), what
         `convert_boxes_to_pooler_format` returns and `label_and_sample_proposals_fixed` writes ("rois" / "head_rois") --
@@ -555,6 +612,12 @@ class ROIPooler(nn.Module):
             if pooler_fmt_boxes.dtype != torch.float32:
                 pooler_fmt_boxes = pooler_fmt_boxes.float()
             return self._pool_fused(pooler_fmt_boxes.detach(), cfg, x)
+        if self._fusable_rotated(x) and pooler_fmt_boxes.shape[1] == 6:
+            # multi-level ROIAlignRotated in one launch per direction (channels_last features): no per-level nonzero /
+            # index_put_ (D2AMD_ROT_POOLER_LOOP=1: the reference's per-level structure below)
+            cfg = (tuple(self.output_size), tuple(self.scales), int(self.sampling_ratio), True, self.min_level,
+                   self.max_level, self.canonical_box_size, self.canonical_level)
+            return _FusedRotatedPool.apply(pooler_fmt_boxes.detach().float().contiguous(), cfg, *x)
         if num_level_assignments == 1:
             return self.level_poolers[0](x[0], pooler_fmt_boxes)
         # reference structure (poolers.py:247-263)

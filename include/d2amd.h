@@ -459,6 +459,25 @@ int d2amd_polygon_crop_and_resize(const double* coords, const int64_t* poly_offs
                                   int n_instances, const float* boxes, const int64_t* index, int n_boxes,
                                   int mask_size, uint8_t* out, int* status, void* stream);
 
+/* ---- Fused multi-level ROIAlignRotated pooler (csrc/roi_pool_rot.hip) --------------------------------------------------
+ * ROIPooler.forward with pooler_type "ROIAlignRotated" (modeling/poolers.py:206-263 on layers/roi_align_rotated.py /
+ * csrc/ROIAlignRotated) in one launch per direction: level assignment (poolers.py:51-59 on RotatedBoxes.area() = w * h)
+ * inside the kernel, no per-level nonzero / index_put_.  Same d2amd_pooler_params as the axis-aligned pooler (`aligned`
+ * is ignored: ROIAlignRotated always samples with the half-pixel shift); NHWC only (d2amd_roi_pooler_rotated_supported).
+ *   rois [K][6] fp32 = (image index, cx, cy, w, h, angle in degrees); output / grad_output [K][PH][PW][C] (NHWC).
+ *   status (device int, may be NULL): bit 0 is set when a ROI has a negative size -- its rows are zero; the reference
+ *   asserts (ROIAlignRotated_cpu.cpp:236-238).
+ * backward: scatter with fp32 atomics, as the reference's (addition order not deterministic); 16-bit gradients
+ * accumulate in an fp32 image in the workspace (d2amd_roi_pooler_rotated_backward_workspace_bytes) and are rounded
+ * once.  grad_inputs are written completely. */
+int d2amd_roi_pooler_rotated_supported(const d2amd_pooler_params* p);
+int d2amd_roi_pooler_rotated_forward(const d2amd_pooler_params* p, const void* const* inputs, const float* rois,
+                                     void* output, int K, int* status, void* stream);
+size_t d2amd_roi_pooler_rotated_backward_workspace_bytes(const d2amd_pooler_params* p);
+int d2amd_roi_pooler_rotated_backward(const d2amd_pooler_params* p, const void* grad_output, const float* rois,
+                                      void* const* grad_inputs, int K, void* workspace, size_t workspace_bytes,
+                                      void* stream);
+
 /* ---- Box-head inference in front of the per-class NMS (csrc/box_head.hip) ---------------------------------------------
  * Replaces detectron2/modeling/roi_heads/fast_rcnn.py:134-158 (fast_rcnn_inference_single_image up to `batched_nms`)
  * for a whole batch, without the reference's per-image host sync (`filter_mask.nonzero()`, :150):
