@@ -704,3 +704,30 @@ def test_fp16_rois_are_not_rounded_to_the_feature_dtype_and_what_that_changes():
     y2 = ROIAlign((7, 7), 0.25, 0, True)(xt, torch.from_numpy(exact_in_fp16.astype(np.float32)).to(DEV)).float().cpu().numpy()
     same = oracle.roi_align_forward(x.astype(np.float32), exact_in_fp16.astype(np.float16).astype(np.float32), (7, 7), 0.25, 0, True)
     assert np.abs(y2 - same).max() <= 2.0 ** -10 * np.abs(same).max() + 1e-4
+
+
+@pytest.mark.parametrize("thr", [0.3, 0.5, 0.7, 0.9])
+def test_nms_rotated_pairs_at_the_area_ratio_bound(thr):
+    """The rotated mask kernel skips the polygon clip for pairs whose area ratio is below 0.99 x threshold (IoU <= min / max
+    area) and for pairs the centre-distance test rejects.  Concentric boxes of equal angle have IoU == area ratio: a ladder
+    of ratios from 0.97 x to 1.01 x the threshold (and the same ladder slightly rotated / shifted) must give the kept set
+    of the oracle's full clip (the restatement of nms_rotated_cpu.cpp), bit for bit."""
+    rng = np.random.default_rng(int(thr * 100))
+    boxes, scores = [], []
+    for g in range(120):
+        cx, cy = rng.uniform(50, 950, 2)
+        w, h = np.exp(rng.uniform(np.log(10), np.log(200), 2))
+        ang = rng.uniform(-90, 90)
+        boxes.append([cx, cy, w, h, ang]); scores.append(1.0 - 1e-3 * g)
+        ratio = thr * rng.uniform(0.97, 1.01)
+        s = np.sqrt(ratio)
+        jitter = rng.choice([0.0, 0.0, 0.3, 1.0])
+        boxes.append([cx + jitter * rng.uniform(-1, 1), cy + jitter * rng.uniform(-1, 1), w * s, h * s,
+                      ang + jitter * rng.uniform(-2, 2)])
+        scores.append(0.5 - 1e-3 * g)
+    b = np.asarray(boxes, np.float32)
+    s = np.asarray(scores, np.float32)
+    want = oracle.nms_rotated(b, s, thr)
+    got = nms_rotated(torch.from_numpy(b).to(DEV), torch.from_numpy(s).to(DEV), thr).cpu().numpy()
+    assert np.array_equal(got, want)
+    assert 120 < len(want) < 240  # some of the smaller boxes are suppressed, some are not
