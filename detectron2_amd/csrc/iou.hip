@@ -87,24 +87,68 @@ static int launch_pairwise(const float* b1, int n, const float* b2, int m, float
 constexpr int ROT_BLOCK = 64;
 constexpr int ROT_ROWS = 16;
 
+// r04: the polygon clip runs on COMPACTED pairs.  A wave owns 64 columns x 16 rows; evaluated row by row, a row's clip
+// ran with whatever lanes survived the exact distance test (rot_pair_is_zero: exactly the pairs whose IoU is +0.f) --
+// in RRPN matching > 99 % of the pairs do not, but half of the rows still had a survivor somewhere in the wave.  Now
+// every lane tests its column against the 16 rows first (zeros are stored right away), the survivors are listed in LDS
+// and the clip runs with lane = one listed pair.
 __global__ __launch_bounds__(ROT_BLOCK) void box_iou_rotated_kernel(
-    const float* __restrict__ b1, int n, const float* __restrict__ b2, int m, float* __restrict__ out) {
+    const float* __restrict__ b1, int n, const float* __restrict__ b2, int m, float* __restrict__ out, int rows_per_block) {
   __shared__ RotIouScratch<ROT_BLOCK> S;
   __shared__ float rows[ROT_ROWS][5];
-  const int row0 = blockIdx.y * ROT_ROWS;
-  const int nrows = min(ROT_ROWS, n - row0);
-  for (int i = threadIdx.x; i < nrows * 5; i += ROT_BLOCK) rows[i / 5][i % 5] = b1[(long)row0 * 5 + i];
-  __syncthreads();
-  const long col = (long)blockIdx.x * ROT_BLOCK + threadIdx.x;
-  if (col >= m) return;
+  __shared__ float cols[5][ROT_BLOCK];
+  __shared__ uint16_t list[ROT_ROWS * ROT_BLOCK];  // row << 6 | lane
+  const int lane = threadIdx.x;
+  const int row0 = blockIdx.y * rows_per_block;
+  const int nrows = min(rows_per_block, n - row0);
+  for (int i = lane; i < nrows * 5; i += ROT_BLOCK) rows[i / 5][i % 5] = b1[(long)row0 * 5 + i];
+  const long col0 = (long)blockIdx.x * ROT_BLOCK;
+  const long col = col0 + lane;
+  const bool in = col < m;
   float cb[5];
 #pragma unroll
-  for (int k = 0; k < 5; k++) cb[k] = b2[col * 5 + k];
+  for (int k = 0; k < 5; k++) {
+    cb[k] = b2[(in ? col : (long)m - 1) * 5 + k];
+    cols[k][lane] = cb[k];
+  }
+  __syncthreads();
+  unsigned live = 0u;  // bit i: (row i, this column) needs the clip
   for (int i = 0; i < nrows; i++) {
     float rb[5];
 #pragma unroll
     for (int k = 0; k < 5; k++) rb[k] = rows[i][k];
-    out[(long)(row0 + i) * m + col] = single_box_iou_rotated<ROT_BLOCK>(rb, cb, S, threadIdx.x);
+    if (!in) continue;
+    if (rot_pair_is_zero(rb, cb)) out[(long)(row0 + i) * m + col] = 0.f;
+    else live |= 1u << i;
+  }
+  const int mine = __builtin_popcount(live);
+  int incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int y = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += y;
+  }
+  const int total = __shfl(incl, 63);
+  {
+    int at = incl - mine;
+    unsigned mbits = live;
+    while (mbits) {
+      const int i = __builtin_ctz(mbits);
+      mbits &= mbits - 1;
+      list[at++] = (uint16_t)((i << 6) | lane);
+    }
+  }
+  __syncthreads();
+  for (int t0 = 0; t0 < total; t0 += ROT_BLOCK) {  // uniform
+    const int t = t0 + lane;
+    const bool on = t < total;
+    const int e = list[on ? t : total - 1];
+    const int i = e >> 6, c = e & 63;
+    float rb[5], cc[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) { rb[k] = rows[i][k]; cc[k] = cols[k][c]; }
+    const float v = single_box_iou_rotated<ROT_BLOCK>(rb, cc, S, lane);
+    if (on) out[(long)(row0 + i) * m + col0 + c] = v;
   }
 }
 
@@ -134,11 +178,15 @@ extern "C" int d2amd_box_iou_rotated(const float* boxes1, int n, const float* bo
   D2_CHECK_ARG(boxes1 && boxes2 && out, "box_iou_rotated: null pointer");
   // the larger set goes on the x (column) axis like the reference's operand swap
   // (box_iou_rotated_cuda.cu:89-100) -- here only grid.y is bounded (65535 * ROT_ROWS rows)
-  D2_CHECK_ARG(cdiv(n, ROT_ROWS) <= 65535, "box_iou_rotated: n too large (%d)", n);
-  dim3 grid(cdiv(m, ROT_BLOCK), cdiv(n, ROT_ROWS));
+  // rows per 64-column wave: 16, or fewer while the launch would have less than ~16 waves per CU (16 x 268,569: 4)
+  int rpb = ROT_ROWS;
+  while (rpb > 1 && (long)cdiv(m, ROT_BLOCK) * cdiv(n, rpb) < 4096 * 4) rpb >>= 1;
+  { const char* e = getenv("D2AMD_IOU_ROT_ROWS"); if (e && atoi(e) >= 1 && atoi(e) <= ROT_ROWS) rpb = atoi(e); }  // A/B
+  D2_CHECK_ARG(cdiv(n, rpb) <= 65535, "box_iou_rotated: n too large (%d)", n);
+  dim3 grid(cdiv(m, ROT_BLOCK), cdiv(n, rpb));
   const bool timed = timing_begin("iou_rotated", (hipStream_t)stream);
   hipLaunchKernelGGL(box_iou_rotated_kernel, grid, dim3(ROT_BLOCK), 0, (hipStream_t)stream, boxes1, n,
-                     boxes2, m, out);
+                     boxes2, m, out, rpb);
   if (timed) timing_end("iou_rotated", (hipStream_t)stream);
   D2_LAUNCH_OK();
   return D2AMD_OK;
