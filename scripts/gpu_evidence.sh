@@ -19,7 +19,7 @@ for n in ("default","maskrcnn_infer","rrpn_micro","retinanet_100k","dcn_r50"):
     except Exception as e: print(n,"failed",e)
 PY
 cd /tmp
-for WL in maskrcnn_train dcn_r50 maskrcnn_infer; do
+for WL in maskrcnn_train dcn_r50 maskrcnn_infer retinanet_100k rrpn_micro; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$WL -o bench -- python $REPO/bench.py --workload $WL --steps 20 --warmup 3 --no-cpu-baseline --no-extra-workloads > $OUT/prof_$WL.log 2>&1
   cp $(find $OUT/prof_$WL -name "*kernel_stats.csv" | head -1) $OUT/${WL}_kernel_stats.csv 2>/dev/null; rm -rf $OUT/prof_$WL
 done
