@@ -17,6 +17,8 @@
 //     position chunks (fp32 atomics); (3) d(bias) = row sums of dY.
 // Accumulation is fp32 everywhere; column values are rounded to the I/O dtype before the MFMA
 // exactly like the reference's column buffer.
+#include <mutex>
+
 #include "dcn_common.h"
 
 namespace d2amd {
@@ -637,23 +639,27 @@ static int fwd_host(const DcnShape& s, const void* x, const void* offset, const 
   return D2AMD_OK;
 }
 
-// the second stream of a backward call (DcnSide), one per device, created on first use.  D2AMD_DCN_NO_SIDE: none.
-static DcnSide* dcn_side() {
-  static DcnSide table[64];
-  static bool made[64] = {};
+// the second stream of a backward call (DcnSide): one per (device, caller's stream), created on first use -- two host
+// threads running backward passes on different streams of one device must not share events.  D2AMD_DCN_NO_SIDE: none.
+static DcnSide* dcn_side(hipStream_t caller) {
+  struct Slot { int dev; hipStream_t caller; DcnSide side; };
+  static Slot slots[32];
+  static int nslots = 0;
+  static std::mutex mu;
   static const bool off = getenv("D2AMD_DCN_NO_SIDE") != nullptr;
   int dev = 0;
-  if (off || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  if (!made[dev]) {
-    DcnSide t{};
-    if (hipStreamCreateWithFlags(&t.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&t.bin, hipEventDisableTiming) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&t.join, hipEventDisableTiming) != hipSuccess) return nullptr;
-    table[dev] = t;
-    made[dev] = true;
-  }
-  return &table[dev];
+  if (off || hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  for (int i = 0; i < nslots; i++)
+    if (slots[i].dev == dev && slots[i].caller == caller) return &slots[i].side;
+  if (nslots == 32) return nullptr;  // (more caller streams than anyone uses: those calls stay on one stream)
+  DcnSide t{};
+  if (hipStreamCreateWithFlags(&t.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  if (hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+  if (hipEventCreateWithFlags(&t.bin, hipEventDisableTiming) != hipSuccess) return nullptr;
+  if (hipEventCreateWithFlags(&t.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+  slots[nslots] = Slot{dev, caller, t};
+  return &slots[nslots++].side;
 }
 
 template <typename T>
@@ -699,7 +705,7 @@ static int bwd_host(const DcnShape& s, const void* x, const void* offset, const 
         float* gmask_f = (gmask && mask) ? w.gmask : nullptr;
         // second stream: the sample binning and the weight-gradient GEMM (dY and the saved column in, its own partial
         // tiles and grad_weight out: nothing the data path touches) run beside the data-gradient kernel
-        DcnSide* sd = dcn_side();
+        DcnSide* sd = dcn_side(st);
         DcnSide side{};
         BwwGemmCall<T> call{&s, &gp, gout, w.col_saved, w.gwr, gweight};
         static const int side_mode = getenv("D2AMD_DCN_SIDE_MODE") ? atoi(getenv("D2AMD_DCN_SIDE_MODE")) : 3;  // A/B: 1 = binning only, 2 = GEMM only

@@ -65,6 +65,30 @@ elif op == "iou_rotated":  # SURVEY 8(d) rotated IoU: 16 x 268,569 (RRPN matchin
     bench_extra.rotated_inputs(w)
     for _ in range(N):
         pairwise_iou_rotated(w.rot_gt[0], w.rot_anchors)
+elif op == "retinanet_select":  # the dense-detector selection alone: 2 x 16.1 M logits, top 20,000 per level
+    from detectron2_amd.modeling import dense_select_predictions
+    an, lg, dl = bench.retina_inputs(dev, [0, 1])
+    for _ in range(N):
+        dense_select_predictions(an, lg, dl, 0.0, bench.RETINA_TOPK)
+elif op in ("pool_rot_fwd", "pool_rot_bwd", "nms_rotated"):  # SURVEY 8(d) rotated rows at the rrpn_micro shapes
+    import bench_extra
+    from detectron2_amd.layers import batched_nms_rotated
+    from detectron2_amd.modeling import ROIPooler
+    bench_extra.rotated_inputs(w)
+    if op == "nms_rotated":
+        b, s, lv = w.rot_nms_in[0]
+        for _ in range(N):
+            batched_nms_rotated(b, s, lv, 0.7)
+    else:
+        pooler = ROIPooler(7, [1.0 / st for st in bench.STRIDES], 0, "ROIAlignRotated")
+        rb = [bench_extra._RBoxes(r) for r in w.rot_rois]
+        if op == "pool_rot_fwd":
+            for _ in range(N):
+                pooler([f.detach() for f in w.feats], rb)
+        else:
+            y = pooler(w.feats, rb)
+            for _ in range(N):
+                torch.autograd.grad([y], w.feats, [w.gbox], retain_graph=True)
 elif op == "match_rpn":
     from detectron2_amd.modeling import Matcher
     mt = Matcher([0.3, 0.7], [0, -1, 1], allow_low_quality_matches=True)
