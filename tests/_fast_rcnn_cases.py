@@ -18,6 +18,8 @@ def make(case, seed=0):
         rows, K, Kb, shapes, thr, topk = [60, 45], 6, 6, [(300, 400)] * 2, -1.0, -1
     elif case == "none_pass":
         rows, K, Kb, shapes, thr = [200, 100], 8, 8, [(300, 400)] * 2, 2.0
+    elif case == "many":  # ~25,000 candidates per image: beyond the batched NMS pipeline's 12,288 (per-image launches)
+        rows, K, Kb, shapes, thr = [1000, 900], 80, 80, [(800, 1333)] * 2, 0.004
     elif case == "ties":  # quantised scores: many equal scores at the top-k cut and inside the NMS order
         rows, K, Kb, shapes, topk = [600, 500], 10, 10, [(400, 600)] * 2, 50
     else:
@@ -47,4 +49,4 @@ def make(case, seed=0):
     return boxes, scores, shapes, thr, nms, topk
 
 
-CASES = ["maskrcnn", "agnostic", "ragged", "nonfinite", "all_pass", "none_pass", "ties"]
+CASES = ["maskrcnn", "agnostic", "ragged", "nonfinite", "all_pass", "none_pass", "ties", "many"]

@@ -94,6 +94,14 @@ def test_rpn_full_size_pipeline_and_nonfinite():
         assert len(r) == len(es) <= 1000
         assert np.array_equal(r.objectness_logits.cpu().numpy(), es)
         assert np.array_equal(r.proposal_boxes.tensor.cpu().numpy(), eb)
+    # small post_nms_topk values (every level keeps more than that): still the oracle's proposals, in the oracle's order
+    for post in (1, 37, 64, 300):
+        res = find_top_rpn_proposals_fused(A, Lg, D, hw, 0.7, 2000, post, 0.0, True)
+        ref = orpn.find_top_rpn_proposals(None, None, None, hw, 0.7, 2000, post, 0.0, selected=sel)
+        for r, (eb, es) in zip(res, ref):
+            assert len(r) == len(es) == post
+            assert np.array_equal(r.objectness_logits.cpu().numpy(), es)
+            assert np.array_equal(r.proposal_boxes.tensor.cpu().numpy(), eb)
     # non-finite predictions
     D[0][1, :4000, 2] = float("nan")
     with pytest.raises(FloatingPointError):
