@@ -185,8 +185,10 @@ def test_reference_test(test_id):
     assert ok, log + "".join(tb for _, tb in res.failures + res.errors)
 
 
+@pytest.mark.gpu
 def test_report():
-    """Prints the executed / not-run reference test ids (after the parametrized cases above)."""
+    """Prints the executed / not-run reference test ids (after the parametrized cases above: marked `gpu` so that it runs
+    in their session)."""
     lines = [f"RUN      {t}: {_REPORT.get(t, 'not executed in this session')}" for t in RUN + RUN_ON_CPU]
     lines += [f"NOT RUN  {t}: {why}" for t, why in sorted(NOT_RUN.items())]
     text = "\n".join(lines)
