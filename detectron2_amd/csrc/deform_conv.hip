@@ -654,7 +654,12 @@ static DcnSide* dcn_side(hipStream_t caller) {
     if (slots[i].dev == dev && slots[i].caller == caller) return &slots[i].side;
   if (nslots == 32) return nullptr;  // (more caller streams than anyone uses: those calls stay on one stream)
   DcnSide t{};
-  if (hipStreamCreateWithFlags(&t.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  {  // LOW priority: the side work fills what the data-gradient kernel leaves idle instead of competing with it
+    int lo = 0, hi = 0;
+    static const bool flat = getenv("D2AMD_DCN_SIDE_FLAT") != nullptr;  // A/B: default priority
+    if (flat || hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = 0;
+    if (hipStreamCreateWithPriority(&t.stream, hipStreamNonBlocking, lo) != hipSuccess) return nullptr;
+  }
   if (hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
   if (hipEventCreateWithFlags(&t.bin, hipEventDisableTiming) != hipSuccess) return nullptr;
   if (hipEventCreateWithFlags(&t.join, hipEventDisableTiming) != hipSuccess) return nullptr;
