@@ -1442,7 +1442,10 @@ int topk_select(const TopkInput& in, bool use_thr, float xmin, uint32_t* sel, in
     const int g = getenv("D2AMD_TOPK_POOL_G") ? atoi(getenv("D2AMD_TOPK_POOL_G")) : 16;
     return g < 1 ? 1 : g > TK_POOL_G_MAX ? TK_POOL_G_MAX : g;
   }();
-  if (!w.tickets && !legacy && pool_g <= resident) {
+  // (every workgroup of the pool kernel must be resident: its segment barriers spin)
+  const long nseg = (long)in.N * in.L;
+  const int pool_g_fit = (int)std::max(1l, std::min((long)pool_g, resident / std::max(1l, nseg)));
+  if (!w.tickets && !legacy && nseg <= resident) {
     const dim3 ggrid(cdiv(cdiv(maxsize_of(in), TK_CHUNK), TK_GSPAN), in.N * in.L);
     // 16-B loads: every segment starts on a 16-B boundary (spans start at multiples of 32,768 elements)
     static const bool no_vec = getenv("D2AMD_TOPK_NO_VEC") != nullptr;  // A/B and test switch
@@ -1483,7 +1486,7 @@ int topk_select(const TopkInput& in, bool use_thr, float xmin, uint32_t* sel, in
     TkPool Q = w.pool;
     Q.no_small = no_small ? 1 : 0;
     hipLaunchKernelGGL(tk_pool1_kernel, segs, dim3(TK_P1_THREADS), 0, s, P, w.st, w.cand, w.kmax, Q);
-    hipLaunchKernelGGL(tk_pool_kernel, dim3(pool_g, in.N * in.L), block, 0, s, P, w.st, w.cand, w.kmax, Q);
+    hipLaunchKernelGGL(tk_pool_kernel, dim3(pool_g_fit, in.N * in.L), block, 0, s, P, w.st, w.cand, w.kmax, Q);
   } else {
   hipLaunchKernelGGL(tk_hist_kernel<0>, grid, block, 0, s, P, w.st, w.hist);
   if (!w.tickets) hipLaunchKernelGGL(tk_scan_kernel<0>, segs, block, 0, s, P, w.st, w.hist);
