@@ -93,9 +93,12 @@ def dense_select_predictions(anchors: List[torch.Tensor], pred_logits: List[torc
 
 def dense_detector_inference_fused(anchors, pred_logits, pred_anchor_deltas, image_sizes, score_thresh: float,
                                    topk_candidates: int, nms_thresh: float, max_detections: int,
-                                   weights=(1.0, 1.0, 1.0, 1.0), scale_clamp: float = _DEFAULT_SCALE_CLAMP):
+                                   weights=(1.0, 1.0, 1.0, 1.0), scale_clamp: float = _DEFAULT_SCALE_CLAMP,
+                                   defer: bool = False):
     """-> list of N `Detections` (pred_boxes: Boxes, scores, pred_classes), score-descending, at most
-    max_detections each (retinanet.py:297-309).  One host sync per batch."""
+    max_detections each (retinanet.py:297-309).  One host sync per batch.
+    defer=True: everything is ENQUEUED (no host sync: the call can be captured in a HIP graph) and a callable is
+    returned that performs the one sync and builds the list."""
     boxes, scores, classes, valid, _, rank = dense_select_predictions(
         anchors, pred_logits, pred_anchor_deltas, score_thresh, topk_candidates, weights, scale_clamp, return_logits=True)
     n = boxes.shape[0]
@@ -108,14 +111,18 @@ def dense_detector_inference_fused(anchors, pred_logits, pred_anchor_deltas, ima
     for a, lg in zip(anchors, pred_logits):
         run_offsets.append(run_offsets[-1] + min(int(a.shape[0]) * int(lg.shape[-1]), topk_candidates))
     if n == 0:
-        return []
+        return (lambda: []) if defer else []
     nms_done = batched_nms_images([(boxes[i], rank[i], classes[i]) for i in range(n)], nms_thresh, defer=True,
                                   runs=(run_offsets, False, int(pred_logits[0].shape[-1])),
                                   gather=[(boxes[i], scores[i], classes[i]) for i in range(n)])
-    keeps, n_finite, _ = nms_done(with_finite=True)  # the one sync
-    out = []
-    for i, k in enumerate(keeps):
-        m = min(max_detections, n_finite[i], len(k))  # the kept rows arrive in keep order: views, no index launch
-        kb, ks, kc = nms_done.gathered[i]
-        out.append(Detections(tuple(image_sizes[i]), Boxes(kb[:m]), ks[:m], kc[:m]))
-    return out
+
+    def finish():
+        keeps, n_finite, _ = nms_done(with_finite=True)  # the one sync
+        out = []
+        for i, k in enumerate(keeps):
+            m = min(max_detections, n_finite[i], len(k))  # the kept rows arrive in keep order: views, no index launch
+            kb, ks, kc = nms_done.gathered[i]
+            out.append(Detections(tuple(image_sizes[i]), Boxes(kb[:m]), ks[:m], kc[:m]))
+        return out
+
+    return finish if defer else finish()

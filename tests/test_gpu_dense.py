@@ -201,6 +201,43 @@ def test_dense_detector_inference_fused_matches_oracle():
         np.testing.assert_allclose(r.pred_boxes.tensor.cpu().numpy(), wb, rtol=2e-6, atol=1e-3)
 
 
+@pytest.mark.parametrize("a_total", [1575, 30000])  # the batched NMS pipeline | one launch per image on side streams
+def test_dense_detector_inference_deferred_is_capturable_in_a_hip_graph(a_total):
+    """defer=True enqueues without a host sync: captured once, replayed on NEW inputs written into the captured buffers,
+    the result equals the eager call's."""
+    K, N = 8, 2
+    g = torch.Generator(device="cpu").manual_seed(5)
+
+    def inputs():
+        c = torch.rand(a_total, 2, generator=g) * torch.tensor([640.0, 512.0])
+        wh = 16.0 + 64.0 * torch.rand(a_total, 2, generator=g)
+        return (torch.cat([c - wh / 2, c + wh / 2], 1).to(DEV), (torch.randn(N, a_total, K, generator=g) * 1.5).to(DEV),
+                (torch.randn(N, a_total, 4, generator=g) * 0.1).to(DEV))
+
+    an, lg, dl = inputs()
+    call = lambda defer: dense_detector_inference_fused([an], [lg], [dl], [(512, 640)] * N, 0.05, 20000, 0.5, 100,
+                                                        defer=defer)
+    call(False)  # lazy initialisation (workspaces, side streams) outside the capture
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            finish = call(True)
+    torch.cuda.current_stream().wait_stream(side)
+    for _ in range(2):
+        an2, lg2, dl2 = inputs()
+        an.copy_(an2), lg.copy_(lg2), dl.copy_(dl2)
+        graph.replay()
+        got = finish()
+        want = call(False)
+        assert len(got) == len(want) == N
+        for a, b in zip(got, want):
+            assert len(a) == len(b) > 0
+            assert torch.equal(a.pred_boxes.tensor, b.pred_boxes.tensor) and torch.equal(a.scores, b.scores)
+            assert torch.equal(a.pred_classes, b.pred_classes)
+
+
 def test_dense_select_errors():
     a = [torch.zeros(4, 4, device=DEV)]
     with pytest.raises(RuntimeError):  # topk beyond the LDS ordering limit
