@@ -898,6 +898,7 @@ def bench_maskrcnn(args, ctx):
         step(w, None, grads)
     sw = Stopwatch(dist, dev)
     KERN = "pool_bwd_staged_r7"
+    KERN_SEL = "pool_bwd_pair,pool_bwd_staged_r7"  # the paired tile gather (both poolers, one launch) when the chain takes it
     use_graph = not args.no_graph
     if use_graph:
         gstep = GraphedConnectedStep(w, grads) if w.connected else GraphedStep(w, grads)
@@ -919,13 +920,13 @@ def bench_maskrcnn(args, ctx):
         allreduce_info = measure_allreduce(args, w, grads, sw, elapsed, dist, world) if grads is not None else None
         # events inside a replayed graph cannot be read: the roofline kernel is timed by the library's launch-stream
         # events in an eager pass of the same steps right after the timed region
-        _dc.lib().d2amd_timing_select(KERN.encode())
+        _dc.lib().d2amd_timing_select(KERN_SEL.encode())
         dom_timer = Timer(only=("backward",))
         for _ in range(args.steps):
             step(w, dom_timer, grads)
         torch.cuda.synchronize()
     else:
-        _dc.lib().d2amd_timing_select(KERN.encode())  # HIP events around the roofline kernel only, in the timed region
+        _dc.lib().d2amd_timing_select(KERN_SEL.encode())  # HIP events around the roofline kernel only, in the timed region
         dom_timer = Timer(only=("backward",))
         sw.start()
         for _ in range(args.steps):
@@ -933,8 +934,12 @@ def bench_maskrcnn(args, ctx):
         elapsed = sw.stop()
         allreduce_info = None
         windows = [elapsed / args.steps * 1e3]
-    ktimes = read_kernel_times([KERN])
-    knames = ["pool_bwd_staged_r7", "pool_bwd_staged_r14", "pool_fwd_r7", "pool_fwd_r14", "nms_mask", "nms_reduce"]
+    ktimes = read_kernel_times(KERN_SEL.split(","))
+    paired = "pool_bwd_pair" in ktimes
+    if paired:
+        KERN = "pool_bwd_pair"
+    knames = ["pool_bwd_pair", "pool_bwd_staged_r7", "pool_bwd_staged_r14", "pool_fwd_r7", "pool_fwd_r14", "nms_mask",
+              "nms_reduce"]
     _dc.lib().d2amd_timing_select(",".join(knames).encode())
     timer = Timer()  # per-op breakdown: a separate, UNTIMED pass with events around every op
     bsteps = min(args.steps, 20)
@@ -964,26 +969,36 @@ def bench_maskrcnn(args, ctx):
     ops["backward"]["ms_per_step_eager_after_graphs" if use_graph else "ms_per_step_timed_region"] = round(dom_ms_timed, 4)
     if args.layout == "nhwc" and KERN in ktimes:
         k_ms, k_n = ktimes[KERN]
-        kb = alg["roi_align_box_bwd"]
+        # the paired launch processes TWO of SURVEY 8(d)'s units (the box head's and the mask head's ROIAlign backward: the
+        # reference zero-fills and writes dX once per pooler and sums the two); the one-unit figure is kept beside it
+        kb = alg["roi_align_box_bwd"] + (alg["roi_align_mask_bwd"] if paired else 0)
+        pmc_key = "roi_align_pair_bwd" if paired else "roi_align_box_bwd"
         roof = {"bound": "hbm",
-                "kernel": "pool_bwd_mfma_kernel<T, 8> (16-bit I/O; fp32: pool_bwd_staged_kernel<float, 4, 8>): the 7x7 "
-                          "(box head) pooler's tile gather over all FPN levels, inside `backward`",
+                "kernel": ("pool_bwd_mfma_kernel<T, 8, true, 16> (d2amd_roi_pooler_backward_pair): ONE tile gather over all "
+                           "FPN levels for the 7x7 (box head) AND the 14x14 (mask head) pooler, inside `backward`" if paired else
+                           "pool_bwd_mfma_kernel<T, 8> (16-bit I/O; fp32: pool_bwd_staged_kernel<float, 4, 8>): the 7x7 "
+                           "(box head) pooler's tile gather over all FPN levels, inside `backward`"),
                 "achieved": round(kb / 1e6 / k_ms, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(kb / 1e6 / k_ms / HBM_PEAK_GBS, 4),
-                "traffic": pmc_traffic("roi_align_box_bwd", args.layout),
-                "traffic_source": pmc_source("roi_align_box_bwd", args.layout),
-                "traffic_note": "PMC bytes of the box-head pooler backward (records + tile lists + tile gather): LESS than the "
-                                "algorithmic figure, which charges a zero fill and a write of every gradient byte (SURVEY "
-                                "8(d)); the tile gather writes each byte once and zero-fills nothing it writes -- "
+                "traffic": pmc_traffic(pmc_key, args.layout),
+                "traffic_source": pmc_source(pmc_key, args.layout),
+                "traffic_note": "PMC bytes of the pooler backward (records + tile lists + tile gather): LESS than the "
+                                "algorithmic figure, which charges a zero fill and a write of every gradient byte per pooler "
+                                "(SURVEY 8(d)); the tile gather writes each byte once and zero-fills nothing it writes -- "
                                 "frac_traffic = these bytes / the kernel's time / peak is the fraction of HBM bandwidth the "
                                 "kernel really uses",
                 "alg_bytes_per_launch": int(kb), "ms_per_launch": round(k_ms, 4), "launches_timed": k_n,
-                "alg_bytes_note": "SURVEY 8(d) ROIAlign bwd: s*K*C*R^2 (dY) + 2*s*sum_l N*C*H_l*W_l (zero fill + write of dX)",
+                "units_per_launch": 2 if paired else 1,
+                "alg_bytes_note": "SURVEY 8(d) ROIAlign bwd, per pooler: s*K*C*R^2 (dY) + 2*s*sum_l N*C*H_l*W_l (zero fill + "
+                                  "write of dX)" + ("; this launch does the box head's unit (%d B) and the mask head's (%d B)"
+                                                    % (alg["roi_align_box_bwd"], alg["roi_align_mask_bwd"]) if paired else ""),
                 "timing": "HIP events recorded by the library on the kernel's launch stream right around the launch, mean over "
                           + ("an eager pass of the same number of steps right after the timed region (the timed region "
                              "replays HIP graphs, inside which events cannot be read)" if use_graph else "the timed steps"),
                 "kernels_ms": {k: round(v[0], 4) for k, v in ktimes.items()}}
-        ktraffic = pmc_traffic("roi_align_box_bwd", args.layout, "kernel_hbm_bytes_per_launch") or roof["traffic"]
+        if paired:  # the conservative reading: the whole launch charged with ONE unit's bytes
+            roof["frac_one_unit"] = round(alg["roi_align_box_bwd"] / 1e6 / k_ms / HBM_PEAK_GBS, 4)
+        ktraffic = pmc_traffic(pmc_key, args.layout, "kernel_hbm_bytes_per_launch") or roof["traffic"]
         if ktraffic:
             roof["traffic_kernel"] = ktraffic  # the gather kernel alone (the op's figure includes records + binning)
             roof["frac_traffic"] = round(ktraffic / 1e6 / k_ms / HBM_PEAK_GBS, 4)

@@ -59,6 +59,8 @@ struct PoolLevels {
   int qsteal;        // how many OTHER XCDs' queues a persistent workgroup tries once its own is empty (0: none)
   int accumulate;    // backward: 1 = grad_input already holds a gradient (another pooler's): add to it, skip empty tiles
   const int* perm;   // forward: ROI processing order (roi_order_kernel), nullptr: workgroup b pools ROI b
+  const int* skip_cnt;  // backward, MFMA tile gather: per-tile ROI counts of ANOTHER pooler whose (paired) launch has
+                        // gathered this pooler's ROIs of every tile it touches: those tiles are skipped here
 };
 
 // detectron2/modeling/poolers.py:51-59 in fp32, operation for operation:
@@ -1379,10 +1381,22 @@ struct __attribute__((aligned(16))) MfmaShared {
   uint16_t Wlo[2][TILE * TILE][WPITCH];
 };
 
-template <typename T, int PB, bool DYN = true>
-__global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, const RoiRec* __restrict__ rec,
-                                                                   const T* __restrict__ gout, int nslab,
-                                                                   int total_blocks, PoolTileIds ids) {
+// PAIRED launch (PB1 != 0, d2amd_roi_pooler_backward_pair): a SECOND pooler of the same feature maps (Mask R-CNN: the
+// mask head's 14 x 14 pooler behind the box head's 7 x 7) has its ROIs of a tile gathered into the SAME accumulators,
+// behind the first pooler's list and in front of the one epilogue -- one queue take, one prologue, one write of the
+// tile for both, where two launches paid each of them twice and the second one read the tile back to add to it.
+struct PoolPairArgs {
+  const void* gout;       // the second pooler's dY [K][PH][PW][C] ...
+  const RoiRec* rec;      // ... and its own binning (roi_records_kernel / tile_lists_kernel over the same tiles)
+  const int* tile_cnt;
+  const void* tile_list;
+  int K, PH, PW;
+};
+template <int V> struct PbTag { static constexpr int value = V; };
+template <typename T, int PB0, bool DYN = true, int PB1 = 0>
+__global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, const RoiRec* __restrict__ rec0,
+                                                                   const T* __restrict__ gout0, int nslab,
+                                                                   int total_blocks, PoolTileIds ids, PoolPairArgs P2) {
   constexpr int NT = 2 * CT, TR = TILE / 2, VEC = 8;
   __shared__ StagedShared<T> S;
   __shared__ MfmaShared M;
@@ -1473,6 +1487,12 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
   const int n = tl / (tiles_y * tiles_x);
   tl -= n * tiles_y * tiles_x;
   const int y0 = (tl / tiles_x) * TILE, x0 = (tl % tiles_x) * TILE;
+  // (behind a PAIRED launch) a tile the first pooler's launch gathered this pooler's ROIs of: nothing left to add
+  if (L.skip_cnt &&
+      __builtin_amdgcn_readfirstlane(L.skip_cnt[ids.first[lvl] + (tile - L.tile_base[lvl])]) > 0) {  // uniform
+    if (!dynamic) break;
+    continue;
+  }
   const int C = L.C, PH = L.PH, PW = L.PW, K = L.K;
   const int CG = C / VEC;
   const int rh = tid / CT, col = (tid >> 5) & 7, lp = tid & 31;  // row half / pixel column / channel lane
@@ -1502,9 +1522,15 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
   // (column, bin) pairs = 2 * PB / 8 waves, so the 8 waves of the group evaluate EPR = 32 / PB list entries per
   // ROUND, all at the same time (box head: 4 entries, one wave per entry and axis).  Weights live in NSLOT = 3 EPR
   // slots: round r + 2 is evaluated during the first item of round r and overwrites round r - 1.
+  const int wave = tid >> 6;
+  // ONE pooler's ROI list of the tile, gathered into `acc` (a generic lambda: instantiated for the launch's pooler and,
+  // in a paired launch, for the second one -- the bins-per-axis class PB is a compile-time constant of the body)
+  auto run_list = [&](auto pb_tag, const T* gout, const RoiRec* rec, const int K, const int PH, const int PW,
+                      const int* tile_cnt_p, const void* tile_list_p, const int qcnt_l,
+                      const int pinfo_l) __attribute__((always_inline)) {
+  constexpr int PB = decltype(pb_tag)::value;
   constexpr int lg = PB == 8 ? 3 : PB == 16 ? 4 : 5;
   constexpr int EPR = 32 >> lg, NSLOT = 3 * EPR;
-  const int wave = tid >> 6;
   const bool wave_ok = slab * (LPP * VEC) + 32 * wave < C && !(L.ablate & 1);  // this wave's 32 channels exist (C % 32 == 0)
   int nlist = 0;
   auto compute_round = [&](int first) __attribute__((always_inline)) {
@@ -1682,17 +1708,17 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
   };
 
   int tl_cnt = -1;
-  if (L.tile_cnt) {
+  if (tile_cnt_p) {
     const int gtile = ids.first[lvl] + (tile - L.tile_base[lvl]);
-    const int c = qcnt >= 0 ? qcnt : L.tile_cnt[gtile];
+    const int c = qcnt_l >= 0 ? qcnt_l : tile_cnt_p[gtile];
     if (c <= TILE_CAP) {
       // a part of a split list walks entries [lo, hi) of it (parts == 1: all of them)
-      const int part = pinfo & 0xff, parts = (pinfo >> 8) & 0xff;
+      const int part = pinfo_l & 0xff, parts = (pinfo_l >> 8) & 0xff;
       const int len = (c + parts - 1) / parts, lo = part * len, hi = min(c, lo + len);
       tl_cnt = max(hi - lo, 0);
       if (tid < tl_cnt) {
         // (two 16-B loads, then the stores: as a struct copy the compiler split it into three loads, each waited for)
-        const uint4* ep = reinterpret_cast<const uint4*>((const TileEntry*)L.tile_list + (long)gtile * TILE_CAP + lo + tid);
+        const uint4* ep = reinterpret_cast<const uint4*>((const TileEntry*)tile_list_p + (long)gtile * TILE_CAP + lo + tid);
         const uint4 e0 = ep[0], e1 = ep[1];
         S.list[tid] = (int)e1.z;  // TileEntry = {HitGeo (6 words), roi, pad}
         HitGeo g;
@@ -1827,6 +1853,8 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
       e = e2; c = c2; wc = wn; wp = wn2; db ^= 1; nb_cur = nb2; nb_pair = nb2p;
     }
   }
+  };  // run_list
+  run_list(PbTag<PB0>{}, gout0, rec0, K, PH, PW, L.tile_cnt, L.tile_list, qcnt, pinfo);
 #ifdef D2AMD_PROFILE
   if (dbg_on) { L.dbg[127] = dbg_n; L.dbg[126] = 0; L.dbg[125] = __builtin_readcyclecounter() - L.dbg[0]; }
 #endif
@@ -1871,6 +1899,19 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
         v[i] = __hip_atomic_load(all + (size_t)q * slot_floats + i * NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
       for (int i = 0; i < 32; i++) acc[i >> 4][i & 15] += v[i];
+    }
+  }
+  // ---- paired launch: the second pooler's ROIs of this tile, into the same accumulators (the last part of a split
+  // first list arrives here with all parts added).  Its list is never walked in parts here: a part is a queue entry of
+  // that pooler's OWN launch, which skips every tile this one takes (L.skip_cnt).
+  if constexpr (PB1 != 0) {
+    if (P2.tile_cnt) {  // uniform
+      const int gtile = ids.first[lvl] + (tile - L.tile_base[lvl]);
+      const int c2 = __builtin_amdgcn_readfirstlane(P2.tile_cnt[gtile]);
+      if (c2 > 0) {
+        __syncthreads();  // everyone is done with the first list's staged bins, weight images and entries
+        run_list(PbTag<PB1>{}, (const T*)P2.gout, P2.rec, P2.K, P2.PH, P2.PW, P2.tile_cnt, P2.tile_list, c2, 1 << 8);
+      }
     }
   }
   // ---- epilogue: accumulators (lane = channel, registers = pixels) -> LDS [pixel][channel] in the I/O dtype ->
@@ -2272,10 +2313,14 @@ static long pool_ntiles(const d2amd_pooler_params* p) {
   return n;
 }
 
+// (pair: this launch also gathers a second pooler's lists -- the MFMA tile gather of a pooler with <= 8 bins per axis
+// only; skip_cnt: this launch leaves out the tiles a paired launch in front of it took; probe: no launch at all, the
+// return value says whether the call would take the MFMA tile gather: OK / EUNSUPPORTED)
 template <typename T>
 static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_output, const float* rois,
                               void* const* grad_inputs, int K, void* workspace, size_t workspace_bytes,
-                              hipStream_t s, bool accumulate, int phase = 0) {
+                              hipStream_t s, bool accumulate, int phase = 0, const PoolPairArgs* pair = nullptr,
+                              const int* skip_cnt = nullptr, bool probe = false, PoolPairArgs* binned_out = nullptr) {
   // phase 0: everything; 1: only the binning (records, per-tile ROI lists, work queues -- depends on the ROIs alone
   // in accumulate mode, so a caller can run it beside other work); 2: only the gather, ADDING, after a phase-1 call
   // with the same arguments and workspace; 3: the same but WRITING: the tiles without ROIs are zero-filled by their
@@ -2320,6 +2365,19 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
   const bool split_capable = staged && sizeof(T) == 2 && !no_mfma_env && p->C % 32 == 0 && p->C <= 8192 &&
       nslab <= SPLIT_MAX_SLABS;
   const size_t slot_bytes = (size_t)nslab * 32 * (2 * CT) * sizeof(float);  // 16 accumulators x 2 tiles x 512 threads
+  if (pair || skip_cnt || probe) {  // the paired gathers exist in the persistent MFMA tile gather only
+    static const bool fixed = getenv("D2AMD_POOL_STATIC") != nullptr || getenv("D2AMD_POOL_STAMPS") != nullptr ||
+        getenv("D2AMD_POOL_STAMPS_STATIC") != nullptr;
+    const int pm = p->pooled_h > p->pooled_w ? p->pooled_h : p->pooled_w;
+    const bool ok = staged && sizeof(T) == 2 && !no_mfma_env && !fixed && p->C % 32 == 0 && p->C <= 8192 && K > 0 &&
+        (pair ? pm <= 8 : true);
+    if (!ok || probe) return ok ? D2AMD_OK : D2AMD_EUNSUPPORTED;
+  }
+  if (binned_out) {  // where this call's binning lives (for the launch that gathers its lists as the second pooler)
+    binned_out->rec = rec;
+    binned_out->tile_cnt = tile_cnt;
+    binned_out->tile_list = tile_list;
+  }
   if (queues) {
     int per[2][8] = {};
     int base[2] = {0, 0};
@@ -2391,6 +2449,7 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
     L.qcap = Q.cap[0];
     L.part_tickets = Q.mem + QCTR;
     L.part_scratch = (float*)((char*)workspace + off_q + pool_queue_bytes(ntiles));
+    L.skip_cnt = skip_cnt;
     const long total = 8l * L.qcap * nslab;
     if (total == 0) return D2AMD_OK;
     static const bool static_slots = getenv("D2AMD_POOL_STATIC") != nullptr;  // A/B: one workgroup per queue slot
@@ -2409,7 +2468,7 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
       L.dbg_block = atoi(getenv("D2AMD_DBG_BLOCK"));
     }
 #endif
-    const char* tname = p->pooled_h <= 7 ? "pool_bwd_staged_r7" : "pool_bwd_staged_r14";
+    const char* tname = pair ? "pool_bwd_pair" : p->pooled_h <= 7 ? "pool_bwd_staged_r7" : "pool_bwd_staged_r14";
     const bool timed = timing_begin(tname, s);
     const int pmax = p->pooled_h > p->pooled_w ? p->pooled_h : p->pooled_w;
     bool mfma = false;
@@ -2425,17 +2484,20 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
         // (tried and dropped, profiles/r03/pool_bwd/README.md: no take counters at all -- workgroup j of an XCD walking
         // its queue with a fixed stride: the gap between tiles halves, but the unsorted queue leaves the workgroups 25 us
         // apart at the end (takes: 10 us): 90.8 us against 74.3)
+        const PoolPairArgs P2 = pair ? *pair : PoolPairArgs{};
         auto launch = [&](auto dyn_fn, auto static_fn) {
           if (L.qctr) {
             const long r = resident_workgroups((const void*)dyn_fn, 2 * CT) & ~7l;
             const unsigned grid = (unsigned)(r >= 8 && r < total ? r : total);
-            hipLaunchKernelGGL(dyn_fn, dim3(grid), dim3(2 * CT), 0, s, L, rec, (const T*)grad_output, nslab, (int)total, ids);
+            hipLaunchKernelGGL(dyn_fn, dim3(grid), dim3(2 * CT), 0, s, L, rec, (const T*)grad_output, nslab, (int)total, ids,
+                               P2);
           } else {
             hipLaunchKernelGGL(static_fn, dim3((unsigned)total), dim3(2 * CT), 0, s, L, rec, (const T*)grad_output, nslab,
-                               (int)total, ids);
+                               (int)total, ids, P2);
           }
         };
-        if (pmax <= 8) launch(pool_bwd_mfma_kernel<T, 8, true>, pool_bwd_mfma_kernel<T, 8, false>);
+        if (pair) launch(pool_bwd_mfma_kernel<T, 8, true, 16>, pool_bwd_mfma_kernel<T, 8, true, 16>);  // (persistent only)
+        else if (pmax <= 8) launch(pool_bwd_mfma_kernel<T, 8, true>, pool_bwd_mfma_kernel<T, 8, false>);
         else if (pmax <= 16) launch(pool_bwd_mfma_kernel<T, 16, true>, pool_bwd_mfma_kernel<T, 16, false>);
         else launch(pool_bwd_mfma_kernel<T, 32, true>, pool_bwd_mfma_kernel<T, 32, false>);
       }
@@ -2753,6 +2815,82 @@ extern "C" int d2amd_roi_pooler_backward_accumulate(const d2amd_pooler_params* p
                                                     const float* rois, void* const* grad_inputs, int K,
                                                     void* workspace, size_t workspace_bytes, void* stream) {
   return pooler_backward_entry(p, grad_output, rois, grad_inputs, K, workspace, workspace_bytes, stream, true);
+}
+
+// Two poolers of the SAME feature maps (the box head's and the mask head's), one gradient: the first pooler's tile gather
+// takes the second one's ROIs of every tile it touches along (pool_bwd_mfma_kernel<T, 8, true, 16>), the second pooler's own
+// launch is left with the tiles only it touches.  = d2amd_roi_pooler_backward(p1 ...) followed by
+// d2amd_roi_pooler_backward_accumulate(p2 ...), except that a tile both touch is rounded to the I/O dtype ONCE (the sum
+// of both gathers in fp32) instead of once per pooler.  EUNSUPPORTED (nothing launched) outside the 16-bit MFMA tile
+// gather with bins per axis <= 8 (first) and 9..16 (second): the caller issues the two calls.
+extern "C" int d2amd_roi_pooler_backward_pair(const d2amd_pooler_params* p1, const void* grad_output1, const float* rois1,
+                                              int K1, void* workspace1, size_t workspace1_bytes,
+                                              const d2amd_pooler_params* p2, const void* grad_output2, const float* rois2,
+                                              int K2, void* workspace2, size_t workspace2_bytes, void* const* grad_inputs,
+                                              void* stream) {
+  int rc = check_pooler(p1, "roi_pooler_backward_pair");
+  if (rc) return rc;
+  rc = check_pooler(p2, "roi_pooler_backward_pair");
+  if (rc) return rc;
+  D2_CHECK_ARG(K1 >= 0 && K2 >= 0, "roi_pooler_backward_pair: bad K");
+  D2_CHECK_ARG(grad_inputs && (K1 == 0 || (grad_output1 && rois1)) && (K2 == 0 || (grad_output2 && rois2)),
+               "roi_pooler_backward_pair: null pointer");
+  bool same = p1->num_levels == p2->num_levels && p1->N == p2->N && p1->C == p2->C && p1->dtype == p2->dtype &&
+      p1->layout == p2->layout;
+  for (int l = 0; same && l < p1->num_levels; l++) same = p1->H[l] == p2->H[l] && p1->W[l] == p2->W[l];
+  D2_CHECK_ARG(same, "roi_pooler_backward_pair: the two poolers must read the same feature maps");
+  static const bool off = getenv("D2AMD_POOL_NO_PAIR") != nullptr;
+  const int pm1 = p1->pooled_h > p1->pooled_w ? p1->pooled_h : p1->pooled_w;
+  const int pm2 = p2->pooled_h > p2->pooled_w ? p2->pooled_h : p2->pooled_w;
+  if (off || K1 == 0 || K2 == 0 || !pooler_fused_ok(p1) || !pooler_fused_ok(p2) || p1->layout != D2AMD_NHWC ||
+      p1->dtype == D2AMD_F32 || pm1 > 8 || pm2 <= 8 || pm2 > 16 || (long)p1->N * p1->C == 0) {
+    set_error("roi_pooler_backward_pair: outside the paired 16-bit tile gather (bins per axis <= 8 and 9..16, NHWC)");
+    return D2AMD_EUNSUPPORTED;
+  }
+  return D2_DISPATCH_DTYPE(p1->dtype, [&]() -> int {
+    if constexpr (sizeof(scalar_t) != 2) {
+      return D2AMD_EUNSUPPORTED;
+    } else {
+      hipStream_t s = (hipStream_t)stream;
+      // both calls must take the MFMA tile gather (probe: nothing is launched)
+      int r = pool_bwd_nhwc_impl<scalar_t>(p1, grad_output1, rois1, grad_inputs, K1, workspace1, workspace1_bytes, s, false, 1,
+                                           nullptr, nullptr, true);
+      if (r) return r;
+      r = pool_bwd_nhwc_impl<scalar_t>(p2, grad_output2, rois2, grad_inputs, K2, workspace2, workspace2_bytes, s, true, 1,
+                                       nullptr, nullptr, true);
+      if (r) return r;
+      // binning: the first pooler's on the caller's stream (it zero-fills the tiles the first pooler does not touch), the
+      // second one's beside it
+      SideStream* side = side_stream();
+      hipStream_t s2 = s;
+      if (side) {
+        D2_HIP_OK(hipEventRecord(side->fork, s));
+        D2_HIP_OK(hipStreamWaitEvent(side->stream, side->fork, 0));
+        s2 = side->stream;
+      }
+      PoolPairArgs b1{}, b2{};
+      r = pool_bwd_nhwc_impl<scalar_t>(p2, grad_output2, rois2, grad_inputs, K2, workspace2, workspace2_bytes, s2, true, 1,
+                                       nullptr, nullptr, false, &b2);
+      int r1 = pool_bwd_nhwc_impl<scalar_t>(p1, grad_output1, rois1, grad_inputs, K1, workspace1, workspace1_bytes, s, false,
+                                            1, nullptr, nullptr, false, &b1);
+      if (side) {  // (joined whatever the calls returned: a capture must not end with a dangling branch)
+        D2_HIP_OK(hipEventRecord(side->join, side->stream));
+        D2_HIP_OK(hipStreamWaitEvent(s, side->join, 0));
+      }
+      if (r) return r;
+      if (r1) return r1;
+      b2.gout = grad_output2;
+      b2.K = K2;
+      b2.PH = p2->pooled_h;
+      b2.PW = p2->pooled_w;
+      // the paired gather: writes every tile the first pooler touches, with both poolers' ROIs
+      r = pool_bwd_nhwc_impl<scalar_t>(p1, grad_output1, rois1, grad_inputs, K1, workspace1, workspace1_bytes, s, false, 2, &b2);
+      if (r) return r;
+      // the second pooler's own tiles (no ROI of the first one): added to the zeros the first binning wrote there
+      return pool_bwd_nhwc_impl<scalar_t>(p2, grad_output2, rois2, grad_inputs, K2, workspace2, workspace2_bytes, s, true, 2,
+                                          nullptr, b1.tile_cnt);
+    }
+  });
 }
 
 extern "C" int d2amd_roi_pooler_backward_phase(const d2amd_pooler_params* p, const void* grad_output,

@@ -232,6 +232,9 @@ _FWD_ORDERED = _os.environ.get("D2AMD_FWD_ORDER", "0") == "1"
 _JOIN_EARLY = _os.environ.get("D2AMD_JOIN_EARLY", "0") == "1"
 _ROT_POOLER_LOOP = _os.environ.get("D2AMD_ROT_POOLER_LOOP", "0") == "1"  # A/B switch: rotated pooler level by level
 _SIDE_BINNING = _os.environ.get("D2AMD_SIDE_BINNING", "1") != "0"  # A/B switch: the later gathers' binning beside the first
+# The first two gathers of a chain in ONE pass over the tiles (d2amd_roi_pooler_backward_pair: box head 7x7 + mask head
+# 14x14); D2AMD_POOL_PAIR=0: one launch per pooler, the second one adding (the A/B and the bit-for-bit autograd sum).
+_PAIR = _os.environ.get("D2AMD_POOL_PAIR", "1") != "0"
 
 
 def _PREBIN(head):
@@ -385,6 +388,22 @@ class _FusedROIPool(Function):
             grads = [torch.empty((n, c, h, w), dtype=g0.dtype, device=dev, memory_format=torch.channels_last)
                      for (h, w) in hw]
         with _C.on_device(dev):
+            if (plain_first and _PAIR and len(works) >= 2 and works[0][3] is None and works[1][3] is None
+                    and works[0][1].shape[0] > 0 and works[1][1].shape[0] > 0 and works[0][0].dtype == works[1][0].dtype):
+                (g1, r1, c1, _), (g2, r2, c2, _) = works[0], works[1]
+                p1 = _params(c1, (n, c), hw, _C.dtype_code(g1), _C.NHWC)
+                p2 = _params(c2, (n, c), hw, _C.dtype_code(g2), _C.NHWC)
+                b1 = L.d2amd_roi_pooler_backward_workspace_bytes(ctypes.byref(p1), r1.shape[0])
+                b2 = L.d2amd_roi_pooler_backward_workspace_bytes(ctypes.byref(p2), r2.shape[0])
+                ws1 = torch.empty(b1, dtype=torch.uint8, device=dev)
+                ws2 = torch.empty(b2, dtype=torch.uint8, device=dev)
+                rc = L.d2amd_roi_pooler_backward_pair(ctypes.byref(p1), _C.ptr(g1), _C.ptr(r1), r1.shape[0], _C.ptr(ws1), b1,
+                                                      ctypes.byref(p2), _C.ptr(g2), _C.ptr(r2), r2.shape[0], _C.ptr(ws2), b2,
+                                                      _ptr_array(grads), _C.stream())
+                if rc == 0:  # both are in `grads`: whatever follows adds
+                    works, plain_first = works[2:], False
+                elif rc != _C.EUNSUPPORTED:
+                    _C.check(rc)
             # The binning of the chain's LATER gathers (records, per-tile lists, queues: ~20 us of small launches each,
             # a function of the ROIs alone) runs on a side stream beside the first gather instead of between the gathers.
             if len(works) > 1 and grads is not None and _SIDE_BINNING:

@@ -1,0 +1,212 @@
+"""GPU tests of the PAIRED pooler backward (d2amd_roi_pooler_backward_pair, csrc/roi_pool.hip: pool_bwd_mfma_kernel<T, 8,
+true, 16>): the box head's 7x7 pooler and the mask head's 14x14 pooler of the same FPN features (roi_heads.py:780-846,
+modeling/poolers.py:206-263 twice) gathered in ONE pass over the gradient's tiles.
+
+Checked against (a) the oracle's two ROIAlign backwards summed (what autograd accumulates in the reference) and (b) the
+library's own two-call sequence d2amd_roi_pooler_backward + d2amd_roi_pooler_backward_accumulate: equal bit for bit on
+every tile only one pooler touches, within the roundings the two-call sequence adds where both do (it rounds each
+pooler's sum to the I/O dtype, then their sum; the paired launch rounds the fp32 sum of both once)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from detectron2_amd import _C
+from detectron2_amd.modeling import ROIPooler
+from detectron2_amd.modeling import poolers as P
+from detectron2_amd.structures import Boxes
+
+from test_gpu_pooler import SCALES, make_inputs, oracle_pooler, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _rois(boxes):
+    allb = np.concatenate(boxes)
+    bidx = np.concatenate([np.full(len(b), i, np.float32) for i, b in enumerate(boxes)])
+    return torch.from_numpy(np.concatenate([bidx[:, None], allb], 1).astype(np.float32)).to(DEV)
+
+
+def _cfg(out):
+    return ((out, out), tuple(SCALES), 0, True, 2, 5, 224, 4)
+
+
+def _nhwc(a, dtype):
+    return torch.from_numpy(a).to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+
+
+def _run(kind, feats, boxes1, g1, boxes2, g2, dtype, out1=7, out2=14):
+    """-> (rc, per-level gradients) of the paired call / of the two-call sequence"""
+    L = _C.lib()
+    n, c = feats[0].shape[:2]
+    hw = [tuple(f.shape[2:]) for f in feats]
+    code = _C.dtype_code(torch.empty(0, dtype=dtype))
+    p1, p2 = P._params(_cfg(out1), (n, c), hw, code, _C.NHWC), P._params(_cfg(out2), (n, c), hw, code, _C.NHWC)
+    r1, r2 = _rois(boxes1), _rois(boxes2)
+    k1, k2 = int(r1.shape[0]), int(r2.shape[0])
+    grads = [torch.full((n, c) + s, 7.0, dtype=dtype, device=DEV).contiguous(memory_format=torch.channels_last) for s in hw]
+    b1 = L.d2amd_roi_pooler_backward_workspace_bytes(ctypes.byref(p1), k1)
+    b2 = L.d2amd_roi_pooler_backward_workspace_bytes(ctypes.byref(p2), k2)
+    ws1, ws2 = torch.empty(b1, dtype=torch.uint8, device=DEV), torch.empty(b2, dtype=torch.uint8, device=DEV)
+    with _C.on_device(grads[0].device):
+        if kind == "pair":
+            rc = L.d2amd_roi_pooler_backward_pair(ctypes.byref(p1), _C.ptr(g1), _C.ptr(r1), k1, _C.ptr(ws1), b1,
+                                                  ctypes.byref(p2), _C.ptr(g2), _C.ptr(r2), k2, _C.ptr(ws2), b2,
+                                                  P._ptr_array(grads), _C.stream())
+        else:
+            rc = L.d2amd_roi_pooler_backward(ctypes.byref(p1), _C.ptr(g1), _C.ptr(r1), P._ptr_array(grads), k1, _C.ptr(ws1),
+                                             b1, _C.stream())
+            if rc == 0:
+                rc = L.d2amd_roi_pooler_backward_accumulate(ctypes.byref(p2), _C.ptr(g2), _C.ptr(r2), P._ptr_array(grads),
+                                                            k2, _C.ptr(ws2), b2, _C.stream())
+    torch.cuda.synchronize()
+    return rc, grads
+
+
+def _ulps_apart(a, b):
+    """distance in representable values of the 16-bit dtype (sign-magnitude bit patterns mapped to a line)"""
+    def line(t):
+        v = t.view(torch.int16).to(torch.int32)
+        return torch.where(v < 0, -(v & 0x7FFF), v)
+    return (line(a) - line(b)).abs()
+
+
+def _clustered(rng, boxes, per_tile, img_h, img_w, size=(150, 210)):
+    out = []
+    for b0 in boxes:
+        c = rng.uniform([150, 120], [300, 200])
+        ctr = c + rng.uniform(-6, 6, (per_tile, 2))
+        wh = rng.uniform(size[0], size[1], (per_tile, 2))
+        b = np.concatenate([ctr - wh / 2, ctr + wh / 2], 1)
+        b[:, 0::2] = b[:, 0::2].clip(0, img_w)
+        b[:, 1::2] = b[:, 1::2].clip(0, img_h)
+        out.append(np.concatenate([b0, b.astype(np.float32)]))
+    return out
+
+
+CASES = {
+    # the second pooler's boxes are a SUBSET of the first one's (Mask R-CNN: the foreground proposals): its own launch
+    # finds every tile taken
+    "subset": dict(per1=48, per2=12, subset=True),
+    # independent boxes: tiles of all three kinds (first only / second only / both)
+    "independent": dict(per1=40, per2=24, subset=False),
+    # a first list beyond SPLIT_MIN on a few tiles (cut into parts; the LAST part to arrive takes the second list along)
+    "first_split": dict(per1=20, per2=16, subset=False, cluster1=64),
+    # a second list beyond the per-tile list capacity (in-kernel scan of the second pooler's records in the paired launch)
+    "second_scans": dict(per1=24, per2=8, subset=False, cluster2=90),
+    # both long
+    "both_long": dict(per1=16, per2=8, subset=False, cluster1=50, cluster2=50),
+    # few, small boxes: most tiles empty, zero-filled by the first pooler's binning
+    "sparse": dict(per1=3, per2=2, subset=False),
+}
+
+
+def _case(name, dtype, C=64, img_h=320, img_w=448):
+    cs = CASES[name]
+    rng = np.random.default_rng(sum(map(ord, name)))
+    feats, boxes1 = make_inputs(rng, 2, C, img_h, img_w, cs["per1"])
+    if cs["subset"]:
+        boxes2 = [b[:cs["per2"]].copy() for b in boxes1]
+    else:
+        _, boxes2 = make_inputs(rng, 2, C, img_h, img_w, cs["per2"])
+    if "cluster1" in cs:
+        boxes1 = _clustered(rng, boxes1, cs["cluster1"], img_h, img_w)
+    if "cluster2" in cs:
+        boxes2 = _clustered(rng, boxes2, cs["cluster2"], img_h, img_w, size=(160, 200))
+    k1, k2 = sum(len(b) for b in boxes1), sum(len(b) for b in boxes2)
+    g1 = _nhwc(rng.standard_normal((k1, C, 7, 7)).astype(np.float32), dtype)
+    g2 = _nhwc(rng.standard_normal((k2, C, 14, 14)).astype(np.float32), dtype)
+    return feats, boxes1, g1, boxes2, g2
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("name", list(CASES))
+def test_pair_vs_oracle_and_vs_the_two_call_sequence(name, dtype):
+    feats, boxes1, g1, boxes2, g2 = _case(name, dtype)
+    rc, pair = _run("pair", feats, boxes1, g1, boxes2, g2, dtype)
+    assert rc == 0, _C.lib().d2amd_last_error().decode()
+    rc, two = _run("two", feats, boxes1, g1, boxes2, g2, dtype)
+    assert rc == 0
+    _, gin1, _ = oracle_pooler(feats, boxes1, 7, 0, True, grad=g1.float().cpu().numpy())
+    _, gin2, _ = oracle_pooler(feats, boxes2, 14, 0, True, grad=g2.float().cpu().numpy())
+    tol = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    differ = 0
+    for l in range(4):
+        want = gin1[l] + gin2[l]
+        assert torch.isfinite(pair[l]).all()
+        assert rel_err(pair[l].float().cpu().numpy(), want) < tol, l
+        # tiles only one pooler touches: the same bits; both: one rounding of the sum against one per pooler + one of
+        # the sum, i.e. |difference| <= ulp(sum1) / 2 + ulp(sum2) / 2 + ulp(result) (+ the fp32 accumulation order)
+        d = _ulps_apart(pair[l], two[l])
+        both = torch.from_numpy((gin1[l] != 0) & (gin2[l] != 0)).to(DEV)
+        if "cluster2" not in CASES[name]:  # (a second list of 41..64 entries is walked in PARTS by the second pooler's own
+            # launch -- partial fp32 sums added in part order -- and whole by the paired one: another summation order)
+            assert int(d[~both].max() if (~both).any() else 0) == 0, l
+        half = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11  # ulp(x) / 2 <= half * |x|
+        bound = half * (np.abs(gin1[l]) + np.abs(gin2[l])) + 2 * half * np.abs(want) + 1e-6 * (np.abs(gin1[l]) + np.abs(gin2[l])) + 2.0 ** -23
+        diff = (pair[l].double() - two[l].double()).abs().cpu().numpy()
+        assert (diff <= bound).all(), (l, float((diff / bound).max()))
+        differ += int((d > 0).sum())
+        # and where they differ the single rounding is the closer one (or as close) to the fp64 sum
+        if (d > 0).any():
+            w = torch.from_numpy(want).to(DEV).double()
+            ep, et = (pair[l].double() - w).abs(), (two[l].double() - w).abs()
+            m = d > 0
+            assert float((ep[m] <= et[m] + 1e-12 * w[m].abs()).float().mean()) > 0.9
+    if name != "sparse":
+        assert differ > 0  # (the case does exercise tiles both poolers touch)
+    # deterministic
+    _, again = _run("pair", feats, boxes1, g1, boxes2, g2, dtype)
+    assert all(torch.equal(a, b) for a, b in zip(pair, again))
+
+
+def test_pair_is_refused_outside_the_16_bit_tile_gather_and_launches_nothing():
+    rng = np.random.default_rng(1)
+    feats, boxes1 = make_inputs(rng, 2, 64, 160, 224, 8)
+    boxes2 = [b[:3] for b in boxes1]
+    # fp32
+    g1 = _nhwc(rng.standard_normal((16, 64, 7, 7)).astype(np.float32), torch.float32)
+    g2 = _nhwc(rng.standard_normal((6, 64, 14, 14)).astype(np.float32), torch.float32)
+    rc, grads = _run("pair", feats, boxes1, g1, boxes2, g2, torch.float32)
+    assert rc == _C.EUNSUPPORTED and all(bool((g == 7.0).all()) for g in grads)
+    # the 14 x 14 pooler first
+    g1 = _nhwc(rng.standard_normal((16, 64, 14, 14)).astype(np.float32), torch.bfloat16)
+    g2 = _nhwc(rng.standard_normal((6, 64, 7, 7)).astype(np.float32), torch.bfloat16)
+    rc, grads = _run("pair", feats, boxes1, g1, boxes2, g2, torch.bfloat16, out1=14, out2=7)
+    assert rc == _C.EUNSUPPORTED and all(bool((g == 7.0).all()) for g in grads)
+    # channels not a multiple of 32
+    feats40 = [f[:, :40].copy() for f in feats]
+    g1 = _nhwc(rng.standard_normal((16, 40, 7, 7)).astype(np.float32), torch.bfloat16)
+    g2 = _nhwc(rng.standard_normal((6, 40, 14, 14)).astype(np.float32), torch.bfloat16)
+    rc, grads = _run("pair", feats40, boxes1, g1, boxes2, g2, torch.bfloat16)
+    assert rc == _C.EUNSUPPORTED and all(bool((g == 7.0).all()) for g in grads)
+
+
+@pytest.mark.parametrize("pair", [True, False])
+def test_chained_poolers_take_the_paired_launch_through_autograd(pair, monkeypatch):
+    """ROIPooler x 2 on the same leaves, one backward: with the pairing on, ONE paired gather (+ the second pooler's
+    launch over what is left) runs; off (D2AMD_POOL_PAIR=0), one gather per pooler.  Same gradients to one ulp."""
+    monkeypatch.setattr(P, "_PAIR", pair)
+    feats, boxes1, g1, boxes2, g2 = _case("independent", torch.bfloat16)
+    names = b"pool_bwd_pair,pool_bwd_staged_r7,pool_bwd_staged_r14"
+    _C.lib().d2amd_timing_select(names)
+    try:
+        xs = [_nhwc(f, torch.bfloat16).requires_grad_(True) for f in feats]
+        yb = ROIPooler(7, SCALES, 0, "ROIAlignV2")(xs, [Boxes(torch.from_numpy(b).to(DEV)) for b in boxes1])
+        ym = ROIPooler(14, SCALES, 0, "ROIAlignV2")(xs, [Boxes(torch.from_numpy(b).to(DEV)) for b in boxes2])
+        torch.autograd.backward([yb, ym], [g1, g2])
+        torch.cuda.synchronize()
+        cnt = {}
+        for kn in names.split(b","):
+            tot, c = ctypes.c_double(0.0), ctypes.c_int(0)
+            _C.check(_C.lib().d2amd_timing_read(kn, ctypes.byref(tot), ctypes.byref(c)))
+            cnt[kn.decode()] = c.value
+    finally:
+        _C.lib().d2amd_timing_select(None)
+        P._ALIASES.clear()
+    assert cnt == ({"pool_bwd_pair": 1, "pool_bwd_staged_r7": 0, "pool_bwd_staged_r14": 1} if pair else
+                   {"pool_bwd_pair": 0, "pool_bwd_staged_r7": 1, "pool_bwd_staged_r14": 1}), cnt
+    _, want = _run("pair" if pair else "two", feats, boxes1, g1, boxes2, g2, torch.bfloat16)
+    assert all(torch.equal(x.grad, w) for x, w in zip(xs, want))
