@@ -59,8 +59,6 @@ struct PoolLevels {
   int qsteal;        // how many OTHER XCDs' queues a persistent workgroup tries once its own is empty (0: none)
   int accumulate;    // backward: 1 = grad_input already holds a gradient (another pooler's): add to it, skip empty tiles
   const int* perm;   // forward: ROI processing order (roi_order_kernel), nullptr: workgroup b pools ROI b
-  const int* skip_cnt;  // backward, MFMA tile gather: per-tile ROI counts of ANOTHER pooler whose (paired) launch has
-                        // gathered this pooler's ROIs of every tile it touches: those tiles are skipped here
 };
 
 // detectron2/modeling/poolers.py:51-59 in fp32, operation for operation:
@@ -455,19 +453,24 @@ __device__ __forceinline__ bool footprint_rect(const RoiGeom& g, int H, int W, i
   return true;
 }
 
+// A SECOND pooler binned together with the first one (d2amd_roi_pooler_backward_pair): records [K1, L.K) are its ROIs,
+// evaluated with its pooled size (same feature maps, level rule, sampling ratio and alignment: checked by the host).
+struct PairBin { const float* rois2; int K1, PH2, PW2; };  // rois2 == nullptr: one pooler, K1 = L.K
 // Also resets the work queues of the backward launches (counters = 0, slots = -1 "no tile").
 __global__ void roi_records_kernel(PoolLevels L, const float* __restrict__ rois, RoiRec* __restrict__ rec,
-                                   int* __restrict__ qmem, int qzero, int qints) {
+                                   int* __restrict__ qmem, int qzero, int qints, PairBin B) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   for (int i = k; i < qints; i += gridDim.x * blockDim.x) qmem[i] = i < qzero ? 0 : -1;  // counters + tickets | slots
   if (k >= L.K) return;
-  const float* r = rois + (long)k * 5;
+  const bool second = B.rois2 != nullptr && k >= B.K1;
+  const float* r = second ? B.rois2 + (long)(k - B.K1) * 5 : rois + (long)k * 5;
+  const int PH = second ? B.PH2 : L.PH, PW = second ? B.PW2 : L.PW;
   RoiRec o{};
   o.level = -1;
   o.batch = (int)r[0];
   const int lvl = assign_level(r + 1, L);
   if (lvl >= 0) {
-    const RoiGeom g = roi_geom_box(r[0], r[1], r[2], r[3], r[4], L.scale[lvl], L.PH, L.PW, L.sr, L.aligned);
+    const RoiGeom g = roi_geom_box(r[0], r[1], r[2], r[3], r[4], L.scale[lvl], PH, PW, L.sr, L.aligned);
     if (footprint_rect(g, L.H[lvl], L.W[lvl], o.fy0, o.fy1, o.fx0, o.fx1)) {
       o.level = lvl;
       o.g = HitGeo{g.start_h, g.start_w, g.bin_h, g.bin_w, 1.f / (float)(g.grid_h * g.grid_w),
@@ -537,14 +540,17 @@ __host__ __device__ __forceinline__ int tile_xcd(int lvl, int n, int ty, int tx,
 // L.tile_base here numbers ALL tiles of all levels (make_levels); the two backward launches map their
 // own tile numbering onto it through `first` (tile id of their first tile per level).
 constexpr int LISTS_WAVES = 16;  // tiles (waves) per workgroup of tile_lists_kernel
+// (tile_cnt1 != nullptr: two poolers binned together -- records [0, K1) are the first one's; the number of its entries in
+// a tile's list goes to tile_cnt1, the second pooler's entries follow them in the list)
 __global__ __launch_bounds__(64 * LISTS_WAVES) void tile_lists_kernel(PoolLevels L, const RoiRec* __restrict__ rec,
                                                                      int ntiles, int* __restrict__ tile_cnt,
-                                                                     TileEntry* __restrict__ tile_list, TileQueues Q) {
+                                                                     TileEntry* __restrict__ tile_list, TileQueues Q,
+                                                                     int K1, int* __restrict__ tile_cnt1) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tile = blockIdx.x * LISTS_WAVES + wave;
   const bool live = tile < ntiles;  // uniform per wave; dead waves only take part in the barriers
   TileGeom g{};
-  int cnt = 0;
+  int cnt = 0, cnt1 = 0;
   if (live) {
     g = tile_geom(L, tile);
     constexpr int UN = 4;  // record heads of 4 x 64 ROIs in flight (one L2 round trip instead of four)
@@ -572,10 +578,12 @@ __global__ __launch_bounds__(64 * LISTS_WAVES) void tile_lists_kernel(PoolLevels
           tile_list[(long)tile * TILE_CAP + pos] = e;
         }
         cnt += __builtin_popcountll(bal);
+        cnt1 += __builtin_popcountll(__ballot(hit && kk < K1));
       }
     }
     if (lane == 0) __hip_atomic_store(&tile_cnt[tile], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (the planner
-  }                                                                                                     // reads it)
+    if (lane == 0 && tile_cnt1) tile_cnt1[tile] = cnt1;                                                  // reads it)
+  }
   if (Q.mem == nullptr) return;  // uniform
   const int H = L.H[g.lvl], W = L.W[g.lvl];
   bool push = live;
@@ -604,7 +612,8 @@ __global__ __launch_bounds__(64 * LISTS_WAVES) void tile_lists_kernel(PoolLevels
     for (int l = 1; l < POOL_MAX_LEVELS; l++)
       if (l == g.lvl) shift = Q.deal_shift[l];
     x = tile_xcd(g.lvl, g.n, g.y0 >> 3, g.x0 >> 3, (W + 7) >> 3, shift);
-    heavy = cnt >= Q.thr[pass];
+    // (an entry of the second pooler of a pair -- more bins per axis -- is about three of the first one's)
+    heavy = cnt + 2 * (tile_cnt1 ? cnt - cnt1 : 0) >= Q.thr[pass];
     key = (heavy ? 0 : 16) + pass * 8 + x;
     // a list long enough to be split is queued by the planner below (the last workgroup), not here
     if (pass == 0 && Q.scr_total > 0 && cnt > SPLIT_MIN && cnt <= TILE_CAP) {
@@ -1382,15 +1391,15 @@ struct __attribute__((aligned(16))) MfmaShared {
 };
 
 // PAIRED launch (PB1 != 0, d2amd_roi_pooler_backward_pair): a SECOND pooler of the same feature maps (Mask R-CNN: the
-// mask head's 14 x 14 pooler behind the box head's 7 x 7) has its ROIs of a tile gathered into the SAME accumulators,
-// behind the first pooler's list and in front of the one epilogue -- one queue take, one prologue, one write of the
-// tile for both, where two launches paid each of them twice and the second one read the tile back to add to it.
+// mask head's 14 x 14 pooler behind the box head's 7 x 7) is binned TOGETHER with the first one -- records [0, K1) are
+// the first pooler's ROIs, [K1, K1 + K2) the second one's, a tile's list holds the first pooler's entries in front of
+// the second one's (tile_cnt1 of them) -- and both sublists are gathered into the SAME accumulators: one queue take, one
+// prologue and one write of the tile for both, where two launches paid each of them twice and the second one read the
+// tile back to add to it.
 struct PoolPairArgs {
-  const void* gout;       // the second pooler's dY [K][PH][PW][C] ...
-  const RoiRec* rec;      // ... and its own binning (roi_records_kernel / tile_lists_kernel over the same tiles)
-  const int* tile_cnt;
-  const void* tile_list;
-  int K, PH, PW;
+  const void* gout;     // the second pooler's dY [K2][PH][PW][C]
+  const int* tile_cnt1; // per tile: entries of the FIRST pooler in its list (the rest are the second one's)
+  int K1, K2, PH, PW;
 };
 template <int V> struct PbTag { static constexpr int value = V; };
 template <typename T, int PB0, bool DYN = true, int PB1 = 0>
@@ -1487,12 +1496,6 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
   const int n = tl / (tiles_y * tiles_x);
   tl -= n * tiles_y * tiles_x;
   const int y0 = (tl / tiles_x) * TILE, x0 = (tl % tiles_x) * TILE;
-  // (behind a PAIRED launch) a tile the first pooler's launch gathered this pooler's ROIs of: nothing left to add
-  if (L.skip_cnt &&
-      __builtin_amdgcn_readfirstlane(L.skip_cnt[ids.first[lvl] + (tile - L.tile_base[lvl])]) > 0) {  // uniform
-    if (!dynamic) break;
-    continue;
-  }
   const int C = L.C, PH = L.PH, PW = L.PW, K = L.K;
   const int CG = C / VEC;
   const int rh = tid / CT, col = (tid >> 5) & 7, lp = tid & 31;  // row half / pixel column / channel lane
@@ -1525,9 +1528,10 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
   const int wave = tid >> 6;
   // ONE pooler's ROI list of the tile, gathered into `acc` (a generic lambda: instantiated for the launch's pooler and,
   // in a paired launch, for the second one -- the bins-per-axis class PB is a compile-time constant of the body)
+  // (entries [lo, hi) of the tile's prepared list, whose ROI indices count from `roi0`; lo < 0: no prepared list, the
+  // pooler's K records are scanned)
   auto run_list = [&](auto pb_tag, const T* gout, const RoiRec* rec, const int K, const int PH, const int PW,
-                      const int* tile_cnt_p, const void* tile_list_p, const int qcnt_l,
-                      const int pinfo_l) __attribute__((always_inline)) {
+                      const int lo, const int hi, const int roi0) __attribute__((always_inline)) {
   constexpr int PB = decltype(pb_tag)::value;
   constexpr int lg = PB == 8 ? 3 : PB == 16 ? 4 : 5;
   constexpr int EPR = 32 >> lg, NSLOT = 3 * EPR;
@@ -1708,24 +1712,18 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
   };
 
   int tl_cnt = -1;
-  if (tile_cnt_p) {
-    const int gtile = ids.first[lvl] + (tile - L.tile_base[lvl]);
-    const int c = qcnt_l >= 0 ? qcnt_l : tile_cnt_p[gtile];
-    if (c <= TILE_CAP) {
-      // a part of a split list walks entries [lo, hi) of it (parts == 1: all of them)
-      const int part = pinfo_l & 0xff, parts = (pinfo_l >> 8) & 0xff;
-      const int len = (c + parts - 1) / parts, lo = part * len, hi = min(c, lo + len);
-      tl_cnt = max(hi - lo, 0);
-      if (tid < tl_cnt) {
-        // (two 16-B loads, then the stores: as a struct copy the compiler split it into three loads, each waited for)
-        const uint4* ep = reinterpret_cast<const uint4*>((const TileEntry*)tile_list_p + (long)gtile * TILE_CAP + lo + tid);
-        const uint4 e0 = ep[0], e1 = ep[1];
-        S.list[tid] = (int)e1.z;  // TileEntry = {HitGeo (6 words), roi, pad}
-        HitGeo g;
-        g.start_h = __uint_as_float(e0.x); g.start_w = __uint_as_float(e0.y); g.bin_h = __uint_as_float(e0.z);
-        g.bin_w = __uint_as_float(e0.w); g.inv = __uint_as_float(e1.x); g.grid = (int)e1.y;
-        S.geo[tid] = g;
-      }
+  if (lo >= 0) {
+    tl_cnt = max(hi - lo, 0);
+    if (tid < tl_cnt) {
+      // (two 16-B loads, then the stores: as a struct copy the compiler split it into three loads, each waited for)
+      const int gtile = ids.first[lvl] + (tile - L.tile_base[lvl]);
+      const uint4* ep = reinterpret_cast<const uint4*>((const TileEntry*)L.tile_list + (long)gtile * TILE_CAP + lo + tid);
+      const uint4 e0 = ep[0], e1 = ep[1];
+      S.list[tid] = (int)e1.z - roi0;  // TileEntry = {HitGeo (6 words), roi, pad}
+      HitGeo g;
+      g.start_h = __uint_as_float(e0.x); g.start_w = __uint_as_float(e0.y); g.bin_h = __uint_as_float(e0.z);
+      g.bin_w = __uint_as_float(e0.w); g.inv = __uint_as_float(e1.x); g.grid = (int)e1.y;
+      S.geo[tid] = g;
     }
   }
   const bool prelist = tl_cnt >= 0;  // uniform
@@ -1854,7 +1852,32 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
     }
   }
   };  // run_list
-  run_list(PbTag<PB0>{}, gout0, rec0, K, PH, PW, L.tile_cnt, L.tile_list, qcnt, pinfo);
+  {
+    // the part of the tile's list this workgroup walks: entries [lo, hi) (parts == 1: all c of them); a paired launch
+    // walks the first pooler's entries of it, [lo, min(hi, c1)), then the second one's, [max(lo, c1), hi)
+    int lo = -1, hi = 0, c1 = 0;
+    if (L.tile_cnt) {
+      const int gtile = ids.first[lvl] + (tile - L.tile_base[lvl]);
+      const int c = qcnt >= 0 ? qcnt : L.tile_cnt[gtile];
+      if (c <= TILE_CAP) {
+        const int part = pinfo & 0xff, parts = (pinfo >> 8) & 0xff;
+        const int len = (c + parts - 1) / parts;
+        lo = part * len;
+        hi = min(c, lo + len);
+        c1 = c;
+        if constexpr (PB1 != 0) c1 = __builtin_amdgcn_readfirstlane(P2.tile_cnt1[gtile]);
+      }
+    }
+    if constexpr (PB1 == 0) {
+      run_list(PbTag<PB0>{}, gout0, rec0, K, PH, PW, lo, hi, 0);
+    } else {
+      run_list(PbTag<PB0>{}, gout0, rec0, P2.K1, PH, PW, lo, lo < 0 ? 0 : min(hi, c1), 0);
+      if (lo < 0 || hi > c1) {  // uniform
+        __syncthreads();  // everyone is done with the first sublist's staged bins, weight images and entries
+        run_list(PbTag<PB1>{}, (const T*)P2.gout, rec0 + P2.K1, P2.K2, P2.PH, P2.PW, lo < 0 ? -1 : max(lo, c1), hi, P2.K1);
+      }
+    }
+  }
 #ifdef D2AMD_PROFILE
   if (dbg_on) { L.dbg[127] = dbg_n; L.dbg[126] = 0; L.dbg[125] = __builtin_readcyclecounter() - L.dbg[0]; }
 #endif
@@ -1899,19 +1922,6 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
         v[i] = __hip_atomic_load(all + (size_t)q * slot_floats + i * NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
       for (int i = 0; i < 32; i++) acc[i >> 4][i & 15] += v[i];
-    }
-  }
-  // ---- paired launch: the second pooler's ROIs of this tile, into the same accumulators (the last part of a split
-  // first list arrives here with all parts added).  Its list is never walked in parts here: a part is a queue entry of
-  // that pooler's OWN launch, which skips every tile this one takes (L.skip_cnt).
-  if constexpr (PB1 != 0) {
-    if (P2.tile_cnt) {  // uniform
-      const int gtile = ids.first[lvl] + (tile - L.tile_base[lvl]);
-      const int c2 = __builtin_amdgcn_readfirstlane(P2.tile_cnt[gtile]);
-      if (c2 > 0) {
-        __syncthreads();  // everyone is done with the first list's staged bins, weight images and entries
-        run_list(PbTag<PB1>{}, (const T*)P2.gout, P2.rec, P2.K, P2.PH, P2.PW, P2.tile_cnt, P2.tile_list, c2, 1 << 8);
-      }
     }
   }
   // ---- epilogue: accumulators (lane = channel, registers = pixels) -> LDS [pixel][channel] in the I/O dtype ->
@@ -2313,14 +2323,16 @@ static long pool_ntiles(const d2amd_pooler_params* p) {
   return n;
 }
 
-// (pair: this launch also gathers a second pooler's lists -- the MFMA tile gather of a pooler with <= 8 bins per axis
-// only; skip_cnt: this launch leaves out the tiles a paired launch in front of it took; probe: no launch at all, the
-// return value says whether the call would take the MFMA tile gather: OK / EUNSUPPORTED)
+// (pair: a second pooler of the same feature maps, binned and gathered together with this one -- phase 0 of the
+// persistent MFMA tile gather of a pooler with <= 8 bins per axis only; probe: no launch at all, the return value says
+// whether the call would take that kernel: OK / EUNSUPPORTED)
+struct PoolPairCall { const d2amd_pooler_params* p2; const void* gout2; const float* rois2; int K2; };
 template <typename T>
 static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_output, const float* rois,
-                              void* const* grad_inputs, int K, void* workspace, size_t workspace_bytes,
-                              hipStream_t s, bool accumulate, int phase = 0, const PoolPairArgs* pair = nullptr,
-                              const int* skip_cnt = nullptr, bool probe = false, PoolPairArgs* binned_out = nullptr) {
+                              void* const* grad_inputs, int K_first, void* workspace, size_t workspace_bytes,
+                              hipStream_t s, bool accumulate, int phase = 0, const PoolPairCall* pair = nullptr,
+                              bool probe = false) {
+  const int K = K_first + (pair ? pair->K2 : 0);  // records: the first pooler's ROIs, then the second one's
   // phase 0: everything; 1: only the binning (records, per-tile ROI lists, work queues -- depends on the ROIs alone
   // in accumulate mode, so a caller can run it beside other work); 2: only the gather, ADDING, after a phase-1 call
   // with the same arguments and workspace; 3: the same but WRITING: the tiles without ROIs are zero-filled by their
@@ -2338,10 +2350,11 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
   // per-tile ROI lists live behind the records when the caller sized the workspace with
   // d2amd_roi_pooler_backward_workspace_bytes (the older K-only size still works: tiles then scan)
   const long ntiles = pool_ntiles(p);
-  const size_t off_cnt = pool_al(need), off_list = off_cnt + pool_al((size_t)ntiles * 4);
+  const size_t off_cnt = pool_al(need), off_list = off_cnt + pool_al((size_t)ntiles * 4) * (pair ? 2 : 1);
   const bool lists = K > 0 && ntiles > 0 && workspace_bytes >= off_list + (size_t)ntiles * TILE_CAP * sizeof(TileEntry) &&
       getenv("D2AMD_POOL_NOLISTS") == nullptr;
   int* tile_cnt = lists ? (int*)((char*)workspace + off_cnt) : nullptr;
+  int* tile_cnt1 = lists && pair ? (int*)((char*)workspace + off_cnt + pool_al((size_t)ntiles * 4)) : nullptr;
   TileEntry* tile_list = lists ? (TileEntry*)((char*)workspace + off_list) : nullptr;
   PoolLevels L0 = make_levels(p, (const void* const*)grad_inputs, K);
   L0.accumulate = (accumulate && phase != 3) ? 1 : 0;
@@ -2365,18 +2378,13 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
   const bool split_capable = staged && sizeof(T) == 2 && !no_mfma_env && p->C % 32 == 0 && p->C <= 8192 &&
       nslab <= SPLIT_MAX_SLABS;
   const size_t slot_bytes = (size_t)nslab * 32 * (2 * CT) * sizeof(float);  // 16 accumulators x 2 tiles x 512 threads
-  if (pair || skip_cnt || probe) {  // the paired gathers exist in the persistent MFMA tile gather only
+  if (pair || probe) {  // the paired gather exists in the persistent MFMA tile gather only
     static const bool fixed = getenv("D2AMD_POOL_STATIC") != nullptr || getenv("D2AMD_POOL_STAMPS") != nullptr ||
         getenv("D2AMD_POOL_STAMPS_STATIC") != nullptr;
     const int pm = p->pooled_h > p->pooled_w ? p->pooled_h : p->pooled_w;
-    const bool ok = staged && sizeof(T) == 2 && !no_mfma_env && !fixed && p->C % 32 == 0 && p->C <= 8192 && K > 0 &&
-        (pair ? pm <= 8 : true);
+    const bool ok = staged && sizeof(T) == 2 && !no_mfma_env && !fixed && p->C % 32 == 0 && p->C <= 8192 && K_first > 0 &&
+        pm <= 8 && phase == 0 && !accumulate;
     if (!ok || probe) return ok ? D2AMD_OK : D2AMD_EUNSUPPORTED;
-  }
-  if (binned_out) {  // where this call's binning lives (for the launch that gathers its lists as the second pooler)
-    binned_out->rec = rec;
-    binned_out->tile_cnt = tile_cnt;
-    binned_out->tile_list = tile_list;
   }
   if (queues) {
     int per[2][8] = {};
@@ -2424,11 +2432,12 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
     D2_LAUNCH_OK();
   }
   if (K > 0 && phase < 2) {
-    hipLaunchKernelGGL(roi_records_kernel, dim3(cdiv(K, 256)), dim3(256), 0, s, L0, rois, rec, Q.mem, qzero, qints);
+    const PairBin PB2{pair ? pair->rois2 : nullptr, K_first, pair ? pair->p2->pooled_h : 0, pair ? pair->p2->pooled_w : 0};
+    hipLaunchKernelGGL(roi_records_kernel, dim3(cdiv(K, 256)), dim3(256), 0, s, L0, rois, rec, Q.mem, qzero, qints, PB2);
     D2_LAUNCH_OK();
     if (lists) {
       hipLaunchKernelGGL(tile_lists_kernel, dim3(cdiv(ntiles, LISTS_WAVES)), dim3(64 * LISTS_WAVES), 0, s, L0, rec, (int)ntiles, tile_cnt,
-                         tile_list, Q);
+                         tile_list, Q, K_first, tile_cnt1);
       D2_LAUNCH_OK();
     }
   }
@@ -2449,7 +2458,6 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
     L.qcap = Q.cap[0];
     L.part_tickets = Q.mem + QCTR;
     L.part_scratch = (float*)((char*)workspace + off_q + pool_queue_bytes(ntiles));
-    L.skip_cnt = skip_cnt;
     const long total = 8l * L.qcap * nslab;
     if (total == 0) return D2AMD_OK;
     static const bool static_slots = getenv("D2AMD_POOL_STATIC") != nullptr;  // A/B: one workgroup per queue slot
@@ -2484,7 +2492,8 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
         // (tried and dropped, profiles/r03/pool_bwd/README.md: no take counters at all -- workgroup j of an XCD walking
         // its queue with a fixed stride: the gap between tiles halves, but the unsorted queue leaves the workgroups 25 us
         // apart at the end (takes: 10 us): 90.8 us against 74.3)
-        const PoolPairArgs P2 = pair ? *pair : PoolPairArgs{};
+        const PoolPairArgs P2 = pair ? PoolPairArgs{pair->gout2, tile_cnt1, K_first, pair->K2, pair->p2->pooled_h,
+                                                    pair->p2->pooled_w} : PoolPairArgs{};
         auto launch = [&](auto dyn_fn, auto static_fn) {
           if (L.qctr) {
             const long r = resident_workgroups((const void*)dyn_fn, 2 * CT) & ~7l;
@@ -2817,79 +2826,60 @@ extern "C" int d2amd_roi_pooler_backward_accumulate(const d2amd_pooler_params* p
   return pooler_backward_entry(p, grad_output, rois, grad_inputs, K, workspace, workspace_bytes, stream, true);
 }
 
-// Two poolers of the SAME feature maps (the box head's and the mask head's), one gradient: the first pooler's tile gather
-// takes the second one's ROIs of every tile it touches along (pool_bwd_mfma_kernel<T, 8, true, 16>), the second pooler's own
-// launch is left with the tiles only it touches.  = d2amd_roi_pooler_backward(p1 ...) followed by
-// d2amd_roi_pooler_backward_accumulate(p2 ...), except that a tile both touch is rounded to the I/O dtype ONCE (the sum
-// of both gathers in fp32) instead of once per pooler.  EUNSUPPORTED (nothing launched) outside the 16-bit MFMA tile
-// gather with bins per axis <= 8 (first) and 9..16 (second): the caller issues the two calls.
+// Two poolers of the SAME feature maps (the box head's and the mask head's), one gradient, ONE pass: both poolers' ROIs are
+// binned together (records, per-tile lists -- the first pooler's entries in front of the second one's -- and one set of
+// work queues over the tiles either touches) and pool_bwd_mfma_kernel<T, 8, true, 16> gathers a tile's two sublists
+// into the same accumulators.  = d2amd_roi_pooler_backward(p1 ...) followed by d2amd_roi_pooler_backward_accumulate(p2
+// ...), except that a tile both touch is rounded to the I/O dtype ONCE (the sum of both gathers in fp32) instead of once
+// per pooler and once for their sum.  EUNSUPPORTED (nothing launched) outside the 16-bit MFMA tile gather with bins per
+// axis <= 8 (first) and 9..16 (second) and equal level rule / sampling: the caller issues the two calls.
+extern "C" size_t d2amd_roi_pooler_backward_pair_workspace_bytes(const d2amd_pooler_params* p1, int K1, int K2) {
+  if (check_pooler(p1, "roi_pooler_backward_pair_workspace_bytes")) return 0;
+  const long k = (long)(K1 > 0 ? K1 : 0) + (K2 > 0 ? K2 : 0);
+  return d2amd_roi_pooler_backward_workspace_bytes(p1, (int)(k < (1l << 30) ? k : (1l << 30))) +
+      pool_al((size_t)pool_ntiles(p1) * 4);  // + the per-tile count of the first pooler's entries
+}
 extern "C" int d2amd_roi_pooler_backward_pair(const d2amd_pooler_params* p1, const void* grad_output1, const float* rois1,
-                                              int K1, void* workspace1, size_t workspace1_bytes,
-                                              const d2amd_pooler_params* p2, const void* grad_output2, const float* rois2,
-                                              int K2, void* workspace2, size_t workspace2_bytes, void* const* grad_inputs,
-                                              void* stream) {
+                                              int K1, const d2amd_pooler_params* p2, const void* grad_output2,
+                                              const float* rois2, int K2, void* const* grad_inputs, void* workspace,
+                                              size_t workspace_bytes, void* stream) {
   int rc = check_pooler(p1, "roi_pooler_backward_pair");
   if (rc) return rc;
   rc = check_pooler(p2, "roi_pooler_backward_pair");
   if (rc) return rc;
-  D2_CHECK_ARG(K1 >= 0 && K2 >= 0, "roi_pooler_backward_pair: bad K");
+  D2_CHECK_ARG(K1 >= 0 && K2 >= 0 && (long)K1 + K2 < (1l << 30), "roi_pooler_backward_pair: bad K");
   D2_CHECK_ARG(grad_inputs && (K1 == 0 || (grad_output1 && rois1)) && (K2 == 0 || (grad_output2 && rois2)),
                "roi_pooler_backward_pair: null pointer");
   bool same = p1->num_levels == p2->num_levels && p1->N == p2->N && p1->C == p2->C && p1->dtype == p2->dtype &&
       p1->layout == p2->layout;
   for (int l = 0; same && l < p1->num_levels; l++) same = p1->H[l] == p2->H[l] && p1->W[l] == p2->W[l];
   D2_CHECK_ARG(same, "roi_pooler_backward_pair: the two poolers must read the same feature maps");
+  // one set of records for both: the level rule, the scales and the sampling must be the same
+  bool rule = p1->sampling_ratio == p2->sampling_ratio && p1->aligned == p2->aligned && p1->min_level == p2->min_level &&
+      p1->max_level == p2->max_level && p1->canonical_level == p2->canonical_level &&
+      p1->canonical_box_size == p2->canonical_box_size;
+  for (int l = 0; rule && l < p1->num_levels; l++) rule = p1->spatial_scale[l] == p2->spatial_scale[l];
   static const bool off = getenv("D2AMD_POOL_NO_PAIR") != nullptr;
   const int pm1 = p1->pooled_h > p1->pooled_w ? p1->pooled_h : p1->pooled_w;
   const int pm2 = p2->pooled_h > p2->pooled_w ? p2->pooled_h : p2->pooled_w;
-  if (off || K1 == 0 || K2 == 0 || !pooler_fused_ok(p1) || !pooler_fused_ok(p2) || p1->layout != D2AMD_NHWC ||
-      p1->dtype == D2AMD_F32 || pm1 > 8 || pm2 <= 8 || pm2 > 16 || (long)p1->N * p1->C == 0) {
-    set_error("roi_pooler_backward_pair: outside the paired 16-bit tile gather (bins per axis <= 8 and 9..16, NHWC)");
+  if (off || !rule || K1 == 0 || K2 == 0 || !pooler_fused_ok(p1) || !pooler_fused_ok(p2) || p1->layout != D2AMD_NHWC ||
+      p1->dtype == D2AMD_F32 || pm1 > 8 || pm2 <= 8 || pm2 > 16 || (long)p1->N * p1->C == 0 ||
+      ((uintptr_t)grad_output2 & 15) != 0) {
+    set_error("roi_pooler_backward_pair: outside the paired 16-bit tile gather (bins per axis <= 8 and 9..16, NHWC, "
+              "the same level rule and sampling)");
     return D2AMD_EUNSUPPORTED;
   }
   return D2_DISPATCH_DTYPE(p1->dtype, [&]() -> int {
-    if constexpr (sizeof(scalar_t) != 2) {
-      return D2AMD_EUNSUPPORTED;
-    } else {
-      hipStream_t s = (hipStream_t)stream;
-      // both calls must take the MFMA tile gather (probe: nothing is launched)
-      int r = pool_bwd_nhwc_impl<scalar_t>(p1, grad_output1, rois1, grad_inputs, K1, workspace1, workspace1_bytes, s, false, 1,
-                                           nullptr, nullptr, true);
-      if (r) return r;
-      r = pool_bwd_nhwc_impl<scalar_t>(p2, grad_output2, rois2, grad_inputs, K2, workspace2, workspace2_bytes, s, true, 1,
-                                       nullptr, nullptr, true);
-      if (r) return r;
-      // binning: the first pooler's on the caller's stream (it zero-fills the tiles the first pooler does not touch), the
-      // second one's beside it
-      SideStream* side = side_stream();
-      hipStream_t s2 = s;
-      if (side) {
-        D2_HIP_OK(hipEventRecord(side->fork, s));
-        D2_HIP_OK(hipStreamWaitEvent(side->stream, side->fork, 0));
-        s2 = side->stream;
-      }
-      PoolPairArgs b1{}, b2{};
-      r = pool_bwd_nhwc_impl<scalar_t>(p2, grad_output2, rois2, grad_inputs, K2, workspace2, workspace2_bytes, s2, true, 1,
-                                       nullptr, nullptr, false, &b2);
-      int r1 = pool_bwd_nhwc_impl<scalar_t>(p1, grad_output1, rois1, grad_inputs, K1, workspace1, workspace1_bytes, s, false,
-                                            1, nullptr, nullptr, false, &b1);
-      if (side) {  // (joined whatever the calls returned: a capture must not end with a dangling branch)
-        D2_HIP_OK(hipEventRecord(side->join, side->stream));
-        D2_HIP_OK(hipStreamWaitEvent(s, side->join, 0));
-      }
-      if (r) return r;
-      if (r1) return r1;
-      b2.gout = grad_output2;
-      b2.K = K2;
-      b2.PH = p2->pooled_h;
-      b2.PW = p2->pooled_w;
-      // the paired gather: writes every tile the first pooler touches, with both poolers' ROIs
-      r = pool_bwd_nhwc_impl<scalar_t>(p1, grad_output1, rois1, grad_inputs, K1, workspace1, workspace1_bytes, s, false, 2, &b2);
-      if (r) return r;
-      // the second pooler's own tiles (no ROI of the first one): added to the zeros the first binning wrote there
-      return pool_bwd_nhwc_impl<scalar_t>(p2, grad_output2, rois2, grad_inputs, K2, workspace2, workspace2_bytes, s, true, 2,
-                                          nullptr, b1.tile_cnt);
+    const PoolPairCall pc{p2, grad_output2, rois2, K2};
+    hipStream_t s = (hipStream_t)stream;
+    // the call must take the persistent MFMA tile gather (probe: nothing is launched)
+    const int r = pool_bwd_nhwc_impl<scalar_t>(p1, grad_output1, rois1, grad_inputs, K1, workspace, workspace_bytes, s, false, 0,
+                                               &pc, true);
+    if (r) {
+      set_error("roi_pooler_backward_pair: outside the paired 16-bit tile gather (workspace, alignment or a profiling switch)");
+      return r;
     }
+    return pool_bwd_nhwc_impl<scalar_t>(p1, grad_output1, rois1, grad_inputs, K1, workspace, workspace_bytes, s, false, 0, &pc);
   });
 }
 

@@ -393,13 +393,11 @@ class _FusedROIPool(Function):
                 (g1, r1, c1, _), (g2, r2, c2, _) = works[0], works[1]
                 p1 = _params(c1, (n, c), hw, _C.dtype_code(g1), _C.NHWC)
                 p2 = _params(c2, (n, c), hw, _C.dtype_code(g2), _C.NHWC)
-                b1 = L.d2amd_roi_pooler_backward_workspace_bytes(ctypes.byref(p1), r1.shape[0])
-                b2 = L.d2amd_roi_pooler_backward_workspace_bytes(ctypes.byref(p2), r2.shape[0])
-                ws1 = torch.empty(b1, dtype=torch.uint8, device=dev)
-                ws2 = torch.empty(b2, dtype=torch.uint8, device=dev)
-                rc = L.d2amd_roi_pooler_backward_pair(ctypes.byref(p1), _C.ptr(g1), _C.ptr(r1), r1.shape[0], _C.ptr(ws1), b1,
-                                                      ctypes.byref(p2), _C.ptr(g2), _C.ptr(r2), r2.shape[0], _C.ptr(ws2), b2,
-                                                      _ptr_array(grads), _C.stream())
+                wsb = L.d2amd_roi_pooler_backward_pair_workspace_bytes(ctypes.byref(p1), r1.shape[0], r2.shape[0])
+                ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+                rc = L.d2amd_roi_pooler_backward_pair(ctypes.byref(p1), _C.ptr(g1), _C.ptr(r1), r1.shape[0],
+                                                      ctypes.byref(p2), _C.ptr(g2), _C.ptr(r2), r2.shape[0],
+                                                      _ptr_array(grads), _C.ptr(ws), wsb, _C.stream())
                 if rc == 0:  # both are in `grads`: whatever follows adds
                     works, plain_first = works[2:], False
                 elif rc != _C.EUNSUPPORTED:

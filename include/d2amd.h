@@ -146,19 +146,18 @@ int d2amd_roi_pooler_backward_accumulate(const d2amd_pooler_params* p, const voi
                                          void* const* grad_inputs, int K, void* workspace, size_t workspace_bytes,
                                          void* stream);
 /* Both poolers of one set of feature maps in ONE pass over the gradient's tiles (Mask R-CNN: the box head's 7x7
- * pooler and the mask head's 14x14 one, roi_heads.py:780-846; modeling/poolers.py:206-263 twice): the first pooler's
- * tile gather takes the second pooler's ROIs of every tile it touches into the same fp32 accumulators -- one queue
- * take, one prologue and ONE write per tile, where d2amd_roi_pooler_backward + d2amd_roi_pooler_backward_accumulate
- * pay each of them twice and read the tile back to add to it; the second pooler's own launch is left with the tiles no
- * ROI of the first one touches.  Result: every element = round(sum1 + sum2) in the I/O dtype (fp32 sums; the two-call
+ * pooler and the mask head's 14x14 one, roi_heads.py:780-846; modeling/poolers.py:206-263 twice): their ROIs are binned
+ * together and a tile's two sublists are gathered into the same fp32 accumulators -- one queue take, one prologue and
+ * ONE write per tile, where d2amd_roi_pooler_backward + d2amd_roi_pooler_backward_accumulate pay each of them twice and
+ * read the tile back to add to it.  Result: every element = round(sum1 + sum2) in the I/O dtype (fp32 sums; the two-call
  * sequence gives round(round(sum1) + round(sum2)): the two differ by those extra roundings, this one is the closer to
- * the fp32 value).
- * workspaceN: d2amd_roi_pooler_backward_workspace_bytes(pN, KN) each.  D2AMD_EUNSUPPORTED -- nothing launched -- outside
- * 16-bit NHWC with bins per axis <= 8 (first) and 9..16 (second), K1, K2 > 0: the caller issues the two calls. */
+ * the fp32 value).  workspace: d2amd_roi_pooler_backward_pair_workspace_bytes(p1, K1, K2).  D2AMD_EUNSUPPORTED -- nothing
+ * launched -- outside 16-bit NHWC with bins per axis <= 8 (first) and 9..16 (second), the same level rule, scales,
+ * sampling ratio and alignment, K1, K2 > 0: the caller issues the two calls. */
+size_t d2amd_roi_pooler_backward_pair_workspace_bytes(const d2amd_pooler_params* p1, int K1, int K2);
 int d2amd_roi_pooler_backward_pair(const d2amd_pooler_params* p1, const void* grad_output1, const float* rois1, int K1,
-                                   void* workspace1, size_t workspace1_bytes, const d2amd_pooler_params* p2,
-                                   const void* grad_output2, const float* rois2, int K2, void* workspace2,
-                                   size_t workspace2_bytes, void* const* grad_inputs, void* stream);
+                                   const d2amd_pooler_params* p2, const void* grad_output2, const float* rois2, int K2,
+                                   void* const* grad_inputs, void* workspace, size_t workspace_bytes, void* stream);
 /* The backward in two calls: phase 1 bins the ROIs (per-ROI records, per-tile ROI lists, work queues: reads `rois`
  * only, writes the workspace only -- it may run on another stream, long before the gradient exists: beside the
  * pooler's forward); a later call with the same arguments and workspace runs the gather: phase 2 ADDS to grad_inputs

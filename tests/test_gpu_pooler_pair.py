@@ -1,6 +1,6 @@
 """GPU tests of the PAIRED pooler backward (d2amd_roi_pooler_backward_pair, csrc/roi_pool.hip: pool_bwd_mfma_kernel<T, 8,
 true, 16>): the box head's 7x7 pooler and the mask head's 14x14 pooler of the same FPN features (roi_heads.py:780-846,
-modeling/poolers.py:206-263 twice) gathered in ONE pass over the gradient's tiles.
+modeling/poolers.py:206-263 twice) binned together and gathered in ONE pass over the gradient's tiles.
 
 Checked against (a) the oracle's two ROIAlign backwards summed (what autograd accumulates in the reference) and (b) the
 library's own two-call sequence d2amd_roi_pooler_backward + d2amd_roi_pooler_backward_accumulate: equal bit for bit on
@@ -47,15 +47,16 @@ def _run(kind, feats, boxes1, g1, boxes2, g2, dtype, out1=7, out2=14):
     r1, r2 = _rois(boxes1), _rois(boxes2)
     k1, k2 = int(r1.shape[0]), int(r2.shape[0])
     grads = [torch.full((n, c) + s, 7.0, dtype=dtype, device=DEV).contiguous(memory_format=torch.channels_last) for s in hw]
-    b1 = L.d2amd_roi_pooler_backward_workspace_bytes(ctypes.byref(p1), k1)
-    b2 = L.d2amd_roi_pooler_backward_workspace_bytes(ctypes.byref(p2), k2)
-    ws1, ws2 = torch.empty(b1, dtype=torch.uint8, device=DEV), torch.empty(b2, dtype=torch.uint8, device=DEV)
     with _C.on_device(grads[0].device):
         if kind == "pair":
-            rc = L.d2amd_roi_pooler_backward_pair(ctypes.byref(p1), _C.ptr(g1), _C.ptr(r1), k1, _C.ptr(ws1), b1,
-                                                  ctypes.byref(p2), _C.ptr(g2), _C.ptr(r2), k2, _C.ptr(ws2), b2,
-                                                  P._ptr_array(grads), _C.stream())
+            wsb = L.d2amd_roi_pooler_backward_pair_workspace_bytes(ctypes.byref(p1), k1, k2)
+            ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+            rc = L.d2amd_roi_pooler_backward_pair(ctypes.byref(p1), _C.ptr(g1), _C.ptr(r1), k1, ctypes.byref(p2), _C.ptr(g2),
+                                                  _C.ptr(r2), k2, P._ptr_array(grads), _C.ptr(ws), wsb, _C.stream())
         else:
+            b1 = L.d2amd_roi_pooler_backward_workspace_bytes(ctypes.byref(p1), k1)
+            b2 = L.d2amd_roi_pooler_backward_workspace_bytes(ctypes.byref(p2), k2)
+            ws1, ws2 = torch.empty(b1, dtype=torch.uint8, device=DEV), torch.empty(b2, dtype=torch.uint8, device=DEV)
             rc = L.d2amd_roi_pooler_backward(ctypes.byref(p1), _C.ptr(g1), _C.ptr(r1), P._ptr_array(grads), k1, _C.ptr(ws1),
                                              b1, _C.stream())
             if rc == 0:
@@ -87,14 +88,13 @@ def _clustered(rng, boxes, per_tile, img_h, img_w, size=(150, 210)):
 
 
 CASES = {
-    # the second pooler's boxes are a SUBSET of the first one's (Mask R-CNN: the foreground proposals): its own launch
-    # finds every tile taken
+    # the second pooler's boxes are a SUBSET of the first one's (Mask R-CNN: the foreground proposals)
     "subset": dict(per1=48, per2=12, subset=True),
     # independent boxes: tiles of all three kinds (first only / second only / both)
     "independent": dict(per1=40, per2=24, subset=False),
-    # a first list beyond SPLIT_MIN on a few tiles (cut into parts; the LAST part to arrive takes the second list along)
+    # lists beyond SPLIT_MIN on a few tiles: cut into parts, some of which hold entries of both poolers
     "first_split": dict(per1=20, per2=16, subset=False, cluster1=64),
-    # a second list beyond the per-tile list capacity (in-kernel scan of the second pooler's records in the paired launch)
+    # lists beyond the per-tile list capacity: in-kernel scan of the first, then of the second pooler's records
     "second_scans": dict(per1=24, per2=8, subset=False, cluster2=90),
     # both long
     "both_long": dict(per1=16, per2=8, subset=False, cluster1=50, cluster2=50),
@@ -141,8 +141,9 @@ def test_pair_vs_oracle_and_vs_the_two_call_sequence(name, dtype):
         # the sum, i.e. |difference| <= ulp(sum1) / 2 + ulp(sum2) / 2 + ulp(result) (+ the fp32 accumulation order)
         d = _ulps_apart(pair[l], two[l])
         both = torch.from_numpy((gin1[l] != 0) & (gin2[l] != 0)).to(DEV)
-        if "cluster2" not in CASES[name]:  # (a second list of 41..64 entries is walked in PARTS by the second pooler's own
-            # launch -- partial fp32 sums added in part order -- and whole by the paired one: another summation order)
+        if "cluster1" not in CASES[name] and "cluster2" not in CASES[name]:  # (a combined list of 41..64 entries is walked in
+            # PARTS -- partial fp32 sums added in part order -- where the single poolers' shorter lists are walked whole,
+            # and the other way round: another summation order)
             assert int(d[~both].max() if (~both).any() else 0) == 0, l
         half = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11  # ulp(x) / 2 <= half * |x|
         bound = half * (np.abs(gin1[l]) + np.abs(gin2[l])) + 2 * half * np.abs(want) + 1e-6 * (np.abs(gin1[l]) + np.abs(gin2[l])) + 2.0 ** -23
@@ -186,8 +187,8 @@ def test_pair_is_refused_outside_the_16_bit_tile_gather_and_launches_nothing():
 
 @pytest.mark.parametrize("pair", [True, False])
 def test_chained_poolers_take_the_paired_launch_through_autograd(pair, monkeypatch):
-    """ROIPooler x 2 on the same leaves, one backward: with the pairing on, ONE paired gather (+ the second pooler's
-    launch over what is left) runs; off (D2AMD_POOL_PAIR=0), one gather per pooler.  Same gradients to one ulp."""
+    """ROIPooler x 2 on the same leaves, one backward: with the pairing on, ONE paired gather runs; off
+    (D2AMD_POOL_PAIR=0), one gather per pooler."""
     monkeypatch.setattr(P, "_PAIR", pair)
     feats, boxes1, g1, boxes2, g2 = _case("independent", torch.bfloat16)
     names = b"pool_bwd_pair,pool_bwd_staged_r7,pool_bwd_staged_r14"
@@ -206,7 +207,7 @@ def test_chained_poolers_take_the_paired_launch_through_autograd(pair, monkeypat
     finally:
         _C.lib().d2amd_timing_select(None)
         P._ALIASES.clear()
-    assert cnt == ({"pool_bwd_pair": 1, "pool_bwd_staged_r7": 0, "pool_bwd_staged_r14": 1} if pair else
+    assert cnt == ({"pool_bwd_pair": 1, "pool_bwd_staged_r7": 0, "pool_bwd_staged_r14": 0} if pair else
                    {"pool_bwd_pair": 0, "pool_bwd_staged_r7": 1, "pool_bwd_staged_r14": 1}), cnt
     _, want = _run("pair" if pair else "two", feats, boxes1, g1, boxes2, g2, torch.bfloat16)
     assert all(torch.equal(x.grad, w) for x, w in zip(xs, want))
