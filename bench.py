@@ -281,6 +281,7 @@ class Workload:
                 fwd += feat[l] + 20 * k + s * k * C * R * R
                 bwd += s * k * C * R * R + 2 * feat[l]
             d[name + "_fwd"], d[name + "_bwd"] = fwd, bwd
+        d["roi_align_pair_fwd"] = d["roi_align_box_fwd"] + d["roi_align_mask_fwd"]  # pool_pair: both units, one launch
         d["backward"] = d["roi_align_box_bwd"] + d["roi_align_mask_bwd"]  # + the mask loss backward (2 x logits)
         d["backward"] += 2 * 256 * 80 * 784 * s
         n, m = N_GT, 268569
@@ -342,7 +343,13 @@ def roi_branches(w):
     from detectron2_amd.structures import crop_and_resize_batch
 
     def poolers():
-        return w.box_pooler(w.feats, w.box_lists), w.mask_pooler(w.feats, w.mask_lists)
+        # both poolers in one launch per direction (pool_pair: the forward values are the separate calls' bit for bit);
+        # D2AMD_BENCH_POOL_SEPARATE=1 (the A/B): one call per pooler, the reference's structure
+        if os.environ.get("D2AMD_BENCH_POOL_SEPARATE") == "1":
+            return w.box_pooler(w.feats, w.box_lists), w.mask_pooler(w.feats, w.mask_lists)
+        from detectron2_amd.modeling import pool_pair
+
+        return pool_pair(w.box_pooler, w.mask_pooler, w.feats, w.box_lists, w.mask_lists)
 
     def labels_and_loss():
         _lab = [w.proposal_matcher.match_boxes(w.gt[i], w.props_with_gt[i]) for i in range(w.n_img)]
@@ -393,8 +400,14 @@ def disconnected_step(w, t=None, grads=None):
     else:
         for i in range(w.n_img):
             run("match_proposals", lambda: w.proposal_matcher.match_boxes(w.gt[i], w.props_with_gt[i]))
-        yb = run("roi_align_box_fwd", lambda: w.box_pooler(w.feats, w.box_lists))
-        ym = run("roi_align_mask_fwd", lambda: w.mask_pooler(w.feats, w.mask_lists))
+        if os.environ.get("D2AMD_BENCH_POOL_SEPARATE") == "1":
+            yb = run("roi_align_box_fwd", lambda: w.box_pooler(w.feats, w.box_lists))
+            ym = run("roi_align_mask_fwd", lambda: w.mask_pooler(w.feats, w.mask_lists))
+        else:
+            from detectron2_amd.modeling import pool_pair
+
+            yb, ym = run("roi_align_pair_fwd", lambda: pool_pair(w.box_pooler, w.mask_pooler, w.feats, w.box_lists,
+                                                                 w.mask_lists))
         tg = run("mask_targets", lambda: crop_and_resize_batch(
             w.gt_masks, [b.tensor for b in w.mask_lists], 28, w.fg_gt_index, w.crop_status))
         loss, _stats = run("mask_loss_fwd", lambda: mask_rcnn_loss_from_targets(w.mask_logits, w.fg_classes, tg))
@@ -500,8 +513,15 @@ def connected_forward(w, run=None, rpn_keys=None, roi_keys=None, sync=False):
     mask_boxes = [samp["boxes"][i, :MASK_ROWS] for i in range(n)]
 
     def poolers():  # (the sampler wrote its rows in pooler format: no conversion launch in front of either pooler)
-        return (run("roi_align_box_fwd", lambda: w.box_pooler.pool_rois(w.feats, samp["rois"])),
-                run("roi_align_mask_fwd", lambda: w.mask_pooler.pool_rois(w.feats, samp["head_rois"])))
+        # both poolers in one launch per direction (pool_pair_rois: the forward values are the separate calls' bit for
+        # bit); D2AMD_BENCH_POOL_SEPARATE=1 (the A/B): one call per pooler, the reference's structure
+        if os.environ.get("D2AMD_BENCH_POOL_SEPARATE") == "1":
+            return (run("roi_align_box_fwd", lambda: w.box_pooler.pool_rois(w.feats, samp["rois"])),
+                    run("roi_align_mask_fwd", lambda: w.mask_pooler.pool_rois(w.feats, samp["head_rois"])))
+        from detectron2_amd.modeling import pool_pair_rois
+
+        return run("roi_align_pair_fwd", lambda: pool_pair_rois(w.box_pooler, w.mask_pooler, w.feats, samp["rois"],
+                                                                samp["head_rois"]))
 
     def targets_and_loss():
         idx = [samp["gt_index"][i, :MASK_ROWS].contiguous() for i in range(n)]
@@ -938,8 +958,8 @@ def bench_maskrcnn(args, ctx):
     paired = "pool_bwd_pair" in ktimes
     if paired:
         KERN = "pool_bwd_pair"
-    knames = ["pool_bwd_pair", "pool_bwd_staged_r7", "pool_bwd_staged_r14", "pool_fwd_r7", "pool_fwd_r14", "nms_mask",
-              "nms_reduce"]
+    knames = ["pool_bwd_pair", "pool_bwd_staged_r7", "pool_bwd_staged_r14", "pool_fwd_pair", "pool_fwd_r7", "pool_fwd_r14",
+              "nms_mask", "nms_reduce"]
     _dc.lib().d2amd_timing_select(",".join(knames).encode())
     timer = Timer()  # per-op breakdown: a separate, UNTIMED pass with events around every op
     bsteps = min(args.steps, 20)

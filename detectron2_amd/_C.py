@@ -79,6 +79,11 @@ _SIGNATURES = {
     "d2amd_roi_pooler_forward_box_lists_ordered": (_i, [ctypes.POINTER(PoolerParams), ctypes.POINTER(_vp),
                                                         ctypes.POINTER(_vp), ctypes.POINTER(_i), _i, _vp, _vp, _vp, _sz,
                                                         _vp]),
+    "d2amd_roi_pooler_forward_pair": (_i, [ctypes.POINTER(PoolerParams), ctypes.POINTER(_vp), _vp, _vp, _i,
+                                           ctypes.POINTER(PoolerParams), _vp, _vp, _i, _vp]),
+    "d2amd_roi_pooler_forward_pair_box_lists": (_i, [ctypes.POINTER(PoolerParams), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
+                                                     ctypes.POINTER(_i), _vp, _vp, ctypes.POINTER(PoolerParams),
+                                                     ctypes.POINTER(_vp), ctypes.POINTER(_i), _vp, _vp, _i, _vp]),
     "d2amd_roi_pooler_backward_workspace_bytes": (_sz, [ctypes.POINTER(PoolerParams), _i]),
     "d2amd_roi_pooler_backward": (_i, [ctypes.POINTER(PoolerParams), _vp, _vp, ctypes.POINTER(_vp), _i, _vp, _sz,
                                        _vp]),

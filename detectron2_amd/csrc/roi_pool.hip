@@ -147,19 +147,36 @@ __device__ __forceinline__ int fwd_roi_of(const PoolLevels& L, int b, int K) {
 
 // ------------------------------------------------------------------------------------------------
 // FORWARD, NHWC.  grid = (K, nsplit); VEC = 16 B of channels per lane (or 1 for odd C / alignment)
+// PAIRED launch (d2amd_roi_pooler_forward_pair; P.rois2 != nullptr, grid = K1 * ns1 + K2 * ns2 workgroups in x): the
+// workgroups of a SECOND pooler of the same feature maps follow the first one's in the same grid -- the box head's
+// launch ends with a quarter of the chip waiting for its largest ROIs (1,024 workgroups, all resident at once: mean
+// 21.9 us, longest 37.7), the mask head's workgroups fill those slots instead of starting behind the last one.
+template <typename T> struct PoolFwdPair { const float* rois2; T* out2; int K1, ns1, K2, ns2, PH2, PW2; };
 template <typename T, int VEC, int NTHR, int U = FWD_U, int WPE = 1>
-__global__ __launch_bounds__(NTHR, WPE) void pool_fwd_nhwc_kernel(PoolLevels L, const float* __restrict__ rois,
-                                                                 T* __restrict__ out, int nsplit) {
+__global__ __launch_bounds__(NTHR, WPE) void pool_fwd_nhwc_kernel(PoolLevels L, const float* __restrict__ rois_,
+                                                                 T* __restrict__ out_, int nsplit_, PoolFwdPair<T> P) {
   __shared__ SepShared S;
   __shared__ int s_level;
-  const int k = fwd_roi_of(L, (int)blockIdx.x, (int)gridDim.x), tid = threadIdx.x;
-  unsigned long long* wst = (L.wgstamps && tid == 0) ? L.wgstamps + 5 * ((size_t)blockIdx.y * gridDim.x + k) : nullptr;
+  const float* rois = rois_;
+  T* out = out_;
+  int nsplit = nsplit_, bx = (int)blockIdx.x, by = (int)blockIdx.y, gx = (int)gridDim.x, PH = L.PH, PW = L.PW;
+  if (P.rois2) {  // uniform
+    const int n1 = P.K1 * P.ns1;
+    if (bx < n1) {
+      by = bx / P.K1; bx -= by * P.K1; gx = P.K1; nsplit = P.ns1;
+    } else {
+      bx -= n1; by = bx / P.K2; bx -= by * P.K2; gx = P.K2; nsplit = P.ns2;
+      rois = P.rois2; out = P.out2; PH = P.PH2; PW = P.PW2;
+    }
+  }
+  const int k = fwd_roi_of(L, bx, gx), tid = threadIdx.x;
+  unsigned long long* wst = (L.wgstamps && tid == 0) ? L.wgstamps + 5 * ((size_t)by * gx + k) : nullptr;
   if (wst) wst[0] = wall_clock64();
   // every thread evaluates the (wave-uniform) level itself: one broadcast load, no LDS round trip / barrier
   const int lvl = __builtin_amdgcn_readfirstlane(assign_level(rois + (long)k * 5 + 1, L));
-  const int C = L.C, PH = L.PH, PW = L.PW, bins = PH * PW;
+  const int C = L.C, bins = PH * PW;
   const int per = (bins + nsplit - 1) / nsplit;
-  const int b_lo = blockIdx.y * per, b_hi = min(bins, b_lo + per);
+  const int b_lo = by * per, b_hi = min(bins, b_lo + per);
   if (b_lo >= b_hi) return;
   const int CG = C / VEC;
   T* outk = out + (long)k * bins * C;
@@ -2023,6 +2040,21 @@ __global__ void box_lists_to_rois_kernel(ImgBoxes e, int K, float* __restrict__ 
   o[0] = (float)b; o[1] = v.x; o[2] = v.y; o[3] = v.z; o[4] = v.w;
 }
 
+// (both box lists of a paired forward in one launch)
+__global__ void box_lists_to_rois_pair_kernel(ImgBoxes e1, int K1, float* __restrict__ rois1, ImgBoxes e2, int K2,
+                                              float* __restrict__ rois2) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K1 + K2) return;
+  const bool second = k >= K1;
+  const ImgBoxes& e = second ? e2 : e1;
+  if (second) k -= K1;
+  int b = 0;
+  for (int i = 0; i < e.n; i++) b += (k >= e.end[i]) ? 1 : 0;
+  const float4 v = reinterpret_cast<const float4*>(e.ptr[b])[k - (b ? e.end[b - 1] : 0)];
+  float* o = (second ? rois2 : rois1) + (long)k * 5;
+  o[0] = (float)b; o[1] = v.x; o[2] = v.y; o[3] = v.z; o[4] = v.w;
+}
+
 // ---- ROI processing order of the forward (see fwd_roi_of); K <= ROI_ORDER_MAX, one workgroup ----------------------
 // A counting sort by bucket = (level, image, cell of the ROI centre at its level, cells in Morton order); the 14
 // bucket bits go to the level and image numbers first, the rest (<= 10) to the cell: 16-px cells on the finest level
@@ -2178,9 +2210,12 @@ static bool all_aligned16(const void* const* data, int n, const void* extra) {
 // single-level entry points, which handle any pooled size through the direct kernels)
 static bool pooler_fused_ok(const d2amd_pooler_params* p) { return p->pooled_h <= MAXP && p->pooled_w <= MAXP; }
 
+// (pair: a second pooler of the same feature maps in the same launch -- the NHWC 16-B vector kernel only, else
+// EUNSUPPORTED with nothing launched)
+struct PoolFwdPairCall { const d2amd_pooler_params* p2; const float* rois2; void* out2; int K2; };
 template <typename T>
 static int pool_fwd_impl(const d2amd_pooler_params* p, const void* const* inputs, const float* rois, void* output,
-                         int K, hipStream_t s, const int* perm = nullptr) {
+                         int K, hipStream_t s, const int* perm = nullptr, const PoolFwdPairCall* pair = nullptr) {
   PoolLevels L = make_levels(p, inputs, K);
   L.perm = p->layout == D2AMD_NHWC ? perm : nullptr;
   const int bins = p->pooled_h * p->pooled_w;
@@ -2205,6 +2240,26 @@ static int pool_fwd_impl(const d2amd_pooler_params* p, const void* const* inputs
     if (nsplit > bins) nsplit = bins;
     D2_CHECK_ARG(nsplit <= 65535, "roi_pooler_forward: internal split too large");
     dim3 grid(K, nsplit);
+    PoolFwdPair<T> P2{};
+    if (pair) {
+      static const bool wide_env = getenv("D2AMD_FWD_VARIANT") && atoi(getenv("D2AMD_FWD_VARIANT")) == 1;
+      const bool ok = vec && nthr == 512 && !wide_env && perm == nullptr && getenv("D2AMD_POOL_STAMPS") == nullptr &&
+          ((uintptr_t)pair->out2 & 15) == 0 && K > 0 && pair->K2 > 0;
+      if (!ok) {
+        set_error("roi_pooler_forward_pair: outside the paired forward (NHWC, 16-B channel vectors, list order)");
+        return D2AMD_EUNSUPPORTED;
+      }
+      const int bins2 = pair->p2->pooled_h * pair->p2->pooled_w;
+      const int passes2 = cdiv((long)bins2 * cg, nthr);
+      int ns2 = 1024 / pair->K2;
+      { const char* e = getenv("D2AMD_FWD_NSPLIT2"); if (e && atoi(e) > 0) ns2 = atoi(e); }  // profiling switch
+      ns2 = ns2 < 1 ? 1 : (ns2 > passes2 ? passes2 : ns2);
+      if (ns2 > bins2) ns2 = bins2;
+      const long total = (long)K * nsplit + (long)pair->K2 * ns2;
+      D2_CHECK_ARG(total < (1l << 30), "roi_pooler_forward_pair: too many workgroups");
+      P2 = PoolFwdPair<T>{pair->rois2, (T*)pair->out2, K, nsplit, pair->K2, ns2, pair->p2->pooled_h, pair->p2->pooled_w};
+      grid = dim3((unsigned)total, 1);
+    }
     PoolLevels Lf = L;
     for (int l = 0; l < p->num_levels; l++)
       if ((long)p->H[l] * p->W[l] * p->C >= (1l << 32)) Lf.tab_off = 1;
@@ -2214,10 +2269,10 @@ static int pool_fwd_impl(const d2amd_pooler_params* p, const void* const* inputs
       D2_HIP_OK(hipMalloc(&Lf.wgstamps, (size_t)nwg * 5 * 8));
       D2_HIP_OK(hipMemsetAsync(Lf.wgstamps, 0, (size_t)nwg * 5 * 8, s));
     }
-    const char* tname = p->pooled_h <= 7 ? "pool_fwd_r7" : "pool_fwd_r14";
+    const char* tname = pair ? "pool_fwd_pair" : p->pooled_h <= 7 ? "pool_fwd_r7" : "pool_fwd_r14";
     const bool timed = timing_begin(tname, s);
     if (vec && nthr == 1024)
-      hipLaunchKernelGGL((pool_fwd_nhwc_kernel<T, VEC, 1024>), grid, dim3(1024), 0, s, Lf, rois, (T*)output, nsplit);
+      hipLaunchKernelGGL((pool_fwd_nhwc_kernel<T, VEC, 1024>), grid, dim3(1024), 0, s, Lf, rois, (T*)output, nsplit, PoolFwdPair<T>{});
     else if (vec && nthr == 512) {
       // 4 loads in flight per lane and <= 84 VGPRs: three 512-thread workgroups per CU instead of two (8 loads, 108
       // VGPRs): 48.3 -> 43.6 us (box), 34.9 -> 30.2 us (mask); D2AMD_FWD_VARIANT=1 selects the previous shape (A/B)
@@ -2228,14 +2283,14 @@ static int pool_fwd_impl(const d2amd_pooler_params* p, const void* const* inputs
       // the same ~21 us per ROI (4.8 us tables + 13.5 chunks x 1.13 us) -- but with 57 KB of LDS and 100 VGPRs two
       // workgroups fit a CU where this kernel runs four: 57-65 us against 44 us for the box head.)
       if (wide)
-        hipLaunchKernelGGL((pool_fwd_nhwc_kernel<T, VEC, 512>), grid, dim3(512), 0, s, Lf, rois, (T*)output, nsplit);
+        hipLaunchKernelGGL((pool_fwd_nhwc_kernel<T, VEC, 512>), grid, dim3(512), 0, s, Lf, rois, (T*)output, nsplit, PoolFwdPair<T>{});
       else
-        hipLaunchKernelGGL((pool_fwd_nhwc_kernel<T, VEC, 512, 4, 6>), grid, dim3(512), 0, s, Lf, rois, (T*)output, nsplit);
+        hipLaunchKernelGGL((pool_fwd_nhwc_kernel<T, VEC, 512, 4, 6>), grid, dim3(512), 0, s, Lf, rois, (T*)output, nsplit, P2);
     }
     else if (vec)
-      hipLaunchKernelGGL((pool_fwd_nhwc_kernel<T, VEC, 256>), grid, dim3(256), 0, s, Lf, rois, (T*)output, nsplit);
+      hipLaunchKernelGGL((pool_fwd_nhwc_kernel<T, VEC, 256>), grid, dim3(256), 0, s, Lf, rois, (T*)output, nsplit, PoolFwdPair<T>{});
     else
-      hipLaunchKernelGGL((pool_fwd_nhwc_kernel<T, 1, 256>), grid, dim3(256), 0, s, Lf, rois, (T*)output, nsplit);
+      hipLaunchKernelGGL((pool_fwd_nhwc_kernel<T, 1, 256>), grid, dim3(256), 0, s, Lf, rois, (T*)output, nsplit, PoolFwdPair<T>{});
     if (timed) timing_end(tname, s);
     if (stamp_path) {
       D2_HIP_OK(hipStreamSynchronize(s));
@@ -2711,6 +2766,42 @@ extern "C" int d2amd_roi_pooler_forward(const d2amd_pooler_params* p, const void
   return pooler_forward_entry(p, inputs, rois, output, K, nullptr, stream);
 }
 
+// Two poolers of the SAME feature maps in ONE launch (the box head's and the mask head's, roi_heads.py:780-846): rows of
+// output1 / output2 are exactly what d2amd_roi_pooler_forward(p1 ...) / (p2 ...) write -- the same workgroups run the same
+// code -- but the second pooler's workgroups start in the slots the first one's free instead of behind its last one.
+// EUNSUPPORTED (nothing launched) outside the NHWC 16-B vector kernel / for different level rules: two calls then.
+extern "C" int d2amd_roi_pooler_forward_pair(const d2amd_pooler_params* p1, const void* const* inputs, const float* rois1,
+                                             void* output1, int K1, const d2amd_pooler_params* p2, const float* rois2,
+                                             void* output2, int K2, void* stream) {
+  int rc = check_pooler(p1, "roi_pooler_forward_pair");
+  if (rc) return rc;
+  rc = check_pooler(p2, "roi_pooler_forward_pair");
+  if (rc) return rc;
+  D2_CHECK_ARG(K1 >= 0 && K2 >= 0, "roi_pooler_forward_pair: bad K");
+  D2_CHECK_ARG(inputs && (K1 == 0 || (rois1 && output1)) && (K2 == 0 || (rois2 && output2)),
+               "roi_pooler_forward_pair: null pointer");
+  bool same = p1->num_levels == p2->num_levels && p1->N == p2->N && p1->C == p2->C && p1->dtype == p2->dtype &&
+      p1->layout == p2->layout;
+  for (int l = 0; same && l < p1->num_levels; l++) same = p1->H[l] == p2->H[l] && p1->W[l] == p2->W[l];
+  D2_CHECK_ARG(same, "roi_pooler_forward_pair: the two poolers must read the same feature maps");
+  bool rule = p1->sampling_ratio == p2->sampling_ratio && p1->aligned == p2->aligned && p1->min_level == p2->min_level &&
+      p1->max_level == p2->max_level && p1->canonical_level == p2->canonical_level &&
+      p1->canonical_box_size == p2->canonical_box_size;
+  for (int l = 0; rule && l < p1->num_levels; l++) rule = p1->spatial_scale[l] == p2->spatial_scale[l];
+  static const bool off = getenv("D2AMD_POOL_NO_PAIR") != nullptr;
+  if (off || !rule || K1 == 0 || K2 == 0 || !pooler_fused_ok(p1) || !pooler_fused_ok(p2) || p1->layout != D2AMD_NHWC ||
+      (long)p1->N * p1->C == 0) {
+    set_error("roi_pooler_forward_pair: outside the paired forward (NHWC, both K > 0, the same level rule and sampling)");
+    return D2AMD_EUNSUPPORTED;
+  }
+  for (int l = 0; l < p1->num_levels; l++)
+    D2_CHECK_ARG(inputs[l] != nullptr || (long)p1->N * p1->H[l] * p1->W[l] == 0, "roi_pooler_forward_pair: null level %d", l);
+  return D2_DISPATCH_DTYPE(p1->dtype, [&]() -> int {
+    const PoolFwdPairCall pc{p2, rois2, output2, K2};
+    return pool_fwd_impl<scalar_t>(p1, inputs, rois1, output1, K1, (hipStream_t)stream, nullptr, &pc);
+  });
+}
+
 extern "C" size_t d2amd_roi_pooler_forward_workspace_bytes(int K) { return (size_t)(K > 0 ? K : 1) * sizeof(int); }
 
 extern "C" int d2amd_roi_pooler_forward_ordered(const d2amd_pooler_params* p, const void* const* inputs,
@@ -2757,6 +2848,33 @@ extern "C" int d2amd_roi_pooler_forward_box_lists(const d2amd_pooler_params* p, 
   hipLaunchKernelGGL(box_lists_to_rois_kernel, dim3(cdiv(K, 256)), dim3(256), 0, (hipStream_t)stream, e, (int)K, rois_out);
   D2_LAUNCH_OK();
   return d2amd_roi_pooler_forward(p, inputs, rois_out, output, (int)K, stream);
+}
+
+// d2amd_roi_pooler_forward_pair for box lists that were never concatenated: ONE conversion launch for both lists (rois1_out
+// / rois2_out, needed again by the backward), then the paired forward -- or, where that does not apply, the two plain
+// forwards: both outputs are always produced.
+extern "C" int d2amd_roi_pooler_forward_pair_box_lists(const d2amd_pooler_params* p1, const void* const* inputs,
+                                                       const float* const* boxes1, const int* counts1, float* rois1_out,
+                                                       void* output1, const d2amd_pooler_params* p2,
+                                                       const float* const* boxes2, const int* counts2, float* rois2_out,
+                                                       void* output2, int num_images, void* stream) {
+  ImgBoxes e1, e2;
+  long K1, K2;
+  int rc = box_lists_arg(e1, K1, boxes1, counts1, num_images);
+  if (rc) return rc;
+  rc = box_lists_arg(e2, K2, boxes2, counts2, num_images);
+  if (rc) return rc;
+  D2_CHECK_ARG((K1 == 0 || rois1_out) && (K2 == 0 || rois2_out), "roi_pooler_forward_pair_box_lists: null rois_out");
+  if (K1 + K2 > 0) {
+    hipLaunchKernelGGL(box_lists_to_rois_pair_kernel, dim3(cdiv(K1 + K2, 256)), dim3(256), 0, (hipStream_t)stream, e1, (int)K1,
+                       rois1_out, e2, (int)K2, rois2_out);
+    D2_LAUNCH_OK();
+  }
+  rc = d2amd_roi_pooler_forward_pair(p1, inputs, rois1_out, output1, (int)K1, p2, rois2_out, output2, (int)K2, stream);
+  if (rc != D2AMD_EUNSUPPORTED) return rc;
+  rc = d2amd_roi_pooler_forward(p1, inputs, rois1_out, output1, (int)K1, stream);
+  if (rc) return rc;
+  return d2amd_roi_pooler_forward(p2, inputs, rois2_out, output2, (int)K2, stream);
 }
 
 extern "C" int d2amd_roi_pooler_forward_box_lists_ordered(const d2amd_pooler_params* p, const void* const* inputs,

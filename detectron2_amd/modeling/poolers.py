@@ -521,6 +521,143 @@ class _FusedRotatedPool(Function):
         return (None, None) + tuple(gr if need else None for gr, need in zip(grads, ctx.needs))
 
 
+class _FusedROIPoolPair(Function):
+    """Two poolers of the same NHWC feature maps, one launch per direction (d2amd_roi_pooler_forward_pair /
+    d2amd_roi_pooler_backward_pair): see `pool_pair`."""
+
+    @staticmethod
+    @disable_torch_compiler
+    def forward(ctx, rois1, rois2, cfg1, cfg2, *feats):
+        # roisN: the (M, 5) pooler-format tensor, or a tuple of per-image (n_i, 4) fp32 HIP box tensors (converted inside
+        # the same C call, both lists by one launch)
+        lists = None
+        if isinstance(rois1, tuple):
+            lists = (rois1, rois2)
+            rois1, rois2 = (torch.empty((sum(int(b.shape[0]) for b in bl), 5), dtype=torch.float32, device=feats[0].device)
+                            for bl in lists)
+        _C.require_gpu(rois1, rois2, *feats, op="pool_pair")
+        n, c = feats[0].shape[:2]
+        hw = [tuple(x.shape[2:]) for x in feats]
+        code = _C.dtype_code(feats[0])
+        p1, p2 = _params(cfg1, (n, c), hw, code, _C.NHWC), _params(cfg2, (n, c), hw, code, _C.NHWC)
+        k1, k2 = int(rois1.shape[0]), int(rois2.shape[0])
+        dev, dt = feats[0].device, feats[0].dtype
+        out1 = torch.empty((k1, c) + tuple(cfg1[0]), dtype=dt, device=dev, memory_format=torch.channels_last)
+        out2 = torch.empty((k2, c) + tuple(cfg2[0]), dtype=dt, device=dev, memory_format=torch.channels_last)
+        L = _C.lib()
+        with _C.on_device(dev):
+            if lists is not None:
+                n_img = len(lists[0])
+                cnt = [(ctypes.c_int * n_img)(*[int(b.shape[0]) for b in bl]) for bl in lists]
+                rc = L.d2amd_roi_pooler_forward_pair_box_lists(
+                    ctypes.byref(p1), _ptr_array(feats), _ptr_array(lists[0]), cnt[0], _C.ptr(rois1), _C.ptr(out1),
+                    ctypes.byref(p2), _ptr_array(lists[1]), cnt[1], _C.ptr(rois2), _C.ptr(out2), n_img, _C.stream())
+            else:
+                rc = L.d2amd_roi_pooler_forward_pair(ctypes.byref(p1), _ptr_array(feats), _C.ptr(rois1), _C.ptr(out1), k1,
+                                                     ctypes.byref(p2), _C.ptr(rois2), _C.ptr(out2), k2, _C.stream())
+            if rc == _C.EUNSUPPORTED:  # (an empty list, different level rules ...): one launch each
+                _C.check(L.d2amd_roi_pooler_forward(ctypes.byref(p1), _ptr_array(feats), _C.ptr(rois1), _C.ptr(out1), k1,
+                                                    _C.stream()))
+                _C.check(L.d2amd_roi_pooler_forward(ctypes.byref(p2), _ptr_array(feats), _C.ptr(rois2), _C.ptr(out2), k2,
+                                                    _C.stream()))
+            else:
+                _C.check(rc)
+        ctx.save_for_backward(rois1, rois2)
+        ctx.cfgs, ctx.hw, ctx.nc, ctx.dtype = (cfg1, cfg2), hw, (n, c), dt
+        ctx.needs = [f.requires_grad for f in feats]
+        ctx.set_materialize_grads(False)
+        return out1, out2
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g1, g2):
+        rois1, rois2 = ctx.saved_tensors
+        (cfg1, cfg2), hw, (n, c) = ctx.cfgs, ctx.hw, ctx.nc
+        if g1 is None and g2 is None:
+            return (None,) * (4 + len(hw))
+        dev = rois1.device
+        works = [(_to_nhwc(g.detach()), r, cfg) for g, r, cfg in ((g1, rois1, cfg1), (g2, rois2, cfg2)) if g is not None]
+        grads = [torch.empty((n, c, h, w), dtype=ctx.dtype, device=dev, memory_format=torch.channels_last) for (h, w) in hw]
+        L = _C.lib()
+        code = _C.dtype_code(grads[0])
+        with _C.on_device(dev):
+            done = False
+            if len(works) == 2 and _PAIR:
+                (ga, ra, ca), (gb, rb, cb) = works
+                pa, pb = _params(ca, (n, c), hw, code, _C.NHWC), _params(cb, (n, c), hw, code, _C.NHWC)
+                wsb = L.d2amd_roi_pooler_backward_pair_workspace_bytes(ctypes.byref(pa), ra.shape[0], rb.shape[0])
+                ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+                rc = L.d2amd_roi_pooler_backward_pair(ctypes.byref(pa), _C.ptr(ga), _C.ptr(ra), ra.shape[0], ctypes.byref(pb),
+                                                      _C.ptr(gb), _C.ptr(rb), rb.shape[0], _ptr_array(grads), _C.ptr(ws), wsb,
+                                                      _C.stream())
+                done = rc == 0
+                if rc not in (0, _C.EUNSUPPORTED):
+                    _C.check(rc)
+            if not done:  # the first writes every tile, the second adds
+                for j, (g, r, cfg) in enumerate(works):
+                    p = _params(cfg, (n, c), hw, code, _C.NHWC)
+                    k = r.shape[0]
+                    wsb = L.d2amd_roi_pooler_backward_workspace_bytes(ctypes.byref(p), k)
+                    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+                    if j == 0:
+                        _C.check(L.d2amd_roi_pooler_backward(ctypes.byref(p), _C.ptr(g), _C.ptr(r), _ptr_array(grads), k,
+                                                             _C.ptr(ws), wsb, _C.stream()))
+                        continue
+                    rc = L.d2amd_roi_pooler_backward_accumulate(ctypes.byref(p), _C.ptr(g), _C.ptr(r), _ptr_array(grads), k,
+                                                                _C.ptr(ws), wsb, _C.stream())
+                    if rc == _C.EUNSUPPORTED:
+                        extra = [torch.empty_like(t) for t in grads]
+                        _C.check(L.d2amd_roi_pooler_backward(ctypes.byref(p), _C.ptr(g), _C.ptr(r), _ptr_array(extra), k,
+                                                             _C.ptr(ws), wsb, _C.stream()))
+                        grads = [a + b for a, b in zip(grads, extra)]
+                    else:
+                        _C.check(rc)
+        return (None, None, None, None) + tuple(g if need else None for g, need in zip(grads, ctx.needs))
+
+
+def pool_pair(pooler1: "ROIPooler", pooler2: "ROIPooler", x: List[torch.Tensor], box_lists1, box_lists2):
+    """(pooler1(x, box_lists1), pooler2(x, box_lists2)) for two multi-level ROIAlign poolers of the SAME feature maps --
+    Mask R-CNN's box head (7x7, the sampled proposals) and mask head (14x14, the foreground ones), roi_heads.py:780-846 --
+    as ONE launch per direction where the features are channels_last HIP tensors: the forward runs both poolers'
+    workgroups in one grid (the mask head's fill the slots the box head's largest ROIs leave idle), the backward bins both
+    ROI sets together and gathers every gradient tile once for both (d2amd_roi_pooler_backward_pair).  The forward values
+    are bit for bit the separate calls'; the gradient rounds the fp32 sum of both poolers once.  Anything else (other
+    layouts, rotated poolers, an empty list, different level rules) takes the two separate calls."""
+    ok = (isinstance(x, list) and len(x) > 0 and pooler1._fusable(x) and pooler2._fusable(x)
+          and _layout_of(x[0]) == _C.NHWC and len(box_lists1) == len(box_lists2) == x[0].shape[0] and len(box_lists1) > 0
+          and len(x) == len(pooler1.level_poolers) == len(pooler2.level_poolers) and _PAIR)
+    if not ok:
+        return pooler1(x, box_lists1), pooler2(x, box_lists2)
+    cfgs = [(tuple(p.output_size), tuple(p.scales), int(p.sampling_ratio), p.pooler_type == "ROIAlignV2", p.min_level,
+             p.max_level, p.canonical_box_size, p.canonical_level) for p in (pooler1, pooler2)]
+    # fast path: per-image fp32 HIP box tensors go to the C ABI as they are
+    dev = x[0].device
+    bts = [tuple(b.tensor if hasattr(b, "tensor") else b for b in bl) for bl in (box_lists1, box_lists2)]
+    if len(bts[0]) <= 64 and all(t.dtype == torch.float32 and t.device == dev and t.dim() == 2 and t.shape[1] == 4
+                                 and t.is_contiguous() and not t.requires_grad and t.data_ptr() % 16 == 0
+                                 for bt in bts for t in bt):
+        return _FusedROIPoolPair.apply(bts[0], bts[1], cfgs[0], cfgs[1], *x)
+    rois = [convert_boxes_to_pooler_format(bl).detach().float().contiguous() for bl in (box_lists1, box_lists2)]
+    return _FusedROIPoolPair.apply(rois[0], rois[1], cfgs[0], cfgs[1], *x)
+
+
+def pool_pair_rois(pooler1: "ROIPooler", pooler2: "ROIPooler", x: List[torch.Tensor], rois1: torch.Tensor,
+                   rois2: torch.Tensor):
+    """`pool_pair` for boxes that already are in pooler format ((M, 5) fp32 rows = image index, x1, y1, x2, y2: what
+    `label_and_sample_proposals_fixed` writes as "rois" / "head_rois"); = (pooler1.pool_rois(x, rois1),
+    pooler2.pool_rois(x, rois2))."""
+    for r in (rois1, rois2):
+        assert r.dim() == 2 and r.shape[1] == 5 and r.dtype == torch.float32 and r.is_contiguous()
+    ok = (isinstance(x, list) and len(x) > 0 and pooler1._fusable(x) and pooler2._fusable(x)
+          and _layout_of(x[0]) == _C.NHWC and len(x) == len(pooler1.level_poolers) == len(pooler2.level_poolers) and _PAIR
+          and rois1.shape[0] > 0 and rois2.shape[0] > 0)
+    if not ok:
+        return pooler1.pool_rois(x, rois1), pooler2.pool_rois(x, rois2)
+    cfgs = [(tuple(p.output_size), tuple(p.scales), int(p.sampling_ratio), p.pooler_type == "ROIAlignV2", p.min_level,
+             p.max_level, p.canonical_box_size, p.canonical_level) for p in (pooler1, pooler2)]
+    return _FusedROIPoolPair.apply(rois1.detach(), rois2.detach(), cfgs[0], cfgs[1], *x)
+
+
 class ROIPooler(nn.Module):
     """Region of interest feature map pooler over one or more feature maps (poolers.py:114-263)."""
 

@@ -117,6 +117,22 @@ int d2amd_roi_pooler_forward(const d2amd_pooler_params* p, const void* const* in
 int d2amd_roi_pooler_forward_box_lists(const d2amd_pooler_params* p, const void* const* inputs,
                                        const float* const* boxes, const int* counts, int num_images,
                                        float* rois_out, void* output, void* stream);
+/* Two poolers of the SAME feature maps in ONE launch (Mask R-CNN's box head 7x7 and mask head 14x14 poolers,
+ * roi_heads.py:780-846): output1 / output2 are bit for bit what d2amd_roi_pooler_forward(p1 ...) and (p2 ...) write; the
+ * second pooler's workgroups fill the slots the first one's free instead of starting behind its last (largest) ROI.
+ * D2AMD_EUNSUPPORTED -- nothing launched -- outside NHWC with 16-byte channel vectors, for K1 or K2 == 0 or different
+ * level rules / scales / sampling: the caller issues the two calls. */
+int d2amd_roi_pooler_forward_pair(const d2amd_pooler_params* p1, const void* const* inputs, const float* rois1,
+                                  void* output1, int K1, const d2amd_pooler_params* p2, const float* rois2,
+                                  void* output2, int K2, void* stream);
+/* The same for box lists that were never concatenated (as d2amd_roi_pooler_forward_box_lists): one conversion launch
+ * for both lists (rois1_out [K1,5], rois2_out [K2,5]: the backward needs them), then the paired forward -- or the two
+ * plain forwards where it does not apply: both outputs are always produced. */
+int d2amd_roi_pooler_forward_pair_box_lists(const d2amd_pooler_params* p1, const void* const* inputs,
+                                            const float* const* boxes1, const int* counts1, float* rois1_out,
+                                            void* output1, const d2amd_pooler_params* p2, const float* const* boxes2,
+                                            const int* counts2, float* rois2_out, void* output2, int num_images,
+                                            void* stream);
 /* Both forwards with a ROI PROCESSING ORDER: the ROIs are sorted by (level, image, Morton code of their centre's 8-px
  * tile) by one small launch (which also converts the box lists), and each XCD pools one contiguous range of that
  * order -- neighbours in the feature map share that XCD's L2 instead of being fetched by all eight.  Results are

@@ -15,6 +15,11 @@ if op == "roi_align_chain_bwd":  # the step's backward: box and mask pooler of t
     yb, ym = w.box_pooler(w.feats, w.box_lists), w.mask_pooler(w.feats, w.mask_lists)
     for _ in range(N):
         torch.autograd.grad([yb, ym], w.feats, [w.gbox, w.gmask], retain_graph=True)
+elif op == "roi_align_pair_fwd":  # both poolers' forward in one launch (pool_pair)
+    from detectron2_amd.modeling import pool_pair
+    feats = [f.detach() for f in w.feats]
+    for _ in range(N):
+        pool_pair(w.box_pooler, w.mask_pooler, feats, w.box_lists, w.mask_lists)
 elif op == "mask_targets":
     from detectron2_amd.structures import crop_and_resize_batch
     for _ in range(N):

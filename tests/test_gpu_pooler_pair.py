@@ -211,3 +211,73 @@ def test_chained_poolers_take_the_paired_launch_through_autograd(pair, monkeypat
                    {"pool_bwd_pair": 0, "pool_bwd_staged_r7": 1, "pool_bwd_staged_r14": 1}), cnt
     _, want = _run("pair" if pair else "two", feats, boxes1, g1, boxes2, g2, torch.bfloat16)
     assert all(torch.equal(x.grad, w) for x, w in zip(xs, want))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("name", ["subset", "independent", "sparse"])
+def test_pool_pair_forward_is_the_two_forwards_bit_for_bit(name, dtype):
+    """d2amd_roi_pooler_forward_pair(_box_lists): the same workgroups run the same code in one grid."""
+    from detectron2_amd.modeling import pool_pair
+
+    feats, boxes1, _, boxes2, _ = _case(name, torch.bfloat16)
+    xs = [_nhwc(f, dtype) for f in feats]
+    b1 = [Boxes(torch.from_numpy(b).to(DEV)) for b in boxes1]
+    b2 = [Boxes(torch.from_numpy(b).to(DEV)) for b in boxes2]
+    pa, pb = ROIPooler(7, SCALES, 0, "ROIAlignV2"), ROIPooler(14, SCALES, 0, "ROIAlignV2")
+    _C.lib().d2amd_timing_select(b"pool_fwd_pair")
+    try:
+        ya, yb = pool_pair(pa, pb, xs, b1, b2)
+        torch.cuda.synchronize()
+        tot, c = ctypes.c_double(0.0), ctypes.c_int(0)
+        _C.check(_C.lib().d2amd_timing_read(b"pool_fwd_pair", ctypes.byref(tot), ctypes.byref(c)))
+    finally:
+        _C.lib().d2amd_timing_select(None)
+    assert c.value == 1  # the paired launch ran (fp32: 16-B vectors of 4 channels, the same kernel)
+    wa, wb = pa(xs, b1), pb(xs, b2)
+    assert ya.shape == wa.shape and yb.shape == wb.shape and torch.equal(ya, wa) and torch.equal(yb, wb)
+    # the (M, 5) route (boxes that are not 16-B aligned fp32 HIP tensors: here fp64 boxes)
+    ya2, yb2 = pool_pair(pa, pb, xs, [Boxes(b.tensor.double()) for b in b1], [Boxes(b.tensor.double()) for b in b2])
+    assert torch.equal(ya2, wa) and torch.equal(yb2, wb)
+
+
+def test_pool_pair_backward_is_the_paired_backward_and_falls_back_cleanly():
+    from detectron2_amd.modeling import pool_pair
+
+    feats, boxes1, g1, boxes2, g2 = _case("independent", torch.bfloat16)
+    b1 = [Boxes(torch.from_numpy(b).to(DEV)) for b in boxes1]
+    b2 = [Boxes(torch.from_numpy(b).to(DEV)) for b in boxes2]
+    pa, pb = ROIPooler(7, SCALES, 0, "ROIAlignV2"), ROIPooler(14, SCALES, 0, "ROIAlignV2")
+    xs = [_nhwc(f, torch.bfloat16).requires_grad_(True) for f in feats]
+    ya, yb = pool_pair(pa, pb, xs, b1, b2)
+    torch.autograd.backward([ya, yb], [g1, g2])
+    _, want = _run("pair", feats, boxes1, g1, boxes2, g2, torch.bfloat16)
+    assert all(torch.equal(x.grad, w) for x, w in zip(xs, want))
+    # only one of the two results is used: that pooler's plain backward
+    for x in xs:
+        x.grad = None
+    ya, yb = pool_pair(pa, pb, xs, b1, b2)
+    yb.backward(g2)
+    xs2 = [_nhwc(f, torch.bfloat16).requires_grad_(True) for f in feats]
+    pb(xs2, b2).backward(g2)
+    assert all(torch.equal(x.grad, y.grad) for x, y in zip(xs, xs2))
+    # NCHW features, an empty image list entry, fp32: the separate calls (same values as calling them)
+    xs3 = [torch.from_numpy(f).to(DEV).requires_grad_(True) for f in feats]
+    ya, yb = pool_pair(pa, pb, xs3, b1, b2)
+    assert torch.equal(ya, pa(xs3, b1)) and torch.equal(yb, pb(xs3, b2))
+    P._ALIASES.clear()
+
+
+def test_pool_pair_rois_is_pool_rois_twice():
+    from detectron2_amd.modeling import pool_pair_rois
+
+    feats, boxes1, g1, boxes2, g2 = _case("subset", torch.bfloat16)
+    pa, pb = ROIPooler(7, SCALES, 0, "ROIAlignV2"), ROIPooler(14, SCALES, 0, "ROIAlignV2")
+    r1, r2 = _rois(boxes1), _rois(boxes2)
+    xs = [_nhwc(f, torch.bfloat16).requires_grad_(True) for f in feats]
+    ya, yb = pool_pair_rois(pa, pb, xs, r1, r2)
+    with torch.no_grad():
+        assert torch.equal(ya, pa.pool_rois(xs, r1)) and torch.equal(yb, pb.pool_rois(xs, r2))
+    torch.autograd.backward([ya, yb], [g1, g2])
+    _, want = _run("pair", feats, boxes1, g1, boxes2, g2, torch.bfloat16)
+    assert all(torch.equal(x.grad, w) for x, w in zip(xs, want))
+    P._ALIASES.clear()
