@@ -281,3 +281,81 @@ def test_pool_pair_rois_is_pool_rois_twice():
     _, want = _run("pair", feats, boxes1, g1, boxes2, g2, torch.bfloat16)
     assert all(torch.equal(x.grad, w) for x, w in zip(xs, want))
     P._ALIASES.clear()
+
+
+@pytest.mark.parametrize("C,out1,out2,sr", [(320, 7, 14, 0),   # two channel slabs, the second one 64 channels wide
+                                            (64, 6, 10, 0),    # other pooled sizes of the two bin classes
+                                            (64, (7, 5), (12, 16), 2),  # non-square, fixed sampling ratio
+                                            (32, 8, 9, 0)])    # the class boundaries: 8 and 9 bins per axis
+def test_pair_other_shapes_vs_oracle(C, out1, out2, sr):
+    rng = np.random.default_rng(C + 7)
+    img_h, img_w = 256, 320
+    feats, boxes1 = make_inputs(rng, 2, C, img_h, img_w, 30)
+    _, boxes2 = make_inputs(rng, 2, C, img_h, img_w, 9)
+    o1 = (out1, out1) if isinstance(out1, int) else out1
+    o2 = (out2, out2) if isinstance(out2, int) else out2
+    k1, k2 = sum(len(b) for b in boxes1), sum(len(b) for b in boxes2)
+    g1 = _nhwc(rng.standard_normal((k1, C) + o1).astype(np.float32), torch.bfloat16)
+    g2 = _nhwc(rng.standard_normal((k2, C) + o2).astype(np.float32), torch.bfloat16)
+    L = _C.lib()
+    hw = [tuple(f.shape[2:]) for f in feats]
+    code = _C.dtype_code(g1)
+    cfg = lambda o: (o, tuple(SCALES), sr, True, 2, 5, 224, 4)
+    p1, p2 = P._params(cfg(o1), (2, C), hw, code, _C.NHWC), P._params(cfg(o2), (2, C), hw, code, _C.NHWC)
+    r1, r2 = _rois(boxes1), _rois(boxes2)
+    grads = [torch.full((2, C) + s, 3.0, dtype=torch.bfloat16, device=DEV).contiguous(memory_format=torch.channels_last)
+             for s in hw]
+    wsb = L.d2amd_roi_pooler_backward_pair_workspace_bytes(ctypes.byref(p1), k1, k2)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    with _C.on_device(grads[0].device):
+        _C.check(L.d2amd_roi_pooler_backward_pair(ctypes.byref(p1), _C.ptr(g1), _C.ptr(r1), k1, ctypes.byref(p2), _C.ptr(g2),
+                                                  _C.ptr(r2), k2, P._ptr_array(grads), _C.ptr(ws), wsb, _C.stream()))
+    torch.cuda.synchronize()
+
+    def oracle_grads(boxes, o, g):
+        import oracle
+        from test_tile_gather_math import assign_levels_restated
+        allb = np.concatenate(boxes)
+        rois = _rois(boxes).cpu().numpy()
+        lv = assign_levels_restated(allb, 2, 5, 224, 4)
+        res = []
+        for l, f in enumerate(feats):
+            sel = np.nonzero(lv == l)[0]
+            res.append(oracle.roi_align_backward(np.ascontiguousarray(g[sel]), rois[sel], f.shape, SCALES[l], sr, True))
+        return res
+
+    w1 = oracle_grads(boxes1, o1, g1.float().cpu().numpy())
+    w2 = oracle_grads(boxes2, o2, g2.float().cpu().numpy())
+    for l in range(4):
+        assert rel_err(grads[l].float().cpu().numpy(), w1[l] + w2[l]) < 2.0 ** -7, l
+
+
+def test_three_chained_poolers_pair_the_first_two_and_add_the_third():
+    """box 7x7 + mask 14x14 + a third 14x14 pooler (keypoint head, roi_heads.py:848-877) on the same leaves."""
+    rng = np.random.default_rng(21)
+    C = 64
+    feats, boxes1 = make_inputs(rng, 2, C, 320, 448, 30)
+    boxes2 = [b[:10] for b in boxes1]
+    boxes3 = [b[5:12] for b in boxes1]
+    gs = [rng.standard_normal((sum(len(b) for b in bl), C, o, o)).astype(np.float32)
+          for bl, o in ((boxes1, 7), (boxes2, 14), (boxes3, 14))]
+    xs = [_nhwc(f, torch.bfloat16).requires_grad_(True) for f in feats]
+    ys = [ROIPooler(o, SCALES, 0, "ROIAlignV2")(xs, [Boxes(torch.from_numpy(b).to(DEV)) for b in bl])
+          for bl, o in ((boxes1, 7), (boxes2, 14), (boxes3, 14))]
+    _C.lib().d2amd_timing_select(b"pool_bwd_pair,pool_bwd_staged_r14")
+    try:
+        torch.autograd.backward(ys, [_nhwc(g, torch.bfloat16) for g in gs])
+        torch.cuda.synchronize()
+        cnt = []
+        for kn in (b"pool_bwd_pair", b"pool_bwd_staged_r14"):
+            tot, c = ctypes.c_double(0.0), ctypes.c_int(0)
+            _C.check(_C.lib().d2amd_timing_read(kn, ctypes.byref(tot), ctypes.byref(c)))
+            cnt.append(c.value)
+    finally:
+        _C.lib().d2amd_timing_select(None)
+        P._ALIASES.clear()
+    assert cnt == [1, 1], cnt
+    want = [sum(t) for t in zip(*[oracle_pooler(feats, bl, o, 0, True, grad=torch.from_numpy(g).to(torch.bfloat16).float().numpy())[1]
+                                  for bl, o, g in ((boxes1, 7, gs[0]), (boxes2, 14, gs[1]), (boxes3, 14, gs[2]))])]
+    for x, w in zip(xs, want):
+        assert rel_err(x.grad.float().cpu().numpy(), w) < 2.0 ** -6
