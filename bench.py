@@ -531,6 +531,9 @@ def connected_forward(w, run=None, rpn_keys=None, roi_keys=None, sync=False):
         return run("mask_loss_fwd", lambda: mask_rcnn_loss_from_targets(w.mask_logits, cls, tg,
                                                                         ignore_invalid_rows=True))
 
+    # (A/B at 0.355 ms, same box: the ROI half WITHOUT this fork 0.3604 / 0.3607 against 0.3573 / 0.3598 -- its two edges
+    # cost ~14 us and the branches slow each other down, for 38 us of overlapped work; targets + loss behind the anchor
+    # labelling on that branch's stream instead 0.3553 / 0.3574 against 0.3536 / 0.3534: profiles/r04/LOG.md)
     if w.overlap and bare:
         (yb, ym), (loss, stats) = fork_join(poolers, targets_and_loss, current_first=True)
         done.join_beside()  # the anchor labels are part of the forward's result
