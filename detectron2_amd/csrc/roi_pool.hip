@@ -2438,7 +2438,7 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
         getenv("D2AMD_POOL_STAMPS_STATIC") != nullptr;
     const int pm = p->pooled_h > p->pooled_w ? p->pooled_h : p->pooled_w;
     const bool ok = staged && sizeof(T) == 2 && !no_mfma_env && !fixed && p->C % 32 == 0 && p->C <= 8192 && K_first > 0 &&
-        pm <= 8 && phase == 0 && !accumulate;
+        pm <= 8 && phase <= 2 && !accumulate;
     if (!ok || probe) return ok ? D2AMD_OK : D2AMD_EUNSUPPORTED;
   }
   if (queues) {
@@ -2957,10 +2957,10 @@ extern "C" size_t d2amd_roi_pooler_backward_pair_workspace_bytes(const d2amd_poo
   return d2amd_roi_pooler_backward_workspace_bytes(p1, (int)(k < (1l << 30) ? k : (1l << 30))) +
       pool_al((size_t)pool_ntiles(p1) * 4);  // + the per-tile count of the first pooler's entries
 }
-extern "C" int d2amd_roi_pooler_backward_pair(const d2amd_pooler_params* p1, const void* grad_output1, const float* rois1,
-                                              int K1, const d2amd_pooler_params* p2, const void* grad_output2,
-                                              const float* rois2, int K2, void* const* grad_inputs, void* workspace,
-                                              size_t workspace_bytes, void* stream) {
+static int pooler_backward_pair_entry(const d2amd_pooler_params* p1, const void* grad_output1, const float* rois1, int K1,
+                                      const d2amd_pooler_params* p2, const void* grad_output2, const float* rois2, int K2,
+                                      void* const* grad_inputs, void* workspace, size_t workspace_bytes, int phase,
+                                      void* stream) {
   int rc = check_pooler(p1, "roi_pooler_backward_pair");
   if (rc) return rc;
   rc = check_pooler(p2, "roi_pooler_backward_pair");
@@ -2991,14 +2991,35 @@ extern "C" int d2amd_roi_pooler_backward_pair(const d2amd_pooler_params* p1, con
     const PoolPairCall pc{p2, grad_output2, rois2, K2};
     hipStream_t s = (hipStream_t)stream;
     // the call must take the persistent MFMA tile gather (probe: nothing is launched)
-    const int r = pool_bwd_nhwc_impl<scalar_t>(p1, grad_output1, rois1, grad_inputs, K1, workspace, workspace_bytes, s, false, 0,
-                                               &pc, true);
+    const int r = pool_bwd_nhwc_impl<scalar_t>(p1, grad_output1, rois1, grad_inputs, K1, workspace, workspace_bytes, s, false,
+                                               phase, &pc, true);
     if (r) {
       set_error("roi_pooler_backward_pair: outside the paired 16-bit tile gather (workspace, alignment or a profiling switch)");
       return r;
     }
-    return pool_bwd_nhwc_impl<scalar_t>(p1, grad_output1, rois1, grad_inputs, K1, workspace, workspace_bytes, s, false, 0, &pc);
+    return pool_bwd_nhwc_impl<scalar_t>(p1, grad_output1, rois1, grad_inputs, K1, workspace, workspace_bytes, s, false, phase,
+                                        &pc);
   });
+}
+extern "C" int d2amd_roi_pooler_backward_pair(const d2amd_pooler_params* p1, const void* grad_output1, const float* rois1,
+                                              int K1, const d2amd_pooler_params* p2, const void* grad_output2,
+                                              const float* rois2, int K2, void* const* grad_inputs, void* workspace,
+                                              size_t workspace_bytes, void* stream) {
+  return pooler_backward_pair_entry(p1, grad_output1, rois1, K1, p2, grad_output2, rois2, K2, grad_inputs, workspace,
+                                    workspace_bytes, 0, stream);
+}
+// The paired backward in two calls (as d2amd_roi_pooler_backward_phase): phase 1 bins both ROI sets -- it reads the rois,
+// writes the workspace and ZERO-FILLS the tiles of grad_inputs no ROI touches, so the gradient tensors must exist, but no
+// gradient value is needed: it can run beside the poolers' forward (grad_outputN: any pointers of the later ones'
+// alignment class) -- phase 2, with the same arguments and workspace, is the tile gather alone.
+extern "C" int d2amd_roi_pooler_backward_pair_phase(const d2amd_pooler_params* p1, const void* grad_output1,
+                                                    const float* rois1, int K1, const d2amd_pooler_params* p2,
+                                                    const void* grad_output2, const float* rois2, int K2,
+                                                    void* const* grad_inputs, void* workspace, size_t workspace_bytes,
+                                                    int phase, void* stream) {
+  D2_CHECK_ARG(phase == 1 || phase == 2, "roi_pooler_backward_pair_phase: phase must be 1 (bin + zero fill) or 2 (gather)");
+  return pooler_backward_pair_entry(p1, grad_output1, rois1, K1, p2, grad_output2, rois2, K2, grad_inputs, workspace,
+                                    workspace_bytes, phase, stream);
 }
 
 extern "C" int d2amd_roi_pooler_backward_phase(const d2amd_pooler_params* p, const void* grad_output,

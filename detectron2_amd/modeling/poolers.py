@@ -521,15 +521,64 @@ class _FusedRotatedPool(Function):
         return (None, None) + tuple(gr if need else None for gr, need in zip(grads, ctx.needs))
 
 
+class PairBackwardPlan:
+    """The binning of a paired pooler backward (`pool_pair_rois(..., plan=...)`), issued AHEAD of the backward: it depends on
+    the ROIs alone (per-ROI records, per-tile lists, work queues, zero fill of the gradient tiles no ROI touches), ~25 us of
+    small launches that otherwise sit between the forward and the tile gather.  `prepare()` may be called on ANY stream
+    once both ROI sets exist -- e.g. on the branch that builds the mask targets beside the poolers' forward -- and
+    allocates the feature gradients it zero-fills; the backward then waits for its event and runs the gather alone
+    (d2amd_roi_pooler_backward_pair_phase 1 / 2).  A plan that was never prepared, or whose call the library declines,
+    changes nothing: the backward bins as usual."""
+
+    def __init__(self):
+        self.ready = None  # (event, ws, ws_bytes, grads, signature)
+
+    def prepare(self, pooler1: "ROIPooler", pooler2: "ROIPooler", x: List[torch.Tensor], rois1: torch.Tensor,
+                rois2: torch.Tensor):
+        self.ready = None
+        if not (_PAIR and len(x) > 0 and pooler1._fusable(x) and pooler2._fusable(x) and _layout_of(x[0]) == _C.NHWC
+                and x[0].dtype in (torch.bfloat16, torch.float16) and rois1.shape[0] > 0 and rois2.shape[0] > 0):
+            return False
+        cfgs = [_pair_cfg(p) for p in (pooler1, pooler2)]
+        n, c = x[0].shape[:2]
+        hw = [tuple(t.shape[2:]) for t in x]
+        dev, dt = x[0].device, x[0].dtype
+        code = _C.dtype_code(x[0])
+        p1, p2 = _params(cfgs[0], (n, c), hw, code, _C.NHWC), _params(cfgs[1], (n, c), hw, code, _C.NHWC)
+        L = _C.lib()
+        k1, k2 = int(rois1.shape[0]), int(rois2.shape[0])
+        grads = [torch.empty((n, c, h, w), dtype=dt, device=dev, memory_format=torch.channels_last) for (h, w) in hw]
+        wsb = L.d2amd_roi_pooler_backward_pair_workspace_bytes(ctypes.byref(p1), k1, k2)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        with _C.on_device(dev):
+            # (no gradient exists yet: the workspace stands in for both dY pointers -- only their alignment is looked at)
+            rc = L.d2amd_roi_pooler_backward_pair_phase(ctypes.byref(p1), _C.ptr(ws), _C.ptr(rois1), k1, ctypes.byref(p2),
+                                                        _C.ptr(ws), _C.ptr(rois2), k2, _ptr_array(grads), _C.ptr(ws), wsb, 1,
+                                                        _C.stream())
+        if rc == _C.EUNSUPPORTED:
+            return False
+        _C.check(rc)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        self.ready = (ev, ws, wsb, grads, (rois1.data_ptr(), rois2.data_ptr(), k1, k2, cfgs[0], cfgs[1], (n, c), tuple(hw), dt))
+        return True
+
+
+def _pair_cfg(p):
+    return (tuple(p.output_size), tuple(p.scales), int(p.sampling_ratio), p.pooler_type == "ROIAlignV2", p.min_level,
+            p.max_level, p.canonical_box_size, p.canonical_level)
+
+
 class _FusedROIPoolPair(Function):
     """Two poolers of the same NHWC feature maps, one launch per direction (d2amd_roi_pooler_forward_pair /
     d2amd_roi_pooler_backward_pair): see `pool_pair`."""
 
     @staticmethod
     @disable_torch_compiler
-    def forward(ctx, rois1, rois2, cfg1, cfg2, *feats):
+    def forward(ctx, rois1, rois2, cfg1, cfg2, plan, *feats):
         # roisN: the (M, 5) pooler-format tensor, or a tuple of per-image (n_i, 4) fp32 HIP box tensors (converted inside
-        # the same C call, both lists by one launch)
+        # the same C call, both lists by one launch); plan: None or a PairBackwardPlan (looked at in the backward)
+        ctx.plan = plan
         lists = None
         if isinstance(rois1, tuple):
             lists = (rois1, rois2)
@@ -574,12 +623,32 @@ class _FusedROIPoolPair(Function):
         rois1, rois2 = ctx.saved_tensors
         (cfg1, cfg2), hw, (n, c) = ctx.cfgs, ctx.hw, ctx.nc
         if g1 is None and g2 is None:
-            return (None,) * (4 + len(hw))
+            return (None,) * (5 + len(hw))
         dev = rois1.device
         works = [(_to_nhwc(g.detach()), r, cfg) for g, r, cfg in ((g1, rois1, cfg1), (g2, rois2, cfg2)) if g is not None]
-        grads = [torch.empty((n, c, h, w), dtype=ctx.dtype, device=dev, memory_format=torch.channels_last) for (h, w) in hw]
         L = _C.lib()
-        code = _C.dtype_code(grads[0])
+        code = _C.dtype_code(works[0][0])
+        # binned ahead of time (PairBackwardPlan.prepare, for exactly these ROI tensors and poolers): the gather alone
+        ready = ctx.plan.ready if ctx.plan is not None else None
+        if ctx.plan is not None:
+            ctx.plan.ready = None
+        if (ready is not None and len(works) == 2 and _PAIR and ready[4] == (rois1.data_ptr(), rois2.data_ptr(),
+                                                                              int(rois1.shape[0]), int(rois2.shape[0]), cfg1,
+                                                                              cfg2, (n, c), tuple(hw), ctx.dtype)):
+            ev, ws, wsb, grads, _ = ready
+            cur = torch.cuda.current_stream(dev)
+            cur.wait_event(ev)
+            ws.record_stream(cur)
+            for g in grads:
+                g.record_stream(cur)
+            (ga, ra, ca), (gb, rb, cb) = works
+            pa, pb = _params(ca, (n, c), hw, code, _C.NHWC), _params(cb, (n, c), hw, code, _C.NHWC)
+            with _C.on_device(dev):
+                _C.check(L.d2amd_roi_pooler_backward_pair_phase(ctypes.byref(pa), _C.ptr(ga), _C.ptr(ra), ra.shape[0],
+                                                                ctypes.byref(pb), _C.ptr(gb), _C.ptr(rb), rb.shape[0],
+                                                                _ptr_array(grads), _C.ptr(ws), wsb, 2, _C.stream()))
+            return (None, None, None, None, None) + tuple(g if need else None for g, need in zip(grads, ctx.needs))
+        grads = [torch.empty((n, c, h, w), dtype=ctx.dtype, device=dev, memory_format=torch.channels_last) for (h, w) in hw]
         with _C.on_device(dev):
             done = False
             if len(works) == 2 and _PAIR:
@@ -612,7 +681,7 @@ class _FusedROIPoolPair(Function):
                         grads = [a + b for a, b in zip(grads, extra)]
                     else:
                         _C.check(rc)
-        return (None, None, None, None) + tuple(g if need else None for g, need in zip(grads, ctx.needs))
+        return (None, None, None, None, None) + tuple(g if need else None for g, need in zip(grads, ctx.needs))
 
 
 def pool_pair(pooler1: "ROIPooler", pooler2: "ROIPooler", x: List[torch.Tensor], box_lists1, box_lists2):
@@ -636,16 +705,17 @@ def pool_pair(pooler1: "ROIPooler", pooler2: "ROIPooler", x: List[torch.Tensor],
     if len(bts[0]) <= 64 and all(t.dtype == torch.float32 and t.device == dev and t.dim() == 2 and t.shape[1] == 4
                                  and t.is_contiguous() and not t.requires_grad and t.data_ptr() % 16 == 0
                                  for bt in bts for t in bt):
-        return _FusedROIPoolPair.apply(bts[0], bts[1], cfgs[0], cfgs[1], *x)
+        return _FusedROIPoolPair.apply(bts[0], bts[1], cfgs[0], cfgs[1], None, *x)
     rois = [convert_boxes_to_pooler_format(bl).detach().float().contiguous() for bl in (box_lists1, box_lists2)]
-    return _FusedROIPoolPair.apply(rois[0], rois[1], cfgs[0], cfgs[1], *x)
+    return _FusedROIPoolPair.apply(rois[0], rois[1], cfgs[0], cfgs[1], None, *x)
 
 
 def pool_pair_rois(pooler1: "ROIPooler", pooler2: "ROIPooler", x: List[torch.Tensor], rois1: torch.Tensor,
-                   rois2: torch.Tensor):
+                   rois2: torch.Tensor, plan: "PairBackwardPlan" = None):
     """`pool_pair` for boxes that already are in pooler format ((M, 5) fp32 rows = image index, x1, y1, x2, y2: what
     `label_and_sample_proposals_fixed` writes as "rois" / "head_rois"); = (pooler1.pool_rois(x, rois1),
-    pooler2.pool_rois(x, rois2))."""
+    pooler2.pool_rois(x, rois2)).  plan: a `PairBackwardPlan` whose `prepare(pooler1, pooler2, x, rois1, rois2)` the caller
+    issues (before the backward, on any stream): the backward's binning then runs there."""
     for r in (rois1, rois2):
         assert r.dim() == 2 and r.shape[1] == 5 and r.dtype == torch.float32 and r.is_contiguous()
     ok = (isinstance(x, list) and len(x) > 0 and pooler1._fusable(x) and pooler2._fusable(x)
@@ -655,7 +725,7 @@ def pool_pair_rois(pooler1: "ROIPooler", pooler2: "ROIPooler", x: List[torch.Ten
         return pooler1.pool_rois(x, rois1), pooler2.pool_rois(x, rois2)
     cfgs = [(tuple(p.output_size), tuple(p.scales), int(p.sampling_ratio), p.pooler_type == "ROIAlignV2", p.min_level,
              p.max_level, p.canonical_box_size, p.canonical_level) for p in (pooler1, pooler2)]
-    return _FusedROIPoolPair.apply(rois1.detach(), rois2.detach(), cfgs[0], cfgs[1], *x)
+    return _FusedROIPoolPair.apply(rois1.detach(), rois2.detach(), cfgs[0], cfgs[1], plan, *x)
 
 
 class ROIPooler(nn.Module):

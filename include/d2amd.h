@@ -174,6 +174,14 @@ size_t d2amd_roi_pooler_backward_pair_workspace_bytes(const d2amd_pooler_params*
 int d2amd_roi_pooler_backward_pair(const d2amd_pooler_params* p1, const void* grad_output1, const float* rois1, int K1,
                                    const d2amd_pooler_params* p2, const void* grad_output2, const float* rois2, int K2,
                                    void* const* grad_inputs, void* workspace, size_t workspace_bytes, void* stream);
+/* The paired backward in two calls: phase 1 bins both ROI sets (reads the rois, writes the workspace and zero-fills
+ * the tiles of grad_inputs no ROI touches: the gradient tensors must exist, no gradient value is needed -- it can run
+ * on another stream beside the poolers' forward; grad_outputN: any pointers of the later ones' alignment class); phase 2,
+ * same arguments and workspace, is the tile gather alone.  D2AMD_EUNSUPPORTED as for the one-call entry. */
+int d2amd_roi_pooler_backward_pair_phase(const d2amd_pooler_params* p1, const void* grad_output1, const float* rois1,
+                                         int K1, const d2amd_pooler_params* p2, const void* grad_output2,
+                                         const float* rois2, int K2, void* const* grad_inputs, void* workspace,
+                                         size_t workspace_bytes, int phase, void* stream);
 /* The backward in two calls: phase 1 bins the ROIs (per-ROI records, per-tile ROI lists, work queues: reads `rois`
  * only, writes the workspace only -- it may run on another stream, long before the gradient exists: beside the
  * pooler's forward); a later call with the same arguments and workspace runs the gather: phase 2 ADDS to grad_inputs

@@ -359,3 +359,46 @@ def test_three_chained_poolers_pair_the_first_two_and_add_the_third():
                                   for bl, o, g in ((boxes1, 7, gs[0]), (boxes2, 14, gs[1]), (boxes3, 14, gs[2]))])]
     for x, w in zip(xs, want):
         assert rel_err(x.grad.float().cpu().numpy(), w) < 2.0 ** -6
+
+
+def test_backward_plan_bins_ahead_on_another_stream_and_gives_the_same_bits():
+    """PairBackwardPlan: the binning issued beside the forward (here: on a side stream, before the backward exists), the
+    backward = the gather alone; a plan prepared for OTHER rois, or never prepared, is ignored."""
+    from detectron2_amd.modeling import PairBackwardPlan, pool_pair_rois
+
+    feats, boxes1, g1, boxes2, g2 = _case("independent", torch.bfloat16)
+    pa, pb = ROIPooler(7, SCALES, 0, "ROIAlignV2"), ROIPooler(14, SCALES, 0, "ROIAlignV2")
+    r1, r2 = _rois(boxes1), _rois(boxes2)
+    _, want = _run("pair", feats, boxes1, g1, boxes2, g2, torch.bfloat16)
+
+    def run(prepare):
+        xs = [_nhwc(f, torch.bfloat16).requires_grad_(True) for f in feats]
+        plan = PairBackwardPlan()
+        ya, yb = pool_pair_rois(pa, pb, xs, r1, r2, plan=plan)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            prepared = prepare(plan, xs)
+        names = b"pool_bwd_pair"
+        _C.lib().d2amd_timing_select(names)
+        try:
+            torch.autograd.backward([ya, yb], [g1, g2])
+            torch.cuda.synchronize()
+            tot, c = ctypes.c_double(0.0), ctypes.c_int(0)
+            _C.check(_C.lib().d2amd_timing_read(names, ctypes.byref(tot), ctypes.byref(c)))
+        finally:
+            _C.lib().d2amd_timing_select(None)
+        assert c.value == 1
+        assert all(torch.equal(x.grad, w) for x, w in zip(xs, want))
+        return prepared, plan
+
+    prepared, plan = run(lambda plan, xs: plan.prepare(pa, pb, xs, r1, r2))
+    assert prepared is True and plan.ready is None  # consumed by the backward
+    run(lambda plan, xs: None)                                                   # never prepared
+    other = r2.clone()
+    prepared, plan = run(lambda plan, xs: plan.prepare(pa, pb, xs, r1, other))   # prepared for another tensor: ignored
+    assert prepared is True
+    # fp32 features: declined (the plain backward runs)
+    xs32 = [_nhwc(f, torch.float32) for f in feats]
+    assert PairBackwardPlan().prepare(pa, pb, xs32, r1, r2) is False
+    P._ALIASES.clear()
