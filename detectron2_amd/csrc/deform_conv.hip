@@ -654,11 +654,16 @@ static DcnSide* dcn_side(hipStream_t caller) {
     if (slots[i].dev == dev && slots[i].caller == caller) return &slots[i].side;
   if (nslots == 32) return nullptr;  // (more caller streams than anyone uses: those calls stay on one stream)
   DcnSide t{};
-  {  // LOW priority: the side work fills what the data-gradient kernel leaves idle instead of competing with it
-    int lo = 0, hi = 0;
-    static const bool flat = getenv("D2AMD_DCN_SIDE_FLAT") != nullptr;  // A/B: default priority
-    if (flat || hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = 0;
-    if (hipStreamCreateWithPriority(&t.stream, hipStreamNonBlocking, lo) != hipSuccess) return nullptr;
+  {
+    // Priority of the side stream (D2AMD_DCN_SIDE_PRIO = low | flat | high).  A LOW-priority stream looked right -- the side
+    // work fills what the data-gradient kernel leaves idle -- and measures the same as the default in a process that runs
+    // nothing else (dcn_r50 3.28-3.30 ms); in a process with other streams alive (the bench's in-line extra workloads
+    // behind the Mask R-CNN step) it made the same step 8.5-8.6 ms, against 3.78 on one stream and 3.88 with the default
+    // priority (profiles/r04/LOG.md).
+    int lo = 0, hi = 0, prio = 0;
+    static const char* mode = getenv("D2AMD_DCN_SIDE_PRIO");
+    if (mode && mode[0] != 'f' && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess) prio = mode[0] == 'l' ? lo : hi;
+    if (hipStreamCreateWithPriority(&t.stream, hipStreamNonBlocking, prio) != hipSuccess) return nullptr;
   }
   if (hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
   if (hipEventCreateWithFlags(&t.bin, hipEventDisableTiming) != hipSuccess) return nullptr;
