@@ -48,15 +48,8 @@ import subprocess
 import sys
 import time
 
-# HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), least-used first: in a process that has created a
-# few dozen streams (this one: the step's branches, the NMS pipelines, graph captures) a new side stream can land on its
-# caller's queue, and the two then run one after the other.  8 queues: no effect on the headline (0.3569 / 0.3617 against
-# 0.3594 / 0.3592), the in-line dcn_r50 3.88 -> 3.53 ms (profiles/r04/LOG.md).  Set before the runtime starts; a caller's
-# own setting wins.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
+import numpy as np
+import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

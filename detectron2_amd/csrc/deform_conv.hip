@@ -639,8 +639,44 @@ static int fwd_host(const DcnShape& s, const void* x, const void* offset, const 
   return D2AMD_OK;
 }
 
+// ---- does a candidate side stream run BESIDE its caller's stream?  HIP maps streams onto a few hardware queues (4 by
+// default, least-used first): in a process that has created dozens of streams a new one can land on its caller's queue,
+// and the "second stream" of the backward then runs behind the first (dcn_r50 in the bench's in-line run: 3.88 ms
+// against 3.28).  The probe: a kernel on the caller's stream waits -- at most 200 us -- for a flag that a kernel on the
+// candidate sets; it sees the flag only if the two were on the device together.
+__global__ void dcn_probe_wait_kernel(int* flag, unsigned long long max_ticks, int* saw) {
+  const unsigned long long t0 = wall_clock64();
+  int v = 0;
+  while ((v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0 && wall_clock64() - t0 < max_ticks)
+    __builtin_amdgcn_s_sleep(16);
+  *saw = v;
+}
+__global__ void dcn_probe_set_kernel(int* flag) { __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// 1: overlaps, 0: runs behind the caller's stream, -1: could not tell (a capture in progress, an error)
+static int dcn_stream_runs_beside(hipStream_t caller, hipStream_t cand) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(caller, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  int* d = nullptr;
+  if (hipMalloc(&d, 2 * sizeof(int)) != hipSuccess) return -1;
+  int res = -1, h[2] = {0, 0};
+  if (hipMemsetAsync(d, 0, 2 * sizeof(int), caller) == hipSuccess && hipStreamSynchronize(caller) == hipSuccess) {
+    hipLaunchKernelGGL(dcn_probe_wait_kernel, dim3(1), dim3(1), 0, caller, d, 20000ull /* x 10 ns */, d + 1);
+    hipLaunchKernelGGL(dcn_probe_set_kernel, dim3(1), dim3(1), 0, cand, d);
+    if (hipStreamSynchronize(caller) == hipSuccess && hipStreamSynchronize(cand) == hipSuccess &&
+        hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess)
+      res = h[1] ? 1 : 0;
+  }
+  (void)hipFree(d);
+  return res;
+}
+
 // the second stream of a backward call (DcnSide): one per (device, caller's stream), created on first use -- two host
 // threads running backward passes on different streams of one device must not share events.  D2AMD_DCN_NO_SIDE: none.
+// First use outside a graph capture costs a few hundred microseconds and two synchronisations of the caller's stream
+// (the probe above, over up to 4 candidate streams); D2AMD_DCN_NO_PROBE: the first candidate, unprobed.
 static DcnSide* dcn_side(hipStream_t caller) {
   struct Slot { int dev; hipStream_t caller; DcnSide side; };
   static Slot slots[32];
@@ -663,7 +699,20 @@ static DcnSide* dcn_side(hipStream_t caller) {
     int lo = 0, hi = 0, prio = 0;
     static const char* mode = getenv("D2AMD_DCN_SIDE_PRIO");
     if (mode && mode[0] != 'f' && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess) prio = mode[0] == 'l' ? lo : hi;
-    if (hipStreamCreateWithPriority(&t.stream, hipStreamNonBlocking, prio) != hipSuccess) return nullptr;
+    static const bool no_probe = getenv("D2AMD_DCN_NO_PROBE") != nullptr;
+    hipStream_t cand[4] = {nullptr, nullptr, nullptr, nullptr};
+    int ncand = 0, pick = 0;
+    for (; ncand < (no_probe ? 1 : 4); ncand++) {
+      if (hipStreamCreateWithPriority(&cand[ncand], hipStreamNonBlocking, prio) != hipSuccess) break;
+      if (no_probe) { ncand++; break; }
+      const int r = dcn_stream_runs_beside(caller, cand[ncand]);
+      if (r != 0) { pick = ncand; ncand++; break; }  // beside the caller (or unknown: nothing better to go by)
+    }
+    if (ncand == 0) return nullptr;
+    if (pick >= ncand) pick = 0;
+    t.stream = cand[pick];
+    for (int i = 0; i < ncand; i++)
+      if (i != pick) (void)hipStreamDestroy(cand[i]);
   }
   if (hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
   if (hipEventCreateWithFlags(&t.bin, hipEventDisableTiming) != hipSuccess) return nullptr;
