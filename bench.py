@@ -1058,7 +1058,9 @@ def bench_maskrcnn(args, ctx):
                    "layout": args.layout, "global_batch": world * w.n_img, "ops_per_step": counts,
                    "step": ("connected: RPN selection + NMS -> label_and_sample_proposals on the NMS's device-side counts -> "
                             "box pooler on the 512 sampled rows / image, mask pooler + targets + masked loss on their "
-                            "first 128 rows; anchor labelling + sampling beside the NMS; no host read inside the step"
+                            "first 128 rows (both poolers as ONE launch per direction: pool_pair_rois / "
+                            "d2amd_roi_pooler_backward_pair); anchor labelling + sampling beside the NMS; no host read inside "
+                            "the step"
                             if w.connected else "disconnected (round 2): fixed ROI lists, the RPN's proposals feed nothing"),
                    "launch": (("ONE HIP graph per step (one hipGraphLaunch, no host sync)" if grads is None else
                                "2 HIP graphs per step (forward | backward, cut for the gradient all-reduce), no host sync")
