@@ -30,6 +30,8 @@ SOURCES = {
     "deform_conv.hip": [],
     "deform_conv_tc.hip": [],
     "dcn_bww_gemm.hip": [],
+    "dcn_gemm.hip": [],
+    "dcn_colpath.hip": [],
     "matcher.hip": ["-ffp-contract=off"],
     "label_sample.hip": ["-ffp-contract=off"],
     "subsample.hip": ["-ffp-contract=off"],

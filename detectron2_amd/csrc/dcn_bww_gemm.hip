@@ -10,8 +10,8 @@
 // promoted from scratch to saved activation -- and the weight gradient is pure matrix work: 9.9 GFLOP per block,
 // HBM-bound at ~86 MB (the column once + dY).
 //
-// Layouts.  col: [chunk q = tap * (C / 32) + ci / 32][position p][32 channels]  (what dcn_fwd_tc_kernel's gather waves
-// write: a stage's tile of a workgroup is one contiguous block).  dY: NHWC [p][Co].  BOTH operands have the reduction
+// Layouts.  col: [position p][tap * C + ci] (what dcn_col_kernel / dcn_fwd_tc_kernel write; r04 kept it in 32-channel
+// chunks [q][p][32], r05 made it the row-major operand of the forward GEMM).  dY: NHWC [p][Co].  BOTH operands have the reduction
 // index (p) as their ROW index, i.e. they are K-major where v_mfma_f32_32x32x16 wants 8 consecutive k per lane: the
 // tiles are staged row-major in LDS by straight 16-B copies and the fragments are read with ds_read_b64_tr_b16, the
 // gfx950 4x4 transpose read (lane mapping: scripts/probes/probe_tr16.hip, used the same way by pool_bwd_mfma_kernel).
@@ -21,7 +21,7 @@
 // accumulator VGPRs); K step 32 positions, LDS double-buffered, next step's global loads in flight under the MFMAs.
 // Split-K partial tiles are written with plain stores and summed IN SPLIT ORDER by bww_gemm_reduce_kernel (no atomics:
 // dW is deterministic), which also converts to the caller's [Co][C][kh][kw] layout.
-#include "dcn_common.h"
+#include "dcn_gemm.h"
 
 namespace d2amd {
 
@@ -34,7 +34,7 @@ constexpr int G_PITCH = 320;  // bytes per k row of a staged tile (256 B of data
 
 struct BwwGemmArgs {
   const void* dy;   // [P][Co]
-  const void* col;  // [Q][P][32]
+  const void* col;  // [P][Q * 32]
   float* part;      // [ksplit][n_mt][n_nt][128][128]
   int P, Co, Q, n_mt, n_nt, ksplit, kchunk, total;
 };
@@ -79,14 +79,7 @@ __global__ __launch_bounds__(256, 2) void dcn_bww_gemm_kernel(BwwGemmArgs a) {
   const int a_row[2] = {tid >> 4, (tid >> 4) + 16};            // 16 threads x 16 B = one 256-B row of 128 channels
   const int a_c16 = tid & 15;
   const bool a_ok = mt * GM + a_c16 * 8 < a.Co;                // (Co % 8 == 0: a 16-B group is in or out as a whole)
-  int b_chunk[2], b_row[2];
-  const int b_q = tid & 3;
-#pragma unroll
-  for (int j = 0; j < 2; j++) {
-    const int idx = tid + 256 * j;
-    b_chunk[j] = idx >> 7;
-    b_row[j] = (idx & 127) >> 2;
-  }
+  // (B like A: 16 threads x 16 B = one 256-B piece of a column row, 128 of its (tap, ci) entries)
   const int q0 = nt * 4;
   g_raw16 ra[2], rb[2];
   auto issue = [&](int step) __attribute__((always_inline)) {
@@ -96,16 +89,15 @@ __global__ __launch_bounds__(256, 2) void dcn_bww_gemm_kernel(BwwGemmArgs a) {
       const int p = kb + a_row[j];
       g_raw16 z = {0u, 0u, 0u, 0u};
       ra[j] = (a_ok && p < k1) ? *reinterpret_cast<const g_raw16*>(dy + ((size_t)p * a.Co + mt * GM + a_c16 * 8) * sizeof(T)) : z;
-      const int q = q0 + b_chunk[j];
-      const int pb = kb + b_row[j];
-      rb[j] = (q < a.Q && pb < k1) ? *reinterpret_cast<const g_raw16*>(col + (((size_t)q * a.P + pb) * 32 + b_q * 8) * sizeof(T)) : z;
+      const int q = q0 + (a_c16 >> 2);
+      rb[j] = (q < a.Q && p < k1) ? *reinterpret_cast<const g_raw16*>(col + (((size_t)p * a.Q + q0) * 32 + a_c16 * 8) * sizeof(T)) : z;
     }
   };
   auto stage = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < 2; j++) {
       *reinterpret_cast<g_raw16*>(&As[buf][a_row[j] * G_PITCH + a_c16 * 16]) = ra[j];
-      *reinterpret_cast<g_raw16*>(&Bs[buf][b_row[j] * G_PITCH + b_chunk[j] * 64 + b_q * 16]) = rb[j];
+      *reinterpret_cast<g_raw16*>(&Bs[buf][a_row[j] * G_PITCH + a_c16 * 16]) = rb[j];
     }
   };
   f32x16_t acc[2][2];
@@ -173,14 +165,16 @@ __global__ __launch_bounds__(256) void bww_gemm_reduce_kernel(const float* __res
   }
 }
 
-BwwGemmPlan dcn_bww_gemm_plan(const DcnShape& s, int dtype) {
+BwwGemmPlan dcn_bww_gemm_plan(const DcnShape& s, int dtype, bool nhwc) {
   BwwGemmPlan pl{};
   pl.ok = false;
   if (getenv("D2AMD_DCN_NO_SAVED_COL")) return pl;  // A/B switch: the re-gathering weight-gradient kernels
   if (dtype != D2AMD_BF16 && dtype != D2AMD_F16) return pl;
   if (s.G != 1 || s.DG != 1 || s.C % 64 != 0 || s.Co % 8 != 0 || s.P <= 0) return pl;
-  const TcPlan f = dcn_tc_plan_fwd(s, dtype);
-  if (!f.ok || f.NKS != 2 || f.wave) return pl;  // the forward kernel that writes the column in 32-channel chunks
+  if (!(nhwc && dcn_colpath_plan(s, dtype).ok)) {  // who writes the column: dcn_col_kernel, or the fused forward kernel
+    const TcPlan f = dcn_tc_plan_fwd(s, dtype);
+    if (!f.ok || f.NKS != 2 || f.wave) return pl;
+  }
   pl.Q = s.K2 * (s.C / 32);
   pl.n_mt = cdiv(s.Co, GM);
   pl.n_nt = cdiv(pl.Q, 4);

@@ -61,6 +61,42 @@ template <> struct Mma<float> {
 // ((r & 3) + 8 * (r >> 2) + 4 * (l >> 5), l & 31)
 __device__ __forceinline__ int frag_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
+// ---- 8 x 16-bit elements as one 16-B register quad -----------------------------------------------
+typedef unsigned int raw16 __attribute__((ext_vector_type(4)));
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+
+__device__ __forceinline__ void tc_unpack(const raw16& r, float (&f)[8], bf16_t) {
+  f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
+  f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
+  f[4] = __uint_as_float(r.z << 16); f[5] = __uint_as_float(r.z & 0xffff0000u);
+  f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
+}
+__device__ __forceinline__ void tc_unpack(const raw16& r, float (&f)[8], f16_t) {
+  const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    f[2 * i] = to_f32(f16_t{(uint16_t)(w[i] & 0xffffu)});
+    f[2 * i + 1] = to_f32(f16_t{(uint16_t)(w[i] >> 16)});
+  }
+}
+__device__ __forceinline__ raw16 tc_pack(const float (&f)[8], bf16_t) {
+  raw16 r;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN preserved
+    const f32x2_t v = {f[2 * i], f[2 * i + 1]};
+    r[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+  }
+  return r;
+}
+__device__ __forceinline__ raw16 tc_pack(const float (&f)[8], f16_t) {
+  raw16 r;
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+    r[i] = (uint32_t)from_f32<f16_t>(f[2 * i]).v | ((uint32_t)from_f32<f16_t>(f[2 * i + 1]).v << 16);
+  return r;
+}
+
 // ---- layout kernels ---------------------------------------------------------------------------
 // [B][R][S] -> [B][S][R] (32x32 LDS tiles): NCHW <-> NHWC with R = C, S = H*W.
 template <typename TI, typename TO>
@@ -105,10 +141,10 @@ int dcn_tc_forward(const DcnShape& s, const TcPlan& pl, const void* x_nhwc, cons
 // weight gradient from the column the forward saved (dcn_bww_gemm.hip): dense split-K GEMM
 struct BwwGemmPlan {
   bool ok;
-  int Q, n_mt, n_nt, ksplit, kchunk;   // Q = K2 * C / 32 column chunks; 128 x 128 output tiles; K range per workgroup
+  int Q, n_mt, n_nt, ksplit, kchunk;   // Q = K2 * C / 32 (the column is [P][Q * 32]); 128 x 128 output tiles; K range per workgroup
   size_t col_bytes, partial_bytes;
 };
-BwwGemmPlan dcn_bww_gemm_plan(const DcnShape& s, int dtype);
+BwwGemmPlan dcn_bww_gemm_plan(const DcnShape& s, int dtype, bool nhwc);
 template <typename T>
 int dcn_bww_gemm(const DcnShape& s, const BwwGemmPlan& pl, const void* dy_nhwc, const void* col, float* partials,
                  void* grad_weight, hipStream_t st);
@@ -150,7 +186,8 @@ template <typename T>
 int dcn_tc_backward_data_gather(const DcnShape& s, const TcBwPlan& pl, const void* x_nhwc, const void* offset,
                                 const void* mask, const void* weight, const void* gout_nhwc, void* gx_t, float* goff,
                                 float* gmask, void* wp, const DcnGatherWs& gw, hipStream_t st,
-                                const DcnSide* side = nullptr);
+                                const DcnSide* side = nullptr, const struct ColPathPlan* cp = nullptr, void* goff_t = nullptr,
+                                void* gmask_t = nullptr, const void* wt_kept = nullptr);
 
 struct TcBwwPlan {
   bool ok;

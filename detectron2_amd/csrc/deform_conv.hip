@@ -19,7 +19,7 @@
 // exactly like the reference's column buffer.
 #include <mutex>
 
-#include "dcn_common.h"
+#include "dcn_gemm.h"
 
 namespace d2amd {
 
@@ -521,12 +521,17 @@ struct DcnWs {
   float* tc_partial;  // fp32 partial outputs when its reduction is split
   TcPlan tc;
   void* col_saved;    // the column the training forward saved / the backward is handed (d2amd_deform_conv_*_saved)
+  ColPathPlan cp;     // channels_last 16-bit: column + dense GEMM (dcn_colpath.hip); cp.ok false: the fused kernels
+  void* cp_col;       // forward: scratch column when the caller keeps none
+  void* cp_wpack;     // packed weights of the GEMM
   size_t total;
 };
 
-static DcnWs carve_ws(const DcnShape& s, int dtype, bool backward, void* base) {
+static DcnWs carve_ws(const DcnShape& s, int dtype, bool backward, bool nhwc, void* base) {
   DcnWs w{};
   w.dtype = dtype;
+  w.nhwc = nhwc;
+  if (nhwc) w.cp = dcn_colpath_plan(s, dtype);
   const size_t es = dtype_size(dtype);
   size_t off = 0;
   auto take = [&](size_t bytes) { void* r = base ? (char*)base + off : nullptr; off += al(bytes); return r; };
@@ -534,7 +539,10 @@ static DcnWs carve_ws(const DcnShape& s, int dtype, bool backward, void* base) {
   const size_t wbytes = (size_t)s.Co * s.Cg * s.K2 * es;
   if (!backward) {
     w.tc = dcn_tc_plan_fwd(s, dtype);
-    if (w.tc.ok) {
+    if (w.cp.ok) {
+      w.cp_wpack = take(w.cp.wpack_bytes);
+      w.cp_col = take(w.cp.col_bytes);
+    } else if (w.tc.ok) {
       w.tc_wp = take(w.tc.wp_bytes);
       w.tc_partial = (float*)take(w.tc.partial_bytes);
     } else {
@@ -552,7 +560,7 @@ static DcnWs carve_ws(const DcnShape& s, int dtype, bool backward, void* base) {
     if (w.use_gather) w.gather.cnt = (int*)take(dcn_gather_cnt_bytes(s));
     {  // fp32 staging of the weight gradient: [g][tap][co][ci] (generic kernels: atomics), or the MFMA kernel's partial tiles
       const TcBwwPlan wp = dcn_tc_plan_bww(s, dtype);
-      const BwwGemmPlan gp = dcn_bww_gemm_plan(s, dtype);  // (the saved-column GEMM's split-K partial tiles)
+      const BwwGemmPlan gp = dcn_bww_gemm_plan(s, dtype, nhwc);  // (the saved-column GEMM's split-K partial tiles)
       size_t stage = (size_t)s.Co * s.Cg * s.K2 * 4;
       if (wp.ok && wp.partial_bytes > stage) stage = wp.partial_bytes;
       if (gp.ok && gp.partial_bytes > stage) stage = gp.partial_bytes;
@@ -610,6 +618,9 @@ static int fwd_host(const DcnShape& s, const void* x, const void* offset, const 
   if (s.B == 0) return D2AMD_OK;
   if (w.nhwc) {  // a channels_last caller: x is what the kernels read, out is written [position][Co]
     if constexpr (sizeof(T) == 2) {
+      if (w.cp.ok)
+        return dcn_colpath_forward<T>(s, w.cp, x, offset, mask, weight, bias, out, w.col_saved ? w.col_saved : w.cp_col,
+                                      w.cp_wpack, w.col_saved ? (char*)w.col_saved + al(w.cp.col_bytes) : nullptr, st);
       if (w.tc.ok)
         return dcn_tc_forward<T>(s, w.tc, x, offset, mask, weight, bias, out, w.tc_wp, w.tc_partial, st, true, w.col_saved);
     }
@@ -751,12 +762,13 @@ static int bwd_host(const DcnShape& s, const void* x, const void* offset, const 
     } else {
       const TcBwPlan bp = dcn_tc_plan_bwd(s, (int)w.dtype);
       const TcBwwPlan wp = dcn_tc_plan_bww(s, (int)w.dtype);
-      if (!(bp.ok && w.use_gather && wp.ok)) {
+      const bool colpath = w.cp.ok && bp.ok && w.use_gather;
+      if (!colpath && !(bp.ok && w.use_gather && wp.ok)) {
         set_error("deform_conv_backward: NHWC is served by the 16-bit MFMA path only (this shape is not)");
         return D2AMD_EUNSUPPORTED;
       }
       const bool need_data = gin || goffset || (gmask && mask);
-      const BwwGemmPlan gp = dcn_bww_gemm_plan(s, (int)w.dtype);
+      const BwwGemmPlan gp = dcn_bww_gemm_plan(s, (int)w.dtype, true);
       const bool gemm_w = gweight && w.col_saved && gp.ok;  // dW = dY^T col from the column the forward saved
       bool gemm_done = false;
       if (need_data) {
@@ -774,11 +786,18 @@ static int bwd_host(const DcnShape& s, const void* x, const void* offset, const 
           side.ctx = &call;
           side.fork = (side_mode & 1) ? side.fork : nullptr;  // (null: the binning stays on the caller's stream)
         }
-        rc = dcn_tc_backward_data_gather<T>(s, bp, x, offset, mask, weight, gout, gin, goff_f, gmask_f, w.wt, w.gather, st,
-                                            sd ? &side : nullptr);
-        if (rc) return rc;
-        rc = cvt_grads<T>(s, w, goffset, (gmask && mask) ? gmask : nullptr, st);
-        if (rc) return rc;
+        if (colpath) {  // (d offset / d mask leave the coordinate-gradient kernel in the I/O dtype: no fp32 staging, no convert)
+          rc = dcn_tc_backward_data_gather<T>(s, bp, x, offset, mask, weight, gout, gin, nullptr, nullptr, w.wt, w.gather, st,
+                                              sd ? &side : nullptr, &w.cp, goffset, (gmask && mask) ? gmask : nullptr,
+                                              w.col_saved ? (const char*)w.col_saved + al(w.cp.col_bytes) : nullptr);
+          if (rc) return rc;
+        } else {
+          rc = dcn_tc_backward_data_gather<T>(s, bp, x, offset, mask, weight, gout, gin, goff_f, gmask_f, w.wt, w.gather, st,
+                                              sd ? &side : nullptr);
+          if (rc) return rc;
+          rc = cvt_grads<T>(s, w, goffset, (gmask && mask) ? gmask : nullptr, st);
+          if (rc) return rc;
+        }
         if (sd) {
           D2_HIP_OK(hipStreamWaitEvent(st, side.join, 0));
           gemm_done = side.work != nullptr;
@@ -860,7 +879,7 @@ static int bwd_host(const DcnShape& s, const void* x, const void* offset, const 
   if (gweight) {
     bool tc_w = false;
     if constexpr (!is32) {
-      const BwwGemmPlan gp = dcn_bww_gemm_plan(s, (int)w.dtype);
+      const BwwGemmPlan gp = dcn_bww_gemm_plan(s, (int)w.dtype, false);
       if (w.col_saved && gp.ok) {  // dW = dY^T col from the column the forward saved (dY as [P][Co])
         if (!need_data) {
           rc = launch_transpose<T, T>((const T*)gout, (T*)w.gout_nhwc, s.B, s.Co, s.L, st);
@@ -920,7 +939,7 @@ using namespace d2amd;
 extern "C" size_t d2amd_deform_conv_workspace_bytes(const d2amd_dcn_params* p, int backward) {
   DcnShape s;
   if (check_params(p, s, "deform_conv_workspace_bytes")) return 0;
-  return carve_ws(s, p->dtype, backward != 0, nullptr).total + 256;
+  return carve_ws(s, p->dtype, backward != 0, p->layout == D2AMD_NHWC, nullptr).total + 256;
 }
 
 static int dcn_forward_impl(const d2amd_dcn_params* p, const void* x, const void* offset, const void* mask,
@@ -931,10 +950,9 @@ static int dcn_forward_impl(const d2amd_dcn_params* p, const void* x, const void
   if (rc) return rc;
   if (s.B == 0) return D2AMD_OK;
   D2_CHECK_ARG(x && offset && weight && out && workspace, "deform_conv_forward: null pointer");
-  DcnWs w = carve_ws(s, p->dtype, false, workspace);
-  w.col_saved = columns;
   D2_CHECK_ARG(p->layout == D2AMD_NCHW || p->layout == D2AMD_NHWC, "deform_conv_forward: bad layout %d", p->layout);
-  w.nhwc = p->layout == D2AMD_NHWC;
+  DcnWs w = carve_ws(s, p->dtype, false, p->layout == D2AMD_NHWC, workspace);
+  w.col_saved = columns;
   if (workspace_bytes < w.total) {
     set_error("deform_conv_forward: workspace too small (%zu < %zu)", workspace_bytes, w.total);
     return D2AMD_EWORKSPACE;
@@ -954,8 +972,11 @@ extern "C" size_t d2amd_deform_conv_columns_bytes(const d2amd_dcn_params* p) {
   DcnShape s;
   if (check_params(p, s, "deform_conv_columns_bytes")) return 0;
   if (s.B == 0) return 0;
-  const BwwGemmPlan gp = dcn_bww_gemm_plan(s, p->dtype);
-  return gp.ok ? gp.col_bytes : 0;
+  const BwwGemmPlan gp = dcn_bww_gemm_plan(s, p->dtype, p->layout == D2AMD_NHWC);
+  if (!gp.ok) return 0;
+  // (the GEMM path also leaves the backward's packed weights behind the column: one pack launch per block and iteration)
+  const ColPathPlan cp = p->layout == D2AMD_NHWC ? dcn_colpath_plan(s, p->dtype) : ColPathPlan{};
+  return cp.ok ? al(gp.col_bytes) + cp.wpack_bytes : gp.col_bytes;
 }
 
 extern "C" int d2amd_deform_conv_forward_columns(const d2amd_dcn_params* p, const void* x, const void* offset,
@@ -975,10 +996,9 @@ static int dcn_backward_impl(const d2amd_dcn_params* p, const void* x, const voi
   int rc = check_params(p, s, "deform_conv_backward");
   if (rc) return rc;
   D2_CHECK_ARG(s.B == 0 || (x && offset && weight && grad_out && workspace), "deform_conv_backward: null pointer");
-  DcnWs w = carve_ws(s, p->dtype, true, workspace);
-  w.col_saved = const_cast<void*>(columns);
   D2_CHECK_ARG(p->layout == D2AMD_NCHW || p->layout == D2AMD_NHWC, "deform_conv_backward: bad layout %d", p->layout);
-  w.nhwc = p->layout == D2AMD_NHWC;
+  DcnWs w = carve_ws(s, p->dtype, true, p->layout == D2AMD_NHWC, workspace);
+  w.col_saved = const_cast<void*>(columns);
   if (s.B > 0 && workspace_bytes < w.total) {
     set_error("deform_conv_backward: workspace too small (%zu < %zu)", workspace_bytes, w.total);
     return D2AMD_EWORKSPACE;

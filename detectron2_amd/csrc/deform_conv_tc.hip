@@ -22,15 +22,11 @@
 //   * small feature maps (res5: 2,100 positions) do not fill 256 CUs with output tiles alone:
 //     the (tap, channel) reduction is split over `ksplit` workgroups writing fp32 partials that a
 //     tiny deterministic kernel sums (+ bias, -> 16 bit).
-#include "dcn_common.h"
+#include "dcn_gemm.h"
 
 #include <stdlib.h>
 
 namespace d2amd {
-
-typedef unsigned int raw16 __attribute__((ext_vector_type(4)));
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 
 struct TcEntry {
   uint32_t off[4];  // byte offset of the corner pixel's channel 0 in x (NHWC); 0 when unused
@@ -47,8 +43,7 @@ struct TcArgs {
   int out_nhwc;  // 1: out (and the fp32 partials) are [position][Co] (a channels_last caller) instead of [b][Co][l]
   unsigned long long* stamps;  // profiling only (D2AMD_DCN_STAMPS): per workgroup {start, after tables, after loop, end} (100 MHz)
   void* col_out;  // training forward: the gathered column (mask folded in, I/O dtype) is ALSO stored, for the weight
-                  // gradient's GEMM -- [tap][channel chunk of 16 NKS][position][16 NKS channels] (a stage's tile of a
-                  // workgroup is one contiguous block); written by the workgroups of output-channel tile 0 only
+                  // gradient's GEMM -- [position][tap * C + channel]; written by the workgroups of output-channel tile 0 only
 };
 
 // Column buffer: per 32-position tile, 2*NKS "subs" (kstep, k-half) of 32 consecutive 16-B slots each, at a
@@ -60,37 +55,6 @@ template <int NKS> struct TcB {
   static constexpr int TILE = 2 * NKS * PS;  // 16-B slots per 32-position tile
   __device__ static __forceinline__ int slot(int ntile, int sub, int n32) { return ntile * TILE + sub * PS + n32; }
 };
-
-__device__ __forceinline__ void tc_unpack(const raw16& r, float (&f)[8], bf16_t) {
-  f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
-  f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
-  f[4] = __uint_as_float(r.z << 16); f[5] = __uint_as_float(r.z & 0xffff0000u);
-  f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
-}
-__device__ __forceinline__ void tc_unpack(const raw16& r, float (&f)[8], f16_t) {
-  const uint32_t w[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    f[2 * i] = to_f32(f16_t{(uint16_t)(w[i] & 0xffffu)});
-    f[2 * i + 1] = to_f32(f16_t{(uint16_t)(w[i] >> 16)});
-  }
-}
-__device__ __forceinline__ raw16 tc_pack(const float (&f)[8], bf16_t) {
-  raw16 r;
-#pragma unroll
-  for (int i = 0; i < 4; i++) {  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN preserved
-    const f32x2_t v = {f[2 * i], f[2 * i + 1]};
-    r[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
-  }
-  return r;
-}
-__device__ __forceinline__ raw16 tc_pack(const float (&f)[8], f16_t) {
-  raw16 r;
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-    r[i] = (uint32_t)from_f32<f16_t>(f[2 * i]).v | ((uint32_t)from_f32<f16_t>(f[2 * i + 1]).v << 16);
-  return r;
-}
 
 // bilinear table entry of (position p, tap, deformable group), as deform_conv_cuda_kernel.cu:96-130,
 // 216-270 (v1) / 665-700, 785-860 (v2): sample inside (-1, H) x (-1, W), corners outside contribute 0
@@ -267,10 +231,10 @@ void dcn_fwd_tc_kernel(DcnShape s, TcArgs a) {
         }
         const raw16 packed = tc_pack(v, T{});
         Bb[BL::slot(n >> 5, sub, n & 31)] = packed;
-        // (uniform pointer test and uniform base; the lane's offset is its item index: (n CHUNK + 8 sub) elements = 16 i
-        // bytes -- 64 lanes store 1 KB contiguous)
+        // (row-major column [position][tap * C + channel], the layout of the GEMM path -- dcn_colpath.hip; a position's
+        // NSUB lanes store CHUNK * 2 consecutive bytes)
         if (col_dst && p0 + n < s.P)
-          *reinterpret_cast<raw16*>(col_dst + ((size_t)cst * s.P + (size_t)p0) * (CHUNK * sizeof(T)) + (size_t)i * 16) = packed;
+          *reinterpret_cast<raw16*>(col_dst + (((size_t)(p0 + n) * s.K2 * s.C + (size_t)cst * CHUNK) * sizeof(T)) + (size_t)sub * 16) = packed;
       }
     };
     // the gathers run TWO stages ahead of the matrix waves (register double buffer), so the L2
@@ -1799,8 +1763,8 @@ TcBwPlan dcn_tc_plan_bwd(const DcnShape& s, int dtype) {
 //   (b) dcn_bwd_data_tc_kernel with `dcol`: the same MFMA stages write the dcol tile as 16-bit rows
 //       col[position][tap][C] (the column buffer of the reference's design, but 16-bit, backward only, and never read
 //       by a GEMM) and still produce d(offset) / d(mask); phase B (the atomics) is gone;
-//   (c) dcn_gather_dx_kernel: one wave per input pixel sorts its list by sample id (fixed summation order:
-//       deterministic) and accumulates  dX[pixel, :] = sum_e w_e * col[sample_e, :]  in fp32 registers, every pixel
+//   (c) dcn_sort_lists_kernel + dcn_gather_dx_kernel: one wave per input pixel sorts its list by sample id (fixed
+//       summation order: deterministic) and accumulates  dX[pixel, :] = sum_e w_e * col[sample_e, :]  in fp32 registers, every pixel
 //       written once in the I/O dtype.  HBM / L2 bound: 36 rows of C x 2 B per pixel on average.
 // Pixels that collect more than DG_CAP entries (adversarial offsets) park the excess in an overflow array that the
 // gather scans when it is non-empty.  deformable_groups == 1 (R50's DCN); other shapes keep the kernel above.
@@ -1850,27 +1814,31 @@ __global__ __launch_bounds__(256) void dcn_bin_samples_kernel(DcnShape s, const 
   }
 }
 
-// RL = lanes per column row = C / 8: every lane loads 16 B (8 channels), a wave instruction covers 64 / RL list entries
-// (C = 128: four rows of 256 B per load; 4-byte loads per lane ran at 2.6 TB/s, r02 profile).  Lane group g = lane / RL
-// takes entries g, g + EPW, ...; the groups' partial sums are added in a fixed order at the end.
-template <typename T, int RL>
-__global__ __launch_bounds__(256) void dcn_gather_dx_kernel(int npix, int C, const int* __restrict__ cnt,
-                                                           const DgEntry* __restrict__ lists,
-                                                           const int* __restrict__ ovf_cnt,
-                                                           const DgOverflow* __restrict__ ovf,
-                                                           const T* __restrict__ col, T* __restrict__ gx) {
-  constexpr int EPW = 64 / RL;  // entries per wave instruction
+// One wave per input pixel sorts its list by sample id, in place: the gather below then adds a pixel's contributions in
+// a fixed order whatever order the binning's atomics handed the slots out in (deterministic dX).  r05: a launch of its own
+// behind the binning -- on the side stream when there is one -- instead of the first 60 % of the gather kernel's
+// instructions on the critical path.  Lane i holds elements i and i + 64 of the <= 128 (sample, weight) pairs.
+__global__ __launch_bounds__(256) void dcn_sort_lists_kernel(int npix, const int* __restrict__ cnt, DgEntry* __restrict__ lists) {
   const int lane = threadIdx.x & 63;
   const long pix = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (pix >= npix) return;  // uniform per wave
   const int n = min(cnt[pix], DG_CAP);
-  // two entries per lane; sort the <= 128 (sample, weight) pairs by sample id: lane i holds elements i and i + 64
-  const DgEntry* lp = lists + pix * DG_CAP;
+  if (n < 2) return;
+  DgEntry* lp = lists + pix * DG_CAP;
   uint32_t k0 = 0xffffffffu, k1 = 0xffffffffu;
   float w0 = 0.f, w1 = 0.f;
   if (lane < n) { const DgEntry e = lp[lane]; k0 = e.sample; w0 = e.w; }
   if (lane + 64 < n) { const DgEntry e = lp[lane + 64]; k1 = e.sample; w1 = e.w; }
-  if (n > 1) {  // uniform.  bitonic sort over 128 virtual positions p = lane (k0) / lane + 64 (k1)
+  if (n <= 64) {  // (uniform) bitonic sort over the 64 lanes
+    for (int kk = 2; kk <= 64; kk <<= 1) {
+      for (int j = kk >> 1; j > 0; j >>= 1) {
+        const uint32_t pk = (uint32_t)__shfl_xor((int)k0, j);
+        const float pw = __shfl_xor(w0, j);
+        const bool take_min = ((lane & j) == 0) == ((lane & kk) == 0);
+        if (take_min ? (pk < k0) : (pk > k0)) { k0 = pk; w0 = pw; }
+      }
+    }
+  } else {  // bitonic sort over 128 virtual positions p = lane (k0) / lane + 64 (k1)
     for (int kk = 2; kk <= 128; kk <<= 1) {
       for (int j = kk >> 1; j > 0; j >>= 1) {
         if (j == 64) {  // partner of position lane is position lane + 64: inside the lane (kk == 128: ascending)
@@ -1880,8 +1848,6 @@ __global__ __launch_bounds__(256) void dcn_gather_dx_kernel(int npix, int C, con
           const float p0w = __shfl_xor(w0, j), p1w = __shfl_xor(w1, j);
           const bool lower = (lane & j) == 0;
           const bool up0 = (lane & kk) == 0, up1 = ((lane + 64) & kk) == 0;  // ascending blocks
-          // an element keeps the smaller key if it is the lower partner of an ascending block (or the upper of a
-          // descending one)
           const bool take_min0 = lower == up0, take_min1 = lower == up1;
           if (take_min0 ? (p0k < k0) : (p0k > k0)) { k0 = p0k; w0 = p0w; }
           if (take_min1 ? (p1k < k1) : (p1k > k1)) { k1 = p1k; w1 = p1w; }
@@ -1889,37 +1855,46 @@ __global__ __launch_bounds__(256) void dcn_gather_dx_kernel(int npix, int C, con
       }
     }
   }
+  if (lane < n) lp[lane] = DgEntry{k0, w0};
+  if (lane + 64 < n) lp[lane + 64] = DgEntry{k1, w1};
+}
+
+// RL = lanes per column row = C / 8: every lane loads 16 B (8 channels), a wave instruction covers EPW = 64 / RL list
+// entries (C = 128: four rows of 256 B per load).  Lane group g = lane / RL takes entries g, g + EPW, ... of the SORTED
+// list -- read straight from memory, one 8-B load per group and entry, UN entries and their rows in flight per group --
+// and the groups' partial sums are added in a fixed order at the end.
+template <typename T, int RL>
+__global__ __launch_bounds__(256) void dcn_gather_dx_kernel(int npix, int C, const int* __restrict__ cnt,
+                                                           const DgEntry* __restrict__ lists,
+                                                           const int* __restrict__ ovf_cnt,
+                                                           const DgOverflow* __restrict__ ovf,
+                                                           const T* __restrict__ col, T* __restrict__ gx) {
+  constexpr int EPW = 64 / RL;  // entries per wave instruction
+  constexpr int UN = 4;         // rows in flight per lane group
+  const int lane = threadIdx.x & 63;
+  const long pix = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pix >= npix) return;  // uniform per wave
+  const int n = min(cnt[pix], DG_CAP);
+  const DgEntry* lp = lists + pix * DG_CAP;
   const int grp = lane / RL, sub = lane - grp * RL;
   float acc[8];
 #pragma unroll
   for (int v = 0; v < 8; v++) acc[v] = 0.f;
   const T* cbase = col + (long)sub * 8;
-  // entry e of the sorted list lives in lane e (k0 / w0) or lane e - 64 (k1 / w1)
-  auto entry = [&](int e, uint32_t& sk, float& sw) __attribute__((always_inline)) {
-    const int src = e & 63;
-    const uint32_t a0 = (uint32_t)__shfl((int)k0, src), a1 = (uint32_t)__shfl((int)k1, src);
-    const float b0 = __shfl(w0, src), b1 = __shfl(w1, src);
-    sk = e < 64 ? a0 : a1;
-    sw = e < 64 ? b0 : b1;
-  };
-  constexpr int UN = 2;  // rows in flight per lane group
   for (int e0 = 0; e0 < n; e0 += EPW * UN) {
+    DgEntry en[UN];
     raw16 q[UN];
-    float wv[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) en[u] = lp[min(e0 + u * EPW + grp, n - 1)];
+#pragma unroll
+    for (int u = 0; u < UN; u++) q[u] = *reinterpret_cast<const raw16*>(cbase + (long)en[u].sample * C);
 #pragma unroll
     for (int u = 0; u < UN; u++) {
-      const int e = e0 + u * EPW + grp;
-      uint32_t sk;
-      entry(min(e, n - 1), sk, wv[u]);
-      if (e >= n) wv[u] = 0.f;
-      q[u] = *reinterpret_cast<const raw16*>(cbase + (long)sk * C);
-    }
-#pragma unroll
-    for (int u = 0; u < UN; u++) {
+      const float wv = (e0 + u * EPW + grp < n) ? en[u].w : 0.f;
       float f[8];
       tc_unpack(q[u], f, T{});
 #pragma unroll
-      for (int v = 0; v < 8; v++) acc[v] += wv[u] * f[v];
+      for (int v = 0; v < 8; v++) acc[v] += wv * f[v];
     }
   }
   const int novf = *ovf_cnt;
@@ -1960,7 +1935,8 @@ __global__ __launch_bounds__(256) void dcn_gather_dx_kernel(int npix, int C, con
 template <typename T>
 int dcn_tc_backward_data_gather(const DcnShape& s, const TcBwPlan& pl, const void* x_nhwc, const void* offset,
                                 const void* mask, const void* weight, const void* gout_nhwc, void* gx_t, float* goff,
-                                float* gmask, void* wp, const DcnGatherWs& gw, hipStream_t st, const DcnSide* side) {
+                                float* gmask, void* wp, const DcnGatherWs& gw, hipStream_t st, const DcnSide* side,
+                                const ColPathPlan* cp, void* goff_t, void* gmask_t, const void* wt_kept) {
   const long npix = (long)s.B * s.H * s.W;
   bool goff_zeroed = false;
   {  // per-call state: pixel counters + the overflow counter (one region) -- and, when the tiles of a pixel are split
@@ -1991,34 +1967,44 @@ int dcn_tc_backward_data_gather(const DcnShape& s, const TcBwPlan& pl, const voi
   hipLaunchKernelGGL((dcn_bin_samples_kernel<T>), dim3(cdiv(nsamp, 256)), dim3(256), 0, bst, s, (const T*)offset,
                      (const T*)mask, gw.cnt, (DgEntry*)gw.lists, ovf_cnt, (DgOverflow*)gw.ovf);
   D2_LAUNCH_OK();
+  if (gx_t) {  // the lists in sample order, for the gather at the end
+    hipLaunchKernelGGL(dcn_sort_lists_kernel, dim3((unsigned)cdiv(npix, 4)), dim3(256), 0, bst, (int)npix, gw.cnt, (DgEntry*)gw.lists);
+    D2_LAUNCH_OK();
+  }
   if (side) {
     D2_HIP_OK(hipEventRecord(side->bin, side->stream));
     if (side->work) { const int wrc = side->work(side->ctx, side->stream); if (wrc) return wrc; }
     D2_HIP_OK(hipEventRecord(side->join, side->stream));
   }
-  {
-    const long groups16 = (long)s.G * s.K2 * (s.Cg / 64) * 2 * (s.Cog / 16) * 64;
-    const int blocks = cdiv(groups16, 256) > 8192 ? 8192 : cdiv(groups16, 256);
-    hipLaunchKernelGGL((tc_pack_weight_t_kernel<T>), dim3(blocks), dim3(256), 0, st, (const T*)weight, (T*)wp, s.G,
-                       s.Cog, s.Cg, s.K2);
+  if (cp) {
+    // r05: dcol = dY Wt^T on the dense GEMM, then d(offset) / d(mask) from dcol and x's corners, written in the I/O dtype
+    const int crc = dcn_colpath_backward_data<T>(s, *cp, x_nhwc, offset, mask, weight, gout_nhwc, gw.col, wp, wt_kept, goff_t, gmask_t, st);
+    if (crc) return crc;
+  } else {
+    {
+      const long groups16 = (long)s.G * s.K2 * (s.Cg / 64) * 2 * (s.Cog / 16) * 64;
+      const int blocks = cdiv(groups16, 256) > 8192 ? 8192 : cdiv(groups16, 256);
+      hipLaunchKernelGGL((tc_pack_weight_t_kernel<T>), dim3(blocks), dim3(256), 0, st, (const T*)weight, (T*)wp, s.G,
+                         s.Cog, s.Cg, s.K2);
+      D2_LAUNCH_OK();
+    }
+    BwArgs a{};
+    a.x = x_nhwc; a.offset = offset; a.mask = mask; a.wp = wp; a.gout = gout_nhwc;
+    a.gx = nullptr; a.goff = goff; a.gmask = gmask; a.dcol = gw.col;
+    { const char* e = getenv("D2AMD_DCN_ABLATE_BWD"); a.ablate = e ? atoi(e) : 0; }
+    a.tiles_y = pl.tiles_y; a.tiles_x = pl.tiles_x; a.csplit = pl.csplit;
+    if (pl.csplit > 1 && !goff_zeroed) {
+      if (goff) { const int zrc = zero_async(goff, (size_t)s.B * s.DG * 2 * s.K2 * s.L * 4, st); if (zrc) return zrc; }
+      if (gmask) { const int zrc = zero_async(gmask, (size_t)s.B * s.DG * s.K2 * s.L * 4, st); if (zrc) return zrc; }
+    }
+    const long total = (long)s.B * pl.tiles_y * pl.tiles_x * s.DG * pl.csplit;
+    D2_CHECK_ARG(total < (1l << 30), "deform_conv: too many tiles");
+    a.total = (int)total;
+    const bool timed = timing_begin("dcn_bwd_data", st);
+    { const int lrc = launch_bwd_data_tc<T>(s, a, (a.total + 7) / 8 * 8, pl.lds, st); if (lrc) return lrc; }
+    if (timed) timing_end("dcn_bwd_data", st);
     D2_LAUNCH_OK();
   }
-  BwArgs a{};
-  a.x = x_nhwc; a.offset = offset; a.mask = mask; a.wp = wp; a.gout = gout_nhwc;
-  a.gx = nullptr; a.goff = goff; a.gmask = gmask; a.dcol = gw.col;
-  { const char* e = getenv("D2AMD_DCN_ABLATE_BWD"); a.ablate = e ? atoi(e) : 0; }
-  a.tiles_y = pl.tiles_y; a.tiles_x = pl.tiles_x; a.csplit = pl.csplit;
-  if (pl.csplit > 1 && !goff_zeroed) {
-    if (goff) { const int zrc = zero_async(goff, (size_t)s.B * s.DG * 2 * s.K2 * s.L * 4, st); if (zrc) return zrc; }
-    if (gmask) { const int zrc = zero_async(gmask, (size_t)s.B * s.DG * s.K2 * s.L * 4, st); if (zrc) return zrc; }
-  }
-  const long total = (long)s.B * pl.tiles_y * pl.tiles_x * s.DG * pl.csplit;
-  D2_CHECK_ARG(total < (1l << 30), "deform_conv: too many tiles");
-  a.total = (int)total;
-  const bool timed = timing_begin("dcn_bwd_data", st);
-  { const int lrc = launch_bwd_data_tc<T>(s, a, (a.total + 7) / 8 * 8, pl.lds, st); if (lrc) return lrc; }
-  if (timed) timing_end("dcn_bwd_data", st);
-  D2_LAUNCH_OK();
   if (side) D2_HIP_OK(hipStreamWaitEvent(st, side->bin, 0));  // (also when nothing gathers: the counters are reused)
   if (gx_t) {
     const bool timed2 = timing_begin("dcn_bwd_gather", st);
@@ -2037,10 +2023,10 @@ int dcn_tc_backward_data_gather(const DcnShape& s, const TcBwPlan& pl, const voi
 }
 template int dcn_tc_backward_data_gather<bf16_t>(const DcnShape&, const TcBwPlan&, const void*, const void*, const void*,
                                                  const void*, const void*, void*, float*, float*, void*,
-                                                 const DcnGatherWs&, hipStream_t, const DcnSide*);
+                                                 const DcnGatherWs&, hipStream_t, const DcnSide*, const ColPathPlan*, void*, void*, const void*);
 template int dcn_tc_backward_data_gather<f16_t>(const DcnShape&, const TcBwPlan&, const void*, const void*, const void*,
                                                 const void*, const void*, void*, float*, float*, void*,
-                                                const DcnGatherWs&, hipStream_t, const DcnSide*);
+                                                const DcnGatherWs&, hipStream_t, const DcnSide*, const ColPathPlan*, void*, void*, const void*);
 
 template <typename T>
 int dcn_tc_backward_data(const DcnShape& s, const TcBwPlan& pl, const void* x_nhwc, const void* offset,

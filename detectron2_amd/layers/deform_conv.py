@@ -171,7 +171,7 @@ class _DeformConv(Function):
 
     @staticmethod
     def forward(ctx, input, offset, weight, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1,
-                im2col_step=64):
+                im2col_step=64, save_columns=None):
         if input is not None and input.dim() != 4:
             raise ValueError("Expected 4D tensor as input, got {}D tensor instead.".format(input.dim()))
         if not input.is_cuda:
@@ -181,8 +181,11 @@ class _DeformConv(Function):
         ctx.stride, ctx.padding, ctx.dilation = ctx.geom[:3]
         ctx.groups, ctx.deformable_groups, ctx.im2col_step = groups, deformable_groups, im2col_step
         ctx.save_for_backward(input, offset, weight)
-        out, ctx.columns = _dcn_forward(input, offset, None, weight, None, *ctx.geom,
-                                        save_columns=bool(ctx.needs_input_grad[2]))
+        # (grad mode is always off inside Function.forward: `deform_conv` below decides outside whether a backward can
+        # follow; a direct .apply caller gets the conservative answer)
+        if save_columns is None:
+            save_columns = bool(ctx.needs_input_grad[2])
+        out, ctx.columns = _dcn_forward(input, offset, None, weight, None, *ctx.geom, save_columns=bool(save_columns))
         return out
 
     @staticmethod
@@ -195,7 +198,7 @@ class _DeformConv(Function):
         gi, goff, _, gw, _ = _dcn_backward(input, offset, None, weight, grad_output, *ctx.geom,
                                            wants[0] or wants[1], wants[2], False, columns=ctx.columns)
         ctx.columns = None
-        return (gi, goff, gw) + (None,) * 6
+        return (gi, goff, gw) + (None,) * 7
 
     _output_size = staticmethod(_output_size)
 
@@ -205,7 +208,7 @@ class _ModulatedDeformConv(Function):
 
     @staticmethod
     def forward(ctx, input, offset, mask, weight, bias=None, stride=1, padding=0, dilation=1, groups=1,
-                deformable_groups=1):
+                deformable_groups=1, save_columns=None):
         if not input.is_cuda:
             raise NotImplementedError("Deformable Conv is not supported on CPUs!")
         ctx.stride, ctx.padding, ctx.dilation = stride, padding, dilation  # scalars, as the reference keeps them
@@ -213,8 +216,9 @@ class _ModulatedDeformConv(Function):
         ctx.geom = (_pair(stride), _pair(padding), _pair(dilation), groups, deformable_groups)
         if any(t.requires_grad for t in (input, offset, mask, weight)):
             ctx.save_for_backward(input, offset, mask, weight)
-        out, ctx.columns = _dcn_forward(input, offset, mask, weight, bias, *ctx.geom,
-                                        save_columns=bool(weight.requires_grad))
+        if save_columns is None:  # (a direct .apply caller; `modulated_deform_conv` below passes the grad mode in)
+            save_columns = bool(weight.requires_grad)
+        out, ctx.columns = _dcn_forward(input, offset, mask, weight, bias, *ctx.geom, save_columns=bool(save_columns))
         return out
 
     @staticmethod
@@ -226,11 +230,27 @@ class _ModulatedDeformConv(Function):
         grads = _dcn_backward(input, offset, mask, weight, grad_output, *ctx.geom, True, True, ctx.with_bias,
                               columns=ctx.columns)
         ctx.columns = None
-        return tuple(grads) + (None,) * 5
+        return tuple(grads) + (None,) * 6
 
 
-deform_conv = _DeformConv.apply
-modulated_deform_conv = _ModulatedDeformConv.apply
+def _keeps_columns(weight):
+    """The training forward keeps its column for the weight gradient -- only when a backward can follow: under
+    torch.no_grad() / inference mode nothing is kept, whatever `weight.requires_grad` says (an eval-mode model's
+    Parameters still require grad)."""
+    return bool(torch.is_grad_enabled() and weight.requires_grad)
+
+
+def deform_conv(input, offset, weight, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1, im2col_step=64):
+    """The reference's `deform_conv = _DeformConv.apply` (deform_conv.py:312), same positional arguments."""
+    return _DeformConv.apply(input, offset, weight, stride, padding, dilation, groups, deformable_groups, im2col_step,
+                             _keeps_columns(weight))
+
+
+def modulated_deform_conv(input, offset, mask, weight, bias=None, stride=1, padding=0, dilation=1, groups=1,
+                          deformable_groups=1):
+    """The reference's `modulated_deform_conv = _ModulatedDeformConv.apply` (deform_conv.py:313)."""
+    return _ModulatedDeformConv.apply(input, offset, mask, weight, bias, stride, padding, dilation, groups,
+                                      deformable_groups, _keeps_columns(weight))
 
 
 class _DeformConvModule(nn.Module):
