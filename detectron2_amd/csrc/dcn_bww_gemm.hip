@@ -147,21 +147,50 @@ __global__ __launch_bounds__(256, 2) void dcn_bww_gemm_kernel(BwwGemmArgs a) {
       }
 }
 
-// dW[co][ci][tap] = sum over the K splits (in split order) of part[ks][mt][nt][co % 128][n % 128], n = tap * C + ci
+// dW[co][ci][tap] = sum over the K splits of part[ks][mt][nt][co % 128][n % 128], n = tap * C + ci.  Workgroup = 64 groups
+// of 4 consecutive n (16-B loads) x 4 interleaved shares of the splits; a share adds its splits in ascending order, the
+// four shares are added in a fixed order through LDS: deterministic, and the chain of dependent loads is a quarter as
+// long (the r04 kernel -- a thread per element walking all splits with 4-B loads -- took 14-24 us for 35 MB).
 template <typename T>
 __global__ __launch_bounds__(256) void bww_gemm_reduce_kernel(const float* __restrict__ part, T* __restrict__ gw, int Co, int C,
                                                              int K2, int n_mt, int n_nt, int ksplit) {
-  const long N = (long)K2 * C;
-  const long total = (long)Co * N;
+  __shared__ float4 sh[3][64];
+  const int N = K2 * C;                       // (a multiple of 64: C % 64 == 0)
+  const int quads = N >> 2;
+  const int q = threadIdx.x & 63, share = threadIdx.x >> 6;
+  const long item = (long)blockIdx.x * 64 + q;  // (co, quad of n)
+  const long items = (long)Co * quads;
+  const bool ok = item < items;
+  const int co = ok ? (int)(item / quads) : 0;
+  const int n = ok ? (int)(item - (long)co * quads) * 4 : 0;
   const size_t tile = (size_t)GM * GN, split = (size_t)n_mt * n_nt * tile;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int co = (int)(i / N);
-    const long n = i - (long)co * N;
-    const float* p = part + ((size_t)(co / GM) * n_nt + (size_t)(n / GN)) * tile + (size_t)(co % GM) * GN + (size_t)(n % GN);
-    float v = 0.f;
-    for (int k = 0; k < ksplit; k++) v += p[(size_t)k * split];
-    const int tap = (int)(n / C), ci = (int)(n - (long)tap * C);
-    gw[((long)co * C + ci) * K2 + tap] = from_f32<T>(v);
+  const float* p = part + ((size_t)(co / GM) * n_nt + (size_t)(n / GN)) * tile + (size_t)(co % GM) * GN + (size_t)(n % GN);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ok) {
+    int k = share;
+    for (; k + 12 < ksplit; k += 16) {  // four loads in flight
+      const float4 a0 = *reinterpret_cast<const float4*>(p + (size_t)k * split);
+      const float4 a1 = *reinterpret_cast<const float4*>(p + (size_t)(k + 4) * split);
+      const float4 a2 = *reinterpret_cast<const float4*>(p + (size_t)(k + 8) * split);
+      const float4 a3 = *reinterpret_cast<const float4*>(p + (size_t)(k + 12) * split);
+      acc.x += a0.x; acc.y += a0.y; acc.z += a0.z; acc.w += a0.w;
+      acc.x += a1.x; acc.y += a1.y; acc.z += a1.z; acc.w += a1.w;
+      acc.x += a2.x; acc.y += a2.y; acc.z += a2.z; acc.w += a2.w;
+      acc.x += a3.x; acc.y += a3.y; acc.z += a3.z; acc.w += a3.w;
+    }
+    for (; k < ksplit; k += 4) {
+      const float4 a0 = *reinterpret_cast<const float4*>(p + (size_t)k * split);
+      acc.x += a0.x; acc.y += a0.y; acc.z += a0.z; acc.w += a0.w;
+    }
+  }
+  if (share > 0) sh[share - 1][q] = acc;
+  __syncthreads();
+  if (share == 0 && ok) {
+#pragma unroll
+    for (int s2 = 0; s2 < 3; s2++) { const float4 o = sh[s2][q]; acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
+    const int tap = n / C, ci = n - tap * C;  // (4 consecutive n share the tap: C % 4 == 0)
+    T* dst = gw + ((long)co * C + ci) * K2 + tap;
+    dst[0] = from_f32<T>(acc.x); dst[K2] = from_f32<T>(acc.y); dst[2 * K2] = from_f32<T>(acc.z); dst[3 * K2] = from_f32<T>(acc.w);
   }
 }
 
@@ -205,9 +234,8 @@ int dcn_bww_gemm(const DcnShape& s, const BwwGemmPlan& pl, const void* dy_nhwc, 
   hipLaunchKernelGGL((dcn_bww_gemm_kernel<T>), dim3(grid), dim3(256), 0, st, a);
   if (timed) timing_end("dcn_bwd_weight", st);
   D2_LAUNCH_OK();
-  const long n = (long)s.Co * s.C * s.K2;
-  const int blocks = cdiv(n, 256) > 4096 ? 4096 : cdiv(n, 256);
-  hipLaunchKernelGGL((bww_gemm_reduce_kernel<T>), dim3(blocks), dim3(256), 0, st, (const float*)partials, (T*)grad_weight,
+  const long items = (long)s.Co * s.C * s.K2 / 4;
+  hipLaunchKernelGGL((bww_gemm_reduce_kernel<T>), dim3(cdiv(items, 64)), dim3(256), 0, st, (const float*)partials, (T*)grad_weight,
                      s.Co, s.C, s.K2, pl.n_mt, pl.n_nt, pl.ksplit);
   D2_LAUNCH_OK();
   return D2AMD_OK;

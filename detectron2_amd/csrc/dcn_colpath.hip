@@ -21,31 +21,26 @@ namespace d2amd {
 
 // ---- weights: W[co][ci][tap] -> Wp[co][tap * C + ci]  (forward: N = Co rows, K contiguous)
 //                               -> Wt[tap * C + ci][co]  (backward-data: N = 9C rows, K = Co contiguous)
-// Workgroup = a 32 co x 32 ci tile with all taps through LDS: 64-B runs on both sides.  The training forward packs BOTH
-// (Wt rides in the tail of the column buffer the caller keeps for the backward): one launch per block and iteration.
+// Workgroup = a 32 co x 32 ci tile of ONE tap through LDS (C / 32 x Co / 32 x K2 workgroups): 64-B runs on both output
+// sides.  The training forward packs BOTH (Wt rides in the tail of the column buffer the caller keeps for the backward):
+// one pack launch per block and iteration.
 template <typename T>
 __global__ __launch_bounds__(256) void dcn_pack_weights_kernel(const T* __restrict__ w, T* __restrict__ wp, T* __restrict__ wt,
                                                               int Co, int C, int K2) {
-  __shared__ T tile[32 * 32 * 9];
-  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32, tid = threadIdx.x;
-  const int run = 32 * K2, n = 32 * run;
-  for (int i = tid; i < n; i += 256) {
-    const int co = i / run, r = i - co * run;
-    tile[i] = w[((long)(co0 + co) * C + ci0) * K2 + r];
-  }
+  __shared__ T tile[32][33];  // [co][ci]
+  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32, tap = blockIdx.z;
+  const int a = threadIdx.x & 31, r = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+  for (int j = 0; j < 4; j++) tile[r + 8 * j][a] = w[((long)(co0 + r + 8 * j) * C + ci0 + a) * K2 + tap];
   __syncthreads();
-  if (wp)
-    for (int i = tid; i < n; i += 256) {  // (co, tap, ci), ci fastest
-      const int ci = i & 31, r = i >> 5;
-      const int tap = r % K2, co = r / K2;
-      wp[((long)(co0 + co) * K2 + tap) * C + ci0 + ci] = tile[co * run + ci * K2 + tap];
-    }
-  if (wt)
-    for (int i = tid; i < n; i += 256) {  // (tap, ci, co), co fastest
-      const int co = i & 31, r = i >> 5;
-      const int ci = r & 31, tap = r >> 5;
-      wt[((long)tap * C + ci0 + ci) * Co + co0 + co] = tile[co * run + ci * K2 + tap];
-    }
+  if (wp) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) wp[((long)(co0 + r + 8 * j) * K2 + tap) * C + ci0 + a] = tile[r + 8 * j][a];
+  }
+  if (wt) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) wt[((long)tap * C + ci0 + r + 8 * j) * Co + co0 + a] = tile[a][r + 8 * j];
+  }
 }
 
 // ---- sample tables ----------------------------------------------------------------------------------------------------
@@ -57,8 +52,10 @@ struct __attribute__((aligned(16))) CpEntry {
   float w[4];        // bilinear weight (forward table: x modulation mask); 0 for corners / samples outside
   float lh, lw, m;   // (backward table) fractional parts, modulation mask
   uint32_t flags;    // bit c: corner c inside; bit 4: sample inside
+  int oidx, midx;    // element index of d offset_h (d offset_w: + L) and of d mask for this sample; -1 beyond the last position
+  int pad[2];
 };
-static_assert(sizeof(CpEntry) == 48, "CpEntry layout");
+static_assert(sizeof(CpEntry) == 64, "CpEntry layout");
 
 template <typename T, bool FOLD_MASK>
 __device__ __forceinline__ CpEntry cp_make_entry(const DcnShape& s, const T* __restrict__ offset, const T* __restrict__ mask,
@@ -67,8 +64,11 @@ __device__ __forceinline__ CpEntry cp_make_entry(const DcnShape& s, const T* __r
 #pragma unroll
   for (int t = 0; t < 4; t++) { e.pix[t] = 0u; e.w[t] = 0.f; }
   e.lh = e.lw = 0.f; e.m = 0.f; e.flags = 0u;
+  e.oidx = e.midx = -1; e.pad[0] = e.pad[1] = 0;
   if (p >= s.P) return e;
   const int b = (int)(p / s.L), l = (int)(p - (long)b * s.L);
+  e.oidx = (int)(((long)b * 2 * s.K2 + 2 * tap) * s.L + l);
+  e.midx = (int)(((long)b * s.K2 + tap) * s.L + l);
   const int ho = l / s.Wo, wo = l - ho * s.Wo;
   const int i = tap / s.kw, j = tap - i * s.kw;
   const long obase = (long)b * 2 * s.K2;
@@ -98,17 +98,35 @@ constexpr int CP_MAXS = 32 * 9;  // samples (positions x taps) of one workgroup'
 // sum over 8 channels of a * b, both 8 x 16-bit: four v_dot2_f32_{bf16,f16} (exact products, fp32 accumulation)
 typedef __attribute__((ext_vector_type(2))) __bf16 cp_bf2;
 typedef __attribute__((ext_vector_type(2))) _Float16 cp_h2;
+// (components taken apart by name: with a[i] in an unrolled loop hipcc 7.2 fed the FIRST dword to all four instructions)
 __device__ __forceinline__ float cp_dot8(const raw16& a, const raw16& b, bf16_t) {
-  float acc = 0.f;
-#pragma unroll
-  for (int i = 0; i < 4; i++) acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(cp_bf2, a[i]), __builtin_bit_cast(cp_bf2, b[i]), acc, false);
-  return acc;
+  float acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(cp_bf2, (uint32_t)a.x), __builtin_bit_cast(cp_bf2, (uint32_t)b.x), 0.f, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(cp_bf2, (uint32_t)a.y), __builtin_bit_cast(cp_bf2, (uint32_t)b.y), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(cp_bf2, (uint32_t)a.z), __builtin_bit_cast(cp_bf2, (uint32_t)b.z), acc, false);
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(cp_bf2, (uint32_t)a.w), __builtin_bit_cast(cp_bf2, (uint32_t)b.w), acc, false);
 }
 __device__ __forceinline__ float cp_dot8(const raw16& a, const raw16& b, f16_t) {
-  float acc = 0.f;
-#pragma unroll
-  for (int i = 0; i < 4; i++) acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(cp_h2, a[i]), __builtin_bit_cast(cp_h2, b[i]), acc, false);
-  return acc;
+  float acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(cp_h2, (uint32_t)a.x), __builtin_bit_cast(cp_h2, (uint32_t)b.x), 0.f, false);
+  acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(cp_h2, (uint32_t)a.y), __builtin_bit_cast(cp_h2, (uint32_t)b.y), acc, false);
+  acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(cp_h2, (uint32_t)a.z), __builtin_bit_cast(cp_h2, (uint32_t)b.z), acc, false);
+  return __builtin_amdgcn_fdot2(__builtin_bit_cast(cp_h2, (uint32_t)a.w), __builtin_bit_cast(cp_h2, (uint32_t)b.w), acc, false);
+}
+
+// Sum over the LPS consecutive lanes of a sample (LPS = 8 .. 64, a power of two), left in the group's LAST lane: DPP row
+// shifts (VALU rate, no LDS -- the ds_bpermute butterfly this replaces was the kernel's largest cost: 16 per item), then
+// row broadcasts across the 16-lane rows.  Order of the additions: fixed.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float cp_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
+}
+__device__ __forceinline__ float cp_group_sum(float v, int LPS) {
+  v += cp_dpp<0x111, 0xf>(v);               // row_shr:1
+  v += cp_dpp<0x112, 0xf>(v);               // row_shr:2
+  v += cp_dpp<0x114, 0xf>(v);               // row_shr:4  -> lanes 7 / 15 of a row: sums of 8
+  if (LPS >= 16) v += cp_dpp<0x118, 0xf>(v);  // row_shr:8  -> lane 15: the row
+  if (LPS >= 32) v += cp_dpp<0x142, 0xa>(v);  // row_bcast:15 into rows 1, 3 -> lanes 31 / 63: two rows
+  if (LPS >= 64) v += cp_dpp<0x143, 0xc>(v);  // row_bcast:31 into rows 2, 3 -> lane 63: the wave
+  return v;
 }
 
 // ---- forward: the column, written once, 16 B per lane, a wave stores 1 KB of consecutive column bytes ------------------
@@ -226,15 +244,10 @@ __global__ __launch_bounds__(256) void dcn_coord_grad_kernel(DcnShape s, const T
       float D[4];
 #pragma unroll
       for (int c = 0; c < 4; c++) D[c] = (flags & (1u << c)) ? cp_dot8(dq[u], q[u][c], T{}) : 0.f;
-      // sum over the sample's lanes (LPS consecutive lanes; LPS <= 64)
-      for (int o = 1; o < LPS; o <<= 1) {
+      // sum over the sample's lanes, left in the last of them
 #pragma unroll
-        for (int c = 0; c < 4; c++) D[c] += __shfl_xor(D[c], o);
-      }
-      if (((it0 + u * 256 + tid) & (LPS - 1)) == 0 && ok[u]) {
-        const long p = p0 + sraw[u] / s.K2;
-        const int tap = sraw[u] % s.K2;
-        const int b = (int)(p / s.L), l = (int)(p - (long)b * s.L);
+      for (int c = 0; c < 4; c++) D[c] = cp_group_sum(D[c], LPS);
+      if (((it0 + u * 256 + tid) & (LPS - 1)) == LPS - 1 && ok[u]) {  // (the table holds the output indices: no divisions here)
         const float lh = e.lh, lw = e.lw, hh = 1.f - lh, hw = 1.f - lw, m = e.m;
         float gh = 0.f, gw = 0.f, gm = 0.f;
         if (flags & 16u) {
@@ -243,11 +256,10 @@ __global__ __launch_bounds__(256) void dcn_coord_grad_kernel(DcnShape s, const T
           gw = m * (hh * (D[1] - D[0]) + lh * (D[3] - D[2]));
         }
         if (goff) {
-          T* ph = goff + ((long)b * 2 * s.K2 + 2 * tap) * s.L + l;
-          ph[0] = from_f32<T>(gh);
-          ph[s.L] = from_f32<T>(gw);
+          goff[e.oidx] = from_f32<T>(gh);
+          goff[e.oidx + s.L] = from_f32<T>(gw);
         }
-        if (gmask) gmask[((long)b * s.K2 + tap) * s.L + l] = from_f32<T>(gm);
+        if (gmask) gmask[e.midx] = from_f32<T>(gm);
       }
     }
   }
@@ -255,8 +267,10 @@ __global__ __launch_bounds__(256) void dcn_coord_grad_kernel(DcnShape s, const T
 
 // ---- host side --------------------------------------------------------------------------------------------------------
 static int cp_positions_per_group(const DcnShape& s) {
+  // >= ~8 workgroups per CU (32 resident waves each with 8 gathers in flight): the kernels are bound by the number of
+  // loads in flight, not by their tables (profiles/r05/LOG.md)
   int np = 32;
-  while (np > 2 && (long)s.P / np < 1024) np >>= 1;
+  while (np > 1 && (long)s.P / np < 2048) np >>= 1;
   return np;
 }
 
@@ -268,7 +282,7 @@ ColPathPlan dcn_colpath_plan(const DcnShape& s, int dtype) {
   if (dtype != D2AMD_BF16 && dtype != D2AMD_F16) return pl;
   if (s.G != 1 || s.DG != 1 || s.K2 > 9 || s.P <= 0) return pl;
   if (!(s.C == 64 || s.C == 128 || s.C == 256 || s.C == 512) || s.Co % 64 != 0) return pl;
-  if ((long)s.P * s.K2 * s.C >= (1l << 31) || (long)s.B * s.H * s.W * s.C * 2 >= (1l << 32)) return pl;
+  if ((long)s.P * s.K2 * s.C >= (1l << 31) || (long)s.B * s.H * s.W * s.C * 2 >= (1l << 32)) return pl;  // (32-bit element indices)
   pl.fwd = gemm_nt_plan(s.P, s.Co, s.K2 * s.C);
   pl.bwd = gemm_nt_plan(s.P, s.K2 * s.C, s.Co);
   if (!pl.fwd.ok || !pl.bwd.ok) return pl;
@@ -283,7 +297,7 @@ template <typename T>
 int dcn_colpath_forward(const DcnShape& s, const ColPathPlan& pl, const void* x_nhwc, const void* offset, const void* mask,
                         const void* weight, const void* bias, void* out_nhwc, void* col, void* wpack, void* wt_keep,
                         hipStream_t st) {
-  hipLaunchKernelGGL((dcn_pack_weights_kernel<T>), dim3(s.C / 32, s.Co / 32), dim3(256), 0, st, (const T*)weight, (T*)wpack,
+  hipLaunchKernelGGL((dcn_pack_weights_kernel<T>), dim3(s.C / 32, s.Co / 32, s.K2), dim3(256), 0, st, (const T*)weight, (T*)wpack,
                      (T*)wt_keep, s.Co, s.C, s.K2);
   D2_LAUNCH_OK();
   const int total = cdiv(s.P, pl.NP);
@@ -308,7 +322,7 @@ int dcn_colpath_backward_data(const DcnShape& s, const ColPathPlan& pl, const vo
                               const void* weight, const void* gout_nhwc, void* dcol, void* wpack, const void* wt_kept,
                               void* goff, void* gmask, hipStream_t st) {
   if (!wt_kept) {  // (no column was kept by the forward: pack here)
-    hipLaunchKernelGGL((dcn_pack_weights_kernel<T>), dim3(s.C / 32, s.Co / 32), dim3(256), 0, st, (const T*)weight, (T*)nullptr,
+    hipLaunchKernelGGL((dcn_pack_weights_kernel<T>), dim3(s.C / 32, s.Co / 32, s.K2), dim3(256), 0, st, (const T*)weight, (T*)nullptr,
                        (T*)wpack, s.Co, s.C, s.K2);
     D2_LAUNCH_OK();
   }

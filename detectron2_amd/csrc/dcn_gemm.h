@@ -52,32 +52,32 @@ __device__ __forceinline__ void gm_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-constexpr int GM_THREADS = 256;
 static inline size_t gemm_nt_lds_bytes(int BM, int BN, int BK, int NST) {
   const size_t stages = (size_t)NST * (BM + BN) * BK * 2;
   const size_t epi = (size_t)BM * (BN * 2 + 16);
   return stages > epi ? stages : epi;
 }
 
-// ABL (probe only): 0 the kernel; 1 no DMA after the prologue; 2 DMA only; 3 DMA + MFMA on constant fragments (no LDS reads);
-// 4 DMA + LDS reads, no MFMA; PF: fragment reads one MFMA k step ahead, pinned with sched_barrier
-template <typename T, int BM, int BN, int BK, int NST, int ABL = 0, bool PF = false>
-__global__ __launch_bounds__(GM_THREADS, (NST * (BM + BN) * BK * 2 <= 80 * 1024) ? 2 : 1) void gemm_nt_kernel(GemmNtArgs a) {
+// WM x WN waves on the tile (4 or 8 waves: with two waves per SIMD one wave's MFMAs cover the other's LDS latency)
+template <typename T, int BM, int BN, int BK, int NST, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, (NST * (BM + BN) * BK * 2 <= 80 * 1024) ? 2 : 1) void gemm_nt_kernel(GemmNtArgs a) {
   extern __shared__ __attribute__((aligned(16))) char gm_smem[];
   static_assert(BK == 32 || BK == 64, "K step");
-  constexpr int TM = BM / 64, TN = BN / 64;         // 32 x 32 MFMA blocks per wave along m / n
+  constexpr int NW = WM * WN, THREADS = 64 * NW;
+  constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);  // 32 x 32 MFMA blocks per wave along m / n
+  static_assert(TM >= 1 && TN >= 1 && (BM / (64 / (BK / 8))) % NW == 0, "tile / wave layout");
   constexpr int ROWS = BM + BN;                     // rows of one stage: X rows, then Wn rows
   constexpr int RB = BK * 2;                        // bytes of one LDS row
   constexpr int SLOTS = BK / 8;                     // 16-B slots per row
   constexpr int RPI = 64 / SLOTS;                   // rows one DMA instruction covers
   constexpr int STAGE = ROWS * RB;
-  constexpr int LPW = ROWS / RPI / 4;               // DMA instructions per wave and stage
+  constexpr int LPW = ROWS / RPI / NW;              // DMA instructions per wave and stage
   constexpr int KK = BK / 16;                       // MFMA k steps per stage
   // swizzle of a row's slots: the 16 lanes one ds_read_b128 cycle serves (16 consecutive rows, one slot) must fall on 16
   // distinct 16-B columns of the 256-B bank row
   auto swz = [](int row) __attribute__((always_inline)) { return BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave & 1, wn = wave >> 1;
+  const int wm = wave % WM, wn = wave / WM;
 
   // XCD-aware decode: an XCD takes a contiguous range of logical ids; the n tiles of an m tile are adjacent (the same
   // X rows are fetched into one L2)
@@ -92,8 +92,8 @@ __global__ __launch_bounds__(GM_THREADS, (NST * (BM + BN) * BK * 2 <= 80 * 1024)
   const char* src[LPW];
 #pragma unroll
   for (int i = 0; i < LPW; i++) {
-    const int q = wave + 4 * i;                       // RPI-row block of the stage
-    const bool isx = i < BM / RPI / 4;                // (BM / RPI is a multiple of 4: compile-time per i)
+    const int q = wave + NW * i;                      // RPI-row block of the stage
+    const bool isx = i < BM / RPI / NW;               // (BM / RPI is a multiple of NW: compile-time per i)
     const int r = q * RPI + lane / SLOTS - (isx ? 0 : BM);
     const int slot = (lane % SLOTS) ^ swz(r);
     const int grow = isx ? min(m0 + r, a.M - 1) : min(n0 + r, a.N - 1);
@@ -101,10 +101,15 @@ __global__ __launch_bounds__(GM_THREADS, (NST * (BM + BN) * BK * 2 <= 80 * 1024)
     const int ld = isx ? a.ldx : a.ldw;
     src[i] = base + (size_t)grow * ld * 2 + slot * 16;
   }
-  auto issue = [&](int stage) __attribute__((always_inline)) {
+  // DMA instructions [i0, i1) of a stage (a wave's instructions go through the CU's address unit at 16 cycles each, and
+  // an in-order wave cannot issue anything behind a vector-memory instruction the unit has not accepted: all LPW at
+  // once stalled the wave ~500 cycles before its first fragment read -- measured, scripts/probes/cu_probe.hip: k step
+  // 768 cycles, DMA 593, both 1,285 -- so the K loop issues them in pieces between its MFMA groups)
+  auto issue = [&](int stage, int i0, int i1) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < LPW; i++) {
-      char* dst = gm_smem + stage * STAGE + (wave + 4 * i) * 1024;  // wave-uniform; the DMA adds lane * 16 (= RPI rows)
+      if (i < i0 || i >= i1) continue;
+      char* dst = gm_smem + stage * STAGE + (wave + NW * i) * 1024;  // wave-uniform; the DMA adds lane * 16 (= RPI rows)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i],
                                        (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
       src[i] += BK * 2;
@@ -116,8 +121,8 @@ __global__ __launch_bounds__(GM_THREADS, (NST * (BM + BN) * BK * 2 <= 80 * 1024)
   int foff[KK];
 #pragma unroll
   for (int kk = 0; kk < KK; kk++) foff[kk] = (lane & 31) * RB + (((2 * kk + (lane >> 5)) ^ sw) << 4);
-  const int xrow0 = wm * (BM / 2) * RB;                   // this wave's X rows within the stage
-  const int wrow0 = (BM + wn * (BN / 2)) * RB;            // this wave's Wn rows
+  const int xrow0 = wm * (BM / WM) * RB;                  // this wave's X rows within the stage
+  const int wrow0 = (BM + wn * (BN / WN)) * RB;           // this wave's Wn rows
 
   f32x16_t acc[TN][TM];
 #pragma unroll
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(GM_THREADS, (NST * (BM + BN) * BK * 2 <= 80 * 1024)
   // ---- pipeline: NST - 1 stages in flight
 #pragma unroll
   for (int s = 0; s < NST - 1; s++)
-    if (s < nk) issue(s);
+    if (s < nk) issue(s, 0, LPW);
   for (int kt = 0; kt < nk; kt++) {
     // stage kt has landed when at most the loads of the later stages issued so far are outstanding
     if constexpr (NST == 2) {
@@ -139,58 +144,21 @@ __global__ __launch_bounds__(GM_THREADS, (NST * (BM + BN) * BK * 2 <= 80 * 1024)
       if (kt + NST - 2 < nk) gm_wait_vm<(NST - 2) * LPW>(); else gm_wait_vm<0>();   // (the tail drains everything)
     }
     __builtin_amdgcn_s_barrier();  // everybody's DMA of stage kt visible; everybody done reading stage kt - 1
-    if (kt + NST - 1 < nk && ABL != 1) issue((kt + NST - 1) % NST);
+    const bool more = kt + NST - 1 < nk;  // uniform
+    const int nxt = (kt + NST - 1) % NST;
     const char* st = gm_smem + (kt % NST) * STAGE;
-    if constexpr (ABL == 2) continue;
-    if constexpr (ABL == 3) {
-      gm_u32x4 c = {(unsigned)kt, 1u, 2u, 3u};
 #pragma unroll
-      for (int kk = 0; kk < KK; kk++)
+    for (int kk = 0; kk < KK; kk++) {
+      gm_u32x4 wf[TN], xf[TM];
 #pragma unroll
-        for (int i = 0; i < TN; i++)
+      for (int i = 0; i < TN; i++) wf[i] = *reinterpret_cast<const gm_u32x4*>(st + wrow0 + i * 32 * RB + foff[kk]);
 #pragma unroll
-          for (int j = 0; j < TM; j++) acc[i][j] = gm_mma<T>(c, c, acc[i][j]);
-      continue;
-    }
-    if constexpr (PF) {
-      // fragments of MFMA k step kk + 1 are requested before the MFMAs of step kk issue
-      gm_u32x4 wf[2][TN], xf[2][TM];
-      auto frags = [&](int b, int kk) __attribute__((always_inline)) {
+      for (int j = 0; j < TM; j++) xf[j] = *reinterpret_cast<const gm_u32x4*>(st + xrow0 + j * 32 * RB + foff[kk]);
+      if (more) issue(nxt, kk * LPW / KK, (kk + 1) * LPW / KK);  // this k step's share of stage kt + NST - 1
 #pragma unroll
-        for (int i = 0; i < TN; i++) wf[b][i] = *reinterpret_cast<const gm_u32x4*>(st + wrow0 + i * 32 * RB + foff[kk]);
+      for (int i = 0; i < TN; i++)
 #pragma unroll
-        for (int j = 0; j < TM; j++) xf[b][j] = *reinterpret_cast<const gm_u32x4*>(st + xrow0 + j * 32 * RB + foff[kk]);
-      };
-      frags(0, 0);
-#pragma unroll
-      for (int kk = 0; kk < KK; kk++) {
-        if (kk + 1 < KK) frags((kk + 1) & 1, kk + 1);
-        __builtin_amdgcn_sched_barrier(0);  // (hipcc otherwise sinks these reads below the MFMAs and reuses their registers)
-#pragma unroll
-        for (int i = 0; i < TN; i++)
-#pragma unroll
-          for (int j = 0; j < TM; j++) acc[i][j] = gm_mma<T>(wf[kk & 1][i], xf[kk & 1][j], acc[i][j]);
-      }
-    } else {
-#pragma unroll
-      for (int kk = 0; kk < KK; kk++) {
-        gm_u32x4 wf[TN], xf[TM];
-#pragma unroll
-        for (int i = 0; i < TN; i++) wf[i] = *reinterpret_cast<const gm_u32x4*>(st + wrow0 + i * 32 * RB + foff[kk]);
-#pragma unroll
-        for (int j = 0; j < TM; j++) xf[j] = *reinterpret_cast<const gm_u32x4*>(st + xrow0 + j * 32 * RB + foff[kk]);
-        if constexpr (ABL == 4) {
-#pragma unroll
-          for (int i = 0; i < TN; i++) asm volatile("" ::"v"(wf[i]));
-#pragma unroll
-          for (int j = 0; j < TM; j++) asm volatile("" ::"v"(xf[j]));
-        } else {
-#pragma unroll
-          for (int i = 0; i < TN; i++)
-#pragma unroll
-            for (int j = 0; j < TM; j++) acc[i][j] = gm_mma<T>(wf[i], xf[j], acc[i][j]);
-        }
-      }
+        for (int j = 0; j < TM; j++) acc[i][j] = gm_mma<T>(wf[i], xf[j], acc[i][j]);
     }
   }
 
@@ -201,7 +169,7 @@ __global__ __launch_bounds__(GM_THREADS, (NST * (BM + BN) * BK * 2 <= 80 * 1024)
   for (int i = 0; i < TN; i++)
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      const int n = wn * (BN / 2) + i * 32 + 8 * q + 4 * (lane >> 5);  // first of this lane's 4 consecutive columns
+      const int n = wn * (BN / WN) + i * 32 + 8 * q + 4 * (lane >> 5);  // first of this lane's 4 consecutive columns
       float b4[4] = {0.f, 0.f, 0.f, 0.f};
       if (a.bias) {
         const T* bp = (const T*)a.bias + min(n0 + n, a.N - 4);
@@ -210,7 +178,7 @@ __global__ __launch_bounds__(GM_THREADS, (NST * (BM + BN) * BK * 2 <= 80 * 1024)
       }
 #pragma unroll
       for (int j = 0; j < TM; j++) {
-        const int m = wm * (BM / 2) + j * 32 + (lane & 31);
+        const int m = wm * (BM / WM) + j * 32 + (lane & 31);
         uint2 w;
         w.x = gm_pack2<T>(acc[i][j][4 * q] + b4[0], acc[i][j][4 * q + 1] + b4[1]);
         w.y = gm_pack2<T>(acc[i][j][4 * q + 2] + b4[2], acc[i][j][4 * q + 3] + b4[3]);
@@ -220,8 +188,8 @@ __global__ __launch_bounds__(GM_THREADS, (NST * (BM + BN) * BK * 2 <= 80 * 1024)
   __syncthreads();
   constexpr int CPR = BN / 8;  // 16-B chunks per row
 #pragma unroll
-  for (int i = 0; i < BM * CPR / GM_THREADS; i++) {
-    const int c = tid + GM_THREADS * i;
+  for (int i = 0; i < BM * CPR / THREADS; i++) {
+    const int c = tid + THREADS * i;
     const int row = c / CPR, ch = c % CPR;
     if (m0 + row < a.M && n0 + ch * 8 < a.N) {
       const gm_u32x4 v = *reinterpret_cast<const gm_u32x4*>(gm_smem + row * OP + ch * 16);
@@ -233,8 +201,7 @@ __global__ __launch_bounds__(GM_THREADS, (NST * (BM + BN) * BK * 2 <= 80 * 1024)
 // ---- host side ------------------------------------------------------------------------------------------------------
 struct GemmNtPlan {
   bool ok;
-  int BM, BN, BK, NST, n_mt, n_nt;
-  int variant;  // probe builds only
+  int BM, BN, BK, NST, WM, WN, n_mt, n_nt;
   size_t lds;
 };
 

@@ -1814,7 +1814,7 @@ __global__ __launch_bounds__(256) void dcn_bin_samples_kernel(DcnShape s, const 
   }
 }
 
-// One wave per input pixel sorts its list by sample id, in place: the gather below then adds a pixel's contributions in
+// One wave per input pixel sorts its list by sample id, in place (all loads precede all stores): the gather below then adds a pixel's contributions in
 // a fixed order whatever order the binning's atomics handed the slots out in (deterministic dX).  r05: a launch of its own
 // behind the binning -- on the side stream when there is one -- instead of the first 60 % of the gather kernel's
 // instructions on the critical path.  Lane i holds elements i and i + 64 of the <= 128 (sample, weight) pairs.
@@ -1829,34 +1829,23 @@ __global__ __launch_bounds__(256) void dcn_sort_lists_kernel(int npix, const int
   float w0 = 0.f, w1 = 0.f;
   if (lane < n) { const DgEntry e = lp[lane]; k0 = e.sample; w0 = e.w; }
   if (lane + 64 < n) { const DgEntry e = lp[lane + 64]; k1 = e.sample; w1 = e.w; }
-  if (n <= 64) {  // (uniform) bitonic sort over the 64 lanes
-    for (int kk = 2; kk <= 64; kk <<= 1) {
-      for (int j = kk >> 1; j > 0; j >>= 1) {
-        const uint32_t pk = (uint32_t)__shfl_xor((int)k0, j);
-        const float pw = __shfl_xor(w0, j);
-        const bool take_min = ((lane & j) == 0) == ((lane & kk) == 0);
-        if (take_min ? (pk < k0) : (pk > k0)) { k0 = pk; w0 = pw; }
-      }
-    }
-  } else {  // bitonic sort over 128 virtual positions p = lane (k0) / lane + 64 (k1)
-    for (int kk = 2; kk <= 128; kk <<= 1) {
-      for (int j = kk >> 1; j > 0; j >>= 1) {
-        if (j == 64) {  // partner of position lane is position lane + 64: inside the lane (kk == 128: ascending)
-          if (k0 > k1) { const uint32_t tk = k0; k0 = k1; k1 = tk; const float tw = w0; w0 = w1; w1 = tw; }
-        } else {
-          const uint32_t p0k = (uint32_t)__shfl_xor((int)k0, j), p1k = (uint32_t)__shfl_xor((int)k1, j);
-          const float p0w = __shfl_xor(w0, j), p1w = __shfl_xor(w1, j);
-          const bool lower = (lane & j) == 0;
-          const bool up0 = (lane & kk) == 0, up1 = ((lane + 64) & kk) == 0;  // ascending blocks
-          const bool take_min0 = lower == up0, take_min1 = lower == up1;
-          if (take_min0 ? (p0k < k0) : (p0k > k0)) { k0 = p0k; w0 = p0w; }
-          if (take_min1 ? (p1k < k1) : (p1k > k1)) { k1 = p1k; w1 = p1w; }
-        }
-      }
-    }
+  // rank of an element = the number of smaller keys (sample ids are distinct within a pixel's list): every key is
+  // broadcast once (v_readlane with a uniform index: SGPR operand of the compare, no LDS, no dependent chain -- the
+  // bitonic network this replaces was 21-28 stages of two ds_bpermute each), then the element is stored at its rank
+  int r0 = 0, r1 = 0;
+  const int n0 = min(n, 64);
+  for (int j = 0; j < n0; j++) {
+    const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)k0, j);
+    r0 += kj < k0;
+    r1 += kj < k1;
   }
-  if (lane < n) lp[lane] = DgEntry{k0, w0};
-  if (lane + 64 < n) lp[lane + 64] = DgEntry{k1, w1};
+  for (int j = 64; j < n; j++) {
+    const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)k1, j - 64);
+    r0 += kj < k0;
+    r1 += kj < k1;
+  }
+  if (lane < n) lp[r0] = DgEntry{k0, w0};
+  if (lane + 64 < n) lp[r1] = DgEntry{k1, w1};
 }
 
 // RL = lanes per column row = C / 8: every lane loads 16 B (8 channels), a wave instruction covers EPW = 64 / RL list

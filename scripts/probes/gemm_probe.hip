@@ -48,33 +48,24 @@ static float frand() {
     }                                                                          \
   } while (0)
 
-static int run(int M, int N, int K, int BM, int BK, int NST, int splitk, bool bias, int BN = 128) {
+static int run(int M, int N, int K, int BM, int BK, int NST, int splitk, bool bias, int BN = 128, int WM = 2, int WN = 2) {
   GemmNtPlan pl = gemm_nt_plan(M, N, K);
   if (!pl.ok) { printf("plan failed\n"); return 1; }
   if (BM > 0) {
-    pl.BM = BM; pl.BN = BN; pl.BK = BK; pl.NST = NST; pl.n_mt = cdiv(M, BM); pl.n_nt = cdiv(N, BN);
-    const int nk = K / BK;
-    pl.ksteps = cdiv(nk, splitk); pl.splitk = cdiv(nk, pl.ksteps);
-    const long tiles = (long)pl.n_mt * pl.n_nt;
-    pl.part_bytes = pl.splitk > 1 ? (size_t)tiles * pl.splitk * pl.BM * pl.BN * 4 : 0;
-    pl.ticket_bytes = pl.splitk > 1 ? (size_t)tiles * 4 : 0;
+    pl.BM = BM; pl.BN = BN; pl.BK = BK; pl.NST = NST; pl.WM = WM; pl.WN = WN; pl.n_mt = cdiv(M, BM); pl.n_nt = cdiv(N, BN);
   }
   std::vector<uint16_t> hx((size_t)M * K), hw((size_t)N * K), hb(N), ho((size_t)M * N);
   for (auto& v : hx) v = f2bf(frand());
   for (auto& v : hw) v = f2bf(frand() * 0.1f);
   for (auto& v : hb) v = f2bf(frand());
-  void *dx, *dw, *dout, *db, *dpart = nullptr, *dtick = nullptr;
+  void *dx, *dw, *dout, *db;
   CK(hipMalloc(&dx, hx.size() * 2)); CK(hipMalloc(&dw, hw.size() * 2)); CK(hipMalloc(&dout, ho.size() * 2)); CK(hipMalloc(&db, N * 2));
   CK(hipMemcpy(dx, hx.data(), hx.size() * 2, hipMemcpyHostToDevice));
   CK(hipMemcpy(dw, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
   CK(hipMemcpy(db, hb.data(), N * 2, hipMemcpyHostToDevice));
   CK(hipMemset(dout, 0xff, ho.size() * 2));
-  if (pl.splitk > 1) {
-    CK(hipMalloc(&dpart, pl.part_bytes)); CK(hipMalloc(&dtick, pl.ticket_bytes));
-    CK(hipMemset(dtick, 0, pl.ticket_bytes));
-  }
   GemmNtArgs a{};
-  a.X = dx; a.Wn = dw; a.out = dout; a.bias = bias ? db : nullptr; a.part = (float*)dpart; a.tickets = (int*)dtick;
+  a.X = dx; a.Wn = dw; a.out = dout; a.bias = bias ? db : nullptr;
   a.M = M; a.N = N; a.K = K; a.ldx = K; a.ldw = K; a.ldo = N;
   if (gemm_nt_launch<bf16_t>(pl, a, 0)) return 1;
   CK(hipDeviceSynchronize());
@@ -116,105 +107,39 @@ static int run(int M, int N, int K, int BM, int BK, int NST, int splitk, bool bi
   float ms = 0;
   CK(hipEventElapsedTime(&ms, e0, e1));
   const double us = ms * 1e3 / REP, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
-  if (getenv("GM_DIAG")) {  // where the time is: X rows all the same (ldx = 0: nothing streams from HBM), and W too
-    GemmNtArgs b = a;
-    b.ldx = 0;
-    for (int i = 0; i < 3; i++) gemm_nt_launch<bf16_t>(pl, b, 0);
-    CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < REP; i++) gemm_nt_launch<bf16_t>(pl, b, 0);
-    CK(hipEventRecord(e1, 0));
-    CK(hipDeviceSynchronize());
-    float ms2 = 0;
-    CK(hipEventElapsedTime(&ms2, e0, e1));
-    b.ldw = 0;
-    CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < REP; i++) gemm_nt_launch<bf16_t>(pl, b, 0);
-    CK(hipEventRecord(e1, 0));
-    CK(hipDeviceSynchronize());
-    float ms3 = 0;
-    CK(hipEventElapsedTime(&ms3, e0, e1));
-    b.ldo = 0;
-    CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < REP; i++) gemm_nt_launch<bf16_t>(pl, b, 0);
-    CK(hipEventRecord(e1, 0));
-    CK(hipDeviceSynchronize());
-    float ms4 = 0;
-    CK(hipEventElapsedTime(&ms4, e0, e1));
-    printf("   diag: ldx=0 %.2f us; ldx=ldw=0 %.2f us; +ldo=0 %.2f us\n", ms2 * 1e3 / REP, ms3 * 1e3 / REP, ms4 * 1e3 / REP);
-    if (pl.BM == 128 && pl.BK == 64 && pl.NST <= 3 && pl.splitk == 1)
-      for (int ab = 1; ab <= 5; ab++) {
-        GemmNtPlan q = pl;
-        q.variant = ab;
-        for (int i = 0; i < 3; i++) gemm_nt_launch<bf16_t>(q, a, 0);
-        CK(hipEventRecord(e0, 0));
-        for (int i = 0; i < REP; i++) gemm_nt_launch<bf16_t>(q, a, 0);
-        CK(hipEventRecord(e1, 0));
-        CK(hipDeviceSynchronize());
-        float ms5 = 0;
-        CK(hipEventElapsedTime(&ms5, e0, e1));
-        const char* names[] = {"", "no DMA", "DMA only", "DMA + MFMA, no fragment reads", "DMA + fragment reads, no MFMA", "fragment prefetch"};
-        printf("   variant %d (%s): %.2f us\n", ab, names[ab], ms5 * 1e3 / REP);
-      }
-  }
-  printf("M=%d N=%d K=%d tile %dx%dx%d nst %d (lds %zu KB) splitk %d (items %d)%s: %.2f us  %.1f TF  bad %d/%d worst %.2f nondet %d\n", M, N, K,
-         pl.BM, pl.BN, pl.BK, pl.NST, gemm_nt_lds_bytes(pl.BM, pl.BN, pl.BK, pl.NST) >> 10, pl.splitk, pl.n_mt * pl.n_nt * pl.splitk, bias ? " +bias" : "", us, tf, bad, NS, worst, nondet);
+  printf("M=%d N=%d K=%d tile %dx%dx%d nst %d waves %dx%d (lds %zu KB, %d tiles)%s: %.2f us  %.1f TF  bad %d/%d worst %.2f nondet %d\n", M, N, K,
+         pl.BM, pl.BN, pl.BK, pl.NST, pl.WM, pl.WN, gemm_nt_lds_bytes(pl.BM, pl.BN, pl.BK, pl.NST) >> 10, pl.n_mt * pl.n_nt, bias ? " +bias" : "", us, tf, bad, NS, worst, nondet);
   hipFree(dx); hipFree(dw); hipFree(dout); hipFree(db);
-  if (dpart) hipFree(dpart);
-  if (dtick) hipFree(dtick);
   return bad != 0 || nondet != 0;
 }
 
 int main(int argc, char** argv) {
   int rc = 0;
-  if (argc >= 8 && !strcmp(argv[1], "diag")) {
-    setenv("GM_DIAG", "1", 1);
-    const int P[3] = {33600, 8400, 2100}, C[3] = {128, 256, 512};
-    for (int s = 0; s < 3; s++) {
-      run(P[s], C[s], 9 * C[s], 128, 64, 2, 1, false);
-      run(P[s], 9 * C[s], C[s], 128, 64, 2, 1, false);
-    }
-    run(32768, 128, 1152, 128, 64, 2, 1, false);
-    run(32768, 128, 1152, 128, 64, 3, 1, false);
-    return 0;
-  }
-  if (argc >= 8 && !strcmp(argv[1], "t64")) {
-    rc |= run(333, 200, 512, 64, 64, 3, 2, true, 64);
-    rc |= run(1000, 136, 1024, 64, 32, 4, 1, false, 64);
-    for (int nst : {2, 3, 4, 6}) rc |= run(2100, 512, 4608, 64, 64, nst, 1, false, 64);
-    for (int nst : {4, 8}) rc |= run(2100, 512, 4608, 64, 32, nst, 1, false, 64);
-    for (int nst : {2, 3, 4, 6}) rc |= run(8400, 256, 2304, 64, 64, nst, 1, false, 64);
-    return rc;
-  }
-  if (argc >= 8) {
-    for (int i = 1; i + 6 < argc; i += 7)
-      rc |= run(atoi(argv[i]), atoi(argv[i + 1]), atoi(argv[i + 2]), atoi(argv[i + 3]), atoi(argv[i + 4]), atoi(argv[i + 5]), atoi(argv[i + 6]), false);
-    return rc;
-  }
-  // small / ragged shapes first (edges, split-K, bias), then the DCN shapes of R50 at 2 images
+  // small / ragged shapes first (edges, bias), then the DCN shapes of R50 at 2 images
   rc |= run(200, 64, 128, 64, 64, 2, 1, true);
   rc |= run(333, 200, 256, 128, 64, 2, 1, false);
-  rc |= run(333, 200, 512, 64, 64, 3, 2, true);
-  rc |= run(1000, 136, 1024, 128, 64, 3, 4, false);
-  rc |= run(333, 200, 512, 128, 32, 5, 2, true);
-  rc |= run(1000, 136, 1024, 64, 32, 6, 1, false);
+  rc |= run(333, 200, 512, 64, 64, 4, 1, true, 64);
+  rc |= run(1000, 136, 1024, 128, 64, 3, 1, false, 128, 2, 4);
+  rc |= run(777, 264, 512, 128, 64, 4, 1, true, 128, 4, 2);
   const int P[3] = {33600, 8400, 2100}, C[3] = {128, 256, 512};
   for (int s = 0; s < 3; s++) {
     rc |= run(P[s], C[s], 9 * C[s], 0, 0, 0, 0, true);    // forward, planned
     rc |= run(P[s], 9 * C[s], C[s], 0, 0, 0, 0, false);   // backward-data, planned
   }
-  const int V[][3] = {{128, 64, 2}, {128, 64, 3}, {128, 64, 4}, {128, 32, 3}, {128, 32, 4}, {128, 32, 5}, {128, 32, 6}, {128, 32, 8},
-                      {64, 64, 2}, {64, 64, 3}, {64, 64, 4}, {64, 64, 5}, {64, 32, 4}, {64, 32, 6}};
+  // {BM, BN, BK, NST, WM, WN}
+  const int V[][6] = {{128, 128, 64, 2, 2, 2}, {128, 128, 64, 3, 2, 2}, {128, 128, 64, 4, 2, 2},
+                      {128, 128, 64, 2, 2, 4}, {128, 128, 64, 3, 2, 4}, {128, 128, 64, 4, 2, 4},
+                      {128, 128, 64, 2, 4, 2}, {128, 128, 64, 3, 4, 2}, {128, 128, 64, 4, 4, 2},
+                      {128, 128, 32, 4, 2, 4}, {128, 128, 32, 6, 2, 4},
+                      {64, 128, 64, 2, 2, 2}, {64, 128, 64, 3, 2, 4}, {64, 128, 64, 4, 2, 4},
+                      {64, 64, 64, 2, 2, 2}, {64, 64, 64, 4, 2, 2}};
   printf("---- no tail: 256 tiles of 128 rows\n");
-  for (auto& v : V) rc |= run(32768, 128, 1152, v[0], v[1], v[2], 1, false);
+  for (auto& v : V) rc |= run(32768, 128, 1152, v[0], v[2], v[3], 1, false, v[1], v[4], v[5]);
   for (int s = 0; s < 3; s++) {
     printf("---- forward stage %d\n", s + 3);
-    for (auto& v : V)
-      for (int sk = 1; sk <= 4; sk *= 2) {
-        if ((long)cdiv(P[s], v[0]) * cdiv(C[s], 128) * sk > 600 || 9 * C[s] / 64 / sk < 4) continue;
-        rc |= run(P[s], C[s], 9 * C[s], v[0], v[1], v[2], sk, false);
-      }
+    for (auto& v : V) rc |= run(P[s], C[s], 9 * C[s], v[0], v[2], v[3], 1, false, v[1], v[4], v[5]);
     printf("---- backward-data stage %d\n", s + 3);
-    for (auto& v : V) rc |= run(P[s], 9 * C[s], C[s], v[0], v[1], v[2], 1, false);
+    for (auto& v : V) rc |= run(P[s], 9 * C[s], C[s], v[0], v[2], v[3], 1, false, v[1], v[4], v[5]);
   }
   printf(rc ? "FAILED\n" : "ALL OK\n");
   return rc;

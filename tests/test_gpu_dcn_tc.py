@@ -385,8 +385,9 @@ def test_columns_are_not_kept_under_no_grad(monkeypatch):
     """inside Function.forward grad mode is always off, so the decision is taken by the functional alias.
     An eval-mode model's Parameters still require grad; under torch.no_grad() the forward must not allocate or write
     the 9x column (d2amd_deform_conv_forward_columns receives columns = NULL)."""
-    from detectron2_amd.layers import deform_conv as dcmod
+    import importlib
 
+    dcmod = importlib.import_module("detectron2_amd.layers.deform_conv")  # (the package re-exports a function of that name)
     asked = []
     real = dcmod._columns
     monkeypatch.setattr(dcmod, "_columns", lambda L, p, device, wanted: (asked.append(bool(wanted)), real(L, p, device, wanted))[1])
