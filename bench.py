@@ -76,6 +76,11 @@ def parse(argv=None):
     ap.add_argument("--layout", choices=["nchw", "nhwc"], default="nhwc",
                     help="feature memory format: nchw (reference default) or nhwc (torch.channels_last)")
     ap.add_argument("--dtype", choices=["bf16", "fp32", "fp16"], default="bf16")
+    ap.add_argument("--rois", choices=["uniform", "clustered"], default="uniform",
+                    help="maskrcnn_train: what the synthetic RPN head predicts.  uniform (default): random logits / deltas -> "
+                         "proposals spread over the image.  clustered: a TRAINED RPN's picture -- anchors score by their IoU "
+                         "with the 16 GT boxes and regress onto them with N(0, 0.1) jitter, plus ~30 %% isolated background "
+                         "boxes: the 1,000 proposals and the 25 %% positives pile up on 16 objects (VERDICT r04, next 5)")
     ap.add_argument("--grad-allreduce", choices=["bf16", "fp32", "off"], default="bf16",
                     help="N > 1, maskrcnn_train: wire dtype of the gradient all-reduce (bf16 = the reference's "
                          "fp16_compress_hook idea, fp32 = plain DDP) or off")
@@ -189,7 +194,7 @@ def blob_bitmasks(gen, boxes):
 class Workload:
     """maskrcnn_train inputs of one rank (also used by scripts/microbench.py)."""
 
-    def __init__(self, dev, dtype, layout, seed=1234, image_ids=(0, 1), full=True):
+    def __init__(self, dev, dtype, layout, seed=1234, image_ids=(0, 1), full=True, rois="uniform"):
         from detectron2_amd.modeling import Matcher, ROIPooler
         from detectron2_amd.structures import BitMasks, Boxes
 
@@ -246,6 +251,9 @@ class Workload:
                            for a in self.anchor_levels]
         self.rpn_deltas = [torch.stack([torch.randn(a.shape[0], 4, generator=g) * 0.2 for g in gens]).to(dev)
                            for a in self.anchor_levels]
+        self.rois_mode = rois
+        if rois == "clustered":
+            self._clustered_rpn_head(gens)
         self.image_sizes = [(IMG_H, IMG_W)] * n_img
         self.anchor_matcher = Matcher([0.3, 0.7], [0, -1, 1], allow_low_quality_matches=True)   # rpn.py / defaults
         self.proposal_matcher = Matcher([0.5], [0, 1], allow_low_quality_matches=False)          # roi_heads.py
@@ -266,6 +274,37 @@ class Workload:
         self.keygen = DeviceKeyGenerator(dev, seed=seed)
         self.loss_grad = torch.ones((), device=dev)  # d(total loss) / d(mask loss): passed in, not filled per step
 
+    def _clustered_rpn_head(self, gens):
+        """RPN head outputs of a TRAINED model (--rois clustered): objectness grows with the anchor's best IoU over the
+        image's GT boxes, the deltas regress the anchor onto that GT box (Box2BoxTransform.get_deltas, weights 1) with
+        N(0, 0.1) jitter -- proposals = GT jittered by ~0.1 x size -- and 0.2 % of the anchors are isolated false
+        positives (~30 % of the 1,000 proposals that survive the NMS)."""
+        dev = self.dev
+        for i, g in enumerate(gens):
+            gt = self.gt[i].cpu()
+            for l, a in enumerate(self.anchor_levels):
+                a = a.cpu()
+                lt = torch.max(a[:, None, :2], gt[None, :, :2])
+                rb = torch.min(a[:, None, 2:], gt[None, :, 2:])
+                inter = (rb - lt).clamp(min=0).prod(dim=2)
+                area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+                area_g = (gt[:, 2] - gt[:, 0]) * (gt[:, 3] - gt[:, 1])
+                iou = inter / (area_a[:, None] + area_g[None] - inter)
+                best, arg = iou.max(dim=1)
+                t = gt[arg]
+                aw, ah = a[:, 2] - a[:, 0], a[:, 3] - a[:, 1]
+                acx, acy = a[:, 0] + 0.5 * aw, a[:, 1] + 0.5 * ah
+                tw, th = (t[:, 2] - t[:, 0]).clamp(min=1), (t[:, 3] - t[:, 1]).clamp(min=1)
+                tcx, tcy = t[:, 0] + 0.5 * tw, t[:, 1] + 0.5 * th
+                d = torch.stack([(tcx - acx) / aw, (tcy - acy) / ah, torch.log(tw / aw), torch.log(th / ah)], 1)
+                near = best > 0.2
+                d = torch.where(near[:, None], d, torch.zeros_like(d)) + torch.randn(a.shape[0], 4, generator=g) * 0.1
+                logit = 8.0 * best + 0.5 * torch.randn(a.shape[0], generator=g) - 4.0
+                fp = torch.rand(a.shape[0], generator=g) < 0.002
+                logit = torch.where(fp, 2.0 + torch.rand(a.shape[0], generator=g) * 3.0, logit)
+                self.rpn_logits[l][i] = logit.to(dev)
+                self.rpn_deltas[l][i] = d.to(dev)
+
     # algorithmic (compulsory) bytes per op, SURVEY.md 8(d)
     def alg_bytes(self):
         s = self.esize
@@ -282,6 +321,13 @@ class Workload:
                 bwd += s * k * C * R * R + 2 * feat[l]
             d[name + "_fwd"], d[name + "_bwd"] = fwd, bwd
         d["roi_align_pair_fwd"] = d["roi_align_box_fwd"] + d["roi_align_mask_fwd"]  # pool_pair: both units, one launch
+        # compulsory bytes of the FUSED backward launch: both poolers' dY read once, every level's
+        # dX written once -- no zero fill, no second write, no read-back (the 8(d) formula charges those per pooler)
+        lv = [l for l in range(4) if self.box_level_counts[0][l] or self.box_level_counts[1][l]]
+        d["roi_align_pair_bwd_compulsory"] = (sum(s * k * C * 49 for k in self.box_level_counts[0]) +
+                                              sum(s * k * C * 196 for k in self.box_level_counts[1]) + sum(feat[l] for l in lv))
+        d["roi_align_box_bwd_compulsory"] = (sum(s * k * C * 49 for k in self.box_level_counts[0]) +
+                                             sum(feat[l] for l in range(4) if self.box_level_counts[0][l]))
         d["backward"] = d["roi_align_box_bwd"] + d["roi_align_mask_bwd"]  # + the mask loss backward (2 x logits)
         d["backward"] += 2 * 256 * 80 * 784 * s
         n, m = N_GT, 268569
@@ -553,6 +599,44 @@ def connected_forward(w, run=None, rpn_keys=None, roi_keys=None, sync=False):
         (yb, ym), (loss, stats) = poolers(), targets_and_loss()
     return {"anchors": anchors_out, "sample": samp, "box_features": yb, "mask_features": ym, "loss": loss,
             "stats": stats, "done": done}
+
+
+def roi_tile_histogram(w, out):
+    """Per-tile list lengths of the pooler backward for the ROIs this step sampled (8 x 8-pixel tiles of each FPN level;
+    an ROI is on the list of every tile its box, grown by the bilinear footprint of one pixel, overlaps): what the tile
+    gather's split planner and heavy-first queues see.  Host-side arithmetic on the sampled rows, outside any timing."""
+    samp = out["sample"]
+    rois = samp["rois"].reshape(-1, 5).float().cpu()          # box head: 512 rows per image
+    head = samp["head_rois"].reshape(-1, 5).float().cpu()     # mask head: the first 128 rows per image
+    edges = [0, 1, 3, 9, 17, 41, 10 ** 9]
+    names = ["0", "1-2", "3-8", "9-16", "17-40", "> 40"]
+    hist = dict.fromkeys(names, 0)
+    longest, tiles_nonempty, entries = 0, 0, 0
+    for lv, (h, wd) in enumerate(FEAT_HW):
+        ty, tx = (h + 7) // 8, (wd + 7) // 8
+        cnt = torch.zeros(w.n_img, ty + 1, tx + 1, dtype=torch.int64)
+        for r in (rois, head):
+            b = r[:, 1:]
+            keep = (assign_levels(b) == lv) & ((b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]) > 0)
+            if not bool(keep.any()):
+                continue
+            img = r[keep, 0].long()
+            bb = b[keep] / STRIDES[lv] - 0.5
+            x0 = ((bb[:, 0] - 1).floor().clamp(0, wd - 1) / 8).long()
+            x1 = ((bb[:, 2] + 1).ceil().clamp(0, wd - 1) / 8).long()
+            y0 = ((bb[:, 1] - 1).floor().clamp(0, h - 1) / 8).long()
+            y1 = ((bb[:, 3] + 1).ceil().clamp(0, h - 1) / 8).long()
+            one = torch.ones_like(img)
+            for (yy, xx, sgn) in ((y0, x0, 1), (y0, x1 + 1, -1), (y1 + 1, x0, -1), (y1 + 1, x1 + 1, 1)):
+                cnt.index_put_((img, yy, xx), sgn * one, accumulate=True)
+        c = cnt.cumsum(1).cumsum(2)[:, :ty, :tx]
+        for k in range(6):
+            hist[names[k]] += int(((c >= edges[k]) & (c < edges[k + 1])).sum())
+        longest = max(longest, int(c.max()))
+        tiles_nonempty += int((c > 0).sum())
+        entries += int(c.sum())
+    return {"tiles_by_list_length": hist, "longest_list": longest, "tiles_with_rois": tiles_nonempty,
+            "list_entries": entries, "rois": int(rois.shape[0] + head.shape[0])}
 
 
 def connected_step(w, t=None, grads=None):
@@ -924,7 +1008,7 @@ def bench_maskrcnn(args, ctx):
     dev, rank, world, dist = ctx["dev"], ctx["rank"], ctx["world"], ctx["dist"]
     dtype = {"bf16": torch.bfloat16, "fp32": torch.float32, "fp16": torch.float16}[args.dtype]
     # weak scaling: 2 images per GPU; rank r owns images [2r, 2r+1] of the global synthetic batch
-    w = Workload(dev, dtype, args.layout, image_ids=global_image_ids(IMAGES_PER_GPU, rank, world))
+    w = Workload(dev, dtype, args.layout, image_ids=global_image_ids(IMAGES_PER_GPU, rank, world), rois=getattr(args, "rois", "uniform"))
     w.overlap = not args.no_overlap
     w.connected = not args.disconnected
     grads = make_gradient_buckets(args, dev, dist, world)
@@ -1006,7 +1090,8 @@ def bench_maskrcnn(args, ctx):
         k_ms, k_n = ktimes[KERN]
         # the paired launch processes TWO of SURVEY 8(d)'s units (the box head's and the mask head's ROIAlign backward: the
         # reference zero-fills and writes dX once per pooler and sums the two); the one-unit figure is kept beside it
-        kb = alg["roi_align_box_bwd"] + (alg["roi_align_mask_bwd"] if paired else 0)
+        kb_survey = alg["roi_align_box_bwd"] + (alg["roi_align_mask_bwd"] if paired else 0)
+        kb = alg["roi_align_pair_bwd_compulsory"] if paired else alg["roi_align_box_bwd_compulsory"]
         pmc_key = "roi_align_pair_bwd" if paired else "roi_align_box_bwd"
         roof = {"bound": "hbm",
                 "kernel": ("pool_bwd_mfma_kernel<T, 8, true, 16> (d2amd_roi_pooler_backward_pair): ONE tile gather over all "
@@ -1017,22 +1102,21 @@ def bench_maskrcnn(args, ctx):
                 "frac": round(kb / 1e6 / k_ms / HBM_PEAK_GBS, 4),
                 "traffic": pmc_traffic(pmc_key, args.layout),
                 "traffic_source": pmc_source(pmc_key, args.layout),
-                "traffic_note": "PMC bytes of the pooler backward (records + tile lists + tile gather): LESS than the "
-                                "algorithmic figure, which charges a zero fill and a write of every gradient byte per pooler "
-                                "(SURVEY 8(d)); the tile gather writes each byte once and zero-fills nothing it writes -- "
-                                "frac_traffic = these bytes / the kernel's time / peak is the fraction of HBM bandwidth the "
-                                "kernel really uses",
+                "traffic_note": "PMC bytes of the pooler backward (records + tile lists + tile gather); frac_traffic = the "
+                                "gather kernel's own PMC bytes / its time / peak",
                 "alg_bytes_per_launch": int(kb), "ms_per_launch": round(k_ms, 4), "launches_timed": k_n,
                 "units_per_launch": 2 if paired else 1,
-                "alg_bytes_note": "SURVEY 8(d) ROIAlign bwd, per pooler: s*K*C*R^2 (dY) + 2*s*sum_l N*C*H_l*W_l (zero fill + "
-                                  "write of dX)" + ("; this launch does the box head's unit (%d B) and the mask head's (%d B)"
-                                                    % (alg["roi_align_box_bwd"], alg["roi_align_mask_bwd"]) if paired else ""),
+                "alg_bytes_note": "`frac` charges the launch with its COMPULSORY bytes: both poolers' dY read once + every "
+                                  "level's dX written once (no zero fill, no second write: the fused launch does neither).  "
+                                  "`frac_survey_units` is the SURVEY 8(d) formula -- per pooler s*K*C*R^2 (dY) + 2*s*sum_l "
+                                  "N*C*H_l*W_l (zero fill + write of dX), which the reference's two launches would move and "
+                                  "this one does not" + ("; box unit %d B + mask unit %d B" % (alg["roi_align_box_bwd"], alg["roi_align_mask_bwd"]) if paired else ""),
+                "frac_survey_units": round(kb_survey / 1e6 / k_ms / HBM_PEAK_GBS, 4),
+                "survey_bytes_per_launch": int(kb_survey),
                 "timing": "HIP events recorded by the library on the kernel's launch stream right around the launch, mean over "
                           + ("an eager pass of the same number of steps right after the timed region (the timed region "
                              "replays HIP graphs, inside which events cannot be read)" if use_graph else "the timed steps"),
                 "kernels_ms": {k: round(v[0], 4) for k, v in ktimes.items()}}
-        if paired:  # the conservative reading: the whole launch charged with ONE unit's bytes
-            roof["frac_one_unit"] = round(alg["roi_align_box_bwd"] / 1e6 / k_ms / HBM_PEAK_GBS, 4)
         ktraffic = pmc_traffic(pmc_key, args.layout, "kernel_hbm_bytes_per_launch") or roof["traffic"]
         if ktraffic:
             roof["traffic_kernel"] = ktraffic  # the gather kernel alone (the op's figure includes records + binning)
@@ -1056,6 +1140,8 @@ def bench_maskrcnn(args, ctx):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "maskrcnn_r50fpn_train_hotpath_bs2_800x1344 (BASELINE configs[1]; configs[2] at n_gpus 8)",
                    "layout": args.layout, "global_batch": world * w.n_img, "ops_per_step": counts,
+                   "rois": w.rois_mode + (" (a trained RPN's picture: proposals and positives clustered on the 16 GT boxes)"
+                                          if w.rois_mode == "clustered" else " (random RPN head: proposals spread over the image)"),
                    "step": ("connected: RPN selection + NMS -> label_and_sample_proposals on the NMS's device-side counts -> "
                             "box pooler on the 512 sampled rows / image, mask pooler + targets + masked loss on their "
                             "first 128 rows (both poolers as ONE launch per direction: pool_pair_rois / "
@@ -1077,6 +1163,11 @@ def bench_maskrcnn(args, ctx):
         "ops": ops,
         "ops_note": f"per-op times: separate untimed pass of {bsteps} steps with HIP events around every op",
     }
+    if w.connected:
+        try:  # (diagnostic: the distribution the tile gather worked on; one eager step after everything timed)
+            out["roi_tiles"] = roi_tile_histogram(w, connected_step(w))
+        except Exception as e:
+            out["roi_tiles"] = {"error": f"{type(e).__name__}: {e}"}
     if allreduce_info is not None:
         out["allreduce"] = allreduce_info
     if not args.no_cpu_baseline and world == 1:
@@ -1533,6 +1624,19 @@ def main():
                 r = fn(a2, ctx)
                 extra[name] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype",
                                                  "config", "roofline", "ops") if k in r}
+            # the same connected step (a) fed NCHW features -- what an UNMODIFIED model hands the poolers: channels_last
+            # staging copies and the transposes of results / gradients included -- and (b) with a
+            # trained RPN's clustered proposals (weak 8): their own short lines
+            for name, over in (("nchw_drop_in", {"layout": "nchw"}), ("clustered_rois", {"rois": "clustered"})):
+                a2 = copy.copy(args)
+                a2.steps, a2.warmup, a2.no_cpu_baseline = 100, 20, True
+                for k, v in over.items():
+                    setattr(a2, k, v)
+                torch.cuda.synchronize()
+                r = bench_maskrcnn(a2, ctx)
+                extra[name] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config",
+                                                 "roofline", "roi_tiles") if k in r}
+                extra[name]["vs_default_step"] = round(r["ms_per_step"] / out["ms_per_step"], 3)
             out["extra_workloads"] = extra
     if rank == 0:
         json_out.write(json.dumps(out) + "\n")

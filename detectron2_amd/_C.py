@@ -197,6 +197,17 @@ def dtype_code(t):
         raise RuntimeError(f"detectron2_amd: unsupported dtype {t.dtype} (float32/float16/bfloat16)")
 
 
+def reference_roi_rounding(rois, feature_dtype):
+    """D2AMD_REFERENCE_ROI_ROUNDING=1: ROIs rounded to the FEATURE dtype before pooling, as the reference does
+    (layers/roi_align.py:60: `rois.to(dtype=input.dtype)`).  Off by default -- the kernels take fp32 ROIs whatever the
+    features are, which is the better numerics (fp16 coordinates above 1,024 px are 1 px apart: up to 0.18 of the feature
+    range, tests/test_gpu_pooler.py) -- on for strict parity with an fp16 / bf16 reference run.  -> fp32 tensor."""
+    r = rois.detach()
+    if feature_dtype in (torch.float16, torch.bfloat16) and os.environ.get("D2AMD_REFERENCE_ROI_ROUNDING") == "1":
+        r = r.to(feature_dtype)
+    return r.float().contiguous()
+
+
 def require_gpu(*tensors, op="op"):
     for t in tensors:
         if t is not None and not t.is_cuda:

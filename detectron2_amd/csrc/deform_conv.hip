@@ -612,12 +612,17 @@ static bool vec_ok(const DcnShape& s) {
   return s.C % 4 == 0 && s.Cg % 4 == 0 && s.cpg % 4 == 0 && s.Cog % 4 == 0 && s.Co % 4 == 0;
 }
 
+static DcnSide* dcn_side(hipStream_t caller);  // (below)
+
 template <typename T>
 static int fwd_host(const DcnShape& s, const void* x, const void* offset, const void* mask, const void* weight,
                     const void* bias, void* out, const DcnWs& w, hipStream_t st) {
   if (s.B == 0) return D2AMD_OK;
   if (w.nhwc) {  // a channels_last caller: x is what the kernels read, out is written [position][Co]
     if constexpr (sizeof(T) == 2) {
+      if (w.cp.ok && w.col_saved) (void)dcn_side(st);  // (a training forward: the backward's second stream is created and
+                                                       // probed HERE -- two stream synchronisations the first time --
+                                                       // not inside the first backward call: ADVICE r04)
       if (w.cp.ok)
         return dcn_colpath_forward<T>(s, w.cp, x, offset, mask, weight, bias, out, w.col_saved ? w.col_saved : w.cp_col,
                                       w.cp_wpack, w.col_saved ? (char*)w.col_saved + al(w.cp.col_bytes) : nullptr, st);

@@ -1948,9 +1948,22 @@ int dcn_tc_backward_data_gather(const DcnShape& s, const TcBwPlan& pl, const voi
   // the binning (behind the zero fill of its counters) -- on the side stream when there is one: only the column gather
   // at the end of this function reads the lists
   hipStream_t bst = st;
+  // Every exit from here on -- an error return included -- leaves the caller's stream WAITING for whatever was enqueued
+  // on the side stream (an unjoined fork would let the side stream read dY / the column / the workspace
+  // after Python frees them, and leaves a stream capture with a dangling branch).  The success path joins in the
+  // caller (deform_conv.hip: bwd_host) once the main-stream work is enqueued too.
+  struct SideJoin {
+    const DcnSide* sd; hipStream_t st; bool armed = false, ok = false;
+    ~SideJoin() {
+      if (!sd || !armed || ok) return;
+      (void)hipEventRecord(sd->join, sd->stream);
+      (void)hipStreamWaitEvent(st, sd->join, 0);
+    }
+  } side_join{side, st};
   if (side) {
     D2_HIP_OK(hipEventRecord(side->bin, st));  // (the fork point)
     D2_HIP_OK(hipStreamWaitEvent(side->stream, side->bin, 0));
+    side_join.armed = true;
     if (side->fork) bst = side->stream;
   }
   hipLaunchKernelGGL((dcn_bin_samples_kernel<T>), dim3(cdiv(nsamp, 256)), dim3(256), 0, bst, s, (const T*)offset,
@@ -2008,6 +2021,7 @@ int dcn_tc_backward_data_gather(const DcnShape& s, const TcBwPlan& pl, const voi
     if (timed2) timing_end("dcn_bwd_gather", st);
     D2_LAUNCH_OK();
   }
+  side_join.ok = true;
   return D2AMD_OK;
 }
 template int dcn_tc_backward_data_gather<bf16_t>(const DcnShape&, const TcBwPlan&, const void*, const void*, const void*,

@@ -1103,11 +1103,14 @@ __device__ __forceinline__ bool nms_mask_rot_tile_compact(const float* __restric
     const uint32_t jcls = (uint32_t)__shfl((int)col_cls, j);
     bool cand = (jcls == my_cls) && (row < n) && (col0 + j > row) && !rot_pair_is_zero(rbx, jb);
     // IoU = inter / (a1 + a2 - inter) <= min(a1, a2) / max(a1, a2): a pair whose area ratio is below the threshold by
-    // more than 1 % cannot reach it (the clip's rounding is ~1e-6 of the areas once every side is >= 0.01; smaller
-    // boxes take the clip: see rot_quick_reject)
+    // more than 1 % cannot reach it -- for boxes whose sides are all >= 1 px.  The clip the reference runs accepts
+    // vertices up to EPS / |side| outside a box (EPS = 1e-5 absolute, box_iou_rotated_utils.h:79-164): at side 0.01 that
+    // is 10 % of the side and the intersection hull can exceed the smaller box by far more than 1 % (0.01 x
+    // 0.01 against 0.011 x 0.019 -> reference IoU 0.59 at area ratio 0.48); at side >= 1 it is <= 1e-5 of it.  Smaller
+    // boxes take the clip.
     {
       const float a1 = rbx[2] * rbx[3], a2 = jb[2] * jb[3];
-      const bool sized = rbx[2] >= 0.01f && rbx[3] >= 0.01f && jb[2] >= 0.01f && jb[3] >= 0.01f;
+      const bool sized = rbx[2] >= 1.f && rbx[3] >= 1.f && jb[2] >= 1.f && jb[3] >= 1.f;
       cand = cand && !(sized && fminf(a1, a2) < thr_ratio * fmaxf(a1, a2));
     }
     cmask |= cand ? (1ull << j) : 0ull;

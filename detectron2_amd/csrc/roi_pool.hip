@@ -426,7 +426,19 @@ constexpr int QTAKE = 64, QTAKE_PITCH = 32;  // (word 1 of a queue's line: scrat
 // (Late round 3: for the bench's lists -- longest 33 -- cutting at 24 changes neither gather (65.1 / 38.9 us with and
 // without, same box) while the planner costs the binning kernel 4.3 us of its 17.9 on the step's critical path.  Lists
 // are cut from 40 entries on now, and the planner only runs when a binning wave has SEEN such a list.)
-constexpr int PART_LEN = 16, SPLIT_MIN = 40, MAX_PARTS = 6;
+#ifndef D2AMD_SPLIT_MIN
+#define D2AMD_SPLIT_MIN 40
+#endif
+#ifndef D2AMD_PART_LEN
+#define D2AMD_PART_LEN 16
+#endif
+// (Round 5, --rois clustered: a trained RPN piles the 1,000 proposals and the positives on 16 objects -- 211 tiles with
+// 17-40 entries, 17 with more, longest 52 (bench.py: roi_tiles) -- and with the cut at 40 the paired gather took 133.8 us
+// against 82 for the spread-out lists.  Same-box A/B of (SPLIT_MIN, PART_LEN): (40, 16) 133.8 | (24, 16) 116.4 | (20, 10)
+// 104.2 | (16, 8) 101.6 | (12, 8) 114.8 | (12, 6) 122.1 us (finer cuts exhaust the scratch slots, and every part pays
+// the tile's prologue and a scratch round trip); the spread-out lists (longest 16) never reach the planner: 80-82 us
+// with every setting.)
+constexpr int PART_LEN = 8, SPLIT_MIN = 16, MAX_PARTS = 6;
 constexpr int SCR_PER_XCD_MAX = 96;  // scratch slots per XCD queue (64 px x C fp32 each: 48 MB at C = 256)
 constexpr int SPLIT_MAX_SLABS = 4;   // channel slabs (of 256 channels, 16-bit) a split tile may have: one ticket each
 constexpr int QTICKETS = 8 * SCR_PER_XCD_MAX * SPLIT_MAX_SLABS;

@@ -23,6 +23,8 @@
 
 #include "topk.h"
 
+#include <mutex>
+
 namespace d2amd {
 
 constexpr int TK_THREADS = 256;
@@ -948,7 +950,11 @@ __global__ __launch_bounds__(TK_THREADS, 4) void tk_gather_kernel(TkParams P, Se
   for (int q = 1; q < TOPK_MAX_LEVELS; q++)
     if (q == l) { cap = Q.cap[q]; poff = Q.off[q]; }
   unsigned long long* out_pool = Q.mem + (long)img * Q.per_img + poff;
+#ifdef D2AMD_TOPK_STAMPS  // (profiling builds only: -DD2AMD_TOPK_STAMPS, scripts/topk_stamps.py)
 #define TKST(k) do { if (P.stamps && tid == 0) P.stamps[((size_t)seg * gridDim.x + blockIdx.x) * 6 + (k)] = wall_clock64(); } while (0)
+#else
+#define TKST(k) do { } while (0)
+#endif
   TKST(0);
   const bool whole = base0 + SPAN <= size;  // uniform: the span exists and every group of it is complete
   constexpr int NV = TK_GGROUP * TK_ITEMS;  // values per thread and group
@@ -1459,14 +1465,17 @@ int topk_select(const TopkInput& in, bool use_thr, float xmin, uint32_t* sel, in
       else if (!vec) hipLaunchKernelGGL((tk_hist0_span_kernel<8, false>), ggrid, block, 0, s, P, w.hist);
       else hipLaunchKernelGGL((tk_hist0_span_kernel<8, true>), ggrid, block, 0, s, P, w.hist);
     }
+#ifdef D2AMD_TOPK_STAMPS
     const char* stamp_path = getenv("D2AMD_TOPK_STAMPS");  // profiling only: per-workgroup stamps of the gather pass
     const size_t stamp_n = (size_t)grid.x * grid.y * 6;
     if (stamp_path) {
       D2_HIP_OK(hipMalloc(&P.stamps, stamp_n * 8));
       D2_HIP_OK(hipMemsetAsync(P.stamps, 0, stamp_n * 8, s));
     }
+#endif
     if (vec) hipLaunchKernelGGL(tk_gather_kernel<true>, ggrid, block, 0, s, P, w.st, w.hist, w.cand, w.kmax, w.pool);
     else hipLaunchKernelGGL(tk_gather_kernel<false>, ggrid, block, 0, s, P, w.st, w.hist, w.cand, w.kmax, w.pool);
+#ifdef D2AMD_TOPK_STAMPS
     if (stamp_path) {
       D2_HIP_OK(hipStreamSynchronize(s));
       unsigned long long* h = (unsigned long long*)malloc(stamp_n * 8);
@@ -1482,6 +1491,7 @@ int topk_select(const TopkInput& in, bool use_thr, float xmin, uint32_t* sel, in
       (void)hipFree(P.stamps);
       P.stamps = nullptr;
     }
+#endif
     static const bool no_small = getenv("D2AMD_TOPK_POOL_NO_SMALL") != nullptr;
     TkPool Q = w.pool;
     Q.no_small = no_small ? 1 : 0;
@@ -1525,10 +1535,16 @@ int topk_select(const TopkInput& in, bool use_thr, float xmin, uint32_t* sel, in
     const size_t others = (size_t)(runs - 1) * run * 8;
     static const bool no_lds_merge = getenv("D2AMD_TOPK_MERGE_GLOBAL") != nullptr;  // A/B switch
     if (others <= 152 * 1024 && run % 1024 == 0 && !no_lds_merge) {
-      static bool attr_set = false;
-      if (!attr_set) {
-        D2_HIP_OK(hipFuncSetAttribute((const void*)tk_merge_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-        attr_set = true;
+      {  // the opt-in for > 64 KB of dynamic LDS is PER DEVICE: one flag per device, under a mutex
+        static std::mutex mu;
+        static bool attr_set[64] = {};
+        int dev = 0;
+        D2_HIP_OK(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> lock(mu);
+        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+          D2_HIP_OK(hipFuncSetAttribute((const void*)tk_merge_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+          if (dev >= 0 && dev < 64) attr_set[dev] = true;
+        }
       }
       hipLaunchKernelGGL(tk_merge_lds_kernel, dim3(in.N * in.L, cdiv(w.kmax, 1024)), dim3(1024), others, s, P, w.st, w.cand,
                          w.kmax, run, sel);

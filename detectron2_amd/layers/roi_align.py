@@ -78,7 +78,7 @@ class _ROIAlign(Function):
             ctx.cfg = (ph, pw, float(spatial_scale), int(sampling_ratio), bool(aligned), tuple(input.shape), "f64")
             return f64_forward(input, rois, ph, pw, spatial_scale, sampling_ratio, aligned, False)
         x, layout = _prep_input(input)
-        rois = rois.detach().float().contiguous()
+        rois = _C.reference_roi_rounding(rois, input.dtype)
         n, c, h, w = x.shape
         k = rois.shape[0]
         out = _empty_like_layout(x, (k, c, ph, pw), layout)

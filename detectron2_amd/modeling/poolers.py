@@ -22,6 +22,7 @@ gathers ADD to it (d2amd_roi_pooler_backward_accumulate): no separate sum, empty
 sum.  A pooler whose result is unused contributes nothing, as in plain autograd.
 """
 import ctypes
+import os
 import math
 from typing import List
 
@@ -250,6 +251,12 @@ class _FusedROIPool(Function):
         # rois: the (M, 5) pooler-format tensor, or a tuple of per-image (n_i, 4) fp32 HIP box tensors -- then the
         # conversion happens inside the same C call (d2amd_roi_pooler_forward_box_lists: no torch.cat, one call less)
         box_lists = None
+        if os.environ.get("D2AMD_REFERENCE_ROI_ROUNDING") == "1" and feats[0].dtype in (torch.float16, torch.bfloat16):
+            # strict-reference mode (_C.reference_roi_rounding): the ROIs as the reference's per-level ROIAlign sees them
+            if isinstance(rois, tuple):
+                rois = tuple(_C.reference_roi_rounding(b, feats[0].dtype) for b in rois)
+            else:
+                rois = _C.reference_roi_rounding(rois, feats[0].dtype)
         if isinstance(rois, tuple):
             box_lists = rois
             rois = torch.empty((sum(int(b.shape[0]) for b in box_lists), 5), dtype=torch.float32,
@@ -560,8 +567,17 @@ class PairBackwardPlan:
         _C.check(rc)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
-        self.ready = (ev, ws, wsb, grads, (rois1.data_ptr(), rois2.data_ptr(), k1, k2, cfgs[0], cfgs[1], (n, c), tuple(hw), dt))
+        # the plan KEEPS the ROI tensors (an address alone can be reused by the caching allocator after a skipped backward)
+        # and their versions (an in-place edit between prepare() and the backward makes the binning stale)
+        self.ready = (ev, ws, wsb, grads, (rois1, rois2, rois1._version, rois2._version, k1, k2, cfgs[0], cfgs[1], (n, c),
+                                           tuple(hw), dt))
         return True
+
+    def matches(self, ready, rois1, rois2, cfg1, cfg2, nc, hw, dt):
+        r1, r2, v1, v2, k1, k2, c1, c2, nc0, hw0, dt0 = ready[4]
+        same = lambda a, b, v: a.data_ptr() == b.data_ptr() and a.shape == b.shape and b._version == v and a.device == b.device
+        return (same(rois1, r1, v1) and same(rois2, r2, v2) and (c1, c2, nc0, hw0, dt0) == (cfg1, cfg2, nc, tuple(hw), dt)
+                and r1._version == v1 and r2._version == v2)
 
 
 def _pair_cfg(p):
@@ -632,9 +648,8 @@ class _FusedROIPoolPair(Function):
         ready = ctx.plan.ready if ctx.plan is not None else None
         if ctx.plan is not None:
             ctx.plan.ready = None
-        if (ready is not None and len(works) == 2 and _PAIR and ready[4] == (rois1.data_ptr(), rois2.data_ptr(),
-                                                                              int(rois1.shape[0]), int(rois2.shape[0]), cfg1,
-                                                                              cfg2, (n, c), tuple(hw), ctx.dtype)):
+        if (ready is not None and len(works) == 2 and _PAIR and
+                ctx.plan.matches(ready, rois1, rois2, cfg1, cfg2, (n, c), hw, ctx.dtype)):
             ev, ws, wsb, grads, _ = ready
             cur = torch.cuda.current_stream(dev)
             cur.wait_event(ev)

@@ -706,6 +706,63 @@ def test_fp16_rois_are_not_rounded_to_the_feature_dtype_and_what_that_changes():
     assert np.abs(y2 - same).max() <= 2.0 ** -10 * np.abs(same).max() + 1e-4
 
 
+@pytest.mark.parametrize("thr", [0.3, 0.5, 0.7])
+def test_nms_rotated_sub_pixel_boxes(thr):
+    """boxes of 0.01-0.05 px -- the reference's clip tolerance (EPS 1e-5 ABSOLUTE) is up to 10 % of their sides,
+    so their IoU can exceed the area ratio: the mask kernel's area-ratio shortcut must not apply to them (it is limited to
+    sides >= 1 px).  Kept sets equal the oracle's full clip, bit for bit."""
+    rng = np.random.default_rng(int(thr * 1000))
+    boxes, scores = [], []
+    for g in range(200):
+        cx, cy = rng.uniform(10, 11, 2)
+        w, h = rng.uniform(0.01, 0.05, 2)
+        ang = rng.uniform(-90, 90)
+        boxes.append([cx, cy, w, h, ang]); scores.append(1.0 - 1e-3 * g)
+        boxes.append([cx + rng.uniform(-0.002, 0.002), cy + rng.uniform(-0.002, 0.002), w * rng.uniform(0.6, 1.9),
+                      h * rng.uniform(0.6, 1.9), ang + rng.uniform(-3, 3)])
+        scores.append(0.5 - 1e-3 * g)
+    b = np.asarray(boxes, np.float32)
+    s = np.asarray(scores, np.float32)
+    want = oracle.nms_rotated(b, s, thr)
+    got = nms_rotated(torch.from_numpy(b).to(DEV), torch.from_numpy(s).to(DEV), thr).cpu().numpy()
+    assert np.array_equal(got, want), (len(got), len(want))
+    idx = np.zeros(len(b), np.int64)
+    got_b = layers.batched_nms_rotated(torch.from_numpy(b).to(DEV), torch.from_numpy(s).to(DEV), torch.from_numpy(idx).to(DEV), thr)
+    assert np.array_equal(got_b.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_reference_roi_rounding_switch(dtype, monkeypatch):
+    """D2AMD_REFERENCE_ROI_ROUNDING=1 (missing 4): the ROIs are rounded to the feature dtype before pooling,
+    as layers/roi_align.py:60 does -- ROIAlign and the fused ROIPooler then equal the oracle on the ROUNDED boxes (what
+    the reference computes) to the 16-bit output rounding, and differ from the default (unrounded) result."""
+    from detectron2_amd.modeling import ROIPooler
+    from detectron2_amd.structures import Boxes
+
+    rng = np.random.default_rng(78)
+    N, C, H, W = 1, 8, 200, 336
+    x = torch.from_numpy(rng.uniform(-1, 1, (N, C, H, W)).astype(np.float32)).to(dtype)
+    rois = random_rois(rng, 64, N, W, H, 0.25, 16.0)
+    xt = x.to(DEV)
+    rt = torch.from_numpy(rois).to(DEV)
+    ulp = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+    plain = ROIAlign((7, 7), 0.25, 0, True)(xt, rt).float().cpu().numpy()
+    monkeypatch.setenv("D2AMD_REFERENCE_ROI_ROUNDING", "1")
+    strict = ROIAlign((7, 7), 0.25, 0, True)(xt, rt).float().cpu().numpy()
+    rounded = torch.from_numpy(rois).to(dtype).float().numpy()
+    want = oracle.roi_align_forward(x.float().numpy(), rounded, (7, 7), 0.25, 0, True)
+    assert np.abs(strict - want).max() <= ulp * np.abs(want).max() + 1e-4
+    assert np.abs(strict - plain).max() > 1e-3  # (coordinates up to 1,344 px: the rounding moves the samples)
+    # the fused pooler (one level here: canonical size chosen so that every box maps to p2)
+    pooler = ROIPooler((7, 7), (0.25,), 0, "ROIAlignV2")
+    boxes = [Boxes(rt[:, 1:].clone())]
+    got = pooler([xt.contiguous(memory_format=torch.channels_last)], boxes).float().cpu().numpy()
+    assert np.abs(got - want).max() <= ulp * np.abs(want).max() + 1e-4
+    monkeypatch.delenv("D2AMD_REFERENCE_ROI_ROUNDING")
+    got0 = pooler([xt.contiguous(memory_format=torch.channels_last)], boxes).float().cpu().numpy()
+    assert np.abs(got0 - plain).max() <= ulp * np.abs(plain).max() + 1e-4
+
+
 @pytest.mark.parametrize("thr", [0.3, 0.5, 0.7, 0.9])
 def test_nms_rotated_pairs_at_the_area_ratio_bound(thr):
     """The rotated mask kernel skips the polygon clip for pairs whose area ratio is below 0.99 x threshold (IoU <= min / max
