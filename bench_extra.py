@@ -126,6 +126,47 @@ def infer_step(w, run=None):
     return {"box_features": box_feats, "mask_features": mask_feats, "detections": dets, "masks": pasted}
 
 
+def infer_step_device(w):
+    """The same chain WITHOUT a host sync: fixed-shape intermediates whose valid lengths stay on the
+    device -- the RPN test path's DeviceProposals (1,000 rows per image, counts read by the next kernels),
+    fast_rcnn_inference_device (candidate windows, one batched NMS, 100 rows per image), the mask pooler / mask inference /
+    paste on those 100 rows -- so the whole step is ONE HIP graph and the host reads once, at its end.  -> (finish, pasted):
+    finish() = the read + the exact detection lists (as the synchronous path's), pasted[i] [100, H, W] valid up to them."""
+    from detectron2_amd.layers import paste_masks_in_image
+    from detectron2_amd.modeling import fast_rcnn_inference_device, find_top_rpn_proposals_fused, mask_rcnn_inference
+    from detectron2_amd.structures import Boxes
+
+    n = w.n_img
+    done = find_top_rpn_proposals_fused(w.anchor_levels, w.rpn_logits, w.rpn_deltas, w.image_sizes, 0.7, INFER_PRE_NMS,
+                                        INFER_POST_NMS, 0.0, False, defer=True, host_result=False)
+    dp = done.device
+    assert dp is not None, "the RPN NMS did not run as the batched device pipeline"
+    cnt = dp.counts()
+    slot = torch.arange(INFER_POST_NMS, device=w.dev)
+    unit = torch.cat([dp.boxes[0].new_zeros(2), dp.boxes[0].new_ones(2)])
+    live = [slot < cnt[i] for i in range(n)]
+    pboxes = [torch.where(live[i][:, None], dp.boxes[i], unit) for i in range(n)]
+    box_feats = w.box_pooler(w.feats_nograd, [Boxes(b) for b in pboxes])
+    probs = torch.softmax(torch.cat([w.cls_logits[i] for i in range(n)]), dim=1)
+    # rows past the proposal count predict nothing: all of their probability on the background column
+    lv = torch.cat(live)
+    bg = torch.cat([probs.new_zeros(probs.shape[1] - 1), probs.new_ones(1)])  # (device fills: capturable)
+    probs = torch.where(lv[:, None], probs, bg)
+    boxes = _apply_deltas(torch.cat([w.box_deltas[i] for i in range(n)]), torch.cat(pboxes))
+    rows = [INFER_POST_NMS] * n
+    probs, boxes = probs.split(rows), boxes.reshape(boxes.shape[0], -1).split(rows)
+    dd = fast_rcnn_inference_device(boxes, probs, [(B.IMG_H, B.IMG_W)] * n, INFER_SCORE_THRESH, INFER_NMS, INFER_DETS,
+                                    capacity=6144)
+    mask_feats = w.mask_pooler(w.feats_nograd, [Boxes(b) for b in dd.boxes])
+    insts = [_Inst(c) for c in dd.classes]
+    logits = torch.cat([w.infer_mask_logits[i][:INFER_DETS] for i in range(n)])
+    mask_rcnn_inference(logits, insts)
+    sx, sy = ORIG_W / B.IMG_W, ORIG_H / B.IMG_H
+    scale = torch.cat([dp.boxes[0].new_full((1,), sx), dp.boxes[0].new_full((1,), sy)]).repeat(2)
+    pasted = [paste_masks_in_image(insts[i].pred_masks[:, 0], dd.boxes[i] * scale, (ORIG_H, ORIG_W), 0.5) for i in range(n)]
+    return dd.finish, pasted, (box_feats, mask_feats)
+
+
 def bench_maskrcnn_infer(args, ctx):
     from detectron2_amd import _C as _dc
     from detectron2_amd.sharding import Stopwatch, global_image_ids
@@ -136,16 +177,49 @@ def bench_maskrcnn_infer(args, ctx):
     w = B.Workload(dev, dtype, args.layout, image_ids=ids)
     w.feats_nograd = [f.detach() for f in w.feats]
     infer_inputs(w)
+    # The chain as ONE HIP graph with one host read at its end (infer_step_device); D2AMD_BENCH_INFER_EAGER=1 (or a capture
+    # error): the eager chain with the reference's host syncs (infer_step).  The graph's detections and pasted masks are
+    # checked against the eager chain's before anything is timed.
+    execution, step = None, None
+    if os.environ.get("D2AMD_BENCH_INFER_EAGER") != "1" and not INFER_LOOP:
+        try:
+            with torch.no_grad():
+                g, (fin, pasted, _feats) = B.GraphedStep._capture(lambda: infer_step_device(w))
+                ref = infer_step(w)
+                g.replay()
+                dets, _rows = fin()
+                for i in range(len(ids)):
+                    m = len(dets[i].scores)
+                    assert torch.equal(dets[i].pred_boxes.tensor, ref["detections"][i][0]) and torch.equal(dets[i].scores, ref["detections"][i][1])
+                    assert torch.equal(pasted[i][:m], ref["masks"][i]), "pasted masks of the graph differ from the eager chain's"
+
+            def step(w_, run=None):  # noqa: F811
+                g.replay()
+                d, _r = fin()
+                return {"detections": [(x.pred_boxes.tensor, x.scores, x.pred_classes, x.num_candidates) for x in d],
+                        "masks": [pasted[i][:len(d[i].scores)] for i in range(len(d))]}
+
+            execution = "one HIP graph per step (RPN test path -> box pooler -> box-head inference -> mask pooler -> mask inference -> paste), ONE host read at its end; results checked equal to the eager chain's"
+        except Exception as e:
+            print(f"[bench] maskrcnn_infer: graph capture failed ({type(e).__name__}: {e}); eager", file=__import__("sys").stderr)
+            torch.cuda.synchronize()
+            step = None
+    graphed = step is not None
+    run_step = step if graphed else infer_step
     with torch.no_grad():
         for _ in range(args.warmup):
-            out = infer_step(w)
+            out = run_step(w)
         knames = ["paste_masks", "pool_fwd_r7", "pool_fwd_r14", "nms_mask", "nms_reduce"]
         _dc.lib().d2amd_timing_select(",".join(knames).encode())
         sw = Stopwatch(dist, dev)
         sw.start()
         for _ in range(args.steps):
-            out = infer_step(w)
+            out = run_step(w)
         elapsed = sw.stop()
+        if graphed:  # (a replayed graph has no per-kernel events: an eager pass of the synchronous chain right after)
+            for _ in range(min(args.steps, 10)):
+                infer_step(w)
+            torch.cuda.synchronize()
         ktimes = B.read_kernel_times(knames)
         _dc.lib().d2amd_timing_select(None)
         t = B.Timer()
@@ -181,7 +255,7 @@ def bench_maskrcnn_infer(args, ctx):
         "config": {"workload": "maskrcnn_r50fpn_inference_hotpath_bs2_800x1344 (SURVEY 8(d): paste / box-head NMS rows)",
                    "layout": args.layout, "global_batch": world * n_img, "proposals_per_image": INFER_POST_NMS,
                    "candidates_above_score_thresh": [d[3] for d in out["detections"]], "detections": ndet,
-                   "paste_size": [ORIG_H, ORIG_W], "execution": ("eager; box-head inference per image as the reference (A/B)" if INFER_LOOP else
+                   "paste_size": [ORIG_H, ORIG_W], "execution": execution or ("eager; box-head inference per image as the reference (A/B)" if INFER_LOOP else
                                  "eager; box-head inference fused over the batch (2 host syncs), the other syncs where the reference has them"),
                    "parallelism": f"dp{world}: images sharded, replicas only (inference, no collective)"},
         "roofline": roof,

@@ -145,10 +145,122 @@ __global__ __launch_bounds__(64 * BH_WAVES) void bh_write_kernel(const BhImages 
   }
 }
 
+// ---- the device-side continuation (no host sync between the filter and the NMS, none behind the NMS) -----------------
+// The candidate WINDOW of an image = the first window[i] = min(window, rows[i] * K) slots of its slice of the candidate
+// arrays (never beyond the slice: the next image's candidates start there).  Slots past the image's count are PARKED --
+// zero box, score -inf, classes of their own (num_classes + slot / 64) -- so that an NMS over the whole window treats them as
+// inert rows that sort last (the RPN path's convention for invalid proposals).
+struct BhWindows {
+  long cap_base[D2AMD_POOLER_MAX_IMAGES];
+  int window[D2AMD_POOLER_MAX_IMAGES];
+  int nms_row[D2AMD_POOLER_MAX_IMAGES];          // (take) the image's row of the NMS result; -1: no NMS ran (empty window)
+  const int64_t* keep[D2AMD_POOLER_MAX_IMAGES];  // (take) the NMS's kept indices into the window
+  int n, K, topk;
+};
+__device__ __forceinline__ void bh_window(const BhWindows& Wd, int img, long& base, int& window, int& nms_row,
+                                          const int64_t*& keep) {
+  base = Wd.cap_base[0]; window = Wd.window[0]; nms_row = Wd.nms_row[0]; keep = Wd.keep[0];
+#pragma unroll
+  for (int q = 1; q < D2AMD_POOLER_MAX_IMAGES; q++)
+    if (q == img) { base = Wd.cap_base[q]; window = Wd.window[q]; nms_row = Wd.nms_row[q]; keep = Wd.keep[q]; }
+}
+__global__ __launch_bounds__(256) void bh_park_kernel(const BhWindows Wd, const int64_t* __restrict__ counts,
+                                                      float4* __restrict__ boxes, float* __restrict__ scores,
+                                                      int64_t* __restrict__ classes) {
+  const int img = blockIdx.y, slot = blockIdx.x * 256 + threadIdx.x;
+  long base; int window, nms_row; const int64_t* keep;
+  bh_window(Wd, img, base, window, nms_row, keep);
+  if (slot >= window || slot < counts[img]) return;
+  boxes[base + slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+  scores[base + slot] = -INFINITY;
+  classes[base + slot] = Wd.K + (slot >> 6);  // (a class per 64 parked slots: one 64 x 64 tile each for the NMS's mask, not (parked / 64)^2 / 2)
+}
+// fast_rcnn.py:161-170 at fixed shape: row t < topk of image i = candidate keep[t] of its window while t < min(kept,
+// finite-score kept, topk); behind that a 1 x 1 box at the origin with score 0 / class 0 / row 0 (harmless for the mask
+// pooler, mask inference and paste that follow).  nms_result: the NMS's {kept, flags, finite, 0} rows.
+__global__ __launch_bounds__(256) void bh_take_kernel(const BhWindows Wd, const int64_t* __restrict__ nms_result,
+                                                      const float4* __restrict__ boxes, const float* __restrict__ scores,
+                                                      const int64_t* __restrict__ classes, const int64_t* __restrict__ rows,
+                                                      float4* __restrict__ ob, float* __restrict__ os, int64_t* __restrict__ oc,
+                                                      int64_t* __restrict__ orow, int64_t* __restrict__ ocount) {
+  const int img = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
+  long base; int window, nms_row; const int64_t* keep;
+  bh_window(Wd, img, base, window, nms_row, keep);
+  int64_t nv = 0;
+  if (nms_row >= 0) {
+    const int64_t kept = nms_result[4 * nms_row], fin = nms_result[4 * nms_row + 2];
+    nv = kept < fin ? kept : fin;
+    nv = nv < 0 ? 0 : (nv > Wd.topk ? Wd.topk : nv);
+  }
+  if (t == 0) ocount[img] = nv;
+  if (t >= Wd.topk) return;
+  const long o = (long)img * Wd.topk + t;
+  if (t < nv) {
+    int64_t k = keep[t];
+    k = k < 0 ? 0 : (k >= window ? window - 1 : k);
+    const long p = base + k;
+    ob[o] = boxes[p]; os[o] = scores[p]; oc[o] = classes[p]; orow[o] = rows[p];
+  } else {
+    ob[o] = make_float4(0.f, 0.f, 1.f, 1.f); os[o] = 0.f; oc[o] = 0; orow[o] = 0;
+  }
+}
+
 }  // namespace d2amd
 
 using namespace d2amd;
 
+static int bh_windows(BhWindows& Wd, const int* rows, int num_images, int num_classes, int window, const char* who) {
+  D2_CHECK_ARG(num_images >= 1 && num_images <= D2AMD_POOLER_MAX_IMAGES, "%s: %d images (max %d)", who, num_images,
+               D2AMD_POOLER_MAX_IMAGES);
+  D2_CHECK_ARG(rows && num_classes >= 1 && window >= 1, "%s: bad arguments", who);
+  Wd.n = num_images; Wd.K = num_classes;
+  long base = 0;
+  for (int i = 0; i < num_images; i++) {
+    const long slice = (long)(rows[i] > 0 ? rows[i] : 0) * num_classes;
+    Wd.cap_base[i] = base;
+    Wd.window[i] = (int)(slice < window ? slice : window);
+    Wd.nms_row[i] = -1;
+    base += slice;
+  }
+  return D2AMD_OK;
+}
+
+extern "C" int d2amd_fast_rcnn_park(const int* rows, int num_images, int num_classes, int window, const int64_t* counts,
+                                    float* out_boxes, float* out_scores, int64_t* out_classes, void* stream) {
+  BhWindows Wd{};
+  const int rc = bh_windows(Wd, rows, num_images, num_classes, window, "fast_rcnn_park");
+  if (rc) return rc;
+  D2_CHECK_ARG(counts && out_boxes && out_scores && out_classes, "fast_rcnn_park: null pointer");
+  hipLaunchKernelGGL(bh_park_kernel, dim3(cdiv(window, 256), num_images), dim3(256), 0, (hipStream_t)stream, Wd, counts,
+                     (float4*)out_boxes, out_scores, out_classes);
+  D2_LAUNCH_OK();
+  return D2AMD_OK;
+}
+
+extern "C" int d2amd_fast_rcnn_take(const int* rows, int num_images, int num_classes, int window, int topk,
+                                    const int64_t* const* keep, const int64_t* nms_result, const float* cand_boxes,
+                                    const float* cand_scores, const int64_t* cand_classes, const int64_t* cand_rows,
+                                    float* det_boxes, float* det_scores, int64_t* det_classes, int64_t* det_rows,
+                                    int64_t* det_counts, void* stream) {
+  BhWindows Wd{};
+  const int rc = bh_windows(Wd, rows, num_images, num_classes, window, "fast_rcnn_take");
+  if (rc) return rc;
+  D2_CHECK_ARG(topk >= 1 && keep && nms_result && cand_boxes && cand_scores && cand_classes && cand_rows && det_boxes &&
+               det_scores && det_classes && det_rows && det_counts, "fast_rcnn_take: bad arguments");
+  Wd.topk = topk;
+  int row = 0;
+  for (int i = 0; i < num_images; i++) {  // (images with an empty window took no part in the NMS: keep[i] may be null)
+    if (Wd.window[i] == 0) continue;
+    D2_CHECK_ARG(keep[i] != nullptr, "fast_rcnn_take: image %d: null keep", i);
+    Wd.keep[i] = keep[i];
+    Wd.nms_row[i] = row++;
+  }
+  hipLaunchKernelGGL(bh_take_kernel, dim3(cdiv(topk, 256), num_images), dim3(256), 0, (hipStream_t)stream, Wd, nms_result,
+                     (const float4*)cand_boxes, cand_scores, cand_classes, cand_rows, (float4*)det_boxes, det_scores,
+                     det_classes, det_rows, det_counts);
+  D2_LAUNCH_OK();
+  return D2AMD_OK;
+}
 extern "C" size_t d2amd_fast_rcnn_filter_workspace_bytes(const int* rows, int num_images) {
   long total = 0;
   for (int i = 0; i < num_images; i++) total += rows[i] > 0 ? rows[i] : 0;

@@ -425,13 +425,7 @@ constexpr int QTAKE = 64, QTAKE_PITCH = 32;  // (word 1 of a queue's line: scrat
 // scratch budget is handed out in TILE ORDER by the last binning workgroup to finish (tile_lists_kernel).
 // (Late round 3: for the bench's lists -- longest 33 -- cutting at 24 changes neither gather (65.1 / 38.9 us with and
 // without, same box) while the planner costs the binning kernel 4.3 us of its 17.9 on the step's critical path.  Lists
-// are cut from 40 entries on now, and the planner only runs when a binning wave has SEEN such a list.)
-#ifndef D2AMD_SPLIT_MIN
-#define D2AMD_SPLIT_MIN 40
-#endif
-#ifndef D2AMD_PART_LEN
-#define D2AMD_PART_LEN 16
-#endif
+// were cut from 40 entries on in round 4, and the planner only runs when a binning wave has SEEN such a list.)
 // (Round 5, --rois clustered: a trained RPN piles the 1,000 proposals and the positives on 16 objects -- 211 tiles with
 // 17-40 entries, 17 with more, longest 52 (bench.py: roi_tiles) -- and with the cut at 40 the paired gather took 133.8 us
 // against 82 for the spread-out lists.  Same-box A/B of (SPLIT_MIN, PART_LEN): (40, 16) 133.8 | (24, 16) 116.4 | (20, 10)

@@ -265,6 +265,7 @@ def _nms_images_batched(inputs, iou_threshold, rotated, defer=False, runs=None, 
         return kept, [c[2] for c in counts], vals[4 * cnt:]
 
     finish.gathered = [g[1] for g in gathered]  # per image: the arrays' rows in keep order (valid up to the kept count)
+    finish.keeps = keeps  # per image: the kept indices [n] on the device, valid up to the kept count (result row, word 0)
     # the batched pipeline wrote every image's {kept, flags, finite, 0} row into result_buffer: a device-side consumer
     # may read the counts there (the per-image fallback of nms_images writes its results elsewhere)
     finish.result_on_device = result_buffer is not None

@@ -19,7 +19,7 @@ from ..layers.nms import batched_nms_images
 from ..structures import Boxes
 from .dense_detector import Detections
 
-__all__ = ["fast_rcnn_inference_fused"]
+__all__ = ["fast_rcnn_inference_fused", "fast_rcnn_inference_device", "DeviceDetections"]
 
 
 def fast_rcnn_inference_fused(boxes: Sequence[torch.Tensor], scores: Sequence[torch.Tensor],
@@ -76,3 +76,114 @@ def fast_rcnn_inference_fused(boxes: Sequence[torch.Tensor], scores: Sequence[to
         results.append(det)
         kept_rows.append(out_rows[base[i]:base[i] + cnt[i]][keep])
     return results, kept_rows
+
+
+class DeviceDetections:
+    """Box-head inference results of a batch with their counts left on the device: per image `boxes` [topk, 4], `scores`
+    [topk], `classes` [topk] (int64), `rows` [topk] (kept row indices), valid up to `counts[i]` (int64 device tensor [N]);
+    rows past the count hold a 1 x 1 box at the origin, score 0, class 0 -- harmless for the mask pooler / mask inference /
+    paste that follow at fixed shape.  `finish()` performs the ONE host read of the step (kept counts + overflow flags,
+    already copied to pinned memory behind the kernels) and returns exactly what fast_rcnn_inference_fused returns."""
+
+    def __init__(self, boxes, scores, classes, rows, counts, finish):
+        self.boxes, self.scores, self.classes, self.rows, self.counts, self.finish = boxes, scores, classes, rows, counts, finish
+
+
+def fast_rcnn_inference_device(boxes: Sequence[torch.Tensor], scores: Sequence[torch.Tensor],
+                               image_shapes: Sequence[Tuple[int, int]], score_thresh: float, nms_thresh: float,
+                               topk_per_image: int, capacity: int = None) -> DeviceDetections:
+    """fast_rcnn_inference (roi_heads/fast_rcnn.py:118-170) for the batch WITHOUT a host sync: every intermediate has a
+    fixed shape, the counts are read by the next kernel on the device (what the training step does since round 3), so the
+    whole inference chain can be captured in one HIP graph and the host reads once at its end.
+
+      d2amd_fast_rcnn_filter (candidates in torch.nonzero's order + counts on the device)
+      -> the first `capacity` candidate slots of every image, slots past the count parked (zero box, score -inf, a class
+         of their own: they suppress nothing, are suppressed by nothing and sort last -- the RPN path's convention)
+      -> ONE d2amd_nms_batched over all images -> the first topk kept rows, gathered at fixed shape.
+
+    capacity: candidate slots per image (default: min(rows x classes, the batched NMS's limit of 12,288)).  An image with
+    MORE candidates above `score_thresh` than that cannot be served at fixed shape: `finish()` sees its count and
+    recomputes the batch through fast_rcnn_inference_fused (two syncs) -- results are always the reference's."""
+    from ..layers import ops as _ops
+
+    n_img = len(boxes)
+    assert n_img == len(scores) == len(image_shapes) and n_img > 0 and topk_per_image > 0
+    _C.require_gpu(*boxes, *scores, op="fast_rcnn_inference")
+    dev = boxes[0].device
+    k_cls = int(scores[0].shape[1]) - 1
+    kb = int(boxes[0].shape[1]) // 4
+    bx = [b.detach().float().contiguous() for b in boxes]
+    sc = [s.detach().float().contiguous() for s in scores]
+    rows = [int(s.shape[0]) for s in sc]
+    base = [0]
+    for r in rows:
+        base.append(base[-1] + r * k_cls)
+    L = _C.lib()
+    if _ops._BATCH_MAX is None:
+        _ops._BATCH_MAX = int(L.d2amd_nms_batched_max_boxes())
+    cap = min(max(max(r * k_cls for r in rows), 1), _ops._BATCH_MAX, capacity or (1 << 30))
+    cap = max(cap, topk_per_image)
+    total = max(base[-1], 1)
+    out_boxes = torch.empty((total, 4), dtype=torch.float32, device=dev)
+    out_scores = torch.empty((total,), dtype=torch.float32, device=dev)
+    out_classes = torch.empty((total,), dtype=torch.int64, device=dev)
+    out_rows = torch.empty((total,), dtype=torch.int64, device=dev)
+    counts = torch.zeros((n_img,), dtype=torch.int64, device=dev)
+    with _C.on_device(dev):
+        rows_c = (ctypes.c_int * n_img)(*rows)
+        hw = (ctypes.c_int * (2 * n_img))(*[int(v) for s in image_shapes for v in s])
+        ws_bytes = L.d2amd_fast_rcnn_filter_workspace_bytes(rows_c, n_img)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        ptrs = lambda ts: (ctypes.c_void_p * n_img)(*[t.data_ptr() for t in ts])
+        _C.check(L.d2amd_fast_rcnn_filter(ptrs(bx), ptrs(sc), rows_c, n_img, k_cls, kb, hw, float(score_thresh),
+                                          _C.ptr(out_boxes), _C.ptr(out_scores), _C.ptr(out_classes), _C.ptr(out_rows),
+                                          _C.ptr(counts), _C.ptr(ws), ws_bytes, _C.stream()))
+    with _C.on_device(dev):
+        _C.check(L.d2amd_fast_rcnn_park(rows_c, n_img, k_cls, cap, _C.ptr(counts), _C.ptr(out_boxes), _C.ptr(out_scores),
+                                        _C.ptr(out_classes), _C.stream()))
+    # the windows themselves: views, no copies -- window_i = min(cap, rows_i x classes) slots, never beyond the image's
+    # own slice; images without a slot (no rows) take no part in the NMS
+    win = [min(cap, rows[i] * k_cls) for i in range(n_img)]
+    live_imgs = [i for i in range(n_img) if win[i] > 0]
+    cand = [(out_boxes[base[i]:base[i] + win[i]], out_scores[base[i]:base[i] + win[i]], out_classes[base[i]:base[i] + win[i]])
+            for i in live_imgs]
+    res = torch.zeros(8 * len(live_imgs) + 2 * n_img, dtype=torch.int32, device=dev)  # NMS rows + the candidate counts (int64)
+    res[8 * len(live_imgs):].view(torch.int64).copy_(counts)
+    nms_done = _ops.nms_images(cand, nms_thresh, False, True, None, None, res, True) if live_imgs else None
+    det_b = torch.empty((n_img, topk_per_image, 4), dtype=torch.float32, device=dev)
+    det_s = torch.empty((n_img, topk_per_image), dtype=torch.float32, device=dev)
+    det_c = torch.empty((n_img, topk_per_image), dtype=torch.int64, device=dev)
+    det_r = torch.empty((n_img, topk_per_image), dtype=torch.int64, device=dev)
+    n_valid = torch.empty((n_img,), dtype=torch.int64, device=dev)
+    keeps = [None] * n_img
+    for j, i in enumerate(live_imgs):
+        keeps[i] = nms_done.keeps[j]
+    with _C.on_device(dev):
+        _C.check(L.d2amd_fast_rcnn_take(rows_c, n_img, k_cls, cap, int(topk_per_image),
+                                        (ctypes.c_void_p * n_img)(*[None if k is None else k.data_ptr() for k in keeps]),
+                                        res.data_ptr(), _C.ptr(out_boxes), _C.ptr(out_scores), _C.ptr(out_classes),
+                                        _C.ptr(out_rows), _C.ptr(det_b), _C.ptr(det_s), _C.ptr(det_c), _C.ptr(det_r),
+                                        _C.ptr(n_valid), _C.stream()))
+    det_b, det_s, det_c, det_r = list(det_b), list(det_s), list(det_c), list(det_r)
+
+    def finish():
+        if nms_done is not None:
+            kept_l, finite_l, tail = nms_done(with_finite=True)  # the one host read (pinned mirror behind the kernels)
+        else:
+            kept_l, finite_l, tail = [], [], res.tolist()
+        cnts = [tail[2 * i] for i in range(n_img)]  # (low words of the int64 candidate counts)
+        if any(c > w_ for c, w_ in zip(cnts, win)):  # more candidates than slots: the exact path
+            return fast_rcnn_inference_fused(boxes, scores, image_shapes, score_thresh, nms_thresh, topk_per_image)
+        results, kept_rows = [], []
+        for i in range(n_img):
+            m = 0
+            if i in live_imgs:
+                j = live_imgs.index(i)
+                m = min(topk_per_image, len(kept_l[j]), finite_l[j])
+            det = Detections(tuple(image_shapes[i]), Boxes(det_b[i][:m]), det_s[i][:m], det_c[i][:m])
+            det.num_candidates = cnts[i]
+            results.append(det)
+            kept_rows.append(det_r[i][:m])
+        return results, kept_rows
+
+    return DeviceDetections(det_b, det_s, det_c, det_r, n_valid, finish)

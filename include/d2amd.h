@@ -535,6 +535,25 @@ int d2amd_fast_rcnn_filter(const float* const* boxes, const float* const* scores
                            float* out_boxes, float* out_scores, int64_t* out_classes, int64_t* out_rows,
                            int64_t* counts, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same path WITHOUT a host sync between the filter, the NMS and the top-k cut (fast_rcnn.py:150-170 reads two sizes on
+ * the host per image): every image works on a fixed WINDOW of its candidate slots.
+ * window_i = min(window, rows[i] * num_classes) slots, the first ones of image i's slice of the candidate arrays (the slice
+ * starts at sum_{j<i} rows[j] * num_classes).
+ * d2amd_fast_rcnn_park: slots [counts[i], window_i) become inert rows -- zero box, score -inf, classes >= num_classes (one per 64 slots) -- so that
+ * d2amd_nms_batched over window_i rows per image (idxs = the class array; images with window_i = 0 left out) gives the
+ * reference's kept set for the live rows, in its order, with the parked rows last.
+ * d2amd_fast_rcnn_take: row t < topk of image i = candidate keep[i][t] while t < min(kept, finite-score kept, topk) of its
+ * NMS result row {kept, flags, finite, 0} (nms_result: int64 [images with window_i > 0][4], in image order; keep[i] may
+ * be NULL for the others); rows behind that hold a 1 x 1 box at the origin, score 0, class 0, row 0.
+ * det_*: [num_images][topk] (boxes x 4); det_counts: int64 [num_images]. */
+int d2amd_fast_rcnn_park(const int* rows, int num_images, int num_classes, int window, const int64_t* counts,
+                         float* out_boxes, float* out_scores, int64_t* out_classes, void* stream);
+int d2amd_fast_rcnn_take(const int* rows, int num_images, int num_classes, int window, int topk,
+                         const int64_t* const* keep, const int64_t* nms_result, const float* cand_boxes,
+                         const float* cand_scores, const int64_t* cand_classes, const int64_t* cand_rows,
+                         float* det_boxes, float* det_scores, int64_t* det_classes, int64_t* det_rows,
+                         int64_t* det_counts, void* stream);
+
 /* ---- Mask-head glue.  detectron2/modeling/roi_heads/mask_head.py:31-158.
  * logits [B,C,HW] `dtype` (HW = Hmask*Wmask, contiguous NCHW), classes [B] int64 or NULL (class-agnostic,
  * C == 1), gt_masks [B,HW] uint8 / bool storage (the output of d2amd_bitmask_crop_and_resize).

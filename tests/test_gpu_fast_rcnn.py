@@ -10,7 +10,7 @@ import torch
 from _fast_rcnn_cases import CASES, make
 from conftest import need_reference
 from detectron2_amd import layers
-from detectron2_amd.modeling import fast_rcnn_inference_fused
+from detectron2_amd.modeling import fast_rcnn_inference_device, fast_rcnn_inference_fused
 from oracle import fast_rcnn as ofr
 from oracle import ref
 
@@ -103,3 +103,58 @@ def test_filter_counts_and_order_without_the_nms():
         want = boxes[i].reshape(rows[i], K, 4)[m].copy()
         want[:, 0::2] = np.clip(want[:, 0::2], 0, w); want[:, 1::2] = np.clip(want[:, 1::2], 0, h)
         assert np.array_equal(ob[sl].cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("case", ["maskrcnn", "agnostic", "ragged", "nonfinite", "none_pass", "ties", "many"])
+@pytest.mark.parametrize("capacity", [None, 3000])
+def test_device_path_equals_the_synchronous_one(case, capacity):
+    """fast_rcnn_inference_device: no host sync until finish() (fixed-shape candidate windows, slots past the count
+    parked; counts read by the NMS on the device) -- the detections, their order and the kept rows are those of
+    fast_rcnn_inference_fused bit for bit; an image with more candidates than slots ("many": ~25,000 > 12,288; capacity
+    3,000 for "maskrcnn") is recomputed by finish() through the synchronous path.  The fixed-shape tensors a captured
+    chain consumes agree with the lists up to the count and hold 1 x 1 boxes / zeros behind it."""
+    boxes, scores, shapes, thr, nms, topk = make(case)
+    tb = [torch.from_numpy(b).to(DEV) for b in boxes]
+    ts = [torch.from_numpy(s).to(DEV) for s in scores]
+    want, want_rows = fast_rcnn_inference_fused(tb, ts, shapes, thr, nms, topk)
+    dd = fast_rcnn_inference_device(tb, ts, shapes, thr, nms, topk, capacity=capacity)
+    got, got_rows = dd.finish()
+    counts = dd.counts.tolist()
+    for i in range(len(boxes)):
+        assert torch.equal(got[i].pred_boxes.tensor, want[i].pred_boxes.tensor), (case, i)
+        assert torch.equal(got[i].scores, want[i].scores) and torch.equal(got[i].pred_classes, want[i].pred_classes)
+        assert torch.equal(got_rows[i], want_rows[i])
+        assert got[i].num_candidates == want[i].num_candidates
+        m = len(want[i].scores)
+        if got[i].num_candidates <= (capacity or 12288):  # served at fixed shape
+            assert counts[i] == m and dd.boxes[i].shape == (topk, 4)
+            assert torch.equal(dd.boxes[i][:m], want[i].pred_boxes.tensor) and torch.equal(dd.classes[i][:m], want[i].pred_classes)
+            assert torch.equal(dd.boxes[i][m:], torch.tensor([0.0, 0.0, 1.0, 1.0], device=DEV).expand(topk - m, 4))
+            assert not dd.scores[i][m:].any() and not dd.classes[i][m:].any()
+
+
+def test_device_path_replays_in_a_hip_graph():
+    """The whole call is capturable: replayed on new inputs (copied into the captured buffers) it gives what the eager
+    synchronous path gives for them."""
+    boxes, scores, shapes, thr, nms, topk = make("maskrcnn")
+    tb = [torch.from_numpy(b).to(DEV) for b in boxes]
+    ts = [torch.from_numpy(s).to(DEV) for s in scores]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            fast_rcnn_inference_device(tb, ts, shapes, thr, nms, topk)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        dd = fast_rcnn_inference_device(tb, ts, shapes, thr, nms, topk)
+    for seed in (1, 2):
+        b2, s2, *_ = make("maskrcnn", seed=seed)
+        for t, src in zip(tb + ts, b2 + s2):
+            t.copy_(torch.from_numpy(src))
+        g.replay()
+        got, _rows = dd.finish()
+        want, _ = fast_rcnn_inference_fused(tb, ts, shapes, thr, nms, topk)
+        for a, b in zip(got, want):
+            assert torch.equal(a.pred_boxes.tensor, b.pred_boxes.tensor) and torch.equal(a.scores, b.scores)
