@@ -1424,7 +1424,8 @@ def bench_dcn(args, ctx):
             torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
-    knames = ["dcn_fwd", "dcn_bwd_data", "dcn_bwd_gather", "dcn_bwd_weight"]
+    knames = ["dcn_fwd_col", "dcn_fwd_gemm", "dcn_bwd_dcol_gemm", "dcn_bwd_coord", "dcn_bwd_gather", "dcn_bwd_weight",
+              "dcn_fwd", "dcn_bwd_data"]  # (the last two: the fused kernels of r01-r04, --layout nchw / D2AMD_DCN_FUSED=1)
     graphed = execution != "eager"
     if not graphed:
         _dc.lib().d2amd_timing_select(",".join(knames).encode())
@@ -1453,10 +1454,14 @@ def bench_dcn(args, ctx):
     roof = {"bound": "mfma", "kernel": None, "achieved": None, "peak": MFMA_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": None, "traffic": None}
     if ktimes and args.dtype != "fp32":
-        dom = max(ktimes, key=lambda k: ktimes[k][0] * ktimes[k][1])
+        gemms = [k for k in ktimes if k in ("dcn_fwd_gemm", "dcn_bwd_dcol_gemm", "dcn_bwd_weight", "dcn_fwd", "dcn_bwd_data")]
+        dom = max(gemms or ktimes, key=lambda k: ktimes[k][0] * ktimes[k][1])  # the matrix kernel that takes the most time
         k_ms, k_n = ktimes[dom]
         roof = {"bound": "mfma",
-                "kernel": {"dcn_fwd": "dcn_fwd_wave_kernel / dcn_fwd_tc_kernel (gather + MFMA, no column buffer)",
+                "kernel": {"dcn_fwd_gemm": "gemm_nt_kernel (Y = col Wp^T + bias: dense NT GEMM, LDS-DMA staged, on the column dcn_col_kernel wrote)",
+                           "dcn_bwd_dcol_gemm": "gemm_nt_kernel (dcol = dY Wt^T: dense NT GEMM; writes the 16-bit column the coordinate-gradient "
+                                                "kernel and the dX gather read)",
+                           "dcn_fwd": "dcn_fwd_wave_kernel / dcn_fwd_tc_kernel (gather + MFMA, no column buffer)",
                            "dcn_bwd_data": "dcn_bwd_data_ws_kernel (wave-specialised: dcol = W^T dY on MFMA by the matrix waves -> "
                                            "16-bit column rows + d offset / d mask by the consumer waves)",
                            "dcn_bwd_gather": "dcn_gather_dx_kernel (dX = per-pixel gather of the column rows; HBM/L2 bound, no flops counted)",
@@ -1465,8 +1470,9 @@ def bench_dcn(args, ctx):
                 "frac": round(per_launch / 1e9 / k_ms / MFMA_BF16_TFLOPS, 4), "traffic": pmc_traffic(dom, args.layout),
                 "traffic_source": pmc_source(dom, args.layout),
                 "traffic_all_kernels": {k: pmc_traffic(k, args.layout) for k in ktimes},
-                "sq_counters": "profiles/r04/dcn_sq_counters.json (waves parked in s_waitcnt / barriers 55-60 % of their "
-                               "cycles, VALU issuing 14-19 %: latency-bound, neither pipe saturated)",
+                "frac_step": round(3 * flops_fwd / 1e12 / (elapsed / args.steps) / (MFMA_BF16_TFLOPS / 1e3) / 1e3, 4),
+                "frac_step_note": "the whole step's 3 GEMMs per block (386 GFLOP) over its wall time, against the dense bf16 MFMA "
+                                  "peak: includes the column / coordinate-gradient / gather kernels, which carry no flops",
                 "alg_flops_per_launch": per_launch, "ms_per_launch": round(k_ms, 4), "launches_timed": k_n,
                 "alg_flops_note": "SURVEY 8(d) DCN: 2*Co*Ci*kh*kw*N*Ho*Wo per block and GEMM (9.9 GFLOP for 2 images, "
                                   "identical for res3/res4/res5); mean over the 13 blocks' launches",

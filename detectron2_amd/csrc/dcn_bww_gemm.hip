@@ -209,7 +209,7 @@ BwwGemmPlan dcn_bww_gemm_plan(const DcnShape& s, int dtype, bool nhwc) {
   pl.n_nt = cdiv(pl.Q, 4);
   const long tiles = (long)pl.n_mt * pl.n_nt;
   int ksplit = (int)((512 + tiles - 1) / tiles);  // ~2 workgroups per CU
-  { const char* e = getenv("D2AMD_DCN_BWW_KSPLIT"); if (e && atoi(e) > 0) ksplit = atoi(e); }
+  { const char* e = d2_prof_env("D2AMD_DCN_BWW_KSPLIT"); if (e && atoi(e) > 0) ksplit = atoi(e); }
   int kchunk = cdiv(cdiv(s.P, ksplit), GK) * GK;
   if (kchunk < 8 * GK) kchunk = 8 * GK;  // at least 8 K steps per workgroup
   pl.kchunk = kchunk;

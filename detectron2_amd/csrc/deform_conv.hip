@@ -713,9 +713,9 @@ static DcnSide* dcn_side(hipStream_t caller) {
     // behind the Mask R-CNN step) it made the same step 8.5-8.6 ms, against 3.78 on one stream and 3.88 with the default
     // priority (profiles/r04/LOG.md).
     int lo = 0, hi = 0, prio = 0;
-    static const char* mode = getenv("D2AMD_DCN_SIDE_PRIO");
+    static const char* mode = d2_prof_env("D2AMD_DCN_SIDE_PRIO");
     if (mode && mode[0] != 'f' && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess) prio = mode[0] == 'l' ? lo : hi;
-    static const bool no_probe = getenv("D2AMD_DCN_NO_PROBE") != nullptr;
+    static const bool no_probe = d2_prof_env("D2AMD_DCN_NO_PROBE") != nullptr;
     hipStream_t cand[4] = {nullptr, nullptr, nullptr, nullptr};
     int ncand = 0, pick = 0;
     for (; ncand < (no_probe ? 1 : 4); ncand++) {
@@ -784,7 +784,7 @@ static int bwd_host(const DcnShape& s, const void* x, const void* offset, const 
         DcnSide* sd = dcn_side(st);
         DcnSide side{};
         BwwGemmCall<T> call{&s, &gp, gout, w.col_saved, w.gwr, gweight};
-        static const int side_mode = getenv("D2AMD_DCN_SIDE_MODE") ? atoi(getenv("D2AMD_DCN_SIDE_MODE")) : 3;  // A/B: 1 = binning only, 2 = GEMM only
+        static const int side_mode = d2_prof_env("D2AMD_DCN_SIDE_MODE") ? atoi(d2_prof_env("D2AMD_DCN_SIDE_MODE")) : 3;  // A/B: 1 = binning only, 2 = GEMM only
         if (sd) {
           side = *sd;
           side.work = (gemm_w && (side_mode & 2)) ? bww_gemm_on<T> : nullptr;

@@ -639,7 +639,7 @@ TcPlan dcn_tc_plan_fwd(const DcnShape& s, int dtype) {
   // chains of L2 round trips), not by the number of gathered elements -- halving the workgroups halves those waves.
   // D2AMD_DCN_FWD_BIG = 1 / 2 selects the variants.
   {
-    const char* e = getenv("D2AMD_DCN_FWD_BIG");
+    const char* e = d2_prof_env("D2AMD_DCN_FWD_BIG");
     const int mode = e ? atoi(e) : 0;
     if (s.Cog >= 256 && mode >= 1) {
       NWM = 2;
@@ -685,7 +685,7 @@ static int tc_launch_fwd2(const DcnShape& s, const TcPlan& pl, const TcArgs& a, 
   if (pl.lds > 64 * 1024)
     D2_HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
   const int grid = (a.total + 7) / 8 * 8;
-  const char* sp = getenv("D2AMD_DCN_STAMPS");  // profiling only: dump per-workgroup timestamps to this file
+  const char* sp = d2_prof_env("D2AMD_DCN_STAMPS");  // profiling only: dump per-workgroup timestamps to this file
   TcArgs a2 = a;
   if (sp) {
     D2_HIP_OK(hipMalloc(&a2.stamps, (size_t)grid * 4 * 8));
@@ -727,7 +727,7 @@ int dcn_tc_forward(const DcnShape& s, const TcPlan& pl, const void* x_nhwc, cons
   TcArgs a{};
   a.x = x_nhwc; a.offset = offset; a.mask = mask; a.wp = wp; a.bias = bias; a.out = out; a.partial = partial;
   a.n_pt = pl.n_pt; a.n_cot = pl.n_cot; a.ksplit = pl.ksplit; a.NCH = pl.NCH; a.S = pl.S;
-  { const char* e = getenv("D2AMD_DCN_ABLATE"); a.ablate = e ? atoi(e) : 0; }
+  { const char* e = d2_prof_env("D2AMD_DCN_ABLATE"); a.ablate = e ? atoi(e) : 0; }
   a.out_nhwc = out_nhwc ? 1 : 0;
   a.col_out = (col_out && !pl.wave && pl.NKS == 2 && s.G == 1 && s.DG == 1) ? col_out : nullptr;  // (dcn_bww_gemm_plan)
   const long total = (long)pl.n_pt * pl.n_cot * s.G * pl.ksplit;
@@ -1662,14 +1662,14 @@ static int launch_bwd_data_tc(const DcnShape& s, const BwArgs& a, int grid, size
   const int KH = s.Cog / 32;
   // MEASURED (profiles/r04/dcn_bwd_data_ab.txt, same box): hoisted dY fragments 103.7 us mean per block against 96.1
   // without (the fully unrolled weight pipeline is shallower than the rolling one) -- off unless D2AMD_DCN_BWD_HOIST=1
-  const bool hoist = s.G == 1 && getenv("D2AMD_DCN_BWD_HOIST") != nullptr;
+  const bool hoist = s.G == 1 && d2_prof_env("D2AMD_DCN_BWD_HOIST") != nullptr;
   auto launch = [&](auto kern) -> int {
     if (lds > 48 * 1024)
       D2_HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, s, a);
     return D2AMD_OK;
   };
-  if (a.dcol && getenv("D2AMD_DCN_BWD_WS0") == nullptr) {  // wave-specialised (default); D2AMD_DCN_BWD_WS0: the one-role kernel
+  if (a.dcol && d2_prof_env("D2AMD_DCN_BWD_WS0") == nullptr) {  // wave-specialised (default); D2AMD_DCN_BWD_WS0: the one-role kernel
     const size_t lds_ws = lds + 2 * 64 * BW_CPITCH * sizeof(float);
     if (lds_ws <= 160 * 1024) {
       auto go = [&](auto kern) -> int {
@@ -1695,7 +1695,7 @@ static int launch_bwd_data_tc(const DcnShape& s, const BwArgs& a, int grid, size
 TcBwPlan dcn_tc_plan_bwd(const DcnShape& s, int dtype) {
   TcBwPlan pl{};
   pl.ok = false;
-  if (getenv("D2AMD_DCN_V1") || getenv("D2AMD_DCN_BWD_V1")) return pl;
+  if (getenv("D2AMD_DCN_V1") || d2_prof_env("D2AMD_DCN_BWD_V1")) return pl;
   if (dtype != D2AMD_BF16 && dtype != D2AMD_F16) return pl;
   if (s.Cg % 64 != 0 || s.cpg % 64 != 0 || s.Cog % 32 != 0 || s.K2 > 64 || s.P <= 0) return pl;
   if ((long)s.B * s.H * s.W * s.C >= (1l << 31)) return pl;  // 32-bit element offsets into gx / x
@@ -1707,7 +1707,7 @@ TcBwPlan dcn_tc_plan_bwd(const DcnShape& s, int dtype) {
     // (the wave-specialised gather-mode kernel runs two 6-wave workgroups per CU = 512 slots: res3's 546 tiles stay
     // whole -- tables once per tile, d(offset) / d(mask) by plain stores, no zero fill; the one-role kernels fill 1,024)
     const bool ws = s.DG == 1 && (s.C == 64 || s.C == 128 || s.C == 256 || s.C == 512) && getenv("D2AMD_DCN_BWD_ATOMICS") == nullptr &&
-        getenv("D2AMD_DCN_BWD_WS0") == nullptr;
+        d2_prof_env("D2AMD_DCN_BWD_WS0") == nullptr;
     // (MEASURED: sizing for 512 slots leaves res3's 546 whole-tile workgroups in TWO rounds of full-length workgroups --
     // 1,092 half-length ones fill 2.13 rounds = 1.5 full lengths: bwd_res3 1.02 -> 1.29 ms per step.  1,024 stays.)
     const long want = 1024;
@@ -1993,7 +1993,7 @@ int dcn_tc_backward_data_gather(const DcnShape& s, const TcBwPlan& pl, const voi
     BwArgs a{};
     a.x = x_nhwc; a.offset = offset; a.mask = mask; a.wp = wp; a.gout = gout_nhwc;
     a.gx = nullptr; a.goff = goff; a.gmask = gmask; a.dcol = gw.col;
-    { const char* e = getenv("D2AMD_DCN_ABLATE_BWD"); a.ablate = e ? atoi(e) : 0; }
+    { const char* e = d2_prof_env("D2AMD_DCN_ABLATE_BWD"); a.ablate = e ? atoi(e) : 0; }
     a.tiles_y = pl.tiles_y; a.tiles_x = pl.tiles_x; a.csplit = pl.csplit;
     if (pl.csplit > 1 && !goff_zeroed) {
       if (goff) { const int zrc = zero_async(goff, (size_t)s.B * s.DG * 2 * s.K2 * s.L * 4, st); if (zrc) return zrc; }
@@ -2068,7 +2068,7 @@ int dcn_tc_backward_data(const DcnShape& s, const TcBwPlan& pl, const void* x_nh
   a.x = x_nhwc; a.offset = offset; a.mask = mask; a.wp = wp; a.gout = gout_nhwc;
   a.gx = gx; a.goff = goff; a.gmask = gmask;
   a.tiles_y = pl.tiles_y; a.tiles_x = pl.tiles_x; a.csplit = pl.csplit;
-  { const char* e = getenv("D2AMD_DCN_ABLATE_BWD"); a.ablate = e ? atoi(e) : 0; }
+  { const char* e = d2_prof_env("D2AMD_DCN_ABLATE_BWD"); a.ablate = e ? atoi(e) : 0; }
   if (pl.csplit > 1) {  // channel shares accumulate d(offset) / d(mask) with atomics
     if (goff) { const int zrc = zero_async(goff, (size_t)s.B * s.DG * 2 * s.K2 * s.L * 4, st); if (zrc) return zrc; }
     if (gmask) { const int zrc = zero_async(gmask, (size_t)s.B * s.DG * s.K2 * s.L * 4, st); if (zrc) return zrc; }
@@ -2567,7 +2567,7 @@ __global__ __launch_bounds__(256) void unpack_gw_partials_kernel(const float* __
 TcBwwPlan dcn_tc_plan_bww(const DcnShape& s, int dtype) {
   TcBwwPlan pl{};
   pl.ok = false;
-  if (getenv("D2AMD_DCN_V1") || getenv("D2AMD_DCN_BWW_V1")) return pl;
+  if (getenv("D2AMD_DCN_V1") || d2_prof_env("D2AMD_DCN_BWW_V1")) return pl;
   if (dtype != D2AMD_BF16 && dtype != D2AMD_F16) return pl;
   if (s.Cg % 64 != 0 || s.cpg % 64 != 0 || s.P <= 0 || s.L < 8) return pl;
   if ((long)s.B * s.H * s.W * s.C * 2 >= (1l << 32)) return pl;
@@ -2586,7 +2586,7 @@ TcBwwPlan dcn_tc_plan_bww(const DcnShape& s, int dtype) {
   pl.partial_bytes = (size_t)tiles * (pch / 4) * 4096 * sizeof(float);
   // cooperative kernel: SH output-channel tiles per workgroup share the column gather (A/B: D2AMD_DCN_BWW_COOP=0)
   pl.share = 0;
-  static const bool no_coop = getenv("D2AMD_DCN_BWW_COOP") && atoi(getenv("D2AMD_DCN_BWW_COOP")) == 0;
+  static const bool no_coop = d2_prof_env("D2AMD_DCN_BWW_COOP") && atoi(d2_prof_env("D2AMD_DCN_BWW_COOP")) == 0;
   if (!no_coop && pl.n_cot % 2 == 0) {
     pl.share = pl.n_cot % 4 == 0 ? 4 : 2;
     const int ng = 4 / pl.share;
@@ -2629,7 +2629,7 @@ int dcn_tc_backward_weight(const DcnShape& s, const TcBwwPlan& pl, const void* x
   D2_CHECK_ARG(waves / 4 < (1l << 30), "deform_conv: too many tiles");
   a.total = (int)(waves / 4);
   const int grid = (a.total + 7) / 8 * 8;
-  const char* ab = getenv("D2AMD_DCN_ABLATE_BWW");  // profiling only
+  const char* ab = d2_prof_env("D2AMD_DCN_ABLATE_BWW");  // profiling only
   const bool timed = timing_begin("dcn_bwd_weight", st);
   switch (ab ? atoi(ab) : 0) {
 #ifdef D2AMD_DCN_ABLATION_BUILD

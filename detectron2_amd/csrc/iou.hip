@@ -181,7 +181,7 @@ extern "C" int d2amd_box_iou_rotated(const float* boxes1, int n, const float* bo
   // rows per 64-column wave: 16, or fewer while the launch would have less than ~16 waves per CU (16 x 268,569: 4)
   int rpb = ROT_ROWS;
   while (rpb > 1 && (long)cdiv(m, ROT_BLOCK) * cdiv(n, rpb) < 4096 * 4) rpb >>= 1;
-  { const char* e = getenv("D2AMD_IOU_ROT_ROWS"); if (e && atoi(e) >= 1 && atoi(e) <= ROT_ROWS) rpb = atoi(e); }  // A/B
+  { const char* e = d2_prof_env("D2AMD_IOU_ROT_ROWS"); if (e && atoi(e) >= 1 && atoi(e) <= ROT_ROWS) rpb = atoi(e); }  // A/B
   D2_CHECK_ARG(cdiv(n, rpb) <= 65535, "box_iou_rotated: n too large (%d)", n);
   dim3 grid(cdiv(m, ROT_BLOCK), cdiv(n, rpb));
   const bool timed = timing_begin("iou_rotated", (hipStream_t)stream);

@@ -1741,13 +1741,13 @@ static int nms_mask_reduce(NmsBatch& B, int rotated, bool any_cls, hipStream_t s
   const dim3 mgrid(nb_max, gy, B.count);
   const bool timed_mask = timing_begin("nms_mask", s);
   if (rotated) {
-    static const bool rot_plain = getenv("D2AMD_NMS_ROT_PLAIN") != nullptr;
+    static const bool rot_plain = d2_prof_env("D2AMD_NMS_ROT_PLAIN") != nullptr;
     B.rot_plain = rot_plain ? 1 : 0;
     hipLaunchKernelGGL(nms_mask_rot_kernel, mgrid, dim3(64), 0, s, B);
   } else {
     const MaskThr m = mask_thr(B.thr);
     B.mid = m.mid;
-    static const bool mask_exact = getenv("D2AMD_NMS_MASK_EXACT") != nullptr;  // test switch: literal formula
+    static const bool mask_exact = d2_prof_env("D2AMD_NMS_MASK_EXACT") != nullptr;  // test switch: literal formula
     if (!m.fast || mask_exact) hipLaunchKernelGGL((nms_mask_kernel<false, false>), mgrid, dim3(64), 0, s, B);
     else if (m.tie_up) hipLaunchKernelGGL((nms_mask_kernel<true, true>), mgrid, dim3(64), 0, s, B);
     else hipLaunchKernelGGL((nms_mask_kernel<true, false>), mgrid, dim3(64), 0, s, B);
@@ -1755,7 +1755,7 @@ static int nms_mask_reduce(NmsBatch& B, int rotated, bool any_cls, hipStream_t s
   if (timed_mask) timing_end("nms_mask", s);
   D2_LAUNCH_OK();
   const int rgrid = any_cls ? 512 : 1;
-  const char* red_stamps = getenv("D2AMD_NMS_STAMPS");  // profiling only: per-block stamps of segment 0 of image 0
+  const char* red_stamps = d2_prof_env("D2AMD_NMS_STAMPS");  // profiling only: per-block stamps of segment 0 of image 0
   B.dbg = nullptr;
   if (red_stamps) {
     D2_HIP_OK(hipMalloc(&B.dbg, 256 * 8));

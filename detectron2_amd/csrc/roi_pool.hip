@@ -2194,7 +2194,7 @@ static PoolLevels make_levels(const d2amd_pooler_params* p, const void* const* d
   L.sr = p->sampling_ratio; L.aligned = p->aligned; L.K = K;
   L.min_level = p->min_level; L.max_level = p->max_level; L.canonical_level = p->canonical_level;
   L.canonical_size = p->canonical_box_size;
-  { const char* e = getenv("D2AMD_ABLATE"); L.ablate = e ? atoi(e) : 0; }
+  { const char* e = d2_prof_env("D2AMD_ABLATE"); L.ablate = e ? atoi(e) : 0; }
   L.dbg = nullptr; L.dbg_block = -1; L.wgstamps = nullptr; L.tile_cnt = nullptr; L.tile_list = nullptr; L.queue = nullptr; L.qcap = 0; L.qctr = nullptr; L.qsteal = 0; L.part_scratch = nullptr; L.part_tickets = nullptr; L.tab_off = 0;
   int base = 0;
   for (int l = 0; l < p->num_levels; l++) {
@@ -2237,19 +2237,19 @@ static int pool_fwd_impl(const d2amd_pooler_params* p, const void* const* inputs
     // the bound is the ~5.5 TB/s of tap bytes requested through L1 (each pixel of a bin's footprint is
     // re-requested by the neighbouring bins); 512 threads and ~1,000 workgroups measured best
     int nthr = vec ? 512 : 256;
-    { const char* e = getenv("D2AMD_FWD_THREADS"); if (e && (atoi(e) == 256 || atoi(e) == 512 || atoi(e) == 1024)) nthr = atoi(e); }
+    { const char* e = d2_prof_env("D2AMD_FWD_THREADS"); if (e && (atoi(e) == 256 || atoi(e) == 512 || atoi(e) == 1024)) nthr = atoi(e); }
     if (!vec) nthr = 256;
     const int passes = cdiv((long)bins * cg, nthr);
     int nsplit = K > 0 ? 1024 / K : 1;
-    { const char* e = getenv("D2AMD_FWD_NSPLIT"); if (e && atoi(e) > 0) nsplit = atoi(e); }  // profiling switch
+    { const char* e = d2_prof_env("D2AMD_FWD_NSPLIT"); if (e && atoi(e) > 0) nsplit = atoi(e); }  // profiling switch
     nsplit = nsplit < 1 ? 1 : (nsplit > passes ? passes : nsplit);
     if (nsplit > bins) nsplit = bins;
     D2_CHECK_ARG(nsplit <= 65535, "roi_pooler_forward: internal split too large");
     dim3 grid(K, nsplit);
     PoolFwdPair<T> P2{};
     if (pair) {
-      static const bool wide_env = getenv("D2AMD_FWD_VARIANT") && atoi(getenv("D2AMD_FWD_VARIANT")) == 1;
-      const bool ok = vec && nthr == 512 && !wide_env && perm == nullptr && getenv("D2AMD_POOL_STAMPS") == nullptr &&
+      static const bool wide_env = d2_prof_env("D2AMD_FWD_VARIANT") && atoi(d2_prof_env("D2AMD_FWD_VARIANT")) == 1;
+      const bool ok = vec && nthr == 512 && !wide_env && perm == nullptr && d2_prof_env("D2AMD_POOL_STAMPS") == nullptr &&
           ((uintptr_t)pair->out2 & 15) == 0 && K > 0 && pair->K2 > 0;
       if (!ok) {
         set_error("roi_pooler_forward_pair: outside the paired forward (NHWC, 16-B channel vectors, list order)");
@@ -2258,7 +2258,7 @@ static int pool_fwd_impl(const d2amd_pooler_params* p, const void* const* inputs
       const int bins2 = pair->p2->pooled_h * pair->p2->pooled_w;
       const int passes2 = cdiv((long)bins2 * cg, nthr);
       int ns2 = 1024 / pair->K2;
-      { const char* e = getenv("D2AMD_FWD_NSPLIT2"); if (e && atoi(e) > 0) ns2 = atoi(e); }  // profiling switch
+      { const char* e = d2_prof_env("D2AMD_FWD_NSPLIT2"); if (e && atoi(e) > 0) ns2 = atoi(e); }  // profiling switch
       ns2 = ns2 < 1 ? 1 : (ns2 > passes2 ? passes2 : ns2);
       if (ns2 > bins2) ns2 = bins2;
       const long total = (long)K * nsplit + (long)pair->K2 * ns2;
@@ -2269,7 +2269,7 @@ static int pool_fwd_impl(const d2amd_pooler_params* p, const void* const* inputs
     PoolLevels Lf = L;
     for (int l = 0; l < p->num_levels; l++)
       if ((long)p->H[l] * p->W[l] * p->C >= (1l << 32)) Lf.tab_off = 1;
-    const char* stamp_path = getenv("D2AMD_POOL_STAMPS");  // profiling only: per-workgroup timeline dump
+    const char* stamp_path = d2_prof_env("D2AMD_POOL_STAMPS");  // profiling only: per-workgroup timeline dump
     const long nwg = (long)K * nsplit;
     if (stamp_path) {
       D2_HIP_OK(hipMalloc(&Lf.wgstamps, (size_t)nwg * 5 * 8));
@@ -2282,7 +2282,7 @@ static int pool_fwd_impl(const d2amd_pooler_params* p, const void* const* inputs
     else if (vec && nthr == 512) {
       // 4 loads in flight per lane and <= 84 VGPRs: three 512-thread workgroups per CU instead of two (8 loads, 108
       // VGPRs): 48.3 -> 43.6 us (box), 34.9 -> 30.2 us (mask); D2AMD_FWD_VARIANT=1 selects the previous shape (A/B)
-      static const bool wide = getenv("D2AMD_FWD_VARIANT") && atoi(getenv("D2AMD_FWD_VARIANT")) == 1;
+      static const bool wide = d2_prof_env("D2AMD_FWD_VARIANT") && atoi(d2_prof_env("D2AMD_FWD_VARIANT")) == 1;
       // (Tried in round 3 and removed, commit eb0e005: the forward as a GEMM on the matrix cores -- the ROI's footprint
       // staged once in chunks of pixel rows, weight image [bin][pixel] as hi + lo 16-bit parts, the backward's
       // contraction with bins and pixels swapped.  Within 1 ulp of this kernel on every case, and a workgroup needs
@@ -2329,7 +2329,7 @@ struct SideStream { hipStream_t stream; hipEvent_t fork, join; };
 static SideStream* side_stream() {
   static SideStream table[64];
   static bool made[64] = {};
-  static const bool off = getenv("D2AMD_NO_SIDE_STREAM") != nullptr;
+  static const bool off = d2_prof_env("D2AMD_NO_SIDE_STREAM") != nullptr;
   int dev = 0;
   if (off || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
   if (!made[dev]) {
@@ -2359,7 +2359,7 @@ static long resident_workgroups(const void* fn, int threads) {
   if (used < 16) cache[used++] = Ent{fn, dev, n};
   return n;
 }
-static bool stamp_path_static() { return getenv("D2AMD_POOL_STAMPS_STATIC") != nullptr; }
+static bool stamp_path_static() { return d2_prof_env("D2AMD_POOL_STAMPS_STATIC") != nullptr; }
 
 // levels with at most this many tiles take the GROUPS > 1 kernel (few tiles <=> long ROI lists)
 constexpr int COARSE_TILES = 512;
@@ -2413,7 +2413,7 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
   const long ntiles = pool_ntiles(p);
   const size_t off_cnt = pool_al(need), off_list = off_cnt + pool_al((size_t)ntiles * 4) * (pair ? 2 : 1);
   const bool lists = K > 0 && ntiles > 0 && workspace_bytes >= off_list + (size_t)ntiles * TILE_CAP * sizeof(TileEntry) &&
-      getenv("D2AMD_POOL_NOLISTS") == nullptr;
+      d2_prof_env("D2AMD_POOL_NOLISTS") == nullptr;
   int* tile_cnt = lists ? (int*)((char*)workspace + off_cnt) : nullptr;
   int* tile_cnt1 = lists && pair ? (int*)((char*)workspace + off_cnt + pool_al((size_t)ntiles * 4)) : nullptr;
   TileEntry* tile_list = lists ? (TileEntry*)((char*)workspace + off_list) : nullptr;
@@ -2425,23 +2425,23 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
   long nblocks4 = 0;
   for (int l = 0; l < p->num_levels; l++) nblocks4 += (long)cdiv(cdiv(p->H[l], TILE), 4) * cdiv(cdiv(p->W[l], TILE), 4) * p->N;
   const bool queues = lists && nblocks4 <= 8192 && ntiles < (1l << 24) &&
-      workspace_bytes >= off_q + pool_queue_bytes(ntiles) && getenv("D2AMD_POOL_NOQUEUE") == nullptr;
+      workspace_bytes >= off_q + pool_queue_bytes(ntiles) && d2_prof_env("D2AMD_POOL_NOQUEUE") == nullptr;
   // one launch of the LDS-staged kernel for all levels (16-B channel vectors + work queues), else the two-launch
   // register-gather kernels
-  const bool staged = queues && vec && getenv("D2AMD_POOL_NOSTAGED") == nullptr;
+  const bool staged = queues && vec && d2_prof_env("D2AMD_POOL_NOSTAGED") == nullptr;
   if (accumulate && !staged) {
     set_error("roi_pooler_backward_accumulate: needs the staged tile gather (16-B aligned channel vectors, work queues)");
     return D2AMD_EUNSUPPORTED;
   }
   if (accumulate && K == 0 && phase != 3) return D2AMD_OK;  // nothing to add
   // lists are split only for the kernel that can add the parts: the 16-bit MFMA tile gather
-  static const bool no_mfma_env = getenv("D2AMD_POOL_NOMFMA") != nullptr;
+  static const bool no_mfma_env = d2_prof_env("D2AMD_POOL_NOMFMA") != nullptr;
   const bool split_capable = staged && sizeof(T) == 2 && !no_mfma_env && p->C % 32 == 0 && p->C <= 8192 &&
       nslab <= SPLIT_MAX_SLABS;
   const size_t slot_bytes = (size_t)nslab * 32 * (2 * CT) * sizeof(float);  // 16 accumulators x 2 tiles x 512 threads
   if (pair || probe) {  // the paired gather exists in the persistent MFMA tile gather only
-    static const bool fixed = getenv("D2AMD_POOL_STATIC") != nullptr || getenv("D2AMD_POOL_STAMPS") != nullptr ||
-        getenv("D2AMD_POOL_STAMPS_STATIC") != nullptr;
+    static const bool fixed = d2_prof_env("D2AMD_POOL_STATIC") != nullptr || d2_prof_env("D2AMD_POOL_STAMPS") != nullptr ||
+        d2_prof_env("D2AMD_POOL_STAMPS_STATIC") != nullptr;
     const int pm = p->pooled_h > p->pooled_w ? p->pooled_h : p->pooled_w;
     const bool ok = staged && sizeof(T) == 2 && !no_mfma_env && !fixed && p->C % 32 == 0 && p->C <= 8192 && K_first > 0 &&
         pm <= 8 && phase <= 2 && !accumulate;
@@ -2456,7 +2456,7 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
       if (pass) Q.coarse_mask |= 1u << l;
       Q.pass_base[l] = base[pass];
       base[pass] += ty * tx * p->N;
-      static const int deal_env = getenv("D2AMD_POOL_DEAL") ? atoi(getenv("D2AMD_POOL_DEAL")) : -1;  // A/B: fixed shift
+      static const int deal_env = d2_prof_env("D2AMD_POOL_DEAL") ? atoi(d2_prof_env("D2AMD_POOL_DEAL")) : -1;  // A/B: fixed shift
       const int sh = deal_env >= 0 ? (deal_env > 2 ? 2 : deal_env) : (ty * tx * p->N <= 512 ? 0 : ty * tx * p->N <= 2048 ? 1 : 2);
       Q.deal_shift[l] = sh;
       const int bs = 1 << sh;
@@ -2467,17 +2467,17 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
     }
     for (int x = 0; x < 8; x++) { Q.cap[0] = max(Q.cap[0], per[0][x]); Q.cap[1] = max(Q.cap[1], per[1][x]); }
     // split lists (the MFMA tile gather only): scratch behind the queues, if the caller's workspace has it
-    static const bool no_split = getenv("D2AMD_POOL_NOSPLIT") != nullptr;
+    static const bool no_split = d2_prof_env("D2AMD_POOL_NOSPLIT") != nullptr;
     const int sx = 8 * min(SCR_PER_XCD_MAX, max(16, Q.cap[0] / 3));
     if (split_capable && !no_split && workspace_bytes >= off_q + pool_queue_bytes(ntiles) + (size_t)sx * slot_bytes) {
       Q.scr_total = sx;
       Q.cap[0] += sx;  // a queue holds at most one entry per tile + (all on one XCD) every part
     }
     Q.qbase = QCTR + QTICKETS;
-    static const int thr_s = getenv("D2AMD_POOL_QTHR") ? atoi(getenv("D2AMD_POOL_QTHR")) : 6;
-    static const int thr_f0 = getenv("D2AMD_POOL_QTHR_FINE") ? atoi(getenv("D2AMD_POOL_QTHR_FINE")) : 4;
+    static const int thr_s = d2_prof_env("D2AMD_POOL_QTHR") ? atoi(d2_prof_env("D2AMD_POOL_QTHR")) : 6;
+    static const int thr_f0 = d2_prof_env("D2AMD_POOL_QTHR_FINE") ? atoi(d2_prof_env("D2AMD_POOL_QTHR_FINE")) : 4;
     const int thr_f = staged ? thr_s : thr_f0;
-    static const int thr_c = getenv("D2AMD_POOL_QTHR_COARSE") ? atoi(getenv("D2AMD_POOL_QTHR_COARSE")) : 16;
+    static const int thr_c = d2_prof_env("D2AMD_POOL_QTHR_COARSE") ? atoi(d2_prof_env("D2AMD_POOL_QTHR_COARSE")) : 16;
     Q.thr[0] = thr_f; Q.thr[1] = thr_c;
     Q.mem = (int*)((char*)workspace + off_q);
     Q.esize = (int)sizeof(T);
@@ -2504,7 +2504,7 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
   }
   if (phase == 1) return D2AMD_OK;
   // profiling switches: D2AMD_BWD_CFG = "<fine GROUPS><fine RS><coarse GROUPS><coarse RS>", e.g. 1122
-  static const int cfg = getenv("D2AMD_BWD_CFG") ? atoi(getenv("D2AMD_BWD_CFG")) : 1222;
+  static const int cfg = d2_prof_env("D2AMD_BWD_CFG") ? atoi(d2_prof_env("D2AMD_BWD_CFG")) : 1222;
   const int fg = cfg / 1000 % 10, fr = cfg / 100 % 10, cgp = cfg / 10 % 10, cr = cfg % 10;
   // The coarse-level launch has few, long-running workgroups (latency bound) and the fine-level one
   // fills the chip at 16 waves / CU: they overlap on a library-owned side stream (fork / join with
@@ -2521,20 +2521,20 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
     L.part_scratch = (float*)((char*)workspace + off_q + pool_queue_bytes(ntiles));
     const long total = 8l * L.qcap * nslab;
     if (total == 0) return D2AMD_OK;
-    static const bool static_slots = getenv("D2AMD_POOL_STATIC") != nullptr;  // A/B: one workgroup per queue slot
+    static const bool static_slots = d2_prof_env("D2AMD_POOL_STATIC") != nullptr;  // A/B: one workgroup per queue slot
     D2_CHECK_ARG(total < (1l << 30), "roi_pooler_backward: too many tiles");
-    const char* stamp_path = getenv("D2AMD_POOL_STAMPS");  // profiling only: per-workgroup timeline dump
+    const char* stamp_path = d2_prof_env("D2AMD_POOL_STAMPS");  // profiling only: per-workgroup timeline dump
     if (stamp_path) {
       D2_HIP_OK(hipMalloc(&L.wgstamps, (size_t)total * 5 * 8));
       D2_HIP_OK(hipMemsetAsync(L.wgstamps, 0, (size_t)total * 5 * 8, s));
     }
 #ifdef D2AMD_PROFILE
     static unsigned long long* dbg_dev = nullptr;
-    if (getenv("D2AMD_DBG_BLOCK")) {
+    if (d2_prof_env("D2AMD_DBG_BLOCK")) {
       if (!dbg_dev) (void)hipMalloc(&dbg_dev, 128 * 8);
       (void)hipMemsetAsync(dbg_dev, 0, 128 * 8, s);
       L.dbg = dbg_dev;
-      L.dbg_block = atoi(getenv("D2AMD_DBG_BLOCK"));
+      L.dbg_block = atoi(d2_prof_env("D2AMD_DBG_BLOCK"));
     }
 #endif
     const char* tname = pair ? "pool_bwd_pair" : p->pooled_h <= 7 ? "pool_bwd_staged_r7" : "pool_bwd_staged_r14";
@@ -2542,13 +2542,13 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
     const int pmax = p->pooled_h > p->pooled_w ? p->pooled_h : p->pooled_w;
     bool mfma = false;
     if constexpr (sizeof(T) == 2) {  // 16-bit I/O: contraction on the matrix cores
-      static const bool no_mfma = getenv("D2AMD_POOL_NOMFMA") != nullptr;
+      static const bool no_mfma = d2_prof_env("D2AMD_POOL_NOMFMA") != nullptr;
       mfma = !no_mfma && p->C % 32 == 0 && p->C <= 8192;
       if (mfma) {
         // persistent workgroups: one resident wave of them (a multiple of 8: every XCD gets the same number), each
         // fetching tiles until all queues are empty; never more than there are queue slots
         if (!static_slots && !stamp_path_static()) L.qctr = Q.mem;
-        static const int steal_env = getenv("D2AMD_POOL_STEAL") ? atoi(getenv("D2AMD_POOL_STEAL")) : 0;
+        static const int steal_env = d2_prof_env("D2AMD_POOL_STEAL") ? atoi(d2_prof_env("D2AMD_POOL_STEAL")) : 0;
         L.qsteal = steal_env < 0 ? 0 : steal_env > 7 ? 7 : steal_env;
         // (tried and dropped, profiles/r03/pool_bwd/README.md: no take counters at all -- workgroup j of an XCD walking
         // its queue with a fixed stride: the gap between tiles halves, but the unsorted queue leaves the workgroups 25 us
@@ -2647,14 +2647,14 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
     }
 #ifdef D2AMD_PROFILE
     static unsigned long long* dbg_dev = nullptr;
-    if (getenv("D2AMD_DBG_BLOCK")) {
+    if (d2_prof_env("D2AMD_DBG_BLOCK")) {
       if (!dbg_dev) (void)hipMalloc(&dbg_dev, 128 * 8);
       (void)hipMemsetAsync(dbg_dev, 0, 128 * 8, ls);
       L.dbg = dbg_dev;
-      L.dbg_block = (pass == atoi(getenv("D2AMD_DBG_PASS") ? getenv("D2AMD_DBG_PASS") : "0")) ? atoi(getenv("D2AMD_DBG_BLOCK")) : -1;
+      L.dbg_block = (pass == atoi(d2_prof_env("D2AMD_DBG_PASS") ? d2_prof_env("D2AMD_DBG_PASS") : "0")) ? atoi(d2_prof_env("D2AMD_DBG_BLOCK")) : -1;
     }
 #endif
-    const char* stamp_path = getenv("D2AMD_POOL_STAMPS");  // profiling only: per-workgroup timeline dump
+    const char* stamp_path = d2_prof_env("D2AMD_POOL_STAMPS");  // profiling only: per-workgroup timeline dump
     if (stamp_path) {
       D2_HIP_OK(hipMalloc(&L.wgstamps, (size_t)total * 5 * 8));
       D2_HIP_OK(hipMemsetAsync(L.wgstamps, 0, (size_t)total * 5 * 8, ls));
@@ -2763,7 +2763,7 @@ static int* roi_order_ws(const d2amd_pooler_params* p, int K, void* workspace, s
   // the ordering launch costs 4-5 us more than the plain conversion)
   if (workspace == nullptr || K < 512 || K > ROI_ORDER_MAX || workspace_bytes < (size_t)K * sizeof(int)) return nullptr;
   if (p->layout != D2AMD_NHWC || p->N > 32 || ((uintptr_t)workspace & 3)) return nullptr;
-  static const bool off = getenv("D2AMD_FWD_NO_ORDER") != nullptr;  // A/B switch
+  static const bool off = d2_prof_env("D2AMD_FWD_NO_ORDER") != nullptr;  // A/B switch
   return off ? nullptr : (int*)workspace;
 }
 

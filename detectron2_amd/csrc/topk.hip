@@ -665,7 +665,7 @@ constexpr int TK_RUN_MAX = 16384;  // one run in LDS: 128 KB
 // bitonic sort walks 16 pairs per thread through 105 steps (250 us for RetinaNet's 20,000 per level, r02 profile);
 // five 4,096 runs sorted by five workgroups + the rank merge take a quarter of that
 static inline int tk_run_for(int kmax) {  // (<= 4,096: one run)
-  static const int run_env = getenv("D2AMD_TOPK_RUN") ? atoi(getenv("D2AMD_TOPK_RUN")) : 0;  // A/B switch: 1024 / 2048 / 4096
+  static const int run_env = d2_prof_env("D2AMD_TOPK_RUN") ? atoi(d2_prof_env("D2AMD_TOPK_RUN")) : 0;  // A/B switch: 1024 / 2048 / 4096
   // 2,048 while the other runs of a segment fit tk_merge_lds_kernel's LDS (k <= 20,480: RetinaNet's 20,000), else 4,096.
   // Measured for 10 x 20,000: sort + merge 36.2 + 9.9 us with 4,096, 21.1 + 15.1 with 2,048, 14.7 + 24.0 with 1,024.
   const int dflt = (long)((kmax + 2047) / 2048 - 1) * 2048 * 8 <= 152 * 1024 ? 2048 : 4096;
@@ -1445,7 +1445,7 @@ int topk_select(const TopkInput& in, bool use_thr, float xmin, uint32_t* sel, in
   // on the device many times over, and the dispatcher hands out workgroups in order (segments are consecutive).
   static const bool legacy = getenv("D2AMD_TOPK_LEGACY") != nullptr;
   static const int pool_g = [] {
-    const int g = getenv("D2AMD_TOPK_POOL_G") ? atoi(getenv("D2AMD_TOPK_POOL_G")) : 16;
+    const int g = d2_prof_env("D2AMD_TOPK_POOL_G") ? atoi(d2_prof_env("D2AMD_TOPK_POOL_G")) : 16;
     return g < 1 ? 1 : g > TK_POOL_G_MAX ? TK_POOL_G_MAX : g;
   }();
   // (every workgroup of the pool kernel must be resident: its segment barriers spin)
@@ -1457,16 +1457,16 @@ int topk_select(const TopkInput& in, bool use_thr, float xmin, uint32_t* sel, in
     static const bool no_vec = getenv("D2AMD_TOPK_NO_VEC") != nullptr;  // A/B and test switch
     bool vec = !no_vec;
     for (int l = 0; l < in.L; l++) vec = vec && ((uintptr_t)in.ptr[l] % 16 == 0) && (in.stride[l] % 4 == 0 || in.N == 1);
-    static const bool old_hist0 = getenv("D2AMD_TOPK_OLD_HIST0") != nullptr;  // A/B switch
+    static const bool old_hist0 = d2_prof_env("D2AMD_TOPK_OLD_HIST0") != nullptr;  // A/B switch
     if (old_hist0) hipLaunchKernelGGL(tk_hist_kernel<0>, grid, block, 0, s, P, w.st, w.hist);
     else {
-      static const int copies = getenv("D2AMD_TOPK_HIST_COPIES") ? atoi(getenv("D2AMD_TOPK_HIST_COPIES")) : 8;
+      static const int copies = d2_prof_env("D2AMD_TOPK_HIST_COPIES") ? atoi(d2_prof_env("D2AMD_TOPK_HIST_COPIES")) : 8;
       if (copies <= 4) hipLaunchKernelGGL((tk_hist0_span_kernel<4, false>), ggrid, block, 0, s, P, w.hist);
       else if (!vec) hipLaunchKernelGGL((tk_hist0_span_kernel<8, false>), ggrid, block, 0, s, P, w.hist);
       else hipLaunchKernelGGL((tk_hist0_span_kernel<8, true>), ggrid, block, 0, s, P, w.hist);
     }
 #ifdef D2AMD_TOPK_STAMPS
-    const char* stamp_path = getenv("D2AMD_TOPK_STAMPS");  // profiling only: per-workgroup stamps of the gather pass
+    const char* stamp_path = d2_prof_env("D2AMD_TOPK_STAMPS");  // profiling only: per-workgroup stamps of the gather pass
     const size_t stamp_n = (size_t)grid.x * grid.y * 6;
     if (stamp_path) {
       D2_HIP_OK(hipMalloc(&P.stamps, stamp_n * 8));
@@ -1510,7 +1510,7 @@ int topk_select(const TopkInput& in, bool use_thr, float xmin, uint32_t* sel, in
   }
   }
   if (w.kmax <= TK_RANK_MAX && !no_fused) {  // (the A/B switch also keeps the bitonic sort under test)
-    static const bool no_epi = getenv("D2AMD_RPN_NO_FUSED_DECODE") != nullptr;  // A/B switch
+    static const bool no_epi = d2_prof_env("D2AMD_RPN_NO_FUSED_DECODE") != nullptr;  // A/B switch
     if (rpn && rpn_done && in.N <= 16 && !no_epi) {
       hipLaunchKernelGGL(tk_rank_kernel<true>, dim3(in.N * in.L, cdiv(w.kmax, 64)), dim3(TK_RANK_THREADS), 0, s, P, w.st, w.cand,
                          w.kmax, sel, cnt, *rpn);

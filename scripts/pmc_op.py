@@ -11,7 +11,12 @@ op, layout, N = sys.argv[1], sys.argv[2], int(sys.argv[3])
 dev = torch.device("cuda", 0)
 w = bench.Workload(dev, torch.bfloat16, layout)
 torch.cuda.synchronize()
-if op == "roi_align_chain_bwd":  # the step's backward: box and mask pooler of the same features, ONE pass, chained
+if op == "connected_step":  # the headline's step itself (eager): its sampled ROI lists are what the paired gather sees there
+    w2 = bench.Workload(dev, torch.bfloat16, layout)
+    w2.connected = True
+    for _ in range(N):
+        bench.connected_step(w2)
+elif op == "roi_align_chain_bwd":  # the step's backward: box and mask pooler of the same features, ONE pass, chained
     yb, ym = w.box_pooler(w.feats, w.box_lists), w.mask_pooler(w.feats, w.mask_lists)
     for _ in range(N):
         torch.autograd.grad([yb, ym], w.feats, [w.gbox, w.gmask], retain_graph=True)
@@ -45,7 +50,10 @@ elif op.startswith("dcn_"):  # dcn_fwd_res3 / dcn_bwd_res4 ...: DCNv2 at the R50
     from detectron2_amd.layers import ModulatedDeformConv
     C, H, W = {"res3": (128, 100, 168), "res4": (256, 50, 84), "res5": (512, 25, 42)}[op.split("_")[2]]
     mod = ModulatedDeformConv(C, C, 3, padding=1, bias=False).to(dev).to(torch.bfloat16)
-    x = torch.randn(2, C, H, W, device=dev, dtype=torch.bfloat16, requires_grad=True)
+    x = torch.randn(2, C, H, W, device=dev, dtype=torch.bfloat16)
+    if layout == "nhwc":  # (the channels_last entry: column + dense GEMM path of round 5)
+        x = x.contiguous(memory_format=torch.channels_last)
+    x.requires_grad_(True)
     off = (torch.randn(2, 18, H, W, device=dev) * 2).to(torch.bfloat16).requires_grad_(True)
     msk = torch.sigmoid(torch.randn(2, 9, H, W, device=dev)).to(torch.bfloat16).requires_grad_(True)
     if "_fwd_" in op:
@@ -55,7 +63,7 @@ elif op.startswith("dcn_"):  # dcn_fwd_res3 / dcn_bwd_res4 ...: DCNv2 at the R50
         g = None  # the forward's kernels by name
         for _ in range(N):
             y = mod(x, off, msk)
-            g = torch.randn_like(y) if g is None else g
+            g = torch.randn_like(y) if g is None else g  # (preserves channels_last)
             torch.autograd.grad([y], [x, off, msk, mod.weight], [g])
 elif op == "paste_masks":  # SURVEY 8(d) paste micro: 100 masks of 28x28 -> 100 x 800 x 1333 bool
     from detectron2_amd.layers import paste_masks_in_image

@@ -416,10 +416,11 @@ def test_backward_is_repeatable_beside_its_own_weight_gradient_gemm():
     import _dcn_cases as dc
     from detectron2_amd import layers
 
+    iters = int(os.environ.get("D2AMD_REPEAT_ITERS", "12"))  # (>= 500 once per round, profiles/r05/)
     for dt in (torch.bfloat16, torch.float16):
         case = dc.make_full("res3", rounding=dt)
         first = None
-        for it in range(12):
+        for it in range(iters):
             out = dc.run_module(layers.modulated_deform_conv, layers.deform_conv, case, "cuda", dt, True)
             if first is None:
                 first = out
