@@ -25,6 +25,7 @@ import bench as B
 # ---------------------------------------------------------------------------------------------- maskrcnn_infer
 INFER_PRE_NMS, INFER_POST_NMS, INFER_SCORE_THRESH, INFER_NMS, INFER_DETS = 1000, 1000, 0.05, 0.5, 100
 INFER_LOOP = os.environ.get("D2AMD_BENCH_INFER_LOOP", "0") == "1"  # A/B: the reference's per-image box-head inference
+INFER_TORCH_PREDICT = os.environ.get("D2AMD_BENCH_INFER_TORCH_PREDICT", "0") == "1"  # A/B: predict_boxes / predict_probs as torch ops
 ORIG_H, ORIG_W = 800, 1333   # the image size detector_postprocess pastes at (BASELINE: 1333x800 inputs)
 
 
@@ -44,6 +45,11 @@ def infer_inputs(w, seed=1234):
     w.cls_logits = [(torch.randn(INFER_POST_NMS, 81, generator=g) * 2.0).to(w.dev) for g in gens]
     w.box_deltas = [(torch.randn(INFER_POST_NMS, 320, generator=g) * 0.1).to(w.dev) for g in gens]
     w.infer_mask_logits = [torch.randn(INFER_DETS, 80, 28, 28, generator=g).to(w.dtype).to(w.dev) for g in gens]
+    # the heads produce ONE tensor for the batch (FastRCNNOutputLayers.forward / the mask head): concatenated once, here
+    w.cls_logits_all, w.box_deltas_all = torch.cat(w.cls_logits), torch.cat(w.box_deltas)
+    w.infer_mask_logits_all = torch.cat(w.infer_mask_logits)
+    sx, sy = ORIG_W / B.IMG_W, ORIG_H / B.IMG_H   # detector_postprocess's scale (postprocessing.py:60-68): a constant of the model
+    w.paste_scale = torch.tensor([sx, sy, sx, sy], device=w.dev)
 
 
 def _apply_deltas(deltas, boxes, weights=(10.0, 10.0, 5.0, 5.0), clamp=math.log(1000.0 / 16)):
@@ -101,10 +107,14 @@ def infer_step(w, run=None):
         # predict_probs / predict_boxes over the batch (fast_rcnn.py:FastRCNNOutputLayers: one softmax, one apply_deltas,
         # split per image), then fast_rcnn_inference: fused (d2amd_fast_rcnn_filter + ONE batched NMS: two host syncs per
         # batch) or -- D2AMD_BENCH_INFER_LOOP=1, the A/B -- the reference's per-image data flow on this package's ops
-        probs = torch.softmax(torch.cat([w.cls_logits[i] for i in range(n)]), dim=1)
-        boxes = _apply_deltas(torch.cat([w.box_deltas[i] for i in range(n)]), torch.cat(pboxes))
         rows = [int(p.shape[0]) for p in pboxes]
-        probs, boxes = probs.split(rows), boxes.reshape(boxes.shape[0], -1).split(rows)
+        if INFER_TORCH_PREDICT:  # A/B: the reference's ~45 elementwise launches
+            probs = torch.softmax(w.cls_logits_all, dim=1)
+            boxes = _apply_deltas(w.box_deltas_all, torch.cat(pboxes))
+            probs, boxes = probs.split(rows), boxes.reshape(boxes.shape[0], -1).split(rows)
+        else:
+            from detectron2_amd.modeling import fast_rcnn_predict
+            boxes, probs = fast_rcnn_predict(w.cls_logits_all, w.box_deltas_all, pboxes)
         if INFER_LOOP:
             return [fast_rcnn_inference_single_image(boxes[i].reshape(rows[i], -1, 4), probs[i], (B.IMG_H, B.IMG_W),
                                                      INFER_SCORE_THRESH, INFER_NMS, INFER_DETS) for i in range(n)]
@@ -133,7 +143,8 @@ def infer_step_device(w):
     paste on those 100 rows -- so the whole step is ONE HIP graph and the host reads once, at its end.  -> (finish, pasted):
     finish() = the read + the exact detection lists (as the synchronous path's), pasted[i] [100, H, W] valid up to them."""
     from detectron2_amd.layers import paste_masks_in_image
-    from detectron2_amd.modeling import fast_rcnn_inference_device, find_top_rpn_proposals_fused, mask_rcnn_inference
+    from detectron2_amd.modeling import (fast_rcnn_inference_device, fast_rcnn_predict, find_top_rpn_proposals_fused,
+                                         mask_rcnn_inference)
     from detectron2_amd.structures import Boxes
 
     n = w.n_img
@@ -141,28 +152,16 @@ def infer_step_device(w):
                                         INFER_POST_NMS, 0.0, False, defer=True, host_result=False)
     dp = done.device
     assert dp is not None, "the RPN NMS did not run as the batched device pipeline"
-    cnt = dp.counts()
-    slot = torch.arange(INFER_POST_NMS, device=w.dev)
-    unit = torch.cat([dp.boxes[0].new_zeros(2), dp.boxes[0].new_ones(2)])
-    live = [slot < cnt[i] for i in range(n)]
-    pboxes = [torch.where(live[i][:, None], dp.boxes[i], unit) for i in range(n)]
+    pboxes = dp.pad_()   # rows behind the device-side proposal count <- a 1 x 1 box (one launch, no host read)
     box_feats = w.box_pooler(w.feats_nograd, [Boxes(b) for b in pboxes])
-    probs = torch.softmax(torch.cat([w.cls_logits[i] for i in range(n)]), dim=1)
-    # rows past the proposal count predict nothing: all of their probability on the background column
-    lv = torch.cat(live)
-    bg = torch.cat([probs.new_zeros(probs.shape[1] - 1), probs.new_ones(1)])  # (device fills: capturable)
-    probs = torch.where(lv[:, None], probs, bg)
-    boxes = _apply_deltas(torch.cat([w.box_deltas[i] for i in range(n)]), torch.cat(pboxes))
-    rows = [INFER_POST_NMS] * n
-    probs, boxes = probs.split(rows), boxes.reshape(boxes.shape[0], -1).split(rows)
+    # predict_boxes + predict_probs in one launch; rows behind the proposal count predict background
+    boxes, probs = fast_rcnn_predict(w.cls_logits_all, w.box_deltas_all, pboxes, limits=dp.limits)
     dd = fast_rcnn_inference_device(boxes, probs, [(B.IMG_H, B.IMG_W)] * n, INFER_SCORE_THRESH, INFER_NMS, INFER_DETS,
                                     capacity=6144)
     mask_feats = w.mask_pooler(w.feats_nograd, [Boxes(b) for b in dd.boxes])
     insts = [_Inst(c) for c in dd.classes]
-    logits = torch.cat([w.infer_mask_logits[i][:INFER_DETS] for i in range(n)])
-    mask_rcnn_inference(logits, insts)
-    sx, sy = ORIG_W / B.IMG_W, ORIG_H / B.IMG_H
-    scale = torch.cat([dp.boxes[0].new_full((1,), sx), dp.boxes[0].new_full((1,), sy)]).repeat(2)
+    mask_rcnn_inference(w.infer_mask_logits_all, insts)
+    scale = w.paste_scale
     pasted = [paste_masks_in_image(insts[i].pred_masks[:, 0], dd.boxes[i] * scale, (ORIG_H, ORIG_W), 0.5) for i in range(n)]
     return dd.finish, pasted, (box_feats, mask_feats)
 

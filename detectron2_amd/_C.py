@@ -148,6 +148,9 @@ _SIGNATURES = {
     "d2amd_fast_rcnn_park": (_i, [ctypes.POINTER(_i), _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "d2amd_fast_rcnn_take": (_i, [ctypes.POINTER(_i), _i, _i, _i, _i, ctypes.POINTER(_vp), _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                   _vp, _vp, _vp, _vp]),
+    "d2amd_fast_rcnn_predict": (_i, [_vp, _vp, _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_i), _i, _i, _i,
+                                     ctypes.POINTER(ctypes.c_float), ctypes.c_float, _i, _vp, _vp, _vp]),
+    "d2amd_proposals_pad": (_i, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_i), _i, _vp]),
     "d2amd_mask_rcnn_inference": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "d2amd_mask_rcnn_loss_workspace_bytes": (_sz, [_i]),
     "d2amd_mask_rcnn_loss_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),

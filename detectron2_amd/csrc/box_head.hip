@@ -205,6 +205,120 @@ __global__ __launch_bounds__(256) void bh_take_kernel(const BhWindows Wd, const 
   }
 }
 
+// ---- FastRCNNOutputLayers.predict_boxes + predict_probs in one launch (fast_rcnn.py:524-568; box_regression.py:88-116) ----
+// The reference runs ~45 elementwise launches here (slices, divisions, clamps, exp, stack, softmax); at 1,000 proposals per
+// image every one of them is a launch latency.  A wave per proposal row: softmax (or sigmoid) of its K + 1 scores with
+// two butterfly reductions, and the K_b class-specific boxes decoded with the reference's fp32 expression order (this
+// file is compiled with -ffp-contract=off).  Rows at / behind an image's live count (a device-side proposal count: rows
+// the RPN's NMS did not fill) predict nothing: all probability on the background column, zero boxes.
+struct BhPredict {
+  const float4* prop[D2AMD_POOLER_MAX_IMAGES];    // [R_i] proposal boxes (fp32 XYXY)
+  const int64_t* limit[D2AMD_POOLER_MAX_IMAGES];  // nullable: {kept, flags, finite} of the NMS that produced the proposals
+  int row_base[D2AMD_POOLER_MAX_IMAGES + 1];
+  int n, K, Kb, sigmoid;
+  float wx, wy, ww, wh, clamp;
+};
+
+constexpr int BHP_WAVES = 4;  // rows per workgroup of the predict kernel (2,000 rows -> 500 workgroups)
+template <typename T>
+__global__ __launch_bounds__(64 * BHP_WAVES) void bh_predict_kernel(const BhPredict P, const T* __restrict__ scores,
+                                                                    const T* __restrict__ deltas,
+                                                                    float4* __restrict__ boxes, T* __restrict__ probs) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * BHP_WAVES + wave;
+  if (row >= P.row_base[P.n]) return;  // uniform per wave
+  const float4* prop = P.prop[0]; const int64_t* limit = P.limit[0]; int base = P.row_base[0], rows = P.row_base[1] - P.row_base[0];
+#pragma unroll
+  for (int q = 1; q < D2AMD_POOLER_MAX_IMAGES; q++)  // (constant indices only into the by-value struct; row_base[q >= n] = total)
+    if (row >= P.row_base[q]) { prop = P.prop[q]; limit = P.limit[q]; base = P.row_base[q]; rows = P.row_base[q + 1] - P.row_base[q]; }
+  const int r = row - base;
+  const int K1 = P.K + 1;
+  const T* s = scores + (long)row * K1;
+  T* o = probs + (long)row * K1;
+  float4* ob = boxes + (long)row * P.Kb;
+  const vec4<T>* dv = reinterpret_cast<const vec4<T>*>(deltas + (long)row * (P.Kb * 4));
+  // every load of the row is issued before anything is computed (the kernel is one memory round trip long): up to 128
+  // scores and 128 class boxes live in registers; wider heads loop over the rest
+  const bool small = K1 <= 128;
+  float v0 = -INFINITY, v1 = -INFINITY;
+  if (lane < K1) v0 = to_f32(s[lane]);
+  if (lane + 64 < K1) v1 = to_f32(s[lane + 64]);
+  vec4<T> d0{}, d1{};
+  if (lane < P.Kb) d0 = dv[lane];
+  if (lane + 64 < P.Kb) d1 = dv[lane + 64];
+  const float4 b = prop[r];
+  bool live = true;
+  if (limit) {
+    int64_t c = limit[0] < limit[2] ? limit[0] : limit[2];
+    c = c < 0 ? 0 : (c > rows ? rows : c);
+    live = r < c;
+  }
+  if (!live) {
+    for (int k = lane; k < K1; k += 64) o[k] = from_f32<T>((k == P.K && !P.sigmoid) ? 1.f : 0.f);
+    for (int k = lane; k < P.Kb; k += 64) ob[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
+  if (P.sigmoid) {
+    for (int k = lane; k < K1; k += 64) {
+      const float x = k == lane ? v0 : (k == lane + 64 ? v1 : to_f32(s[k]));
+      o[k] = from_f32<T>(1.f / (1.f + expf(-x)));
+    }
+  } else {
+    // softmax as ATen evaluates it: exp(x - max) / sum(exp(x - max)), fp32 accumulation
+    float mx = fmaxf(v0, v1);
+    if (!small)
+      for (int k = lane + 128; k < K1; k += 64) mx = fmaxf(mx, to_f32(s[k]));
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+    const float e0 = lane < K1 ? expf(v0 - mx) : 0.f, e1 = lane + 64 < K1 ? expf(v1 - mx) : 0.f;
+    float sum = e0 + e1;
+    if (!small)
+      for (int k = lane + 128; k < K1; k += 64) sum += expf(to_f32(s[k]) - mx);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+    if (lane < K1) o[lane] = from_f32<T>(e0 / sum);
+    if (lane + 64 < K1) o[lane + 64] = from_f32<T>(e1 / sum);
+    if (!small)
+      for (int k = lane + 128; k < K1; k += 64) o[k] = from_f32<T>(expf(to_f32(s[k]) - mx) / sum);
+  }
+  const float widths = b.z - b.x, heights = b.w - b.y;
+  const float ctr_x = b.x + 0.5f * widths, ctr_y = b.y + 0.5f * heights;
+  for (int k = lane; k < P.Kb; k += 64) {
+    float d[4];
+    if (k == lane) unpack4(d0, d);
+    else if (k == lane + 64) unpack4(d1, d);
+    else unpack4(dv[k], d);
+    // `deltas[:, 0::4] / wx` with a Python scalar on a device tensor is ATen's multiplication by the fp32 reciprocal
+    // (BinaryDivTrueKernel: `a * (1 / b)` for a CPU-scalar divisor): P.wx .. P.wh hold 1.f / weight
+    const float dx = d[0] * P.wx, dy = d[1] * P.wy;
+    float dw = d[2] * P.ww, dh = d[3] * P.wh;
+    dw = dw != dw ? dw : fminf(dw, P.clamp);   // torch.clamp(max=) keeps a NaN
+    dh = dh != dh ? dh : fminf(dh, P.clamp);
+    const float pcx = dx * widths + ctr_x, pcy = dy * heights + ctr_y;
+    const float pw = expf(dw) * widths, ph = expf(dh) * heights;
+    ob[k] = make_float4(pcx - 0.5f * pw, pcy - 0.5f * ph, pcx + 0.5f * pw, pcy + 0.5f * ph);
+  }
+}
+
+// rows of a device-side proposal list at / behind its live count <- a 1 x 1 box at the origin (what the pooler and the
+// decode that follow can take without looking at the count)
+struct BhPad {
+  float4* boxes[D2AMD_POOLER_MAX_IMAGES];
+  const int64_t* limit[D2AMD_POOLER_MAX_IMAGES];
+  int rows[D2AMD_POOLER_MAX_IMAGES];
+};
+__global__ __launch_bounds__(256) void bh_pad_kernel(const BhPad P) {
+  const int img = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
+  float4* boxes = P.boxes[0]; const int64_t* limit = P.limit[0]; int rows = P.rows[0];
+#pragma unroll
+  for (int q = 1; q < D2AMD_POOLER_MAX_IMAGES; q++)
+    if (q == img) { boxes = P.boxes[q]; limit = P.limit[q]; rows = P.rows[q]; }
+  if (t >= rows) return;
+  int64_t c = limit[0] < limit[2] ? limit[0] : limit[2];
+  c = c < 0 ? 0 : c;
+  if (t >= c) boxes[t] = make_float4(0.f, 0.f, 1.f, 1.f);
+}
+
 }  // namespace d2amd
 
 using namespace d2amd;
@@ -308,6 +422,60 @@ extern "C" int d2amd_fast_rcnn_filter(const float* const* boxes, const float* co
   D2_LAUNCH_OK();
   hipLaunchKernelGGL(bh_write_kernel, grid, dim3(64 * BH_WAVES), 0, st, I, (const int*)rowcnt, (const int*)rowoff,
                      (const int*)rowidx, (float4*)out_boxes, out_scores, out_classes, out_rows);
+  D2_LAUNCH_OK();
+  return D2AMD_OK;
+}
+
+extern "C" int d2amd_fast_rcnn_predict(const void* scores, const void* deltas, int dtype, const float* const* proposals,
+                                       const int64_t* const* limits, const int* rows, int num_images, int num_classes,
+                                       int num_bbox_reg_classes, const float* weights, float scale_clamp, int use_sigmoid,
+                                       float* boxes_out, void* probs_out, void* stream) {
+  D2_CHECK_ARG(num_images >= 1 && num_images <= D2AMD_POOLER_MAX_IMAGES, "fast_rcnn_predict: %d images (max %d)", num_images,
+               D2AMD_POOLER_MAX_IMAGES);
+  D2_CHECK_ARG(scores && deltas && proposals && rows && weights && boxes_out && probs_out, "fast_rcnn_predict: null pointer");
+  D2_CHECK_ARG(num_classes >= 1 && (num_bbox_reg_classes == num_classes || num_bbox_reg_classes == 1),
+               "fast_rcnn_predict: %d box classes for %d classes", num_bbox_reg_classes, num_classes);
+  D2_CHECK_ARG(weights[0] != 0.f && weights[1] != 0.f && weights[2] != 0.f && weights[3] != 0.f, "fast_rcnn_predict: zero weight");
+  BhPredict P{};
+  P.n = num_images; P.K = num_classes; P.Kb = num_bbox_reg_classes; P.sigmoid = use_sigmoid ? 1 : 0;
+  P.wx = 1.f / weights[0]; P.wy = 1.f / weights[1]; P.ww = 1.f / weights[2]; P.wh = 1.f / weights[3]; P.clamp = scale_clamp;
+  int total = 0;
+  for (int i = 0; i < num_images; i++) {
+    D2_CHECK_ARG(rows[i] >= 0 && (rows[i] == 0 || proposals[i]), "fast_rcnn_predict: image %d: %d rows, proposals %p", i, rows[i],
+                 (const void*)proposals[i]);
+    P.prop[i] = (const float4*)proposals[i];
+    P.limit[i] = limits ? limits[i] : nullptr;
+    P.row_base[i] = total;
+    total += rows[i];
+  }
+  for (int i = num_images; i <= D2AMD_POOLER_MAX_IMAGES; i++) P.row_base[i] = total;
+  if (total == 0) return D2AMD_OK;
+  const dim3 grid(cdiv(total, BHP_WAVES)), block(64 * BHP_WAVES);
+  hipStream_t st = (hipStream_t)stream;
+  switch (dtype) {
+    case D2AMD_F32: hipLaunchKernelGGL(bh_predict_kernel<float>, grid, block, 0, st, P, (const float*)scores, (const float*)deltas, (float4*)boxes_out, (float*)probs_out); break;
+    case D2AMD_F16: hipLaunchKernelGGL(bh_predict_kernel<f16_t>, grid, block, 0, st, P, (const f16_t*)scores, (const f16_t*)deltas, (float4*)boxes_out, (f16_t*)probs_out); break;
+    case D2AMD_BF16: hipLaunchKernelGGL(bh_predict_kernel<bf16_t>, grid, block, 0, st, P, (const bf16_t*)scores, (const bf16_t*)deltas, (float4*)boxes_out, (bf16_t*)probs_out); break;
+    default: D2_CHECK_ARG(false, "fast_rcnn_predict: dtype %d", dtype);
+  }
+  D2_LAUNCH_OK();
+  return D2AMD_OK;
+}
+
+extern "C" int d2amd_proposals_pad(float* const* boxes, const int64_t* const* limits, const int* rows, int num_images,
+                                   void* stream) {
+  D2_CHECK_ARG(num_images >= 1 && num_images <= D2AMD_POOLER_MAX_IMAGES, "proposals_pad: %d images (max %d)", num_images,
+               D2AMD_POOLER_MAX_IMAGES);
+  D2_CHECK_ARG(boxes && limits && rows, "proposals_pad: null pointer");
+  BhPad P{};
+  int mx = 0;
+  for (int i = 0; i < num_images; i++) {
+    D2_CHECK_ARG(rows[i] >= 0 && limits[i] && (rows[i] == 0 || boxes[i]), "proposals_pad: image %d: bad arguments", i);
+    P.boxes[i] = (float4*)boxes[i]; P.limit[i] = limits[i]; P.rows[i] = rows[i];
+    mx = rows[i] > mx ? rows[i] : mx;
+  }
+  if (mx == 0) return D2AMD_OK;
+  hipLaunchKernelGGL(bh_pad_kernel, dim3(cdiv(mx, 256), num_images), dim3(256), 0, (hipStream_t)stream, P);
   D2_LAUNCH_OK();
   return D2AMD_OK;
 }

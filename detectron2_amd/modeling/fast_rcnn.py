@@ -10,6 +10,7 @@ batch instead of two per image, and no torch op on the (row, class) matrix.  Sam
 (`boxes` = predict_boxes, `scores` = predict_probs, per image), same results: the candidates, their order and the NMS
 are the reference's bit for bit (tests/test_gpu_fast_rcnn.py)."""
 import ctypes
+import math
 from typing import List, Sequence, Tuple
 
 import torch
@@ -19,7 +20,9 @@ from ..layers.nms import batched_nms_images
 from ..structures import Boxes
 from .dense_detector import Detections
 
-__all__ = ["fast_rcnn_inference_fused", "fast_rcnn_inference_device", "DeviceDetections"]
+_DEFAULT_SCALE_CLAMP = math.log(1000.0 / 16)  # box_regression.py:16
+
+__all__ = ["fast_rcnn_inference_fused", "fast_rcnn_inference_device", "DeviceDetections", "fast_rcnn_predict"]
 
 
 def fast_rcnn_inference_fused(boxes: Sequence[torch.Tensor], scores: Sequence[torch.Tensor],
@@ -128,7 +131,12 @@ def fast_rcnn_inference_device(boxes: Sequence[torch.Tensor], scores: Sequence[t
     out_scores = torch.empty((total,), dtype=torch.float32, device=dev)
     out_classes = torch.empty((total,), dtype=torch.int64, device=dev)
     out_rows = torch.empty((total,), dtype=torch.int64, device=dev)
-    counts = torch.zeros((n_img,), dtype=torch.int64, device=dev)
+    # images without a slot (no rows) take no part in the NMS; its result rows and the candidate counts (int64) share
+    # one zeroed buffer -- one fill, one mirror copy at the end
+    win = [min(cap, rows[i] * k_cls) for i in range(n_img)]
+    live_imgs = [i for i in range(n_img) if win[i] > 0]
+    res = torch.zeros(8 * len(live_imgs) + 2 * n_img, dtype=torch.int32, device=dev)
+    counts = res[8 * len(live_imgs):].view(torch.int64)
     with _C.on_device(dev):
         rows_c = (ctypes.c_int * n_img)(*rows)
         hw = (ctypes.c_int * (2 * n_img))(*[int(v) for s in image_shapes for v in s])
@@ -142,13 +150,9 @@ def fast_rcnn_inference_device(boxes: Sequence[torch.Tensor], scores: Sequence[t
         _C.check(L.d2amd_fast_rcnn_park(rows_c, n_img, k_cls, cap, _C.ptr(counts), _C.ptr(out_boxes), _C.ptr(out_scores),
                                         _C.ptr(out_classes), _C.stream()))
     # the windows themselves: views, no copies -- window_i = min(cap, rows_i x classes) slots, never beyond the image's
-    # own slice; images without a slot (no rows) take no part in the NMS
-    win = [min(cap, rows[i] * k_cls) for i in range(n_img)]
-    live_imgs = [i for i in range(n_img) if win[i] > 0]
+    # own slice
     cand = [(out_boxes[base[i]:base[i] + win[i]], out_scores[base[i]:base[i] + win[i]], out_classes[base[i]:base[i] + win[i]])
             for i in live_imgs]
-    res = torch.zeros(8 * len(live_imgs) + 2 * n_img, dtype=torch.int32, device=dev)  # NMS rows + the candidate counts (int64)
-    res[8 * len(live_imgs):].view(torch.int64).copy_(counts)
     nms_done = _ops.nms_images(cand, nms_thresh, False, True, None, None, res, True) if live_imgs else None
     det_b = torch.empty((n_img, topk_per_image, 4), dtype=torch.float32, device=dev)
     det_s = torch.empty((n_img, topk_per_image), dtype=torch.float32, device=dev)
@@ -187,3 +191,46 @@ def fast_rcnn_inference_device(boxes: Sequence[torch.Tensor], scores: Sequence[t
         return results, kept_rows
 
     return DeviceDetections(det_b, det_s, det_c, det_r, n_valid, finish)
+
+
+def fast_rcnn_predict(scores: torch.Tensor, proposal_deltas: torch.Tensor, proposal_boxes: Sequence[torch.Tensor],
+                      weights=(10.0, 10.0, 5.0, 5.0), scale_clamp: float = _DEFAULT_SCALE_CLAMP, use_sigmoid_ce: bool = False,
+                      limits: Sequence[torch.Tensor] = None) -> Tuple[Tuple[torch.Tensor, ...], Tuple[torch.Tensor, ...]]:
+    """`FastRCNNOutputLayers.predict_boxes` + `predict_probs` (roi_heads/fast_rcnn.py:524-568) for the batch in ONE launch:
+    `scores` [R, K + 1] and `proposal_deltas` [R, K * 4] or [R, 4] are the box head's outputs for all images (R = sum of the
+    images' proposal counts), `proposal_boxes[i]` [R_i, 4] the images' proposals, `weights` / `scale_clamp`
+    Box2BoxTransform's.  -> (boxes, probs): per image [R_i, K_b * 4] fp32 (box_regression.py:88 decodes in fp32) and
+    [R_i, K + 1] in the scores' dtype -- the two arguments of `fast_rcnn_inference`.  The reference runs ~45 elementwise
+    launches here (apply_deltas' slices / divisions / exp / stack, the softmax); boxes are bit-identical to it, probabilities
+    agree to the last ulp or two (reduction order of the softmax's sum).
+    `limits[i]` (optional; `DeviceProposals.limits`): the proposals are a fixed-shape device-side list whose live length is
+    min(limits[i][0], limits[i][2]) -- rows behind it predict background with probability 1 and zero boxes, no host read."""
+    _C.require_gpu(scores, proposal_deltas, *proposal_boxes, op="fast_rcnn_predict")
+    n_img = len(proposal_boxes)
+    rows = [int(b.shape[0]) for b in proposal_boxes]
+    r_tot = sum(rows)
+    assert scores.dim() == 2 and proposal_deltas.dim() == 2 and scores.shape[0] == r_tot == proposal_deltas.shape[0], \
+        (scores.shape, proposal_deltas.shape, rows)
+    k_cls = int(scores.shape[1]) - 1
+    kb = int(proposal_deltas.shape[1]) // 4
+    assert proposal_deltas.shape[1] == kb * 4 and kb in (1, k_cls), (proposal_deltas.shape, k_cls)
+    dev = scores.device
+    out_dt = scores.dtype
+    dt = out_dt if proposal_deltas.dtype == out_dt else torch.float32  # (mixed dtypes: both as fp32, probabilities cast back)
+    sc = scores.detach().to(dt).contiguous()
+    dl = proposal_deltas.detach().to(dt).contiguous()
+    pb = [b.detach().float().contiguous() for b in proposal_boxes]
+    boxes = torch.empty((r_tot, kb * 4), dtype=torch.float32, device=dev)
+    probs = torch.empty((r_tot, k_cls + 1), dtype=dt, device=dev)
+    if r_tot and n_img:
+        ptrs = lambda ts: (ctypes.c_void_p * n_img)(*[(t.data_ptr() if t is not None and t.numel() else None) for t in ts])
+        lim = None
+        if limits is not None:
+            assert len(limits) == n_img and all(l.dtype == torch.int64 and l.is_contiguous() and l.numel() >= 3 for l in limits)
+            lim = ptrs(limits)
+        wts = (ctypes.c_float * 4)(*[float(v) for v in weights])
+        with _C.on_device(dev):
+            _C.check(_C.lib().d2amd_fast_rcnn_predict(_C.ptr(sc), _C.ptr(dl), _C.dtype_code(sc), ptrs(pb), lim,
+                                                      (ctypes.c_int * n_img)(*rows), n_img, k_cls, kb, wts, float(scale_clamp),
+                                                      1 if use_sigmoid_ce else 0, _C.ptr(boxes), _C.ptr(probs), _C.stream()))
+    return boxes.split(rows), probs.to(out_dt).split(rows)

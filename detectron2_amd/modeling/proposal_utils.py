@@ -55,6 +55,20 @@ class DeviceProposals:
         lim = torch.stack(self.limits)
         return torch.minimum(lim[:, 0], lim[:, 2]).clamp(min=0, max=cap)
 
+    def pad_(self):
+        """rows at / behind the live count <- the box (0, 0, 1, 1), in place and without a host read (one launch): what the
+        box pooler and `fast_rcnn_predict(limits=self.limits)` take at the fixed shape [post_nms_topk, 4].  -> self.boxes"""
+        n = len(self.boxes)
+        if n == 0 or self.boxes[0].shape[0] == 0:
+            return self.boxes
+        assert all(b.is_contiguous() and b.dtype == torch.float32 for b in self.boxes)
+        assert all(l.is_contiguous() and l.dtype == torch.int64 for l in self.limits)
+        vp = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+        with _C.on_device(self.boxes[0].device):
+            _C.check(_C.lib().d2amd_proposals_pad(vp(self.boxes), vp(self.limits), (ctypes.c_int * n)(*[int(b.shape[0]) for b in self.boxes]),
+                                                  n, _C.stream()))
+        return self.boxes
+
 
 def rpn_select_proposals(anchors: List[torch.Tensor], pred_objectness_logits: List[torch.Tensor],
                          pred_anchor_deltas: List[torch.Tensor], image_sizes: List[Tuple[int, int]],

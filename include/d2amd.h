@@ -554,6 +554,27 @@ int d2amd_fast_rcnn_take(const int* rows, int num_images, int num_classes, int w
                          float* det_boxes, float* det_scores, int64_t* det_classes, int64_t* det_rows,
                          int64_t* det_counts, void* stream);
 
+/* FastRCNNOutputLayers.predict_boxes + predict_probs for the batch in ONE launch (roi_heads/fast_rcnn.py:524-568:
+ * `box2box_transform.apply_deltas(proposal_deltas, cat(proposal_boxes))` = box_regression.py:88-116, ~40 elementwise
+ * launches; `F.softmax(scores, -1)` or `scores.sigmoid()` for use_sigmoid_ce).
+ * scores [R, K + 1] and deltas [R, Kb * 4] in `dtype` (R = sum of rows[i], Kb = num_bbox_reg_classes = K or 1), contiguous;
+ * proposals[i] fp32 [rows[i], 4]; weights[4] + scale_clamp = Box2BoxTransform's.  boxes_out fp32 [R, Kb * 4] (apply_deltas
+ * computes in fp32 whatever the head's dtype: box_regression.py:88), probs_out [R, K + 1] in `dtype`.  Decode: the
+ * reference's fp32 expression order as it evaluates on a GPU (no contraction; `deltas / w` for a Python scalar w is ATen's
+ * multiplication by the fp32 reciprocal there, an IEEE division on the CPU: <= 1 ulp apart) -> bit-identical to the device run; softmax: exp(x - max) / sum with
+ * a butterfly sum (last-ulp differences from ATen's reduction order).
+ * limits (nullable; limits[i] nullable): the NMS result row {kept, flags, finite, ..} of the device-side proposal list the
+ * rows came from (DeviceProposals.limits): rows at / behind min(kept, finite) predict nothing -- probability 1 on the
+ * background column (0 everywhere with use_sigmoid), zero boxes -- without the host knowing the count. */
+int d2amd_fast_rcnn_predict(const void* scores, const void* deltas, int dtype, const float* const* proposals,
+                            const int64_t* const* limits, const int* rows, int num_images, int num_classes,
+                            int num_bbox_reg_classes, const float* weights, float scale_clamp, int use_sigmoid,
+                            float* boxes_out, void* probs_out, void* stream);
+/* Rows of device-side proposal lists at / behind their live count min(limits[i][0], limits[i][2]) <- the box (0, 0, 1, 1),
+ * in place: what lets the box pooler and the decode run at the fixed shape [rows[i], 4] (proposal_utils.py:67-135 returns a
+ * list of the live length after a host read). */
+int d2amd_proposals_pad(float* const* boxes, const int64_t* const* limits, const int* rows, int num_images, void* stream);
+
 /* ---- Mask-head glue.  detectron2/modeling/roi_heads/mask_head.py:31-158.
  * logits [B,C,HW] `dtype` (HW = Hmask*Wmask, contiguous NCHW), classes [B] int64 or NULL (class-agnostic,
  * C == 1), gt_masks [B,HW] uint8 / bool storage (the output of d2amd_bitmask_crop_and_resize).

@@ -158,3 +158,85 @@ def test_device_path_replays_in_a_hip_graph():
         want, _ = fast_rcnn_inference_fused(tb, ts, shapes, thr, nms, topk)
         for a, b in zip(got, want):
             assert torch.equal(a.pred_boxes.tensor, b.pred_boxes.tensor) and torch.equal(a.scores, b.scores)
+
+
+# ---- fast_rcnn_predict: FastRCNNOutputLayers.predict_boxes + predict_probs in one launch --------------------------------
+def _torch_apply_deltas(deltas, boxes, weights, clamp):
+    """box_regression.py:88-116 op for op in torch (the elementwise chain the fused launch replaces)."""
+    deltas = deltas.float()
+    boxes = boxes.to(deltas.dtype)
+    widths, heights = boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]
+    ctr_x, ctr_y = boxes[:, 0] + 0.5 * widths, boxes[:, 1] + 0.5 * heights
+    wx, wy, ww, wh = weights
+    dx, dy, dw, dh = deltas[:, 0::4] / wx, deltas[:, 1::4] / wy, deltas[:, 2::4] / ww, deltas[:, 3::4] / wh
+    dw, dh = torch.clamp(dw, max=clamp), torch.clamp(dh, max=clamp)
+    pcx, pcy = dx * widths[:, None] + ctr_x[:, None], dy * heights[:, None] + ctr_y[:, None]
+    pw, ph = torch.exp(dw) * widths[:, None], torch.exp(dh) * heights[:, None]
+    return torch.stack((pcx - 0.5 * pw, pcy - 0.5 * ph, pcx + 0.5 * pw, pcy + 0.5 * ph), dim=-1).reshape(deltas.shape)
+
+
+def _predict_inputs(rows, k_cls, kb, dtype, seed):
+    g = torch.Generator().manual_seed(seed)
+    r = sum(rows)
+    scores = (torch.randn(r, k_cls + 1, generator=g) * 3.0).to(dtype).to(DEV)
+    deltas = (torch.randn(r, kb * 4, generator=g) * 0.5).to(dtype)
+    deltas[::7, 2::4] = 30.0   # past scale_clamp
+    deltas = deltas.to(DEV)
+    xy = torch.rand(r, 2, generator=g) * 700
+    wh = torch.rand(r, 2, generator=g) * 300 + 0.5
+    props = torch.cat([xy, xy + wh], 1).to(DEV)
+    return scores, deltas, list(props.split(rows))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("rows,k_cls,agnostic", [([1000, 1000], 80, False), ([37, 0, 5], 80, True), ([3], 1, False),
+                                                 ([129, 64], 200, False)])
+def test_predict_boxes_and_probs_vs_the_elementwise_chain(dtype, rows, k_cls, agnostic):
+    from detectron2_amd.modeling import fast_rcnn_predict
+
+    kb = 1 if agnostic else k_cls
+    scores, deltas, props = _predict_inputs(rows, k_cls, kb, dtype, 5)
+    weights, clamp = (10.0, 10.0, 5.0, 5.0), float(np.log(1000.0 / 16))
+    boxes, probs = fast_rcnn_predict(scores, deltas, props, weights, clamp)
+    want_b = _torch_apply_deltas(deltas, torch.cat(props), weights, clamp)
+    want_p = torch.softmax(scores, dim=-1)
+    got_b, got_p = torch.cat(boxes), torch.cat(probs)
+    assert [tuple(b.shape) for b in boxes] == [(r, kb * 4) for r in rows] and got_b.dtype == torch.float32
+    assert [tuple(p.shape) for p in probs] == [(r, k_cls + 1) for r in rows] and got_p.dtype == dtype
+    assert torch.equal(got_b, want_b), "decoded boxes differ from box_regression.py's expression order"
+    # softmax: the sum's reduction order differs from ATen's -> a few fp32 ulps before the output rounding
+    tol = {torch.float32: 1e-6, torch.float16: 1e-3, torch.bfloat16: 8e-3}[dtype]
+    assert torch.allclose(got_p.float(), want_p.float(), rtol=tol, atol=1e-9 if dtype == torch.float32 else tol * 1e-2)
+    assert torch.allclose(got_p.float().sum(1), torch.ones(sum(rows), device=DEV), atol={torch.float32: 1e-5}.get(dtype, 2e-2))
+    # sigmoid head (use_sigmoid_ce)
+    _b, sig = fast_rcnn_predict(scores, deltas, props, weights, clamp, use_sigmoid_ce=True)
+    assert torch.allclose(torch.cat(sig).float(), torch.sigmoid(scores.float()).to(dtype).float(), rtol=tol, atol=tol * 1e-2)
+
+
+def test_predict_rows_behind_a_device_side_count():
+    """limits = the NMS result rows of a device-side proposal list: rows at / behind min(kept, finite) predict background
+    with probability 1 and zero boxes; the other rows are untouched by the argument."""
+    from detectron2_amd.modeling import fast_rcnn_predict
+
+    rows = [50, 40, 30]
+    scores, deltas, props = _predict_inputs(rows, 80, 80, torch.float32, 9)
+    lim = [torch.tensor(v, dtype=torch.int64, device=DEV) for v in ([20, 0, 50, 0], [99, 0, 7, 0], [0, 0, 0, 0])]
+    live = [20, 7, 0]
+    b0, p0 = fast_rcnn_predict(scores, deltas, props)
+    b1, p1 = fast_rcnn_predict(scores, deltas, props, limits=lim)
+    for i in range(3):
+        assert torch.equal(b1[i][:live[i]], b0[i][:live[i]]) and torch.equal(p1[i][:live[i]], p0[i][:live[i]])
+        assert (b1[i][live[i]:] == 0).all()
+        assert (p1[i][live[i]:, :-1] == 0).all() and (p1[i][live[i]:, -1] == 1).all()
+
+
+def test_proposals_pad():
+    from detectron2_amd.modeling.proposal_utils import DeviceProposals
+
+    boxes = [torch.rand(10, 4, device=DEV) + 5, torch.rand(6, 4, device=DEV) + 5]
+    keep = [b.clone() for b in boxes]
+    lim = [torch.tensor(v, dtype=torch.int64, device=DEV) for v in ([4, 0, 9, 0], [6, 0, 6, 0])]
+    DeviceProposals(boxes, [None, None], lim, None, [(1, 1)] * 2).pad_()
+    unit = torch.tensor([0.0, 0.0, 1.0, 1.0], device=DEV)
+    assert torch.equal(boxes[0][:4], keep[0][:4]) and (boxes[0][4:] == unit).all()
+    assert torch.equal(boxes[1], keep[1])

@@ -180,3 +180,32 @@ def test_deform_bottleneck_block_identical_inputs(modulated):
         lines.append("%-24s rel L2 %.2e  max / max %.2e" % (name, d, m))
         assert d <= 1e-3 and m <= 1e-2, (name, d, m)  # (gradients pass through three plain convolutions' backward: see _rm)
     _report("DeformBottleneckBlock (modulated=%s), 2 x 1024 x 25 x 42" % modulated, lines)
+
+
+def test_predict_vs_the_references_own_output_layers():
+    """`FastRCNNOutputLayers.predict_boxes` / `predict_probs` of the reference's byte-compiled package
+    (tests/_reference_model.py) on the same head outputs."""
+    from detectron2_amd.modeling import fast_rcnn_predict
+    from test_gpu_fast_rcnn import _predict_inputs
+
+    _rm()
+    from detectron2.layers import ShapeSpec
+    from detectron2.modeling.box_regression import Box2BoxTransform
+    from detectron2.modeling.roi_heads.fast_rcnn import FastRCNNOutputLayers
+    from detectron2.structures import Boxes, Instances
+
+    rows = [300, 211]
+    scores, deltas, props = _predict_inputs(rows, 80, 80, torch.float32, 3)
+    layer = FastRCNNOutputLayers(ShapeSpec(channels=8), box2box_transform=Box2BoxTransform(weights=(10.0, 10.0, 5.0, 5.0)),
+                                 num_classes=80)
+    insts = []
+    for p in props:
+        it = Instances((800, 800))
+        it.proposal_boxes = Boxes(p)
+        insts.append(it)
+    want_b = layer.predict_boxes((scores, deltas), insts)
+    want_p = layer.predict_probs((scores, deltas), insts)
+    boxes, probs = fast_rcnn_predict(scores, deltas, props, (10.0, 10.0, 5.0, 5.0))
+    for i in range(2):
+        assert torch.equal(boxes[i], want_b[i])
+        assert torch.allclose(probs[i], want_p[i], rtol=1e-6, atol=1e-9)
