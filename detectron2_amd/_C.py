@@ -67,7 +67,7 @@ _SIGNATURES = {
     "d2amd_roi_pooler_forward": (_i, [ctypes.POINTER(PoolerParams), ctypes.POINTER(_vp), _vp, _vp, _i, _vp]),
     "d2amd_roi_pooler_rotated_supported": (_i, [ctypes.POINTER(PoolerParams)]),
     "d2amd_roi_pooler_rotated_forward": (_i, [ctypes.POINTER(PoolerParams), ctypes.POINTER(_vp), _vp, _vp, _i, _vp, _vp]),
-    "d2amd_roi_pooler_rotated_backward_workspace_bytes": (_sz, [ctypes.POINTER(PoolerParams)]),
+    "d2amd_roi_pooler_rotated_backward_workspace_bytes": (_sz, [ctypes.POINTER(PoolerParams), _i]),
     "d2amd_roi_pooler_rotated_backward": (_i, [ctypes.POINTER(PoolerParams), _vp, _vp, ctypes.POINTER(_vp), _i, _vp, _sz,
                                                _vp]),
     "d2amd_roi_pooler_forward_box_lists": (_i, [ctypes.POINTER(PoolerParams), ctypes.POINTER(_vp), ctypes.POINTER(_vp),

@@ -521,7 +521,7 @@ class _FusedRotatedPool(Function):
         p = _params(cfg, (n, c), hw, _C.dtype_code(g), _C.NHWC)
         L = _C.lib()
         with _C.on_device(dev):
-            ws_bytes = L.d2amd_roi_pooler_rotated_backward_workspace_bytes(ctypes.byref(p))
+            ws_bytes = L.d2amd_roi_pooler_rotated_backward_workspace_bytes(ctypes.byref(p), int(rois.shape[0]))
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             _C.check(L.d2amd_roi_pooler_rotated_backward(ctypes.byref(p), _C.ptr(g), _C.ptr(rois), _ptr_array(grads),
                                                          rois.shape[0], _C.ptr(ws), ws_bytes, _C.stream()))

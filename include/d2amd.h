@@ -504,13 +504,15 @@ int d2amd_polygon_crop_and_resize(const double* coords, const int64_t* poly_offs
  *   rois [K][6] fp32 = (image index, cx, cy, w, h, angle in degrees); output / grad_output [K][PH][PW][C] (NHWC).
  *   status (device int, may be NULL): bit 0 is set when a ROI has a negative size -- its rows are zero; the reference
  *   asserts (ROIAlignRotated_cpu.cpp:236-238).
- * backward: scatter with fp32 atomics, as the reference's (addition order not deterministic); 16-bit gradients
- * accumulate in an fp32 image in the workspace (d2amd_roi_pooler_rotated_backward_workspace_bytes) and are rounded
- * once.  grad_inputs are written completely. */
+ * backward: a deterministic gather (no atomics, no fp32 image, bit-identical from run to run): the ROIs' merged tap tables
+ * are turned into per-pixel lists of {dY row, weight}, ordered by row, and a wave per pixel accumulates them in fp32 and
+ * writes the pixel once.  ROIs whose bins span more than 64 distinct pixels or 64 samples (bins wider than ~8 px at their
+ * level) take the reference's atomic scatter into an fp32 image the gather adds -- only those are order-dependent, like
+ * upstream.  workspace: d2amd_roi_pooler_rotated_backward_workspace_bytes(p, K).  grad_inputs are written completely. */
 int d2amd_roi_pooler_rotated_supported(const d2amd_pooler_params* p);
 int d2amd_roi_pooler_rotated_forward(const d2amd_pooler_params* p, const void* const* inputs, const float* rois,
                                      void* output, int K, int* status, void* stream);
-size_t d2amd_roi_pooler_rotated_backward_workspace_bytes(const d2amd_pooler_params* p);
+size_t d2amd_roi_pooler_rotated_backward_workspace_bytes(const d2amd_pooler_params* p, int K);
 int d2amd_roi_pooler_rotated_backward(const d2amd_pooler_params* p, const void* grad_output, const float* rois,
                                       void* const* grad_inputs, int K, void* workspace, size_t workspace_bytes,
                                       void* stream);

@@ -139,3 +139,82 @@ def test_negative_size_raises_and_empty_lists_work():
     want, _, _ = oracle_pool(feats, boxes, 7, 2)
     assert got.shape == want.shape == (6, 32, 7, 7)
     assert_close_fp32(got, want, "rot_pooler_one_empty_image", floor=ROI_FLOOR)
+
+
+# ---- the backward as a deterministic gather (r05) ---------------------------------------------------------------------
+def _dense(seed, n_box, size, c=16, jitter=6.0):
+    """n_box boxes per image of about `size` px around ONE spot: long per-pixel lists on one level."""
+    rng = np.random.default_rng(seed)
+    feats = [rng.standard_normal((2, c, 96 * 4 // s, 128 * 4 // s)).astype(np.float32) for s in STRIDES]
+    boxes = []
+    for _ in range(2):
+        ctr = np.array([[250.0, 190.0]]) + rng.uniform(-jitter, jitter, (n_box, 2))
+        wh = size * np.exp(rng.uniform(-0.1, 0.1, (n_box, 2)))
+        ang = rng.uniform(-180, 180, (n_box, 1))
+        boxes.append(np.concatenate([ctr, wh, ang], 1).astype(np.float32))
+    return feats, boxes
+
+
+def _bwd_vs_oracle(feats, boxes, out, sr, tag, dtype=torch.float32, floor=4 * ROI_FLOOR):
+    c = feats[0].shape[1]
+    _, rois, lv = oracle_pool(feats, boxes, out, sr)
+    gy = np.random.default_rng(5).standard_normal((len(rois), c, out, out)).astype(np.float32)
+    if dtype != torch.float32:
+        gy = torch.from_numpy(gy).to(dtype).float().numpy()
+    _, gx = run_fused(feats, boxes, out, sr, dtype, grad=gy)
+    for l, s in enumerate(STRIDES):
+        idx = np.nonzero(lv == l)[0]
+        want = np.zeros_like(feats[l])
+        if len(idx):
+            want = oracle.roi_align_rotated_backward(gy[idx], rois[idx], feats[l].shape, 1.0 / s, sr)
+        if dtype == torch.float32:
+            assert_close_fp32(gx[l], want, f"{tag}_p{l + 2}", floor=floor)
+        else:
+            ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+            assert (np.abs(gx[l] - want) <= ulp * np.abs(want) + 1e-4 * np.abs(want).max()).all(), (tag, l)
+    return gx
+
+
+@pytest.mark.parametrize("n_box,size", [(40, 120.0), (160, 500.0), (700, 600.0)])
+def test_backward_long_pixel_lists(n_box, size):
+    """lists of tens (sorted in registers), hundreds (ranked against LDS) and thousands (against memory) of entries"""
+    feats, boxes = _dense(31, n_box, size)
+    _bwd_vs_oracle(feats, boxes, 7, 2, f"rot_pooler_bwd_dense_{n_box}", floor=16 * ROI_FLOOR)
+
+
+def test_backward_is_deterministic_and_equals_the_atomic_path():
+    import os
+
+    feats, boxes = make(41, c=32, n_box=60)
+    gy = np.random.default_rng(3).standard_normal((120, 32, 7, 7)).astype(np.float32)
+    for dtype in (torch.float32, torch.bfloat16):
+        runs = [run_fused(feats, boxes, 7, 0, dtype, grad=gy)[1] for _ in range(3)]
+        for r in runs[1:]:
+            for a, b in zip(runs[0], r):
+                assert np.array_equal(a, b), "the gather backward differs between runs"
+        os.environ["D2AMD_ROT_BWD_ATOMICS"] = "1"
+        try:
+            atom = run_fused(feats, boxes, 7, 0, dtype, grad=gy)[1]
+        finally:
+            del os.environ["D2AMD_ROT_BWD_ATOMICS"]
+        tol = 1e-5 if dtype == torch.float32 else 2.0 ** -7
+        for a, b in zip(runs[0], atom):
+            assert (np.abs(a - b) <= tol * np.abs(b) + 1e-5 * np.abs(b).max()).all()
+
+
+def test_backward_rois_whose_table_does_not_fit():
+    """bins wider than ~8 px at their level (a 3,000-px box on p5: 14 x 14 samples per bin with sampling_ratio 0): flagged by
+    the table pass, scattered with atomics into the fp32 image the gather adds -- beside ordinary ROIs on the same pixels."""
+    feats, boxes = make(51, c=16, n_box=12)
+    for b in boxes:
+        b[5, :4] = [260.0, 200.0, 3000.0, 2600.0]
+        b[6, :4] = [100.0, 300.0, 40.0, 2900.0]
+    _bwd_vs_oracle(feats, boxes, 7, 0, "rot_pooler_bwd_flagged", floor=16 * ROI_FLOOR)
+    _bwd_vs_oracle(feats, boxes, 7, 0, "rot_pooler_bwd_flagged_bf16", dtype=torch.bfloat16)
+
+
+def test_backward_odd_channel_counts():
+    feats, boxes = make(61, c=6, n_box=10)   # not a multiple of 4: the scalar lanes of the gather
+    _bwd_vs_oracle(feats, boxes, 7, 2, "rot_pooler_bwd_c6")
+    feats, boxes = make(62, c=260, n_box=6)  # two channel slabs
+    _bwd_vs_oracle(feats, boxes, 3, 2, "rot_pooler_bwd_c260")
