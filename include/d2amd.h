@@ -641,11 +641,14 @@ int d2amd_deform_conv_backward(const d2amd_dcn_params* p, const void* x, const v
 /* ---- the column buffer as a SAVED ACTIVATION.  The reference's Python hands `columns` scratch tensors to
  * _C.deform_conv_forward / modulated_deform_conv_forward (layers/deform_conv.py:97-98,248-254; the C++ resizes and
  * refills them per image, deform_conv_cuda.cu:346-353,916-918) and recomputes the im2col in the backward
- * (:1160-1179).  Here the training forward can KEEP the column it gathers -- 16-bit, modulation mask folded in,
- * [kh*kw * C/32 chunks][B*Ho*Wo positions][32 channels]; d2amd_deform_conv_columns_bytes = its size (77 MB for an R50
- * res3 block of 2 images: sized for 288 GB of HBM), 0 when the shape / dtype is not served (fp32, groups > 1,
- * deformable_groups > 1, C % 64 != 0: pass columns = NULL) -- and the backward's weight gradient becomes a dense
- * split-K GEMM dW = dY^T col on MFMA instead of a second gather.  columns = NULL in either call = the plain entry. */
+ * (:1160-1179).  Here the training forward can KEEP the column it builds -- 16-bit, modulation mask folded in; opaque to
+ * the caller: NHWC layout (the column-kernel + dense-GEMM path): [B*Ho*Wo positions][kh*kw*C] row-major followed by the
+ * weights packed per tap as [kh*kw*C][Co]; NCHW layout: [kh*kw * C/32 chunks][positions][32 channels].
+ * d2amd_deform_conv_columns_bytes = its size (77 MB + the weights for an R50 res3 block of 2 images: sized for 288 GB of
+ * HBM), 0 when the shape / dtype is not served (fp32, groups > 1, deformable_groups > 1, C % 64 != 0: pass columns =
+ * NULL) -- and the backward's weight gradient becomes a dense split-K GEMM dW = dY^T col on MFMA instead of a second
+ * gather, its data gradient (NHWC) a dense GEMM against the kept weights.  The same d2amd_dcn_params (layout included) in
+ * both calls.  columns = NULL in either call = the plain entry. */
 size_t d2amd_deform_conv_columns_bytes(const d2amd_dcn_params* p);
 int d2amd_deform_conv_forward_columns(const d2amd_dcn_params* p, const void* x, const void* offset,
                                       const void* mask, const void* weight, const void* bias, void* out,
