@@ -218,3 +218,15 @@ def test_backward_odd_channel_counts():
     _bwd_vs_oracle(feats, boxes, 7, 2, "rot_pooler_bwd_c6")
     feats, boxes = make(62, c=260, n_box=6)  # two channel slabs
     _bwd_vs_oracle(feats, boxes, 3, 2, "rot_pooler_bwd_c260")
+
+
+def test_backward_without_rois_writes_zeros():
+    feats, boxes = make(71, c=16, n_box=5)
+    boxes = [b[:0] for b in boxes]
+    x = [torch.from_numpy(f).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True) for f in feats]
+    pooler = ROIPooler(7, [1.0 / s for s in STRIDES], 2, "ROIAlignRotated")
+    y = pooler(x, [RotatedBoxes(torch.from_numpy(b).to(DEV)) for b in boxes])
+    assert y.shape == (0, 16, 7, 7)
+    (y.sum() + sum(t.sum() * 0 for t in x)).backward()
+    for t in x:
+        assert t.grad is not None and not t.grad.any()
