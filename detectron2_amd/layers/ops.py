@@ -430,6 +430,24 @@ def _roi_align_rotated_backward(grad, rois, spatial_scale, pooled_height, pooled
     gin = _empty_like_layout(g, shape, layout)
     if gin.numel() == 0:
         return gin
+    if layout == _C.NHWC and pooled_height * pooled_width <= 1024:
+        # channels_last: the fused pooler's backward with ONE level -- a deterministic gather instead of the fp32 atomic
+        # scatter (csrc/roi_pool_rot.hip; the level rule is not evaluated for a single level)
+        p = _C.PoolerParams()
+        p.num_levels, p.N, p.C = 1, batch_size, channels
+        p.H[0], p.W[0], p.spatial_scale[0] = height, width, float(spatial_scale)
+        p.pooled_h, p.pooled_w, p.sampling_ratio, p.aligned = pooled_height, pooled_width, int(sampling_ratio), 1
+        p.dtype, p.layout = _C.dtype_code(g), _C.NHWC
+        p.min_level = p.max_level = p.canonical_level = 0
+        p.canonical_box_size = 224.0
+        L = _C.lib()
+        with _C.on_device(g.device):
+            ws_bytes = L.d2amd_roi_pooler_rotated_backward_workspace_bytes(_C.ctypes.byref(p), int(r.shape[0]))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=g.device)
+            _C.check(L.d2amd_roi_pooler_rotated_backward(_C.ctypes.byref(p), _C.ptr(g), _C.ptr(r),
+                                                         (_C.ctypes.c_void_p * 1)(gin.data_ptr()), int(r.shape[0]),
+                                                         _C.ptr(ws), ws_bytes, _C.stream()))
+        return gin
     ws, ws_bytes = None, 0
     if g.dtype != torch.float32:
         ws = torch.empty(gin.numel(), dtype=torch.float32, device=g.device)

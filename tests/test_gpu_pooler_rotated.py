@@ -230,3 +230,40 @@ def test_backward_without_rois_writes_zeros():
     (y.sum() + sum(t.sum() * 0 for t in x)).backward()
     for t in x:
         assert t.grad is not None and not t.grad.any()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_single_level_layer_backward_on_channels_last_is_the_gather(dtype):
+    """layers.ROIAlignRotated on a channels_last input: its backward runs the fused pooler's gather with one level --
+    equal to the NCHW entry's atomic scatter up to the order of the fp32 sums, and bit-identical from run to run."""
+    from detectron2_amd.layers import ROIAlignRotated
+
+    rng = np.random.default_rng(81)
+    x = rng.standard_normal((2, 24, 40, 56)).astype(np.float32)
+    n_roi = 50
+    rois = np.concatenate([rng.integers(0, 2, (n_roi, 1)).astype(np.float32), rng.uniform(0, 220, (n_roi, 2)),
+                           np.exp(rng.uniform(np.log(8), np.log(200), (n_roi, 2))), rng.uniform(-180, 180, (n_roi, 1))],
+                          1).astype(np.float32)
+    gy = rng.standard_normal((n_roi, 24, 7, 7)).astype(np.float32)
+    layer = ROIAlignRotated((7, 7), 0.25, 0)
+
+    def run(channels_last):
+        t = torch.from_numpy(x).to(DEV).to(dtype)
+        if channels_last:
+            t = t.contiguous(memory_format=torch.channels_last)
+        t.requires_grad_(True)
+        y = layer(t, torch.from_numpy(rois).to(DEV))
+        g = torch.from_numpy(gy).to(DEV).to(dtype)
+        y.backward(g.contiguous(memory_format=torch.channels_last) if channels_last else g)
+        return y.detach().float().cpu().numpy(), t.grad.float().cpu().numpy()
+
+    y0, g0 = run(False)
+    y1, g1 = run(True)
+    y2, g2 = run(True)
+    assert np.array_equal(g1, g2), "channels_last backward differs between runs"
+    tol = 1e-5 if dtype == torch.float32 else 2.0 ** -7
+    assert np.allclose(y1, y0, rtol=tol, atol=tol * np.abs(y0).max())
+    assert (np.abs(g1 - g0) <= tol * np.abs(g0) + 1e-5 * np.abs(g0).max() + (0 if dtype == torch.float32 else 2.0 ** -8 * np.abs(g0))).all()
+    if dtype == torch.float32:
+        want = oracle.roi_align_rotated_backward(gy, rois, x.shape, 0.25, 0)
+        assert_close_fp32(g1, want, "rot_layer_bwd_nhwc", floor=4 * ROI_FLOOR)
