@@ -25,10 +25,8 @@ namespace d2amd {
 // sides.  The training forward packs BOTH (Wt rides in the tail of the column buffer the caller keeps for the backward):
 // one pack launch per block and iteration.
 template <typename T>
-__global__ __launch_bounds__(256) void dcn_pack_weights_kernel(const T* __restrict__ w, T* __restrict__ wp, T* __restrict__ wt,
-                                                              int Co, int C, int K2) {
-  __shared__ T tile[32][33];  // [co][ci]
-  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32, tap = blockIdx.z;
+__device__ __forceinline__ void dcn_pack_body(const T* __restrict__ w, T* __restrict__ wp, T* __restrict__ wt, int Co, int C,
+                                              int K2, int ci0, int co0, int tap, T (&tile)[32][33]) {
   const int a = threadIdx.x & 31, r = threadIdx.x >> 5;  // 32 x 8
 #pragma unroll
   for (int j = 0; j < 4; j++) tile[r + 8 * j][a] = w[((long)(co0 + r + 8 * j) * C + ci0 + a) * K2 + tap];
@@ -41,6 +39,12 @@ __global__ __launch_bounds__(256) void dcn_pack_weights_kernel(const T* __restri
 #pragma unroll
     for (int j = 0; j < 4; j++) wt[((long)tap * C + ci0 + r + 8 * j) * Co + co0 + a] = tile[a][r + 8 * j];
   }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void dcn_pack_weights_kernel(const T* __restrict__ w, T* __restrict__ wp, T* __restrict__ wt,
+                                                              int Co, int C, int K2) {
+  __shared__ T tile[32][33];  // [co][ci]
+  dcn_pack_body<T>(w, wp, wt, Co, C, K2, blockIdx.x * 32, blockIdx.y * 32, blockIdx.z, tile);
 }
 
 // ---- sample tables ----------------------------------------------------------------------------------------------------
@@ -136,9 +140,20 @@ __device__ __forceinline__ float cp_group_sum(float v, int LPS) {
 // its workgroups gather stay in its L2.
 template <typename T>
 __global__ __launch_bounds__(256) void dcn_col_kernel(DcnShape s, const T* __restrict__ x, const T* __restrict__ offset,
-                                                     const T* __restrict__ mask, T* __restrict__ col, int NP, int total) {
+                                                     const T* __restrict__ mask, T* __restrict__ col, int NP, int total,
+                                                     const T* __restrict__ weight, T* __restrict__ wp, T* __restrict__ wt) {
   __shared__ CpEntry ent[CP_MAXS];
   const int tid = threadIdx.x;
+  const int ncol = (total + 7) / 8 * 8;
+  if ((int)blockIdx.x >= ncol) {
+    // the weight pack (the GEMM that follows needs it, the column does not): the workgroups behind the column's, in the
+    // same launch -- as its own launch in front of this one it was 4-6 us + an edge of every forward
+    T(&tile)[32][33] = *reinterpret_cast<T(*)[32][33]>(&ent[0]);
+    const int pi = (int)blockIdx.x - ncol, nci = s.C >> 5, nco = s.Co >> 5;
+    const int tap = pi / (nci * nco), rem = pi - tap * (nci * nco);
+    dcn_pack_body<T>(weight, wp, wt, s.Co, s.C, s.K2, (rem % nci) * 32, (rem / nci) * 32, tap, tile);
+    return;
+  }
   const int per_xcd = (total + 7) >> 3;
   const int logical = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
   if (logical >= total) return;
@@ -297,14 +312,12 @@ template <typename T>
 int dcn_colpath_forward(const DcnShape& s, const ColPathPlan& pl, const void* x_nhwc, const void* offset, const void* mask,
                         const void* weight, const void* bias, void* out_nhwc, void* col, void* wpack, void* wt_keep,
                         hipStream_t st) {
-  hipLaunchKernelGGL((dcn_pack_weights_kernel<T>), dim3(s.C / 32, s.Co / 32, s.K2), dim3(256), 0, st, (const T*)weight, (T*)wpack,
-                     (T*)wt_keep, s.Co, s.C, s.K2);
-  D2_LAUNCH_OK();
   const int total = cdiv(s.P, pl.NP);
   {
+    const int npack = (s.C / 32) * (s.Co / 32) * s.K2;
     const bool timed = timing_begin("dcn_fwd_col", st);
-    hipLaunchKernelGGL((dcn_col_kernel<T>), dim3((total + 7) / 8 * 8), dim3(256), 0, st, s, (const T*)x_nhwc, (const T*)offset,
-                       (const T*)mask, (T*)col, pl.NP, total);
+    hipLaunchKernelGGL((dcn_col_kernel<T>), dim3((total + 7) / 8 * 8 + npack), dim3(256), 0, st, s, (const T*)x_nhwc,
+                       (const T*)offset, (const T*)mask, (T*)col, pl.NP, total, (const T*)weight, (T*)wpack, (T*)wt_keep);
     if (timed) timing_end("dcn_fwd_col", st);
     D2_LAUNCH_OK();
   }
