@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the Detectron2 detection hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload maskrcnn_train|retinanet_100k|dcn_r50]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--rois uniform|clustered]
+                    [--workload maskrcnn_train|retinanet_100k|dcn_r50|maskrcnn_infer|rrpn_micro]
 
 `--gpus N` with N > 1 and no torchrun environment: bench.py launches itself as N ranks (one per GPU, RCCL) through
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`; under torchrun it reads
@@ -11,21 +12,31 @@ Workloads (all inputs synthetic, resident in HBM before the timed region; SURVEY
 
 maskrcnn_train (default; BASELINE.json configs[1] / [2], the configuration the metric is quoted on)
     One step = one pass of the TRAINING hot path of Mask R-CNN R50-FPN over 2 images per GPU (1333x800 -> padded
-    800x1344, bf16 FPN features p2..p5, 256 channels), in the order GeneralizedRCNN.forward issues it:
-      RPN       Matcher.match_boxes(16 GT x 268,569 anchors) per image           [rpn.py:307-364: pairwise_iou + Matcher]
+    800x1344, bf16 FPN features p2..p5, 256 channels), CONNECTED as GeneralizedRCNN.forward connects it, captured once and
+    replayed as ONE HIP graph per step with no host read:
+      RPN       Matcher.match_boxes(16 GT x 268,569 anchors) per image + anchor sampling [rpn.py:307-364: pairwise_iou + Matcher]
                 find_top_rpn_proposals_fused: per-level top-2000 of the objectness logits, decode, clip, per-level
-                NMS 0.7 of 2 x 8,819 boxes, top 1000                              [rpn.py:468-533, proposal_utils.py:22-135]
-      ROI heads Matcher.match_boxes(16 GT x 1,016 proposals + GT) per image       [roi_heads.py:257-295]
-                box  ROIPooler 7x7,  512 ROIs / image over p2..p5, forward        [roi_heads.py:_forward_box]
-                mask ROIPooler 14x14, 128 fg ROIs / image, forward                [roi_heads.py:_forward_mask]
+                NMS 0.7 of 2 x 8,819 boxes, top 1000 -- counts left on the device   [rpn.py:468-533, proposal_utils.py:22-135]
+      ROI heads label_and_sample_proposals on the NMS's device-side counts (match + sample 512 rows / image at a fixed
+                shape, written in pooler format)                                   [roi_heads.py:257-295, sampling.py]
+                box  ROIPooler 7x7 on the 512 sampled rows / image, mask ROIPooler 14x14 on their first 128 (one paired
+                launch per direction)                                              [roi_heads.py:_forward_box / _forward_mask]
                 mask targets: gt_masks[matched].crop_and_resize(fg boxes, 28) on (16, 800, 1344) bitmasks / image
-                mask_rcnn_loss forward on (256, 80, 28, 28) logits                [mask_head.py:33-112]
+                mask_rcnn_loss forward on (256, 80, 28, 28) logits, masked by the device-side foreground count [mask_head.py:33-112]
       backward  ONE autograd pass: mask_rcnn_loss backward + both poolers' backward into the FPN features
       N > 1     gradient all-reduce of the model's 44.1 M trainable parameters (RCCL over xGMI; the ROI heads'
-                bucket is issued before the pooler backward and overlaps it; see detectron2_amd/sharding.py)
+                bucket is issued before the pooler backward and overlaps it; see detectron2_amd/sharding.py).  The line's
+                `allreduce` block then carries `value_data_path` (the same step WITHOUT the collective: the hot path's own
+                weak scaling -- compute data-path efficiency from this), `exposed_ms` (what the collective adds to a step; a
+                full model hides it behind its backbone backward, which is outside this step) and `bus_GBps_alone`.
     Not in the step because out of the hot path's scope: backbone / head convolutions and FCs (their
-    outputs -- logits, deltas, mask logits, dY of the pooled features -- are inputs here), `subsample_labels` (the
-    sampled ROI lists are fixed inputs), the optimizer.  `value` = images / second through the hot path, whole job.
+    outputs -- logits, deltas, mask logits, dY of the pooled features -- are inputs here), the optimizer.
+    `value` = images / second through the hot path, whole job.  `--rois clustered`: proposals drawn around 12 objects per
+    image the way a trained RPN's are (also an `extra_workloads` entry of the default line, with the per-tile list
+    histogram); `extra_workloads.nchw_drop_in`: the same step entered with NCHW features.
+    `roofline` = the paired pooler backward (box + mask pooler in one launch): `frac` on the launch's COMPULSORY bytes (dY
+    of both poolers once + every gradient tile written once), `frac_survey_units` on SURVEY 8(d)'s per-unit formula for the
+    two units it processes, `frac_traffic` on its PMC bytes.
 
 retinanet_100k (configs[3]): RetinaNet R50-FPN inference with TOPK_CANDIDATES_TEST 20000 x 5 levels = 100k candidates
     per image, SCORE_THRESH_TEST 0, 80 classes: dense_detector_inference_fused (threshold + top-k over 2 x 16.1 M
@@ -35,8 +46,11 @@ dcn_r50 (configs[4]): the 13 ModulatedDeformConv (DCNv2) blocks of R50 res3-res5
     @50x84, 3 x 512ch @25x42), forward + backward (dX, d offset, d mask, dW), bf16, 2 images.  value = images / second;
     roofline bound = MFMA.
 
-Extra JSON fields: `roofline` (dominant kernel, algorithmic bytes / flops of SURVEY 8(d) over its HIP-event time),
-`cpu_baseline` (the oracle timed on this host), `ops` (per-op breakdown from a separate untimed pass).
+maskrcnn_infer, rrpn_micro: bench_extra.py (the inference chain as one HIP graph; the rotated operators).
+
+Extra JSON fields: `roofline` (dominant kernel, algorithmic bytes / flops over its HIP-event time), `cpu_baseline` (the
+oracle timed on this host), `ops` (per-op breakdown from a separate untimed pass), `extra_workloads` (the other workloads,
+a few steps each, in the default line).
 """
 import argparse
 import ctypes

@@ -2,7 +2,8 @@
 
 * maskrcnn_infer -- the Mask R-CNN R50-FPN INFERENCE hot path of one rank's 2 images: RPN test path (pre / post NMS
   top-k 1,000: proposal_generator/proposal_utils.py:67-135) -> box pooler 7x7 -> `fast_rcnn_inference` (roi_heads/
-  fast_rcnn.py:118-170: decode, clip, score > 0.05, per-class batched_nms at 0.5, top 100) -> mask pooler 14x14 on the
+  fast_rcnn.py:118-170: clip, score > 0.05, per-class batched_nms at 0.5, top 100; in front of it predict_boxes /
+  predict_probs, fast_rcnn.py:524-568, as ONE launch: fast_rcnn_predict) -> mask pooler 14x14 on the
   detections -> `mask_rcnn_inference` (mask_head.py:117-158) -> `paste_masks_in_image` 100 x 800x1333
   (postprocessing.py:60-68).  The box / mask heads' convolutions are inputs (synthetic scores / deltas / mask logits), as
   the backbone is for the training workload.  Roofline kernel: the paste (HBM write-bound, 106.6 MB per image).
@@ -11,8 +12,11 @@
   ROIAlignRotated 7x7 forward + backward of 1,024 ROIs over the 4 FPN levels.  Roofline: the rotated IoU is VALU-bound
   (~400 flop / pair on 40 B of input): the line carries pairs/s beside the (small by construction) HBM fraction.
 
-Both: eager launches (inference has data-dependent sizes, one host sync per stage as in the reference), barrier +
-synchronize bracketed timing, kernel durations from the library's launch-stream events (d2amd_timing_*)."""
+maskrcnn_infer runs as ONE HIP graph per step with one host read at its end (infer_step_device: fixed-shape intermediates
+whose valid lengths stay on the device; the graph's detections and pasted masks are checked equal to the eager,
+reference-style chain of infer_step before anything is timed; D2AMD_BENCH_INFER_EAGER=1 times that chain instead);
+rrpn_micro is eager.  Both: barrier + synchronize bracketed timing, kernel durations from the library's launch-stream events
+(d2amd_timing_*; for the graph: an eager pass right after the timed region)."""
 import math
 import os
 import time
