@@ -108,9 +108,11 @@ __device__ __forceinline__ void rot_sample_taps(const RoiGeom& g, int ph, int pw
 // walks the samples in order adding the taps that hit it -- ns steps of broadcasts instead of the 4 ns serial
 // insert-or-add steps of the first version (110 -> 60 us for the table pass of the RRPN box head), the same sums in the
 // same order.  emit(index, pixel, weight) is called by the lane that owns an entry; -> entries, or -1 beyond `cap`.
+// (smp != nullptr: the samples' taps are staged in 2 KB of LDS per wave and broadcast from there -- the walk over the
+// samples is 8 v_readlane + their SGPR hazards per sample otherwise: 36 of the table pass's 68 us)
 template <typename Emit>
 __device__ __forceinline__ int rot_bin_merge(const RoiGeom& g, int ph, int pw, int ns, int H, int W, float inv, int cap,
-                                             int lane, Emit emit) {
+                                             int lane, Emit emit, uint4* smp = nullptr) {
   uint32_t ofs[4] = {0u, 0u, 0u, 0u};
   float wt[4] = {0.f, 0.f, 0.f, 0.f};
   int ylo = 0x7fffffff, yhi = -1, xlo = 0x7fffffff, xhi = -1;
@@ -136,18 +138,37 @@ __device__ __forceinline__ int rot_bin_merge(const RoiGeom& g, int ph, int pw, i
   }
   if (yhi < 0) return 0;  // no sample inside the map (uniform)
   const int bw = xhi - xlo + 1, ncell = (yhi - ylo + 1) * bw;
+  if (smp) {
+    __builtin_amdgcn_wave_barrier();  // (the previous bin's readers of this wave's slots are done: one wave, in order)
+    if (lane < ns) {
+      smp[2 * lane] = uint4{ofs[0], __float_as_uint(wt[0]), ofs[1], __float_as_uint(wt[1])};
+      smp[2 * lane + 1] = uint4{ofs[2], __float_as_uint(wt[2]), ofs[3], __float_as_uint(wt[3])};
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+  }
   int cnt = 0;
   for (int c0 = 0; c0 < ncell; c0 += 64) {  // uniform
     const int cell = c0 + lane;
     const int cy = cell / bw, cx = cell - cy * bw;
     const uint32_t mypix = cell < ncell ? (uint32_t)((ylo + cy) * W + xlo + cx) : 0xffffffffu;
     float wsum = 0.f;
-    for (int s2 = 0; s2 < ns; s2++) {
+    if (smp) {
+      for (int s2 = 0; s2 < ns; s2++) {
+        const uint4 a = smp[2 * s2], b = smp[2 * s2 + 1];  // (uniform address: broadcast)
+        wsum += mypix == a.x ? __uint_as_float(a.y) : 0.f;
+        wsum += mypix == a.z ? __uint_as_float(a.w) : 0.f;
+        wsum += mypix == b.x ? __uint_as_float(b.y) : 0.f;
+        wsum += mypix == b.z ? __uint_as_float(b.w) : 0.f;
+      }
+    } else {
+      for (int s2 = 0; s2 < ns; s2++) {
 #pragma unroll
-      for (int t = 0; t < 4; t++) {
-        const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)ofs[t], s2);
-        const float w = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(wt[t]), s2));
-        wsum += mypix == o ? w : 0.f;
+        for (int t = 0; t < 4; t++) {
+          const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)ofs[t], s2);
+          const float w = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(wt[t]), s2));
+          wsum += mypix == o ? w : 0.f;
+        }
       }
     }
     const unsigned long long nz = __ballot(wsum != 0.f);
@@ -391,6 +412,7 @@ struct RotGather {
 template <typename T>
 __global__ __launch_bounds__(ROT_THREADS) void rot_bwd_table_kernel(RotLevels L, RotGather G, const float* __restrict__ rois) {
   __shared__ int s_over;
+  __shared__ uint4 s_smp[ROT_THREADS / 64][128];  // per wave: the taps of the current bin's samples
   const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int C = L.C, PH = L.PH, PW = L.PW, bins = PH * PW, cap = G.cap;
   const float* roi = rois + (long)k * 6;
@@ -426,7 +448,7 @@ __global__ __launch_bounds__(ROT_THREADS) void rot_bwd_table_kernel(RotLevels L,
       uint2* tb = tk + (long)b * cap;
       const int cnt = rot_bin_merge(g, ph, pw, ns, H, W, inv, cap, lane, [&](int idx, uint32_t pix, float w) {
         tb[idx] = uint2{pbase + pix, __float_as_uint(w)};
-      });
+      }, s_smp[wave]);
       if (lane == 0) {
         bc[b] = cnt < 0 ? 0 : cnt;
         if (cnt < 0) s_over = 1;
