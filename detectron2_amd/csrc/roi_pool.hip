@@ -45,6 +45,7 @@ struct PoolLevels {
   int dbg_block;
   int ablate;  // profiling only (D2AMD_ABLATE): bit0 skip gather, bit1 skip weights, bit2 skip list scan; MFMA tile
                // gather: bit3 no pairing, bit4 no loads of dY, bit5 no weight images, bit6 no items (empty lists), bit7 no stores
+  const int4* tile_geo;   // backward: per tile {level | image << 8, y0 | x0 << 16, H | W << 16, weight} (tile_lists_kernel)
   const int* tile_cnt;    // backward: per tile, number of ROIs that touch it (nullptr: tiles scan the records)
   const void* tile_list;  // backward: [tile][TILE_CAP] TileEntry in ROI order (valid when tile_cnt[tile] <= TILE_CAP)
   unsigned long long* wgstamps;  // profiling only (D2AMD_POOL_STAMPS): per workgroup {start, lists done, loop done, end, #ROIs}
@@ -432,7 +433,7 @@ constexpr int QTAKE = 64, QTAKE_PITCH = 32;  // (word 1 of a queue's line: scrat
 // 104.2 | (16, 8) 101.6 | (12, 8) 114.8 | (12, 6) 122.1 us (finer cuts exhaust the scratch slots, and every part pays
 // the tile's prologue and a scratch round trip); the spread-out lists (longest 16) never reach the planner: 80-82 us
 // with every setting.)
-constexpr int PART_LEN = 8, SPLIT_MIN = 16, MAX_PARTS = 6;
+constexpr int PART_LEN = 20, SPLIT_MIN = 40, MAX_PARTS = 6;  // (weight units: 16 bins of the entries' windows)
 constexpr int SCR_PER_XCD_MAX = 96;  // scratch slots per XCD queue (64 px x C fp32 each: 48 MB at C = 256)
 constexpr int SPLIT_MAX_SLABS = 4;   // channel slabs (of 256 channels, 16-bit) a split tile may have: one ticket each
 constexpr int QTICKETS = 8 * SCR_PER_XCD_MAX * SPLIT_MAX_SLABS;
@@ -510,8 +511,51 @@ __global__ void roi_records_kernel(PoolLevels L, const float* __restrict__ rois,
 // more than TILE_CAP ROIs (clustered proposals) keep the in-kernel scan.
 constexpr int TILE_CAP = 64;
 // list entry = ROI index + the geometry the weights need (one dependent load less in the tile workgroup)
-struct __attribute__((aligned(16))) TileEntry { HitGeo g; int roi; int pad; };  // 32 bytes
+// inclusive prefix sum over the 64 lanes on the DPP network (row shifts inside the rows of 16, then the row broadcasts):
+// six dependent VALU instructions where six __shfl_up are six LDS-crossbar round trips
+__device__ __forceinline__ int wave_incl_scan(int x) {
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);  // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);  // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);  // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);  // row_shr:8
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+  return x;
+}
+
+// (win: the window of bins that can touch the tile, ph_lo | nph << 8 | pw_lo << 16 | npw << 24 -- axis_window below)
+struct __attribute__((aligned(16))) TileEntry { HitGeo g; int roi; int win; };  // 32 bytes
 static_assert(sizeof(TileEntry) == 32, "TileEntry layout");
+// CONSERVATIVE range of bins, along one axis, with a sample that can put weight on the pixels [t0, t0 + 8) of a map of
+// `size` pixels: lo | n << 8.  Sample i of bin p lies at start + p bin + (i + 0.5) bin / grid (axis_weight); it reaches
+// pixel x iff it is valid (in [-1, size]) and |clamp(y, 0, size - 1) - x| < 1, i.e. iff clamp(y) lies in the OPEN interval
+// (t0 - 1, t0 + 8) -- widened to everything below / above for the first / last tile, where the clamp folds the border
+// strip onto the edge pixel.  The bins whose sample span meets that interval are p in (a, b) with the bounds below
+// (for a negative bin size -- an inverted ROI with a fixed sampling ratio -- first and last sample swap roles).  The
+// bounds are widened by 0.02 bin: every bin with a non-zero weight is inside (fp32 rounding of (lo - start) / bin is
+// < 4e-3 bin for |bin| >= 0.01 px and coordinates < 1e6), a bin too many only adds a zero weight.  Degenerate bins take
+// the whole range.
+__device__ __forceinline__ int axis_window(float start, float bin, int grid, int P, int t0, int size) {
+  int p_lo = 0, p_hi = P - 1;
+  if (fabsf(bin) >= 0.01f && fabsf(start) < 1e6f) {  // (NaN: the whole range)
+    const float lo = t0 == 0 ? -2.f : (float)(t0 - 1), hi = t0 + TILE >= size ? (float)(size + 1) : (float)(t0 + TILE);
+    const float rg = 1.f / (float)grid;
+    const float u = (lo - start) / bin, v = (hi - start) / bin;
+    const float a = (bin > 0.f ? u : v) - ((float)grid - 0.5f) * rg;  // p > a
+    const float b = (bin > 0.f ? v : u) - 0.5f * rg;                  // p < b
+    p_lo = max(0, (int)floorf(fminf(fmaxf(a - 0.02f, -1.f), (float)P)) + 1);
+    p_hi = min(P - 1, (int)ceilf(fminf(fmaxf(b + 0.02f, -1.f), (float)P + 1.f)) - 1);
+  }
+  return p_lo | (max(0, p_hi - p_lo + 1) << 8);
+}
+__device__ __forceinline__ int entry_window(const HitGeo& g, int PH, int PW, int y0, int x0, int H, int W) {
+  return axis_window(g.start_h, g.bin_h, g.grid & 0xffff, PH, y0, H) |
+      (axis_window(g.start_w, g.bin_w, g.grid >> 16, PW, x0, W) << 16);
+}
+// WEIGHT of a tile = the k steps of its contraction: (bins of all its entries' windows) / 16.  What the heavy-first
+// queues and the split planner count with -- a 7 x 7 pooler's entry is about one unit, a 14 x 14 pooler's 3-12 (a small
+// ROI whose 196 bins all fall into one tile: 12), so entry counts misjudge a paired launch's lists by that much.
+__device__ __forceinline__ int win_bins(int win) { return ((win >> 8) & 0xff) * ((win >> 24) & 0xff); }
 struct TileGeom { int lvl, n, y0, x0; };
 __device__ __forceinline__ TileGeom tile_geom(const PoolLevels& L, int tile) {
   TileGeom g;
@@ -547,6 +591,7 @@ struct TileQueues {
   int cap[2], thr[2];
   int pass_base[POOL_MAX_LEVELS];  // pass-local tile id of the first tile of each level
   int deal_shift[POOL_MAX_LEVELS]; // level l is dealt to the XCDs in blocks of (1 << shift) x (1 << shift) tiles
+  int split_min, part_len;         // lists heavier than split_min (weight units) are cut into parts of about part_len
   int qbase;                       // ints from mem to the first queue slot (counters, then the split tiles' tickets)
   int scr_total;                   // scratch slots the split lists of a launch may take (0: lists are never split)
   unsigned coarse_mask;            // bit l: level l belongs to pass 1
@@ -568,14 +613,16 @@ constexpr int LISTS_WAVES = 16;  // tiles (waves) per workgroup of tile_lists_ke
 __global__ __launch_bounds__(64 * LISTS_WAVES) void tile_lists_kernel(PoolLevels L, const RoiRec* __restrict__ rec,
                                                                      int ntiles, int* __restrict__ tile_cnt,
                                                                      TileEntry* __restrict__ tile_list, TileQueues Q,
-                                                                     int K1, int* __restrict__ tile_cnt1) {
+                                                                     int K1, int* __restrict__ tile_cnt1, int PH2, int PW2,
+                                                                     int4* __restrict__ tile_geo) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tile = blockIdx.x * LISTS_WAVES + wave;
   const bool live = tile < ntiles;  // uniform per wave; dead waves only take part in the barriers
   TileGeom g{};
-  int cnt = 0, cnt1 = 0;
+  int cnt = 0, cnt1 = 0, wgt = 0;
   if (live) {
     g = tile_geom(L, tile);
+    int kbins = 0;  // this lane's share of the list's window bins
     constexpr int UN = 4;  // record heads of 4 x 64 ROIs in flight (one L2 round trip instead of four)
     for (int k0 = 0; k0 < L.K; k0 += 64 * UN) {
       int4 ra[UN];
@@ -597,15 +644,24 @@ __global__ __launch_bounds__(64 * LISTS_WAVES) void tile_lists_kernel(PoolLevels
           TileEntry e;
           e.g = rec[kk].g;
           e.roi = kk;
-          e.pad = 0;
+          e.win = entry_window(e.g, kk < K1 ? L.PH : PH2, kk < K1 ? L.PW : PW2, g.y0, g.x0, L.H[g.lvl], L.W[g.lvl]);
           tile_list[(long)tile * TILE_CAP + pos] = e;
+          kbins += win_bins(e.win);
         }
         cnt += __builtin_popcountll(bal);
         cnt1 += __builtin_popcountll(__ballot(hit && kk < K1));
       }
     }
+    wgt = (__builtin_amdgcn_readlane(wave_incl_scan(kbins), 63) + 15) >> 4;
+    if (cnt > TILE_CAP) wgt = cnt;  // (the list did not fit: the gather scans the records; never split, always heavy)
     if (lane == 0) __hip_atomic_store(&tile_cnt[tile], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (the planner
-    if (lane == 0 && tile_cnt1) tile_cnt1[tile] = cnt1;                                                  // reads it)
+    if (lane == 0 && tile_cnt1)                                                                          // reads them)
+      __hip_atomic_store(&tile_cnt1[tile], cnt1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0 && tile_geo) {
+      int4* gp = tile_geo + tile;
+      gp->x = g.lvl | (g.n << 8); gp->y = g.y0 | (g.x0 << 16); gp->z = L.H[g.lvl] | (L.W[g.lvl] << 16);
+      __hip_atomic_store(&gp->w, wgt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   if (Q.mem == nullptr) return;  // uniform
   const int H = L.H[g.lvl], W = L.W[g.lvl];
@@ -635,11 +691,10 @@ __global__ __launch_bounds__(64 * LISTS_WAVES) void tile_lists_kernel(PoolLevels
     for (int l = 1; l < POOL_MAX_LEVELS; l++)
       if (l == g.lvl) shift = Q.deal_shift[l];
     x = tile_xcd(g.lvl, g.n, g.y0 >> 3, g.x0 >> 3, (W + 7) >> 3, shift);
-    // (an entry of the second pooler of a pair -- more bins per axis -- is about three of the first one's)
-    heavy = cnt + 2 * (tile_cnt1 ? cnt - cnt1 : 0) >= Q.thr[pass];
+    heavy = wgt >= Q.thr[pass];
     key = (heavy ? 0 : 16) + pass * 8 + x;
-    // a list long enough to be split is queued by the planner below (the last workgroup), not here
-    if (pass == 0 && Q.scr_total > 0 && cnt > SPLIT_MIN && cnt <= TILE_CAP) {
+    // a list heavy enough to be split is queued by the planner below (the last workgroup), not here
+    if (pass == 0 && Q.scr_total > 0 && wgt > Q.split_min && cnt >= 2 && cnt <= TILE_CAP) {
       push = false; key = -1;
       if (lane == 0) atomicOr(Q.mem + QTAKE + 2, 1);  // (device scope; acknowledged before the ticket below)
     }
@@ -688,12 +743,20 @@ __global__ __launch_bounds__(64 * LISTS_WAVES) void tile_lists_kernel(PoolLevels
     int c = 0;
     if (t < ntiles) c = __hip_atomic_load(&tile_cnt[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     TileGeom tg{};
-    bool cand = c > SPLIT_MIN && c <= TILE_CAP;
+    int wgt = 0;
+    if (t < ntiles) wgt = __hip_atomic_load(&tile_geo[t].w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool cand = wgt > Q.split_min && c >= 2 && c <= TILE_CAP;
     if (cand) {
       tg = tile_geom(L, t);
       cand = ((Q.coarse_mask >> tg.lvl) & 1) == 0;
     }
-    const int want = cand ? min((c + PART_LEN - 1) / PART_LEN, MAX_PARTS) : 0;
+    // parts of equal entry counts, none empty: ceil(c / ceil(c / parts wanted by weight))
+    int want = 0;
+    if (cand) {
+      const int w0 = min(min((wgt + Q.part_len - 1) / Q.part_len, MAX_PARTS), c);
+      const int len = (c + w0 - 1) / w0;
+      want = (c + len - 1) / len;
+    }
     // exclusive scan of `want` in tile order: inside the wave, then over the 16 waves, then the running total
     int incl = want;
 #pragma unroll
@@ -2020,6 +2083,584 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, 
   }  // next tile
 }
 
+// ------------------------------------------------------------------------------------------------
+// BACKWARD, NHWC, 16-bit I/O: the K-CONCATENATED tile gather (r06).
+//
+// The per-item pipeline above pays one exposed global round trip, one barrier and ~2,700 cycles of bookkeeping per
+// (tile, ROI) item for four MFMAs (profiles/r03/pool_bwd/README.md: items 6.3 us of a 10.8 us tile).  The gradient of a
+// tile is ONE contraction, though:  G[64 px][C] = W[64 px][K] . D[K][C]  where k runs over EVERY (list entry, bin of
+// its window) pair of the tile -- box-head and mask-head entries of a paired launch alike: an entry only decides which
+// dY row a k reads and which axis weights form its column of W.  The binning kernel hands every list entry its WINDOW of
+// bins (axis_window: conservative, a bin too many only carries zero weights), so the rows to fetch are known before any
+// weight is.  A tile is processed in ROUNDS of list entries and BATCHES of KCAP k's:
+//   1. wave 0 lays out the round (lane = entry): k offsets (prefix of the window sizes), dY row of the window's first
+//      bin, offsets of the entry's axis weights in the pool;
+//   2. every dY row of the first batch is requested at once by LDS-DMA (global_load_lds, 16 B per lane: two 512-B rows
+//      per wave instruction, no staging registers; a lane finds its row by a 5-step search in the k offsets) -- ONE
+//      exposed round trip per batch instead of one per item, and issued BEFORE the weights are evaluated;
+//   3. while the rows fly: the axis weights Wy[bin][tile row], Wx[bin][tile col] / count of the windows (thread = item
+//      of the flattened pool) and the K TABLE (thread = k: offsets of the k's Wy / Wx rows in the pool); then the weight
+//      image W (hi + lo 16-bit parts) of the batch, lane = pixel;
+//   4. acc += (Whi + Wlo) . D on the matrix cores (operands as in the kernel above: staged dY through
+//      ds_read_b64_tr_b16 = A, weight image = B), wave w owns channels [256 w / NW, 256 (w + 1) / NW).
+// The NEXT tile is fetched during the current one by wave 0: the take on the queue counter right behind the tile's
+// first barrier, the queue slot behind the first batch, the first round's list entries (into registers) before the
+// epilogue's barrier -- three of the four dependent round trips of a tile (counter -> slot -> list -> dY rows) leave the
+// critical path.  (The per-item kernel tried that and lost: its waits were "all my memory operations"; here the uses sit
+// where the wave waits for its DMA anyway.)  Work queues, split lists with scratch + tickets, accumulate mode and the
+// epilogue that writes every pixel once as 16-B channel vectors follow the kernel above; a workgroup serves the queue
+// of its own XCD only.  Tiles whose list exceeds TILE_CAP scan the records in chunks into an LDS hit buffer and feed
+// the same rounds.
+// two fp32 -> one dword of two 16-bit values (hardware conversion, round to nearest even), and back
+typedef float kc_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t kc_pack2(float a, float b, bf16_t) {
+  typedef __bf16 v2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(kc_f2{a, b}, v2));
+}
+__device__ __forceinline__ uint32_t kc_pack2(float a, float b, f16_t) {
+  typedef _Float16 v2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(kc_f2{a, b}, v2));
+}
+__device__ __forceinline__ kc_f2 kc_unpack2(uint32_t u, bf16_t) {
+  return kc_f2{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+}
+__device__ __forceinline__ kc_f2 kc_unpack2(uint32_t u, f16_t) {
+  typedef _Float16 v2 __attribute__((ext_vector_type(2)));
+  return __builtin_convertvector(__builtin_bit_cast(v2, u), kc_f2);
+}
+template <int NW, int KCAP>
+struct __attribute__((aligned(16))) KcShared {
+  static constexpr int NT = 64 * NW, ECAP = 32, WPOOL = 1536, WP = KCAP + 8, TK = NT / KCAP * KCAP;
+  char D[KCAP * 512];         // staged dY rows [k][256 channels], 16-bit; the epilogue's [64 px][256 ch] image lies
+                              // over D + Whi + Wlo (+ wpool)
+  uint16_t Whi[64][WP], Wlo[64][WP];  // weight image [pixel][k] (WP: conflict-free 16-B reads)
+  float wpool[WPOOL];         // axis weights of the round: per entry [nph][8 rows], then [npw][8 cols] (x carries 1 / count)
+  int2 ktab[NT];              // per k of the table: {dY row | second pooler << 31, Wy | Wx << 16 byte offsets in the pool}
+  HitGeo geo[ECAP];
+  int row0[ECAP];             // dY row of the window's first bin
+  int woff[64];               // pool offset                                  } entries past the round: INT_MAX (the
+  int pref[64];               // k offset (exclusive prefix of the window sizes) } searches read them unguarded)
+  int dims[ECAP];             // nph | npw << 8 | PW << 16 | second pooler << 24
+  int org[ECAP];              // ph_lo | pw_lo << 8
+  int hits[ECAP + NT];        // record indices found by the in-kernel scan, in order
+  int wcnt[NW];
+  int ctl[16];                // tile: queue entry, slab, logical id, ticket, part info; round: entries [5], pool floats,
+                              // k's; tile geometry (by wave 0, beside the previous tile): level [8], image, y0, x0, H, W
+  int nbuf;
+};
+
+// (waves per SIMD the register allocation is held to = the workgroups the LDS admits per CU x NW / 4 SIMDs)
+template <typename T, int NW, int KCAP>
+__global__ __launch_bounds__(64 * NW, (160 * 1024 / (int)sizeof(KcShared<NW, KCAP>)) * NW / 4) void pool_bwd_kcat_kernel(
+    PoolLevels L, const RoiRec* __restrict__ rec, const T* __restrict__ gout0, int nslab, PoolPairArgs P2) {
+  using SH = KcShared<NW, KCAP>;
+  constexpr int NT = SH::NT, NH = 8 / NW, CHW = 32 * NH, ECAP = SH::ECAP, WPOOL = SH::WPOOL, TK = SH::TK, VEC = 8;
+  constexpr int RPT = TILE * 4 / NW;  // tile rows a thread stores (its pixel column, 16 B of channels)
+  static_assert(NW == 4 || NW == 8, "waves per workgroup");
+  static_assert(KCAP % 16 == 0 && KCAP * 512 + 4 * 64 * SH::WP + 4 * WPOOL >= 64 * 256 * 2, "the epilogue image lies over D + W + pool");
+  static_assert(TK % 4 == 0 && KCAP % 4 == 0, "the weight image reads 4 table entries at once");
+  static_assert(ECAP <= 64 && WPOOL * 4 < (1 << 15) && WPOOL >= 8 * 64, "entries: one wave; pool byte offsets: 15 bits; an entry fits");
+  __shared__ SH S;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int K1 = P2.gout ? P2.K1 : L.K;  // records [0, K1): the first pooler's ROIs, [K1, L.K): the second one's
+  const int C = L.C, CG = C / VEC;
+  const int myq = (int)blockIdx.x & 7, G = (int)(gridDim.x >> 3);
+  const int nh = L.qctr[myq], nl = L.qctr[16 + myq];  // final: tile_lists_kernel is an earlier launch
+#ifdef D2AMD_PROFILE
+  int dbg_n = 0;
+  bool dbg_on = false;
+#define STAMP() do { if (dbg_on && dbg_n < 120) L.dbg[dbg_n++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP() do {} while (0)
+#endif
+
+  // ---- wave 0: the queue and the next tile's list
+  int nx_qe = -1, nx_pinfo = 1 << 8, nx_sl = 0, nx_lg = 0;  // the NEXT tile (uniform in wave 0)
+  int4 nx_geo = int4{0, 0, 0, 0};                            // its geometry (tile_lists_kernel)
+  uint4 pe0 = uint4{0u, 0u, 0u, 0u}, pe1 = pe0;             // its first round's list entries, lane = entry
+  int take_i = (int)(blockIdx.x >> 3);  // entry of the home queue to fetch next (the first one without a take: 64
+                                        // workgroups hitting one counter in the same microsecond are served in turn)
+  int2 slot_v = int2{-1, 0};
+  bool slot_pending = false;
+  // queue entry `take_i` -> slot_v (a load in flight), nx_sl / nx_lg
+  auto slot_issue = [&]() __attribute__((always_inline)) {
+    const int i = __builtin_amdgcn_readfirstlane(take_i);
+    const int ent = i / nslab;
+    slot_v = int2{-1, 0};
+    if (ent < nh + nl) {
+      const int slot = ent < nh ? ent : L.qcap - 1 - (ent - nh);  // heavy from the front, light from the back
+      slot_v = L.queue[(long)myq * L.qcap + slot];
+      nx_sl = i - ent * nslab;
+      nx_lg = ((slot * nslab + nx_sl) << 3) | myq;  // the workgroup id the static mapping gives this (slot, slab)
+    }
+    slot_pending = true;
+  };
+  // slot_v -> nx_qe / nx_pinfo, and the loads of the tile's first list entries
+  auto entries_issue = [&]() __attribute__((always_inline)) {
+    nx_qe = __builtin_amdgcn_readfirstlane(slot_v.x);
+    nx_pinfo = __builtin_amdgcn_readfirstlane(slot_v.y);
+    slot_pending = false;
+    if (nx_qe >= 0) {
+      const int c = (int)((unsigned)nx_qe >> 24);
+      nx_geo = L.tile_geo[nx_qe & 0xffffff];  // (uniform address; used at the top of the next tile)
+      if (c <= TILE_CAP) {
+        const int part = nx_pinfo & 0xff, parts = (nx_pinfo >> 8) & 0xff;
+        const int len = (c + parts - 1) / parts, lo = part * len, hi = min(c, lo + len);
+        if (lane < min(hi - lo, ECAP)) {
+          const uint4* ep = reinterpret_cast<const uint4*>((const TileEntry*)L.tile_list + (long)(nx_qe & 0xffffff) * TILE_CAP + lo + lane);
+          pe0 = ep[0];
+          pe1 = ep[1];
+        }
+      }
+    }
+  };
+  // the layout of a round, lane = entry (wave 0): k offsets, pool offsets, rows; as many entries as the pool holds
+  auto layout_round = [&](bool valid, int roi, const HitGeo& g, int win) __attribute__((always_inline)) {
+    const int pid = roi >= K1 ? 1 : 0;
+    const int PHe = pid ? P2.PH : L.PH, PWe = pid ? P2.PW : L.PW;
+    const int ph_lo = win & 0xff, nph = (win >> 8) & 0xff, pw_lo = (win >> 16) & 0xff, npw = (win >> 24) & 0xff;
+    const int nb = valid ? nph * npw : 0;
+    const int sz = nb > 0 ? 8 * (nph + npw) : 0;  // (an entry without bins takes no pool space)
+    const int isz = wave_incl_scan(sz), inb = wave_incl_scan(nb);
+    const bool fits = valid && isz <= WPOOL;  // monotone: the round is a prefix of the available entries
+    const int nr = __builtin_amdgcn_readfirstlane(__builtin_popcountll(__ballot(fits)));
+    S.woff[lane] = fits ? isz - sz : 0x7fffffff;
+    S.pref[lane] = fits ? inb - nb : 0x7fffffff;
+    if (fits) {
+      S.geo[lane] = g;
+      S.row0[lane] = ((roi - (pid ? K1 : 0)) * PHe + ph_lo) * PWe + pw_lo;
+      S.dims[lane] = nph | (npw << 8) | (PWe << 16) | (pid << 24);
+      S.org[lane] = ph_lo | (pw_lo << 8);
+    }
+    const int used = __builtin_amdgcn_readlane(isz, max(nr - 1, 0)), ktot = __builtin_amdgcn_readlane(inb, max(nr - 1, 0));
+    if (lane == 0) { S.ctl[5] = nr; S.ctl[6] = nr ? used : 0; S.ctl[7] = nr ? ktot : 0; }
+  };
+  auto unpack_entry = [&](const uint4& e0, const uint4& e1, HitGeo& g, int& roi, int& win) __attribute__((always_inline)) {
+    g.start_h = __uint_as_float(e0.x); g.start_w = __uint_as_float(e0.y); g.bin_h = __uint_as_float(e0.z);
+    g.bin_w = __uint_as_float(e0.w); g.inv = __uint_as_float(e1.x); g.grid = (int)e1.y;
+    roi = (int)e1.z; win = (int)e1.w;
+  };
+  if (wave == 0) {
+    slot_issue();
+    entries_issue();
+  }
+
+  const int tid_k = tid, lane_k = lane;
+  for (int round = 0;; round++) {
+    // (the thread index passes through an opaque move per tile: what is derived from it -- LDS addresses of the epilogue,
+    // store offsets -- is then recomputed per tile instead of being hoisted out of this loop, held across it and, at
+    // the register cap, spilled to scratch)
+    int tid_l = tid_k;
+    asm volatile("" : "+v"(tid_l));
+    const int tid = tid_l, lane = tid & 63;
+    (void)lane_k;
+    // ---- wave 0 publishes the tile and, for a prepared list, its first round
+    if (wave == 0) {
+      if (lane == 0) {
+        S.ctl[0] = nx_qe; S.ctl[1] = nx_sl; S.ctl[2] = nx_lg; S.ctl[4] = nx_pinfo;
+        S.ctl[8] = nx_geo.x & 0xff; S.ctl[9] = nx_geo.x >> 8; S.ctl[10] = nx_geo.y & 0xffff; S.ctl[11] = (int)((unsigned)nx_geo.y >> 16);
+        S.ctl[12] = nx_geo.z & 0xffff; S.ctl[13] = (int)((unsigned)nx_geo.z >> 16);
+      }
+      const int c = (int)((unsigned)nx_qe >> 24);
+      if (nx_qe >= 0 && c <= TILE_CAP) {
+        const int part = nx_pinfo & 0xff, parts = (nx_pinfo >> 8) & 0xff;
+        const int len = (c + parts - 1) / parts, lo = part * len, hi = min(c, lo + len);
+        HitGeo g; int roi, win;
+        unpack_entry(pe0, pe1, g, roi, win);
+        layout_round(lane < min(hi - lo, ECAP), roi, g, win);
+      }
+    }
+    __syncthreads();  // A0
+    const int qe = __builtin_amdgcn_readfirstlane(S.ctl[0]);
+    if (qe < 0) return;  // the queue is empty
+    const int slab = __builtin_amdgcn_readfirstlane(S.ctl[1]);
+    const int logical = __builtin_amdgcn_readfirstlane(S.ctl[2]);
+    const int pinfo = __builtin_amdgcn_readfirstlane(S.ctl[4]);  // part | parts << 8 | scratch slot << 16
+    const int tile = qe & 0xffffff, qcnt = (int)((unsigned)qe >> 24);
+    // the take for the tile after this one
+    if (wave == 0 && lane == 0) take_i = G + atomicAdd(L.qctr + QTAKE + QTAKE_PITCH * myq, 1);
+#ifdef D2AMD_PROFILE
+    dbg_on = L.dbg && logical == L.dbg_block && tid == 0;
+#endif
+    STAMP();
+#define KST(k, v) do { if (L.wgstamps && tid == 0) L.wgstamps[5 * (size_t)logical + (k)] = (v); } while (0)
+    KST(0, wall_clock64());
+    const int lvl = __builtin_amdgcn_readfirstlane(S.ctl[8]), n = __builtin_amdgcn_readfirstlane(S.ctl[9]);
+    const int y0 = __builtin_amdgcn_readfirstlane(S.ctl[10]), x0 = __builtin_amdgcn_readfirstlane(S.ctl[11]);
+    const int H = __builtin_amdgcn_readfirstlane(S.ctl[12]), W = __builtin_amdgcn_readfirstlane(S.ctl[13]);
+    const int lp = tid & 31;          // 16-B channel group of the slab this thread loads / stores
+    const int cg = slab * LPP + lp;
+    const bool cg_ok = cg < CG;
+    const int cofs = min(cg, CG - 1) * VEC;
+    bool ch_ok[NH];
+#pragma unroll
+    for (int h = 0; h < NH; h++) ch_ok[h] = slab * (LPP * VEC) + CHW * wave + 32 * h < C;
+
+    // the part of the tile's list this workgroup walks: entries [lo, hi) of the prepared list, or (lo < 0: more than
+    // TILE_CAP ROIs) the records are scanned
+    int lo = -1, hi = 0;
+    if (qcnt <= TILE_CAP) {
+      const int part = pinfo & 0xff, parts = (pinfo >> 8) & 0xff;
+      const int len = (qcnt + parts - 1) / parts;
+      lo = part * len;
+      hi = min(qcnt, lo + len);
+    }
+    const bool prelist = lo >= 0;
+    const TileEntry* tlist = (const TileEntry*)L.tile_list + (long)tile * TILE_CAP;
+
+    // wave w accumulates channels [CHW w, CHW w + CHW) of the slab: acc[mt][h] = [32 channels of half h] x [pixels of
+    // tile rows 4 mt .. 4 mt + 3]; lane = pixel, a register quad = 4 consecutive channels
+    f32x16_t acc[2][NH];
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+      for (int h = 0; h < NH; h++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[mt][h][i] = 0.f;
+
+    int done = prelist ? lo : 0;  // prelist: next list entry; scan: next record
+    int wst_n = 0;
+    bool have_round = prelist;    // (the first round of a prepared list came with the tile)
+    if (!prelist && tid == 0) S.nbuf = 0;
+    while (true) {
+      // ---- 1. the round's entries
+      if (!have_round) {
+        if (prelist) {
+          if (done >= hi) break;  // uniform: the list is done
+          if (wave == 0) {
+            const bool valid = lane < min(hi - done, ECAP);
+            HitGeo g{}; int roi = 0, win = 0;
+            if (valid) {
+              const uint4* ep = reinterpret_cast<const uint4*>(tlist + done + lane);
+              const uint4 e0 = ep[0], e1 = ep[1];
+              unpack_entry(e0, e1, g, roi, win);
+            }
+            layout_round(valid, roi, g, win);
+          }
+        } else {
+          __syncthreads();  // nbuf / the compacted hit buffer are visible
+          while (true) {
+            const int nbuf = S.nbuf;
+            if (nbuf >= ECAP || done >= L.K) break;  // uniform
+            const int kk = done + tid;
+            const long r = min(kk, L.K - 1);
+            const int4 ra = *reinterpret_cast<const int4*>(&rec[r].level);  // level, batch, fy0, fy1
+            const int2 rb = *reinterpret_cast<const int2*>(&rec[r].fx0);    // fx0, fx1
+            const bool hit = kk < L.K && ra.x == lvl && ra.y == n && ra.w >= y0 && ra.z < y0 + TILE && rb.y >= x0 &&
+                rb.x < x0 + TILE;
+            const unsigned long long bal = __ballot(hit);
+            if (lane == 0) S.wcnt[wave] = __builtin_popcountll(bal);
+            __syncthreads();
+            int off = nbuf, tot = 0;
+#pragma unroll
+            for (int w2 = 0; w2 < NW; w2++) {
+              const int c2 = S.wcnt[w2];
+              if (w2 < wave) off += c2;
+              tot += c2;
+            }
+            if (hit) S.hits[off + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = kk;
+            __syncthreads();  // everyone has read nbuf and the counts
+            if (tid == 0) S.nbuf = nbuf + tot;
+            done += NT;
+            __syncthreads();
+          }
+          const int navail = min(S.nbuf, ECAP);
+          if (navail <= 0) break;  // uniform: the records are done
+          if (wave == 0) {
+            const bool valid = lane < navail;
+            HitGeo g{}; int roi = 0, win = 0;
+            if (valid) {
+              roi = S.hits[lane];
+              const uint2* gp = reinterpret_cast<const uint2*>(&rec[roi].g);
+              const uint2 a = gp[0], b = gp[1], c = gp[2];
+              g.start_h = __uint_as_float(a.x); g.start_w = __uint_as_float(a.y); g.bin_h = __uint_as_float(b.x);
+              g.bin_w = __uint_as_float(b.y); g.inv = __uint_as_float(c.x); g.grid = (int)c.y;
+              const int pid = roi >= K1 ? 1 : 0;
+              win = entry_window(g, pid ? P2.PH : L.PH, pid ? P2.PW : L.PW, y0, x0, H, W);
+            }
+            layout_round(valid, roi, g, win);
+          }
+        }
+        __syncthreads();  // A
+      }
+      have_round = false;
+      const int nr = (L.ablate & 64) ? 0 : S.ctl[5];
+      if (nr <= 0) break;  // uniform (an empty part, or the ablation)
+      const int pool_used = S.ctl[6], ktot = S.ctl[7];
+      if (L.wgstamps) { if (wst_n == 0) KST(1, wall_clock64()); wst_n += nr; }
+      STAMP();
+
+      // entry of k (of pool item i): the last e with pref[e] (woff[e]) <= k; entries without bins are skipped over
+      auto entry_of = [&](const int* __restrict__ tab, int k) __attribute__((always_inline)) {
+        int e = 0;
+#pragma unroll
+        for (int step = 16; step > 0; step >>= 1) e += tab[e + step] <= k ? step : 0;  // (tab[e >= nr] = INT_MAX)
+        return e;
+      };
+      for (int kb0 = 0; kb0 < ktot; kb0 += KCAP) {
+        const int kb = min(KCAP, ktot - kb0), kb16 = (kb + 15) & ~15;
+        const bool new_table = kb0 % TK == 0;  // uniform
+        if (new_table) {
+          // ---- 2. the K table of k in [kb0, kb0 + TK): thread = k, one search in the k offsets
+          if (tid < TK) {  // (k past the round's last: offsets 0 -- the weight image reads the whole batch unguarded)
+            const int k = min(kb0 + tid, ktot - 1);
+            const int e = entry_of(S.pref, k);
+            const int il = k - S.pref[e], dims = S.dims[e];
+            const int nph = dims & 0xff, npw = (dims >> 8) & 0xff, PWe = (dims >> 16) & 0xff, wo = S.woff[e];
+            const int q = (int)(((float)il + 0.5f) * __builtin_amdgcn_rcpf((float)npw));  // il / npw  (il < 1024)
+            const int pi = il - q * npw;
+            const int2 t = int2{(S.row0[e] + q * PWe + pi) | ((dims >> 24) << 31),
+                                ((wo + q * 8) * 4) | (((wo + 8 * nph + pi * 8) * 4) << 16)};  // BYTE offsets into the pool
+            S.ktab[tid] = kb0 + tid < ktot ? t : int2{0, 0};
+          }
+          __syncthreads();  // C
+          STAMP();
+        }
+        // ---- 3. every dY row of the batch by LDS-DMA: lanes 0-31 / 32-63 of an instruction fetch rows k2 / k2 + 1.
+        // (Source addresses first, then the instructions back to back, as inline assembly: the compiler orders an
+        // LDS-DMA it knows about -- __builtin_amdgcn_global_load_lds -- before EVERY later LDS read with s_waitcnt
+        // vmcnt(0), so the first version waited out a full round trip behind each instruction and again before the
+        // weights.  Untracked, the rows are waited for once, in front of barrier D.)
+        if (!(L.ablate & 16)) {
+          constexpr int NI = KCAP / (2 * NW);
+          const int t0 = kb0 % TK;
+          int rows[NI];
+#pragma unroll
+          for (int i = 0; i < NI; i++) rows[i] = S.ktab[t0 + min((i * NW + wave) * 2 + (lane >> 5), kb - 1)].x;
+          const unsigned d_lds = (unsigned)(size_t)S.D;  // (the low word of a flat LDS address is the LDS offset)
+#pragma unroll
+          for (int i = 0; i < NI; i++) {
+            const int k2 = (i * NW + wave) * 2;  // uniform
+            if (k2 < kb && k2 + (lane >> 5) < kb && cg_ok) {
+              const T* src = (rows[i] < 0 ? (const T*)P2.gout : gout0) + (size_t)(unsigned)(rows[i] & 0x7fffffff) * (size_t)C + cofs;
+              asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                           ::"v"(src), "s"(__builtin_amdgcn_readfirstlane(d_lds + k2 * 512)) : "memory");
+            }
+          }
+        }
+        // rows [kb, kb16): zeros (their weights are 0; stale bits might be NaN)
+        for (int z = tid; z < (kb16 - kb) * 32; z += NT)
+          *reinterpret_cast<uint4*>(S.D + (kb + (z >> 5)) * 512 + (z & 31) * 16) = uint4{0u, 0u, 0u, 0u};
+        STAMP();
+        if (kb0 == 0) {
+          // ---- 4a. (first batch, while the rows fly) the axis weights of the round's windows: a WAVE per entry (its
+          // geometry is wave-uniform), lane = (bin of the window, tile row / column): [nph][8], then [npw][8]
+          for (int e = wave; e < nr; e += NW) {
+            const HitGeo g = S.geo[e];
+            const int dims = S.dims[e], org = S.org[e], wo = S.woff[e];
+            const int nph = dims & 0xff, npw = (dims >> 8) & 0xff;
+            const int items = nph * npw > 0 ? 8 * (nph + npw) : 0;  // (an entry without bins owns no pool space)
+            for (int j = lane; j < items; j += 64) {
+              const bool is_x = j >= 8 * nph;
+              const int jj = is_x ? j - 8 * nph : j;
+              const int p = (is_x ? (org >> 8) : (org & 0xff)) + (jj >> 3), r = jj & 7;
+              const int grid = is_x ? (g.grid >> 16) : (g.grid & 0xffff);
+              const int size = is_x ? W : H, pix = (is_x ? x0 : y0) + r;
+              float wv = 0.f;
+              if (pix < size) wv = axis_weight(is_x ? g.start_w : g.start_h, is_x ? g.bin_w : g.bin_h, grid, p, pix, size);
+              S.wpool[wo + j] = is_x ? wv * g.inv : wv;
+            }
+          }
+          STAMP();
+          __syncthreads();  // B: the weights are complete
+          STAMP();
+        }
+        // ---- 4b. the weight image of the batch: lane = pixel, a wave builds 4 consecutive k's per step.  All KCAP
+        // columns, unrolled and without a branch (k past the batch: offset 0, weight selected to 0): the table / pool
+        // reads of every step are in flight together -- guarded per k they ran one LDS round trip after the other.
+        if (!(L.ablate & 32)) {
+          const int t0 = kb0 % TK;
+          const char* pool = reinterpret_cast<const char*>(S.wpool);
+          const int r4 = (lane >> 3) * 4, c4 = (lane & 7) * 4;
+#pragma unroll
+          for (int kq0 = 0; kq0 < KCAP; kq0 += 4 * NW) {
+            const int kq = kq0 + 4 * wave;
+            if (kq >= KCAP) break;  // uniform (only where 4 NW does not divide KCAP)
+            const int4 ca = *reinterpret_cast<const int4*>(&S.ktab[t0 + kq]), cb = *reinterpret_cast<const int4*>(&S.ktab[t0 + kq + 2]);
+            const int codes[4] = {ca.y, ca.w, cb.y, cb.w};
+            float wv[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              const float wy = *reinterpret_cast<const float*>(pool + (codes[j] & 0xffff) + r4);
+              const float wx = *reinterpret_cast<const float*>(pool + ((unsigned)codes[j] >> 16) + c4);
+              wv[j] = kq + j < kb ? wy * wx : 0.f;
+            }
+            // hi = w rounded to the I/O dtype, lo = (w - hi) rounded
+            const uint32_t h01 = kc_pack2(wv[0], wv[1], T{}), h23 = kc_pack2(wv[2], wv[3], T{});
+            const kc_f2 f01 = kc_unpack2(h01, T{}), f23 = kc_unpack2(h23, T{});
+            const uint32_t l01 = kc_pack2(wv[0] - f01.x, wv[1] - f01.y, T{}), l23 = kc_pack2(wv[2] - f23.x, wv[3] - f23.y, T{});
+            *reinterpret_cast<uint2*>(&S.Whi[lane][kq]) = uint2{h01, h23};
+            *reinterpret_cast<uint2*>(&S.Wlo[lane][kq]) = uint2{l01, l23};
+          }
+        }
+        STAMP();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA rows have landed (wave 0: and the take)
+        if (wave == 0 && !slot_pending) slot_issue();  // (the tile's first batch: the take has returned)
+        __syncthreads();                // D
+        STAMP();
+        // ---- 4. acc += (Whi + Wlo) . D
+        if (!(L.ablate & 1)) {
+          const int kh = lane >> 5;
+          for (int ks = 0; ks < kb16 / 16; ks++) {
+            s16x8_t bh[2], bl[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++) {
+              const int px = 32 * mt + (lane & 31);
+              bh[mt] = *reinterpret_cast<const s16x8_t*>(&S.Whi[px][16 * ks + 8 * kh]);
+              bl[mt] = *reinterpret_cast<const s16x8_t*>(&S.Wlo[px][16 * ks + 8 * kh]);
+            }
+#pragma unroll
+            for (int h = 0; h < NH; h++) {
+              if (!ch_ok[h]) continue;  // uniform per wave
+              // tr16 address of this lane inside a [4 k][16 channels] block of the half's 32 channels
+              const char* bp = S.D + (16 * ks + 8 * kh + ((lane & 15) >> 2)) * 512 +
+                  (CHW * wave + 32 * h + 16 * ((lane >> 4) & 1) + (lane & 3) * 4) * 2;
+              const s16x4_t t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)bp);
+              const s16x4_t t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(bp + 4 * 512));
+              const s16x8_t a = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+              for (int mt = 0; mt < 2; mt++) {
+                acc[mt][h] = pool_mma(a, bh[mt], acc[mt][h], T{});
+                acc[mt][h] = pool_mma(a, bl[mt], acc[mt][h], T{});
+              }
+            }
+          }
+        }
+        STAMP();
+        __syncthreads();  // E: D, W (and, behind the last batch, the table / the round's entries) may be overwritten
+        STAMP();
+      }
+      // ---- next round
+      if (prelist) {
+        done += nr;
+      } else {  // the round took the first nr hits: move the others to the front
+        const int rem = S.nbuf - nr;
+        int v0 = 0, v1 = 0;
+        if (tid < rem) v0 = S.hits[nr + tid];
+        if (tid + NT < rem) v1 = S.hits[nr + tid + NT];
+        __syncthreads();
+        if (tid < rem) S.hits[tid] = v0;
+        if (tid + NT < rem) S.hits[tid + NT] = v1;
+        if (tid == 0) S.nbuf = rem;
+      }
+    }
+    KST(2, wall_clock64());
+    if (wave == 0 && !slot_pending) slot_issue();  // (a tile without a batch)
+
+    // ---- split list: this part's accumulators go to its scratch slot; the last part to arrive adds all parts in part
+    // order and writes the tile (see pool_bwd_mfma_kernel)
+    if (((pinfo >> 8) & 0xff) > 1) {  // uniform
+      const int part = pinfo & 0xff, parts = (pinfo >> 8) & 0xff, sbase = (int)((unsigned)pinfo >> 16);
+      constexpr int NA = 32 * NH;  // accumulators per thread
+      const size_t slot_floats = (size_t)nslab * NA * NT;
+      float* mine = L.part_scratch + ((size_t)(sbase + part) * nslab + slab) * NA * NT + tid;
+#pragma unroll
+      for (int i = 0; i < NA; i++)
+        __hip_atomic_store(mine + i * NT, acc[(i >> 4) & 1][i >> 5][i & 15], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_s_waitcnt(0);  // acknowledged = visible
+      __syncthreads();
+      if (tid == 0)
+        S.ctl[3] = __hip_atomic_fetch_add(L.part_tickets + sbase * SPLIT_MAX_SLABS + slab, 1, __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      if (S.ctl[3] != parts - 1) {  // uniform: another part finishes this tile
+        if (wave == 0) entries_issue();
+        KST(3, wall_clock64());
+        KST(4, (unsigned long long)wst_n | (unsigned long long)blockIdx.x << 32 | 1ull << 56);
+        continue;
+      }
+      if (tid == 0)  // re-armed for a second gather over the same binned workspace
+        __hip_atomic_store(L.part_tickets + sbase * SPLIT_MAX_SLABS + slab, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float* all = L.part_scratch + ((size_t)sbase * nslab + slab) * NA * NT + tid;
+#pragma unroll
+      for (int i = 0; i < NA; i++) acc[(i >> 4) & 1][i >> 5][i & 15] = 0.f;
+      for (int q = 0; q < parts; q++) {  // (a part's NA loads in flight together: the combine is their latency)
+        float v[NA];
+#pragma unroll
+        for (int i = 0; i < NA; i++)
+          v[i] = __hip_atomic_load(all + (size_t)q * slot_floats + i * NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int i = 0; i < NA; i++) acc[(i >> 4) & 1][i >> 5][i & 15] += v[i];
+      }
+    }
+    // ---- epilogue: accumulators -> LDS [pixel][channel] in the I/O dtype (a pixel's 32 16-B chunks at chunk ^
+    // (pixel & 31)) -> 16-B channel vectors, every pixel of grad_input written exactly once
+    T* obuf = reinterpret_cast<T*>(&S);
+#pragma unroll
+    for (int h = 0; h < NH; h++) {
+      if (!ch_ok[h]) continue;
+#pragma unroll
+      for (int mt = 0; mt < 2; mt++) {
+        const int px = 32 * mt + (lane & 31);
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const int ch = CHW * wave + 32 * h + 8 * g + 4 * (lane >> 5);  // 4 consecutive channels: half a 16-B chunk
+          uint2 w;
+          w.x = (uint32_t)from_f32<T>(acc[mt][h][4 * g]).v | ((uint32_t)from_f32<T>(acc[mt][h][4 * g + 1]).v << 16);
+          w.y = (uint32_t)from_f32<T>(acc[mt][h][4 * g + 2]).v | ((uint32_t)from_f32<T>(acc[mt][h][4 * g + 3]).v << 16);
+          *reinterpret_cast<uint2*>(obuf + px * (LPP * VEC) + (((ch >> 3) ^ (px & 31)) << 3) + (ch & 4)) = w;
+        }
+      }
+    }
+    if (wave == 0) entries_issue();  // the next tile's queue slot has arrived: its list entries fly under the stores
+    STAMP();
+    const int col = (tid >> 5) & 7, r0 = (tid >> 8) * RPT;  // pixel column / first tile row of this thread
+    const bool mine = cg_ok && x0 + col < W && !(L.ablate & 128);
+    if (L.accumulate) {
+      // the rows this thread adds to are fetched now (the accumulators are dead) and fly under the barrier
+      raw16 held[RPT];
+      T* gi = (T*)L.data[lvl] + (((long)n * H + y0 + r0) * W + min(x0 + col, W - 1)) * C + cofs;
+#pragma unroll
+      for (int i = 0; i < RPT; i++)
+        held[i] = *reinterpret_cast<const raw16*>(gi + (long)max(min(i, H - 1 - (y0 + r0)), -r0) * W * C);
+      __syncthreads();  // F
+      if (mine) {
+#pragma unroll
+        for (int i = 0; i < RPT; i++) {
+          if (y0 + r0 + i >= H) break;
+          const int px = (r0 + i) * TILE + col;
+          const raw16 v = *reinterpret_cast<const raw16*>(obuf + px * (LPP * VEC) + ((lp ^ (px & 31)) * VEC));
+          float a[VEC], b[VEC];  // round(held + round(own)), what autograd's add of two gradients gives
+          unpack16(held[i], a, T{});
+          unpack16(v, b, T{});
+#pragma unroll
+          for (int q = 0; q < VEC; q++) a[q] += b[q];
+          *reinterpret_cast<raw16*>(gi + (long)i * W * C) = pack16(a, T{});
+        }
+      }
+    } else {
+      __syncthreads();  // F
+      STAMP();
+      if (mine) {
+        // (all rows out of LDS first, then the stores back to back: one register set for both made the compiler wait
+        // for every store before the next LDS read could overwrite its data)
+        T* gi = (T*)L.data[lvl] + (((long)n * H + y0 + r0) * W + x0 + col) * C + cofs;
+        raw16 v[RPT];
+#pragma unroll
+        for (int i = 0; i < RPT; i++) {
+          const int px = (r0 + i) * TILE + col;
+          v[i] = *reinterpret_cast<const raw16*>(obuf + px * (LPP * VEC) + ((lp ^ (px & 31)) * VEC));
+        }
+#pragma unroll
+        for (int i = 0; i < RPT; i++)
+          if (y0 + r0 + i < H) *reinterpret_cast<raw16*>(gi + (long)i * W * C) = v[i];
+      }
+    }
+    STAMP();
+#ifdef D2AMD_PROFILE
+    if (dbg_on) { L.dbg[127] = dbg_n; L.dbg[126] = (unsigned long long)wst_n; L.dbg[125] = __builtin_readcyclecounter() - L.dbg[0]; }
+    dbg_n = 0;
+#endif
+    KST(3, wall_clock64());
+    KST(4, (unsigned long long)wst_n | (unsigned long long)blockIdx.x << 32);
+#undef KST
+    // (no barrier here: the image is read before the stores issue; the next tile's first writes over it -- zero rows, DMA
+    // rows -- lie behind its barrier A0, which every wave reaches only after its reads of the image)
+  }
+#undef STAMP
+}
+
 // ---- convert_boxes_to_pooler_format (poolers.py:62-104) in one launch, no host sync -----------------
 struct ImgEnds { int n; int end[D2AMD_POOLER_MAX_IMAGES]; };  // exclusive prefix ends of the per-image box counts
 __global__ void boxes_to_rois_kernel(const float* __restrict__ boxes, int K, int width, ImgEnds e,
@@ -2411,11 +3052,14 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
   // per-tile ROI lists live behind the records when the caller sized the workspace with
   // d2amd_roi_pooler_backward_workspace_bytes (the older K-only size still works: tiles then scan)
   const long ntiles = pool_ntiles(p);
-  const size_t off_cnt = pool_al(need), off_list = off_cnt + pool_al((size_t)ntiles * 4) * (pair ? 2 : 1);
+  // (counts [+ the first pooler's counts of a pair], the tiles' geometry, the lists, the queues, the scratch slots)
+  const size_t off_cnt = pool_al(need), off_geo = off_cnt + pool_al((size_t)ntiles * 4) * (pair ? 2 : 1);
+  const size_t off_list = off_geo + pool_al((size_t)ntiles * sizeof(int4));
   const bool lists = K > 0 && ntiles > 0 && workspace_bytes >= off_list + (size_t)ntiles * TILE_CAP * sizeof(TileEntry) &&
       d2_prof_env("D2AMD_POOL_NOLISTS") == nullptr;
   int* tile_cnt = lists ? (int*)((char*)workspace + off_cnt) : nullptr;
   int* tile_cnt1 = lists && pair ? (int*)((char*)workspace + off_cnt + pool_al((size_t)ntiles * 4)) : nullptr;
+  int4* tile_geo = lists ? (int4*)((char*)workspace + off_geo) : nullptr;
   TileEntry* tile_list = lists ? (TileEntry*)((char*)workspace + off_list) : nullptr;
   PoolLevels L0 = make_levels(p, (const void* const*)grad_inputs, K);
   L0.accumulate = (accumulate && phase != 3) ? 1 : 0;
@@ -2440,8 +3084,7 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
       nslab <= SPLIT_MAX_SLABS;
   const size_t slot_bytes = (size_t)nslab * 32 * (2 * CT) * sizeof(float);  // 16 accumulators x 2 tiles x 512 threads
   if (pair || probe) {  // the paired gather exists in the persistent MFMA tile gather only
-    static const bool fixed = d2_prof_env("D2AMD_POOL_STATIC") != nullptr || d2_prof_env("D2AMD_POOL_STAMPS") != nullptr ||
-        d2_prof_env("D2AMD_POOL_STAMPS_STATIC") != nullptr;
+    static const bool fixed = d2_prof_env("D2AMD_POOL_STATIC") != nullptr || d2_prof_env("D2AMD_POOL_STAMPS_STATIC") != nullptr;
     const int pm = p->pooled_h > p->pooled_w ? p->pooled_h : p->pooled_w;
     const bool ok = staged && sizeof(T) == 2 && !no_mfma_env && !fixed && p->C % 32 == 0 && p->C <= 8192 && K_first > 0 &&
         pm <= 8 && phase <= 2 && !accumulate;
@@ -2479,6 +3122,9 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
     const int thr_f = staged ? thr_s : thr_f0;
     static const int thr_c = d2_prof_env("D2AMD_POOL_QTHR_COARSE") ? atoi(d2_prof_env("D2AMD_POOL_QTHR_COARSE")) : 16;
     Q.thr[0] = thr_f; Q.thr[1] = thr_c;
+    static const int split_min = d2_prof_env("D2AMD_POOL_SPLIT_MIN") ? atoi(d2_prof_env("D2AMD_POOL_SPLIT_MIN")) : SPLIT_MIN;
+    static const int part_len = d2_prof_env("D2AMD_POOL_PART_LEN") ? atoi(d2_prof_env("D2AMD_POOL_PART_LEN")) : PART_LEN;
+    Q.split_min = split_min; Q.part_len = part_len > 0 ? part_len : PART_LEN;
     Q.mem = (int*)((char*)workspace + off_q);
     Q.esize = (int)sizeof(T);
     Q.zero_fill = vec ? 1 : 0;
@@ -2498,7 +3144,8 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
     D2_LAUNCH_OK();
     if (lists) {
       hipLaunchKernelGGL(tile_lists_kernel, dim3(cdiv(ntiles, LISTS_WAVES)), dim3(64 * LISTS_WAVES), 0, s, L0, rec, (int)ntiles, tile_cnt,
-                         tile_list, Q, K_first, tile_cnt1);
+                         tile_list, Q, K_first, tile_cnt1, pair ? pair->p2->pooled_h : p->pooled_h,
+                         pair ? pair->p2->pooled_w : p->pooled_w, tile_geo);
       D2_LAUNCH_OK();
     }
   }
@@ -2515,6 +3162,7 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
     for (int l = 0; l < p->num_levels; l++) ids.first[l] = L0.tile_base[l];
     L.tile_cnt = tile_cnt;
     L.tile_list = tile_list;
+    L.tile_geo = tile_geo;
     L.queue = reinterpret_cast<const int2*>(Q.mem + Q.qbase);
     L.qcap = Q.cap[0];
     L.part_tickets = Q.mem + QCTR;
@@ -2566,6 +3214,20 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
                                (int)total, ids, P2);
           }
         };
+        // r06: the K-concatenated tile gather (persistent workgroups only; D2AMD_POOL_KCAT = 0: the per-item pipeline,
+        // 1: 4 waves x 48 k, 2: 4 x 64, 3: 8 x 64 -- profiling builds)
+        static const int kcat = d2_prof_env("D2AMD_POOL_KCAT") ? atoi(d2_prof_env("D2AMD_POOL_KCAT")) : 1;
+        auto launch_kcat = [&](auto fn, int threads) {
+          const long r = resident_workgroups((const void*)fn, threads) & ~7l;
+          const unsigned grid = (unsigned)(r >= 8 && r < total ? r : total);
+          hipLaunchKernelGGL(fn, dim3(grid), dim3(threads), 0, s, L, rec, (const T*)grad_output, nslab, P2);
+        };
+        if (L.qctr && kcat == 1) launch_kcat(pool_bwd_kcat_kernel<T, 4, 48>, 256);
+        else if (L.qctr && kcat == 2) launch_kcat(pool_bwd_kcat_kernel<T, 4, 64>, 256);
+        else if (L.qctr && kcat == 3) launch_kcat(pool_bwd_kcat_kernel<T, 8, 64>, 512);
+        else if (L.qctr && kcat == 4) launch_kcat(pool_bwd_kcat_kernel<T, 8, 48>, 512);
+        else if (L.qctr && kcat == 5) launch_kcat(pool_bwd_kcat_kernel<T, 4, 32>, 256);
+        else
         if (pair) launch(pool_bwd_mfma_kernel<T, 8, true, 16>, pool_bwd_mfma_kernel<T, 8, true, 16>);  // (persistent only)
         else if (pmax <= 8) launch(pool_bwd_mfma_kernel<T, 8, true>, pool_bwd_mfma_kernel<T, 8, false>);
         else if (pmax <= 16) launch(pool_bwd_mfma_kernel<T, 16, true>, pool_bwd_mfma_kernel<T, 16, false>);
@@ -2915,8 +3577,8 @@ extern "C" size_t d2amd_roi_pooler_backward_workspace_bytes(const d2amd_pooler_p
   // ... + the scratch slots of split tile lists (16-bit I/O; see SPLIT TILES)
   const int vecn = 8, nslab = cdiv(cdiv(p->C, vecn), LPP);
   const size_t scratch = p->dtype == D2AMD_F32 ? 0 : (size_t)8 * SCR_PER_XCD_MAX * nslab * 32 * (2 * CT) * sizeof(float);
-  return pool_al(need) + pool_al((size_t)ntiles * 4) + pool_al((size_t)ntiles * TILE_CAP * sizeof(TileEntry)) +
-      pool_queue_bytes(ntiles) + scratch + 256;
+  return pool_al(need) + pool_al((size_t)ntiles * 4) + pool_al((size_t)ntiles * sizeof(int4)) +
+      pool_al((size_t)ntiles * TILE_CAP * sizeof(TileEntry)) + pool_queue_bytes(ntiles) + scratch + 256;
 }
 
 static int pooler_backward_entry(const d2amd_pooler_params* p, const void* grad_output, const float* rois,

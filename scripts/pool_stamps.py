@@ -6,13 +6,17 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 which = sys.argv[1] if len(sys.argv) > 1 else "box"
 w = bench.Workload(torch.device("cuda", 0), torch.bfloat16, "nhwc")
-pooler, lists, grad = (w.box_pooler, w.box_lists, w.gbox) if which == "box" else (w.mask_pooler, w.mask_lists, w.gmask)
-y = pooler(w.feats, lists)
+if which == "pair":  # both poolers chained onto the same features: ONE paired gather
+    from detectron2_amd.modeling import pool_pair
+    y, grad = list(pool_pair(w.box_pooler, w.mask_pooler, w.feats, w.box_lists, w.mask_lists)), [w.gbox, w.gmask]
+else:
+    pooler, lists, g1 = (w.box_pooler, w.box_lists, w.gbox) if which == "box" else (w.mask_pooler, w.mask_lists, w.gmask)
+    y, grad = [pooler(w.feats, lists)], [g1]
 for _ in range(3):
-    torch.autograd.grad([y], w.feats, [grad], retain_graph=True)
+    torch.autograd.grad(y, w.feats, grad, retain_graph=True)
 torch.cuda.synchronize()
 os.environ["D2AMD_POOL_STAMPS"] = "/tmp/pool_stamps"
-torch.autograd.grad([y], w.feats, [grad], retain_graph=True)
+torch.autograd.grad(y, w.feats, grad, retain_graph=True)
 torch.cuda.synchronize()
 os.environ.pop("D2AMD_POOL_STAMPS")
 for ps, name in ((0, "fine levels"), (1, "coarse levels")):
@@ -23,7 +27,7 @@ for ps, name in ((0, "fine levels"), (1, "coarse levels")):
     t0 = d[:, 1].min()
     st, ls, lp, en = [(d[:, i] - t0) / 100.0 for i in (1, 2, 3, 4)]
     ls = np.where(d[:, 2] > 0, ls, st)
-    n = d[:, 5] & 0xffffffff  # (bits 32+: the XCD whose workgroup ran the tile; the row index & 7 = the queue's XCD)
+    n = d[:, 5] & 0xffffff  # (bits 32+: the XCD whose workgroup ran the tile; the row index & 7 = the queue's XCD)
     stolen = ((d[:, 5] >> 32) & 7) != (d[:, 0] & 7)
     print(f'  tiles taken from another XCD\'s queue: {int(stolen.sum())}')
     print(f"{which} {name}: {len(d)} workgroups, span {en.max():.1f} us; ROIs/tile mean {n.mean():.2f} max {n.max()} zero {np.mean(n == 0):.2f}")
@@ -31,6 +35,10 @@ for ps, name in ((0, "fine levels"), (1, "coarse levels")):
     for nm, a, b in (("scan", st, ls), ("rois", ls, lp), ("write", lp, en), ("total", st, en)):
         v = b - a
         print(f"  {nm:6s}: mean {v.mean():.2f} p50 {np.median(v):.2f} p90 {np.percentile(v, 90):.2f} max {v.max():.2f} us")
+    part = (d[:, 5] >> 56) & 1
+    top = np.argsort(-(en - st))[:8]
+    print("  longest tiles (us, start, ROIs, part of a split list): " + ", ".join(f"{(en - st)[i]:.1f}@{st[i]:.1f} n={n[i] & 0xffffff} p={part[i]}" for i in top))
+    print(f"  parts of split lists: {int(part.sum())}")
     for k in (0, 1, 2, 4, 8, 16, 32):
         m = n == k
         if m.any():
