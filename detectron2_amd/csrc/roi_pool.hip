@@ -57,7 +57,6 @@ struct PoolLevels {
   int* part_tickets;    // ... and one arrival counter per split tile (at its first scratch slot)
   int* qctr;         // backward: the queues' counters (TileQueues::mem); non-null: persistent workgroups FETCH their tiles
                      // (take counter per XCD, then the other XCDs' queues) instead of serving slot blockIdx >> 3
-  int qsteal;        // how many OTHER XCDs' queues a persistent workgroup tries once its own is empty (0: none)
   int accumulate;    // backward: 1 = grad_input already holds a gradient (another pooler's): add to it, skip empty tiles
   const int* perm;   // forward: ROI processing order (roi_order_kernel), nullptr: workgroup b pools ROI b
 };
@@ -552,8 +551,10 @@ __device__ __forceinline__ int entry_window(const HitGeo& g, int PH, int PW, int
   return axis_window(g.start_h, g.bin_h, g.grid & 0xffff, PH, y0, H) |
       (axis_window(g.start_w, g.bin_w, g.grid >> 16, PW, x0, W) << 16);
 }
-// WEIGHT of a tile = the k steps of its contraction: (bins of all its entries' windows) / 16.  What the heavy-first
-// queues and the split planner count with -- a 7 x 7 pooler's entry is about one unit, a 14 x 14 pooler's 3-12 (a small
+// WEIGHT of a tile = (bins of all its entries' windows = the k's of its contraction) / 16.  (The gather's time per tile
+// fits 4.9 us + 0.19 us per entry + 0.052 us per k, profiles/r06/pool_bwd_kcat.md; counting the entries in -- (k + 4 n) / 16
+// -- moved tiles between the queues' heavy and light ends and cost the paired launch 3 us of 50, same box.)  What the
+// heavy-first queues and the split planner count with -- a 7 x 7 pooler's entry is about one unit, a 14 x 14 pooler's 3-12 (a small
 // ROI whose 196 bins all fall into one tile: 12), so entry counts misjudge a paired launch's lists by that much.
 __device__ __forceinline__ int win_bins(int win) { return ((win >> 8) & 0xff) * ((win >> 24) & 0xff); }
 struct TileGeom { int lvl, n, y0, x0; };
@@ -1442,23 +1443,7 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_staged_kernel(PoolLevels L
 }
 
 // ------------------------------------------------------------------------------------------------
-// BACKWARD, NHWC, 16-bit I/O: the staged tile gather with the contraction on MFMA (v9).
-//
-// Per item the gather is a small GEMM: G[64 pixels x 256 channels] += Wt[64 x nb] . dY[nb x 256] over the nb <= 32
-// staged bins.  The VALU version spends most of an item in that contraction (per thread ~6 LDS round trips and ~250
-// dependent VALU instructions, profiles/r01/v8_pool_bwd_phase_stamps.txt); here
-//   * the group builds the item's weight matrix Wt[pixel][bin] = Wy[row][ph] Wx[col][pw] / count once in LDS, as a
-//     HIGH and a LOW 16-bit part (w = hi + lo: the product keeps ~16 significant bits, accumulation is fp32 in the
-//     MFMA, so the result matches the fp32-weight VALU kernel to the rounding of the output);
-//   * wave w owns the 32 channels [32 w, 32 w + 32) of the slab for all 64 pixels: 2 accumulator tiles of
-//     v_mfma_f32_32x32x16 (32 VGPRs, like the VALU kernel);
-//   * A = Wt: one ds_read_b128 per (pixel tile, k step); B = dY straight from the [bin][channel] image the staging
-//     writes, through ds_read_b64_tr_b16 (the hardware 4 x 4 transpose: lane i of a 16-lane group addresses row
-//     i >> 2, columns 4 (i & 3) .. + 3 of a [4 bins][16 channels] block and receives column i -- checked on the
-//     device by scripts/probes/probe_tr16.hip); rows past nb are zero-filled by the staging (0 x stale NaN);
-//   * the epilogue transposes the accumulators through LDS so that every pixel is stored as 16-B channel vectors.
-// Everything around the contraction (queues, lists, weight rounds, windows, items, one barrier per item) is the
-// staged kernel's.  fp32 I/O keeps the VALU kernel (fp32 MFMA runs at the vector rate).
+// 16-bit I/O: operand types of the matrix-core tile gather below.
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
@@ -1470,16 +1455,10 @@ __device__ __forceinline__ f32x16_t pool_mma(s16x8_t a, s16x8_t b, f32x16_t c, b
 __device__ __forceinline__ f32x16_t pool_mma(s16x8_t a, s16x8_t b, f32x16_t c, f16_t) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(pf16x8_t, a), __builtin_bit_cast(pf16x8_t, b), c, 0, 0, 0);
 }
-constexpr int WPITCH = WINCAP + 8;  // 16-bit elements per pixel row of the weight image (80 B: conflict-free b128 reads)
-struct __attribute__((aligned(16))) MfmaShared {
-  uint16_t Whi[2][TILE * TILE][WPITCH];  // [buffer][pixel = row * 8 + col][bin of the item]
-  uint16_t Wlo[2][TILE * TILE][WPITCH];
-};
 
-// PAIRED launch (PB1 != 0, d2amd_roi_pooler_backward_pair): a SECOND pooler of the same feature maps (Mask R-CNN: the
-// mask head's 14 x 14 pooler behind the box head's 7 x 7) is binned TOGETHER with the first one -- records [0, K1) are
-// the first pooler's ROIs, [K1, K1 + K2) the second one's, a tile's list holds the first pooler's entries in front of
-// the second one's (tile_cnt1 of them) -- and both sublists are gathered into the SAME accumulators: one queue take, one
+// PAIRED launch (d2amd_roi_pooler_backward_pair): a SECOND pooler of the same feature maps (Mask R-CNN: the mask head's
+// 14 x 14 pooler behind the box head's 7 x 7) is binned TOGETHER with the first one -- records [0, K1) are the first
+// pooler's ROIs, [K1, K1 + K2) the second one's, a tile has ONE list -- and gathered by ONE launch: one queue take, one
 // prologue and one write of the tile for both, where two launches paid each of them twice and the second one read the
 // tile back to add to it.
 struct PoolPairArgs {
@@ -1487,630 +1466,43 @@ struct PoolPairArgs {
   const int* tile_cnt1; // per tile: entries of the FIRST pooler in its list (the rest are the second one's)
   int K1, K2, PH, PW;
 };
-template <int V> struct PbTag { static constexpr int value = V; };
-template <typename T, int PB0, bool DYN = true, int PB1 = 0>
-__global__ __launch_bounds__(2 * CT, 4) void pool_bwd_mfma_kernel(PoolLevels L, const RoiRec* __restrict__ rec0,
-                                                                   const T* __restrict__ gout0, int nslab,
-                                                                   int total_blocks, PoolTileIds ids, PoolPairArgs P2) {
-  constexpr int NT = 2 * CT, TR = TILE / 2, VEC = 8;
-  __shared__ StagedShared<T> S;
-  __shared__ MfmaShared M;
-  __shared__ int s_fetch[8];
-  // PERSISTENT workgroups (L.qctr): the grid is one wave of resident workgroups, each of which fetches tile after
-  // tile -- from the queue of its own XCD (blockIdx & 7: heavy tiles first) until that is empty, then from the other
-  // XCDs' queues.  With one workgroup per queue slot (the first version) the XCDs ended 12 us apart (4x4-tile blocks
-  // of a coarse level are 16 long lists on ONE queue: 40.9 .. 53.9 us of work per resident slot) and every slot lost
-  // ~2 us per tile between a workgroup's end and the dispatch of the next (profiles/r03/pool_bwd_*_timeline_static.txt).
-  constexpr bool dynamic = DYN;  // (host: L.queue and L.qctr are set)
-  // (Tried and dropped, profiles/r03/pool_bwd/README.md: the take for the NEXT tile issued when the item loop ends and
-  // resolved behind the epilogue's second barrier, the next ROI list loaded while the pixels are stored -- the gap between
-  // tiles went 1.11 -> 0.44 us and the epilogue 1.53 -> 2.59 us: every wait of a wave is "wait for all my memory
-  // operations" (vmcnt counts loads, stores and returning atomics in order), so the latency only moves.)
-  if (threadIdx.x == 0) s_fetch[3] = 0;  // queues found empty so far, starting at the home XCD's (thread 0's)
-  for (int round = 0;; round++) {
-  // (the thread index passes through an opaque move per tile: everything derived from it is then recomputed per tile
-  // like in the one-tile kernel instead of being hoisted out of this loop and held in registers across it -- the body
-  // runs at its 128-VGPR cap, the hoisted values spilled to scratch)
-  int tid = threadIdx.x;
-  asm volatile("" : "+v"(tid));
-  const int lane = tid & 63;
-  int logical, slab, tile, qcnt = -1, pinfo = 1 << 8;  // pinfo: part | parts << 8 | scratch slot << 16
-  if (dynamic) {
-    if (round) __syncthreads();  // the previous tile's readers of the shared buffers (and of s_fetch) are done
-    if (tid == 0) {
-      int e = -1, sl = 0, lg2 = 0, steal = s_fetch[3];
-      while (steal <= L.qsteal) {
-        const int q = ((int)blockIdx.x + steal) & 7;
-        // the FIRST tile of a workgroup is entry blockIdx >> 3 of its own queue, without a take: 64 workgroups hitting
-        // one counter in the same microsecond are served one after the other (~0.1 us each); the counter hands out the
-        // entries from G = workgroups per XCD on
-        const int G = (int)(gridDim.x >> 3);
-        const int i = round == 0 && steal == 0 ? (int)(blockIdx.x >> 3)
-                                               : G + atomicAdd(L.qctr + QTAKE + QTAKE_PITCH * q, 1);
-        const int nh = L.qctr[q], nl = L.qctr[16 + q];  // final: tile_lists_kernel is an earlier launch
-        const int ent = i / nslab;
-        if (ent < nh + nl) {
-          const int slot = ent < nh ? ent : L.qcap - 1 - (ent - nh);  // heavy from the front, light from the back
-          const int2 e2 = L.queue[(long)q * L.qcap + slot];
-          e = e2.x;
-          s_fetch[4] = e2.y;
-          sl = i - ent * nslab;
-          lg2 = ((slot * nslab + sl) << 3) | q;  // the workgroup id the static mapping gives this (slot, slab)
-          break;
-        }
-        steal++;
-      }
-      s_fetch[0] = e; s_fetch[1] = sl; s_fetch[2] = lg2; s_fetch[3] = steal;
-    }
-    __syncthreads();
-    const int e = s_fetch[0];
-    if (e < 0) return;  // every queue is empty (uniform)
-    slab = s_fetch[1];
-    logical = s_fetch[2];
-    pinfo = s_fetch[4];
-    tile = e & 0xffffff;
-    qcnt = (int)((unsigned)e >> 24);
-  } else if (L.queue) {
-    const int j = (int)(blockIdx.x >> 3);
-    const int2 e2 = L.queue[(long)(blockIdx.x & 7) * L.qcap + j / nslab];
-    const int e = e2.x;
-    if (e < 0) return;
-    pinfo = e2.y;
-    logical = (int)blockIdx.x;
-    slab = j % nslab;
-    tile = e & 0xffffff;
-    qcnt = (int)((unsigned)e >> 24);
-  } else {
-    const int per_xcd = (total_blocks + 7) >> 3;
-    logical = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-    if (logical >= total_blocks) return;
-    slab = logical % nslab;
-    tile = logical / nslab;
-  }
-  // profiling stamps (D2AMD_POOL_STAMPS): written where they are taken, the row re-derived from uniform values each
-  // time -- a pointer and a clock value held across the tile cost 4 VGPRs of a kernel at its cap
-#define WST(k, v) do { if (L.wgstamps && tid == 0) L.wgstamps[5 * (size_t)logical + (k)] = (v); } while (0)
-  WST(0, wall_clock64());
-  int wst_n = 0;
-  int lvl = 0;
-#pragma unroll
-  for (int l = 1; l < POOL_MAX_LEVELS; l++)
-    if (l < L.num_levels && tile >= L.tile_base[l]) lvl = l;
-  const int H = L.H[lvl], W = L.W[lvl];
-  const int tiles_x = (W + TILE - 1) / TILE, tiles_y = (H + TILE - 1) / TILE;
-  int tl = tile - L.tile_base[lvl];
-  const int n = tl / (tiles_y * tiles_x);
-  tl -= n * tiles_y * tiles_x;
-  const int y0 = (tl / tiles_x) * TILE, x0 = (tl % tiles_x) * TILE;
-  const int C = L.C, PH = L.PH, PW = L.PW, K = L.K;
-  const int CG = C / VEC;
-  const int rh = tid / CT, col = (tid >> 5) & 7, lp = tid & 31;  // row half / pixel column / channel lane
-  const int cg = slab * LPP + lp;
-  const bool cg_ok = cg < CG;
-  const int cofs = min(cg, CG - 1) * VEC;  // (< C <= 8192)
-  const int sb = tid >> 5;  // staging: this thread moves bins sb and sb + 16 of an item (channel lane lp)
-#undef STAMP
-#ifdef D2AMD_PROFILE
-  const bool dbg_on = L.dbg && logical == L.dbg_block && tid == 0;
-  int dbg_n = 0;
-#define STAMP() do { if (dbg_on && dbg_n < 120) L.dbg[dbg_n++] = __builtin_readcyclecounter(); } while (0)
-#else
-#define STAMP() do {} while (0)
-#endif
-  STAMP();
-
-  // wave w accumulates channels [32 w, 32 w + 32) of the slab, TRANSPOSED (the staged dY is the A operand, the weight
-  // image the B operand): acc[mt] = [32 channels] x [pixels of tile rows 4 mt .. 4 mt + 3]; lane = pixel, a register
-  // quad = 4 consecutive channels -- the epilogue packs a quad into ONE 8-B LDS write (lane = channel, register =
-  // pixel needed 32 2-B writes per lane: 2.5 us per tile, a quarter of the average tile)
-  f32x16_t acc[2];
-#pragma unroll
-  for (int i = 0; i < 16; i++) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
-
-  // Axis weights.  PB = bins per axis rounded up to 8 / 16 / 32; one entry needs 8 x PB (row, bin) and 8 x PB
-  // (column, bin) pairs = 2 * PB / 8 waves, so the 8 waves of the group evaluate EPR = 32 / PB list entries per
-  // ROUND, all at the same time (box head: 4 entries, one wave per entry and axis).  Weights live in NSLOT = 3 EPR
-  // slots: round r + 2 is evaluated during the first item of round r and overwrites round r - 1.
-  const int wave = tid >> 6;
-  // ONE pooler's ROI list of the tile, gathered into `acc` (a generic lambda: instantiated for the launch's pooler and,
-  // in a paired launch, for the second one -- the bins-per-axis class PB is a compile-time constant of the body)
-  // (entries [lo, hi) of the tile's prepared list, whose ROI indices count from `roi0`; lo < 0: no prepared list, the
-  // pooler's K records are scanned)
-  auto run_list = [&](auto pb_tag, const T* gout, const RoiRec* rec, const int K, const int PH, const int PW,
-                      const int lo, const int hi, const int roi0) __attribute__((always_inline)) {
-  constexpr int PB = decltype(pb_tag)::value;
-  constexpr int lg = PB == 8 ? 3 : PB == 16 ? 4 : 5;
-  constexpr int EPR = 32 >> lg, NSLOT = 3 * EPR;
-  const bool wave_ok = slab * (LPP * VEC) + 32 * wave < C && !(L.ablate & 1);  // this wave's 32 channels exist (C % 32 == 0)
-  int nlist = 0;
-  auto compute_round = [&](int first) __attribute__((always_inline)) {
-    constexpr int rows_per_wave = 64 >> lg, waves_per_axis = TILE >> (6 - lg);  // 8,1 / 4,2 / 2,4
-    constexpr int wpe = 2 * waves_per_axis;                                      // waves per entry: 2 / 4 / 8
-    const int li = first + wave / wpe;
-    if (li >= nlist) return;  // uniform per wave
-    const int slot = li % NSLOT;
-    const int w2 = wave % wpe;
-    const HitGeo g = S.geo[li];
-    const bool is_x = w2 >= waves_per_axis;
-    const int wa = is_x ? w2 - waves_per_axis : w2;  // wave within its axis
-    const int p = lane & (PB - 1), r = wa * rows_per_wave + (lane >> lg);
-    const int grid = is_x ? (g.grid >> 16) : (g.grid & 0xffff);
-    const int P = is_x ? PW : PH, size = is_x ? W : H, pix = (is_x ? x0 : y0) + r;
-    float wv = 0.f;
-    if (p < P && pix < size) wv = axis_weight(is_x ? g.start_w : g.start_h, is_x ? g.bin_w : g.bin_h, grid, p, pix, size);
-    if (is_x) S.Wx[((slot << 3) + r) * PB + p] = wv * g.inv;
-    else S.WyT[((slot << lg) + p) * TILE + r] = wv;
-    const unsigned long long bm = __ballot(wv != 0.f);
-    if (lane < rows_per_wave) {
-      const uint32_t m = (uint32_t)(bm >> (lane << lg)) & (PB == 32 ? 0xffffffffu : ((1u << PB) - 1u));
-      if (is_x) S.xmask[slot][wa * rows_per_wave + lane] = m;
-      else S.ymask[slot][wa * rows_per_wave + lane] = m;
-    }
-    if (lane == 0) {
-      uint32_t u = 0;
-      for (int q = 0; q < rows_per_wave; q++) u |= (uint32_t)(bm >> (q << lg)) & (PB == 32 ? 0xffffffffu : ((1u << PB) - 1u));
-      if (is_x) S.xall[slot][wa] = u;
-      else S.yall[slot][wa] = u;
-    }
-  };
-  // window of bins of entry buffer wb that touch the tile (uniform; valid after the barrier that follows its weights)
-  auto window_of = [&](int wb) __attribute__((always_inline)) {
-    constexpr int waves_per_axis = PB / 8;
-    uint32_t ya = S.yall[wb][0], xa = S.xall[wb][0];
-    if (waves_per_axis > 1) { ya |= S.yall[wb][1]; xa |= S.xall[wb][1]; }
-    if (waves_per_axis > 2) { ya |= S.yall[wb][2] | S.yall[wb][3]; xa |= S.xall[wb][2] | S.xall[wb][3]; }
-    Window w;
-    if (ya == 0 || xa == 0) { w.ph_lo = 0; w.nph = 0; w.pw_lo = 0; w.npw = 1; w.rpc = WINCAP; w.nitems = 1; w.rnpw = 1.f; return w; }
-    w.ph_lo = __builtin_ctz(ya); w.nph = 32 - __builtin_clz(ya) - w.ph_lo;
-    w.pw_lo = __builtin_ctz(xa); w.npw = 32 - __builtin_clz(xa) - w.pw_lo;
-    w.rnpw = __builtin_amdgcn_rcpf((float)w.npw);
-    w.rpc = (int)((WINCAP + 0.5f) * w.rnpw);  // WINCAP / npw;  npw <= MAXP = 32 = WINCAP: at least one row of bins
-    w.nitems = (int)((w.nph + w.rpc - 0.5f) * __builtin_amdgcn_rcpf((float)w.rpc));  // ceil(nph / rpc)
-    return w;
-  };
-  // issue the loads of item (entry li with window w, chunk c): bins sb and sb + 16 of the chunk, channel lane lp
-  auto issue_loads = [&](int li, const Window& w, int c, raw16& r0, raw16& r1) __attribute__((always_inline)) {
-    const int pa = w.ph_lo + c * w.rpc;
-    const int nb = min(w.rpc, w.ph_lo + w.nph - pa) * w.npw;  // bins of this item (<= WINCAP); 0 for an empty window
-    const T* gk = gout + (long)S.list[li] * PH * PW * C + cofs;
-    if (nb > 0 && !(L.ablate & 16)) {  // uniform
-      // 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate): bin index < 1024, C <= 8192 (checked by the host)
-      const int j0 = min(sb, nb - 1);
-      const int q0 = (int)((j0 + 0.5f) * w.rnpw);  // j0 / npw
-      const unsigned b0 = __umul24(pa + q0, PW) + w.pw_lo + j0 - __umul24(q0, w.npw);
-      r0 = *reinterpret_cast<const raw16*>(gk + __umul24(b0, C));
-      if (nb > 16) {  // uniform
-        const int j1 = min(sb + 16, nb - 1);
-        const int q1 = (int)((j1 + 0.5f) * w.rnpw);
-        const unsigned b1 = __umul24(pa + q1, PW) + w.pw_lo + j1 - __umul24(q1, w.npw);
-        r1 = *reinterpret_cast<const raw16*>(gk + __umul24(b1, C));
-      }
-    }
-    return nb;
-  };
-
-  // PAIRED items (PB == 8, the box head): a typical window is 3 x 3 ... 4 x 4 bins, i.e. ONE of the item's two 16-bin
-  // k steps -- and the cost of an item is its fixed part (barrier, bookkeeping, weight image, staging: ~2,700 cycles
-  // for 4 MFMAs).  Two consecutive list entries whose whole windows have <= 16 bins therefore share an item: entry A
-  // in k step 0 (bins 0-15: staged by r0, weight image by waves 0-3), entry B in k step 1 (r1, waves 4-7).
-  auto bins_of = [&](const Window& w, int c) __attribute__((always_inline)) {
-    return min(w.rpc, w.nph - c * w.rpc) * w.npw;  // 0 for an empty window
-  };
-  auto issue_loads16 = [&](int li, const Window& w, int nb, raw16& r) __attribute__((always_inline)) {
-    if (nb > 0 && !(L.ablate & 16)) {  // uniform.  chunk 0 of a one-chunk window: bin sb of its nb <= 16 bins
-      const T* gk = gout + (long)S.list[li] * PH * PW * C + cofs;
-      const int j0 = min(sb, nb - 1);
-      const int q0 = (int)((j0 + 0.5f) * w.rnpw);  // j0 / npw
-      const unsigned b0 = __umul24(w.ph_lo + q0, PW) + w.pw_lo + j0 - __umul24(q0, w.npw);
-      r = *reinterpret_cast<const raw16*>(gk + __umul24(b0, C));
-    }
-  };
-  // half h (k step h) of the weight image of a paired item: waves 4 h .. 4 h + 3, always written (zeros past nb:
-  // the k step is contracted whenever the OTHER half has bins)
-  auto build_wimg_half = [&](int buf, int h, int slot, const Window& w, int nb) __attribute__((always_inline)) {
-    const int px = lane, kq = (tid >> 6) * 4, r = px >> 3, cx = px & 7;
-    if ((kq >> 4) != h || (L.ablate & 32)) return;  // uniform per wave
-    const int kl = kq & 15;
-    int q = (int)((kl + 0.5f) * w.rnpw);
-    int pi = kl - (int)__umul24(q, w.npw);
-    const float* wyp = &S.WyT[((slot << lg) + w.ph_lo) * TILE + r];
-    const float* wxp = &S.Wx[((slot << 3) + cx) * PB + w.pw_lo];
-    uint16_t hi[4], lo[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const float wv = kl + j < nb ? wyp[q * TILE] * wxp[pi] : 0.f;
-      if (++pi == w.npw) { pi = 0; q++; }
-      if constexpr (sizeof(T) == 2 && __is_same(T, bf16_t)) {
-        const __bf16 hh = (__bf16)wv;
-        const __bf16 ll = (__bf16)(wv - (float)hh);
-        hi[j] = __builtin_bit_cast(uint16_t, hh);
-        lo[j] = __builtin_bit_cast(uint16_t, ll);
-      } else {
-        const _Float16 hh = (_Float16)wv;
-        const _Float16 ll = (_Float16)(wv - (float)hh);
-        hi[j] = __builtin_bit_cast(uint16_t, hh);
-        lo[j] = __builtin_bit_cast(uint16_t, ll);
-      }
-    }
-    *reinterpret_cast<uint2*>(&M.Whi[buf][px][kq]) = uint2{(uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16)};
-    *reinterpret_cast<uint2*>(&M.Wlo[buf][px][kq]) = uint2{(uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16)};
-  };
-  // weight image of item (entry slot, window w, chunk c) -> buffer buf: thread = (pixel, 4 consecutive bins).
-  // hi = w rounded to the I/O dtype, lo = (w - hi) rounded (hardware conversions: v_cvt_pk_bf16_f32 / v_cvt_f16_f32)
-  auto build_wimg = [&](int buf, int slot, const Window& w, int c) __attribute__((always_inline)) {
-    // wave = 4 consecutive bins, lane = pixel: the waves whose bins lie in a k step the contraction never reads
-    // (bins >= nb rounded up to 16: half of the waves for the typical 9-16 bin window) skip the build altogether
-    const int px = lane, kq = (tid >> 6) * 4, r = px >> 3, cx = px & 7;
-    const int pa = w.ph_lo + c * w.rpc;
-    const int nb = min(w.rpc, w.ph_lo + w.nph - pa) * w.npw;
-    if (kq >= ((nb + 15) & ~15) || (L.ablate & 32)) return;  // uniform per wave
-    int q = (int)((kq + 0.5f) * w.rnpw);  // kq / npw; the following bins advance (q, pi) incrementally
-    int pi = kq - (int)__umul24(q, w.npw);
-    const float* wyp = &S.WyT[((slot << lg) + pa) * TILE + r];
-    const float* wxp = &S.Wx[((slot << 3) + cx) * PB + w.pw_lo];
-    float wv[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      wv[j] = kq + j < nb ? wyp[q * TILE] * wxp[pi] : 0.f;
-      if (++pi == w.npw) { pi = 0; q++; }
-    }
-    uint16_t hi[4], lo[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      if constexpr (sizeof(T) == 2 && __is_same(T, bf16_t)) {
-        const __bf16 h = (__bf16)wv[j];
-        const __bf16 l = (__bf16)(wv[j] - (float)h);
-        hi[j] = __builtin_bit_cast(uint16_t, h);
-        lo[j] = __builtin_bit_cast(uint16_t, l);
-      } else {
-        const _Float16 h = (_Float16)wv[j];
-        const _Float16 l = (_Float16)(wv[j] - (float)h);
-        hi[j] = __builtin_bit_cast(uint16_t, h);
-        lo[j] = __builtin_bit_cast(uint16_t, l);
-      }
-    }
-    *reinterpret_cast<uint2*>(&M.Whi[buf][px][kq]) = uint2{(uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16)};
-    *reinterpret_cast<uint2*>(&M.Wlo[buf][px][kq]) = uint2{(uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16)};
-  };
-  // contraction of one item: acc += (Whi + Wlo)[buf] . D[buf]
-  auto contract = [&](int buf, int nb) __attribute__((always_inline)) {
-    if (!wave_ok || nb <= 0) return;  // uniform per wave
-    const char* dimg = reinterpret_cast<const char*>(&S.D[buf][0][0]);
-    const int kh = lane >> 5;
-    // tr16 address of this lane inside a [4 bins][16 channels] block of the wave's 32 channels
-    const int tr_off = ((lane & 15) >> 2) * (LPP * 16) + (32 * wave + 16 * ((lane >> 4) & 1) + (lane & 3) * 4) * 2;
-#pragma unroll
-    for (int ks = 0; ks < WINCAP / 16; ks++) {
-      if (ks * 16 >= nb) break;  // uniform
-      const char* bp = dimg + (16 * ks + 8 * kh) * (LPP * 16) + tr_off;
-      const s16x4_t t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)bp);
-      const s16x4_t t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(bp + 4 * (LPP * 16)));
-      const s16x8_t b = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-      for (int mt = 0; mt < 2; mt++) {
-        const int px = 32 * mt + (lane & 31);
-        const s16x8_t ah = *reinterpret_cast<const s16x8_t*>(&M.Whi[buf][px][16 * ks + 8 * kh]);
-        const s16x8_t al = *reinterpret_cast<const s16x8_t*>(&M.Wlo[buf][px][16 * ks + 8 * kh]);
-        acc[mt] = pool_mma(b, ah, acc[mt], T{});
-        acc[mt] = pool_mma(b, al, acc[mt], T{});
-      }
-    }
-  };
-
-  int tl_cnt = -1;
-  if (lo >= 0) {
-    tl_cnt = max(hi - lo, 0);
-    if (tid < tl_cnt) {
-      // (two 16-B loads, then the stores: as a struct copy the compiler split it into three loads, each waited for)
-      const int gtile = ids.first[lvl] + (tile - L.tile_base[lvl]);
-      const uint4* ep = reinterpret_cast<const uint4*>((const TileEntry*)L.tile_list + (long)gtile * TILE_CAP + lo + tid);
-      const uint4 e0 = ep[0], e1 = ep[1];
-      S.list[tid] = (int)e1.z - roi0;  // TileEntry = {HitGeo (6 words), roi, pad}
-      HitGeo g;
-      g.start_h = __uint_as_float(e0.x); g.start_w = __uint_as_float(e0.y); g.bin_h = __uint_as_float(e0.z);
-      g.bin_w = __uint_as_float(e0.w); g.inv = __uint_as_float(e1.x); g.grid = (int)e1.y;
-      S.geo[tid] = g;
-    }
-  }
-  const bool prelist = tl_cnt >= 0;  // uniform
-  for (int kbase = 0; kbase < (prelist ? 1 : K); kbase += LCH) {
-    nlist = 0;
-    if (prelist) {
-      nlist = tl_cnt;
-    } else {
-      // ordered list (+ geometry) of the ROIs of this chunk of records that touch the tile (tiles with more
-      // than TILE_CAP ROIs, or no prepared lists)
-      const int kend = min(K, kbase + LCH);
-      const long r = min(kbase + tid, K - 1);
-      const int4 ra = *reinterpret_cast<const int4*>(&rec[r].level);  // level, batch, fy0, fy1
-      const int2 rb = *reinterpret_cast<const int2*>(&rec[r].fx0);    // fx0, fx1
-      const bool hit = kbase + tid < kend && ra.x == lvl && ra.y == n && ra.w >= y0 && ra.z < y0 + TILE &&
-          rb.y >= x0 && rb.x < x0 + TILE;
-      const unsigned long long bal = __ballot(hit);
-      __syncthreads();  // previous chunk's readers of list / geo / wave_cnt / weights / D are done
-      if (lane == 0) S.wave_cnt[tid >> 6] = __builtin_popcountll(bal);
-      __syncthreads();
-      int run = 0;
-#pragma unroll
-      for (int sl = 0; sl < NT / 64; sl++) {
-        if (sl == (tid >> 6) && hit) S.list[run + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = kbase + tid;
-        run += S.wave_cnt[sl];
-      }
-      nlist = run;
-    }
-    if (L.wgstamps) { WST(1, wall_clock64()); wst_n += nlist; }
-    if (L.ablate & 64) nlist = 0;
-    if (nlist == 0) continue;  // uniform
-    __syncthreads();           // list complete
-    if (!prelist) {
-      for (int i = tid; i < nlist; i += NT) S.geo[i] = rec[S.list[i]].g;
-      __syncthreads();
-    }
-
-    // ---- pipeline over the items of the list --------------------------------------------------------
-    compute_round(0);
-    compute_round(EPR);
-    __syncthreads();
-    raw16 r0 = raw16{0u, 0u, 0u, 0u}, r1 = raw16{0u, 0u, 0u, 0u};
-    const raw16 z16 = raw16{0u, 0u, 0u, 0u};
-    // pairing needs the weights of entry e + 2 to be complete one barrier before entry e is contracted: true for
-    // EPR = 4 (PB == 8), not for the larger poolers (whose windows rarely have <= 16 bins anyway)
-    const bool pairing = PB == 8 && !(L.ablate & 8);
-    // the item being prepared / contracted: entry e chunk c with window wc (nb_cur bins), and -- paired -- entry e + 1
-    Window wc = window_of(0), wp = wc;
-    int nb_cur, nb_pair = -1;  // nb_pair >= 0: the item is a pair, entry e + 1 has nb_pair bins
-    {
-      const int nb = bins_of(wc, 0);
-      if (pairing && wc.nitems == 1 && nb <= 16 && 1 < nlist) {
-        wp = window_of(1 % NSLOT);
-        const int nbp = bins_of(wp, 0);
-        if (wp.nitems == 1 && nbp <= 16) nb_pair = nbp;
-      }
-      if (nb_pair >= 0) {
-        issue_loads16(0, wc, nb, r0);
-        issue_loads16(1, wp, nb_pair, r1);
-        build_wimg_half(0, 0, 0, wc, nb);
-        build_wimg_half(0, 1, 1 % NSLOT, wp, nb_pair);
-        S.D[0][sb][lp] = sb < nb ? r0 : z16;
-        S.D[0][sb + 16][lp] = sb < nb_pair ? r1 : z16;
-      } else {
-        (void)issue_loads(0, wc, 0, r0, r1);
-        build_wimg(0, 0, wc, 0);
-        S.D[0][sb][lp] = sb < nb ? r0 : z16;            // rows past nb: zeros (their weights are 0, stale bits might be NaN)
-        if (nb > 16) S.D[0][sb + 16][lp] = sb + 16 < nb ? r1 : z16;  // uniform; the second k step is not read otherwise
-      }
-      nb_cur = nb;
-    }
-    int e = 0, c = 0, db = 0;
-    while (true) {
-      STAMP();
-      __syncthreads();  // D[db] and the weights of e (and e + 1) are complete; everyone is done with D[db ^ 1]
-      STAMP();
-      // next item: the next chunk of this entry's window, or the first chunk of the entry after this item's last one
-      const bool paired = nb_pair >= 0;
-      int e2 = e, c2 = c + 1;
-      Window wn = wc, wn2 = wc;
-      if (paired) { e2 = e + 2; c2 = 0; }
-      else if (c2 >= wc.nitems) { e2 = e + 1; c2 = 0; }
-      const bool have_next = e2 < nlist;
-      int nb2 = 0, nb2p = -1;
-      if (have_next) {
-        if (e2 != e) wn = window_of(e2 % NSLOT);
-        nb2 = bins_of(wn, c2);
-        if (pairing && c2 == 0 && wn.nitems == 1 && nb2 <= 16 && e2 + 1 < nlist) {
-          wn2 = window_of((e2 + 1) % NSLOT);
-          const int nbp = bins_of(wn2, 0);
-          if (wn2.nitems == 1 && nbp <= 16) nb2p = nbp;
-        }
-        if (nb2p >= 0) {
-          issue_loads16(e2, wn, nb2, r0);
-          issue_loads16(e2 + 1, wn2, nb2p, r1);
-        } else {
-          (void)issue_loads(e2, wn, c2, r0, r1);
-        }
-      }
-      STAMP();
-      // axis weights two rounds ahead, started by the first entry of a round (overlaps the loads)
-      if (c == 0 && (e & (EPR - 1)) == 0) compute_round(e + 2 * EPR);
-      else if (paired && ((e + 1) & (EPR - 1)) == 0) compute_round(e + 1 + 2 * EPR);
-      STAMP();
-      // contraction of the item on the matrix cores, then the weight image of the next item
-      contract(db, paired ? (nb_pair > 0 ? 16 + nb_pair : nb_cur) : nb_cur);
-      STAMP();
-      if (have_next) {
-        if (nb2p >= 0) {
-          build_wimg_half(db ^ 1, 0, e2 % NSLOT, wn, nb2);
-          build_wimg_half(db ^ 1, 1, (e2 + 1) % NSLOT, wn2, nb2p);
-        } else {
-          build_wimg(db ^ 1, e2 % NSLOT, wn, c2);
-        }
-      }
-      STAMP();
-      if (!have_next) break;
-      if (nb2p >= 0) {
-        S.D[db ^ 1][sb][lp] = sb < nb2 ? r0 : z16;
-        S.D[db ^ 1][sb + 16][lp] = sb < nb2p ? r1 : z16;
-      } else {
-        S.D[db ^ 1][sb][lp] = sb < nb2 ? r0 : z16;
-        if (nb2 > 16) S.D[db ^ 1][sb + 16][lp] = sb + 16 < nb2 ? r1 : z16;
-      }
-      e = e2; c = c2; wc = wn; wp = wn2; db ^= 1; nb_cur = nb2; nb_pair = nb2p;
-    }
-  }
-  };  // run_list
-  {
-    // the part of the tile's list this workgroup walks: entries [lo, hi) (parts == 1: all c of them); a paired launch
-    // walks the first pooler's entries of it, [lo, min(hi, c1)), then the second one's, [max(lo, c1), hi)
-    int lo = -1, hi = 0, c1 = 0;
-    if (L.tile_cnt) {
-      const int gtile = ids.first[lvl] + (tile - L.tile_base[lvl]);
-      const int c = qcnt >= 0 ? qcnt : L.tile_cnt[gtile];
-      if (c <= TILE_CAP) {
-        const int part = pinfo & 0xff, parts = (pinfo >> 8) & 0xff;
-        const int len = (c + parts - 1) / parts;
-        lo = part * len;
-        hi = min(c, lo + len);
-        c1 = c;
-        if constexpr (PB1 != 0) c1 = __builtin_amdgcn_readfirstlane(P2.tile_cnt1[gtile]);
-      }
-    }
-    if constexpr (PB1 == 0) {
-      run_list(PbTag<PB0>{}, gout0, rec0, K, PH, PW, lo, hi, 0);
-    } else {
-      run_list(PbTag<PB0>{}, gout0, rec0, P2.K1, PH, PW, lo, lo < 0 ? 0 : min(hi, c1), 0);
-      if (lo < 0 || hi > c1) {  // uniform
-        __syncthreads();  // everyone is done with the first sublist's staged bins, weight images and entries
-        run_list(PbTag<PB1>{}, (const T*)P2.gout, rec0 + P2.K1, P2.K2, P2.PH, P2.PW, lo < 0 ? -1 : max(lo, c1), hi, P2.K1);
-      }
-    }
-  }
-#ifdef D2AMD_PROFILE
-  if (dbg_on) { L.dbg[127] = dbg_n; L.dbg[126] = 0; L.dbg[125] = __builtin_readcyclecounter() - L.dbg[0]; }
-#endif
-#define WST2_AT(k) do { if (L.wgstamps && ((L.ablate >> 8) & 7) == (k)) WST(2, wall_clock64()); } while (0)
-  WST2_AT(0);  // (D2AMD_ABLATE bits 8-10 move the "loop done" stamp down the epilogue: 1 = behind its first barrier,
-               // 2 = behind the LDS writes, 3 = behind the second barrier, 4 = behind the global stores)
-  // ---- split list: this part's accumulators go to its scratch slot; the last part to arrive adds all parts in part
-  // order and writes the tile.  Stores / loads / the ticket are device-scope relaxed atomics (performed at the memory
-  // side, visible to every XCD once acknowledged -- the protocol of topk.hip's segment barriers); nothing waits.
-  if (((pinfo >> 8) & 0xff) > 1) {  // uniform
-    const int part = pinfo & 0xff, parts = (pinfo >> 8) & 0xff, sbase = (int)((unsigned)pinfo >> 16);
-    const size_t slot_floats = (size_t)nslab * 32 * NT;
-    float* mine = L.part_scratch + ((size_t)(sbase + part) * nslab + slab) * 32 * NT + tid;
-#pragma unroll
-    for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-      for (int r = 0; r < 16; r++)
-        __hip_atomic_store(mine + (mt * 16 + r) * NT, acc[mt][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_s_waitcnt(0);  // acknowledged = visible
-    __syncthreads();
-    if (tid == 0)
-      s_fetch[5] = __hip_atomic_fetch_add(L.part_tickets + sbase * SPLIT_MAX_SLABS + slab, 1, __ATOMIC_RELAXED,
-                                          __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    if (s_fetch[5] != parts - 1) {  // uniform: another part finishes this tile
-      WST(3, wall_clock64());
-      WST(4, (unsigned long long)wst_n | (unsigned long long)blockIdx.x << 32 | 1ull << 56);  // (bit 56: a part)
-      if (!dynamic) break;
-      continue;
-    }
-    // every part has drawn its ticket: re-arm it, so that a second gather over the same binned workspace (retain_graph,
-    // a C-ABI caller running phase 2 twice after one phase 1) finds it at 0 again instead of never finishing the tile
-    if (tid == 0)
-      __hip_atomic_store(L.part_tickets + sbase * SPLIT_MAX_SLABS + slab, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const float* all = L.part_scratch + ((size_t)sbase * nslab + slab) * 32 * NT + tid;
-#pragma unroll
-    for (int i = 0; i < 32; i++) acc[i >> 4][i & 15] = 0.f;
-    for (int q = 0; q < parts; q++) {
-      float v[32];
-#pragma unroll
-      for (int i = 0; i < 32; i++)
-        v[i] = __hip_atomic_load(all + (size_t)q * slot_floats + i * NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-      for (int i = 0; i < 32; i++) acc[i >> 4][i & 15] += v[i];
-    }
-  }
-  // ---- epilogue: accumulators (lane = channel, registers = pixels) -> LDS [pixel][channel] in the I/O dtype ->
-  // 16-B channel vectors per pixel (every pixel of grad_input is written exactly once)
-  __syncthreads();  // everyone is done with D
-  WST2_AT(1);
-  T* obuf = reinterpret_cast<T*>(&S.D[0][0][0]);  // 64 pixels x 256 channels x 2 B = the two D buffers
-  // (a pixel's 32 16-B chunks are stored at chunk ^ (pixel & 31): the 32 lanes of a half-wave write the SAME chunk of
-  // 32 different pixels, 512 B apart -- one bank group without the swizzle)
-  if (slab * (LPP * VEC) + 32 * wave < C) {
-#pragma unroll
-    for (int mt = 0; mt < 2; mt++) {
-      const int px = 32 * mt + (lane & 31);
-#pragma unroll
-      for (int g = 0; g < 4; g++) {
-        const int ch = 32 * wave + 8 * g + 4 * (lane >> 5);  // 4 consecutive channels: half a 16-B chunk
-        uint2 w;
-        w.x = (uint32_t)from_f32<T>(acc[mt][4 * g]).v | ((uint32_t)from_f32<T>(acc[mt][4 * g + 1]).v << 16);
-        w.y = (uint32_t)from_f32<T>(acc[mt][4 * g + 2]).v | ((uint32_t)from_f32<T>(acc[mt][4 * g + 3]).v << 16);
-        *reinterpret_cast<uint2*>(obuf + px * (LPP * VEC) + (((ch >> 3) ^ (px & 31)) << 3) + (ch & 4)) = w;
-      }
-    }
-  }
-  WST2_AT(2);
-  // Two copies of the store loop, one per mode (L.accumulate is uniform): the rows an accumulating thread adds to are
-  // loaded, used and dead inside ONE block.  Defined under one `if` and used under another they were live around the
-  // whole tile loop for the register allocator (16 VGPRs of a kernel at its cap: spilled to scratch).
-  if (L.accumulate) {
-    // the rows this thread will store are fetched now (the accumulators are dead) and fly under the barrier
-    // (loaded unconditionally from clamped -- valid -- addresses: a conditional definition that is used under a
-    // second condition behind the barrier is a loop-carried value again)
-    raw16 held[TR];
-    const bool mine = cg_ok && x0 + col < W;
-    T* gi = (T*)L.data[lvl] + (((long)n * H + y0 + rh * TR) * W + min(x0 + col, W - 1)) * C + cofs;
-#pragma unroll
-    for (int i = 0; i < TR; i++)
-      held[i] = *reinterpret_cast<const raw16*>(gi + (long)max(min(i, H - 1 - (y0 + rh * TR)), -(rh * TR)) * W * C);
-    __syncthreads();
-    if (mine && !(L.ablate & 128)) {
-#pragma unroll
-      for (int i = 0; i < TR; i++) {
-        if (y0 + rh * TR + i >= H) break;
-        const int px = (rh * TR + i) * TILE + col;
-        const raw16 v = *reinterpret_cast<const raw16*>(obuf + px * (LPP * VEC) + ((lp ^ (px & 31)) * VEC));
-        float a[VEC], b[VEC];  // round(held + round(own)), what autograd's add of two gradients gives
-        unpack16(held[i], a, T{});
-        unpack16(v, b, T{});
-#pragma unroll
-        for (int q = 0; q < VEC; q++) a[q] += b[q];
-        *reinterpret_cast<raw16*>(gi + (long)i * W * C) = pack16(a, T{});
-      }
-    }
-  } else {
-    __syncthreads();
-    WST2_AT(3);
-    if (cg_ok && x0 + col < W && !(L.ablate & 128)) {
-      T* gi = (T*)L.data[lvl] + (((long)n * H + y0 + rh * TR) * W + x0 + col) * C + cofs;
-#pragma unroll
-      for (int i = 0; i < TR; i++) {
-        if (y0 + rh * TR + i >= H) break;
-        const int px = (rh * TR + i) * TILE + col;
-        *reinterpret_cast<raw16*>(gi + (long)i * W * C) =
-            *reinterpret_cast<const raw16*>(obuf + px * (LPP * VEC) + ((lp ^ (px & 31)) * VEC));
-      }
-    }
-  }
-  WST2_AT(4);
-  WST(3, wall_clock64());
-  WST(4, (unsigned long long)wst_n | (unsigned long long)blockIdx.x << 32);  // #ROIs, + the workgroup that ran the tile (& 7: its XCD)
-#undef WST
-#undef WST2_AT
-  if (!dynamic) break;
-  }  // next tile
-}
 
 // ------------------------------------------------------------------------------------------------
-// BACKWARD, NHWC, 16-bit I/O: the K-CONCATENATED tile gather (r06).
+// BACKWARD, NHWC, 16-bit I/O: the K-CONCATENATED tile gather on the matrix cores (r06).
 //
-// The per-item pipeline above pays one exposed global round trip, one barrier and ~2,700 cycles of bookkeeping per
-// (tile, ROI) item for four MFMAs (profiles/r03/pool_bwd/README.md: items 6.3 us of a 10.8 us tile).  The gradient of a
-// tile is ONE contraction, though:  G[64 px][C] = W[64 px][K] . D[K][C]  where k runs over EVERY (list entry, bin of
-// its window) pair of the tile -- box-head and mask-head entries of a paired launch alike: an entry only decides which
-// dY row a k reads and which axis weights form its column of W.  The binning kernel hands every list entry its WINDOW of
-// bins (axis_window: conservative, a bin too many only carries zero weights), so the rows to fetch are known before any
-// weight is.  A tile is processed in ROUNDS of list entries and BATCHES of KCAP k's:
-//   1. wave 0 lays out the round (lane = entry): k offsets (prefix of the window sizes), dY row of the window's first
-//      bin, offsets of the entry's axis weights in the pool;
-//   2. every dY row of the first batch is requested at once by LDS-DMA (global_load_lds, 16 B per lane: two 512-B rows
-//      per wave instruction, no staging registers; a lane finds its row by a 5-step search in the k offsets) -- ONE
-//      exposed round trip per batch instead of one per item, and issued BEFORE the weights are evaluated;
-//   3. while the rows fly: the axis weights Wy[bin][tile row], Wx[bin][tile col] / count of the windows (thread = item
-//      of the flattened pool) and the K TABLE (thread = k: offsets of the k's Wy / Wx rows in the pool); then the weight
-//      image W (hi + lo 16-bit parts) of the batch, lane = pixel;
-//   4. acc += (Whi + Wlo) . D on the matrix cores (operands as in the kernel above: staged dY through
-//      ds_read_b64_tr_b16 = A, weight image = B), wave w owns channels [256 w / NW, 256 (w + 1) / NW).
+// Rounds 3-5 walked a tile's ROI list item by item -- per (tile, ROI) item one exposed global round trip, one barrier
+// and ~2,700 cycles of bookkeeping for four MFMAs (profiles/r03/pool_bwd/README.md: items 6.3 us of a 10.8 us tile; the
+// paired launch 78-85 us).  The gradient of a tile is ONE contraction, though:
+//     G[64 px][C] = W[64 px][K] . D[K][C]      k = every (list entry, bin of its window) pair of the tile
+// -- box-head and mask-head entries of a paired launch alike: an entry only decides which dY row a k reads and which
+// axis weights form its column of W = Wy[row][ph] Wx[col][pw] / count.  The binning kernel hands every list entry its
+// WINDOW of bins (axis_window: conservative, a bin too many only carries zero weights), so the rows to fetch are known
+// before any weight is.  A tile is processed in ROUNDS of list entries and BATCHES of KCAP k's:
+//   1. wave 0 lays out the round (lane = entry): k offsets (prefix of the window sizes, on the DPP network), dY row of
+//      the window's first bin, offsets of the entry's axis weights in the pool;
+//   2. the K TABLE, thread = k (one 5-step search in the k offsets): address of the k's dY row, byte offsets of its Wy /
+//      Wx rows in the pool;
+//   3. every dY row of the batch is requested at once by LDS-DMA (global_load_lds, 16 B per lane: two 512-B rows per
+//      wave instruction, no staging registers) -- ONE exposed round trip per batch instead of one per item, issued
+//      BEFORE the weights are evaluated;
+//   4. while the rows fly: the axis weights of the windows (a wave per entry) and the weight image W of the batch as a
+//      HIGH and a LOW 16-bit part (w = hi + lo keeps 16 significant bits; fp32 accumulation), lane = pixel;
+//   5. acc += (Whi + Wlo) . D with v_mfma_f32_32x32x16: A = the staged dY through ds_read_b64_tr_b16 (the hardware 4 x 4
+//      transpose: lane i of a 16-lane group addresses row i >> 2, columns 4 (i & 3) .. + 3 of a [4 k][16 channels] block
+//      and receives column i -- scripts/probes/probe_tr16.hip), B = the weight image; wave w owns channels
+//      [256 w / NW, 256 (w + 1) / NW) of the slab for all 64 pixels; rows past the batch are zero-filled (0 x stale NaN);
+//   6. the epilogue transposes the accumulators through LDS: every pixel is written once as 16-B channel vectors.
 // The NEXT tile is fetched during the current one by wave 0: the take on the queue counter right behind the tile's
-// first barrier, the queue slot behind the first batch, the first round's list entries (into registers) before the
-// epilogue's barrier -- three of the four dependent round trips of a tile (counter -> slot -> list -> dY rows) leave the
-// critical path.  (The per-item kernel tried that and lost: its waits were "all my memory operations"; here the uses sit
-// where the wave waits for its DMA anyway.)  Work queues, split lists with scratch + tickets, accumulate mode and the
-// epilogue that writes every pixel once as 16-B channel vectors follow the kernel above; a workgroup serves the queue
-// of its own XCD only.  Tiles whose list exceeds TILE_CAP scan the records in chunks into an LDS hit buffer and feed
-// the same rounds.
+// first barrier, the queue slot behind the first batch, the tile's geometry and first list entries (into registers)
+// before the epilogue -- three of the four dependent round trips of a tile (counter -> slot -> list -> dY rows) leave the
+// critical path.  (Two tiles ahead was measured too: 56.8 against 50 us -- a workgroup then sits on two tiles nobody
+// else can take, and the launch ends as late as its slowest workgroup.)
+// PERSISTENT workgroups: the grid is one resident wave of them, each fetching tile after tile from the queue of its own
+// XCD (tile_lists_kernel: heavy tiles first).  SPLIT lists: a part leaves its fp32 accumulators in a scratch slot and
+// takes a ticket, the workgroup that draws the last one adds the parts IN PART ORDER and writes the tile (device-scope
+// relaxed atomics, nobody waits).  Tiles whose list exceeds TILE_CAP scan the records in chunks into an LDS hit buffer
+// and feed the same rounds.  fp32 I/O keeps the VALU kernel above (fp32 MFMA runs at the vector rate).
+// Measurements, what was tried and what the counters say: profiles/r06/pool_bwd_kcat.md.
 // two fp32 -> one dword of two 16-bit values (hardware conversion, round to nearest even), and back
 typedef float kc_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t kc_pack2(float a, float b, bf16_t) {
@@ -2128,6 +1520,13 @@ __device__ __forceinline__ kc_f2 kc_unpack2(uint32_t u, f16_t) {
   typedef _Float16 v2 __attribute__((ext_vector_type(2)));
   return __builtin_convertvector(__builtin_bit_cast(v2, u), kc_f2);
 }
+// the HIGH part of a weight pair: bf16 by truncation (the upper halves of the two words, one v_perm; the low part
+// = w - hi is exact in fp32 and rounded to nearest: hi + lo carries 16 significant bits either way), fp16 by conversion
+__device__ __forceinline__ uint32_t kc_hi2(float a, float b, bf16_t) {
+  return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+}
+__device__ __forceinline__ uint32_t kc_hi2(float a, float b, f16_t t) { return kc_pack2(a, b, t); }
+
 template <int NW, int KCAP>
 struct __attribute__((aligned(16))) KcShared {
   static constexpr int NT = 64 * NW, ECAP = 32, WPOOL = 1536, WP = KCAP + 8, TK = NT / KCAP * KCAP;
@@ -2135,7 +1534,8 @@ struct __attribute__((aligned(16))) KcShared {
                               // over D + Whi + Wlo (+ wpool)
   uint16_t Whi[64][WP], Wlo[64][WP];  // weight image [pixel][k] (WP: conflict-free 16-B reads)
   float wpool[WPOOL];         // axis weights of the round: per entry [nph][8 rows], then [npw][8 cols] (x carries 1 / count)
-  int2 ktab[NT];              // per k of the table: {dY row | second pooler << 31, Wy | Wx << 16 byte offsets in the pool}
+  int4 ktab[NT];              // per k of the table: {address of the dY row's slab (lo, hi), Wy | Wx << 16 byte offsets in
+                              // the pool, -}
   HitGeo geo[ECAP];
   int row0[ECAP];             // dY row of the window's first bin
   int woff[64];               // pool offset                                  } entries past the round: INT_MAX (the
@@ -2388,7 +1788,7 @@ __global__ __launch_bounds__(64 * NW, (160 * 1024 / (int)sizeof(KcShared<NW, KCA
       const int nr = (L.ablate & 64) ? 0 : S.ctl[5];
       if (nr <= 0) break;  // uniform (an empty part, or the ablation)
       const int pool_used = S.ctl[6], ktot = S.ctl[7];
-      if (L.wgstamps) { if (wst_n == 0) KST(1, wall_clock64()); wst_n += nr; }
+      if (L.wgstamps) { if (wst_n == 0) KST(1, wall_clock64()); wst_n += nr + (ktot << 12); }  // entries | k's << 12
       STAMP();
 
       // entry of k (of pool item i): the last e with pref[e] (woff[e]) <= k; entries without bins are skipped over
@@ -2410,9 +1810,11 @@ __global__ __launch_bounds__(64 * NW, (160 * 1024 / (int)sizeof(KcShared<NW, KCA
             const int nph = dims & 0xff, npw = (dims >> 8) & 0xff, PWe = (dims >> 16) & 0xff, wo = S.woff[e];
             const int q = (int)(((float)il + 0.5f) * __builtin_amdgcn_rcpf((float)npw));  // il / npw  (il < 1024)
             const int pi = il - q * npw;
-            const int2 t = int2{(S.row0[e] + q * PWe + pi) | ((dims >> 24) << 31),
-                                ((wo + q * 8) * 4) | (((wo + 8 * nph + pi * 8) * 4) << 16)};  // BYTE offsets into the pool
-            S.ktab[tid] = kb0 + tid < ktot ? t : int2{0, 0};
+            const T* rowp = ((dims >> 24) ? (const T*)P2.gout : gout0) + (size_t)(unsigned)(S.row0[e] + q * PWe + pi) * (size_t)C +
+                slab * (LPP * VEC);
+            const int4 t = int4{(int)(unsigned)(size_t)rowp, (int)(unsigned)((size_t)rowp >> 32),
+                                ((wo + q * 8) * 4) | (((wo + 8 * nph + pi * 8) * 4) << 16), 0};  // BYTE offsets into the pool
+            S.ktab[tid] = kb0 + tid < ktot ? t : int4{0, 0, 0, 0};
           }
           __syncthreads();  // C
           STAMP();
@@ -2425,15 +1827,16 @@ __global__ __launch_bounds__(64 * NW, (160 * 1024 / (int)sizeof(KcShared<NW, KCA
         if (!(L.ablate & 16)) {
           constexpr int NI = KCAP / (2 * NW);
           const int t0 = kb0 % TK;
-          int rows[NI];
+          uint2 rows[NI];
 #pragma unroll
-          for (int i = 0; i < NI; i++) rows[i] = S.ktab[t0 + min((i * NW + wave) * 2 + (lane >> 5), kb - 1)].x;
+          for (int i = 0; i < NI; i++)
+            rows[i] = *reinterpret_cast<const uint2*>(&S.ktab[t0 + min((i * NW + wave) * 2 + (lane >> 5), kb - 1)]);
           const unsigned d_lds = (unsigned)(size_t)S.D;  // (the low word of a flat LDS address is the LDS offset)
 #pragma unroll
           for (int i = 0; i < NI; i++) {
             const int k2 = (i * NW + wave) * 2;  // uniform
             if (k2 < kb && k2 + (lane >> 5) < kb && cg_ok) {
-              const T* src = (rows[i] < 0 ? (const T*)P2.gout : gout0) + (size_t)(unsigned)(rows[i] & 0x7fffffff) * (size_t)C + cofs;
+              const char* src = (const char*)(((size_t)rows[i].y << 32) | rows[i].x) + lp * 16;
               asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
                            ::"v"(src), "s"(__builtin_amdgcn_readfirstlane(d_lds + k2 * 512)) : "memory");
             }
@@ -2477,8 +1880,7 @@ __global__ __launch_bounds__(64 * NW, (160 * 1024 / (int)sizeof(KcShared<NW, KCA
           for (int kq0 = 0; kq0 < KCAP; kq0 += 4 * NW) {
             const int kq = kq0 + 4 * wave;
             if (kq >= KCAP) break;  // uniform (only where 4 NW does not divide KCAP)
-            const int4 ca = *reinterpret_cast<const int4*>(&S.ktab[t0 + kq]), cb = *reinterpret_cast<const int4*>(&S.ktab[t0 + kq + 2]);
-            const int codes[4] = {ca.y, ca.w, cb.y, cb.w};
+            const int codes[4] = {S.ktab[t0 + kq].z, S.ktab[t0 + kq + 1].z, S.ktab[t0 + kq + 2].z, S.ktab[t0 + kq + 3].z};
             float wv[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -2487,7 +1889,7 @@ __global__ __launch_bounds__(64 * NW, (160 * 1024 / (int)sizeof(KcShared<NW, KCA
               wv[j] = kq + j < kb ? wy * wx : 0.f;
             }
             // hi = w rounded to the I/O dtype, lo = (w - hi) rounded
-            const uint32_t h01 = kc_pack2(wv[0], wv[1], T{}), h23 = kc_pack2(wv[2], wv[3], T{});
+            const uint32_t h01 = kc_hi2(wv[0], wv[1], T{}), h23 = kc_hi2(wv[2], wv[3], T{});
             const kc_f2 f01 = kc_unpack2(h01, T{}), f23 = kc_unpack2(h23, T{});
             const uint32_t l01 = kc_pack2(wv[0] - f01.x, wv[1] - f01.y, T{}), l23 = kc_pack2(wv[2] - f23.x, wv[3] - f23.y, T{});
             *reinterpret_cast<uint2*>(&S.Whi[lane][kq]) = uint2{h01, h23};
@@ -2549,7 +1951,7 @@ __global__ __launch_bounds__(64 * NW, (160 * 1024 / (int)sizeof(KcShared<NW, KCA
     if (wave == 0 && !slot_pending) slot_issue();  // (a tile without a batch)
 
     // ---- split list: this part's accumulators go to its scratch slot; the last part to arrive adds all parts in part
-    // order and writes the tile (see pool_bwd_mfma_kernel)
+    // order and writes the tile
     if (((pinfo >> 8) & 0xff) > 1) {  // uniform
       const int part = pinfo & 0xff, parts = (pinfo >> 8) & 0xff, sbase = (int)((unsigned)pinfo >> 16);
       constexpr int NA = 32 * NH;  // accumulators per thread
@@ -2575,13 +1977,16 @@ __global__ __launch_bounds__(64 * NW, (160 * 1024 / (int)sizeof(KcShared<NW, KCA
       const float* all = L.part_scratch + ((size_t)sbase * nslab + slab) * NA * NT + tid;
 #pragma unroll
       for (int i = 0; i < NA; i++) acc[(i >> 4) & 1][i >> 5][i & 15] = 0.f;
-      for (int q = 0; q < parts; q++) {  // (a part's NA loads in flight together: the combine is their latency)
-        float v[NA];
+      for (int q = 0; q < parts; q++) {  // (32 loads of a part in flight together: the combine is their latency)
 #pragma unroll
-        for (int i = 0; i < NA; i++)
-          v[i] = __hip_atomic_load(all + (size_t)q * slot_floats + i * NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i0 = 0; i0 < NA; i0 += 32) {
+          float v[32];
 #pragma unroll
-        for (int i = 0; i < NA; i++) acc[(i >> 4) & 1][i >> 5][i & 15] += v[i];
+          for (int i = 0; i < 32; i++)
+            v[i] = __hip_atomic_load(all + (size_t)q * slot_floats + (i0 + i) * NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+          for (int i = 0; i < 32; i++) acc[(i >> 4) & 1][i0 >> 5][i & 15] += v[i];
+        }
       }
     }
     // ---- epilogue: accumulators -> LDS [pixel][channel] in the I/O dtype (a pixel's 32 16-B chunks at chunk ^
@@ -2836,7 +2241,7 @@ static PoolLevels make_levels(const d2amd_pooler_params* p, const void* const* d
   L.min_level = p->min_level; L.max_level = p->max_level; L.canonical_level = p->canonical_level;
   L.canonical_size = p->canonical_box_size;
   { const char* e = d2_prof_env("D2AMD_ABLATE"); L.ablate = e ? atoi(e) : 0; }
-  L.dbg = nullptr; L.dbg_block = -1; L.wgstamps = nullptr; L.tile_cnt = nullptr; L.tile_list = nullptr; L.queue = nullptr; L.qcap = 0; L.qctr = nullptr; L.qsteal = 0; L.part_scratch = nullptr; L.part_tickets = nullptr; L.tab_off = 0;
+  L.dbg = nullptr; L.dbg_block = -1; L.wgstamps = nullptr; L.tile_cnt = nullptr; L.tile_list = nullptr; L.queue = nullptr; L.qcap = 0; L.qctr = nullptr; L.part_scratch = nullptr; L.part_tickets = nullptr; L.tab_off = 0;
   int base = 0;
   for (int l = 0; l < p->num_levels; l++) {
     L.data[l] = data[l]; L.H[l] = p->H[l]; L.W[l] = p->W[l]; L.scale[l] = p->spatial_scale[l];
@@ -3000,7 +2405,13 @@ static long resident_workgroups(const void* fn, int threads) {
   if (used < 16) cache[used++] = Ent{fn, dev, n};
   return n;
 }
-static bool stamp_path_static() { return d2_prof_env("D2AMD_POOL_STAMPS_STATIC") != nullptr; }
+// shapes the K-concatenated tile gather takes (16-bit I/O): whole 32-channel groups, the tiles' geometry packed into
+// 16 / 24 bits, dY row indices in 31 bits (checked per call where K is known)
+static bool kcat_shape_ok(const d2amd_pooler_params* p) {
+  bool ok = p->C % 32 == 0 && p->C <= 8192 && p->N < (1 << 23);
+  for (int l = 0; l < p->num_levels; l++) ok = ok && p->H[l] < 65536 && p->W[l] < 65536;
+  return ok;
+}
 
 // levels with at most this many tiles take the GROUPS > 1 kernel (few tiles <=> long ROI lists)
 constexpr int COARSE_TILES = 512;
@@ -3080,14 +2491,14 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
   if (accumulate && K == 0 && phase != 3) return D2AMD_OK;  // nothing to add
   // lists are split only for the kernel that can add the parts: the 16-bit MFMA tile gather
   static const bool no_mfma_env = d2_prof_env("D2AMD_POOL_NOMFMA") != nullptr;
-  const bool split_capable = staged && sizeof(T) == 2 && !no_mfma_env && p->C % 32 == 0 && p->C <= 8192 &&
-      nslab <= SPLIT_MAX_SLABS;
+  const bool kcat_ok = staged && sizeof(T) == 2 && !no_mfma_env && kcat_shape_ok(p) &&
+      (long)K_first * p->pooled_h * p->pooled_w < (1l << 31) &&
+      (!pair || (long)pair->K2 * pair->p2->pooled_h * pair->p2->pooled_w < (1l << 31));
+  const bool split_capable = kcat_ok && nslab <= SPLIT_MAX_SLABS;
   const size_t slot_bytes = (size_t)nslab * 32 * (2 * CT) * sizeof(float);  // 16 accumulators x 2 tiles x 512 threads
-  if (pair || probe) {  // the paired gather exists in the persistent MFMA tile gather only
-    static const bool fixed = d2_prof_env("D2AMD_POOL_STATIC") != nullptr || d2_prof_env("D2AMD_POOL_STAMPS_STATIC") != nullptr;
-    const int pm = p->pooled_h > p->pooled_w ? p->pooled_h : p->pooled_w;
-    const bool ok = staged && sizeof(T) == 2 && !no_mfma_env && !fixed && p->C % 32 == 0 && p->C <= 8192 && K_first > 0 &&
-        pm <= 8 && phase <= 2 && !accumulate;
+  if (pair || probe) {  // the paired gather exists in the K-concatenated tile gather only (either pooler may come first:
+    // a list entry carries its own pooled size)
+    const bool ok = kcat_ok && K_first > 0 && phase <= 2 && !accumulate;
     if (!ok || probe) return ok ? D2AMD_OK : D2AMD_EUNSUPPORTED;
   }
   if (queues) {
@@ -3169,7 +2580,6 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
     L.part_scratch = (float*)((char*)workspace + off_q + pool_queue_bytes(ntiles));
     const long total = 8l * L.qcap * nslab;
     if (total == 0) return D2AMD_OK;
-    static const bool static_slots = d2_prof_env("D2AMD_POOL_STATIC") != nullptr;  // A/B: one workgroup per queue slot
     D2_CHECK_ARG(total < (1l << 30), "roi_pooler_backward: too many tiles");
     const char* stamp_path = d2_prof_env("D2AMD_POOL_STAMPS");  // profiling only: per-workgroup timeline dump
     if (stamp_path) {
@@ -3189,49 +2599,20 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
     const bool timed = timing_begin(tname, s);
     const int pmax = p->pooled_h > p->pooled_w ? p->pooled_h : p->pooled_w;
     bool mfma = false;
-    if constexpr (sizeof(T) == 2) {  // 16-bit I/O: contraction on the matrix cores
-      static const bool no_mfma = d2_prof_env("D2AMD_POOL_NOMFMA") != nullptr;
-      mfma = !no_mfma && p->C % 32 == 0 && p->C <= 8192;
+    if constexpr (sizeof(T) == 2) {  // 16-bit I/O: the K-concatenated tile gather on the matrix cores
+      mfma = kcat_ok;
       if (mfma) {
         // persistent workgroups: one resident wave of them (a multiple of 8: every XCD gets the same number), each
-        // fetching tiles until all queues are empty; never more than there are queue slots
-        if (!static_slots && !stamp_path_static()) L.qctr = Q.mem;
-        static const int steal_env = d2_prof_env("D2AMD_POOL_STEAL") ? atoi(d2_prof_env("D2AMD_POOL_STEAL")) : 0;
-        L.qsteal = steal_env < 0 ? 0 : steal_env > 7 ? 7 : steal_env;
-        // (tried and dropped, profiles/r03/pool_bwd/README.md: no take counters at all -- workgroup j of an XCD walking
-        // its queue with a fixed stride: the gap between tiles halves, but the unsorted queue leaves the workgroups 25 us
-        // apart at the end (takes: 10 us): 90.8 us against 74.3)
+        // fetching tiles until its queue is empty; never more than there are queue slots
+        L.qctr = Q.mem;
         const PoolPairArgs P2 = pair ? PoolPairArgs{pair->gout2, tile_cnt1, K_first, pair->K2, pair->p2->pooled_h,
                                                     pair->p2->pooled_w} : PoolPairArgs{};
-        auto launch = [&](auto dyn_fn, auto static_fn) {
-          if (L.qctr) {
-            const long r = resident_workgroups((const void*)dyn_fn, 2 * CT) & ~7l;
-            const unsigned grid = (unsigned)(r >= 8 && r < total ? r : total);
-            hipLaunchKernelGGL(dyn_fn, dim3(grid), dim3(2 * CT), 0, s, L, rec, (const T*)grad_output, nslab, (int)total, ids,
-                               P2);
-          } else {
-            hipLaunchKernelGGL(static_fn, dim3((unsigned)total), dim3(2 * CT), 0, s, L, rec, (const T*)grad_output, nslab,
-                               (int)total, ids, P2);
-          }
-        };
-        // r06: the K-concatenated tile gather (persistent workgroups only; D2AMD_POOL_KCAT = 0: the per-item pipeline,
-        // 1: 4 waves x 48 k, 2: 4 x 64, 3: 8 x 64 -- profiling builds)
-        static const int kcat = d2_prof_env("D2AMD_POOL_KCAT") ? atoi(d2_prof_env("D2AMD_POOL_KCAT")) : 1;
-        auto launch_kcat = [&](auto fn, int threads) {
-          const long r = resident_workgroups((const void*)fn, threads) & ~7l;
-          const unsigned grid = (unsigned)(r >= 8 && r < total ? r : total);
-          hipLaunchKernelGGL(fn, dim3(grid), dim3(threads), 0, s, L, rec, (const T*)grad_output, nslab, P2);
-        };
-        if (L.qctr && kcat == 1) launch_kcat(pool_bwd_kcat_kernel<T, 4, 48>, 256);
-        else if (L.qctr && kcat == 2) launch_kcat(pool_bwd_kcat_kernel<T, 4, 64>, 256);
-        else if (L.qctr && kcat == 3) launch_kcat(pool_bwd_kcat_kernel<T, 8, 64>, 512);
-        else if (L.qctr && kcat == 4) launch_kcat(pool_bwd_kcat_kernel<T, 8, 48>, 512);
-        else if (L.qctr && kcat == 5) launch_kcat(pool_bwd_kcat_kernel<T, 4, 32>, 256);
-        else
-        if (pair) launch(pool_bwd_mfma_kernel<T, 8, true, 16>, pool_bwd_mfma_kernel<T, 8, true, 16>);  // (persistent only)
-        else if (pmax <= 8) launch(pool_bwd_mfma_kernel<T, 8, true>, pool_bwd_mfma_kernel<T, 8, false>);
-        else if (pmax <= 16) launch(pool_bwd_mfma_kernel<T, 16, true>, pool_bwd_mfma_kernel<T, 16, false>);
-        else launch(pool_bwd_mfma_kernel<T, 32, true>, pool_bwd_mfma_kernel<T, 32, false>);
+        // (4 waves x 48 k: three workgroups per CU.  Same-box A/B of the paired launch, profiles/r06/pool_bwd_kcat.md:
+        // 4 x 48: 50.0 | 8 x 64, two per CU: 53.4 | 4 x 64, two per CU: 57-76 | 4 x 32, four per CU, spilling: 58.2 us)
+        auto fn = pool_bwd_kcat_kernel<T, 4, 48>;
+        const long r = resident_workgroups((const void*)fn, 256) & ~7l;
+        const unsigned grid = (unsigned)(r >= 8 && r < total ? r : total);
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(256), 0, s, L, rec, (const T*)grad_output, nslab, P2);
       }
     }
     if (mfma) {

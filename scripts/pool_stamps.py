@@ -27,7 +27,8 @@ for ps, name in ((0, "fine levels"), (1, "coarse levels")):
     t0 = d[:, 1].min()
     st, ls, lp, en = [(d[:, i] - t0) / 100.0 for i in (1, 2, 3, 4)]
     ls = np.where(d[:, 2] > 0, ls, st)
-    n = d[:, 5] & 0xffffff  # (bits 32+: the XCD whose workgroup ran the tile; the row index & 7 = the queue's XCD)
+    kk = (d[:, 5] >> 12) & 0xfffff  # (K-concatenated gather: bins of the tile's windows = k's of its contraction)
+    n = d[:, 5] & 0xfff  # (bits 32+: the XCD whose workgroup ran the tile; the row index & 7 = the queue's XCD)
     stolen = ((d[:, 5] >> 32) & 7) != (d[:, 0] & 7)
     print(f'  tiles taken from another XCD\'s queue: {int(stolen.sum())}')
     print(f"{which} {name}: {len(d)} workgroups, span {en.max():.1f} us; ROIs/tile mean {n.mean():.2f} max {n.max()} zero {np.mean(n == 0):.2f}")
@@ -37,7 +38,15 @@ for ps, name in ((0, "fine levels"), (1, "coarse levels")):
         print(f"  {nm:6s}: mean {v.mean():.2f} p50 {np.median(v):.2f} p90 {np.percentile(v, 90):.2f} max {v.max():.2f} us")
     part = (d[:, 5] >> 56) & 1
     top = np.argsort(-(en - st))[:8]
-    print("  longest tiles (us, start, ROIs, part of a split list): " + ", ".join(f"{(en - st)[i]:.1f}@{st[i]:.1f} n={n[i] & 0xffffff} p={part[i]}" for i in top))
+    print("  longest tiles (us, start, ROIs, k's, part of a split list, logical id): " + ", ".join(f"{(en - st)[i]:.1f}@{st[i]:.1f} n={n[i]} k={kk[i]} p={part[i]} id={d[i, 0]}" for i in top))
+    if kk.sum() > 0:
+        A = np.stack([np.ones(len(d)), n.astype(float), kk.astype(float)], 1)
+        coef, *_ = np.linalg.lstsq(A, (en - st), rcond=None)
+        print(f"  total us per tile ~ {coef[0]:.2f} + {coef[1]:.3f} n + {coef[2]:.4f} k  (k mean {kk.mean():.1f}, sum {kk.sum()})")
+        for lo_, hi_ in ((0, 16), (16, 48), (48, 96), (96, 192), (192, 384), (384, 10 ** 6)):
+            m = (kk > lo_) & (kk <= hi_)
+            if m.any():
+                print(f"    k in ({lo_}, {hi_}]: {m.sum()} tiles, total mean {(en - st)[m].mean():.2f} us, n mean {n[m].mean():.1f}")
     print(f"  parts of split lists: {int(part.sum())}")
     for k in (0, 1, 2, 4, 8, 16, 32):
         m = n == k

@@ -191,11 +191,15 @@ def test_pair_is_refused_outside_the_16_bit_tile_gather_and_launches_nothing():
     g2 = _nhwc(rng.standard_normal((6, 64, 14, 14)).astype(np.float32), torch.float32)
     rc, grads = _run("pair", feats, boxes1, g1, boxes2, g2, torch.float32)
     assert rc == _C.EUNSUPPORTED and all(bool((g == 7.0).all()) for g in grads)
-    # the 14 x 14 pooler first
+    # the 14 x 14 pooler first: taken since r06 (a list entry of the K-concatenated gather carries its own pooled size)
     g1 = _nhwc(rng.standard_normal((16, 64, 14, 14)).astype(np.float32), torch.bfloat16)
     g2 = _nhwc(rng.standard_normal((6, 64, 7, 7)).astype(np.float32), torch.bfloat16)
     rc, grads = _run("pair", feats, boxes1, g1, boxes2, g2, torch.bfloat16, out1=14, out2=7)
-    assert rc == _C.EUNSUPPORTED and all(bool((g == 7.0).all()) for g in grads)
+    assert rc == 0, _C.lib().d2amd_last_error().decode()
+    _, gin1, _ = oracle_pooler(feats, boxes1, 14, 0, True, grad=g1.float().cpu().numpy())
+    _, gin2, _ = oracle_pooler(feats, boxes2, 7, 0, True, grad=g2.float().cpu().numpy())
+    for l in range(4):
+        assert rel_err(grads[l].float().cpu().numpy(), gin1[l] + gin2[l]) < 2.0 ** -7, l
     # channels not a multiple of 32
     feats40 = [f[:, :40].copy() for f in feats]
     g1 = _nhwc(rng.standard_normal((16, 40, 7, 7)).astype(np.float32), torch.bfloat16)
