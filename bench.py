@@ -1108,9 +1108,9 @@ def bench_maskrcnn(args, ctx):
         kb = alg["roi_align_pair_bwd_compulsory"] if paired else alg["roi_align_box_bwd_compulsory"]
         pmc_key = "roi_align_pair_bwd" if paired else "roi_align_box_bwd"
         roof = {"bound": "hbm",
-                "kernel": ("pool_bwd_mfma_kernel<T, 8, true, 16> (d2amd_roi_pooler_backward_pair): ONE tile gather over all "
-                           "FPN levels for the 7x7 (box head) AND the 14x14 (mask head) pooler, inside `backward`" if paired else
-                           "pool_bwd_mfma_kernel<T, 8> (16-bit I/O; fp32: pool_bwd_staged_kernel<float, 4, 8>): the 7x7 "
+                "kernel": ("pool_bwd_kcat_kernel<T, 4, 48> (d2amd_roi_pooler_backward_pair): ONE K-concatenated tile gather "
+                           "over all FPN levels for the 7x7 (box head) AND the 14x14 (mask head) pooler, inside `backward`" if paired else
+                           "pool_bwd_kcat_kernel<T, 4, 48> (16-bit I/O; fp32: pool_bwd_staged_kernel<float, 4, 8>): the 7x7 "
                            "(box head) pooler's tile gather over all FPN levels, inside `backward`"),
                 "achieved": round(kb / 1e6 / k_ms, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(kb / 1e6 / k_ms / HBM_PEAK_GBS, 4),
@@ -1658,6 +1658,27 @@ def main():
                                                  "roofline", "roi_tiles") if k in r}
                 extra[name]["vs_default_step"] = round(r["ms_per_step"] / out["ms_per_step"], 3)
             out["extra_workloads"] = extra
+            # FLAT copies of the figures above (the driver's record keeps top-level scalars only: BENCH_rNN.parsed drops
+            # nested objects)
+            flat = {"dcn_r50_ms": extra["dcn_r50"].get("ms_per_step"),
+                    "dcn_r50_frac_step": (extra["dcn_r50"].get("roofline") or {}).get("frac_step"),
+                    "maskrcnn_infer_ms": extra["maskrcnn_infer"].get("ms_per_step"),
+                    "retinanet_100k_ms": extra["retinanet_100k"].get("ms_per_step"),
+                    "rrpn_micro_ms": extra["rrpn_micro"].get("ms_per_step"),
+                    "nchw_drop_in_ms": extra["nchw_drop_in"].get("ms_per_step"),
+                    "clustered_rois_ms": extra["clustered_rois"].get("ms_per_step")}
+            out.update({k: v for k, v in flat.items() if v is not None})
+        if args.workload == "maskrcnn_train":
+            km = (out.get("roofline") or {}).get("kernels_ms") or {}
+            for key, name in (("pool_bwd_pair_us", "pool_bwd_pair"), ("pool_fwd_pair_us", "pool_fwd_pair")):
+                if name in km:
+                    out[key] = round(km[name] * 1e3, 2)
+            chain = [km.get(k) for k in ("nms_mask", "nms_reduce")]  # (order / finalize: rocprof stats under profiles/)
+            if all(v is not None for v in chain):
+                out["nms_mask_reduce_us"] = round(sum(chain) * 1e3, 2)
+            for k in ("frac", "frac_traffic", "frac_survey_units"):
+                if k in (out.get("roofline") or {}):
+                    out["roofline_" + k] = out["roofline"][k]
     if rank == 0:
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()

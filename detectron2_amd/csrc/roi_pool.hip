@@ -3027,13 +3027,10 @@ static int pooler_backward_pair_entry(const d2amd_pooler_params* p1, const void*
       p1->canonical_box_size == p2->canonical_box_size;
   for (int l = 0; rule && l < p1->num_levels; l++) rule = p1->spatial_scale[l] == p2->spatial_scale[l];
   static const bool off = getenv("D2AMD_POOL_NO_PAIR") != nullptr;
-  const int pm1 = p1->pooled_h > p1->pooled_w ? p1->pooled_h : p1->pooled_w;
-  const int pm2 = p2->pooled_h > p2->pooled_w ? p2->pooled_h : p2->pooled_w;
   if (off || !rule || K1 == 0 || K2 == 0 || !pooler_fused_ok(p1) || !pooler_fused_ok(p2) || p1->layout != D2AMD_NHWC ||
-      p1->dtype == D2AMD_F32 || pm1 > 8 || pm2 <= 8 || pm2 > 16 || (long)p1->N * p1->C == 0 ||
-      ((uintptr_t)grad_output2 & 15) != 0) {
-    set_error("roi_pooler_backward_pair: outside the paired 16-bit tile gather (bins per axis <= 8 and 9..16, NHWC, "
-              "the same level rule and sampling)");
+      p1->dtype == D2AMD_F32 || (long)p1->N * p1->C == 0 || ((uintptr_t)grad_output2 & 15) != 0) {
+    set_error("roi_pooler_backward_pair: outside the paired 16-bit tile gather (16-bit NHWC, pooled sizes <= %d, the same "
+              "level rule and sampling)", MAXP);
     return D2AMD_EUNSUPPORTED;
   }
   return D2_DISPATCH_DTYPE(p1->dtype, [&]() -> int {

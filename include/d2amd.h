@@ -163,13 +163,14 @@ int d2amd_roi_pooler_backward_accumulate(const d2amd_pooler_params* p, const voi
                                          void* stream);
 /* Both poolers of one set of feature maps in ONE pass over the gradient's tiles (Mask R-CNN: the box head's 7x7
  * pooler and the mask head's 14x14 one, roi_heads.py:780-846; modeling/poolers.py:206-263 twice): their ROIs are binned
- * together and a tile's two sublists are gathered into the same fp32 accumulators -- one queue take, one prologue and
- * ONE write per tile, where d2amd_roi_pooler_backward + d2amd_roi_pooler_backward_accumulate pay each of them twice and
- * read the tile back to add to it.  Result: every element = round(sum1 + sum2) in the I/O dtype (fp32 sums; the two-call
- * sequence gives round(round(sum1) + round(sum2)): the two differ by those extra roundings, this one is the closer to
- * the fp32 value).  workspace: d2amd_roi_pooler_backward_pair_workspace_bytes(p1, K1, K2).  D2AMD_EUNSUPPORTED -- nothing
- * launched -- outside 16-bit NHWC with bins per axis <= 8 (first) and 9..16 (second), the same level rule, scales,
- * sampling ratio and alignment, K1, K2 > 0: the caller issues the two calls. */
+ * together and a tile's list is ONE contraction over both poolers' bins into the same fp32 accumulators -- one queue
+ * take, one prologue and ONE write per tile, where d2amd_roi_pooler_backward + d2amd_roi_pooler_backward_accumulate pay
+ * each of them twice and read the tile back to add to it.  Result: every element = round(sum1 + sum2) in the I/O dtype
+ * (fp32 sums; the two-call sequence gives round(round(sum1) + round(sum2)): the two differ by those extra roundings,
+ * this one is the closer to the fp32 value).  workspace: d2amd_roi_pooler_backward_pair_workspace_bytes(p1, K1, K2).
+ * D2AMD_EUNSUPPORTED -- nothing launched -- outside 16-bit NHWC (C a multiple of 32), pooled sizes <= 32 (either pooler
+ * may come first), the same level rule, scales, sampling ratio and alignment, K1, K2 > 0: the caller issues the two
+ * calls. */
 size_t d2amd_roi_pooler_backward_pair_workspace_bytes(const d2amd_pooler_params* p1, int K1, int K2);
 int d2amd_roi_pooler_backward_pair(const d2amd_pooler_params* p1, const void* grad_output1, const float* rois1, int K1,
                                    const d2amd_pooler_params* p2, const void* grad_output2, const float* rois2, int K2,
