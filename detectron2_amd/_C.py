@@ -49,7 +49,7 @@ class PoolerParams(ctypes.Structure):
                 [("H", ctypes.c_int * 8), ("W", ctypes.c_int * 8), ("spatial_scale", ctypes.c_float * 8)] +
                 [(n, ctypes.c_int) for n in ("pooled_h", "pooled_w", "sampling_ratio", "aligned", "dtype", "layout",
                                              "min_level", "max_level", "canonical_level")] +
-                [("canonical_box_size", ctypes.c_float)])
+                [("canonical_box_size", ctypes.c_float), ("roi_rounding", ctypes.c_int)])
 
 
 _SIGNATURES = {
@@ -203,13 +203,30 @@ def dtype_code(t):
         raise RuntimeError(f"detectron2_amd: unsupported dtype {t.dtype} (float32/float16/bfloat16)")
 
 
+# Strict reference parity for 16-bit features: the ROIs rounded to the FEATURE dtype, as the reference does
+# (layers/roi_align.py:60: `rois.to(dtype=input.dtype)` -- under bf16 autocast a coordinate of 1,000 px lands on a multiple
+# of 4 or 8).  Off by default -- the kernels take fp32 ROIs whatever the features are, which is the better numerics (fp16
+# coordinates above 1,024 px are 1 px apart: up to 0.18 of the feature range, tests/test_gpu_pooler.py).  Read ONCE from
+# D2AMD_REFERENCE_ROI_ROUNDING at import; set_reference_roi_rounding() changes it in a running process.
+_REFERENCE_ROI_ROUNDING = os.environ.get("D2AMD_REFERENCE_ROI_ROUNDING") == "1"
+
+
+def set_reference_roi_rounding(on: bool) -> bool:
+    """-> the previous setting"""
+    global _REFERENCE_ROI_ROUNDING
+    prev, _REFERENCE_ROI_ROUNDING = _REFERENCE_ROI_ROUNDING, bool(on)
+    return prev
+
+
+def reference_roi_rounding_on() -> bool:
+    return _REFERENCE_ROI_ROUNDING
+
+
 def reference_roi_rounding(rois, feature_dtype):
-    """D2AMD_REFERENCE_ROI_ROUNDING=1: ROIs rounded to the FEATURE dtype before pooling, as the reference does
-    (layers/roi_align.py:60: `rois.to(dtype=input.dtype)`).  Off by default -- the kernels take fp32 ROIs whatever the
-    features are, which is the better numerics (fp16 coordinates above 1,024 px are 1 px apart: up to 0.18 of the feature
-    range, tests/test_gpu_pooler.py) -- on for strict parity with an fp16 / bf16 reference run.  -> fp32 tensor."""
+    """The (single-level) ROIAlign layers' ROIs: rounded to the feature dtype when the strict mode is on.  -> fp32 tensor.
+    (The fused multi-level pooler rounds in its kernels, BEHIND the level assignment: d2amd_pooler_params.roi_rounding.)"""
     r = rois.detach()
-    if feature_dtype in (torch.float16, torch.bfloat16) and os.environ.get("D2AMD_REFERENCE_ROI_ROUNDING") == "1":
+    if feature_dtype in (torch.float16, torch.bfloat16) and _REFERENCE_ROI_ROUNDING:
         r = r.to(feature_dtype)
     return r.float().contiguous()
 

@@ -26,6 +26,15 @@ __device__ __forceinline__ RoiGeom roi_geom_box(float b, float x1, float y1, flo
   RoiGeom g;
   g.bad = false;
   g.batch = (int)b;
+  // bits 1.. of `aligned`: the ROI coordinates rounded to fp16 (1) / bf16 (2) first -- d2amd_pooler_params.roi_rounding:
+  // what the reference's cast of the ROIs to the feature dtype (layers/roi_align.py:60) makes of them
+  const int rmode = aligned >> 1;
+  aligned &= 1;
+  if (rmode == 1) {
+    x1 = (float)(_Float16)x1; y1 = (float)(_Float16)y1; x2 = (float)(_Float16)x2; y2 = (float)(_Float16)y2;
+  } else if (rmode == 2) {
+    x1 = (float)(__bf16)x1; y1 = (float)(__bf16)y1; x2 = (float)(__bf16)x2; y2 = (float)(__bf16)y2;
+  }
   const float off = aligned ? 0.5f : 0.0f;
   g.start_w = x1 * scale - off;
   g.start_h = y1 * scale - off;

@@ -2237,7 +2237,9 @@ static int check_pooler(const d2amd_pooler_params* p, const char* who) {
 static PoolLevels make_levels(const d2amd_pooler_params* p, const void* const* data, int K) {
   PoolLevels L{};
   L.num_levels = p->num_levels; L.N = p->N; L.C = p->C; L.PH = p->pooled_h; L.PW = p->pooled_w;
-  L.sr = p->sampling_ratio; L.aligned = p->aligned; L.K = K;
+  L.sr = p->sampling_ratio; L.K = K;
+  // (bits 1.. of L.aligned: the rounding of the ROI coordinates behind the level assignment, roi_geom_box)
+  L.aligned = (p->aligned ? 1 : 0) | ((p->roi_rounding ? (p->dtype == D2AMD_F16 ? 1 : p->dtype == D2AMD_BF16 ? 2 : 0) : 0) << 1);
   L.min_level = p->min_level; L.max_level = p->max_level; L.canonical_level = p->canonical_level;
   L.canonical_size = p->canonical_box_size;
   { const char* e = d2_prof_env("D2AMD_ABLATE"); L.ablate = e ? atoi(e) : 0; }
@@ -2833,7 +2835,8 @@ extern "C" int d2amd_roi_pooler_forward_pair(const d2amd_pooler_params* p1, cons
       p1->layout == p2->layout;
   for (int l = 0; same && l < p1->num_levels; l++) same = p1->H[l] == p2->H[l] && p1->W[l] == p2->W[l];
   D2_CHECK_ARG(same, "roi_pooler_forward_pair: the two poolers must read the same feature maps");
-  bool rule = p1->sampling_ratio == p2->sampling_ratio && p1->aligned == p2->aligned && p1->min_level == p2->min_level &&
+  bool rule = p1->sampling_ratio == p2->sampling_ratio && p1->aligned == p2->aligned && p1->roi_rounding == p2->roi_rounding &&
+      p1->min_level == p2->min_level &&
       p1->max_level == p2->max_level && p1->canonical_level == p2->canonical_level &&
       p1->canonical_box_size == p2->canonical_box_size;
   for (int l = 0; rule && l < p1->num_levels; l++) rule = p1->spatial_scale[l] == p2->spatial_scale[l];
@@ -3022,7 +3025,8 @@ static int pooler_backward_pair_entry(const d2amd_pooler_params* p1, const void*
   for (int l = 0; same && l < p1->num_levels; l++) same = p1->H[l] == p2->H[l] && p1->W[l] == p2->W[l];
   D2_CHECK_ARG(same, "roi_pooler_backward_pair: the two poolers must read the same feature maps");
   // one set of records for both: the level rule, the scales and the sampling must be the same
-  bool rule = p1->sampling_ratio == p2->sampling_ratio && p1->aligned == p2->aligned && p1->min_level == p2->min_level &&
+  bool rule = p1->sampling_ratio == p2->sampling_ratio && p1->aligned == p2->aligned && p1->roi_rounding == p2->roi_rounding &&
+      p1->min_level == p2->min_level &&
       p1->max_level == p2->max_level && p1->canonical_level == p2->canonical_level &&
       p1->canonical_box_size == p2->canonical_box_size;
   for (int l = 0; rule && l < p1->num_levels; l++) rule = p1->spatial_scale[l] == p2->spatial_scale[l];

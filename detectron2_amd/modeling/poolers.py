@@ -76,7 +76,7 @@ _PARAMS_CACHE = {}
 
 
 def _params(cfg, feats_shape, hw, dtype_code, layout):
-    key = (cfg, feats_shape, tuple(hw), dtype_code, layout)
+    key = (cfg, feats_shape, tuple(hw), dtype_code, layout, _C.reference_roi_rounding_on())
     p = _PARAMS_CACHE.get(key)
     if p is not None:
         return p
@@ -98,6 +98,7 @@ def _build_params(cfg, feats_shape, hw, dtype_code, layout):
     p.dtype, p.layout = dtype_code, layout
     p.min_level, p.max_level, p.canonical_level = min_level, max_level, canon_level
     p.canonical_box_size = float(canon_size)
+    p.roi_rounding = int(_C.reference_roi_rounding_on())  # (strict reference parity: _C.set_reference_roi_rounding)
     return p
 
 
@@ -251,12 +252,9 @@ class _FusedROIPool(Function):
         # rois: the (M, 5) pooler-format tensor, or a tuple of per-image (n_i, 4) fp32 HIP box tensors -- then the
         # conversion happens inside the same C call (d2amd_roi_pooler_forward_box_lists: no torch.cat, one call less)
         box_lists = None
-        if os.environ.get("D2AMD_REFERENCE_ROI_ROUNDING") == "1" and feats[0].dtype in (torch.float16, torch.bfloat16):
-            # strict-reference mode (_C.reference_roi_rounding): the ROIs as the reference's per-level ROIAlign sees them
-            if isinstance(rois, tuple):
-                rois = tuple(_C.reference_roi_rounding(b, feats[0].dtype) for b in rois)
-            else:
-                rois = _C.reference_roi_rounding(rois, feats[0].dtype)
+        # (strict-reference mode, _C.set_reference_roi_rounding: the kernels round the coordinates to the feature dtype
+        # BEHIND the level assignment -- p.roi_rounding -- as ROIPooler.forward assigns levels from the fp32 boxes and
+        # each level's ROIAlign casts its ROIs, poolers.py:240-262 / roi_align.py:60)
         if isinstance(rois, tuple):
             box_lists = rois
             rois = torch.empty((sum(int(b.shape[0]) for b in box_lists), 5), dtype=torch.float32,

@@ -106,6 +106,10 @@ typedef struct d2amd_pooler_params {
   int pooled_h, pooled_w, sampling_ratio, aligned, dtype, layout;
   int min_level, max_level, canonical_level;
   float canonical_box_size;
+  int roi_rounding;  /* 0: fp32 ROIs as given (default).  1: strict reference parity for 16-bit features -- the ROI
+                      * coordinates are rounded to the FEATURE dtype, as layers/roi_align.py:60 casts them
+                      * (`rois.to(dtype=input.dtype)`), AFTER the level assignment, which ROIPooler.forward
+                      * (poolers.py:240-247) makes from the unrounded boxes. */
 } d2amd_pooler_params;
 int d2amd_roi_pooler_supported(const d2amd_pooler_params* p, int backward);
 int d2amd_roi_pooler_forward(const d2amd_pooler_params* p, const void* const* inputs, const float* rois,

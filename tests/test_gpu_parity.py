@@ -733,7 +733,7 @@ def test_nms_rotated_sub_pixel_boxes(thr):
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_reference_roi_rounding_switch(dtype, monkeypatch):
-    """D2AMD_REFERENCE_ROI_ROUNDING=1 (missing 4): the ROIs are rounded to the feature dtype before pooling,
+    """D2AMD_REFERENCE_ROI_ROUNDING=1 / _C.set_reference_roi_rounding (missing 4): the ROIs are rounded to the feature dtype before pooling,
     as layers/roi_align.py:60 does -- ROIAlign and the fused ROIPooler then equal the oracle on the ROUNDED boxes (what
     the reference computes) to the 16-bit output rounding, and differ from the default (unrounded) result."""
     from detectron2_amd.modeling import ROIPooler
@@ -747,7 +747,9 @@ def test_reference_roi_rounding_switch(dtype, monkeypatch):
     rt = torch.from_numpy(rois).to(DEV)
     ulp = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
     plain = ROIAlign((7, 7), 0.25, 0, True)(xt, rt).float().cpu().numpy()
-    monkeypatch.setenv("D2AMD_REFERENCE_ROI_ROUNDING", "1")
+    from detectron2_amd import _C as _lib
+
+    monkeypatch.setattr(_lib, "_REFERENCE_ROI_ROUNDING", True)
     strict = ROIAlign((7, 7), 0.25, 0, True)(xt, rt).float().cpu().numpy()
     rounded = torch.from_numpy(rois).to(dtype).float().numpy()
     want = oracle.roi_align_forward(x.float().numpy(), rounded, (7, 7), 0.25, 0, True)
@@ -758,9 +760,59 @@ def test_reference_roi_rounding_switch(dtype, monkeypatch):
     boxes = [Boxes(rt[:, 1:].clone())]
     got = pooler([xt.contiguous(memory_format=torch.channels_last)], boxes).float().cpu().numpy()
     assert np.abs(got - want).max() <= ulp * np.abs(want).max() + 1e-4
-    monkeypatch.delenv("D2AMD_REFERENCE_ROI_ROUNDING")
+    monkeypatch.setattr(_lib, "_REFERENCE_ROI_ROUNDING", False)
     got0 = pooler([xt.contiguous(memory_format=torch.channels_last)], boxes).float().cpu().numpy()
     assert np.abs(got0 - plain).max() <= ulp * np.abs(plain).max() + 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_reference_roi_rounding_keeps_the_levels_of_the_unrounded_boxes(dtype, monkeypatch):
+    """ROIPooler.forward (poolers.py:240-262) assigns levels from the fp32 boxes and only each level's
+    ROIAlign casts its ROIs to the feature dtype (roi_align.py:60).  Boxes whose sqrt(area) sits within the 16-bit
+    rounding of a level threshold (112 / 224 / 448 px) would change level if they were rounded FIRST: in strict mode the
+    fused pooler must pool every box on the level of its UNROUNDED size, with ROUNDED coordinates -- forward against the
+    oracle per level, backward (16-bit tile gather, strict mode) against the oracle's scatter of the same rows."""
+    from detectron2_amd import _C as _lib
+    from detectron2_amd.modeling import ROIPooler
+    from detectron2_amd.structures import Boxes
+    from test_tile_gather_math import assign_levels_restated
+
+    rng = np.random.default_rng(5)
+    N, C = 1, 32
+    hw = [(200, 336), (100, 168), (50, 84), (25, 42)]
+    scales = [0.25, 0.125, 0.0625, 0.03125]
+    feats = [rng.uniform(-1, 1, (N, C, h, w)).astype(np.float32) for h, w in hw]
+    boxes = []
+    for thr in (112.0, 224.0, 448.0):  # square-ish boxes a hair below / above each threshold, far from the origin
+        for _ in range(24):
+            s = thr * (1.0 + rng.uniform(-2e-3, 2e-3))
+            a = rng.uniform(0.8, 1.25)
+            w_, h_ = s * np.sqrt(a), s / np.sqrt(a)
+            x1, y1 = rng.uniform(300, 1300 - w_), rng.uniform(100, 790 - h_)
+            boxes.append([x1, y1, x1 + w_, y1 + h_])
+    boxes = np.asarray(boxes, np.float32)
+    lv = assign_levels_restated(boxes, 2, 5, 224, 4)
+    lv_rounded = assign_levels_restated(torch.from_numpy(boxes).to(dtype).float().numpy(), 2, 5, 224, 4)
+    assert (lv != lv_rounded).sum() >= 3, "the case must hold boxes whose level the rounding would change"
+    rounded = torch.from_numpy(boxes).to(dtype).float().numpy()
+    xs = [torch.from_numpy(f).to(DEV).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True) for f in feats]
+    monkeypatch.setattr(_lib, "_REFERENCE_ROI_ROUNDING", True)
+    pooler = ROIPooler((7, 7), scales, 0, "ROIAlignV2")
+    y = pooler(xs, [Boxes(torch.from_numpy(boxes).to(DEV))])
+    got = y.detach().float().cpu().numpy()
+    ulp = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+    g = rng.standard_normal(got.shape).astype(np.float32)
+    y.backward(torch.from_numpy(g).to(DEV).to(dtype).contiguous(memory_format=torch.channels_last))
+    g16 = torch.from_numpy(g).to(dtype).float().numpy()
+    for l in range(4):
+        rows = np.nonzero(lv == l)[0]
+        rois = np.concatenate([np.zeros((len(rows), 1), np.float32), rounded[rows]], 1)
+        f16 = torch.from_numpy(feats[l]).to(dtype).float().numpy()
+        want = oracle.roi_align_forward(f16, rois, (7, 7), scales[l], 0, True)
+        assert np.abs(got[rows] - want).max() <= ulp * np.abs(want).max() + 1e-4, l
+        gin = oracle.roi_align_backward(np.ascontiguousarray(g16[rows]), rois, f16.shape, scales[l], 0, True)
+        d = np.abs(xs[l].grad.float().cpu().numpy() - gin)
+        assert d.max() <= 2 * ulp * np.abs(gin).max() + 1e-4, (l, float(d.max()))
 
 
 @pytest.mark.parametrize("thr", [0.3, 0.5, 0.7, 0.9])
