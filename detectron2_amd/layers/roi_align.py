@@ -78,6 +78,16 @@ class _ROIAlign(Function):
             ctx.cfg = (ph, pw, float(spatial_scale), int(sampling_ratio), bool(aligned), tuple(input.shape), "f64")
             return f64_forward(input, rois, ph, pw, spatial_scale, sampling_ratio, aligned, False)
         x, layout = _prep_input(input)
+        staged = False
+        if layout == _C.NCHW and x.dtype in (torch.float16, torch.bfloat16) and x.shape[1] % 8 == 0 and x.numel():
+            # 16-bit NCHW features -- what an unmodified reference model hands a level's ROIAlign (poolers.py:249-262): the
+            # NHWC kernel reads a tap as contiguous channels, the NCHW kernel cannot and is 5 x slower (profiles/r01).  One
+            # channels_last staging copy per feature tensor, SHARED by the poolers of an iteration (the box head and the
+            # mask head pool the same FPN level: modeling/poolers.py keeps the copy while the tensor is unmodified), and
+            # an NCHW result, as the caller's layout implies.
+            from ..modeling.poolers import _staged_nhwc
+
+            x, layout, staged = _staged_nhwc(x), _C.NHWC, True
         rois = _C.reference_roi_rounding(rois, input.dtype)
         n, c, h, w = x.shape
         k = rois.shape[0]
@@ -86,6 +96,10 @@ class _ROIAlign(Function):
             _C.check(_C.lib().d2amd_roi_align_forward(
                 _C.ptr(x), _C.ptr(rois), _C.ptr(out), n, c, h, w, k, ph, pw, float(spatial_scale),
                 int(sampling_ratio), int(bool(aligned)), _C.dtype_code(x), layout, _C.stream()))
+        if staged:
+            from ..modeling.poolers import _to_nchw
+
+            out, layout = _to_nchw(out), _C.NCHW
         ctx.save_for_backward(rois)
         ctx.cfg = (ph, pw, float(spatial_scale), int(sampling_ratio), bool(aligned), tuple(x.shape), layout)
         return out

@@ -31,6 +31,10 @@ def main():
     ap.add_argument("--model", default="maskrcnn", choices=["maskrcnn", "retinanet"])
     ap.add_argument("--backend", default="product", choices=["product", "reference"])
     ap.add_argument("--size", type=int, nargs=2, default=[800, 1333])
+    ap.add_argument("--fused", action="store_true",
+                    help="detectron2_amd.integrate.patch: the FUSED callers bound into the model (Level 1 of INTEGRATION.md)")
+    ap.add_argument("--count-syncs", action="store_true",
+                    help="host synchronisations per iteration (torch.cuda.set_sync_debug_mode('warn'), counted over 3 iterations)")
     args = ap.parse_args()
 
     import _reference_model as rm
@@ -61,16 +65,42 @@ def main():
         opt.step()
         return loss
 
-    with rm.backend(args.backend), EventStorage(0):
+    import contextlib
+
+    class _Late(contextlib.ExitStack):  # (entered INSIDE rm.backend: the test infrastructure binds pairwise_iou too)
+        def __enter__(self):
+            r = super().__enter__()
+            if args.fused:
+                import detectron2
+                from detectron2_amd import integrate
+
+                self.enter_context(integrate.patch(detectron2, models=[model], layers=False))
+            return r
+
+    stack = _Late()
+    syncs = None
+    with rm.backend(args.backend), stack, EventStorage(0):
         for _ in range(args.warmup):
             iteration()
+        if args.count_syncs:
+            import warnings
+
+            torch.cuda.synchronize()
+            torch.cuda.set_sync_debug_mode("warn")
+            with warnings.catch_warnings(record=True) as rec:
+                warnings.simplefilter("always")
+                for _ in range(3):
+                    iteration()
+            torch.cuda.set_sync_debug_mode("default")
+            syncs = round(sum("synchroniz" in str(w.message).lower() for w in rec) / 3.0, 1)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.iters):
             loss = iteration()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / args.iters
-    print(json.dumps({"model": args.model, "backend": args.backend, "amp_bf16": args.amp, "channels_last": args.channels_last,
+    print(json.dumps({"model": args.model, "backend": args.backend, "fused_callers": args.fused, "host_syncs_per_iteration": syncs,
+                      "amp_bf16": args.amp, "channels_last": args.channels_last,
                       "images_per_iteration": 2, "image_size": args.size, "iterations": args.iters,
                       "s_per_iteration": round(dt, 5), "img_per_s": round(2 / dt, 2), "final_loss": float(loss.detach()),
                       "trainable_parameters": int(sum(p.numel() for p in params)),
