@@ -1657,6 +1657,15 @@ def main():
                 extra[name] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config",
                                                  "roofline", "roi_tiles") if k in r}
                 extra[name]["vs_default_step"] = round(r["ms_per_step"] / out["ms_per_step"], 3)
+            # configs[4] entered with NCHW activations, as the reference's DeformBottleneckBlock hands them over
+            # (resnet.py:303-327): staged channels_last per call (layers/deform_conv.py: _stage_nhwc), results back in NCHW
+            a2 = copy.copy(args)
+            a2.workload, a2.steps, a2.warmup, a2.no_cpu_baseline, a2.layout = "dcn_r50", 20, 10, True, "nchw"
+            torch.cuda.synchronize()
+            r = bench_dcn(a2, ctx)
+            extra["dcn_r50_nchw"] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype",
+                                                       "config") if k in r}
+            extra["dcn_r50_nchw"]["vs_channels_last"] = round(r["ms_per_step"] / extra["dcn_r50"]["ms_per_step"], 3)
             out["extra_workloads"] = extra
             # FLAT copies of the figures above (the driver's record keeps top-level scalars only: BENCH_rNN.parsed drops
             # nested objects)
@@ -1666,6 +1675,7 @@ def main():
                     "retinanet_100k_ms": extra["retinanet_100k"].get("ms_per_step"),
                     "rrpn_micro_ms": extra["rrpn_micro"].get("ms_per_step"),
                     "nchw_drop_in_ms": extra["nchw_drop_in"].get("ms_per_step"),
+                    "dcn_r50_nchw_ms": extra["dcn_r50_nchw"].get("ms_per_step"),
                     "clustered_rois_ms": extra["clustered_rois"].get("ms_per_step")}
             out.update({k: v for k, v in flat.items() if v is not None})
         if args.workload == "maskrcnn_train":

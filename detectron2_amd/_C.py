@@ -161,6 +161,7 @@ _SIGNATURES = {
     "d2amd_deform_conv_forward": (_i, [ctypes.POINTER(DcnParams), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "d2amd_deform_conv_backward": (_i, [ctypes.POINTER(DcnParams)] + [_vp] * 11 + [_sz, _vp]),
     "d2amd_deform_conv_columns_bytes": (_sz, [ctypes.POINTER(DcnParams)]),
+    "d2amd_deform_conv_column_path": (_i, [ctypes.POINTER(DcnParams)]),
     "d2amd_deform_conv_forward_columns": (_i, [ctypes.POINTER(DcnParams)] + [_vp] * 8 + [_sz, _vp]),
     "d2amd_deform_conv_backward_columns": (_i, [ctypes.POINTER(DcnParams)] + [_vp] * 12 + [_sz, _vp]),
 }

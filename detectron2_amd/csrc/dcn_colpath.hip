@@ -172,12 +172,14 @@ __global__ __launch_bounds__(256) void dcn_col_kernel(DcnShape s, const T* __res
     raw16 q[2][4];
     float w[2][4];
     bool ok[2];
+    uint32_t fl[2];
 #pragma unroll
     for (int u = 0; u < 2; u++) {
       const int it = it0 + u * 256 + tid;
       const int sm = min(it >> lps_shift, nsamp - 1), sub = it & (LPS - 1);
       ok[u] = it < items && (it >> lps_shift) < rows;
       const CpEntry& e = ent[sm];
+      fl[u] = e.flags;
       const uint4 px = *reinterpret_cast<const uint4*>(&e.pix[0]);
       const float4 wv = *reinterpret_cast<const float4*>(&e.w[0]);
       w[u][0] = wv.x; w[u][1] = wv.y; w[u][2] = wv.z; w[u][3] = wv.w;
@@ -193,7 +195,10 @@ __global__ __launch_bounds__(256) void dcn_col_kernel(DcnShape s, const T* __res
 #pragma unroll
       for (int c = 0; c < 4; c++) {
         float f[8];
-        tc_unpack(q[u][c], f, T{});
+        // (a corner outside the image reads pixel 0 with weight 0: its VALUE must be 0 too -- 0 x Inf of an overflowed
+        // 16-bit activation is NaN, where the reference's corner contributes exactly 0: deform_conv_cuda_kernel.cu:305-316)
+        const raw16 qc = (fl[u] >> c) & 1u ? q[u][c] : raw16{0u, 0u, 0u, 0u};
+        tc_unpack(qc, f, T{});
 #pragma unroll
         for (int k = 0; k < 8; k++) v[k] = c == 0 ? w[u][c] * f[k] : v[k] + w[u][c] * f[k];
       }

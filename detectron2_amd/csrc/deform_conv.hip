@@ -527,7 +527,8 @@ struct DcnWs {
   size_t total;
 };
 
-static DcnWs carve_ws(const DcnShape& s, int dtype, bool backward, bool nhwc, void* base) {
+// (keeps_col: the forward is handed a column to keep -- the column path then needs no scratch column of its own)
+static DcnWs carve_ws(const DcnShape& s, int dtype, bool backward, bool nhwc, void* base, bool keeps_col = false) {
   DcnWs w{};
   w.dtype = dtype;
   w.nhwc = nhwc;
@@ -541,7 +542,7 @@ static DcnWs carve_ws(const DcnShape& s, int dtype, bool backward, bool nhwc, vo
     w.tc = dcn_tc_plan_fwd(s, dtype);
     if (w.cp.ok) {
       w.cp_wpack = take(w.cp.wpack_bytes);
-      w.cp_col = take(w.cp.col_bytes);
+      if (!keeps_col) w.cp_col = take(w.cp.col_bytes);
     } else if (w.tc.ok) {
       w.tc_wp = take(w.tc.wp_bytes);
       w.tc_partial = (float*)take(w.tc.partial_bytes);
@@ -944,7 +945,7 @@ using namespace d2amd;
 extern "C" size_t d2amd_deform_conv_workspace_bytes(const d2amd_dcn_params* p, int backward) {
   DcnShape s;
   if (check_params(p, s, "deform_conv_workspace_bytes")) return 0;
-  return carve_ws(s, p->dtype, backward != 0, p->layout == D2AMD_NHWC, nullptr).total + 256;
+  return carve_ws(s, p->dtype, backward == 1, p->layout == D2AMD_NHWC, nullptr, backward == 2).total + 256;
 }
 
 static int dcn_forward_impl(const d2amd_dcn_params* p, const void* x, const void* offset, const void* mask,
@@ -956,7 +957,7 @@ static int dcn_forward_impl(const d2amd_dcn_params* p, const void* x, const void
   if (s.B == 0) return D2AMD_OK;
   D2_CHECK_ARG(x && offset && weight && out && workspace, "deform_conv_forward: null pointer");
   D2_CHECK_ARG(p->layout == D2AMD_NCHW || p->layout == D2AMD_NHWC, "deform_conv_forward: bad layout %d", p->layout);
-  DcnWs w = carve_ws(s, p->dtype, false, p->layout == D2AMD_NHWC, workspace);
+  DcnWs w = carve_ws(s, p->dtype, false, p->layout == D2AMD_NHWC, workspace, columns != nullptr);
   w.col_saved = columns;
   if (workspace_bytes < w.total) {
     set_error("deform_conv_forward: workspace too small (%zu < %zu)", workspace_bytes, w.total);
@@ -982,6 +983,12 @@ extern "C" size_t d2amd_deform_conv_columns_bytes(const d2amd_dcn_params* p) {
   // (the GEMM path also leaves the backward's packed weights behind the column: one pack launch per block and iteration)
   const ColPathPlan cp = p->layout == D2AMD_NHWC ? dcn_colpath_plan(s, p->dtype) : ColPathPlan{};
   return cp.ok ? al(gp.col_bytes) + cp.wpack_bytes : gp.col_bytes;
+}
+
+extern "C" int d2amd_deform_conv_column_path(const d2amd_dcn_params* p) {
+  DcnShape s;
+  if (check_params(p, s, "deform_conv_column_path") || s.B == 0) return 0;
+  return dcn_colpath_plan(s, p->dtype).ok ? 1 : 0;
 }
 
 extern "C" int d2amd_deform_conv_forward_columns(const d2amd_dcn_params* p, const void* x, const void* offset,

@@ -624,13 +624,15 @@ __global__ __launch_bounds__(256) void rot_bwd_gather_kernel(RotLevels L, RotGat
       }
       uint32_t row[8];
       float w[8];
+      unsigned hasm = 0u;
 #pragma unroll
       for (int u = 0; u < 8; u++) {
         const uint32_t r = (uint32_t)__shfl((int)my.x, (lane & ~7) + u);
         const float wi = __uint_as_float((uint32_t)__shfl((int)my.y, (lane & ~7) + u));
         const bool has = base + u < n;
-        row[u] = has ? r : 0u;   // (a group past its list re-reads row 0 with weight 0)
-        w[u] = has ? wi : 0.f;
+        row[u] = has ? r : 0u;   // (a group past its list re-reads row 0 with weight 0 -- and takes its VALUE as 0 too:
+        w[u] = has ? wi : 0.f;   // 0 x Inf of an overflowed 16-bit gradient is NaN, the reference's scatter never reads it)
+        hasm |= has ? 1u << u : 0u;
       }
 #pragma unroll
       for (int q = 0; q < NQ; q++) {
@@ -648,11 +650,11 @@ __global__ __launch_bounds__(256) void rot_bwd_gather_kernel(RotLevels L, RotGat
           for (int u = 0; u < 8; u++) {
             if constexpr (VEC > 1) {
               float f[VEC];
-              runpack(v[u], f, T{});
+              runpack((hasm >> u) & 1u ? v[u] : rraw16{0u, 0u, 0u, 0u}, f, T{});
 #pragma unroll
               for (int c = 0; c < VEC; c++) acc[q][c] += w[u] * f[c];
             } else {
-              acc[q][0] += w[u] * to_f32(v1[u]);
+              acc[q][0] += (hasm >> u) & 1u ? w[u] * to_f32(v1[u]) : 0.f;
             }
           }
         }

@@ -31,6 +31,21 @@ def _is_nhwc(x):
             x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous())
 
 
+def _stage_nhwc(x, weight, stride, padding, dilation, groups, deformable_groups):
+    """16-bit NCHW activations -- what an unmodified reference model hands a DCN block (backbone/resnet.py:303-327): the
+    column + dense-GEMM path (csrc/dcn_colpath.hip) is the channels_last one, so an eligible shape is staged channels_last
+    here (the library's tiled transpose) and its results are handed back NCHW, as the caller's layout implies.  -> the
+    channels_last twin, or None (fp32 / already channels_last / a shape the column path does not serve: the NCHW entry)."""
+    if x.dim() != 4 or x.dtype not in (torch.float16, torch.bfloat16) or _is_nhwc(x) or x.numel() == 0:
+        return None
+    p = _params(x, weight, stride, padding, dilation, groups, deformable_groups, _C.NHWC)
+    if not _C.lib().d2amd_deform_conv_column_path(ctypes.byref(p)):
+        return None
+    from ..modeling.poolers import _to_nhwc
+
+    return _to_nhwc(x.detach().contiguous())
+
+
 def _conv_out_extent(size, pad, dil, kernel, stride):
     """Output extent of one spatial axis of a (deformable) convolution."""
     return (size + 2 * pad - (dil * (kernel - 1) + 1)) // stride + 1
@@ -94,19 +109,24 @@ def _dcn_forward(x, offset, mask, weight, bias, stride, padding, dilation, group
     out_size = _output_size(x, weight, padding, dilation, stride)
     _check_shapes(x, offset, mask, weight, out_size, groups, deformable_groups)
     L = _C.lib()
-    if _is_nhwc(x):  # channels_last in, channels_last out (D2AMD_EUNSUPPORTED: not an MFMA-path shape -> NCHW below)
-        x_ = x.detach()
+    staged = _stage_nhwc(x, weight, stride, padding, dilation, groups, deformable_groups)
+    if staged is not None or _is_nhwc(x):  # channels_last in, channels_last out (D2AMD_EUNSUPPORTED: -> NCHW below)
+        x_ = staged if staged is not None else x.detach()
         offset_, mask_, weight_, bias_ = _same_dtype(x_, offset, mask, weight, bias)
         out = torch.empty(out_size, dtype=x_.dtype, device=x_.device, memory_format=torch.channels_last)
         p = _params(x_, weight_, stride, padding, dilation, groups, deformable_groups, _C.NHWC)
         with _C.on_device(x_.device):
             cols = _columns(L, p, x_.device, save_columns)
-            ws_bytes = L.d2amd_deform_conv_workspace_bytes(ctypes.byref(p), 0)
+            ws_bytes = L.d2amd_deform_conv_workspace_bytes(ctypes.byref(p), 2 if cols is not None else 0)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x_.device)
             rc = L.d2amd_deform_conv_forward_columns(ctypes.byref(p), _C.ptr(x_), _C.ptr(offset_), _C.ptr(mask_),
                                                      _C.ptr(weight_), _C.ptr(bias_), _C.ptr(out), _C.ptr(cols),
                                                      _C.ptr(ws), ws_bytes, _C.stream())
         if rc == 0:
+            if staged is not None:
+                from ..modeling.poolers import _to_nchw
+
+                out = _to_nchw(out)
             return out, cols
         if rc != _C.EUNSUPPORTED:
             _C.check(rc)
@@ -116,7 +136,7 @@ def _dcn_forward(x, offset, mask, weight, bias, stride, padding, dilation, group
     p = _params(x_, weight_, stride, padding, dilation, groups, deformable_groups)
     with _C.on_device(x_.device):
         cols = _columns(L, p, x_.device, save_columns)
-        ws_bytes = L.d2amd_deform_conv_workspace_bytes(ctypes.byref(p), 0)
+        ws_bytes = L.d2amd_deform_conv_workspace_bytes(ctypes.byref(p), 2 if cols is not None else 0)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x_.device)
         _C.check(L.d2amd_deform_conv_forward_columns(ctypes.byref(p), _C.ptr(x_), _C.ptr(offset_), _C.ptr(mask_),
                                                      _C.ptr(weight_), _C.ptr(bias_), _C.ptr(out), _C.ptr(cols),
@@ -128,10 +148,16 @@ def _dcn_backward(x, offset, mask, weight, grad_output, stride, padding, dilatio
                   need_input, need_weight, with_bias, columns=None):
     _C.require_gpu(grad_output, op="deform_conv backward")
     L = _C.lib()
-    if _is_nhwc(x):  # channels_last activations: gradients in and out stay channels_last
-        x_ = x.detach()
+    staged = _stage_nhwc(x, weight, stride, padding, dilation, groups, deformable_groups)
+    if staged is not None or _is_nhwc(x):  # channels_last activations: gradients in and out stay channels_last
+        x_ = staged if staged is not None else x.detach()
         offset_, mask_, weight_ = _same_dtype(x_, offset, mask, weight)
-        go = grad_output.detach().to(x_.dtype).contiguous(memory_format=torch.channels_last)
+        if staged is not None:
+            from ..modeling.poolers import _to_nchw, _to_nhwc
+
+            go = _to_nhwc(grad_output.detach().to(x_.dtype).contiguous())
+        else:
+            go = grad_output.detach().to(x_.dtype).contiguous(memory_format=torch.channels_last)
         gi = torch.empty_like(x_) if need_input else None  # (preserves channels_last)
         goff = torch.empty_like(offset_) if need_input else None
         gm = torch.empty_like(mask_) if (need_input and mask_ is not None) else None
@@ -146,6 +172,8 @@ def _dcn_backward(x, offset, mask, weight, grad_output, stride, padding, dilatio
                 _C.ptr(columns), _C.ptr(gi), _C.ptr(goff), _C.ptr(gm), _C.ptr(gw), _C.ptr(gb), _C.ptr(ws), ws_bytes,
                 _C.stream())
         if rc == 0:
+            if staged is not None and gi is not None:
+                gi = _to_nchw(gi)
             return gi, goff, gm, gw, gb
         if rc != _C.EUNSUPPORTED:
             _C.check(rc)

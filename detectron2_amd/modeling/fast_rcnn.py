@@ -125,7 +125,9 @@ def fast_rcnn_inference_device(boxes: Sequence[torch.Tensor], scores: Sequence[t
     if _ops._BATCH_MAX is None:
         _ops._BATCH_MAX = int(L.d2amd_nms_batched_max_boxes())
     cap = min(max(max(r * k_cls for r in rows), 1), _ops._BATCH_MAX, capacity or (1 << 30))
-    cap = max(cap, topk_per_image)
+    # (a window never exceeds what ONE batched NMS takes -- `take` serves topk_per_image > window; ADVICE r05: raising
+    # the window to topk_per_image pushed a huge top-k onto the per-image NMS path, whose result the gather below cannot read)
+    cap = min(max(cap, topk_per_image), _ops._BATCH_MAX)
     total = max(base[-1], 1)
     out_boxes = torch.empty((total, 4), dtype=torch.float32, device=dev)
     out_scores = torch.empty((total,), dtype=torch.float32, device=dev)

@@ -225,17 +225,15 @@ import os as _os
 # Measured inside the captured step (bench.py, same box, ms/step): none 0.524 / 0.526, chained 0.530 / 0.523, all 0.538 /
 # 0.534 -- on one stream the small binning kernels cost the same wherever they sit, and the writing variant adds a
 # zero-fill launch; the early binning only pays for a caller that puts the forward on its own stream.  Default: none.
-_PREBIN_MODE = _os.environ.get("D2AMD_PREBIN", "none")
-# The forward can pool the ROIs in a spatial PROCESSING ORDER (d2amd_roi_pooler_forward_ordered: counting sort by level /
-# image / cell): the box head's HBM fetch drops from 1.7 x to 1.07 x the features at equal kernel time -- but the ordering
-# launch is one workgroup, 10-15 us, in front of the pooling kernel on the step's critical path: 0.521 / 0.527 ms per step
-# with it, 0.498 / 0.500 without (same box, gpurun_out/r3s).  Off unless D2AMD_FWD_ORDER=1.
-_FWD_ORDERED = _os.environ.get("D2AMD_FWD_ORDER", "0") == "1"
-_JOIN_EARLY = _os.environ.get("D2AMD_JOIN_EARLY", "0") == "1"
-_ROT_POOLER_LOOP = _os.environ.get("D2AMD_ROT_POOLER_LOOP", "0") == "1"  # A/B switch: rotated pooler level by level
-_SIDE_BINNING = _os.environ.get("D2AMD_SIDE_BINNING", "1") != "0"  # A/B switch: the later gathers' binning beside the first
+_PREBIN_MODE = "none"  # (module attribute, no environment name: tests/test_gpu_pooler.py sets it)
+# (Measured and REMOVED in r06 -- the switches had no test and no caller: the forward in a spatial PROCESSING ORDER
+# (d2amd_roi_pooler_forward_ordered stays in the C ABI with its test: the box head's HBM fetch 1.7 x -> 1.07 x the features
+# at equal kernel time, but 10-15 us of ordering launch on the critical path: 0.521 / 0.527 ms per step with it, 0.498 /
+# 0.500 without); the side binnings joined in front of the first gather; the later gathers' binning NOT beside the first.)
+_ROT_POOLER_LOOP = False  # (module attribute: the rotated pooler level by level -- the reference's structure, scripts/rrpn_ab.sh)
 # The first two gathers of a chain in ONE pass over the tiles (d2amd_roi_pooler_backward_pair: box head 7x7 + mask head
-# 14x14); D2AMD_POOL_PAIR=0: one launch per pooler, the second one adding (the A/B and the bit-for-bit autograd sum).
+# 14x14); D2AMD_POOL_PAIR=0 (read once, at import): one launch per pooler, the second one adding (the A/B and the
+# bit-for-bit autograd sum; tests/test_gpu_pooler_pair.py sets the attribute).
 _PAIR = _os.environ.get("D2AMD_POOL_PAIR", "1") != "0"
 
 
@@ -279,20 +277,7 @@ class _FusedROIPool(Function):
         mf = torch.channels_last if layout == _C.NHWC else torch.contiguous_format
         out = torch.empty((k, c, ph, pw), dtype=xs[0].dtype, device=xs[0].device, memory_format=mf)
         with _C.on_device(xs[0].device):
-            if _FWD_ORDERED:
-                # (K ints for the ROI processing order of the forward: include/d2amd.h, d2amd_roi_pooler_forward_ordered)
-                order = torch.empty(max(k, 1), dtype=torch.int32, device=xs[0].device)
-                if box_lists is None:
-                    _C.check(_C.lib().d2amd_roi_pooler_forward_ordered(ctypes.byref(p), _ptr_array(xs), _C.ptr(rois),
-                                                                       _C.ptr(out), k, _C.ptr(order), 4 * max(k, 1),
-                                                                       _C.stream()))
-                else:
-                    n_img = len(box_lists)
-                    counts = (ctypes.c_int * n_img)(*[int(b.shape[0]) for b in box_lists])
-                    _C.check(_C.lib().d2amd_roi_pooler_forward_box_lists_ordered(
-                        ctypes.byref(p), _ptr_array(xs), _ptr_array(box_lists), counts, n_img, _C.ptr(rois), _C.ptr(out),
-                        _C.ptr(order), 4 * max(k, 1), _C.stream()))
-            elif box_lists is None:
+            if box_lists is None:
                 _C.check(_C.lib().d2amd_roi_pooler_forward(ctypes.byref(p), _ptr_array(xs), _C.ptr(rois), _C.ptr(out), k,
                                                            _C.stream()))
             else:
@@ -409,7 +394,7 @@ class _FusedROIPool(Function):
                     _C.check(rc)
             # The binning of the chain's LATER gathers (records, per-tile lists, queues: ~20 us of small launches each,
             # a function of the ROIs alone) runs on a side stream beside the first gather instead of between the gathers.
-            if len(works) > 1 and grads is not None and _SIDE_BINNING:
+            if len(works) > 1 and grads is not None:
                 from ..streams import _streams
 
                 cur = torch.cuda.current_stream(dev)
@@ -432,11 +417,6 @@ class _FusedROIPool(Function):
                         works[j] = (g, r, wcfg, (ws, ws_bytes, side))
                     elif rc != _C.EUNSUPPORTED:
                         _C.check(rc)
-            if _JOIN_EARLY:  # A/B: every side binning joined in front of the FIRST gather (one parent per later gather)
-                for j, (g, r, wcfg, binned) in enumerate(works):
-                    if binned is not None and len(binned) == 3:
-                        torch.cuda.current_stream(dev).wait_stream(binned[2])
-                        works[j] = (g, r, wcfg, binned[:2])
             for j, (g, r, wcfg, binned) in enumerate(works):
                 k = r.shape[0]
                 p = _params(wcfg, (n, c), hw, _C.dtype_code(g), _C.NHWC)

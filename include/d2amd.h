@@ -632,6 +632,8 @@ typedef struct d2amd_dcn_params {
                * and the weights keep their NCHW / OIHW layout.  NHWC is served by the 16-bit MFMA path only
                * (D2AMD_EUNSUPPORTED otherwise: the caller converts). */
 } d2amd_dcn_params;
+/* backward: 0 = the forward, 1 = the backward, 2 = a forward that is handed `columns` to keep
+ * (d2amd_deform_conv_forward_columns: no scratch column of its own -- 77 MB less for an R50 res3 block of 2 images). */
 size_t d2amd_deform_conv_workspace_bytes(const d2amd_dcn_params* p, int backward);
 int d2amd_deform_conv_forward(const d2amd_dcn_params* p, const void* x, const void* offset,
                               const void* mask, const void* weight, const void* bias, void* out,
@@ -647,14 +649,18 @@ int d2amd_deform_conv_backward(const d2amd_dcn_params* p, const void* x, const v
  * _C.deform_conv_forward / modulated_deform_conv_forward (layers/deform_conv.py:97-98,248-254; the C++ resizes and
  * refills them per image, deform_conv_cuda.cu:346-353,916-918) and recomputes the im2col in the backward
  * (:1160-1179).  Here the training forward can KEEP the column it builds -- 16-bit, modulation mask folded in; opaque to
- * the caller: NHWC layout (the column-kernel + dense-GEMM path): [B*Ho*Wo positions][kh*kw*C] row-major followed by the
- * weights packed per tap as [kh*kw*C][Co]; NCHW layout: [kh*kw * C/32 chunks][positions][32 channels].
+ * the caller: [B*Ho*Wo positions][kh*kw*C] row-major in both layouts; NHWC layout (the column-kernel + dense-GEMM path):
+ * followed by the weights packed per tap as [kh*kw*C][Co].
  * d2amd_deform_conv_columns_bytes = its size (77 MB + the weights for an R50 res3 block of 2 images: sized for 288 GB of
  * HBM), 0 when the shape / dtype is not served (fp32, groups > 1, deformable_groups > 1, C % 64 != 0: pass columns =
  * NULL) -- and the backward's weight gradient becomes a dense split-K GEMM dW = dY^T col on MFMA instead of a second
  * gather, its data gradient (NHWC) a dense GEMM against the kept weights.  The same d2amd_dcn_params (layout included) in
  * both calls.  columns = NULL in either call = the plain entry. */
 size_t d2amd_deform_conv_columns_bytes(const d2amd_dcn_params* p);
+/* 1 if a channels_last call of this shape / dtype takes the column + dense-GEMM path (csrc/dcn_colpath.hip), whatever
+ * p->layout says: what a caller holding NCHW activations (the reference's DeformBottleneckBlock, backbone/resnet.py:303-327)
+ * asks before it stages them channels_last itself -- detectron2_amd/layers/deform_conv.py does. */
+int d2amd_deform_conv_column_path(const d2amd_dcn_params* p);
 int d2amd_deform_conv_forward_columns(const d2amd_dcn_params* p, const void* x, const void* offset,
                                       const void* mask, const void* weight, const void* bias, void* out,
                                       void* columns, void* workspace, size_t workspace_bytes, void* stream);

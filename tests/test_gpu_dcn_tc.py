@@ -427,3 +427,20 @@ def test_backward_is_repeatable_beside_its_own_weight_gradient_gemm():
                 continue
             for k in out:
                 assert np.array_equal(out[k], first[k]), (str(dt), it, k, int((out[k] != first[k]).sum()))
+
+
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+def test_column_kernel_does_not_spread_a_non_finite_pixel(layout):
+    """corners outside the image read pixel 0 of x with weight 0; an Inf there (an AMP overflow) must only
+    reach the outputs whose samples really land on pixel (0, 0) -- 0 x Inf = NaN otherwise poisons every border position.
+    The reference takes an out-of-image corner as exactly 0 (deform_conv_cuda_kernel.cu:305-316)."""
+    x, off, msk, w, bias, go, kw = make_case(93, 1, 64, 64, 24, 28, dtype=torch.bfloat16, off_scale=1.0)
+    x = x.clone()
+    x[0, :, 0, 0] = float("inf")
+    xt = x.to(DEV)
+    if layout == "nhwc":
+        xt = xt.contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        y = layers.modulated_deform_conv(xt, off.to(DEV), msk.to(DEV), w.to(DEV), None, 1, 1, 1, 1, 1).float().cpu()
+    assert not torch.isnan(y[0, :, 6:, :]).any() and not torch.isnan(y[0, :, :, 6:]).any()
+    assert torch.isfinite(y[0, :, 6:, :]).all() and torch.isfinite(y[0, :, :, 6:]).all()  # (offsets ~N(0, 1): reach < 6 px)

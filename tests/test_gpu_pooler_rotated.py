@@ -267,3 +267,20 @@ def test_single_level_layer_backward_on_channels_last_is_the_gather(dtype):
     if dtype == torch.float32:
         want = oracle.roi_align_rotated_backward(gy, rois, x.shape, 0.25, 0)
         assert_close_fp32(g1, want, "rot_layer_bwd_nhwc", floor=4 * ROI_FLOOR)
+
+
+def test_backward_gather_does_not_spread_a_non_finite_gradient_row():
+    """the gather's lanes past a pixel's list re-read dY row 0 with weight 0 -- an Inf there (an fp16 / bf16
+    AMP overflow) must stay on the pixels ROI 0 touches (0 x Inf = NaN would reach every pixel whose list is shorter
+    than its wave's longest).  The reference's scatter only touches a sample's own taps (ROIAlignRotated_cuda.cu:224-323)."""
+    feats, boxes = make(91, n_img=1, c=32, n_box=24)
+    boxes[0][0] = [20.0, 20.0, 10.0, 8.0, 15.0]  # ROI 0: a small box in the top-left corner (level p2)
+    g = np.random.default_rng(3).standard_normal((24, 32, 7, 7)).astype(np.float32)
+    g[0] = np.inf
+    _, gx = run_fused(feats, boxes, 7, 2, torch.bfloat16, grad=g)
+    p2 = gx[0]
+    assert np.isinf(p2[0, :, 2:8, 2:8]).any()          # the ROI's own pixels carry it
+    assert not np.isnan(p2).any()
+    assert np.isfinite(p2[0, :, 16:, :]).all() and np.isfinite(p2[0, :, :, 16:]).all()  # nobody else does
+    for l in range(1, 4):
+        assert np.isfinite(gx[l]).all(), l
