@@ -45,7 +45,7 @@ struct PoolLevels {
   int dbg_block;
   int ablate;  // profiling only (D2AMD_ABLATE): bit0 skip gather, bit1 skip weights, bit2 skip list scan; MFMA tile
                // gather: bit3 no pairing, bit4 no loads of dY, bit5 no weight images, bit6 no items (empty lists), bit7 no stores
-  const int4* tile_geo;   // backward: per tile {level | image << 8, y0 | x0 << 16, H | W << 16, weight} (tile_lists_kernel)
+  const int4* tile_geo;   // backward: per tile {level | image << 8, y0 | x0 << 16, H | W << 16, -} (tile_lists_kernel)
   const int* tile_cnt;    // backward: per tile, number of ROIs that touch it (nullptr: tiles scan the records)
   const void* tile_list;  // backward: [tile][TILE_CAP] TileEntry in ROI order (valid when tile_cnt[tile] <= TILE_CAP)
   unsigned long long* wgstamps;  // profiling only (D2AMD_POOL_STAMPS): per workgroup {start, lists done, loop done, end, #ROIs}
@@ -531,15 +531,18 @@ static_assert(sizeof(TileEntry) == 32, "TileEntry layout");
 // (t0 - 1, t0 + 8) -- widened to everything below / above for the first / last tile, where the clamp folds the border
 // strip onto the edge pixel.  The bins whose sample span meets that interval are p in (a, b) with the bounds below
 // (for a negative bin size -- an inverted ROI with a fixed sampling ratio -- first and last sample swap roles).  The
-// bounds are widened by 0.02 bin: every bin with a non-zero weight is inside (fp32 rounding of (lo - start) / bin is
-// < 4e-3 bin for |bin| >= 0.01 px and coordinates < 1e6), a bin too many only adds a zero weight.  Degenerate bins take
+// bounds are widened by 0.02 bin: every bin with a non-zero weight is inside (the rounding of the bounds is orders of
+// magnitude below that wherever they are not clamped), a bin too many only adds a zero weight.  Degenerate bins take
 // the whole range.
 __device__ __forceinline__ int axis_window(float start, float bin, int grid, int P, int t0, int size) {
   int p_lo = 0, p_hi = P - 1;
   if (fabsf(bin) >= 0.01f && fabsf(start) < 1e6f) {  // (NaN: the whole range)
     const float lo = t0 == 0 ? -2.f : (float)(t0 - 1), hi = t0 + TILE >= size ? (float)(size + 1) : (float)(t0 + TILE);
-    const float rg = 1.f / (float)grid;
-    const float u = (lo - start) / bin, v = (hi - start) / bin;
+    // (v_rcp_f32 + a multiplication: RELATIVE error ~2e-7 -- where the bounds decide anything, |u|, |v| <= P + 1 <= 33 and
+    // the error is < 1e-5 bin; larger values are clamped below.  The correctly rounded division the library is built
+    // with costs ~10 x as many instructions, and this runs per (tile, ROI) pair on the critical path of the binning.)
+    const float rg = __builtin_amdgcn_rcpf((float)grid), rb = __builtin_amdgcn_rcpf(bin);
+    const float u = (lo - start) * rb, v = (hi - start) * rb;
     const float a = (bin > 0.f ? u : v) - ((float)grid - 0.5f) * rg;  // p > a
     const float b = (bin > 0.f ? v : u) - 0.5f * rg;                  // p < b
     p_lo = max(0, (int)floorf(fminf(fmaxf(a - 0.02f, -1.f), (float)P)) + 1);
@@ -557,6 +560,12 @@ __device__ __forceinline__ int entry_window(const HitGeo& g, int PH, int PW, int
 // heavy-first queues and the split planner count with -- a 7 x 7 pooler's entry is about one unit, a 14 x 14 pooler's 3-12 (a small
 // ROI whose 196 bins all fall into one tile: 12), so entry counts misjudge a paired launch's lists by that much.
 __device__ __forceinline__ int win_bins(int win) { return ((win >> 8) & 0xff) * ((win >> 24) & 0xff); }
+// per-tile word of the binning: the list's length, and -- for the planner -- its weight (lists that fit only; 0 = no ROI)
+__host__ __device__ __forceinline__ int tile_count_pack(int cnt, int wgt) {
+  return cnt == 0 ? 0 : cnt <= 64 ? (1 << 30) | (wgt << 8) | cnt : cnt;  // (64 = TILE_CAP)
+}
+__host__ __device__ __forceinline__ int tile_count_of(int v) { return (v >> 30) & 1 ? v & 0xff : v; }
+__host__ __device__ __forceinline__ int tile_weight_of(int v) { return (v >> 30) & 1 ? (v >> 8) & 0x3fffff : v; }
 struct TileGeom { int lvl, n, y0, x0; };
 __device__ __forceinline__ TileGeom tile_geom(const PoolLevels& L, int tile) {
   TileGeom g;
@@ -653,16 +662,14 @@ __global__ __launch_bounds__(64 * LISTS_WAVES) void tile_lists_kernel(PoolLevels
         cnt1 += __builtin_popcountll(__ballot(hit && kk < K1));
       }
     }
-    wgt = (__builtin_amdgcn_readlane(wave_incl_scan(kbins), 63) + 15) >> 4;
+    wgt = min((__builtin_amdgcn_readlane(wave_incl_scan(kbins), 63) + 15) >> 4, 0x3fffff);
     if (cnt > TILE_CAP) wgt = cnt;  // (the list did not fit: the gather scans the records; never split, always heavy)
-    if (lane == 0) __hip_atomic_store(&tile_cnt[tile], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (the planner
-    if (lane == 0 && tile_cnt1)                                                                          // reads them)
-      __hip_atomic_store(&tile_cnt1[tile], cnt1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (lane == 0 && tile_geo) {
-      int4* gp = tile_geo + tile;
-      gp->x = g.lvl | (g.n << 8); gp->y = g.y0 | (g.x0 << 16); gp->z = L.H[g.lvl] | (L.W[g.lvl] << 16);
-      __hip_atomic_store(&gp->w, wgt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    // The planner (another workgroup of THIS launch) reads the count and the weight: ONE device-scope word.  What only the
+    // gather -- a later launch -- reads is stored plainly: three more write-through stores per tile, each waited for in
+    // front of the planner's ticket, cost this kernel 6.5 us of 23 (same-box A/B, profiles/r06/pool_bwd_kcat.md).
+    if (lane == 0) __hip_atomic_store(&tile_cnt[tile], tile_count_pack(cnt, wgt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0 && tile_cnt1) tile_cnt1[tile] = cnt1;
+    if (lane == 0 && tile_geo) tile_geo[tile] = int4{g.lvl | (g.n << 8), g.y0 | (g.x0 << 16), L.H[g.lvl] | (L.W[g.lvl] << 16), wgt};
   }
   if (Q.mem == nullptr) return;  // uniform
   const int H = L.H[g.lvl], W = L.W[g.lvl];
@@ -742,10 +749,13 @@ __global__ __launch_bounds__(64 * LISTS_WAVES) void tile_lists_kernel(PoolLevels
   for (int t0 = 0; t0 < ntiles; t0 += PT) {
     const int t = t0 + (int)threadIdx.x;
     int c = 0;
-    if (t < ntiles) c = __hip_atomic_load(&tile_cnt[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    TileGeom tg{};
     int wgt = 0;
-    if (t < ntiles) wgt = __hip_atomic_load(&tile_geo[t].w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t < ntiles) {
+      const int v = __hip_atomic_load(&tile_cnt[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      c = tile_count_of(v);
+      wgt = tile_weight_of(v);
+    }
+    TileGeom tg{};
     bool cand = wgt > Q.split_min && c >= 2 && c <= TILE_CAP;
     if (cand) {
       tg = tile_geom(L, t);
@@ -797,7 +807,7 @@ __global__ __launch_bounds__(64 * LISTS_WAVES) void zero_empty_tiles_kernel(Pool
                                                                            const int* __restrict__ tile_cnt, int esize) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tile = blockIdx.x * LISTS_WAVES + wave;
-  if (tile >= ntiles || tile_cnt[tile] != 0) return;
+  if (tile >= ntiles || tile_cnt[tile] != 0) return;  // (tile_count_pack(0, .) == 0)
   const TileGeom g = tile_geom(L, tile);
   const int H = L.H[g.lvl], W = L.W[g.lvl];
   const int rows = min(8, H - g.y0), cols = min(8, W - g.x0);
@@ -923,7 +933,7 @@ __global__ __launch_bounds__(CT * RS * GROUPS, 4) void pool_bwd_nhwc_kernel(Pool
   int tl_cnt = -1;
   if (L.tile_cnt) {
     const int gtile = ids.first[lvl] + (tile - L.tile_base[lvl]);
-    const int c = qcnt >= 0 ? qcnt : L.tile_cnt[gtile];
+    const int c = qcnt >= 0 ? qcnt : tile_count_of(L.tile_cnt[gtile]);
     if (c <= TILE_CAP) {
       tl_cnt = c;
       if (tid < c) {
@@ -1293,7 +1303,7 @@ __global__ __launch_bounds__(2 * CT, 4) void pool_bwd_staged_kernel(PoolLevels L
   int tl_cnt = -1;
   if (L.tile_cnt) {
     const int gtile = ids.first[lvl] + (tile - L.tile_base[lvl]);
-    const int c = qcnt >= 0 ? qcnt : L.tile_cnt[gtile];
+    const int c = qcnt >= 0 ? qcnt : tile_count_of(L.tile_cnt[gtile]);
     if (c <= TILE_CAP) {
       tl_cnt = c;
       if (tid < c) {

@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 kernel stats + one replayed step's timeline of a bench workload.  $1 = workload, $2 = tag
-cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp PYTHONPATH=$PWD; REPO=$PWD; WL=$1; TAG=${2:-$1}; OUT=$REPO/gpurun_out/r05/$TAG; mkdir -p $OUT
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp PYTHONPATH=$PWD; REPO=$PWD; WL=$1; TAG=${2:-$1}; OUT=$REPO/gpurun_out/${ROUND:-r06}/$TAG; mkdir -p $OUT
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python $REPO/bench.py --workload $WL --steps 20 --warmup 3 --no-cpu-baseline --no-extra-workloads ${@:3} > $OUT/prof.log 2>&1
 cp $(find $OUT/prof -name "*kernel_stats.csv" | head -1) $OUT/${WL}_kernel_stats.csv 2>/dev/null
