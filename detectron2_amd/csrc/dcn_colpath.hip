@@ -297,7 +297,7 @@ static int cp_positions_per_group(const DcnShape& s) {
 ColPathPlan dcn_colpath_plan(const DcnShape& s, int dtype) {
   ColPathPlan pl{};
   pl.ok = false;
-  static const bool off = getenv("D2AMD_DCN_FUSED") != nullptr;  // A/B switch: the fused gather-MFMA kernels of r01-r04
+  static const bool off = d2_prof_env("D2AMD_DCN_FUSED") != nullptr;  // A/B switch: the fused gather-MFMA kernels of r01-r04
   if (off) return pl;
   if (dtype != D2AMD_BF16 && dtype != D2AMD_F16) return pl;
   if (s.G != 1 || s.DG != 1 || s.K2 > 9 || s.P <= 0) return pl;

@@ -699,7 +699,7 @@ static DcnSide* dcn_side(hipStream_t caller) {
   static Slot slots[32];
   static int nslots = 0;
   static std::mutex mu;
-  static const bool off = getenv("D2AMD_DCN_NO_SIDE") != nullptr;
+  static const bool off = d2_prof_env("D2AMD_DCN_NO_SIDE") != nullptr;
   int dev = 0;
   if (off || hipGetDevice(&dev) != hipSuccess) return nullptr;
   std::lock_guard<std::mutex> lock(mu);

@@ -2850,7 +2850,7 @@ extern "C" int d2amd_roi_pooler_forward_pair(const d2amd_pooler_params* p1, cons
       p1->max_level == p2->max_level && p1->canonical_level == p2->canonical_level &&
       p1->canonical_box_size == p2->canonical_box_size;
   for (int l = 0; rule && l < p1->num_levels; l++) rule = p1->spatial_scale[l] == p2->spatial_scale[l];
-  static const bool off = getenv("D2AMD_POOL_NO_PAIR") != nullptr;
+  static const bool off = d2_prof_env("D2AMD_POOL_NO_PAIR") != nullptr;
   if (off || !rule || K1 == 0 || K2 == 0 || !pooler_fused_ok(p1) || !pooler_fused_ok(p2) || p1->layout != D2AMD_NHWC ||
       (long)p1->N * p1->C == 0) {
     set_error("roi_pooler_forward_pair: outside the paired forward (NHWC, both K > 0, the same level rule and sampling)");
@@ -3040,7 +3040,7 @@ static int pooler_backward_pair_entry(const d2amd_pooler_params* p1, const void*
       p1->max_level == p2->max_level && p1->canonical_level == p2->canonical_level &&
       p1->canonical_box_size == p2->canonical_box_size;
   for (int l = 0; rule && l < p1->num_levels; l++) rule = p1->spatial_scale[l] == p2->spatial_scale[l];
-  static const bool off = getenv("D2AMD_POOL_NO_PAIR") != nullptr;
+  static const bool off = d2_prof_env("D2AMD_POOL_NO_PAIR") != nullptr;
   if (off || !rule || K1 == 0 || K2 == 0 || !pooler_fused_ok(p1) || !pooler_fused_ok(p2) || p1->layout != D2AMD_NHWC ||
       p1->dtype == D2AMD_F32 || (long)p1->N * p1->C == 0 || ((uintptr_t)grad_output2 & 15) != 0) {
     set_error("roi_pooler_backward_pair: outside the paired 16-bit tile gather (16-bit NHWC, pooled sizes <= %d, the same "
