@@ -946,6 +946,14 @@ __device__ __forceinline__ bool nms_mask_tile(const float* __restrict__ boxes_s,
     bool exact = !FAST || weird;  // uniform
     if (!exact) {
       bool bad = false;
+      // r06: the comparison  inter >= mid * denom  WITHOUT double arithmetic (four quarter-rate instructions per pair were
+      // half of this kernel's VALU time).  With f = the float below mid and h = mid - f (half an ulp of f: a power of two),
+      //     inter - mid * denom  =  A - e,      A = inter - f * denom,   e = h * denom  (exact in fp32),
+      // and d = fma(-f, denom, inter) is A rounded ONCE: sign and magnitude to 2^-24.  So d > 1.001 e  =>  A > e and
+      // d < 0.999 e  =>  A < e, decided in three fp32 instructions; a pair inside that band -- its IoU within an ulp of the
+      // threshold: ~1e-7 of the pairs -- or with a vanishing e sends the tile to the literal formula below, like any
+      // other irregular value.  (Bit-exactness is the bar: tests/test_gpu_parity.py, tests/test_gpu_nms_runs.py.)
+      const float f_lo = __double2float_rd(mid), h_ulp = (float)(mid - (double)f_lo);
       // not unrolled: every wave runs the body once per group, a 64x unrolled body is instruction-fetch bound
 #pragma unroll 1
       for (int g = 0; g < 16; g++) {
@@ -960,9 +968,10 @@ __device__ __forceinline__ bool nms_mask_tile(const float* __restrict__ boxes_s,
           const float ww = vmax0f(xx2 - xx1), hh = vmax0f(yy2 - yy1);
           const float inter = ww * hh;
           const float denom = iarea + jarea - inter;
-          const double p = mid * (double)denom;
-          const bool hit = TIE_UP ? ((double)inter >= p) : ((double)inter > p);
-          bad |= !__builtin_amdgcn_classf(denom, 0x180);  // not (+normal | +denormal): redo the tile literally
+          const float d = __builtin_fmaf(-f_lo, denom, inter), e = h_ulp * denom;
+          const bool hit = d > e;
+          // not (+normal | +denormal), or too close to call in fp32: redo the tile literally
+          bad |= !__builtin_amdgcn_classf(denom, 0x180) | !(d > 1.001f * e || d < 0.999f * e) | !(e > 1e-30f);
           nib |= (hit && jcls == my_cls) ? (1u << q) : 0u;
         }
         word |= (u64)nib << (4 * g);
@@ -1737,7 +1746,8 @@ static int nms_mask_reduce(NmsBatch& B, int rotated, bool any_cls, hipStream_t s
     wcap_max = std::max(wcap_max, B.img[k].wcap);
   }
   // ~8,000 waves per image keep the chip busy; beyond that more workgroups per row block only add dispatches
-  const int gy = std::max(std::min(wcap_max, 8), std::min(std::min(wcap_max, MASK_GRID_Y), cdiv(8192, std::max(nb_max, 1))));
+  int gy = std::max(std::min(wcap_max, 8), std::min(std::min(wcap_max, MASK_GRID_Y), cdiv(8192, std::max(nb_max, 1))));
+  if (const char* e = d2_prof_env("D2AMD_NMS_MASK_GY")) gy = std::max(1, std::min(atoi(e), wcap_max));  // (profiling builds)
   const dim3 mgrid(nb_max, gy, B.count);
   const bool timed_mask = timing_begin("nms_mask", s);
   if (rotated) {
