@@ -1239,8 +1239,15 @@ __device__ __forceinline__ void nms_reduce_body(const u64* __restrict__ mask,
     if (dbg && seg == 0 && tid == 0) dbg[126] = wall_clock64();
     for (int w = tid; w < nb; w += RED_THREADS) removed[w] = 0;
 
-    const int wi = min(RED_NEAR + lane, wcap - 1);
-    const int nunits = nb * RED_SPLIT;
+    // r06, HALF: a segment of <= RED_NEAR + 32 blocks (the RPN's 2,000 per level) needs 32 later words of a row at most,
+    // so a pusher's lanes 32..63 hold 32 MORE rows instead of re-reading the last word: a unit is a whole block, the 15
+    // pushers hold 15 blocks of rows (7.5 before) and a unit's loads are issued 15 blocks ahead of their use -- the
+    // stamps showed wave 0 waiting 1-2 us for a push at 8 of the 32 blocks (profiles/r06/nms_reduce_stamps.txt)
+    const bool half = nb <= RED_NEAR + 32;
+    const int ushift = half ? 0 : 1;  // log2(units per block); RED_SPLIT == 2
+    const int lane_w = half ? (lane & 31) : lane;
+    const int hrow = half ? (lane >> 5) * RED_PUSH_ROWS : 0;
+    const int wi = min(RED_NEAR + lane_w, wcap - 1);
 
     // Flag-synchronised pipeline instead of one workgroup barrier per block (measured: 1.5 us per block with
     // the barrier -- every block waited for a pusher to issue its 64 row loads -- against ~0.3 us of actual
@@ -1275,7 +1282,7 @@ __device__ __forceinline__ void nms_reduce_body(const u64* __restrict__ mask,
           // wait for the pushers: group g must have finished its blocks <= rel - 2
           if (rel >= RED_NEAR) {
             const int g = lane < RED_GROUPS ? lane : 0;
-            const int ulast = (rel - RED_NEAR + 1) * RED_SPLIT - 1;  // last unit of block rel - RED_NEAR
+            const int ulast = ((rel - RED_NEAR + 1) << ushift) - 1;  // last unit of block rel - RED_NEAR
             const int need = ulast >= g ? (ulast - g) / RED_GROUPS + 1 : 0;
             while (__ballot(__hip_atomic_load(&flag_s[1 + g], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need))
               __builtin_amdgcn_s_sleep(1);
@@ -1308,32 +1315,36 @@ __device__ __forceinline__ void nms_reduce_body(const u64* __restrict__ mask,
         // pusher: `rows` = word 2 + lane of the 32 rows of the unit it owns next; the array lives only inside this
         // branch and is redefined by an unconditional (clamped) prefetch on every iteration -- carried across the
         // outer loops or loaded conditionally, the compiler kept two copies, spilled and drained vmcnt per unit
-        const int u0 = (bw - b0) * RED_SPLIT, u1 = (wend - b0 + 1) * RED_SPLIT - 1;
+        const int u0 = (bw - b0) << ushift, u1 = ((wend - b0 + 1) << ushift) - 1;
         u64 rows[RED_PUSH_ROWS];
         auto load_unit = [&](int u) {
-          // rows up to n64 - 1 are allocated (never kept if >= n): the row base is a wave-uniform SGPR address
+          // rows up to n64 - 1 are allocated (never kept if >= n)
           // lanes beyond the segment's last block re-read the last needed word (same cache line, masked at use):
           // 64 distinct words per row pulled 5 lines per row through this CU where ~2 are needed
-          const int wl = min(wi, max(b1 - (b0 + u / RED_SPLIT), 0));
-          const u64* base = mask + ((long)(b0 + u / RED_SPLIT) * 64 + (u % RED_SPLIT) * RED_PUSH_ROWS) * wcap + wl;
+          const int ub = u >> ushift;
+          const int wl = min(wi, max(b1 - (b0 + ub), 0));
+          const u64* base = mask + ((long)(b0 + ub) * 64 + (u - (ub << ushift)) * RED_PUSH_ROWS + hrow) * wcap + wl;
 #pragma unroll
           for (int r = 0; r < RED_PUSH_ROWS; r++) rows[r] = base[(long)r * wcap];
         };
         const int ufirst = u0 + ((grp - u0) % RED_GROUPS + RED_GROUPS) % RED_GROUPS;
+        // (MEASURED, r06: the first unit's rows issued in front of the staging barrier -- between the staging loads and
+        // their LDS writes -- removed wave 0's 1.6 us wait at block RED_NEAR but the barrier then opened 4 us later: 480 row
+        // loads of one CU queue in front of the last waves' staging loads.  26.0 against 24.1 us: not kept.)
         load_unit(min(ufirst, u1));
         for (int u = ufirst; u <= u1; u += RED_GROUPS) {
-          const int rel = u / RED_SPLIT, b = b0 + rel;  // u % RED_GROUPS == grp
+          const int rel = u >> ushift, b = b0 + rel;  // u % RED_GROUPS == grp
           while (__hip_atomic_load(&flag_s[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= rel)
             __builtin_amdgcn_s_sleep(1);
-          const int r0 = (u % RED_SPLIT) * RED_PUSH_ROWS;
-          const uint32_t kept = (uint32_t)(kept_s[(b - bw)] >> r0);
+          const int r0 = (u - (rel << ushift)) * RED_PUSH_ROWS;
+          const uint32_t kept = (uint32_t)(kept_s[(b - bw)] >> (r0 + hrow));  // (HALF: the upper lanes' 32 rows)
           const int nlater = b1 - b;
           u64 acc = 0;
 #pragma unroll
           for (int r = 0; r < RED_PUSH_ROWS; r++)  // kept rows lie in [s, e) by construction
             acc |= ((kept >> r) & 1u) ? rows[r] : 0ull;
-          if ((RED_NEAR + lane) <= nlater && acc) atomicOr(&removed[rel + RED_NEAR + lane], acc);
-          // categories with more than ~4200 boxes: remaining words, fetched now that `kept` is known
+          if ((RED_NEAR + lane_w) <= nlater && acc) atomicOr(&removed[rel + RED_NEAR + lane_w], acc);
+          // categories with more than ~4200 boxes: remaining words, fetched now that `kept` is known (never with HALF)
           for (int w = 64 + RED_NEAR + lane; w <= nlater; w += 64) {
             u64 a2 = 0;
             for (int r = 0; r < RED_PUSH_ROWS; r++) {

@@ -1,6 +1,6 @@
 #!/bin/bash
 # dcn_r50 on the box: the bench line (graph replay) and rocprofv3 kernel stats of the same workload.  $1 = tag
-cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp PYTHONPATH=$PWD; REPO=$PWD; TAG=${1:-dcn}; OUT=$REPO/gpurun_out/r05/$TAG; mkdir -p $OUT
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp PYTHONPATH=$PWD; REPO=$PWD; TAG=${1:-dcn}; OUT=$REPO/gpurun_out/${ROUND:-r06}/$TAG; mkdir -p $OUT
 timeout 300 python bench.py --workload dcn_r50 --no-cpu-baseline > $OUT/bench_dcn_r50.json 2> $OUT/bench_dcn_r50.err; echo "bench rc=$?"
 python - <<PY
 import json
@@ -23,6 +23,14 @@ for (n, grid), v in sorted(g.items()):
     if len(v) < 20: continue
     v.sort()
     out.append("%-62s grid %8d calls %5d  median %8.2f us  p10 %8.2f" % (n, grid, len(v), v[len(v) // 2], v[len(v) // 10]))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+last = rows[-int(len(rows) / 41 + 1):]  # ~ the last replayed step (41 = warmup + timed + capture passes of this command)
+t0 = int(last[0]["Start_Timestamp"])
+with open("$OUT/dcn_r50_last_step_timeline.txt", "w") as f:
+    for r in last:
+        n = re.sub(r"^void d2amd::|^d2amd::", "", r["Kernel_Name"]); n = re.sub(r"\(.*", "", n)[:56]
+        f.write("%9.2f %8.2f  q%-3s %-58s grid %8d\n" % ((int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
+                r.get("Queue_Id", "?"), n, int(r["Grid_Size_X"])))
 open("$OUT/dcn_r50_kernels_by_shape.txt", "w").write("\n".join(out) + "\n")
 print("\n".join(out))
 PY2
