@@ -1159,6 +1159,156 @@ __device__ __forceinline__ bool nms_mask_rot_tile_compact(const float* __restric
   store_mask_words(word, row, col0, lane, w, n, wcap, mask, diagT, w1T, w2T);
   return true;
 }
+// r06: the same tile by a workgroup of ROTW waves.  One wave per 64 x 64 tile left ~9 single-wave workgroups per CU,
+// each a chain of 64 cheap tests + 2-3 clip passes (~50-100 us per tile, nothing to hide a latency behind: 42 G pairs/s
+// against the IoU kernel's 72 G with its 4-16 rows per wave).  Here lane = COLUMN, wave v tests the rows 16 v .. 16 v + 15
+// (row boxes are LDS broadcasts, no shuffles), the four waves append their survivors to ONE list and share its clip
+// passes (64 pairs each, a scratch per wave); wave 0 stores the words.  Same tests, same clip, same operand order
+// (row = the earlier box first: nms_rotated_cpu.cpp:45-54) -- the words are bit-identical to the one-wave tile's.
+constexpr int ROTW = 4;
+// pairs per clip pass of a wave (lanes beyond it idle) -- it sizes the wave's scratch -- and workgroups per CU the kernel
+// is compiled for.  MEASURED (rrpn_micro's 2 x 8,819 boxes, same box, before the projection bound): 64 pairs / 2 per CU
+// (61 KB of LDS) 126 us | 32 / 4 (37 KB, 106 VGPRs) 118.5 | 32 / 3 118 | 16 / 4 185 (twice the passes).
+constexpr int ROT_PASS = 32;
+constexpr int ROT_OCC = 4;
+struct RotTileWg {
+  float rowb[5][64], colb[5][64];
+  float rowcs[2][64], colcs[2][64];  // cos, sin of the boxes' angles (the projection bound below)
+  uint32_t rcls[64], ccls[64];
+  unsigned long long words[64];
+  uint16_t list[64 * 64];
+  int total;
+};
+// Upper bound of the intersection area of two rotated boxes from their projections: the intersection lies inside the
+// rectangle spanned -- in the frame of box 1 -- by the overlaps of the two boxes' projections onto box 1's axes, and
+// likewise in the frame of box 2; it is also no larger than either box.  (rot_vertices: the width axis of a box is
+// (cos, -sin), the height axis (sin, cos).)  SLACK px are added to every overlap length: the centre difference is taken
+// in fp32 here (the reference shifts by the midpoint in double) and sin / cos are fp32 -- errors of ~1e-4 px at 1,000 px.
+__device__ __forceinline__ float rot_inter_upper_bound(const float* __restrict__ b1, float c1, float s1,
+                                                       const float* __restrict__ b2, float c2, float s2) {
+  constexpr float SLACK = 1e-2f;
+  const float dx = b2[0] - b1[0], dy = b2[1] - b1[1];
+  const float cd = fabsf(c1 * c2 + s1 * s2), sd = fabsf(s1 * c2 - c1 * s2);
+  const float hw1 = 0.5f * b1[2], hh1 = 0.5f * b1[3], hw2 = 0.5f * b2[2], hh2 = 0.5f * b2[3];
+  auto frame = [&](float cu, float su, float hwa, float hha, float hwb, float hhb) {
+    // box a's frame: box b's centre at (du, dv), its half extents along a's axes (eu, ev)
+    const float du = dx * cu - dy * su, dv = dx * su + dy * cu;
+    const float eu = hwb * cd + hhb * sd, ev = hwb * sd + hhb * cd;
+    const float ou = fminf(hwa, du + eu) - fmaxf(-hwa, du - eu) + SLACK;
+    const float ov = fminf(hha, dv + ev) - fmaxf(-hha, dv - ev) + SLACK;
+    return fmaxf(ou, 0.f) * fmaxf(ov, 0.f);
+  };
+  // (in box 2's frame the centre difference changes sign: the overlaps are symmetric in it)
+  return fminf(frame(c1, s1, hw1, hh1, hw2, hh2), frame(c2, s2, hw2, hh2, hw1, hh1));
+}
+__device__ __forceinline__ bool nms_mask_rot_tile_wg(const float* __restrict__ boxes_s, int n, int wcap, int rb, int w,
+                                                     double thr, u64* __restrict__ mask, u64* __restrict__ diagT,
+                                                     u64* __restrict__ w1T, u64* __restrict__ w2T,
+                                                     RotIouScratch<ROT_PASS>* S, RotTileWg& T) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int cb = rb + w;
+  const int col0 = cb * 64;
+  const int nblocks = (n + 63) >> 6;
+  if (cb >= nblocks || w >= wcap) return false;
+  const uint32_t row_last = __float_as_uint(boxes_s[(long)min(rb * 64 + 63, n - 1) * BOX_REC + 5]);
+  const uint32_t col_first = __float_as_uint(boxes_s[(long)col0 * BOX_REC + 5]);
+  if (col_first > row_last) return false;  // (see nms_mask_tile)
+  __syncthreads();  // (the previous tile's LDS is no longer read)
+  if (wv < 2) {
+    const int rec = min((wv == 0 ? rb * 64 : col0) + lane, n - 1);
+    float (&dst)[5][64] = wv == 0 ? T.rowb : T.colb;
+#pragma unroll
+    for (int k = 0; k < 5; k++) dst[k][lane] = boxes_s[(long)rec * BOX_REC + k];
+    (wv == 0 ? T.rcls : T.ccls)[lane] = __float_as_uint(boxes_s[(long)rec * BOX_REC + 5]);
+    {
+      const float th = boxes_s[(long)rec * BOX_REC + 4] * 0.01745329251f;
+      float (&cs)[2][64] = wv == 0 ? T.rowcs : T.colcs;
+      cs[0][lane] = cosf(th);
+      cs[1][lane] = sinf(th);
+    }
+    if (wv == 0) {
+      T.words[lane] = 0ull;
+      if (lane == 0) T.total = 0;
+    }
+  }
+  __syncthreads();
+  const float thr_ratio = (float)(0.99 * thr);
+  float cbx[5];
+#pragma unroll
+  for (int k = 0; k < 5; k++) cbx[k] = T.colb[k][lane];
+  const uint32_t col_cls = T.ccls[lane];
+  const float ccos = T.colcs[0][lane], csin = T.colcs[1][lane];
+  const bool cin = col0 + lane < n;
+  unsigned live = 0u;  // bit i: (row 16 wv + i, this column) needs the clip
+#pragma unroll 4
+  for (int i = 0; i < 64 / ROTW; i++) {
+    const int r = wv * (64 / ROTW) + i, row = rb * 64 + r;
+    if (row >= n) break;  // uniform
+    float rbx[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) rbx[k] = T.rowb[k][r];
+    bool cand = cin && (col_cls == T.rcls[r]) && (col0 + lane > row) && !rot_pair_is_zero(rbx, cbx);
+    {  // (the area-ratio bound of nms_mask_rot_tile_compact, same operands)
+      const float a1 = rbx[2] * rbx[3], a2 = cbx[2] * cbx[3];
+      const bool sized = rbx[2] >= 1.f && rbx[3] >= 1.f && cbx[2] >= 1.f && cbx[3] >= 1.f;
+      cand = cand && !(sized && fminf(a1, a2) < thr_ratio * fmaxf(a1, a2));
+      // r06: IoU = inter / (a1 + a2 - inter) grows with inter, and inter <= the projection bound: a pair whose BOUND gives
+      // an IoU more than 1 % below the threshold cannot reach it (same size condition as above: at sides >= 1 px the
+      // reference's vertex / edge tolerances are <= 1e-5 of a side).  The centre-distance test passes every pair within the
+      // sum of the half DIAGONALS -- for the RRPN's elongated anchors most of those do not overlap by half.
+      if (cand && sized) {
+        const float ub = rot_inter_upper_bound(rbx, T.rowcs[0][r], T.rowcs[1][r], cbx, ccos, csin);
+        cand = !(ub * (1.f + thr_ratio) < thr_ratio * (a1 + a2));
+      }
+    }
+    live |= cand ? (1u << i) : 0u;
+  }
+  const int mine = __builtin_popcount(live);
+  int incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int y = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += y;
+  }
+  int base = 0;
+  if (lane == 63 && incl > 0) base = atomicAdd(&T.total, incl);
+  base = __shfl(base, 63);
+  {
+    int at = base + incl - mine;
+    unsigned m = live;
+    while (m) {
+      const int i = __builtin_ctz(m);
+      m &= m - 1;
+      T.list[at++] = (uint16_t)(((wv * (64 / ROTW) + i) << 6) | lane);
+    }
+  }
+  __syncthreads();
+  const int total = T.total;
+  for (int t0 = wv * ROT_PASS; t0 < total; t0 += ROTW * ROT_PASS) {  // uniform per wave
+    const int t = t0 + lane;
+    const bool on = lane < ROT_PASS && t < total;
+    const int e = T.list[on ? t : total - 1];
+    const int r = e >> 6, j = e & 63;
+    float b1[5], b2[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) { b1[k] = T.rowb[k][r]; b2[k] = T.colb[k][j]; }
+    if (ROT_PASS == 64 || lane < ROT_PASS) {
+      const float ovr = single_box_iou_rotated<ROT_PASS>(b1, b2, S[wv], lane);
+      if (on && (double)ovr >= thr) atomicOr(&T.words[r], 1ull << j);  // nms_rotated_cpu.cpp:54
+    }
+  }
+  __syncthreads();
+  if (wv == 0) store_mask_words(T.words[lane], rb * 64 + lane, col0, lane, w, n, wcap, mask, diagT, w1T, w2T);
+  return true;
+}
+__device__ __forceinline__ void nms_mask_rot_wg_body(const float* __restrict__ boxes_s, int n, int wcap, double thr,
+                                                     u64* __restrict__ mask, u64* __restrict__ diagT,
+                                                     u64* __restrict__ w1T, u64* __restrict__ w2T) {
+  __shared__ RotIouScratch<ROT_PASS> S[ROTW];
+  __shared__ RotTileWg T;
+  for (int w = blockIdx.y; w < wcap; w += gridDim.y)
+    if (!nms_mask_rot_tile_wg(boxes_s, n, wcap, blockIdx.x, w, thr, mask, diagT, w1T, w2T, S, T)) break;
+}
 __device__ __forceinline__ void nms_mask_rot_body(const float* __restrict__ boxes_s, int n, int wcap, double thr,
                                                   u64* __restrict__ mask, u64* __restrict__ diagT,
                                                   u64* __restrict__ w1T, u64* __restrict__ w2T, int plain = 0) {
@@ -1705,6 +1855,10 @@ __global__ __launch_bounds__(64) void nms_mask_rot_kernel(const NmsBatch B) {
   const NmsImg& I = B.img[blockIdx.z];
   nms_mask_rot_body(I.w.boxes_s, I.n, I.wcap, B.thr, I.w.mask, I.w.diagT, I.w.w1T, I.w.w2T, B.rot_plain);
 }
+__global__ __launch_bounds__(64 * ROTW, ROT_OCC) void nms_mask_rot_wg_kernel(const NmsBatch B) {
+  const NmsImg& I = B.img[blockIdx.z];
+  nms_mask_rot_wg_body(I.w.boxes_s, I.n, I.wcap, B.thr, I.w.mask, I.w.diagT, I.w.w1T, I.w.w2T);
+}
 __global__ __launch_bounds__(RED_THREADS) void nms_reduce_kernel(const NmsBatch B) {
   const NmsImg& I = B.img[blockIdx.z];
   nms_reduce_body(I.w.mask, I.w.diagT, I.w.w1T, I.w.w2T, I.cls_s, I.n, I.wcap, I.mpc, I.w.seg_start,
@@ -1764,7 +1918,11 @@ static int nms_mask_reduce(NmsBatch& B, int rotated, bool any_cls, hipStream_t s
   if (rotated) {
     static const bool rot_plain = d2_prof_env("D2AMD_NMS_ROT_PLAIN") != nullptr;
     B.rot_plain = rot_plain ? 1 : 0;
-    hipLaunchKernelGGL(nms_mask_rot_kernel, mgrid, dim3(64), 0, s, B);
+    // thr > 0: the workgroup tile (r06); D2AMD_NMS_ROT_WAVE (profiling builds): r04's one-wave tile.  thr <= 0 "suppresses"
+    // the pairs the distance test rejects too: the plain tile.
+    static const bool rot_wave = d2_prof_env("D2AMD_NMS_ROT_WAVE") != nullptr;
+    if (B.thr > 0.0 && !rot_plain && !rot_wave) hipLaunchKernelGGL(nms_mask_rot_wg_kernel, mgrid, dim3(64 * ROTW), 0, s, B);
+    else hipLaunchKernelGGL(nms_mask_rot_kernel, mgrid, dim3(64), 0, s, B);
   } else {
     const MaskThr m = mask_thr(B.thr);
     B.mid = m.mid;

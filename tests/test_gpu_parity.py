@@ -840,3 +840,47 @@ def test_nms_rotated_pairs_at_the_area_ratio_bound(thr):
     got = nms_rotated(torch.from_numpy(b).to(DEV), torch.from_numpy(s).to(DEV), thr).cpu().numpy()
     assert np.array_equal(got, want)
     assert 120 < len(want) < 240  # some of the smaller boxes are suppressed, some are not
+
+
+@pytest.mark.parametrize("thr", [0.1, 0.3, 0.5, 0.7, 0.9])
+def test_nms_rotated_pairs_at_the_projection_bound(thr):
+    """r06: the rotated mask tile also skips the clip when the PROJECTION bound of the intersection (overlap of the two boxes'
+    projections on the axes of either box) gives an IoU more than 1 % below the threshold.  For two boxes of equal angle
+    shifted along an axis the bound IS the intersection: ladders of shifts whose IoU runs from 0.97 x to 1.01 x the
+    threshold -- equal angle, slightly different angles, crossing elongated boxes -- and RRPN-like clusters (shared centres,
+    angles every 30 degrees, aspect ratios up to 1:8) must give the kept set of the oracle's full clip."""
+    rng = np.random.default_rng(1000 + int(thr * 100))
+    boxes, scores = [], []
+    for g in range(60):  # shift ladders: IoU = (w - d) / (w + d) for equal boxes shifted by d along the width axis
+        cx, cy = rng.uniform(100, 900, 2)
+        w, h = np.exp(rng.uniform(np.log(8), np.log(300))), np.exp(rng.uniform(np.log(4), np.log(60)))
+        ang = rng.uniform(-180, 180)
+        iou = thr * rng.uniform(0.97, 1.01)
+        d = w * (1 - iou) / (1 + iou)
+        t = np.deg2rad(ang)
+        ux, uy = np.cos(t), -np.sin(t)  # the width axis of a box (rot_vertices)
+        boxes.append([cx, cy, w, h, ang]); scores.append(1.0 - 1e-3 * g)
+        dang = rng.choice([0.0, 0.0, 0.5, 3.0]) * rng.uniform(-1, 1)
+        boxes.append([cx + d * ux, cy + d * uy, w, h, ang + dang]); scores.append(0.6 - 1e-3 * g)
+    for g in range(40):  # crossing boxes: a long thin one over a wider one, the angle between them 60-90 degrees
+        cx, cy = rng.uniform(100, 900, 2)
+        w1, h1 = rng.uniform(60, 200), rng.uniform(20, 60)
+        ang = rng.uniform(-90, 90)
+        boxes.append([cx, cy, w1, h1, ang]); scores.append(0.5 - 1e-3 * g)
+        boxes.append([cx + rng.uniform(-3, 3), cy + rng.uniform(-3, 3), h1 * rng.uniform(0.8, 1.6), w1 * rng.uniform(0.3, 1.2),
+                      ang + rng.uniform(60, 90)])
+        scores.append(0.4 - 1e-3 * g)
+    for g in range(12):  # RRPN-like clusters
+        cx, cy = rng.uniform(200, 800, 2)
+        size = rng.uniform(32, 128)
+        for a in range(-90, 90, 30):
+            for ar in (0.125, 0.5, 1.0, 2.0):
+                boxes.append([cx + rng.uniform(-8, 8), cy + rng.uniform(-8, 8), size * np.sqrt(ar) * rng.uniform(0.8, 1.25),
+                              size / np.sqrt(ar) * rng.uniform(0.8, 1.25), a + rng.uniform(-10, 10)])
+                scores.append(rng.uniform(0.0, 0.3))
+    b = np.asarray(boxes, np.float32)
+    s = np.asarray(scores, np.float32)
+    want = oracle.nms_rotated(b, s, thr)
+    got = nms_rotated(torch.from_numpy(b).to(DEV), torch.from_numpy(s).to(DEV), thr).cpu().numpy()
+    assert np.array_equal(got, want)
+    assert 60 < len(want) < len(b)
