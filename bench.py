@@ -586,15 +586,18 @@ def connected_forward(w, run=None, rpn_keys=None, roi_keys=None, sync=False):
     # The binning of the poolers' backward depends on the sampled ROIs alone and CAN be issued here, on the targets / loss
     # branch beside the poolers' forward (PairBackwardPlan): D2AMD_BENCH_PREBIN=1.  Measured at 0.358 ms (same box): 0.3621 /
     # 0.362 with it against 0.3583 / 0.3574 -- both branches already end together, and the backward waits for the longer.
+    # r06 (step 0.324 ms, same box, scripts/r06_prebin_ab.sh): on the targets branch (=1) 0.3339-0.3375; on a THIRD branch
+    # forked beside the two (=2) 0.3278-0.3286; off 0.3226-0.3248 -- the third branch's two graph edges and the phase
+    # split's zero-fill launch cost more than the 25 us of binning they take out of the backward.
     plan = None
-    if w.overlap and bare and os.environ.get("D2AMD_BENCH_PREBIN") == "1" \
-            and os.environ.get("D2AMD_BENCH_POOL_SEPARATE") != "1":
+    prebin = os.environ.get("D2AMD_BENCH_PREBIN", "0")
+    if w.overlap and bare and prebin in ("1", "2") and os.environ.get("D2AMD_BENCH_POOL_SEPARATE") != "1":
         from detectron2_amd.modeling import PairBackwardPlan
 
         plan = PairBackwardPlan()
 
     def targets_and_loss():
-        if plan is not None:
+        if plan is not None and prebin == "1":
             plan.prepare(w.box_pooler, w.mask_pooler, w.feats, samp["rois"], samp["head_rois"])
         idx = [samp["gt_index"][i, :MASK_ROWS].contiguous() for i in range(n)]
         cls = samp["head_classes"].reshape(-1)  # (contiguous: written by the sampler, no copy launch on this branch)
@@ -606,7 +609,12 @@ def connected_forward(w, run=None, rpn_keys=None, roi_keys=None, sync=False):
     # (A/B at 0.355 ms, same box: the ROI half WITHOUT this fork 0.3604 / 0.3607 against 0.3573 / 0.3598 -- its two edges
     # cost ~14 us and the branches slow each other down, for 38 us of overlapped work; targets + loss behind the anchor
     # labelling on that branch's stream instead 0.3553 / 0.3574 against 0.3536 / 0.3534: profiles/r04/LOG.md)
-    if w.overlap and bare:
+    if w.overlap and bare and plan is not None and prebin == "2":  # the binning on a THIRD branch
+        (yb, ym), (loss, stats), _ = fork_join(
+            poolers, targets_and_loss,
+            lambda: plan.prepare(w.box_pooler, w.mask_pooler, w.feats, samp["rois"], samp["head_rois"]), current_first=True)
+        done.join_beside()
+    elif w.overlap and bare:
         (yb, ym), (loss, stats) = fork_join(poolers, targets_and_loss, current_first=True)
         done.join_beside()  # the anchor labels are part of the forward's result
     else:
