@@ -254,7 +254,9 @@ def _distinct_scores(rng, n):
     return (rng.permutation(n).astype(np.float32) + 1) / np.float32(n + 1)
 
 
-@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 127, 1000, 4097])
+# (2176 .. 2305: 34, 35, 36, 37 blocks of 64 -- the reduction's pusher waves hold a whole block of rows up to 35 blocks
+# of a segment (r06) and half blocks beyond; 4097 / 4400: rows with more than 64 later words)
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 127, 1000, 2176, 2239, 2240, 2241, 2305, 4097, 4400])
 def test_nms_bit_exact(n):
     rng = np.random.default_rng(100 + n)
     b, s = _boxes(rng, n), _distinct_scores(rng, n)
