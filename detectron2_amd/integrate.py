@@ -120,7 +120,7 @@ def patch(detectron2=None, models: Iterable = (), layers: bool = True, fused: bo
           only: Optional[Iterable[str]] = None) -> Patched:
     """Bind `detectron2` (default: the imported package) to this library; see the module docstring.  `models`: already
     built models whose ROIPooler instances are converted in place.  `only`: a subset of the fused bindings
-    {"matcher", "pooler", "rpn", "box_inference", "mask_head"} (default: all of them)."""
+    {"matcher", "pooler", "rpn", "box_inference", "mask_head", "dense"} (default: all of them)."""
     want = lambda k: only is None or k in set(only)
     if detectron2 is None:
         import detectron2  # noqa: F811
@@ -273,6 +273,37 @@ def patch(detectron2=None, models: Iterable = (), layers: bool = True, fused: bo
     if want("mask_head"):
         _rebind_everywhere(h, pkg, "mask_rcnn_loss", ref_loss, mask_rcnn_loss)
         _rebind_everywhere(h, pkg, "mask_rcnn_inference", mh.mask_rcnn_inference, M.mask_rcnn_inference)
+
+    # ---- RetinaNet inference: per-level threshold + top-k + decode and the per-class NMS of the batch in one device
+    # pipeline (retinanet.py:257-309, dense_detector.py:186-260: a Python loop over images x levels with a nonzero / topk /
+    # index chain and one batched_nms per image)
+    try:
+        rn = imp("modeling.meta_arch.retinanet")
+    except ImportError:  # (a trimmed package without the dense detectors)
+        rn = None
+    if rn is not None and want("dense"):
+        ref_forward_inference = rn.RetinaNet.forward_inference
+
+        def forward_inference(self, images, features, predictions):
+            tr = self.box2box_transform
+            if type(tr).__name__ != "Box2BoxTransform" or len(features) == 0 or not features[0].is_cuda:
+                return ref_forward_inference(self, images, features, predictions)
+            pred_logits, pred_anchor_deltas = self._transpose_dense_predictions(predictions, [self.num_classes, 4])
+            anchors = self.anchor_generator(features)
+            dets = M.dense_detector_inference_fused(
+                [a.tensor for a in anchors], pred_logits, pred_anchor_deltas, [tuple(sz) for sz in images.image_sizes],
+                self.test_score_thresh, self.test_topk_candidates, self.test_nms_thresh, self.max_detections_per_image,
+                weights=tuple(tr.weights), scale_clamp=tr.scale_clamp)
+            out = []
+            for d in dets:
+                res = Instances(tuple(d.image_size))
+                res.pred_boxes = D2Boxes(d.pred_boxes.tensor)
+                res.scores = d.scores
+                res.pred_classes = d.pred_classes
+                out.append(res)
+            return out
+
+        h._set(rn.RetinaNet, "forward_inference", forward_inference)
 
     if samplers:
         smp = imp("modeling.sampling")

@@ -168,6 +168,18 @@ def test_retinanet_r50_fpn_identical_inputs():
         assert torch.equal(a.pred_classes, b.pred_classes)
         assert torch.equal(a.pred_boxes.tensor, b.pred_boxes.tensor) and torch.equal(a.scores, b.scores)
         lines.append("inference: %d detections, boxes / scores / classes bit-equal (batched_nms over 80 classes)" % len(a))
+    # r06: the FUSED dense-detector inference bound into the model (integrate.patch "dense": RetinaNet.forward_inference ->
+    # dense_detector_inference_fused): the same detections -- classes equal, boxes / scores to fp32 rounding of the decode
+    # and the sigmoid (the fused selection ranks by the logits and evaluates the score once per selected row)
+    iq = _infer_pass(rm, model, inputs, "product_fused")
+    for a, b in zip(iq, ir):
+        assert len(a) == len(b), (len(a), len(b))
+        assert torch.equal(a.pred_classes, b.pred_classes)
+        db = float((a.pred_boxes.tensor - b.pred_boxes.tensor).abs().max())
+        ds = float((a.scores - b.scores).abs().max())
+        lines.append("inference, fused dense detector: %d detections, classes equal, max |d box| %.2e px, max |d score| %.2e"
+                     % (len(a), db, ds))
+        assert db <= 1e-3 and ds <= 1e-6, (db, ds)
     _report("RetinaNet R50-FPN, 2 x 640x800", lines)
 
 
