@@ -545,7 +545,7 @@ def connected_forward(w, run=None, rpn_keys=None, roi_keys=None, sync=False):
 
         # (forking this branch at the very START of the step instead was measured -- D2AMD_BENCH_FORK experiments,
         # gpurun_out/r3z*: 0.465-0.48 against 0.458 ms; the branch the graph does not launch on starts ~10 us late, and
-        # the matcher slows the selection's latency-bound chain)
+        # the matcher slows the selection's latency-bound chain; r06 at 0.325 ms, same box: 0.3277-0.3281 against 0.3229-0.3266)
         done = find_top_rpn_proposals_fused(w.anchor_levels, w.rpn_logits, w.rpn_deltas, w.image_sizes, 0.7, 2000, 1000,
                                             0.0, True, defer=True, beside_nms=side, join_beside=False,
                                             host_result=sync)
