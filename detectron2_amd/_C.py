@@ -139,6 +139,7 @@ _SIGNATURES = {
     "d2amd_bitmask_crop_and_resize": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "d2amd_bitmask_crop_and_resize_indexed": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "d2amd_transpose_batched": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "d2amd_transpose_multi": (_i, [_vp, _vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), _i, _i, _i, _vp]),
     "d2amd_polygon_crop_and_resize": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "d2amd_bitmask_crop_and_resize_batch": (_i, [_i, ctypes.POINTER(_vp), ctypes.POINTER(_i), ctypes.POINTER(_vp),
                                                  ctypes.POINTER(_vp), ctypes.POINTER(_i), _i, _i, _i, _vp, _vp, _vp]),

@@ -138,7 +138,69 @@ def _to_nchw(t):
     return t.contiguous()
 
 
+def _transpose_many(pairs, nhwc_to_nchw: bool):
+    """[(src, dst)] 4-D tensors of one batch size / dtype / device, NCHW -> NHWC (or back) in ONE launch
+    (d2amd_transpose_multi, <= 8 tensors per launch)."""
+    for i in range(0, len(pairs), 8):
+        chunk = pairs[i:i + 8]
+        k = len(chunk)
+        srcs, dsts = (ctypes.c_void_p * k)(), (ctypes.c_void_p * k)()
+        rows, cols = (ctypes.c_int * k)(), (ctypes.c_int * k)()
+        for j, (a, b) in enumerate(chunk):
+            n, c, h, w = a.shape
+            srcs[j], dsts[j] = a.data_ptr(), b.data_ptr()
+            rows[j], cols[j] = (h * w, c) if nhwc_to_nchw else (c, h * w)
+        a0 = chunk[0][0]
+        with _C.on_device(a0.device):
+            _C.check(_C.lib().d2amd_transpose_multi(srcs, dsts, rows, cols, k, int(a0.shape[0]), a0.element_size(), _C.stream()))
+
+
+def _batchable(ts):
+    t0 = ts[0]
+    return all(t.dim() == 4 and t.is_cuda and t.dtype == t0.dtype and t.device == t0.device and t.shape[0] == t0.shape[0]
+               and t.element_size() in (2, 4) and t.numel() and not t.requires_grad for t in ts)
+
+
+def _to_nchw_many(ts):
+    """_to_nchw of every tensor of the list; the channels_last ones of a batchable list in one launch."""
+    todo = [i for i, t in enumerate(ts) if t is not None and t.dim() == 4 and not t.is_contiguous()
+            and t.is_contiguous(memory_format=torch.channels_last)]
+    if len(todo) < 2 or not _batchable([ts[i] for i in todo]):
+        return [None if t is None else _to_nchw(t) for t in ts]
+    out = [None if t is None else t for t in ts]
+    pairs = []
+    for i in todo:
+        out[i] = torch.empty(ts[i].shape, dtype=ts[i].dtype, device=ts[i].device)
+        pairs.append((ts[i], out[i]))
+    _transpose_many(pairs, True)
+    return [None if t is None else (t if i in todo else _to_nchw(t)) for i, t in enumerate(out)]
+
+
 _NHWC_CACHE = {}  # id(feature tensor) -> (weakref, version, channels_last copy)
+
+
+def _staged_nhwc_many(feats):
+    """_staged_nhwc of every feature map; the copies that are not cached yet are made by ONE launch."""
+    import weakref
+    bases = [f._base if f._base is not None and f._base.shape == f.shape and f._base.stride() == f.stride() else f for f in feats]
+    hit = []
+    for b in bases:
+        ent = _NHWC_CACHE.get(id(b))
+        hit.append(ent[2] if ent is not None and ent[0]() is b and ent[1] == b._version else None)
+    miss = [i for i, h in enumerate(hit) if h is None]
+    srcs = [feats[i].detach() for i in miss]
+    if len(miss) < 2 or not (_batchable(srcs) and all(t.is_contiguous() for t in srcs)):
+        return [_staged_nhwc(f) for f in feats]
+    pairs = [(t, torch.empty_like(t, memory_format=torch.channels_last)) for t in srcs]
+    _transpose_many(pairs, False)
+    for k in [k for k, e in _NHWC_CACHE.items() if e[0]() is None]:
+        del _NHWC_CACHE[k]
+    if len(_NHWC_CACHE) + len(miss) > 16:
+        _NHWC_CACHE.clear()
+    for i, (_, cl) in zip(miss, pairs):
+        _NHWC_CACHE[id(bases[i])] = (weakref.ref(bases[i]), bases[i]._version, cl)
+        hit[i] = cl
+    return hit
 
 
 def _staged_nhwc(f):
@@ -265,7 +327,7 @@ class _FusedROIPool(Function):
             # 5x slower (profiles/r01).  For 16-bit NCHW features the forward therefore stages a channels_last
             # copy (one pass over the features, shared by the poolers of an iteration) and returns an NCHW
             # result, like the backward already does for the gradients.  fp32 keeps the dedicated NCHW kernel.
-            feats_used, layout = [_staged_nhwc(f) for f in feats], _C.NHWC
+            feats_used, layout = _staged_nhwc_many(list(feats)), _C.NHWC
         else:
             feats_used = feats
         xs = [f if layout == _C.NHWC else f.contiguous() for f in feats_used]
@@ -456,6 +518,9 @@ class _FusedROIPool(Function):
                     _C.check(rc)
         if grads is None:
             return (None, None, None, None, None) + (None,) * len(hw)
+        if ctx.nchw_caller:  # (all levels' gradients back to the caller's layout in one launch)
+            res = _to_nchw_many([g if need else None for g, need in zip(grads, ctx.needs)])
+            return (None, None, None, None, None) + tuple(res)
         return (None, None, None, None, None) + tuple(back(g) if need else None for g, need in zip(grads, ctx.needs))
 
 

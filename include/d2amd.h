@@ -61,6 +61,10 @@ int d2amd_timing_read(const char* kernel, double* total_ms, int* launches);
  * unmodified (NCHW) model's feature maps, pooled results and gradients in and out of the NHWC kernels; the reference
  * has no counterpart (torchvision's ops are NCHW throughout). */
 int d2amd_transpose_batched(const void* src, void* dst, int batch, int rows, int cols, int element_size, void* stream);
+/* The same for up to 8 tensors of one batch size and element size in ONE launch (the FPN levels of an NCHW model on the
+ * way in, their gradients on the way out): src[t] [batch][rows[t]][cols[t]] -> dst[t] [batch][cols[t]][rows[t]]. */
+int d2amd_transpose_multi(const void* const* src, void* const* dst, const int* rows, const int* cols, int count, int batch,
+                          int element_size, void* stream);
 
 /* ---- ROIAlign (axis-aligned).  Replaces torchvision.ops.roi_align as called from
  * detectron2/layers/roi_align.py:58-65 (forward) and its autograd backward.

@@ -390,6 +390,17 @@ def test_transpose_entry_and_nchw_callers_get_nchw_back(dtype):
         assert torch.equal(cl.permute(0, 2, 3, 1).contiguous(), t.permute(0, 2, 3, 1).contiguous())
         back = _to_nchw(cl)
         assert back.is_contiguous() and torch.equal(back, t)
+    # r06, d2amd_transpose_multi: several tensors of one batch size in one launch (the FPN levels on the way in, their
+    # gradients on the way out), odd sizes included
+    from detectron2_amd.modeling.poolers import _staged_nhwc_many, _to_nchw_many
+
+    lv = [torch.randn(sh, device=DEV).to(dtype) for sh in [(2, 64, 50, 84), (2, 64, 25, 42), (2, 64, 13, 21), (2, 64, 7, 11),
+                                                            (2, 64, 1, 3)]]
+    st = _staged_nhwc_many(lv)
+    assert all(c.is_contiguous(memory_format=torch.channels_last) and torch.equal(c, t) for c, t in zip(st, lv))
+    assert all(a is b for a, b in zip(_staged_nhwc_many(lv), st))  # (cached: the same copies for the second pooler)
+    bk = _to_nchw_many(st + [None])
+    assert bk[-1] is None and all(b.is_contiguous() and torch.equal(b, t) for b, t in zip(bk, lv))
     rng = np.random.default_rng(12)
     feats, boxes = make_inputs(rng, 2, 32, 96, 128, 20)
     pooler = ROIPooler(7, SCALES, 0, "ROIAlignV2")
