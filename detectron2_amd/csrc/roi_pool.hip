@@ -152,7 +152,7 @@ __device__ __forceinline__ int fwd_roi_of(const PoolLevels& L, int b, int K) {
 // launch ends with a quarter of the chip waiting for its largest ROIs (1,024 workgroups, all resident at once: mean
 // 21.9 us, longest 37.7), the mask head's workgroups fill those slots instead of starting behind the last one.
 template <typename T> struct PoolFwdPair { const float* rois2; T* out2; int K1, ns1, K2, ns2, PH2, PW2; };
-template <typename T, int VEC, int NTHR, int U = FWD_U, int WPE = 1>
+template <typename T, int VEC, int NTHR, int U = FWD_U, int WPE = 1, bool PIPE = false>
 __global__ __launch_bounds__(NTHR, WPE) void pool_fwd_nhwc_kernel(PoolLevels L, const float* __restrict__ rois_,
                                                                  T* __restrict__ out_, int nsplit_, PoolFwdPair<T> P) {
   __shared__ SepShared S;
@@ -244,6 +244,43 @@ __global__ __launch_bounds__(NTHR, WPE) void pool_fwd_nhwc_kernel(PoolLevels L, 
         float acc[VEC];
 #pragma unroll
         for (int c = 0; c < VEC; c++) acc[c] = 0.f;
+        if constexpr (PIPE) {
+        // r06: the NEXT round's U loads are requested before this round's are consumed (two register sets, the same sequence
+        // of additions: bit-identical).  Stand-alone the paired launch is 1 us slower with it (52.1 against 51.2 us), inside the
+        // connected step -- beside the targets branch -- the step is 5 us shorter (0.3185-0.3192 against 0.3228-0.3277 ms,
+        // same box; U = 6 at two workgroups per CU: 58 us alone, 0.318-0.322 in the step; U = 2 / 3 at four: no gain).  The single
+        // poolers of the inference step gain nothing from it (maskrcnn_infer 0.381-0.384 against 0.384-0.387): PIPE is the
+        // paired launch's only.
+        auto ld = [&](int t0, raw16 (&raw)[U], float (&w)[U]) {
+#pragma unroll
+          for (int u = 0; u < U; u++) {
+            const int t = t0 + u;
+            const uint2 tp = tab[min(t, nt - 1)];
+            w[u] = t < nt ? __uint_as_float(tp.y) : 0.f;
+            raw[u] = *reinterpret_cast<const raw16*>(base + tp.x);
+          }
+        };
+        auto mac = [&](const raw16 (&raw)[U], const float (&w)[U]) {
+#pragma unroll
+          for (int u = 0; u < U; u++) {
+            float f[VEC];
+            unpack16(raw[u], f, T{});
+#pragma unroll
+            for (int c = 0; c < VEC; c++) acc[c] += w[u] * f[c];
+          }
+        };
+        raw16 ra[U], rb[U];
+        float wa[U], wb[U];
+        if (nt > 0) ld(0, ra, wa);
+        for (int t0 = 0; t0 < nt; t0 += 2 * U) {
+          if (t0 + U < nt) ld(t0 + U, rb, wb);
+          mac(ra, wa);
+          if (t0 + U < nt) {
+            if (t0 + 2 * U < nt) ld(t0 + 2 * U, ra, wa);
+            mac(rb, wb);
+          }
+        }
+        } else {
         for (int t0 = 0; t0 < nt; t0 += U) {
           raw16 raw[U];
           float w[U];
@@ -261,6 +298,7 @@ __global__ __launch_bounds__(NTHR, WPE) void pool_fwd_nhwc_kernel(PoolLevels L, 
 #pragma unroll
             for (int c = 0; c < VEC; c++) acc[c] += w[u] * f[c];
           }
+        }
         }
         *reinterpret_cast<raw16*>(outk + (long)b * C + (long)q * VEC) = pack16(acc, T{});
       }
@@ -2349,7 +2387,7 @@ static int pool_fwd_impl(const d2amd_pooler_params* p, const void* const* inputs
       if (wide)
         hipLaunchKernelGGL((pool_fwd_nhwc_kernel<T, VEC, 512>), grid, dim3(512), 0, s, Lf, rois, (T*)output, nsplit, PoolFwdPair<T>{});
       else
-        hipLaunchKernelGGL((pool_fwd_nhwc_kernel<T, VEC, 512, 4, 6>), grid, dim3(512), 0, s, Lf, rois, (T*)output, nsplit, P2);
+        hipLaunchKernelGGL((pool_fwd_nhwc_kernel<T, VEC, 512, 4, 6, true>), grid, dim3(512), 0, s, Lf, rois, (T*)output, nsplit, P2);
     }
     else if (vec)
       hipLaunchKernelGGL((pool_fwd_nhwc_kernel<T, VEC, 256>), grid, dim3(256), 0, s, Lf, rois, (T*)output, nsplit, PoolFwdPair<T>{});
