@@ -496,7 +496,12 @@ def anchor_labels(w, keys=None):
     device.  -> (labels [N, A] int8 in {-1, 0, 1}, matched ground-truth index [N, A], counts [N, 2])"""
     from detectron2_amd.modeling import subsample_anchor_labels_
 
+    ab = os.environ.get("D2AMD_BENCH_ABLATE", "")  # (sensitivity experiments only: the step then computes LESS)
+    if "anchors" in ab:
+        return None, None, None
     matches, labels = w.anchor_matcher.match_boxes_batch(w.gt, w.anchors)
+    if "subsample" in ab:
+        return labels, matches, None
     labels, counts = subsample_anchor_labels_(labels, RPN_BATCH, RPN_POS_FRACTION, keys=keys)
     return labels, matches, counts
 
@@ -601,7 +606,11 @@ def connected_forward(w, run=None, rpn_keys=None, roi_keys=None, sync=False):
             plan.prepare(w.box_pooler, w.mask_pooler, w.feats, samp["rois"], samp["head_rois"])
         idx = [samp["gt_index"][i, :MASK_ROWS].contiguous() for i in range(n)]
         cls = samp["head_classes"].reshape(-1)  # (contiguous: written by the sampler, no copy launch on this branch)
-        tg = run("mask_targets", lambda: crop_and_resize_batch(w.gt_masks, mask_boxes, 28, idx, w.crop_status))
+        if "crop" in os.environ.get("D2AMD_BENCH_ABLATE", ""):  # (sensitivity experiment: constant targets)
+            tg = w._abl_tg if hasattr(w, "_abl_tg") else crop_and_resize_batch(w.gt_masks, mask_boxes, 28, idx, w.crop_status)
+            w._abl_tg = tg
+        else:
+            tg = run("mask_targets", lambda: crop_and_resize_batch(w.gt_masks, mask_boxes, 28, idx, w.crop_status))
         # background / padding rows among the 128 do not count (class 80 / -1): masked loss, row count on the device
         return run("mask_loss_fwd", lambda: mask_rcnn_loss_from_targets(w.mask_logits, cls, tg,
                                                                         ignore_invalid_rows=True))

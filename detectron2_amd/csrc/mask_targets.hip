@@ -45,7 +45,13 @@ __device__ __forceinline__ float crop_sample(const uint8_t* __restrict__ m, int 
 // Tier 2 (a mean within ~1e-4 of 0.5, or a band too large for the LDS tables): the workgroup produces the bin's
 // sample VALUES 256 at a time and one thread adds them in the reference's order (iy outer, ix inner, then / count).
 // The result is bit-identical to the sequential evaluation for every input.
-constexpr int CROP_THREADS = 256;
+// Workgroup size.  A (box, bin row) is a chain of dependent steps (index -> box -> tables -> band -> bins) whose widest one
+// uses ~100-200 threads (the band's columns): with 256-thread workgroups the 7,168 of a step's 256 boxes ran in 3.5 rounds
+// of 8 per CU.  MEASURED (r06, same box): 256 threads 26.2 us alone / connected step 0.3156-0.3181 ms | 128: 17.5 us /
+// 0.3065-0.3106 | 64: 19.1 us / 0.3131-0.3164.  (Several bin rows per workgroup -- the prologue once -- was worse: 2 rows
+// 29 against 31 us alone, 4 rows 34, 7 rows 50.)
+constexpr int CROP_THREADS = 128;
+constexpr int CROP_LPB = CROP_THREADS / 64;  // lanes per bin in tier 1 (64 bins per row at most)
 constexpr int CROP_MAX_IMAGES = 64;
 constexpr int CROP_ROWS = 64;    // pixel rows of a bin row's band the Wy table holds
 constexpr int CROP_COLS = 2048;  // pixel columns of the band the CS table holds
@@ -155,18 +161,18 @@ __global__ __launch_bounds__(CROP_THREADS) void bitmask_crop_kernel(CropBatch B,
       s_cs[c] = acc;
     }
     __syncthreads();
-    // bins: 4 lanes per bin (64 bins max), each lane takes every 4th column sample
-    const int pw = tid >> 2, sub = tid & 3;
+    // bins: CROP_LPB lanes per bin (64 bins max), each lane takes every CROP_LPB-th column sample
+    const int pw = tid / CROP_LPB, sub = tid % CROP_LPB;
     float part = 0.f;
     if (pw < M) {
       const float x_base = roi_start_w + (float)pw * bin_size_w;
-      for (int ix = sub; ix < grid_w; ix += 4) {
+      for (int ix = sub; ix < grid_w; ix += CROP_LPB) {
         const CropAxis a = crop_axis(x_base + ((float)ix + .5f) * bin_size_w / (float)grid_w, W);
         if (a.in) part += a.wlo * s_cs[a.lo - c0] + a.whi * s_cs[a.hi - c0];
       }
     }
-    part += __shfl_xor(part, 1, 64);
-    part += __shfl_xor(part, 2, 64);
+#pragma unroll
+    for (int d = 1; d < CROP_LPB; d <<= 1) part += __shfl_xor(part, d, 64);
     if (pw < M && sub == 0) {
       const float approx = part / count;
       const float tol = (float)(2 * ni + 4 * (grid_h + grid_w) + 16) * 1.2e-7f + 1e-6f;  // 2 x the bound, + the divide
