@@ -248,9 +248,9 @@ __global__ __launch_bounds__(NTHR, WPE) void pool_fwd_nhwc_kernel(PoolLevels L, 
         // r06: the NEXT round's U loads are requested before this round's are consumed (two register sets, the same sequence
         // of additions: bit-identical).  Stand-alone the paired launch is 1 us slower with it (52.1 against 51.2 us), inside the
         // connected step -- beside the targets branch -- the step is 5 us shorter (0.3185-0.3192 against 0.3228-0.3277 ms,
-        // same box; U = 6 at two workgroups per CU: 58 us alone, 0.318-0.322 in the step; U = 2 / 3 at four: no gain).  The single
-        // poolers of the inference step gain nothing from it (maskrcnn_infer 0.381-0.384 against 0.384-0.387): PIPE is the
-        // paired launch's only.
+        // same box; U = 6 at two workgroups per CU: 58 us alone, 0.318-0.322 in the step; U = 2 / 3 at four: no gain).  PIPE is on
+        // for the 512-thread shape (the paired launch and single poolers of >= ~1,000 workgroups); the 1,024- / 256-thread
+        // shapes of small launches gain nothing from it (maskrcnn_infer 0.384-0.387 with it against 0.381-0.384).
         auto ld = [&](int t0, raw16 (&raw)[U], float (&w)[U]) {
 #pragma unroll
           for (int u = 0; u < U; u++) {
