@@ -92,6 +92,8 @@ _SIGNATURES = {
     "d2amd_roi_pooler_backward_pair_workspace_bytes": (_sz, [ctypes.POINTER(PoolerParams), _i, _i]),
     "d2amd_roi_pooler_backward_pair": (_i, [ctypes.POINTER(PoolerParams), _vp, _vp, _i, ctypes.POINTER(PoolerParams), _vp,
                                             _vp, _i, ctypes.POINTER(_vp), _vp, _sz, _vp]),
+    "d2amd_roi_pooler_forward_pair_records": (_i, [ctypes.POINTER(PoolerParams), ctypes.POINTER(_vp), _vp, _vp, _i, ctypes.POINTER(PoolerParams),
+                                                   _vp, _vp, _i, _vp, _sz, ctypes.POINTER(ctypes.c_int), _vp]),
     "d2amd_roi_pooler_backward_pair_phase": (_i, [ctypes.POINTER(PoolerParams), _vp, _vp, _i, ctypes.POINTER(PoolerParams),
                                                   _vp, _vp, _i, ctypes.POINTER(_vp), _vp, _sz, _i, _vp]),
     "d2amd_roi_pooler_backward_phase": (_i, [ctypes.POINTER(PoolerParams), _vp, _vp, ctypes.POINTER(_vp), _i, _vp, _sz,

@@ -145,13 +145,64 @@ __device__ __forceinline__ int fwd_roi_of(const PoolLevels& L, int b, int K) {
   return L.perm[(((t >> 4) << 3) + x) * 16 + (t & 15)];
 }
 
+// Per-ROI record written once per backward call by roi_records_kernel: what a tile workgroup needs
+// to decide "does this ROI touch my tile" with a few integer compares (the first versions evaluated
+// the whole geometry -- two IEEE divisions, sqrt, log2 -- per candidate and per tile: ~6k cycles of
+// every workgroup), plus the geometry the weights need.
+struct HitGeo { float start_h, start_w, bin_h, bin_w, inv; int grid; };  // grid = grid_h | grid_w << 16
+// global tile id (numbering of tile_lists_kernel) of the first tile of each level in this launch
+struct PoolTileIds { int first[POOL_MAX_LEVELS]; };
+struct RoiRec {
+  int level, batch;        // level = -1: contributes nothing (no level, empty sampling grid, outside)
+  int fy0, fy1, fx0, fx1;  // conservative pixel rectangle [fy0, fy1] x [fx0, fx1] that can receive gradient
+  HitGeo g;
+};  // 48 bytes
+
+// conservative footprint rectangle of an ROI on its level; false if it cannot contribute
+__device__ __forceinline__ bool footprint_rect(const RoiGeom& g, int H, int W, int& fy0, int& fy1, int& fx0,
+                                               int& fx1) {
+  if (g.grid_h <= 0 || g.grid_w <= 0) return false;
+  // samples lie strictly inside (start, start + roi) -- or (start + roi, start) for an inverted ROI (x2 < x1 with
+  // aligned = True and sampling_ratio > 0: negative bin size, the forward still samples there); valid ones in
+  // [-1, size]; pixels touched are floor(max(s, 0)) and +1, clamped to size - 1
+  const float y_a = fminf(g.start_h, g.start_h + g.roi_h), yhi = fmaxf(g.start_h, g.start_h + g.roi_h);
+  const float x_a = fminf(g.start_w, g.start_w + g.roi_w), xhi = fmaxf(g.start_w, g.start_w + g.roi_w);
+  const float ylo = fmaxf(y_a, 0.f), xlo = fmaxf(x_a, 0.f);
+  if (!(yhi >= -1.f && y_a <= (float)H && xhi >= -1.f && x_a <= (float)W)) return false;  // also NaN
+  fy0 = (int)fminf(ylo, 1e9f); fy1 = min((int)fminf(fmaxf(yhi, 0.f), 1e9f) + 1, H - 1);
+  fx0 = (int)fminf(xlo, 1e9f); fx1 = min((int)fminf(fmaxf(xhi, 0.f), 1e9f) + 1, W - 1);
+  return true;
+}
+
+// the record of one ROI (roi_records_kernel; r06: also written by the paired forward's workgroups, see PoolFwdPair)
+__device__ __forceinline__ RoiRec make_roi_rec(const PoolLevels& L, const float* __restrict__ r, int PH, int PW) {
+  RoiRec o{};
+  o.level = -1;
+  o.batch = (int)r[0];
+  const int lvl = assign_level(r + 1, L);
+  if (lvl >= 0) {
+    const RoiGeom g = roi_geom_box(r[0], r[1], r[2], r[3], r[4], L.scale[lvl], PH, PW, L.sr, L.aligned);
+    if (footprint_rect(g, L.H[lvl], L.W[lvl], o.fy0, o.fy1, o.fx0, o.fx1)) {
+      o.level = lvl;
+      o.g = HitGeo{g.start_h, g.start_w, g.bin_h, g.bin_w, 1.f / (float)(g.grid_h * g.grid_w),
+                   (g.grid_h & 0xffff) | (g.grid_w << 16)};
+    }
+  }
+  return o;
+}
+
 // ------------------------------------------------------------------------------------------------
 // FORWARD, NHWC.  grid = (K, nsplit); VEC = 16 B of channels per lane (or 1 for odd C / alignment)
 // PAIRED launch (d2amd_roi_pooler_forward_pair; P.rois2 != nullptr, grid = K1 * ns1 + K2 * ns2 workgroups in x): the
 // workgroups of a SECOND pooler of the same feature maps follow the first one's in the same grid -- the box head's
 // launch ends with a quarter of the chip waiting for its largest ROIs (1,024 workgroups, all resident at once: mean
 // 21.9 us, longest 37.7), the mask head's workgroups fill those slots instead of starting behind the last one.
-template <typename T> struct PoolFwdPair { const float* rois2; T* out2; int K1, ns1, K2, ns2, PH2, PW2; };
+// r06, rec != nullptr: the launch ALSO does what roi_records_kernel does for the paired backward of the same ROIs -- the
+// first workgroup of an ROI writes its record (records [0, K1): the first pooler's, then the second one's), all workgroups
+// together reset the backward's work queues -- into the backward's workspace, which the caller allocated ahead
+// (d2amd_roi_pooler_forward_pair_records): the backward then starts with its tile lists, 7.6 us + a dependency edge earlier.
+template <typename T> struct PoolFwdPair { const float* rois2; T* out2; int K1, ns1, K2, ns2, PH2, PW2;
+                                           RoiRec* rec; int* qmem; int qzero, qints; };
 template <typename T, int VEC, int NTHR, int U = FWD_U, int WPE = 1, bool PIPE = false>
 __global__ __launch_bounds__(NTHR, WPE) void pool_fwd_nhwc_kernel(PoolLevels L, const float* __restrict__ rois_,
                                                                  T* __restrict__ out_, int nsplit_, PoolFwdPair<T> P) {
@@ -160,6 +211,7 @@ __global__ __launch_bounds__(NTHR, WPE) void pool_fwd_nhwc_kernel(PoolLevels L, 
   const float* rois = rois_;
   T* out = out_;
   int nsplit = nsplit_, bx = (int)blockIdx.x, by = (int)blockIdx.y, gx = (int)gridDim.x, PH = L.PH, PW = L.PW;
+  bool second = false;
   if (P.rois2) {  // uniform
     const int n1 = P.K1 * P.ns1;
     if (bx < n1) {
@@ -167,9 +219,14 @@ __global__ __launch_bounds__(NTHR, WPE) void pool_fwd_nhwc_kernel(PoolLevels L, 
     } else {
       bx -= n1; by = bx / P.K2; bx -= by * P.K2; gx = P.K2; nsplit = P.ns2;
       rois = P.rois2; out = P.out2; PH = P.PH2; PW = P.PW2;
+      second = true;
     }
   }
   const int k = fwd_roi_of(L, bx, gx), tid = threadIdx.x;
+  if (P.rec) {  // uniform (paired launch only: perm == nullptr, k == bx)
+    for (int i = (int)blockIdx.x * NTHR + tid; i < P.qints; i += (int)gridDim.x * NTHR) P.qmem[i] = i < P.qzero ? 0 : -1;
+    if (by == 0 && tid == 0) P.rec[(second ? P.K1 : 0) + k] = make_roi_rec(L, rois + (long)k * 5, PH, PW);
+  }
   unsigned long long* wst = (L.wgstamps && tid == 0) ? L.wgstamps + 5 * ((size_t)by * gx + k) : nullptr;
   if (wst) wst[0] = wall_clock64();
   // every thread evaluates the (wave-uniform) level itself: one broadcast load, no LDS round trip / barrier
@@ -475,19 +532,6 @@ constexpr int SCR_PER_XCD_MAX = 96;  // scratch slots per XCD queue (64 px x C f
 constexpr int SPLIT_MAX_SLABS = 4;   // channel slabs (of 256 channels, 16-bit) a split tile may have: one ticket each
 constexpr int QTICKETS = 8 * SCR_PER_XCD_MAX * SPLIT_MAX_SLABS;
 
-// Per-ROI record written once per backward call by roi_records_kernel: what a tile workgroup needs
-// to decide "does this ROI touch my tile" with a few integer compares (the first versions evaluated
-// the whole geometry -- two IEEE divisions, sqrt, log2 -- per candidate and per tile: ~6k cycles of
-// every workgroup), plus the geometry the weights need.
-struct HitGeo { float start_h, start_w, bin_h, bin_w, inv; int grid; };  // grid = grid_h | grid_w << 16
-// global tile id (numbering of tile_lists_kernel) of the first tile of each level in this launch
-struct PoolTileIds { int first[POOL_MAX_LEVELS]; };
-struct RoiRec {
-  int level, batch;        // level = -1: contributes nothing (no level, empty sampling grid, outside)
-  int fy0, fy1, fx0, fx1;  // conservative pixel rectangle [fy0, fy1] x [fx0, fx1] that can receive gradient
-  HitGeo g;
-};  // 48 bytes
-
 template <int GROUPS>
 struct TileShared {
   int list[LCH];
@@ -497,22 +541,6 @@ struct TileShared {
   uint32_t ymask[GROUPS][2][TILE], xmask[GROUPS][2][TILE];
   int wave_cnt[LCH / 64];
 };
-
-// conservative footprint rectangle of an ROI on its level; false if it cannot contribute
-__device__ __forceinline__ bool footprint_rect(const RoiGeom& g, int H, int W, int& fy0, int& fy1, int& fx0,
-                                               int& fx1) {
-  if (g.grid_h <= 0 || g.grid_w <= 0) return false;
-  // samples lie strictly inside (start, start + roi) -- or (start + roi, start) for an inverted ROI (x2 < x1 with
-  // aligned = True and sampling_ratio > 0: negative bin size, the forward still samples there); valid ones in
-  // [-1, size]; pixels touched are floor(max(s, 0)) and +1, clamped to size - 1
-  const float y_a = fminf(g.start_h, g.start_h + g.roi_h), yhi = fmaxf(g.start_h, g.start_h + g.roi_h);
-  const float x_a = fminf(g.start_w, g.start_w + g.roi_w), xhi = fmaxf(g.start_w, g.start_w + g.roi_w);
-  const float ylo = fmaxf(y_a, 0.f), xlo = fmaxf(x_a, 0.f);
-  if (!(yhi >= -1.f && y_a <= (float)H && xhi >= -1.f && x_a <= (float)W)) return false;  // also NaN
-  fy0 = (int)fminf(ylo, 1e9f); fy1 = min((int)fminf(fmaxf(yhi, 0.f), 1e9f) + 1, H - 1);
-  fx0 = (int)fminf(xlo, 1e9f); fx1 = min((int)fminf(fmaxf(xhi, 0.f), 1e9f) + 1, W - 1);
-  return true;
-}
 
 // A SECOND pooler binned together with the first one (d2amd_roi_pooler_backward_pair): records [K1, L.K) are its ROIs,
 // evaluated with its pooled size (same feature maps, level rule, sampling ratio and alignment: checked by the host).
@@ -526,19 +554,7 @@ __global__ void roi_records_kernel(PoolLevels L, const float* __restrict__ rois,
   const bool second = B.rois2 != nullptr && k >= B.K1;
   const float* r = second ? B.rois2 + (long)(k - B.K1) * 5 : rois + (long)k * 5;
   const int PH = second ? B.PH2 : L.PH, PW = second ? B.PW2 : L.PW;
-  RoiRec o{};
-  o.level = -1;
-  o.batch = (int)r[0];
-  const int lvl = assign_level(r + 1, L);
-  if (lvl >= 0) {
-    const RoiGeom g = roi_geom_box(r[0], r[1], r[2], r[3], r[4], L.scale[lvl], PH, PW, L.sr, L.aligned);
-    if (footprint_rect(g, L.H[lvl], L.W[lvl], o.fy0, o.fy1, o.fx0, o.fx1)) {
-      o.level = lvl;
-      o.g = HitGeo{g.start_h, g.start_w, g.bin_h, g.bin_w, 1.f / (float)(g.grid_h * g.grid_w),
-                   (g.grid_h & 0xffff) | (g.grid_w << 16)};
-    }
-  }
-  rec[k] = o;
+  rec[k] = make_roi_rec(L, r, PH, PW);
 }
 
 // Per-tile ROI lists, built once per backward call by one WAVE per tile: the 64 lanes test 64 records at
@@ -2314,7 +2330,9 @@ static bool pooler_fused_ok(const d2amd_pooler_params* p) { return p->pooled_h <
 
 // (pair: a second pooler of the same feature maps in the same launch -- the NHWC 16-B vector kernel only, else
 // EUNSUPPORTED with nothing launched)
-struct PoolFwdPairCall { const d2amd_pooler_params* p2; const float* rois2; void* out2; int K2; };
+// where the backward keeps its records and its queue words (pool_bwd_nhwc_impl, phase 4, fills it: no launch)
+struct PoolRecPlan { RoiRec* rec; int* qmem; int qzero, qints; };
+struct PoolFwdPairCall { const d2amd_pooler_params* p2; const float* rois2; void* out2; int K2; const PoolRecPlan* plan; };
 template <typename T>
 static int pool_fwd_impl(const d2amd_pooler_params* p, const void* const* inputs, const float* rois, void* output,
                          int K, hipStream_t s, const int* perm = nullptr, const PoolFwdPairCall* pair = nullptr) {
@@ -2359,7 +2377,9 @@ static int pool_fwd_impl(const d2amd_pooler_params* p, const void* const* inputs
       if (ns2 > bins2) ns2 = bins2;
       const long total = (long)K * nsplit + (long)pair->K2 * ns2;
       D2_CHECK_ARG(total < (1l << 30), "roi_pooler_forward_pair: too many workgroups");
-      P2 = PoolFwdPair<T>{pair->rois2, (T*)pair->out2, K, nsplit, pair->K2, ns2, pair->p2->pooled_h, pair->p2->pooled_w};
+      P2 = PoolFwdPair<T>{pair->rois2, (T*)pair->out2, K, nsplit, pair->K2, ns2, pair->p2->pooled_h, pair->p2->pooled_w,
+                          nullptr, nullptr, 0, 0};
+      if (pair->plan) { P2.rec = pair->plan->rec; P2.qmem = pair->plan->qmem; P2.qzero = pair->plan->qzero; P2.qints = pair->plan->qints; }
       grid = dim3((unsigned)total, 1);
     }
     PoolLevels Lf = L;
@@ -2490,16 +2510,19 @@ static long pool_ntiles(const d2amd_pooler_params* p) {
 // persistent MFMA tile gather of a pooler with <= 8 bins per axis only; probe: no launch at all, the return value says
 // whether the call would take that kernel: OK / EUNSUPPORTED)
 struct PoolPairCall { const d2amd_pooler_params* p2; const void* gout2; const float* rois2; int K2; };
+
 template <typename T>
 static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_output, const float* rois,
                               void* const* grad_inputs, int K_first, void* workspace, size_t workspace_bytes,
                               hipStream_t s, bool accumulate, int phase = 0, const PoolPairCall* pair = nullptr,
-                              bool probe = false) {
+                              bool probe = false, PoolRecPlan* plan = nullptr) {
   const int K = K_first + (pair ? pair->K2 : 0);  // records: the first pooler's ROIs, then the second one's
   // phase 0: everything; 1: only the binning (records, per-tile ROI lists, work queues -- depends on the ROIs alone
   // in accumulate mode, so a caller can run it beside other work); 2: only the gather, ADDING, after a phase-1 call
   // with the same arguments and workspace; 3: the same but WRITING: the tiles without ROIs are zero-filled by their
   // own small launch, every other tile is written once (= what phase 0 without `accumulate` produces)
+  // r06 -- 4: no launch, `plan` receives where the records and the queue words live (the paired FORWARD of the same ROIs
+  // writes them: d2amd_roi_pooler_forward_pair_records); 5: phase 0 without the records launch, after such a forward
   constexpr int VEC = V16<T>::N;
   const bool vec = (p->C % VEC == 0) && all_aligned16((const void* const*)grad_inputs, p->num_levels, grad_output);
   const int cg = vec ? p->C / VEC : p->C;
@@ -2548,7 +2571,7 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
   const size_t slot_bytes = (size_t)nslab * 32 * (2 * CT) * sizeof(float);  // 16 accumulators x 2 tiles x 512 threads
   if (pair || probe) {  // the paired gather exists in the K-concatenated tile gather only (either pooler may come first:
     // a list entry carries its own pooled size)
-    const bool ok = kcat_ok && K_first > 0 && phase <= 2 && !accumulate;
+    const bool ok = kcat_ok && K_first > 0 && (phase <= 2 || phase == 4 || phase == 5) && !accumulate;
     if (!ok || probe) return ok ? D2AMD_OK : D2AMD_EUNSUPPORTED;
   }
   if (queues) {
@@ -2599,10 +2622,21 @@ static int pool_bwd_nhwc_impl(const d2amd_pooler_params* p, const void* grad_out
                        (int)ntiles, (const int*)tile_cnt, (int)sizeof(T));
     D2_LAUNCH_OK();
   }
-  if (K > 0 && phase < 2) {
+  if (phase == 4) {
+    if (!(pair && queues && lists && plan)) return D2AMD_EUNSUPPORTED;
+    *plan = PoolRecPlan{rec, Q.mem, qzero, qints};
+    return D2AMD_OK;
+  }
+  if (phase == 5 && !(pair && queues && lists)) {
+    set_error("roi_pooler_backward_pair: phase 5 outside the paired tile gather");
+    return D2AMD_EUNSUPPORTED;
+  }
+  if (K > 0 && (phase < 2 || phase == 5)) {
     const PairBin PB2{pair ? pair->rois2 : nullptr, K_first, pair ? pair->p2->pooled_h : 0, pair ? pair->p2->pooled_w : 0};
-    hipLaunchKernelGGL(roi_records_kernel, dim3(cdiv(K, 256)), dim3(256), 0, s, L0, rois, rec, Q.mem, qzero, qints, PB2);
-    D2_LAUNCH_OK();
+    if (phase != 5) {
+      hipLaunchKernelGGL(roi_records_kernel, dim3(cdiv(K, 256)), dim3(256), 0, s, L0, rois, rec, Q.mem, qzero, qints, PB2);
+      D2_LAUNCH_OK();
+    }
     if (lists) {
       hipLaunchKernelGGL(tile_lists_kernel, dim3(cdiv(ntiles, LISTS_WAVES)), dim3(64 * LISTS_WAVES), 0, s, L0, rec, (int)ntiles, tile_cnt,
                          tile_list, Q, K_first, tile_cnt1, pair ? pair->p2->pooled_h : p->pooled_h,
@@ -2869,9 +2903,9 @@ extern "C" int d2amd_roi_pooler_forward(const d2amd_pooler_params* p, const void
 // output1 / output2 are exactly what d2amd_roi_pooler_forward(p1 ...) / (p2 ...) write -- the same workgroups run the same
 // code -- but the second pooler's workgroups start in the slots the first one's free instead of behind its last one.
 // EUNSUPPORTED (nothing launched) outside the NHWC 16-B vector kernel / for different level rules: two calls then.
-extern "C" int d2amd_roi_pooler_forward_pair(const d2amd_pooler_params* p1, const void* const* inputs, const float* rois1,
-                                             void* output1, int K1, const d2amd_pooler_params* p2, const float* rois2,
-                                             void* output2, int K2, void* stream) {
+static int pooler_forward_pair_entry(const d2amd_pooler_params* p1, const void* const* inputs, const float* rois1,
+                                     void* output1, int K1, const d2amd_pooler_params* p2, const float* rois2,
+                                     void* output2, int K2, const PoolRecPlan* rec_plan, void* stream) {
   int rc = check_pooler(p1, "roi_pooler_forward_pair");
   if (rc) return rc;
   rc = check_pooler(p2, "roi_pooler_forward_pair");
@@ -2897,9 +2931,14 @@ extern "C" int d2amd_roi_pooler_forward_pair(const d2amd_pooler_params* p1, cons
   for (int l = 0; l < p1->num_levels; l++)
     D2_CHECK_ARG(inputs[l] != nullptr || (long)p1->N * p1->H[l] * p1->W[l] == 0, "roi_pooler_forward_pair: null level %d", l);
   return D2_DISPATCH_DTYPE(p1->dtype, [&]() -> int {
-    const PoolFwdPairCall pc{p2, rois2, output2, K2};
+    const PoolFwdPairCall pc{p2, rois2, output2, K2, rec_plan};
     return pool_fwd_impl<scalar_t>(p1, inputs, rois1, output1, K1, (hipStream_t)stream, nullptr, &pc);
   });
+}
+extern "C" int d2amd_roi_pooler_forward_pair(const d2amd_pooler_params* p1, const void* const* inputs, const float* rois1,
+                                             void* output1, int K1, const d2amd_pooler_params* p2, const float* rois2,
+                                             void* output2, int K2, void* stream) {
+  return pooler_forward_pair_entry(p1, inputs, rois1, output1, K1, p2, rois2, output2, K2, nullptr, stream);
 }
 
 extern "C" size_t d2amd_roi_pooler_forward_workspace_bytes(int K) { return (size_t)(K > 0 ? K : 1) * sizeof(int); }
@@ -3060,7 +3099,7 @@ extern "C" size_t d2amd_roi_pooler_backward_pair_workspace_bytes(const d2amd_poo
 static int pooler_backward_pair_entry(const d2amd_pooler_params* p1, const void* grad_output1, const float* rois1, int K1,
                                       const d2amd_pooler_params* p2, const void* grad_output2, const float* rois2, int K2,
                                       void* const* grad_inputs, void* workspace, size_t workspace_bytes, int phase,
-                                      void* stream) {
+                                      void* stream, PoolRecPlan* plan = nullptr) {
   int rc = check_pooler(p1, "roi_pooler_backward_pair");
   if (rc) return rc;
   rc = check_pooler(p2, "roi_pooler_backward_pair");
@@ -3096,7 +3135,7 @@ static int pooler_backward_pair_entry(const d2amd_pooler_params* p1, const void*
       return r;
     }
     return pool_bwd_nhwc_impl<scalar_t>(p1, grad_output1, rois1, grad_inputs, K1, workspace, workspace_bytes, s, false, phase,
-                                        &pc);
+                                        &pc, false, plan);
   });
 }
 extern "C" int d2amd_roi_pooler_backward_pair(const d2amd_pooler_params* p1, const void* grad_output1, const float* rois1,
@@ -3115,7 +3154,8 @@ extern "C" int d2amd_roi_pooler_backward_pair_phase(const d2amd_pooler_params* p
                                                     const void* grad_output2, const float* rois2, int K2,
                                                     void* const* grad_inputs, void* workspace, size_t workspace_bytes,
                                                     int phase, void* stream) {
-  D2_CHECK_ARG(phase == 1 || phase == 2, "roi_pooler_backward_pair_phase: phase must be 1 (bin + zero fill) or 2 (gather)");
+  D2_CHECK_ARG(phase == 1 || phase == 2 || phase == 5, "roi_pooler_backward_pair_phase: phase must be 1 (bin + zero fill), 2 "
+               "(gather) or 5 (lists + gather behind d2amd_roi_pooler_forward_pair_records)");
   return pooler_backward_pair_entry(p1, grad_output1, rois1, K1, p2, grad_output2, rois2, K2, grad_inputs, workspace,
                                     workspace_bytes, phase, stream);
 }
@@ -3126,4 +3166,31 @@ extern "C" int d2amd_roi_pooler_backward_phase(const d2amd_pooler_params* p, con
   D2_CHECK_ARG(phase >= 1 && phase <= 3, "roi_pooler_backward_phase: phase must be 1 (bin), 2 (gather, adding) or 3 "
                "(gather, writing)");
   return pooler_backward_entry(p, grad_output, rois, grad_inputs, K, workspace, workspace_bytes, stream, true, phase);
+}
+
+// The paired forward that ALSO prepares the paired backward of the same ROIs (r06): the records and the reset of the work
+// queues -- roi_records_kernel, the first launch of d2amd_roi_pooler_backward_pair -- are done by the forward's workgroups
+// into `bwd_workspace` (d2amd_roi_pooler_backward_pair_workspace_bytes(p1, K1, K2) bytes, kept by the caller until the
+// backward).  *records_written = 1: call d2amd_roi_pooler_backward_pair_phase(..., phase 5) with that workspace and the same
+// ROIs (it starts with the tile lists); 0: the workspace was not touched (configuration outside the paired tile gather):
+// call d2amd_roi_pooler_backward_pair as usual.  The outputs are d2amd_roi_pooler_forward_pair's either way.
+extern "C" int d2amd_roi_pooler_forward_pair_records(const d2amd_pooler_params* p1, const void* const* inputs,
+                                                     const float* rois1, void* output1, int K1,
+                                                     const d2amd_pooler_params* p2, const float* rois2, void* output2,
+                                                     int K2, void* bwd_workspace, size_t bwd_workspace_bytes,
+                                                     int* records_written, void* stream) {
+  D2_CHECK_ARG(records_written != nullptr, "roi_pooler_forward_pair_records: null pointer");
+  *records_written = 0;
+  PoolRecPlan plan{};
+  bool have = false;
+  if (bwd_workspace && inputs && rois1 && rois2 && K1 > 0 && K2 > 0 && check_pooler(p1, "roi_pooler_forward_pair_records") == 0 &&
+      check_pooler(p2, "roi_pooler_forward_pair_records") == 0) {
+    // (no gradient exists yet: the workspace stands in for both dY pointers and the features for the gradient tensors --
+    // only their alignment class is looked at; phase 4 launches nothing)
+    have = pooler_backward_pair_entry(p1, bwd_workspace, rois1, K1, p2, bwd_workspace, rois2, K2, (void* const*)inputs,
+                                      bwd_workspace, bwd_workspace_bytes, 4, stream, &plan) == D2AMD_OK;
+  }
+  const int rc = pooler_forward_pair_entry(p1, inputs, rois1, output1, K1, p2, rois2, output2, K2, have ? &plan : nullptr, stream);
+  if (rc == D2AMD_OK && have) *records_written = 1;
+  return rc;
 }

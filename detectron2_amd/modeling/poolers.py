@@ -297,6 +297,9 @@ _ROT_POOLER_LOOP = False  # (module attribute: the rotated pooler level by level
 # 14x14); D2AMD_POOL_PAIR=0 (read once, at import): one launch per pooler, the second one adding (the A/B and the
 # bit-for-bit autograd sum; tests/test_gpu_pooler_pair.py sets the attribute).
 _PAIR = _os.environ.get("D2AMD_POOL_PAIR", "1") != "0"
+# The paired forward also writes the paired backward's per-ROI records and resets its work queues (r06:
+# d2amd_roi_pooler_forward_pair_records): module attribute, tests/test_gpu_pooler_pair.py compares both settings bit for bit.
+_FWD_RECORDS = _os.environ.get("D2AMD_POOL_FWD_RECORDS", "1") != "0"  # (read once, at import: the A/B)
 
 
 def _PREBIN(head):
@@ -638,6 +641,7 @@ class _FusedROIPoolPair(Function):
         # roisN: the (M, 5) pooler-format tensor, or a tuple of per-image (n_i, 4) fp32 HIP box tensors (converted inside
         # the same C call, both lists by one launch); plan: None or a PairBackwardPlan (looked at in the backward)
         ctx.plan = plan
+        ctx.prep = None
         lists = None
         if isinstance(rois1, tuple):
             lists = (rois1, rois2)
@@ -660,6 +664,17 @@ class _FusedROIPoolPair(Function):
                 rc = L.d2amd_roi_pooler_forward_pair_box_lists(
                     ctypes.byref(p1), _ptr_array(feats), _ptr_array(lists[0]), cnt[0], _C.ptr(rois1), _C.ptr(out1),
                     ctypes.byref(p2), _ptr_array(lists[1]), cnt[1], _C.ptr(rois2), _C.ptr(out2), n_img, _C.stream())
+            elif _FWD_RECORDS and _PAIR and plan is None and k1 > 0 and k2 > 0 and any(ctx.needs_input_grad[5:]):
+                # (training: the forward's workgroups also write the backward's per-ROI records and reset its queues into
+                # the backward's workspace, allocated here and kept until then: the backward starts with its tile lists)
+                wsb = L.d2amd_roi_pooler_backward_pair_workspace_bytes(ctypes.byref(p1), k1, k2)
+                ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+                wrote = ctypes.c_int(0)
+                rc = L.d2amd_roi_pooler_forward_pair_records(ctypes.byref(p1), _ptr_array(feats), _C.ptr(rois1), _C.ptr(out1),
+                                                             k1, ctypes.byref(p2), _C.ptr(rois2), _C.ptr(out2), k2, _C.ptr(ws),
+                                                             wsb, ctypes.byref(wrote), _C.stream())
+                if rc == 0 and wrote.value:
+                    ctx.prep = (ws, wsb)
             else:
                 rc = L.d2amd_roi_pooler_forward_pair(ctypes.byref(p1), _ptr_array(feats), _C.ptr(rois1), _C.ptr(out1), k1,
                                                      ctypes.byref(p2), _C.ptr(rois2), _C.ptr(out2), k2, _C.stream())
@@ -709,7 +724,19 @@ class _FusedROIPoolPair(Function):
         grads = [torch.empty((n, c, h, w), dtype=ctx.dtype, device=dev, memory_format=torch.channels_last) for (h, w) in hw]
         with _C.on_device(dev):
             done = False
-            if len(works) == 2 and _PAIR:
+            prep, ctx.prep = ctx.prep, None
+            if len(works) == 2 and _PAIR and prep is not None:  # records + queue reset came with the forward
+                (ga, ra, ca), (gb, rb, cb) = works
+                pa, pb = _params(ca, (n, c), hw, code, _C.NHWC), _params(cb, (n, c), hw, code, _C.NHWC)
+                ws, wsb = prep
+                ws.record_stream(torch.cuda.current_stream(dev))
+                rc = L.d2amd_roi_pooler_backward_pair_phase(ctypes.byref(pa), _C.ptr(ga), _C.ptr(ra), ra.shape[0],
+                                                            ctypes.byref(pb), _C.ptr(gb), _C.ptr(rb), rb.shape[0],
+                                                            _ptr_array(grads), _C.ptr(ws), wsb, 5, _C.stream())
+                done = rc == 0
+                if rc not in (0, _C.EUNSUPPORTED):
+                    _C.check(rc)
+            if not done and len(works) == 2 and _PAIR:
                 (ga, ra, ca), (gb, rb, cb) = works
                 pa, pb = _params(ca, (n, c), hw, code, _C.NHWC), _params(cb, (n, c), hw, code, _C.NHWC)
                 wsb = L.d2amd_roi_pooler_backward_pair_workspace_bytes(ctypes.byref(pa), ra.shape[0], rb.shape[0])

@@ -186,7 +186,19 @@ int d2amd_roi_pooler_backward_pair(const d2amd_pooler_params* p1, const void* gr
 /* The paired backward in two calls: phase 1 bins both ROI sets (reads the rois, writes the workspace and zero-fills
  * the tiles of grad_inputs no ROI touches: the gradient tensors must exist, no gradient value is needed -- it can run
  * on another stream beside the poolers' forward; grad_outputN: any pointers of the later ones' alignment class); phase 2,
- * same arguments and workspace, is the tile gather alone.  D2AMD_EUNSUPPORTED as for the one-call entry. */
+ * same arguments and workspace, is the tile gather alone; phase 5 = the one-call backward without its records launch, behind
+ * d2amd_roi_pooler_forward_pair_records (above).  D2AMD_EUNSUPPORTED as for the one-call entry. */
+/* The paired forward that ALSO prepares the paired backward of the same ROIs: the per-ROI records and the reset of the
+ * work queues -- the first launch of d2amd_roi_pooler_backward_pair -- are done by the forward's workgroups into
+ * bwd_workspace (d2amd_roi_pooler_backward_pair_workspace_bytes(p1, K1, K2) bytes; the caller keeps it, and the ROI
+ * tensors, unchanged until the backward).  *records_written = 1: run the backward as
+ * d2amd_roi_pooler_backward_pair_phase(..., phase 5) with that workspace (it starts with the tile lists); 0: the workspace
+ * was not touched (a configuration outside the paired tile gather): d2amd_roi_pooler_backward_pair as usual.  Outputs and
+ * return codes are d2amd_roi_pooler_forward_pair's.  (modeling/poolers.py:206-263 twice + the head of their backward.) */
+int d2amd_roi_pooler_forward_pair_records(const d2amd_pooler_params* p1, const void* const* inputs, const float* rois1,
+                                          void* output1, int K1, const d2amd_pooler_params* p2, const float* rois2,
+                                          void* output2, int K2, void* bwd_workspace, size_t bwd_workspace_bytes,
+                                          int* records_written, void* stream);
 int d2amd_roi_pooler_backward_pair_phase(const d2amd_pooler_params* p1, const void* grad_output1, const float* rois1,
                                          int K1, const d2amd_pooler_params* p2, const void* grad_output2,
                                          const float* rois2, int K2, void* const* grad_inputs, void* workspace,

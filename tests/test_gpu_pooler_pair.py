@@ -425,3 +425,40 @@ def test_backward_plan_bins_ahead_on_another_stream_and_gives_the_same_bits():
     xs32 = [_nhwc(f, torch.float32) for f in feats]
     assert PairBackwardPlan().prepare(pa, pb, xs32, r1, r2) is False
     P._ALIASES.clear()
+
+
+@pytest.mark.parametrize("name", ["subset", "independent", "both_long", "sparse"])
+def test_forward_written_records_give_the_same_gradients(name, monkeypatch):
+    """r06, d2amd_roi_pooler_forward_pair_records + d2amd_roi_pooler_backward_pair_phase(5): the paired forward's workgroups
+    write the backward's per-ROI records and reset its work queues (the workspace is allocated with the forward); outputs
+    and gradients are the bits of the plain forward + the one-call backward (`_FWD_RECORDS = False`), also when the same
+    forward is differentiated twice in a row (a fresh workspace per forward) and when only one result is used."""
+    from detectron2_amd.modeling import pool_pair_rois
+
+    feats, boxes1, g1, boxes2, g2 = _case(name, torch.bfloat16)
+    pa, pb = ROIPooler(7, SCALES, 0, "ROIAlignV2"), ROIPooler(14, SCALES, 0, "ROIAlignV2")
+    r1, r2 = _rois(boxes1), _rois(boxes2)
+    res = {}
+    for flag in (False, True, True):
+        monkeypatch.setattr(P, "_FWD_RECORDS", flag)
+        xs = [_nhwc(f, torch.bfloat16).requires_grad_(True) for f in feats]
+        ya, yb = pool_pair_rois(pa, pb, xs, r1, r2)
+        assert (ya.grad_fn.prep is not None) == flag
+        torch.autograd.backward([ya, yb], [g1, g2])
+        out = (ya.detach(), yb.detach(), [x.grad for x in xs])
+        if flag in res:
+            assert torch.equal(out[0], res[flag][0]) and all(torch.equal(a, b) for a, b in zip(out[2], res[flag][2]))
+        res[flag] = out
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    assert all(torch.equal(a, b) for a, b in zip(res[True][2], res[False][2]))
+    _, want = _run("pair", feats, boxes1, g1, boxes2, g2, torch.bfloat16)
+    assert all(torch.equal(a, w) for a, w in zip(res[True][2], want))
+    # only the second result is used: the prepared workspace is dropped, that pooler's plain backward runs
+    monkeypatch.setattr(P, "_FWD_RECORDS", True)
+    xs = [_nhwc(f, torch.bfloat16).requires_grad_(True) for f in feats]
+    ya, yb = pool_pair_rois(pa, pb, xs, r1, r2)
+    yb.backward(g2)
+    xs2 = [_nhwc(f, torch.bfloat16).requires_grad_(True) for f in feats]
+    pb.pool_rois(xs2, r2).backward(g2)
+    assert all(torch.equal(x.grad, y.grad) for x, y in zip(xs, xs2))
+    P._ALIASES.clear()
